@@ -1,0 +1,161 @@
+/*
+ * tracs_hip.h -- C ABI of libtracs_hip.so, the MI355X (gfx950) implementation of the TRACS
+ * all-pairs distance path.  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * Two layers:
+ *   (1) HOST entry points -- exactly what the reference's pybind11 module binds
+ *       (/root/reference/src/python_bindings.cpp:12-25).  Host pointers in, host pointers out.
+ *   (2) DEVICE entry points -- the same kernels with device pointers and a hipStream_t
+ *       (passed as void*), for callers that keep the alignment resident in HBM (bench.py,
+ *       the multi-GPU driver, `tracs distance`).  Asynchronous on the given stream.
+ *
+ * Every function returns 0 on success or a negative TRACS_E_* code; tracs_last_error()
+ * returns the message for the calling thread (the Python layer raises RuntimeError with it,
+ * reproducing the reference's messages: src/pairsnp.hpp:86,90,96-97,342).
+ */
+#ifndef TRACS_HIP_H
+#define TRACS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRACS_OK            0
+#define TRACS_E_ARG        -1   /* bad argument (e.g. "Invalid number of fasta files!") */
+#define TRACS_E_FASTA      -2   /* "Error reading FASTA!"                        (pairsnp.hpp:86,90) */
+#define TRACS_E_RAGGED     -4   /* "Error reading FASTA, variable sequence lengths!" (pairsnp.hpp:96-97) */
+#define TRACS_E_OPEN       -5   /* file cannot be opened (the reference does not diagnose this) */
+#define TRACS_E_HIP        -6   /* HIP runtime error / no device */
+#define TRACS_E_NOMEM      -7
+
+const char *tracs_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+int tracs_abi_version(void);
+/* Number of visible HIP devices (<=0: none).  Does not throw. */
+int tracs_device_count(void);
+
+/* ===================================================================================== */
+/* (1) HOST ENTRY POINTS -- the pybind11 surface                                          */
+/* ===================================================================================== */
+
+/* pairsnp(fasta, n_threads, dist, filter)
+ *   replaces: src/python_bindings.cpp:12-13 -> src/pairsnp.hpp:320-457.
+ *   fasta: 1 path (all i<j) or 2 paths (file0 x file1 only, pairsnp.hpp:352-360); plain or gzip.
+ *   n_threads: accepted for signature parity; the pair loop runs on the GPU.
+ *   dist: emit pairs with d <= dist (signed int compare, pairsnp.hpp:405).
+ *   filter: recombination filter (pairsnp.hpp:251-318); 0 => filt_distances are `len` zeros
+ *           (pairsnp.hpp:452 with combine_vectors :31).
+ * The result is an opaque handle read through the accessors below; rows/cols/... are
+ * row-major (i, then j) like the reference (pairsnp.hpp:451-455).                         */
+typedef struct tracs_pairsnp_result tracs_pairsnp_result;
+int tracs_pairsnp(const char *const *fasta, int n_fasta, int n_threads, int dist, int filter,
+                  tracs_pairsnp_result **out);
+size_t tracs_pairsnp_len(const tracs_pairsnp_result *r);          /* number of emitted pairs */
+size_t tracs_pairsnp_nseq(const tracs_pairsnp_result *r);         /* records loaded, both files */
+size_t tracs_pairsnp_seqlen(const tracs_pairsnp_result *r);       /* alignment length L */
+const uint64_t *tracs_pairsnp_rows(const tracs_pairsnp_result *r);
+const uint64_t *tracs_pairsnp_cols(const tracs_pairsnp_result *r);
+const uint64_t *tracs_pairsnp_distances(const tracs_pairsnp_result *r);
+const uint64_t *tracs_pairsnp_filt_distances(const tracs_pairsnp_result *r);
+const uint64_t *tracs_pairsnp_ncompared(const tracs_pairsnp_result *r);
+const char *tracs_pairsnp_name(const tracs_pairsnp_result *r, size_t i);
+void tracs_pairsnp_free(tracs_pairsnp_result *r);
+
+/* trans_dist(snpdiff, datediff, lamb, beta, threshold_Ek) -> (p0_log[n], eK[n])
+ *   replaces: src/python_bindings.cpp:19-21 -> src/transcluster.hpp:240-287.               */
+int tracs_trans_dist(const int32_t *snpdiff, const double *datediff, size_t n, double lamb, double beta,
+                     double threshold_Ek, double *p0_log, double *eK);
+
+/* lprob_k_given_N(N, k, delta, lamb, beta, lgamma) -> (lprob, lhs)
+ *   replaces: src/python_bindings.cpp:15-17 -> src/transcluster.hpp:90-129.
+ *   lgamma[i] = ln Gamma(i), length > N+k+1 (caller supplied, as in tests/test_llk.py:26).
+ *   Batched: n independent (N,k,delta) triples share lamb, beta and the table.             */
+int tracs_lprob_k_given_N(const uint64_t *N, const uint64_t *k, const double *delta, size_t n, double lamb,
+                          double beta, const double *lgamma, size_t lgamma_len, double *lprob, double *lhs);
+
+/* calculate_posteriors(counts[L,K], alphas[K], keep, threshold) -> posterior[L,K]
+ *   replaces: src/python_bindings.cpp:23-25 -> src/dmultinomial.hpp:8-86.  K <= 8.          */
+int tracs_calculate_posteriors(const double *counts, size_t L, size_t K, const double *alphas, int keep,
+                               double threshold, double *posterior);
+
+/* Threshold single-linkage clustering = connected components of the edge list, labelled as
+ * scipy.sparse.csgraph.connected_components(directed=False) labels them
+ *   replaces: tracs/cluster.py:126-129.  edges (I[e], J[e]) over nodes 0..n-1.             */
+int tracs_connected_components(const int32_t *I, const int32_t *J, size_t n_edges, size_t n_nodes,
+                               int32_t *labels, int32_t *n_components);
+
+/* ===================================================================================== */
+/* (2) DEVICE ENTRY POINTS                                                                */
+/* ===================================================================================== */
+
+/* A packed alignment resident in HBM: five bit planes (A,C,G,T and N = A&C&G&T) per sample,
+ * 128-site groups, sample-minor: uint4[group][plane][n_pad] (DESIGN.md "Data layout").     */
+typedef struct tracs_alignment tracs_alignment;
+int tracs_alignment_create(size_t n, size_t L, tracs_alignment **out);
+void tracs_alignment_free(tracs_alignment *a);
+size_t tracs_alignment_n(const tracs_alignment *a);
+size_t tracs_alignment_len(const tracs_alignment *a);
+size_t tracs_alignment_bytes(const tracs_alignment *a);   /* HBM bytes of the packed planes */
+void *tracs_alignment_planes(const tracs_alignment *a);   /* device pointer (for tests) */
+/* Pack `count` samples of ASCII (IUPAC, any case; load_seqs pairsnp.hpp:107-199) into samples
+ * [first, first+count).  `ascii` is count*L bytes, row-major; host or device pointer
+ * (ascii_on_device).  The pack itself is a HIP kernel either way.                           */
+int tracs_alignment_pack(tracs_alignment *a, const uint8_t *ascii, size_t first, size_t count,
+                         int ascii_on_device, void *stream);
+/* Read FASTA/FASTQ(.gz) with kseq semantics (src/kseq.h:170-208) and pack it.  names_out
+ * receives a malloc'ed block of NUL-separated names (free with tracs_free).                 */
+int tracs_alignment_from_fasta(const char *const *fasta, int n_fasta, tracs_alignment **out,
+                               char **names_out, size_t *names_bytes, size_t *n_first_file);
+void tracs_free(void *p);
+
+/* Dense pair block: for rows i in [row_begin,row_end) and columns j in [max(col_begin,i+1), n)
+ *   dist[i*ld + j]  = d(i,j)  = L - popcount(match)           (pairsnp.hpp:398-403)
+ *   ncomp[i*ld + j] = nn(i,j) = L - popcount(N_i | N_j)       (pairsnp.hpp:417-420)
+ * Other cells are not written.  dist/ncomp are device uint32 matrices with leading dimension
+ * ld >= n; ncomp may be NULL (then only d is computed: 5 VALU ops/word instead of 7).       */
+int tracs_pairsnp_dense(const tracs_alignment *a, size_t row_begin, size_t row_end, size_t col_begin,
+                        uint32_t *dist, uint32_t *ncomp, size_t ld, void *stream);
+
+/* Thresholded COO extraction from a dense block, row-major, same cell set as above.
+ * Phase 1 (counts==per-row counts, device int64[row_end-row_begin+1] exclusive offsets on return),
+ * phase 2 fills rows/cols/d/nn (device uint32) at those offsets.                            */
+int tracs_coo_count(const uint32_t *dist, size_t ld, size_t n, size_t row_begin, size_t row_end,
+                    size_t col_begin, int32_t dist_threshold, int64_t *offsets, void *stream);
+int tracs_coo_fill(const uint32_t *dist, const uint32_t *ncomp, size_t ld, size_t n, size_t row_begin,
+                   size_t row_end, size_t col_begin, int32_t dist_threshold, const int64_t *offsets,
+                   uint32_t *rows, uint32_t *cols, uint32_t *d, uint32_t *nn, void *stream);
+
+/* transcluster on device arrays (same math as tracs_trans_dist).  workspace is managed
+ * internally (hipMallocAsync on the stream).  exp_p0 != 0 writes exp(p0) (what
+ * tracs/transcluster.py:38-39 returns with log=False).                                     */
+int tracs_trans_dist_device(const int32_t *snpdiff, const double *datediff, size_t n, double lamb,
+                            double beta, double threshold_Ek, int exp_p0, double *p0, double *eK,
+                            void *stream);
+/* Dense variant used by the distance pipeline: for the same cell set as tracs_pairsnp_dense,
+ * delta(i,j) = |day_i - day_j| * 86400 / 31556952.0  (tracs/transcluster.py:5,26-33), N = dist[i*ld+j];
+ * writes p0[i*ld+j] (exp'ed if exp_p0) and eK[i*ld+j].  Cells with dist > dist_threshold are skipped. */
+int tracs_trans_dist_dense(const uint32_t *dist, size_t ld, size_t n, size_t row_begin, size_t row_end,
+                           size_t col_begin, int32_t dist_threshold, const int32_t *days, double lamb,
+                           double beta, double threshold_Ek, int exp_p0, double *p0, double *eK,
+                           void *stream);
+
+/* calculate_posteriors on device arrays; counts/posterior are device f64 [L][K].            */
+int tracs_calculate_posteriors_device(const double *counts, size_t L, size_t K, const double *alphas_host,
+                                      int keep, double threshold, double *posterior, void *stream);
+/* Fused production form (config 4): uint16 counts [L][4] -> 4-bit allele mask per site
+ * (bit0=A..bit3=T set where posterior > 0, i.e. what tracs/align.py:616-622 turns into an
+ * IUPAC letter), two sites per output byte (low nibble = even site).                        */
+int tracs_posterior_codes_device(const uint16_t *counts, size_t L, const double *alphas_host, int keep,
+                                 double threshold, uint8_t *codes, void *stream);
+
+/* Connected components on device edge arrays; labels as tracs_connected_components.         */
+int tracs_connected_components_device(const int32_t *I, const int32_t *J, size_t n_edges, size_t n_nodes,
+                                      int32_t *labels, int32_t *n_components_host, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRACS_HIP_H */

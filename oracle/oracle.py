@@ -1,0 +1,256 @@
+"""ctypes face of oracle/liboracle.so plus an independent numpy brute force.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under tracs_amd/ may import this module.
+
+Reference lines restated by each function are cited in oracle/tracs_oracle.c.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(quiet=True):
+    """Compile liboracle.so (and oracle/_ref when /root/reference is present)."""
+    out = subprocess.run(["make", "-C", _HERE, "all"], capture_output=True, text=True)
+    if out.returncode != 0:
+        raise RuntimeError("oracle build failed:\n" + out.stdout + out.stderr)
+    if not quiet:
+        print(out.stdout)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        u64p = C.POINTER(C.c_uint64)
+        dp = C.POINTER(C.c_double)
+        L.orc_iupac_mask.restype = C.c_uint8
+        L.orc_iupac_mask.argtypes = [C.c_int]
+        L.orc_words.restype = C.c_size_t
+        L.orc_words.argtypes = [C.c_size_t]
+        L.orc_pack.restype = None
+        L.orc_pack.argtypes = [C.c_char_p, C.c_size_t, C.c_size_t, u64p]
+        L.orc_pairsnp.restype = C.c_int64
+        L.orc_pairsnp.argtypes = [u64p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_int,
+                                  u64p, u64p, u64p, u64p]
+        L.orc_pairsnp_rows_checksum.restype = C.c_uint64
+        L.orc_pairsnp_rows_checksum.argtypes = [u64p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int]
+        L.orc_lprob_k_given_N.restype = None
+        L.orc_lprob_k_given_N.argtypes = [C.c_size_t, C.c_size_t, C.c_double, C.c_double, C.c_double, dp, dp]
+        L.orc_lprob_k_given_N_2.restype = None
+        L.orc_lprob_k_given_N_2.argtypes = [C.c_size_t, C.c_size_t, C.c_double, C.c_double, C.c_double, dp]
+        L.orc_expected_k.restype = C.c_double
+        L.orc_expected_k.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_int)]
+        L.orc_trans_dist.restype = None
+        L.orc_trans_dist.argtypes = [C.POINTER(C.c_int), dp, C.c_size_t, C.c_double, C.c_double, C.c_double, dp, dp]
+        L.orc_calculate_posteriors.restype = None
+        L.orc_calculate_posteriors.argtypes = [dp, C.c_size_t, C.c_size_t, dp, C.c_int, C.c_double, dp]
+        L.orc_read_fasta.restype = C.c_int
+        L.orc_read_fasta.argtypes = [C.c_char_p, C.c_void_p]
+        L.orc_free_fasta.restype = None
+        L.orc_free_fasta.argtypes = [C.c_void_p]
+        L.orc_num_threads.restype = C.c_int
+        _LIB = L
+    return _LIB
+
+
+def ref_module():
+    """The reference's transcluster/dmultinomial compiled in place (oracle/_ref), or None."""
+    d = os.path.join(_HERE, "_ref")
+    if not os.path.isdir(d):
+        return None
+    if d not in sys.path:
+        sys.path.insert(0, d)
+    try:
+        import _tracs_ref
+        return _tracs_ref
+    except ImportError:
+        return None
+
+
+def kseq_dump_path():
+    p = os.path.join(_HERE, "_ref", "kseq_dump")
+    return p if os.path.exists(p) else None
+
+
+def _u64p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint64))
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class _Fasta(C.Structure):
+    _fields_ = [("n", C.c_size_t), ("L", C.c_size_t), ("seq", C.c_void_p), ("names", C.c_void_p),
+                ("names_bytes", C.c_size_t)]
+
+
+_ERR = {-2: "Error reading FASTA!", -4: "Error reading FASTA, variable sequence lengths!",
+        -5: "cannot open FASTA"}
+
+
+def read_fasta(path):
+    """-> (names: list[str], seqs: np.uint8[n, L]) with kseq semantics."""
+    f = _Fasta()
+    rc = lib().orc_read_fasta(os.fsencode(path), C.byref(f))
+    if rc != 0:
+        raise RuntimeError(_ERR.get(rc, "FASTA error %d" % rc))
+    try:
+        seqs = np.frombuffer(C.string_at(f.seq, f.n * f.L), dtype=np.uint8).reshape(f.n, f.L).copy() \
+            if f.n * f.L else np.zeros((f.n, f.L), np.uint8)
+        raw = C.string_at(f.names, f.names_bytes) if f.names_bytes else b""
+        names = [x.decode("latin-1") for x in raw.split(b"\0")[:f.n]]
+    finally:
+        lib().orc_free_fasta(C.byref(f))
+    return names, seqs
+
+
+def pack(seqs):
+    """seqs uint8[n, L] ASCII -> planes uint64[4, n, W] (A,C,G,T)."""
+    seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+    n, L = seqs.shape
+    W = (L + 63) // 64
+    planes = np.zeros((4, n, max(W, 1)), dtype=np.uint64)[:, :, :W].copy()
+    if n and L:
+        lib().orc_pack(seqs.ctypes.data_as(C.c_char_p), n, L, _u64p(planes))
+    return planes
+
+
+def pairsnp_arrays(seqs, n0=None, dist=2147483647, n_threads=1):
+    """seqs uint8[n, L]; n0 = size of the first file in two-file mode (cross pairs only,
+    src/pairsnp.hpp:352-360).  -> rows, cols, d, nn as uint64 arrays, row-major."""
+    seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+    n, L = seqs.shape
+    planes = pack(seqs)
+    i_end, j_start = (n, 0) if n0 is None else (n0, n0)
+    null = C.POINTER(C.c_uint64)()
+    cnt = lib().orc_pairsnp(_u64p(planes), n, L, i_end, j_start, int(dist), n_threads, null, null, null, null)
+    rows = np.zeros(cnt, np.uint64); cols = np.zeros(cnt, np.uint64)
+    d = np.zeros(cnt, np.uint64); nn = np.zeros(cnt, np.uint64)
+    if cnt:
+        lib().orc_pairsnp(_u64p(planes), n, L, i_end, j_start, int(dist), n_threads,
+                          _u64p(rows), _u64p(cols), _u64p(d), _u64p(nn))
+    return rows, cols, d, nn
+
+
+def pairsnp(fasta, n_threads, dist, filter):
+    """Oracle twin of TRACS.pairsnp (src/pairsnp.hpp:320-457, filter=False only)."""
+    if len(fasta) < 1 or len(fasta) > 2:
+        raise RuntimeError("Invalid number of fasta files!")
+    if filter:
+        raise NotImplementedError("oracle: filter_recomb is unpinned (Boost binomial)")
+    names, seqs = read_fasta(fasta[0])
+    n0 = None
+    if len(fasta) == 2:
+        names2, seqs2 = read_fasta(fasta[1])
+        n0 = len(names)
+        names = names + names2
+        if seqs.shape[0] and seqs2.shape[0] and seqs.shape[1] != seqs2.shape[1]:
+            raise RuntimeError("oracle: the two files differ in alignment length")
+        seqs = np.concatenate([seqs, seqs2], axis=0)
+    r, c, d, nn = pairsnp_arrays(seqs, n0=n0, dist=dist, n_threads=n_threads)
+    return (r.tolist(), c.tolist(), d.tolist(), names, [0] * len(d), nn.tolist())
+
+
+def pairsnp_rows_checksum(planes, L, n_rows, n_threads):
+    planes = np.ascontiguousarray(planes, dtype=np.uint64)
+    n = planes.shape[1]
+    return lib().orc_pairsnp_rows_checksum(_u64p(planes), n, L, n_rows, n_threads)
+
+
+# ---- independent brute force (per site, no bit tricks) ----------------------------------
+_MASK = np.full(256, 15, np.uint8)
+for _ch, _m in {"A": 1, "C": 2, "G": 4, "T": 8, "M": 3, "R": 5, "W": 9, "S": 6, "Y": 10, "K": 12,
+                "V": 7, "H": 11, "D": 13, "B": 14}.items():
+    _MASK[ord(_ch)] = _m
+    _MASK[ord(_ch.lower())] = _m
+
+
+def brute_pairsnp(seqs, n0=None, dist=2147483647):
+    """d = #sites whose allele sets are disjoint; nn = #sites where neither is fully
+    ambiguous -- written from the definition, not from the bit-plane code."""
+    m = _MASK[np.asarray(seqs, np.uint8)]
+    n = m.shape[0]
+    i_end, j_start = (n, 0) if n0 is None else (n0, n0)
+    R, Cc, D, NN = [], [], [], []
+    for i in range(i_end):
+        for j in range(max(j_start, i + 1), n):
+            d = int(np.count_nonzero((m[i] & m[j]) == 0))
+            if d <= dist:
+                R.append(i); Cc.append(j); D.append(d)
+                NN.append(int(np.count_nonzero((m[i] != 15) & (m[j] != 15))))
+    return (np.array(R, np.uint64), np.array(Cc, np.uint64), np.array(D, np.uint64), np.array(NN, np.uint64))
+
+
+# ---- transcluster / dmultinomial --------------------------------------------------------
+def lprob_k_given_N(N, k, delta, lamb, beta, lgamma):
+    lg = np.ascontiguousarray(lgamma, dtype=np.float64)
+    out = np.zeros(2)
+    lib().orc_lprob_k_given_N(N, k, delta, lamb, beta, _dp(lg), _dp(out))
+    return (float(out[0]), float(out[1]))
+
+
+def lprob_k_given_N_2(N, k, delta, lamb, beta):
+    out = np.zeros(2)
+    lib().orc_lprob_k_given_N_2(N, k, delta, lamb, beta, _dp(out))
+    return (float(out[0]), float(out[1]))
+
+
+def expected_k(N, delta, lamb, beta, thr):
+    ks = C.c_int(0)
+    v = lib().orc_expected_k(int(N), delta, lamb, beta, thr, C.byref(ks))
+    return float(v), ks.value
+
+
+def trans_dist(snpdiff, datediff, lamb, beta, threshold_Ek):
+    n = np.ascontiguousarray(snpdiff, dtype=np.int32)
+    d = np.ascontiguousarray(datediff, dtype=np.float64)
+    p0 = np.zeros(len(n)); eK = np.zeros(len(n))
+    if len(n):
+        lib().orc_trans_dist(n.ctypes.data_as(C.POINTER(C.c_int)), _dp(d), len(n), lamb, beta, threshold_Ek,
+                             _dp(p0), _dp(eK))
+    return p0, eK
+
+
+def calculate_posteriors(counts, alphas, keep, threshold):
+    c = np.ascontiguousarray(counts, dtype=np.float64)
+    a = np.ascontiguousarray(alphas, dtype=np.float64)
+    out = np.zeros_like(c)
+    if c.shape[0]:
+        lib().orc_calculate_posteriors(_dp(c), c.shape[0], c.shape[1], _dp(a), int(bool(keep)), threshold, _dp(out))
+    return out
+
+
+def connected_components(n, I, J):
+    """Labels as scipy.sparse.csgraph.connected_components(directed=False) returns them
+    (tracs/cluster.py:126-129): component ids in order of each component's smallest node."""
+    parent = list(range(n))
+
+    def find(x):
+        while parent[x] != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+    for a, b in zip(I, J):
+        ra, rb = find(int(a)), find(int(b))
+        if ra != rb:
+            parent[max(ra, rb)] = min(ra, rb)
+    labels = np.empty(n, np.int32)
+    ids = {}
+    for v in range(n):
+        r = find(v)
+        if r not in ids:
+            ids[r] = len(ids)
+        labels[v] = ids[r]
+    return labels

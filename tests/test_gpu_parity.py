@@ -1,0 +1,162 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the oracle on the same seeded
+inputs.  Bit-exact for integer work; 1e-6 relative (BASELINE.json north_star) for floating point,
+with far tighter observed agreement asserted where the arithmetic is the same."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6          # north_star tolerance for log-likelihoods / E(K)
+
+
+@pytest.fixture(scope="module")
+def api(hiplib):
+    import torch  # noqa: F401  (one HIP runtime)
+    from tracs_amd import api
+    return api
+
+
+def _write(tmp_path, seqs, name="a.fa", **kw):
+    from tracs_amd import synth
+    p = os.path.join(str(tmp_path), name)
+    synth.write_fasta(p, seqs, **kw)
+    return p
+
+
+@pytest.mark.parametrize("n,L", [(2, 1), (5, 37), (17, 128), (64, 129), (65, 1000), (130, 4097), (300, 20000)])
+def test_pairsnp_matches_oracle(api, oracle, tmp_path, n, L):
+    from tracs_amd import synth
+    seqs = synth.alignment(n, L, seed=100 + n, mu_lineage=0.02, mu_sample=0.01, p_n=0.03, p_partial=0.02,
+                           p_lower=0.05, p_other=0.02)
+    fa = _write(tmp_path, seqs, width=60)
+    r, c, d, names, filt, nn = api.pairsnp_arrays([fa], 1, 2147483647, False)
+    er, ec, ed, enn = oracle.pairsnp_arrays(seqs)
+    assert names == ["s%d" % i for i in range(n)]
+    assert np.array_equal(r, er) and np.array_equal(c, ec)
+    assert np.array_equal(d, ed)
+    assert np.array_equal(nn, enn)
+    assert np.array_equal(filt, np.zeros(len(d), np.uint64))      # `len` zeros when filter is off
+
+
+def test_pairsnp_threshold_and_order(api, oracle, tmp_path):
+    from tracs_amd import synth
+    seqs = synth.alignment(200, 3000, seed=5, mu_lineage=0.01, mu_sample=0.002, p_n=0.02)
+    fa = _write(tmp_path, seqs, gz=True, name="a.fa.gz")
+    for dist in (-1, 0, 3, 20, 60):
+        r, c, d, _, _, nn = api.pairsnp_arrays([fa], 4, dist, False)
+        er, ec, ed, enn = oracle.pairsnp_arrays(seqs, dist=dist)
+        assert np.array_equal(r, er) and np.array_equal(c, ec) and np.array_equal(d, ed) and np.array_equal(nn, enn)
+        assert (d.astype(np.int64) <= dist).all()
+
+
+def test_pairsnp_two_files(api, oracle, tmp_path):
+    from tracs_amd import synth
+    seqs = synth.alignment(90, 1500, seed=9, mu_lineage=0.02, mu_sample=0.01, p_n=0.05, p_partial=0.02)
+    fa = _write(tmp_path, seqs[:37], name="q.fa", names=["q%d" % i for i in range(37)])
+    fb = _write(tmp_path, seqs[37:], name="db.fa", names=["db%d" % i for i in range(53)])
+    r, c, d, names, _, nn = api.pairsnp_arrays([fa, fb], 1, 40, False)
+    er, ec, ed, enn = oracle.pairsnp_arrays(seqs, n0=37, dist=40)
+    assert len(names) == 90 and names[0] == "q0" and names[37] == "db0"
+    assert np.array_equal(r, er) and np.array_equal(c, ec) and np.array_equal(d, ed) and np.array_equal(nn, enn)
+    assert r.max() < 37 and c.min() >= 37
+
+
+def test_pairsnp_list_api_and_errors(api, tmp_path):
+    from tracs_amd import synth
+    seqs = synth.alignment(4, 50, seed=1)
+    fa = _write(tmp_path, seqs)
+    out = api.pairsnp(fasta=[fa], n_threads=1, dist=10, filter=False)
+    assert isinstance(out, tuple) and len(out) == 6 and all(isinstance(x, list) for x in out)
+    assert all(isinstance(v, int) for v in out[0] + out[1] + out[2] + out[4] + out[5])
+    with pytest.raises(RuntimeError, match="Invalid number of fasta files!"):
+        api.pairsnp(fasta=[fa, fa, fa], n_threads=1, dist=10, filter=False)
+    ragged = os.path.join(str(tmp_path), "ragged.fa")
+    with open(ragged, "w") as fh:
+        fh.write(">a\nACGT\n>b\nACG\n")
+    with pytest.raises(RuntimeError, match="variable sequence lengths"):
+        api.pairsnp(fasta=[ragged], n_threads=1, dist=10, filter=False)
+    empty = os.path.join(str(tmp_path), "empty.fa")
+    open(empty, "w").close()
+    out = api.pairsnp(fasta=[empty], n_threads=1, dist=10, filter=False)
+    assert out == ([], [], [], [], [], [])
+    one = os.path.join(str(tmp_path), "one.fa")
+    with open(one, "w") as fh:
+        fh.write(">only\nACGTN\n")
+    assert api.pairsnp(fasta=[one], n_threads=1, dist=10, filter=False) == ([], [], [], ["only"], [], [])
+
+
+def test_trans_dist_matches_oracle(api, oracle):
+    rng = np.random.default_rng(11)
+    for lamb, beta in ((1e-3 * 29903, 73.0), (5.3, 6.0), (3.0, 52.0)):
+        N = rng.integers(0, 80, 4000).astype(np.int32)
+        days = rng.integers(0, 500, 4000)
+        days[:200] = 0                                    # delta == 0 branch
+        delta = days.astype(np.float64) * 86400.0 / 31556952.0
+        p0, ek = api.trans_dist_arrays(N, delta, lamb, beta, 0.01)
+        ep0, eek = oracle.trans_dist(N, delta, lamb, beta, 0.01)
+        assert np.allclose(p0, ep0, rtol=RTOL, atol=0)
+        assert np.allclose(ek, eek, rtol=RTOL, atol=0)
+        # observed agreement is ~1e-12: guard against silent degradation
+        assert np.max(np.abs(p0 - ep0) / np.abs(ep0)) < 1e-9
+        assert np.max(np.abs(ek - eek) / np.abs(eek)) < 1e-9
+
+
+def test_trans_dist_reference_known_answers(api):
+    # /root/reference/tests/test_trans_distance.py:29-42 (1-day gap, SNP 0 and 2, defaults)
+    dd = [86400.0 / 31556952.0] * 2
+    p0, ek = api.trans_dist([0, 2], dd, 1e-3 * 29903, 73.0, 0.01)
+    assert abs(dd[0] - 0.002737907006988508) < 1e-15
+    assert abs(np.exp(p0[0]) - 0.23794988406662973) < 1e-6 and abs(np.exp(p0[1]) - 0.024467137572328577) < 1e-6
+    assert abs(ek[0] - 2.6335200453700187) < 1e-6 and abs(ek[1] - 7.315670110063259) < 1e-6
+    assert isinstance(p0, list) and isinstance(ek, list)
+
+
+def test_lprob_k_given_N_reference_known_answer(api):
+    # /root/reference/tests/test_llk.py:21-29 (Sage symbolic integral)
+    from scipy.special import gammaln
+    lp, lhs = api.lprob_k_given_N(7, 4, 0.16963, 3, 52, gammaln(range(20)))
+    assert abs(lp + 17.9565184209608) < 1e-6
+    assert abs(lhs - 12.0861694243766) < 1e-6
+
+
+def test_lprob_k_given_N_matches_oracle(api, oracle):
+    from scipy.special import gammaln
+    lg = gammaln(np.arange(400))
+    rng = np.random.default_rng(3)
+    for _ in range(40):
+        N, k = int(rng.integers(0, 150)), int(rng.integers(0, 150))
+        delta = float(rng.choice([0.0, 0.0027, 0.1, 0.8, 2.5]))
+        a = api.lprob_k_given_N(N, k, delta, 5.3, 6.0, lg)
+        b = oracle.lprob_k_given_N(N, k, delta, 5.3, 6.0, lg)
+        assert np.allclose(a, b, rtol=1e-9, atol=0)
+
+
+@pytest.mark.parametrize("keep", [False, True])
+def test_calculate_posteriors_matches_oracle(api, oracle, keep):
+    from tracs_amd import synth
+    counts = synth.allele_counts(50000, seed=4, depth=25, p_two=0.05).astype(np.float64)
+    counts[:50] = 0                                       # zero coverage rows
+    counts[50:100] = 7                                    # four-way ties
+    counts[100:150, 1] = counts[100:150, 0]               # two-way ties
+    alphas = [0.889048781117318, 20.8156311152126, 0.1, 4.38181182238621]
+    for thr in (0.0, 0.01, 0.05, 0.3):
+        got = api.calculate_posteriors(counts, alphas, keep, thr)
+        exp = oracle.calculate_posteriors(counts, alphas, keep, thr)
+        assert got.shape == exp.shape and got.dtype == np.float64
+        assert np.array_equal(got, exp)                   # one add + one IEEE divide per cell: bit-exact
+
+
+def test_connected_components_matches_scipy_order(api, oracle):
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import connected_components
+    rng = np.random.default_rng(8)
+    for n, m in ((1, 0), (10, 0), (50, 30), (2000, 1500), (20000, 30000)):
+        I = rng.integers(0, n, m).astype(np.int32)
+        J = rng.integers(0, n, m).astype(np.int32)
+        nc, lab = api.connected_components(n, I, J)
+        G = csr_matrix((np.ones(m), (I, J)), shape=(n, n))
+        enc, elab = connected_components(csgraph=G, directed=False, return_labels=True)
+        assert nc == enc and np.array_equal(lab, elab)
+        assert np.array_equal(lab, oracle.connected_components(n, I, J))

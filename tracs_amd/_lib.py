@@ -1,0 +1,122 @@
+"""ctypes binding of libtracs_hip.so (include/tracs_hip.h).
+
+The HIP library IS the product: there is no CPU fallback.  If the shared library is missing,
+does not load, or no GPU is visible, calls raise -- they never route through oracle/.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtracs_hip.so")
+_lib = None
+
+# every symbol include/tracs_hip.h declares (tests/test_cabi.py checks the .so exports them all)
+SYMBOLS = [
+    "tracs_last_error", "tracs_abi_version", "tracs_device_count",
+    "tracs_pairsnp", "tracs_pairsnp_len", "tracs_pairsnp_nseq", "tracs_pairsnp_seqlen", "tracs_pairsnp_rows",
+    "tracs_pairsnp_cols", "tracs_pairsnp_distances", "tracs_pairsnp_filt_distances", "tracs_pairsnp_ncompared",
+    "tracs_pairsnp_name", "tracs_pairsnp_free",
+    "tracs_trans_dist", "tracs_lprob_k_given_N", "tracs_calculate_posteriors", "tracs_connected_components",
+    "tracs_alignment_create", "tracs_alignment_free", "tracs_alignment_n", "tracs_alignment_len",
+    "tracs_alignment_bytes", "tracs_alignment_planes", "tracs_alignment_pack", "tracs_alignment_from_fasta",
+    "tracs_free",
+    "tracs_pairsnp_dense", "tracs_coo_count", "tracs_coo_fill",
+    "tracs_trans_dist_device", "tracs_trans_dist_dense",
+    "tracs_calculate_posteriors_device", "tracs_posterior_codes_device",
+    "tracs_connected_components_device",
+]
+
+
+class TracsError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library (building nothing: run `python -m tracs_amd.build` or __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TracsError("libtracs_hip.so is missing (%s): build it with `python -m tracs_amd.build`; "
+                         "there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, sz, i32, i64, dbl = C.c_void_p, C.c_size_t, C.c_int32, C.c_int64, C.c_double
+    u64p, dp = C.POINTER(C.c_uint64), C.POINTER(C.c_double)
+    L.tracs_last_error.restype = C.c_char_p
+    L.tracs_abi_version.restype = C.c_int
+    L.tracs_device_count.restype = C.c_int
+    L.tracs_pairsnp.restype = C.c_int
+    L.tracs_pairsnp.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    for name in ("len", "nseq", "seqlen"):
+        f = getattr(L, "tracs_pairsnp_" + name)
+        f.restype = sz
+        f.argtypes = [vp]
+    for name in ("rows", "cols", "distances", "filt_distances", "ncompared"):
+        f = getattr(L, "tracs_pairsnp_" + name)
+        f.restype = u64p
+        f.argtypes = [vp]
+    L.tracs_pairsnp_name.restype = C.c_char_p
+    L.tracs_pairsnp_name.argtypes = [vp, sz]
+    L.tracs_pairsnp_free.restype = None
+    L.tracs_pairsnp_free.argtypes = [vp]
+    L.tracs_trans_dist.restype = C.c_int
+    L.tracs_trans_dist.argtypes = [C.POINTER(i32), dp, sz, dbl, dbl, dbl, dp, dp]
+    L.tracs_lprob_k_given_N.restype = C.c_int
+    L.tracs_lprob_k_given_N.argtypes = [u64p, u64p, dp, sz, dbl, dbl, dp, sz, dp, dp]
+    L.tracs_calculate_posteriors.restype = C.c_int
+    L.tracs_calculate_posteriors.argtypes = [dp, sz, sz, dp, C.c_int, dbl, dp]
+    L.tracs_connected_components.restype = C.c_int
+    L.tracs_connected_components.argtypes = [C.POINTER(i32), C.POINTER(i32), sz, sz, C.POINTER(i32), C.POINTER(i32)]
+    L.tracs_alignment_create.restype = C.c_int
+    L.tracs_alignment_create.argtypes = [sz, sz, C.POINTER(vp)]
+    L.tracs_alignment_free.restype = None
+    L.tracs_alignment_free.argtypes = [vp]
+    for name in ("n", "len", "bytes"):
+        f = getattr(L, "tracs_alignment_" + name)
+        f.restype = sz
+        f.argtypes = [vp]
+    L.tracs_alignment_planes.restype = vp
+    L.tracs_alignment_planes.argtypes = [vp]
+    L.tracs_alignment_pack.restype = C.c_int
+    L.tracs_alignment_pack.argtypes = [vp, vp, sz, sz, C.c_int, vp]
+    L.tracs_alignment_from_fasta.restype = C.c_int
+    L.tracs_alignment_from_fasta.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.POINTER(vp), C.POINTER(vp),
+                                             C.POINTER(sz), C.POINTER(sz)]
+    L.tracs_free.restype = None
+    L.tracs_free.argtypes = [vp]
+    L.tracs_pairsnp_dense.restype = C.c_int
+    L.tracs_pairsnp_dense.argtypes = [vp, sz, sz, sz, vp, vp, sz, vp]
+    L.tracs_coo_count.restype = C.c_int
+    L.tracs_coo_count.argtypes = [vp, sz, sz, sz, sz, sz, i32, vp, vp]
+    L.tracs_coo_fill.restype = C.c_int
+    L.tracs_coo_fill.argtypes = [vp, vp, sz, sz, sz, sz, sz, i32, vp, vp, vp, vp, vp, vp]
+    L.tracs_trans_dist_device.restype = C.c_int
+    L.tracs_trans_dist_device.argtypes = [vp, vp, sz, dbl, dbl, dbl, C.c_int, vp, vp, vp]
+    L.tracs_trans_dist_dense.restype = C.c_int
+    L.tracs_trans_dist_dense.argtypes = [vp, sz, sz, sz, sz, sz, i32, vp, dbl, dbl, dbl, C.c_int, vp, vp, vp]
+    L.tracs_calculate_posteriors_device.restype = C.c_int
+    L.tracs_calculate_posteriors_device.argtypes = [vp, sz, sz, dp, C.c_int, dbl, vp, vp]
+    L.tracs_posterior_codes_device.restype = C.c_int
+    L.tracs_posterior_codes_device.argtypes = [vp, sz, dp, C.c_int, dbl, vp, vp]
+    L.tracs_connected_components_device.restype = C.c_int
+    L.tracs_connected_components_device.argtypes = [vp, vp, sz, sz, vp, C.POINTER(i32), vp]
+    L.tracs_debug_iupac_mask.restype = C.c_int
+    L.tracs_debug_iupac_mask.argtypes = [C.c_int]
+    _lib = L
+    return L
+
+
+def check(rc):
+    """Raise RuntimeError with the library's message (the reference raises RuntimeError with the
+    same strings: src/pairsnp.hpp:86,96-97,342) on a non-zero return code."""
+    if rc != 0:
+        msg = load().tracs_last_error()
+        raise RuntimeError(msg.decode("utf-8", "replace") if msg else "libtracs_hip error %d" % rc)
+
+
+def require_gpu():
+    L = load()
+    if L.tracs_device_count() <= 0:
+        raise TracsError("no MI355X/HIP device visible: the TRACS distance path runs on the GPU only "
+                         "(there is no CPU fallback)")
+    return L

@@ -1,0 +1,214 @@
+// capi.hip -- library-wide state (error slot, scratch pool) and the host-level pairsnp entry.
+//
+// tracs_pairsnp restates the DRIVER part of /root/reference/src/pairsnp.hpp:320-457:
+// argument check (:340-343), one- vs two-file pair ranges (:352-360), the output tuple (:451-457).
+// The arithmetic is in pairsnp.hip.
+#include "common.h"
+#include "fasta.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+namespace tracs {
+
+static thread_local std::string g_error;
+void set_error(const std::string &msg) { g_error = msg; }
+
+struct Scratch { void *ptr = nullptr; size_t bytes = 0; };
+static Scratch g_scratch[8][64];
+static std::mutex g_scratch_mu;
+
+int workspace_get(int slot, size_t bytes, void **out)
+{
+    int dev = 0;
+    TRACS_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 8 || slot < 0 || slot >= 64) { set_error("workspace_get: bad device/slot"); return TRACS_E_ARG; }
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    Scratch &s = g_scratch[dev][slot];
+    if (s.bytes < bytes) {
+        if (s.ptr) { TRACS_HIP_CHECK(hipDeviceSynchronize()); TRACS_HIP_CHECK(hipFree(s.ptr)); s.ptr = nullptr; s.bytes = 0; }
+        const size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&s.ptr, want);
+        if (e != hipSuccess) { s.ptr = nullptr; set_error(std::string("hipMalloc(workspace): ") + hipGetErrorString(e)); return TRACS_E_NOMEM; }
+        s.bytes = want;
+    }
+    *out = s.ptr;
+    return TRACS_OK;
+}
+
+void workspace_release_all()
+{
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    for (auto &dev : g_scratch)
+        for (auto &s : dev)
+            if (s.ptr) { (void)hipFree(s.ptr); s.ptr = nullptr; s.bytes = 0; }
+}
+
+}  // namespace tracs
+
+using namespace tracs;
+
+struct tracs_pairsnp_result {
+    size_t nseq = 0, L = 0;
+    std::vector<uint64_t> rows, cols, dist, filt, ncomp;
+    std::vector<std::string> names;
+};
+
+extern "C" {
+
+const char *tracs_last_error(void) { return g_error.c_str(); }
+int tracs_abi_version(void) { return 1; }
+
+int tracs_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void tracs_free(void *p) { std::free(p); }
+
+int tracs_alignment_from_fasta(const char *const *fasta, int n_fasta, tracs_alignment **out, char **names_out,
+                               size_t *names_bytes, size_t *n_first_file)
+{
+    if (out) *out = nullptr;
+    if (names_out) *names_out = nullptr;
+    if (!fasta || !out || n_fasta < 1 || n_fasta > 2) { set_error("Invalid number of fasta files!"); return TRACS_E_ARG; }
+    FastaData fd;
+    size_t n0 = 0;
+    for (int f = 0; f < n_fasta; f++) {
+        std::string err;
+        FastaData one;
+        int rc = read_fasta(fasta[f], one, err);
+        if (rc) { set_error(err); return rc; }
+        if (f == 0) { fd = std::move(one); n0 = fd.n; }
+        else {
+            // load_seqs only checks lengths inside one file (pairsnp.hpp:94-98); two files of different
+            // length would make the reference AND bitsets of different sizes (undefined) -- refuse.
+            if (fd.n && one.n && one.L != fd.L) { set_error("Error reading FASTA, variable sequence lengths!"); return TRACS_E_RAGGED; }
+            if (!fd.n) fd.L = one.L;
+            fd.seq.insert(fd.seq.end(), one.seq.begin(), one.seq.end());
+            fd.names.insert(fd.names.end(), one.names.begin(), one.names.end());
+            fd.n += one.n;
+        }
+    }
+    tracs_alignment *a = nullptr;
+    int rc = tracs_alignment_create(fd.n, fd.L, &a);
+    if (rc) return rc;
+    // pack in sample batches of <= 1 GiB of ASCII
+    const size_t batch = fd.L ? std::max<size_t>(1, (1ull << 30) / fd.L) : fd.n;
+    for (size_t s = 0; s < fd.n && fd.L; s += batch) {
+        const size_t cnt = std::min(batch, fd.n - s);
+        rc = tracs_alignment_pack(a, fd.seq.data() + s * fd.L, s, cnt, 0, nullptr);
+        if (rc) { tracs_alignment_free(a); return rc; }
+    }
+    if (names_out) {
+        size_t bytes = 0;
+        for (auto &nm : fd.names) bytes += nm.size() + 1;
+        char *blk = static_cast<char *>(std::malloc(bytes ? bytes : 1));
+        size_t o = 0;
+        for (auto &nm : fd.names) { std::memcpy(blk + o, nm.c_str(), nm.size() + 1); o += nm.size() + 1; }
+        *names_out = blk;
+        if (names_bytes) *names_bytes = bytes;
+    }
+    if (n_first_file) *n_first_file = n0;
+    *out = a;
+    return TRACS_OK;
+}
+
+int tracs_pairsnp(const char *const *fasta, int n_fasta, int n_threads, int dist, int filter, tracs_pairsnp_result **out)
+{
+    (void)n_threads;
+    if (!out) { set_error("tracs_pairsnp: out is NULL"); return TRACS_E_ARG; }
+    *out = nullptr;
+    if (n_fasta < 1 || n_fasta > 2 || !fasta) { set_error("Invalid number of fasta files!"); return TRACS_E_ARG; }   // :340-343
+    if (filter) { set_error("pairsnp(filter=True): the recombination filter is not implemented in this build"); return TRACS_E_ARG; }
+    tracs_alignment *a = nullptr;
+    char *names = nullptr;
+    size_t names_bytes = 0, n0 = 0;
+    int rc = tracs_alignment_from_fasta(fasta, n_fasta, &a, &names, &names_bytes, &n0);
+    if (rc) return rc;
+    auto *res = new tracs_pairsnp_result();
+    res->nseq = a->n; res->L = a->L;
+    { size_t o = 0; for (size_t i = 0; i < a->n; i++) { res->names.emplace_back(names + o); o += res->names.back().size() + 1; } }
+    tracs_free(names);
+    // pair ranges (:348-360)
+    const size_t n = a->n;
+    const size_t i_end = n_fasta == 1 ? n : n0;
+    const size_t j_start = n_fasta == 1 ? 0 : n0;
+
+    unsigned *d_dist = nullptr, *d_nn = nullptr, *d_rows = nullptr, *d_cols = nullptr, *d_d = nullptr, *d_n = nullptr;
+    long long *d_off = nullptr;
+    auto cleanup = [&]() {
+        void *p[] = {d_dist, d_nn, d_rows, d_cols, d_d, d_n, d_off};
+        for (void *q : p) if (q) (void)hipFree(q);
+        tracs_alignment_free(a);
+    };
+#define PS_CHECK(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { cleanup(); delete res; set_error(std::string(#x ": ") + hipGetErrorString(e__)); return TRACS_E_HIP; } } while (0)
+#define PS_RC(x) do { int r__ = (x); if (r__) { cleanup(); delete res; return r__; } } while (0)
+    if (n >= 2 && i_end > 0) {
+        // row panels bounded to ~1 GiB per dense matrix
+        const size_t panel = std::max<size_t>(64, std::min<size_t>(i_end, (1ull << 28) / std::max<size_t>(n, 1)));
+        PS_CHECK(hipMalloc(reinterpret_cast<void **>(&d_dist), panel * n * 4));
+        PS_CHECK(hipMalloc(reinterpret_cast<void **>(&d_nn), panel * n * 4));
+        PS_CHECK(hipMalloc(reinterpret_cast<void **>(&d_off), (panel + 1) * 8));
+        size_t cap = 0;
+        std::vector<unsigned> h32;
+        for (size_t r0 = 0; r0 < i_end; r0 += panel) {
+            const size_t r1 = std::min(i_end, r0 + panel);
+            // the dense block is addressed as base[(i) * ld + j] with i absolute: shift the base
+            unsigned *bd = d_dist - r0 * n, *bn = d_nn - r0 * n;
+            PS_RC(tracs_pairsnp_dense(a, r0, r1, j_start, bd, bn, n, nullptr));
+            PS_RC(tracs_coo_count(bd, n, n, r0, r1, j_start, dist, reinterpret_cast<int64_t *>(d_off), nullptr));
+            long long total = 0;
+            PS_CHECK(hipMemcpy(&total, d_off + (r1 - r0), 8, hipMemcpyDeviceToHost));
+            if (total <= 0) continue;
+            if ((size_t)total > cap) {
+                void *p[] = {d_rows, d_cols, d_d, d_n};
+                for (void *q : p) if (q) PS_CHECK(hipFree(q));
+                d_rows = d_cols = d_d = d_n = nullptr;
+                cap = (size_t)total;
+                PS_CHECK(hipMalloc(reinterpret_cast<void **>(&d_rows), cap * 4));
+                PS_CHECK(hipMalloc(reinterpret_cast<void **>(&d_cols), cap * 4));
+                PS_CHECK(hipMalloc(reinterpret_cast<void **>(&d_d), cap * 4));
+                PS_CHECK(hipMalloc(reinterpret_cast<void **>(&d_n), cap * 4));
+            }
+            PS_RC(tracs_coo_fill(bd, bn, n, n, r0, r1, j_start, dist, reinterpret_cast<int64_t *>(d_off), d_rows, d_cols, d_d, d_n, nullptr));
+            h32.resize((size_t)total);
+            auto pull = [&](unsigned *src, std::vector<uint64_t> &dst) -> hipError_t {
+                hipError_t e = hipMemcpy(h32.data(), src, (size_t)total * 4, hipMemcpyDeviceToHost);
+                if (e != hipSuccess) return e;
+                const size_t base = dst.size();
+                dst.resize(base + (size_t)total);
+                for (size_t t = 0; t < (size_t)total; t++) dst[base + t] = h32[t];
+                return hipSuccess;
+            };
+            PS_CHECK(pull(d_rows, res->rows));
+            PS_CHECK(pull(d_cols, res->cols));
+            PS_CHECK(pull(d_d, res->dist));
+            PS_CHECK(pull(d_n, res->ncomp));
+        }
+    }
+#undef PS_CHECK
+#undef PS_RC
+    res->filt.assign(res->rows.size(), 0);      // filter off: `len` zeros (:452 via combine_vectors :31)
+    cleanup();
+    *out = res;
+    return TRACS_OK;
+}
+
+size_t tracs_pairsnp_len(const tracs_pairsnp_result *r) { return r ? r->rows.size() : 0; }
+size_t tracs_pairsnp_nseq(const tracs_pairsnp_result *r) { return r ? r->nseq : 0; }
+size_t tracs_pairsnp_seqlen(const tracs_pairsnp_result *r) { return r ? r->L : 0; }
+const uint64_t *tracs_pairsnp_rows(const tracs_pairsnp_result *r) { return r ? r->rows.data() : nullptr; }
+const uint64_t *tracs_pairsnp_cols(const tracs_pairsnp_result *r) { return r ? r->cols.data() : nullptr; }
+const uint64_t *tracs_pairsnp_distances(const tracs_pairsnp_result *r) { return r ? r->dist.data() : nullptr; }
+const uint64_t *tracs_pairsnp_filt_distances(const tracs_pairsnp_result *r) { return r ? r->filt.data() : nullptr; }
+const uint64_t *tracs_pairsnp_ncompared(const tracs_pairsnp_result *r) { return r ? r->ncomp.data() : nullptr; }
+const char *tracs_pairsnp_name(const tracs_pairsnp_result *r, size_t i) { return (r && i < r->names.size()) ? r->names[i].c_str() : nullptr; }
+void tracs_pairsnp_free(tracs_pairsnp_result *r) { delete r; }
+
+}  // extern "C"

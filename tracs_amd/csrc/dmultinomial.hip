@@ -1,0 +1,199 @@
+// dmultinomial.hip -- per-site Dirichlet-multinomial posterior filter for gfx950 (f64, HBM-bound).
+//
+// Reference behaviour restated (never copied): /root/reference/src/dmultinomial.hpp:8-86
+//   alphas sorted descending (:13), a0 = sum (:14), a_min = alphas[0]/a0 (:15);
+//   per row: denom = sum of counts in column order (:38-42); stable descending argsort (:45-47);
+//   denom <= 0 -> every cell a_min (:53-56); else cell idx[j] = (c + alpha[rank]) / (denom + a0),
+//   the rank advancing only when the next sorted count differs (:59-64);
+//   then cells <= threshold become `threshold` if keep && count > 0 else 0 (:69-82).
+// One thread per site; a row is 32 B in / 32 B out for K = 4, read and written as 2 x 16 B.
+#include "common.h"
+
+namespace tracs {
+
+constexpr int KMAX = 8;
+
+struct Alphas { double a[KMAX]; double a0, a_min; };
+
+// The reference walks the stably sorted row and advances the alpha rank whenever the next sorted
+// count differs (:59-64).  Equal counts are contiguous after the sort, so the rank a cell gets is
+// the number of DISTINCT count values strictly greater than its own -- computed here directly,
+// with static indices only (runtime-indexed per-thread arrays would live in scratch memory).
+template <int K>
+__device__ __forceinline__ void posterior_row(const double (&row)[K], const Alphas &A, int keep, double expected,
+                                              double (&res)[K])
+{
+    double denom = 0;
+#pragma unroll
+    for (int j = 0; j < K; j++) denom += row[j];
+    if (denom <= 0) {
+#pragma unroll
+        for (int j = 0; j < K; j++) res[j] = A.a_min;
+    } else {
+        const double den = denom + A.a0;
+        bool first[K];       // first occurrence of its value
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            bool f = true;
+#pragma unroll
+            for (int h = 0; h < i; h++) f = f && (row[h] != row[i]);
+            first[i] = f;
+        }
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+            int rank = 0;
+#pragma unroll
+            for (int i = 0; i < K; i++) rank += (first[i] && row[i] > row[j]) ? 1 : 0;
+            double al = A.a[0];
+#pragma unroll
+            for (int r = 1; r < K; r++) al = rank == r ? A.a[r] : al;
+            res[j] = (row[j] + al) / den;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < K; j++)
+        if (res[j] <= expected) res[j] = (keep && (row[j] > 0)) ? expected : 0.0;
+}
+
+// K = 4 fast path: double2 x 2 per row
+__global__ __launch_bounds__(256) void posteriors4_kernel(const double2 *__restrict__ counts, size_t L, Alphas A, int keep,
+                                                          double expected, double2 *__restrict__ post)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (size_t)gridDim.x * blockDim.x) {
+        const double2 lo = counts[2 * i], hi = counts[2 * i + 1];
+        const double row[4] = {lo.x, lo.y, hi.x, hi.y};
+        double res[4];
+        posterior_row<4>(row, A, keep, expected, res);
+        post[2 * i] = make_double2(res[0], res[1]);
+        post[2 * i + 1] = make_double2(res[2], res[3]);
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void posteriorsK_kernel(const double *__restrict__ counts, size_t L, Alphas A, int keep,
+                                                          double expected, double *__restrict__ post)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (size_t)gridDim.x * blockDim.x) {
+        double row[K], res[K];
+#pragma unroll
+        for (int j = 0; j < K; j++) row[j] = counts[i * K + j];
+        posterior_row<K>(row, A, keep, expected, res);
+#pragma unroll
+        for (int j = 0; j < K; j++) post[i * K + j] = res[j];
+    }
+}
+
+// production form: uint16 counts (A,C,G,T) -> 4-bit allele mask, two sites per byte.
+// A thread handles two sites = 16 B in, 1 B out.
+__global__ __launch_bounds__(256) void posterior_codes_kernel(const uint4 *__restrict__ counts2, size_t L, Alphas A, int keep,
+                                                              double expected, uint8_t *__restrict__ codes)
+{
+    const size_t npairs = (L + 1) / 2;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < npairs; t += (size_t)gridDim.x * blockDim.x) {
+        uint4 v;
+        if (2 * t + 1 < L) v = counts2[t];
+        else {   // odd tail: only 8 valid bytes
+            const uint2 h = reinterpret_cast<const uint2 *>(counts2)[2 * t];
+            v = make_uint4(h.x, h.y, 0u, 0u);
+        }
+        unsigned out = 0;
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const unsigned w0 = s == 0 ? v.x : v.z, w1 = s == 0 ? v.y : v.w;
+            const double row[4] = {(double)(w0 & 0xFFFFu), (double)(w0 >> 16), (double)(w1 & 0xFFFFu), (double)(w1 >> 16)};
+            double res[4];
+            posterior_row<4>(row, A, keep, expected, res);
+            unsigned m = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) m |= (res[j] > 0.0 ? 1u : 0u) << j;
+            if (2 * t + s < L) out |= m << (4 * s);
+        }
+        codes[t] = (uint8_t)out;
+    }
+}
+
+static int make_alphas(const double *alphas, size_t K, Alphas &A)
+{
+    if (K < 1 || K > KMAX) { set_error("calculate_posteriors: 1 <= K <= 8 alleles supported"); return TRACS_E_ARG; }
+    for (size_t j = 0; j < KMAX; j++) A.a[j] = 0.0;
+    for (size_t j = 0; j < K; j++) A.a[j] = alphas[j];
+    for (size_t a = 1; a < K; a++) {       // descending (:13)
+        const double v = A.a[a];
+        size_t b = a;
+        while (b > 0 && A.a[b - 1] < v) { A.a[b] = A.a[b - 1]; b--; }
+        A.a[b] = v;
+    }
+    A.a0 = 0.0;
+    for (size_t j = 0; j < K; j++) A.a0 += A.a[j];     // :14, same order as std::accumulate
+    A.a_min = A.a[0] / A.a0;                           // :15
+    return TRACS_OK;
+}
+
+}  // namespace tracs
+
+using namespace tracs;
+
+extern "C" {
+
+int tracs_calculate_posteriors_device(const double *counts, size_t L, size_t K, const double *alphas_host, int keep,
+                                      double threshold, double *posterior, void *stream_)
+{
+    if (L == 0) return TRACS_OK;
+    if (!counts || !alphas_host || !posterior) { set_error("tracs_calculate_posteriors_device: NULL argument"); return TRACS_E_ARG; }
+    Alphas A;
+    int rc = make_alphas(alphas_host, K, A);
+    if (rc) return rc;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const unsigned blocks = (unsigned)std::min<size_t>((L + 255) / 256, 256 * 16);
+    switch (K) {
+    case 4:
+        hipLaunchKernelGGL(posteriors4_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const double2 *>(counts), L, A,
+                           keep, threshold, reinterpret_cast<double2 *>(posterior));
+        break;
+#define TRACS_K_CASE(KK) case KK: hipLaunchKernelGGL((posteriorsK_kernel<KK>), dim3(blocks), dim3(256), 0, stream, counts, L, A, keep, threshold, posterior); break;
+        TRACS_K_CASE(1) TRACS_K_CASE(2) TRACS_K_CASE(3) TRACS_K_CASE(5) TRACS_K_CASE(6) TRACS_K_CASE(7) TRACS_K_CASE(8)
+#undef TRACS_K_CASE
+    default: set_error("calculate_posteriors: unsupported K"); return TRACS_E_ARG;
+    }
+    TRACS_HIP_CHECK(hipGetLastError());
+    return TRACS_OK;
+}
+
+int tracs_posterior_codes_device(const uint16_t *counts, size_t L, const double *alphas_host, int keep, double threshold,
+                                 uint8_t *codes, void *stream_)
+{
+    if (L == 0) return TRACS_OK;
+    if (!counts || !alphas_host || !codes) { set_error("tracs_posterior_codes_device: NULL argument"); return TRACS_E_ARG; }
+    Alphas A;
+    int rc = make_alphas(alphas_host, 4, A);
+    if (rc) return rc;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const size_t npairs = (L + 1) / 2;
+    const unsigned blocks = (unsigned)std::min<size_t>((npairs + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(posterior_codes_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const uint4 *>(counts), L, A,
+                       keep, threshold, codes);
+    TRACS_HIP_CHECK(hipGetLastError());
+    return TRACS_OK;
+}
+
+int tracs_calculate_posteriors(const double *counts, size_t L, size_t K, const double *alphas, int keep, double threshold,
+                               double *posterior)
+{
+    if (L == 0) return TRACS_OK;
+    if (!counts || !alphas || !posterior) { set_error("tracs_calculate_posteriors: NULL argument"); return TRACS_E_ARG; }
+    double *dC = nullptr, *dP = nullptr;
+    const size_t bytes = L * K * sizeof(double);
+    auto cleanup = [&]() { if (dC) (void)hipFree(dC); if (dP) (void)hipFree(dP); };
+#define CP_CHECK(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { cleanup(); set_error(std::string(#x ": ") + hipGetErrorString(e__)); return TRACS_E_HIP; } } while (0)
+    CP_CHECK(hipMalloc(reinterpret_cast<void **>(&dC), bytes));
+    CP_CHECK(hipMalloc(reinterpret_cast<void **>(&dP), bytes));
+    CP_CHECK(hipMemcpy(dC, counts, bytes, hipMemcpyHostToDevice));
+    int rc = tracs_calculate_posteriors_device(dC, L, K, alphas, keep, threshold, dP, nullptr);
+    if (rc) { cleanup(); return rc; }
+    CP_CHECK(hipMemcpy(posterior, dP, bytes, hipMemcpyDeviceToHost));
+#undef CP_CHECK
+    cleanup();
+    return TRACS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,545 @@
+// pairsnp.hip -- pack + all-pairs SNP/compared-sites kernels for gfx950 (CDNA4).
+//
+// Reference behaviour restated (never copied): /root/reference/src/pairsnp.hpp
+//   load_seqs :107-199  (IUPAC -> four allele bit sets)        -> pack_kernel
+//   pair loop :395-420  (match/popcount, compared sites)        -> pairsnp_tile_kernel
+//   emit d <= dist :405, row-major order :451-455               -> coo_count/coo_fill
+//
+// Design (DESIGN.md "pairsnp kernel"): integer VALU-bound after tiling.  One workgroup owns a
+// TI x TJ tile of the pair matrix and walks the alignment in 128-site groups:
+//   * the TJ column samples of a group are staged through LDS (double buffered, 16 B/lane
+//     coalesced loads, conflict-free ds_read_b128);
+//   * each wave owns R rows whose words are WAVE-UNIFORM, so they are fetched with scalar
+//     loads (s_load_dwordx4..x16 through the scalar cache) and enter the VALU as SGPR
+//     operands -- no LDS traffic and no VGPRs for the row side;
+//   * per 32 sites and pair: v_and, 3 x v_and_or, v_bcnt(+acc) for d; v_or, v_bcnt(+acc) for nn.
+#include "common.h"
+
+#include <algorithm>
+#include <vector>
+
+namespace tracs {
+
+// ---------------------------------------------------------------------------------------
+// IUPAC letter -> allele-set nibble (bit0=A,1=C,2=G,3=T).  load_seqs upper-cases, maps the
+// 14 unambiguous/partial codes, and sends EVERYTHING else to all four bits
+// (pairsnp.hpp:110,112-198).  26 nibbles packed in two 64-bit constants, index = letter-'A'.
+__host__ __device__ __forceinline__ unsigned iupac_mask(unsigned ch)
+{
+    const unsigned up = ch & 0xDFu;            // 'a'..'z' -> 'A'..'Z'; nothing else lands in A..Z
+    const unsigned idx = up - 'A';
+    if (ch > 0x7Fu || idx > 25u) return 15u;
+    //                       PONMLKJIHGFEDCBA                ......ZYXWVUTSRQ
+    const unsigned long long lo = 0xFFF3FCFFB4FFD2E1ull, hi = 0xFFFFFFFAF97F865Full;
+    return (unsigned)(((idx < 16u ? lo : hi) >> ((idx & 15u) * 4u)) & 15ull);
+}
+
+// ---------------------------------------------------------------------------------------
+// pack: one thread = one (sample, 128-site group): 128 ASCII bytes -> 5 planes x uint4.
+// Lanes run over samples so the 5 stores per thread are 1 KiB-coalesced per wave.
+__global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ ascii, size_t L, size_t count,
+                                                   size_t first, uint4 *__restrict__ planes, size_t n_pad,
+                                                   size_t groups)
+{
+    const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    const size_t g = (size_t)blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (s >= count || g >= groups) return;
+    const size_t site0 = g * SITES_PER_GROUP;
+    const uint8_t *src = ascii + s * L + site0;
+    const unsigned nvalid = (unsigned)((L - site0) < (size_t)SITES_PER_GROUP ? (L - site0) : SITES_PER_GROUP);
+    unsigned pl[NPLANES][4];
+#pragma unroll
+    for (int p = 0; p < NPLANES; p++)
+#pragma unroll
+        for (int w = 0; w < 4; w++) pl[p][w] = 0;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) && nvalid == SITES_PER_GROUP;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        unsigned char chunk[32];
+        if (aligned) {
+            const uint4 *v = reinterpret_cast<const uint4 *>(src + w * 32);
+            uint4 a = v[0], b = v[1];
+            *reinterpret_cast<uint4 *>(&chunk[0]) = a;
+            *reinterpret_cast<uint4 *>(&chunk[16]) = b;
+        } else {
+#pragma unroll
+            for (int b = 0; b < 32; b++) {
+                const unsigned idx = w * 32 + b;
+                chunk[b] = idx < nvalid ? src[idx] : 0;
+            }
+        }
+        unsigned A = 0, C = 0, G = 0, T = 0, N = 0;
+#pragma unroll
+        for (int b = 0; b < 32; b++) {
+            const unsigned idx = w * 32 + b;
+            unsigned m = iupac_mask(chunk[b]);
+            if (idx >= nvalid) m = 0;      // tail bits: no allele, not N => never match, never masked
+            A |= (m & 1u) << b;
+            C |= ((m >> 1) & 1u) << b;
+            G |= ((m >> 2) & 1u) << b;
+            T |= ((m >> 3) & 1u) << b;
+            N |= (m == 15u ? 1u : 0u) << b;
+        }
+        pl[0][w] = A; pl[1][w] = C; pl[2][w] = G; pl[3][w] = T; pl[4][w] = N;
+    }
+#pragma unroll
+    for (int p = 0; p < NPLANES; p++)
+        planes[(g * NPLANES + p) * n_pad + first + s] = make_uint4(pl[p][0], pl[p][1], pl[p][2], pl[p][3]);
+}
+
+// ---------------------------------------------------------------------------------------
+// XCD-aware, bijective remap of the hardware block id (guide T1): blocks b, b+8, b+16.. share
+// an XCD (and its L2); give each XCD a contiguous run of the logical schedule so that the
+// tiles resident on one XCD at a time are neighbours and share row/column panels in L2.
+__device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nwg)
+{
+    const unsigned q = nwg >> 3, r = nwg & 7u, xcd = b & 7u, k = b >> 3;
+    const unsigned base = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+    return base + k;
+}
+
+// (s & v) | m in ONE VALU op.  Left to itself hipcc re-associates the four-plane OR into
+// and, and_or, and, and, or3 (6 ops with the popcount); the asm pins and + 3 x and_or (5 ops).
+// `s` is a wave-uniform row word held in an SGPR (VOP3 on gfx9 takes one scalar source).
+__device__ __forceinline__ unsigned and_or(unsigned s, unsigned v, unsigned m)
+{
+    unsigned r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "s"(s), "v"(v), "v"(m));
+    return r;
+}
+
+__device__ __forceinline__ void pair_words(unsigned ai_a, unsigned ai_c, unsigned ai_g, unsigned ai_t,
+                                           unsigned bj_a, unsigned bj_c, unsigned bj_g, unsigned bj_t,
+                                           unsigned &acc)
+{
+    unsigned m = ai_a & bj_a;            // v_and_b32
+    m = and_or(ai_c, bj_c, m);           // v_and_or_b32
+    m = and_or(ai_g, bj_g, m);           // v_and_or_b32
+    m = and_or(ai_t, bj_t, m);           // v_and_or_b32
+    acc += __popc(m);                    // v_bcnt_u32_b32 (popcount + accumulate)
+}
+
+// NW waves per workgroup, R rows per wave, C columns per lane, GC groups per LDS stage.
+template <int NW, int R, int C, int GC, bool WITH_NN>
+__global__ __launch_bounds__(NW * 64) void pairsnp_tile_kernel(
+    const uint4 *__restrict__ P, size_t n_pad, int groups, const int2 *__restrict__ tiles, int n_tiles,
+    int groups_per_split, int ksplit, unsigned L, unsigned n, unsigned row_end, unsigned col_begin,
+    unsigned *__restrict__ dist, unsigned *__restrict__ ncomp, size_t ld)
+{
+    constexpr int NT = NW * 64;
+    constexpr int TJ = 64 * C;
+    constexpr int STAGE = GC * NPLANES * TJ;     // uint4 per LDS stage
+    constexpr int LPT = STAGE / NT;              // staging loads per thread
+    static_assert(STAGE % NT == 0, "stage must divide evenly over the workgroup");
+    __shared__ uint4 lds[2][STAGE];
+
+    const unsigned q = xcd_remap(blockIdx.x, gridDim.x);
+    const int ks = (int)(q / (unsigned)n_tiles);
+    const int2 tile = tiles[q - (unsigned)ks * (unsigned)n_tiles];
+    const int i0 = tile.x, j0 = tile.y;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g_begin = ks * groups_per_split;
+    const int g_end = min(groups, g_begin + groups_per_split);
+
+    unsigned accM[R][C], accN[R][C];
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int c = 0; c < C; c++) { accM[r][c] = 0; accN[r][c] = 0; }
+
+    uint4 stage_regs[LPT];
+    auto stage_load = [&](int gs) {
+#pragma unroll
+        for (int k = 0; k < LPT; k++) {
+            const int e = tid + k * NT;
+            const int gp = e / TJ;               // local group*5 + plane
+            const int g = gs + gp / NPLANES;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (g < g_end) v = P[((size_t)gs * NPLANES + gp) * n_pad + (size_t)j0 + (e % TJ)];
+            stage_regs[k] = v;
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < LPT; k++) lds[buf][tid + k * NT] = stage_regs[k];
+    };
+
+    stage_load(g_begin);
+    stage_store(0);
+    __syncthreads();
+
+    int buf = 0;
+    for (int gs = g_begin; gs < g_end; gs += GC) {
+        const bool more = gs + GC < g_end;
+        if (more) stage_load(gs + GC);
+#pragma unroll
+        for (int gl = 0; gl < GC; gl++) {
+            const int g = gs + gl;
+            if (g < g_end) {                      // wave-uniform
+                uint4 bj[C][NPLANES];
+#pragma unroll
+                for (int c = 0; c < C; c++)
+#pragma unroll
+                    for (int p = 0; p < NPLANES; p++)
+                        if (WITH_NN || p < 4) bj[c][p] = lds[buf][(gl * NPLANES + p) * TJ + lane + 64 * c];
+                // wave-uniform row words: scalar loads
+                const uint4 *rowp = P + (size_t)g * NPLANES * n_pad + (size_t)(i0 + wave * R);
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const uint4 a = rowp[r];
+                    const uint4 cc = rowp[n_pad + r];
+                    const uint4 gg = rowp[2 * n_pad + r];
+                    const uint4 t = rowp[3 * n_pad + r];
+#pragma unroll
+                    for (int c = 0; c < C; c++) {
+                        pair_words(a.x, cc.x, gg.x, t.x, bj[c][0].x, bj[c][1].x, bj[c][2].x, bj[c][3].x, accM[r][c]);
+                        pair_words(a.y, cc.y, gg.y, t.y, bj[c][0].y, bj[c][1].y, bj[c][2].y, bj[c][3].y, accM[r][c]);
+                        pair_words(a.z, cc.z, gg.z, t.z, bj[c][0].z, bj[c][1].z, bj[c][2].z, bj[c][3].z, accM[r][c]);
+                        pair_words(a.w, cc.w, gg.w, t.w, bj[c][0].w, bj[c][1].w, bj[c][2].w, bj[c][3].w, accM[r][c]);
+                    }
+                    if (WITH_NN) {
+                        const uint4 nn = rowp[4 * n_pad + r];
+#pragma unroll
+                        for (int c = 0; c < C; c++) {
+                            accN[r][c] += __popc(nn.x | bj[c][4].x);
+                            accN[r][c] += __popc(nn.y | bj[c][4].y);
+                            accN[r][c] += __popc(nn.z | bj[c][4].z);
+                            accN[r][c] += __popc(nn.w | bj[c][4].w);
+                        }
+                    }
+                }
+            }
+        }
+        if (more) stage_store(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // epilogue: d = L - matches, nn = L - masked; only cells of the requested set are written
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const unsigned i = (unsigned)(i0 + wave * R + r);
+        if (i >= row_end) continue;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const unsigned j = (unsigned)(j0 + lane + 64 * c);
+            if (j < n && j > i && j >= col_begin) {
+                const size_t o = (size_t)i * ld + j;
+                if (ksplit == 1) {
+                    dist[o] = L - accM[r][c];
+                    if (WITH_NN) ncomp[o] = L - accN[r][c];
+                } else {                                  // cells were initialised to L
+                    atomicSub(&dist[o], accM[r][c]);
+                    if (WITH_NN) atomicSub(&ncomp[o], accN[r][c]);
+                }
+            }
+        }
+    }
+}
+
+// cells of the block <- L (only needed when the group range is split over workgroups)
+__global__ void init_cells_kernel(unsigned *__restrict__ dist, unsigned *__restrict__ ncomp, size_t ld, unsigned n,
+                                  unsigned row_begin, unsigned row_end, unsigned col_begin, unsigned L)
+{
+    const unsigned i = row_begin + blockIdx.y;
+    if (i >= row_end) return;
+    for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
+        if (j > i && j >= col_begin) {
+            dist[(size_t)i * ld + j] = L;
+            if (ncomp) ncomp[(size_t)i * ld + j] = L;
+        }
+}
+
+// ---------------------------------------------------------------------------------------
+// COO extraction, row-major like combine_vectors (pairsnp.hpp:451-455).  One wave per row.
+__global__ __launch_bounds__(64) void coo_count_kernel(const unsigned *__restrict__ dist, size_t ld, unsigned n,
+                                                       unsigned row_begin, unsigned row_end, unsigned col_begin,
+                                                       int thr, long long *__restrict__ counts)
+{
+    const unsigned i = row_begin + blockIdx.x;
+    if (i >= row_end) return;
+    const unsigned jb = max(col_begin, i + 1);
+    long long c = 0;
+    for (unsigned j = jb + threadIdx.x; j < n; j += 64) {
+        const long long d = (long long)dist[(size_t)i * ld + j];
+        if (d <= (long long)thr) c++;
+    }
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if (threadIdx.x == 0) counts[blockIdx.x] = c;
+}
+
+// exclusive scan of per-row counts (rows <= a few 100k): single workgroup, serial over chunks
+__global__ __launch_bounds__(1024) void scan_rows_kernel(long long *__restrict__ counts, size_t nrows)
+{
+    __shared__ long long part[1024];
+    __shared__ long long carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (size_t base = 0; base < nrows + 1; base += 1024) {
+        const size_t idx = base + threadIdx.x;
+        const long long v = idx < nrows ? counts[idx] : 0;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            long long t = threadIdx.x >= (unsigned)off ? part[threadIdx.x - off] : 0;
+            __syncthreads();
+            part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const long long incl = part[threadIdx.x];
+        const long long c0 = carry;
+        __syncthreads();
+        if (idx <= nrows) counts[idx] = c0 + incl - v;      // exclusive
+        if (threadIdx.x == 1023) carry = c0 + incl;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(64) void coo_fill_kernel(const unsigned *__restrict__ dist,
+                                                      const unsigned *__restrict__ ncomp, size_t ld, unsigned n,
+                                                      unsigned row_begin, unsigned row_end, unsigned col_begin,
+                                                      int thr, const long long *__restrict__ offsets,
+                                                      unsigned *__restrict__ rows, unsigned *__restrict__ cols,
+                                                      unsigned *__restrict__ dd, unsigned *__restrict__ nn)
+{
+    const unsigned i = row_begin + blockIdx.x;
+    if (i >= row_end) return;
+    const unsigned jb = max(col_begin, i + 1);
+    long long o = offsets[blockIdx.x];
+    for (unsigned j0 = jb; j0 < n; j0 += 64) {
+        const unsigned j = j0 + threadIdx.x;
+        unsigned d = 0;
+        bool keep = false;
+        if (j < n) {
+            d = dist[(size_t)i * ld + j];
+            keep = (long long)d <= (long long)thr;
+        }
+        const unsigned long long mask = __ballot(keep);
+        if (keep) {
+            const long long pos = o + __popcll(mask & ((1ull << threadIdx.x) - 1ull));
+            rows[pos] = i; cols[pos] = j; dd[pos] = d;
+            if (nn) nn[pos] = ncomp ? ncomp[(size_t)i * ld + j] : 0u;
+        }
+        o += __popcll(mask);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+struct TileCfg { int ti, tj; };
+
+// tile schedule: upper-trapezoid tiles of the block, supertile-major so that consecutive
+// entries (= tiles resident together on one XCD after xcd_remap) share row/column panels.
+static void build_tiles(size_t n, size_t row_begin, size_t row_end, size_t col_begin, int ti, int tj,
+                        std::vector<int2> &out)
+{
+    out.clear();
+    if (row_end <= row_begin) return;
+    const size_t nbi = (row_end - row_begin + ti - 1) / ti;
+    const size_t nbj = (n + tj - 1) / tj;
+    const size_t SI = 4, SJ = 8;     // 32 tiles per supertile = one XCD's resident set
+    for (size_t sbi = 0; sbi < nbi; sbi += SI)
+        for (size_t sbj = 0; sbj < nbj; sbj += SJ)
+            for (size_t bi = sbi; bi < std::min(nbi, sbi + SI); bi++)
+                for (size_t bj = sbj; bj < std::min(nbj, sbj + SJ); bj++) {
+                    const size_t i0 = row_begin + bi * ti, j0 = bj * tj;
+                    const size_t jmax = std::min(n, j0 + tj) - 1;          // last column of the tile
+                    const size_t jneed = std::max(col_begin, i0 + 1);      // first cell of the tile's first row
+                    if (jmax < jneed) continue;                            // wholly below the diagonal / left of col_begin
+                    out.push_back(make_int2((int)i0, (int)j0));
+                }
+}
+
+}  // namespace tracs
+
+using namespace tracs;
+
+extern "C" {
+
+int tracs_debug_iupac_mask(int ch) { return (int)iupac_mask((unsigned)ch & 0xFFu); }
+
+int tracs_alignment_create(size_t n, size_t L, tracs_alignment **out)
+{
+    if (!out) { set_error("tracs_alignment_create: out is NULL"); return TRACS_E_ARG; }
+    *out = nullptr;
+    if (n >= (1ull << 31) || L >= (1ull << 32)) { set_error("alignment too large (n < 2^31, L < 2^32)"); return TRACS_E_ARG; }
+    auto *a = new tracs_alignment();
+    a->n = n; a->L = L; a->n_pad = pad_samples(n); a->groups = groups_for(L);
+    const size_t bytes = tracs_alignment_bytes(a);
+    if (bytes) {
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&a->planes), bytes);
+        if (e != hipSuccess) { set_error(std::string("hipMalloc(planes): ") + hipGetErrorString(e)); delete a; return TRACS_E_NOMEM; }
+        e = hipMemset(a->planes, 0, bytes);
+        if (e != hipSuccess) { set_error(std::string("hipMemset(planes): ") + hipGetErrorString(e)); hipFree(a->planes); delete a; return TRACS_E_HIP; }
+    }
+    *out = a;
+    return TRACS_OK;
+}
+
+void tracs_alignment_free(tracs_alignment *a)
+{
+    if (!a) return;
+    if (a->planes) (void)hipFree(a->planes);
+    if (a->d_tiles) (void)hipFree(a->d_tiles);
+    delete a;
+}
+
+size_t tracs_alignment_n(const tracs_alignment *a) { return a ? a->n : 0; }
+size_t tracs_alignment_len(const tracs_alignment *a) { return a ? a->L : 0; }
+size_t tracs_alignment_bytes(const tracs_alignment *a)
+{
+    if (!a || !a->n || !a->L) return 0;
+    // + one tile edge of slack: row tiles start at row_begin + k*TI and may read (never use) up to
+    // TI-1 samples past n_pad in the last (group, plane) run
+    return (a->groups * NPLANES * a->n_pad + SAMPLE_PAD) * sizeof(uint4);
+}
+void *tracs_alignment_planes(const tracs_alignment *a) { return a ? a->planes : nullptr; }
+
+int tracs_alignment_pack(tracs_alignment *a, const uint8_t *ascii, size_t first, size_t count, int ascii_on_device,
+                         void *stream_)
+{
+    if (!a || (!ascii && count)) { set_error("tracs_alignment_pack: NULL argument"); return TRACS_E_ARG; }
+    if (first + count > a->n) { set_error("tracs_alignment_pack: sample range outside the alignment"); return TRACS_E_ARG; }
+    if (!count || !a->L) return TRACS_OK;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const uint8_t *d_ascii = ascii;
+    uint8_t *tmp = nullptr;
+    if (!ascii_on_device) {
+        TRACS_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&tmp), count * a->L));
+        hipError_t e = hipMemcpyAsync(tmp, ascii, count * a->L, hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) { (void)hipFree(tmp); set_error(std::string("H2D ascii: ") + hipGetErrorString(e)); return TRACS_E_HIP; }
+        d_ascii = tmp;
+    }
+    dim3 grid((unsigned)((count + 63) / 64), (unsigned)((a->groups + 3) / 4));
+    // grid.y is limited to 65535: L up to 33.5 Mbp per launch; loop for longer alignments
+    const size_t max_gy = 65535;
+    for (size_t gy0 = 0; gy0 < grid.y; gy0 += max_gy) {
+        // shift the group window by offsetting pointers is not possible for `planes` (group-major),
+        // so pass the window through blockIdx.y + base via a second launch with adjusted L-window
+        if (gy0 != 0) { if (tmp) (void)hipFree(tmp); set_error("alignment longer than 33.5 Mbp per pack launch not supported yet"); return TRACS_E_ARG; }
+        dim3 g2(grid.x, (unsigned)std::min<size_t>(grid.y, max_gy));
+        hipLaunchKernelGGL(pack_kernel, g2, dim3(256), 0, stream, d_ascii, a->L, count, first, a->planes, a->n_pad, a->groups);
+    }
+    TRACS_HIP_CHECK(hipGetLastError());
+    if (tmp) {
+        TRACS_HIP_CHECK(hipStreamSynchronize(stream));
+        TRACS_HIP_CHECK(hipFree(tmp));
+    }
+    return TRACS_OK;
+}
+
+// tile-shape choice.  NW=8 waves, R rows/wave, C cols/lane -> tile (8R) x (64C).
+#ifndef TRACS_TILE_R
+#define TRACS_TILE_R 8
+#endif
+#ifndef TRACS_TILE_C
+#define TRACS_TILE_C 2
+#endif
+#ifndef TRACS_TILE_GC
+#define TRACS_TILE_GC 4
+#endif
+static constexpr int kNW = 8, kR = TRACS_TILE_R, kC = TRACS_TILE_C, kGC = TRACS_TILE_GC;
+static constexpr int kTI = kNW * kR, kTJ = 64 * kC;
+
+int tracs_pairsnp_dense(const tracs_alignment *a_, size_t row_begin, size_t row_end, size_t col_begin, uint32_t *dist,
+                        uint32_t *ncomp, size_t ld, void *stream_)
+{
+    tracs_alignment *a = const_cast<tracs_alignment *>(a_);
+    if (!a || !dist) { set_error("tracs_pairsnp_dense: NULL argument"); return TRACS_E_ARG; }
+    if (row_end > a->n) row_end = a->n;
+    if (row_begin >= row_end || a->n < 2) return TRACS_OK;
+    if (ld < a->n) { set_error("tracs_pairsnp_dense: ld < n"); return TRACS_E_ARG; }
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+
+    if (a->L == 0) {   // every pair: d = 0, nn = 0
+        dim3 grid(64, (unsigned)(row_end - row_begin));
+        hipLaunchKernelGGL(init_cells_kernel, grid, dim3(256), 0, stream, dist, ncomp, ld, (unsigned)a->n,
+                           (unsigned)row_begin, (unsigned)row_end, (unsigned)col_begin, 0u);
+        TRACS_HIP_CHECK(hipGetLastError());
+        return TRACS_OK;
+    }
+
+    // (re)build the cached tile schedule
+    if (a->key_rb != row_begin || a->key_re != row_end || a->key_cb != col_begin || a->key_ti != kTI || a->key_tj != kTJ) {
+        std::vector<int2> tiles;
+        build_tiles(a->n, row_begin, row_end, col_begin, kTI, kTJ, tiles);
+        if (tiles.size() > a->tiles_cap) {
+            if (a->d_tiles) TRACS_HIP_CHECK(hipFree(a->d_tiles));
+            a->d_tiles = nullptr;
+            a->tiles_cap = tiles.size() * 2 + 64;
+            TRACS_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&a->d_tiles), a->tiles_cap * sizeof(int2)));
+        }
+        if (!tiles.empty()) {
+            TRACS_HIP_CHECK(hipMemcpyAsync(a->d_tiles, tiles.data(), tiles.size() * sizeof(int2), hipMemcpyHostToDevice, stream));
+            TRACS_HIP_CHECK(hipStreamSynchronize(stream));   // `tiles` is a stack vector
+        }
+        a->n_tiles = tiles.size();
+        a->key_rb = row_begin; a->key_re = row_end; a->key_cb = col_begin; a->key_ti = kTI; a->key_tj = kTJ;
+    }
+    if (a->n_tiles == 0) return TRACS_OK;
+
+    // split the group range when there are too few tiles to fill 256 CUs (x2 workgroups each)
+    const int groups = (int)a->groups;
+    int ksplit = 1;
+    const size_t target_wg = 1024;
+    if (a->n_tiles < target_wg) {
+        ksplit = (int)std::min<size_t>((target_wg + a->n_tiles - 1) / a->n_tiles, (size_t)std::max(1, groups / (4 * kGC)));
+        if (ksplit < 1) ksplit = 1;
+    }
+    int gps = (groups + ksplit - 1) / ksplit;
+    gps = (gps + kGC - 1) / kGC * kGC;             // stage aligned
+    ksplit = (groups + gps - 1) / gps;
+
+    if (ksplit > 1) {
+        dim3 grid(64, (unsigned)(row_end - row_begin));
+        hipLaunchKernelGGL(init_cells_kernel, grid, dim3(256), 0, stream, dist, ncomp, ld, (unsigned)a->n,
+                           (unsigned)row_begin, (unsigned)row_end, (unsigned)col_begin, (unsigned)a->L);
+    }
+    const unsigned nwg = (unsigned)(a->n_tiles * (size_t)ksplit);
+    if (ncomp)
+        hipLaunchKernelGGL((pairsnp_tile_kernel<kNW, kR, kC, kGC, true>), dim3(nwg), dim3(kNW * 64), 0, stream, a->planes,
+                           a->n_pad, groups, a->d_tiles, (int)a->n_tiles, gps, ksplit, (unsigned)a->L, (unsigned)a->n,
+                           (unsigned)row_end, (unsigned)col_begin, dist, ncomp, ld);
+    else
+        hipLaunchKernelGGL((pairsnp_tile_kernel<kNW, kR, kC, kGC, false>), dim3(nwg), dim3(kNW * 64), 0, stream, a->planes,
+                           a->n_pad, groups, a->d_tiles, (int)a->n_tiles, gps, ksplit, (unsigned)a->L, (unsigned)a->n,
+                           (unsigned)row_end, (unsigned)col_begin, dist, ncomp, ld);
+    TRACS_HIP_CHECK(hipGetLastError());
+    return TRACS_OK;
+}
+
+int tracs_coo_count(const uint32_t *dist, size_t ld, size_t n, size_t row_begin, size_t row_end, size_t col_begin,
+                    int32_t thr, int64_t *offsets, void *stream_)
+{
+    if (!dist || !offsets) { set_error("tracs_coo_count: NULL argument"); return TRACS_E_ARG; }
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (row_end > n) row_end = n;
+    const size_t nrows = row_end > row_begin ? row_end - row_begin : 0;
+    if (nrows)
+        hipLaunchKernelGGL(coo_count_kernel, dim3((unsigned)nrows), dim3(64), 0, stream, dist, ld, (unsigned)n,
+                           (unsigned)row_begin, (unsigned)row_end, (unsigned)col_begin, (int)thr,
+                           reinterpret_cast<long long *>(offsets));
+    hipLaunchKernelGGL(scan_rows_kernel, dim3(1), dim3(1024), 0, stream, reinterpret_cast<long long *>(offsets), nrows);
+    TRACS_HIP_CHECK(hipGetLastError());
+    return TRACS_OK;
+}
+
+int tracs_coo_fill(const uint32_t *dist, const uint32_t *ncomp, size_t ld, size_t n, size_t row_begin, size_t row_end,
+                   size_t col_begin, int32_t thr, const int64_t *offsets, uint32_t *rows, uint32_t *cols, uint32_t *d,
+                   uint32_t *nn, void *stream_)
+{
+    if (!dist || !offsets || !rows || !cols || !d) { set_error("tracs_coo_fill: NULL argument"); return TRACS_E_ARG; }
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (row_end > n) row_end = n;
+    const size_t nrows = row_end > row_begin ? row_end - row_begin : 0;
+    if (!nrows) return TRACS_OK;
+    hipLaunchKernelGGL(coo_fill_kernel, dim3((unsigned)nrows), dim3(64), 0, stream, dist, ncomp, ld, (unsigned)n,
+                       (unsigned)row_begin, (unsigned)row_end, (unsigned)col_begin, (int)thr,
+                       reinterpret_cast<const long long *>(offsets), rows, cols, d, nn);
+    TRACS_HIP_CHECK(hipGetLastError());
+    return TRACS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,420 @@
+// transcluster.hip -- transmission-distance kernels (f64) for gfx950.
+//
+// Reference behaviour restated (never copied): /root/reference/src/transcluster.hpp
+//   logaddexpd :62-75, lprob_k_given_N :90-129, lprob_k_given_N_2 :131-170,
+//   upper_bound_E :173-188, expected_k :191-238, trans_dist :240-287
+// and tracs/transcluster.py:5,26-39 (date difference in years, exp(p0)).
+//
+// Structure (DESIGN.md "transcluster kernels"):
+//   1. dedup: the per-pair answer is a pure function of the key (N, delta), which the reference
+//      memoises in two hash maps (:245-246).  Here a device open-addressing table assigns every
+//      element the slot of its key (atomicCAS claims a slot for the first element of a key).
+//   2. key kernel: one thread per distinct key evaluates p0 and E(K).  The reference's O(N+k)
+//      inner sums per k are replaced by running sums (exact algebra, see tc_eval) so a key costs
+//      O(N + k_stop) logaddexp instead of O(k_stop * (N + k_stop)); the stopping test uses the
+//      same quantities in the same order, so the truncation point k_stop is the reference's.
+//   3. gather: each element copies the result of its slot.
+#include "common.h"
+
+#include <cmath>
+#include <vector>
+
+namespace tracs {
+
+constexpr int LG_TABLE = 32768;     // lgamma(n) table, n < LG_TABLE; beyond: lgamma() inline
+
+struct TcParams {
+    double lamb, beta, thr;
+    double ln_lamb, ln_beta, ln_lb;   // log(lamb), log(beta), log(lamb+beta): filled on the device
+};
+
+__device__ __forceinline__ double lae(double x, double y)   // logaddexpd, transcluster.hpp:62-75
+{
+    const double tmp = x - y;
+    if (x == y) return x + 0.693147180559945309417232121458176568;
+    if (tmp > 0) return x + log1p(exp(-tmp));
+    else if (tmp <= 0) return y + log1p(exp(tmp));
+    return tmp;
+}
+
+__device__ __forceinline__ double lg_at(const double *__restrict__ lg, long long n)
+{
+    return n < LG_TABLE ? lg[n] : lgamma((double)n);
+}
+
+// i * log(x) as the shipped -ffast-math build evaluates it: the i == 0 term is 0 even when
+// log(x) = -inf (delta == 0) -- SURVEY.md 8c; pinned by tests/golden (delta = 0 rows).
+__device__ __forceinline__ double imul(long long i, double l) { return i == 0 ? 0.0 : (double)i * l; }
+
+// p0 = lprob_k_given_N_2(N, 0, delta)[0]  (trans_dist :276-282)
+// eK = expected_k(N, delta, ...)          (:191-238)
+//
+// For delta > 0 the reference evaluates, for every k,
+//   lhs_k      = (N+1)ln(lamb) + k ln(beta) + lgG(N+k+1) - lgG(N+1) - lgG(k+1) - delta*beta - pois      (:140-149)
+//   integral_k = ln sum_{i=0}^{N+k} delta^(N+k-i)/(N+k-i)! (lamb+beta)^-(i+1)                            (:152-158)
+// with pois = ln sum_{i<=N} (lamb*delta)^i / i!  independent of k.  Substituting j = N+k-i,
+//   integral_k = -(N+k+1) ln(lamb+beta) + ln S_{N+k},   S_M = sum_{j<=M} (delta(lamb+beta))^j / j!
+// so S is a running sum in k.  All terms are positive: no cancellation is introduced.
+__device__ void tc_eval(int N, double delta, const TcParams &P, const double *__restrict__ lg, double &p0, double &eK,
+                        int &k_stop)
+{
+    const double n1 = (double)(N + 1);
+    const double lg_n1 = lg_at(lg, (long long)N + 1);
+    double lprob = -INFINITY, elprob = -INFINITY;
+    int k = 1;
+    if (delta > 0) {
+        const double lx = log(P.lamb * delta);
+        double pois = -INFINITY;                                       // :144-148, same fold order
+        for (long long i = 0; i <= N; i++) pois = lae(imul(i, lx) - lg_at(lg, i + 1), pois);
+        const double upper = exp(P.ln_beta + delta * P.lamb + log(n1) - (P.ln_lamb + pois));   // :185
+        const double ld = log(delta);
+        double lnS = -INFINITY;
+        for (long long j = 0; j <= N; j++) lnS = lae(lnS, imul(j, ld) + (double)j * P.ln_lb - lg_at(lg, j + 1));
+        {
+            double l0 = (n1 * P.ln_lamb + 0.0 * P.ln_beta + lg_n1);
+            l0 = l0 - lg_n1 - lg_at(lg, 1) - delta * P.beta;
+            l0 -= pois;
+            p0 = l0 + (lnS - n1 * P.ln_lb);
+        }
+        double diff = P.thr + 1;
+        while ((diff > P.thr) && (k < 10000)) {                        // :207
+            const long long M = (long long)N + k;
+            lnS = lae(lnS, imul(M, ld) + (double)M * P.ln_lb - lg_at(lg, M + 1));
+            double lhs = (n1 * P.ln_lamb + (double)k * P.ln_beta + lg_at(lg, M + 1));   // :140
+            lhs = lhs - lg_n1 - lg_at(lg, (long long)k + 1) - delta * P.beta;            // :141
+            lhs -= pois;                                                                // :149
+            const double m1 = (double)(M + 1) * P.ln_lb;
+            const double lk = log((double)k);
+            lprob = lae(lprob, (lhs + (lnS - m1)) + lk);                                // :227
+            elprob = lae(elprob, lhs + lk + delta * (P.lamb + P.beta) - m1);            // :231
+            diff = upper - exp(elprob);                                                 // :232
+            k++;
+        }
+    } else {
+        // closed form (:163-167); upper bound with pois = 0 (fast-math build, see imul)
+        const double upper = exp(P.ln_beta + log(n1) - P.ln_lamb);
+        p0 = (n1 * P.ln_lamb + 0.0 * P.ln_beta + lg_n1 - lg_n1 - lg_at(lg, 1) - n1 * P.ln_lb);
+        double diff = P.thr + 1;
+        while ((diff > P.thr) && (k < 10000)) {
+            const long long M = (long long)N + k;
+            const double m1 = (double)(M + 1) * P.ln_lb;
+            const double lhs = (n1 * P.ln_lamb + (double)k * P.ln_beta + lg_at(lg, M + 1) - lg_n1 -
+                                lg_at(lg, (long long)k + 1) - m1);
+            const double lk = log((double)k);
+            lprob = lae(lprob, lhs + lk);
+            elprob = lae(elprob, lhs + lk + delta * (P.lamb + P.beta) - m1);
+            diff = upper - exp(elprob);
+            k++;
+        }
+    }
+    eK = exp(lprob);                                                   // :237
+    k_stop = k;
+}
+
+__global__ void lgamma_table_kernel(double *__restrict__ lg, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) lg[i] = lgamma((double)i);   // lg[0] = +inf like std::lgamma(0.0) (:255-257)
+}
+
+// ---- key sources ------------------------------------------------------------------------
+struct ArraySource {            // trans_dist(snpdiff[], datediff[])
+    const int *N;
+    const double *delta;
+    size_t n;
+    __device__ size_t size() const { return n; }
+    __device__ bool get(size_t e, int &Nv, double &dv) const { Nv = N[e]; dv = delta[e]; return true; }
+    __device__ size_t out_index(size_t e) const { return e; }
+};
+
+struct DenseSource {            // cells of a dense distance block, delta from sampling days
+    const unsigned *dist;
+    const int *days;
+    size_t ld, n, row_begin, row_end, col_begin;
+    int thr;
+    __device__ size_t size() const { return (row_end - row_begin) * n; }
+    __device__ bool get(size_t e, int &Nv, double &dv) const
+    {
+        const size_t i = row_begin + e / n, j = e % n;
+        if (j <= i || j < col_begin) return false;
+        const unsigned d = dist[i * ld + j];
+        if ((long long)d > (long long)thr) return false;
+        Nv = (int)d;
+        // tracs/transcluster.py:26-33: |t_i - t_j| / 31556952.0 with t = whole days in seconds (exact in f64)
+        const long long dd = (long long)days[i] - (long long)days[j];
+        dv = (double)((dd < 0 ? -dd : dd) * 86400ll) / 31556952.0;
+        return true;
+    }
+    __device__ size_t out_index(size_t e) const { return (row_begin + e / n) * ld + e % n; }
+};
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x)
+{
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+    return x;
+}
+
+constexpr unsigned EMPTY = 0xFFFFFFFFu;
+
+// slots[h] = element index of the key's first claimant.  eslot[e] = slot of e's key.
+template <class Src>
+__global__ void dedup_insert_kernel(Src src, unsigned *__restrict__ slots, unsigned cap_mask,
+                                    unsigned *__restrict__ eslot)
+{
+    const size_t total = src.size();
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        int N; double d;
+        if (!src.get(e, N, d)) { eslot[e] = EMPTY; continue; }
+        unsigned h = (unsigned)mix64((unsigned long long)__double_as_longlong(d) ^ ((unsigned long long)(unsigned)N * 0x9E3779B97F4A7C15ull)) & cap_mask;
+        for (;;) {
+            unsigned cur = slots[h];
+            if (cur == EMPTY) {
+                cur = atomicCAS(&slots[h], EMPTY, (unsigned)e);
+                if (cur == EMPTY) { eslot[e] = h; break; }
+            }
+            int N2; double d2;
+            src.get((size_t)cur, N2, d2);
+            if (N2 == N && __double_as_longlong(d2) == __double_as_longlong(d)) { eslot[e] = h; break; }
+            h = (h + 1u) & cap_mask;
+        }
+    }
+}
+
+__global__ void dedup_count_kernel(const unsigned *__restrict__ slots, unsigned cap, unsigned *__restrict__ n_keys)
+{
+    unsigned c = 0;
+    for (unsigned h = blockIdx.x * blockDim.x + threadIdx.x; h < cap; h += gridDim.x * blockDim.x) c += slots[h] != EMPTY;
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(n_keys, c);
+}
+
+// compact the claimed slots into a dense list of keys
+__global__ void dedup_collect_kernel(const unsigned *__restrict__ slots, unsigned cap, unsigned *__restrict__ slot_id,
+                                     unsigned *__restrict__ key_elem, unsigned *__restrict__ n_keys)
+{
+    for (unsigned h = blockIdx.x * blockDim.x + threadIdx.x; h < cap; h += gridDim.x * blockDim.x) {
+        const unsigned e = slots[h];
+        if (e != EMPTY) {
+            const unsigned id = atomicAdd(n_keys, 1u);
+            slot_id[h] = id;
+            key_elem[id] = e;
+        }
+    }
+}
+
+template <class Src>
+__global__ void tc_keys_kernel(Src src, const unsigned *__restrict__ key_elem, unsigned nk, TcParams P,
+                               const double *__restrict__ lg, double *__restrict__ key_p0, double *__restrict__ key_eK)
+{
+    P.ln_lamb = log(P.lamb); P.ln_beta = log(P.beta); P.ln_lb = log(P.lamb + P.beta);
+    for (unsigned id = blockIdx.x * blockDim.x + threadIdx.x; id < nk; id += gridDim.x * blockDim.x) {
+        int N; double d;
+        src.get((size_t)key_elem[id], N, d);
+        double p0, eK; int ks;
+        tc_eval(N, d, P, lg, p0, eK, ks);
+        key_p0[id] = p0;
+        key_eK[id] = eK;
+    }
+}
+
+template <class Src>
+__global__ void tc_gather_kernel(Src src, const unsigned *__restrict__ eslot, const unsigned *__restrict__ slot_id,
+                                 const double *__restrict__ key_p0, const double *__restrict__ key_eK, int exp_p0,
+                                 double *__restrict__ p0, double *__restrict__ eK)
+{
+    const size_t total = src.size();
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const unsigned h = eslot[e];
+        if (h == EMPTY) continue;
+        const unsigned id = slot_id[h];
+        const size_t o = src.out_index(e);
+        const double v = key_p0[id];
+        p0[o] = exp_p0 ? exp(v) : v;
+        eK[o] = key_eK[id];
+    }
+}
+
+// lprob_k_given_N (older formulation, exported for tests/test_llk.py): transcluster.hpp:90-129
+__global__ void lprob_k_given_N_kernel(const unsigned long long *__restrict__ Ns, const unsigned long long *__restrict__ ks,
+                                       const double *__restrict__ deltas, size_t n, double lamb, double beta,
+                                       const double *__restrict__ lg, double *__restrict__ out_lprob,
+                                       double *__restrict__ out_lhs)
+{
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const long long N = (long long)Ns[e], k = (long long)ks[e];
+    const double delta = deltas[e];
+    double lprob, lhs;
+    if (delta > 0) {
+        lprob = ((double)(N + 1) * log(lamb) - delta * (lamb + beta) + (double)k * log(beta) - lg[k + 1]);
+        double pois = -INFINITY;
+        const double lx = log(lamb * delta);
+        for (long long i = 0; i <= N; i++) pois = lae(imul(i, lx) - lg[i + 1], pois);
+        pois -= lamb * delta;
+        lprob -= pois;
+        double integral = -INFINITY;
+        const double ld = log(delta), llb = log(lamb + beta);
+        for (long long i = 0; i <= N + k; i++)
+            integral = lae(lg[N + k + 1] - lg[i + 1] - lg[N + k - i + 1] + imul(N + k - i, ld) + lg[i + 1] -
+                               (double)(i + 1) * llb,
+                           integral);
+        integral -= lg[N + 1];
+        lhs = lprob;
+        lprob += integral;
+    } else {
+        lprob = ((double)(N + 1) * log(lamb) + (double)k * log(beta) + lg[N + k + 1] - lg[N + 1] - lg[k + 1] -
+                 (double)(N + k + 1) * log(lamb + beta));
+        lhs = lprob;
+    }
+    out_lprob[e] = lprob;
+    out_lhs[e] = lhs;
+}
+
+// process-wide lgamma table (built once per device)
+static double *g_lg[64] = {nullptr};
+
+static int get_lgamma_table(hipStream_t stream, const double **out)
+{
+    int dev = 0;
+    TRACS_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) { set_error("device index out of range"); return TRACS_E_HIP; }
+    if (!g_lg[dev]) {
+        double *p = nullptr;
+        TRACS_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p), LG_TABLE * sizeof(double)));
+        hipLaunchKernelGGL(lgamma_table_kernel, dim3((LG_TABLE + 255) / 256), dim3(256), 0, stream, p, LG_TABLE);
+        TRACS_HIP_CHECK(hipGetLastError());
+        TRACS_HIP_CHECK(hipStreamSynchronize(stream));
+        g_lg[dev] = p;
+    }
+    *out = g_lg[dev];
+    return TRACS_OK;
+}
+
+struct TcWorkspaceIds { enum { SLOTS = 0, ESLOT, SLOT_ID, NKEYS, KEY_ELEM, KEY_P0, KEY_EK }; };
+
+template <class Src>
+static int run_trans_dist(const Src &src, size_t total, double lamb, double beta, double thr, int exp_p0, double *p0,
+                          double *eK, hipStream_t stream)
+{
+    if (total == 0) return TRACS_OK;
+    if (total >= 0xFFFFFFF0ull) { set_error("trans_dist: more than 2^32 elements per call"); return TRACS_E_ARG; }
+    const double *lg = nullptr;
+    int rc = get_lgamma_table(stream, &lg);
+    if (rc) return rc;
+    unsigned cap = 1024;
+    while ((size_t)cap < 2 * total && cap < (1u << 31)) cap <<= 1;
+    unsigned *slots, *eslot, *slot_id, *n_keys, *key_elem;
+    double *key_p0, *key_eK;
+    if ((rc = workspace_get(TcWorkspaceIds::SLOTS, (size_t)cap * 4, reinterpret_cast<void **>(&slots)))) return rc;
+    if ((rc = workspace_get(TcWorkspaceIds::ESLOT, total * 4, reinterpret_cast<void **>(&eslot)))) return rc;
+    if ((rc = workspace_get(TcWorkspaceIds::SLOT_ID, (size_t)cap * 4, reinterpret_cast<void **>(&slot_id)))) return rc;
+    if ((rc = workspace_get(TcWorkspaceIds::NKEYS, 64, reinterpret_cast<void **>(&n_keys)))) return rc;
+    TRACS_HIP_CHECK(hipMemsetAsync(slots, 0xFF, (size_t)cap * 4, stream));
+    TRACS_HIP_CHECK(hipMemsetAsync(n_keys, 0, 4, stream));
+    const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL((dedup_insert_kernel<Src>), dim3(blocks), dim3(256), 0, stream, src, slots, cap - 1, eslot);
+    TRACS_HIP_CHECK(hipGetLastError());
+    // first pass over the table only counts the claimed slots so the key arrays can be sized
+    // exactly (one 4-byte readback per call), the second assigns ids.
+    hipLaunchKernelGGL(dedup_count_kernel, dim3((unsigned)std::min<size_t>((cap + 255) / 256, 256 * 32)), dim3(256), 0, stream,
+                       slots, cap, n_keys);
+    unsigned nk = 0;
+    TRACS_HIP_CHECK(hipMemcpyAsync(&nk, n_keys, 4, hipMemcpyDeviceToHost, stream));
+    TRACS_HIP_CHECK(hipStreamSynchronize(stream));
+    if (nk == 0) return TRACS_OK;
+    if ((rc = workspace_get(TcWorkspaceIds::KEY_ELEM, (size_t)nk * 4, reinterpret_cast<void **>(&key_elem)))) return rc;
+    if ((rc = workspace_get(TcWorkspaceIds::KEY_P0, (size_t)nk * 8, reinterpret_cast<void **>(&key_p0)))) return rc;
+    if ((rc = workspace_get(TcWorkspaceIds::KEY_EK, (size_t)nk * 8, reinterpret_cast<void **>(&key_eK)))) return rc;
+    TRACS_HIP_CHECK(hipMemsetAsync(n_keys, 0, 4, stream));
+    hipLaunchKernelGGL(dedup_collect_kernel, dim3((unsigned)std::min<size_t>((cap + 255) / 256, 256 * 32)), dim3(256), 0, stream,
+                       slots, cap, slot_id, key_elem, n_keys);
+    TcParams P;
+    P.lamb = lamb; P.beta = beta; P.thr = thr;
+    P.ln_lamb = P.ln_beta = P.ln_lb = 0.0;
+    // one wave per block: keys differ widely in trip count, small blocks keep the SIMDs busy
+    hipLaunchKernelGGL((tc_keys_kernel<Src>), dim3((nk + 63) / 64), dim3(64), 0, stream, src, key_elem, nk, P, lg, key_p0, key_eK);
+    hipLaunchKernelGGL((tc_gather_kernel<Src>), dim3(blocks), dim3(256), 0, stream, src, eslot, slot_id, key_p0, key_eK,
+                       exp_p0, p0, eK);
+    TRACS_HIP_CHECK(hipGetLastError());
+    return TRACS_OK;
+}
+
+}  // namespace tracs
+
+using namespace tracs;
+
+extern "C" {
+
+int tracs_trans_dist_device(const int32_t *snpdiff, const double *datediff, size_t n, double lamb, double beta,
+                            double threshold_Ek, int exp_p0, double *p0, double *eK, void *stream)
+{
+    if (n && (!snpdiff || !datediff || !p0 || !eK)) { set_error("tracs_trans_dist_device: NULL argument"); return TRACS_E_ARG; }
+    ArraySource src{snpdiff, datediff, n};
+    return run_trans_dist(src, n, lamb, beta, threshold_Ek, exp_p0, p0, eK, static_cast<hipStream_t>(stream));
+}
+
+int tracs_trans_dist_dense(const uint32_t *dist, size_t ld, size_t n, size_t row_begin, size_t row_end, size_t col_begin,
+                           int32_t dist_threshold, const int32_t *days, double lamb, double beta, double threshold_Ek,
+                           int exp_p0, double *p0, double *eK, void *stream)
+{
+    if (!dist || !days || !p0 || !eK) { set_error("tracs_trans_dist_dense: NULL argument"); return TRACS_E_ARG; }
+    if (row_end > n) row_end = n;
+    if (row_begin >= row_end) return TRACS_OK;
+    DenseSource src{dist, days, ld, n, row_begin, row_end, col_begin, dist_threshold};
+    return run_trans_dist(src, (row_end - row_begin) * n, lamb, beta, threshold_Ek, exp_p0, p0, eK,
+                          static_cast<hipStream_t>(stream));
+}
+
+int tracs_trans_dist(const int32_t *snpdiff, const double *datediff, size_t n, double lamb, double beta,
+                     double threshold_Ek, double *p0_log, double *eK)
+{
+    if (n == 0) return TRACS_OK;
+    if (!snpdiff || !datediff || !p0_log || !eK) { set_error("tracs_trans_dist: NULL argument"); return TRACS_E_ARG; }
+    int *dN = nullptr; double *dD = nullptr, *dP = nullptr, *dE = nullptr;
+    auto cleanup = [&]() { if (dN) (void)hipFree(dN); if (dD) (void)hipFree(dD); if (dP) (void)hipFree(dP); if (dE) (void)hipFree(dE); };
+#define TD_CHECK(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { cleanup(); set_error(std::string(#x ": ") + hipGetErrorString(e__)); return TRACS_E_HIP; } } while (0)
+    TD_CHECK(hipMalloc(reinterpret_cast<void **>(&dN), n * 4));
+    TD_CHECK(hipMalloc(reinterpret_cast<void **>(&dD), n * 8));
+    TD_CHECK(hipMalloc(reinterpret_cast<void **>(&dP), n * 8));
+    TD_CHECK(hipMalloc(reinterpret_cast<void **>(&dE), n * 8));
+    TD_CHECK(hipMemcpy(dN, snpdiff, n * 4, hipMemcpyHostToDevice));
+    TD_CHECK(hipMemcpy(dD, datediff, n * 8, hipMemcpyHostToDevice));
+    int rc = tracs_trans_dist_device(dN, dD, n, lamb, beta, threshold_Ek, 0, dP, dE, nullptr);
+    if (rc) { cleanup(); return rc; }
+    TD_CHECK(hipMemcpy(p0_log, dP, n * 8, hipMemcpyDeviceToHost));
+    TD_CHECK(hipMemcpy(eK, dE, n * 8, hipMemcpyDeviceToHost));
+#undef TD_CHECK
+    cleanup();
+    return TRACS_OK;
+}
+
+int tracs_lprob_k_given_N(const uint64_t *N, const uint64_t *k, const double *delta, size_t n, double lamb, double beta,
+                          const double *lgamma_tab, size_t lgamma_len, double *lprob, double *lhs)
+{
+    if (n == 0) return TRACS_OK;
+    if (!N || !k || !delta || !lgamma_tab || !lprob || !lhs) { set_error("tracs_lprob_k_given_N: NULL argument"); return TRACS_E_ARG; }
+    for (size_t i = 0; i < n; i++)
+        if (N[i] + k[i] + 1 >= lgamma_len) { set_error("tracs_lprob_k_given_N: lgamma table shorter than N+k+2"); return TRACS_E_ARG; }
+    unsigned long long *dN = nullptr, *dK = nullptr; double *dD = nullptr, *dL = nullptr, *dO = nullptr, *dH = nullptr;
+    auto cleanup = [&]() { void *p[] = {dN, dK, dD, dL, dO, dH}; for (void *q : p) if (q) (void)hipFree(q); };
+#define LP_CHECK(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { cleanup(); set_error(std::string(#x ": ") + hipGetErrorString(e__)); return TRACS_E_HIP; } } while (0)
+    LP_CHECK(hipMalloc(reinterpret_cast<void **>(&dN), n * 8));
+    LP_CHECK(hipMalloc(reinterpret_cast<void **>(&dK), n * 8));
+    LP_CHECK(hipMalloc(reinterpret_cast<void **>(&dD), n * 8));
+    LP_CHECK(hipMalloc(reinterpret_cast<void **>(&dL), lgamma_len * 8));
+    LP_CHECK(hipMalloc(reinterpret_cast<void **>(&dO), n * 8));
+    LP_CHECK(hipMalloc(reinterpret_cast<void **>(&dH), n * 8));
+    LP_CHECK(hipMemcpy(dN, N, n * 8, hipMemcpyHostToDevice));
+    LP_CHECK(hipMemcpy(dK, k, n * 8, hipMemcpyHostToDevice));
+    LP_CHECK(hipMemcpy(dD, delta, n * 8, hipMemcpyHostToDevice));
+    LP_CHECK(hipMemcpy(dL, lgamma_tab, lgamma_len * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(lprob_k_given_N_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, nullptr, dN, dK, dD, n, lamb, beta, dL, dO, dH);
+    LP_CHECK(hipGetLastError());
+    LP_CHECK(hipMemcpy(lprob, dO, n * 8, hipMemcpyDeviceToHost));
+    LP_CHECK(hipMemcpy(lhs, dH, n * 8, hipMemcpyDeviceToHost));
+#undef LP_CHECK
+    cleanup();
+    return TRACS_OK;
+}
+
+}  // extern "C"

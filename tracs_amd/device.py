@@ -1,0 +1,151 @@
+"""Device-resident entry points (include/tracs_hip.h part 2) over torch tensors.
+
+torch is used for device memory, streams and torch.distributed only -- plumbing; every kernel is
+in libtracs_hip.so.  Import torch BEFORE this module's first call so that both share one HIP
+runtime (torch ships its own libamdhip64.so with the same soname).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class Alignment:
+    """A packed alignment resident in HBM (tracs_alignment)."""
+
+    def __init__(self, n, L):
+        self._L = _lib.require_gpu()
+        self._h = C.c_void_p()
+        _lib.check(self._L.tracs_alignment_create(int(n), int(L), C.byref(self._h)))
+        self.n, self.L = int(n), int(L)
+
+    @classmethod
+    def from_fasta(cls, paths):
+        import os
+        L = _lib.require_gpu()
+        arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
+        h, names, nb, n0 = C.c_void_p(), C.c_void_p(), C.c_size_t(0), C.c_size_t(0)
+        _lib.check(L.tracs_alignment_from_fasta(arr, len(paths), C.byref(h), C.byref(names), C.byref(nb), C.byref(n0)))
+        self = cls.__new__(cls)
+        self._L, self._h = L, h
+        self.n, self.L = L.tracs_alignment_n(h), L.tracs_alignment_len(h)
+        raw = C.string_at(names, nb.value) if nb.value else b""
+        L.tracs_free(names)
+        self.names = [x.decode("utf-8", "replace") for x in raw.split(b"\0")[:self.n]]
+        self.n_first = n0.value
+        return self
+
+    def pack(self, ascii_u8, first=0):
+        """ascii_u8: torch.uint8 [count, L] on the GPU, or a numpy uint8 array on the host."""
+        if isinstance(ascii_u8, torch.Tensor):
+            assert ascii_u8.dtype == torch.uint8 and ascii_u8.is_contiguous() and ascii_u8.shape[1] == self.L
+            on_dev = 1 if ascii_u8.is_cuda else 0
+            ptr, count = C.c_void_p(ascii_u8.data_ptr()), ascii_u8.shape[0]
+        else:
+            a = np.ascontiguousarray(ascii_u8, dtype=np.uint8)
+            assert a.ndim == 2 and a.shape[1] == self.L
+            on_dev, ptr, count = 0, C.c_void_p(a.ctypes.data), a.shape[0]
+        _lib.check(self._L.tracs_alignment_pack(self._h, ptr, int(first), int(count), on_dev, _stream()))
+
+    @property
+    def nbytes(self):
+        return self._L.tracs_alignment_bytes(self._h)
+
+    def planes_ptr(self):
+        return self._L.tracs_alignment_planes(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.tracs_alignment_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def pairsnp_dense(aln, dist, ncomp=None, row_begin=0, row_end=None, col_begin=0):
+    """dist/ncomp: torch.int32 (bit pattern uint32) [>=n, ld] device matrices, written for the cells
+    rows [row_begin,row_end) x cols [max(col_begin,i+1), n)."""
+    row_end = aln.n if row_end is None else row_end
+    ld = dist.stride(0)
+    _lib.check(aln._L.tracs_pairsnp_dense(aln._h, int(row_begin), int(row_end), int(col_begin), _ptr(dist), _ptr(ncomp),
+                                          int(ld), _stream()))
+
+
+def coo_from_dense(dist, ncomp, n, dist_threshold=2147483647, row_begin=0, row_end=None, col_begin=0):
+    """-> rows, cols, d, nn (torch.int32 on device), row-major like the reference's output."""
+    L = _lib.require_gpu()
+    row_end = n if row_end is None else row_end
+    nrows = max(0, row_end - row_begin)
+    off = torch.zeros(nrows + 1, dtype=torch.int64, device=dist.device)
+    ld = dist.stride(0)
+    _lib.check(L.tracs_coo_count(_ptr(dist), ld, n, row_begin, row_end, col_begin, int(dist_threshold), _ptr(off), _stream()))
+    total = int(off[nrows].item())
+    out = [torch.empty(total, dtype=torch.int32, device=dist.device) for _ in range(4)]
+    if total:
+        _lib.check(L.tracs_coo_fill(_ptr(dist), _ptr(ncomp), ld, n, row_begin, row_end, col_begin, int(dist_threshold),
+                                    _ptr(off), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(out[3]), _stream()))
+    return out
+
+
+def trans_dist_device(snpdiff, datediff, lamb, beta, threshold_Ek, exp_p0=False):
+    L = _lib.require_gpu()
+    n = snpdiff.numel()
+    p0 = torch.empty(n, dtype=torch.float64, device=snpdiff.device)
+    eK = torch.empty(n, dtype=torch.float64, device=snpdiff.device)
+    _lib.check(L.tracs_trans_dist_device(_ptr(snpdiff), _ptr(datediff), n, float(lamb), float(beta), float(threshold_Ek),
+                                         int(exp_p0), _ptr(p0), _ptr(eK), _stream()))
+    return p0, eK
+
+
+def trans_dist_dense(dist, n, days, lamb, beta, threshold_Ek, p0, eK, exp_p0=True, dist_threshold=2147483647,
+                     row_begin=0, row_end=None, col_begin=0):
+    L = _lib.require_gpu()
+    row_end = n if row_end is None else row_end
+    ld = dist.stride(0)
+    assert p0.stride(0) == ld and eK.stride(0) == ld
+    _lib.check(L.tracs_trans_dist_dense(_ptr(dist), ld, n, row_begin, row_end, col_begin, int(dist_threshold), _ptr(days),
+                                        float(lamb), float(beta), float(threshold_Ek), int(exp_p0), _ptr(p0), _ptr(eK),
+                                        _stream()))
+
+
+def calculate_posteriors_device(counts, alphas, keep, threshold):
+    L = _lib.require_gpu()
+    a = np.ascontiguousarray(alphas, dtype=np.float64)
+    out = torch.empty_like(counts)
+    _lib.check(L.tracs_calculate_posteriors_device(_ptr(counts), counts.shape[0], counts.shape[1],
+                                                   a.ctypes.data_as(C.POINTER(C.c_double)), int(bool(keep)),
+                                                   float(threshold), _ptr(out), _stream()))
+    return out
+
+
+def posterior_codes_device(counts_u16, alphas, keep, threshold):
+    """counts_u16: torch.int16/uint16 [L,4] -> torch.uint8 [(L+1)//2] packed allele masks."""
+    L = _lib.require_gpu()
+    a = np.ascontiguousarray(alphas, dtype=np.float64)
+    n = counts_u16.shape[0]
+    out = torch.empty((n + 1) // 2, dtype=torch.uint8, device=counts_u16.device)
+    _lib.check(L.tracs_posterior_codes_device(_ptr(counts_u16), n, a.ctypes.data_as(C.POINTER(C.c_double)),
+                                              int(bool(keep)), float(threshold), _ptr(out), _stream()))
+    return out
+
+
+def connected_components_device(I, J, n_nodes):
+    L = _lib.require_gpu()
+    labels = torch.empty(n_nodes, dtype=torch.int32, device=I.device)
+    nc = C.c_int32(0)
+    _lib.check(L.tracs_connected_components_device(_ptr(I), _ptr(J), I.numel(), n_nodes, _ptr(labels), C.byref(nc), _stream()))
+    return int(nc.value), labels

@@ -1,0 +1,110 @@
+"""`tracs distance` -- pairwise SNP + transmission distances, GPU path.
+
+Command line, CSV schema and row filtering follow /root/reference/tracs/distance.py:
+flags :15-131, dates CSV :145-151, per-MSA pairsnp :159-176, transmission block :179-204,
+CSV rows :206-258 (header :157).  The pair loop and the transcluster integral run on the MI355X.
+"""
+import argparse
+import logging
+import os
+from datetime import date
+
+from .api import pairsnp
+from .transcluster import calculate_trans_prob
+from .utils import check_positive_float, check_positive_int
+
+HEADER = ("sampleA,sampleB,date difference,SNP distance,transmission distance,expected K,"
+          "filtered SNP distance,sites considered,MSA file\n")
+
+
+def distance_parser(parser):
+    parser.description = ("Estimates pairwise SNP and transmission distances between each pair of samples "
+                          "aligned to the same reference genome.")
+    io = parser.add_argument_group("Input/output")
+    io.add_argument("--msa", dest="msa_files", required=True, type=os.path.abspath, nargs="+",
+                    help="Input fasta files formatted by the align and merge functions")
+    io.add_argument("--msa-db", dest="msa_db", type=os.path.abspath, default=None,
+                    help="A database MSA used to compare each sequence to. By default all pairwise comparisons "
+                         "within each MSA are considered.")
+    io.add_argument("--meta", dest="metadata", default=None, type=os.path.abspath,
+                    help="Location of metadata in csv format. The first column must include the sequence names "
+                         "and the second column must include sampling dates.")
+    io.add_argument("-o", "--output", dest="output_file", required=True, type=str,
+                    help="name of the output file to store the pairwise distance estimates.")
+    snp = parser.add_argument_group("SNP distance options")
+    snp.add_argument("-D", "--snp_threshold", dest="snp_threshold", type=check_positive_int, default=2147483647,
+                     help="Only output those transmission pairs with a SNP distance <= D")
+    snp.add_argument("--filter", dest="recomb_filter", action="store_true", default=False,
+                     help="Filter out regions with unusually high SNP distances often caused by HGT")
+    tr = parser.add_argument_group("Transmission distance options")
+    tr.add_argument("--clock_rate", dest="clock_rate", type=check_positive_float, default=1e-3 * 29903,
+                    help="clock rate as defined in the transcluster paper (SNPs/genome/year) default=1e-3 * 29903")
+    tr.add_argument("--trans_rate", dest="trans_rate", type=check_positive_float, default=73.0,
+                    help="transmission rate as defined in the transcluster paper (transmissions/year) default=73")
+    tr.add_argument("-K", "--trans_threshold", dest="trans_threshold", type=check_positive_int, default=None,
+                    help="Only outputs those pairs where the most likely number of intermediate hosts <= K")
+    tr.add_argument("--precision", dest="precision", type=check_positive_float, default=0.01,
+                    help="The precision used to calculate E(K) (default=0.01).")
+    parser.add_argument("-t", "--threads", dest="n_cpu", type=check_positive_int, default=1,
+                        help="number of threads to use (default=1; the pair loop runs on the GPU)")
+    parser.add_argument("--loglevel", type=str.upper, default="INFO",
+                        choices=["DEBUG", "INFO", "WARNING", "ERROR", "CRITICAL"], help="Set the logging threshold.")
+    parser.set_defaults(func=distance)
+    return parser
+
+
+def _read_dates(path):
+    dates = {}
+    with open(path, "r") as fh:
+        next(fh)                                   # header line is skipped (:148)
+        for line in fh:
+            f = line.strip().split(",")
+            dates[f[0]] = (f[1], date.fromisoformat(f[1]))
+    return dates
+
+
+def distance(args):
+    logging.basicConfig(level=args.loglevel, format="%(asctime)s - %(levelname)s - %(message)s",
+                        datefmt="%Y-%m-%d %H:%M:%S")
+    logging.info("Loading metadata...")
+    dates = _read_dates(args.metadata) if args.metadata is not None else None
+    logging.info("Estimating transmission distances...")
+    with open(args.output_file, "w") as out:
+        out.write(HEADER)
+        for msa in args.msa_files:
+            logging.info("Calculating pairwise snp distances for %s", msa)
+            msas = [msa, args.msa_db] if args.msa_db is not None else [msa]
+            rows, cols, snpd, names, filt, ncomp = pairsnp(fasta=msas, n_threads=args.n_cpu, dist=args.snp_threshold,
+                                                           filter=args.recomb_filter)
+            with_dates = dates is not None and len(rows) > 0
+            if with_dates:
+                logging.info("Inferring transmission probabilities for %s", msa)
+                # with --filter the transmission model is driven by the FILTERED distance (:183-193)
+                drive = filt if args.recomb_filter else snpd
+                tdist, ek, ddiff = calculate_trans_prob([rows, cols, drive], sample_dates=dates, K=100,
+                                                        lamb=args.clock_rate, beta=args.trans_rate, samplenames=names,
+                                                        log=False, precision=args.precision)
+                if not args.recomb_filter:
+                    filt = ["NA"] * len(snpd)                                   # (:204)
+            logging.info("Saving distances for %s", msa)
+            ref = os.path.basename(msa).split(".")[0].replace("_combined", "")  # (:208-209)
+            if with_dates:
+                kmax = args.trans_threshold
+                for t in range(len(rows)):
+                    if kmax is None or kmax >= ek[t]:
+                        out.write(",".join([names[rows[t]], names[cols[t]], str(ddiff[t]), str(int(snpd[t])),
+                                            str(tdist[t]), str(ek[t]), str(filt[t]), str(ncomp[t]), ref]) + "\n")
+            else:
+                for t in range(len(rows)):
+                    out.write(",".join([names[rows[t]], names[cols[t]], "NA", str(int(snpd[t])), "NA", "NA",
+                                        str(filt[t]), str(ncomp[t]), ref]) + "\n")
+
+
+def main():
+    parser = distance_parser(argparse.ArgumentParser())
+    args = parser.parse_args()
+    args.func(args)
+
+
+if __name__ == "__main__":
+    main()

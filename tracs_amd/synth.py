@@ -1,0 +1,141 @@
+"""Seeded synthetic alignments, dates and count tables.
+
+The mutation model follows the idea of the reference's simulator (scripts/tracs-sim.py:10-46:
+substitute a different base at chosen positions); the code is ours.  A two-level star phylogeny
+gives outbreak-like SNP distances: lineage founders differ from the ancestor at Bernoulli(mu_lineage)
+sites, samples from their founder at Bernoulli(mu_sample) sites; Bernoulli(p_n) sites become 'N'.
+"""
+import numpy as np
+
+_BASES = np.frombuffer(b"ACGT", dtype=np.uint8)
+_IUPAC_PARTIAL = np.frombuffer(b"MRWSYKVHDB", dtype=np.uint8)
+_OTHER = np.frombuffer(b"N-?Xn.*", dtype=np.uint8)
+
+
+def _mutate(idx, rng, mu):
+    """idx: int8[..., L] base indices 0..3 -> copy with a different base at Bernoulli(mu) sites."""
+    out = idx.copy()
+    L = idx.shape[-1]
+    k = rng.binomial(L, mu) if mu > 0 else 0
+    if k:
+        pos = rng.choice(L, size=k, replace=False)
+        out[pos] = (out[pos] + rng.integers(1, 4, size=k)) & 3
+    return out
+
+
+def alignment(n, L, seed, mu_lineage=1e-4, mu_sample=1e-5, n_lineages=None, p_n=0.01, p_partial=0.0,
+              p_lower=0.0, p_other=0.0):
+    """-> uint8[n, L] ASCII.  p_partial: IUPAC two/three-base codes; p_lower: lower-case letters;
+    p_other: '-', '?', 'X', '.', '*' and friends (all of which the reference treats as N)."""
+    rng = np.random.default_rng(seed)
+    anc = rng.integers(0, 4, size=L, dtype=np.int8)
+    n_lineages = max(1, n // 16) if n_lineages is None else n_lineages
+    founders = [_mutate(anc, rng, mu_lineage) for _ in range(n_lineages)]
+    out = np.empty((n, L), dtype=np.uint8)
+    for s in range(n):
+        idx = _mutate(founders[s % n_lineages], rng, mu_sample)
+        row = _BASES[idx]
+        if p_n > 0:
+            row[rng.random(L) < p_n] = ord("N")
+        if p_partial > 0:
+            m = rng.random(L) < p_partial
+            row[m] = _IUPAC_PARTIAL[rng.integers(0, len(_IUPAC_PARTIAL), size=int(m.sum()))]
+        if p_other > 0:
+            m = rng.random(L) < p_other
+            row[m] = _OTHER[rng.integers(0, len(_OTHER), size=int(m.sum()))]
+        if p_lower > 0:
+            m = (rng.random(L) < p_lower) & (row >= 65) & (row <= 90)
+            row[m] = row[m] + 32
+        out[s] = row
+    return out
+
+
+def write_fasta(path, seqs, names=None, width=0, gz=False):
+    """width = 0: one line per record; else wrapped."""
+    import gzip
+    names = names or ["s%d" % i for i in range(seqs.shape[0])]
+    op = gzip.open if gz else open
+    with op(path, "wb") as fh:
+        for nm, row in zip(names, seqs):
+            fh.write(b">" + nm.encode() + b"\n")
+            b = row.tobytes()
+            if width:
+                for o in range(0, len(b), width):
+                    fh.write(b[o:o + width] + b"\n")
+            else:
+                fh.write(b + b"\n")
+    return names
+
+
+def dates(n, seed, span_days=730, start="2020-01-01"):
+    """-> (iso strings, integer days since 1970-01-01), uniform in [start, start+span_days)."""
+    from datetime import date, timedelta
+    rng = np.random.default_rng(seed)
+    d0 = date.fromisoformat(start)
+    off = rng.integers(0, span_days, size=n)
+    ds = [d0 + timedelta(days=int(o)) for o in off]
+    epoch = date(1970, 1, 1)
+    return [d.isoformat() for d in ds], np.array([(d - epoch).days for d in ds], dtype=np.int32)
+
+
+def allele_counts(L, seed, depth=30, eps=0.01, p_two=0.01):
+    """-> uint16[L, 4] pileup counts: Multinomial(Poisson(depth), (1-eps, eps/3, ...)) on a random
+    major allele, with a fraction p_two of two-allele sites at 0.7/0.3."""
+    rng = np.random.default_rng(seed)
+    major = rng.integers(0, 4, size=L)
+    dep = rng.poisson(depth, size=L)
+    p = np.full((L, 4), eps / 3)
+    p[np.arange(L), major] = 1 - eps
+    two = rng.random(L) < p_two
+    minor = (major + rng.integers(1, 4, size=L)) & 3
+    p[two] = eps / 2
+    p[two, major[two]] = 0.7 * (1 - eps)
+    p[two, minor[two]] = 0.3 * (1 - eps)
+    p /= p.sum(1, keepdims=True)
+    # multinomial per row via sequential binomials (vectorised)
+    out = np.zeros((L, 4), dtype=np.int64)
+    rem = dep.copy()
+    prem = np.ones(L)
+    for k in range(3):
+        q = np.clip(p[:, k] / prem, 0, 1)
+        out[:, k] = rng.binomial(rem, q)
+        rem -= out[:, k]
+        prem -= p[:, k]
+    out[:, 3] = rem
+    return out.astype(np.uint16)
+
+
+# ---- on-device generation for the benchmark (torch) -------------------------------------
+def pack_synthetic_device(aln, seed, mu_lineage=1e-5, mu_sample=1e-6, n_lineages=None, p_n=0.01, batch=32):
+    """Fill a tracs_amd.device.Alignment with the same two-level model, generated on the GPU in
+    batches of `batch` samples (the ASCII never exists on the host).  Setup code, untimed."""
+    import torch
+    n, L = aln.n, aln.L
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = torch.Generator(device=dev)
+    g.manual_seed(int(seed))
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    anc = torch.randint(0, 4, (L,), generator=g, device=dev, dtype=torch.int8)
+    n_lineages = max(1, n // 16) if n_lineages is None else n_lineages
+
+    def mutate(base, mu):
+        k = int(torch.poisson(torch.tensor(float(L * mu)), generator=None).item()) if mu > 0 else 0
+        out = base.clone()
+        if k:
+            pos = torch.randint(0, L, (k,), generator=g, device=dev)
+            out[pos] = (out[pos] + torch.randint(1, 4, (k,), generator=g, device=dev, dtype=torch.int8)) & 3
+        return out
+    torch.manual_seed(int(seed))
+    founders = [mutate(anc, mu_lineage) for _ in range(n_lineages)]
+    for s0 in range(0, n, batch):
+        cnt = min(batch, n - s0)
+        rows = torch.empty((cnt, L), dtype=torch.uint8, device=dev)
+        for b in range(cnt):
+            idx = mutate(founders[(s0 + b) % n_lineages], mu_sample)
+            rows[b] = lut[idx.long()]
+        if p_n > 0:
+            for b in range(cnt):
+                m = torch.rand(L, generator=g, device=dev) < p_n
+                rows[b][m] = ord("N")
+        aln.pack(rows, first=s0)
+    torch.cuda.synchronize()
