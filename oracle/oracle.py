@@ -51,6 +51,9 @@ def lib():
         L.orc_lprob_k_given_N_2.argtypes = [C.c_size_t, C.c_size_t, C.c_double, C.c_double, C.c_double, dp]
         L.orc_expected_k.restype = C.c_double
         L.orc_expected_k.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_int)]
+        L.orc_expected_k_trace.restype = C.c_int
+        L.orc_expected_k_trace.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
+                                           dp, dp, dp]
         L.orc_trans_dist.restype = None
         L.orc_trans_dist.argtypes = [C.POINTER(C.c_int), dp, C.c_size_t, C.c_double, C.c_double, C.c_double, dp, dp]
         L.orc_calculate_posteriors.restype = None
@@ -211,6 +214,32 @@ def expected_k(N, delta, lamb, beta, thr):
     ks = C.c_int(0)
     v = lib().orc_expected_k(int(N), delta, lamb, beta, thr, C.byref(ks))
     return float(v), ks.value
+
+
+def expected_k_trace(N, delta, lamb, beta, thr, extra=8):
+    """-> dict(k_stop, upper, partial[k], diffs[k]) -- see orc_expected_k_trace."""
+    cap = 10000 + extra + 2
+    partial = np.full(cap, np.nan)
+    diffs = np.full(cap, np.nan)
+    up = C.c_double(0)
+    ks = lib().orc_expected_k_trace(int(N), float(delta), lamb, beta, thr, extra, cap, _dp(partial), _dp(diffs),
+                                    C.byref(up))
+    return dict(k_stop=ks, upper=up.value, partial=partial, diffs=diffs)
+
+
+def ek_conditioning(N, delta, lamb, beta, thr):
+    """Classify the reference's stopping rule for one key:
+    'saturated' (ran to k = 10000), 'well' (the threshold crossing is far above the rounding noise of
+    exp(elprob), which is ~upper * 1e-13 after the accumulation) or 'ill' (decided by rounding)."""
+    t = expected_k_trace(N, delta, lamb, beta, thr, extra=0)
+    ks = t["k_stop"]
+    if ks >= 10000:
+        return "saturated", t
+    noise = abs(t["upper"]) * 1e-12
+    last_above = t["diffs"][ks - 2] if ks >= 3 else np.inf      # diff after the last-but-one iteration
+    at_stop = t["diffs"][ks - 1]
+    margin = min(abs(last_above - thr), abs(at_stop - thr))
+    return ("well" if margin > 100 * noise else "ill"), t
 
 
 def trans_dist(snpdiff, datediff, lamb, beta, threshold_Ek):

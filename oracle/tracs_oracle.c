@@ -399,6 +399,42 @@ double orc_expected_k(int N, double delta, double lamb, double beta, double thre
     return r;
 }
 
+/* Trace of the same loop for the tests: partial[k] = exp(lprob) after the iteration with index k
+ * (k = 1..), diffs[k] = diff_bound after it, for `extra` iterations PAST the reference's stopping
+ * point.  Where the bound `upper` is huge (few SNPs over a long time gap) the reference's loop ends
+ * when exp(elprob) meets `upper` to the last bit, i.e. the truncation point is decided by rounding
+ * noise (it moves with libm / FMA contraction); tests use the trace to accept a truncation within a
+ * few k of the oracle's there (DESIGN.md "E(K) truncation").  Returns k_stop (the value of k when the
+ * reference's while-loop exits).                                                                    */
+int orc_expected_k_trace(int N, double delta, double lamb, double beta, double threshold_Ek, int extra,
+                         int cap, double *partial, double *diffs, double *upper_out)
+{
+    size_t n_tab = 10000;
+    double *lg = (double *)malloc(n_tab * sizeof(double));
+    for (size_t i = 0; i < n_tab; i++) lg[i] = lgamma((double)i);
+    double lprob = -INFINITY, elprob = -INFINITY;
+    double upper_bound = upper_bound_E(lg, n_tab, delta, lamb, beta, (size_t)N);
+    double diff_bound = threshold_Ek + 1;
+    int k = 1, k_stop = -1;
+    while (k < cap) {
+        if (k_stop < 0 && !((diff_bound > threshold_Ek) && (k < 10000))) k_stop = k;
+        if (k_stop >= 0 && k >= k_stop + extra) break;
+        double r[2];
+        lprob_k_given_N_2((size_t)N, (size_t)k, delta, lamb, beta, lg, n_tab, r);
+        lprob = logaddexpd(lprob, r[0] + log((double)k));
+        elprob = logaddexpd(elprob, r[1] + log((double)k) + delta * (lamb + beta) -
+                                        (double)(N + k + 1) * log(lamb + beta));
+        diff_bound = upper_bound - exp(elprob);
+        partial[k] = exp(lprob);
+        diffs[k] = diff_bound;
+        k++;
+    }
+    if (k_stop < 0) k_stop = k;
+    if (upper_out) *upper_out = upper_bound;
+    free(lg);
+    return k_stop;
+}
+
 /* src/transcluster.hpp:240-287.  Returns p0 (log) and eK per pair.  The two hash
  * caches (:245-246) are replaced by a sort-free linear memo over distinct keys:
  * same values, since every cached entry is a pure function of its key.        */

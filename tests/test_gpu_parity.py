@@ -2,9 +2,12 @@
 inputs.  Bit-exact for integer work; 1e-6 relative (BASELINE.json north_star) for floating point,
 with far tighter observed agreement asserted where the arithmetic is the same."""
 import os
+import sys
 
 import numpy as np
 import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -88,19 +91,20 @@ def test_pairsnp_list_api_and_errors(api, tmp_path):
 
 
 def test_trans_dist_matches_oracle(api, oracle):
+    from ek_parity import check_trans_dist
     rng = np.random.default_rng(11)
+    total = {}
     for lamb, beta in ((1e-3 * 29903, 73.0), (5.3, 6.0), (3.0, 52.0)):
-        N = rng.integers(0, 80, 4000).astype(np.int32)
-        days = rng.integers(0, 500, 4000)
-        days[:200] = 0                                    # delta == 0 branch
+        N = rng.integers(0, 80, 1500).astype(np.int32)
+        days = rng.integers(0, 500, 1500)
+        days[:100] = 0                                    # delta == 0 branch
         delta = days.astype(np.float64) * 86400.0 / 31556952.0
         p0, ek = api.trans_dist_arrays(N, delta, lamb, beta, 0.01)
-        ep0, eek = oracle.trans_dist(N, delta, lamb, beta, 0.01)
-        assert np.allclose(p0, ep0, rtol=RTOL, atol=0)
-        assert np.allclose(ek, eek, rtol=RTOL, atol=0)
-        # observed agreement is ~1e-12: guard against silent degradation
-        assert np.max(np.abs(p0 - ep0) / np.abs(ep0)) < 1e-9
-        assert np.max(np.abs(ek - eek) / np.abs(eek)) < 1e-9
+        counts = check_trans_dist(oracle, N, delta, lamb, beta, 0.01, p0, ek)
+        for k, v in counts.items():
+            total[k] = total.get(k, 0) + v
+    print("E(K) keys by conditioning:", total)
+    assert total.get("well", 0) > 1000 and total.get("saturated", 0) > 10
 
 
 def test_trans_dist_reference_known_answers(api):

@@ -106,36 +106,49 @@ def allele_counts(L, seed, depth=30, eps=0.01, p_two=0.01):
 
 
 # ---- on-device generation for the benchmark (torch) -------------------------------------
-def pack_synthetic_device(aln, seed, mu_lineage=1e-5, mu_sample=1e-6, n_lineages=None, p_n=0.01, batch=32):
-    """Fill a tracs_amd.device.Alignment with the same two-level model, generated on the GPU in
-    batches of `batch` samples (the ASCII never exists on the host).  Setup code, untimed."""
+def generate_device(n, L, seed, emit, mu_lineage=1e-5, mu_sample=1e-6, n_lineages=None, p_n=0.01, batch=32,
+                    limit=None):
+    """The same two-level model generated on the GPU in batches of `batch` samples; every batch
+    (uint8 [cnt, L] ASCII on the device) is handed to emit(rows, first).  Deterministic in `seed`;
+    `limit` stops after the first `limit` samples (same values as a full run).  Setup code, untimed."""
     import torch
-    n, L = aln.n, aln.L
     dev = torch.device("cuda", torch.cuda.current_device())
     g = torch.Generator(device=dev)
     g.manual_seed(int(seed))
+    host_rng = np.random.default_rng(int(seed))
     lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
     anc = torch.randint(0, 4, (L,), generator=g, device=dev, dtype=torch.int8)
     n_lineages = max(1, n // 16) if n_lineages is None else n_lineages
 
     def mutate(base, mu):
-        k = int(torch.poisson(torch.tensor(float(L * mu)), generator=None).item()) if mu > 0 else 0
+        k = int(host_rng.poisson(L * mu)) if mu > 0 else 0
         out = base.clone()
         if k:
             pos = torch.randint(0, L, (k,), generator=g, device=dev)
             out[pos] = (out[pos] + torch.randint(1, 4, (k,), generator=g, device=dev, dtype=torch.int8)) & 3
         return out
-    torch.manual_seed(int(seed))
     founders = [mutate(anc, mu_lineage) for _ in range(n_lineages)]
-    for s0 in range(0, n, batch):
+    stop = n if limit is None else min(n, limit)
+    for s0 in range(0, stop, batch):
         cnt = min(batch, n - s0)
         rows = torch.empty((cnt, L), dtype=torch.uint8, device=dev)
         for b in range(cnt):
             idx = mutate(founders[(s0 + b) % n_lineages], mu_sample)
             rows[b] = lut[idx.long()]
-        if p_n > 0:
-            for b in range(cnt):
+            if p_n > 0:
                 m = torch.rand(L, generator=g, device=dev) < p_n
                 rows[b][m] = ord("N")
-        aln.pack(rows, first=s0)
+        emit(rows, s0)
     torch.cuda.synchronize()
+
+
+def pack_synthetic_device(aln, seed, **kw):
+    """Fill a tracs_amd.device.Alignment from generate_device (the ASCII never exists on the host)."""
+    generate_device(aln.n, aln.L, seed, lambda rows, first: aln.pack(rows, first=first), **kw)
+
+
+def first_samples_host(n, L, seed, m, **kw):
+    """The first m samples of the same synthetic alignment, as a host uint8 [m, L] array."""
+    chunks = []
+    generate_device(n, L, seed, lambda rows, first: chunks.append(rows.cpu().numpy()), limit=m, **kw)
+    return np.concatenate(chunks, axis=0)[:m]
