@@ -147,6 +147,21 @@ def pairsnp_arrays(seqs, n0=None, dist=2147483647, n_threads=1):
     return rows, cols, d, nn
 
 
+def pairsnp_planes(planes, L, n0=None, dist=2147483647, n_threads=1):
+    """The pair loop on already packed planes (uint64 [4, n, W])."""
+    planes = np.ascontiguousarray(planes, dtype=np.uint64)
+    n = planes.shape[1]
+    i_end, j_start = (n, 0) if n0 is None else (n0, n0)
+    # one call: pass 1 (all d) + pass 2 (compared sites of the emitted pairs), as the reference runs them
+    if j_start == 0:
+        cap = n * (n - 1) // 2
+    else:
+        cap = i_end * (n - j_start)
+    out = [np.zeros(cap, np.uint64) for _ in range(4)]
+    cnt = lib().orc_pairsnp(_u64p(planes), n, L, i_end, j_start, int(dist), n_threads, *[_u64p(a) for a in out]) if cap else 0
+    return [a[:cnt] for a in out]
+
+
 def pairsnp(fasta, n_threads, dist, filter):
     """Oracle twin of TRACS.pairsnp (src/pairsnp.hpp:320-457, filter=False only)."""
     if len(fasta) < 1 or len(fasta) > 2:
