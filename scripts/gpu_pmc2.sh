@@ -1,0 +1,25 @@
+#!/bin/bash
+# usage: bash scripts/gpu_pmc2.sh <tag> <samples> <sites> <variant>  -- compact PMC set for one kernel variant
+TAG=$1; NS=$2; NL=$3; V=$4
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+export TRACS_TILE_VARIANT=$V
+cd /tmp
+T="python3 $GRAFT_REPO_ROOT/scripts/prof_target.py $NS $NL 1"
+run() { name=$1; shift; timeout 600 rocprofv3 --kernel-include-regex "pairsnp_" --pmc "$@" --output-format csv -d $OUT/$name -o pmc -- $T > $OUT/$name.log 2>&1; }
+run sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_ACTIVE_INST_VALU
+run sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS
+run l2 GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum
+run fetch FETCH_SIZE
+python3 - <<PY
+import csv,collections
+for d in ['sq1','sq2','l2','fetch']:
+    try:
+        rows=list(csv.DictReader(open('$OUT/'+d+'/pmc_counter_collection.csv')))
+    except Exception as e:
+        print(d,'missing',e); continue
+    agg=collections.defaultdict(list)
+    for r in rows: agg[r['Counter_Name']].append(float(r['Counter_Value']))
+    print(d, {k:"%.4g"%(sum(v)/len(v)) for k,v in agg.items()})
+PY

@@ -28,7 +28,7 @@ void set_error(const std::string &msg);
 // contiguous 1..4 KiB run: coalesced for the LDS stage and for the scalar row loads.
 constexpr int NPLANES = 5;
 constexpr int SITES_PER_GROUP = 128;
-constexpr int SAMPLE_PAD = 256;      // n_pad is a multiple of every tile edge
+constexpr int SAMPLE_PAD = 2048;     // n_pad is a multiple of every tile edge (widest: rowcast 2048 columns)
 
 static inline size_t groups_for(size_t L) { return (L + SITES_PER_GROUP - 1) / SITES_PER_GROUP; }
 static inline size_t pad_samples(size_t n) { return (n + SAMPLE_PAD - 1) / SAMPLE_PAD * SAMPLE_PAD; }

@@ -16,6 +16,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace tracs {
@@ -98,39 +99,53 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nwg)
     return base + k;
 }
 
-// (s & v) | m in ONE VALU op.  Left to itself hipcc re-associates the four-plane OR into
+// (x & v) | m in ONE VALU op.  Left to itself hipcc re-associates the four-plane OR into
 // and, and_or, and, and, or3 (6 ops with the popcount); the asm pins and + 3 x and_or (5 ops).
-// `s` is a wave-uniform row word held in an SGPR (VOP3 on gfx9 takes one scalar source).
-__device__ __forceinline__ unsigned and_or(unsigned s, unsigned v, unsigned m)
+// SCALAR: `x` is a wave-uniform row word held in an SGPR (VOP3 on gfx9 takes one scalar source).
+template <bool SCALAR>
+__device__ __forceinline__ unsigned and_or(unsigned x, unsigned v, unsigned m)
 {
     unsigned r;
-    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "s"(s), "v"(v), "v"(m));
+    if (SCALAR) asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "s"(x), "v"(v), "v"(m));
+    else asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(v), "v"(m));
     return r;
 }
 
+template <bool SCALAR>
 __device__ __forceinline__ void pair_words(unsigned ai_a, unsigned ai_c, unsigned ai_g, unsigned ai_t,
                                            unsigned bj_a, unsigned bj_c, unsigned bj_g, unsigned bj_t,
                                            unsigned &acc)
 {
-    unsigned m = ai_a & bj_a;            // v_and_b32
-    m = and_or(ai_c, bj_c, m);           // v_and_or_b32
-    m = and_or(ai_g, bj_g, m);           // v_and_or_b32
-    m = and_or(ai_t, bj_t, m);           // v_and_or_b32
-    acc += __popc(m);                    // v_bcnt_u32_b32 (popcount + accumulate)
+    unsigned m = ai_a & bj_a;                    // v_and_b32
+    m = and_or<SCALAR>(ai_c, bj_c, m);           // v_and_or_b32
+    m = and_or<SCALAR>(ai_g, bj_g, m);           // v_and_or_b32
+    m = and_or<SCALAR>(ai_t, bj_t, m);           // v_and_or_b32
+    acc += __popc(m);                            // v_bcnt_u32_b32 (popcount + accumulate)
 }
 
+// Where a wave's row words come from.
+//   ROW_SMEM    scalar loads (s_load_dwordx8/16) straight from HBM/L2 through the scalar cache -> SGPR operands
+//   ROW_SMEM_PF the same, software-pipelined: the next RB rows are requested before the current RB are consumed
+//   ROW_LDS     rows staged in LDS next to the columns and read back with a wave-uniform (broadcast) ds_read -> VGPRs
+enum { ROW_SMEM = 0, ROW_SMEM_PF = 1, ROW_LDS = 2, ROW_SMEM_PF1 = 6,
+       // timing-only ablations (WRONG RESULTS; never the default): operands frozen outside the group loop
+       ABL_ROWS_FIXED = 3, ABL_COLS_FIXED = 4, ABL_BOTH_FIXED = 5 };
+
 // NW waves per workgroup, R rows per wave, C columns per lane, GC groups per LDS stage.
-template <int NW, int R, int C, int GC, bool WITH_NN>
-__global__ __launch_bounds__(NW * 64) void pairsnp_tile_kernel(
+template <int NW, int R, int C, int GC, bool WITH_NN, int ROWSRC, int MINW = 1>
+__global__ __launch_bounds__(NW * 64, MINW) void pairsnp_tile_kernel(
     const uint4 *__restrict__ P, size_t n_pad, int groups, const int2 *__restrict__ tiles, int n_tiles,
     int groups_per_split, int ksplit, unsigned L, unsigned n, unsigned row_end, unsigned col_begin,
     unsigned *__restrict__ dist, unsigned *__restrict__ ncomp, size_t ld)
 {
     constexpr int NT = NW * 64;
+    constexpr int TI = NW * R;
     constexpr int TJ = 64 * C;
-    constexpr int STAGE = GC * NPLANES * TJ;     // uint4 per LDS stage
-    constexpr int LPT = STAGE / NT;              // staging loads per thread
-    static_assert(STAGE % NT == 0, "stage must divide evenly over the workgroup");
+    constexpr int TS = TJ + (ROWSRC == ROW_LDS ? TI : 0);   // samples staged per (group, plane)
+    constexpr int STAGE = GC * NPLANES * TS;                // uint4 per LDS stage
+    constexpr int LPT = (STAGE + NT - 1) / NT;              // staging loads per thread
+    constexpr bool SC = ROWSRC != ROW_LDS;   // row operands are scalar (SGPR)
+    constexpr int NPL = WITH_NN ? NPLANES : 4;
     __shared__ uint4 lds[2][STAGE];
 
     const unsigned q = xcd_remap(blockIdx.x, gridDim.x);
@@ -154,25 +169,84 @@ __global__ __launch_bounds__(NW * 64) void pairsnp_tile_kernel(
 #pragma unroll
         for (int k = 0; k < LPT; k++) {
             const int e = tid + k * NT;
-            const int gp = e / TJ;               // local group*5 + plane
+            const int gp = e / TS;               // local group*5 + plane
+            const int sidx = e - gp * TS;
             const int g = gs + gp / NPLANES;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (g < g_end) v = P[((size_t)gs * NPLANES + gp) * n_pad + (size_t)j0 + (e % TJ)];
+            if ((STAGE % NT == 0 || e < STAGE) && g < g_end) {
+                const size_t smp = sidx < TJ ? (size_t)j0 + sidx : (size_t)i0 + (sidx - TJ);
+                v = P[((size_t)gs * NPLANES + gp) * n_pad + smp];
+            }
             stage_regs[k] = v;
         }
     };
     auto stage_store = [&](int buf) {
 #pragma unroll
-        for (int k = 0; k < LPT; k++) lds[buf][tid + k * NT] = stage_regs[k];
+        for (int k = 0; k < LPT; k++) {
+            const int e = tid + k * NT;
+            if (STAGE % NT == 0 || e < STAGE) lds[buf][e] = stage_regs[k];
+        }
+    };
+    // one row batch (RB rows, all planes) against the lane's C columns
+    auto consume = [&](const uint4 (*ai)[NPLANES], int r0, int nrows, const uint4 (&bj)[C][NPLANES]) {
+#pragma unroll
+        for (int rr = 0; rr < nrows; rr++) {
+            const int r = r0 + rr;
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                pair_words<SC>(ai[rr][0].x, ai[rr][1].x, ai[rr][2].x, ai[rr][3].x, bj[c][0].x, bj[c][1].x, bj[c][2].x, bj[c][3].x, accM[r][c]);
+                pair_words<SC>(ai[rr][0].y, ai[rr][1].y, ai[rr][2].y, ai[rr][3].y, bj[c][0].y, bj[c][1].y, bj[c][2].y, bj[c][3].y, accM[r][c]);
+                pair_words<SC>(ai[rr][0].z, ai[rr][1].z, ai[rr][2].z, ai[rr][3].z, bj[c][0].z, bj[c][1].z, bj[c][2].z, bj[c][3].z, accM[r][c]);
+                pair_words<SC>(ai[rr][0].w, ai[rr][1].w, ai[rr][2].w, ai[rr][3].w, bj[c][0].w, bj[c][1].w, bj[c][2].w, bj[c][3].w, accM[r][c]);
+            }
+            if (WITH_NN) {
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    accN[r][c] += __popc(ai[rr][4].x | bj[c][4].x);
+                    accN[r][c] += __popc(ai[rr][4].y | bj[c][4].y);
+                    accN[r][c] += __popc(ai[rr][4].z | bj[c][4].z);
+                    accN[r][c] += __popc(ai[rr][4].w | bj[c][4].w);
+                }
+            }
+        }
+    };
+    constexpr bool PF = ROWSRC == ROW_SMEM_PF || ROWSRC == ROW_SMEM_PF1;
+    constexpr int RB = (ROWSRC == ROW_SMEM_PF) ? 2 : ((ROWSRC == ROW_LDS || ROWSRC == ROW_SMEM_PF1) ? 1 : (R >= 4 ? 4 : R));   // rows per batch
+    constexpr int NB = R / RB;
+    static_assert(R % RB == 0, "row batch must divide R");
+    const size_t row0 = (size_t)(i0 + wave * R);
+    auto load_rows_global = [&](int g, int b, uint4 (*dst)[NPLANES]) {   // wave-uniform addresses: scalar loads
+        const uint4 *rowp = P + (size_t)g * NPLANES * n_pad + row0 + (size_t)(b * RB);
+#pragma unroll
+        for (int rr = 0; rr < RB; rr++)
+#pragma unroll
+            for (int p = 0; p < NPL; p++) dst[rr][p] = rowp[(size_t)p * n_pad + rr];
     };
 
     stage_load(g_begin);
     stage_store(0);
     __syncthreads();
 
+    uint4 cur[RB][NPLANES];
+    if (PF && g_begin < g_end) load_rows_global(g_begin, 0, cur);
+    constexpr bool ROWS_FIXED = ROWSRC == ABL_ROWS_FIXED || ROWSRC == ABL_BOTH_FIXED;
+    constexpr bool COLS_FIXED = ROWSRC == ABL_COLS_FIXED || ROWSRC == ABL_BOTH_FIXED;
+    uint4 fixed_rows[NB][RB][NPLANES];
+    uint4 fixed_bj[C][NPLANES];
+    if (ROWS_FIXED) {
+#pragma unroll
+        for (int b = 0; b < NB; b++) load_rows_global(g_begin, b, fixed_rows[b]);
+    }
+    if (COLS_FIXED) {
+#pragma unroll
+        for (int c = 0; c < C; c++)
+#pragma unroll
+            for (int p = 0; p < NPL; p++) fixed_bj[c][p] = lds[0][p * TS + lane + 64 * c];
+    }
+
     int buf = 0;
     for (int gs = g_begin; gs < g_end; gs += GC) {
-        const bool more = gs + GC < g_end;
+        const bool more = !COLS_FIXED && gs + GC < g_end;
         if (more) stage_load(gs + GC);
 #pragma unroll
         for (int gl = 0; gl < GC; gl++) {
@@ -182,39 +256,42 @@ __global__ __launch_bounds__(NW * 64) void pairsnp_tile_kernel(
 #pragma unroll
                 for (int c = 0; c < C; c++)
 #pragma unroll
-                    for (int p = 0; p < NPLANES; p++)
-                        if (WITH_NN || p < 4) bj[c][p] = lds[buf][(gl * NPLANES + p) * TJ + lane + 64 * c];
-                // wave-uniform row words: scalar loads
-                const uint4 *rowp = P + (size_t)g * NPLANES * n_pad + (size_t)(i0 + wave * R);
-#pragma unroll
-                for (int r = 0; r < R; r++) {
-                    const uint4 a = rowp[r];
-                    const uint4 cc = rowp[n_pad + r];
-                    const uint4 gg = rowp[2 * n_pad + r];
-                    const uint4 t = rowp[3 * n_pad + r];
-#pragma unroll
-                    for (int c = 0; c < C; c++) {
-                        pair_words(a.x, cc.x, gg.x, t.x, bj[c][0].x, bj[c][1].x, bj[c][2].x, bj[c][3].x, accM[r][c]);
-                        pair_words(a.y, cc.y, gg.y, t.y, bj[c][0].y, bj[c][1].y, bj[c][2].y, bj[c][3].y, accM[r][c]);
-                        pair_words(a.z, cc.z, gg.z, t.z, bj[c][0].z, bj[c][1].z, bj[c][2].z, bj[c][3].z, accM[r][c]);
-                        pair_words(a.w, cc.w, gg.w, t.w, bj[c][0].w, bj[c][1].w, bj[c][2].w, bj[c][3].w, accM[r][c]);
+                    for (int p = 0; p < NPL; p++) {
+                        if (COLS_FIXED) { bj[c][p] = fixed_bj[c][p]; bj[c][p].x ^= (unsigned)g; }   // keep it group-dependent
+                        else bj[c][p] = lds[buf][(gl * NPLANES + p) * TS + lane + 64 * c];
                     }
-                    if (WITH_NN) {
-                        const uint4 nn = rowp[4 * n_pad + r];
 #pragma unroll
-                        for (int c = 0; c < C; c++) {
-                            accN[r][c] += __popc(nn.x | bj[c][4].x);
-                            accN[r][c] += __popc(nn.y | bj[c][4].y);
-                            accN[r][c] += __popc(nn.z | bj[c][4].z);
-                            accN[r][c] += __popc(nn.w | bj[c][4].w);
-                        }
+                for (int b = 0; b < NB; b++) {
+                    if (ROWS_FIXED) {
+                        consume(fixed_rows[b], b * RB, RB, bj);
+                    } else if (ROWSRC == ROW_SMEM || ROWSRC == ABL_COLS_FIXED) {
+                        load_rows_global(g, b, cur);
+                        consume(cur, b * RB, RB, bj);
+                    } else if (PF) {
+                        uint4 nxt[RB][NPLANES];
+#pragma unroll
+                        for (int rr = 0; rr < RB; rr++)
+#pragma unroll
+                            for (int p = 0; p < NPL; p++) nxt[rr][p] = cur[rr][p];
+                        if (b + 1 < NB) load_rows_global(g, b + 1, nxt);
+                        else if (g + 1 < g_end) load_rows_global(g + 1, 0, nxt);
+                        __builtin_amdgcn_sched_barrier(0);      // keep the next batch's loads ahead of this batch's VALU
+                        consume(cur, b * RB, RB, bj);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int rr = 0; rr < RB; rr++)
+#pragma unroll
+                            for (int p = 0; p < NPL; p++) cur[rr][p] = nxt[rr][p];
+                    } else {
+#pragma unroll
+                        for (int p = 0; p < NPL; p++) cur[0][p] = lds[buf][(gl * NPLANES + p) * TS + TJ + wave * R + b];
+                        consume(cur, b, 1, bj);
                     }
                 }
             }
         }
         if (more) stage_store(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
+        if (!COLS_FIXED) { __syncthreads(); buf ^= 1; }
     }
 
     // epilogue: d = L - matches, nn = L - masked; only cells of the requested set are written
@@ -231,6 +308,114 @@ __global__ __launch_bounds__(NW * 64) void pairsnp_tile_kernel(
                     dist[o] = L - accM[r][c];
                     if (WITH_NN) ncomp[o] = L - accN[r][c];
                 } else {                                  // cells were initialised to L
+                    atomicSub(&dist[o], accM[r][c]);
+                    if (WITH_NN) atomicSub(&ncomp[o], accN[r][c]);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// "rowcast" kernel: no LDS, no barriers.
+//   * all NW waves of a workgroup work on the SAME R rows: the row words are wave-uniform AND shared by
+//     the whole workgroup, so the scalar loads of waves 1..NW-1 hit the scalar cache (the 64 x 128 tile
+//     kernel above gives every wave its own rows and is limited by scalar-cache MISS throughput:
+//     DESIGN.md "what limits the tile kernel");
+//   * every wave owns its own 64*C columns, fetched straight into VGPRs with 16 B/lane coalesced loads,
+//     one group ahead (double buffered in registers);
+//   * accumulators: R x C x 2 VGPRs per lane (R = 32, C = 2 -> 128), 2 waves per SIMD.
+template <int NW, int R, int C, bool WITH_NN>
+__global__ __launch_bounds__(NW * 64) void pairsnp_rowcast_kernel(
+    const uint4 *__restrict__ P, size_t n_pad, int groups, const int2 *__restrict__ tiles, int n_tiles,
+    int groups_per_split, int ksplit, unsigned L, unsigned n, unsigned row_end, unsigned col_begin,
+    unsigned *__restrict__ dist, unsigned *__restrict__ ncomp, size_t ld)
+{
+    constexpr int NPL = WITH_NN ? NPLANES : 4;
+    constexpr int RB = 4;                         // rows per scalar batch: 5 x s_load_dwordx16 = 80 SGPRs
+    static_assert(R % RB == 0, "R must be a multiple of 4");
+    const unsigned q = xcd_remap(blockIdx.x, gridDim.x);
+    const int ks = (int)(q / (unsigned)n_tiles);
+    const int2 tile = tiles[q - (unsigned)ks * (unsigned)n_tiles];
+    const int i0 = tile.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int jw = tile.y + wave * (64 * C);      // first column of this wave
+    // nothing to do if every column of the wave is <= the tile's first row, or outside the matrix
+    if (jw + 64 * C - 1 <= i0 || (unsigned)jw >= n || (unsigned)(jw + 64 * C - 1) < col_begin) return;
+    const int g_begin = ks * groups_per_split;
+    const int g_end = min(groups, g_begin + groups_per_split);
+
+    unsigned accM[R][C], accN[R][C];
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int c = 0; c < C; c++) { accM[r][c] = 0; accN[r][c] = 0; }
+
+    const uint4 *colp = P + (size_t)jw + lane;
+    auto load_cols = [&](int g, uint4 (&bj)[C][NPLANES]) {
+#pragma unroll
+        for (int c = 0; c < C; c++)
+#pragma unroll
+            for (int p = 0; p < NPL; p++) bj[c][p] = colp[((size_t)g * NPLANES + p) * n_pad + 64 * c];
+    };
+    auto do_group = [&](int g, const uint4 (&bj)[C][NPLANES]) {
+        const uint4 *rowp = P + (size_t)g * NPLANES * n_pad + (size_t)i0;       // wave-uniform, workgroup-uniform
+#pragma unroll
+        for (int b = 0; b < R / RB; b++) {
+            uint4 ai[RB][NPLANES];
+#pragma unroll
+            for (int rr = 0; rr < RB; rr++)
+#pragma unroll
+                for (int p = 0; p < NPL; p++) ai[rr][p] = rowp[(size_t)p * n_pad + b * RB + rr];
+#pragma unroll
+            for (int rr = 0; rr < RB; rr++) {
+                const int r = b * RB + rr;
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    pair_words<true>(ai[rr][0].x, ai[rr][1].x, ai[rr][2].x, ai[rr][3].x, bj[c][0].x, bj[c][1].x, bj[c][2].x, bj[c][3].x, accM[r][c]);
+                    pair_words<true>(ai[rr][0].y, ai[rr][1].y, ai[rr][2].y, ai[rr][3].y, bj[c][0].y, bj[c][1].y, bj[c][2].y, bj[c][3].y, accM[r][c]);
+                    pair_words<true>(ai[rr][0].z, ai[rr][1].z, ai[rr][2].z, ai[rr][3].z, bj[c][0].z, bj[c][1].z, bj[c][2].z, bj[c][3].z, accM[r][c]);
+                    pair_words<true>(ai[rr][0].w, ai[rr][1].w, ai[rr][2].w, ai[rr][3].w, bj[c][0].w, bj[c][1].w, bj[c][2].w, bj[c][3].w, accM[r][c]);
+                }
+                if (WITH_NN) {
+#pragma unroll
+                    for (int c = 0; c < C; c++) {
+                        accN[r][c] += __popc(ai[rr][4].x | bj[c][4].x);
+                        accN[r][c] += __popc(ai[rr][4].y | bj[c][4].y);
+                        accN[r][c] += __popc(ai[rr][4].z | bj[c][4].z);
+                        accN[r][c] += __popc(ai[rr][4].w | bj[c][4].w);
+                    }
+                }
+            }
+        }
+    };
+
+    // two groups per iteration so the register double buffer needs no copies
+    uint4 bjA[C][NPLANES], bjB[C][NPLANES];
+    if (g_begin < g_end) load_cols(g_begin, bjA);
+    for (int g = g_begin; g < g_end; g += 2) {
+        if (g + 1 < g_end) load_cols(g + 1, bjB);
+        do_group(g, bjA);
+        if (g + 1 < g_end) {
+            if (g + 2 < g_end) load_cols(g + 2, bjA);
+            do_group(g + 1, bjB);
+        }
+    }
+
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const unsigned i = (unsigned)(i0 + r);
+        if (i >= row_end) continue;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const unsigned j = (unsigned)(jw + lane + 64 * c);
+            if (j < n && j > i && j >= col_begin) {
+                const size_t o = (size_t)i * ld + j;
+                if (ksplit == 1) {
+                    dist[o] = L - accM[r][c];
+                    if (WITH_NN) ncomp[o] = L - accN[r][c];
+                } else {
                     atomicSub(&dist[o], accM[r][c]);
                     if (WITH_NN) atomicSub(&ncomp[o], accN[r][c]);
                 }
@@ -356,6 +541,98 @@ static void build_tiles(size_t n, size_t row_begin, size_t row_end, size_t col_b
 
 using namespace tracs;
 
+// Kernel variants (tile shape x row-operand source).  TRACS_TILE_VARIANT selects one at run time
+// (default: the fastest measured on MI355X, see DESIGN.md "pairsnp kernel: variants measured").
+struct TileVariant {
+    const char *name;
+    int ti, tj, gc, nthreads;
+    void (*launch)(bool with_nn, unsigned nwg, hipStream_t stream, const uint4 *P, size_t n_pad, int groups, const int2 *tiles,
+                   int n_tiles, int gps, int ksplit, unsigned L, unsigned n, unsigned row_end, unsigned col_begin,
+                   unsigned *dist, unsigned *ncomp, size_t ld);
+};
+
+template <int NW, int R, int C, int GC, int ROWSRC, int MINW = 1>
+static void launch_variant(bool with_nn, unsigned nwg, hipStream_t stream, const uint4 *P, size_t n_pad, int groups,
+                           const int2 *tiles, int n_tiles, int gps, int ksplit, unsigned L, unsigned n, unsigned row_end,
+                           unsigned col_begin, unsigned *dist, unsigned *ncomp, size_t ld)
+{
+    if (with_nn)
+        hipLaunchKernelGGL((pairsnp_tile_kernel<NW, R, C, GC, true, ROWSRC, MINW>), dim3(nwg), dim3(NW * 64), 0, stream, P, n_pad, groups,
+                           tiles, n_tiles, gps, ksplit, L, n, row_end, col_begin, dist, ncomp, ld);
+    else
+        hipLaunchKernelGGL((pairsnp_tile_kernel<NW, R, C, GC, false, ROWSRC, MINW>), dim3(nwg), dim3(NW * 64), 0, stream, P, n_pad, groups,
+                           tiles, n_tiles, gps, ksplit, L, n, row_end, col_begin, dist, ncomp, ld);
+}
+
+template <int NW, int R, int C>
+static void launch_rowcast(bool with_nn, unsigned nwg, hipStream_t stream, const uint4 *P, size_t n_pad, int groups,
+                           const int2 *tiles, int n_tiles, int gps, int ksplit, unsigned L, unsigned n, unsigned row_end,
+                           unsigned col_begin, unsigned *dist, unsigned *ncomp, size_t ld)
+{
+    if (with_nn)
+        hipLaunchKernelGGL((pairsnp_rowcast_kernel<NW, R, C, true>), dim3(nwg), dim3(NW * 64), 0, stream, P, n_pad, groups, tiles,
+                           n_tiles, gps, ksplit, L, n, row_end, col_begin, dist, ncomp, ld);
+    else
+        hipLaunchKernelGGL((pairsnp_rowcast_kernel<NW, R, C, false>), dim3(nwg), dim3(NW * 64), 0, stream, P, n_pad, groups, tiles,
+                           n_tiles, gps, ksplit, L, n, row_end, col_begin, dist, ncomp, ld);
+}
+#define TRACS_ROWCAST(NW, R, C) {"rowcast" #NW "x" #R "x" #C, R, (NW) * 64 * (C), 1, (NW) * 64, launch_rowcast<NW, R, C>}
+
+#define TRACS_VARIANT_W(NW, R, C, GC, SRC, MINW) {#NW "x" #R "x" #C "x" #GC ":" #SRC "/w" #MINW, (NW) * (R), 64 * (C), GC, (NW) * 64, launch_variant<NW, R, C, GC, SRC, MINW>}
+#define TRACS_VARIANT(NW, R, C, GC, SRC) {#NW "x" #R "x" #C "x" #GC ":" #SRC, (NW) * (R), 64 * (C), GC, (NW) * 64, launch_variant<NW, R, C, GC, SRC>}
+static const TileVariant kVariants[] = {
+    TRACS_VARIANT(8, 8, 2, 4, ROW_SMEM),      // 0: 64 x 128 tile, rows by scalar loads
+    TRACS_VARIANT(8, 8, 2, 2, ROW_SMEM),      // 1
+    TRACS_VARIANT(8, 8, 2, 4, ROW_SMEM_PF),   // 2: + software-pipelined row loads
+    TRACS_VARIANT(8, 8, 2, 2, ROW_SMEM_PF),   // 3
+    TRACS_VARIANT(8, 8, 2, 2, ROW_LDS),       // 4: rows through LDS
+    TRACS_VARIANT(8, 4, 4, 2, ROW_SMEM_PF),   // 5: 32 x 256 tile
+    TRACS_VARIANT(16, 4, 4, 2, ROW_SMEM_PF),  // 6: 64 x 256 tile, 16 waves
+    TRACS_VARIANT(16, 8, 2, 2, ROW_SMEM_PF),  // 7: 128 x 128 tile, 16 waves
+    TRACS_VARIANT(16, 8, 2, 2, ROW_LDS),      // 8
+    TRACS_VARIANT(8, 4, 4, 2, ROW_LDS),       // 9
+    TRACS_VARIANT(8, 8, 2, 4, ROW_SMEM_PF1),     // 10: one-row batches
+    TRACS_VARIANT(8, 8, 2, 2, ROW_SMEM_PF1),     // 11
+    TRACS_VARIANT(8, 4, 4, 2, ROW_SMEM_PF1),     // 12
+    TRACS_VARIANT(8, 8, 2, 4, ABL_ROWS_FIXED),   // 13 timing-only
+    TRACS_VARIANT(8, 8, 2, 4, ABL_COLS_FIXED),   // 14 timing-only
+    TRACS_VARIANT(8, 8, 2, 4, ABL_BOTH_FIXED),   // 15 timing-only
+    TRACS_ROWCAST(8, 32, 2),                     // 16: 32 rows x 1024 cols per workgroup
+    TRACS_ROWCAST(4, 32, 2),                     // 17: 32 x 512
+    TRACS_ROWCAST(8, 16, 4),                     // 18: 16 x 2048
+    TRACS_ROWCAST(4, 16, 4),                     // 19: 16 x 1024
+    TRACS_ROWCAST(8, 16, 2),                     // 20: 16 x 1024, 64 accumulators
+    TRACS_ROWCAST(16, 32, 2),                    // 21: 32 x 2048 (16 waves -> VGPR cap 128: expect spills)
+    TRACS_VARIANT(8, 8, 4, 2, ROW_LDS),          // 22: 64 x 256 tile, rows through LDS
+    TRACS_VARIANT(8, 8, 4, 1, ROW_LDS),          // 23
+    TRACS_VARIANT(4, 8, 4, 2, ROW_LDS),          // 24: 32 x 256, 4 waves
+    TRACS_VARIANT(8, 4, 8, 1, ROW_LDS),          // 25: 32 x 512
+    TRACS_VARIANT(8, 16, 2, 2, ROW_LDS),         // 26: 128 x 128
+    TRACS_VARIANT(4, 16, 4, 1, ROW_LDS),         // 27: 64 x 256, 4 waves, 128 accumulators
+    TRACS_VARIANT_W(8, 8, 2, 2, ROW_LDS, 4),     // 28: 64 x 128, <=128 VGPRs so two workgroups share a CU
+    TRACS_VARIANT_W(8, 8, 2, 1, ROW_LDS, 4),     // 29
+    TRACS_VARIANT_W(4, 8, 2, 2, ROW_LDS, 4),     // 30: 32 x 128, four workgroups per CU
+    TRACS_VARIANT_W(4, 16, 2, 2, ROW_LDS, 3),    // 31: 64 x 128 with 4 waves
+    TRACS_VARIANT_W(8, 8, 2, 4, ROW_SMEM, 4),    // 32
+};
+static constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
+#ifndef TRACS_DEFAULT_VARIANT
+#define TRACS_DEFAULT_VARIANT 31
+#endif
+
+static const TileVariant &current_variant()
+{
+    static int chosen = -1;
+    if (chosen < 0) {
+        chosen = TRACS_DEFAULT_VARIANT;
+        if (const char *e = std::getenv("TRACS_TILE_VARIANT")) {
+            const int v = std::atoi(e);
+            if (v >= 0 && v < kNumVariants) chosen = v;
+        }
+    }
+    return kVariants[chosen];
+}
+
 extern "C" {
 
 int tracs_debug_iupac_mask(int ch) { return (int)iupac_mask((unsigned)ch & 0xFFu); }
@@ -372,7 +649,7 @@ int tracs_alignment_create(size_t n, size_t L, tracs_alignment **out)
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&a->planes), bytes);
         if (e != hipSuccess) { set_error(std::string("hipMalloc(planes): ") + hipGetErrorString(e)); delete a; return TRACS_E_NOMEM; }
         e = hipMemset(a->planes, 0, bytes);
-        if (e != hipSuccess) { set_error(std::string("hipMemset(planes): ") + hipGetErrorString(e)); hipFree(a->planes); delete a; return TRACS_E_HIP; }
+        if (e != hipSuccess) { set_error(std::string("hipMemset(planes): ") + hipGetErrorString(e)); (void)hipFree(a->planes); delete a; return TRACS_E_HIP; }
     }
     *out = a;
     return TRACS_OK;
@@ -430,18 +707,7 @@ int tracs_alignment_pack(tracs_alignment *a, const uint8_t *ascii, size_t first,
     return TRACS_OK;
 }
 
-// tile-shape choice.  NW=8 waves, R rows/wave, C cols/lane -> tile (8R) x (64C).
-#ifndef TRACS_TILE_R
-#define TRACS_TILE_R 8
-#endif
-#ifndef TRACS_TILE_C
-#define TRACS_TILE_C 2
-#endif
-#ifndef TRACS_TILE_GC
-#define TRACS_TILE_GC 4
-#endif
-static constexpr int kNW = 8, kR = TRACS_TILE_R, kC = TRACS_TILE_C, kGC = TRACS_TILE_GC;
-static constexpr int kTI = kNW * kR, kTJ = 64 * kC;
+const char *tracs_debug_tile_variant(void) { return current_variant().name; }
 
 int tracs_pairsnp_dense(const tracs_alignment *a_, size_t row_begin, size_t row_end, size_t col_begin, uint32_t *dist,
                         uint32_t *ncomp, size_t ld, void *stream_)
@@ -462,6 +728,8 @@ int tracs_pairsnp_dense(const tracs_alignment *a_, size_t row_begin, size_t row_
     }
 
     // (re)build the cached tile schedule
+    const TileVariant &V = current_variant();
+    const int kTI = V.ti, kTJ = V.tj, kGC = V.gc;
     if (a->key_rb != row_begin || a->key_re != row_end || a->key_cb != col_begin || a->key_ti != kTI || a->key_tj != kTJ) {
         std::vector<int2> tiles;
         build_tiles(a->n, row_begin, row_end, col_begin, kTI, kTJ, tiles);
@@ -498,14 +766,8 @@ int tracs_pairsnp_dense(const tracs_alignment *a_, size_t row_begin, size_t row_
                            (unsigned)row_begin, (unsigned)row_end, (unsigned)col_begin, (unsigned)a->L);
     }
     const unsigned nwg = (unsigned)(a->n_tiles * (size_t)ksplit);
-    if (ncomp)
-        hipLaunchKernelGGL((pairsnp_tile_kernel<kNW, kR, kC, kGC, true>), dim3(nwg), dim3(kNW * 64), 0, stream, a->planes,
-                           a->n_pad, groups, a->d_tiles, (int)a->n_tiles, gps, ksplit, (unsigned)a->L, (unsigned)a->n,
-                           (unsigned)row_end, (unsigned)col_begin, dist, ncomp, ld);
-    else
-        hipLaunchKernelGGL((pairsnp_tile_kernel<kNW, kR, kC, kGC, false>), dim3(nwg), dim3(kNW * 64), 0, stream, a->planes,
-                           a->n_pad, groups, a->d_tiles, (int)a->n_tiles, gps, ksplit, (unsigned)a->L, (unsigned)a->n,
-                           (unsigned)row_end, (unsigned)col_begin, dist, ncomp, ld);
+    V.launch(ncomp != nullptr, nwg, stream, a->planes, a->n_pad, groups, a->d_tiles, (int)a->n_tiles, gps, ksplit, (unsigned)a->L,
+             (unsigned)a->n, (unsigned)row_end, (unsigned)col_begin, dist, ncomp, ld);
     TRACS_HIP_CHECK(hipGetLastError());
     return TRACS_OK;
 }
