@@ -44,20 +44,12 @@ def parse():
     return ap.parse_args()
 
 
-def row_chunks(n, world, align=64):
-    """2*world equal row chunks; rank r owns chunk r and chunk 2*world-1-r (work ~ N - i per row)."""
-    nchunk = 2 * world
-    cs = (n + nchunk - 1) // nchunk
-    cs = (cs + align - 1) // align * align
-    return cs, nchunk
-
-
 def main():
     args = parse()
     import torch
     import torch.distributed as dist
     from tracs_amd import device as dev
-    from tracs_amd import synth
+    from tracs_amd import partition, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -79,18 +71,9 @@ def main():
     days = torch.from_numpy(days_np).to(device)
     setup_s = time.time() - t0
 
-    cs, nchunk = row_chunks(n, world)
+    cs, nchunk = partition.row_chunks(n, world)
     rows_pad = cs * nchunk
-    mine = [rank, nchunk - 1 - rank]
-    # row ranges of this rank (the two chunks are adjacent -- one launch -- when world == 1)
-    ranges = []
-    for c in sorted(mine):
-        r0, r1 = c * cs, min(n, (c + 1) * cs)
-        if r0 < r1:
-            if ranges and ranges[-1][1] == r0:
-                ranges[-1] = (ranges[-1][0], r1)
-            else:
-                ranges.append((r0, r1))
+    ranges = partition.rank_ranges(n, rank, world)        # this rank's row panels (one launch each)
     dmat = torch.zeros((rows_pad, n), dtype=torch.int32, device=device)
     nmat = torch.zeros((rows_pad, n), dtype=torch.int32, device=device)
     pmat = torch.zeros((rows_pad, n), dtype=torch.float64, device=device)
@@ -108,14 +91,7 @@ def main():
         for r0, r1 in ranges:
             dev.trans_dist_dense(dmat, n, days, args.lamb, args.beta, args.precision, pmat, emat, exp_p0=True,
                                  row_begin=r0, row_end=r1)
-        if world > 1:
-            for m in (dmat, nmat, pmat, emat):
-                for half in (0, 1):
-                    # chunk index contributed by rank q in this half
-                    outs = [m[(q if half == 0 else nchunk - 1 - q) * cs:(q if half == 0 else nchunk - 1 - q) * cs + cs]
-                            for q in range(world)]
-                    c = mine[half]
-                    dist.all_gather(outs, m[c * cs:(c + 1) * cs])
+        partition.gather_panels((dmat, nmat, pmat, emat), n, rank, world, dist)
 
     for it in range(args.warmup):
         step(it)
@@ -137,10 +113,7 @@ def main():
         elapsed = float(t.item())
 
     pairs_total = n * (n - 1) // 2
-    my_pairs = 0
-    for r0, r1 in ranges:
-        for_rows = max(0, r1 - r0)
-        my_pairs += for_rows * (n - 1) - (r0 + r1 - 1) * for_rows // 2                       # sum over rows of (n-1-i)
+    my_pairs = sum(partition.pairs_in_rows(n, r0, r1) for r0, r1 in ranges)
     kern_ms = [ev0[i].elapsed_time(ev1[i]) for i in range(args.warmup, args.warmup + args.steps)]
     kern_s = sum(kern_ms) / len(kern_ms) / 1e3 / len(ranges)      # average duration of ONE launch
     my_pairs_per_launch = my_pairs / len(ranges)

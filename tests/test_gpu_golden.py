@@ -1,0 +1,277 @@
+"""GPU path against the committed golden fixtures, the device-resident entry points, and size-independent
+properties at larger sizes.  Everything goes through the C ABI (ctypes)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def torch_mod(hiplib):
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+@pytest.fixture(scope="module")
+def api(torch_mod):
+    from tracs_amd import api
+    return api
+
+
+@pytest.fixture(scope="module")
+def dev(torch_mod):
+    from tracs_amd import device
+    return device
+
+
+def _load(golden_dir, name):
+    with open(os.path.join(golden_dir, name)) as fh:
+        return json.load(fh)
+
+
+def test_trans_dist_golden(api, oracle, golden_dir):
+    from ek_parity import check_ek
+    g = _load(golden_dir, "transcluster_golden.json")
+    counts = {}
+    for grid in g["trans_dist"]:
+        N, delta = np.array(grid["N"], np.int32), np.array(grid["delta"])
+        p0, ek = api.trans_dist_arrays(N, delta, grid["lamb"], grid["beta"], grid["thr"])
+        assert np.allclose(p0, grid["p0"], rtol=1e-6, atol=0)                  # vs the reference build (log-likelihood)
+        assert np.max(np.abs(p0 - grid["p0"]) / np.abs(grid["p0"])) < 1e-9
+        for i, cls in enumerate(grid["conditioning"]):
+            if cls == "well":                                                   # vs the reference build
+                assert abs(ek[i] - grid["eK"][i]) <= 1e-6 * abs(grid["eK"][i])
+            check_ek(oracle, N[i], delta[i], grid["lamb"], grid["beta"], grid["thr"], ek[i], counts)   # vs the oracle
+    assert counts["well"] > 250
+
+
+def test_lprob_golden(api, golden_dir):
+    from scipy.special import gammaln
+    g = _load(golden_dir, "transcluster_golden.json")["lprob"]
+    lg = gammaln(np.arange(g["lgamma_len"]))
+    for r in g["rows"]:
+        got = api.lprob_k_given_N(r["N"], r["k"], r["delta"], r["lamb"], r["beta"], lg)
+        assert np.allclose(got, r["lprob_k_given_N"], rtol=1e-6, atol=1e-9)
+        assert np.allclose(got, r["lprob_k_given_N"], rtol=1e-10, atol=1e-11)
+
+
+def test_posteriors_golden(api, golden_dir):
+    z = np.load(os.path.join(golden_dir, "posteriors_golden.npz"))
+    counts = z["counts"]
+    for i, m in enumerate(json.loads(str(z["meta"]))):
+        got = api.calculate_posteriors(counts, m["alphas"], m["keep"], m["threshold"])
+        exp = z["post_%d" % i]
+        assert np.max(np.abs(got - exp) / np.maximum(np.abs(exp), 1e-300)) <= 4e-16, m
+
+
+def test_fasta_reader_golden(api, oracle, golden_dir, tmp_path):
+    g = _load(golden_dir, "kseq_golden.json")
+    for name, case in g.items():
+        if case.get("crash"):
+            continue
+        p = os.path.join(str(tmp_path), name)
+        with open(p, "wb") as fh:
+            fh.write(case["text"].encode("latin-1"))
+        recs = case["records"]
+        if case["rc"] == -2:
+            with pytest.raises(RuntimeError, match="Error reading FASTA!"):
+                api.pairsnp_arrays([p], 1, 2147483647, False)
+            continue
+        if len({len(r[1]) for r in recs}) > 1:
+            with pytest.raises(RuntimeError, match="variable sequence lengths"):
+                api.pairsnp_arrays([p], 1, 2147483647, False)
+            continue
+        r, c, d, names, _, nn = api.pairsnp_arrays([p], 1, 2147483647, False)
+        assert names == [x[0] for x in recs], name
+        if len(recs) >= 2:
+            seqs = np.array([np.frombuffer(x[1].encode("latin-1"), np.uint8) for x in recs])
+            er, ec, ed, enn = oracle.pairsnp_arrays(seqs)
+            assert np.array_equal(d, ed) and np.array_equal(nn, enn), name
+
+
+def test_pairsnp_fixture(api, golden_dir, tmp_path):
+    from tracs_amd import synth
+    g = _load(golden_dir, "pairsnp_unpinned.json")
+    for name, c in g["cases"].items():
+        seqs = np.array([np.frombuffer(s.encode("ascii"), np.uint8) for s in c["seqs"]])
+        td = str(tmp_path)
+        if c["n0"] is None:
+            fa = os.path.join(td, "a.fa")
+            synth.write_fasta(fa, seqs)
+            files = [fa]
+        else:
+            fa, fb = os.path.join(td, "a.fa"), os.path.join(td, "b.fa")
+            synth.write_fasta(fa, seqs[:c["n0"]])
+            synth.write_fasta(fb, seqs[c["n0"]:])
+            files = [fa, fb]
+        out = api.pairsnp(fasta=files, n_threads=1, dist=c["dist"], filter=False)
+        assert out[0] == c["rows"] and out[1] == c["cols"] and out[2] == c["d"] and out[5] == c["nn"], name
+
+
+def test_cli_end_to_end_vs_reference_driver(api, golden_dir, tmp_path, monkeypatch):
+    """`tracs distance` + `tracs cluster` on the GPU against the CSVs the reference's own drivers wrote."""
+    from test_host_logic import _materialise, _rows_equal
+    from tracs_amd import cluster, distance
+    pyref = _load(golden_dir, "python_reference_golden.json")
+    td = str(tmp_path)
+    _materialise(pyref, td)
+    for run in ("meta", "nometa", "meta_thr", "msadb"):
+        r = pyref["distance"]["runs"][run]
+        out = os.path.join(td, run + ".csv")
+        monkeypatch.setattr(sys, "argv", ["d"] + [a.replace("TMP", td) for a in r["argv"]] + ["-o", out, "--loglevel", "ERROR"])
+        distance.main()
+        _rows_equal(open(out).read(), r["csv"])
+    for key, exp in pyref["cluster"]["runs"].items():
+        col, thr = key.split("_")
+        cluster._ids.clear()
+        out = os.path.join(td, "c.csv")
+        monkeypatch.setattr(sys, "argv", ["c", "-d", os.path.join(td, "meta.csv"), "-o", out, "-c", thr, "-D", col,
+                                          "--loglevel", "ERROR"])
+        cluster.main()
+        assert open(out).read() == exp, key
+    cluster._ids.clear()
+
+
+def test_drop_in_module_names():
+    import TRACS
+    for f in ("pairsnp", "trans_dist", "lprob_k_given_N", "calculate_posteriors"):
+        assert callable(getattr(TRACS, f))
+
+
+# ---- device-resident entry points --------------------------------------------------------------------------
+def test_dense_coo_and_transcluster_device(dev, oracle, torch_mod):
+    from ek_parity import check_ek
+    from tracs_amd import synth
+    torch = torch_mod
+    n, L = 333, 7000
+    seqs = synth.alignment(n, L, seed=31, mu_lineage=0.004, mu_sample=0.001, p_n=0.02, p_partial=0.01, p_lower=0.05)
+    aln = dev.Alignment(n, L)
+    aln.pack(seqs[:100], first=0)                                  # host pointer
+    aln.pack(torch.from_numpy(seqs[100:]).cuda(), first=100)       # device pointer
+    d = torch.full((n, n), -1, dtype=torch.int32, device="cuda")
+    nn = torch.full((n, n), -1, dtype=torch.int32, device="cuda")
+    dev.pairsnp_dense(aln, d, nn)
+    er, ec, ed, enn = oracle.pairsnp_arrays(seqs)
+    ri, ci = er.astype(np.int64), ec.astype(np.int64)
+    dh, nh = d.cpu().numpy(), nn.cpu().numpy()
+    assert np.array_equal(dh[ri, ci], ed.astype(np.int32)) and np.array_equal(nh[ri, ci], enn.astype(np.int32))
+    assert (np.tril(dh) == -1).all()                               # nothing outside the cell set is written
+    # d only (ncomp = NULL): the 5-op kernel
+    d2 = torch.full((n, n), -1, dtype=torch.int32, device="cuda")
+    dev.pairsnp_dense(aln, d2, None, row_begin=50, row_end=200, col_begin=120)
+    sel = (ri >= 50) & (ri < 200) & (ci >= 120)
+    d2h = d2.cpu().numpy()
+    assert np.array_equal(d2h[ri[sel], ci[sel]], ed[sel].astype(np.int32)) and (d2h != -1).sum() == sel.sum()
+    # COO
+    for thr in (2147483647, 25, 3, -1):
+        rows, cols, dd, nc = dev.coo_from_dense(d, nn, n, dist_threshold=thr)
+        xr, xc, xd, xn = oracle.pairsnp_arrays(seqs, dist=thr)
+        assert np.array_equal(rows.cpu().numpy(), xr.astype(np.int32)) and np.array_equal(cols.cpu().numpy(), xc.astype(np.int32))
+        assert np.array_equal(dd.cpu().numpy(), xd.astype(np.int32)) and np.array_equal(nc.cpu().numpy(), xn.astype(np.int32))
+    # transcluster on the dense block, delta from integer days
+    _, days = synth.dates(n, seed=31, span_days=200)
+    p = torch.zeros((n, n), dtype=torch.float64, device="cuda")
+    e = torch.zeros((n, n), dtype=torch.float64, device="cuda")
+    dev.trans_dist_dense(d, n, torch.from_numpy(days).cuda(), 5.3, 6.0, 0.01, p, e, exp_p0=True, dist_threshold=60)
+    keep = ed <= 60
+    delta = np.abs(days[ri] - days[ci]).astype(np.float64) * 86400.0 / 31556952.0
+    ep0, _ = oracle.trans_dist(ed[keep].astype(np.int32), delta[keep], 5.3, 6.0, 0.01)
+    ph, eh = p.cpu().numpy(), e.cpu().numpy()
+    assert np.allclose(ph[ri[keep], ci[keep]], np.exp(ep0), rtol=1e-6, atol=0)
+    seen = set()
+    for t in np.where(keep)[0][::7]:
+        key = (int(ed[t]), float(delta[t]))
+        if key not in seen:
+            seen.add(key)
+            check_ek(oracle, key[0], key[1], 5.3, 6.0, 0.01, eh[ri[t], ci[t]])
+    assert (ph[ri[~keep], ci[~keep]] == 0).all()                   # cells above the SNP threshold are skipped
+    aln.close()
+
+
+def test_split_group_range_small_n_long_L(dev, oracle, torch_mod):
+    """Few tiles + long alignment: the group range is split over workgroups (atomic accumulation path)."""
+    from tracs_amd import synth
+    torch = torch_mod
+    n, L = 40, 300000
+    seqs = synth.alignment(n, L, seed=77, mu_lineage=2e-4, mu_sample=1e-4, p_n=0.01)
+    aln = dev.Alignment(n, L)
+    aln.pack(seqs)
+    d = torch.zeros((n, n), dtype=torch.int32, device="cuda")
+    nn = torch.zeros((n, n), dtype=torch.int32, device="cuda")
+    for _ in range(2):                                            # twice: the init pass must reset the cells
+        dev.pairsnp_dense(aln, d, nn)
+    er, ec, ed, enn = oracle.pairsnp_arrays(seqs, n_threads=8)
+    ri, ci = er.astype(np.int64), ec.astype(np.int64)
+    assert np.array_equal(d.cpu().numpy()[ri, ci], ed.astype(np.int32))
+    assert np.array_equal(nn.cpu().numpy()[ri, ci], enn.astype(np.int32))
+
+
+def test_properties_at_scale(dev, oracle, torch_mod):
+    """1 500 x 200 kb: properties that need no oracle at full size + an oracle-checked sub-block."""
+    from tracs_amd import synth
+    torch = torch_mod
+    n, L = 1500, 200000
+    seqs = synth.alignment(n, L, seed=12, mu_lineage=5e-4, mu_sample=1e-4, p_n=0.01, p_partial=0.002)
+    aln = dev.Alignment(n, L)
+    aln.pack(seqs)
+    d = torch.zeros((n, n), dtype=torch.int32, device="cuda")
+    nn = torch.zeros((n, n), dtype=torch.int32, device="cuda")
+    dev.pairsnp_dense(aln, d, nn)
+    iu = torch.triu_indices(n, n, offset=1, device="cuda")
+    dv, nv = d[iu[0], iu[1]], nn[iu[0], iu[1]]
+    assert bool((dv <= nv).all()) and bool((nv <= L).all()) and bool((dv >= 0).all())
+    # permutation invariance: reversing the sample order transposes the pair set
+    aln2 = dev.Alignment(n, L)
+    aln2.pack(np.ascontiguousarray(seqs[::-1]))
+    d2 = torch.zeros((n, n), dtype=torch.int32, device="cuda")
+    dev.pairsnp_dense(aln2, d2, None)
+    full = d + d.t()
+    full2 = d2 + d2.t()
+    assert bool(torch.equal(full, torch.flip(full2, dims=(0, 1))))
+    # two-block consistency: rows [0, 700) x cols >= 700 computed as a rectangular block
+    d3 = torch.zeros((n, n), dtype=torch.int32, device="cuda")
+    dev.pairsnp_dense(aln, d3, None, row_begin=0, row_end=700, col_begin=700)
+    assert bool(torch.equal(d3[:700, 700:], d[:700, 700:])) and int(d3[:, :700].abs().sum()) == 0
+    # oracle on a 96-sample sub-block
+    sub = np.sort(np.random.default_rng(1).choice(n, 96, replace=False))
+    er, ec, ed, enn = oracle.pairsnp_arrays(seqs[sub], n_threads=8)
+    gi, gj = sub[er.astype(np.int64)], sub[ec.astype(np.int64)]
+    assert np.array_equal(d.cpu().numpy()[gi, gj], ed.astype(np.int32))
+    assert np.array_equal(nn.cpu().numpy()[gi, gj], enn.astype(np.int32))
+
+
+def test_posterior_codes_and_device_posteriors(dev, oracle, torch_mod):
+    from tracs_amd import synth
+    torch = torch_mod
+    L = 100001
+    counts = synth.allele_counts(L, seed=3, depth=18, p_two=0.05)
+    counts[:10] = 0
+    alphas = [20.8156311152126, 4.38181182238621, 0.889048781117318, 0.1]
+    for keep in (False, True):
+        post = oracle.calculate_posteriors(counts.astype(np.float64), alphas, keep, 0.02)
+        got = dev.calculate_posteriors_device(torch.from_numpy(counts.astype(np.float64)).cuda(), alphas, keep, 0.02)
+        assert np.array_equal(got.cpu().numpy(), post)
+        codes = dev.posterior_codes_device(torch.from_numpy(counts.view(np.int16)).cuda(), alphas, keep, 0.02).cpu().numpy()
+        mask = ((post > 0).astype(np.uint8) * np.array([1, 2, 4, 8], np.uint8)).sum(1).astype(np.uint8)
+        exp = np.zeros((L + 1) // 2, np.uint8)
+        exp |= mask[0::2]
+        exp[:L // 2] |= (mask[1::2] << 4)
+        assert np.array_equal(codes, exp)
+
+
+def test_connected_components_device(dev, torch_mod):
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import connected_components
+    torch = torch_mod
+    rng = np.random.default_rng(4)
+    n, m = 100000, 120000
+    I, J = rng.integers(0, n, m).astype(np.int32), rng.integers(0, n, m).astype(np.int32)
+    nc, lab = dev.connected_components_device(torch.from_numpy(I).cuda(), torch.from_numpy(J).cuda(), n)
+    enc, elab = connected_components(csgraph=csr_matrix((np.ones(m), (I, J)), shape=(n, n)), directed=False)
+    assert nc == enc and np.array_equal(lab.cpu().numpy(), elab)
