@@ -29,8 +29,6 @@ for lamb, beta in ((5.3, 6.0), (29.903, 73.0), (3.0, 52.0)):
             assert abs(ek[i] - rek[i]) <= 1e-9 * abs(rek[i]), (lamb, N[i], days[i], ek[i], rek[i])
         elif abs(ek[i] - rek[i]) > 1e-9 * abs(rek[i]):
             bad += 1
-    u = [R.ref_upper_bound_E(float(d), lamb, beta, int(n)) for n, d in zip(N[:50], delta[:50])]
-    assert all(np.isfinite(u))
 counts = rng.poisson(6, (2000, 4)).astype(float); counts[:30] = 0; counts[30:60] = 4
 for keep in (False, True):
     a = O.calculate_posteriors(counts, [3.0, 0.2, 9.0, 0.7], keep, 0.04)
