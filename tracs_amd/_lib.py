@@ -31,11 +31,31 @@ class TracsError(RuntimeError):
     pass
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch wheels bundle their own libamdhip64.so (soname libamdhip64.so.7, but torch links it as
+    `libamdhip64.so`).  If our library pulled in /opt/rocm's copy first, a later `import torch` would load a
+    SECOND HIP runtime into the process and one of the two would see no device.  So when torch is installed,
+    its copy is loaded first (no torch import needed); our DT_NEEDED libamdhip64.so.7 then resolves to it."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is not None and spec.origin:
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
 def load():
     """Load the library (building nothing: run `python -m tracs_amd.build` or __graft_entry__.build())."""
     global _lib
     if _lib is not None:
         return _lib
+    _share_hip_runtime_with_torch()
     if not os.path.exists(LIB_PATH):
         raise TracsError("libtracs_hip.so is missing (%s): build it with `python -m tracs_amd.build`; "
                          "there is no CPU fallback" % LIB_PATH)
