@@ -248,9 +248,12 @@ def ek_conditioning(N, delta, lamb, beta, thr):
     exp(elprob), which is ~upper * 1e-13 after the accumulation) or 'ill' (decided by rounding)."""
     t = expected_k_trace(N, delta, lamb, beta, thr, extra=0)
     ks = t["k_stop"]
-    if ks >= 10000:
-        return "saturated", t
     noise = abs(t["upper"]) * 1e-12
+    if ks >= 10000:
+        # ran to the cap.  Robust only if the bound was never approached to within rounding noise; otherwise a
+        # different rounding could have ended the loop early (the stop is decided by the last bits of exp(elprob))
+        closest = np.nanmin(t["diffs"][1:ks])
+        return ("saturated" if closest - thr > 100 * noise else "ill"), t
     last_above = t["diffs"][ks - 2] if ks >= 3 else np.inf      # diff after the last-but-one iteration
     at_stop = t["diffs"][ks - 1]
     margin = min(abs(last_above - thr), abs(at_stop - thr))

@@ -55,8 +55,10 @@ __device__ __forceinline__ double imul(long long i, double l) { return i == 0 ? 
 // with pois = ln sum_{i<=N} (lamb*delta)^i / i!  independent of k.  Substituting j = N+k-i,
 //   integral_k = -(N+k+1) ln(lamb+beta) + ln S_{N+k},   S_M = sum_{j<=M} (delta(lamb+beta))^j / j!
 // so S is a running sum in k.  All terms are positive: no cancellation is introduced.
-__device__ void tc_eval(int N, double delta, const TcParams &P, const double *__restrict__ lg, double &p0, double &eK,
-                        int &k_stop)
+// k_cap: evaluate at most k_cap-1 terms here; returns false if the reference's loop would still be running
+// (the key is then finished by tc_long_keys_kernel, one wave per key).
+__device__ bool tc_eval(int N, double delta, const TcParams &P, const double *__restrict__ lg, double &p0, double &eK,
+                        int &k_stop, int k_cap)
 {
     const double n1 = (double)(N + 1);
     const double lg_n1 = lg_at(lg, (long long)N + 1);
@@ -78,6 +80,7 @@ __device__ void tc_eval(int N, double delta, const TcParams &P, const double *__
         }
         double diff = P.thr + 1;
         while ((diff > P.thr) && (k < 10000)) {                        // :207
+            if (k >= k_cap) { k_stop = k; return false; }
             const long long M = (long long)N + k;
             lnS = lae(lnS, imul(M, ld) + (double)M * P.ln_lb - lg_at(lg, M + 1));
             double lhs = (n1 * P.ln_lamb + (double)k * P.ln_beta + lg_at(lg, M + 1));   // :140
@@ -96,6 +99,7 @@ __device__ void tc_eval(int N, double delta, const TcParams &P, const double *__
         p0 = (n1 * P.ln_lamb + 0.0 * P.ln_beta + lg_n1 - lg_n1 - lg_at(lg, 1) - n1 * P.ln_lb);
         double diff = P.thr + 1;
         while ((diff > P.thr) && (k < 10000)) {
+            if (k >= k_cap) { k_stop = k; return false; }
             const long long M = (long long)N + k;
             const double m1 = (double)(M + 1) * P.ln_lb;
             const double lhs = (n1 * P.ln_lamb + (double)k * P.ln_beta + lg_at(lg, M + 1) - lg_n1 -
@@ -109,6 +113,84 @@ __device__ void tc_eval(int N, double delta, const TcParams &P, const double *__
     }
     eK = exp(lprob);                                                   // :237
     k_stop = k;
+    return true;
+}
+
+// ---- wave-parallel E(K) for long series -------------------------------------------------------------
+// One wave per key, 64 consecutive k per step.  The three running quantities of the loop (S, lprob, elprob)
+// are log-space prefix sums, so a step is: per-lane terms, three inclusive wave scans with logaddexp, the
+// reference's stopping test on every lane's prefix, and a ballot for the first lane that satisfies it.
+// Summation order differs from the serial loop by rounding only (all terms positive).
+__device__ __forceinline__ double wave_scan_lae(double v, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double o = __shfl_up(v, off, 64);
+        if (lane >= off) v = lae(v, o);
+    }
+    return v;
+}
+
+__device__ void tc_eval_wave(int N, double delta, const TcParams &P, const double *__restrict__ lg, double &eK)
+{
+    const int lane = threadIdx.x & 63;
+    const double n1 = (double)(N + 1);
+    const double lg_n1 = lg_at(lg, (long long)N + 1);
+    const bool pos = delta > 0;
+    double pois = 0.0, lnS = -INFINITY, ld = 0.0, upper;
+    if (pos) {
+        const double lx = log(P.lamb * delta);
+        ld = log(delta);
+        // pois and S_N: lane-strided terms, then a wave reduction (order differs from :144-148 by rounding only)
+        double pp = -INFINITY, ss = -INFINITY;
+        for (long long i = lane; i <= N; i += 64) {
+            pp = lae(imul(i, lx) - lg_at(lg, i + 1), pp);
+            ss = lae(ss, imul(i, ld) + (double)i * P.ln_lb - lg_at(lg, i + 1));
+        }
+        pp = wave_scan_lae(pp, lane); ss = wave_scan_lae(ss, lane);
+        pois = __shfl(pp, 63, 64); lnS = __shfl(ss, 63, 64);
+        upper = exp(P.ln_beta + delta * P.lamb + log(n1) - (P.ln_lamb + pois));
+    } else {
+        upper = exp(P.ln_beta + log(n1) - P.ln_lamb);
+    }
+    double lprob = -INFINITY, elprob = -INFINITY;
+    for (int k0 = 1; k0 < 10000; k0 += 64) {
+        const int k = k0 + lane;
+        const bool live = k < 10000;
+        const long long M = (long long)N + k;
+        const double m1 = (double)(M + 1) * P.ln_lb;
+        const double lk = log((double)k);
+        double t1, t2;
+        if (pos) {
+            double a = live ? imul(M, ld) + (double)M * P.ln_lb - lg_at(lg, M + 1) : -INFINITY;
+            const double Sk = lae(lnS, wave_scan_lae(a, lane));
+            double lhs = (n1 * P.ln_lamb + (double)k * P.ln_beta + lg_at(lg, M + 1));
+            lhs = lhs - lg_n1 - lg_at(lg, (long long)k + 1) - delta * P.beta;
+            lhs -= pois;
+            t1 = (lhs + (Sk - m1)) + lk;
+            t2 = lhs + lk + delta * (P.lamb + P.beta) - m1;
+            lnS = __shfl(Sk, 63, 64);
+        } else {
+            const double lhs = (n1 * P.ln_lamb + (double)k * P.ln_beta + lg_at(lg, M + 1) - lg_n1 -
+                                lg_at(lg, (long long)k + 1) - m1);
+            t1 = lhs + lk;
+            t2 = lhs + lk + delta * (P.lamb + P.beta) - m1;
+        }
+        if (!live) { t1 = -INFINITY; t2 = -INFINITY; }
+        const double lp = lae(lprob, wave_scan_lae(t1, lane));
+        const double el = lae(elprob, wave_scan_lae(t2, lane));
+        const double diff = upper - exp(el);
+        const bool stop = live && !(diff > P.thr);                     // the while condition fails after this k
+        const unsigned long long m = __ballot(stop);
+        if (m) {
+            const int f = __ffsll((long long)m) - 1;
+            eK = exp(__shfl(lp, f, 64));
+            return;
+        }
+        lprob = __shfl(lp, 63, 64);
+        elprob = __shfl(el, 63, 64);
+    }
+    eK = exp(lprob);                                                   // ran to k = 9999
 }
 
 __global__ void lgamma_table_kernel(double *__restrict__ lg, int n)
@@ -202,18 +284,40 @@ __global__ void dedup_collect_kernel(const unsigned *__restrict__ slots, unsigne
     }
 }
 
+constexpr int TC_SERIAL_CAP = 192;      // terms evaluated by the one-thread-per-key kernel before a key is handed over
+
 template <class Src>
 __global__ void tc_keys_kernel(Src src, const unsigned *__restrict__ key_elem, unsigned nk, TcParams P,
-                               const double *__restrict__ lg, double *__restrict__ key_p0, double *__restrict__ key_eK)
+                               const double *__restrict__ lg, double *__restrict__ key_p0, double *__restrict__ key_eK,
+                               unsigned *__restrict__ long_ids, unsigned *__restrict__ n_long)
 {
     P.ln_lamb = log(P.lamb); P.ln_beta = log(P.beta); P.ln_lb = log(P.lamb + P.beta);
     for (unsigned id = blockIdx.x * blockDim.x + threadIdx.x; id < nk; id += gridDim.x * blockDim.x) {
         int N; double d;
         src.get((size_t)key_elem[id], N, d);
-        double p0, eK; int ks;
-        tc_eval(N, d, P, lg, p0, eK, ks);
+        double p0, eK = 0.0; int ks;
+        const bool done = tc_eval(N, d, P, lg, p0, eK, ks, TC_SERIAL_CAP);
         key_p0[id] = p0;
-        key_eK[id] = eK;
+        if (done) key_eK[id] = eK;
+        else long_ids[atomicAdd(n_long, 1u)] = id;
+    }
+}
+
+template <class Src>
+__global__ __launch_bounds__(64) void tc_long_keys_kernel(Src src, const unsigned *__restrict__ key_elem,
+                                                          const unsigned *__restrict__ long_ids,
+                                                          const unsigned *__restrict__ n_long, TcParams P,
+                                                          const double *__restrict__ lg, double *__restrict__ key_eK)
+{
+    P.ln_lamb = log(P.lamb); P.ln_beta = log(P.beta); P.ln_lb = log(P.lamb + P.beta);
+    const unsigned nl = *n_long;
+    for (unsigned w = blockIdx.x; w < nl; w += gridDim.x) {
+        const unsigned id = long_ids[w];
+        int N; double d;
+        src.get((size_t)key_elem[id], N, d);
+        double eK;
+        tc_eval_wave(N, d, P, lg, eK);
+        if ((threadIdx.x & 63) == 0) key_eK[id] = eK;
     }
 }
 
@@ -290,7 +394,7 @@ static int get_lgamma_table(hipStream_t stream, const double **out)
     return TRACS_OK;
 }
 
-struct TcWorkspaceIds { enum { SLOTS = 0, ESLOT, SLOT_ID, NKEYS, KEY_ELEM, KEY_P0, KEY_EK }; };
+struct TcWorkspaceIds { enum { SLOTS = 0, ESLOT, SLOT_ID, NKEYS, KEY_ELEM, KEY_P0, KEY_EK, LONG_IDS }; };
 
 template <class Src>
 static int run_trans_dist(const Src &src, size_t total, double lamb, double beta, double thr, int exp_p0, double *p0,
@@ -303,7 +407,7 @@ static int run_trans_dist(const Src &src, size_t total, double lamb, double beta
     if (rc) return rc;
     unsigned cap = 1024;
     while ((size_t)cap < 2 * total && cap < (1u << 31)) cap <<= 1;
-    unsigned *slots, *eslot, *slot_id, *n_keys, *key_elem;
+    unsigned *slots, *eslot, *slot_id, *n_keys, *key_elem, *long_ids;
     double *key_p0, *key_eK;
     if ((rc = workspace_get(TcWorkspaceIds::SLOTS, (size_t)cap * 4, reinterpret_cast<void **>(&slots)))) return rc;
     if ((rc = workspace_get(TcWorkspaceIds::ESLOT, total * 4, reinterpret_cast<void **>(&eslot)))) return rc;
@@ -325,14 +429,19 @@ static int run_trans_dist(const Src &src, size_t total, double lamb, double beta
     if ((rc = workspace_get(TcWorkspaceIds::KEY_ELEM, (size_t)nk * 4, reinterpret_cast<void **>(&key_elem)))) return rc;
     if ((rc = workspace_get(TcWorkspaceIds::KEY_P0, (size_t)nk * 8, reinterpret_cast<void **>(&key_p0)))) return rc;
     if ((rc = workspace_get(TcWorkspaceIds::KEY_EK, (size_t)nk * 8, reinterpret_cast<void **>(&key_eK)))) return rc;
-    TRACS_HIP_CHECK(hipMemsetAsync(n_keys, 0, 4, stream));
+    if ((rc = workspace_get(TcWorkspaceIds::LONG_IDS, (size_t)nk * 4, reinterpret_cast<void **>(&long_ids)))) return rc;
+    TRACS_HIP_CHECK(hipMemsetAsync(n_keys, 0, 8, stream));          // [0] key counter, [1] long-key counter
     hipLaunchKernelGGL(dedup_collect_kernel, dim3((unsigned)std::min<size_t>((cap + 255) / 256, 256 * 32)), dim3(256), 0, stream,
                        slots, cap, slot_id, key_elem, n_keys);
     TcParams P;
     P.lamb = lamb; P.beta = beta; P.thr = thr;
     P.ln_lamb = P.ln_beta = P.ln_lb = 0.0;
     // one wave per block: keys differ widely in trip count, small blocks keep the SIMDs busy
-    hipLaunchKernelGGL((tc_keys_kernel<Src>), dim3((nk + 63) / 64), dim3(64), 0, stream, src, key_elem, nk, P, lg, key_p0, key_eK);
+    hipLaunchKernelGGL((tc_keys_kernel<Src>), dim3((nk + 63) / 64), dim3(64), 0, stream, src, key_elem, nk, P, lg, key_p0, key_eK,
+                       long_ids, n_keys + 1);
+    // long series (E(K) loop beyond TC_SERIAL_CAP terms): one wave per key
+    hipLaunchKernelGGL((tc_long_keys_kernel<Src>), dim3(std::min<unsigned>(nk, 256u * 32u)), dim3(64), 0, stream, src, key_elem,
+                       long_ids, n_keys + 1, P, lg, key_eK);
     hipLaunchKernelGGL((tc_gather_kernel<Src>), dim3(blocks), dim3(256), 0, stream, src, eslot, slot_id, key_p0, key_eK,
                        exp_p0, p0, eK);
     TRACS_HIP_CHECK(hipGetLastError());
