@@ -132,7 +132,11 @@ enum { ROW_SMEM = 0, ROW_SMEM_PF = 1, ROW_LDS = 2, ROW_SMEM_PF1 = 6,
        ABL_ROWS_FIXED = 3, ABL_COLS_FIXED = 4, ABL_BOTH_FIXED = 5 };
 
 // NW waves per workgroup, R rows per wave, C columns per lane, GC groups per LDS stage.
-template <int NW, int R, int C, int GC, bool WITH_NN, int ROWSRC, int MINW = 1>
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+
+// GLDS: stage with global_load_lds_dwordx4 (HBM/L2 -> LDS directly, no staging VGPRs, no ds_write)
+template <int NW, int R, int C, int GC, bool WITH_NN, int ROWSRC, int MINW = 1, bool GLDS = false>
 __global__ __launch_bounds__(NW * 64, MINW) void pairsnp_tile_kernel(
     const uint4 *__restrict__ P, size_t n_pad, int groups, const int2 *__restrict__ tiles, int n_tiles,
     int groups_per_split, int ksplit, unsigned L, unsigned n, unsigned row_end, unsigned col_begin,
@@ -164,10 +168,27 @@ __global__ __launch_bounds__(NW * 64, MINW) void pairsnp_tile_kernel(
 #pragma unroll
         for (int c = 0; c < C; c++) { accM[r][c] = 0; accN[r][c] = 0; }
 
-    uint4 stage_regs[LPT];
-    auto stage_load = [&](int gs) {
+    static_assert(!GLDS || TS % 64 == 0, "glds needs wave-uniform (group, plane) per wave instruction");
+    // direct-to-LDS stage: LDS address = wave-uniform base + lane * 16 -- exactly the stage's linear order
+    auto stage_glds = [&](int gs, int b) {
 #pragma unroll
         for (int k = 0; k < LPT; k++) {
+            const int e0 = (wave + k * NW) * 64;        // wave-uniform
+            if (STAGE % NT == 0 || e0 < STAGE) {
+                const int gp = e0 / TS;
+                const int sidx = e0 - gp * TS + lane;
+                if (gs + gp / NPLANES < g_end) {
+                    const size_t smp = sidx < TJ ? (size_t)j0 + sidx : (size_t)i0 + (sidx - TJ);
+                    __builtin_amdgcn_global_load_lds((glb_void_t *)(P + ((size_t)gs * NPLANES + gp) * n_pad + smp),
+                                                     (lds_void_t *)&lds[b][e0], 16, 0, 0);
+                }
+            }
+        }
+    };
+    uint4 stage_regs[GLDS ? 1 : LPT];
+    auto stage_load = [&](int gs) {
+#pragma unroll
+        for (int k = 0; k < (GLDS ? 0 : LPT); k++) {
             const int e = tid + k * NT;
             const int gp = e / TS;               // local group*5 + plane
             const int sidx = e - gp * TS;
@@ -182,7 +203,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void pairsnp_tile_kernel(
     };
     auto stage_store = [&](int buf) {
 #pragma unroll
-        for (int k = 0; k < LPT; k++) {
+        for (int k = 0; k < (GLDS ? 0 : LPT); k++) {
             const int e = tid + k * NT;
             if (STAGE % NT == 0 || e < STAGE) lds[buf][e] = stage_regs[k];
         }
@@ -223,8 +244,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void pairsnp_tile_kernel(
             for (int p = 0; p < NPL; p++) dst[rr][p] = rowp[(size_t)p * n_pad + rr];
     };
 
-    stage_load(g_begin);
-    stage_store(0);
+    if (GLDS) stage_glds(g_begin, 0);
+    else { stage_load(g_begin); stage_store(0); }
     __syncthreads();
 
     uint4 cur[RB][NPLANES];
@@ -247,7 +268,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void pairsnp_tile_kernel(
     int buf = 0;
     for (int gs = g_begin; gs < g_end; gs += GC) {
         const bool more = !COLS_FIXED && gs + GC < g_end;
-        if (more) stage_load(gs + GC);
+        if (more) { if (GLDS) stage_glds(gs + GC, buf ^ 1); else stage_load(gs + GC); }
 #pragma unroll
         for (int gl = 0; gl < GC; gl++) {
             const int g = gs + gl;
@@ -551,16 +572,16 @@ struct TileVariant {
                    unsigned *dist, unsigned *ncomp, size_t ld);
 };
 
-template <int NW, int R, int C, int GC, int ROWSRC, int MINW = 1>
+template <int NW, int R, int C, int GC, int ROWSRC, int MINW = 1, bool GLDS = false>
 static void launch_variant(bool with_nn, unsigned nwg, hipStream_t stream, const uint4 *P, size_t n_pad, int groups,
                            const int2 *tiles, int n_tiles, int gps, int ksplit, unsigned L, unsigned n, unsigned row_end,
                            unsigned col_begin, unsigned *dist, unsigned *ncomp, size_t ld)
 {
     if (with_nn)
-        hipLaunchKernelGGL((pairsnp_tile_kernel<NW, R, C, GC, true, ROWSRC, MINW>), dim3(nwg), dim3(NW * 64), 0, stream, P, n_pad, groups,
+        hipLaunchKernelGGL((pairsnp_tile_kernel<NW, R, C, GC, true, ROWSRC, MINW, GLDS>), dim3(nwg), dim3(NW * 64), 0, stream, P, n_pad, groups,
                            tiles, n_tiles, gps, ksplit, L, n, row_end, col_begin, dist, ncomp, ld);
     else
-        hipLaunchKernelGGL((pairsnp_tile_kernel<NW, R, C, GC, false, ROWSRC, MINW>), dim3(nwg), dim3(NW * 64), 0, stream, P, n_pad, groups,
+        hipLaunchKernelGGL((pairsnp_tile_kernel<NW, R, C, GC, false, ROWSRC, MINW, GLDS>), dim3(nwg), dim3(NW * 64), 0, stream, P, n_pad, groups,
                            tiles, n_tiles, gps, ksplit, L, n, row_end, col_begin, dist, ncomp, ld);
 }
 
@@ -579,6 +600,7 @@ static void launch_rowcast(bool with_nn, unsigned nwg, hipStream_t stream, const
 #define TRACS_ROWCAST(NW, R, C) {"rowcast" #NW "x" #R "x" #C, R, (NW) * 64 * (C), 1, (NW) * 64, launch_rowcast<NW, R, C>}
 
 #define TRACS_VARIANT_W(NW, R, C, GC, SRC, MINW) {#NW "x" #R "x" #C "x" #GC ":" #SRC "/w" #MINW, (NW) * (R), 64 * (C), GC, (NW) * 64, launch_variant<NW, R, C, GC, SRC, MINW>}
+#define TRACS_VARIANT_G(NW, R, C, GC, SRC, MINW) {#NW "x" #R "x" #C "x" #GC ":" #SRC "/w" #MINW "/glds", (NW) * (R), 64 * (C), GC, (NW) * 64, launch_variant<NW, R, C, GC, SRC, MINW, true>}
 #define TRACS_VARIANT(NW, R, C, GC, SRC) {#NW "x" #R "x" #C "x" #GC ":" #SRC, (NW) * (R), 64 * (C), GC, (NW) * 64, launch_variant<NW, R, C, GC, SRC>}
 static const TileVariant kVariants[] = {
     TRACS_VARIANT(8, 8, 2, 4, ROW_SMEM),      // 0: 64 x 128 tile, rows by scalar loads
@@ -614,10 +636,23 @@ static const TileVariant kVariants[] = {
     TRACS_VARIANT_W(4, 8, 2, 2, ROW_LDS, 4),     // 30: 32 x 128, four workgroups per CU
     TRACS_VARIANT_W(4, 16, 2, 2, ROW_LDS, 3),    // 31: 64 x 128 with 4 waves
     TRACS_VARIANT_W(8, 8, 2, 4, ROW_SMEM, 4),    // 32
+    TRACS_VARIANT_G(4, 16, 2, 2, ROW_LDS, 2),    // 33: variant 31 with direct-to-LDS staging
+    TRACS_VARIANT_G(4, 16, 2, 4, ROW_LDS, 2),    // 34
+    TRACS_VARIANT_G(8, 8, 2, 2, ROW_LDS, 4),     // 35
+    TRACS_VARIANT_G(8, 8, 2, 4, ROW_LDS, 4),     // 36
+    TRACS_VARIANT_G(4, 16, 2, 1, ROW_LDS, 2),    // 37
+    TRACS_VARIANT_G(8, 16, 2, 2, ROW_LDS, 2),    // 38
+    TRACS_VARIANT_G(4, 16, 2, 2, ROW_LDS, 3),    // 39
+    TRACS_VARIANT_G(16, 8, 2, 2, ROW_LDS, 4),    // 40
+    TRACS_VARIANT_G(8, 8, 2, 1, ROW_LDS, 4),     // 41
+    TRACS_VARIANT_G(8, 8, 2, 3, ROW_LDS, 4),     // 42
+    TRACS_VARIANT_G(4, 16, 2, 1, ROW_LDS, 3),    // 43
+    TRACS_VARIANT_G(8, 8, 2, 2, ROW_LDS, 3),     // 44
+    TRACS_VARIANT_G(8, 8, 2, 2, ROW_LDS, 5),     // 45
 };
 static constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 #ifndef TRACS_DEFAULT_VARIANT
-#define TRACS_DEFAULT_VARIANT 31
+#define TRACS_DEFAULT_VARIANT 35
 #endif
 
 static const TileVariant &current_variant()
