@@ -63,6 +63,12 @@ def lib():
         L.orc_free_fasta.restype = None
         L.orc_free_fasta.argtypes = [C.c_void_p]
         L.orc_num_threads.restype = C.c_int
+        L.orc_binomial_cdf.restype = C.c_double
+        L.orc_binomial_cdf.argtypes = [C.c_int, C.c_double, C.c_int]
+        L.orc_filter_recomb_positions.restype = C.c_uint64
+        L.orc_filter_recomb_positions.argtypes = [C.POINTER(C.c_int64), C.c_int64, C.c_int64]
+        L.orc_filter_recomb_pairs.restype = None
+        L.orc_filter_recomb_pairs.argtypes = [u64p, C.c_size_t, C.c_size_t, u64p, u64p, C.c_size_t, C.c_int, u64p]
         _LIB = L
     return _LIB
 
@@ -162,12 +168,32 @@ def pairsnp_planes(planes, L, n0=None, dist=2147483647, n_threads=1):
     return [a[:cnt] for a in out]
 
 
+def binomial_cdf(n, p, k):
+    return lib().orc_binomial_cdf(int(n), float(p), int(k))
+
+
+def filter_recomb_positions(pos, L):
+    pos = np.ascontiguousarray(pos, dtype=np.int64)
+    return int(lib().orc_filter_recomb_positions(pos.ctypes.data_as(C.POINTER(C.c_int64)), len(pos), int(L)))
+
+
+def filter_recomb_pairs(seqs, rows, cols, n_threads=1):
+    """Filtered SNP distance (src/pairsnp.hpp:251-318) of the listed pairs.  PARITY UNPINNED (Boost)."""
+    seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+    n, L = seqs.shape
+    planes = pack(seqs)
+    r = np.ascontiguousarray(rows, dtype=np.uint64)
+    c = np.ascontiguousarray(cols, dtype=np.uint64)
+    out = np.zeros(len(r), np.uint64)
+    if len(r):
+        lib().orc_filter_recomb_pairs(_u64p(planes), n, L, _u64p(r), _u64p(c), len(r), n_threads, _u64p(out))
+    return out
+
+
 def pairsnp(fasta, n_threads, dist, filter):
-    """Oracle twin of TRACS.pairsnp (src/pairsnp.hpp:320-457, filter=False only)."""
+    """Oracle twin of TRACS.pairsnp (src/pairsnp.hpp:320-457)."""
     if len(fasta) < 1 or len(fasta) > 2:
         raise RuntimeError("Invalid number of fasta files!")
-    if filter:
-        raise NotImplementedError("oracle: filter_recomb is unpinned (Boost binomial)")
     names, seqs = read_fasta(fasta[0])
     n0 = None
     if len(fasta) == 2:
@@ -178,7 +204,8 @@ def pairsnp(fasta, n_threads, dist, filter):
             raise RuntimeError("oracle: the two files differ in alignment length")
         seqs = np.concatenate([seqs, seqs2], axis=0)
     r, c, d, nn = pairsnp_arrays(seqs, n0=n0, dist=dist, n_threads=n_threads)
-    return (r.tolist(), c.tolist(), d.tolist(), names, [0] * len(d), nn.tolist())
+    filt = filter_recomb_pairs(seqs, r, c, n_threads).tolist() if filter else [0] * len(d)
+    return (r.tolist(), c.tolist(), d.tolist(), names, filt, nn.tolist())
 
 
 def pairsnp_rows_checksum(planes, L, n_rows, n_threads):

@@ -525,3 +525,113 @@ int orc_num_threads(void)
     return 1;
 #endif
 }
+
+/* ------------------------------------------------------------------------- */
+/* Recombination filter.  src/pairsnp.hpp:223-318 (filter_recomb, range_count) with
+ * cached_binomial_cdf (:41-58) = boost::math::cdf(binomial_distribution(n, p), k).
+ * PARITY UNPINNED: Boost is absent and the reference's golden input (long_filt.aln,
+ * tests/test_pairsnp.py:14-21) is not in the tree.  Boost documents
+ *   cdf(binomial(n, p), k) = ibetac(k + 1, n - k, p)  for k < n,  1 for k = n;
+ * here ibetac comes from the Lentz continued fraction for the regularised incomplete
+ * beta function (checked against scipy.stats.binom.cdf in tests/test_filter_recomb.py). */
+static double betacf(double a, double b, double x)
+{
+    const double FPMIN = 1e-300, EPS = 1e-16;
+    double qab = a + b, qap = a + 1.0, qam = a - 1.0, c = 1.0, d = 1.0 - qab * x / qap;
+    if (fabs(d) < FPMIN) d = FPMIN;
+    d = 1.0 / d;
+    double h = d;
+    for (int m = 1; m <= 100000; m++) {
+        int m2 = 2 * m;
+        double aa = m * (b - m) * x / ((qam + m2) * (a + m2));
+        d = 1.0 + aa * d; if (fabs(d) < FPMIN) d = FPMIN;
+        c = 1.0 + aa / c; if (fabs(c) < FPMIN) c = FPMIN;
+        d = 1.0 / d; h *= d * c;
+        aa = -(a + m) * (qab + m) * x / ((a + m2) * (qap + m2));
+        d = 1.0 + aa * d; if (fabs(d) < FPMIN) d = FPMIN;
+        c = 1.0 + aa / c; if (fabs(c) < FPMIN) c = FPMIN;
+        d = 1.0 / d;
+        double del = d * c;
+        h *= del;
+        if (fabs(del - 1.0) < EPS) break;
+    }
+    return h;
+}
+
+static double ibeta_reg(double a, double b, double x)      /* I_x(a, b) */
+{
+    if (x <= 0.0) return 0.0;
+    if (x >= 1.0) return 1.0;
+    double bt = exp(lgamma(a + b) - lgamma(a) - lgamma(b) + a * log(x) + b * log1p(-x));
+    if (x < (a + 1.0) / (a + b + 2.0)) return bt * betacf(a, b, x) / a;
+    return 1.0 - bt * betacf(b, a, 1.0 - x) / b;
+}
+
+double orc_binomial_cdf(int n, double p, int k)
+{
+    if (k >= n) return 1.0;
+    if (k < 0) return 0.0;
+    return 1.0 - ibeta_reg((double)k + 1.0, (double)(n - k), p);      /* ibetac(k+1, n-k, p) */
+}
+
+/* positions[] = sorted SNP sites of one pair (the set bits of the flipped match set, :254). */
+uint64_t orc_filter_recomb_positions(const int64_t *pos, int64_t d_count, int64_t aln_length)
+{
+    double d = (double)d_count;
+    if (d <= 1) return (uint64_t)d_count;                                   /* :259-261 */
+    double p = d / (double)aln_length;                                      /* :265 */
+    double p_value_threshold = 0.05 / d;                                    /* :266 */
+    int window_size_half = (int)(1.0 / p / 2.0 + 1);                        /* :269 */
+    if (window_size_half > 5000) window_size_half = 5000;                   /* :270 */
+    if (window_size_half < 50) window_size_half = 50;                       /* :271 */
+    uint64_t filtered_d = 0;
+    for (int64_t t = 0; t < d_count; t++) {                                 /* :281 */
+        int i = (int)pos[t];
+        int64_t left = i - window_size_half; if (left < 0) left = 0;        /* :284 */
+        int64_t right = (int64_t)i + window_size_half + 1; if (right > aln_length) right = aln_length;   /* :285 */
+        /* range_count :223-248: scan from the first set bit; count those in [left, right), span first..last */
+        int64_t count = 0, first = 0, length = 0;
+        for (int64_t u = 0; u < d_count && pos[u] < right; u++)
+            if (pos[u] >= left) {
+                if (count == 0) first = pos[u];
+                count++;
+                length = pos[u] - first + 1;
+            }
+        if (count > 1) {                                                    /* :294-309 */
+            double p_value = 1.0 - orc_binomial_cdf((int)length, p, (int)count);
+            if (p_value >= p_value_threshold) filtered_d++;
+        } else {
+            filtered_d++;
+        }
+    }
+    return filtered_d;
+}
+
+/* filtered distance of every listed pair: planes as orc_pack; rows/cols index samples. */
+void orc_filter_recomb_pairs(const uint64_t *planes, size_t n, size_t L, const uint64_t *rows, const uint64_t *cols,
+                             size_t n_pairs, int n_threads, uint64_t *filt)
+{
+    size_t W = orc_words(L);
+    const uint64_t *A = planes, *C = planes + n * W, *G = planes + 2 * n * W, *T = planes + 3 * n * W;
+    if (n_threads < 1) n_threads = 1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
+    for (int64_t t = 0; t < (int64_t)n_pairs; t++) {
+        size_t i = rows[t], j = cols[t];
+        int64_t cap = 1024, cnt = 0;
+        int64_t *pos = (int64_t *)malloc(cap * sizeof(int64_t));
+        for (size_t w = 0; w < W; w++) {
+            uint64_t m = (A[i * W + w] & A[j * W + w]) | (C[i * W + w] & C[j * W + w]) | (G[i * W + w] & G[j * W + w]) |
+                         (T[i * W + w] & T[j * W + w]);
+            uint64_t snp = ~m;                                              /* res.flip() :254 (L bits only) */
+            if (w == W - 1 && (L & 63)) snp &= (1ull << (L & 63)) - 1;
+            while (snp) {
+                int b = __builtin_ctzll(snp);
+                snp &= snp - 1;
+                if (cnt == cap) { cap *= 2; pos = (int64_t *)realloc(pos, cap * sizeof(int64_t)); }
+                pos[cnt++] = (int64_t)(w * 64 + b);
+            }
+        }
+        filt[t] = orc_filter_recomb_positions(pos, cnt, (int64_t)L);
+        free(pos);
+    }
+}
