@@ -46,7 +46,7 @@ int tracs_device_count(void);
  *   fasta: 1 path (all i<j) or 2 paths (file0 x file1 only, pairsnp.hpp:352-360); plain or gzip.
  *   n_threads: accepted for signature parity; the pair loop runs on the GPU.
  *   dist: emit pairs with d <= dist (signed int compare, pairsnp.hpp:405).
- *   filter: recombination filter (pairsnp.hpp:251-318); 0 => filt_distances are `len` zeros
+ *   filter: recombination filter (pairsnp.hpp:251-318; parity unpinned); 0 => filt_distances are `len` zeros
  *           (pairsnp.hpp:452 with combine_vectors :31).
  * The result is an opaque handle read through the accessors below; rows/cols/... are
  * row-major (i, then j) like the reference (pairsnp.hpp:451-455).                         */
@@ -127,6 +127,14 @@ int tracs_coo_count(const uint32_t *dist, size_t ld, size_t n, size_t row_begin,
 int tracs_coo_fill(const uint32_t *dist, const uint32_t *ncomp, size_t ld, size_t n, size_t row_begin,
                    size_t row_end, size_t col_begin, int32_t dist_threshold, const int64_t *offsets,
                    uint32_t *rows, uint32_t *cols, uint32_t *d, uint32_t *nn, void *stream);
+
+/* Recombination filter (src/pairsnp.hpp:251-318) on emitted pairs.  rows/cols: device uint32[n_pairs];
+ * pos_off: device int64[n_pairs+1] = exclusive scan of the pairs' SNP distances; positions: device uint32
+ * workspace of pos_off[n_pairs] entries (receives each pair's sorted SNP sites); found[t] = SNP bits seen
+ * (equals the distance); filt[t] = filtered distance.                                                  */
+int tracs_filter_recomb_device(const tracs_alignment *a, const uint32_t *rows, const uint32_t *cols, size_t n_pairs,
+                               const int64_t *pos_off, uint32_t *positions, uint32_t *found, uint32_t *filt,
+                               void *stream);
 
 /* transcluster on device arrays (same math as tracs_trans_dist).  workspace is managed
  * internally (hipMallocAsync on the stream).  exp_p0 != 0 writes exp(p0) (what

@@ -184,7 +184,9 @@ def python_reference():
         synth.write_fasta(q, seqs[:9], names=names[:9], gz=True)
         runs = {"meta": ["--msa", msa, "--meta", meta], "nometa": ["--msa", msa],
                 "meta_thr": ["--msa", msa, "--meta", meta, "-D", "6", "-K", "12", "--clock_rate", "5.3", "--trans_rate", "6.0"],
-                "msadb": ["--msa", q, "--msa-db", db, "--meta", meta, "-D", "40"]}
+                "msadb": ["--msa", q, "--msa-db", db, "--meta", meta, "-D", "40"],
+                "filter": ["--msa", msa, "--meta", meta, "--filter", "--clock_rate", "5.3", "--trans_rate", "6.0"],
+                "filter_nometa": ["--msa", msa, "--filter", "-D", "30"]}
         csvs = {}
         for key, argv in runs.items():
             o = os.path.join(td, key + ".csv")

@@ -1,0 +1,124 @@
+"""Recombination filter (src/pairsnp.hpp:223-318).  PARITY UNPINNED: the reference needs Boost's binomial CDF
+and its golden input long_filt.aln is not in the tree, so the oracle is checked against first principles
+(scipy's binomial CDF, an independent Python restatement) and the GPU against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+
+def _py_filter(pos, L):
+    """Independent restatement of filter_recomb with scipy's binomial CDF."""
+    from scipy.stats import binom
+    d = len(pos)
+    if d <= 1:
+        return d
+    p = d / L
+    thr = 0.05 / d
+    w = max(min(int(1.0 / p / 2.0 + 1), 5000), 50)
+    kept = 0
+    pos = np.asarray(pos)
+    for i in pos:
+        left, right = max(0, i - w), min(L, i + w + 1)
+        inside = pos[(pos >= left) & (pos < right)]
+        if len(inside) > 1:
+            n = int(inside[-1] - inside[0] + 1)
+            if 1.0 - binom.cdf(len(inside), n, p) >= thr:
+                kept += 1
+        else:
+            kept += 1
+    return kept
+
+
+def test_oracle_binomial_cdf_vs_scipy(oracle):
+    from scipy.stats import binom
+    rng = np.random.default_rng(1)
+    for _ in range(2000):
+        n = int(rng.integers(1, 10002))
+        p = float(rng.choice([1e-6, 1e-4, 2e-3, 0.05, 0.3]))
+        k = int(rng.integers(0, min(n, 80) + 1))
+        assert abs(oracle.binomial_cdf(n, p, k) - binom.cdf(k, n, p)) < 1e-9
+
+
+def test_oracle_filter_vs_python_restatement(oracle):
+    rng = np.random.default_rng(2)
+    for L, d, block in ((100000, 30, 0), (100000, 30, 25), (2000000, 400, 150), (5000, 2, 0), (5000, 1, 0), (5000, 0, 0)):
+        pos = set(rng.choice(L, size=d, replace=False).tolist())
+        if block:
+            start = int(rng.integers(0, L - 600))
+            pos |= set((start + rng.choice(500, size=block, replace=False)).tolist())
+        pos = sorted(pos)
+        assert oracle.filter_recomb_positions(pos, L) == _py_filter(pos, L)
+
+
+def test_oracle_filter_removes_a_planted_block(oracle):
+    from tracs_amd import synth
+    L = 150000
+    seqs = synth.alignment(5, L, seed=3, mu_lineage=3e-4, mu_sample=1e-4, p_n=0.0)
+    lut = np.zeros(256, np.uint8)
+    for a, b in zip(b"ACGT", b"CGTA"):
+        lut[a] = b
+    seqs[1, 60000:60300] = lut[seqs[1, 60000:60300]]          # 300 consecutive substitutions in sample 1
+    r, c, d, _ = oracle.pairsnp_arrays(seqs)
+    f = oracle.filter_recomb_pairs(seqs, r, c, 2)
+    for ri, ci, di, fi in zip(r, c, d, f):
+        assert fi <= di
+        if 1 in (ri, ci):
+            assert di >= 300 and fi <= di - 290          # the block is filtered out
+    out = oracle.pairsnp([_write(seqs)], 1, 2147483647, True)
+    assert out[4] == f.tolist()
+
+
+def _write(seqs):
+    import tempfile
+    from tracs_amd import synth
+    p = os.path.join(tempfile.mkdtemp(), "f.fa")
+    synth.write_fasta(p, seqs)
+    return p
+
+
+@pytest.mark.gpu
+def test_gpu_filter_matches_oracle(oracle, hiplib, tmp_path):
+    import torch  # noqa: F401
+    from tracs_amd import api, synth
+    L = 120000
+    seqs = synth.alignment(24, L, seed=8, mu_lineage=4e-4, mu_sample=1e-4, p_n=0.01, p_partial=0.002)
+    lut = np.zeros(256, np.uint8)
+    for a, b in zip(b"ACGTN", b"CGTAN"):
+        lut[a] = b
+    seqs[3, 1000:1200] = lut[seqs[3, 1000:1200]]
+    seqs[7, L - 150:] = lut[seqs[7, L - 150:]]                   # block touching the end of the alignment
+    fa = os.path.join(str(tmp_path), "f.fa")
+    synth.write_fasta(fa, seqs, width=70)
+    med = int(np.median(oracle.pairsnp_arrays(seqs)[2]))
+    for dist in (2147483647, med):
+        r, c, d, names, filt, nn = api.pairsnp_arrays([fa], 1, dist, True)
+        er, ec, ed, enn = oracle.pairsnp_arrays(seqs, dist=dist)
+        assert np.array_equal(r, er) and np.array_equal(c, ec) and np.array_equal(d, ed) and np.array_equal(nn, enn)
+        ef = oracle.filter_recomb_pairs(seqs, er, ec, 4)
+        assert np.array_equal(filt, ef), np.where(filt != ef)
+        assert len(d) > 10 and (filt <= d).all() and (filt < d).any()
+    out = api.pairsnp(fasta=[fa], n_threads=1, dist=med, filter=True)
+    assert out[4] == ef.tolist() and all(isinstance(v, int) for v in out[4])
+
+
+@pytest.mark.gpu
+def test_gpu_filter_positions_are_the_snp_sites(oracle, hiplib):
+    import torch
+    from tracs_amd import device as dev
+    from tracs_amd import synth
+    L, n = 70001, 9
+    seqs = synth.alignment(n, L, seed=5, mu_lineage=1e-3, mu_sample=3e-4, p_n=0.02, p_partial=0.01, p_lower=0.1)
+    aln = dev.Alignment(n, L)
+    aln.pack(seqs)
+    r, c, d, _ = oracle.pairsnp_arrays(seqs)
+    rows = torch.from_numpy(r.astype(np.int32)).cuda()
+    cols = torch.from_numpy(c.astype(np.int32)).cuda()
+    dd = torch.from_numpy(d.astype(np.int32)).cuda()
+    filt, found, pos, off = dev.filter_recomb_device(aln, rows, cols, dd)
+    assert np.array_equal(found.cpu().numpy(), d.astype(np.int32))
+    m = oracle._MASK[seqs]
+    pos, off = pos.cpu().numpy(), off.cpu().numpy()
+    for t in range(len(r)):
+        sites = np.nonzero((m[r[t]] & m[c[t]]) == 0)[0]
+        assert np.array_equal(pos[off[t]:off[t + 1]], sites.astype(np.int32))

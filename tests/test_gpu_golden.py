@@ -121,7 +121,7 @@ def test_cli_end_to_end_vs_reference_driver(api, golden_dir, tmp_path, monkeypat
     pyref = _load(golden_dir, "python_reference_golden.json")
     td = str(tmp_path)
     _materialise(pyref, td)
-    for run in ("meta", "nometa", "meta_thr", "msadb"):
+    for run in ("meta", "nometa", "meta_thr", "msadb", "filter", "filter_nometa"):
         r = pyref["distance"]["runs"][run]
         out = os.path.join(td, run + ".csv")
         monkeypatch.setattr(sys, "argv", ["d"] + [a.replace("TMP", td) for a in r["argv"]] + ["-o", out, "--loglevel", "ERROR"])

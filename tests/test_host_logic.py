@@ -61,7 +61,7 @@ def _rows_equal(got, exp, float_cols=(2, 4, 5)):
                 assert fa[c] == fb[c], (a, b)
 
 
-@pytest.mark.parametrize("run", ["meta", "nometa", "meta_thr", "msadb"])
+@pytest.mark.parametrize("run", ["meta", "nometa", "meta_thr", "msadb", "filter", "filter_nometa"])
 def test_distance_cli_csv_matches_reference_driver(pyref, oracle_kernels, tmp_path, monkeypatch, run):
     from tracs_amd import distance
     td = str(tmp_path)

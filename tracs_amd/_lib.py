@@ -20,7 +20,7 @@ SYMBOLS = [
     "tracs_alignment_create", "tracs_alignment_free", "tracs_alignment_n", "tracs_alignment_len",
     "tracs_alignment_bytes", "tracs_alignment_planes", "tracs_alignment_pack", "tracs_alignment_from_fasta",
     "tracs_free",
-    "tracs_pairsnp_dense", "tracs_coo_count", "tracs_coo_fill",
+    "tracs_pairsnp_dense", "tracs_coo_count", "tracs_coo_fill", "tracs_filter_recomb_device",
     "tracs_trans_dist_device", "tracs_trans_dist_dense",
     "tracs_calculate_posteriors_device", "tracs_posterior_codes_device",
     "tracs_connected_components_device",
@@ -110,6 +110,8 @@ def load():
     L.tracs_coo_count.argtypes = [vp, sz, sz, sz, sz, sz, i32, vp, vp]
     L.tracs_coo_fill.restype = C.c_int
     L.tracs_coo_fill.argtypes = [vp, vp, sz, sz, sz, sz, sz, i32, vp, vp, vp, vp, vp, vp]
+    L.tracs_filter_recomb_device.restype = C.c_int
+    L.tracs_filter_recomb_device.argtypes = [vp, vp, vp, sz, vp, vp, vp, vp, vp]
     L.tracs_trans_dist_device.restype = C.c_int
     L.tracs_trans_dist_device.argtypes = [vp, vp, sz, dbl, dbl, dbl, C.c_int, vp, vp, vp]
     L.tracs_trans_dist_dense.restype = C.c_int

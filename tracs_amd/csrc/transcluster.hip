@@ -394,6 +394,8 @@ static int get_lgamma_table(hipStream_t stream, const double **out)
     return TRACS_OK;
 }
 
+int get_lgamma_table_for_filter(hipStream_t stream, const double **out) { return get_lgamma_table(stream, out); }
+
 struct TcWorkspaceIds { enum { SLOTS = 0, ESLOT, SLOT_ID, NKEYS, KEY_ELEM, KEY_P0, KEY_EK, LONG_IDS }; };
 
 template <class Src>

@@ -101,6 +101,21 @@ def coo_from_dense(dist, ncomp, n, dist_threshold=2147483647, row_begin=0, row_e
     return out
 
 
+def filter_recomb_device(aln, rows, cols, d):
+    """rows/cols/d: torch.int32 device vectors of emitted pairs -> filtered distances (torch.int32)."""
+    L = _lib.require_gpu()
+    n = rows.numel()
+    off = torch.zeros(n + 1, dtype=torch.int64, device=rows.device)
+    off[1:] = torch.cumsum(d.to(torch.int64), 0)
+    total = int(off[n].item()) if n else 0
+    pos = torch.empty(max(total, 1), dtype=torch.int32, device=rows.device)
+    found = torch.empty(max(n, 1), dtype=torch.int32, device=rows.device)
+    filt = torch.empty(max(n, 1), dtype=torch.int32, device=rows.device)
+    _lib.check(L.tracs_filter_recomb_device(aln._h, _ptr(rows), _ptr(cols), n, _ptr(off), _ptr(pos), _ptr(found), _ptr(filt),
+                                            _stream()))
+    return filt[:n], found[:n], pos[:total], off
+
+
 def trans_dist_device(snpdiff, datediff, lamb, beta, threshold_Ek, exp_p0=False):
     L = _lib.require_gpu()
     n = snpdiff.numel()
