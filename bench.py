@@ -26,7 +26,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12            # B/s, MI355X HBM3E spec (MI355X_MICROARCH.md "Chip-level parameters")
-VALU_PEAK = 256 * 4 * 32 * 2.4e9   # 32-bit lane-ops/s: 256 CU x 4 SIMD32 x 2.4 GHz
+VALU_PEAK = 256 * 4 * 32 * 2.4e9   # 32-bit lane-ops/s: 256 CU x 4 SIMD32 x 2.4 GHz (nominal FP32-vector issue rate)
+# Per encoding: VALU ops per 32 sites and pair, algorithmic bytes per pair as a fraction of L, and the
+# rate a register-only loop of exactly that instruction mix sustains on MI355X (scripts/micro/valu_ops.hip,
+# profiles/r01/valu_ops_microbench.txt) -- the practical issue ceiling of the kernel.
+ENCODINGS = {"general": {"ops": 7, "bytes_per_site": 1.0, "mix_ceiling": 44.3e12},
+             "consensus": {"ops": 6, "bytes_per_site": 0.75, "mix_ceiling": 49.7e12}}
 
 
 def parse():
@@ -124,16 +129,20 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = pairs_total * args.steps / elapsed
-        alg_bytes = float(my_pairs_per_launch) * L                       # general IUPAC encoding, L bytes per pair
-        lane_ops = float(my_pairs_per_launch) * ((L + 127) // 128) * 4 * 7
+        enc = aln.encoding or "general"
+        E = ENCODINGS[enc]
+        alg_bytes = float(my_pairs_per_launch) * L * E["bytes_per_site"]   # L (general) / 0.75 L (consensus) per pair
+        lane_ops = float(my_pairs_per_launch) * ((L + 127) // 128) * 4 * E["ops"]
         roof = {"bound": "hbm", "achieved": alg_bytes / kern_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": alg_bytes / kern_s / HBM_PEAK, "traffic": _traffic_from_profiles(n, L, world),
-                "kernel": "pairsnp_tile_kernel", "kernel_ms": kern_s * 1e3,
-                "algorithmic_bytes_per_pair": L,
+                "kernel": "pairsnp_tile_kernel", "kernel_ms": kern_s * 1e3, "encoding": enc,
+                "algorithmic_bytes_per_pair": L * E["bytes_per_site"],
                 "note": "algorithmic bytes are re-used from LDS/L2 tiles, so achieved > HBM peak is expected; "
                         "the binding limit is integer VALU (see valu)",
                 "valu": {"achieved": lane_ops / kern_s / 1e12, "peak": VALU_PEAK / 1e12, "unit": "Tlane-op/s",
-                         "frac": lane_ops / kern_s / VALU_PEAK, "ops_per_32_sites_per_pair": 7}}
+                         "frac": lane_ops / kern_s / VALU_PEAK, "ops_per_32_sites_per_pair": E["ops"],
+                         "measured_mix_ceiling": E["mix_ceiling"] / 1e12,
+                         "frac_of_measured_mix_ceiling": lane_ops / kern_s / E["mix_ceiling"]}}
         out = {"metric": "sample-pairs/sec for 10kx5Mbp SNP+transcluster distance", "value": value,
                "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,

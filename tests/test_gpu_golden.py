@@ -194,22 +194,58 @@ def test_dense_coo_and_transcluster_device(dev, oracle, torch_mod):
     aln.close()
 
 
+def test_encoding_selection_and_consensus_parity(dev, oracle, torch_mod):
+    """ACGT + anything-that-means-N (N, n, -, ?, lower case) takes the 3-plane consensus kernel; a single partial
+    IUPAC code anywhere sends the whole alignment to the general kernel.  Both must equal the oracle."""
+    from tracs_amd import synth
+    torch = torch_mod
+    n, L = 150, 9000
+    seqs = synth.alignment(n, L, seed=41, mu_lineage=0.01, mu_sample=0.004, p_n=0.03, p_lower=0.2, p_other=0.02)
+    er, ec, ed, enn = oracle.pairsnp_arrays(seqs)
+    ri, ci = er.astype(np.int64), ec.astype(np.int64)
+    aln = dev.Alignment(n, L)
+    aln.pack(seqs)
+    assert aln.encoding is None
+    for with_nn in (True, False):
+        d = torch.zeros((n, n), dtype=torch.int32, device="cuda")
+        nn = torch.zeros((n, n), dtype=torch.int32, device="cuda") if with_nn else None
+        dev.pairsnp_dense(aln, d, nn)
+        assert aln.encoding == "consensus"
+        assert np.array_equal(d.cpu().numpy()[ri, ci], ed.astype(np.int32))
+        if with_nn:
+            assert np.array_equal(nn.cpu().numpy()[ri, ci], enn.astype(np.int32))
+    seqs2 = seqs.copy()
+    seqs2[77, 4321] = ord("r")                                     # one partial code
+    aln.pack(seqs2[77:78], first=77)
+    assert aln.encoding is None
+    d = torch.zeros((n, n), dtype=torch.int32, device="cuda")
+    nn = torch.zeros((n, n), dtype=torch.int32, device="cuda")
+    dev.pairsnp_dense(aln, d, nn)
+    assert aln.encoding == "general"
+    er, ec, ed, enn = oracle.pairsnp_arrays(seqs2)
+    assert np.array_equal(d.cpu().numpy()[ri, ci], ed.astype(np.int32)) and np.array_equal(nn.cpu().numpy()[ri, ci], enn.astype(np.int32))
+    aln.close()
+
+
 def test_split_group_range_small_n_long_L(dev, oracle, torch_mod):
     """Few tiles + long alignment: the group range is split over workgroups (atomic accumulation path)."""
     from tracs_amd import synth
     torch = torch_mod
     n, L = 40, 300000
-    seqs = synth.alignment(n, L, seed=77, mu_lineage=2e-4, mu_sample=1e-4, p_n=0.01)
-    aln = dev.Alignment(n, L)
-    aln.pack(seqs)
-    d = torch.zeros((n, n), dtype=torch.int32, device="cuda")
-    nn = torch.zeros((n, n), dtype=torch.int32, device="cuda")
-    for _ in range(2):                                            # twice: the init pass must reset the cells
-        dev.pairsnp_dense(aln, d, nn)
-    er, ec, ed, enn = oracle.pairsnp_arrays(seqs, n_threads=8)
-    ri, ci = er.astype(np.int64), ec.astype(np.int64)
-    assert np.array_equal(d.cpu().numpy()[ri, ci], ed.astype(np.int32))
-    assert np.array_equal(nn.cpu().numpy()[ri, ci], enn.astype(np.int32))
+    for p_partial, enc in ((0.0, "consensus"), (0.001, "general")):
+        seqs = synth.alignment(n, L, seed=77, mu_lineage=2e-4, mu_sample=1e-4, p_n=0.01, p_partial=p_partial)
+        aln = dev.Alignment(n, L)
+        aln.pack(seqs)
+        d = torch.zeros((n, n), dtype=torch.int32, device="cuda")
+        nn = torch.zeros((n, n), dtype=torch.int32, device="cuda")
+        for _ in range(2):                                        # twice: the init pass must reset the cells
+            dev.pairsnp_dense(aln, d, nn)
+        assert aln.encoding == enc
+        er, ec, ed, enn = oracle.pairsnp_arrays(seqs, n_threads=8)
+        ri, ci = er.astype(np.int64), ec.astype(np.int64)
+        assert np.array_equal(d.cpu().numpy()[ri, ci], ed.astype(np.int32))
+        assert np.array_equal(nn.cpu().numpy()[ri, ci], enn.astype(np.int32))
+        aln.close()
 
 
 def test_properties_at_scale(dev, oracle, torch_mod):

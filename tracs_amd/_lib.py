@@ -122,6 +122,9 @@ def load():
     L.tracs_posterior_codes_device.argtypes = [vp, sz, dp, C.c_int, dbl, vp, vp]
     L.tracs_connected_components_device.restype = C.c_int
     L.tracs_connected_components_device.argtypes = [vp, vp, sz, sz, vp, C.POINTER(i32), vp]
+    L.tracs_debug_alignment_encoding.restype = C.c_int
+    L.tracs_debug_alignment_encoding.argtypes = [vp]
+    L.tracs_debug_tile_variant.restype = C.c_char_p
     L.tracs_debug_iupac_mask.restype = C.c_int
     L.tracs_debug_iupac_mask.argtypes = [C.c_int]
     _lib = L

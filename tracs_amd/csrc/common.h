@@ -37,7 +37,11 @@ static inline size_t pad_samples(size_t n) { return (n + SAMPLE_PAD - 1) / SAMPL
 
 struct tracs_alignment {
     size_t n = 0, L = 0, n_pad = 0, groups = 0;
-    uint4 *planes = nullptr;     // device
+    uint4 *planes = nullptr;     // device: general encoding, 5 planes
+    uint4 *cplanes = nullptr;    // device: consensus encoding, 3 planes (derived on demand, only if valid)
+    unsigned *d_flag = nullptr;  // device: "some site has a partial IUPAC code"
+    bool dirty = true;           // packed since the encoding was last decided
+    int enc = 0;                 // 0 general, 1 consensus
     // cached tile schedule for the last dense region (device + host mirror)
     int2 *d_tiles = nullptr;
     size_t n_tiles = 0, tiles_cap = 0;

@@ -16,6 +16,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <vector>
 
@@ -100,14 +101,17 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nwg)
 }
 
 // (x & v) | m in ONE VALU op.  Left to itself hipcc re-associates the four-plane OR into
-// and, and_or, and, and, or3 (6 ops with the popcount); the asm pins and + 3 x and_or (5 ops).
-// SCALAR: `x` is a wave-uniform row word held in an SGPR (VOP3 on gfx9 takes one scalar source).
+// and, and_or, and, and, or3 (6 ops with the popcount); the asm pins and + 3 fused ops (5 ops).
+// Which fused op matters (scripts/micro/valu_ops.hip, profiles/r01/valu_ops_microbench.txt): gfx950's
+// v_bitop3_b32 (any 3-input boolean function, here truth table 0xEA = (a & b) | c) issues at the rate of a plain
+// v_and_b32 when all three sources are VGPRs, while v_and_or_b32 / v_or3_b32 / v_bcnt_u32_b32 -- and ANY op with an
+// SGPR source -- take ~1.6x as long.  SCALAR (row word in an SGPR) keeps v_and_or_b32: it is in the slow class anyway.
 template <bool SCALAR>
 __device__ __forceinline__ unsigned and_or(unsigned x, unsigned v, unsigned m)
 {
     unsigned r;
     if (SCALAR) asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "s"(x), "v"(v), "v"(m));
-    else asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(v), "v"(m));
+    else asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xea" : "=v"(r) : "v"(x), "v"(v), "v"(m));
     return r;
 }
 
@@ -136,20 +140,25 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
 
 // GLDS: stage with global_load_lds_dwordx4 (HBM/L2 -> LDS directly, no staging VGPRs, no ds_write)
-template <int NW, int R, int C, int GC, bool WITH_NN, int ROWSRC, int MINW = 1, bool GLDS = false>
+// ENC = 0: general IUPAC encoding, 5 planes (A, C, G, T, N), 24 issue cycles per 32 sites and pair.
+// ENC = 1: consensus encoding, 3 planes (X = base bit 0, Y = base bit 1, V = site is an unambiguous base), valid when
+//          every site of every sample is A/C/G/T or fully ambiguous: d = popc(((Xi^Xj)|(Yi^Yj)) & Vi & Vj),
+//          nn = popc(Vi & Vj): VOP2 logic only, 18 issue cycles, 3/5 of the bytes.
+template <int NW, int R, int C, int GC, bool WITH_NN, int ROWSRC, int MINW = 1, bool GLDS = false, int ENC = 0>
 __global__ __launch_bounds__(NW * 64, MINW) void pairsnp_tile_kernel(
     const uint4 *__restrict__ P, size_t n_pad, int groups, const int2 *__restrict__ tiles, int n_tiles,
     int groups_per_split, int ksplit, unsigned L, unsigned n, unsigned row_end, unsigned col_begin,
     unsigned *__restrict__ dist, unsigned *__restrict__ ncomp, size_t ld)
 {
+    constexpr int NP = ENC ? 3 : NPLANES;                   // planes of this encoding
     constexpr int NT = NW * 64;
     constexpr int TI = NW * R;
     constexpr int TJ = 64 * C;
     constexpr int TS = TJ + (ROWSRC == ROW_LDS ? TI : 0);   // samples staged per (group, plane)
-    constexpr int STAGE = GC * NPLANES * TS;                // uint4 per LDS stage
+    constexpr int STAGE = GC * NP * TS;                // uint4 per LDS stage
     constexpr int LPT = (STAGE + NT - 1) / NT;              // staging loads per thread
     constexpr bool SC = ROWSRC != ROW_LDS;   // row operands are scalar (SGPR)
-    constexpr int NPL = WITH_NN ? NPLANES : 4;
+    constexpr int NPL = ENC ? 3 : (WITH_NN ? NP : 4);    // planes actually read
     __shared__ uint4 lds[2][STAGE];
 
     const unsigned q = xcd_remap(blockIdx.x, gridDim.x);
@@ -177,9 +186,9 @@ __global__ __launch_bounds__(NW * 64, MINW) void pairsnp_tile_kernel(
             if (STAGE % NT == 0 || e0 < STAGE) {
                 const int gp = e0 / TS;
                 const int sidx = e0 - gp * TS + lane;
-                if (gs + gp / NPLANES < g_end) {
+                if (gs + gp / NP < g_end) {
                     const size_t smp = sidx < TJ ? (size_t)j0 + sidx : (size_t)i0 + (sidx - TJ);
-                    __builtin_amdgcn_global_load_lds((glb_void_t *)(P + ((size_t)gs * NPLANES + gp) * n_pad + smp),
+                    __builtin_amdgcn_global_load_lds((glb_void_t *)(P + ((size_t)gs * NP + gp) * n_pad + smp),
                                                      (lds_void_t *)&lds[b][e0], 16, 0, 0);
                 }
             }
@@ -192,11 +201,11 @@ __global__ __launch_bounds__(NW * 64, MINW) void pairsnp_tile_kernel(
             const int e = tid + k * NT;
             const int gp = e / TS;               // local group*5 + plane
             const int sidx = e - gp * TS;
-            const int g = gs + gp / NPLANES;
+            const int g = gs + gp / NP;
             uint4 v = make_uint4(0, 0, 0, 0);
             if ((STAGE % NT == 0 || e < STAGE) && g < g_end) {
                 const size_t smp = sidx < TJ ? (size_t)j0 + sidx : (size_t)i0 + (sidx - TJ);
-                v = P[((size_t)gs * NPLANES + gp) * n_pad + smp];
+                v = P[((size_t)gs * NP + gp) * n_pad + smp];
             }
             stage_regs[k] = v;
         }
@@ -209,24 +218,38 @@ __global__ __launch_bounds__(NW * 64, MINW) void pairsnp_tile_kernel(
         }
     };
     // one row batch (RB rows, all planes) against the lane's C columns
-    auto consume = [&](const uint4 (*ai)[NPLANES], int r0, int nrows, const uint4 (&bj)[C][NPLANES]) {
+    auto consume = [&](const uint4 (*ai)[NP], int r0, int nrows, const uint4 (&bj)[C][NP]) {
 #pragma unroll
         for (int rr = 0; rr < nrows; rr++) {
             const int r = r0 + rr;
+            if (ENC) {
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+#define TRACS_CONS_WORD(W)                                                                              \
+                    {                                                                                   \
+                        const unsigned v = ai[rr][2].W & bj[c][2].W;                                    \
+                        if (WITH_NN) accN[r][c] += __popc(v);                                           \
+                        accM[r][c] += __popc(((ai[rr][0].W ^ bj[c][0].W) | (ai[rr][1].W ^ bj[c][1].W)) & v); \
+                    }
+                    TRACS_CONS_WORD(x) TRACS_CONS_WORD(y) TRACS_CONS_WORD(z) TRACS_CONS_WORD(w)
+#undef TRACS_CONS_WORD
+                }
+                continue;
+            }
 #pragma unroll
             for (int c = 0; c < C; c++) {
-                pair_words<SC>(ai[rr][0].x, ai[rr][1].x, ai[rr][2].x, ai[rr][3].x, bj[c][0].x, bj[c][1].x, bj[c][2].x, bj[c][3].x, accM[r][c]);
-                pair_words<SC>(ai[rr][0].y, ai[rr][1].y, ai[rr][2].y, ai[rr][3].y, bj[c][0].y, bj[c][1].y, bj[c][2].y, bj[c][3].y, accM[r][c]);
-                pair_words<SC>(ai[rr][0].z, ai[rr][1].z, ai[rr][2].z, ai[rr][3].z, bj[c][0].z, bj[c][1].z, bj[c][2].z, bj[c][3].z, accM[r][c]);
-                pair_words<SC>(ai[rr][0].w, ai[rr][1].w, ai[rr][2].w, ai[rr][3].w, bj[c][0].w, bj[c][1].w, bj[c][2].w, bj[c][3].w, accM[r][c]);
+                pair_words<SC>(ai[rr][0].x, ai[rr][1].x, ai[rr][2].x, ai[rr][3 % NP].x, bj[c][0].x, bj[c][1].x, bj[c][2].x, bj[c][3 % NP].x, accM[r][c]);
+                pair_words<SC>(ai[rr][0].y, ai[rr][1].y, ai[rr][2].y, ai[rr][3 % NP].y, bj[c][0].y, bj[c][1].y, bj[c][2].y, bj[c][3 % NP].y, accM[r][c]);
+                pair_words<SC>(ai[rr][0].z, ai[rr][1].z, ai[rr][2].z, ai[rr][3 % NP].z, bj[c][0].z, bj[c][1].z, bj[c][2].z, bj[c][3 % NP].z, accM[r][c]);
+                pair_words<SC>(ai[rr][0].w, ai[rr][1].w, ai[rr][2].w, ai[rr][3 % NP].w, bj[c][0].w, bj[c][1].w, bj[c][2].w, bj[c][3 % NP].w, accM[r][c]);
             }
             if (WITH_NN) {
 #pragma unroll
                 for (int c = 0; c < C; c++) {
-                    accN[r][c] += __popc(ai[rr][4].x | bj[c][4].x);
-                    accN[r][c] += __popc(ai[rr][4].y | bj[c][4].y);
-                    accN[r][c] += __popc(ai[rr][4].z | bj[c][4].z);
-                    accN[r][c] += __popc(ai[rr][4].w | bj[c][4].w);
+                    accN[r][c] += __popc(ai[rr][4 % NP].x | bj[c][4 % NP].x);
+                    accN[r][c] += __popc(ai[rr][4 % NP].y | bj[c][4 % NP].y);
+                    accN[r][c] += __popc(ai[rr][4 % NP].z | bj[c][4 % NP].z);
+                    accN[r][c] += __popc(ai[rr][4 % NP].w | bj[c][4 % NP].w);
                 }
             }
         }
@@ -236,8 +259,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void pairsnp_tile_kernel(
     constexpr int NB = R / RB;
     static_assert(R % RB == 0, "row batch must divide R");
     const size_t row0 = (size_t)(i0 + wave * R);
-    auto load_rows_global = [&](int g, int b, uint4 (*dst)[NPLANES]) {   // wave-uniform addresses: scalar loads
-        const uint4 *rowp = P + (size_t)g * NPLANES * n_pad + row0 + (size_t)(b * RB);
+    auto load_rows_global = [&](int g, int b, uint4 (*dst)[NP]) {   // wave-uniform addresses: scalar loads
+        const uint4 *rowp = P + (size_t)g * NP * n_pad + row0 + (size_t)(b * RB);
 #pragma unroll
         for (int rr = 0; rr < RB; rr++)
 #pragma unroll
@@ -248,12 +271,12 @@ __global__ __launch_bounds__(NW * 64, MINW) void pairsnp_tile_kernel(
     else { stage_load(g_begin); stage_store(0); }
     __syncthreads();
 
-    uint4 cur[RB][NPLANES];
+    uint4 cur[RB][NP];
     if (PF && g_begin < g_end) load_rows_global(g_begin, 0, cur);
     constexpr bool ROWS_FIXED = ROWSRC == ABL_ROWS_FIXED || ROWSRC == ABL_BOTH_FIXED;
     constexpr bool COLS_FIXED = ROWSRC == ABL_COLS_FIXED || ROWSRC == ABL_BOTH_FIXED;
-    uint4 fixed_rows[NB][RB][NPLANES];
-    uint4 fixed_bj[C][NPLANES];
+    uint4 fixed_rows[NB][RB][NP];
+    uint4 fixed_bj[C][NP];
     if (ROWS_FIXED) {
 #pragma unroll
         for (int b = 0; b < NB; b++) load_rows_global(g_begin, b, fixed_rows[b]);
@@ -273,13 +296,13 @@ __global__ __launch_bounds__(NW * 64, MINW) void pairsnp_tile_kernel(
         for (int gl = 0; gl < GC; gl++) {
             const int g = gs + gl;
             if (g < g_end) {                      // wave-uniform
-                uint4 bj[C][NPLANES];
+                uint4 bj[C][NP];
 #pragma unroll
                 for (int c = 0; c < C; c++)
 #pragma unroll
                     for (int p = 0; p < NPL; p++) {
                         if (COLS_FIXED) { bj[c][p] = fixed_bj[c][p]; bj[c][p].x ^= (unsigned)g; }   // keep it group-dependent
-                        else bj[c][p] = lds[buf][(gl * NPLANES + p) * TS + lane + 64 * c];
+                        else bj[c][p] = lds[buf][(gl * NP + p) * TS + lane + 64 * c];
                     }
 #pragma unroll
                 for (int b = 0; b < NB; b++) {
@@ -289,7 +312,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void pairsnp_tile_kernel(
                         load_rows_global(g, b, cur);
                         consume(cur, b * RB, RB, bj);
                     } else if (PF) {
-                        uint4 nxt[RB][NPLANES];
+                        uint4 nxt[RB][NP];
 #pragma unroll
                         for (int rr = 0; rr < RB; rr++)
 #pragma unroll
@@ -305,7 +328,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void pairsnp_tile_kernel(
                             for (int p = 0; p < NPL; p++) cur[rr][p] = nxt[rr][p];
                     } else {
 #pragma unroll
-                        for (int p = 0; p < NPL; p++) cur[0][p] = lds[buf][(gl * NPLANES + p) * TS + TJ + wave * R + b];
+                        for (int p = 0; p < NPL; p++) cur[0][p] = lds[buf][(gl * NP + p) * TS + TJ + wave * R + b];
                         consume(cur, b, 1, bj);
                     }
                 }
@@ -325,7 +348,15 @@ __global__ __launch_bounds__(NW * 64, MINW) void pairsnp_tile_kernel(
             const unsigned j = (unsigned)(j0 + lane + 64 * c);
             if (j < n && j > i && j >= col_begin) {
                 const size_t o = (size_t)i * ld + j;
-                if (ksplit == 1) {
+                if (ENC) {                                // accumulators hold d and nn themselves
+                    if (ksplit == 1) {
+                        dist[o] = accM[r][c];
+                        if (WITH_NN) ncomp[o] = accN[r][c];
+                    } else {                              // cells were initialised to 0
+                        atomicAdd(&dist[o], accM[r][c]);
+                        if (WITH_NN) atomicAdd(&ncomp[o], accN[r][c]);
+                    }
+                } else if (ksplit == 1) {
                     dist[o] = L - accM[r][c];
                     if (WITH_NN) ncomp[o] = L - accN[r][c];
                 } else {                                  // cells were initialised to L
@@ -443,6 +474,35 @@ __global__ __launch_bounds__(NW * 64) void pairsnp_rowcast_kernel(
             }
         }
     }
+}
+
+// general planes -> consensus planes (+ flag: does any site carry a partial ambiguity code?)
+__global__ __launch_bounds__(256) void derive_consensus_kernel(const uint4 *__restrict__ P, uint4 *__restrict__ Q, size_t n_pad,
+                                                               size_t groups, unsigned *__restrict__ partial_flag)
+{
+    const size_t total = groups * n_pad;
+    unsigned bad = 0;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t g = e / n_pad, s = e - g * n_pad;
+        const uint4 A = P[(g * NPLANES + 0) * n_pad + s], Cc = P[(g * NPLANES + 1) * n_pad + s];
+        const uint4 G = P[(g * NPLANES + 2) * n_pad + s], T = P[(g * NPLANES + 3) * n_pad + s];
+        const uint4 N = P[(g * NPLANES + 4) * n_pad + s];
+        uint4 X, Y, V;
+#define TRACS_DERIVE(W)                                                                         \
+        {                                                                                       \
+            const unsigned two = (A.W & Cc.W) | (A.W & G.W) | (A.W & T.W) | (Cc.W & G.W) | (Cc.W & T.W) | (G.W & T.W); \
+            bad |= two & ~N.W;                          /* 2 or 3 alleles set: IUPAC partial code */ \
+            V.W = (A.W | Cc.W | G.W | T.W) & ~N.W;      /* exactly one allele (tail bits: none) */ \
+            X.W = (Cc.W | T.W) & V.W;                   /* A=00 C=01 G=10 T=11 */              \
+            Y.W = (G.W | T.W) & V.W;                                                            \
+        }
+        TRACS_DERIVE(x) TRACS_DERIVE(y) TRACS_DERIVE(z) TRACS_DERIVE(w)
+#undef TRACS_DERIVE
+        Q[(g * 3 + 0) * n_pad + s] = X;
+        Q[(g * 3 + 1) * n_pad + s] = Y;
+        Q[(g * 3 + 2) * n_pad + s] = V;
+    }
+    if (bad) atomicOr(partial_flag, 1u);
 }
 
 // cells of the block <- L (only needed when the group range is split over workgroups)
@@ -564,24 +624,26 @@ using namespace tracs;
 
 // Kernel variants (tile shape x row-operand source).  TRACS_TILE_VARIANT selects one at run time
 // (default: the fastest measured on MI355X, see DESIGN.md "pairsnp kernel: variants measured").
+typedef void (*TileLaunch)(bool with_nn, unsigned nwg, hipStream_t stream, const uint4 *P, size_t n_pad, int groups,
+                           const int2 *tiles, int n_tiles, int gps, int ksplit, unsigned L, unsigned n, unsigned row_end,
+                           unsigned col_begin, unsigned *dist, unsigned *ncomp, size_t ld);
 struct TileVariant {
     const char *name;
     int ti, tj, gc, nthreads;
-    void (*launch)(bool with_nn, unsigned nwg, hipStream_t stream, const uint4 *P, size_t n_pad, int groups, const int2 *tiles,
-                   int n_tiles, int gps, int ksplit, unsigned L, unsigned n, unsigned row_end, unsigned col_begin,
-                   unsigned *dist, unsigned *ncomp, size_t ld);
+    TileLaunch launch;                 // general IUPAC encoding (5 planes)
+    TileLaunch launch_cons = nullptr;  // consensus encoding (3 planes), when the variant has one
 };
 
-template <int NW, int R, int C, int GC, int ROWSRC, int MINW = 1, bool GLDS = false>
+template <int NW, int R, int C, int GC, int ROWSRC, int MINW = 1, bool GLDS = false, int ENC = 0>
 static void launch_variant(bool with_nn, unsigned nwg, hipStream_t stream, const uint4 *P, size_t n_pad, int groups,
                            const int2 *tiles, int n_tiles, int gps, int ksplit, unsigned L, unsigned n, unsigned row_end,
                            unsigned col_begin, unsigned *dist, unsigned *ncomp, size_t ld)
 {
     if (with_nn)
-        hipLaunchKernelGGL((pairsnp_tile_kernel<NW, R, C, GC, true, ROWSRC, MINW, GLDS>), dim3(nwg), dim3(NW * 64), 0, stream, P, n_pad, groups,
+        hipLaunchKernelGGL((pairsnp_tile_kernel<NW, R, C, GC, true, ROWSRC, MINW, GLDS, ENC>), dim3(nwg), dim3(NW * 64), 0, stream, P, n_pad, groups,
                            tiles, n_tiles, gps, ksplit, L, n, row_end, col_begin, dist, ncomp, ld);
     else
-        hipLaunchKernelGGL((pairsnp_tile_kernel<NW, R, C, GC, false, ROWSRC, MINW, GLDS>), dim3(nwg), dim3(NW * 64), 0, stream, P, n_pad, groups,
+        hipLaunchKernelGGL((pairsnp_tile_kernel<NW, R, C, GC, false, ROWSRC, MINW, GLDS, ENC>), dim3(nwg), dim3(NW * 64), 0, stream, P, n_pad, groups,
                            tiles, n_tiles, gps, ksplit, L, n, row_end, col_begin, dist, ncomp, ld);
 }
 
@@ -601,6 +663,7 @@ static void launch_rowcast(bool with_nn, unsigned nwg, hipStream_t stream, const
 
 #define TRACS_VARIANT_W(NW, R, C, GC, SRC, MINW) {#NW "x" #R "x" #C "x" #GC ":" #SRC "/w" #MINW, (NW) * (R), 64 * (C), GC, (NW) * 64, launch_variant<NW, R, C, GC, SRC, MINW>}
 #define TRACS_VARIANT_G(NW, R, C, GC, SRC, MINW) {#NW "x" #R "x" #C "x" #GC ":" #SRC "/w" #MINW "/glds", (NW) * (R), 64 * (C), GC, (NW) * 64, launch_variant<NW, R, C, GC, SRC, MINW, true>}
+#define TRACS_VARIANT_GC(NW, R, C, GC, SRC, MINW) {#NW "x" #R "x" #C "x" #GC ":" #SRC "/w" #MINW "/glds+cons", (NW) * (R), 64 * (C), GC, (NW) * 64, launch_variant<NW, R, C, GC, SRC, MINW, true, 0>, launch_variant<NW, R, C, GC, SRC, MINW, true, 1>}
 #define TRACS_VARIANT(NW, R, C, GC, SRC) {#NW "x" #R "x" #C "x" #GC ":" #SRC, (NW) * (R), 64 * (C), GC, (NW) * 64, launch_variant<NW, R, C, GC, SRC>}
 static const TileVariant kVariants[] = {
     TRACS_VARIANT(8, 8, 2, 4, ROW_SMEM),      // 0: 64 x 128 tile, rows by scalar loads
@@ -638,9 +701,9 @@ static const TileVariant kVariants[] = {
     TRACS_VARIANT_W(8, 8, 2, 4, ROW_SMEM, 4),    // 32
     TRACS_VARIANT_G(4, 16, 2, 2, ROW_LDS, 2),    // 33: variant 31 with direct-to-LDS staging
     TRACS_VARIANT_G(4, 16, 2, 4, ROW_LDS, 2),    // 34
-    TRACS_VARIANT_G(8, 8, 2, 2, ROW_LDS, 4),     // 35
+    TRACS_VARIANT_GC(8, 8, 2, 2, ROW_LDS, 4),    // 35: default
     TRACS_VARIANT_G(8, 8, 2, 4, ROW_LDS, 4),     // 36
-    TRACS_VARIANT_G(4, 16, 2, 1, ROW_LDS, 2),    // 37
+    TRACS_VARIANT_GC(4, 16, 2, 1, ROW_LDS, 2),   // 37
     TRACS_VARIANT_G(8, 16, 2, 2, ROW_LDS, 2),    // 38
     TRACS_VARIANT_G(4, 16, 2, 2, ROW_LDS, 3),    // 39
     TRACS_VARIANT_G(16, 8, 2, 2, ROW_LDS, 4),    // 40
@@ -649,23 +712,40 @@ static const TileVariant kVariants[] = {
     TRACS_VARIANT_G(4, 16, 2, 1, ROW_LDS, 3),    // 43
     TRACS_VARIANT_G(8, 8, 2, 2, ROW_LDS, 3),     // 44
     TRACS_VARIANT_G(8, 8, 2, 2, ROW_LDS, 5),     // 45
+    TRACS_VARIANT_GC(8, 8, 4, 1, ROW_LDS, 2),    // 46: 64 x 256 (consensus planes are lighter)
+    TRACS_VARIANT_GC(8, 8, 2, 4, ROW_LDS, 4),    // 47
+    TRACS_VARIANT_GC(8, 16, 2, 2, ROW_LDS, 2),   // 48
+    TRACS_VARIANT_GC(16, 8, 2, 2, ROW_LDS, 4),   // 49
+    TRACS_VARIANT_GC(8, 8, 4, 2, ROW_LDS, 3),    // 50
+    TRACS_VARIANT_GC(8, 16, 2, 4, ROW_LDS, 3),   // 51
+    TRACS_VARIANT_GC(4, 16, 2, 4, ROW_LDS, 3),   // 52
+    TRACS_VARIANT_GC(4, 16, 4, 2, ROW_LDS, 2),   // 53
+    TRACS_VARIANT_GC(8, 8, 2, 5, ROW_LDS, 4),    // 54
+    TRACS_VARIANT_GC(8, 8, 2, 3, ROW_LDS, 4),    // 55
+    TRACS_VARIANT_GC(4, 16, 2, 2, ROW_LDS, 3),   // 56
 };
 static constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
+// fastest measured on MI355X (profiles/r01/tile_variant_sweeps.txt): one default per encoding
 #ifndef TRACS_DEFAULT_VARIANT
-#define TRACS_DEFAULT_VARIANT 35
+#define TRACS_DEFAULT_VARIANT 35            // general IUPAC encoding: 8 waves x 8 rows x 2 cols, GC = 2
+#endif
+#ifndef TRACS_DEFAULT_VARIANT_CONS
+#define TRACS_DEFAULT_VARIANT_CONS 56       // consensus encoding: 4 waves x 16 rows x 2 cols, GC = 2
 #endif
 
-static const TileVariant &current_variant()
+static const TileVariant &current_variant(bool consensus = false)
 {
-    static int chosen = -1;
-    if (chosen < 0) {
-        chosen = TRACS_DEFAULT_VARIANT;
+    static int chosen[2] = {-1, -1};
+    if (chosen[0] < 0) {
+        chosen[0] = TRACS_DEFAULT_VARIANT;
+        chosen[1] = TRACS_DEFAULT_VARIANT_CONS;
         if (const char *e = std::getenv("TRACS_TILE_VARIANT")) {
             const int v = std::atoi(e);
-            if (v >= 0 && v < kNumVariants) chosen = v;
+            if (v >= 0 && v < kNumVariants) chosen[0] = chosen[1] = v;
         }
+        if (!kVariants[chosen[1]].launch_cons) chosen[1] = chosen[0];
     }
-    return kVariants[chosen];
+    return kVariants[chosen[consensus ? 1 : 0]];
 }
 
 extern "C" {
@@ -694,6 +774,8 @@ void tracs_alignment_free(tracs_alignment *a)
 {
     if (!a) return;
     if (a->planes) (void)hipFree(a->planes);
+    if (a->cplanes) (void)hipFree(a->cplanes);
+    if (a->d_flag) (void)hipFree(a->d_flag);
     if (a->d_tiles) (void)hipFree(a->d_tiles);
     delete a;
 }
@@ -715,6 +797,7 @@ int tracs_alignment_pack(tracs_alignment *a, const uint8_t *ascii, size_t first,
     if (!a || (!ascii && count)) { set_error("tracs_alignment_pack: NULL argument"); return TRACS_E_ARG; }
     if (first + count > a->n) { set_error("tracs_alignment_pack: sample range outside the alignment"); return TRACS_E_ARG; }
     if (!count || !a->L) return TRACS_OK;
+    a->dirty = true;                   // the consensus form (if any) must be re-derived
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const uint8_t *d_ascii = ascii;
     uint8_t *tmp = nullptr;
@@ -743,6 +826,8 @@ int tracs_alignment_pack(tracs_alignment *a, const uint8_t *ascii, size_t first,
 }
 
 const char *tracs_debug_tile_variant(void) { return current_variant().name; }
+// 1 if the last dense call on this alignment used the consensus (3-plane) encoding, 0 general, -1 not decided yet
+int tracs_debug_alignment_encoding(const tracs_alignment *a) { return !a ? -1 : (a->dirty ? -1 : a->enc); }
 
 int tracs_pairsnp_dense(const tracs_alignment *a_, size_t row_begin, size_t row_end, size_t col_begin, uint32_t *dist,
                         uint32_t *ncomp, size_t ld, void *stream_)
@@ -763,8 +848,31 @@ int tracs_pairsnp_dense(const tracs_alignment *a_, size_t row_begin, size_t row_
     }
 
     // (re)build the cached tile schedule
-    const TileVariant &V = current_variant();
+    // choose the encoding: consensus (3 planes, VOP2/bitop3 logic only) when no sample carries a partial IUPAC code
+    if (a->dirty) {
+        a->enc = 0;
+        static const bool force_general = std::getenv("TRACS_FORCE_GENERAL") != nullptr;
+        if (current_variant(true).launch_cons && !force_general) {
+            const size_t cbytes = (a->groups * 3 * a->n_pad + SAMPLE_PAD) * sizeof(uint4);
+            if (!a->cplanes) {
+                TRACS_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&a->cplanes), cbytes));
+                TRACS_HIP_CHECK(hipMemsetAsync(a->cplanes, 0, cbytes, stream));
+            }
+            if (!a->d_flag) TRACS_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&a->d_flag), 64));
+            TRACS_HIP_CHECK(hipMemsetAsync(a->d_flag, 0, 4, stream));
+            hipLaunchKernelGGL(derive_consensus_kernel, dim3(256 * 16), dim3(256), 0, stream, a->planes, a->cplanes, a->n_pad,
+                               a->groups, a->d_flag);
+            unsigned flag = 1;
+            TRACS_HIP_CHECK(hipMemcpyAsync(&flag, a->d_flag, 4, hipMemcpyDeviceToHost, stream));
+            TRACS_HIP_CHECK(hipStreamSynchronize(stream));
+            if (flag == 0) a->enc = 1;
+            else { TRACS_HIP_CHECK(hipFree(a->cplanes)); a->cplanes = nullptr; }
+        }
+        a->dirty = false;
+    }
+    const TileVariant &V = current_variant(a->enc == 1);
     const int kTI = V.ti, kTJ = V.tj, kGC = V.gc;
+    const bool cons = a->enc == 1 && V.launch_cons;
     if (a->key_rb != row_begin || a->key_re != row_end || a->key_cb != col_begin || a->key_ti != kTI || a->key_tj != kTJ) {
         std::vector<int2> tiles;
         build_tiles(a->n, row_begin, row_end, col_begin, kTI, kTJ, tiles);
@@ -783,13 +891,25 @@ int tracs_pairsnp_dense(const tracs_alignment *a_, size_t row_begin, size_t row_
     }
     if (a->n_tiles == 0) return TRACS_OK;
 
-    // split the group range when there are too few tiles to fill 256 CUs (x2 workgroups each)
+    // Split the group range over workgroups (integer atomics, still exact) when that fills the chip better:
+    // too few tiles (config 2), or a ragged last round of resident workgroups (tail effect).  Workgroup slots =
+    // CUs x workgroups per CU for this variant (VGPR/LDS bound: 2 for every default shape).
     const int groups = (int)a->groups;
     int ksplit = 1;
-    const size_t target_wg = 1024;
-    if (a->n_tiles < target_wg) {
-        ksplit = (int)std::min<size_t>((target_wg + a->n_tiles - 1) / a->n_tiles, (size_t)std::max(1, groups / (4 * kGC)));
-        if (ksplit < 1) ksplit = 1;
+    {
+        static int cus = 0;
+        if (!cus) { hipDeviceProp_t pr; int dv = 0; (void)hipGetDevice(&dv); cus = (hipGetDeviceProperties(&pr, dv) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }
+        const double slots = 2.0 * cus;
+        const int max_split = std::max(1, groups / (8 * kGC));
+        double best = -1.0;
+        for (int k = 1; k <= std::min(max_split, 64); k++) {
+            const double wgs = (double)a->n_tiles * k;
+            const double rounds = std::ceil(wgs / slots);
+            const double eff = wgs / (rounds * slots) - 0.002 * (k - 1);     // small bias towards fewer splits
+            if (eff > best + 1e-9) { best = eff; ksplit = k; }
+            if (rounds >= 40) break;                                         // tail < 2.5 % from here on
+        }
+        if (const char *e = std::getenv("TRACS_KSPLIT")) { const int v = std::atoi(e); if (v >= 1 && v <= max_split) ksplit = v; }
     }
     int gps = (groups + ksplit - 1) / ksplit;
     gps = (gps + kGC - 1) / kGC * kGC;             // stage aligned
@@ -798,10 +918,10 @@ int tracs_pairsnp_dense(const tracs_alignment *a_, size_t row_begin, size_t row_
     if (ksplit > 1) {
         dim3 grid(64, (unsigned)(row_end - row_begin));
         hipLaunchKernelGGL(init_cells_kernel, grid, dim3(256), 0, stream, dist, ncomp, ld, (unsigned)a->n,
-                           (unsigned)row_begin, (unsigned)row_end, (unsigned)col_begin, (unsigned)a->L);
+                           (unsigned)row_begin, (unsigned)row_end, (unsigned)col_begin, cons ? 0u : (unsigned)a->L);
     }
     const unsigned nwg = (unsigned)(a->n_tiles * (size_t)ksplit);
-    V.launch(ncomp != nullptr, nwg, stream, a->planes, a->n_pad, groups, a->d_tiles, (int)a->n_tiles, gps, ksplit, (unsigned)a->L,
+    (cons ? V.launch_cons : V.launch)(ncomp != nullptr, nwg, stream, cons ? a->cplanes : a->planes, a->n_pad, groups, a->d_tiles, (int)a->n_tiles, gps, ksplit, (unsigned)a->L,
              (unsigned)a->n, (unsigned)row_end, (unsigned)col_begin, dist, ncomp, ld);
     TRACS_HIP_CHECK(hipGetLastError());
     return TRACS_OK;

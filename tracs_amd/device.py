@@ -58,6 +58,12 @@ class Alignment:
         _lib.check(self._L.tracs_alignment_pack(self._h, ptr, int(first), int(count), on_dev, _stream()))
 
     @property
+    def encoding(self):
+        """'consensus' (3 planes) / 'general' (5 planes) as used by the last dense call, None before the first."""
+        e = self._L.tracs_debug_alignment_encoding(self._h)
+        return {0: "general", 1: "consensus"}.get(e)
+
+    @property
     def nbytes(self):
         return self._L.tracs_alignment_bytes(self._h)
 
