@@ -81,6 +81,13 @@ int tracs_lprob_k_given_N(const uint64_t *N, const uint64_t *k, const double *de
 int tracs_calculate_posteriors(const double *counts, size_t L, size_t K, const double *alphas, int keep,
                                double threshold, double *posterior);
 
+/* find_dirichlet_priors(counts[L,K], max_iter, tol, method, error_filt_threshold) -> alphas[K] (descending)
+ *   replaces: tracs/dirichlet_multinomial.py:9-73 (the fit whose output calculate_posteriors consumes,
+ *   tracs/align.py:536-538).  method 0 = Minka fixed point (the reference's default branch), 1 = leave-one-out;
+ *   error_filt_threshold < 0 = None.  Fewer than 6 polymorphic sites -> (0,..,0,1) like the reference.        */
+int tracs_find_dirichlet_priors(const double *counts, size_t L, size_t K, int max_iter, double tol, int method,
+                                double error_filt_threshold, double *alphas_out, int *iters_out);
+
 /* Threshold single-linkage clustering = connected components of the edge list, labelled as
  * scipy.sparse.csgraph.connected_components(directed=False) labels them
  *   replaces: tracs/cluster.py:126-129.  edges (I[e], J[e]) over nodes 0..n-1.             */
@@ -158,6 +165,10 @@ int tracs_calculate_posteriors_device(const double *counts, size_t L, size_t K, 
  * IUPAC letter), two sites per output byte (low nibble = even site).                        */
 int tracs_posterior_codes_device(const uint16_t *counts, size_t L, const double *alphas_host, int keep,
                                  double threshold, uint8_t *codes, void *stream);
+
+int tracs_find_dirichlet_priors_device(const double *counts, size_t L, size_t K, int max_iter, double tol, int method,
+                                       double error_filt_threshold, double *alphas_out_host, int *iters_out,
+                                       void *stream);
 
 /* Connected components on device edge arrays; labels as tracs_connected_components.         */
 int tracs_connected_components_device(const int32_t *I, const int32_t *J, size_t n_edges, size_t n_nodes,

@@ -306,6 +306,39 @@ def calculate_posteriors(counts, alphas, keep, threshold):
     return out
 
 
+def find_dirichlet_priors(counts, max_iter=1000, tol=1e-5, method="FPI", error_filt_threshold=None):
+    """numpy/scipy restatement of tracs/dirichlet_multinomial.py:9-73 (own structure; pinned by
+    tests/golden/python_reference_golden.json, which holds the reference's outputs incl. the R MGLM known answer)."""
+    from scipy.special import psi
+    x = np.array(counts, dtype=np.float64)
+    K = x.shape[1]
+    if error_filt_threshold is not None:                       # :13-15
+        with np.errstate(divide="ignore", invalid="ignore"):
+            freq = x / x.sum(1, keepdims=True)
+        x[freq < error_filt_threshold] = 0
+    poly = np.count_nonzero(x, axis=1) > 1                    # :20-35
+    if poly.sum() <= 5:
+        out = np.zeros(K)
+        out[-1] = 1.0
+        return out
+    x = np.sort(x[poly], axis=1)                               # :36
+    tot = x.sum(1)
+    alpha = x.mean(0) + 0.5                                    # :40
+    for _ in range(max_iter):
+        a0 = alpha.sum()
+        if method == "LOO":                                    # :43-54
+            new = alpha * (x / (x - 1 + alpha)).sum(0) / (tot / (tot - 1 + a0)).sum()
+            done = np.max(np.abs(new - alpha)) < tol
+            alpha = new
+        else:                                                  # :56-68
+            new = alpha * (psi(x + alpha) - psi(alpha)).sum(0) / (psi(tot + a0) - psi(a0)).sum()
+            done = np.sum(np.abs(new - alpha)) < tol
+            alpha = new if done else np.maximum(new, 1e-16)
+        if done:
+            break
+    return np.sort(alpha)[::-1]                                # :70
+
+
 def connected_components(n, I, J):
     """Labels as scipy.sparse.csgraph.connected_components(directed=False) returns them
     (tracs/cluster.py:126-129): component ids in order of each component's smallest node."""

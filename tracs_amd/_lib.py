@@ -17,6 +17,7 @@ SYMBOLS = [
     "tracs_pairsnp_cols", "tracs_pairsnp_distances", "tracs_pairsnp_filt_distances", "tracs_pairsnp_ncompared",
     "tracs_pairsnp_name", "tracs_pairsnp_free",
     "tracs_trans_dist", "tracs_lprob_k_given_N", "tracs_calculate_posteriors", "tracs_connected_components",
+    "tracs_find_dirichlet_priors", "tracs_find_dirichlet_priors_device",
     "tracs_alignment_create", "tracs_alignment_free", "tracs_alignment_n", "tracs_alignment_len",
     "tracs_alignment_bytes", "tracs_alignment_planes", "tracs_alignment_pack", "tracs_alignment_from_fasta",
     "tracs_free",
@@ -85,6 +86,10 @@ def load():
     L.tracs_lprob_k_given_N.argtypes = [u64p, u64p, dp, sz, dbl, dbl, dp, sz, dp, dp]
     L.tracs_calculate_posteriors.restype = C.c_int
     L.tracs_calculate_posteriors.argtypes = [dp, sz, sz, dp, C.c_int, dbl, dp]
+    L.tracs_find_dirichlet_priors.restype = C.c_int
+    L.tracs_find_dirichlet_priors.argtypes = [dp, sz, sz, C.c_int, dbl, C.c_int, dbl, dp, C.POINTER(C.c_int)]
+    L.tracs_find_dirichlet_priors_device.restype = C.c_int
+    L.tracs_find_dirichlet_priors_device.argtypes = [vp, sz, sz, C.c_int, dbl, C.c_int, dbl, dp, C.POINTER(C.c_int), vp]
     L.tracs_connected_components.restype = C.c_int
     L.tracs_connected_components.argtypes = [C.POINTER(i32), C.POINTER(i32), sz, sz, C.POINTER(i32), C.POINTER(i32)]
     L.tracs_alignment_create.restype = C.c_int
