@@ -84,7 +84,37 @@ __global__ __launch_bounds__(256) void posteriorsK_kernel(const double *__restri
 }
 
 // production form: uint16 counts (A,C,G,T) -> 4-bit allele mask, two sites per byte.
-// A thread handles two sites = 16 B in, 1 B out.
+// Only "is the thresholded posterior > 0" is needed, so the divide of :59 is replaced by a comparison of the
+// numerator with threshold * denominator; the exact quotient is formed only inside a 4-ulp guard band around the
+// threshold, which keeps the decision identical to the reference's `post <= threshold` on the divided value.
+__device__ __forceinline__ unsigned posterior_mask4(const unsigned (&c)[4], const Alphas &A, int keep, double expected)
+{
+    const unsigned tot = c[0] + c[1] + c[2] + c[3];                      // exact: the f64 sum of :38-42 is exact for integers < 2^53
+    if (tot == 0) {                                                      // :53-56: every cell a_min; counts are zero: `keep` cannot apply
+        return (!(A.a_min <= expected) && A.a_min > 0.0) ? 15u : 0u;
+    }
+    const double den = (double)tot + A.a0;
+    const double lim = expected * den, hi = lim * (1.0 + 1e-15), lo = lim * (1.0 - 1e-15);
+    // rank of a cell = number of distinct count values strictly greater (see posterior_row); integer compares only
+    const bool f1 = c[1] != c[0], f2 = c[2] != c[0] && c[2] != c[1], f3 = c[3] != c[0] && c[3] != c[1] && c[3] != c[2];
+    unsigned m = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int rank = (int)(c[0] > c[j]) + (int)(f1 && c[1] > c[j]) + (int)(f2 && c[2] > c[j]) + (int)(f3 && c[3] > c[j]);
+        const double al = rank == 0 ? A.a[0] : rank == 1 ? A.a[1] : rank == 2 ? A.a[2] : A.a[3];
+        const double num = (double)c[j] + al;
+        bool above;                                                      // post > expected ?
+        if (num > hi) above = true;
+        else if (num < lo) above = false;
+        else above = !((num / den) <= expected);                         // guard band: the reference's own arithmetic
+        const bool bit = above ? (num > 0.0) : (keep && c[j] > 0 && expected > 0.0);   // den > 0: sign(num/den) = sign(num)
+        m |= (bit ? 1u : 0u) << j;
+    }
+    return m;
+}
+
+// one thread = two sites: 16 B in, 1 B out (an 8-site / 4-byte-store form measured 13 % slower: the kernel is bound by
+// the f64 compare chain, not by its stores -- bench_aux.py)
 __global__ __launch_bounds__(256) void posterior_codes_kernel(const uint4 *__restrict__ counts2, size_t L, Alphas A, int keep,
                                                               double expected, uint8_t *__restrict__ codes)
 {
@@ -100,13 +130,8 @@ __global__ __launch_bounds__(256) void posterior_codes_kernel(const uint4 *__res
 #pragma unroll
         for (int s = 0; s < 2; s++) {
             const unsigned w0 = s == 0 ? v.x : v.z, w1 = s == 0 ? v.y : v.w;
-            const double row[4] = {(double)(w0 & 0xFFFFu), (double)(w0 >> 16), (double)(w1 & 0xFFFFu), (double)(w1 >> 16)};
-            double res[4];
-            posterior_row<4>(row, A, keep, expected, res);
-            unsigned m = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) m |= (res[j] > 0.0 ? 1u : 0u) << j;
-            if (2 * t + s < L) out |= m << (4 * s);
+            const unsigned row[4] = {w0 & 0xFFFFu, w0 >> 16, w1 & 0xFFFFu, w1 >> 16};
+            if (2 * t + s < L) out |= posterior_mask4(row, A, keep, expected) << (4 * s);
         }
         codes[t] = (uint8_t)out;
     }
