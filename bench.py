@@ -93,10 +93,12 @@ def main():
         for r0, r1 in ranges:
             dev.pairsnp_dense(aln, dmat, nmat, row_begin=r0, row_end=r1)
         ev1[it].record()
-        for r0, r1 in ranges:
-            dev.trans_dist_dense(dmat, n, days, args.lamb, args.beta, args.precision, pmat, emat, exp_p0=True,
-                                 row_begin=r0, row_end=r1)
-        partition.gather_panels((dmat, nmat, pmat, emat), n, rank, world, dist)
+        # the SNP panels travel (RCCL, own stream) while transcluster runs on this rank's panels
+        works = partition.gather_panels((dmat, nmat), n, rank, world, dist, async_op=True)
+        dev.trans_dist_dense_ranges(dmat, n, days, args.lamb, args.beta, args.precision, pmat, emat, ranges, exp_p0=True)
+        works += partition.gather_panels((pmat, emat), n, rank, world, dist, async_op=True)
+        for w in works:
+            w.wait()
 
     for it in range(args.warmup):
         step(it)

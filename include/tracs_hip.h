@@ -157,6 +157,11 @@ int tracs_trans_dist_dense(const uint32_t *dist, size_t ld, size_t n, size_t row
                            double beta, double threshold_Ek, int exp_p0, double *p0, double *eK,
                            void *stream);
 
+/* Same over one or two row panels [b0,e0) (, [b1,e1)) in ONE pass (one key table): row_ranges = {b0,e0[,b1,e1]}. */
+int tracs_trans_dist_dense2(const uint32_t *dist, size_t ld, size_t n, const size_t *row_ranges, int n_ranges,
+                            size_t col_begin, int32_t dist_threshold, const int32_t *days, double lamb, double beta,
+                            double threshold_Ek, int exp_p0, double *p0, double *eK, void *stream);
+
 /* calculate_posteriors on device arrays; counts/posterior are device f64 [L][K].            */
 int tracs_calculate_posteriors_device(const double *counts, size_t L, size_t K, const double *alphas_host,
                                       int keep, double threshold, double *posterior, void *stream);

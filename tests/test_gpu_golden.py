@@ -191,6 +191,14 @@ def test_dense_coo_and_transcluster_device(dev, oracle, torch_mod):
             seen.add(key)
             check_ek(oracle, key[0], key[1], 5.3, 6.0, 0.01, eh[ri[t], ci[t]])
     assert (ph[ri[~keep], ci[~keep]] == 0).all()                   # cells above the SNP threshold are skipped
+    # two row panels in one pass (the multi-GPU partition's shape) == the full pass on those rows
+    p2 = torch.zeros((n, n), dtype=torch.float64, device="cuda")
+    e2 = torch.zeros((n, n), dtype=torch.float64, device="cuda")
+    dev.trans_dist_dense_ranges(d, n, torch.from_numpy(days).cuda(), 5.3, 6.0, 0.01, p2, e2, [(0, 40), (250, 333)],
+                                exp_p0=True, dist_threshold=60)
+    rows = list(range(0, 40)) + list(range(250, 333))
+    assert torch.equal(p2[rows], p[rows]) and torch.equal(e2[rows], e[rows])
+    assert float(p2[40:250].abs().sum()) == 0.0
     aln.close()
 
 

@@ -41,7 +41,8 @@ def _worker(rank, world, port, n, L, seed, ret):
             nmat[r[sel].astype(np.int64), c[sel].astype(np.int64)] = torch.from_numpy(nn[sel].astype(np.int32))
             mine += int(sel.sum())
             assert int(sel.sum()) == partition.pairs_in_rows(n, r0, r1)
-        partition.gather_panels((dmat, nmat), n, rank, world, dist, align=8)
+        for w in partition.gather_panels((dmat, nmat), n, rank, world, dist, align=8, async_op=(n % 2 == 0)):
+            w.wait()
         r, c, d, nn = O.pairsnp_planes(planes, L)
         full_d = torch.zeros((cs * nchunk, n), dtype=torch.int32)
         full_n = torch.zeros((cs * nchunk, n), dtype=torch.int32)

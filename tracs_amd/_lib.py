@@ -22,7 +22,7 @@ SYMBOLS = [
     "tracs_alignment_bytes", "tracs_alignment_planes", "tracs_alignment_pack", "tracs_alignment_from_fasta",
     "tracs_free",
     "tracs_pairsnp_dense", "tracs_coo_count", "tracs_coo_fill", "tracs_filter_recomb_device",
-    "tracs_trans_dist_device", "tracs_trans_dist_dense",
+    "tracs_trans_dist_device", "tracs_trans_dist_dense", "tracs_trans_dist_dense2",
     "tracs_calculate_posteriors_device", "tracs_posterior_codes_device",
     "tracs_connected_components_device",
 ]
@@ -121,6 +121,8 @@ def load():
     L.tracs_trans_dist_device.argtypes = [vp, vp, sz, dbl, dbl, dbl, C.c_int, vp, vp, vp]
     L.tracs_trans_dist_dense.restype = C.c_int
     L.tracs_trans_dist_dense.argtypes = [vp, sz, sz, sz, sz, sz, i32, vp, dbl, dbl, dbl, C.c_int, vp, vp, vp]
+    L.tracs_trans_dist_dense2.restype = C.c_int
+    L.tracs_trans_dist_dense2.argtypes = [vp, sz, sz, C.POINTER(sz), C.c_int, sz, i32, vp, dbl, dbl, dbl, C.c_int, vp, vp, vp]
     L.tracs_calculate_posteriors_device.restype = C.c_int
     L.tracs_calculate_posteriors_device.argtypes = [vp, sz, sz, dp, C.c_int, dbl, vp, vp]
     L.tracs_posterior_codes_device.restype = C.c_int

@@ -22,21 +22,24 @@ namespace tracs {
 
 namespace {
 
+// Block reader over gzread with direct access to the current block (the hot loops below scan it in place).
 class ByteStream {
 public:
-    explicit ByteStream(gzFile f) : f_(f), buf_(1u << 20) {}
-    // next byte or -1 at end of file
-    int get()
+    explicit ByteStream(gzFile f) : f_(f), buf_(4u << 20) {}
+    bool fill()                                       // true if at least one byte is available
     {
-        if (pos_ >= len_) {
-            if (eof_) return -1;
-            const int r = gzread(f_, buf_.data(), (unsigned)buf_.size());
-            if (r <= 0) { eof_ = true; return -1; }
-            len_ = (size_t)r;
-            pos_ = 0;
-        }
-        return (unsigned char)buf_[pos_++];
+        if (pos_ < len_) return true;
+        if (eof_) return false;
+        const int r = gzread(f_, buf_.data(), (unsigned)buf_.size());
+        if (r <= 0) { eof_ = true; return false; }
+        len_ = (size_t)r;
+        pos_ = 0;
+        return true;
     }
+    int get() { return fill() ? (unsigned char)buf_[pos_++] : -1; }
+    const unsigned char *cur() const { return reinterpret_cast<const unsigned char *>(buf_.data()) + pos_; }
+    size_t avail() const { return len_ - pos_; }
+    void advance(size_t k) { pos_ += k; }
 
 private:
     gzFile f_;
@@ -44,6 +47,8 @@ private:
     size_t pos_ = 0, len_ = 0;
     bool eof_ = false;
 };
+
+inline bool is_graph(unsigned c) { return c - 33u < 94u; }      // isgraph() in the C locale: 33..126
 
 }  // namespace
 
@@ -70,10 +75,27 @@ int read_fasta(const std::string &path, FastaData &out, std::string &err)
         if (c == -1) break;                                   // header char was the last byte: no record
         while (c != -1 && !std::isspace(c)) { name.push_back((char)c); c = in.get(); }
         if (c != -1 && c != '\n') while ((c = in.get()) != -1 && c != '\n') {}
-        // sequence
+        // sequence: scan whole blocks in place -- every printable byte up to the next '>', '+' or '@'
         rec.clear();
-        while ((c = in.get()) != -1 && c != '>' && c != '+' && c != '@')
-            if (std::isgraph(c)) rec.push_back((uint8_t)c);
+        if (out.L) rec.reserve(out.L + 64);
+        c = -1;
+        while (in.fill()) {
+            const unsigned char *p = in.cur();
+            const size_t n = in.avail();
+            const size_t base = rec.size();
+            rec.resize(base + n);
+            uint8_t *dst = rec.data() + base;
+            size_t k = 0, w = 0;
+            for (; k < n; k++) {
+                const unsigned ch = p[k];
+                if (ch == '>' || ch == '+' || ch == '@') break;
+                dst[w] = (uint8_t)ch;                         // branch-free append of printable bytes
+                w += is_graph(ch);
+            }
+            rec.resize(base + w);
+            if (k < n) { c = p[k]; in.advance(k + 1); break; }
+            in.advance(n);
+        }
         pending = (c == '>' || c == '@') ? c : 0;
         if (c == '+') {
             while ((c = in.get()) != -1 && c != '\n') {}

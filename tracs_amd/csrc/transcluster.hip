@@ -121,14 +121,22 @@ __device__ bool tc_eval(int N, double delta, const TcParams &P, const double *__
 // are log-space prefix sums, so a step is: per-lane terms, three inclusive wave scans with logaddexp, the
 // reference's stopping test on every lane's prefix, and a ballot for the first lane that satisfies it.
 // Summation order differs from the serial loop by rounding only (all terms positive).
+// inclusive log-space prefix sum across the wave: ln sum_{l' <= l} exp(v_l').  Done in linear space relative to the
+// wave maximum (one exp and one log per lane instead of a logaddexp per scan step); terms more than ~700 below the
+// maximum underflow to 0, which is below double precision of the sum anyway.
 __device__ __forceinline__ double wave_scan_lae(double v, int lane)
 {
+    double m = v;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+    if (m == -INFINITY) return -INFINITY;
+    double e = exp(v - m);
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-        const double o = __shfl_up(v, off, 64);
-        if (lane >= off) v = lae(v, o);
+        const double o = __shfl_up(e, off, 64);
+        if (lane >= off) e += o;
     }
-    return v;
+    return m + log(e);
 }
 
 __device__ void tc_eval_wave(int N, double delta, const TcParams &P, const double *__restrict__ lg, double &eK)
@@ -214,10 +222,13 @@ struct DenseSource {            // cells of a dense distance block, delta from s
     const int *days;
     size_t ld, n, row_begin, row_end, col_begin;
     int thr;
-    __device__ size_t size() const { return (row_end - row_begin) * n; }
+    size_t row_begin2 = 0, row_end2 = 0;     // optional second row panel (the multi-GPU partition gives each rank two)
+    __device__ __host__ size_t rows1() const { return row_end - row_begin; }
+    __device__ size_t size() const { return (rows1() + (row_end2 - row_begin2)) * n; }
+    __device__ size_t row_of(size_t r) const { return r < rows1() ? row_begin + r : row_begin2 + (r - rows1()); }
     __device__ bool get(size_t e, int &Nv, double &dv) const
     {
-        const size_t i = row_begin + e / n, j = e % n;
+        const size_t i = row_of(e / n), j = e % n;
         if (j <= i || j < col_begin) return false;
         const unsigned d = dist[i * ld + j];
         if ((long long)d > (long long)thr) return false;
@@ -227,7 +238,7 @@ struct DenseSource {            // cells of a dense distance block, delta from s
         dv = (double)((dd < 0 ? -dd : dd) * 86400ll) / 31556952.0;
         return true;
     }
-    __device__ size_t out_index(size_t e) const { return (row_begin + e / n) * ld + e % n; }
+    __device__ size_t out_index(size_t e) const { return row_of(e / n) * ld + e % n; }
 };
 
 __device__ __forceinline__ unsigned long long mix64(unsigned long long x)
@@ -474,6 +485,19 @@ int tracs_trans_dist_dense(const uint32_t *dist, size_t ld, size_t n, size_t row
     DenseSource src{dist, days, ld, n, row_begin, row_end, col_begin, dist_threshold};
     return run_trans_dist(src, (row_end - row_begin) * n, lamb, beta, threshold_Ek, exp_p0, p0, eK,
                           static_cast<hipStream_t>(stream));
+}
+
+int tracs_trans_dist_dense2(const uint32_t *dist, size_t ld, size_t n, const size_t *row_ranges, int n_ranges, size_t col_begin,
+                            int32_t dist_threshold, const int32_t *days, double lamb, double beta, double threshold_Ek,
+                            int exp_p0, double *p0, double *eK, void *stream)
+{
+    if (!dist || !days || !p0 || !eK || !row_ranges) { set_error("tracs_trans_dist_dense2: NULL argument"); return TRACS_E_ARG; }
+    if (n_ranges < 1 || n_ranges > 2) { set_error("tracs_trans_dist_dense2: 1 or 2 row ranges"); return TRACS_E_ARG; }
+    DenseSource src{dist, days, ld, n, std::min(row_ranges[0], n), std::min(row_ranges[1], n), col_begin, dist_threshold};
+    if (n_ranges == 2) { src.row_begin2 = std::min(row_ranges[2], n); src.row_end2 = std::min(row_ranges[3], n); }
+    if (src.row_end < src.row_begin || src.row_end2 < src.row_begin2) { set_error("tracs_trans_dist_dense2: bad range"); return TRACS_E_ARG; }
+    const size_t total = ((src.row_end - src.row_begin) + (src.row_end2 - src.row_begin2)) * n;
+    return run_trans_dist(src, total, lamb, beta, threshold_Ek, exp_p0, p0, eK, static_cast<hipStream_t>(stream));
 }
 
 int tracs_trans_dist(const int32_t *snpdiff, const double *datediff, size_t n, double lamb, double beta,

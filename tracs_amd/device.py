@@ -143,6 +143,19 @@ def trans_dist_dense(dist, n, days, lamb, beta, threshold_Ek, p0, eK, exp_p0=Tru
                                         _stream()))
 
 
+def trans_dist_dense_ranges(dist, n, days, lamb, beta, threshold_Ek, p0, eK, ranges, exp_p0=True,
+                            dist_threshold=2147483647, col_begin=0):
+    """One pass (one key table) over one or two row panels: ranges = [(b0, e0)] or [(b0, e0), (b1, e1)]."""
+    L = _lib.require_gpu()
+    ld = dist.stride(0)
+    assert p0.stride(0) == ld and eK.stride(0) == ld and 1 <= len(ranges) <= 2
+    flat = [int(x) for r in ranges for x in r]
+    arr = (C.c_size_t * len(flat))(*flat)
+    _lib.check(L.tracs_trans_dist_dense2(_ptr(dist), ld, n, arr, len(ranges), col_begin, int(dist_threshold), _ptr(days),
+                                         float(lamb), float(beta), float(threshold_Ek), int(exp_p0), _ptr(p0), _ptr(eK),
+                                         _stream()))
+
+
 def calculate_posteriors_device(counts, alphas, keep, threshold):
     L = _lib.require_gpu()
     a = np.ascontiguousarray(alphas, dtype=np.float64)

@@ -42,11 +42,13 @@ def pairs_in_rows(n, r0, r1):
     return cnt * (n - 1) - (r0 + r1 - 1) * cnt // 2
 
 
-def gather_panels(mats, n, rank, world, dist, align=64):
+def gather_panels(mats, n, rank, world, dist, align=64, async_op=False):
     """All-gather the row panels of every matrix in `mats` (each [rows_pad, ld], rows_pad = 2*world*chunk_rows)
-    so that afterwards every rank holds all rows.  `dist` is torch.distributed."""
+    so that afterwards every rank holds all rows.  `dist` is torch.distributed.  With async_op the collectives are
+    only enqueued (they run on the communicator's stream, overlapping later kernels); wait on the returned works."""
+    works = []
     if world == 1:
-        return
+        return works
     cs, nchunk = row_chunks(n, world, align)
     mine = rank_chunks(rank, world)
     for m in mats:
@@ -57,4 +59,7 @@ def gather_panels(mats, n, rank, world, dist, align=64):
                 c = rank_chunks(q, world)[half]
                 outs.append(m[c * cs:(c + 1) * cs])
             c = mine[half]
-            dist.all_gather(outs, m[c * cs:(c + 1) * cs])
+            w = dist.all_gather(outs, m[c * cs:(c + 1) * cs], async_op=async_op)
+            if async_op:
+                works.append(w)
+    return works
