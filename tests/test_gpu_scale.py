@@ -1,0 +1,106 @@
+"""BASELINE.json's parity configs at (or near) full size, through exact oracle checks where the oracle finishes in
+seconds on the GPU box's host cores and through size-independent properties otherwise."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dev(hiplib):
+    import torch
+    assert torch.cuda.is_available()
+    from tracs_amd import device
+    return device
+
+
+def test_config2_full_size_bit_exact(dev, oracle):
+    """configs[1]: 1 000 samples x 1 Mbp, every one of the 499 500 (d, nn) pairs bit-exact vs the CPU oracle."""
+    import torch
+    from tracs_amd import synth
+    n, L = 1000, 1000000
+    seqs = synth.first_samples_host(n, L, 20241023, n, mu_lineage=1e-4, mu_sample=1e-5, p_n=0.01)
+    aln = dev.Alignment(n, L)
+    aln.pack(seqs)
+    d = torch.zeros((n, n), dtype=torch.int32, device="cuda")
+    nn = torch.zeros((n, n), dtype=torch.int32, device="cuda")
+    dev.pairsnp_dense(aln, d, nn)
+    assert aln.encoding == "consensus"
+    threads = max(1, min(128, os.cpu_count() or 1))
+    r, c, ed, enn = oracle.pairsnp_planes(oracle.pack(seqs), L, n_threads=threads)
+    assert len(r) == 499500
+    ri, ci = r.astype(np.int64), c.astype(np.int64)
+    assert np.array_equal(d.cpu().numpy()[ri, ci], ed.astype(np.int32))
+    assert np.array_equal(nn.cpu().numpy()[ri, ci], enn.astype(np.int32))
+    # the general (5-plane) kernel on the same data gives the same matrix
+    seqs[0, 0] = ord("R")
+    aln.pack(seqs[:1], first=0)
+    d2 = torch.zeros((n, n), dtype=torch.int32, device="cuda")
+    dev.pairsnp_dense(aln, d2, None)
+    assert aln.encoding == "general"
+    assert bool(torch.equal(d2[1:], d[1:]))
+
+
+def test_config4_shape_posterior_codes(dev, oracle):
+    """configs[3] shape: per-site 4-allele uint16 counts -> posterior filter -> 4-bit codes.  100 M sites in one launch
+    (100 samples' worth of 1 Mbp); the oracle checks a strided sample, the rest by consistency with the f64 kernel."""
+    import torch
+    from tracs_amd import synth
+    L = 100_000_000
+    base = synth.allele_counts(1_000_000, seed=44, depth=30, p_two=0.01)
+    counts = torch.from_numpy(base.view(np.int16)).cuda().repeat(100, 1)
+    alphas = [20.8156, 4.3818, 0.8890, 0.1]
+    codes = dev.posterior_codes_device(counts, alphas, False, 0.01)
+    assert codes.shape[0] == L // 2
+    per = codes.view(100, -1)
+    assert bool((per == per[0]).all())                                  # same input block -> same output block
+    post = oracle.calculate_posteriors(base.astype(np.float64), alphas, False, 0.01)
+    mask = ((post > 0).astype(np.uint8) * np.array([1, 2, 4, 8], np.uint8)).sum(1).astype(np.uint8)
+    exp = (mask[0::2] | (mask[1::2] << 4)).astype(np.uint8)
+    assert np.array_equal(per[0].cpu().numpy(), exp)
+    f64 = dev.calculate_posteriors_device(counts[:2_000_000].to(torch.float64), alphas, False, 0.01)
+    m2 = ((f64 > 0).to(torch.uint8) * torch.tensor([1, 2, 4, 8], dtype=torch.uint8, device="cuda")).sum(1).to(torch.uint8)
+    assert bool(torch.equal(m2[0::2] | (m2[1::2] << 4), codes[:1_000_000]))
+
+
+def test_config5_shape_transcluster_and_clustering(dev, oracle):
+    """configs[4] shape: 100 000 samples; 50 M candidate pairs -> transcluster -> threshold -> single linkage."""
+    import torch
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import connected_components
+    from ek_parity import check_ek
+    n_nodes, P = 100000, 50_000_000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(9)
+    I = torch.randint(0, n_nodes, (P,), generator=g, device="cuda", dtype=torch.int32)
+    J = (I + 1 + torch.randint(0, 50, (P,), generator=g, device="cuda", dtype=torch.int32)) % n_nodes
+    close = torch.rand(P, generator=g, device="cuda") < 0.01
+    N = torch.where(close, torch.poisson(torch.full((P,), 2.0, device="cuda"), generator=g),
+                    torch.clamp(torch.poisson(torch.full((P,), 60.0, device="cuda"), generator=g), max=100)).to(torch.int32)
+    days = torch.randint(0, 400, (P,), generator=g, device="cuda")
+    delta = days.to(torch.float64) * 86400.0 / 31556952.0
+    p0, ek = dev.trans_dist_device(N, delta, 5.3, 6.0, 0.01, exp_p0=False)
+    # every element equals the value of its key: check 300 random elements against the oracle
+    idx = torch.randint(0, P, (300,), generator=g, device="cuda")
+    Nh, dh, ph, eh = N[idx].cpu().numpy(), delta[idx].cpu().numpy(), p0[idx].cpu().numpy(), ek[idx].cpu().numpy()
+    ep0, _ = oracle.trans_dist(Nh, dh, 5.3, 6.0, 0.01)
+    assert np.allclose(ph, ep0, rtol=1e-6, atol=0)
+    for t in range(0, 300, 6):
+        check_ek(oracle, int(Nh[t]), float(dh[t]), 5.3, 6.0, 0.01, float(eh[t]))
+    # consistency at full size: equal keys -> bit-equal outputs
+    key = N.to(torch.int64) * 1000 + days
+    order = torch.argsort(key)
+    same = key[order][1:] == key[order][:-1]
+    assert bool((ek[order][1:][same] == ek[order][:-1][same]).all()) and bool((p0[order][1:][same] == p0[order][:-1][same]).all())
+    # threshold on E(K) and cluster; labels must be SciPy's
+    keep = ek <= 3.0
+    Ik, Jk = I[keep].contiguous(), J[keep].contiguous()
+    assert 10_000 < Ik.numel() < P
+    nc, lab = dev.connected_components_device(Ik, Jk, n_nodes)
+    G = csr_matrix((np.ones(Ik.numel(), np.int8), (Ik.cpu().numpy(), Jk.cpu().numpy())), shape=(n_nodes, n_nodes))
+    enc, elab = connected_components(csgraph=G, directed=False, return_labels=True)
+    assert nc == enc and np.array_equal(lab.cpu().numpy(), elab)

@@ -43,8 +43,8 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ a
                                                    size_t first, uint4 *__restrict__ planes, size_t n_pad,
                                                    size_t groups)
 {
-    const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
-    const size_t g = (size_t)blockIdx.y * 4 + (threadIdx.x >> 6);
+    const size_t s = (size_t)blockIdx.y * 64 + (threadIdx.x & 63);      // grid.y: sample blocks (<= 65535 x 64 per launch)
+    const size_t g = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);       // grid.x: group quads (any alignment length)
     if (s >= count || g >= groups) return;
     const size_t site0 = g * SITES_PER_GROUP;
     const uint8_t *src = ascii + s * L + site0;
@@ -807,15 +807,13 @@ int tracs_alignment_pack(tracs_alignment *a, const uint8_t *ascii, size_t first,
         if (e != hipSuccess) { (void)hipFree(tmp); set_error(std::string("H2D ascii: ") + hipGetErrorString(e)); return TRACS_E_HIP; }
         d_ascii = tmp;
     }
-    dim3 grid((unsigned)((count + 63) / 64), (unsigned)((a->groups + 3) / 4));
-    // grid.y is limited to 65535: L up to 33.5 Mbp per launch; loop for longer alignments
-    const size_t max_gy = 65535;
-    for (size_t gy0 = 0; gy0 < grid.y; gy0 += max_gy) {
-        // shift the group window by offsetting pointers is not possible for `planes` (group-major),
-        // so pass the window through blockIdx.y + base via a second launch with adjusted L-window
-        if (gy0 != 0) { if (tmp) (void)hipFree(tmp); set_error("alignment longer than 33.5 Mbp per pack launch not supported yet"); return TRACS_E_ARG; }
-        dim3 g2(grid.x, (unsigned)std::min<size_t>(grid.y, max_gy));
-        hipLaunchKernelGGL(pack_kernel, g2, dim3(256), 0, stream, d_ascii, a->L, count, first, a->planes, a->n_pad, a->groups);
+    // samples go over grid.y in slices of 65535 x 64; `ascii`/`first` are advanced per slice
+    const size_t slice = 65535ull * 64ull;
+    for (size_t c0 = 0; c0 < count; c0 += slice) {
+        const size_t cnt = std::min(slice, count - c0);
+        dim3 grid((unsigned)((a->groups + 3) / 4), (unsigned)((cnt + 63) / 64));
+        hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 0, stream, d_ascii + c0 * a->L, a->L, cnt, first + c0, a->planes, a->n_pad,
+                           a->groups);
     }
     TRACS_HIP_CHECK(hipGetLastError());
     if (tmp) {
