@@ -252,14 +252,18 @@ constexpr unsigned EMPTY = 0xFFFFFFFFu;
 // slots[h] = element index of the key's first claimant.  eslot[e] = slot of e's key.
 template <class Src>
 __global__ void dedup_insert_kernel(Src src, unsigned *__restrict__ slots, unsigned cap_mask,
-                                    unsigned *__restrict__ eslot)
+                                    unsigned *__restrict__ eslot, unsigned *__restrict__ overflow)
 {
+    // The table starts small (L2-resident: real inputs have few distinct (N, delta) keys); a probe sequence longer than
+    // MAX_PROBE means it is too full -- the host then retries with a 16x larger table.
+    constexpr int MAX_PROBE = 128;
     const size_t total = src.size();
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         int N; double d;
         if (!src.get(e, N, d)) { eslot[e] = EMPTY; continue; }
         unsigned h = (unsigned)mix64((unsigned long long)__double_as_longlong(d) ^ ((unsigned long long)(unsigned)N * 0x9E3779B97F4A7C15ull)) & cap_mask;
-        for (;;) {
+        for (int probe = 0;; probe++) {
+            if (probe >= MAX_PROBE) { *overflow = 1u; eslot[e] = EMPTY; break; }
             unsigned cur = slots[h];
             if (cur == EMPTY) {
                 cur = atomicCAS(&slots[h], EMPTY, (unsigned)e);
@@ -418,26 +422,37 @@ static int run_trans_dist(const Src &src, size_t total, double lamb, double beta
     const double *lg = nullptr;
     int rc = get_lgamma_table(stream, &lg);
     if (rc) return rc;
-    unsigned cap = 1024;
-    while ((size_t)cap < 2 * total && cap < (1u << 31)) cap <<= 1;
+    unsigned cap_max = 1024;
+    while ((size_t)cap_max < 2 * total && cap_max < (1u << 31)) cap_max <<= 1;
+    unsigned cap = std::min(cap_max, 1u << 20);
     unsigned *slots, *eslot, *slot_id, *n_keys, *key_elem, *long_ids;
     double *key_p0, *key_eK;
-    if ((rc = workspace_get(TcWorkspaceIds::SLOTS, (size_t)cap * 4, reinterpret_cast<void **>(&slots)))) return rc;
     if ((rc = workspace_get(TcWorkspaceIds::ESLOT, total * 4, reinterpret_cast<void **>(&eslot)))) return rc;
-    if ((rc = workspace_get(TcWorkspaceIds::SLOT_ID, (size_t)cap * 4, reinterpret_cast<void **>(&slot_id)))) return rc;
     if ((rc = workspace_get(TcWorkspaceIds::NKEYS, 64, reinterpret_cast<void **>(&n_keys)))) return rc;
-    TRACS_HIP_CHECK(hipMemsetAsync(slots, 0xFF, (size_t)cap * 4, stream));
-    TRACS_HIP_CHECK(hipMemsetAsync(n_keys, 0, 4, stream));
     const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 32);
-    hipLaunchKernelGGL((dedup_insert_kernel<Src>), dim3(blocks), dim3(256), 0, stream, src, slots, cap - 1, eslot);
-    TRACS_HIP_CHECK(hipGetLastError());
-    // first pass over the table only counts the claimed slots so the key arrays can be sized
-    // exactly (one 4-byte readback per call), the second assigns ids.
-    hipLaunchKernelGGL(dedup_count_kernel, dim3((unsigned)std::min<size_t>((cap + 255) / 256, 256 * 32)), dim3(256), 0, stream,
-                       slots, cap, n_keys);
     unsigned nk = 0;
-    TRACS_HIP_CHECK(hipMemcpyAsync(&nk, n_keys, 4, hipMemcpyDeviceToHost, stream));
-    TRACS_HIP_CHECK(hipStreamSynchronize(stream));
+    for (;;) {
+        if ((rc = workspace_get(TcWorkspaceIds::SLOTS, (size_t)cap * 4, reinterpret_cast<void **>(&slots)))) return rc;
+        if ((rc = workspace_get(TcWorkspaceIds::SLOT_ID, (size_t)cap * 4, reinterpret_cast<void **>(&slot_id)))) return rc;
+        TRACS_HIP_CHECK(hipMemsetAsync(slots, 0xFF, (size_t)cap * 4, stream));
+        TRACS_HIP_CHECK(hipMemsetAsync(n_keys, 0, 16, stream));     // [0] keys, [1] long keys, [2] overflow flag
+        hipLaunchKernelGGL((dedup_insert_kernel<Src>), dim3(blocks), dim3(256), 0, stream, src, slots, cap - 1, eslot, n_keys + 2);
+        TRACS_HIP_CHECK(hipGetLastError());
+        // first pass over the table only counts the claimed slots so the key arrays can be sized
+        // exactly (one small readback per call), the second assigns ids.
+        hipLaunchKernelGGL(dedup_count_kernel, dim3((unsigned)std::min<size_t>((cap + 255) / 256, 256 * 32)), dim3(256), 0, stream,
+                           slots, cap, n_keys);
+        unsigned h3[3] = {0, 0, 0};
+        TRACS_HIP_CHECK(hipMemcpyAsync(h3, n_keys, 12, hipMemcpyDeviceToHost, stream));
+        TRACS_HIP_CHECK(hipStreamSynchronize(stream));
+        nk = h3[0];
+        if (!h3[2] && (size_t)nk * 2 <= cap) break;                 // fits with load factor <= 0.5
+        if (cap >= cap_max) {
+            if (h3[2]) { set_error("trans_dist: key table overflow"); return TRACS_E_HIP; }
+            break;
+        }
+        cap = (unsigned)std::min<unsigned long long>((unsigned long long)cap * 16ull, cap_max);
+    }
     if (nk == 0) return TRACS_OK;
     if ((rc = workspace_get(TcWorkspaceIds::KEY_ELEM, (size_t)nk * 4, reinterpret_cast<void **>(&key_elem)))) return rc;
     if ((rc = workspace_get(TcWorkspaceIds::KEY_P0, (size_t)nk * 8, reinterpret_cast<void **>(&key_p0)))) return rc;
