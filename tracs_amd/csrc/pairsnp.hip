@@ -741,7 +741,9 @@ static const TileVariant &current_variant(bool consensus = false)
         chosen[1] = TRACS_DEFAULT_VARIANT_CONS;
         if (const char *e = std::getenv("TRACS_TILE_VARIANT")) {
             const int v = std::atoi(e);
-            if (v >= 0 && v < kNumVariants) chosen[0] = chosen[1] = v;
+            // ids 13-15 are timing-only ablations that produce WRONG RESULTS: reachable only with TRACS_ALLOW_ABLATION=1
+            const bool ablation = v >= 13 && v <= 15;
+            if (v >= 0 && v < kNumVariants && (!ablation || std::getenv("TRACS_ALLOW_ABLATION"))) chosen[0] = chosen[1] = v;
         }
         if (!kVariants[chosen[1]].launch_cons) chosen[1] = chosen[0];
     }
