@@ -61,10 +61,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world != 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)          # (several ranks on one GPU only happens in the gloo smoke test)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("TRACS_BENCH_BACKEND", "nccl")      # "nccl" IS RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     n, L = args.samples, args.sites
     seed = 20241022 + 2
@@ -127,6 +133,16 @@ def main():
 
     # sanity: spot-check a few cells against first principles is done in tests; here only a checksum
     checksum = int(dmat[:n].sum().item()) if rank == 0 else 0
+    if os.environ.get("TRACS_BENCH_VERIFY") and rank == 0:
+        # the gathered matrices must equal a single-pass recomputation on this rank
+        d1, n1 = torch.zeros_like(dmat), torch.zeros_like(nmat)
+        p1, e1 = torch.zeros_like(pmat), torch.zeros_like(emat)
+        dev.pairsnp_dense(aln, d1, n1)
+        dev.trans_dist_dense_ranges(d1, n, days, args.lamb, args.beta, args.precision, p1, e1, [(0, n)], exp_p0=True)
+        ok = bool(torch.equal(d1, dmat) and torch.equal(n1, nmat) and torch.equal(p1, pmat) and torch.equal(e1, emat))
+        print("VERIFY gathered == single-pass:", ok, file=sys.stderr, flush=True)
+        if not ok:
+            raise SystemExit("VERIFY FAILED")
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3

@@ -104,3 +104,23 @@ def test_config5_shape_transcluster_and_clustering(dev, oracle):
     G = csr_matrix((np.ones(Ik.numel(), np.int8), (Ik.cpu().numpy(), Jk.cpu().numpy())), shape=(n_nodes, n_nodes))
     enc, elab = connected_components(csgraph=G, directed=False, return_labels=True)
     assert nc == enc and np.array_equal(lab.cpu().numpy(), elab)
+
+
+def test_multirank_driver_path_on_one_gpu():
+    """bench.py's N > 1 path (row-panel partition, two-panel transcluster pass, async panel all-gathers) with two gloo ranks
+    sharing the GPU: the gathered d / nn / P / E(K) matrices must equal a single-pass recomputation (TRACS_BENCH_VERIFY)."""
+    import socket
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, TRACS_BENCH_BACKEND="gloo", TRACS_BENCH_VERIFY="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1",
+                          "--warmup", "1", "--samples", "1501", "--sites", "100000"], capture_output=True, text=True, env=env,
+                         timeout=600, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "VERIFY gathered == single-pass: True" in out.stderr
+    assert '"n_gpus": 2' in out.stdout and '"scaling": "strong"' in out.stdout
