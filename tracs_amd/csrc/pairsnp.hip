@@ -854,19 +854,28 @@ int tracs_pairsnp_dense(const tracs_alignment *a_, size_t row_begin, size_t row_
         static const bool force_general = std::getenv("TRACS_FORCE_GENERAL") != nullptr;
         if (current_variant(true).launch_cons && !force_general) {
             const size_t cbytes = (a->groups * 3 * a->n_pad + SAMPLE_PAD) * sizeof(uint4);
-            if (!a->cplanes) {
-                TRACS_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&a->cplanes), cbytes));
-                TRACS_HIP_CHECK(hipMemsetAsync(a->cplanes, 0, cbytes, stream));
+            bool have = a->cplanes != nullptr;
+            if (!have) {
+                // no room for the second copy (very large alignments): stay on the general kernel
+                if (hipMalloc(reinterpret_cast<void **>(&a->cplanes), cbytes) == hipSuccess) {
+                    have = true;
+                    TRACS_HIP_CHECK(hipMemsetAsync(a->cplanes, 0, cbytes, stream));
+                } else {
+                    a->cplanes = nullptr;
+                    (void)hipGetLastError();
+                }
             }
-            if (!a->d_flag) TRACS_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&a->d_flag), 64));
-            TRACS_HIP_CHECK(hipMemsetAsync(a->d_flag, 0, 4, stream));
-            hipLaunchKernelGGL(derive_consensus_kernel, dim3(256 * 16), dim3(256), 0, stream, a->planes, a->cplanes, a->n_pad,
-                               a->groups, a->d_flag);
-            unsigned flag = 1;
-            TRACS_HIP_CHECK(hipMemcpyAsync(&flag, a->d_flag, 4, hipMemcpyDeviceToHost, stream));
-            TRACS_HIP_CHECK(hipStreamSynchronize(stream));
-            if (flag == 0) a->enc = 1;
-            else { TRACS_HIP_CHECK(hipFree(a->cplanes)); a->cplanes = nullptr; }
+            if (have) {
+                if (!a->d_flag) TRACS_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&a->d_flag), 64));
+                TRACS_HIP_CHECK(hipMemsetAsync(a->d_flag, 0, 4, stream));
+                hipLaunchKernelGGL(derive_consensus_kernel, dim3(256 * 16), dim3(256), 0, stream, a->planes, a->cplanes, a->n_pad,
+                                   a->groups, a->d_flag);
+                unsigned flag = 1;
+                TRACS_HIP_CHECK(hipMemcpyAsync(&flag, a->d_flag, 4, hipMemcpyDeviceToHost, stream));
+                TRACS_HIP_CHECK(hipStreamSynchronize(stream));
+                if (flag == 0) a->enc = 1;
+                else { TRACS_HIP_CHECK(hipFree(a->cplanes)); a->cplanes = nullptr; }
+            }
         }
         a->dirty = false;
     }
