@@ -175,6 +175,17 @@ int tracs_find_dirichlet_priors_device(const double *counts, size_t L, size_t K,
                                        double error_filt_threshold, double *alphas_out_host, int *iters_out,
                                        void *stream);
 
+/* The same with the align stage's coverage rules (tracs/align.py:599-613): sites with total count < min_cov, or with
+ * cov_lo <= total <= cov_hi (outlier band; pass cov_lo > cov_hi to disable), become fully ambiguous (mask 15).        */
+int tracs_posterior_codes_cov_device(const uint16_t *counts, size_t L, const double *alphas_host, int keep,
+                                     double threshold, uint32_t min_cov, double cov_lo, double cov_hi, uint8_t *codes,
+                                     void *stream);
+/* 4-bit masks -> IUPAC letters as tracs/align.py:285-323,616-622 ('X' for mask 0, 'N' for 15); ascii: device, L bytes. */
+int tracs_codes_to_iupac_device(const uint8_t *codes, size_t L, uint8_t *ascii, void *stream);
+/* Pack ONE sample straight from its 4-bit masks (no FASTA round trip): mask 0 ('X') is treated like every other
+ * non-IUPAC letter, i.e. fully ambiguous (src/pairsnp.hpp:192-197).  codes: device, (L+1)/2 bytes.                   */
+int tracs_alignment_pack_codes(tracs_alignment *a, const uint8_t *codes, size_t sample, void *stream);
+
 /* Connected components on device edge arrays; labels as tracs_connected_components.         */
 int tracs_connected_components_device(const int32_t *I, const int32_t *J, size_t n_edges, size_t n_nodes,
                                       int32_t *labels, int32_t *n_components_host, void *stream);

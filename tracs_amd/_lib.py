@@ -23,7 +23,8 @@ SYMBOLS = [
     "tracs_free",
     "tracs_pairsnp_dense", "tracs_coo_count", "tracs_coo_fill", "tracs_filter_recomb_device",
     "tracs_trans_dist_device", "tracs_trans_dist_dense", "tracs_trans_dist_dense2",
-    "tracs_calculate_posteriors_device", "tracs_posterior_codes_device",
+    "tracs_calculate_posteriors_device", "tracs_posterior_codes_device", "tracs_posterior_codes_cov_device",
+    "tracs_codes_to_iupac_device", "tracs_alignment_pack_codes",
     "tracs_connected_components_device",
 ]
 
@@ -127,6 +128,12 @@ def load():
     L.tracs_calculate_posteriors_device.argtypes = [vp, sz, sz, dp, C.c_int, dbl, vp, vp]
     L.tracs_posterior_codes_device.restype = C.c_int
     L.tracs_posterior_codes_device.argtypes = [vp, sz, dp, C.c_int, dbl, vp, vp]
+    L.tracs_posterior_codes_cov_device.restype = C.c_int
+    L.tracs_posterior_codes_cov_device.argtypes = [vp, sz, dp, C.c_int, dbl, C.c_uint32, dbl, dbl, vp, vp]
+    L.tracs_codes_to_iupac_device.restype = C.c_int
+    L.tracs_codes_to_iupac_device.argtypes = [vp, sz, vp, vp]
+    L.tracs_alignment_pack_codes.restype = C.c_int
+    L.tracs_alignment_pack_codes.argtypes = [vp, vp, sz, vp]
     L.tracs_connected_components_device.restype = C.c_int
     L.tracs_connected_components_device.argtypes = [vp, vp, sz, sz, vp, C.POINTER(i32), vp]
     L.tracs_debug_alignment_encoding.restype = C.c_int

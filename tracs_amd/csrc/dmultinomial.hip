@@ -115,8 +115,12 @@ __device__ __forceinline__ unsigned posterior_mask4(const unsigned (&c)[4], cons
 
 // one thread = two sites: 16 B in, 1 B out (an 8-site / 4-byte-store form measured 13 % slower: the kernel is bound by
 // the f64 compare chain, not by its stores -- bench_aux.py)
+// Coverage rules of the align stage applied after the posterior filter (tracs/align.py:599-613): sites whose total count
+// is below min_cov, or inside the outlier band [cov_lo, cov_hi] (disabled when cov_lo > cov_hi), become fully ambiguous.
+struct CovRule { unsigned min_cov; double cov_lo, cov_hi; };
+
 __global__ __launch_bounds__(256) void posterior_codes_kernel(const uint4 *__restrict__ counts2, size_t L, Alphas A, int keep,
-                                                              double expected, uint8_t *__restrict__ codes)
+                                                              double expected, CovRule cov, uint8_t *__restrict__ codes)
 {
     const size_t npairs = (L + 1) / 2;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < npairs; t += (size_t)gridDim.x * blockDim.x) {
@@ -131,10 +135,24 @@ __global__ __launch_bounds__(256) void posterior_codes_kernel(const uint4 *__res
         for (int s = 0; s < 2; s++) {
             const unsigned w0 = s == 0 ? v.x : v.z, w1 = s == 0 ? v.y : v.w;
             const unsigned row[4] = {w0 & 0xFFFFu, w0 >> 16, w1 & 0xFFFFu, w1 >> 16};
-            if (2 * t + s < L) out |= posterior_mask4(row, A, keep, expected) << (4 * s);
+            if (2 * t + s < L) {
+                const unsigned rs = row[0] + row[1] + row[2] + row[3];
+                const bool masked = rs < cov.min_cov || ((double)rs >= cov.cov_lo && (double)rs <= cov.cov_hi);
+                out |= (masked ? 15u : posterior_mask4(row, A, keep, expected)) << (4 * s);
+            }
         }
         codes[t] = (uint8_t)out;
     }
+}
+
+// 4-bit allele mask -> IUPAC letter exactly as tracs/align.py:285-323 maps np.packbits(..., bitorder="little"):
+// 0 -> 'X' (no allele survived), 15 -> 'N'.
+__global__ void codes_to_iupac_kernel(const uint8_t *__restrict__ codes, size_t L, uint8_t *__restrict__ ascii)
+{
+    //                          0    1    2    3    4    5    6    7    8    9    10   11   12   13   14   15
+    const char lut[17] = "XACMGRSVTWYHKDBN";
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (size_t)gridDim.x * blockDim.x)
+        ascii[i] = (uint8_t)lut[(codes[i >> 1] >> (4 * (i & 1))) & 15u];
 }
 
 static int make_alphas(const double *alphas, size_t K, Alphas &A)
@@ -184,8 +202,27 @@ int tracs_calculate_posteriors_device(const double *counts, size_t L, size_t K, 
     return TRACS_OK;
 }
 
+int tracs_codes_to_iupac_device(const uint8_t *codes, size_t L, uint8_t *ascii, void *stream_)
+{
+    if (L == 0) return TRACS_OK;
+    if (!codes || !ascii) { set_error("tracs_codes_to_iupac_device: NULL argument"); return TRACS_E_ARG; }
+    hipLaunchKernelGGL(codes_to_iupac_kernel, dim3((unsigned)std::min<size_t>((L + 255) / 256, 256 * 16)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream_), codes, L, ascii);
+    TRACS_HIP_CHECK(hipGetLastError());
+    return TRACS_OK;
+}
+
+int tracs_posterior_codes_cov_device(const uint16_t *counts, size_t L, const double *alphas_host, int keep, double threshold,
+                                     uint32_t min_cov, double cov_lo, double cov_hi, uint8_t *codes, void *stream_);
+
 int tracs_posterior_codes_device(const uint16_t *counts, size_t L, const double *alphas_host, int keep, double threshold,
                                  uint8_t *codes, void *stream_)
+{
+    return tracs_posterior_codes_cov_device(counts, L, alphas_host, keep, threshold, 0u, 1.0, 0.0, codes, stream_);
+}
+
+int tracs_posterior_codes_cov_device(const uint16_t *counts, size_t L, const double *alphas_host, int keep, double threshold,
+                                     uint32_t min_cov, double cov_lo, double cov_hi, uint8_t *codes, void *stream_)
 {
     if (L == 0) return TRACS_OK;
     if (!counts || !alphas_host || !codes) { set_error("tracs_posterior_codes_device: NULL argument"); return TRACS_E_ARG; }
@@ -195,8 +232,9 @@ int tracs_posterior_codes_device(const uint16_t *counts, size_t L, const double 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const size_t npairs = (L + 1) / 2;
     const unsigned blocks = (unsigned)std::min<size_t>((npairs + 255) / 256, 256 * 16);
+    const CovRule cov{min_cov, cov_lo, cov_hi};
     hipLaunchKernelGGL(posterior_codes_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const uint4 *>(counts), L, A,
-                       keep, threshold, codes);
+                       keep, threshold, cov, codes);
     TRACS_HIP_CHECK(hipGetLastError());
     return TRACS_OK;
 }

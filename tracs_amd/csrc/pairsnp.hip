@@ -89,6 +89,32 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ a
         planes[(g * NPLANES + p) * n_pad + first + s] = make_uint4(pl[p][0], pl[p][1], pl[p][2], pl[p][3]);
 }
 
+// pack one sample from 4-bit allele masks (two sites per byte, low nibble first): one thread per 128-site group
+__global__ __launch_bounds__(256) void pack_codes_kernel(const uint8_t *__restrict__ codes, size_t L, size_t sample,
+                                                         uint4 *__restrict__ planes, size_t n_pad, size_t groups)
+{
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= groups) return;
+    unsigned pl[NPLANES][4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        unsigned A = 0, C = 0, G = 0, T = 0, N = 0;
+        for (int b = 0; b < 32; b++) {
+            const size_t site = g * SITES_PER_GROUP + w * 32 + b;
+            if (site < L) {
+                unsigned m = (codes[site >> 1] >> (4 * (site & 1))) & 15u;
+                if (m == 0) m = 15u;             // 'X' -> everything else -> all four alleles (pairsnp.hpp:192-197)
+                A |= (m & 1u) << b; C |= ((m >> 1) & 1u) << b; G |= ((m >> 2) & 1u) << b; T |= ((m >> 3) & 1u) << b;
+                N |= (m == 15u ? 1u : 0u) << b;
+            }
+        }
+        pl[0][w] = A; pl[1][w] = C; pl[2][w] = G; pl[3][w] = T; pl[4][w] = N;
+    }
+#pragma unroll
+    for (int p = 0; p < NPLANES; p++)
+        planes[(g * NPLANES + p) * n_pad + sample] = make_uint4(pl[p][0], pl[p][1], pl[p][2], pl[p][3]);
+}
+
 // ---------------------------------------------------------------------------------------
 // XCD-aware, bijective remap of the hardware block id (guide T1): blocks b, b+8, b+16.. share
 // an XCD (and its L2); give each XCD a contiguous run of the logical schedule so that the
@@ -723,6 +749,10 @@ static const TileVariant kVariants[] = {
     TRACS_VARIANT_GC(8, 8, 2, 5, ROW_LDS, 4),    // 54
     TRACS_VARIANT_GC(8, 8, 2, 3, ROW_LDS, 4),    // 55
     TRACS_VARIANT_GC(4, 16, 2, 2, ROW_LDS, 3),   // 56
+    TRACS_VARIANT_GC(4, 16, 3, 2, ROW_LDS, 3),   // 57: 64 x 192 tile
+    TRACS_VARIANT_GC(8, 8, 3, 2, ROW_LDS, 3),    // 58
+    TRACS_VARIANT_GC(4, 16, 3, 1, ROW_LDS, 3),   // 59
+    TRACS_VARIANT_GC(4, 16, 3, 2, ROW_LDS, 2),   // 60
 };
 static constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 // fastest measured on MI355X (profiles/r01/tile_variant_sweeps.txt): one default per encoding
@@ -932,6 +962,18 @@ int tracs_pairsnp_dense(const tracs_alignment *a_, size_t row_begin, size_t row_
     const unsigned nwg = (unsigned)(a->n_tiles * (size_t)ksplit);
     (cons ? V.launch_cons : V.launch)(ncomp != nullptr, nwg, stream, cons ? a->cplanes : a->planes, a->n_pad, groups, a->d_tiles, (int)a->n_tiles, gps, ksplit, (unsigned)a->L,
              (unsigned)a->n, (unsigned)row_end, (unsigned)col_begin, dist, ncomp, ld);
+    TRACS_HIP_CHECK(hipGetLastError());
+    return TRACS_OK;
+}
+
+int tracs_alignment_pack_codes(tracs_alignment *a, const uint8_t *codes, size_t sample, void *stream_)
+{
+    if (!a || !codes) { set_error("tracs_alignment_pack_codes: NULL argument"); return TRACS_E_ARG; }
+    if (sample >= a->n) { set_error("tracs_alignment_pack_codes: sample index outside the alignment"); return TRACS_E_ARG; }
+    if (!a->L) return TRACS_OK;
+    a->dirty = true;
+    hipLaunchKernelGGL(pack_codes_kernel, dim3((unsigned)((a->groups + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                       codes, a->L, sample, a->planes, a->n_pad, a->groups);
     TRACS_HIP_CHECK(hipGetLastError());
     return TRACS_OK;
 }

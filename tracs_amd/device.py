@@ -57,6 +57,11 @@ class Alignment:
             on_dev, ptr, count = 0, C.c_void_p(a.ctypes.data), a.shape[0]
         _lib.check(self._L.tracs_alignment_pack(self._h, ptr, int(first), int(count), on_dev, _stream()))
 
+    def pack_codes(self, codes, sample):
+        """Pack one sample straight from its packed 4-bit allele masks (posterior_codes_device output)."""
+        assert codes.dtype == torch.uint8 and codes.is_cuda and codes.numel() == (self.L + 1) // 2
+        _lib.check(self._L.tracs_alignment_pack_codes(self._h, _ptr(codes), int(sample), _stream()))
+
     @property
     def encoding(self):
         """'consensus' (3 planes) / 'general' (5 planes) as used by the last dense call, None before the first."""
@@ -166,14 +171,25 @@ def calculate_posteriors_device(counts, alphas, keep, threshold):
     return out
 
 
-def posterior_codes_device(counts_u16, alphas, keep, threshold):
-    """counts_u16: torch.int16/uint16 [L,4] -> torch.uint8 [(L+1)//2] packed allele masks."""
+def posterior_codes_device(counts_u16, alphas, keep, threshold, min_cov=0, cov_band=None):
+    """counts_u16: torch.int16/uint16 [L,4] -> torch.uint8 [(L+1)//2] packed allele masks (low nibble = even site).
+    min_cov / cov_band=(lo, hi): the align stage's coverage rules (sites below min_cov or inside the band become N)."""
     L = _lib.require_gpu()
     a = np.ascontiguousarray(alphas, dtype=np.float64)
     n = counts_u16.shape[0]
     out = torch.empty((n + 1) // 2, dtype=torch.uint8, device=counts_u16.device)
-    _lib.check(L.tracs_posterior_codes_device(_ptr(counts_u16), n, a.ctypes.data_as(C.POINTER(C.c_double)),
-                                              int(bool(keep)), float(threshold), _ptr(out), _stream()))
+    lo, hi = cov_band if cov_band is not None else (1.0, 0.0)
+    _lib.check(L.tracs_posterior_codes_cov_device(_ptr(counts_u16), n, a.ctypes.data_as(C.POINTER(C.c_double)),
+                                                  int(bool(keep)), float(threshold), int(min_cov), float(lo), float(hi),
+                                                  _ptr(out), _stream()))
+    return out
+
+
+def codes_to_iupac_device(codes, L):
+    """packed 4-bit masks -> torch.uint8 [L] IUPAC letters ('X' for an empty mask), tracs/align.py:285-323."""
+    lib = _lib.require_gpu()
+    out = torch.empty(L, dtype=torch.uint8, device=codes.device)
+    _lib.check(lib.tracs_codes_to_iupac_device(_ptr(codes), L, _ptr(out), _stream()))
     return out
 
 
