@@ -37,8 +37,9 @@ def test_counts_to_codes_to_planes(hiplib, oracle, tmp_path):
         counts[5 * s:5 * s + 40] = 0                                                       # uncovered stretch
         keep = bool(s & 1)
         band = (2.0, 4.0) if s == 3 else None
-        ref = _reference_sequence(oracle, counts, alphas, keep, 0.05, 3, band)
-        codes = dev.posterior_codes_device(torch.from_numpy(counts.view(np.int16)).cuda(), alphas, keep, 0.05, min_cov=3,
+        thr = 0.2 + 0.05 * (s % 3)
+        ref = _reference_sequence(oracle, counts, alphas, keep, thr, 3, band)
+        codes = dev.posterior_codes_device(torch.from_numpy(counts.view(np.int16)).cuda(), alphas, keep, thr, min_cov=3,
                                            cov_band=band)
         got = dev.codes_to_iupac_device(codes, L).cpu().numpy()
         assert np.array_equal(got, ref), (s, np.where(got != ref)[0][:5])
