@@ -10,12 +10,17 @@ KSEQ_INIT(gzFile, gzread)
 int main(int argc, char **argv)
 {
     if (argc < 2) return 2;
+    int quiet = argc > 2 && argv[2][0] == '-' && argv[2][1] == 'q';   /* -q: parse only (timing the reference reader) */
     gzFile fp = gzopen(argv[1], "r");
     if (!fp) { printf("#rc=-5\n"); return 0; }
     kseq_t *seq = kseq_init(fp);
     int l;
-    while ((l = kseq_read(seq)) >= 0)
-        printf("%s\t%s\n", seq->name.s ? seq->name.s : "", (seq->seq.s && l > 0) ? seq->seq.s : "");
+    long nrec = 0, nbytes = 0;
+    while ((l = kseq_read(seq)) >= 0) {
+        nrec++; nbytes += l;
+        if (!quiet) printf("%s\t%s\n", seq->name.s ? seq->name.s : "", (seq->seq.s && l > 0) ? seq->seq.s : "");
+    }
+    if (quiet) printf("#records=%ld bases=%ld\n", nrec, nbytes);
     printf("#rc=%d\n", l);
     kseq_destroy(seq);
     gzclose(fp);
