@@ -87,3 +87,47 @@ def test_product_never_imports_the_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
                 assert "liboracle" not in text and "oracle/" not in text.replace("oracle/.", ""), f
     assert "oracle" not in open(os.path.join(ROOT, "TRACS.py")).read()
+
+
+def test_parallel_fasta_reader_equals_serial_state_machine(hiplib, tmp_path):
+    """Large well-formed plain FASTA takes the multi-threaded mmap path; it must return exactly what the serial kseq
+    restatement returns, and anything not well-formed must fall back (same results, same errors)."""
+    import numpy as np
+
+    def parse(path, serial):
+        if serial:
+            os.environ["TRACS_SERIAL_FASTA"] = "1"
+        else:
+            os.environ.pop("TRACS_SERIAL_FASTA", None)
+        n, L, h = C.c_size_t(0), C.c_size_t(0), C.c_uint64(0)
+        rc = hiplib.tracs_debug_read_fasta(path.encode(), C.byref(n), C.byref(L), C.byref(h))
+        os.environ.pop("TRACS_SERIAL_FASTA", None)
+        return rc, n.value, L.value, h.value, hiplib.tracs_last_error()
+
+    rng = np.random.default_rng(0)
+    L, n = 1_000_003, 80
+    base = np.frombuffer(b"ACGTN", np.uint8)[rng.integers(0, 5, L)]
+    good = os.path.join(str(tmp_path), "big.fa")
+    with open(good, "wb") as f:
+        for s in range(n):
+            row = base.copy()
+            row[rng.integers(0, L, 100)] = ord("a")
+            sep = b"\r\n" if s % 7 == 3 else b"\n"
+            f.write(b">rec%d some comment > with gt\n" % s)
+            f.write(sep.join(row[o:o + 70].tobytes() for o in range(0, L, 70)))
+            if s != n - 1:
+                f.write(sep)
+    a, b = parse(good, False), parse(good, True)
+    assert a[0] == 0 and a[:4] == b[:4] and a[1] == n and a[2] == L
+    # a stray '>' inside a sequence line: kseq splits the record there -> ragged; both paths must say so
+    bad = os.path.join(str(tmp_path), "bad.fa")
+    data = open(good, "rb").read()
+    k = data.index(b"\n", 200) + 30
+    open(bad, "wb").write(data[:k] + b">" + data[k + 1:])
+    a, b = parse(bad, False), parse(bad, True)
+    assert a[0] == b[0] == -4 and a[4] == b[4] == b"Error reading FASTA, variable sequence lengths!"
+    # junk before the first header: the serial rules skip it; the fast path must decline and agree
+    junk = os.path.join(str(tmp_path), "junk.fa")
+    open(junk, "wb").write(b"# comment line\n" + data)
+    a, b = parse(junk, False), parse(junk, True)
+    assert a[0] == 0 and a[:4] == b[:4] and a[1] == n

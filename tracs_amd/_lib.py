@@ -136,6 +136,8 @@ def load():
     L.tracs_alignment_pack_codes.argtypes = [vp, vp, sz, vp]
     L.tracs_connected_components_device.restype = C.c_int
     L.tracs_connected_components_device.argtypes = [vp, vp, sz, sz, vp, C.POINTER(i32), vp]
+    L.tracs_debug_read_fasta.restype = C.c_int
+    L.tracs_debug_read_fasta.argtypes = [C.c_char_p, C.POINTER(sz), C.POINTER(sz), C.POINTER(C.c_uint64)]
     L.tracs_debug_alignment_encoding.restype = C.c_int
     L.tracs_debug_alignment_encoding.argtypes = [vp]
     L.tracs_debug_tile_variant.restype = C.c_char_p

@@ -71,6 +71,23 @@ int tracs_device_count(void)
 
 void tracs_free(void *p) { std::free(p); }
 
+// host-only: parse a FASTA and return record count, length and an FNV-1a hash over names and sequences (tests)
+int tracs_debug_read_fasta(const char *path, size_t *n, size_t *L, uint64_t *hash)
+{
+    FastaData fd;
+    std::string err;
+    const int rc = read_fasta(path, fd, err);
+    if (rc) { set_error(err); return rc; }
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const uint8_t *b, size_t k) { for (size_t i = 0; i < k; i++) { h ^= b[i]; h *= 1099511628211ull; } };
+    for (auto &nm : fd.names) { mix(reinterpret_cast<const uint8_t *>(nm.data()), nm.size()); const uint8_t z = 0; mix(&z, 1); }
+    mix(fd.seq.data(), fd.seq.size());
+    if (n) *n = fd.n;
+    if (L) *L = fd.L;
+    if (hash) *hash = h;
+    return TRACS_OK;
+}
+
 int tracs_alignment_from_fasta(const char *const *fasta, int n_fasta, tracs_alignment **out, char **names_out,
                                size_t *names_bytes, size_t *n_first_file)
 {

@@ -9,14 +9,22 @@
 //   * '+' opens a FASTQ quality block: the rest of that line is skipped, then as many printable
 //     bytes as the sequence has are consumed; a shorter block is an error;
 //   * all records must have one length ("Error reading FASTA, variable sequence lengths!").
-// Own implementation: a streaming state machine over 1 MiB gzread blocks (zlib reads plain and
-// gzip files alike, as gzopen does for the reference).
+// Own implementation: a streaming state machine over 4 MiB gzread blocks (zlib reads plain and gzip files alike, as
+// gzopen does for the reference), plus a multi-threaded mmap fast path for large well-formed plain FASTA files.
 #include "fasta.h"
 
 #include <zlib.h>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
 #include <cctype>
 #include <cstring>
+#include <thread>
 
 namespace tracs {
 
@@ -52,8 +60,102 @@ inline bool is_graph(unsigned c) { return c - 33u < 94u; }      // isgraph() in 
 
 }  // namespace
 
+// ---- parallel fast path for plain (uncompressed) FASTA -------------------------------------------------------
+// Valid exactly when the byte-level rules above reduce to "records start at '>' in column 0": the file begins with
+// '>', every other '>' follows a newline, and no '>', '+' or '@' occurs inside a sequence line.  Anything else
+// (FASTQ, junk before the first header, '>' mid-line, ragged lengths) returns false and the serial state machine
+// below -- the exact restatement of kseq -- reads the file and produces the reference's behaviour and messages.
+static bool read_fasta_parallel(const std::string &path, FastaData &out)
+{
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size < 64 * 1024 * 1024) { close(fd); return false; }   // small files: serial
+    const size_t size = (size_t)st.st_size;
+    void *m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return false;
+    const unsigned char *p = static_cast<const unsigned char *>(m);
+    bool ok = p[0] == '>' && !(p[0] == 0x1f && p[1] == 0x8b);
+    std::vector<size_t> starts;
+    const unsigned T = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    if (ok) {
+        // record starts: '>' at offset 0 or right after a newline
+        std::vector<std::vector<size_t>> part(T);
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < T; t++)
+            th.emplace_back([&, t]() {
+                const size_t a = size * t / T, b = size * (t + 1) / T;
+                const unsigned char *q = p + std::max<size_t>(a, 1);
+                const unsigned char *e = p + b;
+                while (q < e && (q = static_cast<const unsigned char *>(memchr(q, '>', (size_t)(e - q)))) != nullptr) {
+                    if (q[-1] == '\n') part[t].push_back((size_t)(q - p));
+                    q++;
+                }
+            });
+        for (auto &x : th) x.join();
+        starts.push_back(0);
+        for (auto &v : part) starts.insert(starts.end(), v.begin(), v.end());
+    }
+    size_t L = 0;
+    const size_t nrec = starts.size();
+    std::vector<std::string> names(nrec);
+    std::vector<uint8_t> seq;
+    if (ok) {
+        // length of the first record fixes L
+        auto body_of = [&](size_t r, size_t &b0, size_t &b1) {
+            const size_t s0 = starts[r], s1 = r + 1 < nrec ? starts[r + 1] : size;
+            const unsigned char *nl = static_cast<const unsigned char *>(memchr(p + s0, '\n', s1 - s0));
+            b0 = nl ? (size_t)(nl - p) + 1 : s1;
+            b1 = s1;
+        };
+        size_t b0, b1;
+        body_of(0, b0, b1);
+        for (size_t k = b0; k < b1; k++) L += is_graph(p[k]);
+        seq.resize(nrec * L);
+        std::atomic<bool> bad{false};
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < T; t++)
+            th.emplace_back([&]() {
+                for (;;) {
+                    const size_t r = next.fetch_add(1);
+                    if (r >= nrec || bad.load(std::memory_order_relaxed)) return;
+                    size_t c0, c1;
+                    body_of(r, c0, c1);
+                    // header: name = bytes after '>' up to the first whitespace
+                    size_t h = starts[r] + 1;
+                    const size_t hend = c0 ? c0 - 1 : 0;
+                    size_t he = h;
+                    while (he < hend && !std::isspace(p[he])) he++;
+                    names[r].assign(reinterpret_cast<const char *>(p + h), he - h);
+                    uint8_t *dst = seq.data() + r * L;
+                    size_t w = 0;
+                    bool stray = false;
+                    for (size_t k = c0; k < c1; k++) {
+                        const unsigned ch = p[k];
+                        stray |= (ch == '>') | (ch == '+') | (ch == '@');
+                        if (w < L) dst[w] = (uint8_t)ch;
+                        w += is_graph(ch);
+                    }
+                    if (stray || w != L) bad.store(true);
+                }
+            });
+        for (auto &x : th) x.join();
+        ok = !bad.load();
+    }
+    munmap(m, size);
+    if (!ok) return false;
+    out.n = nrec;
+    out.L = L;
+    out.seq = std::move(seq);
+    out.names = std::move(names);
+    return true;
+}
+
 int read_fasta(const std::string &path, FastaData &out, std::string &err)
 {
+    if (out.n == 0 && out.seq.empty() && !getenv("TRACS_SERIAL_FASTA") && read_fasta_parallel(path, out)) return TRACS_OK;
     gzFile f = gzopen(path.c_str(), "rb");
     if (!f) { err = "cannot open '" + path + "'"; return TRACS_E_OPEN; }
     gzbuffer(f, 1u << 20);
