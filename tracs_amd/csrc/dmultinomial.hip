@@ -87,29 +87,44 @@ __global__ __launch_bounds__(256) void posteriorsK_kernel(const double *__restri
 // Only "is the thresholded posterior > 0" is needed, so the divide of :59 is replaced by a comparison of the
 // numerator with threshold * denominator; the exact quotient is formed only inside a 4-ulp guard band around the
 // threshold, which keeps the decision identical to the reference's `post <= threshold` on the divided value.
+__device__ __forceinline__ void cmpx_desc(unsigned &a, unsigned &b)
+{
+    const unsigned hi = max(a, b), lo = min(a, b);
+    a = hi; b = lo;
+}
+
+// Integer route to the ranks: sort the four (count << 2 | allele) keys descending with a 5-exchange network; equal counts
+// are adjacent, so the alpha rank (number of distinct larger counts, see posterior_row) grows by one exactly where the
+// sorted count changes (:59-64).  Only the final "posterior > threshold" comparison is floating point.
 __device__ __forceinline__ unsigned posterior_mask4(const unsigned (&c)[4], const Alphas &A, int keep, double expected)
 {
     const unsigned tot = c[0] + c[1] + c[2] + c[3];                      // exact: the f64 sum of :38-42 is exact for integers < 2^53
     if (tot == 0) {                                                      // :53-56: every cell a_min; counts are zero: `keep` cannot apply
         return (!(A.a_min <= expected) && A.a_min > 0.0) ? 15u : 0u;
     }
+    unsigned k0 = (c[0] << 2) | 0u, k1 = (c[1] << 2) | 1u, k2 = (c[2] << 2) | 2u, k3 = (c[3] << 2) | 3u;
+    cmpx_desc(k0, k1); cmpx_desc(k2, k3); cmpx_desc(k0, k2); cmpx_desc(k1, k3); cmpx_desc(k1, k2);
+    const unsigned s0 = k0 >> 2, s1 = k1 >> 2, s2 = k2 >> 2, s3 = k3 >> 2;
+    const bool n1 = s1 != s0, n2 = s2 != s1, n3 = s3 != s2;              // rank steps
+    const double al0 = A.a[0];
+    const double al1 = n1 ? A.a[1] : al0;
+    const double al2 = n2 ? (n1 ? A.a[2] : A.a[1]) : al1;
+    const double al3 = n3 ? ((n1 && n2) ? A.a[3] : ((n1 || n2) ? A.a[2] : A.a[1])) : al2;
     const double den = (double)tot + A.a0;
     const double lim = expected * den, hi = lim * (1.0 + 1e-15), lo = lim * (1.0 - 1e-15);
-    // rank of a cell = number of distinct count values strictly greater (see posterior_row); integer compares only
-    const bool f1 = c[1] != c[0], f2 = c[2] != c[0] && c[2] != c[1], f3 = c[3] != c[0] && c[3] != c[1] && c[3] != c[2];
     unsigned m = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int rank = (int)(c[0] > c[j]) + (int)(f1 && c[1] > c[j]) + (int)(f2 && c[2] > c[j]) + (int)(f3 && c[3] > c[j]);
-        const double al = rank == 0 ? A.a[0] : rank == 1 ? A.a[1] : rank == 2 ? A.a[2] : A.a[3];
-        const double num = (double)c[j] + al;
-        bool above;                                                      // post > expected ?
-        if (num > hi) above = true;
-        else if (num < lo) above = false;
-        else above = !((num / den) <= expected);                         // guard band: the reference's own arithmetic
-        const bool bit = above ? (num > 0.0) : (keep && c[j] > 0 && expected > 0.0);   // den > 0: sign(num/den) = sign(num)
-        m |= (bit ? 1u : 0u) << j;
+#define TRACS_CELL(S, AL, K)                                                                                       \
+    {                                                                                                              \
+        const double num = (double)(S) + (AL);                                                                     \
+        bool above;                                   /* post > expected ? */                                      \
+        if (num > hi) above = true;                                                                                \
+        else if (num < lo) above = false;                                                                          \
+        else above = !((num / den) <= expected);      /* guard band: the reference's own arithmetic */             \
+        const bool bit = above ? (num > 0.0) : (keep && (S) > 0 && expected > 0.0);                                \
+        m |= (bit ? 1u : 0u) << ((K) & 3u);                                                                        \
     }
+    TRACS_CELL(s0, al0, k0) TRACS_CELL(s1, al1, k1) TRACS_CELL(s2, al2, k2) TRACS_CELL(s3, al3, k3)
+#undef TRACS_CELL
     return m;
 }
 
