@@ -126,6 +126,12 @@ void tracs_free(void *p);
 int tracs_pairsnp_dense(const tracs_alignment *a, size_t row_begin, size_t row_end, size_t col_begin,
                         uint32_t *dist, uint32_t *ncomp, size_t ld, void *stream);
 
+/* Thresholded form: identical for every pair with d <= dist_threshold; a pair beyond the threshold (never emitted,
+ * src/pairsnp.hpp:405) may come back as 0xFFFFFFFF instead of its exact distance, because workgroups stop reading the
+ * alignment once every pair of their tile is past the threshold.                                                    */
+int tracs_pairsnp_dense_thr(const tracs_alignment *a, size_t row_begin, size_t row_end, size_t col_begin,
+                            uint32_t *dist, uint32_t *ncomp, size_t ld, int32_t dist_threshold, void *stream);
+
 /* Thresholded COO extraction from a dense block, row-major, same cell set as above.
  * Phase 1 (counts==per-row counts, device int64[row_end-row_begin+1] exclusive offsets on return),
  * phase 2 fills rows/cols/d/nn (device uint32) at those offsets.                            */

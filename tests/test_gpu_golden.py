@@ -319,3 +319,36 @@ def test_connected_components_device(dev, torch_mod):
     nc, lab = dev.connected_components_device(torch.from_numpy(I).cuda(), torch.from_numpy(J).cuda(), n)
     enc, elab = connected_components(csgraph=csr_matrix((np.ones(m), (I, J)), shape=(n, n)), directed=False)
     assert nc == enc and np.array_equal(lab.cpu().numpy(), elab)
+
+
+def test_thresholded_dense_early_out(dev, oracle, torch_mod):
+    """With a SNP threshold, tiles whose pairs are all past it stop reading the alignment; every pair <= threshold must
+    still be exact (both encodings), and the COO output must equal the oracle's."""
+    from tracs_amd import synth
+    torch = torch_mod
+    n, L = 700, 120000
+    for p_partial, enc in ((0.0, "consensus"), (0.0005, "general")):
+        # 10 well separated lineages (~ 2 * 3e-3 * L = 700 SNPs apart), close samples inside (~ 2 * 5e-5 * L = 12)
+        seqs = synth.alignment(n, L, seed=61, mu_lineage=3e-3, mu_sample=5e-5, n_lineages=10, p_n=0.01, p_partial=p_partial)
+        seqs = seqs[np.argsort(np.arange(n) % 10, kind="stable")]          # group the lineages so whole tiles are far apart
+        aln = dev.Alignment(n, L)
+        aln.pack(seqs)
+        for thr in (40, 0):
+            d = torch.zeros((n, n), dtype=torch.int32, device="cuda")
+            nn = torch.zeros((n, n), dtype=torch.int32, device="cuda")
+            dev.pairsnp_dense(aln, d, nn, dist_threshold=thr)
+            assert aln.encoding == enc
+            er, ec, ed, enn = oracle.pairsnp_arrays(seqs, n_threads=16)
+            ri, ci = er.astype(np.int64), ec.astype(np.int64)
+            dh = d.cpu().numpy().view(np.uint32)
+            keep = ed <= thr
+            assert np.array_equal(dh[ri[keep], ci[keep]], ed[keep].astype(np.uint32))
+            assert np.array_equal(nn.cpu().numpy()[ri[keep], ci[keep]], enn[keep].astype(np.int32))
+            far = dh[ri[~keep], ci[~keep]]
+            assert (far.astype(np.int64) > thr).all()                      # exact or the 0xFFFFFFFF sentinel, never <= thr
+            assert (far == 0xFFFFFFFF).mean() > 0.5                        # most far tiles did stop early
+            rows, cols, dd, nc = dev.coo_from_dense(d, nn, n, dist_threshold=thr)
+            xr, xc, xd, xn = oracle.pairsnp_arrays(seqs, dist=thr, n_threads=16)
+            assert np.array_equal(rows.cpu().numpy(), xr.astype(np.int32)) and np.array_equal(dd.cpu().numpy(), xd.astype(np.int32))
+            assert np.array_equal(cols.cpu().numpy(), xc.astype(np.int32)) and np.array_equal(nc.cpu().numpy(), xn.astype(np.int32))
+        aln.close()

@@ -21,7 +21,7 @@ SYMBOLS = [
     "tracs_alignment_create", "tracs_alignment_free", "tracs_alignment_n", "tracs_alignment_len",
     "tracs_alignment_bytes", "tracs_alignment_planes", "tracs_alignment_pack", "tracs_alignment_from_fasta",
     "tracs_free",
-    "tracs_pairsnp_dense", "tracs_coo_count", "tracs_coo_fill", "tracs_filter_recomb_device",
+    "tracs_pairsnp_dense", "tracs_pairsnp_dense_thr", "tracs_coo_count", "tracs_coo_fill", "tracs_filter_recomb_device",
     "tracs_trans_dist_device", "tracs_trans_dist_dense", "tracs_trans_dist_dense2",
     "tracs_calculate_posteriors_device", "tracs_posterior_codes_device", "tracs_posterior_codes_cov_device",
     "tracs_codes_to_iupac_device", "tracs_alignment_pack_codes",
@@ -112,6 +112,8 @@ def load():
     L.tracs_free.argtypes = [vp]
     L.tracs_pairsnp_dense.restype = C.c_int
     L.tracs_pairsnp_dense.argtypes = [vp, sz, sz, sz, vp, vp, sz, vp]
+    L.tracs_pairsnp_dense_thr.restype = C.c_int
+    L.tracs_pairsnp_dense_thr.argtypes = [vp, sz, sz, sz, vp, vp, sz, i32, vp]
     L.tracs_coo_count.restype = C.c_int
     L.tracs_coo_count.argtypes = [vp, sz, sz, sz, sz, sz, i32, vp, vp]
     L.tracs_coo_fill.restype = C.c_int

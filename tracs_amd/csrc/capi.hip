@@ -179,7 +179,7 @@ int tracs_pairsnp(const char *const *fasta, int n_fasta, int n_threads, int dist
             const size_t r1 = std::min(i_end, r0 + panel);
             // the dense block is addressed as base[(i) * ld + j] with i absolute: shift the base
             unsigned *bd = d_dist - r0 * n, *bn = d_nn - r0 * n;
-            PS_RC(tracs_pairsnp_dense(a, r0, r1, j_start, bd, bn, n, nullptr));
+            PS_RC(tracs_pairsnp_dense_thr(a, r0, r1, j_start, bd, bn, n, dist, nullptr));   // early out beyond `dist`
             PS_RC(tracs_coo_count(bd, n, n, r0, r1, j_start, dist, reinterpret_cast<int64_t *>(d_off), nullptr));
             long long total = 0;
             PS_CHECK(hipMemcpy(&total, d_off + (r1 - r0), 8, hipMemcpyDeviceToHost));

@@ -174,7 +174,7 @@ template <int NW, int R, int C, int GC, bool WITH_NN, int ROWSRC, int MINW = 1, 
 __global__ __launch_bounds__(NW * 64, MINW) void pairsnp_tile_kernel(
     const uint4 *__restrict__ P, size_t n_pad, int groups, const int2 *__restrict__ tiles, int n_tiles,
     int groups_per_split, int ksplit, unsigned L, unsigned n, unsigned row_end, unsigned col_begin,
-    unsigned *__restrict__ dist, unsigned *__restrict__ ncomp, size_t ld)
+    unsigned *__restrict__ dist, unsigned *__restrict__ ncomp, size_t ld, unsigned thr)
 {
     constexpr int NP = ENC ? 3 : NPLANES;                   // planes of this encoding
     constexpr int NT = NW * 64;
@@ -314,6 +314,14 @@ __global__ __launch_bounds__(NW * 64, MINW) void pairsnp_tile_kernel(
             for (int p = 0; p < NPL; p++) fixed_bj[c][p] = lds[0][p * TS + lane + 64 * c];
     }
 
+    // Early out for thresholded runs (thr != ~0u, ksplit == 1): every 4th stage the workgroup takes the minimum partial
+    // distance over its valid cells; partial distances only grow, so once the minimum exceeds the threshold no pair of the
+    // tile can be emitted (src/pairsnp.hpp:405) and the rest of the alignment is skipped.  Cells then hold 0xFFFFFFFF.
+    __shared__ unsigned wmin[NW];
+    const bool can_exit = thr != 0xFFFFFFFFu && j0 >= i0 + TI;      // tiles touching the diagonal hold d(i,i) = 0 cells
+    bool early = false;
+    int stage_no = 0;
+
     int buf = 0;
     for (int gs = g_begin; gs < g_end; gs += GC) {
         const bool more = !COLS_FIXED && gs + GC < g_end;
@@ -361,7 +369,31 @@ __global__ __launch_bounds__(NW * 64, MINW) void pairsnp_tile_kernel(
             }
         }
         if (more) stage_store(buf ^ 1);
+        const bool check = can_exit && more && ((++stage_no) & 3) == 0;
+        if (check) {
+            const unsigned done_sites = (unsigned)(min(gs + GC, g_end) - g_begin) * SITES_PER_GROUP;
+            unsigned mn = 0xFFFFFFFFu;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const bool row_ok = (unsigned)(i0 + wave * R + r) < row_end;
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    const bool ok = row_ok && (unsigned)(j0 + lane + 64 * c) < n;
+                    const unsigned dsofar = ENC ? accM[r][c] : done_sites - accM[r][c];
+                    mn = min(mn, ok ? dsofar : 0xFFFFFFFFu);
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mn = min(mn, (unsigned)__shfl_xor((int)mn, off, 64));
+            if (lane == 0) wmin[wave] = mn;
+        }
         if (!COLS_FIXED) { __syncthreads(); buf ^= 1; }
+        if (check) {
+            unsigned m = wmin[0];
+#pragma unroll
+            for (int w = 1; w < NW; w++) m = min(m, wmin[w]);
+            if (m > thr) { early = true; break; }
+        }
     }
 
     // epilogue: d = L - matches, nn = L - masked; only cells of the requested set are written
@@ -374,7 +406,10 @@ __global__ __launch_bounds__(NW * 64, MINW) void pairsnp_tile_kernel(
             const unsigned j = (unsigned)(j0 + lane + 64 * c);
             if (j < n && j > i && j >= col_begin) {
                 const size_t o = (size_t)i * ld + j;
-                if (ENC) {                                // accumulators hold d and nn themselves
+                if (early) {                              // every pair of the tile is beyond the threshold
+                    dist[o] = 0xFFFFFFFFu;
+                    if (WITH_NN) ncomp[o] = 0u;
+                } else if (ENC) {                         // accumulators hold d and nn themselves
                     if (ksplit == 1) {
                         dist[o] = accM[r][c];
                         if (WITH_NN) ncomp[o] = accN[r][c];
@@ -652,7 +687,7 @@ using namespace tracs;
 // (default: the fastest measured on MI355X, see DESIGN.md "pairsnp kernel: variants measured").
 typedef void (*TileLaunch)(bool with_nn, unsigned nwg, hipStream_t stream, const uint4 *P, size_t n_pad, int groups,
                            const int2 *tiles, int n_tiles, int gps, int ksplit, unsigned L, unsigned n, unsigned row_end,
-                           unsigned col_begin, unsigned *dist, unsigned *ncomp, size_t ld);
+                           unsigned col_begin, unsigned *dist, unsigned *ncomp, size_t ld, unsigned thr);
 struct TileVariant {
     const char *name;
     int ti, tj, gc, nthreads;
@@ -663,20 +698,20 @@ struct TileVariant {
 template <int NW, int R, int C, int GC, int ROWSRC, int MINW = 1, bool GLDS = false, int ENC = 0>
 static void launch_variant(bool with_nn, unsigned nwg, hipStream_t stream, const uint4 *P, size_t n_pad, int groups,
                            const int2 *tiles, int n_tiles, int gps, int ksplit, unsigned L, unsigned n, unsigned row_end,
-                           unsigned col_begin, unsigned *dist, unsigned *ncomp, size_t ld)
+                           unsigned col_begin, unsigned *dist, unsigned *ncomp, size_t ld, unsigned thr)
 {
     if (with_nn)
         hipLaunchKernelGGL((pairsnp_tile_kernel<NW, R, C, GC, true, ROWSRC, MINW, GLDS, ENC>), dim3(nwg), dim3(NW * 64), 0, stream, P, n_pad, groups,
-                           tiles, n_tiles, gps, ksplit, L, n, row_end, col_begin, dist, ncomp, ld);
+                           tiles, n_tiles, gps, ksplit, L, n, row_end, col_begin, dist, ncomp, ld, thr);
     else
         hipLaunchKernelGGL((pairsnp_tile_kernel<NW, R, C, GC, false, ROWSRC, MINW, GLDS, ENC>), dim3(nwg), dim3(NW * 64), 0, stream, P, n_pad, groups,
-                           tiles, n_tiles, gps, ksplit, L, n, row_end, col_begin, dist, ncomp, ld);
+                           tiles, n_tiles, gps, ksplit, L, n, row_end, col_begin, dist, ncomp, ld, thr);
 }
 
 template <int NW, int R, int C>
 static void launch_rowcast(bool with_nn, unsigned nwg, hipStream_t stream, const uint4 *P, size_t n_pad, int groups,
                            const int2 *tiles, int n_tiles, int gps, int ksplit, unsigned L, unsigned n, unsigned row_end,
-                           unsigned col_begin, unsigned *dist, unsigned *ncomp, size_t ld)
+                           unsigned col_begin, unsigned *dist, unsigned *ncomp, size_t ld, unsigned /*thr: no early out here*/)
 {
     if (with_nn)
         hipLaunchKernelGGL((pairsnp_rowcast_kernel<NW, R, C, true>), dim3(nwg), dim3(NW * 64), 0, stream, P, n_pad, groups, tiles,
@@ -743,7 +778,7 @@ static const TileVariant kVariants[] = {
     TRACS_VARIANT_GC(8, 16, 2, 2, ROW_LDS, 2),   // 48
     TRACS_VARIANT_GC(16, 8, 2, 2, ROW_LDS, 4),   // 49
     TRACS_VARIANT_GC(8, 8, 4, 2, ROW_LDS, 3),    // 50
-    TRACS_VARIANT_GC(8, 16, 2, 4, ROW_LDS, 3),   // 51
+    TRACS_VARIANT_GC(8, 16, 2, 3, ROW_LDS, 3),   // 51
     TRACS_VARIANT_GC(4, 16, 2, 4, ROW_LDS, 3),   // 52
     TRACS_VARIANT_GC(4, 16, 4, 2, ROW_LDS, 2),   // 53
     TRACS_VARIANT_GC(8, 8, 2, 5, ROW_LDS, 4),    // 54
@@ -859,8 +894,25 @@ const char *tracs_debug_tile_variant(void) { return current_variant().name; }
 // 1 if the last dense call on this alignment used the consensus (3-plane) encoding, 0 general, -1 not decided yet
 int tracs_debug_alignment_encoding(const tracs_alignment *a) { return !a ? -1 : (a->dirty ? -1 : a->enc); }
 
+static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_t row_end, size_t col_begin, uint32_t *dist,
+                              uint32_t *ncomp, size_t ld, void *stream_, unsigned thr);
+
 int tracs_pairsnp_dense(const tracs_alignment *a_, size_t row_begin, size_t row_end, size_t col_begin, uint32_t *dist,
                         uint32_t *ncomp, size_t ld, void *stream_)
+{
+    return pairsnp_dense_impl(a_, row_begin, row_end, col_begin, dist, ncomp, ld, stream_, 0xFFFFFFFFu);
+}
+
+int tracs_pairsnp_dense_thr(const tracs_alignment *a_, size_t row_begin, size_t row_end, size_t col_begin, uint32_t *dist,
+                            uint32_t *ncomp, size_t ld, int32_t dist_threshold, void *stream_)
+{
+    // a negative threshold emits nothing; any d > threshold may come back as 0xFFFFFFFF
+    const unsigned thr = dist_threshold < 0 ? 0u : (unsigned)dist_threshold;
+    return pairsnp_dense_impl(a_, row_begin, row_end, col_begin, dist, ncomp, ld, stream_, dist_threshold == 2147483647 ? 0xFFFFFFFFu : thr);
+}
+
+static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_t row_end, size_t col_begin, uint32_t *dist,
+                              uint32_t *ncomp, size_t ld, void *stream_, unsigned thr)
 {
     tracs_alignment *a = const_cast<tracs_alignment *>(a_);
     if (!a || !dist) { set_error("tracs_pairsnp_dense: NULL argument"); return TRACS_E_ARG; }
@@ -949,6 +1001,7 @@ int tracs_pairsnp_dense(const tracs_alignment *a_, size_t row_begin, size_t row_
             if (rounds >= 40) break;                                         // tail < 2.5 % from here on
         }
         if (const char *e = std::getenv("TRACS_KSPLIT")) { const int v = std::atoi(e); if (v >= 1 && v <= max_split) ksplit = v; }
+        if (thr != 0xFFFFFFFFu) ksplit = 1;          // the early out needs whole-alignment partial distances per workgroup
     }
     int gps = (groups + ksplit - 1) / ksplit;
     gps = (gps + kGC - 1) / kGC * kGC;             // stage aligned
@@ -961,7 +1014,7 @@ int tracs_pairsnp_dense(const tracs_alignment *a_, size_t row_begin, size_t row_
     }
     const unsigned nwg = (unsigned)(a->n_tiles * (size_t)ksplit);
     (cons ? V.launch_cons : V.launch)(ncomp != nullptr, nwg, stream, cons ? a->cplanes : a->planes, a->n_pad, groups, a->d_tiles, (int)a->n_tiles, gps, ksplit, (unsigned)a->L,
-             (unsigned)a->n, (unsigned)row_end, (unsigned)col_begin, dist, ncomp, ld);
+             (unsigned)a->n, (unsigned)row_end, (unsigned)col_begin, dist, ncomp, ld, thr);
     TRACS_HIP_CHECK(hipGetLastError());
     return TRACS_OK;
 }

@@ -87,13 +87,18 @@ class Alignment:
             pass
 
 
-def pairsnp_dense(aln, dist, ncomp=None, row_begin=0, row_end=None, col_begin=0):
+def pairsnp_dense(aln, dist, ncomp=None, row_begin=0, row_end=None, col_begin=0, dist_threshold=None):
     """dist/ncomp: torch.int32 (bit pattern uint32) [>=n, ld] device matrices, written for the cells
-    rows [row_begin,row_end) x cols [max(col_begin,i+1), n)."""
+    rows [row_begin,row_end) x cols [max(col_begin,i+1), n).  With dist_threshold, pairs beyond it may read -1
+    (0xFFFFFFFF): tiles stop early once all their pairs are past the threshold."""
     row_end = aln.n if row_end is None else row_end
     ld = dist.stride(0)
-    _lib.check(aln._L.tracs_pairsnp_dense(aln._h, int(row_begin), int(row_end), int(col_begin), _ptr(dist), _ptr(ncomp),
-                                          int(ld), _stream()))
+    if dist_threshold is None:
+        _lib.check(aln._L.tracs_pairsnp_dense(aln._h, int(row_begin), int(row_end), int(col_begin), _ptr(dist), _ptr(ncomp),
+                                              int(ld), _stream()))
+    else:
+        _lib.check(aln._L.tracs_pairsnp_dense_thr(aln._h, int(row_begin), int(row_end), int(col_begin), _ptr(dist),
+                                                  _ptr(ncomp), int(ld), int(dist_threshold), _stream()))
 
 
 def coo_from_dense(dist, ncomp, n, dist_threshold=2147483647, row_begin=0, row_end=None, col_begin=0):
