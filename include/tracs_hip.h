@@ -126,9 +126,12 @@ void tracs_free(void *p);
 int tracs_pairsnp_dense(const tracs_alignment *a, size_t row_begin, size_t row_end, size_t col_begin,
                         uint32_t *dist, uint32_t *ncomp, size_t ld, void *stream);
 
-/* Thresholded form: identical for every pair with d <= dist_threshold; a pair beyond the threshold (never emitted,
- * src/pairsnp.hpp:405) may come back as 0xFFFFFFFF instead of its exact distance, because workgroups stop reading the
- * alignment once every pair of their tile is past the threshold.                                                    */
+/* Thresholded form: identical (d and nn) for every pair with d <= dist_threshold.  A pair beyond the threshold (never
+ * emitted, src/pairsnp.hpp:405) may come back with bit 31 of its distance set (0xFFFFFFFF, or a partial count | 2^31) and
+ * an unspecified ncomp, because workgroups stop reading the alignment once every pair of their tile is past the
+ * threshold: read such cells as "> threshold" (as a signed int32 they are negative; tracs_coo_count/fill skip them).
+ * Long alignments take two passes (a 1/8 prefix over all tiles, then the rest over the surviving tiles only); this call
+ * synchronises the stream once between them.                                                                          */
 int tracs_pairsnp_dense_thr(const tracs_alignment *a, size_t row_begin, size_t row_end, size_t col_begin,
                             uint32_t *dist, uint32_t *ncomp, size_t ld, int32_t dist_threshold, void *stream);
 

@@ -153,6 +153,19 @@ __device__ __forceinline__ void pair_words(unsigned ai_a, unsigned ai_c, unsigne
     acc += __popc(m);                            // v_bcnt_u32_b32 (popcount + accumulate)
 }
 
+// Two-pass thresholded runs (tracs_pairsnp_dense_thr on long alignments):
+//   phase 1  "prefix":    one workgroup per tile walks groups [0, groups) of a SHORT prefix; a tile whose every pair already
+//                         exceeds the threshold there is dead (cells 0xFFFFFFFF, live[tile] = 0), the others keep their exact
+//                         partial counts in dist/ncomp (live[tile] = 1);
+//   phase 2  "remainder": groups [g_base, groups) of the live tiles only (compacted tile list), split over ksplit workgroups
+//                         that ADD their partial counts onto the prefix's.
+//   phase 0  everything in one launch (the unthresholded path and short alignments).
+struct TilePhase {
+    int phase;
+    int g_base;
+    unsigned char *live;
+};
+
 // Where a wave's row words come from.
 //   ROW_SMEM    scalar loads (s_load_dwordx8/16) straight from HBM/L2 through the scalar cache -> SGPR operands
 //   ROW_SMEM_PF the same, software-pipelined: the next RB rows are requested before the current RB are consumed
@@ -174,7 +187,7 @@ template <int NW, int R, int C, int GC, bool WITH_NN, int ROWSRC, int MINW = 1, 
 __global__ __launch_bounds__(NW * 64, MINW) void pairsnp_tile_kernel(
     const uint4 *__restrict__ P, size_t n_pad, int groups, const int2 *__restrict__ tiles, int n_tiles,
     int groups_per_split, int ksplit, unsigned L, unsigned n, unsigned row_end, unsigned col_begin,
-    unsigned *__restrict__ dist, unsigned *__restrict__ ncomp, size_t ld, unsigned thr)
+    unsigned *__restrict__ dist, unsigned *__restrict__ ncomp, size_t ld, unsigned thr, TilePhase ph)
 {
     constexpr int NP = ENC ? 3 : NPLANES;                   // planes of this encoding
     constexpr int NT = NW * 64;
@@ -189,13 +202,15 @@ __global__ __launch_bounds__(NW * 64, MINW) void pairsnp_tile_kernel(
 
     const unsigned q = xcd_remap(blockIdx.x, gridDim.x);
     const int ks = (int)(q / (unsigned)n_tiles);
-    const int2 tile = tiles[q - (unsigned)ks * (unsigned)n_tiles];
+    const unsigned tile_no = q - (unsigned)ks * (unsigned)n_tiles;
+    const int2 tile = tiles[tile_no];
     const int i0 = tile.x, j0 = tile.y;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g_begin = ks * groups_per_split;
+    const int g_begin = ph.g_base + ks * groups_per_split;
     const int g_end = min(groups, g_begin + groups_per_split);
+    if (g_begin >= g_end) return;
 
     unsigned accM[R][C], accN[R][C];
 #pragma unroll
@@ -314,9 +329,10 @@ __global__ __launch_bounds__(NW * 64, MINW) void pairsnp_tile_kernel(
             for (int p = 0; p < NPL; p++) fixed_bj[c][p] = lds[0][p * TS + lane + 64 * c];
     }
 
-    // Early out for thresholded runs (thr != ~0u, ksplit == 1): every 4th stage the workgroup takes the minimum partial
-    // distance over its valid cells; partial distances only grow, so once the minimum exceeds the threshold no pair of the
-    // tile can be emitted (src/pairsnp.hpp:405) and the rest of the alignment is skipped.  Cells then hold 0xFFFFFFFF.
+    // Early out for thresholded runs (thr != ~0u): every 4th stage the workgroup takes the minimum, over its valid cells,
+    // of the partial distance accumulated in ITS group range; partial distances only grow, so once that minimum exceeds the
+    // threshold no pair of the tile can be emitted (src/pairsnp.hpp:405) and the rest of the range is skipped.  Cells then
+    // hold 0xFFFFFFFF (whole alignment in one workgroup) or have bit 31 set (split range).
     __shared__ unsigned wmin[NW];
     const bool can_exit = thr != 0xFFFFFFFFu && j0 >= i0 + TI;      // tiles touching the diagonal hold d(i,i) = 0 cells
     bool early = false;
@@ -369,9 +385,10 @@ __global__ __launch_bounds__(NW * 64, MINW) void pairsnp_tile_kernel(
             }
         }
         if (more) stage_store(buf ^ 1);
-        const bool check = can_exit && more && ((++stage_no) & 3) == 0;
+        // checked every 4th stage, and at the end of a prefix pass (that verdict decides whether phase 2 visits the tile)
+        const bool check = can_exit && (more ? ((++stage_no) & 3) == 0 : ph.phase == 1);
         if (check) {
-            const unsigned done_sites = (unsigned)(min(gs + GC, g_end) - g_begin) * SITES_PER_GROUP;
+            const unsigned done_sites = min(L, (unsigned)min(gs + GC, g_end) * SITES_PER_GROUP) - (unsigned)g_begin * SITES_PER_GROUP;
             unsigned mn = 0xFFFFFFFFu;
 #pragma unroll
             for (int r = 0; r < R; r++) {
@@ -396,7 +413,12 @@ __global__ __launch_bounds__(NW * 64, MINW) void pairsnp_tile_kernel(
         }
     }
 
-    // epilogue: d = L - matches, nn = L - masked; only cells of the requested set are written
+    // epilogue: d = sites - matches, nn = sites - masked over this workgroup's group range; only cells of the requested set
+    // are written.  `single`: this workgroup is the cell's only writer and stores; otherwise partial counts are added.
+    const bool single = ksplit == 1 && ph.phase != 2;
+    // sites of this range (the last group is clipped to L); phase 0 keeps the whole-alignment form d = L - sum(matches)
+    const unsigned Lc = ph.phase ? min(L, (unsigned)g_end * SITES_PER_GROUP) - (unsigned)g_begin * SITES_PER_GROUP : L;
+    if (ph.phase == 1 && tid == 0) ph.live[tile_no] = early ? 0 : 1;
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const unsigned i = (unsigned)(i0 + wave * R + r);
@@ -407,19 +429,24 @@ __global__ __launch_bounds__(NW * 64, MINW) void pairsnp_tile_kernel(
             if (j < n && j > i && j >= col_begin) {
                 const size_t o = (size_t)i * ld + j;
                 if (early) {                              // every pair of the tile is beyond the threshold
-                    dist[o] = 0xFFFFFFFFu;
-                    if (WITH_NN) ncomp[o] = 0u;
+                    // shared cell: this range alone already exceeds the threshold; the other ranges keep adding their
+                    // partial counts (< 2^31), so the marker bit survives whatever order the atomics land in
+                    if (single) dist[o] = 0xFFFFFFFFu; else atomicOr(&dist[o], 0x80000000u);
+                    if (WITH_NN && single) ncomp[o] = 0u;
                 } else if (ENC) {                         // accumulators hold d and nn themselves
-                    if (ksplit == 1) {
+                    if (single) {
                         dist[o] = accM[r][c];
                         if (WITH_NN) ncomp[o] = accN[r][c];
-                    } else {                              // cells were initialised to 0
+                    } else {                              // cells were initialised to 0 (phase 0) / hold the prefix counts
                         atomicAdd(&dist[o], accM[r][c]);
                         if (WITH_NN) atomicAdd(&ncomp[o], accN[r][c]);
                     }
-                } else if (ksplit == 1) {
-                    dist[o] = L - accM[r][c];
-                    if (WITH_NN) ncomp[o] = L - accN[r][c];
+                } else if (single) {
+                    dist[o] = Lc - accM[r][c];
+                    if (WITH_NN) ncomp[o] = Lc - accN[r][c];
+                } else if (ph.phase == 2) {               // cells hold the prefix counts
+                    atomicAdd(&dist[o], Lc - accM[r][c]);
+                    if (WITH_NN) atomicAdd(&ncomp[o], Lc - accN[r][c]);
                 } else {                                  // cells were initialised to L
                     atomicSub(&dist[o], accM[r][c]);
                     if (WITH_NN) atomicSub(&ncomp[o], accN[r][c]);
@@ -567,6 +594,14 @@ __global__ __launch_bounds__(256) void derive_consensus_kernel(const uint4 *__re
 }
 
 // cells of the block <- L (only needed when the group range is split over workgroups)
+// live tiles of a prefix pass -> compact list (order does not matter: every tile owns its cells)
+__global__ void compact_live_kernel(const int2 *__restrict__ tiles, const unsigned char *__restrict__ live, unsigned n_tiles,
+                                    int2 *__restrict__ out, unsigned *__restrict__ n_out)
+{
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_tiles && live[t]) out[atomicAdd(n_out, 1u)] = tiles[t];
+}
+
 __global__ void init_cells_kernel(unsigned *__restrict__ dist, unsigned *__restrict__ ncomp, size_t ld, unsigned n,
                                   unsigned row_begin, unsigned row_end, unsigned col_begin, unsigned L)
 {
@@ -687,7 +722,7 @@ using namespace tracs;
 // (default: the fastest measured on MI355X, see DESIGN.md "pairsnp kernel: variants measured").
 typedef void (*TileLaunch)(bool with_nn, unsigned nwg, hipStream_t stream, const uint4 *P, size_t n_pad, int groups,
                            const int2 *tiles, int n_tiles, int gps, int ksplit, unsigned L, unsigned n, unsigned row_end,
-                           unsigned col_begin, unsigned *dist, unsigned *ncomp, size_t ld, unsigned thr);
+                           unsigned col_begin, unsigned *dist, unsigned *ncomp, size_t ld, unsigned thr, TilePhase ph);
 struct TileVariant {
     const char *name;
     int ti, tj, gc, nthreads;
@@ -698,20 +733,20 @@ struct TileVariant {
 template <int NW, int R, int C, int GC, int ROWSRC, int MINW = 1, bool GLDS = false, int ENC = 0>
 static void launch_variant(bool with_nn, unsigned nwg, hipStream_t stream, const uint4 *P, size_t n_pad, int groups,
                            const int2 *tiles, int n_tiles, int gps, int ksplit, unsigned L, unsigned n, unsigned row_end,
-                           unsigned col_begin, unsigned *dist, unsigned *ncomp, size_t ld, unsigned thr)
+                           unsigned col_begin, unsigned *dist, unsigned *ncomp, size_t ld, unsigned thr, TilePhase ph)
 {
     if (with_nn)
         hipLaunchKernelGGL((pairsnp_tile_kernel<NW, R, C, GC, true, ROWSRC, MINW, GLDS, ENC>), dim3(nwg), dim3(NW * 64), 0, stream, P, n_pad, groups,
-                           tiles, n_tiles, gps, ksplit, L, n, row_end, col_begin, dist, ncomp, ld, thr);
+                           tiles, n_tiles, gps, ksplit, L, n, row_end, col_begin, dist, ncomp, ld, thr, ph);
     else
         hipLaunchKernelGGL((pairsnp_tile_kernel<NW, R, C, GC, false, ROWSRC, MINW, GLDS, ENC>), dim3(nwg), dim3(NW * 64), 0, stream, P, n_pad, groups,
-                           tiles, n_tiles, gps, ksplit, L, n, row_end, col_begin, dist, ncomp, ld, thr);
+                           tiles, n_tiles, gps, ksplit, L, n, row_end, col_begin, dist, ncomp, ld, thr, ph);
 }
 
 template <int NW, int R, int C>
 static void launch_rowcast(bool with_nn, unsigned nwg, hipStream_t stream, const uint4 *P, size_t n_pad, int groups,
                            const int2 *tiles, int n_tiles, int gps, int ksplit, unsigned L, unsigned n, unsigned row_end,
-                           unsigned col_begin, unsigned *dist, unsigned *ncomp, size_t ld, unsigned /*thr: no early out here*/)
+                           unsigned col_begin, unsigned *dist, unsigned *ncomp, size_t ld, unsigned /*thr: no early out here*/, TilePhase)
 {
     if (with_nn)
         hipLaunchKernelGGL((pairsnp_rowcast_kernel<NW, R, C, true>), dim3(nwg), dim3(NW * 64), 0, stream, P, n_pad, groups, tiles,
@@ -987,10 +1022,11 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
     // CUs x workgroups per CU for this variant (VGPR/LDS bound: 2 for every default shape).
     const int groups = (int)a->groups;
     int ksplit = 1;
+    double slots = 512.0;
     {
         static int cus = 0;
         if (!cus) { hipDeviceProp_t pr; int dv = 0; (void)hipGetDevice(&dv); cus = (hipGetDeviceProperties(&pr, dv) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }
-        const double slots = 2.0 * cus;
+        slots = 2.0 * cus;
         const int max_split = std::max(1, groups / (8 * kGC));
         double best = -1.0;
         for (int k = 1; k <= std::min(max_split, 64); k++) {
@@ -1001,20 +1037,59 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
             if (rounds >= 40) break;                                         // tail < 2.5 % from here on
         }
         if (const char *e = std::getenv("TRACS_KSPLIT")) { const int v = std::atoi(e); if (v >= 1 && v <= max_split) ksplit = v; }
-        if (thr != 0xFFFFFFFFu) ksplit = 1;          // the early out needs whole-alignment partial distances per workgroup
     }
-    int gps = (groups + ksplit - 1) / ksplit;
-    gps = (gps + kGC - 1) / kGC * kGC;             // stage aligned
-    ksplit = (groups + gps - 1) / gps;
+    auto stage_split = [&](int range, int k, int &gps_out) {       // k workgroups over `range` groups, stage aligned
+        int g = (range + k - 1) / k;
+        g = (g + kGC - 1) / kGC * kGC;
+        gps_out = g;
+        return (range + g - 1) / g;
+    };
+    auto launch = [&](const int2 *tl, unsigned nwg, int ntl, int g_end, int gps, int k, unsigned t, TilePhase ph) {
+        (cons ? V.launch_cons : V.launch)(ncomp != nullptr, nwg, stream, cons ? a->cplanes : a->planes, a->n_pad, g_end, tl,
+                                          ntl, gps, k, (unsigned)a->L, (unsigned)a->n, (unsigned)row_end,
+                                          (unsigned)col_begin, dist, ncomp, ld, t, ph);
+    };
 
+    // Thresholded run on a long alignment: two passes.  The prefix pass (1/8 of the groups, one workgroup per tile) leaves
+    // exact partial counts and a live flag per tile; the remainder pass visits the live tiles only, its range split so that the
+    // few surviving tiles still fill the chip.  Dead tiles cost 1/8 of a full pass or less (they also stop inside the prefix).
+    static const bool no_two_pass = std::getenv("TRACS_THR_ONE_PASS") != nullptr;
+    if (thr != 0xFFFFFFFFu && V.launch != nullptr && V.gc > 1 && !no_two_pass && groups >= 64 * kGC) {
+        int prefix = std::max(8 * kGC, groups / 8 / kGC * kGC);
+        if (const char *e = std::getenv("TRACS_THR_PREFIX")) { const int v = std::atoi(e) / kGC * kGC; if (v >= kGC && v < groups) prefix = v; }
+        unsigned char *live = nullptr;
+        int2 *live_tiles = nullptr;
+        unsigned *n_live_d = nullptr;
+        int rc;
+        if ((rc = tracs::workspace_get(48, a->n_tiles, reinterpret_cast<void **>(&live)))) return rc;
+        if ((rc = tracs::workspace_get(49, a->n_tiles * sizeof(int2), reinterpret_cast<void **>(&live_tiles)))) return rc;
+        if ((rc = tracs::workspace_get(50, 64, reinterpret_cast<void **>(&n_live_d)))) return rc;
+        TRACS_HIP_CHECK(hipMemsetAsync(n_live_d, 0, 4, stream));
+        launch(a->d_tiles, (unsigned)a->n_tiles, (int)a->n_tiles, prefix, prefix, 1, thr, TilePhase{1, 0, live});
+        hipLaunchKernelGGL(compact_live_kernel, dim3((unsigned)((a->n_tiles + 255) / 256)), dim3(256), 0, stream, a->d_tiles, live,
+                           (unsigned)a->n_tiles, live_tiles, n_live_d);
+        unsigned n_live = 0;
+        TRACS_HIP_CHECK(hipMemcpyAsync(&n_live, n_live_d, 4, hipMemcpyDeviceToHost, stream));
+        TRACS_HIP_CHECK(hipStreamSynchronize(stream));
+        if (n_live) {
+            // enough workgroups for ~4 rounds of the chip, never more than 32 ranges (each range costs one atomic per cell)
+            int gps2 = 0;
+            const int want = (int)std::ceil(4.0 * slots / (double)n_live);
+            const int k2 = stage_split(groups - prefix, std::max(1, std::min({32, want, (groups - prefix) / (16 * kGC)})), gps2);
+            launch(live_tiles, (unsigned)(n_live * (size_t)k2), (int)n_live, groups, gps2, k2, thr, TilePhase{2, prefix, nullptr});
+        }
+        TRACS_HIP_CHECK(hipGetLastError());
+        return TRACS_OK;
+    }
+
+    int gps = 0;
+    ksplit = stage_split(groups, ksplit, gps);
     if (ksplit > 1) {
         dim3 grid(64, (unsigned)(row_end - row_begin));
         hipLaunchKernelGGL(init_cells_kernel, grid, dim3(256), 0, stream, dist, ncomp, ld, (unsigned)a->n,
                            (unsigned)row_begin, (unsigned)row_end, (unsigned)col_begin, cons ? 0u : (unsigned)a->L);
     }
-    const unsigned nwg = (unsigned)(a->n_tiles * (size_t)ksplit);
-    (cons ? V.launch_cons : V.launch)(ncomp != nullptr, nwg, stream, cons ? a->cplanes : a->planes, a->n_pad, groups, a->d_tiles, (int)a->n_tiles, gps, ksplit, (unsigned)a->L,
-             (unsigned)a->n, (unsigned)row_end, (unsigned)col_begin, dist, ncomp, ld, thr);
+    launch(a->d_tiles, (unsigned)(a->n_tiles * (size_t)ksplit), (int)a->n_tiles, groups, gps, ksplit, thr, TilePhase{0, 0, nullptr});
     TRACS_HIP_CHECK(hipGetLastError());
     return TRACS_OK;
 }

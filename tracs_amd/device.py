@@ -89,8 +89,8 @@ class Alignment:
 
 def pairsnp_dense(aln, dist, ncomp=None, row_begin=0, row_end=None, col_begin=0, dist_threshold=None):
     """dist/ncomp: torch.int32 (bit pattern uint32) [>=n, ld] device matrices, written for the cells
-    rows [row_begin,row_end) x cols [max(col_begin,i+1), n).  With dist_threshold, pairs beyond it may read -1
-    (0xFFFFFFFF): tiles stop early once all their pairs are past the threshold."""
+    rows [row_begin,row_end) x cols [max(col_begin,i+1), n).  With dist_threshold, pairs beyond it may come back
+    negative (bit 31 set) with an unspecified ncomp: tiles stop early once all their pairs are past the threshold."""
     row_end = aln.n if row_end is None else row_end
     ld = dist.stride(0)
     if dist_threshold is None:
