@@ -189,6 +189,17 @@ int tracs_find_dirichlet_priors_device(const double *counts, size_t L, size_t K,
 int tracs_posterior_codes_cov_device(const uint16_t *counts, size_t L, const double *alphas_host, int keep,
                                      double threshold, uint32_t min_cov, double cov_lo, double cov_hi, uint8_t *codes,
                                      void *stream);
+/* Align stage before the posterior filter (tracs/align.py:473-516): one pass over device f64 counts [L][4] that
+ *   - histograms the per-site coverage rs = A+C+G+T into hist[min(rs, nbins-1)] (device uint64[nbins], zeroed here): the
+ *     stage's statistics (fraction covered, fraction >= min_cov, np.median / np.quantile of the non-zero coverages,
+ *     :476-480,522,559) are order statistics of it;
+ *   - narrows the counts to uint16 [L][4] (counts16, may be NULL) for the two code kernels;
+ *   - sets *bad (device uint32) if any count is not an integer in [0, 65535].                                          */
+int tracs_coverage_profile_device(const double *counts, size_t L, uint64_t *hist, size_t nbins, uint16_t *counts16,
+                                  uint32_t *bad, void *stream);
+/* --consensus calls (tracs/align.py:482-493): mask = the first allele with the largest count; 15 (N) where the total
+ * count is below min_cov.  Same packed 4-bit output as tracs_posterior_codes_device.                                   */
+int tracs_consensus_codes_device(const uint16_t *counts16, size_t L, uint32_t min_cov, uint8_t *codes, void *stream);
 /* 4-bit masks -> IUPAC letters as tracs/align.py:285-323,616-622 ('X' for mask 0, 'N' for 15); ascii: device, L bytes. */
 int tracs_codes_to_iupac_device(const uint8_t *codes, size_t L, uint8_t *ascii, void *stream);
 /* Pack ONE sample straight from its 4-bit masks (no FASTA round trip): mask 0 ('X') is treated like every other
@@ -198,6 +209,31 @@ int tracs_alignment_pack_codes(tracs_alignment *a, const uint8_t *codes, size_t 
 /* Connected components on device edge arrays; labels as tracs_connected_components.         */
 int tracs_connected_components_device(const int32_t *I, const int32_t *J, size_t n_edges, size_t n_nodes,
                                       int32_t *labels, int32_t *n_components_host, void *stream);
+
+/* ===================================================================================== */
+/* (3) ON-DISK FORMATS either side of the path (host side)            */
+/* ===================================================================================== */
+
+/* `htsbox pileup -C -s 0` text (plain or gzip) -> allele counts, the parse loop of tracs/align.py:452-472.
+ *   Per line: fields split at whitespace; contig = field 0, 1-based position = field 1, reference base = field 2,
+ *   alleles = second-to-last field split at ',', strand counts = last field split at ':' (pieces 1 and 2, each split
+ *   at ','); count[A|C|G|T] = forward + reverse for alleles that are exactly A/C/G/T when the reference base is one
+ *   too; with require_both_strands an allele seen on one strand only counts 0; a repeated position overwrites.
+ *   counts: host [sum(contig_lengths)][4] f64 in contig order (np.concatenate at :473), zeroed here first.
+ *   Unknown contig, position outside its contig or a non-integer field is an error (the reference raises).      */
+int tracs_pileup_counts(const char *path, const char *const *contig_names, const uint64_t *contig_lengths,
+                        size_t n_contigs, int require_both_strands, double *counts, uint64_t *n_lines_out);
+
+/* posterior [L][K] f64 -> gzip CSV exactly as np.savetxt(fmt="%0.5f", delimiter=",") + the trailing "\n" the
+ * reference appends (tracs/align.py:580-596).  gzip_level 0..9.                                                   */
+int tracs_write_posterior_csv(const char *path, const double *post, size_t L, size_t K, int gzip_level);
+
+/* write_alignment of tracs/combine.py:220-239: one single-record FASTA per sample -> "<ref>_combined.fasta.gz" with
+ * records ">sample\nSEQUENCE\n" in input order.  Samples are compressed in parallel as separate gzip members
+ * (n_threads <= 0: all cores; gzip_level < 0: 6).  frac_n[s] = count('N')/len, lengths[s] = len (the ncov dict);
+ * a file with more than one record is an error ("... contains more than one sequence").                         */
+int tracs_combine_fasta(const char *out_path, const char *const *sample_names, const char *const *fasta_paths,
+                        size_t n, int n_threads, int gzip_level, double *frac_n, uint64_t *lengths);
 
 #ifdef __cplusplus
 }

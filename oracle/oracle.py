@@ -361,3 +361,100 @@ def connected_components(n, I, J):
             ids[r] = len(ids)
         labels[v] = ids[r]
     return labels
+
+
+# ---- align post-pileup stage and combine --------------------------------------------------------
+# PARITY UNPINNED: tracs/align.py and tracs/combine.py import pyfastx (absent here) and align() shells out to minimap2 /
+# htsbox, so neither can be run in this container and the reference ships no fixture for them.  These are line-by-line
+# restatements of the cited blocks; calculate_posteriors / find_dirichlet_priors inside them ARE pinned (see above).
+
+_IUPAC_LUT = np.frombuffer(b"XACMGRSVTWYHKDBN", dtype=np.uint8)     # index = packbits(little) of (A,C,G,T) > 0, align.py:285-323
+
+
+def pileup_counts(lines, contigs, require_both_strands=False):
+    """tracs/align.py:444-473.  lines: iterable of str; contigs: [(name, length)] in reference-FASTA order."""
+    npos = {"A": 0, "C": 1, "G": 2, "T": 3}
+    per = {name: np.zeros((length, 4), dtype=float) for name, length in contigs}
+    for raw in lines:
+        f = raw.strip().split()
+        contig, pos = f[0], int(f[1]) - 1
+        alleles = f[-2].split(",")
+        strands = f[-1].split(":")[1:]
+        row = np.zeros(4, dtype=float)
+        for nuc, a, b in zip(alleles, strands[0].split(","), strands[1].split(",")):
+            a, b = int(a), int(b)
+            if nuc not in npos or f[2] not in npos:
+                continue
+            if require_both_strands and (a == 0 or b == 0):
+                a = b = 0
+            row[npos[nuc]] = a + b
+        if pos < 0 or pos >= per[contig].shape[0]:
+            raise IndexError("position outside the contig")     # (the reference wraps pos 0 to the last row; we refuse)
+        per[contig][pos, :] = row
+    return np.concatenate([per[name] for name, _ in contigs]) if contigs else np.zeros((0, 4))
+
+
+def call_sequence(all_counts, min_cov=5, error_threshold=0.01, consensus=False, keep_all=False, keep_cov_outliers=False,
+                  alphas=None):
+    """tracs/align.py:476-647 from the concatenated counts to the sequence string.
+    -> dict(sequence=str or None (reference skipped), alphas, threshold, band, posterior (after the coverage rules)).
+    alphas: use these instead of fitting (tests pass the device's fit so that a last-bit difference in an alpha cannot
+    move a site across the threshold; the fit itself is compared separately)."""
+    all_counts = np.array(all_counts, dtype=float)
+    rs = np.sum(all_counts, 1)
+    nz_cov = np.sum(all_counts[rs > 0,], 1)
+    median_cov = np.median(nz_cov)
+    out = dict(sequence=None, alphas=None, threshold=None, band=None, posterior=None, csv=None)
+    if consensus:                                                                  # :482-516
+        one = np.zeros_like(all_counts, dtype=int)
+        one[np.arange(all_counts.shape[0]), np.argmax(all_counts, axis=1)] = 1
+        one[rs < min_cov,] = 1
+        seq = _IUPAC_LUT[np.packbits(one > 0, axis=1, bitorder="little").flatten()].tobytes().decode()
+        if seq.count("N") / float(len(seq)) > 0.75:
+            return out
+        out["sequence"] = seq
+        return out
+    thr = max(min_cov / median_cov, error_threshold)                               # :521
+    if np.sum(rs >= min_cov) / all_counts.shape[0] < 0.25:                         # :522,531-535
+        return out
+    if alphas is None:
+        alphas = find_dirichlet_priors(all_counts, method="FPI", error_filt_threshold=error_threshold)   # :537-539
+    alphas = np.asarray(alphas, dtype=float)
+    if thr <= alphas[1] / (median_cov + np.sum(alphas)):                           # :541-549
+        thr = alphas[1] / (median_cov + np.sum(alphas)) + 0.01
+    band = None
+    use_band = (not keep_cov_outliers) and median_cov > 50 and alphas[1] / np.sum(alphas) > thr      # :552-556
+    if use_band:
+        lo = alphas[1] / thr - np.sum(alphas)                                      # :557
+        lq = np.quantile(nz_cov, [0.25, 0.5])                                      # :559
+        hi = lq[0] - 1.5 * (lq[1] - lq[0])                                         # :560
+        band = (lo, hi)
+    post = calculate_posteriors(all_counts, alphas, keep_all, thr)                 # :575-577
+    out["csv"] = post.copy()                                                       # what np.savetxt writes (:580-596)
+    if use_band and band[1] > band[0]:                                             # :599-611
+        post[(rs <= band[1]) & (rs >= band[0]),] = 1
+    post[rs < min_cov,] = 1                                                        # :613
+    seq = _IUPAC_LUT[np.packbits(post > 0, axis=1, bitorder="little").flatten()].tobytes().decode()   # :616-622
+    out.update(alphas=alphas, threshold=thr, band=band, posterior=post)
+    if seq.count("N") / float(len(seq)) > 0.75:                                    # :626-630
+        return out
+    out["sequence"] = seq
+    return out
+
+
+def posterior_csv_text(post):
+    """np.savetxt(fmt='%0.5f', delimiter=',') + the extra newline (tracs/align.py:589-596), as bytes."""
+    import io
+    b = io.BytesIO()
+    np.savetxt(b, post, delimiter=",", newline="\n", fmt="%0.5f")
+    b.write(b"\n")
+    return b.getvalue()
+
+
+def combined_fasta_text(records):
+    """tracs/combine.py:227-238.  records: [(sample, sequence)] -> (text, {sample: (frac_N, length)})."""
+    text, ncov = "", {}
+    for sample, seq in records:
+        text += ">%s\n%s\n" % (sample, seq)
+        ncov[sample] = (seq.count("N") / len(seq), len(seq))
+    return text, ncov

@@ -1,0 +1,171 @@
+"""On-disk formats either side of the distance path, host code of libtracs_hip.so, no GPU needed:
+pileup text -> counts (tracs/align.py:452-473), posterior CSV (:580-596), `tracs combine` (tracs/combine.py:100-239).
+Checked against oracle.py's restatements of those blocks (PARITY UNPINNED: the reference modules need pyfastx / htsbox)."""
+import gzip
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+
+def _pileup_lines(rng, contigs, n_lines):
+    """Lines shaped like `htsbox pileup -C -s 0` output, plus every oddity the reference's parser reacts to."""
+    alleles_pool = ["A", "C", "G", "T", "N", "-1A", "+2AC", "*", "a"]
+    lines = []
+    for _ in range(n_lines):
+        name, length = contigs[rng.integers(len(contigs))]
+        pos = int(rng.integers(1, length + 1))
+        refb = "ACGTNacgtR"[rng.integers(10)]
+        k = int(rng.integers(1, 5))
+        al = [alleles_pool[i] for i in rng.integers(0, len(alleles_pool), k)]
+        if rng.random() < 0.1:
+            al.append(al[0])                                  # a repeated allele: the later count wins
+        fwd = [str(int(x)) for x in rng.integers(0, 40, len(al))]
+        rev = [str(int(x)) for x in rng.integers(0, 40, len(al))]
+        if rng.random() < 0.3:
+            fwd[0] = "0"
+        if rng.random() < 0.1:
+            rev = rev[:-1] or ["3"]                           # ragged lists: zip() stops at the shortest
+        tot = str(sum(map(int, fwd)) + sum(map(int, rev)))
+        mid = ["x"] * int(rng.integers(0, 3))                 # extra columns between ref base and alleles
+        sep = "\t" if rng.random() < 0.8 else "  "
+        lines.append(sep.join([name, str(pos), refb] + mid + [",".join(al), tot + ":" + ",".join(fwd) + ":" + ",".join(rev)]))
+    return lines
+
+
+@pytest.mark.parametrize("both", [False, True])
+def test_pileup_counts_match_restatement(both, oracle, tmp_path):
+    from tracs_amd import align_post
+    rng = np.random.default_rng(5)
+    contigs = [("NC_000001.1", 700), ("plasmid|p2", 90), ("c3", 1)]
+    lines = _pileup_lines(rng, contigs, 4000)
+    want = oracle.pileup_counts(lines, contigs, both)
+    assert want.sum() > 0 and (want[:700] > 0).any() and (want[700:790] > 0).any()
+    plain = tmp_path / "p.txt"
+    plain.write_text("\n".join(lines))                        # no trailing newline
+    gz = tmp_path / "p.txt.gz"
+    with gzip.open(gz, "wt") as f:
+        f.write("\n".join(lines) + "\n")
+    for path in (plain, gz):
+        got = align_post.pileup_counts(str(path), contigs, both)
+        assert got.dtype == np.float64 and got.shape == (791, 4)
+        assert np.array_equal(got, want)
+
+
+def test_pileup_counts_errors_and_edges(tmp_path):
+    from tracs_amd import align_post
+    contigs = [("c", 10)]
+
+    def run(text):
+        p = tmp_path / "e.txt"
+        p.write_text(text)
+        return align_post.pileup_counts(str(p), contigs)
+
+    assert run("").shape == (10, 4) and run("").sum() == 0
+    ok = run("c 3 A A,C 9:4,1:3,1\r\nc\t3\tA\tG\t2:1:1\n")     # CR is whitespace for str.split(); second line overwrites the row
+    assert ok[2].tolist() == [0, 0, 2, 0] and ok.sum() == 2
+    for bad in ("d 3 A A 1:1:0\n", "c 11 A A 1:1:0\n", "c 0 A A 1:1:0\n", "c x A A 1:1:0\n", "c 3 A A 1:x:0\n", "c 3 A A 5\n",
+                "c 3\n", "c 3 A A 1:1:0\n\nc 4 A A 1:1:0\n"):
+        with pytest.raises(RuntimeError, match="pileup line"):
+            run(bad)
+    with pytest.raises(FileNotFoundError):
+        align_post.pileup_counts(str(tmp_path / "missing.txt"), contigs)
+
+
+def test_read_contigs(tmp_path):
+    from tracs_amd import align_post
+    fa = tmp_path / "ref.fa"
+    fa.write_text(">c1 some description\nACGT\nAC\n>c2\n\nGGG\n>empty\n")
+    assert align_post.read_contigs(str(fa)) == [("c1", 6), ("c2", 3), ("empty", 0)]
+    with gzip.open(tmp_path / "ref.fa.gz", "wt") as f:
+        f.write(">x\nAC\n")
+    assert align_post.read_contigs(str(tmp_path / "ref.fa.gz")) == [("x", 2)]
+
+
+def test_posterior_csv_bytes(oracle, tmp_path):
+    from tracs_amd import align_post
+    rng = np.random.default_rng(9)
+    post = rng.random((150001, 4))
+    post[rng.random(post.shape) < 0.5] = 0.0
+    post[:8] = [[0.000005, 0.000015, 0.999995, 1.0], [0.5, 0.125, 0.0625, 1e-7], [2.5e-6, 7.5e-6, 0.1, 0.9],
+                [1.0, 1.0, 1.0, 1.0], [0.0, 0.0, 0.0, 0.0], [123.456789, 0.3, 0.3, 0.3], [0.999994999, 0.5, 0.5, 0.5],
+                [0.00001, 0.00002, 0.00003, 0.00004]]
+    path = str(tmp_path / "post.csv.gz")
+    align_post.write_posterior_csv(path, post)
+    with gzip.open(path, "rb") as f:
+        got = f.read()
+    assert got == oracle.posterior_csv_text(post)
+    align_post.write_posterior_csv(path, np.zeros((0, 4)))
+    with gzip.open(path, "rb") as f:
+        assert f.read() == b"\n"
+
+
+def _make_align_dirs(tmp_path, rng):
+    """Three sample directories as `tracs align` leaves them, two reference genomes."""
+    recs = {}
+    dirs = []
+    for s in range(3):
+        d = tmp_path / ("sample%d" % s)
+        d.mkdir()
+        dirs.append(str(d))
+        for ref in ("GCF_1.1", "GCF_2") if s != 2 else ("GCF_1.1",):
+            seq = "".join(rng.choice(list("ACGTNRYn"), 5000 + 7 * len(ref)))
+            recs[("sample%d" % s, ref)] = seq
+            name = "s%d_posterior_counts_ref_%s.fasta" % (s, ref)
+            if s == 1:                                        # gzip + wrapped lines: any FASTA layout is accepted
+                with gzip.open(d / (name + ".gz"), "wt") as f:
+                    f.write(">whatever desc\n" + "\n".join(seq[i:i + 61] for i in range(0, len(seq), 61)) + "\n")
+            else:
+                (d / name).write_text(">s%d_%s\n%s\n" % (s, ref, seq))
+        (d / ("s%d_sourmash_hits.csv" % s)).write_text(
+            "intersect_bp,f_orig_query,f_match,f_unique_to_query,f_unique_weighted,average_abund,median_abund,std_abund,"
+            "filename,name,md5,f_match_orig\n"
+            '1000,0.5,0.25,0.125,0.1,1,1,0,db.zip,"GCF_1.1 Escherichia coli strain K-12",abc,0.3\n'
+            '10,0.1,0.2,0.3,0.1,1,1,0,db.zip,"GCF_9 Unmapped species",abc,0.3\n')
+    return dirs, recs
+
+
+def test_combine_matches_restatement(oracle, hiplib, tmp_path):
+    from tracs_amd import combine
+    rng = np.random.default_rng(21)
+    dirs, recs = _make_align_dirs(tmp_path, rng)
+    out = str(tmp_path / "combined")
+    rc = subprocess.run([sys.executable, "-m", "tracs_amd", "combine", "-i"] + dirs + ["-o", out, "-t", "3"],
+                        capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert rc.returncode == 0, rc.stderr
+    for ref in ("GCF_1.1", "GCF_2"):
+        samples = [s for s in ("sample0", "sample1", "sample2") if (s, ref) in recs]
+        text, ncov = oracle.combined_fasta_text([(s, recs[(s, ref)]) for s in samples])
+        path = os.path.join(out, ref + "_combined.fasta.gz")
+        with gzip.open(path, "rt") as f:                      # one gzip member per sample reads as one stream
+            assert f.read() == text
+        # the file is what `tracs distance` ingests: our reader sees the same records
+        import ctypes as C
+        n, L = C.c_size_t(0), C.c_size_t(0)
+        assert hiplib.tracs_debug_read_fasta(path.encode(), C.byref(n), C.byref(L), None) == 0
+        assert n.value == len(samples) and L.value == len(recs[(samples[0], ref)])
+        got = combine.write_alignment(ref, [(s, os.path.join(tmp_path, s, p)) for s in samples
+                                            for p in os.listdir(tmp_path / s) if "_ref_" + ref + ".fasta" in p],
+                                      os.path.join(out, "again_"))
+        assert got == {(s, ref): ncov[s] for s in samples}
+    meta = open(os.path.join(out, "combined_metadata.csv")).read().splitlines()
+    assert meta[0] == ("sample,accession,intersect_bp,f_orig_query,f_match,f_unique_to_query,coverage,mean_depth,"
+                       "mean_nonzero_depth,frac_N,species")
+    s0 = recs[("sample0", "GCF_1.1")]
+    assert meta[1] == "sample0,GCF_1.1,1000,0.5,0.25,0.125,NA,NA,NA,%s,Escherichia coli strain K-12" % str(s0.count("N") / len(s0))
+    assert meta[2] == "sample0,GCF_9,10,0.1,0.2,0.3,NA,NA,NA,NA,Unmapped species"
+    assert len(meta) == 1 + 2 * 3
+
+
+def test_combine_refuses_multi_record_and_bad_names(tmp_path):
+    from tracs_amd import combine
+    d = tmp_path / "s"
+    d.mkdir()
+    (d / "s_posterior_counts_ref_X.fasta").write_text(">a\nACGT\n>b\nACGT\n")
+    with pytest.raises(SystemExit):
+        combine.write_alignment("X", [("s", str(d / "s_posterior_counts_ref_X.fasta"))], str(tmp_path) + os.sep)
+    with pytest.raises(SystemExit):
+        combine.find_ref("not_an_align_output.txt")
+    assert combine.find_ref("/x/y/p_posterior_counts_ref_GCF_000005845.2.fasta.gz") == "GCF_000005845.2"

@@ -1,16 +1,48 @@
 """`tracs <command>` for the commands on the GPU distance path (reference: tracs/__main__.py:15-57).
 
-Only `distance` and `cluster` exist here; align/combine/threshold/build-db/pipe/plot are outside
-the scope of this repository and are reported as such.
+`distance` and `cluster` are the hot path; `combine` and `align-post` are the data formats either side of it (SURVEY.md 8f
+row 4: `align-post` is the part of `tracs align` after the pileup, tracs/align.py:444-647, with that command's option names).
+Read mapping (`align` proper), threshold/build-db/pipe/plot are outside the scope of this repository and are reported as such.
 """
 import argparse
 import sys
 
 from . import __version__
 from .cluster import cluster_parser
+from .combine import combine_parser
 from .distance import distance_parser
 
-OUT_OF_SCOPE = ["align", "combine", "threshold", "build-db", "pipe", "plot"]
+OUT_OF_SCOPE = ["align", "threshold", "build-db", "pipe", "plot"]
+
+
+def align_post_parser(parser):
+    parser.description = "The post-pileup stage of `tracs align`: pileup text -> posterior counts CSV + FASTA (on the GPU)"
+    parser.add_argument("--pileup", required=True, help="`htsbox pileup -C -s 0` output (plain or gzip)")
+    parser.add_argument("--reference", required=True, help="reference genome FASTA the reads were mapped to")
+    parser.add_argument("--ref-id", dest="ref", required=True, help="reference genome id used in the output file names")
+    parser.add_argument("-o", "--output", dest="output_dir", required=True, help="output directory")
+    parser.add_argument("-p", "--prefix", dest="prefix", required=True, help="sample prefix of the output file names")
+    parser.add_argument("--consensus", dest="consensus", action="store_true", default=False)
+    parser.add_argument("--min-cov", dest="min_cov", default=5, type=int, help="Minimum read coverage (default=5).")
+    parser.add_argument("--keep-cov-outliers", dest="keep_cov_outliers", action="store_true", default=False)
+    parser.add_argument("--error-perc", dest="error_threshold", default=0.01, type=float)
+    parser.add_argument("--either-strand", dest="require_both_strands", action="store_false", default=True)
+    parser.add_argument("--keep-all", dest="keep_all", action="store_true", default=False)
+
+    def run(args):
+        import logging
+        import os
+        from .align_post import align_post
+        logging.basicConfig(level="INFO", format="%(asctime)s - %(levelname)s - %(message)s")
+        os.makedirs(args.output_dir, exist_ok=True)
+        res = align_post(args.pileup, args.reference, args.output_dir, args.prefix, args.ref, args.min_cov,
+                         args.error_threshold, args.require_both_strands, args.consensus, args.keep_all,
+                         args.keep_cov_outliers, log=logging.info)
+        if res["fasta"] is None:
+            logging.info("Skipping reference: %s (insufficient coverage or more than 75%% N)" % args.ref)
+
+    parser.set_defaults(func=run)
+    return parser
 
 
 def main():
@@ -19,6 +51,8 @@ def main():
     sub = parser.add_subparsers(title="subcommands", dest="command")
     distance_parser(sub.add_parser("distance"))
     cluster_parser(sub.add_parser("cluster"))
+    combine_parser(sub.add_parser("combine"))
+    align_post_parser(sub.add_parser("align-post"))
     if len(sys.argv) > 1 and sys.argv[1] in OUT_OF_SCOPE:
         parser.error("'%s' is not part of the MI355X distance path; use the reference TRACS for it" % sys.argv[1])
     args = parser.parse_args()

@@ -24,8 +24,10 @@ SYMBOLS = [
     "tracs_pairsnp_dense", "tracs_pairsnp_dense_thr", "tracs_coo_count", "tracs_coo_fill", "tracs_filter_recomb_device",
     "tracs_trans_dist_device", "tracs_trans_dist_dense", "tracs_trans_dist_dense2",
     "tracs_calculate_posteriors_device", "tracs_posterior_codes_device", "tracs_posterior_codes_cov_device",
-    "tracs_codes_to_iupac_device", "tracs_alignment_pack_codes",
+    "tracs_codes_to_iupac_device", "tracs_alignment_pack_codes", "tracs_coverage_profile_device",
+    "tracs_consensus_codes_device",
     "tracs_connected_components_device",
+    "tracs_pileup_counts", "tracs_write_posterior_csv", "tracs_combine_fasta",
 ]
 
 
@@ -138,6 +140,17 @@ def load():
     L.tracs_alignment_pack_codes.argtypes = [vp, vp, sz, vp]
     L.tracs_connected_components_device.restype = C.c_int
     L.tracs_connected_components_device.argtypes = [vp, vp, sz, sz, vp, C.POINTER(i32), vp]
+    cpp = C.POINTER(C.c_char_p)
+    L.tracs_coverage_profile_device.restype = C.c_int
+    L.tracs_coverage_profile_device.argtypes = [vp, sz, vp, sz, vp, vp, vp]
+    L.tracs_consensus_codes_device.restype = C.c_int
+    L.tracs_consensus_codes_device.argtypes = [vp, sz, C.c_uint32, vp, vp]
+    L.tracs_pileup_counts.restype = C.c_int
+    L.tracs_pileup_counts.argtypes = [C.c_char_p, cpp, u64p, sz, C.c_int, dp, u64p]
+    L.tracs_write_posterior_csv.restype = C.c_int
+    L.tracs_write_posterior_csv.argtypes = [C.c_char_p, dp, sz, sz, C.c_int]
+    L.tracs_combine_fasta.restype = C.c_int
+    L.tracs_combine_fasta.argtypes = [C.c_char_p, cpp, cpp, sz, C.c_int, C.c_int, dp, u64p]
     L.tracs_debug_read_fasta.restype = C.c_int
     L.tracs_debug_read_fasta.argtypes = [C.c_char_p, C.POINTER(sz), C.POINTER(sz), C.POINTER(C.c_uint64)]
     L.tracs_debug_alignment_encoding.restype = C.c_int

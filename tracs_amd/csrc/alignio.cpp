@@ -1,0 +1,299 @@
+// alignio.cpp -- the on-disk formats either side of the distance path, host side:
+//   tracs_pileup_counts        `htsbox pileup -C -s 0` text(.gz) -> allele counts [L,4]      (tracs/align.py:444-475)
+//   tracs_write_posterior_csv  posterior [L,4] -> <prefix>_posterior_counts_ref_<ref>.csv.gz   (tracs/align.py:580-596)
+//   tracs_combine_fasta        per-sample posterior FASTA files -> <ref>_combined.fasta.gz    (tracs/combine.py:220-239)
+// Own implementation; the behaviour (field positions, what is skipped, what overwrites what) follows the lines cited.
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "fasta.h"
+
+namespace tracs {
+void set_error(const std::string &msg);
+}
+using tracs::set_error;
+
+namespace {
+
+inline bool is_space(unsigned char c) { return c == ' ' || (c >= 9 && c <= 13); }   // str.split() separators (ASCII)
+
+struct Field { const char *p; size_t n; };
+
+// Python's int() on a short ASCII token: optional sign, digits, optional single underscores between digits are NOT
+// accepted here (htsbox never writes them).  Returns false on anything else.
+bool parse_int(const char *p, size_t n, long long &out)
+{
+    if (!n) return false;
+    size_t i = 0;
+    bool neg = false;
+    if (p[0] == '+' || p[0] == '-') { neg = p[0] == '-'; i = 1; }
+    if (i >= n || n - i > 18) return false;
+    long long v = 0;
+    for (; i < n; i++) {
+        if (p[i] < '0' || p[i] > '9') return false;
+        v = v * 10 + (p[i] - '0');
+    }
+    out = neg ? -v : v;
+    return true;
+}
+
+inline int base_index(const char *p, size_t n)      // the reference's npos dict: exactly "A","C","G","T" (align.py:445)
+{
+    if (n != 1) return -1;
+    switch (p[0]) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return -1; }
+}
+
+// split [p, p+n) at `sep`, like str.split(sep): always at least one (possibly empty) piece
+void split_char(const char *p, size_t n, char sep, std::vector<Field> &out)
+{
+    out.clear();
+    const char *s = p, *e = p + n;
+    for (const char *q = p; q < e; q++)
+        if (*q == sep) { out.push_back({s, (size_t)(q - s)}); s = q + 1; }
+    out.push_back({s, (size_t)(e - s)});
+}
+
+}  // namespace
+
+extern "C" {
+
+int tracs_pileup_counts(const char *path, const char *const *contig_names, const uint64_t *contig_lengths, size_t n_contigs,
+                        int require_both_strands, double *counts, uint64_t *n_lines_out)
+{
+    if (!path || (!contig_names && n_contigs) || (!contig_lengths && n_contigs) || !counts) {
+        set_error("tracs_pileup_counts: NULL argument");
+        return TRACS_E_ARG;
+    }
+    std::unordered_map<std::string, std::pair<uint64_t, uint64_t>> where;      // name -> (first row, length)
+    uint64_t total = 0;
+    for (size_t c = 0; c < n_contigs; c++) {
+        if (!where.emplace(contig_names[c], std::make_pair(total, contig_lengths[c])).second) {
+            set_error(std::string("tracs_pileup_counts: duplicate contig name '") + contig_names[c] + "'");
+            return TRACS_E_ARG;
+        }
+        total += contig_lengths[c];
+    }
+    std::memset(counts, 0, (size_t)total * 4 * sizeof(double));                 // np.zeros((len(seq), 4)), align.py:449-450
+    gzFile f = gzopen(path, "rb");
+    if (!f) { set_error(std::string("cannot open '") + path + "'"); return TRACS_E_OPEN; }
+    gzbuffer(f, 1u << 20);
+
+    std::vector<char> buf(8u << 20);
+    size_t have = 0;
+    bool eof = false;
+    uint64_t line_no = 0;
+    std::vector<Field> fields, nucs, parts, fwd, rev;
+    std::string last_contig;
+    std::pair<uint64_t, uint64_t> last_where{0, 0};
+    int rc = TRACS_OK;
+    auto fail = [&](const std::string &what) {
+        set_error("pileup line " + std::to_string(line_no) + ": " + what);
+        rc = TRACS_E_FASTA;
+    };
+    auto do_line = [&](const char *p, size_t n) {
+        line_no++;
+        // line.strip().split(): whitespace-separated fields (align.py:456)
+        fields.clear();
+        size_t i = 0;
+        while (i < n) {
+            while (i < n && is_space((unsigned char)p[i])) i++;
+            if (i >= n) break;
+            const size_t s = i;
+            while (i < n && !is_space((unsigned char)p[i])) i++;
+            fields.push_back({p + s, i - s});
+        }
+        if (fields.size() < 3) { fail("fewer than 3 fields"); return; }
+        const Field &contig = fields[0];
+        if (last_contig.size() != contig.n || std::memcmp(last_contig.data(), contig.p, contig.n) != 0) {
+            last_contig.assign(contig.p, contig.n);
+            auto it = where.find(last_contig);
+            if (it == where.end()) { fail("contig '" + last_contig + "' is not in the reference"); return; }
+            last_where = it->second;
+        }
+        long long pos1 = 0;
+        if (!parse_int(fields[1].p, fields[1].n, pos1)) { fail("position is not an integer"); return; }
+        if (pos1 < 1 || (uint64_t)pos1 > last_where.second) { fail("position outside the contig"); return; }
+        const bool ref_ok = base_index(fields[2].p, fields[2].n) >= 0;          // line[2] not in npos -> every allele skipped (:466)
+        const Field &fn = fields[fields.size() - 2], &fc = fields[fields.size() - 1];
+        split_char(fn.p, fn.n, ',', nucs);                                       // line[-2].split(",")   (:459)
+        split_char(fc.p, fc.n, ':', parts);                                      // line[-1].split(":")[1:] (:460)
+        if (parts.size() < 3) { fail("allele-count column has fewer than two strand lists"); return; }
+        split_char(parts[1].p, parts[1].n, ',', fwd);
+        split_char(parts[2].p, parts[2].n, ',', rev);
+        double row[4] = {0.0, 0.0, 0.0, 0.0};
+        const size_t m = std::min(nucs.size(), std::min(fwd.size(), rev.size()));   // zip() stops at the shortest (:462-464)
+        for (size_t k = 0; k < m; k++) {
+            long long c1 = 0, c2 = 0;
+            if (!parse_int(fwd[k].p, fwd[k].n, c1) || !parse_int(rev[k].p, rev[k].n, c2)) { fail("allele count is not an integer"); return; }
+            const int b = base_index(nucs[k].p, nucs[k].n);
+            if (b < 0 || !ref_ok) continue;
+            if (require_both_strands && (c1 == 0 || c2 == 0)) c1 = c2 = 0;       // :468-470
+            row[b] = (double)(c1 + c2);                                          // assignment: a repeated allele overwrites (:471)
+        }
+        double *dst = counts + (size_t)(last_where.first + (uint64_t)pos1 - 1) * 4;
+        dst[0] = row[0]; dst[1] = row[1]; dst[2] = row[2]; dst[3] = row[3];      // a repeated position overwrites (:472)
+    };
+    while (rc == TRACS_OK) {
+        if (!eof) {
+            if (have == buf.size()) buf.resize(buf.size() * 2);                  // a line longer than the buffer
+            const int r = gzread(f, buf.data() + have, (unsigned)std::min<size_t>(buf.size() - have, 1u << 30));
+            if (r < 0) { set_error(std::string("error reading '") + path + "'"); rc = TRACS_E_FASTA; break; }
+            if (r == 0) eof = true;
+            have += (size_t)r;
+        }
+        size_t start = 0;
+        for (;;) {
+            const char *nl = static_cast<const char *>(std::memchr(buf.data() + start, '\n', have - start));
+            if (!nl) break;
+            do_line(buf.data() + start, (size_t)(nl - (buf.data() + start)));
+            start = (size_t)(nl - buf.data()) + 1;
+            if (rc != TRACS_OK) break;
+        }
+        if (rc != TRACS_OK) break;
+        std::memmove(buf.data(), buf.data() + start, have - start);
+        have -= start;
+        if (eof) {
+            if (have) do_line(buf.data(), have);                                 // last line without a newline
+            break;
+        }
+    }
+    gzclose(f);
+    if (n_lines_out) *n_lines_out = line_no;
+    return rc;
+}
+
+// np.savetxt(fmt="%0.5f", delimiter=",") through gzip, plus the extra "\n" the reference appends (align.py:580-596).
+int tracs_write_posterior_csv(const char *path, const double *post, size_t L, size_t K, int gzip_level)
+{
+    if (!path || (!post && L) || K == 0 || K > 64) { set_error("tracs_write_posterior_csv: bad argument"); return TRACS_E_ARG; }
+    char mode[8];
+    std::snprintf(mode, sizeof mode, "wb%d", std::max(0, std::min(9, gzip_level)));
+    gzFile f = gzopen(path, mode);
+    if (!f) { set_error(std::string("cannot open '") + path + "' for writing"); return TRACS_E_OPEN; }
+    gzbuffer(f, 1u << 20);
+    // rows are formatted in parallel into per-chunk buffers, written in order
+    const size_t chunk = 1u << 16;
+    const unsigned T = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    int rc = TRACS_OK;
+    for (size_t base = 0; base < L && rc == TRACS_OK; base += chunk * T) {
+        std::vector<std::string> out(T);
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < T; t++)
+            th.emplace_back([&, t]() {
+                const size_t r0 = std::min(L, base + (size_t)t * chunk), r1 = std::min(L, r0 + chunk);
+                std::string &s = out[t];
+                s.reserve((r1 - r0) * K * 10);
+                char tmp[512];
+                for (size_t r = r0; r < r1; r++)
+                    for (size_t k = 0; k < K; k++) {
+                        const int w = std::snprintf(tmp, sizeof tmp, "%0.5f", post[r * K + k]);
+                        s.append(tmp, (size_t)w);
+                        s.push_back(k + 1 < K ? ',' : '\n');
+                    }
+            });
+        for (auto &x : th) x.join();
+        for (unsigned t = 0; t < T; t++)
+            if (!out[t].empty() && gzwrite(f, out[t].data(), (unsigned)out[t].size()) != (int)out[t].size()) {
+                set_error(std::string("error writing '") + path + "'");
+                rc = TRACS_E_OPEN;
+                break;
+            }
+    }
+    if (rc == TRACS_OK && gzwrite(f, "\n", 1) != 1) { set_error(std::string("error writing '") + path + "'"); rc = TRACS_E_OPEN; }
+    if (gzclose(f) != Z_OK && rc == TRACS_OK) { set_error(std::string("error closing '") + path + "'"); rc = TRACS_E_OPEN; }
+    return rc;
+}
+
+// One gzip member per sample (a multi-member gzip file is what gzopen/zcat/kseq read as one stream), compressed in
+// parallel and written in input order:  ">" sample "\n" sequence "\n"  (tracs/combine.py:227-231).
+int tracs_combine_fasta(const char *out_path, const char *const *sample_names, const char *const *fasta_paths, size_t n,
+                        int n_threads, int gzip_level, double *frac_n, uint64_t *lengths)
+{
+    if (!out_path || (n && (!sample_names || !fasta_paths))) { set_error("tracs_combine_fasta: NULL argument"); return TRACS_E_ARG; }
+    FILE *fo = std::fopen(out_path, "wb");
+    if (!fo) { set_error(std::string("cannot open '") + out_path + "' for writing"); return TRACS_E_OPEN; }
+    const unsigned T = (unsigned)std::max(1, std::min(n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency(), 64));
+    const int level = gzip_level < 0 ? 6 : std::min(9, gzip_level);
+    std::mutex mu;
+    std::string first_error;
+    int rc = TRACS_OK;
+    for (size_t base = 0; base < n && rc == TRACS_OK; base += T) {
+        const size_t cnt = std::min<size_t>(T, n - base);
+        std::vector<std::vector<unsigned char>> member(cnt);
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < cnt; t++)
+            th.emplace_back([&, t]() {
+                const size_t s = base + t;
+                tracs::FastaData fd;
+                std::string err;
+                int r = tracs::read_fasta(fasta_paths[s], fd, err);
+                if (r == TRACS_E_RAGGED || (r == TRACS_OK && fd.n > 1)) {       // combine.py:233-237
+                    r = TRACS_E_FASTA;
+                    err = std::string("ERROR: ") + fasta_paths[s] + " contains more than one sequence";
+                }
+                if (r != TRACS_OK) {
+                    std::lock_guard<std::mutex> lock(mu);
+                    if (rc == TRACS_OK) { rc = r; first_error = err; }
+                    return;
+                }
+                if (fd.n == 0) {                                                 // no record: nothing written, no ncov entry
+                    if (frac_n) frac_n[s] = -1.0;
+                    if (lengths) lengths[s] = 0;
+                    return;
+                }
+                std::string text;
+                text.reserve(fd.L + std::strlen(sample_names[s]) + 4);
+                text.push_back('>');
+                text += sample_names[s];
+                text.push_back('\n');
+                text.append(reinterpret_cast<const char *>(fd.seq.data()), fd.L);
+                text.push_back('\n');
+                size_t nN = 0;
+                for (size_t k = 0; k < fd.L; k++) nN += fd.seq[k] == 'N';
+                if (frac_n) frac_n[s] = fd.L ? (double)nN / (double)fd.L : 0.0;  // seq.count("N") / len(seq)  (:238)
+                if (lengths) lengths[s] = fd.L;
+                z_stream zs;
+                std::memset(&zs, 0, sizeof zs);
+                if (deflateInit2(&zs, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) {
+                    std::lock_guard<std::mutex> lock(mu);
+                    if (rc == TRACS_OK) { rc = TRACS_E_NOMEM; first_error = "deflateInit2 failed"; }
+                    return;
+                }
+                std::vector<unsigned char> &o = member[t];
+                o.resize(deflateBound(&zs, (uLong)text.size()) + 64);
+                zs.next_in = reinterpret_cast<Bytef *>(const_cast<char *>(text.data()));
+                zs.avail_in = (uInt)text.size();
+                zs.next_out = o.data();
+                zs.avail_out = (uInt)o.size();
+                const int zr = deflate(&zs, Z_FINISH);
+                o.resize(zr == Z_STREAM_END ? zs.total_out : 0);
+                deflateEnd(&zs);
+                if (zr != Z_STREAM_END) {
+                    std::lock_guard<std::mutex> lock(mu);
+                    if (rc == TRACS_OK) { rc = TRACS_E_NOMEM; first_error = "deflate failed"; }
+                }
+            });
+        for (auto &x : th) x.join();
+        if (rc != TRACS_OK) break;
+        for (size_t t = 0; t < cnt; t++)
+            if (!member[t].empty() && std::fwrite(member[t].data(), 1, member[t].size(), fo) != member[t].size()) {
+                rc = TRACS_E_OPEN;
+                first_error = std::string("error writing '") + out_path + "'";
+                break;
+            }
+    }
+    if (std::fclose(fo) != 0 && rc == TRACS_OK) { rc = TRACS_E_OPEN; first_error = std::string("error closing '") + out_path + "'"; }
+    if (rc != TRACS_OK) set_error(first_error);
+    return rc;
+}
+
+}  // extern "C"

@@ -160,6 +160,63 @@ __global__ __launch_bounds__(256) void posterior_codes_kernel(const uint4 *__res
     }
 }
 
+// ---- align stage, before the posterior filter (tracs/align.py:473-516) ------------------------------------------------
+// One pass over the f64 counts the pileup parser produced: narrow to uint16 (what posterior_codes_kernel reads), and
+// histogram the per-site coverage rs = sum of the four counts -- every statistic the stage needs (fraction covered,
+// fraction >= min_cov, np.median / np.quantile of the non-zero coverages) is an order statistic of that histogram.
+// A count that is not an integer in [0, 65535] raises the `bad` flag (the host then refuses: no silent narrowing).
+constexpr int COV_LDS_BINS = 8192;
+__global__ __launch_bounds__(256) void coverage_profile_kernel(const double *__restrict__ counts, size_t L, unsigned nbins,
+                                                               unsigned long long *__restrict__ hist,
+                                                               uint16_t *__restrict__ counts16, unsigned *__restrict__ bad)
+{
+    __shared__ unsigned local[COV_LDS_BINS];
+    for (int b = threadIdx.x; b < COV_LDS_BINS; b += blockDim.x) local[b] = 0;
+    __syncthreads();
+    bool any_bad = false;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (size_t)gridDim.x * blockDim.x) {
+        const double2 lo = reinterpret_cast<const double2 *>(counts)[2 * i], hi = reinterpret_cast<const double2 *>(counts)[2 * i + 1];
+        const double c[4] = {lo.x, lo.y, hi.x, hi.y};
+        unsigned v[4], rs = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const bool ok = c[k] >= 0.0 && c[k] <= 65535.0 && c[k] == (double)(unsigned)c[k];
+            any_bad |= !ok;
+            v[k] = ok ? (unsigned)c[k] : 0u;
+            rs += v[k];
+        }
+        if (counts16) reinterpret_cast<uint2 *>(counts16)[i] = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
+        if (rs < (unsigned)COV_LDS_BINS) atomicAdd(&local[rs], 1u);
+        else atomicAdd(&hist[min(rs, nbins - 1)], 1ull);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < COV_LDS_BINS; b += blockDim.x)
+        if (local[b]) atomicAdd(&hist[min((unsigned)b, nbins - 1)], (unsigned long long)local[b]);
+    if (any_bad) atomicOr(bad, 1u);
+}
+
+// --consensus (tracs/align.py:482-493): the first allele with the largest count, or every allele (N) below min_cov.
+__global__ __launch_bounds__(256) void consensus_codes_kernel(const uint2 *__restrict__ counts16, size_t L, unsigned min_cov,
+                                                              uint8_t *__restrict__ codes)
+{
+    const size_t npairs = (L + 1) / 2;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < npairs; t += (size_t)gridDim.x * blockDim.x) {
+        unsigned out = 0;
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            if (2 * t + s >= L) continue;
+            const uint2 w = counts16[2 * t + s];
+            const unsigned c[4] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16};
+            unsigned best = 0;
+#pragma unroll
+            for (int k = 1; k < 4; k++) best = c[k] > c[best] ? k : best;           // np.argmax: first maximum
+            const unsigned rs = c[0] + c[1] + c[2] + c[3];
+            out |= (rs < min_cov ? 15u : (1u << best)) << (4 * s);
+        }
+        codes[t] = (uint8_t)out;
+    }
+}
+
 // 4-bit allele mask -> IUPAC letter exactly as tracs/align.py:285-323 maps np.packbits(..., bitorder="little"):
 // 0 -> 'X' (no allele survived), 15 -> 'N'.
 __global__ void codes_to_iupac_kernel(const uint8_t *__restrict__ codes, size_t L, uint8_t *__restrict__ ascii)
@@ -250,6 +307,32 @@ int tracs_posterior_codes_cov_device(const uint16_t *counts, size_t L, const dou
     const CovRule cov{min_cov, cov_lo, cov_hi};
     hipLaunchKernelGGL(posterior_codes_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const uint4 *>(counts), L, A,
                        keep, threshold, cov, codes);
+    TRACS_HIP_CHECK(hipGetLastError());
+    return TRACS_OK;
+}
+
+int tracs_coverage_profile_device(const double *counts, size_t L, uint64_t *hist, size_t nbins, uint16_t *counts16,
+                                  uint32_t *bad, void *stream_)
+{
+    if (!hist || !bad || nbins < 2 || nbins > 0x7FFFFFFFu || (!counts && L)) { set_error("tracs_coverage_profile_device: bad argument"); return TRACS_E_ARG; }
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    TRACS_HIP_CHECK(hipMemsetAsync(hist, 0, nbins * sizeof(uint64_t), stream));
+    TRACS_HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(uint32_t), stream));
+    if (L == 0) return TRACS_OK;
+    const unsigned blocks = (unsigned)std::min<size_t>((L + 255) / 256, 256 * 4);
+    hipLaunchKernelGGL(coverage_profile_kernel, dim3(blocks), dim3(256), 0, stream, counts, L, (unsigned)nbins,
+                       reinterpret_cast<unsigned long long *>(hist), counts16, bad);
+    TRACS_HIP_CHECK(hipGetLastError());
+    return TRACS_OK;
+}
+
+int tracs_consensus_codes_device(const uint16_t *counts16, size_t L, uint32_t min_cov, uint8_t *codes, void *stream_)
+{
+    if (L == 0) return TRACS_OK;
+    if (!counts16 || !codes) { set_error("tracs_consensus_codes_device: NULL argument"); return TRACS_E_ARG; }
+    const size_t npairs = (L + 1) / 2;
+    hipLaunchKernelGGL(consensus_codes_kernel, dim3((unsigned)std::min<size_t>((npairs + 255) / 256, 256 * 16)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream_), reinterpret_cast<const uint2 *>(counts16), L, min_cov, codes);
     TRACS_HIP_CHECK(hipGetLastError());
     return TRACS_OK;
 }
