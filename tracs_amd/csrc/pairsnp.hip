@@ -823,6 +823,22 @@ static const TileVariant kVariants[] = {
     TRACS_VARIANT_GC(8, 8, 3, 2, ROW_LDS, 3),    // 58
     TRACS_VARIANT_GC(4, 16, 3, 1, ROW_LDS, 3),   // 59
     TRACS_VARIANT_GC(4, 16, 3, 2, ROW_LDS, 2),   // 60
+    TRACS_VARIANT_GC(4, 16, 2, 2, ROW_LDS, 4),   // 61: 56 squeezed to 128 VGPRs (4 workgroups/CU)
+    TRACS_VARIANT_GC(4, 16, 2, 1, ROW_LDS, 4),   // 62
+    TRACS_VARIANT_GC(4, 16, 2, 3, ROW_LDS, 4),   // 63
+    TRACS_VARIANT_GC(4, 16, 1, 2, ROW_LDS, 4),   // 64: 64 x 64 tile
+    TRACS_VARIANT_GC(4, 16, 1, 1, ROW_LDS, 4),   // 65
+    TRACS_VARIANT_GC(4, 16, 1, 4, ROW_LDS, 4),   // 66
+    TRACS_VARIANT_GC(8, 8, 1, 2, ROW_LDS, 4),    // 67
+    TRACS_VARIANT_GC(8, 16, 1, 2, ROW_LDS, 2),   // 68: 128 x 64
+    TRACS_VARIANT_GC(4, 32, 1, 2, ROW_LDS, 2),   // 69: 128 x 64, 4 waves
+    TRACS_VARIANT_GC(4, 16, 1, 2, ROW_LDS, 6),   // 70
+    TRACS_VARIANT_GC(4, 16, 1, 2, ROW_LDS, 8),   // 71
+    TRACS_VARIANT_GC(8, 8, 1, 2, ROW_LDS, 8),    // 72
+    TRACS_VARIANT_GC(16, 4, 1, 2, ROW_LDS, 8),   // 73
+    TRACS_VARIANT_GC(2, 32, 1, 2, ROW_LDS, 4),   // 74: 64 x 64, 2 waves
+    TRACS_VARIANT_GC(4, 16, 1, 3, ROW_LDS, 4),   // 75
+    TRACS_VARIANT_GC(4, 16, 1, 2, ROW_LDS, 5),   // 76
 };
 static constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 // fastest measured on MI355X (profiles/r01/tile_variant_sweeps.txt): one default per encoding
@@ -830,7 +846,7 @@ static constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0
 #define TRACS_DEFAULT_VARIANT 35            // general IUPAC encoding: 8 waves x 8 rows x 2 cols, GC = 2
 #endif
 #ifndef TRACS_DEFAULT_VARIANT_CONS
-#define TRACS_DEFAULT_VARIANT_CONS 56       // consensus encoding: 4 waves x 16 rows x 2 cols, GC = 2
+#define TRACS_DEFAULT_VARIANT_CONS 64       // consensus encoding: 4 waves x 16 rows x 1 col (64 x 64 tile), GC = 2, 94 VGPRs
 #endif
 
 static const TileVariant &current_variant(bool consensus = false)
@@ -1026,7 +1042,9 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
     {
         static int cus = 0;
         if (!cus) { hipDeviceProp_t pr; int dv = 0; (void)hipGetDevice(&dv); cus = (hipGetDeviceProperties(&pr, dv) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }
-        slots = 2.0 * cus;
+        // resident workgroups per CU (VGPR/LDS bound) of the shapes that are defaults; 2 is right for every other general shape
+        const int vid = (int)(&V - kVariants);
+        slots = (cons ? (vid == 64 ? 5.0 : vid == 56 ? 3.0 : 2.0) : 2.0) * cus;
         const int max_split = std::max(1, groups / (8 * kGC));
         double best = -1.0;
         for (int k = 1; k <= std::min(max_split, 64); k++) {
