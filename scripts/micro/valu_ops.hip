@@ -36,6 +36,16 @@ __global__ __launch_bounds__(256) void k(unsigned *out, unsigned s0, unsigned s1
                 asm volatile("v_or_b32 %0, %1, %2" : "=v"(m) : "v"(b[(i + 8) % NA]), "v"(b[(i + 9) % NA]));
                 asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a[(i + 1) % NA]) : "v"(m));
             }
+            if (MODE == 16) asm volatile("v_xor_b32_dpp %0, %1, %0 row_newbcast:5 row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(b[i]));
+            if (MODE == 17) {   // consensus pair-word with the row operand taken through DPP row_newbcast (no broadcast LDS reads)
+                unsigned v, t, u;
+                asm volatile("v_and_b32_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "=v"(v) : "v"(b[i]), "v"(b[(i + 1) % NA]));
+                asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a[i]) : "v"(v));
+                asm volatile("v_xor_b32_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "=v"(t) : "v"(b[(i + 2) % NA]), "v"(b[(i + 3) % NA]));
+                asm volatile("v_xor_b32_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "=v"(u) : "v"(b[(i + 4) % NA]), "v"(b[(i + 5) % NA]));
+                asm volatile("v_bitop3_b32 %0, %1, %2, %0 bitop3:0xa8" : "+v"(v) : "v"(t), "v"(u));
+                asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a[(i + 1) % NA]) : "v"(v));
+            }
             if (MODE == 15) {   // consensus pair-word: and, bcnt, xor, xor, bitop3, bcnt
                 unsigned v, t, u;
                 asm volatile("v_and_b32 %0, %1, %2" : "=v"(v) : "v"(b[i]), "v"(b[(i + 1) % NA]));
@@ -52,9 +62,9 @@ __global__ __launch_bounds__(256) void k(unsigned *out, unsigned s0, unsigned s1
     for (int i = 0; i < NA; i++) r += a[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
-template <int MODE> int run(const char *name)
+template <int MODE> int run(const char *name, int waves_per_simd = 4)
 {
-    const int blocks = 256 * 4, iters = 40000;     // 4 waves per SIMD, ~5 ms per run
+    const int blocks = 256 * waves_per_simd, iters = 40000;     // 4 waves per SIMD by default, ~5 ms per run
     unsigned *d; CHECK(hipMalloc(&d, (size_t)blocks * 256 * 4));
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, 3u, 5u, 10);
@@ -63,7 +73,7 @@ template <int MODE> int run(const char *name)
     hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, 3u, 5u, iters);
     CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
     float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
-    const double instr = (double)blocks * 4 * iters * NA * (MODE == 14 ? 7 : MODE == 15 ? 6 : 1);
+    const double instr = (double)blocks * 4 * iters * NA * (MODE == 14 ? 7 : (MODE == 15 || MODE == 17) ? 6 : 1);
     printf("%-34s %.3f ms  %.2f Tlane-op/s  %.2f cycles/wave-instr/SIMD @2.4GHz\n", name, ms, instr * 64 / ms / 1e9, (ms * 1e-3 * 2.4e9) / (instr / 1024.0));
     CHECK(hipFree(d)); return 0;
 }
@@ -73,5 +83,8 @@ int main()
     run<8>("v_and_or_b32 svv"); run<4>("v_bcnt_u32_b32"); run<5>("v_bitop3_b32 vvv"); run<9>("v_bitop3_b32 svv"); run<6>("v_or3_b32");
     run<7>("v_add_u32"); run<10>("v_mad_u32_u24"); run<11>("v_bfi_b32"); run<12>("v_dot4_u32_u8"); run<13>("v_pk_add_u16");
     run<14>("general pair-word mix (7 ops)"); run<15>("consensus pair-word mix (6 ops)");
+    run<16>("v_xor_b32_dpp row_newbcast"); run<17>("consensus mix, rows via DPP row_newbcast");
+    run<15>("consensus mix, 2 waves/SIMD", 2); run<15>("consensus mix, 3 waves/SIMD", 3); run<15>("consensus mix, 5 waves/SIMD", 5);
+    run<15>("consensus mix, 6 waves/SIMD", 6); run<15>("consensus mix, 7 waves/SIMD", 7); run<15>("consensus mix, 8 waves/SIMD", 8); run<17>("consensus mix via DPP, 5 waves/SIMD", 5); run<14>("general mix, 2 waves/SIMD", 2);
     return 0;
 }
