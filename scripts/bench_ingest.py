@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+from tracs_amd import combine  # noqa: E402
 from tracs_amd import device as dev  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 400
@@ -20,6 +21,7 @@ tmp = os.environ.get("TMPDIR", "/tmp")
 rng = np.random.default_rng(3)
 base = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, L)]
 plain, gz = os.path.join(tmp, "ingest.fa"), os.path.join(tmp, "ingest.fa.gz")
+parts = []                                               # per-sample files for `combine` (what tracs align leaves behind)
 with open(plain, "wb") as f, gzip.open(gz, "wb", compresslevel=1) as g:
     for s in range(n):
         row = base.copy()
@@ -29,8 +31,19 @@ with open(plain, "wb") as f, gzip.open(gz, "wb", compresslevel=1) as g:
         f.write(rec)
         if s < n // 8:
             g.write(rec)
+        if s < n // 2:
+            pp = os.path.join(tmp, "ingest_part%d_posterior_counts_ref_R.fasta" % s)
+            with open(pp, "wb") as h:
+                h.write(rec)
+            parts.append(("s%d" % s, pp))
 out = {"samples": n, "sites": L}
-for label, path in (("plain", plain), ("gzip", gz)):
+t0 = time.perf_counter()
+combine.write_alignment("ingest_R", parts, tmp + os.sep, n_threads=0)
+out["combine_s"] = time.perf_counter() - t0
+members = os.path.join(tmp, "ingest_R_combined.fasta.gz")
+for _, pp in parts:
+    os.remove(pp)
+for label, path in (("plain", plain), ("gzip", gz), ("gzip_indexed_members", members)):
     mb = os.path.getsize(path) / 1e6
     t0 = time.perf_counter()
     a = dev.Alignment.from_fasta([path])
@@ -48,3 +61,4 @@ for label, path in (("plain", plain), ("gzip", gz)):
 print(json.dumps(out))
 os.remove(plain)
 os.remove(gz)
+os.remove(members)

@@ -169,3 +169,64 @@ def test_combine_refuses_multi_record_and_bad_names(tmp_path):
     with pytest.raises(SystemExit):
         combine.find_ref("not_an_align_output.txt")
     assert combine.find_ref("/x/y/p_posterior_counts_ref_GCF_000005845.2.fasta.gz") == "GCF_000005845.2"
+
+
+def _tr_member(text):
+    """One gzip member with the "TR" size subfield, as tracs_combine_fasta writes them."""
+    import struct
+    import zlib
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    body = co.compress(text) + co.flush()
+    total = 10 + 2 + 12 + len(body) + 8
+    return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\x03" + struct.pack("<H", 12) + b"TR" + struct.pack("<HQ", 8, total) + body +
+            struct.pack("<II", zlib.crc32(text), len(text) & 0xFFFFFFFF))
+
+
+def test_indexed_member_reader_equals_serial_state_machine(hiplib, tmp_path):
+    """The parallel reader for combine's own files (one gzip member per sample, sizes in an FEXTRA subfield) must give
+    exactly what the serial kseq restatement gives, and must step aside for anything that is not one clean record per
+    member -- the serial reader then produces the reference's behaviour and messages."""
+    import ctypes as C
+    from tracs_amd import combine
+
+    def read(path, serial):
+        if serial:
+            os.environ["TRACS_SERIAL_FASTA"] = "1"
+        n, L, h = C.c_size_t(0), C.c_size_t(0), C.c_uint64(0)
+        rc = hiplib.tracs_debug_read_fasta(os.fsencode(path), C.byref(n), C.byref(L), C.byref(h))
+        os.environ.pop("TRACS_SERIAL_FASTA", None)
+        return rc, n.value, L.value, h.value, hiplib.tracs_last_error()
+
+    rng = np.random.default_rng(4)
+    alns = []
+    for s in range(37):
+        d = tmp_path / ("d%d" % s)
+        d.mkdir()
+        seq = "".join(rng.choice(list("ACGTNacgtRY-"), 20011))
+        (d / "x_posterior_counts_ref_R.fasta").write_text(">x%d something\n%s\n" % (s, seq))
+        alns.append(("sample_%d" % s, str(d / "x_posterior_counts_ref_R.fasta")))
+    combine.write_alignment("R", alns, str(tmp_path) + os.sep, n_threads=5)
+    good = str(tmp_path / "R_combined.fasta.gz")
+    raw = open(good, "rb").read()
+    assert raw[:4] == b"\x1f\x8b\x08\x04" and raw[12:14] == b"TR"
+    fast, slow = read(good, False), read(good, True)
+    assert fast == slow and fast[0] == 0 and fast[1] == 37 and fast[2] == 20011
+    with gzip.open(good, "rb") as f:                                        # and it is an ordinary gzip file
+        assert f.read().count(b">") == 37
+
+    cases = {
+        "two_records_in_a_member": _tr_member(b">a\nACGT\n") + _tr_member(b">b\nACGT\n>c\nACGT\n"),
+        "ragged": _tr_member(b">a\nACGT\n") + _tr_member(b">b\nACG\n"),
+        "fastq": _tr_member(b"@a\nACGT\n+\nIIII\n") + _tr_member(b"@b\nACGT\n+\nIIII\n"),
+        "junk_before_header": _tr_member(b"xx>a\nACGT\n") + _tr_member(b">b\nACGT\n"),
+        "chain_then_plain_member": _tr_member(b">a\nACGT\n") + gzip.compress(b">b\nACGT\n"),
+        "wrapped_lines_and_crlf": _tr_member(b">a x\r\nAC\r\nGT\r\n") + _tr_member(b">b\nA\nC\nG\nT"),
+        "truncated_size": _tr_member(b">a\nACGT\n")[:-3],
+    }
+    for name, blob in cases.items():
+        path = str(tmp_path / (name + ".fa.gz"))
+        open(path, "wb").write(blob)
+        assert read(path, False) == read(path, True), name
+    assert read(str(tmp_path / "two_records_in_a_member.fa.gz"), False)[1] == 3
+    assert read(str(tmp_path / "ragged.fa.gz"), False)[0] != 0
+    assert read(str(tmp_path / "wrapped_lines_and_crlf.fa.gz"), False)[1:3] == (2, 4)

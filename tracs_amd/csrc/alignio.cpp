@@ -268,8 +268,17 @@ int tracs_combine_fasta(const char *out_path, const char *const *sample_names, c
                     if (rc == TRACS_OK) { rc = TRACS_E_NOMEM; first_error = "deflateInit2 failed"; }
                     return;
                 }
+                // gzip FEXTRA subfield "TR": the member's total size in bytes (patched in below), so a reader can hop from
+                // member to member and inflate them in parallel (fasta.cpp); every other gzip reader ignores extra fields
+                unsigned char extra[12] = {'T', 'R', 8, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                gz_header gh;
+                std::memset(&gh, 0, sizeof gh);
+                gh.os = 3;
+                gh.extra = extra;
+                gh.extra_len = sizeof extra;
+                deflateSetHeader(&zs, &gh);
                 std::vector<unsigned char> &o = member[t];
-                o.resize(deflateBound(&zs, (uLong)text.size()) + 64);
+                o.resize(deflateBound(&zs, (uLong)text.size()) + 128);
                 zs.next_in = reinterpret_cast<Bytef *>(const_cast<char *>(text.data()));
                 zs.avail_in = (uInt)text.size();
                 zs.next_out = o.data();
@@ -277,6 +286,10 @@ int tracs_combine_fasta(const char *out_path, const char *const *sample_names, c
                 const int zr = deflate(&zs, Z_FINISH);
                 o.resize(zr == Z_STREAM_END ? zs.total_out : 0);
                 deflateEnd(&zs);
+                if (o.size() > 24 && o[3] == 4 && o[12] == 'T' && o[13] == 'R') {   // FLG = FEXTRA only: payload at byte 16
+                    const uint64_t sz = o.size();
+                    for (int b = 0; b < 8; b++) o[16 + b] = (unsigned char)(sz >> (8 * b));
+                }
                 if (zr != Z_STREAM_END) {
                     std::lock_guard<std::mutex> lock(mu);
                     if (rc == TRACS_OK) { rc = TRACS_E_NOMEM; first_error = "deflate failed"; }

@@ -153,8 +153,117 @@ static bool read_fasta_parallel(const std::string &path, FastaData &out)
     return true;
 }
 
+// ---- parallel fast path for gzip files made of indexed members ------------------------------------------------------
+// `tracs combine` here (tracs_combine_fasta, alignio.cpp) writes one gzip member per sample and records each member's
+// size in a gzip FEXTRA subfield "TR".  Such a file is walked member to member without inflating anything, the members
+// are inflated in parallel, and each must hold exactly one plain record (">name ...\nSEQUENCE\n", no '>', '+', '@' in the
+// sequence).  Any other gzip file -- no subfield, a chain that does not end at EOF, a member that is not one clean record,
+// ragged lengths -- returns false and is read by the serial state machine below, which owns every error message.
+static bool read_fasta_members(const std::string &path, FastaData &out)
+{
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size < 32) { close(fd); return false; }
+    const size_t size = (size_t)st.st_size;
+    void *m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return false;
+    const unsigned char *p = static_cast<const unsigned char *>(m);
+    std::vector<std::pair<size_t, size_t>> members;       // (offset, size)
+    bool ok = true;
+    for (size_t off = 0; off < size;) {
+        const unsigned char *h = p + off;
+        // 10-byte header, FLG has FEXTRA, first subfield is ours
+        if (size - off < 32 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4) || h[12] != 'T' || h[13] != 'R' ||
+            h[14] != 8 || h[15] != 0) { ok = false; break; }
+        uint64_t sz = 0;
+        for (int b = 0; b < 8; b++) sz |= (uint64_t)h[16 + b] << (8 * b);
+        if (sz < 32 || sz > size - off) { ok = false; break; }
+        members.emplace_back(off, (size_t)sz);
+        off += (size_t)sz;
+    }
+    if (!ok || members.empty()) { munmap(m, size); return false; }
+    const size_t nrec = members.size();
+    auto isize_of = [&](size_t r) {                       // gzip trailer: uncompressed size mod 2^32
+        const unsigned char *t = p + members[r].first + members[r].second - 4;
+        return (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
+    };
+    std::vector<std::string> names(nrec);
+    std::vector<uint8_t> seq;
+    std::atomic<bool> bad{false};
+    std::atomic<size_t> next{0};
+    size_t L = 0;
+    const unsigned T = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    // one member -> its record; r == 0 runs first, alone, and fixes L
+    auto do_member = [&](size_t r, std::vector<unsigned char> &text) -> bool {
+        const size_t want = isize_of(r);
+        if (members[r].second > 0xFFFFFFFFu) return false;
+        text.resize(want + 1);
+        z_stream zs;
+        std::memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, 15 + 16) != Z_OK) return false;
+        zs.next_in = const_cast<Bytef *>(p + members[r].first);
+        zs.avail_in = (uInt)members[r].second;
+        zs.next_out = text.data();
+        zs.avail_out = (uInt)text.size();
+        const int zr = inflate(&zs, Z_FINISH);
+        const size_t got = zs.total_out;
+        const bool whole = zr == Z_STREAM_END && zs.avail_in == 0;
+        inflateEnd(&zs);
+        if (!whole || got != want || got < 2 || text[0] != '>') return false;
+        const unsigned char *nl = static_cast<const unsigned char *>(std::memchr(text.data(), '\n', got));
+        if (!nl) return false;
+        size_t he = 1;
+        const size_t hend = (size_t)(nl - text.data());
+        while (he < hend && !std::isspace(text[he])) he++;
+        names[r].assign(reinterpret_cast<const char *>(text.data() + 1), he - 1);
+        const size_t b0 = hend + 1;
+        if (r == 0) {
+            size_t cnt = 0;
+            for (size_t k = b0; k < got; k++) cnt += is_graph(text[k]);
+            L = cnt;
+            seq.resize(nrec * L);
+        }
+        uint8_t *dst = seq.data() + r * L;
+        size_t w = 0;
+        bool stray = false;
+        for (size_t k = b0; k < got; k++) {
+            const unsigned ch = text[k];
+            stray |= (ch == '>') | (ch == '+') | (ch == '@');
+            if (w < L) dst[w] = (uint8_t)ch;
+            w += is_graph(ch);
+        }
+        return !stray && w == L;
+    };
+    {
+        std::vector<unsigned char> text;
+        if (!do_member(0, text)) { munmap(m, size); return false; }
+    }
+    next.store(1);
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < T; t++)
+        th.emplace_back([&]() {
+            std::vector<unsigned char> text;
+            for (;;) {
+                const size_t r = next.fetch_add(1);
+                if (r >= nrec || bad.load(std::memory_order_relaxed)) return;
+                if (!do_member(r, text)) bad.store(true);
+            }
+        });
+    for (auto &x : th) x.join();
+    munmap(m, size);
+    if (bad.load()) return false;
+    out.n = nrec;
+    out.L = L;
+    out.seq = std::move(seq);
+    out.names = std::move(names);
+    return true;
+}
+
 int read_fasta(const std::string &path, FastaData &out, std::string &err)
 {
+    if (out.n == 0 && out.seq.empty() && !getenv("TRACS_SERIAL_FASTA") && read_fasta_members(path, out)) return TRACS_OK;
     if (out.n == 0 && out.seq.empty() && !getenv("TRACS_SERIAL_FASTA") && read_fasta_parallel(path, out)) return TRACS_OK;
     gzFile f = gzopen(path.c_str(), "rb");
     if (!f) { err = "cannot open '" + path + "'"; return TRACS_E_OPEN; }
