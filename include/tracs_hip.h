@@ -228,6 +228,15 @@ int tracs_pileup_counts(const char *path, const char *const *contig_names, const
  * reference appends (tracs/align.py:580-596).  gzip_level 0..9.                                                   */
 int tracs_write_posterior_csv(const char *path, const double *post, size_t L, size_t K, int gzip_level);
 
+/* Rows of `tracs distance`'s CSV appended to path (tracs/distance.py:206-258; the caller writes the header, :157):
+ *   names[rows[t]],names[cols[t]],str(delta),str(int(snpd)),str(P),str(E(K)),filtered,str(nn),ref
+ * floats print exactly as Python's str(float) / str(numpy.float64).  with_dates = 0: "NA" for delta, P, E(K) (:240-258).
+ * filt == NULL: "NA" in the filtered column (:204).  k_max < 0: no -K filter; else rows with k_max >= E(K) only (:222). */
+int tracs_write_distance_rows(const char *path, const char *const *names, const uint64_t *rows, const uint64_t *cols,
+                              const uint64_t *snpd, const uint64_t *filt, const uint64_t *ncomp, const double *delta,
+                              const double *p_direct, const double *e_k, size_t n, int with_dates, double k_max,
+                              const char *ref, uint64_t *rows_written);
+
 /* write_alignment of tracs/combine.py:220-239: one single-record FASTA per sample -> "<ref>_combined.fasta.gz" with
  * records ">sample\nSEQUENCE\n" in input order.  Samples are compressed in parallel as separate gzip members
  * (n_threads <= 0: all cores; gzip_level < 0: 6).  frac_n[s] = count('N')/len, lengths[s] = len (the ncov dict);

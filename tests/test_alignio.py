@@ -230,3 +230,43 @@ def test_indexed_member_reader_equals_serial_state_machine(hiplib, tmp_path):
     assert read(str(tmp_path / "two_records_in_a_member.fa.gz"), False)[1] == 3
     assert read(str(tmp_path / "ragged.fa.gz"), False)[0] != 0
     assert read(str(tmp_path / "wrapped_lines_and_crlf.fa.gz"), False)[1:3] == (2, 4)
+
+
+def test_distance_rows_writer_is_python_str_exact(hiplib, tmp_path):
+    """tracs_write_distance_rows == the reference's ",".join([... str(x) ...]) + "\\n" loop (tracs/distance.py:212-258):
+    shortest-repr floats in Python's notation, the -K filter, and the two "NA" layouts."""
+    from tracs_amd import distance
+    rng = np.random.default_rng(12)
+    n, ns = 70001, 300
+    names = ["s%d|x y" % i if i % 7 else "Sample-%d" % i for i in range(ns)]
+    rows = rng.integers(0, ns, n).astype(np.uint64)
+    cols = rng.integers(0, ns, n).astype(np.uint64)
+    snpd = rng.integers(0, 3000, n).astype(np.uint64)
+    filt = rng.integers(0, 3000, n).astype(np.uint64)
+    nn = rng.integers(0, 5000000, n).astype(np.uint64)
+    ddiff = rng.integers(0, 730, n) * 86400.0 / 31556952.0
+    tdist = np.exp(rng.uniform(-60, 0, n))
+    tdist[:5] = [0.0, 1.0, 1e-5, 9.999e-5, 1e-320]
+    ek = np.exp(rng.uniform(-12, 40, n))
+    ek[5:9] = [np.nan, np.inf, 5.0, 1e16]
+
+    def expect(with_dates, filt_col, kmax):
+        out = []
+        for t in range(n):
+            if with_dates:
+                if kmax is None or kmax >= ek[t]:
+                    out.append(",".join([names[rows[t]], names[cols[t]], str(ddiff[t]), str(int(snpd[t])), str(tdist[t]), str(ek[t]),
+                                         "NA" if filt_col is None else str(int(filt_col[t])), str(int(nn[t])), "REF"]) + "\n")
+            else:
+                out.append(",".join([names[rows[t]], names[cols[t]], "NA", str(int(snpd[t])), "NA", "NA", str(int(filt_col[t])),
+                                     str(int(nn[t])), "REF"]) + "\n")
+        return "".join(out)
+
+    for with_dates, fc, kmax in ((True, None, None), (True, filt, 5), (True, None, 0), (False, filt, None)):
+        path = str(tmp_path / "rows.csv")
+        open(path, "w").write("HEADER\n")
+        w = distance._append_rows(path, names, rows, cols, snpd, fc, nn, ddiff if with_dates else None, tdist if with_dates else None,
+                                  ek if with_dates else None, kmax, "REF")
+        want = expect(with_dates, fc, kmax)
+        assert open(path).read() == "HEADER\n" + want
+        assert w == want.count("\n")

@@ -23,7 +23,11 @@ def oracle_kernels(monkeypatch, oracle):
     import tracs_amd.cluster as cl
     import tracs_amd.distance as di
     import tracs_amd.transcluster as tc
-    monkeypatch.setattr(di, "pairsnp", oracle.pairsnp)
+    def pairsnp_arrays(fasta, n_threads=1, dist=2147483647, filter=False):
+        r, c, d, names, f, nn = oracle.pairsnp(fasta, n_threads, dist, filter)
+        u = lambda x: np.asarray(x, dtype=np.uint64)
+        return u(r), u(c), u(d), names, u(f), u(nn)
+    monkeypatch.setattr(di, "pairsnp_arrays", pairsnp_arrays)
     monkeypatch.setattr(tc, "trans_dist_arrays", oracle.trans_dist)
     monkeypatch.setattr(cl, "connected_components",
                         lambda n, I, J: (int(oracle.connected_components(n, I, J).max()) + 1 if n else 0,

@@ -27,7 +27,7 @@ SYMBOLS = [
     "tracs_codes_to_iupac_device", "tracs_alignment_pack_codes", "tracs_coverage_profile_device",
     "tracs_consensus_codes_device",
     "tracs_connected_components_device",
-    "tracs_pileup_counts", "tracs_write_posterior_csv", "tracs_combine_fasta",
+    "tracs_pileup_counts", "tracs_write_posterior_csv", "tracs_combine_fasta", "tracs_write_distance_rows",
 ]
 
 
@@ -149,6 +149,10 @@ def load():
     L.tracs_pileup_counts.argtypes = [C.c_char_p, cpp, u64p, sz, C.c_int, dp, u64p]
     L.tracs_write_posterior_csv.restype = C.c_int
     L.tracs_write_posterior_csv.argtypes = [C.c_char_p, dp, sz, sz, C.c_int]
+    L.tracs_write_distance_rows.restype = C.c_int
+    L.tracs_write_distance_rows.argtypes = [C.c_char_p, cpp, u64p, u64p, u64p, u64p, u64p, dp, dp, dp, sz, C.c_int, dbl, C.c_char_p, u64p]
+    L.tracs_debug_format_floats.restype = C.c_long
+    L.tracs_debug_format_floats.argtypes = [dp, sz, C.c_char_p, sz]
     L.tracs_combine_fasta.restype = C.c_int
     L.tracs_combine_fasta.argtypes = [C.c_char_p, cpp, cpp, sz, C.c_int, C.c_int, dp, u64p]
     L.tracs_debug_read_fasta.restype = C.c_int

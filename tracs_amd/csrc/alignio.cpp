@@ -7,6 +7,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <charconv>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -60,6 +62,65 @@ void split_char(const char *p, size_t n, char sep, std::vector<Field> &out)
     for (const char *q = p; q < e; q++)
         if (*q == sep) { out.push_back({s, (size_t)(q - s)}); s = q + 1; }
     out.push_back({s, (size_t)(e - s)});
+}
+
+// str(float) / str(numpy.float64) as CPython and numpy print them (float_repr_style "short"): the shortest digit string
+// that round-trips, positional notation when 1e-4 <= |x| < 1e16, otherwise d[.ddd]e[+-]XX; "inf", "nan", "-0.0".
+size_t format_py_float(double x, char *out)
+{
+    if (std::isnan(x)) { std::memcpy(out, "nan", 3); return 3; }
+    if (std::isinf(x)) { const char *t = x < 0 ? "-inf" : "inf"; const size_t k = std::strlen(t); std::memcpy(out, t, k); return k; }
+    char sci[40];
+    const auto r = std::to_chars(sci, sci + sizeof sci, x, std::chars_format::scientific);     // [-]d[.ddd]e[+-]XX, shortest
+    const char *p = sci, *end = r.ptr;
+    char *o = out;
+    if (*p == '-') { *o++ = '-'; p++; }
+    char digits[24];
+    int nd = 0;
+    const char *e = p;
+    while (e < end && *e != 'e') { if (*e != '.') digits[nd++] = *e; e++; }
+    int exp10 = 0;
+    {
+        const char *q = e + 1;
+        const bool neg = *q == '-';
+        if (*q == '+' || *q == '-') q++;
+        while (q < end) exp10 = exp10 * 10 + (*q++ - '0');
+        if (neg) exp10 = -exp10;
+    }
+    if (exp10 < -4 || exp10 >= 16) {                      // exponent form, at least two exponent digits
+        *o++ = digits[0];
+        if (nd > 1) { *o++ = '.'; std::memcpy(o, digits + 1, (size_t)nd - 1); o += nd - 1; }
+        *o++ = 'e';
+        *o++ = exp10 < 0 ? '-' : '+';
+        const int a = exp10 < 0 ? -exp10 : exp10;
+        if (a >= 100) { *o++ = (char)('0' + a / 100); *o++ = (char)('0' + a / 10 % 10); *o++ = (char)('0' + a % 10); }
+        else { *o++ = (char)('0' + a / 10); *o++ = (char)('0' + a % 10); }
+    } else if (exp10 >= 0) {                              // ddd[.ddd] or ddd000.0
+        const int ip = exp10 + 1;                         // digits before the point
+        if (nd <= ip) {
+            std::memcpy(o, digits, (size_t)nd); o += nd;
+            for (int k = nd; k < ip; k++) *o++ = '0';
+            *o++ = '.'; *o++ = '0';
+        } else {
+            std::memcpy(o, digits, (size_t)ip); o += ip;
+            *o++ = '.';
+            std::memcpy(o, digits + ip, (size_t)(nd - ip)); o += nd - ip;
+        }
+    } else {                                              // 0.000ddd
+        *o++ = '0'; *o++ = '.';
+        for (int k = 0; k < -exp10 - 1; k++) *o++ = '0';
+        std::memcpy(o, digits, (size_t)nd); o += nd;
+    }
+    return (size_t)(o - out);
+}
+
+size_t format_u64(uint64_t v, char *out)
+{
+    char tmp[24];
+    int k = 0;
+    do { tmp[k++] = (char)('0' + v % 10); v /= 10; } while (v);
+    for (int i = 0; i < k; i++) out[i] = tmp[k - 1 - i];
+    return (size_t)k;
 }
 
 }  // namespace
@@ -211,6 +272,82 @@ int tracs_write_posterior_csv(const char *path, const double *post, size_t L, si
     if (rc == TRACS_OK && gzwrite(f, "\n", 1) != 1) { set_error(std::string("error writing '") + path + "'"); rc = TRACS_E_OPEN; }
     if (gzclose(f) != Z_OK && rc == TRACS_OK) { set_error(std::string("error closing '") + path + "'"); rc = TRACS_E_OPEN; }
     return rc;
+}
+
+// Rows of `tracs distance`'s CSV (tracs/distance.py:206-258), appended to `path`:
+//   nameA,nameB,str(delta),str(int(d)),str(P),str(E(K)),filtered,str(nn),ref
+// with_dates = 0 writes "NA" for delta, P and E(K).  filt == NULL writes "NA" in the filtered column (metadata on, --filter
+// off, :204), otherwise the integers.  k_max < 0 means no -K filter; else only rows with k_max >= E(K) are written (:222).
+int tracs_write_distance_rows(const char *path, const char *const *names, const uint64_t *rows, const uint64_t *cols,
+                              const uint64_t *snpd, const uint64_t *filt, const uint64_t *ncomp, const double *delta,
+                              const double *p_direct, const double *e_k, size_t n, int with_dates, double k_max,
+                              const char *ref, uint64_t *rows_written)
+{
+    if (!path || !ref || (n && (!names || !rows || !cols || !snpd || !ncomp)) || (with_dates && n && (!delta || !p_direct || !e_k))) {
+        set_error("tracs_write_distance_rows: NULL argument");
+        return TRACS_E_ARG;
+    }
+    FILE *fo = std::fopen(path, "ab");
+    if (!fo) { set_error(std::string("cannot open '") + path + "' for writing"); return TRACS_E_OPEN; }
+    const size_t ref_len = std::strlen(ref);
+    const unsigned T = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    const size_t chunk = 1u << 15;
+    uint64_t written = 0;
+    int rc = TRACS_OK;
+    for (size_t base = 0; base < n && rc == TRACS_OK; base += chunk * T) {
+        std::vector<std::string> out(T);
+        std::vector<uint64_t> cnt(T, 0);
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < T; t++)
+            th.emplace_back([&, t]() {
+                const size_t r0 = std::min(n, base + (size_t)t * chunk), r1 = std::min(n, r0 + chunk);
+                std::string &s = out[t];
+                s.reserve((r1 - r0) * 96);
+                char tmp[64];
+                for (size_t r = r0; r < r1; r++) {
+                    if (with_dates && k_max >= 0.0 && !(k_max >= e_k[r])) continue;
+                    s += names[rows[r]]; s.push_back(',');
+                    s += names[cols[r]]; s.push_back(',');
+                    if (with_dates) s.append(tmp, format_py_float(delta[r], tmp)); else s += "NA";
+                    s.push_back(',');
+                    s.append(tmp, format_u64(snpd[r], tmp)); s.push_back(',');
+                    if (with_dates) s.append(tmp, format_py_float(p_direct[r], tmp)); else s += "NA";
+                    s.push_back(',');
+                    if (with_dates) s.append(tmp, format_py_float(e_k[r], tmp)); else s += "NA";
+                    s.push_back(',');
+                    if (filt) s.append(tmp, format_u64(filt[r], tmp)); else s += "NA";
+                    s.push_back(',');
+                    s.append(tmp, format_u64(ncomp[r], tmp)); s.push_back(',');
+                    s.append(ref, ref_len);
+                    s.push_back('\n');
+                    cnt[t]++;
+                }
+            });
+        for (auto &x : th) x.join();
+        for (unsigned t = 0; t < T; t++) {
+            written += cnt[t];
+            if (!out[t].empty() && std::fwrite(out[t].data(), 1, out[t].size(), fo) != out[t].size()) {
+                set_error(std::string("error writing '") + path + "'");
+                rc = TRACS_E_OPEN;
+                break;
+            }
+        }
+    }
+    if (std::fclose(fo) != 0 && rc == TRACS_OK) { set_error(std::string("error closing '") + path + "'"); rc = TRACS_E_OPEN; }
+    if (rows_written) *rows_written = written;
+    return rc;
+}
+
+// test hook: str(float) of n doubles, '\n'-separated, into buf (cap bytes); returns the bytes used or -1
+long tracs_debug_format_floats(const double *x, size_t n, char *buf, size_t cap)
+{
+    size_t used = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (cap - used < 40) return -1;
+        used += format_py_float(x[i], buf + used);
+        buf[used++] = '\n';
+    }
+    return (long)used;
 }
 
 // One gzip member per sample (a multi-member gzip file is what gzopen/zcat/kseq read as one stream), compressed in

@@ -5,11 +5,15 @@ flags :15-131, dates CSV :145-151, per-MSA pairsnp :159-176, transmission block 
 CSV rows :206-258 (header :157).  The pair loop and the transcluster integral run on the MI355X.
 """
 import argparse
+import ctypes as C
 import logging
 import os
 from datetime import date
 
-from .api import pairsnp
+import numpy as np
+
+from . import _lib
+from .api import pairsnp_arrays
 from .transcluster import calculate_trans_prob
 from .utils import check_positive_float, check_positive_int
 
@@ -63,6 +67,33 @@ def _read_dates(path):
     return dates
 
 
+def _append_rows(path, names, rows, cols, snpd, filt, ncomp, ddiff, tdist, ek, kmax, ref):
+    """CSV rows in the reference's format (:206-258), formatted and written by libtracs_hip.so's host code; floats print as
+    Python's str(float).  ddiff is None without metadata; filt is None for the "NA" column."""
+    L = _lib.load()
+    u64p, dp = C.POINTER(C.c_uint64), C.POINTER(C.c_double)
+
+    def u64(a):
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        return a, a.ctypes.data_as(u64p)
+
+    def f64(a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        return a, a.ctypes.data_as(dp)
+
+    n = len(rows)
+    keep = [u64(rows), u64(cols), u64(snpd), u64(ncomp)]
+    kf = u64(filt) if filt is not None else (None, None)
+    with_dates = ddiff is not None
+    fl = [f64(ddiff), f64(tdist), f64(ek)] if with_dates else [(None, None)] * 3
+    cnames = (C.c_char_p * len(names))(*[x.encode() for x in names])
+    written = C.c_uint64(0)
+    _lib.check(L.tracs_write_distance_rows(os.fsencode(path), cnames, keep[0][1], keep[1][1], keep[2][1], kf[1], keep[3][1],
+                                           fl[0][1], fl[1][1], fl[2][1], n, int(with_dates),
+                                           -1.0 if kmax is None else float(kmax), ref.encode(), C.byref(written)))
+    return written.value
+
+
 def distance(args):
     logging.basicConfig(level=args.loglevel, format="%(asctime)s - %(levelname)s - %(message)s",
                         datefmt="%Y-%m-%d %H:%M:%S")
@@ -71,33 +102,26 @@ def distance(args):
     logging.info("Estimating transmission distances...")
     with open(args.output_file, "w") as out:
         out.write(HEADER)
-        for msa in args.msa_files:
-            logging.info("Calculating pairwise snp distances for %s", msa)
-            msas = [msa, args.msa_db] if args.msa_db is not None else [msa]
-            rows, cols, snpd, names, filt, ncomp = pairsnp(fasta=msas, n_threads=args.n_cpu, dist=args.snp_threshold,
-                                                           filter=args.recomb_filter)
-            with_dates = dates is not None and len(rows) > 0
-            if with_dates:
-                logging.info("Inferring transmission probabilities for %s", msa)
-                # with --filter the transmission model is driven by the FILTERED distance (:183-193)
-                drive = filt if args.recomb_filter else snpd
-                tdist, ek, ddiff = calculate_trans_prob([rows, cols, drive], sample_dates=dates, K=100,
-                                                        lamb=args.clock_rate, beta=args.trans_rate, samplenames=names,
-                                                        log=False, precision=args.precision)
-                if not args.recomb_filter:
-                    filt = ["NA"] * len(snpd)                                   # (:204)
-            logging.info("Saving distances for %s", msa)
-            ref = os.path.basename(msa).split(".")[0].replace("_combined", "")  # (:208-209)
-            if with_dates:
-                kmax = args.trans_threshold
-                for t in range(len(rows)):
-                    if kmax is None or kmax >= ek[t]:
-                        out.write(",".join([names[rows[t]], names[cols[t]], str(ddiff[t]), str(int(snpd[t])),
-                                            str(tdist[t]), str(ek[t]), str(filt[t]), str(ncomp[t]), ref]) + "\n")
-            else:
-                for t in range(len(rows)):
-                    out.write(",".join([names[rows[t]], names[cols[t]], "NA", str(int(snpd[t])), "NA", "NA",
-                                        str(filt[t]), str(ncomp[t]), ref]) + "\n")
+    for msa in args.msa_files:
+        logging.info("Calculating pairwise snp distances for %s", msa)
+        msas = [msa, args.msa_db] if args.msa_db is not None else [msa]
+        rows, cols, snpd, names, filt, ncomp = pairsnp_arrays(fasta=msas, n_threads=args.n_cpu, dist=args.snp_threshold,
+                                                              filter=args.recomb_filter)
+        with_dates = dates is not None and len(rows) > 0
+        tdist = ek = ddiff = None
+        if with_dates:
+            logging.info("Inferring transmission probabilities for %s", msa)
+            # with --filter the transmission model is driven by the FILTERED distance (:183-193)
+            drive = filt if args.recomb_filter else snpd
+            tdist, ek, ddiff = calculate_trans_prob([rows, cols, drive], sample_dates=dates, K=100,
+                                                    lamb=args.clock_rate, beta=args.trans_rate, samplenames=names,
+                                                    log=False, precision=args.precision)
+            if not args.recomb_filter:
+                filt = None                                                     # a column of "NA" (:204)
+        logging.info("Saving distances for %s", msa)
+        ref = os.path.basename(msa).split(".")[0].replace("_combined", "")      # (:208-209)
+        _append_rows(args.output_file, names, rows, cols, snpd, filt, ncomp, ddiff, tdist, ek,
+                     args.trans_threshold if with_dates else None, ref)
 
 
 def main():
