@@ -237,6 +237,21 @@ int tracs_write_distance_rows(const char *path, const char *const *names, const 
                               const double *p_direct, const double *e_k, size_t n, int with_dates, double k_max,
                               const char *ref, uint64_t *rows_written);
 
+/* `tracs cluster` input (tracs/cluster.py:100-116): distance CSV -> node names in first-appearance order (sampleA before
+ * sampleB; ids continue after the n_seed names given, like the reference's function-level table) and the edges whose
+ * field `column` (3 snp, 6 filter, 4 direct, 5 expectedK, :90-97) is <= threshold.  The header line is skipped; a field
+ * that float() would refuse is an error carrying Python's message.                                                    */
+typedef struct tracs_edge_list tracs_edge_list;
+int tracs_read_distance_edges(const char *path, int column, double threshold, const char *const *seed_names,
+                              size_t n_seed, tracs_edge_list **out);
+size_t tracs_edges_count(const tracs_edge_list *e);
+uint64_t tracs_edges_rows(const tracs_edge_list *e);          /* data lines read */
+size_t tracs_edges_n_names(const tracs_edge_list *e);
+const char *tracs_edges_name(const tracs_edge_list *e, size_t i);
+const int32_t *tracs_edges_i(const tracs_edge_list *e);
+const int32_t *tracs_edges_j(const tracs_edge_list *e);
+void tracs_edges_free(tracs_edge_list *e);
+
 /* write_alignment of tracs/combine.py:220-239: one single-record FASTA per sample -> "<ref>_combined.fasta.gz" with
  * records ">sample\nSEQUENCE\n" in input order.  Samples are compressed in parallel as separate gzip members
  * (n_threads <= 0: all cores; gzip_level < 0: 6).  frac_n[s] = count('N')/len, lengths[s] = len (the ncov dict);

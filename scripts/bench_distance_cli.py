@@ -35,4 +35,12 @@ for label, extra in (("all_pairs", []), ("snp_threshold_20", ["-D", "20"])):
     assert rc.returncode == 0, rc.stderr
     rows = sum(1 for _ in open(csv)) - 1
     out[label] = {"s": dt, "rows": rows, "csv_MB": os.path.getsize(csv) / 1e6, "pairs_per_s_end_to_end": out["pairs"] / dt}
+for label, argv in (("cluster_snp_10", ["-c", "10", "-D", "snp"]), ("cluster_expectedK_5", ["-c", "5", "-D", "expectedK"])):
+    t0 = time.perf_counter()
+    rc = subprocess.run([sys.executable, "-m", "tracs_amd", "cluster", "-d", os.path.join(tmp, "all_pairs.csv"), "-o",
+                         os.path.join(tmp, label + ".csv"), "--loglevel", "ERROR"] + argv, cwd=root, capture_output=True, text=True)
+    dt = time.perf_counter() - t0
+    assert rc.returncode == 0, rc.stderr
+    labs = [int(x.split(",")[1]) for x in open(os.path.join(tmp, label + ".csv")).read().split("\n")[1:] if x]
+    out[label] = {"s": dt, "csv_rows_per_s": out["all_pairs"]["rows"] / dt, "clusters": max(labs) + 1, "samples": len(labs)}
 print(json.dumps(out))

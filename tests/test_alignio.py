@@ -270,3 +270,55 @@ def test_distance_rows_writer_is_python_str_exact(hiplib, tmp_path):
         want = expect(with_dates, fc, kmax)
         assert open(path).read() == "HEADER\n" + want
         assert w == want.count("\n")
+
+
+def test_distance_edge_reader_equals_python_scan(hiplib, tmp_path):
+    """tracs_read_distance_edges vs the reference's own loop (tracs/cluster.py:100-116) on a multi-megabyte CSV that is
+    parsed in many chunks: ids by first appearance in FILE order, every column, nan/inf/padded values, error cases."""
+    from tracs_amd import cluster as cl
+    rng = np.random.default_rng(31)
+    ns, n = 900, 120000
+    names = ["iso_%d" % i for i in rng.permutation(ns)]
+    lines = ["sampleA,sampleB,date difference,SNP distance,transmission distance,expected K,filtered SNP distance,sites considered,MSA file"]
+    for t in range(n):
+        a, b = rng.integers(0, ns, 2)
+        ek = rng.choice(["nan", "inf", " 3.5 ", "1e-05", str(float(np.exp(rng.uniform(-5, 8))))])
+        lines.append("%s,%s,%s,%d,%s,%s,%d,%d,ref" % (names[a], names[b], str(rng.random()), rng.integers(0, 200), str(float(rng.random())),
+                                                     ek, rng.integers(0, 200), rng.integers(0, 10**6)))
+    path = str(tmp_path / "dist.csv")
+    open(path, "w").write("\n".join(lines) + ("\n" if n % 2 else ""))
+    assert os.path.getsize(path) > 8 << 20
+
+    def python_scan(col, thr, ids):
+        I, J, count = [], [], 0
+        for line in lines[1:]:
+            f = line.strip().split(",")
+            for nm in (f[0], f[1]):
+                if nm not in ids:
+                    ids[nm] = len(ids)
+            if float(f[col]) <= thr:
+                I.append(ids[f[0]])
+                J.append(ids[f[1]])
+            count += 1
+        return count, I, J
+
+    for col, thr in ((3, 20.0), (5, 4.0), (4, 0.5), (6, 1e9)):
+        cl._ids.clear()
+        cl._ids["seeded_before"] = 0                                 # ids persist across calls in one process
+        want_ids = {"seeded_before": 0}
+        wc, wi, wj = python_scan(col, thr, want_ids)
+        gc, gi, gj = cl.read_edges(path, col, thr)
+        assert gc == wc and gi.tolist() == wi and gj.tolist() == wj
+        assert list(cl._ids.items()) == list(want_ids.items())
+    cl._ids.clear()
+    for bad, exc in (("h\na,b,1,NA,0.1,2,3,4,r\n", ValueError), ("h\na,b,1\n", IndexError), ("h\na,b,1,2,3,4,5,6,r\n\n", IndexError),
+                     ("", StopIteration)):
+        p2 = str(tmp_path / "bad.csv")
+        open(p2, "w").write(bad)
+        with pytest.raises(exc):
+            cl.read_edges(p2, 3, 1.0)
+        cl._ids.clear()
+    open(p2, "w").write("header only\n")
+    assert cl.read_edges(p2, 3, 1.0)[0] == 0
+    with pytest.raises(FileNotFoundError):
+        cl.read_edges(str(tmp_path / "nope.csv"), 3, 1.0)

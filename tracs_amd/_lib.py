@@ -28,6 +28,8 @@ SYMBOLS = [
     "tracs_consensus_codes_device",
     "tracs_connected_components_device",
     "tracs_pileup_counts", "tracs_write_posterior_csv", "tracs_combine_fasta", "tracs_write_distance_rows",
+    "tracs_read_distance_edges", "tracs_edges_count", "tracs_edges_rows", "tracs_edges_n_names", "tracs_edges_name", "tracs_edges_i",
+    "tracs_edges_j", "tracs_edges_free",
 ]
 
 
@@ -153,6 +155,22 @@ def load():
     L.tracs_write_distance_rows.argtypes = [C.c_char_p, cpp, u64p, u64p, u64p, u64p, u64p, dp, dp, dp, sz, C.c_int, dbl, C.c_char_p, u64p]
     L.tracs_debug_format_floats.restype = C.c_long
     L.tracs_debug_format_floats.argtypes = [dp, sz, C.c_char_p, sz]
+    L.tracs_read_distance_edges.restype = C.c_int
+    L.tracs_read_distance_edges.argtypes = [C.c_char_p, C.c_int, dbl, cpp, sz, C.POINTER(vp)]
+    L.tracs_edges_count.restype = sz
+    L.tracs_edges_count.argtypes = [vp]
+    L.tracs_edges_rows.restype = C.c_uint64
+    L.tracs_edges_rows.argtypes = [vp]
+    L.tracs_edges_n_names.restype = sz
+    L.tracs_edges_n_names.argtypes = [vp]
+    L.tracs_edges_name.restype = C.c_char_p
+    L.tracs_edges_name.argtypes = [vp, sz]
+    L.tracs_edges_i.restype = C.POINTER(i32)
+    L.tracs_edges_i.argtypes = [vp]
+    L.tracs_edges_j.restype = C.POINTER(i32)
+    L.tracs_edges_j.argtypes = [vp]
+    L.tracs_edges_free.restype = None
+    L.tracs_edges_free.argtypes = [vp]
     L.tracs_combine_fasta.restype = C.c_int
     L.tracs_combine_fasta.argtypes = [C.c_char_p, cpp, cpp, sz, C.c_int, C.c_int, dp, u64p]
     L.tracs_debug_read_fasta.restype = C.c_int

@@ -6,11 +6,13 @@ first-appearance order with sampleA before sampleB (:11-21,108-109), edges kept 
 `sample,cluster` in node-id order (:134-137).
 """
 import argparse
+import ctypes as C
 import logging
 import os
 
 import numpy as np
 
+from . import _lib
 from .api import connected_components
 
 COLUMN = {"snp": 3, "filter": 6, "direct": 4, "expectedK": 5}
@@ -46,33 +48,50 @@ def cluster_parser(parser):
     return parser
 
 
+def read_edges(distance_file, col, threshold):
+    """The reference's CSV scan (:100-116) in libtracs_hip.so's host code: parallel parse, ids merged in file order.
+    -> (number of data lines, I, J); new names are appended to the persistent id table."""
+    L = _lib.load()
+    seed = list(_ids.keys())
+    arr = (C.c_char_p * len(seed))(*[x.encode() for x in seed])
+    h = C.c_void_p()
+    rc = L.tracs_read_distance_edges(os.fsencode(distance_file), int(col), float(threshold), arr, len(seed), C.byref(h))
+    if rc:
+        msg = L.tracs_last_error().decode("utf-8", "replace")
+        if msg.startswith("could not convert string to float"):
+            raise ValueError(msg)
+        if msg == "list index out of range":
+            raise IndexError(msg)
+        if msg == "StopIteration":
+            raise StopIteration
+        if msg.startswith("cannot open"):
+            raise FileNotFoundError(distance_file)
+        _lib.check(rc)
+    try:
+        for i in range(len(seed), L.tracs_edges_n_names(h)):
+            index_count(L.tracs_edges_name(h, i).decode("utf-8", "replace"))
+        ne = L.tracs_edges_count(h)
+        I = np.ctypeslib.as_array(L.tracs_edges_i(h), shape=(ne,)).copy() if ne else np.zeros(0, np.int32)
+        J = np.ctypeslib.as_array(L.tracs_edges_j(h), shape=(ne,)).copy() if ne else np.zeros(0, np.int32)
+        return int(L.tracs_edges_rows(h)), I, J
+    finally:
+        L.tracs_edges_free(h)
+
+
 def cluster(args):
     logging.basicConfig(level=args.loglevel, format="%(asctime)s - %(levelname)s - %(message)s",
                         datefmt="%Y-%m-%d %H:%M:%S")
-    col = COLUMN[args.distance]
-    I, J = [], []
-    count = 0
-    with open(args.distance_file, "r") as fh:
-        next(fh)
-        for line in fh:
-            f = line.strip().split(",")
-            a = index_count(f[0])
-            b = index_count(f[1])
-            if float(f[col]) <= args.threshold:
-                I.append(a)
-                J.append(b)
-            count += 1
+    count, I, J = read_edges(args.distance_file, COLUMN[args.distance], args.threshold)
     if count <= 0:
         logging.warning("No distances available! Abandoning clustering.")
         return
     names = list(_ids.keys())
     logging.info("Clustering %d samples...", len(names))
-    n_components, labels = connected_components(len(names), np.asarray(I, np.int32), np.asarray(J, np.int32))
+    n_components, labels = connected_components(len(names), I, J)
     logging.info("%d putative transmission clusters found!", n_components)
     with open(args.output_file, "w") as out:
         out.write("sample,cluster\n")
-        for i, lab in enumerate(labels):
-            out.write(names[i] + "," + str(int(lab)) + "\n")
+        out.write("".join("%s,%d\n" % (names[i], int(lab)) for i, lab in enumerate(labels)))
 
 
 def main():

@@ -5,14 +5,21 @@
 // Own implementation; the behaviour (field positions, what is skipped, what overwrites what) follows the lines cited.
 #include <zlib.h>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <atomic>
 #include <charconv>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
+#include <string_view>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -349,6 +356,170 @@ long tracs_debug_format_floats(const double *x, size_t n, char *buf, size_t cap)
     }
     return (long)used;
 }
+
+// ---- `tracs cluster` input: the distance CSV -> node ids + thresholded edges (tracs/cluster.py:100-116) -------------------
+struct tracs_edge_list {
+    std::vector<std::string> names;       // node id -> name, ids in first-appearance order (sampleA before sampleB)
+    std::vector<int32_t> I, J;            // edges with value <= threshold
+    uint64_t n_rows = 0;                  // data lines read (the reference's `count`)
+};
+
+// Header line skipped; every other line: strip, split at ',', node ids for fields 0 and 1 (new names get the next id;
+// ids continue after the n_seed names passed in, which is how the reference's function-level table behaves across calls,
+// tracs/cluster.py:11-21), edge iff float(field[column]) <= threshold.  A field that is not a float is an error with
+// Python's message; chunks are parsed in parallel and merged in file order, so ids equal the serial scan's.
+int tracs_read_distance_edges(const char *path, int column, double threshold, const char *const *seed_names, size_t n_seed,
+                              tracs_edge_list **out)
+{
+    if (out) *out = nullptr;
+    if (!path || !out || column < 2 || (n_seed && !seed_names)) { set_error("tracs_read_distance_edges: bad argument"); return TRACS_E_ARG; }
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) { set_error(std::string("cannot open '") + path + "'"); return TRACS_E_OPEN; }
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); set_error(std::string("cannot stat '") + path + "'"); return TRACS_E_OPEN; }
+    const size_t size = (size_t)st.st_size;
+    auto res = std::make_unique<tracs_edge_list>();
+    for (size_t i = 0; i < n_seed; i++) res->names.emplace_back(seed_names[i]);
+    if (size == 0) { close(fd); set_error("StopIteration"); return TRACS_E_FASTA; }        // next(infile) on an empty file raises
+    void *m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) { set_error(std::string("cannot map '") + path + "'"); return TRACS_E_OPEN; }
+    const char *p = static_cast<const char *>(m);
+    const char *hdr = static_cast<const char *>(std::memchr(p, '\n', size));
+    const size_t body0 = hdr ? (size_t)(hdr - p) + 1 : size;
+
+    struct Chunk {
+        std::vector<std::string_view> local;                       // distinct names, first-appearance order within the chunk
+        std::unordered_map<std::string_view, int32_t> idx;
+        std::vector<int32_t> a, b;                                 // per kept row: local ids
+        uint64_t rows = 0;
+        std::string error;
+        uint64_t error_row = 0;
+    };
+    const unsigned T = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    const size_t nchunks = std::max<size_t>(1, std::min<size_t>(T * 4, (size - body0) / (1u << 20) + 1));
+    std::vector<size_t> cut(nchunks + 1, size);
+    cut[0] = body0;
+    for (size_t c = 1; c < nchunks; c++) {                        // chunk boundaries at line starts
+        size_t pos = body0 + (size - body0) * c / nchunks;
+        if (pos < cut[c - 1]) pos = cut[c - 1];
+        const char *nl = pos < size ? static_cast<const char *>(std::memchr(p + pos, '\n', size - pos)) : nullptr;
+        cut[c] = nl ? (size_t)(nl - p) + 1 : size;
+    }
+    std::vector<Chunk> chunks(nchunks);
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const size_t c = next.fetch_add(1);
+            if (c >= nchunks) return;
+            Chunk &ch = chunks[c];
+            auto local_id = [&](std::string_view nm) {
+                auto it = ch.idx.find(nm);
+                if (it != ch.idx.end()) return it->second;
+                const int32_t id = (int32_t)ch.local.size();
+                ch.local.push_back(nm);
+                ch.idx.emplace(nm, id);
+                return id;
+            };
+            size_t pos = cut[c];
+            const size_t end = cut[c + 1];
+            while (pos < end) {
+                const char *nl = static_cast<const char *>(std::memchr(p + pos, '\n', end - pos));
+                size_t e = nl ? (size_t)(nl - p) : end;
+                const size_t nextpos = nl ? e + 1 : end;
+                size_t b = pos;
+                while (b < e && is_space((unsigned char)p[b])) b++;          // line.strip()
+                while (e > b && is_space((unsigned char)p[e - 1])) e--;
+                ch.rows++;
+                // fields 0, 1 and `column`
+                size_t f0 = b, fe = b;
+                int field = 0;
+                std::string_view n0, n1, val;
+                bool have = false;
+                for (size_t k = b; k <= e; k++) {
+                    if (k == e || p[k] == ',') {
+                        fe = k;
+                        if (field == 0) n0 = std::string_view(p + f0, fe - f0);
+                        else if (field == 1) n1 = std::string_view(p + f0, fe - f0);
+                        if (field == column) { val = std::string_view(p + f0, fe - f0); have = true; }
+                        field++;
+                        f0 = k + 1;
+                        if (have && field > 1) break;
+                    }
+                }
+                if (!have || field < 2) {
+                    if (ch.error.empty()) { ch.error = "list index out of range"; ch.error_row = ch.rows; }
+                    pos = nextpos;
+                    continue;
+                }
+                const int32_t ia = local_id(n0), ib = local_id(n1);
+                // float(): optional surrounding whitespace, the whole token must convert
+                size_t v0 = 0, v1 = val.size();
+                while (v0 < v1 && is_space((unsigned char)val[v0])) v0++;
+                while (v1 > v0 && is_space((unsigned char)val[v1 - 1])) v1--;
+                char tmp[64];
+                double x = 0.0;
+                bool ok = v1 > v0 && v1 - v0 < sizeof tmp;
+                if (ok) {
+                    std::memcpy(tmp, val.data() + v0, v1 - v0);
+                    tmp[v1 - v0] = 0;
+                    char *endp = nullptr;
+                    x = std::strtod(tmp, &endp);
+                    ok = endp == tmp + (v1 - v0) && !(tmp[0] == '0' && (tmp[1] == 'x' || tmp[1] == 'X'));
+                }
+                if (!ok) {
+                    if (ch.error.empty()) { ch.error = "could not convert string to float: '" + std::string(val) + "'"; ch.error_row = ch.rows; }
+                    pos = nextpos;
+                    continue;
+                }
+                if (x <= threshold) { ch.a.push_back(ia); ch.b.push_back(ib); }
+                pos = nextpos;
+            }
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < std::min<size_t>(T, nchunks); t++) th.emplace_back(work);
+        for (auto &x : th) x.join();
+    }
+    // merge in file order: global ids by first appearance
+    std::unordered_map<std::string, int32_t> gid;
+    for (size_t i = 0; i < res->names.size(); i++) gid.emplace(res->names[i], (int32_t)i);
+    int rc = TRACS_OK;
+    uint64_t rows_before = 0;
+    for (size_t c = 0; c < nchunks && rc == TRACS_OK; c++) {
+        Chunk &ch = chunks[c];
+        if (!ch.error.empty()) {                                    // the serial scan would have stopped at this row
+            set_error(ch.error);
+            rc = TRACS_E_FASTA;
+            break;
+        }
+        std::vector<int32_t> map(ch.local.size());
+        for (size_t k = 0; k < ch.local.size(); k++) {
+            std::string nm(ch.local[k]);
+            auto it = gid.find(nm);
+            if (it == gid.end()) {
+                it = gid.emplace(nm, (int32_t)res->names.size()).first;
+                res->names.push_back(std::move(nm));
+            }
+            map[k] = it->second;
+        }
+        for (size_t k = 0; k < ch.a.size(); k++) { res->I.push_back(map[ch.a[k]]); res->J.push_back(map[ch.b[k]]); }
+        rows_before += ch.rows;
+    }
+    res->n_rows = rows_before;
+    munmap(m, size);
+    if (rc != TRACS_OK) return rc;
+    *out = res.release();
+    return TRACS_OK;
+}
+size_t tracs_edges_count(const tracs_edge_list *e) { return e ? e->I.size() : 0; }
+uint64_t tracs_edges_rows(const tracs_edge_list *e) { return e ? e->n_rows : 0; }
+size_t tracs_edges_n_names(const tracs_edge_list *e) { return e ? e->names.size() : 0; }
+const char *tracs_edges_name(const tracs_edge_list *e, size_t i) { return e && i < e->names.size() ? e->names[i].c_str() : ""; }
+const int32_t *tracs_edges_i(const tracs_edge_list *e) { return e ? e->I.data() : nullptr; }
+const int32_t *tracs_edges_j(const tracs_edge_list *e) { return e ? e->J.data() : nullptr; }
+void tracs_edges_free(tracs_edge_list *e) { delete e; }
 
 // One gzip member per sample (a multi-member gzip file is what gzopen/zcat/kseq read as one stream), compressed in
 // parallel and written in input order:  ">" sample "\n" sequence "\n"  (tracs/combine.py:227-231).
