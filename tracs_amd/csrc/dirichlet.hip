@@ -8,7 +8,7 @@
 //   until sum|delta| < tol, clamping at 1e-16 (:55-68), or the leave-one-out update until max|delta| < tol (:42-54);
 //   result sorted descending (:70).
 // The per-iteration sums over the polymorphic sites are block reductions (deterministic two-stage); the 4-element
-// update runs in a one-thread kernel so the whole fit stays on the device; the host only polls the "converged" flag.
+// update runs in a one-wave kernel so the whole fit stays on the device; the host only polls the "converged" flag.
 #include "common.h"
 
 namespace tracs {
@@ -95,15 +95,18 @@ __global__ __launch_bounds__(256) void dm_sums_kernel(const double *__restrict__
         for (int k = 0; k <= DK; k++) partial[(size_t)blockIdx.x * (DK + 1) + k] = sh[0][k];
 }
 
-__global__ void dm_update_kernel(const double *__restrict__ partial, int nblocks, const unsigned *__restrict__ n_kept, int K,
+__global__ __launch_bounds__(64) void dm_update_kernel(const double *__restrict__ partial, int nblocks, const unsigned *__restrict__ n_kept, int K,
                                  int mode, double tol, DmState *__restrict__ st)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // one wave: lane l adds the partials of blocks l, l + 64, ... then a fixed xor tree -- same order every run
     if (mode != 0 && st->done) return;
     double s[DK + 1];
     for (int k = 0; k <= DK; k++) s[k] = 0.0;
-    for (int b = 0; b < nblocks; b++)
+    for (int b = (int)threadIdx.x; b < nblocks; b += 64)
         for (int k = 0; k <= DK; k++) s[k] += partial[(size_t)b * (DK + 1) + k];
+    for (int k = 0; k <= DK; k++)
+        for (int off = 32; off > 0; off >>= 1) s[k] += __shfl_xor(s[k], off, 64);
+    if (threadIdx.x != 0) return;
     const unsigned M = *n_kept;
     if (mode == 0) {                                                  // alpha0 = mean + 0.5 (:40)
         for (int k = 0; k < K; k++) st->alpha[k] = s[k] / (double)M + 0.5;
@@ -168,16 +171,16 @@ int tracs_find_dirichlet_priors_device(const double *counts, size_t L, size_t K,
     }
     const int nblocks = (int)std::min<unsigned>((M + 255) / 256, DM_BLOCKS);
     hipLaunchKernelGGL(dm_sums_kernel, dim3(nblocks), dim3(256), 0, stream, rows, n_kept, (int)K, 0, st, partial);
-    hipLaunchKernelGGL(dm_update_kernel, dim3(1), dim3(1), 0, stream, partial, nblocks, n_kept, (int)K, 0, tol, st);
+    hipLaunchKernelGGL(dm_update_kernel, dim3(1), dim3(64), 0, stream, partial, nblocks, n_kept, (int)K, 0, tol, st);
     const int mode = method == 1 ? 2 : 1;
     DmState h;
     h.done = 0;
     int it = 0;
     while (it < max_iter) {
-        const int burst = std::min(8, max_iter - it);                  // launches after convergence are no-ops
+        const int burst = std::min(32, max_iter - it);                 // launches after convergence are no-ops
         for (int b = 0; b < burst; b++) {
             hipLaunchKernelGGL(dm_sums_kernel, dim3(nblocks), dim3(256), 0, stream, rows, n_kept, (int)K, mode, st, partial);
-            hipLaunchKernelGGL(dm_update_kernel, dim3(1), dim3(1), 0, stream, partial, nblocks, n_kept, (int)K, mode, tol, st);
+            hipLaunchKernelGGL(dm_update_kernel, dim3(1), dim3(64), 0, stream, partial, nblocks, n_kept, (int)K, mode, tol, st);
         }
         it += burst;
         TRACS_HIP_CHECK(hipMemcpyAsync(&h, st, sizeof(DmState), hipMemcpyDeviceToHost, stream));
