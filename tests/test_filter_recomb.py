@@ -77,8 +77,15 @@ def _write(seqs):
     return p
 
 
+@pytest.fixture(params=["wave_per_pair", "pair_per_lane"])
+def extract_kernel(request, monkeypatch):
+    """Both extraction kernels: the library picks by the number of emitted pairs (TRACS_FILTER_LANES_MIN overrides)."""
+    monkeypatch.setenv("TRACS_FILTER_LANES_MIN", "0" if request.param == "pair_per_lane" else "1000000000000")
+    return request.param
+
+
 @pytest.mark.gpu
-def test_gpu_filter_matches_oracle(oracle, hiplib, tmp_path):
+def test_gpu_filter_matches_oracle(oracle, hiplib, tmp_path, extract_kernel):
     import torch  # noqa: F401
     from tracs_amd import api, synth
     L = 120000
@@ -103,7 +110,7 @@ def test_gpu_filter_matches_oracle(oracle, hiplib, tmp_path):
 
 
 @pytest.mark.gpu
-def test_gpu_filter_positions_are_the_snp_sites(oracle, hiplib):
+def test_gpu_filter_positions_are_the_snp_sites(oracle, hiplib, extract_kernel):
     import torch
     from tracs_amd import device as dev
     from tracs_amd import synth

@@ -14,6 +14,8 @@
 // PARITY UNPINNED: Boost's ibetac is replaced by the exact finite sum.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace tracs {
 
 __global__ __launch_bounds__(64) void filter_extract_kernel(const uint4 *__restrict__ P, size_t n_pad, unsigned L,
@@ -63,6 +65,54 @@ __global__ __launch_bounds__(64) void filter_extract_kernel(const uint4 *__restr
         }
         if (lane == 0) found[t] = total;
     }
+}
+
+// Large emitted sets: one PAIR per lane, every lane walks the whole alignment.  The COO list is row-major, so the 64 pairs of
+// a wave mostly share their row (one broadcast 16 B load per plane) and have consecutive columns (64 x 16 B contiguous): full
+// sectors instead of the per-pair kernel's isolated 16 B segments.  Positions come out in site order per pair by construction.
+__global__ __launch_bounds__(256) void filter_extract_lanes_kernel(const uint4 *__restrict__ P, size_t n_pad, unsigned L,
+                                                                  unsigned groups, const unsigned *__restrict__ rows,
+                                                                  const unsigned *__restrict__ cols, size_t n_pairs,
+                                                                  const long long *__restrict__ pos_off,
+                                                                  unsigned *__restrict__ positions, unsigned *__restrict__ found)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool act = t < n_pairs;
+    const size_t si = act ? rows[t] : 0, sj = act ? cols[t] : 0;
+    long long o = act ? pos_off[t] : 0;
+    const long long start = o, cap = act ? pos_off[t + 1] : 0;
+    auto emit = [&](unsigned snp, unsigned w) {
+        while (snp) {
+            const int b = __ffs(snp) - 1;
+            snp &= snp - 1;
+            if (o < cap) positions[o] = w * 32 + b;
+            o++;
+        }
+    };
+#pragma unroll 2
+    for (unsigned g = 0; g < groups; g++) {
+        const uint4 *base = P + (size_t)g * NPLANES * n_pad;
+        const uint4 a0 = base[si], a1 = base[n_pad + si], a2 = base[2 * n_pad + si], a3 = base[3 * n_pad + si];
+        const uint4 b0 = base[sj], b1 = base[n_pad + sj], b2 = base[2 * n_pad + sj], b3 = base[3 * n_pad + sj];
+        uint4 snp;                                                            // res.flip(), src/pairsnp.hpp:254
+        snp.x = ~((a0.x & b0.x) | (a1.x & b1.x) | (a2.x & b2.x) | (a3.x & b3.x));
+        snp.y = ~((a0.y & b0.y) | (a1.y & b1.y) | (a2.y & b2.y) | (a3.y & b3.y));
+        snp.z = ~((a0.z & b0.z) | (a1.z & b1.z) | (a2.z & b2.z) | (a3.z & b3.z));
+        snp.w = ~((a0.w & b0.w) | (a1.w & b1.w) | (a2.w & b2.w) | (a3.w & b3.w));
+        if (g + 1 == groups) {                                                // only the L real bits are flipped
+            unsigned *sw = &snp.x;
+            for (int c = 0; c < 4; c++) {
+                const unsigned long long first = ((unsigned long long)g * 4 + c) * 32;
+                if (first >= L) sw[c] = 0;
+                else if (L - first < 32) sw[c] &= (1u << (unsigned)(L - first)) - 1u;
+            }
+        }
+        if (!act) continue;
+        if (snp.x | snp.y | snp.z | snp.w) {
+            emit(snp.x, g * 4 + 0); emit(snp.y, g * 4 + 1); emit(snp.z, g * 4 + 2); emit(snp.w, g * 4 + 3);
+        }
+    }
+    if (act) found[t] = (unsigned)(o - start);
 }
 
 __device__ __forceinline__ long long lower_bound_u32(const unsigned *a, long long n, long long key)
@@ -157,8 +207,16 @@ int tracs_filter_recomb_device(const tracs_alignment *a, const uint32_t *rows, c
     int rc = get_lgamma_table_for_filter(stream, &lg);
     if (rc) return rc;
     const unsigned blocks = (unsigned)std::min<size_t>(n_pairs, 256 * 64);
-    hipLaunchKernelGGL(filter_extract_kernel, dim3(blocks), dim3(64), 0, stream, a->planes, a->n_pad, (unsigned)a->L, rows, cols,
-                       n_pairs, reinterpret_cast<const long long *>(pos_off), positions, found);
+    // a pair per lane needs enough pairs to fill the chip (every lane walks all groups); below that, a wave per pair
+    size_t lanes_min = 16384;
+    if (const char *e = std::getenv("TRACS_FILTER_LANES_MIN")) lanes_min = (size_t)std::strtoull(e, nullptr, 10);
+    if (n_pairs >= lanes_min)
+        hipLaunchKernelGGL(filter_extract_lanes_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, stream, a->planes,
+                           a->n_pad, (unsigned)a->L, (unsigned)a->groups, rows, cols, n_pairs,
+                           reinterpret_cast<const long long *>(pos_off), positions, found);
+    else
+        hipLaunchKernelGGL(filter_extract_kernel, dim3(blocks), dim3(64), 0, stream, a->planes, a->n_pad, (unsigned)a->L, rows, cols,
+                           n_pairs, reinterpret_cast<const long long *>(pos_off), positions, found);
     hipLaunchKernelGGL(filter_test_kernel, dim3(blocks), dim3(64), 0, stream, positions, reinterpret_cast<const long long *>(pos_off),
                        n_pairs, (unsigned)a->L, lg, filt);
     TRACS_HIP_CHECK(hipGetLastError());
