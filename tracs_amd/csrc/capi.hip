@@ -80,8 +80,10 @@ int tracs_debug_read_fasta(const char *path, size_t *n, size_t *L, uint64_t *has
     if (rc) { set_error(err); return rc; }
     uint64_t h = 1469598103934665603ull;
     auto mix = [&](const uint8_t *b, size_t k) { for (size_t i = 0; i < k; i++) { h ^= b[i]; h *= 1099511628211ull; } };
-    for (auto &nm : fd.names) { mix(reinterpret_cast<const uint8_t *>(nm.data()), nm.size()); const uint8_t z = 0; mix(&z, 1); }
-    mix(fd.seq.data(), fd.seq.size());
+    if (hash) {
+        for (auto &nm : fd.names) { mix(reinterpret_cast<const uint8_t *>(nm.data()), nm.size()); const uint8_t z = 0; mix(&z, 1); }
+        mix(fd.seq.data(), fd.seq.size());
+    }
     if (n) *n = fd.n;
     if (L) *L = fd.L;
     if (hash) *hash = h;

@@ -78,7 +78,7 @@ static bool read_fasta_parallel(const std::string &path, FastaData &out)
     const unsigned char *p = static_cast<const unsigned char *>(m);
     bool ok = p[0] == '>' && !(p[0] == 0x1f && p[1] == 0x8b);
     std::vector<size_t> starts;
-    const unsigned T = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    const unsigned T = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
     if (ok) {
         // record starts: '>' at offset 0 or right after a newline
         std::vector<std::vector<size_t>> part(T);
@@ -100,7 +100,7 @@ static bool read_fasta_parallel(const std::string &path, FastaData &out)
     size_t L = 0;
     const size_t nrec = starts.size();
     std::vector<std::string> names(nrec);
-    std::vector<uint8_t> seq;
+    ByteVec seq;
     if (ok) {
         // length of the first record fixes L
         auto body_of = [&](size_t r, size_t &b0, size_t &b1) {
@@ -190,7 +190,7 @@ static bool read_fasta_members(const std::string &path, FastaData &out)
         return (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
     };
     std::vector<std::string> names(nrec);
-    std::vector<uint8_t> seq;
+    ByteVec seq;
     std::atomic<bool> bad{false};
     std::atomic<size_t> next{0};
     size_t L = 0;
