@@ -457,6 +457,155 @@ __global__ __launch_bounds__(NW * 64, MINW) void pairsnp_tile_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
+// Matrix-core form of the CONSENSUS pair loop (default for plain passes; TRACS_MFMA=0 disables): the pair loop is integer-VALU-bound
+// (DESIGN.md 3.1), and it is a Gram matrix.  With every base as three signs  x = (-1)^X, y = (-1)^Y, z = x*y  (all three 0
+// where the site is not a base) two samples contribute  x x' + y y' + z z' = +3  at a site where they agree and  -1  where
+// they differ, so over a site range   S = 4*matches - nn,   nn = sum v v',   d = nn - matches = (3 nn - S) / 4.
+// S and nn are accumulated by v_mfma_scale_f32_32x32x64_f8f6f4 on fp4 (E2M1) operands: +1.0 = 0x2, -1.0 = 0xA, 0 = 0x0,
+// scale 2^0.  Products and partial sums are integers below 2^24 (the host limits a workgroup's range to 2^22 sites), so
+// the fp32 accumulators are exact and the result is bit-identical to the VALU kernel's.
+// Operands are expanded in registers from the 3 bit planes, never stored: the K index of the MFMA is ours to choose as
+// long as both operands agree, so dword q of a 32-site chunk takes the sites whose bit index is = q (mod 4) and the
+// expansion is "mask, shift, or" -- 32 VALU ops per (sample, 32 sites) for all four operand planes (x, y, z, v).
+// One workgroup = 4 waves = a 128 x 128 tile (each wave 64 x 64 = 2 x 2 MFMA blocks, two accumulator sets); the bit planes
+// of the tile's 256 samples are staged HBM -> LDS directly like in the VALU kernel.
+typedef int mfma_v8i __attribute__((ext_vector_type(8)));
+typedef float mfma_v16f __attribute__((ext_vector_type(16)));
+
+struct Fp4Planes { unsigned x[4], y[4], z[4], v[4]; };
+
+__device__ __forceinline__ void expand_fp4(unsigned X, unsigned Y, unsigned V, Fp4Planes &o)
+{
+    const unsigned tx = X & V, ty = Y & V, tz = (X ^ Y) & V;
+    o.v[0] = (V & 0x11111111u) << 1;
+    o.v[1] = V & 0x22222222u;
+    o.v[2] = (V & 0x44444444u) >> 1;
+    o.v[3] = (V & 0x88888888u) >> 2;
+#define TRACS_SIGN_PLANE(T, O)                              \
+    O[0] = ((T & 0x11111111u) << 3) | o.v[0];               \
+    O[1] = ((T & 0x22222222u) << 2) | o.v[1];               \
+    O[2] = ((T & 0x44444444u) << 1) | o.v[2];               \
+    O[3] = (T & 0x88888888u) | o.v[3];
+    TRACS_SIGN_PLANE(tx, o.x) TRACS_SIGN_PLANE(ty, o.y) TRACS_SIGN_PLANE(tz, o.z)
+#undef TRACS_SIGN_PLANE
+}
+
+__device__ __forceinline__ mfma_v8i fp4_operand(const unsigned (&w)[4])
+{
+    mfma_v8i r = {(int)w[0], (int)w[1], (int)w[2], (int)w[3], 0, 0, 0, 0};
+    return r;
+}
+
+template <int GC, bool WITH_NN>
+__global__ __launch_bounds__(256, 2) void pairsnp_mfma_kernel(
+    const uint4 *__restrict__ P, size_t n_pad, int groups, const int2 *__restrict__ tiles, int n_tiles,
+    int groups_per_split, int ksplit, unsigned n, unsigned row_end, unsigned col_begin,
+    unsigned *__restrict__ dist, unsigned *__restrict__ ncomp, size_t ld, int scale)
+{
+    constexpr int NP = 3, TJ = 128, TS = 256, NT = 256;
+    constexpr int STAGE = GC * NP * TS;
+    constexpr int LPT = STAGE / NT;
+    __shared__ uint4 lds[2][STAGE];
+
+    const unsigned q = xcd_remap(blockIdx.x, gridDim.x);
+    const int ks = (int)(q / (unsigned)n_tiles);
+    const int2 tile = tiles[q - (unsigned)ks * (unsigned)n_tiles];
+    const int i0 = tile.x, j0 = tile.y;
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int g_begin = ks * groups_per_split;
+    const int g_end = min(groups, g_begin + groups_per_split);
+    if (g_begin >= g_end) return;
+
+    auto stage_glds = [&](int gs, int b) {
+#pragma unroll
+        for (int k = 0; k < LPT; k++) {
+            const int e0 = (wave + k * 4) * 64;
+            const int gp = e0 / TS;
+            const int sidx = e0 - gp * TS + lane;
+            if (gs + gp / NP < g_end) {
+                const size_t smp = sidx < TJ ? (size_t)j0 + sidx : (size_t)i0 + (sidx - TJ);
+                __builtin_amdgcn_global_load_lds((glb_void_t *)(P + ((size_t)gs * NP + gp) * n_pad + smp), (lds_void_t *)&lds[b][e0], 16, 0, 0);
+            }
+        }
+    };
+    // this lane's four samples inside a staged (group, plane) row: row blocks 0,1 then column blocks 0,1
+    int slot[4];
+    slot[0] = TJ + wr * 64 + l32;
+    slot[1] = TJ + wr * 64 + 32 + l32;
+    slot[2] = wc * 64 + l32;
+    slot[3] = wc * 64 + 32 + l32;
+
+    mfma_v16f accS[2][2], accV[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) { accS[a][b][r] = 0.0f; accV[a][b][r] = 0.0f; }
+
+    stage_glds(g_begin, 0);
+    __syncthreads();
+    int buf = 0;
+    for (int gs = g_begin; gs < g_end; gs += GC) {
+        const bool more = gs + GC < g_end;
+        if (more) stage_glds(gs + GC, buf ^ 1);
+#pragma unroll
+        for (int gl = 0; gl < GC; gl++) {
+            if (gs + gl < g_end) {
+#pragma unroll
+                for (int st = 0; st < 2; st++) {                 // two 64-site steps per 128-site group
+                    Fp4Planes op[4];
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        const unsigned *wx = reinterpret_cast<const unsigned *>(&lds[buf][(gl * NP + 0) * TS + slot[b]]);
+                        const unsigned *wy = reinterpret_cast<const unsigned *>(&lds[buf][(gl * NP + 1) * TS + slot[b]]);
+                        const unsigned *wv = reinterpret_cast<const unsigned *>(&lds[buf][(gl * NP + 2) * TS + slot[b]]);
+                        expand_fp4(wx[2 * st + h], wy[2 * st + h], wv[2 * st + h], op[b]);
+                    }
+#pragma unroll
+                    for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+                        for (int cb = 0; cb < 2; cb++) {
+                            accS[rb][cb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp4_operand(op[rb].x), fp4_operand(op[2 + cb].x), accS[rb][cb], 4, 4, 0, scale, 0, scale);
+                            accS[rb][cb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp4_operand(op[rb].y), fp4_operand(op[2 + cb].y), accS[rb][cb], 4, 4, 0, scale, 0, scale);
+                            accS[rb][cb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp4_operand(op[rb].z), fp4_operand(op[2 + cb].z), accS[rb][cb], 4, 4, 0, scale, 0, scale);
+                            accV[rb][cb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp4_operand(op[rb].v), fp4_operand(op[2 + cb].v), accV[rb][cb], 4, 4, 0, scale, 0, scale);
+                        }
+                }
+            }
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // C/D layout of the 32x32 MFMA: register r of lane l holds column l & 31, row (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
+#pragma unroll
+    for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+        for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const unsigned i = (unsigned)(i0 + wr * 64 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
+                const unsigned j = (unsigned)(j0 + wc * 64 + cb * 32 + l32);
+                if (i < row_end && j < n && j > i && j >= col_begin) {
+                    const int nn = (int)accV[rb][cb][r];
+                    const int S = (int)accS[rb][cb][r];
+                    const unsigned d = (unsigned)((3 * nn - S) >> 2);
+                    const size_t o = (size_t)i * ld + j;
+                    if (ksplit == 1) {
+                        dist[o] = d;
+                        if (WITH_NN) ncomp[o] = (unsigned)nn;
+                    } else {
+                        atomicAdd(&dist[o], d);
+                        if (WITH_NN) atomicAdd(&ncomp[o], (unsigned)nn);
+                    }
+                }
+            }
+}
+
+// ---------------------------------------------------------------------------------------
 // "rowcast" kernel: no LDS, no barriers.
 //   * all NW waves of a workgroup work on the SAME R rows: the row words are wave-uniform AND shared by
 //     the whole workgroup, so the scalar loads of waves 1..NW-1 hit the scalar cache (the 64 x 128 tile
@@ -1013,8 +1162,11 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
         a->dirty = false;
     }
     const TileVariant &V = current_variant(a->enc == 1);
-    const int kTI = V.ti, kTJ = V.tj, kGC = V.gc;
     const bool cons = a->enc == 1 && V.launch_cons;
+    // matrix-core kernel: consensus encoding, plain (unthresholded) passes; TRACS_MFMA=0 keeps the VALU tile kernel
+    static const bool mfma_off = [] { const char *e = std::getenv("TRACS_MFMA"); return e && e[0] == '0'; }();
+    const bool mfma = cons && thr == 0xFFFFFFFFu && !mfma_off && !std::getenv("TRACS_TILE_VARIANT");
+    const int kTI = mfma ? 128 : V.ti, kTJ = mfma ? 128 : V.tj, kGC = mfma ? 2 : V.gc;
     if (a->key_rb != row_begin || a->key_re != row_end || a->key_cb != col_begin || a->key_ti != kTI || a->key_tj != kTJ) {
         std::vector<int2> tiles;
         build_tiles(a->n, row_begin, row_end, col_begin, kTI, kTJ, tiles);
@@ -1096,6 +1248,29 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
             const int k2 = stage_split(groups - prefix, std::max(1, std::min({32, want, (groups - prefix) / (16 * kGC)})), gps2);
             launch(live_tiles, (unsigned)(n_live * (size_t)k2), (int)n_live, groups, gps2, k2, thr, TilePhase{2, prefix, nullptr});
         }
+        TRACS_HIP_CHECK(hipGetLastError());
+        return TRACS_OK;
+    }
+
+    if (mfma) {
+        // fp32 accumulators are exact while a workgroup's range stays below 2^22 sites (|S| <= 3 * 2^22 < 2^24)
+        const int max_gps = (1 << 22) / SITES_PER_GROUP;
+        int k = std::max(ksplit, (groups + max_gps - 1) / max_gps);
+        if (const char *e = std::getenv("TRACS_KSPLIT")) { const int v = std::atoi(e); if (v >= k) k = v; }
+        int gps_m = 0;
+        k = stage_split(groups, k, gps_m);
+        if (k > 1) {
+            dim3 grid(64, (unsigned)(row_end - row_begin));
+            hipLaunchKernelGGL(init_cells_kernel, grid, dim3(256), 0, stream, dist, ncomp, ld, (unsigned)a->n, (unsigned)row_begin,
+                               (unsigned)row_end, (unsigned)col_begin, 0u);
+        }
+        const unsigned nwg = (unsigned)(a->n_tiles * (size_t)k);
+        if (ncomp)
+            hipLaunchKernelGGL((pairsnp_mfma_kernel<2, true>), dim3(nwg), dim3(256), 0, stream, a->cplanes, a->n_pad, groups, a->d_tiles,
+                               (int)a->n_tiles, gps_m, k, (unsigned)a->n, (unsigned)row_end, (unsigned)col_begin, dist, ncomp, ld, 127);
+        else
+            hipLaunchKernelGGL((pairsnp_mfma_kernel<2, false>), dim3(nwg), dim3(256), 0, stream, a->cplanes, a->n_pad, groups, a->d_tiles,
+                               (int)a->n_tiles, gps_m, k, (unsigned)a->n, (unsigned)row_end, (unsigned)col_begin, dist, ncomp, ld, 127);
         TRACS_HIP_CHECK(hipGetLastError());
         return TRACS_OK;
     }
