@@ -347,7 +347,8 @@ def test_thresholded_dense_early_out(dev, oracle, torch_mod):
             assert np.array_equal(nn.cpu().numpy()[ri[keep], ci[keep]], enn[keep].astype(np.int32))
             far = dh[ri[~keep], ci[~keep]]
             assert (far.astype(np.int64) > thr).all()                      # exact, 0xFFFFFFFF or bit 31 set: never <= thr
-            assert (far >= 0x80000000).mean() > (0.5 if L > 100000 else 0.2)   # most far tiles did stop early
+            if L > 100000:                                                 # two-pass run: most far tiles died in the prefix pass
+                assert (far >= 0x80000000).mean() > 0.5                    # (short alignments take one plain pass: all exact)
             rows, cols, dd, nc = dev.coo_from_dense(d, nn, n, dist_threshold=thr)
             xr, xc, xd, xn = oracle.pairsnp_arrays(seqs, dist=thr, n_threads=16)
             assert np.array_equal(rows.cpu().numpy(), xr.astype(np.int32)) and np.array_equal(dd.cpu().numpy(), xd.astype(np.int32))

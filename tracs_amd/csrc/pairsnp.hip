@@ -474,6 +474,9 @@ typedef float mfma_v16f __attribute__((ext_vector_type(16)));
 
 struct Fp4Planes { unsigned x[4], y[4], z[4], v[4]; };
 
+// dword q of a chunk holds the sites with bit index = q (mod 4): nibble = (sign & valid) << 3 | valid << 1.
+// (A v_bitop3_b32 form with the masks in VGPRs -- every op in the fast issue class -- measured 3 % SLOWER: the kernel is
+// paced by the matrix pipe, not by VALU issue.)
 __device__ __forceinline__ void expand_fp4(unsigned X, unsigned Y, unsigned V, Fp4Planes &o)
 {
     const unsigned tx = X & V, ty = Y & V, tz = (X ^ Y) & V;
@@ -496,15 +499,16 @@ __device__ __forceinline__ mfma_v8i fp4_operand(const unsigned (&w)[4])
     return r;
 }
 
-template <int GC, bool WITH_NN>
-__global__ __launch_bounds__(256, 2) void pairsnp_mfma_kernel(
+template <int GC, bool WITH_NN, int ABL = 0, int NWR = 2, int NWC = 2>
+__global__ __launch_bounds__(NWR * NWC * 64, 2) void pairsnp_mfma_kernel(
     const uint4 *__restrict__ P, size_t n_pad, int groups, const int2 *__restrict__ tiles, int n_tiles,
     int groups_per_split, int ksplit, unsigned n, unsigned row_end, unsigned col_begin,
-    unsigned *__restrict__ dist, unsigned *__restrict__ ncomp, size_t ld, int scale)
+    unsigned *__restrict__ dist, unsigned *__restrict__ ncomp, size_t ld, int scale, unsigned thr, TilePhase ph)
 {
-    constexpr int NP = 3, TJ = 128, TS = 256, NT = 256;
+    constexpr int NP = 3, NW = NWR * NWC, TI = NWR * 64, TJ = NWC * 64, TS = TI + TJ, NT = NW * 64;
     constexpr int STAGE = GC * NP * TS;
-    constexpr int LPT = STAGE / NT;
+    constexpr int LPT = (STAGE + NT - 1) / NT;
+    static_assert(TS % 64 == 0, "a wave's 64 staging lanes must stay inside one (group, plane) row");
     __shared__ uint4 lds[2][STAGE];
 
     const unsigned q = xcd_remap(blockIdx.x, gridDim.x);
@@ -513,21 +517,23 @@ __global__ __launch_bounds__(256, 2) void pairsnp_mfma_kernel(
     const int i0 = tile.x, j0 = tile.y;
     const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
-    const int g_begin = ks * groups_per_split;
+    const int wr = wave / NWC, wc = wave % NWC;
+    const int g_begin = ph.g_base + ks * groups_per_split;
     const int g_end = min(groups, g_begin + groups_per_split);
     if (g_begin >= g_end) return;
 
     auto stage_glds = [&](int gs, int b) {
 #pragma unroll
         for (int k = 0; k < LPT; k++) {
-            const int e0 = (wave + k * 4) * 64;
+            const int e0 = (wave + k * NW) * 64;
+            if (STAGE % NT != 0 && e0 >= STAGE) continue;       // wave-uniform
             const int gp = e0 / TS;
             const int sidx = e0 - gp * TS + lane;
-            if (gs + gp / NP < g_end) {
-                const size_t smp = sidx < TJ ? (size_t)j0 + sidx : (size_t)i0 + (sidx - TJ);
-                __builtin_amdgcn_global_load_lds((glb_void_t *)(P + ((size_t)gs * NP + gp) * n_pad + smp), (lds_void_t *)&lds[b][e0], 16, 0, 0);
-            }
+            // groups past this workgroup's range are read from the zeroed tail behind the last plane (never packed into):
+            // zero words expand to zero operands, so the compute loop needs no range branch
+            const size_t smp = sidx < TJ ? (size_t)j0 + sidx : (size_t)i0 + (sidx - TJ);
+            const uint4 *src = gs + gp / NP < g_end ? P + ((size_t)gs * NP + gp) * n_pad + smp : P + (size_t)groups * NP * n_pad + sidx;
+            __builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)&lds[b][e0], 16, 0, 0);
         }
     };
     // this lane's four samples inside a staged (group, plane) row: row blocks 0,1 then column blocks 0,1
@@ -553,7 +559,7 @@ __global__ __launch_bounds__(256, 2) void pairsnp_mfma_kernel(
         if (more) stage_glds(gs + GC, buf ^ 1);
 #pragma unroll
         for (int gl = 0; gl < GC; gl++) {
-            if (gs + gl < g_end) {
+            {
 #pragma unroll
                 for (int st = 0; st < 2; st++) {                 // two 64-site steps per 128-site group
                     Fp4Planes op[4];
@@ -562,24 +568,72 @@ __global__ __launch_bounds__(256, 2) void pairsnp_mfma_kernel(
                         const unsigned *wx = reinterpret_cast<const unsigned *>(&lds[buf][(gl * NP + 0) * TS + slot[b]]);
                         const unsigned *wy = reinterpret_cast<const unsigned *>(&lds[buf][(gl * NP + 1) * TS + slot[b]]);
                         const unsigned *wv = reinterpret_cast<const unsigned *>(&lds[buf][(gl * NP + 2) * TS + slot[b]]);
+                        if (ABL == 1) {   // timing only: no expansion
+                            const unsigned a0 = wx[2 * st + h], a1 = wy[2 * st + h], a2 = wv[2 * st + h];
+                            for (int q = 0; q < 4; q++) { op[b].x[q] = a0; op[b].y[q] = a1; op[b].z[q] = a2; op[b].v[q] = a0 ^ a1; }
+                        } else
                         expand_fp4(wx[2 * st + h], wy[2 * st + h], wv[2 * st + h], op[b]);
                     }
 #pragma unroll
                     for (int rb = 0; rb < 2; rb++)
 #pragma unroll
                         for (int cb = 0; cb < 2; cb++) {
-                            accS[rb][cb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp4_operand(op[rb].x), fp4_operand(op[2 + cb].x), accS[rb][cb], 4, 4, 0, scale, 0, scale);
-                            accS[rb][cb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp4_operand(op[rb].y), fp4_operand(op[2 + cb].y), accS[rb][cb], 4, 4, 0, scale, 0, scale);
-                            accS[rb][cb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp4_operand(op[rb].z), fp4_operand(op[2 + cb].z), accS[rb][cb], 4, 4, 0, scale, 0, scale);
-                            accV[rb][cb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp4_operand(op[rb].v), fp4_operand(op[2 + cb].v), accV[rb][cb], 4, 4, 0, scale, 0, scale);
+                            if (ABL == 2) {   // timing only: no matrix instructions
+                                accS[rb][cb][0] += __int_as_float((op[rb].x[0] ^ op[2 + cb].x[1]) + (op[rb].y[2] ^ op[2 + cb].y[3]) + (op[rb].z[0] ^ op[2 + cb].z[1]) + (op[rb].v[2] ^ op[2 + cb].v[3])
+                                                                  + (op[rb].x[2] ^ op[2 + cb].x[3]) + (op[rb].y[0] ^ op[2 + cb].y[1]) + (op[rb].z[2] ^ op[2 + cb].z[3]) + (op[rb].v[0] ^ op[2 + cb].v[1]));
+                                continue;
+                            }
+#define TRACS_MFMA(ACC, PL) ACC[rb][cb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp4_operand(op[rb].PL), fp4_operand(op[2 + cb].PL), ACC[rb][cb], 4, 4, 0, scale, 0, scale);
+                            TRACS_MFMA(accS, x) TRACS_MFMA(accS, y) TRACS_MFMA(accS, z) TRACS_MFMA(accV, v)
+#undef TRACS_MFMA
                         }
                 }
             }
+        }
+        // one matrix instruction, then the eight VALU ops (and the LDS read) of a later step's expansion in its shadow
+#pragma unroll
+        for (int k = 0; k < GC * 2 * 16; k++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
         __syncthreads();
         buf ^= 1;
     }
 
+    // Thresholded two-pass runs (TilePhase, see the tile kernel): at the end of the prefix pass a tile whose every pair is
+    // already past the threshold is dead -- cells 0xFFFFFFFF, live flag 0 -- and the remainder pass never visits it.
+    const unsigned tile_no = q - (unsigned)ks * (unsigned)n_tiles;
+    bool dead = false;
+    if (ph.phase == 1) {
+        unsigned mn = 0xFFFFFFFFu;
+        if (j0 >= i0 + TI) {                                   // tiles touching the diagonal hold d(i,i) = 0 cells: always live
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+                for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const unsigned i = (unsigned)(i0 + wr * 64 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
+                        const unsigned j = (unsigned)(j0 + wc * 64 + cb * 32 + l32);
+                        const unsigned d = (unsigned)((3 * (int)accV[rb][cb][r] - (int)accS[rb][cb][r]) >> 2);
+                        mn = min(mn, (i < row_end && j < n) ? d : 0xFFFFFFFFu);
+                    }
+        } else {
+            mn = 0u;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mn = min(mn, (unsigned)__shfl_xor((int)mn, off, 64));
+        unsigned *wmin = reinterpret_cast<unsigned *>(&lds[0][0]);      // the staging buffers are idle now (last barrier passed)
+        if (lane == 0) wmin[wave] = mn;
+        __syncthreads();
+        unsigned m = wmin[0];
+#pragma unroll
+        for (int w = 1; w < NW; w++) m = min(m, wmin[w]);
+        dead = m > thr;
+        if (tid == 0) ph.live[tile_no] = dead ? 0 : 1;
+    }
+    const bool single = ksplit == 1 && ph.phase != 2;
     // C/D layout of the 32x32 MFMA: register r of lane l holds column l & 31, row (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
 #pragma unroll
     for (int rb = 0; rb < 2; rb++)
@@ -594,10 +648,13 @@ __global__ __launch_bounds__(256, 2) void pairsnp_mfma_kernel(
                     const int S = (int)accS[rb][cb][r];
                     const unsigned d = (unsigned)((3 * nn - S) >> 2);
                     const size_t o = (size_t)i * ld + j;
-                    if (ksplit == 1) {
+                    if (dead) {
+                        dist[o] = 0xFFFFFFFFu;
+                        if (WITH_NN) ncomp[o] = 0u;
+                    } else if (single) {
                         dist[o] = d;
                         if (WITH_NN) ncomp[o] = (unsigned)nn;
-                    } else {
+                    } else {                                   // cells were zeroed (split range) / hold the prefix counts
                         atomicAdd(&dist[o], d);
                         if (WITH_NN) atomicAdd(&ncomp[o], (unsigned)nn);
                     }
@@ -1163,9 +1220,9 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
     }
     const TileVariant &V = current_variant(a->enc == 1);
     const bool cons = a->enc == 1 && V.launch_cons;
-    // matrix-core kernel: consensus encoding, plain (unthresholded) passes; TRACS_MFMA=0 keeps the VALU tile kernel
+    // matrix-core kernel for the consensus encoding; TRACS_MFMA=0 (or an explicit TRACS_TILE_VARIANT) keeps the VALU tile kernel
     static const bool mfma_off = [] { const char *e = std::getenv("TRACS_MFMA"); return e && e[0] == '0'; }();
-    const bool mfma = cons && thr == 0xFFFFFFFFu && !mfma_off && !std::getenv("TRACS_TILE_VARIANT");
+    const bool mfma = cons && !mfma_off && !std::getenv("TRACS_TILE_VARIANT");
     const int kTI = mfma ? 128 : V.ti, kTJ = mfma ? 128 : V.tj, kGC = mfma ? 2 : V.gc;
     if (a->key_rb != row_begin || a->key_re != row_end || a->key_cb != col_begin || a->key_ti != kTI || a->key_tj != kTJ) {
         std::vector<int2> tiles;
@@ -1196,7 +1253,7 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
         if (!cus) { hipDeviceProp_t pr; int dv = 0; (void)hipGetDevice(&dv); cus = (hipGetDeviceProperties(&pr, dv) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }
         // resident workgroups per CU (VGPR/LDS bound) of the shapes that are defaults; 2 is right for every other general shape
         const int vid = (int)(&V - kVariants);
-        slots = (cons ? (vid == 64 ? 5.0 : vid == 56 ? 3.0 : 2.0) : 2.0) * cus;
+        slots = (mfma ? 2.0 : cons ? (vid == 64 ? 5.0 : vid == 56 ? 3.0 : 2.0) : 2.0) * cus;
         const int max_split = std::max(1, groups / (8 * kGC));
         double best = -1.0;
         for (int k = 1; k <= std::min(max_split, 64); k++) {
@@ -1214,7 +1271,21 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
         gps_out = g;
         return (range + g - 1) / g;
     };
+    // fp32 accumulators of the matrix-core kernel are exact while a workgroup's range stays below 2^22 sites (|S| <= 3 * 2^22 < 2^24)
+    const int max_gps = mfma ? (1 << 22) / SITES_PER_GROUP : groups;
     auto launch = [&](const int2 *tl, unsigned nwg, int ntl, int g_end, int gps, int k, unsigned t, TilePhase ph) {
+        if (mfma) {
+            int abl = 0;
+            if (const char *ab = std::getenv("TRACS_MFMA_ABL")) abl = std::getenv("TRACS_ALLOW_ABLATION") ? std::atoi(ab) : 0;   // timing only, WRONG RESULTS
+#define TRACS_MFMA_LAUNCH(NN, A) hipLaunchKernelGGL((pairsnp_mfma_kernel<2, NN, A>), dim3(nwg), dim3(256), 0, stream, a->cplanes, a->n_pad, g_end, tl, ntl, gps, k, \
+                                                    (unsigned)a->n, (unsigned)row_end, (unsigned)col_begin, dist, ncomp, ld, 127, t, ph)
+            if (abl == 1) TRACS_MFMA_LAUNCH(true, 1);
+            else if (abl == 2) TRACS_MFMA_LAUNCH(true, 2);
+            else if (ncomp) TRACS_MFMA_LAUNCH(true, 0);
+            else TRACS_MFMA_LAUNCH(false, 0);
+#undef TRACS_MFMA_LAUNCH
+            return;
+        }
         (cons ? V.launch_cons : V.launch)(ncomp != nullptr, nwg, stream, cons ? a->cplanes : a->planes, a->n_pad, g_end, tl,
                                           ntl, gps, k, (unsigned)a->L, (unsigned)a->n, (unsigned)row_end,
                                           (unsigned)col_begin, dist, ncomp, ld, t, ph);
@@ -1225,7 +1296,7 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
     // few surviving tiles still fill the chip.  Dead tiles cost 1/8 of a full pass or less (they also stop inside the prefix).
     static const bool no_two_pass = std::getenv("TRACS_THR_ONE_PASS") != nullptr;
     if (thr != 0xFFFFFFFFu && V.launch != nullptr && V.gc > 1 && !no_two_pass && groups >= 64 * kGC) {
-        int prefix = std::max(8 * kGC, groups / 8 / kGC * kGC);
+        int prefix = std::min(max_gps / kGC * kGC, std::max(8 * kGC, groups / 8 / kGC * kGC));
         if (const char *e = std::getenv("TRACS_THR_PREFIX")) { const int v = std::atoi(e) / kGC * kGC; if (v >= kGC && v < groups) prefix = v; }
         unsigned char *live = nullptr;
         int2 *live_tiles = nullptr;
@@ -1245,36 +1316,14 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
             // enough workgroups for ~4 rounds of the chip, never more than 32 ranges (each range costs one atomic per cell)
             int gps2 = 0;
             const int want = (int)std::ceil(4.0 * slots / (double)n_live);
-            const int k2 = stage_split(groups - prefix, std::max(1, std::min({32, want, (groups - prefix) / (16 * kGC)})), gps2);
+            const int k2 = stage_split(groups - prefix, std::max({1, std::min({32, want, (groups - prefix) / (16 * kGC)}), (groups - prefix + max_gps - 1) / max_gps}), gps2);
             launch(live_tiles, (unsigned)(n_live * (size_t)k2), (int)n_live, groups, gps2, k2, thr, TilePhase{2, prefix, nullptr});
         }
         TRACS_HIP_CHECK(hipGetLastError());
         return TRACS_OK;
     }
 
-    if (mfma) {
-        // fp32 accumulators are exact while a workgroup's range stays below 2^22 sites (|S| <= 3 * 2^22 < 2^24)
-        const int max_gps = (1 << 22) / SITES_PER_GROUP;
-        int k = std::max(ksplit, (groups + max_gps - 1) / max_gps);
-        if (const char *e = std::getenv("TRACS_KSPLIT")) { const int v = std::atoi(e); if (v >= k) k = v; }
-        int gps_m = 0;
-        k = stage_split(groups, k, gps_m);
-        if (k > 1) {
-            dim3 grid(64, (unsigned)(row_end - row_begin));
-            hipLaunchKernelGGL(init_cells_kernel, grid, dim3(256), 0, stream, dist, ncomp, ld, (unsigned)a->n, (unsigned)row_begin,
-                               (unsigned)row_end, (unsigned)col_begin, 0u);
-        }
-        const unsigned nwg = (unsigned)(a->n_tiles * (size_t)k);
-        if (ncomp)
-            hipLaunchKernelGGL((pairsnp_mfma_kernel<2, true>), dim3(nwg), dim3(256), 0, stream, a->cplanes, a->n_pad, groups, a->d_tiles,
-                               (int)a->n_tiles, gps_m, k, (unsigned)a->n, (unsigned)row_end, (unsigned)col_begin, dist, ncomp, ld, 127);
-        else
-            hipLaunchKernelGGL((pairsnp_mfma_kernel<2, false>), dim3(nwg), dim3(256), 0, stream, a->cplanes, a->n_pad, groups, a->d_tiles,
-                               (int)a->n_tiles, gps_m, k, (unsigned)a->n, (unsigned)row_end, (unsigned)col_begin, dist, ncomp, ld, 127);
-        TRACS_HIP_CHECK(hipGetLastError());
-        return TRACS_OK;
-    }
-
+    if (mfma) ksplit = std::max(ksplit, (groups + max_gps - 1) / max_gps);
     int gps = 0;
     ksplit = stage_split(groups, ksplit, gps);
     if (ksplit > 1) {
