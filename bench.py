@@ -27,6 +27,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12            # B/s, MI355X HBM3E spec (MI355X_MICROARCH.md "Chip-level parameters")
 VALU_PEAK = 256 * 4 * 32 * 2.4e9   # 32-bit lane-ops/s: 256 CU x 4 SIMD32 x 2.4 GHz (nominal FP32-vector issue rate)
+MFMA_FP4_PEAK = 10.0e15      # flop/s, dense fp4 MFMA (MI355X_MICROARCH.md: "~10 PF dense")
+MFMA_FP4_MEASURED = 7.1e15   # bare v_mfma_scale_f32_32x32x64_f8f6f4 loop on +-1 operands (clock-limited; profiles/r01/mfma_fp4_rate.txt)
 # Per encoding: VALU ops per 32 sites and pair, algorithmic bytes per pair as a fraction of L, and the
 # rate a register-only loop of exactly that instruction mix sustains on MI355X (scripts/micro/valu_ops.hip,
 # profiles/r01/valu_ops_microbench.txt) -- the practical issue ceiling of the kernel.
@@ -151,16 +153,28 @@ def main():
         E = ENCODINGS[enc]
         alg_bytes = float(my_pairs_per_launch) * L * E["bytes_per_site"]   # L (general) / 0.75 L (consensus) per pair
         lane_ops = float(my_pairs_per_launch) * ((L + 127) // 128) * 4 * E["ops"]
-        roof = {"bound": "hbm", "achieved": alg_bytes / kern_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": alg_bytes / kern_s / HBM_PEAK, "traffic": _traffic_from_profiles(n, L, world),
-                "kernel": "pairsnp_tile_kernel", "kernel_ms": kern_s * 1e3, "encoding": enc,
-                "algorithmic_bytes_per_pair": L * E["bytes_per_site"],
-                "note": "algorithmic bytes are re-used from LDS/L2 tiles, so achieved > HBM peak is expected; "
-                        "the binding limit is integer VALU (see valu)",
-                "valu": {"achieved": lane_ops / kern_s / 1e12, "peak": VALU_PEAK / 1e12, "unit": "Tlane-op/s",
-                         "frac": lane_ops / kern_s / VALU_PEAK, "ops_per_32_sites_per_pair": E["ops"],
-                         "measured_mix_ceiling": E["mix_ceiling"] / 1e12,
-                         "frac_of_measured_mix_ceiling": lane_ops / kern_s / E["mix_ceiling"]}}
+        hbm = {"achieved": alg_bytes / kern_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg_bytes / kern_s / HBM_PEAK,
+               "algorithmic_bytes_per_pair": L * E["bytes_per_site"]}
+        traffic = _traffic_from_profiles(n, L, world, aln.kernel)
+        if aln.kernel == "mfma":
+            # matrix-core kernel: every site is four fp4 operand values (x, y, z, v) per sample -> 4 MACs = 8 flop per pair and site
+            flop = float(my_pairs_per_launch) * L * 8.0
+            roof = {"bound": "mfma", "achieved": flop / kern_s / 1e12, "peak": MFMA_FP4_PEAK / 1e12, "unit": "TFLOP/s",
+                    "frac": flop / kern_s / MFMA_FP4_PEAK, "traffic": traffic, "kernel": "pairsnp_mfma_kernel",
+                    "kernel_ms": kern_s * 1e3, "encoding": enc, "algorithmic_flop_per_pair": L * 8.0,
+                    "measured_fp4_ceiling": MFMA_FP4_MEASURED / 1e12,
+                    "frac_of_measured_fp4_ceiling": flop / kern_s / MFMA_FP4_MEASURED,
+                    "note": "v_mfma_scale_f32_32x32x64_f8f6f4 on fp4 operands; peak = dense fp4 (MI355X_MICROARCH.md); the measured "
+                            "ceiling is the bare instruction rate with this kernel's +-1 operand data (scripts/micro/mfma_fp4_rate.hip)",
+                    "hbm": hbm}
+        else:
+            roof = dict(hbm, bound="hbm", traffic=traffic, kernel="pairsnp_tile_kernel", kernel_ms=kern_s * 1e3, encoding=enc,
+                        note="algorithmic bytes are re-used from LDS/L2 tiles, so achieved > HBM peak is expected; "
+                             "the binding limit is integer VALU (see valu)",
+                        valu={"achieved": lane_ops / kern_s / 1e12, "peak": VALU_PEAK / 1e12, "unit": "Tlane-op/s",
+                              "frac": lane_ops / kern_s / VALU_PEAK, "ops_per_32_sites_per_pair": E["ops"],
+                              "measured_mix_ceiling": E["mix_ceiling"] / 1e12,
+                              "frac_of_measured_mix_ceiling": lane_ops / kern_s / E["mix_ceiling"]})
         out = {"metric": "sample-pairs/sec for 10kx5Mbp SNP+transcluster distance", "value": value,
                "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -180,14 +194,16 @@ def main():
         dist.destroy_process_group()
 
 
-def _traffic_from_profiles(n, L, world):
-    """HBM bytes per launch from the committed PMC summary (profiles/pmc_*.json), if one matches."""
+def _traffic_from_profiles(n, L, world, kernel):
+    """HBM bytes per launch of the kernel that ran, from the committed PMC summary (profiles/pmc_summary.json), if one matches."""
     p = os.path.join(ROOT, "profiles", "pmc_summary.json")
     try:
         with open(p) as fh:
             d = json.load(fh)
-        key = "%dx%d@%d" % (n, L, world)
-        return d.get(key, {}).get("hbm_bytes_per_launch")
+        e = d.get("%dx%d@%d" % (n, L, world), {})
+        if ("mfma" in e.get("kernel", "")) != (kernel == "mfma"):
+            return None
+        return e.get("hbm_bytes_per_launch")
     except Exception:
         return None
 

@@ -177,6 +177,8 @@ def load():
     L.tracs_debug_read_fasta.argtypes = [C.c_char_p, C.POINTER(sz), C.POINTER(sz), C.POINTER(C.c_uint64)]
     L.tracs_debug_alignment_encoding.restype = C.c_int
     L.tracs_debug_alignment_encoding.argtypes = [vp]
+    L.tracs_debug_alignment_kernel.restype = C.c_int
+    L.tracs_debug_alignment_kernel.argtypes = [vp]
     L.tracs_debug_tile_variant.restype = C.c_char_p
     L.tracs_debug_iupac_mask.restype = C.c_int
     L.tracs_debug_iupac_mask.argtypes = [C.c_int]

@@ -42,6 +42,7 @@ struct tracs_alignment {
     unsigned *d_flag = nullptr;  // device: "some site has a partial IUPAC code"
     bool dirty = true;           // packed since the encoding was last decided
     int enc = 0;                 // 0 general, 1 consensus
+    int last_kernel = -1;        // kernel of the last dense call: 0 VALU tile kernel, 1 matrix-core kernel
     // cached tile schedule for the last dense region (device + host mirror)
     int2 *d_tiles = nullptr;
     size_t n_tiles = 0, tiles_cap = 0;

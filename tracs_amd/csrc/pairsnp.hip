@@ -1150,6 +1150,8 @@ int tracs_alignment_pack(tracs_alignment *a, const uint8_t *ascii, size_t first,
 const char *tracs_debug_tile_variant(void) { return current_variant().name; }
 // 1 if the last dense call on this alignment used the consensus (3-plane) encoding, 0 general, -1 not decided yet
 int tracs_debug_alignment_encoding(const tracs_alignment *a) { return !a ? -1 : (a->dirty ? -1 : a->enc); }
+// kernel of the last dense call on this alignment: 0 VALU tile kernel, 1 matrix-core kernel, -1 none yet
+int tracs_debug_alignment_kernel(const tracs_alignment *a) { return !a ? -1 : a->last_kernel; }
 
 static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_t row_end, size_t col_begin, uint32_t *dist,
                               uint32_t *ncomp, size_t ld, void *stream_, unsigned thr);
@@ -1224,6 +1226,7 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
     static const bool mfma_off = [] { const char *e = std::getenv("TRACS_MFMA"); return e && e[0] == '0'; }();
     const bool mfma = cons && !mfma_off && !std::getenv("TRACS_TILE_VARIANT");
     const int kTI = mfma ? 128 : V.ti, kTJ = mfma ? 128 : V.tj, kGC = mfma ? 2 : V.gc;
+    a->last_kernel = mfma ? 1 : 0;
     if (a->key_rb != row_begin || a->key_re != row_end || a->key_cb != col_begin || a->key_ti != kTI || a->key_tj != kTJ) {
         std::vector<int2> tiles;
         build_tiles(a->n, row_begin, row_end, col_begin, kTI, kTJ, tiles);

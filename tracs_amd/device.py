@@ -69,6 +69,11 @@ class Alignment:
         return {0: "general", 1: "consensus"}.get(e)
 
     @property
+    def kernel(self):
+        """'mfma' (matrix-core kernel) / 'valu' (tile kernel) as used by the last dense call, None before the first."""
+        return {0: "valu", 1: "mfma"}.get(self._L.tracs_debug_alignment_kernel(self._h))
+
+    @property
     def nbytes(self):
         return self._L.tracs_alignment_bytes(self._h)
 
