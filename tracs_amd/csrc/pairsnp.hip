@@ -15,6 +15,8 @@
 //   * per 32 sites and pair: v_and, 3 x v_and_or, v_bcnt(+acc) for d; v_or, v_bcnt(+acc) for nn.
 #include "common.h"
 
+#include <type_traits>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -499,25 +501,36 @@ __device__ __forceinline__ mfma_v8i fp4_operand(const unsigned (&w)[4])
     return r;
 }
 
-template <int GC, bool WITH_NN, int ABL = 0, int NWR = 2, int NWC = 2>
-__global__ __launch_bounds__(NWR * NWC * 64, 2) void pairsnp_mfma_kernel(
+typedef float mfma_v4f __attribute__((ext_vector_type(4)));
+
+// MS = 32: v_mfma_scale_f32_32x32x64 (a lane's operand = sample l & 31, 32-site word 2 * step + (l >> 5); two steps per group)
+// MS = 16: v_mfma_scale_f32_16x16x128 (sample l & 15, word l >> 4; one step per 128-site group).  Same flops per clock on
+//          paper; the bare 16 x 16 instruction holds a higher clock on this kernel's data (profiles/r01/mfma_fp4_rate.txt: 8.4 vs
+//          7.5-7.9 PFLOP/s) but the whole kernel is 3.5 % slower with it (31.9 vs 30.7 ms per 400 kbp): TRACS_MFMA_SHAPE=16.
+template <int GC, bool WITH_NN, int ABL = 0, int MS = 32>
+__global__ __launch_bounds__(256, 2) void pairsnp_mfma_kernel(
     const uint4 *__restrict__ P, size_t n_pad, int groups, const int2 *__restrict__ tiles, int n_tiles,
     int groups_per_split, int ksplit, unsigned n, unsigned row_end, unsigned col_begin,
     unsigned *__restrict__ dist, unsigned *__restrict__ ncomp, size_t ld, int scale, unsigned thr, TilePhase ph)
 {
-    constexpr int NP = 3, NW = NWR * NWC, TI = NWR * 64, TJ = NWC * 64, TS = TI + TJ, NT = NW * 64;
+    constexpr int NP = 3, NW = 4, TI = 128, TJ = 128, TS = TI + TJ, NT = NW * 64;
     constexpr int STAGE = GC * NP * TS;
-    constexpr int LPT = (STAGE + NT - 1) / NT;
-    static_assert(TS % 64 == 0, "a wave's 64 staging lanes must stay inside one (group, plane) row");
+    constexpr int LPT = STAGE / NT;
+    constexpr int NB = 64 / MS;                  // MFMA blocks per side of a wave's 64 x 64 tile
+    constexpr int STEPS = MS == 32 ? 2 : 1;      // matrix steps per 128-site group
+    constexpr int AR = MS == 32 ? 16 : 4;        // accumulator registers per block
+    using AccT = typename std::conditional<MS == 32, mfma_v16f, mfma_v4f>::type;
+    static_assert(STAGE % NT == 0, "stage must divide over the workgroup");
     __shared__ uint4 lds[2][STAGE];
 
     const unsigned q = xcd_remap(blockIdx.x, gridDim.x);
     const int ks = (int)(q / (unsigned)n_tiles);
-    const int2 tile = tiles[q - (unsigned)ks * (unsigned)n_tiles];
+    const unsigned tile_no = q - (unsigned)ks * (unsigned)n_tiles;
+    const int2 tile = tiles[tile_no];
     const int i0 = tile.x, j0 = tile.y;
-    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, h = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, lb = lane & (MS - 1), hk = lane / MS;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave / NWC, wc = wave % NWC;
+    const int wr = wave >> 1, wc = wave & 1;
     const int g_begin = ph.g_base + ks * groups_per_split;
     const int g_end = min(groups, g_begin + groups_per_split);
     if (g_begin >= g_end) return;
@@ -526,7 +539,6 @@ __global__ __launch_bounds__(NWR * NWC * 64, 2) void pairsnp_mfma_kernel(
 #pragma unroll
         for (int k = 0; k < LPT; k++) {
             const int e0 = (wave + k * NW) * 64;
-            if (STAGE % NT != 0 && e0 >= STAGE) continue;       // wave-uniform
             const int gp = e0 / TS;
             const int sidx = e0 - gp * TS + lane;
             // groups past this workgroup's range are read from the zeroed tail behind the last plane (never packed into):
@@ -536,20 +548,28 @@ __global__ __launch_bounds__(NWR * NWC * 64, 2) void pairsnp_mfma_kernel(
             __builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)&lds[b][e0], 16, 0, 0);
         }
     };
-    // this lane's four samples inside a staged (group, plane) row: row blocks 0,1 then column blocks 0,1
-    int slot[4];
-    slot[0] = TJ + wr * 64 + l32;
-    slot[1] = TJ + wr * 64 + 32 + l32;
-    slot[2] = wc * 64 + l32;
-    slot[3] = wc * 64 + 32 + l32;
+    // this lane's sample inside a staged (group, plane) row, per row block / column block of the wave's tile
+    const int row_slot = TJ + wr * 64 + lb, col_slot = wc * 64 + lb;
 
-    mfma_v16f accS[2][2], accV[2][2];
+    AccT accS[NB][NB], accV[NB][NB];
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+    for (int a = 0; a < NB; a++)
 #pragma unroll
-        for (int b = 0; b < 2; b++)
+        for (int b = 0; b < NB; b++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) { accS[a][b][r] = 0.0f; accV[a][b][r] = 0.0f; }
+            for (int r = 0; r < AR; r++) { accS[a][b][r] = 0.0f; accV[a][b][r] = 0.0f; }
+
+    auto load_expand = [&](int buf, int gl, int slot, int word, Fp4Planes &o) {
+        const unsigned *wx = reinterpret_cast<const unsigned *>(&lds[buf][(gl * NP + 0) * TS + slot]);
+        const unsigned *wy = reinterpret_cast<const unsigned *>(&lds[buf][(gl * NP + 1) * TS + slot]);
+        const unsigned *wv = reinterpret_cast<const unsigned *>(&lds[buf][(gl * NP + 2) * TS + slot]);
+        if (ABL == 1) {   // timing only: no expansion
+            const unsigned a0 = wx[word], a1 = wy[word], a2 = wv[word];
+            for (int k = 0; k < 4; k++) { o.x[k] = a0; o.y[k] = a1; o.z[k] = a2; o.v[k] = a0 ^ a1; }
+        } else {
+            expand_fp4(wx[word], wy[word], wv[word], o);
+        }
+    };
 
     stage_glds(g_begin, 0);
     __syncthreads();
@@ -559,65 +579,64 @@ __global__ __launch_bounds__(NWR * NWC * 64, 2) void pairsnp_mfma_kernel(
         if (more) stage_glds(gs + GC, buf ^ 1);
 #pragma unroll
         for (int gl = 0; gl < GC; gl++) {
-            {
 #pragma unroll
-                for (int st = 0; st < 2; st++) {                 // two 64-site steps per 128-site group
-                    Fp4Planes op[4];
+            for (int st = 0; st < STEPS; st++) {
+                const int word = MS == 32 ? 2 * st + hk : hk;
+                Fp4Planes rows[NB];
 #pragma unroll
-                    for (int b = 0; b < 4; b++) {
-                        const unsigned *wx = reinterpret_cast<const unsigned *>(&lds[buf][(gl * NP + 0) * TS + slot[b]]);
-                        const unsigned *wy = reinterpret_cast<const unsigned *>(&lds[buf][(gl * NP + 1) * TS + slot[b]]);
-                        const unsigned *wv = reinterpret_cast<const unsigned *>(&lds[buf][(gl * NP + 2) * TS + slot[b]]);
-                        if (ABL == 1) {   // timing only: no expansion
-                            const unsigned a0 = wx[2 * st + h], a1 = wy[2 * st + h], a2 = wv[2 * st + h];
-                            for (int q = 0; q < 4; q++) { op[b].x[q] = a0; op[b].y[q] = a1; op[b].z[q] = a2; op[b].v[q] = a0 ^ a1; }
-                        } else
-                        expand_fp4(wx[2 * st + h], wy[2 * st + h], wv[2 * st + h], op[b]);
-                    }
+                for (int rb = 0; rb < NB; rb++) load_expand(buf, gl, row_slot + rb * MS, word, rows[rb]);
 #pragma unroll
-                    for (int rb = 0; rb < 2; rb++)
+                for (int cb = 0; cb < NB; cb++) {
+                    Fp4Planes col;
+                    load_expand(buf, gl, col_slot + cb * MS, word, col);
 #pragma unroll
-                        for (int cb = 0; cb < 2; cb++) {
-                            if (ABL == 2) {   // timing only: no matrix instructions
-                                accS[rb][cb][0] += __int_as_float((op[rb].x[0] ^ op[2 + cb].x[1]) + (op[rb].y[2] ^ op[2 + cb].y[3]) + (op[rb].z[0] ^ op[2 + cb].z[1]) + (op[rb].v[2] ^ op[2 + cb].v[3])
-                                                                  + (op[rb].x[2] ^ op[2 + cb].x[3]) + (op[rb].y[0] ^ op[2 + cb].y[1]) + (op[rb].z[2] ^ op[2 + cb].z[3]) + (op[rb].v[0] ^ op[2 + cb].v[1]));
-                                continue;
-                            }
-#define TRACS_MFMA(ACC, PL) ACC[rb][cb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp4_operand(op[rb].PL), fp4_operand(op[2 + cb].PL), ACC[rb][cb], 4, 4, 0, scale, 0, scale);
-                            TRACS_MFMA(accS, x) TRACS_MFMA(accS, y) TRACS_MFMA(accS, z) TRACS_MFMA(accV, v)
-#undef TRACS_MFMA
+                    for (int rb = 0; rb < NB; rb++) {
+                        if (ABL == 2) {   // timing only: no matrix instructions
+                            accS[rb][cb][0] += __int_as_float((rows[rb].x[0] ^ col.x[1]) + (rows[rb].y[2] ^ col.y[3]) + (rows[rb].z[0] ^ col.z[1]) + (rows[rb].v[2] ^ col.v[3])
+                                                              + (rows[rb].x[2] ^ col.x[3]) + (rows[rb].y[0] ^ col.y[1]) + (rows[rb].z[2] ^ col.z[3]) + (rows[rb].v[0] ^ col.v[1]));
+                            continue;
                         }
+#define TRACS_MFMA(ACC, PL)                                                                                                                  \
+    if constexpr (MS == 32)                                                                                                                  \
+        ACC[rb][cb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp4_operand(rows[rb].PL), fp4_operand(col.PL), ACC[rb][cb], 4, 4, 0, scale, 0, scale); \
+    else                                                                                                                                     \
+        ACC[rb][cb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fp4_operand(rows[rb].PL), fp4_operand(col.PL), ACC[rb][cb], 4, 4, 0, scale, 0, scale);
+                        TRACS_MFMA(accS, x) TRACS_MFMA(accS, y) TRACS_MFMA(accS, z) TRACS_MFMA(accV, v)
+#undef TRACS_MFMA
+                    }
                 }
             }
         }
-        // one matrix instruction, then the eight VALU ops (and the LDS read) of a later step's expansion in its shadow
+        // one matrix instruction, then the VALU ops (and the LDS read) of a later expansion in its shadow
 #pragma unroll
-        for (int k = 0; k < GC * 2 * 16; k++) {
+        for (int k = 0; k < GC * STEPS * NB * NB * 4; k++) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, MS == 32 ? 8 : 4, 0);
+            if (MS == 32 || (k & 1)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
         __syncthreads();
         buf ^= 1;
     }
 
+    // C/D layout: 32 x 32: register r of lane l = column l & 31, row (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    //             16 x 16: column l & 15, row 4 * (l >> 4) + r
+    auto cell_row = [&](int rb, int r) { return (unsigned)(i0 + wr * 64 + rb * MS + (MS == 32 ? (r & 3) + 8 * (r >> 2) + 4 * hk : 4 * hk + r)); };
+    auto cell_col = [&](int cb) { return (unsigned)(j0 + wc * 64 + cb * MS + lb); };
+
     // Thresholded two-pass runs (TilePhase, see the tile kernel): at the end of the prefix pass a tile whose every pair is
     // already past the threshold is dead -- cells 0xFFFFFFFF, live flag 0 -- and the remainder pass never visits it.
-    const unsigned tile_no = q - (unsigned)ks * (unsigned)n_tiles;
     bool dead = false;
     if (ph.phase == 1) {
         unsigned mn = 0xFFFFFFFFu;
         if (j0 >= i0 + TI) {                                   // tiles touching the diagonal hold d(i,i) = 0 cells: always live
 #pragma unroll
-            for (int rb = 0; rb < 2; rb++)
+            for (int rb = 0; rb < NB; rb++)
 #pragma unroll
-                for (int cb = 0; cb < 2; cb++)
+                for (int cb = 0; cb < NB; cb++)
 #pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const unsigned i = (unsigned)(i0 + wr * 64 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
-                        const unsigned j = (unsigned)(j0 + wc * 64 + cb * 32 + l32);
+                    for (int r = 0; r < AR; r++) {
                         const unsigned d = (unsigned)((3 * (int)accV[rb][cb][r] - (int)accS[rb][cb][r]) >> 2);
-                        mn = min(mn, (i < row_end && j < n) ? d : 0xFFFFFFFFu);
+                        mn = min(mn, (cell_row(rb, r) < row_end && cell_col(cb) < n) ? d : 0xFFFFFFFFu);
                     }
         } else {
             mn = 0u;
@@ -634,15 +653,13 @@ __global__ __launch_bounds__(NWR * NWC * 64, 2) void pairsnp_mfma_kernel(
         if (tid == 0) ph.live[tile_no] = dead ? 0 : 1;
     }
     const bool single = ksplit == 1 && ph.phase != 2;
-    // C/D layout of the 32x32 MFMA: register r of lane l holds column l & 31, row (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
 #pragma unroll
-    for (int rb = 0; rb < 2; rb++)
+    for (int rb = 0; rb < NB; rb++)
 #pragma unroll
-        for (int cb = 0; cb < 2; cb++)
+        for (int cb = 0; cb < NB; cb++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const unsigned i = (unsigned)(i0 + wr * 64 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
-                const unsigned j = (unsigned)(j0 + wc * 64 + cb * 32 + l32);
+            for (int r = 0; r < AR; r++) {
+                const unsigned i = cell_row(rb, r), j = cell_col(cb);
                 if (i < row_end && j < n && j > i && j >= col_begin) {
                     const int nn = (int)accV[rb][cb][r];
                     const int S = (int)accS[rb][cb][r];
@@ -1280,12 +1297,14 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
         if (mfma) {
             int abl = 0;
             if (const char *ab = std::getenv("TRACS_MFMA_ABL")) abl = std::getenv("TRACS_ALLOW_ABLATION") ? std::atoi(ab) : 0;   // timing only, WRONG RESULTS
-#define TRACS_MFMA_LAUNCH(NN, A) hipLaunchKernelGGL((pairsnp_mfma_kernel<2, NN, A>), dim3(nwg), dim3(256), 0, stream, a->cplanes, a->n_pad, g_end, tl, ntl, gps, k, \
-                                                    (unsigned)a->n, (unsigned)row_end, (unsigned)col_begin, dist, ncomp, ld, 127, t, ph)
-            if (abl == 1) TRACS_MFMA_LAUNCH(true, 1);
-            else if (abl == 2) TRACS_MFMA_LAUNCH(true, 2);
-            else if (ncomp) TRACS_MFMA_LAUNCH(true, 0);
-            else TRACS_MFMA_LAUNCH(false, 0);
+            static const int shape = [] { const char *e = std::getenv("TRACS_MFMA_SHAPE"); return e && std::atoi(e) == 16 ? 16 : 32; }();   // 32 measured 3.5 % faster
+#define TRACS_MFMA_LAUNCH(NN, A, MS) hipLaunchKernelGGL((pairsnp_mfma_kernel<2, NN, A, MS>), dim3(nwg), dim3(256), 0, stream, a->cplanes, a->n_pad, g_end, tl, ntl, gps, k, \
+                                                        (unsigned)a->n, (unsigned)row_end, (unsigned)col_begin, dist, ncomp, ld, 127, t, ph)
+            if (abl == 1) TRACS_MFMA_LAUNCH(true, 1, 32);
+            else if (abl == 2) TRACS_MFMA_LAUNCH(true, 2, 32);
+            else if (shape == 32) { if (ncomp) TRACS_MFMA_LAUNCH(true, 0, 32); else TRACS_MFMA_LAUNCH(false, 0, 32); }
+            else if (ncomp) TRACS_MFMA_LAUNCH(true, 0, 16);
+            else TRACS_MFMA_LAUNCH(false, 0, 16);
 #undef TRACS_MFMA_LAUNCH
             return;
         }
