@@ -118,7 +118,7 @@ def test_multirank_driver_path_on_one_gpu():
     s.close()
     env = dict(os.environ, TRACS_BENCH_BACKEND="gloo", TRACS_BENCH_VERIFY="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                          "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3",
                           "--warmup", "1", "--samples", "1501", "--sites", "100000"], capture_output=True, text=True, env=env,
                          timeout=600, cwd=root)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
