@@ -87,3 +87,33 @@ def _has_partial(seqs):
     for ch in b"MRWSYKVHDBmrwsykvhdb":
         full[ch] = False
     return bool((~ok & ~full)[seqs].any())
+
+
+def test_matrix_core_kernel_extremes(hiplib, oracle):
+    """The consensus pass accumulates S = 4 * matches - nn and nn in fp32 matrix-core accumulators.  Push both to their extremes
+    over a range longer than one exact chunk (2^22 sites, so the host must split it): samples that differ at EVERY site
+    (S = -nn = -L), that agree everywhere (S = 3 L), that share no compared site, and patterned ones."""
+    import torch
+    from tracs_amd import device as dev
+    L = (1 << 22) + 70003
+    rng = np.random.default_rng(8)
+    base = np.frombuffer(b"ACGT", np.uint8)
+    rows = [np.full(L, ord("A"), np.uint8), np.full(L, ord("C"), np.uint8), np.full(L, ord("G"), np.uint8), np.full(L, ord("T"), np.uint8),
+            np.full(L, ord("N"), np.uint8), np.full(L, ord("A"), np.uint8), base[np.arange(L) & 3].copy(), base[(np.arange(L) >> 5) & 3].copy(),
+            base[rng.integers(0, 4, L)]]
+    rows[7][::3] = ord("-")
+    rows[8][rng.random(L) < 0.3] = ord("n")
+    seqs = np.array(rows)
+    n = len(seqs)
+    aln = dev.Alignment(n, L)
+    aln.pack(seqs)
+    d = torch.zeros((n, n), dtype=torch.int32, device="cuda")
+    nn = torch.zeros((n, n), dtype=torch.int32, device="cuda")
+    dev.pairsnp_dense(aln, d, nn)
+    assert aln.encoding == "consensus" and aln.kernel == "mfma"
+    er, ec, ed, enn = oracle.pairsnp_arrays(seqs, n_threads=8)
+    ri, ci = er.astype(np.int64), ec.astype(np.int64)
+    assert np.array_equal(d.cpu().numpy()[ri, ci], ed.astype(np.int32))
+    assert np.array_equal(nn.cpu().numpy()[ri, ci], enn.astype(np.int32))
+    assert ed[(ri == 0) & (ci == 1)][0] == L and ed[(ri == 0) & (ci == 5)][0] == 0 and enn[(ri == 0) & (ci == 4)][0] == 0
+    aln.close()
