@@ -481,7 +481,7 @@ struct Fp4Planes { unsigned x[4], y[4], z[4], v[4]; };
 // paced by the matrix pipe, not by VALU issue.)
 __device__ __forceinline__ void expand_fp4(unsigned X, unsigned Y, unsigned V, Fp4Planes &o)
 {
-    const unsigned tx = X & V, ty = Y & V, tz = (X ^ Y) & V;
+    const unsigned tx = X, ty = Y, tz = X ^ Y;          // the consensus planes are stored masked: X = Y = 0 where V = 0
     o.v[0] = (V & 0x11111111u) << 1;
     o.v[1] = V & 0x22222222u;
     o.v[2] = (V & 0x44444444u) >> 1;
