@@ -1242,7 +1242,9 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
     // matrix-core kernel for the consensus encoding; TRACS_MFMA=0 (or an explicit TRACS_TILE_VARIANT) keeps the VALU tile kernel
     static const bool mfma_off = [] { const char *e = std::getenv("TRACS_MFMA"); return e && e[0] == '0'; }();
     const bool mfma = cons && !mfma_off && !std::getenv("TRACS_TILE_VARIANT");
-    const int kTI = mfma ? 128 : V.ti, kTJ = mfma ? 128 : V.tj, kGC = mfma ? 2 : V.gc;
+    // groups per LDS stage of the matrix-core kernel: 1 measured best (29.3 ms per 400 kbp; 2: 30.2, 3: 29.8)
+    static const int mfma_gc = [] { const char *e = std::getenv("TRACS_MFMA_GC"); const int v = e ? std::atoi(e) : 1; return v == 2 || v == 3 ? v : 1; }();
+    const int kTI = mfma ? 128 : V.ti, kTJ = mfma ? 128 : V.tj, kGC = mfma ? mfma_gc : V.gc;
     a->last_kernel = mfma ? 1 : 0;
     if (a->key_rb != row_begin || a->key_re != row_end || a->key_cb != col_begin || a->key_ti != kTI || a->key_tj != kTJ) {
         std::vector<int2> tiles;
@@ -1298,13 +1300,16 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
             int abl = 0;
             if (const char *ab = std::getenv("TRACS_MFMA_ABL")) abl = std::getenv("TRACS_ALLOW_ABLATION") ? std::atoi(ab) : 0;   // timing only, WRONG RESULTS
             static const int shape = [] { const char *e = std::getenv("TRACS_MFMA_SHAPE"); return e && std::atoi(e) == 16 ? 16 : 32; }();   // 32 measured 3.5 % faster
-#define TRACS_MFMA_LAUNCH(NN, A, MS) hipLaunchKernelGGL((pairsnp_mfma_kernel<2, NN, A, MS>), dim3(nwg), dim3(256), 0, stream, a->cplanes, a->n_pad, g_end, tl, ntl, gps, k, \
-                                                        (unsigned)a->n, (unsigned)row_end, (unsigned)col_begin, dist, ncomp, ld, 127, t, ph)
-            if (abl == 1) TRACS_MFMA_LAUNCH(true, 1, 32);
-            else if (abl == 2) TRACS_MFMA_LAUNCH(true, 2, 32);
-            else if (shape == 32) { if (ncomp) TRACS_MFMA_LAUNCH(true, 0, 32); else TRACS_MFMA_LAUNCH(false, 0, 32); }
-            else if (ncomp) TRACS_MFMA_LAUNCH(true, 0, 16);
-            else TRACS_MFMA_LAUNCH(false, 0, 16);
+#define TRACS_MFMA_LAUNCH(G, NN, A, MS) hipLaunchKernelGGL((pairsnp_mfma_kernel<G, NN, A, MS>), dim3(nwg), dim3(256), 0, stream, a->cplanes, a->n_pad, g_end, tl, ntl, gps, k, \
+                                                           (unsigned)a->n, (unsigned)row_end, (unsigned)col_begin, dist, ncomp, ld, 127, t, ph)
+#define TRACS_MFMA_BY_NN(G, MS) do { if (ncomp) TRACS_MFMA_LAUNCH(G, true, 0, MS); else TRACS_MFMA_LAUNCH(G, false, 0, MS); } while (0)
+            if (abl == 1) TRACS_MFMA_LAUNCH(1, true, 1, 32);
+            else if (abl == 2) TRACS_MFMA_LAUNCH(1, true, 2, 32);
+            else if (shape == 16) TRACS_MFMA_BY_NN(1, 16);
+            else if (kGC == 2) TRACS_MFMA_BY_NN(2, 32);
+            else if (kGC == 3) TRACS_MFMA_BY_NN(3, 32);
+            else TRACS_MFMA_BY_NN(1, 32);
+#undef TRACS_MFMA_BY_NN
 #undef TRACS_MFMA_LAUNCH
             return;
         }
