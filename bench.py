@@ -9,11 +9,13 @@ Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 
 one full pass: pairsnp (d and compared sites for all N(N-1)/2 pairs) + transcluster (P(direct),
 E(K) for every pair from SNP distance and sampling-date gap).  With N ranks the row panels of the
 pair matrix are dealt to the ranks (fold pairing: chunk r and chunk 2N-1-r, equal work), every rank
-holds the whole packed alignment, and the per-rank result panels are exchanged with an RCCL
-all-gather at the end of the step (strong scaling: the problem is fixed, `value` = total pairs / time).
+holds the whole packed alignment, and the per-rank result panels are exchanged with RCCL all-gathers
+that overlap the next step's pair kernel (strong scaling: the problem is fixed, `value` = total pairs / time;
+every step's panels have arrived on every rank before the clock stops).
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (pairsnp_tile_kernel) from HIP
-events on the launch stream; `cpu_baseline` is the oracle (CPU port of the reference algorithm) timed
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel from HIP events on the launch stream:
+pairsnp_mfma_kernel (consensus alignments: exact fp4 Gram products on the matrix cores, bound "mfma", with the HBM
+view in roofline.hbm) or pairsnp_tile_kernel (general IUPAC alignments: integer VALU, reported against HBM); `cpu_baseline` is the oracle (CPU port of the reference algorithm) timed
 on the host cores on a bounded sample of the same workload (rank 0, N=1 only).
 """
 import argparse
