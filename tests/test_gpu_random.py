@@ -117,3 +117,25 @@ def test_matrix_core_kernel_extremes(hiplib, oracle):
     assert np.array_equal(nn.cpu().numpy()[ri, ci], enn.astype(np.int32))
     assert ed[(ri == 0) & (ci == 1)][0] == L and ed[(ri == 0) & (ci == 5)][0] == 0 and enn[(ri == 0) & (ci == 4)][0] == 0
     aln.close()
+
+
+@pytest.mark.parametrize("partial", [False, True], ids=["consensus", "general"])
+def test_panel_that_runs_past_the_sample_padding(partial, hiplib, oracle):
+    """n equal to the sample padding (2048) and an unaligned row panel: the last tile's rows start inside the alignment and
+    end beyond the padded sample count, so its staging reads run into the next plane row (garbage for rows >= n, which must
+    stay masked) or, for the very last row, into the zeroed tail."""
+    import torch
+    from tracs_amd import device as dev
+    from tracs_amd import synth
+    n, L, r0, r1 = 2048, 700, 1957, 2048
+    seqs = synth.alignment(n, L, seed=77, mu_lineage=5e-3, mu_sample=2e-3, n_lineages=9, p_n=0.03, p_partial=0.01 if partial else 0.0)
+    aln = dev.Alignment(n, L)
+    aln.pack(seqs)
+    d = torch.full((n, n), -3, dtype=torch.int32, device="cuda")
+    nn = torch.full((n, n), -3, dtype=torch.int32, device="cuda")
+    dev.pairsnp_dense(aln, d, nn, row_begin=r0, row_end=r1)
+    er, ec, ed, enn = oracle.pairsnp_arrays(seqs[r0:], n_threads=8)
+    ri, ci = er.astype(np.int64) + r0, ec.astype(np.int64) + r0
+    assert np.array_equal(d.cpu().numpy()[ri, ci], ed.astype(np.int32)) and np.array_equal(nn.cpu().numpy()[ri, ci], enn.astype(np.int32))
+    assert int((d[:r0] != -3).sum().item()) == 0
+    aln.close()
