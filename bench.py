@@ -81,7 +81,8 @@ def main():
     # ---- setup (untimed): packed alignment resident in HBM, sampling days -------------------
     t0 = time.time()
     aln = dev.Alignment(n, L)
-    synth.pack_synthetic_device(aln, seed=seed, mu_lineage=1e-5, mu_sample=1e-6, p_n=0.01)
+    p_partial = float(os.environ.get("TRACS_BENCH_PARTIAL", "0"))
+    synth.pack_synthetic_device(aln, seed=seed, mu_lineage=1e-5, mu_sample=1e-6, p_n=0.01, p_partial=p_partial)
     _, days_np = synth.dates(n, seed=seed)
     days = torch.from_numpy(days_np).to(device)
     setup_s = time.time() - t0
@@ -174,9 +175,9 @@ def main():
         hbm = {"achieved": alg_bytes / kern_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg_bytes / kern_s / HBM_PEAK,
                "algorithmic_bytes_per_pair": L * E["bytes_per_site"]}
         traffic = _traffic_from_profiles(n, L, world, aln.kernel)
-        if aln.kernel == "mfma":
+        if aln.kernel in ("mfma", "mfma-general"):
             # matrix-core kernel: every site is four fp4 operand values (x, y, z, v) per sample -> 4 MACs = 8 flop per pair and site
-            flop = float(my_pairs_per_launch) * L * 8.0
+            flop = float(my_pairs_per_launch) * L * (8.0 if aln.kernel == "mfma" else 10.0)
             roof = {"bound": "mfma", "achieved": flop / kern_s / 1e12, "peak": MFMA_FP4_PEAK / 1e12, "unit": "TFLOP/s",
                     "frac": flop / kern_s / MFMA_FP4_PEAK, "traffic": traffic, "kernel": "pairsnp_mfma_kernel",
                     "kernel_ms": kern_s * 1e3, "encoding": enc, "algorithmic_flop_per_pair": L * 8.0,
@@ -219,7 +220,7 @@ def _traffic_from_profiles(n, L, world, kernel):
         with open(p) as fh:
             d = json.load(fh)
         e = d.get("%dx%d@%d" % (n, L, world), {})
-        if ("mfma" in e.get("kernel", "")) != (kernel == "mfma"):
+        if ("mfma" in e.get("kernel", "")) != (kernel == "mfma") or kernel == "mfma-general":
             return None
         return e.get("hbm_bytes_per_launch")
     except Exception:
@@ -238,7 +239,8 @@ def cpu_baseline(n, L, seed, days_np, args, dmat, nmat):
     cores = O.lib().orc_num_threads()
     # trans_dist costs ~ms per DISTINCT key and dominates small samples: bound the pair count first
     m = int(max(16, min(n, 96)))
-    seqs = synth.first_samples_host(n, L, seed, m, mu_lineage=1e-5, mu_sample=1e-6, p_n=0.01)
+    seqs = synth.first_samples_host(n, L, seed, m, mu_lineage=1e-5, mu_sample=1e-6, p_n=0.01,
+                                    p_partial=float(os.environ.get("TRACS_BENCH_PARTIAL", "0")))
     planes = O.pack(seqs)                                   # untimed, like the GPU side's resident planes
     t0 = time.perf_counter()
     r, c, d, nn = O.pairsnp_planes(planes, L, dist=2147483647, n_threads=cores)

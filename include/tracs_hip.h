@@ -9,6 +9,10 @@
  *       (passed as void*), for callers that keep the alignment resident in HBM (bench.py,
  *       the multi-GPU driver, `tracs distance`).  Asynchronous on the given stream.
  *
+ * Threading: entry points that run kernels are serialised per device inside the library (scratch buffers and the cached
+ * state of a tracs_alignment are shared), and scratch is stream-ordered: a call that arrives on a different stream than
+ * the previous call on that device synchronises the device first.  Use one stream per device for overlap-free pipelines.
+ *
  * Every function returns 0 on success or a negative TRACS_E_* code; tracs_last_error()
  * returns the message for the calling thread (the Python layer raises RuntimeError with it,
  * reproducing the reference's messages: src/pairsnp.hpp:86,90,96-97,342).
@@ -122,7 +126,7 @@ void tracs_free(void *p);
  *   dist[i*ld + j]  = d(i,j)  = L - popcount(match)           (pairsnp.hpp:398-403)
  *   ncomp[i*ld + j] = nn(i,j) = L - popcount(N_i | N_j)       (pairsnp.hpp:417-420)
  * Other cells are not written.  dist/ncomp are device uint32 matrices with leading dimension
- * ld >= n; ncomp may be NULL (then only d is computed: 5 VALU ops/word instead of 7).       */
+ * ld >= n; ncomp may be NULL (then only d is written).                                           */
 int tracs_pairsnp_dense(const tracs_alignment *a, size_t row_begin, size_t row_end, size_t col_begin,
                         uint32_t *dist, uint32_t *ncomp, size_t ld, void *stream);
 
@@ -200,11 +204,24 @@ int tracs_coverage_profile_device(const double *counts, size_t L, uint64_t *hist
 /* --consensus calls (tracs/align.py:482-493): mask = the first allele with the largest count; 15 (N) where the total
  * count is below min_cov.  Same packed 4-bit output as tracs_posterior_codes_device.                                   */
 int tracs_consensus_codes_device(const uint16_t *counts16, size_t L, uint32_t min_cov, uint8_t *codes, void *stream);
+/* The three entry points above for per-allele counts beyond 65535 (deep amplicon / viral data; the reference works on
+ * float64 counts of any depth, tracs/align.py:444-647): uint32 counts [L][4], each < 2^30.  The coverage histogram's last
+ * bin then collects every total >= nbins - 1; callers needing order statistics up there take them from the counts.      */
+int tracs_coverage_profile_device32(const double *counts, size_t L, uint64_t *hist, size_t nbins, uint32_t *counts32,
+                                    uint32_t *bad, void *stream);
+int tracs_posterior_codes_cov_device32(const uint32_t *counts, size_t L, const double *alphas_host, int keep,
+                                       double threshold, uint32_t min_cov, double cov_lo, double cov_hi, uint8_t *codes,
+                                       void *stream);
+int tracs_consensus_codes_device32(const uint32_t *counts32, size_t L, uint32_t min_cov, uint8_t *codes, void *stream);
 /* 4-bit masks -> IUPAC letters as tracs/align.py:285-323,616-622 ('X' for mask 0, 'N' for 15); ascii: device, L bytes. */
 int tracs_codes_to_iupac_device(const uint8_t *codes, size_t L, uint8_t *ascii, void *stream);
 /* Pack ONE sample straight from its 4-bit masks (no FASTA round trip): mask 0 ('X') is treated like every other
  * non-IUPAC letter, i.e. fully ambiguous (src/pairsnp.hpp:192-197).  codes: device, (L+1)/2 bytes.                   */
 int tracs_alignment_pack_codes(tracs_alignment *a, const uint8_t *codes, size_t sample, void *stream);
+/* The same for `count` samples [first, first+count) in one launch: sample k's masks start at codes + k * stride_bytes
+ * (stride_bytes >= (L+1)/2; a multiple of 16 lets the kernel use 16-byte loads).                                       */
+int tracs_alignment_pack_codes_batch(tracs_alignment *a, const uint8_t *codes, size_t stride_bytes, size_t first,
+                                     size_t count, void *stream);
 
 /* Connected components on device edge arrays; labels as tracs_connected_components.         */
 int tracs_connected_components_device(const int32_t *I, const int32_t *J, size_t n_edges, size_t n_nodes,

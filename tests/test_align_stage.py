@@ -73,7 +73,7 @@ def _counts_for(case, L=40011):
     c[dup] = np.floor(c[dup] / 2.5)
     for i in case.get("poly", ()):
         c[i] = [5, 3, 0, 0]
-    return c
+    return c * case.get("scale", 1)
 
 
 _CASES = [
@@ -85,6 +85,10 @@ _CASES = [
     dict(seed=6, depth=30, p_zero=0.8, opts=dict()),                               # < 25 % of the genome covered: skipped
     dict(seed=7, depth=30, p_zero=0.8, opts=dict(consensus=True)),                 # > 75 % N: skipped
     dict(seed=8, depth=8, flat=True, poly=(5, 600, 7000), opts=dict(min_cov=2)),   # <= 5 polymorphic sites: alphas (0,0,0,1)
+    # depth beyond uint16 (deep amplicon / viral data; the reference works on float64 counts of any depth): uint32 kernels
+    dict(seed=9, depth=120, p_dup=0.05, scale=700, opts=dict()),                   # per-allele counts ~84 000, totals inside the histogram
+    dict(seed=10, depth=120, p_dup=0.05, scale=3000, opts=dict()),                 # totals ~360 000: beyond the histogram, sorted order statistics
+    dict(seed=11, depth=25, scale=4000, opts=dict(consensus=True, min_cov=7)),
 ]
 
 
@@ -125,7 +129,7 @@ def test_call_sequence_refuses_counts_it_cannot_narrow(hiplib):
     from tracs_amd import align_post
     from tracs_amd._lib import TracsError
     c = np.full((100, 4), 3.0)
-    for bad in (70000.0, 2.5, -1.0, np.nan):
+    for bad in (2.0 ** 30, 2.5, -1.0, np.nan):
         x = c.copy()
         x[17, 2] = bad
         with pytest.raises(TracsError):

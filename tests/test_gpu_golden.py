@@ -36,19 +36,42 @@ def _load(golden_dir, name):
 
 
 def test_trans_dist_golden(api, oracle, golden_dir):
+    """p0 and E(K) against the goldens produced by oracle/_ref (the reference's transcluster.hpp compiled with setup.py's flags).
+    E(K) by stopping-rule class (tests/ek_parity.py): 'well' 1e-6 vs the reference; 'ill' (the reference's stop is decided by
+    rounding noise; two builds of the reference itself disagree there) bounded at 5 % vs the reference and bracketed by the
+    series vs the oracle; 'saturated' (k = 10000: the reference reads past its 10 000-entry lgamma table, src/transcluster.hpp
+    :140 with :253-258, so its value depends on heap contents) vs the oracle only.  The per-class deviations are written to
+    gpurun_out/ek_golden_classes.json (committed as profiles/r02/ek_golden_classes.json)."""
     from ek_parity import check_ek
     g = _load(golden_dir, "transcluster_golden.json")
-    counts = {}
+    counts, dev = {}, {"well": [], "ill": [], "saturated": []}
+    ref_inf = 0
     for grid in g["trans_dist"]:
         N, delta = np.array(grid["N"], np.int32), np.array(grid["delta"])
         p0, ek = api.trans_dist_arrays(N, delta, grid["lamb"], grid["beta"], grid["thr"])
         assert np.allclose(p0, grid["p0"], rtol=1e-6, atol=0)                  # vs the reference build (log-likelihood)
         assert np.max(np.abs(p0 - grid["p0"]) / np.abs(grid["p0"])) < 1e-9
         for i, cls in enumerate(grid["conditioning"]):
-            if cls == "well":                                                   # vs the reference build
-                assert abs(ek[i] - grid["eK"][i]) <= 1e-6 * abs(grid["eK"][i])
+            ref = grid["eK"][i]
+            if not np.isfinite(ref):                                            # the reference's exp() overflowed; ours stays finite
+                assert cls == "ill" and np.isfinite(ek[i])
+                ref_inf += 1
+            else:
+                rel = abs(ek[i] - ref) / max(abs(ref), 1e-300)
+                dev[cls].append(rel)
+                if cls == "well":
+                    assert rel <= 1e-6, (N[i], delta[i], ek[i], ref)
+                elif cls == "ill":
+                    assert rel <= 0.05, (N[i], delta[i], ek[i], ref)
             check_ek(oracle, N[i], delta[i], grid["lamb"], grid["beta"], grid["thr"], ek[i], counts)   # vs the oracle
-    assert counts["well"] > 250
+    assert counts["well"] > 250 and counts.get("ill", 0) >= 10
+    summary = {c: {"keys": len(v), "max_rel_vs_ref": float(np.max(v)) if v else None,
+                   "n_above_1e-6": int(np.sum(np.array(v) > 1e-6))} for c, v in dev.items()}
+    summary["ill"]["reference_returned_inf"] = ref_inf
+    summary["saturated"]["note"] = "reference value depends on heap contents (out-of-bounds lgamma read); not a parity target"
+    os.makedirs(os.path.join(os.path.dirname(golden_dir), "..", "gpurun_out"), exist_ok=True)
+    with open(os.path.join(os.path.dirname(golden_dir), "..", "gpurun_out", "ek_golden_classes.json"), "w") as fh:
+        json.dump(summary, fh, indent=1)
 
 
 def test_lprob_golden(api, golden_dir):

@@ -149,3 +149,28 @@ def test_main_dispatch_and_out_of_scope(monkeypatch, capsys):
     with pytest.raises(SystemExit):
         m.main()
     assert "not part of the MI355X distance path" in capsys.readouterr().err
+
+
+def test_general_matrix_core_identity():
+    """The identity behind the general matrix-core path (csrc/pairsnp_mfma.hip, csrc/general_sparse.hip): for every pair of
+    IUPAC code vectors  d = L - G + 3 NN + T1 + T2  and  nn = L - c_i - c_j + NN  with the one-hot Gram G = sum |S_i n S_j|,
+    NN = #(both N), T1 = sum over (partial, N) sites of |M| - 1, T2 = sum over (partial, partial) sites of (|M n M'| - 1)^+ --
+    checked against the definition (src/pairsnp.hpp:398-403,417-420) on random code matrices over all 15 codes."""
+    rng = np.random.default_rng(5)
+    n, L = 10, 3000
+    pc = np.array([bin(x).count("1") for x in range(16)])
+    for p_special in (1.0, 0.05):
+        codes = 1 << rng.integers(0, 4, size=(n, L))
+        m = rng.random((n, L)) < p_special
+        codes[m] = rng.integers(1, 16, size=int(m.sum()))
+        for i in range(n):
+            for j in range(i + 1, n):
+                a, b = codes[i], codes[j]
+                inter = pc[a & b]
+                d_true, nn_true = int((inter == 0).sum()), int(((a != 15) & (b != 15)).sum())
+                pa, pb = (pc[a] > 1) & (a != 15), (pc[b] > 1) & (b != 15)
+                G, NN = int(inter.sum()), int(((a == 15) & (b == 15)).sum())
+                T1 = int(((pc[a] - 1) * pa * (b == 15)).sum() + ((pc[b] - 1) * pb * (a == 15)).sum())
+                T2 = int((np.maximum(inter - 1, 0) * (pa & pb)).sum())
+                assert L - G + 3 * NN + T1 + T2 == d_true
+                assert L - int((a == 15).sum()) - int((b == 15).sum()) + NN == nn_true

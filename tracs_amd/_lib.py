@@ -24,7 +24,8 @@ SYMBOLS = [
     "tracs_pairsnp_dense", "tracs_pairsnp_dense_thr", "tracs_coo_count", "tracs_coo_fill", "tracs_filter_recomb_device",
     "tracs_trans_dist_device", "tracs_trans_dist_dense", "tracs_trans_dist_dense2",
     "tracs_calculate_posteriors_device", "tracs_posterior_codes_device", "tracs_posterior_codes_cov_device",
-    "tracs_codes_to_iupac_device", "tracs_alignment_pack_codes", "tracs_coverage_profile_device",
+    "tracs_codes_to_iupac_device", "tracs_alignment_pack_codes", "tracs_alignment_pack_codes_batch",
+    "tracs_coverage_profile_device32", "tracs_posterior_codes_cov_device32", "tracs_consensus_codes_device32", "tracs_coverage_profile_device",
     "tracs_consensus_codes_device",
     "tracs_connected_components_device",
     "tracs_pileup_counts", "tracs_write_posterior_csv", "tracs_combine_fasta", "tracs_write_distance_rows",
@@ -140,6 +141,8 @@ def load():
     L.tracs_codes_to_iupac_device.argtypes = [vp, sz, vp, vp]
     L.tracs_alignment_pack_codes.restype = C.c_int
     L.tracs_alignment_pack_codes.argtypes = [vp, vp, sz, vp]
+    L.tracs_alignment_pack_codes_batch.restype = C.c_int
+    L.tracs_alignment_pack_codes_batch.argtypes = [vp, vp, sz, sz, sz, vp]
     L.tracs_connected_components_device.restype = C.c_int
     L.tracs_connected_components_device.argtypes = [vp, vp, sz, sz, vp, C.POINTER(i32), vp]
     cpp = C.POINTER(C.c_char_p)
@@ -147,6 +150,12 @@ def load():
     L.tracs_coverage_profile_device.argtypes = [vp, sz, vp, sz, vp, vp, vp]
     L.tracs_consensus_codes_device.restype = C.c_int
     L.tracs_consensus_codes_device.argtypes = [vp, sz, C.c_uint32, vp, vp]
+    L.tracs_coverage_profile_device32.restype = C.c_int
+    L.tracs_coverage_profile_device32.argtypes = [vp, sz, vp, sz, vp, vp, vp]
+    L.tracs_posterior_codes_cov_device32.restype = C.c_int
+    L.tracs_posterior_codes_cov_device32.argtypes = [vp, sz, dp, C.c_int, dbl, C.c_uint32, dbl, dbl, vp, vp]
+    L.tracs_consensus_codes_device32.restype = C.c_int
+    L.tracs_consensus_codes_device32.argtypes = [vp, sz, C.c_uint32, vp, vp]
     L.tracs_pileup_counts.restype = C.c_int
     L.tracs_pileup_counts.argtypes = [C.c_char_p, cpp, u64p, sz, C.c_int, dp, u64p]
     L.tracs_write_posterior_csv.restype = C.c_int
@@ -180,6 +189,7 @@ def load():
     L.tracs_debug_alignment_kernel.restype = C.c_int
     L.tracs_debug_alignment_kernel.argtypes = [vp]
     L.tracs_debug_tile_variant.restype = C.c_char_p
+    L.tracs_debug_mfma_shape.restype = C.c_char_p
     L.tracs_debug_iupac_mask.restype = C.c_int
     L.tracs_debug_iupac_mask.argtypes = [C.c_int]
     _lib = L

@@ -126,6 +126,25 @@ class CoverageProfile:
         return _np_lerp(self._nz_kth(lo), self._nz_kth(hi), h - lo)
 
 
+class SortedCoverageProfile(CoverageProfile):
+    """The same statistics when some site is deeper than the histogram reaches (coverage >= COV_BINS - 1): order statistics
+    are read from the sorted non-zero coverages (a device sort) instead of from histogram bins."""
+
+    def __init__(self, rs, L):                                 # rs: torch int64 [L] per-site totals, on the device
+        import torch
+        self.L = int(L)
+        self._rs = rs
+        nz = rs[rs > 0]
+        self._sorted = torch.sort(nz).values
+        self.n_nonzero = int(nz.numel())
+
+    def frac_at_least(self, min_cov):
+        return int((self._rs >= int(np.ceil(min_cov))).sum().item()) / self.L
+
+    def _nz_kth(self, k):
+        return int(self._sorted[k].item())
+
+
 def call_sequence(all_counts, min_cov=5, error_threshold=0.01, consensus=False, keep_all=False, keep_cov_outliers=False,
                   want_posterior=True, log=None):
     """Counts [L,4] (numpy, as pileup_counts returns them) -> the called sequence, on the GPU.
@@ -147,9 +166,19 @@ def call_sequence(all_counts, min_cov=5, error_threshold=0.01, consensus=False, 
     bad = torch.empty(1, dtype=torch.int32, device="cuda")
     _lib.check(lib.tracs_coverage_profile_device(dev._ptr(counts), L, dev._ptr(hist), COV_BINS, dev._ptr(c16), dev._ptr(bad),
                                                  dev._stream()))
-    if int(bad.item()):
-        raise _lib.TracsError("allele counts must be integers in [0, 65535] on the device path")
-    prof = CoverageProfile(hist.cpu().numpy(), L)
+    wide = bool(int(bad.item()))
+    if wide:
+        # some count is above 65535 (deep amplicon / viral data): the uint32 forms of the same kernels
+        c16 = torch.empty((L, 4), dtype=torch.int32, device="cuda")
+        _lib.check(lib.tracs_coverage_profile_device32(dev._ptr(counts), L, dev._ptr(hist), COV_BINS, dev._ptr(c16), dev._ptr(bad),
+                                                       dev._stream()))
+        if int(bad.item()):
+            raise _lib.TracsError("allele counts must be non-negative integers below 2^30")
+    hist_h = hist.cpu().numpy()
+    if wide and hist_h[-1] > 0:
+        prof = SortedCoverageProfile(c16.to(torch.int64).sum(dim=1), L)
+    else:
+        prof = CoverageProfile(hist_h, L)
     median_cov = prof.median_nonzero()
     out = dict(sequence=None, codes=None, alphas=None, threshold=None, band=None, posterior=None,
                frac_covered=prof.frac_covered(), frac_min_cov=prof.frac_at_least(min_cov), median_cov=median_cov)
@@ -165,7 +194,8 @@ def call_sequence(all_counts, min_cov=5, error_threshold=0.01, consensus=False, 
     if consensus:                                                              # :482-516
         say("Consensus requested. Skipping all coverage filters!")
         codes = torch.empty((L + 1) // 2, dtype=torch.uint8, device="cuda")
-        _lib.check(lib.tracs_consensus_codes_device(dev._ptr(c16), L, int(np.ceil(min_cov)), dev._ptr(codes), dev._stream()))
+        fn = lib.tracs_consensus_codes_device32 if wide else lib.tracs_consensus_codes_device
+        _lib.check(fn(dev._ptr(c16), L, int(np.ceil(min_cov)), dev._ptr(codes), dev._stream()))
         return finish(codes)
 
     with np.errstate(divide="ignore", invalid="ignore"):
@@ -194,7 +224,7 @@ def call_sequence(all_counts, min_cov=5, error_threshold=0.01, consensus=False, 
     if want_posterior:                                                         # :575-577, written to the .csv.gz before the coverage rules
         out["posterior"] = dev.calculate_posteriors_device(counts, alphas, keep_all, thr).cpu().numpy()
     apply_band = band if (use_band and band[1] > band[0]) else None            # :599-611
-    codes = dev.posterior_codes_device(c16, alphas, keep_all, thr, min_cov=int(np.ceil(min_cov)), cov_band=apply_band)
+    codes = dev.posterior_codes_device(c16, alphas, keep_all, thr, min_cov=int(np.ceil(min_cov)), cov_band=apply_band)   # int16 or int32 counts
     out.update(alphas=alphas, threshold=float(thr), band=band)
     return finish(codes)
 

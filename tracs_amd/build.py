@@ -7,8 +7,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libtracs_hip.so")
-SOURCES = ["capi.hip", "pairsnp.hip", "transcluster.hip", "dmultinomial.hip", "cluster.hip", "filter.hip", "dirichlet.hip", "fasta.cpp", "alignio.cpp"]
-HEADERS = ["common.h", "fasta.h", os.path.join("..", "..", "include", "tracs_hip.h")]
+SOURCES = ["capi.hip", "pairsnp.hip", "pairsnp_mfma.hip", "general_sparse.hip", "transcluster.hip", "dmultinomial.hip", "cluster.hip", "filter.hip", "dirichlet.hip", "fasta.cpp", "alignio.cpp"]
+HEADERS = ["common.h", "pairsnp_kernels.h", "fasta.h", os.path.join("..", "..", "include", "tracs_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fgpu-rdc" if False else "-fno-gpu-rdc",
          "-Wall", "-Wno-unused-function", "-ffp-contract=off"]
@@ -21,15 +21,20 @@ def _stale():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
-def build(force=False, verbose=False, extra_flags=()):
-    """Compile every HIP source for gfx950 and link the shared library.  Cross-compiles without a GPU."""
-    if not force and not _stale():
-        return LIB
-    os.makedirs(LIBDIR, exist_ok=True)
+def build(force=False, verbose=False, extra_flags=(), libdir=None):
+    """Compile every HIP source for gfx950 and link the shared library.  Cross-compiles without a GPU.
+    TRACS_EXTRA_HIPCC_FLAGS adds flags (e.g. -DTRACS_MFMA_SWEEP: every matrix-core tile shape, for shape sweeps).
+    libdir: build into another directory (tests/test_build.py compiles from scratch without touching the loaded library)."""
+    extra_flags = list(extra_flags) + os.environ.get("TRACS_EXTRA_HIPCC_FLAGS", "").split()
+    out_dir = LIBDIR if libdir is None else libdir
+    lib = os.path.join(out_dir, "libtracs_hip.so")
+    if libdir is None and not force and not _stale():
+        return lib
+    os.makedirs(out_dir, exist_ok=True)
     objs = []
     procs = []
     for src in SOURCES:
-        obj = os.path.join(LIBDIR, os.path.splitext(src)[0] + ".o")
+        obj = os.path.join(out_dir, os.path.splitext(src)[0] + ".o")
         cmd = [HIPCC] + FLAGS + list(extra_flags) + (["-x", "hip"] if src.endswith(".hip") else []) + \
               ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
@@ -46,11 +51,14 @@ def build(force=False, verbose=False, extra_flags=()):
             print(out)
     if failed:
         raise RuntimeError("libtracs_hip.so: compilation failed")
-    cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-lz"]
+    # link next to the target and rename over it: a process that has the old file mapped keeps its own copy
+    tmp = lib + ".tmp.%d" % os.getpid()
+    cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", tmp] + objs + ["-lz"]
     out = subprocess.run(cmd, capture_output=True, text=True)
     if out.returncode != 0:
         raise RuntimeError("libtracs_hip.so: link failed:\n" + out.stdout + out.stderr)
-    return LIB
+    os.replace(tmp, lib)
+    return lib
 
 
 if __name__ == "__main__":

@@ -62,54 +62,74 @@ def write_alignment(ref, alns, output_dir, n_threads=0, gzip_level=6):
     return {(alns[i][0], ref): (frac[i], int(lens[i])) for i in range(n) if frac[i] >= 0.0}
 
 
+METADATA_HEADER = ("sample", "accession", "intersect_bp", "f_orig_query", "f_match", "f_unique_to_query", "coverage",
+                   "mean_depth", "mean_nonzero_depth", "frac_N", "species")
+
+
+def _sample_name(directory):
+    return os.path.basename(os.path.normpath(directory))
+
+
+def _resolve_directories(arg):
+    """-i takes the directories themselves, or ONE file listing them one per line (tracs/combine.py:111-113)."""
+    dirs = list(arg)
+    if len(dirs) == 1:
+        with open(dirs[0], "r") as fh:
+            dirs = [ln.strip() for ln in fh]
+    missing = [d for d in dirs if not os.path.isdir(d)]
+    if missing:
+        logging.error("ERROR: {} is not a directory".format(missing[0]))
+        sys.exit(1)
+    return dirs
+
+
+def _alignments_by_reference(dirs):
+    """{reference id: [(sample, fasta path), ...]} over every `*posterior_counts_ref_*.fasta*` of every directory."""
+    by_ref = defaultdict(list)
+    for d in dirs:
+        for path in glob.iglob(os.path.join(d, "*posterior_counts_ref_*.fasta*")):
+            by_ref[find_ref(path)].append((_sample_name(d), path))
+    return by_ref
+
+
+def _hit_rows(hits_csv):
+    """(accession, species, first four columns) per data line of a `*_sourmash_hits.csv`; column 9 is '"<accession> <species>"'."""
+    with open(hits_csv, "r") as fh:
+        fh.readline()
+        for ln in fh:
+            cols = ln.strip().split(",")
+            label = cols[9]
+            accession = label.split()[0].strip('"')
+            yield accession, label.replace(accession, "").replace('"', "").strip(), cols[:4]
+
+
+def _write_metadata(path, dirs, frac_n):
+    """combined_metadata.csv: one row per sourmash hit; the three coverage columns are "NA" (the reference's coverage pass is
+    commented out, tracs/combine.py:141-163), frac_N comes from the combined alignments."""
+    with open(path, "w") as out:
+        out.write(",".join(METADATA_HEADER) + "\n")
+        for d in dirs:
+            sample = _sample_name(d)
+            for hits in glob.iglob(os.path.join(d, "*_sourmash_hits.csv")):
+                for accession, species, head in _hit_rows(hits):
+                    known = frac_n.get((sample, accession))
+                    out.write(",".join([sample, accession, *head, "NA", "NA", "NA", "NA" if known is None else str(known[0]), species]) + "\n")
+
+
 def combine(args):
     logging.basicConfig(level=args.loglevel, format="%(asctime)s - %(levelname)s - %(message)s", datefmt="%Y-%m-%d %H:%M:%S")
-    if len(args.directories) == 1:                             # a single argument is a file listing the directories (:111-113)
-        with open(args.directories[0], "r") as infile:
-            args.directories = [line.strip() for line in infile.readlines()]
-    for directory in args.directories:
-        if not os.path.isdir(directory):
-            logging.error("ERROR: {} is not a directory".format(directory))
-            sys.exit(1)
-    if not os.path.exists(args.output_dir):
-        os.mkdir(args.output_dir)
-    args.output_dir = os.path.join(args.output_dir, "")
-
-    alignments = defaultdict(list)                             # by reference genome (:127-132)
-    for directory in args.directories:
-        sample = os.path.basename(os.path.normpath(directory))
-        for aln in glob.iglob(os.path.join(directory, "*posterior_counts_ref_*.fasta*")):
-            alignments[find_ref(aln)].append((sample, aln))
-
-    ncovs = {}
-    for ref, alns in alignments.items():
-        ncovs.update(write_alignment(ref, alns, args.output_dir, n_threads=args.n_cpu))
-
-    # sourmash hits -> combined_metadata.csv; the coverage columns are "NA" in the reference too (its coverage pass is
-    # commented out, tracs/combine.py:141-163)
-    with open(args.output_dir + "combined_metadata.csv", "w") as outfile:
-        outfile.write("sample,accession,intersect_bp,f_orig_query,f_match,f_unique_to_query,coverage,mean_depth,"
-                      "mean_nonzero_depth,frac_N,species\n")
-        for directory in args.directories:
-            sample = os.path.basename(os.path.normpath(directory))
-            for hits in glob.iglob(os.path.join(directory, "*_sourmash_hits.csv")):
-                with open(hits, "r") as infile:
-                    next(infile)
-                    for line in infile:
-                        f = line.strip().split(",")
-                        accession = f[9].split()[0].strip('"')
-                        species = f[9].replace(accession, "").replace('"', "").strip()
-                        frac_n = str(ncovs[(sample, accession)][0]) if (sample, accession) in ncovs else "NA"
-                        outfile.write(",".join([sample, accession] + f[:4] + ["NA", "NA", "NA", frac_n, species]) + "\n")
-    return
+    dirs = _resolve_directories(args.directories)
+    os.makedirs(args.output_dir, exist_ok=True)
+    prefix = os.path.join(args.output_dir, "")
+    frac_n = {}
+    for ref, alns in _alignments_by_reference(dirs).items():
+        frac_n.update(write_alignment(ref, alns, prefix, n_threads=args.n_cpu))
+    _write_metadata(prefix + "combined_metadata.csv", dirs, frac_n)
 
 
 def main():
-    parser = argparse.ArgumentParser()
-    parser = combine_parser(parser)
-    args = parser.parse_args()
+    args = combine_parser(argparse.ArgumentParser()).parse_args()
     args.func(args)
-    return
 
 
 if __name__ == "__main__":

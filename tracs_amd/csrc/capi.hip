@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 namespace tracs {
@@ -39,6 +40,20 @@ int workspace_get(int slot, size_t bytes, void **out)
     return TRACS_OK;
 }
 
+static std::recursive_mutex g_call_mu[8];
+static hipStream_t g_last_stream[8];
+static bool g_have_stream[8];
+
+DeviceCall::DeviceCall(hipStream_t stream) : dev(0)
+{
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 8) dev = 0;
+    g_call_mu[dev].lock();
+    if (g_have_stream[dev] && g_last_stream[dev] != stream) (void)hipDeviceSynchronize();
+    g_last_stream[dev] = stream;
+    g_have_stream[dev] = true;
+}
+DeviceCall::~DeviceCall() { g_call_mu[dev].unlock(); }
+
 void workspace_release_all()
 {
     std::lock_guard<std::mutex> lock(g_scratch_mu);
@@ -50,6 +65,24 @@ void workspace_release_all()
 }  // namespace tracs
 
 using namespace tracs;
+
+// dst[base + t] = src[t] (uint32 -> uint64) on several host threads: at 5 x 10^7 pairs the five result columns are 2 GB
+static void widen_append(std::vector<uint64_t> &dst, const unsigned *src, size_t count)
+{
+    const size_t base = dst.size();
+    dst.resize(base + count);
+    uint64_t *out = dst.data() + base;
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const size_t nthr = count < (1u << 20) ? 1 : hw;
+    if (nthr == 1) { for (size_t t = 0; t < count; t++) out[t] = src[t]; return; }
+    std::vector<std::thread> pool;
+    const size_t per = (count + nthr - 1) / nthr;
+    for (size_t k = 0; k < nthr; k++) {
+        const size_t b = k * per, e = std::min(count, b + per);
+        if (b < e) pool.emplace_back([=]() { for (size_t t = b; t < e; t++) out[t] = src[t]; });
+    }
+    for (auto &th : pool) th.join();
+}
 
 struct tracs_pairsnp_result {
     size_t nseq = 0, L = 0;
@@ -201,9 +234,7 @@ int tracs_pairsnp(const char *const *fasta, int n_fasta, int n_threads, int dist
             auto pull = [&](unsigned *src, std::vector<uint64_t> &dst) -> hipError_t {
                 hipError_t e = hipMemcpy(h32.data(), src, (size_t)total * 4, hipMemcpyDeviceToHost);
                 if (e != hipSuccess) return e;
-                const size_t base = dst.size();
-                dst.resize(base + (size_t)total);
-                for (size_t t = 0; t < (size_t)total; t++) dst[base + t] = h32[t];
+                widen_append(dst, h32.data(), (size_t)total);
                 return hipSuccess;
             };
             PS_CHECK(pull(d_rows, res->rows));
@@ -247,7 +278,7 @@ int tracs_pairsnp(const char *const *fasta, int n_fasta, int n_threads, int dist
                     for (size_t t = 0; t < np; t++)
                         if (h32[t] != res->dist[base + t0 + t]) { cleanup(); delete res; set_error("filter: SNP site list does not match the distance (internal error)"); return TRACS_E_HIP; }
                     PS_CHECK(hipMemcpy(h32.data(), d_filt, np * 4, hipMemcpyDeviceToHost));
-                    for (size_t t = 0; t < np; t++) res->filt.push_back(h32[t]);
+                    widen_append(res->filt, h32.data(), np);
                     t0 = t1;
                 }
             }

@@ -107,6 +107,7 @@ int tracs_connected_components_device(const int32_t *I, const int32_t *J, size_t
     if (!labels || (n_edges && (!I || !J))) { set_error("tracs_connected_components_device: NULL argument"); return TRACS_E_ARG; }
     if (n_nodes >= (1ull << 31)) { set_error("connected_components: more than 2^31 nodes"); return TRACS_E_ARG; }
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    DeviceCall guard(stream);
     int *parent, *flag, *root, *total;
     int rc;
     if ((rc = workspace_get(CcWorkspaceIds::PARENT, n_nodes * 4, reinterpret_cast<void **>(&parent)))) return rc;

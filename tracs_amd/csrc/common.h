@@ -28,12 +28,17 @@ void set_error(const std::string &msg);
 // contiguous 1..4 KiB run: coalesced for the LDS stage and for the scalar row loads.
 constexpr int NPLANES = 5;
 constexpr int SITES_PER_GROUP = 128;
-constexpr int SAMPLE_PAD = 2048;     // n_pad is a multiple of every tile edge (widest: rowcast 2048 columns)
+constexpr int SAMPLE_PAD = 64;       // n_pad is a multiple of one staging wave-instruction (64 samples x 16 B)
+constexpr int TAIL_PAD = 512;        // zeroed uint4 behind the last plane: tiles may read (never use) up to one tile edge past n_pad
+constexpr int PAD_GROUPS = 1;        // all-zero groups behind the last real one: the matrix-core kernels' two-group stages may
+                                     // overhang the alignment by one group (zero planes contribute nothing)
 
 static inline size_t groups_for(size_t L) { return (L + SITES_PER_GROUP - 1) / SITES_PER_GROUP; }
 static inline size_t pad_samples(size_t n) { return (n + SAMPLE_PAD - 1) / SAMPLE_PAD * SAMPLE_PAD; }
 
 }  // namespace tracs
+
+namespace tracs { struct GeneralSparse; }
 
 struct tracs_alignment {
     size_t n = 0, L = 0, n_pad = 0, groups = 0;
@@ -42,7 +47,9 @@ struct tracs_alignment {
     unsigned *d_flag = nullptr;  // device: "some site has a partial IUPAC code"
     bool dirty = true;           // packed since the encoding was last decided
     int enc = 0;                 // 0 general, 1 consensus
-    int last_kernel = -1;        // kernel of the last dense call: 0 VALU tile kernel, 1 matrix-core kernel
+    int last_kernel = -1;        // kernel of the last dense call: 0 VALU tile kernel, 1 / 2 matrix-core kernel (consensus / one-hot)
+    tracs::GeneralSparse *sparse = nullptr;   // general matrix-core path: per-site / per-sample lists of N and partial codes
+    int sparse_state = 0;        // 0 not built, 1 built, -1 not available for this alignment (too dense / too large / no memory)
     // cached tile schedule for the last dense region (device + host mirror)
     int2 *d_tiles = nullptr;
     size_t n_tiles = 0, tiles_cap = 0;
@@ -51,8 +58,18 @@ struct tracs_alignment {
 };
 
 namespace tracs {
-// Grow-only per-device scratch buffers (slot ids are small integers owned by each .hip file).
-// Not thread-safe across concurrent calls on one device: one in-flight library call per device.
+// Grow-only per-device scratch buffers (slot ids are small integers owned by each .hip file), shared by every entry point.
+// Entry points that use them, or the cached state of a tracs_alignment, hold a DeviceCall for their whole body:
+//   * calls on one device are serialised (ctypes releases the GIL, so two Python threads can be inside the library);
+//   * scratch is only stream-ordered, so when a call arrives on a different stream than the previous call on that device
+//     the device is synchronised first.  Re-entrant on the owning thread (tracs_pairsnp calls the dense entry points).
 int workspace_get(int slot, size_t bytes, void **out);
 void workspace_release_all();
+struct DeviceCall {
+    explicit DeviceCall(hipStream_t stream);
+    ~DeviceCall();
+    DeviceCall(const DeviceCall &) = delete;
+    DeviceCall &operator=(const DeviceCall &) = delete;
+    int dev;
+};
 }  // namespace tracs

@@ -144,6 +144,7 @@ int tracs_find_dirichlet_priors_device(const double *counts, size_t L, size_t K,
     if (!counts || !alphas_out) { set_error("tracs_find_dirichlet_priors_device: NULL argument"); return TRACS_E_ARG; }
     if (K < 1 || K > DK) { set_error("find_dirichlet_priors: 1 <= K <= 8 alleles supported"); return TRACS_E_ARG; }
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    DeviceCall guard(stream);
     double *rows = nullptr, *partial = nullptr;
     unsigned *n_kept = nullptr;
     DmState *st = nullptr;

@@ -134,26 +134,36 @@ __device__ __forceinline__ unsigned posterior_mask4(const unsigned (&c)[4], cons
 // is below min_cov, or inside the outlier band [cov_lo, cov_hi] (disabled when cov_lo > cov_hi), become fully ambiguous.
 struct CovRule { unsigned min_cov; double cov_lo, cov_hi; };
 
-__global__ __launch_bounds__(256) void posterior_codes_kernel(const uint4 *__restrict__ counts2, size_t L, Alphas A, int keep,
+// WIDE = false: uint16 counts, 16 B per site pair; WIDE = true: uint32 counts (depth above 65535: deep amplicon / viral data)
+template <bool WIDE>
+__global__ __launch_bounds__(256) void posterior_codes_kernel(const void *__restrict__ counts_, size_t L, Alphas A, int keep,
                                                               double expected, CovRule cov, uint8_t *__restrict__ codes)
 {
     const size_t npairs = (L + 1) / 2;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < npairs; t += (size_t)gridDim.x * blockDim.x) {
-        uint4 v;
-        if (2 * t + 1 < L) v = counts2[t];
-        else {   // odd tail: only 8 valid bytes
-            const uint2 h = reinterpret_cast<const uint2 *>(counts2)[2 * t];
-            v = make_uint4(h.x, h.y, 0u, 0u);
+        unsigned rows[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        if (WIDE) {
+            const uint4 *c = reinterpret_cast<const uint4 *>(counts_);
+#pragma unroll
+            for (int s = 0; s < 2; s++)
+                if (2 * t + s < L) { const uint4 v = c[2 * t + s]; rows[s][0] = v.x; rows[s][1] = v.y; rows[s][2] = v.z; rows[s][3] = v.w; }
+        } else {
+            uint4 v;
+            if (2 * t + 1 < L) v = reinterpret_cast<const uint4 *>(counts_)[t];
+            else {   // odd tail: only 8 valid bytes
+                const uint2 h = reinterpret_cast<const uint2 *>(counts_)[2 * t];
+                v = make_uint4(h.x, h.y, 0u, 0u);
+            }
+            rows[0][0] = v.x & 0xFFFFu; rows[0][1] = v.x >> 16; rows[0][2] = v.y & 0xFFFFu; rows[0][3] = v.y >> 16;
+            rows[1][0] = v.z & 0xFFFFu; rows[1][1] = v.z >> 16; rows[1][2] = v.w & 0xFFFFu; rows[1][3] = v.w >> 16;
         }
         unsigned out = 0;
 #pragma unroll
         for (int s = 0; s < 2; s++) {
-            const unsigned w0 = s == 0 ? v.x : v.z, w1 = s == 0 ? v.y : v.w;
-            const unsigned row[4] = {w0 & 0xFFFFu, w0 >> 16, w1 & 0xFFFFu, w1 >> 16};
             if (2 * t + s < L) {
-                const unsigned rs = row[0] + row[1] + row[2] + row[3];
+                const unsigned rs = rows[s][0] + rows[s][1] + rows[s][2] + rows[s][3];
                 const bool masked = rs < cov.min_cov || ((double)rs >= cov.cov_lo && (double)rs <= cov.cov_hi);
-                out |= (masked ? 15u : posterior_mask4(row, A, keep, expected)) << (4 * s);
+                out |= (masked ? 15u : posterior_mask4(rows[s], A, keep, expected)) << (4 * s);
             }
         }
         codes[t] = (uint8_t)out;
@@ -166,9 +176,11 @@ __global__ __launch_bounds__(256) void posterior_codes_kernel(const uint4 *__res
 // fraction >= min_cov, np.median / np.quantile of the non-zero coverages) is an order statistic of that histogram.
 // A count that is not an integer in [0, 65535] raises the `bad` flag (the host then refuses: no silent narrowing).
 constexpr int COV_LDS_BINS = 8192;
+constexpr double COUNT_MAX_WIDE = 1073741823.0;      // 2^30 - 1: posterior_mask4 sorts (count << 2 | allele) keys
+template <bool WIDE>
 __global__ __launch_bounds__(256) void coverage_profile_kernel(const double *__restrict__ counts, size_t L, unsigned nbins,
                                                                unsigned long long *__restrict__ hist,
-                                                               uint16_t *__restrict__ counts16, unsigned *__restrict__ bad)
+                                                               void *__restrict__ counts_out, unsigned *__restrict__ bad)
 {
     __shared__ unsigned local[COV_LDS_BINS];
     for (int b = threadIdx.x; b < COV_LDS_BINS; b += blockDim.x) local[b] = 0;
@@ -180,14 +192,17 @@ __global__ __launch_bounds__(256) void coverage_profile_kernel(const double *__r
         unsigned v[4], rs = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const bool ok = c[k] >= 0.0 && c[k] <= 65535.0 && c[k] == (double)(unsigned)c[k];
+            const bool ok = c[k] >= 0.0 && c[k] <= (WIDE ? COUNT_MAX_WIDE : 65535.0) && c[k] == (double)(unsigned)c[k];
             any_bad |= !ok;
             v[k] = ok ? (unsigned)c[k] : 0u;
             rs += v[k];
         }
-        if (counts16) reinterpret_cast<uint2 *>(counts16)[i] = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
+        if (counts_out) {
+            if (WIDE) reinterpret_cast<uint4 *>(counts_out)[i] = make_uint4(v[0], v[1], v[2], v[3]);
+            else reinterpret_cast<uint2 *>(counts_out)[i] = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
+        }
         if (rs < (unsigned)COV_LDS_BINS) atomicAdd(&local[rs], 1u);
-        else atomicAdd(&hist[min(rs, nbins - 1)], 1ull);
+        else atomicAdd(&hist[min(rs, nbins - 1)], 1ull);     // the last bin collects every coverage >= nbins - 1
     }
     __syncthreads();
     for (int b = threadIdx.x; b < COV_LDS_BINS; b += blockDim.x)
@@ -196,7 +211,8 @@ __global__ __launch_bounds__(256) void coverage_profile_kernel(const double *__r
 }
 
 // --consensus (tracs/align.py:482-493): the first allele with the largest count, or every allele (N) below min_cov.
-__global__ __launch_bounds__(256) void consensus_codes_kernel(const uint2 *__restrict__ counts16, size_t L, unsigned min_cov,
+template <bool WIDE>
+__global__ __launch_bounds__(256) void consensus_codes_kernel(const void *__restrict__ counts_, size_t L, unsigned min_cov,
                                                               uint8_t *__restrict__ codes)
 {
     const size_t npairs = (L + 1) / 2;
@@ -205,8 +221,9 @@ __global__ __launch_bounds__(256) void consensus_codes_kernel(const uint2 *__res
 #pragma unroll
         for (int s = 0; s < 2; s++) {
             if (2 * t + s >= L) continue;
-            const uint2 w = counts16[2 * t + s];
-            const unsigned c[4] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16};
+            unsigned c[4];
+            if (WIDE) { const uint4 w = reinterpret_cast<const uint4 *>(counts_)[2 * t + s]; c[0] = w.x; c[1] = w.y; c[2] = w.z; c[3] = w.w; }
+            else { const uint2 w = reinterpret_cast<const uint2 *>(counts_)[2 * t + s]; c[0] = w.x & 0xFFFFu; c[1] = w.x >> 16; c[2] = w.y & 0xFFFFu; c[3] = w.y >> 16; }
             unsigned best = 0;
 #pragma unroll
             for (int k = 1; k < 4; k++) best = c[k] > c[best] ? k : best;           // np.argmax: first maximum
@@ -293,8 +310,8 @@ int tracs_posterior_codes_device(const uint16_t *counts, size_t L, const double 
     return tracs_posterior_codes_cov_device(counts, L, alphas_host, keep, threshold, 0u, 1.0, 0.0, codes, stream_);
 }
 
-int tracs_posterior_codes_cov_device(const uint16_t *counts, size_t L, const double *alphas_host, int keep, double threshold,
-                                     uint32_t min_cov, double cov_lo, double cov_hi, uint8_t *codes, void *stream_)
+static int posterior_codes_impl(bool wide, const void *counts, size_t L, const double *alphas_host, int keep, double threshold,
+                                uint32_t min_cov, double cov_lo, double cov_hi, uint8_t *codes, void *stream_)
 {
     if (L == 0) return TRACS_OK;
     if (!counts || !alphas_host || !codes) { set_error("tracs_posterior_codes_device: NULL argument"); return TRACS_E_ARG; }
@@ -305,14 +322,26 @@ int tracs_posterior_codes_cov_device(const uint16_t *counts, size_t L, const dou
     const size_t npairs = (L + 1) / 2;
     const unsigned blocks = (unsigned)std::min<size_t>((npairs + 255) / 256, 256 * 16);
     const CovRule cov{min_cov, cov_lo, cov_hi};
-    hipLaunchKernelGGL(posterior_codes_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const uint4 *>(counts), L, A,
-                       keep, threshold, cov, codes);
+    if (wide) hipLaunchKernelGGL(posterior_codes_kernel<true>, dim3(blocks), dim3(256), 0, stream, counts, L, A, keep, threshold, cov, codes);
+    else hipLaunchKernelGGL(posterior_codes_kernel<false>, dim3(blocks), dim3(256), 0, stream, counts, L, A, keep, threshold, cov, codes);
     TRACS_HIP_CHECK(hipGetLastError());
     return TRACS_OK;
 }
 
-int tracs_coverage_profile_device(const double *counts, size_t L, uint64_t *hist, size_t nbins, uint16_t *counts16,
-                                  uint32_t *bad, void *stream_)
+int tracs_posterior_codes_cov_device(const uint16_t *counts, size_t L, const double *alphas_host, int keep, double threshold,
+                                     uint32_t min_cov, double cov_lo, double cov_hi, uint8_t *codes, void *stream_)
+{
+    return posterior_codes_impl(false, counts, L, alphas_host, keep, threshold, min_cov, cov_lo, cov_hi, codes, stream_);
+}
+
+int tracs_posterior_codes_cov_device32(const uint32_t *counts, size_t L, const double *alphas_host, int keep, double threshold,
+                                       uint32_t min_cov, double cov_lo, double cov_hi, uint8_t *codes, void *stream_)
+{
+    return posterior_codes_impl(true, counts, L, alphas_host, keep, threshold, min_cov, cov_lo, cov_hi, codes, stream_);
+}
+
+static int coverage_profile_impl(bool wide, const double *counts, size_t L, uint64_t *hist, size_t nbins, void *counts_out,
+                                 uint32_t *bad, void *stream_)
 {
     if (!hist || !bad || nbins < 2 || nbins > 0x7FFFFFFFu || (!counts && L)) { set_error("tracs_coverage_profile_device: bad argument"); return TRACS_E_ARG; }
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -320,21 +349,46 @@ int tracs_coverage_profile_device(const double *counts, size_t L, uint64_t *hist
     TRACS_HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(uint32_t), stream));
     if (L == 0) return TRACS_OK;
     const unsigned blocks = (unsigned)std::min<size_t>((L + 255) / 256, 256 * 4);
-    hipLaunchKernelGGL(coverage_profile_kernel, dim3(blocks), dim3(256), 0, stream, counts, L, (unsigned)nbins,
-                       reinterpret_cast<unsigned long long *>(hist), counts16, bad);
+    if (wide) hipLaunchKernelGGL(coverage_profile_kernel<true>, dim3(blocks), dim3(256), 0, stream, counts, L, (unsigned)nbins,
+                                 reinterpret_cast<unsigned long long *>(hist), counts_out, bad);
+    else hipLaunchKernelGGL(coverage_profile_kernel<false>, dim3(blocks), dim3(256), 0, stream, counts, L, (unsigned)nbins,
+                            reinterpret_cast<unsigned long long *>(hist), counts_out, bad);
+    TRACS_HIP_CHECK(hipGetLastError());
+    return TRACS_OK;
+}
+
+int tracs_coverage_profile_device(const double *counts, size_t L, uint64_t *hist, size_t nbins, uint16_t *counts16,
+                                  uint32_t *bad, void *stream_)
+{
+    return coverage_profile_impl(false, counts, L, hist, nbins, counts16, bad, stream_);
+}
+
+int tracs_coverage_profile_device32(const double *counts, size_t L, uint64_t *hist, size_t nbins, uint32_t *counts32,
+                                    uint32_t *bad, void *stream_)
+{
+    return coverage_profile_impl(true, counts, L, hist, nbins, counts32, bad, stream_);
+}
+
+static int consensus_codes_impl(bool wide, const void *counts, size_t L, uint32_t min_cov, uint8_t *codes, void *stream_)
+{
+    if (L == 0) return TRACS_OK;
+    if (!counts || !codes) { set_error("tracs_consensus_codes_device: NULL argument"); return TRACS_E_ARG; }
+    const size_t npairs = (L + 1) / 2;
+    const dim3 grid((unsigned)std::min<size_t>((npairs + 255) / 256, 256 * 16));
+    if (wide) hipLaunchKernelGGL(consensus_codes_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream_), counts, L, min_cov, codes);
+    else hipLaunchKernelGGL(consensus_codes_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream_), counts, L, min_cov, codes);
     TRACS_HIP_CHECK(hipGetLastError());
     return TRACS_OK;
 }
 
 int tracs_consensus_codes_device(const uint16_t *counts16, size_t L, uint32_t min_cov, uint8_t *codes, void *stream_)
 {
-    if (L == 0) return TRACS_OK;
-    if (!counts16 || !codes) { set_error("tracs_consensus_codes_device: NULL argument"); return TRACS_E_ARG; }
-    const size_t npairs = (L + 1) / 2;
-    hipLaunchKernelGGL(consensus_codes_kernel, dim3((unsigned)std::min<size_t>((npairs + 255) / 256, 256 * 16)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream_), reinterpret_cast<const uint2 *>(counts16), L, min_cov, codes);
-    TRACS_HIP_CHECK(hipGetLastError());
-    return TRACS_OK;
+    return consensus_codes_impl(false, counts16, L, min_cov, codes, stream_);
+}
+
+int tracs_consensus_codes_device32(const uint32_t *counts32, size_t L, uint32_t min_cov, uint8_t *codes, void *stream_)
+{
+    return consensus_codes_impl(true, counts32, L, min_cov, codes, stream_);
 }
 
 int tracs_calculate_posteriors(const double *counts, size_t L, size_t K, const double *alphas, int keep, double threshold,

@@ -203,6 +203,7 @@ int tracs_filter_recomb_device(const tracs_alignment *a, const uint32_t *rows, c
     if (!a || !rows || !cols || !pos_off || !positions || !found || !filt) { set_error("tracs_filter_recomb_device: NULL argument"); return TRACS_E_ARG; }
     if (a->L >= (1ull << 31)) { set_error("filter: alignment longer than 2^31 sites"); return TRACS_E_ARG; }
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    DeviceCall guard(stream);
     const double *lg = nullptr;
     int rc = get_lgamma_table_for_filter(stream, &lg);
     if (rc) return rc;

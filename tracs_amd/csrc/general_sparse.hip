@@ -1,0 +1,331 @@
+// general_sparse.hip -- the partial-code terms of the general matrix-core path (gfx950).
+//
+// Reference behaviour restated (never copied): /root/reference/src/pairsnp.hpp:398-403,417-420.
+// For an alignment with partial IUPAC codes (M, R, W, S, Y, K, V, H, D, B; load_seqs :127-189) pairsnp_mfma_kernel<GENERAL>
+// leaves, per pair,  dist = L - G + 3 NN  and  ncomp = NN  with the one-hot Gram G = sum_s |S_i n S_j| and NN = #(both N).
+// |S n S'| over-counts a match exactly when both codes hold more than one allele:
+//     (N, N): 4 instead of 1            -> the 3 NN above
+//     (partial M, N): |M| instead of 1  -> T1 = sum over such sites of (|M| - 1)
+//     (partial M, partial M'): |M n M'| instead of [M n M' != {}]  -> T2 = sum of (|M n M'| - 1)^+
+// so  d = L - G + 3 NN + T1 + T2  and  nn = L - c_i - c_j + NN  (c_i = number of N sites of sample i; tests/test_host_logic.py
+// checks the identity on random code matrices).  T1 and T2 only involve sites where a sample carries a partial code -- a
+// fraction of a percent of a real alignment -- so they are computed from sparse lists:
+//     per sample  : its sites that are N or partial, in site order            (s_off / s_ent: site << 4 | code, 15 = N)
+//     per site    : the samples that are partial there, with their code       (p_off / p_ent: sample << 4 | mask)
+//                   the samples that are N there                              (n_off / n_ent: sample)
+// general_fixup_kernel gives row i of the pair matrix to one workgroup: the row's correction is accumulated in LDS with
+// ds_add (for every special site of sample i, walk the site's lists), then added to dist, together with nn's c_i, c_j terms.
+// The lists are built once per pack (cached on the alignment handle, like the consensus planes).
+#include "pairsnp_kernels.h"
+
+#include <algorithm>
+#include <vector>
+
+namespace tracs {
+
+struct GeneralSparse {
+    unsigned long long *s_off = nullptr, *p_off = nullptr, *n_off = nullptr;
+    unsigned *s_ent = nullptr, *p_ent = nullptr, *n_ent = nullptr;
+    unsigned *c_n = nullptr;
+    double est_updates = 0.0;
+};
+
+static constexpr int GS_CHUNKS = 64;          // per-sample list building: group chunks per sample
+
+// special-site masks of one 32-site word: N, and "partial" = two or more alleles but not all four
+__device__ __forceinline__ void special_masks(unsigned A, unsigned C, unsigned G, unsigned T, unsigned N, unsigned &nm, unsigned &pm)
+{
+    const unsigned two = (A & C) | (A & G) | (A & T) | (C & G) | (C & T) | (G & T);
+    nm = N;
+    pm = two & ~N;
+}
+
+__device__ __forceinline__ unsigned word_of(const uint4 &v, int w) { return w == 0 ? v.x : w == 1 ? v.y : w == 2 ? v.z : v.w; }
+
+// pass A / B over the planes, lanes over samples (coalesced), one thread = (sample, chunk of groups), walked in site order.
+// FILL = false: cnt[s * GS_CHUNKS + chunk] = special sites of the chunk, cn[s * GS_CHUNKS + chunk] = N sites of the chunk.
+// FILL = true : entries written from off[s * GS_CHUNKS + chunk] on.
+template <bool FILL>
+__global__ __launch_bounds__(256) void gs_sample_kernel(const uint4 *__restrict__ P, size_t n_pad, size_t n, size_t groups,
+                                                        size_t gpc, unsigned *__restrict__ cnt, unsigned *__restrict__ cn,
+                                                        const unsigned long long *__restrict__ off, unsigned *__restrict__ ent)
+{
+    const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    const size_t chunk = (size_t)blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (s >= n || chunk >= GS_CHUNKS) return;
+    const size_t g0 = chunk * gpc, g1 = min(groups, g0 + gpc);
+    unsigned c_all = 0, c_n = 0;
+    unsigned long long o = FILL ? off[s * GS_CHUNKS + chunk] : 0ull;
+    for (size_t g = g0; g < g1; g++) {
+        const uint4 *base = P + (g * NPLANES) * n_pad + s;
+        const uint4 A = base[0], C = base[n_pad], G = base[2 * n_pad], T = base[3 * n_pad], N = base[4 * n_pad];
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            unsigned nm, pm;
+            special_masks(word_of(A, w), word_of(C, w), word_of(G, w), word_of(T, w), word_of(N, w), nm, pm);
+            if (!FILL) { c_all += __popc(nm | pm); c_n += __popc(nm); continue; }
+            unsigned m = nm | pm;
+            while (m) {
+                const int b = __ffs(m) - 1;
+                m &= m - 1;
+                const unsigned code = ((word_of(A, w) >> b) & 1u) | (((word_of(C, w) >> b) & 1u) << 1) | (((word_of(G, w) >> b) & 1u) << 2) |
+                                      (((word_of(T, w) >> b) & 1u) << 3);
+                ent[o++] = (unsigned)((g * SITES_PER_GROUP + w * 32 + b) << 4) | code;
+            }
+        }
+    }
+    if (!FILL) { cnt[s * GS_CHUNKS + chunk] = c_all; cn[s * GS_CHUNKS + chunk] = c_n; }
+}
+
+// per-sample totals -> c_n[s], and the exclusive scan of cnt over (sample, chunk) in row-major order -> off (u64).
+// One workgroup; n * GS_CHUNKS elements.
+__global__ __launch_bounds__(1024) void gs_scan_kernel(const unsigned *__restrict__ v, size_t count, unsigned long long *__restrict__ out)
+{
+    __shared__ unsigned long long part[1024];
+    __shared__ unsigned long long carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    // each thread takes a run of consecutive elements so the block-level scan runs once per 1024 * RUN elements
+    constexpr int RUN = 16;
+    for (size_t base = 0; base <= count; base += 1024 * RUN) {
+        const size_t b0 = base + (size_t)threadIdx.x * RUN;
+        unsigned long long local[RUN], sum = 0;
+#pragma unroll
+        for (int k = 0; k < RUN; k++) { local[k] = sum; sum += (b0 + k < count) ? v[b0 + k] : 0u; }
+        part[threadIdx.x] = sum;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const unsigned long long t = threadIdx.x >= (unsigned)off ? part[threadIdx.x - off] : 0;
+            __syncthreads();
+            part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const unsigned long long excl = part[threadIdx.x] - sum + carry;
+#pragma unroll
+        for (int k = 0; k < RUN; k++) if (b0 + k <= count) out[b0 + k] = excl + local[k];
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += part[1023];
+        __syncthreads();
+    }
+}
+
+__global__ void gs_sample_totals_kernel(const unsigned *__restrict__ cn, size_t n, unsigned *__restrict__ c_n,
+                                        const unsigned long long *__restrict__ off, unsigned long long *__restrict__ s_off)
+{
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > n) return;
+    s_off[s] = off[s * GS_CHUNKS];                       // off has n * GS_CHUNKS + 1 entries
+    if (s < n) {
+        unsigned t = 0;
+        for (int k = 0; k < GS_CHUNKS; k++) t += cn[s * GS_CHUNKS + k];
+        c_n[s] = t;
+    }
+}
+
+// pass C / D: one workgroup per 128-site group, threads over samples (coalesced).  FILL = false: per-site counts of partial
+// and N samples (+ the work estimate sum_s cP (cN + cP / 2)).  FILL = true: entries placed through LDS cursors.
+template <bool FILL>
+__global__ __launch_bounds__(256) void gs_site_kernel(const uint4 *__restrict__ P, size_t n_pad, size_t n, size_t L,
+                                                      unsigned *__restrict__ cntP, unsigned *__restrict__ cntN,
+                                                      const unsigned long long *__restrict__ p_off, const unsigned long long *__restrict__ n_off,
+                                                      unsigned *__restrict__ p_ent, unsigned *__restrict__ n_ent, double *__restrict__ est)
+{
+    __shared__ unsigned cP[SITES_PER_GROUP], cN[SITES_PER_GROUP];
+    const size_t g = blockIdx.x;
+    const size_t site0 = g * SITES_PER_GROUP;
+    if (threadIdx.x < SITES_PER_GROUP) { cP[threadIdx.x] = 0; cN[threadIdx.x] = 0; }
+    __syncthreads();
+    const unsigned long long pb = FILL ? p_off[site0] : 0ull, nb = FILL ? n_off[site0] : 0ull;
+    if (FILL && threadIdx.x < SITES_PER_GROUP && site0 + threadIdx.x < L) {
+        cP[threadIdx.x] = (unsigned)(p_off[site0 + threadIdx.x] - pb);       // cursors relative to the group's first entry
+        cN[threadIdx.x] = (unsigned)(n_off[site0 + threadIdx.x] - nb);
+    }
+    if (FILL) __syncthreads();
+    for (size_t s = threadIdx.x; s < n; s += blockDim.x) {
+        const uint4 *base = P + (g * NPLANES) * n_pad + s;
+        const uint4 A = base[0], C = base[n_pad], G = base[2 * n_pad], T = base[3 * n_pad], N = base[4 * n_pad];
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            unsigned nm, pm;
+            special_masks(word_of(A, w), word_of(C, w), word_of(G, w), word_of(T, w), word_of(N, w), nm, pm);
+            while (nm) {
+                const int b = __ffs(nm) - 1;
+                nm &= nm - 1;
+                const unsigned slot = atomicAdd(&cN[w * 32 + b], 1u);
+                if (FILL) n_ent[nb + slot] = (unsigned)s;
+            }
+            while (pm) {
+                const int b = __ffs(pm) - 1;
+                pm &= pm - 1;
+                const unsigned slot = atomicAdd(&cP[w * 32 + b], 1u);
+                if (FILL) {
+                    const unsigned code = ((word_of(A, w) >> b) & 1u) | (((word_of(C, w) >> b) & 1u) << 1) | (((word_of(G, w) >> b) & 1u) << 2) |
+                                          (((word_of(T, w) >> b) & 1u) << 3);
+                    p_ent[pb + slot] = ((unsigned)s << 4) | code;
+                }
+            }
+        }
+    }
+    if (FILL) return;
+    __syncthreads();
+    if (threadIdx.x < SITES_PER_GROUP) {
+        const size_t site = site0 + threadIdx.x;
+        double e = 0.0;
+        if (site < L) {
+            cntP[site] = cP[threadIdx.x];
+            cntN[site] = cN[threadIdx.x];
+            e = (double)cP[threadIdx.x] * ((double)cN[threadIdx.x] + 0.5 * (double)cP[threadIdx.x]);
+        }
+        for (int off = 32; off > 0; off >>= 1) e += __shfl_down(e, off, 64);
+        if ((threadIdx.x & 63) == 0 && e > 0.0) atomicAdd(est, e);
+    }
+}
+
+// Row i of the pair matrix: T1 + T2 accumulated in LDS, then added to dist; ncomp gets its c_i, c_j terms.
+// A quarter wave (16 lanes) takes one special site of sample i at a time and walks that site's lists.
+__global__ __launch_bounds__(1024) void general_fixup_kernel(const unsigned long long *__restrict__ s_off, const unsigned *__restrict__ s_ent,
+                                                             const unsigned long long *__restrict__ p_off, const unsigned *__restrict__ p_ent,
+                                                             const unsigned long long *__restrict__ n_off, const unsigned *__restrict__ n_ent,
+                                                             const unsigned *__restrict__ c_n, unsigned L, unsigned n, unsigned row_begin,
+                                                             unsigned col_begin, unsigned chunk, unsigned *__restrict__ dist,
+                                                             unsigned *__restrict__ ncomp, size_t ld)
+{
+    extern __shared__ unsigned row[];
+    const unsigned i = row_begin + blockIdx.x;
+    const unsigned c0 = blockIdx.y * chunk, c1 = min(n, c0 + chunk);
+    if (c1 <= i + 1 || c1 <= col_begin) return;            // no cell (i, j > i) in this column chunk
+    for (unsigned j = threadIdx.x; j < c1 - c0; j += blockDim.x) row[j] = 0;
+    __syncthreads();
+    const unsigned sub = threadIdx.x >> 4, nsub = blockDim.x >> 4, l16 = threadIdx.x & 15;
+    const unsigned long long e0 = s_off[i], e1 = s_off[i + 1];
+    for (unsigned long long e = e0 + sub; e < e1; e += nsub) {
+        const unsigned ent = s_ent[e];
+        const unsigned site = ent >> 4, code = ent & 15u;
+        const unsigned long long pa = p_off[site], pz = p_off[site + 1];
+        if (code == 15u) {                                   // i is N here: every partial j > i gains |M_j| - 1
+            for (unsigned long long t = pa + l16; t < pz; t += 16) {
+                const unsigned pe = p_ent[t], j = pe >> 4;
+                if (j > i && j >= c0 && j < c1) atomicAdd(&row[j - c0], (unsigned)__popc(pe & 15u) - 1u);
+            }
+        } else {                                             // i is partial here
+            const unsigned k = (unsigned)__popc(code) - 1u;
+            const unsigned long long na = n_off[site], nz = n_off[site + 1];
+            for (unsigned long long t = na + l16; t < nz; t += 16) {
+                const unsigned j = n_ent[t];
+                if (j > i && j >= c0 && j < c1) atomicAdd(&row[j - c0], k);
+            }
+            for (unsigned long long t = pa + l16; t < pz; t += 16) {
+                const unsigned pe = p_ent[t], j = pe >> 4;
+                const int sh = __popc(pe & code) - 1;
+                if (sh > 0 && j > i && j >= c0 && j < c1) atomicAdd(&row[j - c0], (unsigned)sh);
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned ci = c_n[i];
+    for (unsigned j = c0 + threadIdx.x; j < c1; j += blockDim.x)
+        if (j > i && j >= col_begin) {
+            const size_t o = (size_t)i * ld + j;
+            const unsigned t = row[j - c0];
+            if (t) dist[o] += t;
+            if (ncomp) ncomp[o] += L - ci - c_n[j];
+        }
+}
+
+void general_sparse_free(tracs_alignment *a)
+{
+    if (!a) return;
+    if (a->sparse) {
+        GeneralSparse *g = a->sparse;
+        void *p[] = {g->s_off, g->p_off, g->n_off, g->s_ent, g->p_ent, g->n_ent, g->c_n};
+        for (void *q : p) if (q) (void)hipFree(q);
+        delete g;
+        a->sparse = nullptr;
+    }
+    a->sparse_state = 0;
+}
+
+int general_sparse_get(tracs_alignment *a, hipStream_t stream, int *ok, double *est_updates)
+{
+    *ok = 0;
+    if (a->sparse_state == -1) return TRACS_OK;
+    if (a->sparse_state == 1) { *ok = 1; *est_updates = a->sparse->est_updates; return TRACS_OK; }
+    a->sparse_state = -1;
+    const size_t n = a->n, L = a->L, groups = a->groups;
+    if (L >= (1ull << 28) || n >= (1ull << 28)) return TRACS_OK;        // entries hold site << 4 / sample << 4
+    auto *g = new GeneralSparse();
+    a->sparse = g;
+    unsigned *cnt = nullptr, *cn = nullptr, *cntP = nullptr, *cntN = nullptr;
+    unsigned long long *off = nullptr;
+    double *d_est = nullptr;
+    auto tmp_free = [&]() { void *p[] = {cnt, cn, cntP, cntN, off, d_est}; for (void *q : p) if (q) (void)hipFree(q); };
+    auto fail_soft = [&]() { tmp_free(); (void)hipGetLastError(); general_sparse_free(a); a->sparse_state = -1; return TRACS_OK; };
+#define GS_TRY(x) do { if ((x) != hipSuccess) return fail_soft(); } while (0)
+    const size_t nsc = n * GS_CHUNKS;
+    const size_t gpc = (groups + GS_CHUNKS - 1) / GS_CHUNKS;
+    GS_TRY(hipMalloc(reinterpret_cast<void **>(&cnt), nsc * 4));
+    GS_TRY(hipMalloc(reinterpret_cast<void **>(&cn), nsc * 4));
+    GS_TRY(hipMalloc(reinterpret_cast<void **>(&off), (nsc + 1) * 8));
+    GS_TRY(hipMalloc(reinterpret_cast<void **>(&cntP), (L + 1) * 4));
+    GS_TRY(hipMalloc(reinterpret_cast<void **>(&cntN), (L + 1) * 4));
+    GS_TRY(hipMalloc(reinterpret_cast<void **>(&d_est), 8));
+    GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->s_off), (n + 1) * 8));
+    GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->p_off), (L + 1) * 8));
+    GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->n_off), (L + 1) * 8));
+    GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->c_n), std::max<size_t>(n, 1) * 4));
+    GS_TRY(hipMemsetAsync(d_est, 0, 8, stream));
+
+    const dim3 sgrid((unsigned)((n + 63) / 64), GS_CHUNKS / 4);
+    hipLaunchKernelGGL((gs_sample_kernel<false>), sgrid, dim3(256), 0, stream, a->planes, a->n_pad, n, groups, gpc, cnt, cn, nullptr, nullptr);
+    hipLaunchKernelGGL(gs_scan_kernel, dim3(1), dim3(1024), 0, stream, cnt, nsc, off);
+    hipLaunchKernelGGL(gs_sample_totals_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, stream, cn, n, g->c_n, off, g->s_off);
+    hipLaunchKernelGGL((gs_site_kernel<false>), dim3((unsigned)groups), dim3(256), 0, stream, a->planes, a->n_pad, n, L, cntP, cntN,
+                       nullptr, nullptr, nullptr, nullptr, d_est);
+    hipLaunchKernelGGL(gs_scan_kernel, dim3(1), dim3(1024), 0, stream, cntP, L, g->p_off);
+    hipLaunchKernelGGL(gs_scan_kernel, dim3(1), dim3(1024), 0, stream, cntN, L, g->n_off);
+    unsigned long long tot_s = 0, tot_p = 0, tot_n = 0;
+    double est = 0.0;
+    GS_TRY(hipMemcpyAsync(&tot_s, off + nsc, 8, hipMemcpyDeviceToHost, stream));
+    GS_TRY(hipMemcpyAsync(&tot_p, g->p_off + L, 8, hipMemcpyDeviceToHost, stream));
+    GS_TRY(hipMemcpyAsync(&tot_n, g->n_off + L, 8, hipMemcpyDeviceToHost, stream));
+    GS_TRY(hipMemcpyAsync(&est, d_est, 8, hipMemcpyDeviceToHost, stream));
+    GS_TRY(hipStreamSynchronize(stream));
+    if (tot_s != tot_p + tot_n) { tmp_free(); general_sparse_free(a); set_error("general_sparse: list totals disagree (internal error)"); return TRACS_E_HIP; }
+    // the lists must stay a small fraction of the planes: beyond one entry per 8 sites the VALU kernel is the better tool anyway
+    if ((double)tot_s > (double)n * (double)L / 8.0) return fail_soft();
+    GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->s_ent), std::max<size_t>(tot_s, 1) * 4));
+    GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->p_ent), std::max<size_t>(tot_p, 1) * 4));
+    GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->n_ent), std::max<size_t>(tot_n, 1) * 4));
+    hipLaunchKernelGGL((gs_sample_kernel<true>), sgrid, dim3(256), 0, stream, a->planes, a->n_pad, n, groups, gpc, nullptr, nullptr, off, g->s_ent);
+    hipLaunchKernelGGL((gs_site_kernel<true>), dim3((unsigned)groups), dim3(256), 0, stream, a->planes, a->n_pad, n, L, nullptr, nullptr,
+                       g->p_off, g->n_off, g->p_ent, g->n_ent, nullptr);
+    GS_TRY(hipGetLastError());
+    GS_TRY(hipStreamSynchronize(stream));
+#undef GS_TRY
+    tmp_free();
+    g->est_updates = est;
+    a->sparse_state = 1;
+    *ok = 1;
+    *est_updates = est;
+    return TRACS_OK;
+}
+
+int general_sparse_fixup(tracs_alignment *a, size_t row_begin, size_t row_end, size_t col_begin, unsigned *dist, unsigned *ncomp,
+                         size_t ld, hipStream_t stream)
+{
+    if (a->sparse_state != 1 || !a->sparse) { set_error("general_sparse_fixup: lists not built"); return TRACS_E_ARG; }
+    const GeneralSparse *g = a->sparse;
+    const unsigned chunk = (unsigned)std::min<size_t>((a->n + 63) / 64 * 64, 32768);
+    static bool attr_set = false;
+    if (!attr_set) {
+        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(general_fixup_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4));
+        attr_set = true;
+    }
+    const dim3 grid((unsigned)(row_end - row_begin), (unsigned)((a->n + chunk - 1) / chunk));
+    hipLaunchKernelGGL(general_fixup_kernel, grid, dim3(1024), chunk * 4, stream, g->s_off, g->s_ent, g->p_off, g->p_ent, g->n_off,
+                       g->n_ent, g->c_n, (unsigned)a->L, (unsigned)a->n, (unsigned)row_begin, (unsigned)col_begin, chunk, dist, ncomp, ld);
+    TRACS_HIP_CHECK(hipGetLastError());
+    return TRACS_OK;
+}
+
+}  // namespace tracs

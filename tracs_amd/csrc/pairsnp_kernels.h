@@ -1,0 +1,73 @@
+// pairsnp_kernels.h -- declarations shared by the pair-loop translation units (pairsnp.hip: pack, VALU tile kernel,
+// COO, host driver; pairsnp_mfma.hip: matrix-core kernels; general_sparse.hip: partial-code correction).
+#pragma once
+#include "common.h"
+
+namespace tracs {
+
+// Two-pass thresholded runs (tracs_pairsnp_dense_thr on long alignments):
+//   phase 1  "prefix":    one workgroup per tile walks a SHORT prefix of the alignment; a tile whose every pair already
+//                         exceeds the threshold there is dead (cells 0xFFFFFFFF, live[tile] = 0), the others keep their
+//                         exact partial counts in dist/ncomp (live[tile] = 1);
+//   phase 2  "remainder": groups [g_base, groups) of the live tiles only (compacted tile list), split over ksplit
+//                         workgroups that ADD their partial counts onto the prefix's;
+//   phase 0  everything in one launch (the unthresholded path and short alignments).
+struct TilePhase {
+    int phase;
+    int g_base;
+    unsigned char *live;
+};
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+
+// XCD-aware, bijective remap of the hardware block id: blocks b, b+8, b+16.. share an XCD (and its L2); give each XCD a
+// contiguous run of the logical schedule so that the tiles resident on one XCD at a time are neighbours and share
+// row/column panels in L2.
+__device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nwg)
+{
+    const unsigned q = nwg >> 3, r = nwg & 7u, xcd = b & 7u, k = b >> 3;
+    const unsigned base = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+    return base + k;
+}
+
+// ---- matrix-core kernels (pairsnp_mfma.hip) ---------------------------------------------------------------------
+struct MfmaArgs {
+    const uint4 *P;            // consensus planes (3 per group) or general planes (5 per group)
+    size_t n_pad;
+    int groups;                // end of the group range of this launch
+    const int2 *tiles;
+    int n_tiles;
+    int gps, ksplit;           // groups per workgroup range, ranges per tile
+    unsigned L, n, row_end, col_begin;
+    unsigned *dist, *ncomp;
+    size_t ld;
+    unsigned thr;
+    TilePhase ph;
+};
+
+struct MfmaShape {
+    const char *name;
+    int nbr, nbc;              // 32 x 32 blocks per wave: the workgroup (2 x 2 waves) owns a (64 nbr) x (64 nbc) tile
+    int ti, tj;
+    int gc_cons, gc_gen;       // groups per LDS stage, consensus / general encoding (0: shape not built for it)
+    int wg_per_cu;
+};
+// The shapes compiled into the library; index 0 is the default.  TRACS_MFMA_TILE=<name> selects another (diagnostics).
+int mfma_shape_count();
+const MfmaShape &mfma_shape(int idx);
+int mfma_shape_current();
+// general = false: consensus encoding (operands x, y, z, v);  true: general encoding (one-hot A, C, G, T + N).
+int launch_pairsnp_mfma(int shape, bool general, bool with_nn, unsigned nwg, hipStream_t stream, const MfmaArgs &a);
+
+// ---- sparse side structures of the general matrix-core path (general_sparse.hip) -------------------------------
+struct GeneralSparse;
+// Builds (or returns the cached) per-site / per-sample lists of N and partial-code entries.  *ok = 0 when the alignment is
+// outside what the path supports (too long, too many entries, no memory): the caller then stays on the VALU kernel.
+int general_sparse_get(tracs_alignment *a, hipStream_t stream, int *ok, double *est_updates);
+void general_sparse_free(tracs_alignment *a);
+// dist[i][j] += T1 + T2 (partial-code terms), ncomp[i][j] += L - c_i - c_j for the cells of the dense region.
+int general_sparse_fixup(tracs_alignment *a, size_t row_begin, size_t row_end, size_t col_begin, unsigned *dist,
+                         unsigned *ncomp, size_t ld, hipStream_t stream);
+
+}  // namespace tracs

@@ -418,6 +418,7 @@ static int run_trans_dist(const Src &src, size_t total, double lamb, double beta
                           double *eK, hipStream_t stream)
 {
     if (total == 0) return TRACS_OK;
+    DeviceCall guard(stream);
     if (total >= 0xFFFFFFF0ull) { set_error("trans_dist: more than 2^32 elements per call"); return TRACS_E_ARG; }
     const double *lg = nullptr;
     int rc = get_lgamma_table(stream, &lg);

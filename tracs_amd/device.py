@@ -58,9 +58,16 @@ class Alignment:
         _lib.check(self._L.tracs_alignment_pack(self._h, ptr, int(first), int(count), on_dev, _stream()))
 
     def pack_codes(self, codes, sample):
-        """Pack one sample straight from its packed 4-bit allele masks (posterior_codes_device output)."""
-        assert codes.dtype == torch.uint8 and codes.is_cuda and codes.numel() == (self.L + 1) // 2
-        _lib.check(self._L.tracs_alignment_pack_codes(self._h, _ptr(codes), int(sample), _stream()))
+        """Pack samples straight from their packed 4-bit allele masks (posterior_codes_device output):
+        codes uint8 [(L+1)//2] -> one sample, or uint8 [count, stride >= (L+1)//2] -> samples sample..sample+count-1."""
+        assert codes.dtype == torch.uint8 and codes.is_cuda
+        if codes.dim() == 1:
+            assert codes.numel() == (self.L + 1) // 2
+            _lib.check(self._L.tracs_alignment_pack_codes(self._h, _ptr(codes), int(sample), _stream()))
+        else:
+            assert codes.dim() == 2 and codes.stride(1) == 1 and codes.shape[1] >= (self.L + 1) // 2
+            _lib.check(self._L.tracs_alignment_pack_codes_batch(self._h, _ptr(codes), int(codes.stride(0)), int(sample),
+                                                                int(codes.shape[0]), _stream()))
 
     @property
     def encoding(self):
@@ -70,8 +77,9 @@ class Alignment:
 
     @property
     def kernel(self):
-        """'mfma' (matrix-core kernel) / 'valu' (tile kernel) as used by the last dense call, None before the first."""
-        return {0: "valu", 1: "mfma"}.get(self._L.tracs_debug_alignment_kernel(self._h))
+        """'mfma' (matrix-core kernel, consensus operands) / 'mfma-general' (matrix-core kernel, one-hot operands + sparse
+        partial-code correction) / 'valu' (tile kernel) as used by the last dense call, None before the first."""
+        return {0: "valu", 1: "mfma", 2: "mfma-general"}.get(self._L.tracs_debug_alignment_kernel(self._h))
 
     @property
     def nbytes(self):
@@ -182,16 +190,18 @@ def calculate_posteriors_device(counts, alphas, keep, threshold):
 
 
 def posterior_codes_device(counts_u16, alphas, keep, threshold, min_cov=0, cov_band=None):
-    """counts_u16: torch.int16/uint16 [L,4] -> torch.uint8 [(L+1)//2] packed allele masks (low nibble = even site).
-    min_cov / cov_band=(lo, hi): the align stage's coverage rules (sites below min_cov or inside the band become N)."""
+    """counts_u16: torch.int16/uint16 [L,4] (or int32 [L,4] for depths above 65535) -> torch.uint8 [(L+1)//2] packed allele
+    masks (low nibble = even site).  min_cov / cov_band=(lo, hi): the align stage's coverage rules (sites below min_cov or
+    inside the band become N)."""
     L = _lib.require_gpu()
     a = np.ascontiguousarray(alphas, dtype=np.float64)
     n = counts_u16.shape[0]
     out = torch.empty((n + 1) // 2, dtype=torch.uint8, device=counts_u16.device)
     lo, hi = cov_band if cov_band is not None else (1.0, 0.0)
-    _lib.check(L.tracs_posterior_codes_cov_device(_ptr(counts_u16), n, a.ctypes.data_as(C.POINTER(C.c_double)),
-                                                  int(bool(keep)), float(threshold), int(min_cov), float(lo), float(hi),
-                                                  _ptr(out), _stream()))
+    assert counts_u16.is_contiguous() and counts_u16.element_size() in (2, 4)
+    fn = L.tracs_posterior_codes_cov_device32 if counts_u16.element_size() == 4 else L.tracs_posterior_codes_cov_device
+    _lib.check(fn(_ptr(counts_u16), n, a.ctypes.data_as(C.POINTER(C.c_double)), int(bool(keep)), float(threshold), int(min_cov),
+                  float(lo), float(hi), _ptr(out), _stream()))
     return out
 
 

@@ -107,7 +107,7 @@ def allele_counts(L, seed, depth=30, eps=0.01, p_two=0.01):
 
 # ---- on-device generation for the benchmark (torch) -------------------------------------
 def generate_device(n, L, seed, emit, mu_lineage=1e-5, mu_sample=1e-6, n_lineages=None, p_n=0.01, batch=32,
-                    limit=None):
+                    limit=None, p_partial=0.0):
     """The same two-level model generated on the GPU in batches of `batch` samples; every batch
     (uint8 [cnt, L] ASCII on the device) is handed to emit(rows, first).  Deterministic in `seed`;
     `limit` stops after the first `limit` samples (same values as a full run).  Setup code, untimed."""
@@ -117,6 +117,7 @@ def generate_device(n, L, seed, emit, mu_lineage=1e-5, mu_sample=1e-6, n_lineage
     g.manual_seed(int(seed))
     host_rng = np.random.default_rng(int(seed))
     lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    plut = torch.tensor(list(b"MRWSYKVHDB"), dtype=torch.uint8, device=dev)
     anc = torch.randint(0, 4, (L,), generator=g, device=dev, dtype=torch.int8)
     n_lineages = max(1, n // 16) if n_lineages is None else n_lineages
 
@@ -138,6 +139,10 @@ def generate_device(n, L, seed, emit, mu_lineage=1e-5, mu_sample=1e-6, n_lineage
             if p_n > 0:
                 m = torch.rand(L, generator=g, device=dev) < p_n
                 rows[b][m] = ord("N")
+            if p_partial > 0:       # two/three-allele IUPAC codes at uniformly random sites (SURVEY.md 8d, config 4 mix)
+                m = torch.rand(L, generator=g, device=dev) < p_partial
+                k = int(m.sum().item())
+                rows[b][m] = plut[torch.randint(0, 10, (k,), generator=g, device=dev)]
         emit(rows, s0)
     torch.cuda.synchronize()
 
