@@ -4,19 +4,26 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 10 000 samples x
-5 000 000 sites, synthetic, packed planes RESIDENT IN HBM before the timed region.  One step =
-one full pass: pairsnp (d and compared sites for all N(N-1)/2 pairs) + transcluster (P(direct),
-E(K) for every pair from SNP distance and sampling-date gap).  With N ranks the row panels of the
-pair matrix are dealt to the ranks (fold pairing: chunk r and chunk 2N-1-r, equal work), every rank
-holds the whole packed alignment, and the per-rank result panels are exchanged with RCCL all-gathers
-that overlap the next step's pair kernel (strong scaling: the problem is fixed, `value` = total pairs / time;
-every step's panels have arrived on every rank before the clock stops).
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on; SURVEY.md 8d): 10 000 samples x
+5 000 000 sites, synthetic -- one ancestor of iid uniform bases, every sample a copy with a different base at
+Bernoulli(mu = 1e-4) sites (E[d] ~ 2 mu L ~ 1 000 before masking) and 'N' at Bernoulli(0.01) sites: a consensus (ACGTN)
+alignment -- packed planes RESIDENT IN HBM before the timed region.  One step = one full pass: pairsnp (d and compared
+sites for all N(N-1)/2 pairs) + transcluster (P(direct), E(K) for every pair from SNP distance and sampling-date gap).
+With N ranks the row panels of the pair matrix are dealt to the ranks (fold pairing: chunk r and chunk 2N-1-r, equal
+work), every rank holds the whole packed alignment, and the per-rank d / nn panels are exchanged with RCCL all-gathers
+(P and E(K) are re-derived from d on the consumer: tc gather is ~1 ms, the f64 panels would be 2/3 of the bytes).
+Strong scaling: the problem is fixed, `value` = total pairs / time; every step's panels have arrived on every rank
+before the clock stops.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel from HIP events on the launch stream:
-pairsnp_mfma_kernel (consensus alignments: exact fp4 Gram products on the matrix cores, bound "mfma", with the HBM
-view in roofline.hbm) or pairsnp_tile_kernel (general IUPAC alignments: integer VALU, reported against HBM); `cpu_baseline` is the oracle (CPU port of the reference algorithm) timed
-on the host cores on a bounded sample of the same workload (rank 0, N=1 only).
+Prints ONE JSON line (rank 0):
+  roofline          the dominant kernel of the timed region (pairsnp_mfma_kernel, consensus operands) from HIP events on
+                    the launch stream: exact fp4 Gram products on the matrix cores, bound "mfma"; HBM view in roofline.hbm
+  roofline_general  the same pass over the SAME alignment with 0.5 % partial IUPAC codes added (SURVEY.md 8d's C4 mix):
+                    one-hot matrix-core kernel + sparse partial-code correction (N = 1 only; not part of `value`)
+  dm_frontend       counts -> posterior filter -> 4-bit codes -> packed planes for a batch of samples (SURVEY.md 8d C3's
+                    "counts->posterior->code fused front-end"), timed separately (N = 1 only)
+  cpu_baseline      the oracle (CPU port of the reference algorithm) on the host cores on a bounded sample of the same
+                    workload, pair loop and trans_dist legs reported separately (rank 0, N = 1 only)
 """
 import argparse
 import json
@@ -33,9 +40,14 @@ MFMA_FP4_PEAK = 10.0e15      # flop/s, dense fp4 MFMA (MI355X_MICROARCH.md: "~10
 MFMA_FP4_MEASURED = 7.1e15   # bare v_mfma_scale_f32_32x32x64_f8f6f4 loop on +-1 operands (clock-limited; profiles/r01/mfma_fp4_rate.txt)
 # Per encoding: VALU ops per 32 sites and pair, algorithmic bytes per pair as a fraction of L, and the
 # rate a register-only loop of exactly that instruction mix sustains on MI355X (scripts/micro/valu_ops.hip,
-# profiles/r01/valu_ops_microbench.txt) -- the practical issue ceiling of the kernel.
+# profiles/r01/valu_ops_microbench.txt) -- the practical issue ceiling of the VALU kernel.
 ENCODINGS = {"general": {"ops": 7, "bytes_per_site": 1.0, "mix_ceiling": 44.3e12},
              "consensus": {"ops": 6, "bytes_per_site": 0.75, "mix_ceiling": 49.7e12}}
+# matrix-core forms: fp4 operand values per site and sample (x, y, z, v / one-hot A, C, G, T + N) -> flop per pair and site
+MFMA_FLOP_PER_SITE = {"mfma": 8.0, "mfma-general": 10.0}
+MU = 1e-4                    # per-sample substitution probability
+P_N = 0.01
+P_PARTIAL_C4 = 0.005         # SURVEY.md 8d, config 4 mix: partial-ambiguity IUPAC codes
 
 
 def parse():
@@ -45,18 +57,55 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--samples", type=int, default=int(os.environ.get("TRACS_BENCH_SAMPLES", 10000)))
     ap.add_argument("--sites", type=int, default=int(os.environ.get("TRACS_BENCH_SITES", 5000000)))
+    ap.add_argument("--partial", type=float, default=float(os.environ.get("TRACS_BENCH_PARTIAL", "0")),
+                    help="fraction of partial IUPAC codes in the TIMED alignment (default 0: consensus, the metric's workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
+    ap.add_argument("--no-extras", action="store_true", help="skip roofline_general and dm_frontend")
+    ap.add_argument("--cpu-seconds", type=float, default=6.0, help="minimum wall time of each CPU baseline leg")
     ap.add_argument("--lamb", type=float, default=1e-3 * 29903)     # tracs distance defaults (distance.py:76-90)
     ap.add_argument("--beta", type=float, default=73.0)
     ap.add_argument("--precision", type=float, default=0.01)
     return ap.parse_args()
 
 
+def synth_kw(p_partial=0.0):
+    """SURVEY.md 8d's generator: star phylogeny (one lineage = the ancestor itself), mu per sample, 1 % N."""
+    return dict(mu_lineage=0.0, mu_sample=MU, n_lineages=1, p_n=P_N, p_partial=p_partial)
+
+
+def roofline_of(kernel, enc, pairs_per_launch, L, kern_s, traffic):
+    E = ENCODINGS[enc]
+    alg_bytes = float(pairs_per_launch) * L * E["bytes_per_site"]       # SURVEY 8d: L (general) / 0.75 L (consensus) per pair
+    hbm = {"achieved": alg_bytes / kern_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg_bytes / kern_s / HBM_PEAK,
+           "algorithmic_bytes_per_pair": L * E["bytes_per_site"],
+           "note": "SURVEY 8d's byte count assumes no tile reuse; every byte fetched is shared by a whole tile from LDS, so "
+                   "achieved > peak here and the matrix pipe / VALU is what binds"}
+    if kernel in MFMA_FLOP_PER_SITE:
+        fps = MFMA_FLOP_PER_SITE[kernel]
+        flop = float(pairs_per_launch) * L * fps
+        return {"bound": "mfma", "achieved": flop / kern_s / 1e12, "peak": MFMA_FP4_PEAK / 1e12, "unit": "TFLOP/s",
+                "frac": flop / kern_s / MFMA_FP4_PEAK, "traffic": traffic,
+                "kernel": "pairsnp_mfma_kernel" + ("<general> + general_fixup_kernel" if kernel == "mfma-general" else ""),
+                "kernel_ms": kern_s * 1e3, "encoding": enc, "algorithmic_flop_per_pair": L * fps,
+                "measured_fp4_ceiling": MFMA_FP4_MEASURED / 1e12, "frac_of_measured_fp4_ceiling": flop / kern_s / MFMA_FP4_MEASURED,
+                "note": "v_mfma_scale_f32_32x32x64_f8f6f4 on fp4 operands; %g flop per pair and site is the flop count of THIS "
+                        "formulation (%s), not an algorithm-intrinsic number; peak = dense fp4 (MI355X_MICROARCH.md); the "
+                        "measured ceiling is the bare instruction rate on +-1 operand data (scripts/micro/mfma_fp4_rate.hip)"
+                        % (fps, "operand planes x, y, z = x*y, v" if kernel == "mfma" else "one-hot planes A, C, G, T and N"),
+                "hbm": hbm}
+    lane_ops = float(pairs_per_launch) * ((L + 127) // 128) * 4 * E["ops"]
+    return dict(hbm, bound="hbm", traffic=traffic, kernel="pairsnp_tile_kernel", kernel_ms=kern_s * 1e3, encoding=enc,
+                valu={"achieved": lane_ops / kern_s / 1e12, "peak": VALU_PEAK / 1e12, "unit": "Tlane-op/s",
+                      "frac": lane_ops / kern_s / VALU_PEAK, "ops_per_32_sites_per_pair": E["ops"],
+                      "measured_mix_ceiling": E["mix_ceiling"] / 1e12,
+                      "frac_of_measured_mix_ceiling": lane_ops / kern_s / E["mix_ceiling"]})
+
+
 def main():
     args = parse()
     import torch
     import torch.distributed as dist
+    from tracs_amd import _lib
     from tracs_amd import device as dev
     from tracs_amd import partition, synth
 
@@ -81,60 +130,79 @@ def main():
     # ---- setup (untimed): packed alignment resident in HBM, sampling days -------------------
     t0 = time.time()
     aln = dev.Alignment(n, L)
-    p_partial = float(os.environ.get("TRACS_BENCH_PARTIAL", "0"))
-    synth.pack_synthetic_device(aln, seed=seed, mu_lineage=1e-5, mu_sample=1e-6, p_n=0.01, p_partial=p_partial)
+    synth.pack_synthetic_device(aln, seed=seed, **synth_kw(args.partial))
     _, days_np = synth.dates(n, seed=seed)
     days = torch.from_numpy(days_np).to(device)
+    torch.cuda.synchronize()
     setup_s = time.time() - t0
 
     cs, nchunk = partition.row_chunks(n, world)
     rows_pad = cs * nchunk
     ranges = partition.rank_ranges(n, rank, world)        # this rank's row panels (one launch each)
-    # Two sets of result matrices when the panels travel: step s writes set s % 2 and its all-gathers are only waited for
+    # Two sets of d / nn matrices when the panels travel: step s writes set s % 2 and its all-gathers are only waited for
     # before that set is written again (and at the end of the timed region), so the exchange of one step overlaps the pair
-    # kernel of the next -- the way consecutive batches run in production.  One set on a single GPU.
+    # kernel of the next -- the way consecutive batches run in production.  One set on a single GPU.  P and E(K) never
+    # travel: each rank derives them for the whole matrix from the gathered d (one key table, ~1 ms of gather per matrix).
     nsets = 2 if world > 1 else 1
-    sets = [(torch.zeros((rows_pad, n), dtype=torch.int32, device=device), torch.zeros((rows_pad, n), dtype=torch.int32, device=device),
-             torch.zeros((rows_pad, n), dtype=torch.float64, device=device), torch.zeros((rows_pad, n), dtype=torch.float64, device=device))
+    sets = [(torch.zeros((rows_pad, n), dtype=torch.int32, device=device), torch.zeros((rows_pad, n), dtype=torch.int32, device=device))
             for _ in range(nsets)]
-    pending = [[] for _ in range(nsets)]
+    pmat = torch.zeros((rows_pad, n), dtype=torch.float64, device=device)
+    emat = torch.zeros((rows_pad, n), dtype=torch.float64, device=device)
+    pending = [None for _ in range(nsets)]
 
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + args.warmup)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + args.warmup)]
+    tc_ev = []
+    keys = [0]
+
+    def finish(k):
+        """transcluster over the WHOLE matrix of set k (all rows are present: own panels + gathered ones)."""
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        dev.trans_dist_dense_ranges(sets[k][0], n, days, args.lamb, args.beta, args.precision, pmat, emat, [(0, n)], exp_p0=True)
+        b.record()
+        tc_ev.append((a, b))
+        keys[0] = int(_lib.load().tracs_debug_last_trans_dist_keys())
 
     def step(it):
         k = it % nsets
-        dmat, nmat, pmat, emat = sets[k]
-        for w in pending[k]:                                  # this set's previous exchange must be over before it is rewritten
-            w.wait()
+        dmat, nmat = sets[k]
+        if pending[k] is not None:                            # this set's exchange (two steps ago) must be over, and consumed
+            for w in pending[k]:
+                w.wait()
+            finish(k)
+            pending[k] = None
         # pairsnp: the dominant kernel, bracketed by HIP events on the launch stream
         ev0[it].record()
         for r0, r1 in ranges:
             dev.pairsnp_dense(aln, dmat, nmat, row_begin=r0, row_end=r1)
         ev1[it].record()
-        # the SNP panels travel (RCCL, own stream) while transcluster runs on this rank's panels
-        works = partition.gather_panels((dmat, nmat), n, rank, world, dist, async_op=True)
-        dev.trans_dist_dense_ranges(dmat, n, days, args.lamb, args.beta, args.precision, pmat, emat, ranges, exp_p0=True)
-        works += partition.gather_panels((pmat, emat), n, rank, world, dist, async_op=True)
-        pending[k] = works
+        if world > 1:                                         # the d / nn panels travel while the next step's pair kernel runs
+            pending[k] = partition.gather_panels((dmat, nmat), n, rank, world, dist, async_op=True)
+        else:
+            finish(k)
 
-    def drain():
-        for k in range(nsets):
-            for w in pending[k]:
-                w.wait()
-            pending[k] = []
+    def drain(next_it):
+        for j in range(nsets):                                # oldest set first
+            k = (next_it + j) % nsets
+            if pending[k] is not None:
+                for w in pending[k]:
+                    w.wait()
+                finish(k)
+                pending[k] = None
 
     for it in range(args.warmup):
         step(it)
-    drain()
+    drain(args.warmup)
     torch.cuda.synchronize()
+    del tc_ev[:]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for it in range(args.warmup, args.warmup + args.steps):
         step(it)
-    drain()                                                   # every step's panels have arrived on every rank
+    drain(args.warmup + args.steps)                           # every step's panels have arrived and every matrix is complete on every rank
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -147,20 +215,19 @@ def main():
 
     pairs_total = n * (n - 1) // 2
     my_pairs = sum(partition.pairs_in_rows(n, r0, r1) for r0, r1 in ranges)
-    kern_ms = [ev0[i].elapsed_time(ev1[i]) for i in range(args.warmup, args.warmup + args.steps)]
+    timed = range(args.warmup, args.warmup + args.steps)
+    kern_ms = [ev0[i].elapsed_time(ev1[i]) for i in timed]
+    tc_ms = [a.elapsed_time(b) for a, b in tc_ev] or [0.0]
     kern_s = sum(kern_ms) / len(kern_ms) / 1e3 / len(ranges)      # average duration of ONE launch
     my_pairs_per_launch = my_pairs / len(ranges)
 
-    # sanity: spot-check a few cells against first principles is done in tests; here only a checksum
-    dmat, nmat, pmat, emat = sets[(args.warmup + args.steps - 1) % nsets]        # the last step's results
+    dmat, nmat = sets[(args.warmup + args.steps - 1) % nsets]    # the last step's results
     checksum = int(dmat[:n].sum().item()) if rank == 0 else 0
     if os.environ.get("TRACS_BENCH_VERIFY") and rank == 0:
         # the gathered matrices must equal a single-pass recomputation on this rank
         d1, n1 = torch.zeros_like(dmat), torch.zeros_like(nmat)
-        p1, e1 = torch.zeros_like(pmat), torch.zeros_like(emat)
         dev.pairsnp_dense(aln, d1, n1)
-        dev.trans_dist_dense_ranges(d1, n, days, args.lamb, args.beta, args.precision, p1, e1, [(0, n)], exp_p0=True)
-        ok = bool(torch.equal(d1, dmat) and torch.equal(n1, nmat) and torch.equal(p1, pmat) and torch.equal(e1, emat))
+        ok = bool(torch.equal(d1, dmat) and torch.equal(n1, nmat))
         print("VERIFY gathered == single-pass:", ok, file=sys.stderr, flush=True)
         if not ok:
             raise SystemExit("VERIFY FAILED")
@@ -169,44 +236,28 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = pairs_total * args.steps / elapsed
         enc = aln.encoding or "general"
-        E = ENCODINGS[enc]
-        alg_bytes = float(my_pairs_per_launch) * L * E["bytes_per_site"]   # L (general) / 0.75 L (consensus) per pair
-        lane_ops = float(my_pairs_per_launch) * ((L + 127) // 128) * 4 * E["ops"]
-        hbm = {"achieved": alg_bytes / kern_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg_bytes / kern_s / HBM_PEAK,
-               "algorithmic_bytes_per_pair": L * E["bytes_per_site"]}
         traffic = _traffic_from_profiles(n, L, world, aln.kernel)
-        if aln.kernel in ("mfma", "mfma-general"):
-            # matrix-core kernel: every site is four fp4 operand values (x, y, z, v) per sample -> 4 MACs = 8 flop per pair and site
-            flop = float(my_pairs_per_launch) * L * (8.0 if aln.kernel == "mfma" else 10.0)
-            roof = {"bound": "mfma", "achieved": flop / kern_s / 1e12, "peak": MFMA_FP4_PEAK / 1e12, "unit": "TFLOP/s",
-                    "frac": flop / kern_s / MFMA_FP4_PEAK, "traffic": traffic, "kernel": "pairsnp_mfma_kernel",
-                    "kernel_ms": kern_s * 1e3, "encoding": enc, "algorithmic_flop_per_pair": L * 8.0,
-                    "measured_fp4_ceiling": MFMA_FP4_MEASURED / 1e12,
-                    "frac_of_measured_fp4_ceiling": flop / kern_s / MFMA_FP4_MEASURED,
-                    "note": "v_mfma_scale_f32_32x32x64_f8f6f4 on fp4 operands; peak = dense fp4 (MI355X_MICROARCH.md); the measured "
-                            "ceiling is the bare instruction rate with this kernel's +-1 operand data (scripts/micro/mfma_fp4_rate.hip)",
-                    "hbm": hbm}
-        else:
-            roof = dict(hbm, bound="hbm", traffic=traffic, kernel="pairsnp_tile_kernel", kernel_ms=kern_s * 1e3, encoding=enc,
-                        note="algorithmic bytes are re-used from LDS/L2 tiles, so achieved > HBM peak is expected; "
-                             "the binding limit is integer VALU (see valu)",
-                        valu={"achieved": lane_ops / kern_s / 1e12, "peak": VALU_PEAK / 1e12, "unit": "Tlane-op/s",
-                              "frac": lane_ops / kern_s / VALU_PEAK, "ops_per_32_sites_per_pair": E["ops"],
-                              "measured_mix_ceiling": E["mix_ceiling"] / 1e12,
-                              "frac_of_measured_mix_ceiling": lane_ops / kern_s / E["mix_ceiling"]})
+        roof = roofline_of(aln.kernel, enc, my_pairs_per_launch, L, kern_s, traffic)
+        enc_name = "consensus (ACGTN) alignment" if enc == "consensus" else "general IUPAC alignment (%.2g partial codes)" % args.partial
         out = {"metric": "sample-pairs/sec for 10kx5Mbp SNP+transcluster distance", "value": value,
                "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "u32", "data": "synthetic",
-               "config": {"workload": "%d samples x %d sites, pairsnp (d + compared sites) + transcluster (P, E(K)), "
-                                      "all %d pairs" % (n, L, pairs_total),
-                          "samples": n, "sites": L, "pairs": pairs_total, "clock_rate": args.lamb,
-                          "trans_rate": args.beta, "precision": args.precision,
-                          "partition": "row panels, fold pairing, %d rank(s); RCCL all-gather of result panels, overlapped with the next step" % world,
+               "config": {"workload": "%d samples x %d sites, %s, mu = %g per sample + %g N (SURVEY 8d): pairsnp (d + compared "
+                                      "sites) + transcluster (P, E(K)), all %d pairs" % (n, L, enc_name, MU, P_N, pairs_total),
+                          "samples": n, "sites": L, "pairs": pairs_total, "encoding": enc, "kernel": aln.kernel,
+                          "mean_d": checksum / float(pairs_total), "distinct_keys": keys[0],
+                          "clock_rate": args.lamb, "trans_rate": args.beta, "precision": args.precision,
+                          "transcluster_ms_per_step": sum(tc_ms) / len(tc_ms),
+                          "partition": "row panels, fold pairing, %d rank(s); RCCL all-gather of the d / nn panels; P and E(K) derived "
+                                       "on every rank from the gathered d" % world,
                           "setup_seconds": round(setup_s, 1), "checksum_d": checksum},
                "roofline": roof}
+        if world == 1 and not args.no_extras and args.partial == 0:
+            out["roofline_general"] = general_pass(args, n, L, seed, dev, synth, torch, device)
+            out["dm_frontend"] = dm_frontend(args, L, dev, torch, device)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n, L, seed, days_np, args, dmat, nmat)
+            out["cpu_baseline"] = cpu_baseline(n, L, seed, days_np, args, dmat, nmat, keys[0])
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -214,54 +265,155 @@ def main():
 
 
 def _traffic_from_profiles(n, L, world, kernel):
-    """HBM bytes per launch of the kernel that ran, from the committed PMC summary (profiles/pmc_summary.json), if one matches."""
+    """HBM bytes per launch of the kernel that ran, from the COMMITTED PMC summary (profiles/pmc_summary.json) if it holds an
+    entry for this size and kernel: a figure from separate --pmc passes of the same command, not from this run."""
     p = os.path.join(ROOT, "profiles", "pmc_summary.json")
     try:
         with open(p) as fh:
             d = json.load(fh)
         e = d.get("%dx%d@%d" % (n, L, world), {})
-        if ("mfma" in e.get("kernel", "")) != (kernel == "mfma") or kernel == "mfma-general":
+        if e.get("kernel_tag") != kernel:
             return None
         return e.get("hbm_bytes_per_launch")
     except Exception:
         return None
 
 
-def cpu_baseline(n, L, seed, days_np, args, dmat, nmat):
-    """The oracle (C/OpenMP port of the reference algorithm) on the host cores, on a bounded sample of
-    the same workload: the first m samples of the SAME synthetic alignment, all m(m-1)/2 pairs at full
-    length L through the pair loop (both passes, as the reference runs them; planes already packed, like
-    the GPU's timed region), then trans_dist on those pairs (serial and memoised per (N, delta) key, as
-    in the reference).  m is sized so the whole leg is ~cpu-seconds."""
+def general_pass(args, n, L, seed, dev, synth, torch, device):
+    """The general-encoding path on the same workload with SURVEY 8d's C4 mix of partial codes: its own alignment handle,
+    2 passes timed with HIP events (not part of `value`)."""
+    aln = dev.Alignment(n, L)
+    synth.pack_synthetic_device(aln, seed=seed, **synth_kw(P_PARTIAL_C4))
+    dmat = torch.zeros((n, n), dtype=torch.int32, device=device)
+    nmat = torch.zeros((n, n), dtype=torch.int32, device=device)
+    dev.pairsnp_dense(aln, dmat, nmat)                        # warm-up: decides the encoding, builds the sparse lists (untimed setup)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 2
+    e0.record()
+    for _ in range(reps):
+        dev.pairsnp_dense(aln, dmat, nmat)
+    e1.record()
+    torch.cuda.synchronize()
+    kern_s = e0.elapsed_time(e1) / 1e3 / reps
+    r = roofline_of(aln.kernel, "general", n * (n - 1) // 2, L, kern_s, None)
+    r["workload"] = "the same alignment + %.3g partial IUPAC codes per site (uniformly random sites and codes)" % P_PARTIAL_C4
+    r["mean_d"] = float(dmat.sum().item()) / (n * (n - 1) // 2)
+    aln.close()
+    return r
+
+
+def dm_frontend(args, L, dev, torch, device):
+    """counts -> per-site Dirichlet-multinomial posterior filter -> 4-bit allele masks -> packed planes, for a batch of
+    samples (what `tracs align` does per sample before the FASTA exists, tracs/align.py:536-577,613-622, fused on the
+    device), then the pair kernel over that batch.  HBM-bound: 8 B in (4 x uint16 counts) + 0.5 B out per site-row."""
+    import numpy as np
+    batch = 32
+    g = torch.Generator(device=device)
+    g.manual_seed(99)
+    alphas = np.array([20.8156311152126, 4.38181182238621, 0.889048781117318, 0.1])
+    # SURVEY 8d, config 4 counts: depth ~ Poisson(30) on a random major allele, eps = 0.01 errors, 1 % two-allele sites
+    counts = torch.zeros((batch, L, 4), dtype=torch.int16, device=device)
+    ar = torch.arange(4, device=device)[None, :]
+    for b in range(batch):
+        major = torch.randint(0, 4, (L,), generator=g, device=device)
+        depth = torch.poisson(torch.full((L,), 30.0, device=device), generator=g).to(torch.int16)
+        minor = (major + 1 + torch.randint(0, 3, (L,), generator=g, device=device)) & 3
+        err = (torch.rand(L, generator=g, device=device) < 0.25).to(torch.int16)
+        two = (torch.rand(L, generator=g, device=device) < 0.01).to(torch.int16) * 9
+        c = (ar == major[:, None]).to(torch.int16) * depth[:, None]
+        c += (ar == minor[:, None]).to(torch.int16) * err[:, None]
+        c += (ar == ((major + 2) & 3)[:, None]).to(torch.int16) * two[:, None]
+        counts[b] = c
+    del c
+    aln = dev.Alignment(batch, L)
+    stride = ((L + 1) // 2 + 15) // 16 * 16
+    codes = torch.zeros((batch, stride), dtype=torch.uint8, device=device)
+    dmat = torch.zeros((batch, batch), dtype=torch.int32, device=device)
+    nmat = torch.zeros((batch, batch), dtype=torch.int32, device=device)
+
+    def chain():
+        for b in range(batch):
+            codes[b, :(L + 1) // 2] = dev.posterior_codes_device(counts[b], alphas, False, 0.05)
+        aln.pack_codes(codes, 0)
+        dev.pairsnp_dense(aln, dmat, nmat)
+    chain()
+    torch.cuda.synchronize()
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    e[0].record()
+    for b in range(batch):
+        codes[b, :(L + 1) // 2] = dev.posterior_codes_device(counts[b], alphas, False, 0.05)
+    e[1].record()
+    aln.pack_codes(codes, 0)
+    e[2].record()
+    dev.pairsnp_dense(aln, dmat, nmat)
+    e[3].record()
+    torch.cuda.synchronize()
+    t_post, t_pack, t_pair = e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2]), e[2].elapsed_time(e[3])
+    sites = float(batch) * L
+    out = {"samples": batch, "sites_per_sample": L,
+           "posterior_codes_ms": t_post, "pack_codes_ms": t_pack, "pairsnp_ms": t_pair, "encoding": aln.encoding,
+           "posterior_codes_GBps": sites * 8.5 / (t_post / 1e3) / 1e9, "pack_codes_GBps": sites * (0.5 + 0.625) / (t_pack / 1e3) / 1e9,
+           "site_rows_per_s": sites / ((t_post + t_pack) / 1e3),
+           "note": "posterior_codes includes one device-to-device copy of each sample's codes into the batch buffer; "
+                   "algorithmic bytes: 8.5 B per site-row (posterior), 1.125 B (pack)"}
+    aln.close()
+    return out
+
+
+def cpu_baseline(n, L, seed, days_np, args, dmat, nmat, n_keys_full):
+    """The oracle (C/OpenMP port of the reference algorithm) on the host cores, on a bounded sample of the same workload.
+    Two legs, reported separately and never extrapolated through each other:
+      pair loop   the first m samples of the SAME alignment, all m(m-1)/2 pairs at full length L, both passes, as the
+                  reference runs them (planes already packed, like the GPU's timed region), repeated until >= cpu-seconds;
+      trans_dist  serial and memoised per (N, delta) key, as in the reference, over the distinct keys of those pairs (bounded
+                  to the first ones that fit the time budget) -> keys/s.
+    `value` = pairs / (pairs / pair-loop rate + KEYS OF THE FULL MATRIX / key rate), the full matrix's distinct-key count being
+    the one the GPU's dedup table reported -- distinct keys saturate with the pair count, pairs do not."""
     import numpy as np
     from oracle import oracle as O
     from tracs_amd import synth
     cores = O.lib().orc_num_threads()
-    # trans_dist costs ~ms per DISTINCT key and dominates small samples: bound the pair count first
-    m = int(max(16, min(n, 96)))
-    seqs = synth.first_samples_host(n, L, seed, m, mu_lineage=1e-5, mu_sample=1e-6, p_n=0.01,
-                                    p_partial=float(os.environ.get("TRACS_BENCH_PARTIAL", "0")))
+    m = int(max(16, min(n, 128)))
+    seqs = synth.first_samples_host(n, L, seed, m, **synth_kw(args.partial))
     planes = O.pack(seqs)                                   # untimed, like the GPU side's resident planes
-    t0 = time.perf_counter()
-    r, c, d, nn = O.pairsnp_planes(planes, L, dist=2147483647, n_threads=cores)
-    t_snp = time.perf_counter() - t0
-    delta = np.abs(days_np[r.astype(np.int64)] - days_np[c.astype(np.int64)]).astype(np.float64) * 86400.0 / 31556952.0
-    t1 = time.perf_counter()
-    O.trans_dist(d.astype(np.int32), delta, args.lamb, args.beta, args.precision)
-    t_tc = time.perf_counter() - t1
     pairs = m * (m - 1) // 2
-    nkeys = len(set(zip(d.tolist(), delta.tolist())))
+    reps, t_snp = 0, 0.0
+    while t_snp < args.cpu_seconds and reps < 1000:
+        t0 = time.perf_counter()
+        r, c, d, nn = O.pairsnp_planes(planes, L, dist=2147483647, n_threads=cores)
+        t_snp += time.perf_counter() - t0
+        reps += 1
+    pair_rate = pairs * reps / t_snp
     # the sample doubles as a full-size parity check: the GPU's d / nn for these pairs must be bit-equal
     ri, ci = r.astype(np.int64), c.astype(np.int64)
     gd = dmat[:m, :m].cpu().numpy().astype(np.int64)[ri, ci]
     gn = nmat[:m, :m].cpu().numpy().astype(np.int64)[ri, ci]
     if not (np.array_equal(gd, d.astype(np.int64)) and np.array_equal(gn, nn.astype(np.int64))):
         raise SystemExit("PARITY FAILURE: GPU d/nn differ from the oracle on the %d x %d sample block" % (m, m))
-    return {"value": pairs / (t_snp + t_tc), "unit": "pairs/s", "cores": cores, "kind": "port",
-            "pairsnp_pairs_per_s": pairs / t_snp, "trans_dist_keys_per_s": nkeys / t_tc,
-            "sample": "first %d samples x %d sites of the same alignment = %d pairs: oracle pair loop, two passes, "
-                      "%d OpenMP threads (%.2f s) + serial memoised trans_dist over %d distinct (N, delta) keys "
-                      "(%.2f s); GPU d/nn bit-equal on this block" % (m, L, pairs, cores, t_snp, nkeys, t_tc)}
+    delta = np.abs(days_np[ri] - days_np[ci]).astype(np.float64) * 86400.0 / 31556952.0
+    # distinct keys in first-appearance order; time them in growing batches until the budget is spent
+    _, first = np.unique(np.stack([d.astype(np.float64), delta]), axis=1, return_index=True)
+    order = np.sort(first)
+    kd, kdel = d[order].astype(np.int32), delta[order]
+    done, t_tc, batch = 0, 0.0, 64
+    while done < len(order) and t_tc < args.cpu_seconds:
+        hi = min(len(order), done + batch)
+        t1 = time.perf_counter()
+        O.trans_dist(kd[done:hi], kdel[done:hi], args.lamb, args.beta, args.precision)
+        t_tc += time.perf_counter() - t1
+        done, batch = hi, batch * 2
+    key_rate = done / t_tc
+    pairs_total = n * (n - 1) // 2
+    value = pairs_total / (pairs_total / pair_rate + n_keys_full / key_rate)
+    return {"value": value, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "pairsnp_pairs_per_s": pair_rate, "pairsnp_threads": cores, "pairsnp_seconds": t_snp,
+            "trans_dist_keys_per_s": key_rate, "trans_dist_threads": 1, "trans_dist_seconds": t_tc,
+            "distinct_keys_full_matrix": n_keys_full,
+            "sample": "pair loop: first %d samples x %d sites of the same alignment = %d pairs, oracle pair loop (two passes), %d OpenMP "
+                      "threads, %d repeats = %.1f s; trans_dist: serial memoised, %d distinct (N, delta) keys of those pairs = %.1f s; "
+                      "value = pairs / (pairs / pair rate + %d distinct keys of the full matrix (GPU dedup) / key rate); GPU d/nn "
+                      "bit-equal on this block" % (m, L, pairs, cores, reps, t_snp, done, t_tc, n_keys_full)}
 
 
 if __name__ == "__main__":

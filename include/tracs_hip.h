@@ -148,6 +148,16 @@ int tracs_coo_fill(const uint32_t *dist, const uint32_t *ncomp, size_t ld, size_
                    size_t row_end, size_t col_begin, int32_t dist_threshold, const int64_t *offsets,
                    uint32_t *rows, uint32_t *cols, uint32_t *d, uint32_t *nn, void *stream);
 
+/* Threshold edges of a float64 panel (E(K) or P(direct) as written by tracs_trans_dist_dense; what `tracs cluster -D
+ * expectedK|direct -c T` keeps, tracs/cluster.py:110-112): cells (i, j) of the same cell set whose SNP distance was emitted
+ * (dist <= dist_threshold) and whose value is <= threshold, row-major.  Same two phases as tracs_coo_count/fill; vals (the
+ * kept values) may be NULL.  This is the per-rank edge list the multi-GPU clustering path gathers.       */
+int tracs_edges_count_f64(const double *val, const uint32_t *dist, size_t ld, size_t n, size_t row_begin, size_t row_end,
+                          size_t col_begin, int32_t dist_threshold, double threshold, int64_t *offsets, void *stream);
+int tracs_edges_fill_f64(const double *val, const uint32_t *dist, size_t ld, size_t n, size_t row_begin, size_t row_end,
+                         size_t col_begin, int32_t dist_threshold, double threshold, const int64_t *offsets, uint32_t *rows,
+                         uint32_t *cols, double *vals, void *stream);
+
 /* Recombination filter (src/pairsnp.hpp:251-318) on emitted pairs.  rows/cols: device uint32[n_pairs];
  * pos_off: device int64[n_pairs+1] = exclusive scan of the pairs' SNP distances; positions: device uint32
  * workspace of pos_off[n_pairs] entries (receives each pair's sorted SNP sites); found[t] = SNP bits seen

@@ -124,3 +124,33 @@ def test_multirank_driver_path_on_one_gpu():
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "VERIFY gathered == single-pass: True" in out.stderr
     assert '"n_gpus": 2' in out.stdout and '"scaling": "strong"' in out.stdout
+
+
+@pytest.mark.parametrize("mode", ["plain", "thresholded+filter+db"])
+def test_distance_cli_two_ranks_equals_one(mode, tmp_path):
+    """`tracs distance --gpus 2` (one process per rank, row-chunk partition, COO gather on rank 0; two gloo ranks sharing the
+    GPU here) writes byte for byte the CSV of the single-GPU run."""
+    import subprocess
+    from tracs_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n, L = 203, 30000
+    seqs = synth.alignment(n, L, seed=31, mu_lineage=3e-3, mu_sample=4e-4, p_n=0.02, p_partial=0.003)
+    names = ["s%03d" % i for i in range(n)]
+    fa = tmp_path / "aln_combined.fasta"
+    synth.write_fasta(str(fa), seqs[:150], names=names[:150])
+    db = tmp_path / "db.fasta"
+    synth.write_fasta(str(db), seqs[150:], names=names[150:])
+    iso, _ = synth.dates(n, seed=31, span_days=300)
+    meta = tmp_path / "dates.csv"
+    meta.write_text("name,date\n" + "".join("%s,%s\n" % (a, b) for a, b in zip(names, iso)))
+    extra = [] if mode == "plain" else ["-D", "60", "--filter", "--msa-db", str(db), "-K", "40"]
+    outs = []
+    for gpus in (1, 2):
+        out = tmp_path / ("out%d.csv" % gpus)
+        env = dict(os.environ, TRACS_DIST_BACKEND="gloo")
+        rc = subprocess.run([sys.executable, "-m", "tracs_amd", "distance", "--msa", str(fa), "--meta", str(meta), "-o", str(out),
+                             "--gpus", str(gpus)] + extra, capture_output=True, text=True, cwd=root, env=env, timeout=600)
+        assert rc.returncode == 0, rc.stdout[-2000:] + rc.stderr[-3000:]
+        outs.append(open(out).read())
+    assert outs[0] == outs[1]
+    assert outs[0].count("\n") > 1000

@@ -24,7 +24,7 @@ SYMBOLS = [
     "tracs_pairsnp_dense", "tracs_pairsnp_dense_thr", "tracs_coo_count", "tracs_coo_fill", "tracs_filter_recomb_device",
     "tracs_trans_dist_device", "tracs_trans_dist_dense", "tracs_trans_dist_dense2",
     "tracs_calculate_posteriors_device", "tracs_posterior_codes_device", "tracs_posterior_codes_cov_device",
-    "tracs_codes_to_iupac_device", "tracs_alignment_pack_codes", "tracs_alignment_pack_codes_batch",
+    "tracs_codes_to_iupac_device", "tracs_alignment_pack_codes", "tracs_alignment_pack_codes_batch", "tracs_edges_count_f64", "tracs_edges_fill_f64",
     "tracs_coverage_profile_device32", "tracs_posterior_codes_cov_device32", "tracs_consensus_codes_device32", "tracs_coverage_profile_device",
     "tracs_consensus_codes_device",
     "tracs_connected_components_device",
@@ -123,6 +123,10 @@ def load():
     L.tracs_coo_count.argtypes = [vp, sz, sz, sz, sz, sz, i32, vp, vp]
     L.tracs_coo_fill.restype = C.c_int
     L.tracs_coo_fill.argtypes = [vp, vp, sz, sz, sz, sz, sz, i32, vp, vp, vp, vp, vp, vp]
+    L.tracs_edges_count_f64.restype = C.c_int
+    L.tracs_edges_count_f64.argtypes = [vp, vp, sz, sz, sz, sz, sz, C.c_int32, dbl, vp, vp]
+    L.tracs_edges_fill_f64.restype = C.c_int
+    L.tracs_edges_fill_f64.argtypes = [vp, vp, sz, sz, sz, sz, sz, C.c_int32, dbl, vp, vp, vp, vp, vp]
     L.tracs_filter_recomb_device.restype = C.c_int
     L.tracs_filter_recomb_device.argtypes = [vp, vp, vp, sz, vp, vp, vp, vp, vp]
     L.tracs_trans_dist_device.restype = C.c_int
@@ -190,6 +194,7 @@ def load():
     L.tracs_debug_alignment_kernel.argtypes = [vp]
     L.tracs_debug_tile_variant.restype = C.c_char_p
     L.tracs_debug_mfma_shape.restype = C.c_char_p
+    L.tracs_debug_last_trans_dist_keys.restype = C.c_uint64
     L.tracs_debug_iupac_mask.restype = C.c_int
     L.tracs_debug_iupac_mask.argtypes = [C.c_int]
     _lib = L

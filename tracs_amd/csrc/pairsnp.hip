@@ -480,8 +480,50 @@ __global__ __launch_bounds__(64) void coo_fill_kernel(const unsigned *__restrict
     }
 }
 
-// ---------------------------------------------------------------------------------------
-// host side
+// Threshold edges of a float64 matrix (E(K) or P(direct) panels; `tracs cluster -D expectedK|direct`, tracs/cluster.py:110-112):
+// cells (i, j > i) whose SNP distance was emitted (dist <= dist_thr) and whose value is <= thr, row-major, one wave per row.
+__global__ __launch_bounds__(64) void edge_count_f64_kernel(const double *__restrict__ val, const unsigned *__restrict__ dist, size_t ld,
+                                                            unsigned n, unsigned row_begin, unsigned row_end, unsigned col_begin,
+                                                            int dist_thr, double thr, long long *__restrict__ counts)
+{
+    const unsigned i = row_begin + blockIdx.x;
+    if (i >= row_end) return;
+    long long c = 0;
+    for (unsigned j = max(col_begin, i + 1) + threadIdx.x; j < n; j += 64) {
+        const size_t o = (size_t)i * ld + j;
+        if ((long long)dist[o] <= (long long)dist_thr && val[o] <= thr) c++;
+    }
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if (threadIdx.x == 0) counts[blockIdx.x] = c;
+}
+
+__global__ __launch_bounds__(64) void edge_fill_f64_kernel(const double *__restrict__ val, const unsigned *__restrict__ dist, size_t ld,
+                                                           unsigned n, unsigned row_begin, unsigned row_end, unsigned col_begin,
+                                                           int dist_thr, double thr, const long long *__restrict__ offsets,
+                                                           unsigned *__restrict__ rows, unsigned *__restrict__ cols, double *__restrict__ vals)
+{
+    const unsigned i = row_begin + blockIdx.x;
+    if (i >= row_end) return;
+    long long o = offsets[blockIdx.x];
+    for (unsigned j0 = max(col_begin, i + 1); j0 < n; j0 += 64) {
+        const unsigned j = j0 + threadIdx.x;
+        bool keep = false;
+        double v = 0.0;
+        if (j < n) {
+            const size_t c = (size_t)i * ld + j;
+            v = val[c];
+            keep = (long long)dist[c] <= (long long)dist_thr && v <= thr;
+        }
+        const unsigned long long mask = __ballot(keep);
+        if (keep) {
+            const long long pos = o + __popcll(mask & ((1ull << threadIdx.x) - 1ull));
+            rows[pos] = i; cols[pos] = j;
+            if (vals) vals[pos] = v;
+        }
+        o += __popcll(mask);
+    }
+}
+
 
 
 // tile schedule: upper-trapezoid tiles of the block, supertile-major so that consecutive
@@ -913,6 +955,37 @@ int tracs_coo_fill(const uint32_t *dist, const uint32_t *ncomp, size_t ld, size_
     hipLaunchKernelGGL(coo_fill_kernel, dim3((unsigned)nrows), dim3(64), 0, stream, dist, ncomp, ld, (unsigned)n,
                        (unsigned)row_begin, (unsigned)row_end, (unsigned)col_begin, (int)thr,
                        reinterpret_cast<const long long *>(offsets), rows, cols, d, nn);
+    TRACS_HIP_CHECK(hipGetLastError());
+    return TRACS_OK;
+}
+
+int tracs_edges_count_f64(const double *val, const uint32_t *dist, size_t ld, size_t n, size_t row_begin, size_t row_end,
+                          size_t col_begin, int32_t dist_threshold, double threshold, int64_t *offsets, void *stream_)
+{
+    if (!val || !dist || !offsets) { set_error("tracs_edges_count_f64: NULL argument"); return TRACS_E_ARG; }
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (row_end > n) row_end = n;
+    const size_t nrows = row_end > row_begin ? row_end - row_begin : 0;
+    if (nrows)
+        hipLaunchKernelGGL(edge_count_f64_kernel, dim3((unsigned)nrows), dim3(64), 0, stream, val, dist, ld, (unsigned)n, (unsigned)row_begin,
+                           (unsigned)row_end, (unsigned)col_begin, (int)dist_threshold, threshold, reinterpret_cast<long long *>(offsets));
+    hipLaunchKernelGGL(scan_rows_kernel, dim3(1), dim3(1024), 0, stream, reinterpret_cast<long long *>(offsets), nrows);
+    TRACS_HIP_CHECK(hipGetLastError());
+    return TRACS_OK;
+}
+
+int tracs_edges_fill_f64(const double *val, const uint32_t *dist, size_t ld, size_t n, size_t row_begin, size_t row_end,
+                         size_t col_begin, int32_t dist_threshold, double threshold, const int64_t *offsets, uint32_t *rows,
+                         uint32_t *cols, double *vals, void *stream_)
+{
+    if (!val || !dist || !offsets || !rows || !cols) { set_error("tracs_edges_fill_f64: NULL argument"); return TRACS_E_ARG; }
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (row_end > n) row_end = n;
+    const size_t nrows = row_end > row_begin ? row_end - row_begin : 0;
+    if (!nrows) return TRACS_OK;
+    hipLaunchKernelGGL(edge_fill_f64_kernel, dim3((unsigned)nrows), dim3(64), 0, stream, val, dist, ld, (unsigned)n, (unsigned)row_begin,
+                       (unsigned)row_end, (unsigned)col_begin, (int)dist_threshold, threshold, reinterpret_cast<const long long *>(offsets),
+                       rows, cols, vals);
     TRACS_HIP_CHECK(hipGetLastError());
     return TRACS_OK;
 }

@@ -105,6 +105,20 @@ __global__ __launch_bounds__(256, (NBR * NBC > 4 ? 1 : 2)) void pairsnp_mfma_ker
             run += n_pad;
         }
     };
+    // The same loads one at a time, dealt round-robin to the waves (piece k of this wave = wave-instruction wave + 4 k of
+    // the stage): inside the loop one piece goes out per unit, so that its issue cost (tens of cycles for an LDS-DMA
+    // instruction) lands in the shadow of matrix instructions already queued instead of in a burst at the top of the stage.
+    constexpr int NLOAD = GC * NP * CH, LPW = (NLOAD + NW - 1) / NW;
+    auto stage_piece = [&](int gs, int b, int k) {
+        // a wave without a piece of its own repeats the stage's last one (same bytes to the same place): no branch in the unit
+        const int t = min(wave + k * NW, NLOAD - 1);
+        const int r = t / CH, c = t - r * CH;
+        const int s0 = c * 64;
+        // 32-bit element offset inside the stage (n_pad < 2^28 samples): one SGPR per piece instead of an address pair
+        const unsigned off = (unsigned)r * (unsigned)n_pad + (unsigned)(s0 < TJ ? j0 + s0 : i0 + (s0 - TJ));
+        __builtin_amdgcn_global_load_lds((glb_void_t *)(P + (size_t)gs * NP * n_pad + off + lane),
+                                         (lds_void_t *)&lds[b][r * TS + c * 64], 16, 0, 0);
+    };
     // this lane's sample inside a staged (group, plane) run, per row block / column block of the wave's tile; a lane takes
     // the two 32-site words 2 hk, 2 hk + 1 of the group (one ds_read_b64, conflict-free at the 16-byte sample stride)
     const int row_slot = TJ + wr * WI + lb, col_slot = wc * WJ + lb;
@@ -135,9 +149,13 @@ __global__ __launch_bounds__(256, (NBR * NBC > 4 ? 1 : 2)) void pairsnp_mfma_ker
     _Pragma("unroll") for (int cb = 0; cb < NBC; cb++)                                                      \
         _Pragma("unroll") for (int rb = 0; rb < NBR; rb++)                                                  \
             TRACS_MFMA_FP4(ACC[rb][cb], fp4_operand(OPS[rb]), fp4_operand(OPS[NBR + cb]), SC);
+#define TRACS_UNIT_STAGE(UNITS)                                                                             \
+    _Pragma("unroll") for (int k = 0; k < (LPW + (UNITS) - 1) / (UNITS); k++)                                \
+        if (piece < LPW) stage_piece(gn, buf ^ 1, piece++);
 #define TRACS_UNIT_SCHED(NVALU, NDS)                                                                        \
     _Pragma("unroll") for (int k = 0; k < NBR * NBC; k++) {                                                 \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                  \
+        if (k == 0) __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);                                      \
         __builtin_amdgcn_sched_group_barrier(0x002, ((NVALU) + NBR * NBC - 1) / (NBR * NBC), 0);            \
         if (k < (NDS)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                   \
     }                                                                                                       \
@@ -147,7 +165,9 @@ __global__ __launch_bounds__(256, (NBR * NBC > 4 ? 1 : 2)) void pairsnp_mfma_ker
     __syncthreads();
     int buf = 0;
     for (int gs = g_begin; gs < g_end; gs += GC) {
-        if (gs + GC < g_end) stage_glds(gs + GC, buf ^ 1);
+        // next stage to fetch; on the last stage the current one is fetched again (valid memory, never read): no branch in the body
+        const int gn = gs + GC < g_end ? gs + GC : gs;
+        int piece = 0;
         if constexpr (!GENERAL) {
             // units per 32-site step: v, x, y, z.  vq = the v operand, also the magnitude bits of the three sign operands.
             uint2 rawV[NB], rawXY[NB][2];               // this lane's two words (st = 0, 1) of the current group, per block
@@ -192,20 +212,24 @@ __global__ __launch_bounds__(256, (NBR * NBC > 4 ? 1 : 2)) void pairsnp_mfma_ker
                     // unit v: nn += v v'   | build x
                     TRACS_UNIT_MFMAS(accV, vq, 127)
                     make_sign(st, 0, op[0]);
+                    TRACS_UNIT_STAGE(GC * 8)
                     TRACS_UNIT_SCHED(NB * 7, 0)
                     // unit x | build y
                     TRACS_UNIT_MFMAS(accS, op[0], 127)
                     make_sign(st, 1, op[1]);
+                    TRACS_UNIT_STAGE(GC * 8)
                     TRACS_UNIT_SCHED(NB * 7, 0)
                     // unit y | build z; the V words of the next group are requested here (this group's are done with)
                     TRACS_UNIT_MFMAS(accS, op[1], 127)
                     make_sign(st, 2, op[0]);
                     if (next_group) load_v(gl + 1);
+                    TRACS_UNIT_STAGE(GC * 8)
                     TRACS_UNIT_SCHED(NB * 8, NB)
                     // unit z | build the next step's v; the X, Y words of the next group are requested
                     TRACS_UNIT_MFMAS(accS, op[0], 127)
                     if (more) make_v(st ^ 1);
                     if (next_group) load_xy(gl + 1);
+                    TRACS_UNIT_STAGE(GC * 8)
                     TRACS_UNIT_SCHED(NB * 7, NB * 2)
                 }
             }
@@ -234,18 +258,22 @@ __global__ __launch_bounds__(256, (NBR * NBC > 4 ? 1 : 2)) void pairsnp_mfma_ker
                 if (p < 4) { TRACS_UNIT_MFMAS(accS, op[0], 128) } else { TRACS_UNIT_MFMAS(accV, op[0], 128) }
                 TRACS_MAKE_RES(p, 1, op[1])
                 if (p + 1 < NPLANES) load_raw(p + 1);
+                TRACS_UNIT_STAGE(NPLANES * 4)
                 TRACS_UNIT_SCHED(NB * 4, NB * 2)
                 // residue 1 (1.0 * 1.0) | build residue 2
                 if (p < 4) { TRACS_UNIT_MFMAS(accS, op[1], 127) } else { TRACS_UNIT_MFMAS(accV, op[1], 127) }
                 TRACS_MAKE_RES(p, 2, op[0])
+                TRACS_UNIT_STAGE(NPLANES * 4)
                 TRACS_UNIT_SCHED(NB * 4, 0)
                 // residue 2 (2.0 * 2.0 * 2^-2) | build residue 3
                 if (p < 4) { TRACS_UNIT_MFMAS(accS, op[0], 126) } else { TRACS_UNIT_MFMAS(accV, op[0], 126) }
                 TRACS_MAKE_RES(p, 3, op[1])
+                TRACS_UNIT_STAGE(NPLANES * 4)
                 TRACS_UNIT_SCHED(NB * 8, 0)
                 // residue 3 | build the next plane's residue 0
                 if (p < 4) { TRACS_UNIT_MFMAS(accS, op[1], 126) } else { TRACS_UNIT_MFMAS(accV, op[1], 126) }
                 if (p + 1 < NPLANES) { TRACS_MAKE_RES(p + 1, 0, op[0]) }
+                TRACS_UNIT_STAGE(NPLANES * 4)
                 TRACS_UNIT_SCHED(NB * 4, 0)
             }
 #undef TRACS_MAKE_RES
@@ -255,6 +283,7 @@ __global__ __launch_bounds__(256, (NBR * NBC > 4 ? 1 : 2)) void pairsnp_mfma_ker
     }
 #undef TRACS_UNIT_MFMAS
 #undef TRACS_UNIT_SCHED
+#undef TRACS_UNIT_STAGE
 
     // C/D layout of the 32 x 32 instruction: register r of lane l = column l & 31, row (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
     auto cell_row = [&](int rb, int r) { return (unsigned)(i0 + wr * WI + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hk); };
@@ -333,16 +362,19 @@ static void launch_one(unsigned nwg, hipStream_t stream, const MfmaArgs &a)
 }
 
 struct ShapeEntry { MfmaShape s; MfmaLaunchFn cons, gen; };
-#define TRACS_SHAPE(R, C, GCC, WPC) {{#R "x" #C, R, C, 64 * (R), 64 * (C), GCC, 2, WPC}, launch_one<false, R, C, GCC>, launch_one<true, R, C, 2>}
+#define TRACS_SHAPE_N(NAME, R, C, GCC, WPC) {{NAME, R, C, 64 * (R), 64 * (C), GCC, 2, WPC}, launch_one<false, R, C, GCC>, launch_one<true, R, C, 2>}
+#define TRACS_SHAPE(R, C, GCC, WPC) TRACS_SHAPE_N(#R "x" #C, R, C, GCC, WPC)
 static const ShapeEntry kShapes[] = {
-    TRACS_SHAPE(3, 2, 2, 1),        // default: 192 x 128 pairs per workgroup, 192 accumulator AGPRs, one wave per SIMD
-    TRACS_SHAPE(2, 2, 1, 2),        // 128 x 128, two workgroups per CU (the round-1 shape)
+    TRACS_SHAPE(2, 2, 1, 2),        // default: 128 x 128 pairs per workgroup, two workgroups per CU (two waves per SIMD)
+    TRACS_SHAPE(3, 2, 2, 1),        // 192 x 128, 192 accumulator AGPRs, one wave per SIMD: fewer expansions per matrix instruction,
+                                    // but measured 18 % slower (profiles/r02/mfma_shape_sweep.txt): one wave cannot hide its own stalls
 #ifdef TRACS_MFMA_SWEEP
+    TRACS_SHAPE_N("2x2g2", 2, 2, 2, 2),   // consensus with two groups per stage (half the barriers)
     TRACS_SHAPE(2, 3, 2, 1),
-    TRACS_SHAPE(4, 2, 2, 1),
 #endif
 };
 #undef TRACS_SHAPE
+#undef TRACS_SHAPE_N
 
 int mfma_shape_count() { return (int)(sizeof(kShapes) / sizeof(kShapes[0])); }
 const MfmaShape &mfma_shape(int idx) { return kShapes[idx].s; }

@@ -413,13 +413,16 @@ int get_lgamma_table_for_filter(hipStream_t stream, const double **out) { return
 
 struct TcWorkspaceIds { enum { SLOTS = 0, ESLOT, SLOT_ID, NKEYS, KEY_ELEM, KEY_P0, KEY_EK, LONG_IDS }; };
 
+static unsigned long long g_last_keys = 0;        // distinct (N, delta) keys of the last entry-point call (bench.py reports it)
+constexpr size_t TD_MAX_ELEMS = 1ull << 31;       // elements per pass: element indices and slots are 32-bit
+
 template <class Src>
 static int run_trans_dist(const Src &src, size_t total, double lamb, double beta, double thr, int exp_p0, double *p0,
                           double *eK, hipStream_t stream)
 {
     if (total == 0) return TRACS_OK;
     DeviceCall guard(stream);
-    if (total >= 0xFFFFFFF0ull) { set_error("trans_dist: more than 2^32 elements per call"); return TRACS_E_ARG; }
+    if (total > TD_MAX_ELEMS) { set_error("trans_dist: more than 2^31 elements per pass (internal error)"); return TRACS_E_ARG; }
     const double *lg = nullptr;
     int rc = get_lgamma_table(stream, &lg);
     if (rc) return rc;
@@ -454,6 +457,7 @@ static int run_trans_dist(const Src &src, size_t total, double lamb, double beta
         }
         cap = (unsigned)std::min<unsigned long long>((unsigned long long)cap * 16ull, cap_max);
     }
+    g_last_keys += nk;
     if (nk == 0) return TRACS_OK;
     if ((rc = workspace_get(TcWorkspaceIds::KEY_ELEM, (size_t)nk * 4, reinterpret_cast<void **>(&key_elem)))) return rc;
     if ((rc = workspace_get(TcWorkspaceIds::KEY_P0, (size_t)nk * 8, reinterpret_cast<void **>(&key_p0)))) return rc;
@@ -483,12 +487,44 @@ using namespace tracs;
 
 extern "C" {
 
+unsigned long long tracs_debug_last_trans_dist_keys(void) { return g_last_keys; }
+
+// More than 2^31 elements go in passes (each with its own key table): an unthresholded `tracs distance --meta` run with
+// ~92 700 samples or more hands over > 4.29 x 10^9 pairs in one call (src/transcluster.hpp:263 simply loops).
 int tracs_trans_dist_device(const int32_t *snpdiff, const double *datediff, size_t n, double lamb, double beta,
                             double threshold_Ek, int exp_p0, double *p0, double *eK, void *stream)
 {
     if (n && (!snpdiff || !datediff || !p0 || !eK)) { set_error("tracs_trans_dist_device: NULL argument"); return TRACS_E_ARG; }
-    ArraySource src{snpdiff, datediff, n};
-    return run_trans_dist(src, n, lamb, beta, threshold_Ek, exp_p0, p0, eK, static_cast<hipStream_t>(stream));
+    g_last_keys = 0;
+    for (size_t o = 0; o < n; o += TD_MAX_ELEMS) {
+        const size_t cnt = std::min(TD_MAX_ELEMS, n - o);
+        ArraySource src{snpdiff + o, datediff + o, cnt};
+        const int rc = run_trans_dist(src, cnt, lamb, beta, threshold_Ek, exp_p0, p0 + o, eK + o, static_cast<hipStream_t>(stream));
+        if (rc) return rc;
+    }
+    return TRACS_OK;
+}
+
+// row panels of a dense block in passes of at most TD_MAX_ELEMS cells
+static int dense_passes(DenseSource src, double lamb, double beta, double thr, int exp_p0, double *p0, double *eK, hipStream_t stream)
+{
+    if (src.n == 0) return TRACS_OK;
+    if (src.n >= TD_MAX_ELEMS) { set_error("trans_dist: more than 2^31 samples"); return TRACS_E_ARG; }
+    const size_t rows_max = std::max<size_t>(1, TD_MAX_ELEMS / src.n);
+    const size_t ranges[2][2] = {{src.row_begin, src.row_end}, {src.row_begin2, src.row_end2}};
+    g_last_keys = 0;
+    // both panels in one pass (one key table) when they fit; else panel by panel, chunk by chunk
+    if ((ranges[0][1] - ranges[0][0]) + (ranges[1][1] - ranges[1][0]) <= rows_max)
+        return run_trans_dist(src, ((ranges[0][1] - ranges[0][0]) + (ranges[1][1] - ranges[1][0])) * src.n, lamb, beta, thr, exp_p0, p0, eK, stream);
+    for (int k = 0; k < 2; k++)
+        for (size_t r0 = ranges[k][0]; r0 < ranges[k][1]; r0 += rows_max) {
+            DenseSource part = src;
+            part.row_begin = r0; part.row_end = std::min(ranges[k][1], r0 + rows_max);
+            part.row_begin2 = part.row_end2 = 0;
+            const int rc = run_trans_dist(part, (part.row_end - part.row_begin) * src.n, lamb, beta, thr, exp_p0, p0, eK, stream);
+            if (rc) return rc;
+        }
+    return TRACS_OK;
 }
 
 int tracs_trans_dist_dense(const uint32_t *dist, size_t ld, size_t n, size_t row_begin, size_t row_end, size_t col_begin,
@@ -499,8 +535,7 @@ int tracs_trans_dist_dense(const uint32_t *dist, size_t ld, size_t n, size_t row
     if (row_end > n) row_end = n;
     if (row_begin >= row_end) return TRACS_OK;
     DenseSource src{dist, days, ld, n, row_begin, row_end, col_begin, dist_threshold};
-    return run_trans_dist(src, (row_end - row_begin) * n, lamb, beta, threshold_Ek, exp_p0, p0, eK,
-                          static_cast<hipStream_t>(stream));
+    return dense_passes(src, lamb, beta, threshold_Ek, exp_p0, p0, eK, static_cast<hipStream_t>(stream));
 }
 
 int tracs_trans_dist_dense2(const uint32_t *dist, size_t ld, size_t n, const size_t *row_ranges, int n_ranges, size_t col_begin,
@@ -512,8 +547,7 @@ int tracs_trans_dist_dense2(const uint32_t *dist, size_t ld, size_t n, const siz
     DenseSource src{dist, days, ld, n, std::min(row_ranges[0], n), std::min(row_ranges[1], n), col_begin, dist_threshold};
     if (n_ranges == 2) { src.row_begin2 = std::min(row_ranges[2], n); src.row_end2 = std::min(row_ranges[3], n); }
     if (src.row_end < src.row_begin || src.row_end2 < src.row_begin2) { set_error("tracs_trans_dist_dense2: bad range"); return TRACS_E_ARG; }
-    const size_t total = ((src.row_end - src.row_begin) + (src.row_end2 - src.row_begin2)) * n;
-    return run_trans_dist(src, total, lamb, beta, threshold_Ek, exp_p0, p0, eK, static_cast<hipStream_t>(stream));
+    return dense_passes(src, lamb, beta, threshold_Ek, exp_p0, p0, eK, static_cast<hipStream_t>(stream));
 }
 
 int tracs_trans_dist(const int32_t *snpdiff, const double *datediff, size_t n, double lamb, double beta,

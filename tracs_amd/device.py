@@ -20,6 +20,14 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+def _panel_ptr(t, base_row):
+    """Pointer the dense entry points can index with ABSOLUTE row numbers when `t` ([rows, ld]) only holds rows
+    base_row.. of the matrix (row panels of matrices too large to allocate whole)."""
+    if t is None:
+        return C.c_void_p(0)
+    return C.c_void_p(t.data_ptr() - int(base_row) * t.stride(0) * t.element_size())
+
+
 class Alignment:
     """A packed alignment resident in HBM (tracs_alignment)."""
 
@@ -100,34 +108,57 @@ class Alignment:
             pass
 
 
-def pairsnp_dense(aln, dist, ncomp=None, row_begin=0, row_end=None, col_begin=0, dist_threshold=None):
-    """dist/ncomp: torch.int32 (bit pattern uint32) [>=n, ld] device matrices, written for the cells
-    rows [row_begin,row_end) x cols [max(col_begin,i+1), n).  With dist_threshold, pairs beyond it may come back
-    negative (bit 31 set) with an unspecified ncomp: tiles stop early once all their pairs are past the threshold."""
+def pairsnp_dense(aln, dist, ncomp=None, row_begin=0, row_end=None, col_begin=0, dist_threshold=None, base_row=0):
+    """dist/ncomp: torch.int32 (bit pattern uint32) device matrices [rows, ld >= n] holding rows base_row.. of the pair matrix,
+    written for the cells rows [row_begin,row_end) x cols [max(col_begin,i+1), n).  With dist_threshold, pairs beyond it may
+    come back negative (bit 31 set) with an unspecified ncomp: tiles stop early once all their pairs are past the threshold."""
     row_end = aln.n if row_end is None else row_end
     ld = dist.stride(0)
+    assert base_row <= row_begin and row_end - base_row <= dist.shape[0]
     if dist_threshold is None:
-        _lib.check(aln._L.tracs_pairsnp_dense(aln._h, int(row_begin), int(row_end), int(col_begin), _ptr(dist), _ptr(ncomp),
-                                              int(ld), _stream()))
+        _lib.check(aln._L.tracs_pairsnp_dense(aln._h, int(row_begin), int(row_end), int(col_begin), _panel_ptr(dist, base_row),
+                                              _panel_ptr(ncomp, base_row), int(ld), _stream()))
     else:
-        _lib.check(aln._L.tracs_pairsnp_dense_thr(aln._h, int(row_begin), int(row_end), int(col_begin), _ptr(dist),
-                                                  _ptr(ncomp), int(ld), int(dist_threshold), _stream()))
+        _lib.check(aln._L.tracs_pairsnp_dense_thr(aln._h, int(row_begin), int(row_end), int(col_begin), _panel_ptr(dist, base_row),
+                                                  _panel_ptr(ncomp, base_row), int(ld), int(dist_threshold), _stream()))
 
 
-def coo_from_dense(dist, ncomp, n, dist_threshold=2147483647, row_begin=0, row_end=None, col_begin=0):
+def coo_from_dense(dist, ncomp, n, dist_threshold=2147483647, row_begin=0, row_end=None, col_begin=0, base_row=0):
     """-> rows, cols, d, nn (torch.int32 on device), row-major like the reference's output."""
     L = _lib.require_gpu()
     row_end = n if row_end is None else row_end
     nrows = max(0, row_end - row_begin)
     off = torch.zeros(nrows + 1, dtype=torch.int64, device=dist.device)
     ld = dist.stride(0)
-    _lib.check(L.tracs_coo_count(_ptr(dist), ld, n, row_begin, row_end, col_begin, int(dist_threshold), _ptr(off), _stream()))
+    _lib.check(L.tracs_coo_count(_panel_ptr(dist, base_row), ld, n, row_begin, row_end, col_begin, int(dist_threshold), _ptr(off), _stream()))
     total = int(off[nrows].item())
     out = [torch.empty(total, dtype=torch.int32, device=dist.device) for _ in range(4)]
     if total:
-        _lib.check(L.tracs_coo_fill(_ptr(dist), _ptr(ncomp), ld, n, row_begin, row_end, col_begin, int(dist_threshold),
-                                    _ptr(off), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(out[3]), _stream()))
+        _lib.check(L.tracs_coo_fill(_panel_ptr(dist, base_row), _panel_ptr(ncomp, base_row), ld, n, row_begin, row_end, col_begin,
+                                    int(dist_threshold), _ptr(off), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(out[3]), _stream()))
     return out
+
+
+def edges_from_dense_f64(val, dist, n, threshold, dist_threshold=2147483647, row_begin=0, row_end=None, col_begin=0, base_row=0,
+                         with_values=False):
+    """Cells (i, j > i) with dist <= dist_threshold and val <= threshold, row-major -> rows, cols (torch.int32)[, values f64]:
+    the edges `tracs cluster -D expectedK|direct -c threshold` keeps (tracs/cluster.py:110-112), straight from device panels."""
+    L = _lib.require_gpu()
+    row_end = n if row_end is None else row_end
+    nrows = max(0, row_end - row_begin)
+    off = torch.zeros(nrows + 1, dtype=torch.int64, device=val.device)
+    ld = val.stride(0)
+    assert dist.stride(0) == ld
+    _lib.check(L.tracs_edges_count_f64(_panel_ptr(val, base_row), _panel_ptr(dist, base_row), ld, n, row_begin, row_end, col_begin,
+                                       int(dist_threshold), float(threshold), _ptr(off), _stream()))
+    total = int(off[nrows].item())
+    rows = torch.empty(total, dtype=torch.int32, device=val.device)
+    cols = torch.empty(total, dtype=torch.int32, device=val.device)
+    vals = torch.empty(total, dtype=torch.float64, device=val.device) if with_values else None
+    if total:
+        _lib.check(L.tracs_edges_fill_f64(_panel_ptr(val, base_row), _panel_ptr(dist, base_row), ld, n, row_begin, row_end, col_begin,
+                                          int(dist_threshold), float(threshold), _ptr(off), _ptr(rows), _ptr(cols), _ptr(vals), _stream()))
+    return (rows, cols, vals) if with_values else (rows, cols)
 
 
 def filter_recomb_device(aln, rows, cols, d):
@@ -156,14 +187,14 @@ def trans_dist_device(snpdiff, datediff, lamb, beta, threshold_Ek, exp_p0=False)
 
 
 def trans_dist_dense(dist, n, days, lamb, beta, threshold_Ek, p0, eK, exp_p0=True, dist_threshold=2147483647,
-                     row_begin=0, row_end=None, col_begin=0):
+                     row_begin=0, row_end=None, col_begin=0, base_row=0):
     L = _lib.require_gpu()
     row_end = n if row_end is None else row_end
     ld = dist.stride(0)
     assert p0.stride(0) == ld and eK.stride(0) == ld
-    _lib.check(L.tracs_trans_dist_dense(_ptr(dist), ld, n, row_begin, row_end, col_begin, int(dist_threshold), _ptr(days),
-                                        float(lamb), float(beta), float(threshold_Ek), int(exp_p0), _ptr(p0), _ptr(eK),
-                                        _stream()))
+    _lib.check(L.tracs_trans_dist_dense(_panel_ptr(dist, base_row), ld, n, row_begin, row_end, col_begin, int(dist_threshold), _ptr(days),
+                                        float(lamb), float(beta), float(threshold_Ek), int(exp_p0), _panel_ptr(p0, base_row),
+                                        _panel_ptr(eK, base_row), _stream()))
 
 
 def trans_dist_dense_ranges(dist, n, days, lamb, beta, threshold_Ek, p0, eK, ranges, exp_p0=True,

@@ -53,6 +53,9 @@ def distance_parser(parser):
                         help="number of threads to use (default=1; the pair loop runs on the GPU)")
     parser.add_argument("--loglevel", type=str.upper, default="INFO",
                         choices=["DEBUG", "INFO", "WARNING", "ERROR", "CRITICAL"], help="Set the logging threshold.")
+    parser.add_argument("--gpus", dest="gpus", type=check_positive_int, default=1,
+                        help="number of GPUs of this node to spread the pair matrix over (default=1; one process per GPU, "
+                             "row-panel partition, results gathered on the first; not in the reference)")
     parser.set_defaults(func=distance)
     return parser
 
@@ -94,19 +97,69 @@ def _append_rows(path, names, rows, cols, snpd, filt, ncomp, ddiff, tdist, ek, k
     return written.value
 
 
+def _cli_of(args):
+    """The command line that reproduces `args` (the multi-GPU path re-launches itself, one process per GPU)."""
+    argv = ["distance", "--msa"] + list(args.msa_files) + ["-o", args.output_file, "-D", str(args.snp_threshold),
+                                                            "--clock_rate", repr(float(args.clock_rate)), "--trans_rate", repr(float(args.trans_rate)),
+                                                            "--precision", repr(float(args.precision)), "-t", str(args.n_cpu),
+                                                            "--loglevel", args.loglevel, "--gpus", str(args.gpus)]
+    if args.msa_db is not None:
+        argv += ["--msa-db", args.msa_db]
+    if args.metadata is not None:
+        argv += ["--meta", args.metadata]
+    if args.recomb_filter:
+        argv += ["--filter"]
+    if args.trans_threshold is not None:
+        argv += ["-K", str(args.trans_threshold)]
+    return argv
+
+
+def _pairs_multi_gpu(msas, args, ctx):
+    """pairsnp's six outputs for one MSA, computed by all ranks and assembled on rank 0 (None on the others)."""
+    from . import device as dev
+    from . import multigpu, partition
+    dist, rank, world, _ = ctx
+    aln = dev.Alignment.from_fasta(msas)                  # every rank parses and packs: each holds the whole alignment
+    n = aln.n
+    i_end, j_start = (n, 0) if len(msas) == 1 else (aln.n_first, aln.n_first)      # src/pairsnp.hpp:348-360
+    parts = multigpu.pairs_of_rank(aln, i_end, j_start, args.snp_threshold, rank, world, args.recomb_filter)
+    got = partition.gather_coo(parts, world, rank, dist)
+    names = aln.names
+    aln.close()
+    if rank != 0:
+        return None
+    host = [g.cpu().numpy().astype(np.uint32).astype(np.uint64) for g in got]
+    filt = host[4] if args.recomb_filter else np.zeros(len(host[0]), np.uint64)     # filter off: `len` zeros (:452)
+    return host[0], host[1], host[2], names, filt, host[3]
+
+
 def distance(args):
+    from . import multigpu
+    if getattr(args, "gpus", 1) > 1 and not multigpu.in_worker():
+        rc = multigpu.spawn("tracs_amd", _cli_of(args), args.gpus)     # before anything here has touched the GPU
+        if rc:
+            raise SystemExit(rc)
+        return
+    ctx = multigpu.init() if multigpu.in_worker() else None
+    lead = ctx is None or ctx[1] == 0
     logging.basicConfig(level=args.loglevel, format="%(asctime)s - %(levelname)s - %(message)s",
                         datefmt="%Y-%m-%d %H:%M:%S")
     logging.info("Loading metadata...")
     dates = _read_dates(args.metadata) if args.metadata is not None else None
     logging.info("Estimating transmission distances...")
-    with open(args.output_file, "w") as out:
-        out.write(HEADER)
+    if lead:
+        with open(args.output_file, "w") as out:
+            out.write(HEADER)
     for msa in args.msa_files:
         logging.info("Calculating pairwise snp distances for %s", msa)
         msas = [msa, args.msa_db] if args.msa_db is not None else [msa]
-        rows, cols, snpd, names, filt, ncomp = pairsnp_arrays(fasta=msas, n_threads=args.n_cpu, dist=args.snp_threshold,
-                                                              filter=args.recomb_filter)
+        if ctx is None:
+            res = pairsnp_arrays(fasta=msas, n_threads=args.n_cpu, dist=args.snp_threshold, filter=args.recomb_filter)
+        else:
+            res = _pairs_multi_gpu(msas, args, ctx)
+        if not lead:
+            continue
+        rows, cols, snpd, names, filt, ncomp = res
         with_dates = dates is not None and len(rows) > 0
         tdist = ek = ddiff = None
         if with_dates:
@@ -122,6 +175,9 @@ def distance(args):
         ref = os.path.basename(msa).split(".")[0].replace("_combined", "")      # (:208-209)
         _append_rows(args.output_file, names, rows, cols, snpd, filt, ncomp, ddiff, tdist, ek,
                      args.trans_threshold if with_dates else None, ref)
+    if ctx is not None:
+        ctx[0].barrier()
+        ctx[0].destroy_process_group()
 
 
 def main():

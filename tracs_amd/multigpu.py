@@ -1,0 +1,128 @@
+"""One process per GPU: the product-level multi-GPU path of `tracs distance` (and of distance -> threshold clustering).
+
+north_star / SURVEY.md 8e: the N x N pair space is block-partitioned over the GPUs of one node (tracs_amd/partition.py: 2P row
+chunks, fold pairing), every rank holds the whole packed alignment, there is no collective during compute; what travels are
+the per-rank results -- here the thresholded COO lists (rows, cols, d, nn[, filtered d]) in row-major chunk order, i.e. exactly
+the tuple src/pairsnp.hpp:451-457 returns, assembled on rank 0 -- or, for clustering, only the (i, j) of the edges that pass
+the threshold (tracs/cluster.py:110-112).  P(direct) and E(K) never travel: rank 0 derives them from the gathered d and the
+dates (tc gather is ~1 ms; the f64 values would be 2/3 of the bytes).
+
+`spawn()` re-launches the current command under torch.distributed.run BEFORE anything has touched the GPU (a process that has
+initialised HIP must not exec); the workers find RANK / LOCAL_RANK / WORLD_SIZE in the environment.
+"""
+import os
+import socket
+import subprocess
+import sys
+
+from . import partition
+
+
+def in_worker():
+    return int(os.environ.get("WORLD_SIZE", "1")) > 1 and "RANK" in os.environ
+
+
+def spawn(module, argv, gpus):
+    """python -m torch.distributed.run --nproc-per-node gpus -m <module> <argv...>; returns the exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(gpus)), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", module] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def init():
+    """-> (torch.distributed, rank, world, device).  Backend: RCCL ("nccl") when every rank has its own GPU, gloo when ranks
+    share a device (smoke tests) or TRACS_DIST_BACKEND says so."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    ndev = torch.cuda.device_count()
+    torch.cuda.set_device(local % max(ndev, 1))
+    device = torch.device("cuda", local % max(ndev, 1))
+    backend = os.environ.get("TRACS_DIST_BACKEND", "nccl" if ndev >= world else "gloo")
+    if not dist.is_initialized():
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
+    return dist, rank, world, device
+
+
+def panel_rows(n, budget_bytes=1 << 30):
+    """Rows per dense panel so that one uint32 panel stays within budget_bytes (a multiple of 64, at least 64)."""
+    return max(64, (budget_bytes // (4 * max(n, 1))) // 64 * 64)
+
+
+def pairs_of_rank(aln, i_end, j_start, dist_threshold, rank, world, recomb_filter=False, align=64):
+    """This rank's share of pairsnp's output: {chunk: (rows, cols, d, nn[, filt])} int32 device tensors, row-major inside
+    each chunk.  Rows i < i_end, columns j >= max(j_start, i + 1) (one file: i_end = n, j_start = 0; two files: i_end =
+    j_start = n0, src/pairsnp.hpp:348-360)."""
+    import torch
+    from . import device as dev
+    n = aln.n
+    rows_max = panel_rows(n)
+    cs, _ = partition.row_chunks(i_end, world, align)
+    dev_ = torch.device("cuda", torch.cuda.current_device())
+    dpan = torch.empty((min(rows_max, max(cs, 64)), n), dtype=torch.int32, device=dev_)
+    npan = torch.empty_like(dpan)
+    parts = {}
+    k = 5 if recomb_filter else 4
+    for c in sorted(set(partition.rank_chunks(rank, world))):
+        r0c, r1c = c * cs, min(i_end, (c + 1) * cs)
+        acc = [[] for _ in range(k)]
+        for r0 in range(r0c, max(r0c, r1c), dpan.shape[0]):
+            r1 = min(r1c, r0 + dpan.shape[0])
+            dev.pairsnp_dense(aln, dpan, npan, row_begin=r0, row_end=r1, col_begin=j_start, dist_threshold=dist_threshold, base_row=r0)
+            got = dev.coo_from_dense(dpan, npan, n, dist_threshold, row_begin=r0, row_end=r1, col_begin=j_start, base_row=r0)
+            if recomb_filter:
+                got = list(got) + [dev.filter_recomb_device(aln, got[0], got[1], got[2])[0].clone()]
+            for t in range(k):
+                acc[t].append(got[t])
+        parts[c] = tuple(torch.cat(a) if a else torch.empty(0, dtype=torch.int32, device=dev_) for a in acc)
+    return parts
+
+
+def edges_of_rank(dist_fn, n, days, lamb, beta, precision, column, threshold, rank, world, dist_threshold=2147483647, align=64):
+    """Threshold edges of this rank's row chunks for clustering on a transmission column (`tracs cluster -D direct|expectedK`):
+    dist_fn(dpan, npan, r0, r1) fills the SNP panel rows [r0, r1) (pairsnp_dense on an alignment, or a synthetic source),
+    transcluster runs on the panel, and only the (i, j) with value <= threshold leave the device.
+    -> {chunk: (rows, cols)} int32 device tensors."""
+    import torch
+    from . import device as dev
+    rows_max = panel_rows(n, 1 << 29)
+    cs, _ = partition.row_chunks(n, world, align)
+    dev_ = torch.device("cuda", torch.cuda.current_device())
+    rows_p = min(rows_max, max(cs, 64))
+    dpan = torch.empty((rows_p, n), dtype=torch.int32, device=dev_)
+    npan = torch.empty_like(dpan)
+    ppan = torch.empty((rows_p, n), dtype=torch.float64, device=dev_)
+    epan = torch.empty_like(ppan)
+    parts = {}
+    for c in sorted(set(partition.rank_chunks(rank, world))):
+        r0c, r1c = c * cs, min(n, (c + 1) * cs)
+        acc = [[], []]
+        for r0 in range(r0c, max(r0c, r1c), rows_p):
+            r1 = min(r1c, r0 + rows_p)
+            dist_fn(dpan, npan, r0, r1)
+            dev.trans_dist_dense(dpan, n, days, lamb, beta, precision, ppan, epan, exp_p0=True, dist_threshold=dist_threshold,
+                                 row_begin=r0, row_end=r1, base_row=r0)
+            val = epan if column == "expectedK" else ppan
+            e = dev.edges_from_dense_f64(val, dpan, n, threshold, dist_threshold, row_begin=r0, row_end=r1, base_row=r0)
+            acc[0].append(e[0]); acc[1].append(e[1])
+        parts[c] = tuple(torch.cat(a) if a else torch.empty(0, dtype=torch.int32, device=dev_) for a in acc)
+    return parts
+
+
+def cluster_edges(parts, n_nodes, rank, world, dist):
+    """Gather the per-rank edge lists to rank 0 and label the connected components there (SciPy's numbering,
+    tracs/cluster.py:126-129).  -> (n_components, labels int32 device tensor) on rank 0, None elsewhere."""
+    from . import device as dev
+    got = partition.gather_coo(parts, world, rank, dist)
+    if rank != 0:
+        return None
+    return dev.connected_components_device(got[0], got[1], n_nodes)

@@ -63,3 +63,64 @@ def gather_panels(mats, n, rank, world, dist, align=64, async_op=False):
             if async_op:
                 works.append(w)
     return works
+
+
+def chunk_owner(c, world):
+    """Rank that owns row chunk c (0 <= c < 2 * world) under the fold pairing."""
+    return c if c < world else 2 * world - 1 - c
+
+
+def rank_chunk_ranges(n, rank, world, align=64):
+    """[(chunk index, r0, r1), ...] of `rank`, clipped to n, empty chunks dropped, ascending."""
+    cs, _ = row_chunks(n, world, align)
+    out = []
+    for c in sorted(rank_chunks(rank, world)):
+        r0, r1 = c * cs, min(n, (c + 1) * cs)
+        if r0 < r1:
+            out.append((c, r0, r1))
+    return out
+
+
+def gather_coo(parts, world, rank, dist, dst=0):
+    """Variable-length gather of per-chunk COO lists to rank `dst`, in CHUNK ORDER (= row-major order of the whole pair
+    matrix, src/pairsnp.hpp:451-455): the multi-GPU form of `tracs distance` and of the thresholded edge lists that feed the
+    clustering (the counts first, then the variable-length payload).
+
+    parts: {chunk index: tuple of K equally long 1-D tensors}, one entry for EVERY chunk this rank owns (empty tensors for a
+    chunk without pairs; same K, dtypes and device on every rank): rows/cols/d/nn, or the i/j of threshold edges.
+    Returns on dst a list of K concatenated tensors, None elsewhere.  One all-reduce carries the 2*world counts (each chunk
+    has one owner, so the sum IS the gather), then point-to-point payloads (dist.send / dist.recv: RCCL over xGMI between
+    GPUs, gloo in the CPU tests)."""
+    import torch
+    nchunk = 2 * world
+    mine = sorted(set(rank_chunks(rank, world)))
+    assert sorted(parts) == mine, "gather_coo: pass one entry per owned chunk"
+    proto = parts[mine[0]]
+    k = len(proto)
+    counts = torch.zeros(nchunk, dtype=torch.int64, device=proto[0].device)
+    for c, tensors in parts.items():
+        assert len(tensors) == k and len({int(t.numel()) for t in tensors}) == 1
+        counts[c] = tensors[0].numel()
+    if world > 1:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    counts = [int(x) for x in counts.cpu().tolist()]
+    out = [[] for _ in range(k)]
+    for c in range(nchunk):
+        q = chunk_owner(c, world)
+        if counts[c] == 0:
+            continue
+        if q == dst:
+            if rank == dst:
+                for t in range(k):
+                    out[t].append(parts[c][t])
+        elif rank == q:
+            for t in range(k):
+                dist.send(parts[c][t].contiguous(), dst=dst)
+        elif rank == dst:
+            for t in range(k):
+                buf = torch.empty(counts[c], dtype=proto[t].dtype, device=proto[t].device)
+                dist.recv(buf, src=q)
+                out[t].append(buf)
+    if rank != dst:
+        return None
+    return [torch.cat(out[t]) if out[t] else torch.empty(0, dtype=proto[t].dtype, device=proto[t].device) for t in range(k)]
