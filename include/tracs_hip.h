@@ -34,6 +34,7 @@ extern "C" {
 #define TRACS_E_OPEN       -5   /* file cannot be opened (the reference does not diagnose this) */
 #define TRACS_E_HIP        -6   /* HIP runtime error / no device */
 #define TRACS_E_NOMEM      -7
+#define TRACS_E_INTERRUPTED -8  /* "Interrupted by user!" (SIGINT during tracs_pairsnp; pairsnp.hpp:434-441 exits instead) */
 
 const char *tracs_last_error(void);
 /* ABI version of this header; bumped on any signature change. */

@@ -204,6 +204,8 @@ def load():
 def check(rc):
     """Raise RuntimeError with the library's message (the reference raises RuntimeError with the
     same strings: src/pairsnp.hpp:86,96-97,342) on a non-zero return code."""
+    if rc == -8:                                   # TRACS_E_INTERRUPTED: Ctrl-C arrived while the library held the call
+        raise KeyboardInterrupt("Interrupted by user!")
     if rc != 0:
         msg = load().tracs_last_error()
         raise RuntimeError(msg.decode("utf-8", "replace") if msg else "libtracs_hip error %d" % rc)

@@ -7,6 +7,7 @@
 #include "fasta.h"
 
 #include <algorithm>
+#include <csignal>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -83,6 +84,27 @@ static void widen_append(std::vector<uint64_t> &dst, const unsigned *src, size_t
     }
     for (auto &th : pool) th.join();
 }
+
+// Ctrl-C during tracs_pairsnp (src/pairsnp.hpp:21-25,326,385-388,434-441: the reference installs its own SIGINT handler, lets
+// the loop drain, prints "Interrupted by user!" and exit(1)s).  Here the handler only lives for the duration of the call, the
+// panel loop looks at the flag between row panels (a running kernel cannot be stopped: <= one panel, ~0.4 s at 10 000 x 5 Mbp),
+// and the call returns TRACS_E_INTERRUPTED with the reference's message; the Python layer raises KeyboardInterrupt.
+static volatile sig_atomic_t g_sigint = 0;
+static void on_sigint(int) { g_sigint = 1; }
+struct SigintScope {
+    struct sigaction old;
+    bool installed;
+    SigintScope()
+    {
+        g_sigint = 0;
+        struct sigaction sa;
+        std::memset(&sa, 0, sizeof(sa));
+        sa.sa_handler = on_sigint;
+        sigemptyset(&sa.sa_mask);
+        installed = sigaction(SIGINT, &sa, &old) == 0;
+    }
+    ~SigintScope() { if (installed) (void)sigaction(SIGINT, &old, nullptr); }
+};
 
 struct tracs_pairsnp_result {
     size_t nseq = 0, L = 0;
@@ -177,6 +199,7 @@ int tracs_pairsnp(const char *const *fasta, int n_fasta, int n_threads, int dist
     if (!out) { set_error("tracs_pairsnp: out is NULL"); return TRACS_E_ARG; }
     *out = nullptr;
     if (n_fasta < 1 || n_fasta > 2 || !fasta) { set_error("Invalid number of fasta files!"); return TRACS_E_ARG; }   // :340-343
+    SigintScope sigint;
     tracs_alignment *a = nullptr;
     char *names = nullptr;
     size_t names_bytes = 0, n0 = 0;
@@ -211,6 +234,7 @@ int tracs_pairsnp(const char *const *fasta, int n_fasta, int n_threads, int dist
         size_t cap = 0;
         std::vector<unsigned> h32;
         for (size_t r0 = 0; r0 < i_end; r0 += panel) {
+            if (g_sigint) { cleanup(); delete res; set_error("Interrupted by user!"); return TRACS_E_INTERRUPTED; }
             const size_t r1 = std::min(i_end, r0 + panel);
             // the dense block is addressed as base[(i) * ld + j] with i absolute: shift the base
             unsigned *bd = d_dist - r0 * n, *bn = d_nn - r0 * n;

@@ -7,8 +7,8 @@
 //   Minka fixed point  alpha_k <- alpha_k * sum_i[psi(x_ik + alpha_k) - psi(alpha_k)] / sum_i[psi(n_i + a0) - psi(a0)]
 //   until sum|delta| < tol, clamping at 1e-16 (:55-68), or the leave-one-out update until max|delta| < tol (:42-54);
 //   result sorted descending (:70).
-// The per-iteration sums over the polymorphic sites are block reductions (deterministic two-stage); the 4-element
-// update runs in a one-wave kernel so the whole fit stays on the device; the host only polls the "converged" flag.
+// The per-iteration sums over the polymorphic sites are block reductions (deterministic: site-ordered compaction, fixed two-stage tree); the
+// 4-element update runs in a one-wave kernel so the whole fit stays on the device; the host only polls the "converged" flag.
 #include "common.h"
 
 namespace tracs {
@@ -32,30 +32,71 @@ struct DmState {
     int done, iters, n_rows;
 };
 
-// filter + select + sort: writes kept rows (ascending) to `rows`, counts them
-__global__ void dm_select_kernel(const double *__restrict__ counts, size_t L, int K, double filt, int use_filt,
-                                 double *__restrict__ rows, unsigned *__restrict__ n_kept)
+// filter + select + sort: kept rows (each sorted ascending) go to `rows` IN SITE ORDER -- a deterministic compaction (every
+// block owns a contiguous run of sites; PASS 0 counts its kept rows, dm_block_offsets_kernel scans the block counts, PASS 1
+// writes at block offset + rank inside the block), so the f64 summation order of dm_sums_kernel, and with it every bit of the
+// fitted alphas and the iteration count, is the same on every run.
+template <int PASS>
+__global__ __launch_bounds__(256) void dm_select_kernel(const double *__restrict__ counts, size_t L, int K, double filt, int use_filt,
+                                                        size_t chunk, unsigned *__restrict__ block_cnt,
+                                                        const unsigned *__restrict__ block_off, double *__restrict__ rows)
 {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (size_t)gridDim.x * blockDim.x) {
+    __shared__ unsigned wave_tot[4];
+    const size_t begin = (size_t)blockIdx.x * chunk, end = min(L, begin + chunk);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned running = PASS ? block_off[blockIdx.x] : 0u;
+    for (size_t base = begin; base < end; base += 256) {
+        const size_t i = base + threadIdx.x;
         double v[DK];
-        double tot = 0.0;
-        for (int k = 0; k < K; k++) { v[k] = counts[i * K + k]; tot += v[k]; }
-        if (use_filt)
-            for (int k = 0; k < K; k++)
-                if (v[k] / tot < filt) v[k] = 0.0;       // NaN (0/0) compares false: row unchanged, as in numpy
-        int nz = 0;
-        for (int k = 0; k < K; k++) nz += v[k] != 0.0;
-        if (nz > 1) {
+        bool keep = false;
+        if (i < end) {
+            double tot = 0.0;
+            for (int k = 0; k < K; k++) { v[k] = counts[i * K + k]; tot += v[k]; }
+            if (use_filt)
+                for (int k = 0; k < K; k++)
+                    if (v[k] / tot < filt) v[k] = 0.0;       // NaN (0/0) compares false: row unchanged, as in numpy
+            int nz = 0;
+            for (int k = 0; k < K; k++) nz += v[k] != 0.0;
+            keep = nz > 1;
+        }
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) wave_tot[wave] = (unsigned)__popcll(m);
+        __syncthreads();
+        unsigned before = 0, total = 0;
+        for (int w = 0; w < 4; w++) { if (w < wave) before += wave_tot[w]; total += wave_tot[w]; }
+        if (PASS && keep) {
             for (int a = 1; a < K; a++) {                  // ascending insertion sort
                 const double x = v[a];
                 int b = a;
                 while (b > 0 && v[b - 1] > x) { v[b] = v[b - 1]; b--; }
                 v[b] = x;
             }
-            const unsigned o = atomicAdd(n_kept, 1u);
-            for (int k = 0; k < K; k++) rows[(size_t)o * K + k] = v[k];
+            const size_t o = (size_t)running + before + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            for (int k = 0; k < K; k++) rows[o * K + k] = v[k];
         }
+        running += total;
+        __syncthreads();
     }
+    if (!PASS && threadIdx.x == 0) block_cnt[blockIdx.x] = running;
+}
+
+// exclusive scan of the (<= 1024) block counts by one wave; the grand total is the number of kept rows
+__global__ __launch_bounds__(64) void dm_block_offsets_kernel(const unsigned *__restrict__ block_cnt, int nblocks, unsigned *__restrict__ block_off,
+                                                              unsigned *__restrict__ n_kept)
+{
+    unsigned carry = 0;
+    for (int base = 0; base < nblocks; base += 64) {
+        const int b = base + (int)threadIdx.x;
+        const unsigned c = b < nblocks ? block_cnt[b] : 0u;
+        unsigned incl = c;
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned t = __shfl_up(incl, off, 64);
+            if ((int)threadIdx.x >= off) incl += t;
+        }
+        if (b < nblocks) block_off[b] = carry + incl - c;
+        carry += __shfl(incl, 63, 64);
+    }
+    if (threadIdx.x == 0) *n_kept = carry;
 }
 
 // mode 0: column sums (for the initial alpha); mode 1: FPI sums; mode 2: LOO sums
@@ -149,7 +190,7 @@ int tracs_find_dirichlet_priors_device(const double *counts, size_t L, size_t K,
     unsigned *n_kept = nullptr;
     DmState *st = nullptr;
     int rc;
-    enum { WS_ROWS = 32, WS_PARTIAL, WS_NKEPT, WS_STATE };
+    enum { WS_ROWS = 32, WS_PARTIAL, WS_NKEPT, WS_STATE, WS_BLOCKS };
     if ((rc = workspace_get(WS_ROWS, std::max<size_t>(L, 1) * K * 8, reinterpret_cast<void **>(&rows)))) return rc;
     if ((rc = workspace_get(WS_PARTIAL, (size_t)DM_BLOCKS * (DK + 1) * 8, reinterpret_cast<void **>(&partial)))) return rc;
     if ((rc = workspace_get(WS_NKEPT, 64, reinterpret_cast<void **>(&n_kept)))) return rc;
@@ -157,9 +198,17 @@ int tracs_find_dirichlet_priors_device(const double *counts, size_t L, size_t K,
     TRACS_HIP_CHECK(hipMemsetAsync(n_kept, 0, 4, stream));
     TRACS_HIP_CHECK(hipMemsetAsync(st, 0, sizeof(DmState), stream));
     if (L) {
-        const unsigned blocks = (unsigned)std::min<size_t>((L + 255) / 256, 4096);
-        hipLaunchKernelGGL(dm_select_kernel, dim3(blocks), dim3(256), 0, stream, counts, L, (int)K, error_filt_threshold,
-                           error_filt_threshold >= 0 ? 1 : 0, rows, n_kept);
+        const unsigned blocks = (unsigned)std::min<size_t>((L + 255) / 256, 1024);
+        const size_t chunk = ((L + blocks - 1) / blocks + 255) / 256 * 256;           // contiguous sites per block, whole tiles
+        unsigned *block_cnt = nullptr;
+        if ((rc = workspace_get(WS_BLOCKS, 2 * 1024 * sizeof(unsigned), reinterpret_cast<void **>(&block_cnt)))) return rc;
+        unsigned *block_off = block_cnt + 1024;
+        const int use_filt = error_filt_threshold >= 0 ? 1 : 0;
+        hipLaunchKernelGGL(dm_select_kernel<0>, dim3(blocks), dim3(256), 0, stream, counts, L, (int)K, error_filt_threshold, use_filt, chunk,
+                           block_cnt, block_off, rows);
+        hipLaunchKernelGGL(dm_block_offsets_kernel, dim3(1), dim3(64), 0, stream, block_cnt, (int)blocks, block_off, n_kept);
+        hipLaunchKernelGGL(dm_select_kernel<1>, dim3(blocks), dim3(256), 0, stream, counts, L, (int)K, error_filt_threshold, use_filt, chunk,
+                           block_cnt, block_off, rows);
     }
     unsigned M = 0;
     TRACS_HIP_CHECK(hipMemcpyAsync(&M, n_kept, 4, hipMemcpyDeviceToHost, stream));

@@ -182,7 +182,6 @@ __global__ __launch_bounds__(256) void gs_site_kernel(const uint4 *__restrict__ 
 }
 
 // Row i of the pair matrix: T1 + T2 accumulated in LDS, then added to dist; ncomp gets its c_i, c_j terms.
-// A quarter wave (16 lanes) takes one special site of sample i at a time and walks that site's lists.
 __global__ __launch_bounds__(1024) void general_fixup_kernel(const unsigned long long *__restrict__ s_off, const unsigned *__restrict__ s_ent,
                                                              const unsigned long long *__restrict__ p_off, const unsigned *__restrict__ p_ent,
                                                              const unsigned long long *__restrict__ n_off, const unsigned *__restrict__ n_ent,
@@ -196,28 +195,42 @@ __global__ __launch_bounds__(1024) void general_fixup_kernel(const unsigned long
     if (c1 <= i + 1 || c1 <= col_begin) return;            // no cell (i, j > i) in this column chunk
     for (unsigned j = threadIdx.x; j < c1 - c0; j += blockDim.x) row[j] = 0;
     __syncthreads();
+    // A quarter wave takes 16 special sites of sample i at a time: lane l fetches entry l and its site's list bounds (one memory
+    // round trip for the 16 of them), then the 16 lanes walk the 16 sites' lists together.
     const unsigned sub = threadIdx.x >> 4, nsub = blockDim.x >> 4, l16 = threadIdx.x & 15;
     const unsigned long long e0 = s_off[i], e1 = s_off[i + 1];
-    for (unsigned long long e = e0 + sub; e < e1; e += nsub) {
-        const unsigned ent = s_ent[e];
-        const unsigned site = ent >> 4, code = ent & 15u;
-        const unsigned long long pa = p_off[site], pz = p_off[site + 1];
-        if (code == 15u) {                                   // i is N here: every partial j > i gains |M_j| - 1
-            for (unsigned long long t = pa + l16; t < pz; t += 16) {
-                const unsigned pe = p_ent[t], j = pe >> 4;
-                if (j > i && j >= c0 && j < c1) atomicAdd(&row[j - c0], (unsigned)__popc(pe & 15u) - 1u);
-            }
-        } else {                                             // i is partial here
-            const unsigned k = (unsigned)__popc(code) - 1u;
-            const unsigned long long na = n_off[site], nz = n_off[site + 1];
-            for (unsigned long long t = na + l16; t < nz; t += 16) {
-                const unsigned j = n_ent[t];
-                if (j > i && j >= c0 && j < c1) atomicAdd(&row[j - c0], k);
-            }
-            for (unsigned long long t = pa + l16; t < pz; t += 16) {
-                const unsigned pe = p_ent[t], j = pe >> 4;
-                const int sh = __popc(pe & code) - 1;
-                if (sh > 0 && j > i && j >= c0 && j < c1) atomicAdd(&row[j - c0], (unsigned)sh);
+    for (unsigned long long base = e0 + (unsigned long long)sub * 16; base < e1; base += (unsigned long long)nsub * 16) {
+        const unsigned long long e = base + l16;
+        unsigned my_code = 0;
+        unsigned long long my_pa = 0, my_pz = 0, my_na = 0, my_nz = 0;
+        if (e < e1) {
+            const unsigned ent = s_ent[e];
+            const unsigned site = ent >> 4;
+            my_code = ent & 15u;
+            my_pa = p_off[site]; my_pz = p_off[site + 1];
+            if (my_code != 15u) { my_na = n_off[site]; my_nz = n_off[site + 1]; }
+        }
+        const int cnt = (int)min((unsigned long long)16, e1 - base);
+        for (int k = 0; k < cnt; k++) {
+            const unsigned code = __shfl(my_code, k, 16);
+            const unsigned long long pa = __shfl(my_pa, k, 16), pz = __shfl(my_pz, k, 16);
+            if (code == 15u) {                               // i is N here: every partial j > i gains |M_j| - 1
+                for (unsigned long long t = pa + l16; t < pz; t += 16) {
+                    const unsigned pe = p_ent[t], j = pe >> 4;
+                    if (j > i && j >= c0 && j < c1) atomicAdd(&row[j - c0], (unsigned)__popc(pe & 15u) - 1u);
+                }
+            } else {                                         // i is partial here
+                const unsigned kk = (unsigned)__popc(code) - 1u;
+                const unsigned long long na = __shfl(my_na, k, 16), nz = __shfl(my_nz, k, 16);
+                for (unsigned long long t = na + l16; t < nz; t += 16) {
+                    const unsigned j = n_ent[t];
+                    if (j > i && j >= c0 && j < c1) atomicAdd(&row[j - c0], kk);
+                }
+                for (unsigned long long t = pa + l16; t < pz; t += 16) {
+                    const unsigned pe = p_ent[t], j = pe >> 4;
+                    const int sh = __popc(pe & code) - 1;
+                    if (sh > 0 && j > i && j >= c0 && j < c1) atomicAdd(&row[j - c0], (unsigned)sh);
+                }
             }
         }
     }
