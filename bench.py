@@ -266,15 +266,13 @@ def main():
 
 def _traffic_from_profiles(n, L, world, kernel):
     """HBM bytes per launch of the kernel that ran, from the COMMITTED PMC summary (profiles/pmc_summary.json) if it holds an
-    entry for this size and kernel: a figure from separate --pmc passes of the same command, not from this run."""
+    entry for this size and kernel: a figure from separate --pmc passes of the same kernel on the same shape (FETCH_SIZE /
+    WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes), not from this run; None when there is no such entry."""
     p = os.path.join(ROOT, "profiles", "pmc_summary.json")
     try:
         with open(p) as fh:
-            d = json.load(fh)
-        e = d.get("%dx%d@%d" % (n, L, world), {})
-        if e.get("kernel_tag") != kernel:
-            return None
-        return e.get("hbm_bytes_per_launch")
+            e = json.load(fh).get("%dx%d@%d/%s" % (n, L, world, kernel))
+        return None if e is None else e.get("hbm_bytes_per_launch")
     except Exception:
         return None
 
@@ -296,7 +294,7 @@ def general_pass(args, n, L, seed, dev, synth, torch, device):
     e1.record()
     torch.cuda.synchronize()
     kern_s = e0.elapsed_time(e1) / 1e3 / reps
-    r = roofline_of(aln.kernel, "general", n * (n - 1) // 2, L, kern_s, None)
+    r = roofline_of(aln.kernel, "general", n * (n - 1) // 2, L, kern_s, _traffic_from_profiles(n, L, 1, aln.kernel))
     r["workload"] = "the same alignment + %.3g partial IUPAC codes per site (uniformly random sites and codes)" % P_PARTIAL_C4
     r["mean_d"] = float(dmat.sum().item()) / (n * (n - 1) // 2)
     aln.close()

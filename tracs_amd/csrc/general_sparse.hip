@@ -211,28 +211,31 @@ __global__ __launch_bounds__(1024) void general_fixup_kernel(const unsigned long
             if (my_code != 15u) { my_na = n_off[site]; my_nz = n_off[site + 1]; }
         }
         const int cnt = (int)min((unsigned long long)16, e1 - base);
+        // a list is walked 64 entries at a time: each lane requests its four entries before it touches the first, so the walk
+        // costs one memory round trip per 64 list entries instead of one per 16
+#define TRACS_WALK(ENT, A_, Z_, BODY)                                                                    \
+        for (unsigned long long t = (A_) + l16; t < (Z_); t += 64) {                                         \
+            const bool h1 = t + 16 < (Z_), h2 = t + 32 < (Z_), h3 = t + 48 < (Z_);                            \
+            const unsigned v0 = ENT[t], v1 = h1 ? ENT[t + 16] : 0u, v2 = h2 ? ENT[t + 32] : 0u, v3 = h3 ? ENT[t + 48] : 0u; \
+            { const unsigned v = v0; BODY }                                                                   \
+            if (h1) { const unsigned v = v1; BODY }                                                           \
+            if (h2) { const unsigned v = v2; BODY }                                                           \
+            if (h3) { const unsigned v = v3; BODY }                                                           \
+        }
         for (int k = 0; k < cnt; k++) {
             const unsigned code = __shfl(my_code, k, 16);
             const unsigned long long pa = __shfl(my_pa, k, 16), pz = __shfl(my_pz, k, 16);
             if (code == 15u) {                               // i is N here: every partial j > i gains |M_j| - 1
-                for (unsigned long long t = pa + l16; t < pz; t += 16) {
-                    const unsigned pe = p_ent[t], j = pe >> 4;
-                    if (j > i && j >= c0 && j < c1) atomicAdd(&row[j - c0], (unsigned)__popc(pe & 15u) - 1u);
-                }
+                TRACS_WALK(p_ent, pa, pz, { const unsigned j = v >> 4; if (j > i && j >= c0 && j < c1) atomicAdd(&row[j - c0], (unsigned)__popc(v & 15u) - 1u); })
             } else {                                         // i is partial here
                 const unsigned kk = (unsigned)__popc(code) - 1u;
                 const unsigned long long na = __shfl(my_na, k, 16), nz = __shfl(my_nz, k, 16);
-                for (unsigned long long t = na + l16; t < nz; t += 16) {
-                    const unsigned j = n_ent[t];
-                    if (j > i && j >= c0 && j < c1) atomicAdd(&row[j - c0], kk);
-                }
-                for (unsigned long long t = pa + l16; t < pz; t += 16) {
-                    const unsigned pe = p_ent[t], j = pe >> 4;
-                    const int sh = __popc(pe & code) - 1;
-                    if (sh > 0 && j > i && j >= c0 && j < c1) atomicAdd(&row[j - c0], (unsigned)sh);
-                }
+                TRACS_WALK(n_ent, na, nz, { const unsigned j = v; if (j > i && j >= c0 && j < c1) atomicAdd(&row[j - c0], kk); })
+                TRACS_WALK(p_ent, pa, pz, { const unsigned j = v >> 4; const int sh = __popc(v & code) - 1;
+                                            if (sh > 0 && j > i && j >= c0 && j < c1) atomicAdd(&row[j - c0], (unsigned)sh); })
             }
         }
+#undef TRACS_WALK
     }
     __syncthreads();
     const unsigned ci = c_n[i];

@@ -16,7 +16,9 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
+#include <utility>
 #include <vector>
 
 namespace tracs {
@@ -535,7 +537,16 @@ static void build_tiles(size_t n, size_t row_begin, size_t row_end, size_t col_b
     if (row_end <= row_begin) return;
     const size_t nbi = (row_end - row_begin + ti - 1) / ti;
     const size_t nbj = (n + tj - 1) / tj;
-    const size_t SI = 4, SJ = 8;     // 32 tiles per supertile = one XCD's resident set
+    // tiles per supertile ~ one XCD's resident set; TRACS_SUPERTILE=<rows>x<cols> overrides (diagnostics)
+    static const std::pair<size_t, size_t> shape = [] {
+        std::pair<size_t, size_t> v{4, 8};
+        if (const char *e = std::getenv("TRACS_SUPERTILE")) {
+            unsigned a = 0, b = 0;
+            if (std::sscanf(e, "%ux%u", &a, &b) == 2 && a >= 1 && b >= 1 && a <= 64 && b <= 64) v = {a, b};
+        }
+        return v;
+    }();
+    const size_t SI = shape.first, SJ = shape.second;
     for (size_t sbi = 0; sbi < nbi; sbi += SI)
         for (size_t sbj = 0; sbj < nbj; sbj += SJ)
             for (size_t bi = sbi; bi < std::min(nbi, sbi + SI); bi++)
@@ -807,7 +818,7 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
             const double all_cells = 0.5 * (double)a->n * (double)a->n;
             const double frac = std::min(1.0, cells / std::max(1.0, all_cells));
             const double t_valu = cells * (double)groups * 4.0 * 7.0 / 38e12;
-            const double t_mfma = cells * (double)a->L * 10.0 / 5.5e15 + updates * frac / 1.5e11;
+            const double t_mfma = cells * (double)a->L * 10.0 / 5.4e15 + updates * frac / 3.0e11;      // measured: 5.4 PFLOP/s, 4 x 10^11 list entries/s
             static const int force = env_flag("TRACS_GENERAL_MFMA");          // 1: always, 0: never (diagnostics)
             mfma_general = force == 1 || (force != 0 && t_mfma < t_valu);
         }
