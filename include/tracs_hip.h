@@ -111,7 +111,10 @@ void tracs_alignment_free(tracs_alignment *a);
 size_t tracs_alignment_n(const tracs_alignment *a);
 size_t tracs_alignment_len(const tracs_alignment *a);
 size_t tracs_alignment_bytes(const tracs_alignment *a);   /* HBM bytes of the packed planes */
-void *tracs_alignment_planes(const tracs_alignment *a);   /* device pointer (for tests) */
+void *tracs_alignment_planes(const tracs_alignment *a);   /* device pointer of the packed planes (tracs_alignment_bytes long) */
+/* The planes were written through that pointer from outside the library (e.g. an RCCL broadcast from the rank that packed):
+ * forget every cached derived form (consensus planes, sparse lists, tile schedule stay valid per geometry).          */
+int tracs_alignment_touch(tracs_alignment *a);
 /* Pack `count` samples of ASCII (IUPAC, any case; load_seqs pairsnp.hpp:107-199) into samples
  * [first, first+count).  `ascii` is count*L bytes, row-major; host or device pointer
  * (ascii_on_device).  The pack itself is a HIP kernel either way.                           */
@@ -132,9 +135,10 @@ int tracs_pairsnp_dense(const tracs_alignment *a, size_t row_begin, size_t row_e
                         uint32_t *dist, uint32_t *ncomp, size_t ld, void *stream);
 
 /* Thresholded form: identical (d and nn) for every pair with d <= dist_threshold.  A pair beyond the threshold (never
- * emitted, src/pairsnp.hpp:405) may come back with bit 31 of its distance set (0xFFFFFFFF, or a partial count | 2^31) and
- * an unspecified ncomp, because workgroups stop reading the alignment once every pair of their tile is past the
- * threshold: read such cells as "> threshold" (as a signed int32 they are negative; tracs_coo_count/fill skip them).
+ * emitted, src/pairsnp.hpp:405) may come back with bit 31 of its distance set (0xFFFFFFFF, or a partial count | 2^31), or
+ * (general alignments) with a lower bound of its distance that already exceeds the threshold, and an unspecified ncomp,
+ * because workgroups stop reading the alignment once every pair of their tile is past the threshold: read every cell
+ * that is not <= dist_threshold as a signed int32 as "> threshold" (tracs_coo_count/fill skip them).
  * Long alignments take two passes (a 1/8 prefix over all tiles, then the rest over the surviving tiles only); this call
  * synchronises the stream once between them.                                                                          */
 int tracs_pairsnp_dense_thr(const tracs_alignment *a, size_t row_begin, size_t row_end, size_t col_begin,

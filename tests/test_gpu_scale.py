@@ -154,3 +154,32 @@ def test_distance_cli_two_ranks_equals_one(mode, tmp_path):
         outs.append(open(out).read())
     assert outs[0] == outs[1]
     assert outs[0].count("\n") > (1000 if mode == "plain" else 100)
+
+
+def test_general_path_beyond_one_lds_row(dev, oracle):
+    """33 100 samples with partial codes: the sparse correction's row no longer fits one 32 768-column LDS chunk, the sample ids
+    in the per-site lists pass 2^15, and the matrix holds 5.5 x 10^8 pairs; 80 samples spread over the whole range (and all
+    their cross pairs) against the oracle, plus the thresholded pass on the same handle."""
+    import torch
+    from tracs_amd import synth
+    n, L = 33100, 1500
+    seqs = synth.alignment(n, L, seed=77, mu_lineage=0.03, mu_sample=0.01, n_lineages=40, p_n=0.02, p_partial=0.01)
+    aln = dev.Alignment(n, L)
+    aln.pack(seqs)
+    d = torch.zeros((n, n), dtype=torch.int32, device="cuda")
+    nn = torch.zeros((n, n), dtype=torch.int32, device="cuda")
+    dev.pairsnp_dense(aln, d, nn)
+    assert aln.encoding == "general" and aln.kernel == "mfma-general"
+    sub = np.sort(np.concatenate([np.arange(0, 20), np.arange(16380, 16400), np.arange(32758, 32778), np.arange(n - 20, n)]))
+    er, ec, ed, enn = oracle.pairsnp_arrays(seqs[sub], n_threads=8)
+    t = torch.from_numpy(sub).cuda()
+    dsub, nsub = d[t][:, t].cpu().numpy(), nn[t][:, t].cpu().numpy()
+    li, lj = er.astype(np.int64), ec.astype(np.int64)
+    assert np.array_equal(dsub[li, lj], ed.astype(np.int32)) and np.array_equal(nsub[li, lj], enn.astype(np.int32))
+    thr = int(np.percentile(ed, 20))
+    d2 = torch.zeros((n, n), dtype=torch.int32, device="cuda")
+    dev.pairsnp_dense(aln, d2, None, dist_threshold=thr)
+    d2s = d2[t][:, t].cpu().numpy()
+    keep = ed <= thr
+    assert keep.sum() > 100 and np.array_equal(d2s[li[keep], lj[keep]], ed[keep].astype(np.int32))
+    assert ((d2s[li[~keep], lj[~keep]].astype(np.int64) > thr) | (d2s[li[~keep], lj[~keep]] < 0)).all()

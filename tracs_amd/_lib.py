@@ -19,7 +19,7 @@ SYMBOLS = [
     "tracs_trans_dist", "tracs_lprob_k_given_N", "tracs_calculate_posteriors", "tracs_connected_components",
     "tracs_find_dirichlet_priors", "tracs_find_dirichlet_priors_device",
     "tracs_alignment_create", "tracs_alignment_free", "tracs_alignment_n", "tracs_alignment_len",
-    "tracs_alignment_bytes", "tracs_alignment_planes", "tracs_alignment_pack", "tracs_alignment_from_fasta",
+    "tracs_alignment_bytes", "tracs_alignment_planes", "tracs_alignment_touch", "tracs_alignment_pack", "tracs_alignment_from_fasta",
     "tracs_free",
     "tracs_pairsnp_dense", "tracs_pairsnp_dense_thr", "tracs_coo_count", "tracs_coo_fill", "tracs_filter_recomb_device",
     "tracs_trans_dist_device", "tracs_trans_dist_dense", "tracs_trans_dist_dense2",
@@ -108,6 +108,8 @@ def load():
         f.argtypes = [vp]
     L.tracs_alignment_planes.restype = vp
     L.tracs_alignment_planes.argtypes = [vp]
+    L.tracs_alignment_touch.restype = C.c_int
+    L.tracs_alignment_touch.argtypes = [vp]
     L.tracs_alignment_pack.restype = C.c_int
     L.tracs_alignment_pack.argtypes = [vp, vp, sz, sz, C.c_int, vp]
     L.tracs_alignment_from_fasta.restype = C.c_int

@@ -656,6 +656,14 @@ size_t tracs_alignment_bytes(const tracs_alignment *a)
 }
 void *tracs_alignment_planes(const tracs_alignment *a) { return a ? a->planes : nullptr; }
 
+int tracs_alignment_touch(tracs_alignment *a)
+{
+    if (!a) { set_error("tracs_alignment_touch: NULL argument"); return TRACS_E_ARG; }
+    DeviceCall guard(nullptr);
+    a->dirty = true;                   // the consensus form / sparse lists (if any) must be re-derived
+    return TRACS_OK;
+}
+
 int tracs_alignment_pack(tracs_alignment *a, const uint8_t *ascii, size_t first, size_t count, int ascii_on_device,
                          void *stream_)
 {
@@ -807,9 +815,10 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
     static const bool mfma_off = env_flag("TRACS_MFMA") == 0 || std::getenv("TRACS_TILE_VARIANT") != nullptr;
     bool mfma = cons && !mfma_off;
     bool mfma_general = false;
-    if (!cons && !mfma_off && thr == 0xFFFFFFFFu && a->L < (1ull << 28)) {
-        // plain pass over a general alignment: one-hot Gram on the matrix cores + the sparse partial-code terms, when the
-        // side lists exist (or can be built) and the sparse work is small beside what the VALU kernel would cost
+    if (!cons && !mfma_off && a->L < (1ull << 28)) {
+        // general alignment: one-hot Gram on the matrix cores + the sparse partial-code terms, when the side lists exist (or
+        // can be built) and the sparse work is small beside what the VALU kernel would cost.  Thresholded passes too: the
+        // kernel's value bounds the distance from below, so tiles it declares dead are dead (pairsnp_mfma.hip)
         int ok = 0;
         double updates = 0.0;
         const int rc = general_sparse_get(a, stream, &ok, &updates);
@@ -919,6 +928,7 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
             const int k2 = stage_split(groups - prefix, std::max({1, std::min({32, want, (groups - prefix) / (16 * kGC)}), (groups - prefix + max_gps - 1) / max_gps}), gps2);
             if ((rc = launch(live_tiles, (unsigned)(n_live * (size_t)k2), (int)n_live, groups, gps2, k2, thr, TilePhase{2, prefix, nullptr}))) return rc;
         }
+        if (mfma_general && (rc = general_sparse_fixup(a, row_begin, row_end, col_begin, dist, ncomp, ld, stream))) return rc;
         TRACS_HIP_CHECK(hipGetLastError());
         return TRACS_OK;
     }

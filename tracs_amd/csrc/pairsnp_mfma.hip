@@ -289,11 +289,15 @@ __global__ __launch_bounds__(256, (NBR * NBC > 4 ? 1 : 2)) void pairsnp_mfma_ker
     auto cell_row = [&](int rb, int r) { return (unsigned)(i0 + wr * WI + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hk); };
     auto cell_col = [&](int cb) { return (unsigned)(j0 + wc * WJ + cb * 32 + lb); };
 
-    // Thresholded two-pass runs (TilePhase; consensus encoding only): at the end of the prefix pass a tile whose every pair
-    // is already past the threshold is dead -- cells 0xFFFFFFFF, live flag 0 -- and the remainder pass never visits it.
+    // sites of this workgroup's range (the last group is clipped to L): the general form's  L_range - G + 3 NN
+    const unsigned Lc = min(A.L, (unsigned)g_end * SITES_PER_GROUP) - (unsigned)g_begin * SITES_PER_GROUP;
+    // Thresholded two-pass runs (TilePhase): at the end of the prefix pass a tile whose every pair is already past the
+    // threshold is dead -- live flag 0, the remainder pass never visits it -- and its cells are flagged.  In the general form the
+    // kernel's value is a LOWER bound of the range's distance (the sparse terms T1, T2 >= 0 are added later), which is the safe
+    // side for "already past the threshold"; it can be negative before the correction, hence the signed compare.
     bool dead = false;
-    if (!GENERAL && A.ph.phase == 1) {
-        unsigned mn = 0xFFFFFFFFu;
+    if (A.ph.phase == 1) {
+        int mn = 0x7FFFFFFF;
         if (j0 >= i0 + TI) {                                   // tiles touching the diagonal hold d(i,i) = 0 cells: always live
 #pragma unroll
             for (int rb = 0; rb < NBR; rb++)
@@ -302,28 +306,27 @@ __global__ __launch_bounds__(256, (NBR * NBC > 4 ? 1 : 2)) void pairsnp_mfma_ker
                 {
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
-                        const unsigned d = (unsigned)((3 * (int)accV[rb][cb][r] - (int)accS[rb][cb][r]) >> 2);
-                        mn = min(mn, (cell_row(rb, r) < A.row_end && cell_col(cb) < A.n) ? d : 0xFFFFFFFFu);
+                        const int V = (int)accV[rb][cb][r], S = (int)accS[rb][cb][r];
+                        const int d = GENERAL ? (int)Lc - S + 3 * V : ((3 * V - S) >> 2);
+                        mn = min(mn, (cell_row(rb, r) < A.row_end && cell_col(cb) < A.n) ? d : 0x7FFFFFFF);
                     }
                     __builtin_amdgcn_sched_barrier(0);     // one block at a time: the accumulators stay where they are
                 }
         } else {
-            mn = 0u;
+            mn = -0x7FFFFFFF;
         }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) mn = min(mn, (unsigned)__shfl_xor((int)mn, off, 64));
-        unsigned *wmin = reinterpret_cast<unsigned *>(&lds[0][0]);      // the staging buffers are idle now (last barrier passed)
+        for (int off = 32; off > 0; off >>= 1) mn = min(mn, __shfl_xor(mn, off, 64));
+        int *wmin = reinterpret_cast<int *>(&lds[0][0]);      // the staging buffers are idle now (last barrier passed)
         if (lane == 0) wmin[wave] = mn;
         __syncthreads();
-        unsigned m = wmin[0];
+        int m = wmin[0];
 #pragma unroll
         for (int w = 1; w < NW; w++) m = min(m, wmin[w]);
-        dead = m > A.thr;
+        dead = (long long)m > (long long)A.thr;
         if (tid == 0) A.ph.live[tile_no] = dead ? 0 : 1;
     }
     const bool single = A.ksplit == 1 && A.ph.phase != 2;
-    // general form: sites of this workgroup's range (the last group is clipped to L)
-    const unsigned Lc = min(A.L, (unsigned)g_end * SITES_PER_GROUP) - (unsigned)g_begin * SITES_PER_GROUP;
 #pragma unroll
     for (int rb = 0; rb < NBR; rb++)
 #pragma unroll
@@ -339,7 +342,9 @@ __global__ __launch_bounds__(256, (NBR * NBC > 4 ? 1 : 2)) void pairsnp_mfma_ker
                     const unsigned d = GENERAL ? Lc - (unsigned)S + 3u * (unsigned)V : (unsigned)((3 * V - S) >> 2);
                     const size_t o = (size_t)i * A.ld + j;
                     if (dead) {
-                        A.dist[o] = 0xFFFFFFFFu;
+                        // consensus: flagged.  general: the prefix's lower bound itself (> threshold, and the sparse terms added
+                        // later only raise it) -- a flag value could collide with a legitimately negative intermediate
+                        A.dist[o] = GENERAL ? d : 0xFFFFFFFFu;
                         if (A.ncomp) A.ncomp[o] = 0u;
                     } else if (single) {
                         A.dist[o] = d;

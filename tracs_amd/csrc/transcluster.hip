@@ -57,8 +57,10 @@ __device__ __forceinline__ double imul(long long i, double l) { return i == 0 ? 
 // so S is a running sum in k.  All terms are positive: no cancellation is introduced.
 // k_cap: evaluate at most k_cap-1 terms here; returns false if the reference's loop would still be running
 // (the key is then finished by tc_long_keys_kernel, one wave per key).
+// state (4 doubles, may be NULL): when the cap is hit, the running sums {pois, lnS, lprob, elprob} at k = k_stop, so that
+// tc_eval_wave resumes there instead of starting over (the O(N) prefix and the first k_cap terms are not summed twice).
 __device__ bool tc_eval(int N, double delta, const TcParams &P, const double *__restrict__ lg, double &p0, double &eK,
-                        int &k_stop, int k_cap)
+                        int &k_stop, int k_cap, double *__restrict__ state = nullptr)
 {
     const double n1 = (double)(N + 1);
     const double lg_n1 = lg_at(lg, (long long)N + 1);
@@ -80,7 +82,11 @@ __device__ bool tc_eval(int N, double delta, const TcParams &P, const double *__
         }
         double diff = P.thr + 1;
         while ((diff > P.thr) && (k < 10000)) {                        // :207
-            if (k >= k_cap) { k_stop = k; return false; }
+            if (k >= k_cap) {
+                k_stop = k;
+                if (state) { state[0] = pois; state[1] = lnS; state[2] = lprob; state[3] = elprob; }
+                return false;
+            }
             const long long M = (long long)N + k;
             lnS = lae(lnS, imul(M, ld) + (double)M * P.ln_lb - lg_at(lg, M + 1));
             double lhs = (n1 * P.ln_lamb + (double)k * P.ln_beta + lg_at(lg, M + 1));   // :140
@@ -99,7 +105,11 @@ __device__ bool tc_eval(int N, double delta, const TcParams &P, const double *__
         p0 = (n1 * P.ln_lamb + 0.0 * P.ln_beta + lg_n1 - lg_n1 - lg_at(lg, 1) - n1 * P.ln_lb);
         double diff = P.thr + 1;
         while ((diff > P.thr) && (k < 10000)) {
-            if (k >= k_cap) { k_stop = k; return false; }
+            if (k >= k_cap) {
+                k_stop = k;
+                if (state) { state[0] = 0.0; state[1] = -INFINITY; state[2] = lprob; state[3] = elprob; }
+                return false;
+            }
             const long long M = (long long)N + k;
             const double m1 = (double)(M + 1) * P.ln_lb;
             const double lhs = (n1 * P.ln_lamb + (double)k * P.ln_beta + lg_at(lg, M + 1) - lg_n1 -
@@ -139,30 +149,24 @@ __device__ __forceinline__ double wave_scan_lae(double v, int lane)
     return m + log(e);
 }
 
-__device__ void tc_eval_wave(int N, double delta, const TcParams &P, const double *__restrict__ lg, double &eK)
+// Resumes the serial loop of tc_eval at k = k_start from its running sums `state` = {pois, lnS, lprob, elprob}.
+__device__ void tc_eval_wave(int N, double delta, const TcParams &P, const double *__restrict__ lg, double &eK,
+                             const double *__restrict__ state, int k_start)
 {
     const int lane = threadIdx.x & 63;
     const double n1 = (double)(N + 1);
     const double lg_n1 = lg_at(lg, (long long)N + 1);
     const bool pos = delta > 0;
-    double pois = 0.0, lnS = -INFINITY, ld = 0.0, upper;
+    const double pois = state[0];
+    double lnS = state[1], ld = 0.0, upper;
     if (pos) {
-        const double lx = log(P.lamb * delta);
         ld = log(delta);
-        // pois and S_N: lane-strided terms, then a wave reduction (order differs from :144-148 by rounding only)
-        double pp = -INFINITY, ss = -INFINITY;
-        for (long long i = lane; i <= N; i += 64) {
-            pp = lae(imul(i, lx) - lg_at(lg, i + 1), pp);
-            ss = lae(ss, imul(i, ld) + (double)i * P.ln_lb - lg_at(lg, i + 1));
-        }
-        pp = wave_scan_lae(pp, lane); ss = wave_scan_lae(ss, lane);
-        pois = __shfl(pp, 63, 64); lnS = __shfl(ss, 63, 64);
         upper = exp(P.ln_beta + delta * P.lamb + log(n1) - (P.ln_lamb + pois));
     } else {
         upper = exp(P.ln_beta + log(n1) - P.ln_lamb);
     }
-    double lprob = -INFINITY, elprob = -INFINITY;
-    for (int k0 = 1; k0 < 10000; k0 += 64) {
+    double lprob = state[2], elprob = state[3];
+    for (int k0 = k_start; k0 < 10000; k0 += 64) {
         const int k = k0 + lane;
         const bool live = k < 10000;
         const long long M = (long long)N + k;
@@ -304,14 +308,14 @@ constexpr int TC_SERIAL_CAP = 192;      // terms evaluated by the one-thread-per
 template <class Src>
 __global__ void tc_keys_kernel(Src src, const unsigned *__restrict__ key_elem, unsigned nk, TcParams P,
                                const double *__restrict__ lg, double *__restrict__ key_p0, double *__restrict__ key_eK,
-                               unsigned *__restrict__ long_ids, unsigned *__restrict__ n_long)
+                               unsigned *__restrict__ long_ids, unsigned *__restrict__ n_long, double *__restrict__ key_state)
 {
     P.ln_lamb = log(P.lamb); P.ln_beta = log(P.beta); P.ln_lb = log(P.lamb + P.beta);
     for (unsigned id = blockIdx.x * blockDim.x + threadIdx.x; id < nk; id += gridDim.x * blockDim.x) {
         int N; double d;
         src.get((size_t)key_elem[id], N, d);
         double p0, eK = 0.0; int ks;
-        const bool done = tc_eval(N, d, P, lg, p0, eK, ks, TC_SERIAL_CAP);
+        const bool done = tc_eval(N, d, P, lg, p0, eK, ks, TC_SERIAL_CAP, key_state + 4 * (size_t)id);
         key_p0[id] = p0;
         if (done) key_eK[id] = eK;
         else long_ids[atomicAdd(n_long, 1u)] = id;
@@ -322,7 +326,8 @@ template <class Src>
 __global__ __launch_bounds__(64) void tc_long_keys_kernel(Src src, const unsigned *__restrict__ key_elem,
                                                           const unsigned *__restrict__ long_ids,
                                                           const unsigned *__restrict__ n_long, TcParams P,
-                                                          const double *__restrict__ lg, double *__restrict__ key_eK)
+                                                          const double *__restrict__ lg, double *__restrict__ key_eK,
+                                                          const double *__restrict__ key_state)
 {
     P.ln_lamb = log(P.lamb); P.ln_beta = log(P.beta); P.ln_lb = log(P.lamb + P.beta);
     const unsigned nl = *n_long;
@@ -331,7 +336,7 @@ __global__ __launch_bounds__(64) void tc_long_keys_kernel(Src src, const unsigne
         int N; double d;
         src.get((size_t)key_elem[id], N, d);
         double eK;
-        tc_eval_wave(N, d, P, lg, eK);
+        tc_eval_wave(N, d, P, lg, eK, key_state + 4 * (size_t)id, TC_SERIAL_CAP);
         if ((threadIdx.x & 63) == 0) key_eK[id] = eK;
     }
 }
@@ -411,7 +416,7 @@ static int get_lgamma_table(hipStream_t stream, const double **out)
 
 int get_lgamma_table_for_filter(hipStream_t stream, const double **out) { return get_lgamma_table(stream, out); }
 
-struct TcWorkspaceIds { enum { SLOTS = 0, ESLOT, SLOT_ID, NKEYS, KEY_ELEM, KEY_P0, KEY_EK, LONG_IDS }; };
+struct TcWorkspaceIds { enum { SLOTS = 0, ESLOT, SLOT_ID, NKEYS, KEY_ELEM, KEY_P0, KEY_EK, LONG_IDS, KEY_STATE }; };
 
 static unsigned long long g_last_keys = 0;        // distinct (N, delta) keys of the last entry-point call (bench.py reports it)
 constexpr size_t TD_MAX_ELEMS = 1ull << 31;       // elements per pass: element indices and slots are 32-bit
@@ -463,6 +468,8 @@ static int run_trans_dist(const Src &src, size_t total, double lamb, double beta
     if ((rc = workspace_get(TcWorkspaceIds::KEY_P0, (size_t)nk * 8, reinterpret_cast<void **>(&key_p0)))) return rc;
     if ((rc = workspace_get(TcWorkspaceIds::KEY_EK, (size_t)nk * 8, reinterpret_cast<void **>(&key_eK)))) return rc;
     if ((rc = workspace_get(TcWorkspaceIds::LONG_IDS, (size_t)nk * 4, reinterpret_cast<void **>(&long_ids)))) return rc;
+    double *key_state = nullptr;
+    if ((rc = workspace_get(TcWorkspaceIds::KEY_STATE, (size_t)nk * 32, reinterpret_cast<void **>(&key_state)))) return rc;
     TRACS_HIP_CHECK(hipMemsetAsync(n_keys, 0, 8, stream));          // [0] key counter, [1] long-key counter
     hipLaunchKernelGGL(dedup_collect_kernel, dim3((unsigned)std::min<size_t>((cap + 255) / 256, 256 * 32)), dim3(256), 0, stream,
                        slots, cap, slot_id, key_elem, n_keys);
@@ -471,10 +478,10 @@ static int run_trans_dist(const Src &src, size_t total, double lamb, double beta
     P.ln_lamb = P.ln_beta = P.ln_lb = 0.0;
     // one wave per block: keys differ widely in trip count, small blocks keep the SIMDs busy
     hipLaunchKernelGGL((tc_keys_kernel<Src>), dim3((nk + 63) / 64), dim3(64), 0, stream, src, key_elem, nk, P, lg, key_p0, key_eK,
-                       long_ids, n_keys + 1);
+                       long_ids, n_keys + 1, key_state);
     // long series (E(K) loop beyond TC_SERIAL_CAP terms): one wave per key
     hipLaunchKernelGGL((tc_long_keys_kernel<Src>), dim3(std::min<unsigned>(nk, 256u * 32u)), dim3(64), 0, stream, src, key_elem,
-                       long_ids, n_keys + 1, P, lg, key_eK);
+                       long_ids, n_keys + 1, P, lg, key_eK, key_state);
     hipLaunchKernelGGL((tc_gather_kernel<Src>), dim3(blocks), dim3(256), 0, stream, src, eslot, slot_id, key_p0, key_eK,
                        exp_p0, p0, eK);
     TRACS_HIP_CHECK(hipGetLastError());

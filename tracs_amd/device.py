@@ -65,6 +65,10 @@ class Alignment:
             on_dev, ptr, count = 0, C.c_void_p(a.ctypes.data), a.shape[0]
         _lib.check(self._L.tracs_alignment_pack(self._h, ptr, int(first), int(count), on_dev, _stream()))
 
+    def mark_packed(self):
+        """The planes were written from outside the library (a broadcast from another rank): drop every cached derived form."""
+        _lib.check(self._L.tracs_alignment_touch(self._h))
+
     def pack_codes(self, codes, sample):
         """Pack samples straight from their packed 4-bit allele masks (posterior_codes_device output):
         codes uint8 [(L+1)//2] -> one sample, or uint8 [count, stride >= (L+1)//2] -> samples sample..sample+count-1."""

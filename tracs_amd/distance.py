@@ -118,8 +118,11 @@ def _pairs_multi_gpu(msas, args, ctx):
     """pairsnp's six outputs for one MSA, computed by all ranks and assembled on rank 0 (None on the others)."""
     from . import device as dev
     from . import multigpu, partition
-    dist, rank, world, _ = ctx
-    aln = dev.Alignment.from_fasta(msas)                  # every rank parses and packs: each holds the whole alignment
+    dist, rank, world, device = ctx
+    if os.environ.get("TRACS_DIST_PARSE_ALL"):
+        aln = dev.Alignment.from_fasta(msas)              # every rank parses and packs
+    else:
+        aln = multigpu.shared_alignment(msas, dist, rank, world, device)      # rank 0 parses, the packed planes are broadcast
     n = aln.n
     i_end, j_start = (n, 0) if len(msas) == 1 else (aln.n_first, aln.n_first)      # src/pairsnp.hpp:348-360
     parts = multigpu.pairs_of_rank(aln, i_end, j_start, args.snp_threshold, rank, world, args.recomb_filter)

@@ -53,6 +53,38 @@ def init():
     return dist, rank, world, device
 
 
+class _DeviceBytes:
+    """A raw device allocation as a `__cuda_array_interface__` object, so torch can view it without a copy."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 3}
+
+
+def shared_alignment(paths, dist, rank, world, device):
+    """One rank reads and packs the FASTA(s); the packed planes (5 L / 8 bytes per sample) reach the other ranks with an RCCL
+    broadcast (31 GB at 10 000 x 5 Mbp: a fraction of a second over xGMI, against parsing 50 GB of text on every rank).
+    -> Alignment with .names and .n_first on every rank."""
+    import torch
+    from . import device as dev
+    aln = dev.Alignment.from_fasta(paths) if rank == 0 else None
+    meta = [(aln.n, aln.L, aln.n_first, aln.names)] if rank == 0 else [None]
+    dist.broadcast_object_list(meta, src=0)
+    n, L, n_first, names = meta[0]
+    if rank != 0:
+        aln = dev.Alignment(n, L)
+        aln.names, aln.n_first = names, n_first
+    nbytes = aln.nbytes
+    if nbytes:
+        view = torch.as_tensor(_DeviceBytes(aln.planes_ptr(), nbytes), device=device)
+        step = 1 << 30
+        for o in range(0, nbytes, step):
+            dist.broadcast(view[o:o + step], src=0)
+        torch.cuda.synchronize()
+        if rank != 0:
+            aln.mark_packed()
+    return aln
+
+
 def panel_rows(n, budget_bytes=1 << 30):
     """Rows per dense panel so that one uint32 panel stays within budget_bytes (a multiple of 64, at least 64)."""
     return max(64, (budget_bytes // (4 * max(n, 1))) // 64 * 64)
