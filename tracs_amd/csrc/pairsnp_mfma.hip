@@ -13,7 +13,7 @@
 //         S = 4 * matches - nn,   nn = sum v v',   d = nn - matches = (3 nn - S) / 4.
 //
 //   GENERAL encoding (any IUPAC code; planes A, C, G, T, N as load_seqs builds them):
-//     one-hot Gram  G = sum_s |S_i n S_j|  (four planes, values 0/1)  and  NN = sum_s n_i n_j  (N plane).  For every pair of
+//     one-hot Gram  G = sum_s |S_i n S_j|  (four planes, values 0/1)  and  NN = sum_s n_i n_j  (n = A & C & G & T, formed in registers).  For every pair of
 //     codes of which at most one is a partial code,  [S n S' != {}] = |S n S'| - 3 [both N] - (|M| - 1) [one partial, one N],
 //     so   d = L - G + 3 NN + T1 + T2,   nn = L - c_i - c_j + NN     (c_i = number of N sites of sample i)
 //     where T1 (partial x N) and T2 (partial x partial sharing >= 2 alleles) are sums over the few sites at which a sample
@@ -55,7 +55,9 @@ __device__ __forceinline__ mfma_v8i fp4_operand(const unsigned (&w)[4])
 template <bool GENERAL, int NBR, int NBC, int GC>
 __global__ __launch_bounds__(256, (NBR * NBC > 4 ? 1 : 2)) void pairsnp_mfma_kernel(const MfmaArgs A)
 {
-    constexpr int NP = GENERAL ? NPLANES : 3, NW = 4;
+    // NP planes are staged per group, GP is the group's stride in the stored planes: the general form stages A, C, G, T only and
+    // forms N = A & C & G & T in registers (3 VALU ops per word against a fifth of the staging traffic)
+    constexpr int NP = GENERAL ? 4 : 3, GP = GENERAL ? NPLANES : 3, NW = 4;
     constexpr int WI = NBR * 32, WJ = NBC * 32;             // wave tile
     constexpr int TI = 2 * WI, TJ = 2 * WJ, TS = TI + TJ;   // workgroup tile, samples staged per (group, plane)
     constexpr int STAGE = GC * NP * TS;                     // uint4 per LDS stage
@@ -93,16 +95,15 @@ __global__ __launch_bounds__(256, (NBR * NBC > 4 ? 1 : 2)) void pairsnp_mfma_ker
         chunk_smp[cc] = s0 < TJ ? (size_t)j0 + s0 : (size_t)i0 + (s0 - TJ);
     }
     auto stage_glds = [&](int gs, int b) {
-        const uint4 *run = P + (size_t)gs * NP * n_pad + lane;
 #pragma unroll
         for (int r = 0; r < GC * NP; r++) {
+            const uint4 *run = P + ((size_t)(gs + r / NP) * GP + (r % NP)) * n_pad + lane;
 #pragma unroll
             for (int cc = 0; cc < CPW; cc++) {
                 const int c = wave + cc * NW;
                 if (CH % NW == 0 || c < CH)                 // wave-uniform
                     __builtin_amdgcn_global_load_lds((glb_void_t *)(run + chunk_smp[cc]), (lds_void_t *)&lds[b][r * TS + c * 64], 16, 0, 0);
             }
-            run += n_pad;
         }
     };
     // The same loads one at a time, dealt round-robin to the waves (piece k of this wave = wave-instruction wave + 4 k of
@@ -115,8 +116,8 @@ __global__ __launch_bounds__(256, (NBR * NBC > 4 ? 1 : 2)) void pairsnp_mfma_ker
         const int r = t / CH, c = t - r * CH;
         const int s0 = c * 64;
         // 32-bit element offset inside the stage (n_pad < 2^28 samples): one SGPR per piece instead of an address pair
-        const unsigned off = (unsigned)r * (unsigned)n_pad + (unsigned)(s0 < TJ ? j0 + s0 : i0 + (s0 - TJ));
-        __builtin_amdgcn_global_load_lds((glb_void_t *)(P + (size_t)gs * NP * n_pad + off + lane),
+        const unsigned off = (unsigned)((r / NP) * GP + (r % NP)) * (unsigned)n_pad + (unsigned)(s0 < TJ ? j0 + s0 : i0 + (s0 - TJ));
+        __builtin_amdgcn_global_load_lds((glb_void_t *)(P + (size_t)gs * GP * n_pad + off + lane),
                                          (lds_void_t *)&lds[b][r * TS + c * 64], 16, 0, 0);
     };
     // this lane's sample inside a staged (group, plane) run, per row block / column block of the wave's tile; a lane takes
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(256, (NBR * NBC > 4 ? 1 : 2)) void pairsnp_mfma_ker
             }
         } else {
             // units: plane p (A, C, G, T -> G; N -> NN) x residue class q of the four words of the stage's two groups
-            unsigned raw[2][NB][4], op[2][NB][4];
+            unsigned raw[2][NB][4], nraw[NB][4], op[2][NB][4];
             auto load_raw = [&](int p) {
 #pragma unroll
                 for (int b = 0; b < NB; b++) {
@@ -243,39 +244,46 @@ __global__ __launch_bounds__(256, (NBR * NBC > 4 ? 1 : 2)) void pairsnp_mfma_ker
                     raw[p & 1][b][0] = a.x; raw[p & 1][b][1] = a.y; raw[p & 1][b][2] = c.x; raw[p & 1][b][3] = c.y;
                 }
             };
-#define TRACS_MAKE_RES(P_, Q_, O_)                                                                          \
+#define TRACS_MAKE_RES(SRC_, Q_, O_)                                                                        \
             _Pragma("unroll") for (int b = 0; b < NB; b++)                                                  \
                 _Pragma("unroll") for (int w = 0; w < 4; w++) {                                                 \
-                    const unsigned rw_ = raw[(P_) & 1][b][w];                                               \
+                    const unsigned rw_ = SRC_[b][w];                                                        \
                     O_[b][w] = (Q_) == 0 ? (rw_ & M1) : (Q_) == 1 ? (rw_ & M2) : (Q_) == 2 ? (rw_ & M4) : ((rw_ >> 1) & M4); \
                 }
+            // N plane = A & C & G & T, folded in as each allele plane's words arrive
+#define TRACS_FOLD_N(P_)                                                                                    \
+            _Pragma("unroll") for (int b = 0; b < NB; b++)                                                  \
+                _Pragma("unroll") for (int w = 0; w < 4; w++) nraw[b][w] = (P_) == 0 ? raw[0][b][w] : (nraw[b][w] & raw[(P_) & 1][b][w]);
             load_raw(0);
-            TRACS_MAKE_RES(0, 0, op[0])
+            TRACS_MAKE_RES(raw[0], 0, op[0])
+            TRACS_FOLD_N(0)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int p = 0; p < NPLANES; p++) {
-                // residue 0 (0.5 * 0.5 * 2^2) | build residue 1; request the next plane's words
-                if (p < 4) { TRACS_UNIT_MFMAS(accS, op[0], 128) } else { TRACS_UNIT_MFMAS(accV, op[0], 128) }
-                TRACS_MAKE_RES(p, 1, op[1])
-                if (p + 1 < NPLANES) load_raw(p + 1);
+                // residue 0 (0.5 * 0.5 * 2^2) | build residue 1; request the next allele plane's words
+                if (p < 4) { TRACS_UNIT_MFMAS(accS, op[0], 128) TRACS_MAKE_RES(raw[p & 1], 1, op[1]) }
+                else { TRACS_UNIT_MFMAS(accV, op[0], 128) TRACS_MAKE_RES(nraw, 1, op[1]) }
+                if (p + 1 < 4) load_raw(p + 1);
                 TRACS_UNIT_STAGE(NPLANES * 4)
                 TRACS_UNIT_SCHED(NB * 4, NB * 2)
                 // residue 1 (1.0 * 1.0) | build residue 2
-                if (p < 4) { TRACS_UNIT_MFMAS(accS, op[1], 127) } else { TRACS_UNIT_MFMAS(accV, op[1], 127) }
-                TRACS_MAKE_RES(p, 2, op[0])
+                if (p < 4) { TRACS_UNIT_MFMAS(accS, op[1], 127) TRACS_MAKE_RES(raw[p & 1], 2, op[0]) }
+                else { TRACS_UNIT_MFMAS(accV, op[1], 127) TRACS_MAKE_RES(nraw, 2, op[0]) }
                 TRACS_UNIT_STAGE(NPLANES * 4)
                 TRACS_UNIT_SCHED(NB * 4, 0)
                 // residue 2 (2.0 * 2.0 * 2^-2) | build residue 3
-                if (p < 4) { TRACS_UNIT_MFMAS(accS, op[0], 126) } else { TRACS_UNIT_MFMAS(accV, op[0], 126) }
-                TRACS_MAKE_RES(p, 3, op[1])
+                if (p < 4) { TRACS_UNIT_MFMAS(accS, op[0], 126) TRACS_MAKE_RES(raw[p & 1], 3, op[1]) }
+                else { TRACS_UNIT_MFMAS(accV, op[0], 126) TRACS_MAKE_RES(nraw, 3, op[1]) }
                 TRACS_UNIT_STAGE(NPLANES * 4)
                 TRACS_UNIT_SCHED(NB * 8, 0)
-                // residue 3 | build the next plane's residue 0
+                // residue 3 | build the next plane's residue 0 (and fold the next allele plane into N)
                 if (p < 4) { TRACS_UNIT_MFMAS(accS, op[1], 126) } else { TRACS_UNIT_MFMAS(accV, op[1], 126) }
-                if (p + 1 < NPLANES) { TRACS_MAKE_RES(p + 1, 0, op[0]) }
+                if (p + 1 < 4) { TRACS_MAKE_RES(raw[(p + 1) & 1], 0, op[0]) TRACS_FOLD_N(p + 1) }
+                else if (p + 1 == 4) { TRACS_MAKE_RES(nraw, 0, op[0]) }
                 TRACS_UNIT_STAGE(NPLANES * 4)
-                TRACS_UNIT_SCHED(NB * 4, 0)
+                TRACS_UNIT_SCHED(NB * 8, 0)
             }
+#undef TRACS_FOLD_N
 #undef TRACS_MAKE_RES
         }
         __syncthreads();

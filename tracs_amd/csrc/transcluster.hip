@@ -165,7 +165,23 @@ __device__ void tc_eval_wave(int N, double delta, const TcParams &P, const doubl
     } else {
         upper = exp(P.ln_beta + log(n1) - P.ln_lamb);
     }
-    double lprob = state[2], elprob = state[3];
+    // lprob and elprob run in LINEAR space here (sums of positive terms: exp(t - max) per lane, one wave prefix sum, scaled back by
+    // exp(max)): a step costs one exp per lane and sum instead of an exp, a log and a logaddexp; the values stay far inside the double
+    // range (lprob's terms are k P(k | N) <= 1e4, elprob's are bounded by `upper`), and only rounding differs from the log-space fold.
+    double Lp = exp(state[2]), El = exp(state[3]);
+    auto scan_lin = [&](double t) {                                   // inclusive prefix sums of exp(t_l), this wave
+        double m = t;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+        if (m == -INFINITY) return 0.0;
+        double e = exp(t - m);
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const double o = __shfl_up(e, off, 64);
+            if (lane >= off) e += o;
+        }
+        return e * exp(m);
+    };
     for (int k0 = k_start; k0 < 10000; k0 += 64) {
         const int k = k0 + lane;
         const bool live = k < 10000;
@@ -189,20 +205,20 @@ __device__ void tc_eval_wave(int N, double delta, const TcParams &P, const doubl
             t2 = lhs + lk + delta * (P.lamb + P.beta) - m1;
         }
         if (!live) { t1 = -INFINITY; t2 = -INFINITY; }
-        const double lp = lae(lprob, wave_scan_lae(t1, lane));
-        const double el = lae(elprob, wave_scan_lae(t2, lane));
-        const double diff = upper - exp(el);
+        const double lp = Lp + scan_lin(t1);
+        const double el = El + scan_lin(t2);
+        const double diff = upper - el;
         const bool stop = live && !(diff > P.thr);                     // the while condition fails after this k
         const unsigned long long m = __ballot(stop);
         if (m) {
             const int f = __ffsll((long long)m) - 1;
-            eK = exp(__shfl(lp, f, 64));
+            eK = __shfl(lp, f, 64);
             return;
         }
-        lprob = __shfl(lp, 63, 64);
-        elprob = __shfl(el, 63, 64);
+        Lp = __shfl(lp, 63, 64);
+        El = __shfl(el, 63, 64);
     }
-    eK = exp(lprob);                                                   // ran to k = 9999
+    eK = Lp;                                                           // ran to k = 9999
 }
 
 __global__ void lgamma_table_kernel(double *__restrict__ lg, int n)
