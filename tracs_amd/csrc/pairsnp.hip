@@ -725,7 +725,7 @@ int tracs_alignment_pack_codes(tracs_alignment *a, const uint8_t *codes, size_t 
 }
 
 const char *tracs_debug_tile_variant(void) { return current_variant(false).name; }
-const char *tracs_debug_mfma_shape(void) { return mfma_shape(mfma_shape_current()).name; }
+const char *tracs_debug_mfma_shape(void) { return mfma_shape(mfma_shape_current(false)).name; }
 // 1 if the last dense call on this alignment used the consensus (3-plane) encoding, 0 general, -1 not decided yet
 int tracs_debug_alignment_encoding(const tracs_alignment *a) { return !a ? -1 : (a->dirty ? -1 : a->enc); }
 // kernel of the last dense call on this alignment: 0 VALU tile kernel, 1 matrix-core kernel (consensus operands),
@@ -833,7 +833,7 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
         }
     }
     mfma = mfma || mfma_general;
-    const int shape_id = mfma_shape_current();
+    const int shape_id = mfma_shape_current(mfma_general);
     const MfmaShape &S = mfma_shape(shape_id);
     const int kGC = mfma ? (mfma_general ? S.gc_gen : S.gc_cons) : V.gc;
     const int kTI = mfma ? S.ti : V.ti, kTJ = mfma ? S.tj : V.tj;

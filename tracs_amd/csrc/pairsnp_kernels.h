@@ -53,10 +53,10 @@ struct MfmaShape {
     int gc_cons, gc_gen;       // groups per LDS stage, consensus / general encoding (0: shape not built for it)
     int wg_per_cu;
 };
-// The shapes compiled into the library; index 0 is the default.  TRACS_MFMA_TILE=<name> selects another (diagnostics).
+// The shapes compiled into the library; one default per encoding.  TRACS_MFMA_TILE=<name> selects another for both (diagnostics).
 int mfma_shape_count();
 const MfmaShape &mfma_shape(int idx);
-int mfma_shape_current();
+int mfma_shape_current(bool general);
 // general = false: consensus encoding (operands x, y, z, v);  true: general encoding (one-hot A, C, G, T + N).
 int launch_pairsnp_mfma(int shape, bool general, bool with_nn, unsigned nwg, hipStream_t stream, const MfmaArgs &a);
 

@@ -52,14 +52,14 @@ __device__ __forceinline__ mfma_v8i fp4_operand(const unsigned (&w)[4])
 #define TRACS_MFMA_FP4(ACC, A_, B_, SC) \
     ACC = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A_, B_, ACC, 4, 4, 0, SC, 0, SC)
 
-template <bool GENERAL, int NBR, int NBC, int GC>
-__global__ __launch_bounds__(256, (NBR * NBC > 4 ? 1 : 2)) void pairsnp_mfma_kernel(const MfmaArgs A)
+template <bool GENERAL, int NBR, int NBC, int GC, int NWR = 2, int NWC = 2>
+__global__ __launch_bounds__(NWR * NWC * 64, (NBR * NBC > 4 ? 1 : 2)) void pairsnp_mfma_kernel(const MfmaArgs A)
 {
     // NP planes are staged per group, GP is the group's stride in the stored planes: the general form stages A, C, G, T only and
     // forms N = A & C & G & T in registers (3 VALU ops per word against a fifth of the staging traffic)
-    constexpr int NP = GENERAL ? 4 : 3, GP = GENERAL ? NPLANES : 3, NW = 4;
+    constexpr int NP = GENERAL ? 4 : 3, GP = GENERAL ? NPLANES : 3, NW = NWR * NWC;
     constexpr int WI = NBR * 32, WJ = NBC * 32;             // wave tile
-    constexpr int TI = 2 * WI, TJ = 2 * WJ, TS = TI + TJ;   // workgroup tile, samples staged per (group, plane)
+    constexpr int TI = NWR * WI, TJ = NWC * WJ, TS = TI + TJ;   // workgroup tile, samples staged per (group, plane)
     constexpr int STAGE = GC * NP * TS;                     // uint4 per LDS stage
     static_assert(TS % 64 == 0, "a staging wave-instruction must stay inside one (group, plane) run");
     static_assert(STAGE % 64 == 0, "stage must be whole wave-instructions");
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256, (NBR * NBC > 4 ? 1 : 2)) void pairsnp_mfma_ker
     const int i0 = tile.x, j0 = tile.y;
     const int tid = threadIdx.x, lane = tid & 63, lb = lane & 31, hk = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / NWC, wc = wave % NWC;
     const int g_begin = A.ph.g_base + ks * A.gps;
     const int g_end = min(A.groups, g_begin + A.gps);
     if (g_begin >= g_end) return;
@@ -368,38 +368,43 @@ __global__ __launch_bounds__(256, (NBR * NBC > 4 ? 1 : 2)) void pairsnp_mfma_ker
 
 // ---------------------------------------------------------------------------------------------------------------------
 typedef void (*MfmaLaunchFn)(unsigned nwg, hipStream_t stream, const MfmaArgs &a);
-template <bool GENERAL, int NBR, int NBC, int GC>
+template <bool GENERAL, int NBR, int NBC, int GC, int NWR = 2, int NWC = 2>
 static void launch_one(unsigned nwg, hipStream_t stream, const MfmaArgs &a)
 {
-    hipLaunchKernelGGL((pairsnp_mfma_kernel<GENERAL, NBR, NBC, GC>), dim3(nwg), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((pairsnp_mfma_kernel<GENERAL, NBR, NBC, GC, NWR, NWC>), dim3(nwg), dim3(NWR * NWC * 64), 0, stream, a);
 }
 
 struct ShapeEntry { MfmaShape s; MfmaLaunchFn cons, gen; };
 #define TRACS_SHAPE_N(NAME, R, C, GCC, WPC) {{NAME, R, C, 64 * (R), 64 * (C), GCC, 2, WPC}, launch_one<false, R, C, GCC>, launch_one<true, R, C, 2>}
+#define TRACS_SHAPE_W(NAME, R, C, GCC, WR, WC, WPC) {{NAME, R, C, 32 * (R) * (WR), 32 * (C) * (WC), GCC, 2, WPC}, launch_one<false, R, C, GCC, WR, WC>, launch_one<true, R, C, 2, WR, WC>}
 #define TRACS_SHAPE(R, C, GCC, WPC) TRACS_SHAPE_N(#R "x" #C, R, C, GCC, WPC)
 static const ShapeEntry kShapes[] = {
-    TRACS_SHAPE(2, 2, 1, 2),        // default: 128 x 128 pairs per workgroup, two workgroups per CU (two waves per SIMD)
-    TRACS_SHAPE(3, 2, 2, 1),        // 192 x 128, 192 accumulator AGPRs, one wave per SIMD: fewer expansions per matrix instruction,
-                                    // but measured 18 % slower (profiles/r02/mfma_shape_sweep.txt): one wave cannot hide its own stalls
+    TRACS_SHAPE(2, 2, 1, 2),                      // 0: 128 x 128 pairs per workgroup, four waves, two workgroups per CU -- consensus default
+    TRACS_SHAPE_W("2x2w4x2", 2, 2, 1, 4, 2, 1),   // 1: eight waves (4 x 2), 256 x 128 pairs, one workgroup per CU: a quarter less staging per
+                                                  //    matrix instruction -- general default (505 vs 528 ms; consensus 354 vs 348)
+    TRACS_SHAPE(3, 2, 2, 1),                      // 2: 192 x 128, 192 accumulator AGPRs, one wave per SIMD: fewer expansions per matrix
+                                                  //    instruction, but 18 % slower: one wave cannot hide its own stalls
 #ifdef TRACS_MFMA_SWEEP
-    TRACS_SHAPE_N("2x2g2", 2, 2, 2, 2),   // consensus with two groups per stage (half the barriers)
+    TRACS_SHAPE_N("2x2g2", 2, 2, 2, 2),           // consensus with two groups per stage (half the barriers)
     TRACS_SHAPE(2, 3, 2, 1),
+    TRACS_SHAPE_W("2x2w2x4", 2, 2, 1, 2, 4, 1),   // 128 x 256
 #endif
 };
 #undef TRACS_SHAPE
 #undef TRACS_SHAPE_N
+#undef TRACS_SHAPE_W
 
 int mfma_shape_count() { return (int)(sizeof(kShapes) / sizeof(kShapes[0])); }
 const MfmaShape &mfma_shape(int idx) { return kShapes[idx].s; }
-int mfma_shape_current()
+int mfma_shape_current(bool general)
 {
-    static const int chosen = [] {
+    static const int forced = [] {
         if (const char *e = std::getenv("TRACS_MFMA_TILE"))
             for (int i = 0; i < mfma_shape_count(); i++)
                 if (!std::strcmp(e, kShapes[i].s.name)) return i;
-        return 0;
+        return -1;
     }();
-    return chosen;
+    return forced >= 0 ? forced : (general ? 1 : 0);
 }
 
 int launch_pairsnp_mfma(int shape, bool general, bool /*with_nn*/, unsigned nwg, hipStream_t stream, const MfmaArgs &a)
