@@ -1,12 +1,12 @@
 #!/bin/bash
 # round 2: full GPU suite, 2x2 stage-depth A/B, the bench line + rocprofv3 kernel trace of the same command, PMC passes
 cd "$GRAFT_REPO_ROOT" || exit 1
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r02d
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r02n
 mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 1800 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pytest rc $?" >> $OUT/pytest.log
 tail -4 $OUT/pytest.log
-for shape in 2x2 2x2g2 3x2; do
+for shape in 2x2 2x2w4x2 3x2; do
   echo "== consensus $shape" >> $OUT/sweep.log
   TRACS_MFMA_TILE=$shape TRACS_BENCH_SITES=400000 timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras >> $OUT/sweep.log 2>&1
 done

@@ -375,7 +375,8 @@ def test_thresholded_dense_early_out(dev, oracle, torch_mod):
                     assert (far >= 0x80000000).mean() > 0.5                # dead tiles are flagged
                 else:                                                      # general: dead tiles keep a lower bound that is already > thr
                     stopped = far != ed[~keep].astype(np.uint32)
-                    assert stopped.mean() > 0.5 and (far[stopped].astype(np.int64) < ed[~keep][stopped].astype(np.int64)).all()
+                    # (256 x 128-pair workgroups: with 70-sample lineages fewer tiles are wholly far than with 128 x 128)
+                    assert stopped.mean() > 0.2 and (far[stopped].astype(np.int64) < ed[~keep][stopped].astype(np.int64)).all()
             rows, cols, dd, nc = dev.coo_from_dense(d, nn, n, dist_threshold=thr)
             xr, xc, xd, xn = oracle.pairsnp_arrays(seqs, dist=thr, n_threads=16)
             assert np.array_equal(rows.cpu().numpy(), xr.astype(np.int32)) and np.array_equal(dd.cpu().numpy(), xd.astype(np.int32))
