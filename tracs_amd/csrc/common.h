@@ -44,7 +44,6 @@ struct tracs_alignment {
     size_t n = 0, L = 0, n_pad = 0, groups = 0;
     uint4 *planes = nullptr;     // device: general encoding, 5 planes
     uint4 *cplanes = nullptr;    // device: consensus encoding, 3 planes (derived on demand, only if valid)
-    uint4 *cwplanes = nullptr;   // device: consensus encoding as operand-ready words, 5 planes (derived on demand from cplanes)
     unsigned *d_flag = nullptr;  // device: "some site has a partial IUPAC code"
     bool dirty = true;           // packed since the encoding was last decided
     int enc = 0;                 // 0 general, 1 consensus

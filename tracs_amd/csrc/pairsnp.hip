@@ -387,27 +387,6 @@ __global__ __launch_bounds__(256) void derive_consensus_kernel(const uint4 *__re
     if (bad) atomicOr(partial_flag, 1u);
 }
 
-// consensus planes (X, Y, V) -> operand-ready words: per (group, sample) four uint4 = the x operands of the group's four
-// 32-site words (dword q takes the sites with bit index = q (mod 4); nibble = x sign << 3 | valid << 1) and one uint4 of Y words
-__global__ __launch_bounds__(256) void derive_consensus_words_kernel(const uint4 *__restrict__ Q, uint4 *__restrict__ W, size_t n_pad, size_t groups)
-{
-    const size_t total = groups * n_pad;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-        const size_t g = e / n_pad, s = e - g * n_pad;
-        const uint4 X = Q[(g * 3 + 0) * n_pad + s], Y = Q[(g * 3 + 1) * n_pad + s], V = Q[(g * 3 + 2) * n_pad + s];
-        const unsigned xs[4] = {X.x, X.y, X.z, X.w}, vs[4] = {V.x, V.y, V.z, V.w};
-#pragma unroll
-        for (int w = 0; w < 4; w++) {
-            const unsigned x = xs[w], v = vs[w];
-            W[(g * NPLANES + w) * n_pad + s] = make_uint4(((x << 3) & 0x88888888u) | ((v << 1) & 0x22222222u),
-                                                          ((x << 2) & 0x88888888u) | (v & 0x22222222u),
-                                                          ((x << 1) & 0x88888888u) | ((v >> 1) & 0x22222222u),
-                                                          (x & 0x88888888u) | ((v >> 2) & 0x22222222u));
-        }
-        W[(g * NPLANES + 4) * n_pad + s] = Y;
-    }
-}
-
 // cells of the block <- L (only needed when the group range is split over workgroups)
 // live tiles of a prefix pass -> compact list (order does not matter: every tile owns its cells)
 __global__ void compact_live_kernel(const int2 *__restrict__ tiles, const unsigned char *__restrict__ live, unsigned n_tiles,
@@ -661,7 +640,6 @@ void tracs_alignment_free(tracs_alignment *a)
     general_sparse_free(a);
     if (a->planes) (void)hipFree(a->planes);
     if (a->cplanes) (void)hipFree(a->cplanes);
-    if (a->cwplanes) (void)hipFree(a->cwplanes);
     if (a->d_flag) (void)hipFree(a->d_flag);
     if (a->d_tiles) (void)hipFree(a->d_tiles);
     delete a;
@@ -800,7 +778,6 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
     if (a->dirty) {
         a->enc = 0;
         general_sparse_free(a);
-        if (a->cwplanes) { TRACS_HIP_CHECK(hipFree(a->cwplanes)); a->cwplanes = nullptr; }
         static const bool force_general = std::getenv("TRACS_FORCE_GENERAL") != nullptr;
         if (!force_general) {
             const size_t cbytes = plane_bytes(a, 3);
@@ -856,23 +833,6 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
         }
     }
     mfma = mfma || mfma_general;
-    // consensus operands from operand-ready word planes (TRACS_CONS_WORDS=1; derived on first use, 5 planes instead of 3)
-    static const bool want_words = env_flag("TRACS_CONS_WORDS") == 1;
-    bool cons_words = false;
-    if (mfma && cons && want_words) {
-        if (!a->cwplanes) {
-            const size_t wbytes = plane_bytes(a, NPLANES);
-            if (hipMalloc(reinterpret_cast<void **>(&a->cwplanes), wbytes) == hipSuccess) {
-                TRACS_HIP_CHECK(hipMemsetAsync(a->cwplanes, 0, wbytes, stream));
-                hipLaunchKernelGGL(derive_consensus_words_kernel, dim3(256 * 16), dim3(256), 0, stream, a->cplanes, a->cwplanes, a->n_pad, a->groups);
-                TRACS_HIP_CHECK(hipGetLastError());
-            } else {
-                a->cwplanes = nullptr;
-                (void)hipGetLastError();
-            }
-        }
-        cons_words = a->cwplanes != nullptr;
-    }
     const int shape_id = mfma_shape_current(mfma_general);
     const MfmaShape &S = mfma_shape(shape_id);
     const int kGC = mfma ? (mfma_general ? S.gc_gen : S.gc_cons) : V.gc;
@@ -929,11 +889,11 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
     auto launch = [&](const int2 *tl, unsigned nwg, int ntl, int g_end, int gps, int k, unsigned t, TilePhase ph) -> int {
         if (mfma) {
             MfmaArgs A;
-            A.P = mfma_general ? a->planes : cons_words ? a->cwplanes : a->cplanes;
+            A.P = mfma_general ? a->planes : a->cplanes;
             A.n_pad = a->n_pad; A.groups = g_end; A.tiles = tl; A.n_tiles = ntl; A.gps = gps; A.ksplit = k;
             A.L = (unsigned)a->L; A.n = (unsigned)a->n; A.row_end = (unsigned)row_end; A.col_begin = (unsigned)col_begin;
             A.dist = dist; A.ncomp = ncomp; A.ld = ld; A.thr = t; A.ph = ph;
-            return launch_pairsnp_mfma(shape_id, mfma_general ? 1 : cons_words ? 2 : 0, nwg, stream, A);
+            return launch_pairsnp_mfma(shape_id, mfma_general, ncomp != nullptr, nwg, stream, A);
         }
         V.launch[cons ? 1 : 0](ncomp != nullptr, nwg, stream, cons ? a->cplanes : a->planes, a->n_pad, g_end, tl, ntl, gps, k,
                                (unsigned)a->L, (unsigned)a->n, (unsigned)row_end, (unsigned)col_begin, dist, ncomp, ld, t, ph);

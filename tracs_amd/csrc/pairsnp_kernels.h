@@ -57,9 +57,8 @@ struct MfmaShape {
 int mfma_shape_count();
 const MfmaShape &mfma_shape(int idx);
 int mfma_shape_current(bool general);
-// mode 0: consensus encoding from the bit planes X, Y, V;  1: general encoding (one-hot A, C, G, T + N);
-// mode 2: consensus encoding from operand-ready word planes (5 per group).
-int launch_pairsnp_mfma(int shape, int mode, unsigned nwg, hipStream_t stream, const MfmaArgs &a);
+// general = false: consensus encoding (operands x, y, z, v);  true: general encoding (one-hot A, C, G, T + N).
+int launch_pairsnp_mfma(int shape, bool general, bool with_nn, unsigned nwg, hipStream_t stream, const MfmaArgs &a);
 
 // ---- sparse side structures of the general matrix-core path (general_sparse.hip) -------------------------------
 struct GeneralSparse;

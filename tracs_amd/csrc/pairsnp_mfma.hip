@@ -52,18 +52,12 @@ __device__ __forceinline__ mfma_v8i fp4_operand(const unsigned (&w)[4])
 #define TRACS_MFMA_FP4(ACC, A_, B_, SC) \
     ACC = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A_, B_, ACC, 4, 4, 0, SC, 0, SC)
 
-// MODE 0: consensus operands from the three bit planes X, Y, V;  MODE 1: general (one-hot) operands;
-// MODE 2: consensus operands from the "operand-ready" planes (derive_consensus_words_kernel): per group and sample four uint4
-//         that ARE the x operands of the group's four 32-site words (nibble = x sign << 3 | valid << 1) plus one uint4 of Y words;
-//         v = x & 0x2222.., y = shifted Y sign | v, z = x ^ (y & 0x8888..): 15 VALU ops per (sample, 32 sites) instead of 29,
-//         for 5/3 of the staging traffic.
-template <int MODE, int NBR, int NBC, int GC, int NWR = 2, int NWC = 2>
+template <bool GENERAL, int NBR, int NBC, int GC, int NWR = 2, int NWC = 2>
 __global__ __launch_bounds__(NWR * NWC * 64, (NBR * NBC > 4 ? 1 : 2)) void pairsnp_mfma_kernel(const MfmaArgs A)
 {
-    constexpr bool GENERAL = MODE == 1;
     // NP planes are staged per group, GP is the group's stride in the stored planes: the general form stages A, C, G, T only and
     // forms N = A & C & G & T in registers (3 VALU ops per word against a fifth of the staging traffic)
-    constexpr int NP = MODE == 1 ? 4 : MODE == 2 ? 5 : 3, GP = MODE == 0 ? 3 : NPLANES, NW = NWR * NWC;
+    constexpr int NP = GENERAL ? 4 : 3, GP = GENERAL ? NPLANES : 3, NW = NWR * NWC;
     constexpr int WI = NBR * 32, WJ = NBC * 32;             // wave tile
     constexpr int TI = NWR * WI, TJ = NWC * WJ, TS = TI + TJ;   // workgroup tile, samples staged per (group, plane)
     constexpr int STAGE = GC * NP * TS;                     // uint4 per LDS stage
@@ -175,69 +169,7 @@ __global__ __launch_bounds__(NWR * NWC * 64, (NBR * NBC > 4 ? 1 : 2)) void pairs
         // next stage to fetch; on the last stage the current one is fetched again (valid memory, never read): no branch in the body
         const int gn = gs + GC < g_end ? gs + GC : gs;
         int piece = 0;
-        if constexpr (MODE == 2) {
-            // units per 32-site step: x (the staged words as they are), v, y, z.  This lane's words of a group are 2 hk, 2 hk + 1:
-            // plane 2 hk + st holds the x operand of step st, plane 4 the Y words.
-            uint4 xw[2][NB];
-            uint2 yw[NB];
-            unsigned ov[NB][4], oy[NB][4], oz[NB][4];
-            auto load_x = [&](int gl, int st, uint4 (&dst)[NB]) {
-#pragma unroll
-                for (int b = 0; b < NB; b++) dst[b] = lds[buf][(gl * NP + 2 * hk + st) * TS + slot_of(b)];
-            };
-            auto load_y = [&](int gl) {
-#pragma unroll
-                for (int b = 0; b < NB; b++) yw[b] = rd2(buf, gl, 4, slot_of(b));
-            };
-            load_x(0, 0, xw[0]);
-            load_y(0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int gl = 0; gl < GC; gl++) {
-#pragma unroll
-                for (int st = 0; st < 2; st++) {
-                    const int par = (gl * 2 + st) & 1;
-                    const bool more = !(gl == GC - 1 && st == 1);
-                    unsigned ox[NB][4];
-#pragma unroll
-                    for (int b = 0; b < NB; b++) { ox[b][0] = xw[par][b].x; ox[b][1] = xw[par][b].y; ox[b][2] = xw[par][b].z; ox[b][3] = xw[par][b].w; }
-                    // unit x | build v; request the next step's x words
-                    TRACS_UNIT_MFMAS(accS, ox, 127)
-#pragma unroll
-                    for (int b = 0; b < NB; b++)
-#pragma unroll
-                        for (int q = 0; q < 4; q++) ov[b][q] = ox[b][q] & M2;
-                    if (more) load_x(st ? gl + 1 : gl, st ^ 1, xw[par ^ 1]);
-                    TRACS_UNIT_STAGE(GC * 8)
-                    TRACS_UNIT_SCHED(NB * 4, NB)
-                    // unit v: nn += v v' | build y
-                    TRACS_UNIT_MFMAS(accV, ov, 127)
-#pragma unroll
-                    for (int b = 0; b < NB; b++) {
-                        const unsigned Y = st ? yw[b].y : yw[b].x;
-                        oy[b][0] = __builtin_amdgcn_bitop3_b32(Y << 3, M8, ov[b][0], 0xEA);     // (a & b) | c
-                        oy[b][1] = __builtin_amdgcn_bitop3_b32(Y << 2, M8, ov[b][1], 0xEA);
-                        oy[b][2] = __builtin_amdgcn_bitop3_b32(Y << 1, M8, ov[b][2], 0xEA);
-                        oy[b][3] = __builtin_amdgcn_bitop3_b32(Y, M8, ov[b][3], 0xEA);
-                    }
-                    TRACS_UNIT_STAGE(GC * 8)
-                    TRACS_UNIT_SCHED(NB * 7, 0)
-                    // unit y | build z = x * y: sign x ^ sign y, magnitude of x
-                    TRACS_UNIT_MFMAS(accS, oy, 127)
-#pragma unroll
-                    for (int b = 0; b < NB; b++)
-#pragma unroll
-                        for (int q = 0; q < 4; q++) oz[b][q] = __builtin_amdgcn_bitop3_b32(ox[b][q], oy[b][q], M8, 0x78);   // a ^ (b & c)
-                    TRACS_UNIT_STAGE(GC * 8)
-                    TRACS_UNIT_SCHED(NB * 4, 0)
-                    // unit z | the next group's Y words are requested (this group's were last used in unit v)
-                    TRACS_UNIT_MFMAS(accS, oz, 127)
-                    if (st == 1 && gl + 1 < GC) load_y(gl + 1);
-                    TRACS_UNIT_STAGE(GC * 8)
-                    TRACS_UNIT_SCHED(0, NB)
-                }
-            }
-        } else if constexpr (!GENERAL) {
+        if constexpr (!GENERAL) {
             // units per 32-site step: v, x, y, z.  vq = the v operand, also the magnitude bits of the three sign operands.
             uint2 rawV[NB], rawXY[NB][2];               // this lane's two words (st = 0, 1) of the current group, per block
             unsigned vq[NB][4], op[2][NB][4];
@@ -436,15 +368,15 @@ __global__ __launch_bounds__(NWR * NWC * 64, (NBR * NBC > 4 ? 1 : 2)) void pairs
 
 // ---------------------------------------------------------------------------------------------------------------------
 typedef void (*MfmaLaunchFn)(unsigned nwg, hipStream_t stream, const MfmaArgs &a);
-template <int MODE, int NBR, int NBC, int GC, int NWR = 2, int NWC = 2>
+template <bool GENERAL, int NBR, int NBC, int GC, int NWR = 2, int NWC = 2>
 static void launch_one(unsigned nwg, hipStream_t stream, const MfmaArgs &a)
 {
-    hipLaunchKernelGGL((pairsnp_mfma_kernel<MODE, NBR, NBC, GC, NWR, NWC>), dim3(nwg), dim3(NWR * NWC * 64), 0, stream, a);
+    hipLaunchKernelGGL((pairsnp_mfma_kernel<GENERAL, NBR, NBC, GC, NWR, NWC>), dim3(nwg), dim3(NWR * NWC * 64), 0, stream, a);
 }
 
-struct ShapeEntry { MfmaShape s; MfmaLaunchFn cons, gen, cw; };
-#define TRACS_SHAPE_N(NAME, R, C, GCC, WPC) {{NAME, R, C, 64 * (R), 64 * (C), GCC, 2, WPC}, launch_one<0, R, C, GCC>, launch_one<1, R, C, 2>, launch_one<2, R, C, GCC>}
-#define TRACS_SHAPE_W(NAME, R, C, GCC, WR, WC, WPC) {{NAME, R, C, 32 * (R) * (WR), 32 * (C) * (WC), GCC, 2, WPC}, launch_one<0, R, C, GCC, WR, WC>, launch_one<1, R, C, 2, WR, WC>, launch_one<2, R, C, GCC, WR, WC>}
+struct ShapeEntry { MfmaShape s; MfmaLaunchFn cons, gen; };
+#define TRACS_SHAPE_N(NAME, R, C, GCC, WPC) {{NAME, R, C, 64 * (R), 64 * (C), GCC, 2, WPC}, launch_one<false, R, C, GCC>, launch_one<true, R, C, 2>}
+#define TRACS_SHAPE_W(NAME, R, C, GCC, WR, WC, WPC) {{NAME, R, C, 32 * (R) * (WR), 32 * (C) * (WC), GCC, 2, WPC}, launch_one<false, R, C, GCC, WR, WC>, launch_one<true, R, C, 2, WR, WC>}
 #define TRACS_SHAPE(R, C, GCC, WPC) TRACS_SHAPE_N(#R "x" #C, R, C, GCC, WPC)
 static const ShapeEntry kShapes[] = {
     TRACS_SHAPE(2, 2, 1, 2),                      // 0: 128 x 128 pairs per workgroup, four waves, two workgroups per CU -- consensus default
@@ -475,10 +407,10 @@ int mfma_shape_current(bool general)
     return forced >= 0 ? forced : (general ? 1 : 0);
 }
 
-int launch_pairsnp_mfma(int shape, int mode, unsigned nwg, hipStream_t stream, const MfmaArgs &a)
+int launch_pairsnp_mfma(int shape, bool general, bool /*with_nn*/, unsigned nwg, hipStream_t stream, const MfmaArgs &a)
 {
-    if (shape < 0 || shape >= mfma_shape_count() || mode < 0 || mode > 2) { set_error("launch_pairsnp_mfma: bad shape / mode"); return TRACS_E_ARG; }
-    (mode == 1 ? kShapes[shape].gen : mode == 2 ? kShapes[shape].cw : kShapes[shape].cons)(nwg, stream, a);
+    if (shape < 0 || shape >= mfma_shape_count()) { set_error("launch_pairsnp_mfma: bad shape"); return TRACS_E_ARG; }
+    (general ? kShapes[shape].gen : kShapes[shape].cons)(nwg, stream, a);
     return TRACS_OK;
 }
 
