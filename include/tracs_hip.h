@@ -190,6 +190,20 @@ int tracs_trans_dist_dense2(const uint32_t *dist, size_t ld, size_t n, const siz
                             size_t col_begin, int32_t dist_threshold, const int32_t *days, double lamb, double beta,
                             double threshold_Ek, int exp_p0, double *p0, double *eK, void *stream);
 
+/* Multi-GPU form of the dense variant: the distinct (N, day gap) keys of the cells are evaluated into a dense key
+ * table [n_max + 1][d_max + 1] (device f64, zeroed by the caller; log p0 and E(K)); a rank evaluates only the keys of its hash
+ * class `part` of `parts`, the caller all-reduces (sums) the tables over the ranks, and tracs_trans_table_gather then writes
+ * p0 / eK of every cell from the completed table.  *overflow (device uint32, zeroed by the caller) is set if a key falls
+ * outside the table.  Same arithmetic as tracs_trans_dist_dense.                                                       */
+int tracs_trans_table_dense(const uint32_t *dist, size_t ld, size_t n, size_t row_begin, size_t row_end, size_t col_begin,
+                            int32_t dist_threshold, const int32_t *days, double lamb, double beta, double threshold_Ek,
+                            int part, int parts, uint32_t n_max, uint32_t d_max, double *table_p0, double *table_eK,
+                            uint32_t *overflow, void *stream);
+int tracs_trans_table_gather(const uint32_t *dist, size_t ld, size_t n, size_t row_begin, size_t row_end, size_t col_begin,
+                             int32_t dist_threshold, const int32_t *days, uint32_t n_max, uint32_t d_max,
+                             const double *table_p0, const double *table_eK, int exp_p0, double *p0, double *eK,
+                             uint32_t *overflow, void *stream);
+
 /* calculate_posteriors on device arrays; counts/posterior are device f64 [L][K].            */
 int tracs_calculate_posteriors_device(const double *counts, size_t L, size_t K, const double *alphas_host,
                                       int keep, double threshold, double *posterior, void *stream);

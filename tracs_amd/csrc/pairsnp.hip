@@ -893,7 +893,7 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
             A.n_pad = a->n_pad; A.groups = g_end; A.tiles = tl; A.n_tiles = ntl; A.gps = gps; A.ksplit = k;
             A.L = (unsigned)a->L; A.n = (unsigned)a->n; A.row_end = (unsigned)row_end; A.col_begin = (unsigned)col_begin;
             A.dist = dist; A.ncomp = ncomp; A.ld = ld; A.thr = t; A.ph = ph;
-            return launch_pairsnp_mfma(shape_id, mfma_general, ncomp != nullptr, nwg, stream, A);
+            return launch_pairsnp_mfma(shape_id, mfma_general, nwg, stream, A);
         }
         V.launch[cons ? 1 : 0](ncomp != nullptr, nwg, stream, cons ? a->cplanes : a->planes, a->n_pad, g_end, tl, ntl, gps, k,
                                (unsigned)a->L, (unsigned)a->n, (unsigned)row_end, (unsigned)col_begin, dist, ncomp, ld, t, ph);

@@ -58,7 +58,7 @@ int mfma_shape_count();
 const MfmaShape &mfma_shape(int idx);
 int mfma_shape_current(bool general);
 // general = false: consensus encoding (operands x, y, z, v);  true: general encoding (one-hot A, C, G, T + N).
-int launch_pairsnp_mfma(int shape, bool general, bool with_nn, unsigned nwg, hipStream_t stream, const MfmaArgs &a);
+int launch_pairsnp_mfma(int shape, bool general, unsigned nwg, hipStream_t stream, const MfmaArgs &a);
 
 // ---- sparse side structures of the general matrix-core path (general_sparse.hip) -------------------------------
 struct GeneralSparse;

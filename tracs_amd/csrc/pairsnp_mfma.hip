@@ -13,8 +13,8 @@
 //         S = 4 * matches - nn,   nn = sum v v',   d = nn - matches = (3 nn - S) / 4.
 //
 //   GENERAL encoding (any IUPAC code; planes A, C, G, T, N as load_seqs builds them):
-//     one-hot Gram  G = sum_s |S_i n S_j|  (four planes, values 0/1)  and  NN = sum_s n_i n_j  (n = A & C & G & T, formed in registers).  For every pair of
-//     codes of which at most one is a partial code,  [S n S' != {}] = |S n S'| - 3 [both N] - (|M| - 1) [one partial, one N],
+//     one-hot Gram  G = sum_s |S_i n S_j|  (four planes, values 0/1)  and  NN = sum_s n_i n_j  (n = A & C & G & T: only the
+//     four allele planes are staged, n is formed in registers).  For every pair of codes of which at most one is a partial code,  [S n S' != {}] = |S n S'| - 3 [both N] - (|M| - 1) [one partial, one N],
 //     so   d = L - G + 3 NN + T1 + T2,   nn = L - c_i - c_j + NN     (c_i = number of N sites of sample i)
 //     where T1 (partial x N) and T2 (partial x partial sharing >= 2 alleles) are sums over the few sites at which a sample
 //     carries a partial code: general_sparse.hip adds them (and the c_i, c_j terms) afterwards.
@@ -28,10 +28,11 @@
 //              onto 0100); the per-instruction block scale (2^+2, 2^0, 2^-2) makes every product exactly 1:
 //              5 VALU ops per (sample, plane, 32 sites).
 //
-// Structure: a workgroup = 2 x 2 waves; each wave owns NBR x NBC blocks of 32 x 32 pairs (two fp32 accumulator sets);
-// an MFMA holds the SIMD's vector issue for 8 of its 32 cycles and the rest hides at most ~6 VALU instructions, so the
-// wave tile is what sets the VALU : MFMA ratio -- (NBR + NBC) expansions feed 4 NBR NBC (5 NBR NBC) instructions.
-// The bit planes of the tile's samples are staged HBM -> LDS directly (global_load_lds_dwordx4), double-buffered.
+// Structure: a workgroup = NWR x NWC waves (2 x 2 for the consensus form, 4 x 2 for the general one, which is the
+// memory-hungrier); each wave owns NBR x NBC blocks of 32 x 32 pairs (two fp32 accumulator sets).  The wave tile sets the
+// VALU : MFMA ratio -- (NBR + NBC) expansions feed 4 NBR NBC (5 NBR NBC) instructions -- but larger wave tiles mean one wave
+// per SIMD and lose (measured).  The bit planes of the tile's samples are staged HBM -> LDS directly
+// (global_load_lds_dwordx4), double-buffered, the staging instructions spread over the units of the software pipeline.
 #include "pairsnp_kernels.h"
 
 #include <cstdlib>
@@ -407,7 +408,7 @@ int mfma_shape_current(bool general)
     return forced >= 0 ? forced : (general ? 1 : 0);
 }
 
-int launch_pairsnp_mfma(int shape, bool general, bool /*with_nn*/, unsigned nwg, hipStream_t stream, const MfmaArgs &a)
+int launch_pairsnp_mfma(int shape, bool general, unsigned nwg, hipStream_t stream, const MfmaArgs &a)
 {
     if (shape < 0 || shape >= mfma_shape_count()) { set_error("launch_pairsnp_mfma: bad shape"); return TRACS_E_ARG; }
     (general ? kShapes[shape].gen : kShapes[shape].cons)(nwg, stream, a);

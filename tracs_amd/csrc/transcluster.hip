@@ -228,6 +228,12 @@ __global__ void lgamma_table_kernel(double *__restrict__ lg, int n)
 }
 
 // ---- key sources ------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x)
+{
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+    return x;
+}
+
 struct ArraySource {            // trans_dist(snpdiff[], datediff[])
     const int *N;
     const double *delta;
@@ -235,6 +241,7 @@ struct ArraySource {            // trans_dist(snpdiff[], datediff[])
     __device__ size_t size() const { return n; }
     __device__ bool get(size_t e, int &Nv, double &dv) const { Nv = N[e]; dv = delta[e]; return true; }
     __device__ size_t out_index(size_t e) const { return e; }
+    __device__ long long day_gap(size_t) const { return -1; }
 };
 
 struct DenseSource {            // cells of a dense distance block, delta from sampling days
@@ -259,13 +266,32 @@ struct DenseSource {            // cells of a dense distance block, delta from s
         return true;
     }
     __device__ size_t out_index(size_t e) const { return row_of(e / n) * ld + e % n; }
+    __device__ long long day_gap(size_t e) const
+    {
+        const long long dd = (long long)days[row_of(e / n)] - (long long)days[e % n];
+        return dd < 0 ? -dd : dd;
+    }
 };
 
-__device__ __forceinline__ unsigned long long mix64(unsigned long long x)
-{
-    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
-    return x;
-}
+// Key table of the multi-GPU path: results of the distinct (N, day gap) keys in a dense [n_max + 1][d_max + 1] layout that
+// every rank indexes the same way.  A rank evaluates the keys of its hash class (part of parts) and leaves the others 0, so an
+// all-reduce (sum) of the tables completes them: 16 bytes per key travel instead of 16 bytes per pair, and a rank pays for
+// 1 / parts of the key evaluations instead of all of them.
+struct KeyTable {
+    int part = 0, parts = 1;
+    unsigned n_max = 0, d_max = 0;
+    double *p0 = nullptr, *eK = nullptr;
+    unsigned *overflow = nullptr;          // set when a key falls outside the table
+    __device__ bool mine(int N, long long gap) const
+    {
+        return parts <= 1 || (int)(mix64(((unsigned long long)(unsigned)N << 32) ^ (unsigned long long)gap) % (unsigned long long)parts) == part;
+    }
+    __device__ long long index(int N, long long gap) const
+    {
+        if (N < 0 || (unsigned)N > n_max || gap < 0 || gap > (long long)d_max) { if (overflow) *overflow = 1u; return -1; }
+        return (long long)N * ((long long)d_max + 1) + gap;
+    }
+};
 
 constexpr unsigned EMPTY = 0xFFFFFFFFu;
 
@@ -324,16 +350,24 @@ constexpr int TC_SERIAL_CAP = 192;      // terms evaluated by the one-thread-per
 template <class Src>
 __global__ void tc_keys_kernel(Src src, const unsigned *__restrict__ key_elem, unsigned nk, TcParams P,
                                const double *__restrict__ lg, double *__restrict__ key_p0, double *__restrict__ key_eK,
-                               unsigned *__restrict__ long_ids, unsigned *__restrict__ n_long, double *__restrict__ key_state)
+                               unsigned *__restrict__ long_ids, unsigned *__restrict__ n_long, double *__restrict__ key_state, KeyTable kt)
 {
     P.ln_lamb = log(P.lamb); P.ln_beta = log(P.beta); P.ln_lb = log(P.lamb + P.beta);
     for (unsigned id = blockIdx.x * blockDim.x + threadIdx.x; id < nk; id += gridDim.x * blockDim.x) {
         int N; double d;
-        src.get((size_t)key_elem[id], N, d);
+        const size_t elem = (size_t)key_elem[id];
+        src.get(elem, N, d);
+        long long slot = -1;
+        if (kt.p0) {
+            const long long gap = src.day_gap(elem);
+            if (!kt.mine(N, gap)) { key_p0[id] = 0.0; key_eK[id] = 0.0; continue; }      // another rank's key
+            slot = kt.index(N, gap);
+        }
         double p0, eK = 0.0; int ks;
         const bool done = tc_eval(N, d, P, lg, p0, eK, ks, TC_SERIAL_CAP, key_state + 4 * (size_t)id);
         key_p0[id] = p0;
-        if (done) key_eK[id] = eK;
+        if (slot >= 0) kt.p0[slot] = p0;
+        if (done) { key_eK[id] = eK; if (slot >= 0) kt.eK[slot] = eK; }
         else long_ids[atomicAdd(n_long, 1u)] = id;
     }
 }
@@ -343,17 +377,37 @@ __global__ __launch_bounds__(64) void tc_long_keys_kernel(Src src, const unsigne
                                                           const unsigned *__restrict__ long_ids,
                                                           const unsigned *__restrict__ n_long, TcParams P,
                                                           const double *__restrict__ lg, double *__restrict__ key_eK,
-                                                          const double *__restrict__ key_state)
+                                                          const double *__restrict__ key_state, KeyTable kt)
 {
     P.ln_lamb = log(P.lamb); P.ln_beta = log(P.beta); P.ln_lb = log(P.lamb + P.beta);
     const unsigned nl = *n_long;
     for (unsigned w = blockIdx.x; w < nl; w += gridDim.x) {
         const unsigned id = long_ids[w];
         int N; double d;
-        src.get((size_t)key_elem[id], N, d);
+        const size_t elem = (size_t)key_elem[id];
+        src.get(elem, N, d);
         double eK;
         tc_eval_wave(N, d, P, lg, eK, key_state + 4 * (size_t)id, TC_SERIAL_CAP);
-        if ((threadIdx.x & 63) == 0) key_eK[id] = eK;
+        if ((threadIdx.x & 63) == 0) {
+            key_eK[id] = eK;
+            if (kt.p0) { const long long slot = kt.index(N, src.day_gap(elem)); if (slot >= 0) kt.eK[slot] = eK; }
+        }
+    }
+}
+
+// multi-GPU path: P / E(K) of every cell from the completed key table
+__global__ void tc_table_gather_kernel(DenseSource src, KeyTable kt, int exp_p0, double *__restrict__ p0, double *__restrict__ eK)
+{
+    const size_t total = src.size();
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        int N; double d;
+        if (!src.get(e, N, d)) continue;
+        const long long slot = kt.index(N, src.day_gap(e));
+        if (slot < 0) continue;
+        const size_t o = src.out_index(e);
+        const double v = kt.p0[slot];
+        p0[o] = exp_p0 ? exp(v) : v;
+        eK[o] = kt.eK[slot];
     }
 }
 
@@ -439,7 +493,7 @@ constexpr size_t TD_MAX_ELEMS = 1ull << 31;       // elements per pass: element 
 
 template <class Src>
 static int run_trans_dist(const Src &src, size_t total, double lamb, double beta, double thr, int exp_p0, double *p0,
-                          double *eK, hipStream_t stream)
+                          double *eK, hipStream_t stream, const KeyTable &kt = KeyTable())
 {
     if (total == 0) return TRACS_OK;
     DeviceCall guard(stream);
@@ -494,12 +548,13 @@ static int run_trans_dist(const Src &src, size_t total, double lamb, double beta
     P.ln_lamb = P.ln_beta = P.ln_lb = 0.0;
     // one wave per block: keys differ widely in trip count, small blocks keep the SIMDs busy
     hipLaunchKernelGGL((tc_keys_kernel<Src>), dim3((nk + 63) / 64), dim3(64), 0, stream, src, key_elem, nk, P, lg, key_p0, key_eK,
-                       long_ids, n_keys + 1, key_state);
+                       long_ids, n_keys + 1, key_state, kt);
     // long series (E(K) loop beyond TC_SERIAL_CAP terms): one wave per key
     hipLaunchKernelGGL((tc_long_keys_kernel<Src>), dim3(std::min<unsigned>(nk, 256u * 32u)), dim3(64), 0, stream, src, key_elem,
-                       long_ids, n_keys + 1, P, lg, key_eK, key_state);
-    hipLaunchKernelGGL((tc_gather_kernel<Src>), dim3(blocks), dim3(256), 0, stream, src, eslot, slot_id, key_p0, key_eK,
-                       exp_p0, p0, eK);
+                       long_ids, n_keys + 1, P, lg, key_eK, key_state, kt);
+    if (p0 && eK)                        // (the key-table form fills its table only)
+        hipLaunchKernelGGL((tc_gather_kernel<Src>), dim3(blocks), dim3(256), 0, stream, src, eslot, slot_id, key_p0, key_eK,
+                           exp_p0, p0, eK);
     TRACS_HIP_CHECK(hipGetLastError());
     return TRACS_OK;
 }
@@ -571,6 +626,40 @@ int tracs_trans_dist_dense2(const uint32_t *dist, size_t ld, size_t n, const siz
     if (n_ranges == 2) { src.row_begin2 = std::min(row_ranges[2], n); src.row_end2 = std::min(row_ranges[3], n); }
     if (src.row_end < src.row_begin || src.row_end2 < src.row_begin2) { set_error("tracs_trans_dist_dense2: bad range"); return TRACS_E_ARG; }
     return dense_passes(src, lamb, beta, threshold_Ek, exp_p0, p0, eK, static_cast<hipStream_t>(stream));
+}
+
+int tracs_trans_table_dense(const uint32_t *dist, size_t ld, size_t n, size_t row_begin, size_t row_end, size_t col_begin,
+                            int32_t dist_threshold, const int32_t *days, double lamb, double beta, double threshold_Ek, int part,
+                            int parts, uint32_t n_max, uint32_t d_max, double *table_p0, double *table_eK, uint32_t *overflow,
+                            void *stream)
+{
+    if (!dist || !days || !table_p0 || !table_eK || !overflow) { set_error("tracs_trans_table_dense: NULL argument"); return TRACS_E_ARG; }
+    if (parts < 1 || part < 0 || part >= parts) { set_error("tracs_trans_table_dense: bad key partition"); return TRACS_E_ARG; }
+    if (row_end > n) row_end = n;
+    if (row_begin >= row_end) return TRACS_OK;
+    if ((row_end - row_begin) * n > TD_MAX_ELEMS) { set_error("tracs_trans_table_dense: more than 2^31 cells per call"); return TRACS_E_ARG; }
+    DenseSource src{dist, days, ld, n, row_begin, row_end, col_begin, dist_threshold};
+    KeyTable kt;
+    kt.part = part; kt.parts = parts; kt.n_max = n_max; kt.d_max = d_max; kt.p0 = table_p0; kt.eK = table_eK; kt.overflow = overflow;
+    g_last_keys = 0;
+    return run_trans_dist(src, (row_end - row_begin) * n, lamb, beta, threshold_Ek, 0, nullptr, nullptr, static_cast<hipStream_t>(stream), kt);
+}
+
+int tracs_trans_table_gather(const uint32_t *dist, size_t ld, size_t n, size_t row_begin, size_t row_end, size_t col_begin,
+                             int32_t dist_threshold, const int32_t *days, uint32_t n_max, uint32_t d_max, const double *table_p0,
+                             const double *table_eK, int exp_p0, double *p0, double *eK, uint32_t *overflow, void *stream)
+{
+    if (!dist || !days || !table_p0 || !table_eK || !p0 || !eK || !overflow) { set_error("tracs_trans_table_gather: NULL argument"); return TRACS_E_ARG; }
+    if (row_end > n) row_end = n;
+    if (row_begin >= row_end) return TRACS_OK;
+    DenseSource src{dist, days, ld, n, row_begin, row_end, col_begin, dist_threshold};
+    KeyTable kt;
+    kt.n_max = n_max; kt.d_max = d_max; kt.p0 = const_cast<double *>(table_p0); kt.eK = const_cast<double *>(table_eK); kt.overflow = overflow;
+    const size_t total = (row_end - row_begin) * n;
+    hipLaunchKernelGGL(tc_table_gather_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 256 * 32)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), src, kt, exp_p0, p0, eK);
+    TRACS_HIP_CHECK(hipGetLastError());
+    return TRACS_OK;
 }
 
 int tracs_trans_dist(const int32_t *snpdiff, const double *datediff, size_t n, double lamb, double beta,

@@ -214,6 +214,32 @@ def trans_dist_dense_ranges(dist, n, days, lamb, beta, threshold_Ek, p0, eK, ran
                                          _stream()))
 
 
+def trans_dist_dense_partitioned(dist, n, days, lamb, beta, threshold_Ek, p0, eK, part, parts, all_reduce, exp_p0=True,
+                                 dist_threshold=2147483647, n_max=None, d_max=None):
+    """trans_dist_dense over the WHOLE matrix on every rank, with the key evaluations split over the ranks: this rank evaluates
+    the keys of hash class `part` of `parts` into a dense key table, `all_reduce(tensor)` sums the tables over the ranks
+    (torch.distributed: RCCL), and p0 / eK of every cell are read from the completed table."""
+    L = _lib.require_gpu()
+    ld = dist.stride(0)
+    assert p0.stride(0) == ld and eK.stride(0) == ld
+    if n_max is None:
+        valid = torch.triu(dist[:n, :n], diagonal=1)
+        n_max = int(torch.where(valid <= dist_threshold, valid, torch.zeros_like(valid)).max().item())
+    if d_max is None:
+        d_max = int((days.max() - days.min()).item())
+    table = torch.zeros((2, n_max + 1, d_max + 1), dtype=torch.float64, device=dist.device)
+    flag = torch.zeros(1, dtype=torch.int32, device=dist.device)
+    _lib.check(L.tracs_trans_table_dense(_ptr(dist), ld, n, 0, n, 0, int(dist_threshold), _ptr(days), float(lamb), float(beta),
+                                         float(threshold_Ek), int(part), int(parts), n_max, d_max, _ptr(table[0]), _ptr(table[1]),
+                                         _ptr(flag), _stream()))
+    if parts > 1:
+        all_reduce(table)
+    _lib.check(L.tracs_trans_table_gather(_ptr(dist), ld, n, 0, n, 0, int(dist_threshold), _ptr(days), n_max, d_max, _ptr(table[0]),
+                                          _ptr(table[1]), int(exp_p0), _ptr(p0), _ptr(eK), _ptr(flag), _stream()))
+    if int(flag.item()):
+        raise _lib.TracsError("trans_dist key table too small (n_max / d_max)")
+
+
 def calculate_posteriors_device(counts, alphas, keep, threshold):
     L = _lib.require_gpu()
     a = np.ascontiguousarray(alphas, dtype=np.float64)
