@@ -183,3 +183,28 @@ def test_general_path_beyond_one_lds_row(dev, oracle):
     keep = ed <= thr
     assert keep.sum() > 100 and np.array_equal(d2s[li[keep], lj[keep]], ed[keep].astype(np.int32))
     assert ((d2s[li[~keep], lj[~keep]].astype(np.int64) > thr) | (d2s[li[~keep], lj[~keep]] < 0)).all()
+
+
+def test_config5_edge_clustering_two_ranks_equals_one():
+    """scripts/bench_config5.py (per-rank panels -> transcluster -> E(K) threshold edges -> edge gather -> components) with two
+    gloo ranks sharing the GPU gives the components of the single-process run; the single-process run checks itself against SciPy."""
+    import json
+    import socket
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "scripts", "bench_config5.py")
+    one = subprocess.run([sys.executable, script, "--samples", "6100", "--check", "6100"], capture_output=True, text=True, cwd=root, timeout=600)
+    assert one.returncode == 0, one.stderr[-3000:]
+    r1 = json.loads(one.stdout.strip().splitlines()[-1])
+    assert r1["scipy_check"] is True and r1["edges_rank0_chunks"] > 1000 and 1 < r1["components"] < 6100
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, TRACS_DIST_BACKEND="gloo")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), script, "--samples", "6100", "--gpus", "2"], capture_output=True, text=True,
+                         cwd=root, env=env, timeout=600)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-3000:]
+    r2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+    assert r2["n_gpus"] == 2 and r2["components"] == r1["components"]

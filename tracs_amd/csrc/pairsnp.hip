@@ -812,7 +812,9 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
     const double cells = (double)(row_end - row_begin) * (double)a->n;      // upper bound of the cells of this call
 
     // ---- kernel: matrix cores unless switched off (TRACS_MFMA=0, or an explicit TRACS_TILE_VARIANT) ------------------------
-    static const bool mfma_off = env_flag("TRACS_MFMA") == 0 || std::getenv("TRACS_TILE_VARIANT") != nullptr;
+    // (the matrix-core kernels keep 32-bit element offsets inside a stage: n_pad < 2^28 samples)
+    static const bool mfma_env_off = env_flag("TRACS_MFMA") == 0 || std::getenv("TRACS_TILE_VARIANT") != nullptr;
+    const bool mfma_off = mfma_env_off || a->n_pad >= (1ull << 28);
     bool mfma = cons && !mfma_off;
     bool mfma_general = false;
     if (!cons && !mfma_off && a->L < (1ull << 28)) {
