@@ -211,31 +211,55 @@ __global__ __launch_bounds__(1024) void general_fixup_kernel(const unsigned long
             if (my_code != 15u) { my_na = n_off[site]; my_nz = n_off[site + 1]; }
         }
         const int cnt = (int)min((unsigned long long)16, e1 - base);
-        // a list is walked 64 entries at a time: each lane requests its four entries before it touches the first, so the walk
-        // costs one memory round trip per 64 list entries instead of one per 16
-#define TRACS_WALK(ENT, A_, Z_, BODY)                                                                    \
-        for (unsigned long long t = (A_) + l16; t < (Z_); t += 64) {                                         \
-            const bool h1 = t + 16 < (Z_), h2 = t + 32 < (Z_), h3 = t + 48 < (Z_);                            \
-            const unsigned v0 = ENT[t], v1 = h1 ? ENT[t + 16] : 0u, v2 = h2 ? ENT[t + 32] : 0u, v3 = h3 ? ENT[t + 48] : 0u; \
-            { const unsigned v = v0; BODY }                                                                   \
-            if (h1) { const unsigned v = v1; BODY }                                                           \
-            if (h2) { const unsigned v = v2; BODY }                                                           \
-            if (h3) { const unsigned v = v3; BODY }                                                           \
-        }
-        for (int k = 0; k < cnt; k++) {
+        // The 16 sites' lists are walked one site after the other, 64 list entries per memory round trip (each lane requests its
+        // four entries before it touches the first) -- and the first round trip of site k + 1 (the head of its partial list, and
+        // of its N list when i is partial there) is already in flight while site k's entries are applied.
+        struct Head { unsigned p[4], n[4]; };
+        auto fetch_head = [&](int k, Head &h) {
             const unsigned code = __shfl(my_code, k, 16);
-            const unsigned long long pa = __shfl(my_pa, k, 16), pz = __shfl(my_pz, k, 16);
-            if (code == 15u) {                               // i is N here: every partial j > i gains |M_j| - 1
-                TRACS_WALK(p_ent, pa, pz, { const unsigned j = v >> 4; if (j > i && j >= c0 && j < c1) atomicAdd(&row[j - c0], (unsigned)__popc(v & 15u) - 1u); })
-            } else {                                         // i is partial here
-                const unsigned kk = (unsigned)__popc(code) - 1u;
-                const unsigned long long na = __shfl(my_na, k, 16), nz = __shfl(my_nz, k, 16);
-                TRACS_WALK(n_ent, na, nz, { const unsigned j = v; if (j > i && j >= c0 && j < c1) atomicAdd(&row[j - c0], kk); })
-                TRACS_WALK(p_ent, pa, pz, { const unsigned j = v >> 4; const int sh = __popc(v & code) - 1;
-                                            if (sh > 0 && j > i && j >= c0 && j < c1) atomicAdd(&row[j - c0], (unsigned)sh); })
+            const unsigned long long pa = __shfl(my_pa, k, 16) + l16, pz = __shfl(my_pz, k, 16);
+            const unsigned long long na = __shfl(my_na, k, 16) + l16, nz = __shfl(my_nz, k, 16);
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                h.p[m] = pa + 16 * m < pz ? p_ent[pa + 16 * m] : 0xFFFFFFFFu;
+                h.n[m] = (code != 15u && na + 16 * m < nz) ? n_ent[na + 16 * m] : 0xFFFFFFFFu;
             }
+        };
+        Head cur, nxt;
+        fetch_head(0, cur);
+        for (int k = 0; k < cnt; k++) {
+            if (k + 1 < cnt) fetch_head(k + 1, nxt);
+            const unsigned code = __shfl(my_code, k, 16);
+            const bool i_is_n = code == 15u;
+            const unsigned kk = (unsigned)__popc(code) - 1u;           // |M_i| - 1 when i is partial here
+            auto apply_p = [&](unsigned v) {                          // a partial j: i N -> |M_j| - 1; both partial -> (|M_i n M_j| - 1)^+
+                const unsigned j = v >> 4;
+                const int add = i_is_n ? __popc(v & 15u) - 1 : __popc(v & code) - 1;
+                if (add > 0 && j > i && j >= c0 && j < c1) atomicAdd(&row[j - c0], (unsigned)add);
+            };
+            auto apply_n = [&](unsigned j) {                          // an N j, i partial here: |M_i| - 1
+                if (j > i && j >= c0 && j < c1) atomicAdd(&row[j - c0], kk);
+            };
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                if (cur.p[m] != 0xFFFFFFFFu) apply_p(cur.p[m]);
+                if (cur.n[m] != 0xFFFFFFFFu) apply_n(cur.n[m]);
+            }
+            // the tails beyond the first 64 entries (N lists of ~100 samples at 1 % N; rarely the partial list)
+            const unsigned long long pz = __shfl(my_pz, k, 16), nz = __shfl(my_nz, k, 16);
+            for (unsigned long long t = __shfl(my_pa, k, 16) + 64 + l16; t < pz; t += 64) {
+                const bool h1 = t + 16 < pz, h2 = t + 32 < pz, h3 = t + 48 < pz;
+                const unsigned v0 = p_ent[t], v1 = h1 ? p_ent[t + 16] : 0u, v2 = h2 ? p_ent[t + 32] : 0u, v3 = h3 ? p_ent[t + 48] : 0u;
+                apply_p(v0); if (h1) apply_p(v1); if (h2) apply_p(v2); if (h3) apply_p(v3);
+            }
+            if (!i_is_n)
+                for (unsigned long long t = __shfl(my_na, k, 16) + 64 + l16; t < nz; t += 64) {
+                    const bool h1 = t + 16 < nz, h2 = t + 32 < nz, h3 = t + 48 < nz;
+                    const unsigned v0 = n_ent[t], v1 = h1 ? n_ent[t + 16] : 0u, v2 = h2 ? n_ent[t + 32] : 0u, v3 = h3 ? n_ent[t + 48] : 0u;
+                    apply_n(v0); if (h1) apply_n(v1); if (h2) apply_n(v2); if (h3) apply_n(v3);
+                }
+            cur = nxt;
         }
-#undef TRACS_WALK
     }
     __syncthreads();
     const unsigned ci = c_n[i];
