@@ -416,14 +416,45 @@ def cpu_baseline(n, L, seed, days_np, args, dmat, nmat, n_keys_full):
     key_rate = done / t_tc
     pairs_total = n * (n - 1) // 2
     value = pairs_total / (pairs_total / pair_rate + n_keys_full / key_rate)
+    ref = _reference_trans_dist(kd[:done], kdel[:done], args)
     return {"value": value, "unit": "pairs/s", "cores": cores, "kind": "port",
             "pairsnp_pairs_per_s": pair_rate, "pairsnp_threads": cores, "pairsnp_seconds": t_snp,
             "trans_dist_keys_per_s": key_rate, "trans_dist_threads": 1, "trans_dist_seconds": t_tc,
+            "trans_dist_reference": ref,
             "distinct_keys_full_matrix": n_keys_full,
             "sample": "pair loop: first %d samples x %d sites of the same alignment = %d pairs, oracle pair loop (two passes), %d OpenMP "
                       "threads, %d repeats = %.1f s; trans_dist: serial memoised, %d distinct (N, delta) keys of those pairs = %.1f s; "
                       "value = pairs / (pairs / pair rate + %d distinct keys of the full matrix (GPU dedup) / key rate); GPU d/nn "
                       "bit-equal on this block" % (m, L, pairs, cores, reps, t_snp, done, t_tc, n_keys_full)}
+
+
+def _reference_trans_dist(kd, kdel, args):
+    """The same distinct keys through oracle/_ref (the reference's own transcluster source compiled in place by oracle/Makefile
+    with the reference's flags), serial, in a child process because that build's -ffast-math sets flush-to-zero for the whole
+    process.  Reported beside the port's key rate, not folded into `value`; None when oracle/_ref was not built."""
+    import subprocess, tempfile
+    import numpy as np
+    here = os.path.dirname(os.path.abspath(__file__))
+    if not os.path.isdir(os.path.join(here, "oracle", "_ref")) or len(kd) == 0:
+        return None
+    code = ("import sys, time, json, numpy as np\n"
+            "sys.path.insert(0, %r)\n"
+            "from oracle import oracle as O\n"
+            "R = O.ref_module()\n"
+            "if R is None: print('null'); sys.exit(0)\n"
+            "z = np.load(sys.argv[1]); N = z['N'].tolist(); D = z['D'].tolist()\n"
+            "t0 = time.perf_counter(); e = R.ref_trans_dist(N, D, %r, %r, %r); t = time.perf_counter() - t0\n"
+            "print(json.dumps({'keys': len(N), 'seconds': t, 'keys_per_s': len(N) / t, 'kind': 'reference', 'threads': 1}))\n"
+            % (here, args.lamb, args.beta, args.precision))
+    with tempfile.TemporaryDirectory() as tmp:
+        f = os.path.join(tmp, "keys.npz")
+        np.savez(f, N=np.asarray(kd, dtype=np.int64), D=np.asarray(kdel, dtype=np.float64))
+        try:
+            out = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True,
+                                 timeout=max(120.0, 20 * args.cpu_seconds))
+            return json.loads(out.stdout.strip().splitlines()[-1]) if out.returncode == 0 and out.stdout.strip() else None
+        except (subprocess.TimeoutExpired, ValueError):
+            return None
 
 
 if __name__ == "__main__":
