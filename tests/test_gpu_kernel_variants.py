@@ -17,6 +17,7 @@ sys.path.insert(0, %(root)r)
 from oracle import oracle as O
 from tracs_amd import device as dev, synth
 used = set()
+classes = set()
 for n, L, p_partial in ((300, 20000, 0.0), (300, 20000, 0.004), (131, 130000, 0.0), (131, 130000, 0.002), (70, 777, 0.02)):
     seqs = synth.alignment(n, L, seed=n + L, mu_lineage=2e-3, mu_sample=3e-4, n_lineages=5, p_n=0.02, p_partial=p_partial, p_other=0.001)
     aln = dev.Alignment(n, L)
@@ -26,6 +27,7 @@ for n, L, p_partial in ((300, 20000, 0.0), (300, 20000, 0.004), (131, 130000, 0.
     d = torch.zeros((n, n), dtype=torch.int32, device="cuda"); nn = torch.zeros_like(d)
     dev.pairsnp_dense(aln, d, nn)
     used.add((aln.encoding, aln.kernel))
+    classes.add(aln.site_classes is not None)
     assert np.array_equal(d.cpu().numpy()[ri, ci], ed.astype(np.int32)), ("d", n, L, p_partial)
     assert np.array_equal(nn.cpu().numpy()[ri, ci], enn.astype(np.int32)), ("nn", n, L, p_partial)
     thr = int(np.percentile(ed, 30))
@@ -44,6 +46,7 @@ for n, L, p_partial in ((300, 20000, 0.0), (300, 20000, 0.004), (131, 130000, 0.
     assert np.array_equal(d.cpu().numpy()[ri[sel], ci[sel]], ed[sel].astype(np.int32))
     aln.close()
 print("USED", sorted(used))
+print("CLASSES", sorted(classes))
 '''
 
 VARIANTS = [
@@ -55,6 +58,9 @@ VARIANTS = [
     ({"TRACS_TILE_VARIANT": "2"}, {("consensus", "valu"), ("general", "valu")}),
     ({"TRACS_TILE_VARIANT": "3", "TRACS_KSPLIT": "3"}, {("consensus", "valu"), ("general", "valu")}),
     ({"TRACS_KSPLIT": "4", "TRACS_SUPERTILE": "2x2"}, {("consensus", "mfma"), ("general", "mfma-general")}),
+    ({"TRACS_SITE_CLASSES": "0"}, {("consensus", "mfma"), ("general", "mfma-general")}),
+    ({"TRACS_SITE_CLASSES": "1", "TRACS_KSPLIT": "3"}, {("consensus", "mfma"), ("general", "mfma-general")}),
+    ({"TRACS_SITE_CLASSES": "1", "TRACS_MFMA_TILE": "2x2w4x2"}, {("consensus", "mfma"), ("general", "mfma-general")}),
 ]
 
 
@@ -66,3 +72,11 @@ def test_kernel_variant_against_oracle(hiplib, oracle, env, expect):
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("USED")][-1]
     used = set(eval(line[5:]))
     assert used == expect, (used, expect)
+    # site classes (csrc/site_classes.hip) only ever run with the matrix-core kernels; forced on / off by their switch
+    classes = set(eval([ln for ln in out.stdout.splitlines() if ln.startswith("CLASSES")][-1][8:]))
+    if env.get("TRACS_SITE_CLASSES") == "0" or all(k == "valu" for _, k in expect):
+        assert classes == {False}, classes
+    elif env.get("TRACS_SITE_CLASSES") == "1":
+        assert classes == {True}, classes
+    else:
+        assert True in classes, classes

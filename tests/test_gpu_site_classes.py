@@ -1,0 +1,126 @@
+"""Site classes (csrc/site_classes.hip): alignments whose sites are mostly invariant run the pair kernels over the variable
+sites only and complete the compared-sites counts with a one-operand pass over the invariant sites.  Results must stay
+bit-identical to the oracle's pair loop (src/pairsnp.hpp:395-420) in every geometry: both encodings, plain / thresholded /
+panel calls, class sizes that are not multiples of a group, no variable site at all, no invariant site at all."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+BASES = np.frombuffer(b"ACGT", dtype=np.uint8)
+PARTIAL = np.frombuffer(b"MRWSYKVHDB", dtype=np.uint8)
+
+
+def _structured(n, L, seed, mu=2e-4, p_n=0.02, p_empty=0.01, p_partial=0.0, identical=False):
+    """One ancestor, per-sample substitutions at rate mu, N at rate p_n, whole columns of N at rate p_empty, optional
+    partial IUPAC codes; `identical`: no substitutions at all (every site invariant or empty)."""
+    rng = np.random.default_rng(seed)
+    anc = BASES[rng.integers(0, 4, size=L)]
+    seqs = np.tile(anc, (n, 1))
+    if not identical:
+        mut = rng.random((n, L)) < mu
+        seqs[mut] = BASES[rng.integers(0, 4, size=int(mut.sum()))]
+    seqs[rng.random((n, L)) < p_n] = ord("N")
+    seqs[:, rng.random(L) < p_empty] = ord("N")
+    if p_partial:
+        part = rng.random((n, L)) < p_partial
+        seqs[part] = PARTIAL[rng.integers(0, len(PARTIAL), size=int(part.sum()))]
+    return seqs
+
+
+def _check(dev, oracle, seqs, expect_classes=True, thresholds=True):
+    import torch
+    n, L = seqs.shape
+    aln = dev.Alignment(n, L)
+    aln.pack(seqs)
+    er, ec, ed, enn = oracle.pairsnp_arrays(seqs, n_threads=8)
+    ri, ci = er.astype(np.int64), ec.astype(np.int64)
+    d = torch.zeros((n, n), dtype=torch.int32, device="cuda")
+    nn = torch.zeros_like(d)
+    dev.pairsnp_dense(aln, d, nn)
+    cls = aln.site_classes
+    assert (cls is not None) == expect_classes, cls
+    if cls is not None:
+        assert cls[0] + cls[1] <= L
+    assert np.array_equal(d.cpu().numpy()[ri, ci], ed.astype(np.int32))
+    assert np.array_equal(nn.cpu().numpy()[ri, ci], enn.astype(np.int32))
+    # d only (no compared-sites matrix): the counting pass is skipped
+    d.zero_()
+    dev.pairsnp_dense(aln, d, None)
+    assert np.array_equal(d.cpu().numpy()[ri, ci], ed.astype(np.int32))
+    # a row panel against a column block (two-file geometry)
+    d.zero_(); nn.zero_()
+    dev.pairsnp_dense(aln, d, nn, row_begin=n // 4, row_end=n // 2, col_begin=n // 3)
+    sel = (ri >= n // 4) & (ri < n // 2) & (ci >= n // 3)
+    assert np.array_equal(d.cpu().numpy()[ri[sel], ci[sel]], ed[sel].astype(np.int32))
+    assert np.array_equal(nn.cpu().numpy()[ri[sel], ci[sel]], enn[sel].astype(np.int32))
+    if thresholds and len(ed):
+        for q in (10, 60):
+            thr = int(np.percentile(ed, q))
+            d.zero_(); nn.zero_()
+            dev.pairsnp_dense(aln, d, nn, dist_threshold=thr)
+            keep = ed <= thr
+            dh = d.cpu().numpy()
+            assert np.array_equal(dh[ri[keep], ci[keep]], ed[keep].astype(np.int32))
+            assert np.array_equal(nn.cpu().numpy()[ri[keep], ci[keep]], enn[keep].astype(np.int32))
+            far = dh[ri[~keep], ci[~keep]].astype(np.int64)
+            assert ((far > thr) | (far < 0)).all()
+    aln.close()
+    return cls
+
+
+@pytest.mark.parametrize("n,L,p_partial", [(70, 5000, 0.0), (70, 5000, 0.0005), (200, 40000, 0.0), (200, 40000, 0.0002),
+                                           (131, 300001, 0.0), (131, 300001, 0.0001), (33, 129, 0.0), (700, 9000, 0.0)])
+def test_site_classes_match_oracle(hiplib, oracle, n, L, p_partial):
+    from tracs_amd import device as dev
+    seqs = _structured(n, L, seed=n * 7 + L, p_partial=p_partial, mu=2e-4 if L > 1000 else 5e-3)
+    cls = _check(dev, oracle, seqs)
+    assert 0 < cls[0] < L and cls[1] > 0
+
+
+def test_no_variable_site(hiplib, oracle):
+    """Identical samples (+ N): every distance is 0 and the compared-sites counts come from the invariant sites alone."""
+    from tracs_amd import device as dev
+    seqs = _structured(90, 7000, seed=3, identical=True)
+    cls = _check(dev, oracle, seqs, thresholds=False)
+    assert cls[0] == 0 and cls[1] > 0
+
+
+def test_single_variable_site_and_ragged_classes(hiplib, oracle):
+    from tracs_amd import device as dev
+    seqs = _structured(150, 1000, seed=4, identical=True, p_empty=0.0)
+    seqs[7, 500] = ord("A") if seqs[0, 500] != ord("A") else ord("C")
+    seqs[:, 500][seqs[:, 500] == ord("N")] = seqs[0, 0]           # keep the site comparable whatever row 0 holds
+    cls = _check(dev, oracle, seqs)
+    assert cls[0] >= 1
+
+
+def test_dense_alignment_stays_whole(hiplib, oracle):
+    """Uniformly random bases: every site is variable, the classes are not used (cost model, csrc/site_classes.hip)."""
+    from tracs_amd import device as dev
+    rng = np.random.default_rng(8)
+    seqs = BASES[rng.integers(0, 4, size=(100, 3000))]
+    seqs[rng.random(seqs.shape) < 0.02] = ord("N")
+    _check(dev, oracle, seqs, expect_classes=False)
+
+
+def test_repack_redecides(hiplib, oracle):
+    """Packing again drops the classes of the previous contents."""
+    import torch
+    from tracs_amd import device as dev
+    n, L = 64, 6000
+    a = _structured(n, L, seed=21)
+    rng = np.random.default_rng(22)
+    b = BASES[rng.integers(0, 4, size=(n, L))]
+    aln = dev.Alignment(n, L)
+    d = torch.zeros((n, n), dtype=torch.int32, device="cuda")
+    nn = torch.zeros_like(d)
+    for seqs, expect in ((a, True), (b, False), (a, True)):
+        aln.pack(seqs)
+        dev.pairsnp_dense(aln, d, nn)
+        assert (aln.site_classes is not None) == expect
+        er, ec, ed, enn = oracle.pairsnp_arrays(seqs, n_threads=8)
+        ri, ci = er.astype(np.int64), ec.astype(np.int64)
+        assert np.array_equal(d.cpu().numpy()[ri, ci], ed.astype(np.int32))
+        assert np.array_equal(nn.cpu().numpy()[ri, ci], enn.astype(np.int32))
+    aln.close()

@@ -174,3 +174,37 @@ def test_general_matrix_core_identity():
                 T2 = int((np.maximum(inter - 1, 0) * (pa & pb)).sum())
                 assert L - G + 3 * NN + T1 + T2 == d_true
                 assert L - int((a == 15).sum()) - int((b == 15).sum()) + NN == nn_true
+
+
+def test_site_class_identity():
+    """The identity behind site classes (csrc/site_classes.hip): with the sites cut into variable (two samples carry different
+    bases, or some sample carries a partial IUPAC code), invariant (not variable, some sample is a base) and empty (all N),
+    d(i, j) over all sites = d over the variable sites, and nn(i, j) = nn over the variable sites + sum over the invariant
+    sites of [i is a base][j is a base] -- checked against the definition (src/pairsnp.hpp:398-403,417-420)."""
+    rng = np.random.default_rng(11)
+    n, L = 12, 4000
+    pc = np.array([bin(x).count("1") for x in range(16)])
+    for p_partial in (0.0, 0.002):
+        anc = 1 << rng.integers(0, 4, size=L)
+        codes = np.tile(anc, (n, 1))
+        mut = rng.random((n, L)) < 0.01
+        codes[mut] = 1 << rng.integers(0, 4, size=int(mut.sum()))
+        codes[rng.random((n, L)) < 0.05] = 15
+        codes[:, rng.random(L) < 0.02] = 15                       # empty sites
+        part = rng.random((n, L)) < p_partial
+        codes[part] = rng.integers(1, 16, size=int(part.sum()))
+        is_n = codes == 15
+        partial = (pc[codes] > 1) & ~is_n
+        seen = np.zeros((4, L), dtype=bool)                        # allele b seen at a base (non-N) position
+        for b in range(4):
+            seen[b] = (((codes >> b) & 1).astype(bool) & ~is_n).any(axis=0)
+        var = partial.any(axis=0) | (seen.sum(axis=0) >= 2)
+        inv = ~var & (~is_n).any(axis=0)
+        assert 0 < var.sum() < L and inv.sum() > 0 and (~var & ~inv).sum() > 0
+        for i in range(n):
+            for j in range(i + 1, n):
+                a, b = codes[i], codes[j]
+                miss = pc[a & b] == 0
+                both = ~is_n[i] & ~is_n[j]
+                assert int(miss.sum()) == int(miss[var].sum())
+                assert int(both.sum()) == int(both[var].sum()) + int(both[inv].sum())

@@ -198,6 +198,12 @@ def load():
     L.tracs_debug_alignment_encoding.argtypes = [vp]
     L.tracs_debug_alignment_kernel.restype = C.c_int
     L.tracs_debug_alignment_kernel.argtypes = [vp]
+    L.tracs_debug_alignment_site_classes.restype = C.c_int
+    L.tracs_debug_alignment_site_classes.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.tracs_debug_pair_timing.restype = None
+    L.tracs_debug_pair_timing.argtypes = [C.c_int]
+    L.tracs_debug_last_pair_ms.restype = C.c_int
+    L.tracs_debug_last_pair_ms.argtypes = [C.POINTER(C.c_float)]
     L.tracs_debug_tile_variant.restype = C.c_char_p
     L.tracs_debug_mfma_shape.restype = C.c_char_p
     L.tracs_debug_last_trans_dist_keys.restype = C.c_uint64

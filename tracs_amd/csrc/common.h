@@ -48,6 +48,14 @@ struct tracs_alignment {
     bool dirty = true;           // packed since the encoding was last decided
     int enc = 0;                 // 0 general, 1 consensus
     int last_kernel = -1;        // kernel of the last dense call: 0 VALU tile kernel, 1 / 2 matrix-core kernel (consensus / one-hot)
+    // Site classes (site_classes.hip), decided once per pack: a site at which every sample that is not N carries the same
+    // base adds 0 to every distance and [neither is N] to every compared-sites count.  When enough sites are like that the
+    // pair kernels read `vplanes` -- the alignment restricted to the VARIABLE sites, same encoding and layout as their usual
+    // source -- and a one-operand matrix-core pass over `iplanes` (the INVARIANT sites' "is a base here" plane) adds the rest
+    // of the compared-sites counts.  Sites at which every sample is N belong to neither.
+    uint4 *vplanes = nullptr, *iplanes = nullptr;
+    size_t L_var = 0, L_inv = 0, groups_var = 0, groups_inv = 0;
+    int classes_state = 0;       // 0 not decided, 1 in use, -1 not in use for this alignment
     tracs::GeneralSparse *sparse = nullptr;   // general matrix-core path: per-site / per-sample lists of N and partial codes
     int sparse_state = 0;        // 0 not built, 1 built, -1 not available for this alignment (too dense / too large / no memory)
     // cached tile schedule for the last dense region (device + host mirror)
@@ -58,6 +66,15 @@ struct tracs_alignment {
 };
 
 namespace tracs {
+// what the pair kernels read: the whole alignment, or its variable sites (site classes in use)
+static inline const uint4 *pair_planes(const tracs_alignment *a, bool consensus)
+{
+    return a->classes_state == 1 ? a->vplanes : (consensus ? a->cplanes : a->planes);
+}
+static inline size_t pair_L(const tracs_alignment *a) { return a->classes_state == 1 ? a->L_var : a->L; }
+static inline size_t pair_groups(const tracs_alignment *a) { return a->classes_state == 1 ? a->groups_var : a->groups; }
+constexpr int COUNT_PAD_GROUPS = 3;  // zero groups behind `iplanes`: the counting pass stages four groups at a time
+
 // Grow-only per-device scratch buffers (slot ids are small integers owned by each .hip file), shared by every entry point.
 // Entry points that use them, or the cached state of a tracs_alignment, hold a DeviceCall for their whole body:
 //   * calls on one device are serialised (ctypes releases the GIL, so two Python threads can be inside the library);

@@ -291,7 +291,8 @@ int general_sparse_get(tracs_alignment *a, hipStream_t stream, int *ok, double *
     if (a->sparse_state == -1) return TRACS_OK;
     if (a->sparse_state == 1) { *ok = 1; *est_updates = a->sparse->est_updates; return TRACS_OK; }
     a->sparse_state = -1;
-    const size_t n = a->n, L = a->L, groups = a->groups;
+    const size_t n = a->n, L = pair_L(a), groups = pair_groups(a);      // the variable sites only when site classes are in use
+    const uint4 *planes = pair_planes(a, false);
     if (L >= (1ull << 28) || n >= (1ull << 28)) return TRACS_OK;        // entries hold site << 4 / sample << 4
     auto *g = new GeneralSparse();
     a->sparse = g;
@@ -316,10 +317,10 @@ int general_sparse_get(tracs_alignment *a, hipStream_t stream, int *ok, double *
     GS_TRY(hipMemsetAsync(d_est, 0, 8, stream));
 
     const dim3 sgrid((unsigned)((n + 63) / 64), GS_CHUNKS / 4);
-    hipLaunchKernelGGL((gs_sample_kernel<false>), sgrid, dim3(256), 0, stream, a->planes, a->n_pad, n, groups, gpc, cnt, cn, nullptr, nullptr);
+    hipLaunchKernelGGL((gs_sample_kernel<false>), sgrid, dim3(256), 0, stream, planes, a->n_pad, n, groups, gpc, cnt, cn, nullptr, nullptr);
     hipLaunchKernelGGL(gs_scan_kernel, dim3(1), dim3(1024), 0, stream, cnt, nsc, off);
     hipLaunchKernelGGL(gs_sample_totals_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, stream, cn, n, g->c_n, off, g->s_off);
-    hipLaunchKernelGGL((gs_site_kernel<false>), dim3((unsigned)groups), dim3(256), 0, stream, a->planes, a->n_pad, n, L, cntP, cntN,
+    hipLaunchKernelGGL((gs_site_kernel<false>), dim3((unsigned)groups), dim3(256), 0, stream, planes, a->n_pad, n, L, cntP, cntN,
                        nullptr, nullptr, nullptr, nullptr, d_est);
     hipLaunchKernelGGL(gs_scan_kernel, dim3(1), dim3(1024), 0, stream, cntP, L, g->p_off);
     hipLaunchKernelGGL(gs_scan_kernel, dim3(1), dim3(1024), 0, stream, cntN, L, g->n_off);
@@ -336,8 +337,8 @@ int general_sparse_get(tracs_alignment *a, hipStream_t stream, int *ok, double *
     GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->s_ent), std::max<size_t>(tot_s, 1) * 4));
     GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->p_ent), std::max<size_t>(tot_p, 1) * 4));
     GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->n_ent), std::max<size_t>(tot_n, 1) * 4));
-    hipLaunchKernelGGL((gs_sample_kernel<true>), sgrid, dim3(256), 0, stream, a->planes, a->n_pad, n, groups, gpc, nullptr, nullptr, off, g->s_ent);
-    hipLaunchKernelGGL((gs_site_kernel<true>), dim3((unsigned)groups), dim3(256), 0, stream, a->planes, a->n_pad, n, L, nullptr, nullptr,
+    hipLaunchKernelGGL((gs_sample_kernel<true>), sgrid, dim3(256), 0, stream, planes, a->n_pad, n, groups, gpc, nullptr, nullptr, off, g->s_ent);
+    hipLaunchKernelGGL((gs_site_kernel<true>), dim3((unsigned)groups), dim3(256), 0, stream, planes, a->n_pad, n, L, nullptr, nullptr,
                        g->p_off, g->n_off, g->p_ent, g->n_ent, nullptr);
     GS_TRY(hipGetLastError());
     GS_TRY(hipStreamSynchronize(stream));
@@ -363,7 +364,7 @@ int general_sparse_fixup(tracs_alignment *a, size_t row_begin, size_t row_end, s
     }
     const dim3 grid((unsigned)(row_end - row_begin), (unsigned)((a->n + chunk - 1) / chunk));
     hipLaunchKernelGGL(general_fixup_kernel, grid, dim3(1024), chunk * 4, stream, g->s_off, g->s_ent, g->p_off, g->p_ent, g->n_off,
-                       g->n_ent, g->c_n, (unsigned)a->L, (unsigned)a->n, (unsigned)row_begin, (unsigned)col_begin, chunk, dist, ncomp, ld);
+                       g->n_ent, g->c_n, (unsigned)pair_L(a), (unsigned)a->n, (unsigned)row_begin, (unsigned)col_begin, chunk, dist, ncomp, ld);
     TRACS_HIP_CHECK(hipGetLastError());
     return TRACS_OK;
 }

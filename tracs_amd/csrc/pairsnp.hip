@@ -638,6 +638,7 @@ void tracs_alignment_free(tracs_alignment *a)
 {
     if (!a) return;
     general_sparse_free(a);
+    site_classes_free(a);
     if (a->planes) (void)hipFree(a->planes);
     if (a->cplanes) (void)hipFree(a->cplanes);
     if (a->d_flag) (void)hipFree(a->d_flag);
@@ -732,6 +733,37 @@ int tracs_debug_alignment_encoding(const tracs_alignment *a) { return !a ? -1 : 
 // 2 matrix-core kernel (one-hot operands) + sparse partial-code correction, -1 none yet
 int tracs_debug_alignment_kernel(const tracs_alignment *a) { return !a ? -1 : a->last_kernel; }
 
+int tracs_debug_alignment_site_classes(const tracs_alignment *a, uint64_t *out)
+{
+    if (!a) return 0;
+    if (out) { out[0] = a->classes_state == 1 ? a->L_var : 0; out[1] = a->classes_state == 1 ? a->L_inv : 0; }
+    return a->classes_state;
+}
+
+// Diagnostics for bench.py: HIP events on the launch stream around the three parts of a dense call (pair kernel incl. its
+// cell initialisation / sparse partial-code correction / invariant-site counting pass).  Off by default.
+static bool g_pair_timing = false;
+static hipEvent_t g_pair_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+static bool g_pair_ev_valid = false;
+void tracs_debug_pair_timing(int on)
+{
+    g_pair_timing = on != 0;
+    if (g_pair_timing && !g_pair_ev[0])
+        for (auto &e : g_pair_ev) (void)hipEventCreate(&e);
+}
+int tracs_debug_last_pair_ms(float *out)
+{
+    if (!out || !g_pair_ev_valid) return TRACS_E_ARG;
+    if (hipEventSynchronize(g_pair_ev[3]) != hipSuccess) return TRACS_E_HIP;
+    for (int k = 0; k < 3; k++)
+        if (hipEventElapsedTime(&out[k], g_pair_ev[k], g_pair_ev[k + 1]) != hipSuccess) return TRACS_E_HIP;
+    return TRACS_OK;
+}
+static inline void pair_mark(int k, hipStream_t stream)
+{
+    if (g_pair_timing && g_pair_ev[k]) { (void)hipEventRecord(g_pair_ev[k], stream); if (k == 3) g_pair_ev_valid = true; }
+}
+
 static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_t row_end, size_t col_begin, uint32_t *dist,
                               uint32_t *ncomp, size_t ld, void *stream_, unsigned thr);
 
@@ -778,6 +810,7 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
     if (a->dirty) {
         a->enc = 0;
         general_sparse_free(a);
+        site_classes_free(a);
         static const bool force_general = std::getenv("TRACS_FORCE_GENERAL") != nullptr;
         if (!force_general) {
             const size_t cbytes = plane_bytes(a, 3);
@@ -808,16 +841,22 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
     }
     const bool cons = a->enc == 1;
     const TileVariant &V = current_variant(cons);
-    const int groups = (int)a->groups;
     const double cells = (double)(row_end - row_begin) * (double)a->n;      // upper bound of the cells of this call
 
     // ---- kernel: matrix cores unless switched off (TRACS_MFMA=0, or an explicit TRACS_TILE_VARIANT) ------------------------
     // (the matrix-core kernels keep 32-bit element offsets inside a stage: n_pad < 2^28 samples)
     static const bool mfma_env_off = env_flag("TRACS_MFMA") == 0 || std::getenv("TRACS_TILE_VARIANT") != nullptr;
     const bool mfma_off = mfma_env_off || a->n_pad >= (1ull << 28);
+    // ---- site classes (site_classes.hip), decided once per pack: the matrix-core kernels then read the variable sites only,
+    // and a one-operand pass over the invariant sites completes the compared-sites counts
+    if (!mfma_off && a->classes_state == 0) {
+        const int rc = site_classes_decide(a, cons, stream);
+        if (rc) return rc;
+        if (a->classes_state == 1 && cons) { TRACS_HIP_CHECK(hipFree(a->cplanes)); a->cplanes = nullptr; }   // replaced by vplanes
+    }
     bool mfma = cons && !mfma_off;
     bool mfma_general = false;
-    if (!cons && !mfma_off && a->L < (1ull << 28)) {
+    for (int attempt = 0; attempt < 2 && !cons && !mfma_off && pair_L(a) < (1ull << 28); attempt++) {
         // general alignment: one-hot Gram on the matrix cores + the sparse partial-code terms, when the side lists exist (or
         // can be built) and the sparse work is small beside what the VALU kernel would cost.  Thresholded passes too: the
         // kernel's value bounds the distance from below, so tiles it declares dead are dead (pairsnp_mfma.hip)
@@ -828,13 +867,22 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
         if (ok) {
             const double all_cells = 0.5 * (double)a->n * (double)a->n;
             const double frac = std::min(1.0, cells / std::max(1.0, all_cells));
-            const double t_valu = cells * (double)groups * 4.0 * 7.0 / 38e12;
-            const double t_mfma = cells * (double)a->L * 10.0 / 5.4e15 + updates * frac / 3.0e11;      // measured: 5.4 PFLOP/s, 4 x 10^11 list entries/s
+            const double t_valu = cells * (double)a->groups * 4.0 * 7.0 / 38e12;
+            const double t_mfma = cells * ((double)pair_L(a) * 10.0 + (a->classes_state == 1 ? (double)a->L_inv * 2.0 : 0.0)) / 5.4e15
+                                  + updates * frac / 3.0e11;                  // measured: 5.4 PFLOP/s, 4 x 10^11 list entries/s
             static const int force = env_flag("TRACS_GENERAL_MFMA");          // 1: always, 0: never (diagnostics)
             mfma_general = force == 1 || (force != 0 && t_mfma < t_valu);
         }
+        if (mfma_general || a->classes_state != 1) break;
+        // the VALU kernel reads the whole alignment: drop the classes (and the lists built on them) and look again
+        general_sparse_free(a);
+        site_classes_free(a);
+        a->classes_state = -1;
     }
+    if (!cons && !mfma_general && a->classes_state == 1) { general_sparse_free(a); site_classes_free(a); a->classes_state = -1; }
     mfma = mfma || mfma_general;
+    const bool classes = a->classes_state == 1;
+    const int groups = (int)pair_groups(a);
     const int shape_id = mfma_shape_current(mfma_general);
     const MfmaShape &S = mfma_shape(shape_id);
     const int kGC = mfma ? (mfma_general ? S.gc_gen : S.gc_cons) : V.gc;
@@ -862,23 +910,27 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
 
     // Split the group range over workgroups (integer atomics, still exact) when that fills the chip better:
     // too few tiles (config 2), or a ragged last round of resident workgroups (tail effect).
-    int ksplit = 1;
     double slots = 512.0;
     {
         static int cus = 0;
         if (!cus) { hipDeviceProp_t pr; int dv = 0; (void)hipGetDevice(&dv); cus = (hipGetDeviceProperties(&pr, dv) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }
         slots = (double)(mfma ? S.wg_per_cu : V.wg_per_cu[cons ? 1 : 0]) * cus;
-        const int max_split = std::max(1, groups / (8 * kGC));
+    }
+    auto pick_split = [&](size_t n_tiles, int range, int gc) {
+        int pick = 1;
+        const int max_split = std::max(1, range / (8 * gc));
         double best = -1.0;
         for (int k = 1; k <= std::min(max_split, 64); k++) {
-            const double wgs = (double)a->n_tiles * k;
+            const double wgs = (double)n_tiles * k;
             const double rounds = std::ceil(wgs / slots);
             const double eff = wgs / (rounds * slots) - 0.002 * (k - 1);     // small bias towards fewer splits
-            if (eff > best + 1e-9) { best = eff; ksplit = k; }
+            if (eff > best + 1e-9) { best = eff; pick = k; }
             if (rounds >= 40) break;                                         // tail < 2.5 % from here on
         }
-        if (const char *e = std::getenv("TRACS_KSPLIT")) { const int v = std::atoi(e); if (v >= 1 && v <= max_split) ksplit = v; }
-    }
+        if (const char *e = std::getenv("TRACS_KSPLIT")) { const int v = std::atoi(e); if (v >= 1 && v <= max_split) pick = v; }
+        return pick;
+    };
+    int ksplit = pick_split(a->n_tiles, groups, kGC);
     auto stage_split = [&](int range, int k, int &gps_out) {       // k workgroups over `range` groups, stage aligned
         int g = (range + k - 1) / k;
         g = (g + kGC - 1) / kGC * kGC;
@@ -891,9 +943,9 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
     auto launch = [&](const int2 *tl, unsigned nwg, int ntl, int g_end, int gps, int k, unsigned t, TilePhase ph) -> int {
         if (mfma) {
             MfmaArgs A;
-            A.P = mfma_general ? a->planes : a->cplanes;
+            A.P = pair_planes(a, !mfma_general);
             A.n_pad = a->n_pad; A.groups = g_end; A.tiles = tl; A.n_tiles = ntl; A.gps = gps; A.ksplit = k;
-            A.L = (unsigned)a->L; A.n = (unsigned)a->n; A.row_end = (unsigned)row_end; A.col_begin = (unsigned)col_begin;
+            A.L = (unsigned)pair_L(a); A.n = (unsigned)a->n; A.row_end = (unsigned)row_end; A.col_begin = (unsigned)col_begin;
             A.dist = dist; A.ncomp = ncomp; A.ld = ld; A.thr = t; A.ph = ph;
             return launch_pairsnp_mfma(shape_id, mfma_general, nwg, stream, A);
         }
@@ -901,6 +953,33 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
                                (unsigned)a->L, (unsigned)a->n, (unsigned)row_end, (unsigned)col_begin, dist, ncomp, ld, t, ph);
         return TRACS_OK;
     };
+
+    // Site classes: nn += sum v v' over the invariant sites, for the tiles whose cells are complete (all, or the live ones of
+    // a thresholded run).  Ranges of at most 2^23 sites keep the fp32 partial sums exact; the cells already hold the variable
+    // sites' counts, so every range adds with integer atomics.
+    auto count_pass = [&](const int2 *tl, size_t ntl) -> int {
+        if (!classes || !ncomp || a->L_inv == 0 || ntl == 0) return TRACS_OK;
+        const int gi = (int)a->groups_inv, gcc = S.gc_cnt;
+        int k = std::max(pick_split(ntl, gi, gcc), (gi + (1 << 16) - 1) >> 16);
+        int g = (gi + k - 1) / k;
+        g = (g + gcc - 1) / gcc * gcc;
+        k = (gi + g - 1) / g;
+        MfmaArgs A;
+        A.P = a->iplanes; A.n_pad = a->n_pad; A.groups = gi; A.tiles = tl; A.n_tiles = (int)ntl; A.gps = g; A.ksplit = k;
+        A.L = (unsigned)a->L_inv; A.n = (unsigned)a->n; A.row_end = (unsigned)row_end; A.col_begin = (unsigned)col_begin;
+        A.dist = dist; A.ncomp = ncomp; A.ld = ld; A.thr = 0xFFFFFFFFu; A.ph = TilePhase{0, 0, nullptr};
+        return launch_pairsnp_count(shape_id, (unsigned)(ntl * (size_t)k), stream, A);
+    };
+    if (classes && groups == 0) {
+        // no variable site at all: every distance is 0, the compared-sites counts come from the invariant sites alone
+        dim3 grid(64, (unsigned)(row_end - row_begin));
+        hipLaunchKernelGGL(init_cells_kernel, grid, dim3(256), 0, stream, dist, ncomp, ld, (unsigned)a->n,
+                           (unsigned)row_begin, (unsigned)row_end, (unsigned)col_begin, 0u);
+        const int rc = count_pass(a->d_tiles, a->n_tiles);
+        if (rc) return rc;
+        TRACS_HIP_CHECK(hipGetLastError());
+        return TRACS_OK;
+    }
 
     // Thresholded run on a long alignment: two passes.  The prefix pass (1/8 of the groups, one workgroup per tile) leaves
     // exact partial counts and a live flag per tile; the remainder pass visits the live tiles only, its range split so that the
@@ -931,6 +1010,7 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
             if ((rc = launch(live_tiles, (unsigned)(n_live * (size_t)k2), (int)n_live, groups, gps2, k2, thr, TilePhase{2, prefix, nullptr}))) return rc;
         }
         if (mfma_general && (rc = general_sparse_fixup(a, row_begin, row_end, col_begin, dist, ncomp, ld, stream))) return rc;
+        if ((rc = count_pass(live_tiles, n_live))) return rc;
         TRACS_HIP_CHECK(hipGetLastError());
         return TRACS_OK;
     }
@@ -938,6 +1018,7 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
     if (mfma) ksplit = std::max(ksplit, (groups + max_gps - 1) / max_gps);
     int gps = 0;
     ksplit = stage_split(groups, ksplit, gps);
+    pair_mark(0, stream);
     if (ksplit > 1) {
         dim3 grid(64, (unsigned)(row_end - row_begin));
         hipLaunchKernelGGL(init_cells_kernel, grid, dim3(256), 0, stream, dist, ncomp, ld, (unsigned)a->n,
@@ -945,7 +1026,11 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
     }
     int rc = launch(a->d_tiles, (unsigned)(a->n_tiles * (size_t)ksplit), (int)a->n_tiles, groups, gps, ksplit, thr, TilePhase{0, 0, nullptr});
     if (rc) return rc;
+    pair_mark(1, stream);
     if (mfma_general && (rc = general_sparse_fixup(a, row_begin, row_end, col_begin, dist, ncomp, ld, stream))) return rc;
+    pair_mark(2, stream);
+    if ((rc = count_pass(a->d_tiles, a->n_tiles))) return rc;
+    pair_mark(3, stream);
     TRACS_HIP_CHECK(hipGetLastError());
     return TRACS_OK;
 }

@@ -51,6 +51,7 @@ struct MfmaShape {
     int nbr, nbc;              // 32 x 32 blocks per wave: the workgroup (2 x 2 waves) owns a (64 nbr) x (64 nbc) tile
     int ti, tj;
     int gc_cons, gc_gen;       // groups per LDS stage, consensus / general encoding (0: shape not built for it)
+    int gc_cnt;                // groups per LDS stage of the counting form (site classes: invariant sites, one plane)
     int wg_per_cu;
 };
 // The shapes compiled into the library; one default per encoding.  TRACS_MFMA_TILE=<name> selects another for both (diagnostics).
@@ -59,6 +60,12 @@ const MfmaShape &mfma_shape(int idx);
 int mfma_shape_current(bool general);
 // general = false: consensus encoding (operands x, y, z, v);  true: general encoding (one-hot A, C, G, T + N).
 int launch_pairsnp_mfma(int shape, bool general, unsigned nwg, hipStream_t stream, const MfmaArgs &a);
+// the counting form: a.P = one plane per group ("is a base here"), ncomp[i][j] += sum v_i v_j over groups [g_base.., a.groups)
+int launch_pairsnp_count(int shape, unsigned nwg, hipStream_t stream, const MfmaArgs &a);
+
+// ---- site classes (site_classes.hip) --------------------------------------------------------------------------
+int site_classes_decide(tracs_alignment *a, bool consensus, hipStream_t stream);
+void site_classes_free(tracs_alignment *a);
 
 // ---- sparse side structures of the general matrix-core path (general_sparse.hip) -------------------------------
 struct GeneralSparse;

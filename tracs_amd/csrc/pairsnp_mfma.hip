@@ -53,19 +53,23 @@ __device__ __forceinline__ mfma_v8i fp4_operand(const unsigned (&w)[4])
 #define TRACS_MFMA_FP4(ACC, A_, B_, SC) \
     ACC = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A_, B_, ACC, 4, 4, 0, SC, 0, SC)
 
-template <bool GENERAL, int NBR, int NBC, int GC, int NWR = 2, int NWC = 2>
+// COUNT: the one-operand pass over the invariant sites of an alignment cut into site classes (site_classes.hip): a single
+// stored plane v ("this sample is a base here"), nn += sum v v' with the general form's residue-class operands, nothing else.
+template <bool GENERAL, int NBR, int NBC, int GC, int NWR = 2, int NWC = 2, bool COUNT = false>
 __global__ __launch_bounds__(NWR * NWC * 64, (NBR * NBC > 4 ? 1 : 2)) void pairsnp_mfma_kernel(const MfmaArgs A)
 {
     // NP planes are staged per group, GP is the group's stride in the stored planes: the general form stages A, C, G, T only and
     // forms N = A & C & G & T in registers (3 VALU ops per word against a fifth of the staging traffic)
-    constexpr int NP = GENERAL ? 4 : 3, GP = GENERAL ? NPLANES : 3, NW = NWR * NWC;
+    constexpr int NP = COUNT ? 1 : GENERAL ? 4 : 3, GP = COUNT ? 1 : GENERAL ? NPLANES : 3, NW = NWR * NWC;
+    static_assert(!(COUNT && GENERAL), "COUNT is its own form");
     constexpr int WI = NBR * 32, WJ = NBC * 32;             // wave tile
     constexpr int TI = NWR * WI, TJ = NWC * WJ, TS = TI + TJ;   // workgroup tile, samples staged per (group, plane)
     constexpr int STAGE = GC * NP * TS;                     // uint4 per LDS stage
     static_assert(TS % 64 == 0, "a staging wave-instruction must stay inside one (group, plane) run");
     static_assert(STAGE % 64 == 0, "stage must be whole wave-instructions");
     static_assert(!GENERAL || GC == 2, "the general form takes one residue class of four words: two groups per stage");
-    static_assert(GC - 1 <= PAD_GROUPS, "stages may overhang the alignment by GC - 1 zero groups");
+    static_assert(!COUNT || GC % 2 == 0, "the counting form takes one residue class of four words: pairs of groups");
+    static_assert(GC - 1 <= (COUNT ? COUNT_PAD_GROUPS : PAD_GROUPS), "stages may overhang the alignment by GC - 1 zero groups");
     __shared__ uint4 lds[2][STAGE];
 
     const unsigned q = xcd_remap(blockIdx.x, gridDim.x);
@@ -170,7 +174,47 @@ __global__ __launch_bounds__(NWR * NWC * 64, (NBR * NBC > 4 ? 1 : 2)) void pairs
         // next stage to fetch; on the last stage the current one is fetched again (valid memory, never read): no branch in the body
         const int gn = gs + GC < g_end ? gs + GC : gs;
         int piece = 0;
-        if constexpr (!GENERAL) {
+        if constexpr (COUNT) {
+            // units: residue class q of the four words of a pair of groups, all into accV
+            unsigned raw[2][NB][4], op[2][NB][4];
+            auto load_raw = [&](int gp) {
+#pragma unroll
+                for (int b = 0; b < NB; b++) {
+                    const uint2 a = rd2(buf, 2 * gp, 0, slot_of(b)), c = rd2(buf, 2 * gp + 1, 0, slot_of(b));
+                    raw[gp & 1][b][0] = a.x; raw[gp & 1][b][1] = a.y; raw[gp & 1][b][2] = c.x; raw[gp & 1][b][3] = c.y;
+                }
+            };
+#define TRACS_MAKE_RES(SRC_, Q_, O_)                                                                        \
+            _Pragma("unroll") for (int b = 0; b < NB; b++)                                                  \
+                _Pragma("unroll") for (int w = 0; w < 4; w++) {                                                 \
+                    const unsigned rw_ = SRC_[b][w];                                                        \
+                    O_[b][w] = (Q_) == 0 ? (rw_ & M1) : (Q_) == 1 ? (rw_ & M2) : (Q_) == 2 ? (rw_ & M4) : ((rw_ >> 1) & M4); \
+                }
+            load_raw(0);
+            TRACS_MAKE_RES(raw[0], 0, op[0])
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int gp = 0; gp < GC / 2; gp++) {
+                TRACS_UNIT_MFMAS(accV, op[0], 128)
+                TRACS_MAKE_RES(raw[gp & 1], 1, op[1])
+                if (gp + 1 < GC / 2) load_raw(gp + 1);
+                TRACS_UNIT_STAGE(GC * 2)
+                TRACS_UNIT_SCHED(NB * 4, NB * 2)
+                TRACS_UNIT_MFMAS(accV, op[1], 127)
+                TRACS_MAKE_RES(raw[gp & 1], 2, op[0])
+                TRACS_UNIT_STAGE(GC * 2)
+                TRACS_UNIT_SCHED(NB * 4, 0)
+                TRACS_UNIT_MFMAS(accV, op[0], 126)
+                TRACS_MAKE_RES(raw[gp & 1], 3, op[1])
+                TRACS_UNIT_STAGE(GC * 2)
+                TRACS_UNIT_SCHED(NB * 8, 0)
+                TRACS_UNIT_MFMAS(accV, op[1], 126)
+                if (gp + 1 < GC / 2) { TRACS_MAKE_RES(raw[(gp + 1) & 1], 0, op[0]) }
+                TRACS_UNIT_STAGE(GC * 2)
+                TRACS_UNIT_SCHED(NB * 4, 0)
+            }
+#undef TRACS_MAKE_RES
+        } else if constexpr (!GENERAL) {
             // units per 32-site step: v, x, y, z.  vq = the v operand, also the magnitude bits of the three sign operands.
             uint2 rawV[NB], rawXY[NB][2];               // this lane's two words (st = 0, 1) of the current group, per block
             unsigned vq[NB][4], op[2][NB][4];
@@ -346,6 +390,10 @@ __global__ __launch_bounds__(NWR * NWC * 64, (NBR * NBC > 4 ? 1 : 2)) void pairs
                 const unsigned i = cell_row(rb, r), j = cell_col(cb);
                 if (i < A.row_end && j < A.n && j > i && j >= A.col_begin) {
                     const int V = (int)accV[rb][cb][r];
+                    if constexpr (COUNT) {                     // the cells hold the variable sites' counts already
+                        atomicAdd(&A.ncomp[(size_t)i * A.ld + j], (unsigned)V);
+                        continue;
+                    }
                     const int S = (int)accS[rb][cb][r];
                     // consensus: d, nn of the range.  general: L_range - G + 3 NN and NN (general_sparse_fixup completes both)
                     const unsigned d = GENERAL ? Lc - (unsigned)S + 3u * (unsigned)V : (unsigned)((3 * V - S) >> 2);
@@ -369,15 +417,16 @@ __global__ __launch_bounds__(NWR * NWC * 64, (NBR * NBC > 4 ? 1 : 2)) void pairs
 
 // ---------------------------------------------------------------------------------------------------------------------
 typedef void (*MfmaLaunchFn)(unsigned nwg, hipStream_t stream, const MfmaArgs &a);
-template <bool GENERAL, int NBR, int NBC, int GC, int NWR = 2, int NWC = 2>
+template <bool GENERAL, int NBR, int NBC, int GC, int NWR = 2, int NWC = 2, bool COUNT = false>
 static void launch_one(unsigned nwg, hipStream_t stream, const MfmaArgs &a)
 {
-    hipLaunchKernelGGL((pairsnp_mfma_kernel<GENERAL, NBR, NBC, GC, NWR, NWC>), dim3(nwg), dim3(NWR * NWC * 64), 0, stream, a);
+    hipLaunchKernelGGL((pairsnp_mfma_kernel<GENERAL, NBR, NBC, GC, NWR, NWC, COUNT>), dim3(nwg), dim3(NWR * NWC * 64), 0, stream, a);
 }
 
-struct ShapeEntry { MfmaShape s; MfmaLaunchFn cons, gen; };
-#define TRACS_SHAPE_N(NAME, R, C, GCC, WPC) {{NAME, R, C, 64 * (R), 64 * (C), GCC, 2, WPC}, launch_one<false, R, C, GCC>, launch_one<true, R, C, 2>}
-#define TRACS_SHAPE_W(NAME, R, C, GCC, WR, WC, WPC) {{NAME, R, C, 32 * (R) * (WR), 32 * (C) * (WC), GCC, 2, WPC}, launch_one<false, R, C, GCC, WR, WC>, launch_one<true, R, C, 2, WR, WC>}
+constexpr int GC_COUNT = 4;                       // groups per stage of the counting form (two residue-class rounds per barrier)
+struct ShapeEntry { MfmaShape s; MfmaLaunchFn cons, gen, cnt; };
+#define TRACS_SHAPE_N(NAME, R, C, GCC, WPC) {{NAME, R, C, 64 * (R), 64 * (C), GCC, 2, GC_COUNT, WPC}, launch_one<false, R, C, GCC>, launch_one<true, R, C, 2>, launch_one<false, R, C, GC_COUNT, 2, 2, true>}
+#define TRACS_SHAPE_W(NAME, R, C, GCC, WR, WC, WPC) {{NAME, R, C, 32 * (R) * (WR), 32 * (C) * (WC), GCC, 2, GC_COUNT, WPC}, launch_one<false, R, C, GCC, WR, WC>, launch_one<true, R, C, 2, WR, WC>, launch_one<false, R, C, GC_COUNT, WR, WC, true>}
 #define TRACS_SHAPE(R, C, GCC, WPC) TRACS_SHAPE_N(#R "x" #C, R, C, GCC, WPC)
 static const ShapeEntry kShapes[] = {
     TRACS_SHAPE(2, 2, 1, 2),                      // 0: 128 x 128 pairs per workgroup, four waves, two workgroups per CU -- consensus default
@@ -412,6 +461,13 @@ int launch_pairsnp_mfma(int shape, bool general, unsigned nwg, hipStream_t strea
 {
     if (shape < 0 || shape >= mfma_shape_count()) { set_error("launch_pairsnp_mfma: bad shape"); return TRACS_E_ARG; }
     (general ? kShapes[shape].gen : kShapes[shape].cons)(nwg, stream, a);
+    return TRACS_OK;
+}
+
+int launch_pairsnp_count(int shape, unsigned nwg, hipStream_t stream, const MfmaArgs &a)
+{
+    if (shape < 0 || shape >= mfma_shape_count() || !a.ncomp) { set_error("launch_pairsnp_count: bad argument"); return TRACS_E_ARG; }
+    kShapes[shape].cnt(nwg, stream, a);
     return TRACS_OK;
 }
 

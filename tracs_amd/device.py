@@ -94,6 +94,16 @@ class Alignment:
         return {0: "valu", 1: "mfma", 2: "mfma-general"}.get(self._L.tracs_debug_alignment_kernel(self._h))
 
     @property
+    def site_classes(self):
+        """(variable sites, invariant sites) when the last dense call ran on site classes (csrc/site_classes.hip): the pair
+        kernel read the variable sites only and a one-operand pass over the invariant sites completed the compared-sites
+        counts; None when the whole alignment was read."""
+        import ctypes as C
+        out = (C.c_uint64 * 2)()
+        state = self._L.tracs_debug_alignment_site_classes(self._h, out)
+        return (int(out[0]), int(out[1])) if state == 1 else None
+
+    @property
     def nbytes(self):
         return self._L.tracs_alignment_bytes(self._h)
 
