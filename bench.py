@@ -45,6 +45,7 @@ ENCODINGS = {"general": {"ops": 7, "bytes_per_site": 1.0, "mix_ceiling": 44.3e12
              "consensus": {"ops": 6, "bytes_per_site": 0.75, "mix_ceiling": 49.7e12}}
 # matrix-core forms: fp4 operand values per site and sample (x, y, z, v / one-hot A, C, G, T + N) -> flop per pair and site
 MFMA_FLOP_PER_SITE = {"mfma": 8.0, "mfma-general": 10.0}
+COUNT_FLOP_PER_SITE = 2.0    # the counting pass over invariant sites (site classes): one operand plane
 MU = 1e-4                    # per-sample substitution probability
 P_N = 0.01
 P_PARTIAL_C4 = 0.005         # SURVEY.md 8d, config 4 mix: partial-ambiguity IUPAC codes
@@ -71,6 +72,23 @@ def parse():
 def synth_kw(p_partial=0.0):
     """SURVEY.md 8d's generator: star phylogeny (one lineage = the ancestor itself), mu per sample, 1 % N."""
     return dict(mu_lineage=0.0, mu_sample=MU, n_lineages=1, p_n=P_N, p_partial=p_partial)
+
+
+def pair_split_ms(lib):
+    """(pair kernel, sparse partial-code correction, invariant-site counting pass) of the LAST dense call, from HIP events the
+    library records on the launch stream (tracs_debug_pair_timing)."""
+    import ctypes as C
+    out = (C.c_float * 3)()
+    return [float(x) for x in out] if lib.tracs_debug_last_pair_ms(out) == 0 else None
+
+
+def count_roofline(pairs_per_launch, L_inv, count_s):
+    flop = float(pairs_per_launch) * L_inv * COUNT_FLOP_PER_SITE
+    return {"kernel": "pairsnp_mfma_kernel<COUNT>", "kernel_ms": count_s * 1e3, "sites": L_inv, "bound": "mfma", "traffic": None,
+            "algorithmic_flop_per_pair": L_inv * COUNT_FLOP_PER_SITE, "measured_fp4_ceiling": MFMA_FP4_MEASURED / 1e12,
+            "frac_of_measured_fp4_ceiling": flop / count_s / MFMA_FP4_MEASURED,
+            "achieved": flop / count_s / 1e12, "peak": MFMA_FP4_PEAK / 1e12, "unit": "TFLOP/s", "frac": flop / count_s / MFMA_FP4_PEAK,
+            "note": "nn += sum v_i v_j over the invariant sites: one fp4 operand plane, %g flop per pair and site" % COUNT_FLOP_PER_SITE}
 
 
 def roofline_of(kernel, enc, pairs_per_launch, L, kern_s, traffic):
@@ -201,6 +219,8 @@ def main():
                 finish(k)
                 pending[k] = None
 
+    lib = _lib.load()
+    lib.tracs_debug_pair_timing(1)
     for it in range(args.warmup):
         step(it)
     drain(args.warmup)
@@ -228,8 +248,10 @@ def main():
     timed = range(args.warmup, args.warmup + args.steps)
     kern_ms = [ev0[i].elapsed_time(ev1[i]) for i in timed]
     tc_ms = [a.elapsed_time(b) for a, b in tc_ev] or [0.0]
-    kern_s = sum(kern_ms) / len(kern_ms) / 1e3 / len(ranges)      # average duration of ONE launch
+    kern_s = sum(kern_ms) / len(kern_ms) / 1e3 / len(ranges)      # average duration of ONE dense call (all its kernels)
     my_pairs_per_launch = my_pairs / len(ranges)
+    split = pair_split_ms(lib)                                    # the last call's kernels, one by one
+    classes = aln.site_classes                                    # (variable, invariant) sites, or None: whole alignment read
 
     dmat, nmat = sets[(args.warmup + args.steps - 1) % nsets]    # the last step's results
     checksum = int(dmat[:n].sum().item()) if rank == 0 else 0
@@ -248,8 +270,31 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = pairs_total * args.steps / elapsed
         enc = aln.encoding or "general"
-        traffic = _traffic_from_profiles(n, L, world, aln.kernel)
-        roof = roofline_of(aln.kernel, enc, my_pairs_per_launch, L, kern_s, traffic)
+        traffic = _traffic_from_profiles(n, L, world, aln.kernel + ("+classes" if classes else ""))
+        last_pairs = partition.pairs_in_rows(n, *ranges[-1])      # `split` belongs to the last call of the step
+        if classes and split:
+            # site classes (csrc/site_classes.hip): pair kernel over the dense sites, lists for the minority sites, one-operand
+            # counting pass over the counted sites.  `roofline` = whichever matrix-core kernel takes longer; the other beside it.
+            dense, counted, minority, full = classes
+            main = roofline_of(aln.kernel, enc, last_pairs, dense, max(split[0], 1e-3) / 1e3, traffic if split[0] >= split[2] else None)
+            cnt = count_roofline(last_pairs, counted, max(split[2], 1e-3) / 1e3)
+            if split[2] > split[0]:
+                cnt["traffic"] = traffic
+                roof, other = cnt, main
+            else:
+                roof, other = main, cnt
+            roof["other_matrix_core_kernel"] = {k: other[k] for k in ("kernel", "kernel_ms", "achieved", "frac", "unit") if k in other}
+            roof["minority_lists_ms"] = split[1]
+            roof["dense_call_ms"] = kern_s * 1e3
+            roof["site_classes"] = {"dense": dense, "counted": counted, "minority": minority, "full": full,
+                                    "empty": L - dense - counted - full,
+                                    "note": "decided once per pack, results bit-identical (csrc/site_classes.hip): the pair kernel reads the dense "
+                                            "sites only; sites at which <= a few samples differ from the others (minority) add their distances "
+                                            "from sparse lists (general_fixup_kernel<MINOR>); nn of every non-dense site with an N comes from "
+                                            "a one-operand matrix-core pass (counted), sites without any N add a constant (full). "
+                                            "TRACS_SITE_CLASSES=0 reads every site with the pair kernel, TRACS_MINORITY=0 keeps the minority sites dense"}
+        else:
+            roof = roofline_of(aln.kernel, enc, my_pairs_per_launch, L, kern_s, traffic)
         enc_name = "consensus (ACGTN) alignment" if enc == "consensus" else "general IUPAC alignment (%.2g partial codes)" % args.partial
         out = {"metric": "sample-pairs/sec for 10kx5Mbp SNP+transcluster distance", "value": value,
                "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -306,7 +351,18 @@ def general_pass(args, n, L, seed, dev, synth, torch, device):
     e1.record()
     torch.cuda.synchronize()
     kern_s = e0.elapsed_time(e1) / 1e3 / reps
-    r = roofline_of(aln.kernel, "general", n * (n - 1) // 2, L, kern_s, _traffic_from_profiles(n, L, 1, aln.kernel))
+    from tracs_amd import _lib
+    split, classes, pairs = pair_split_ms(_lib.load()), aln.site_classes, n * (n - 1) // 2
+    traffic = _traffic_from_profiles(n, L, 1, aln.kernel + ("+classes" if classes else ""))
+    if classes and split:
+        r = roofline_of(aln.kernel, "general", pairs, classes[0], (split[0] + split[1]) / 1e3, traffic)
+        r["count_pass"] = count_roofline(pairs, classes[1], max(split[2], 1e-3) / 1e3)
+        r["site_classes"] = {"dense": classes[0], "counted": classes[1], "empty": L - classes[0] - classes[1]}
+    else:
+        r = roofline_of(aln.kernel, "general", pairs, L, kern_s, traffic)
+    r["dense_call_ms"] = kern_s * 1e3
+    if split:
+        r["kernels_ms"] = {"pairsnp_mfma_kernel": split[0], "general_fixup_kernel": split[1], "count_pass": split[2]}
     r["workload"] = "the same alignment + %.3g partial IUPAC codes per site (uniformly random sites and codes)" % P_PARTIAL_C4
     r["mean_d"] = float(dmat.sum().item()) / (n * (n - 1) // 2)
     aln.close()

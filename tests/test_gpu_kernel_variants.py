@@ -61,6 +61,7 @@ VARIANTS = [
     ({"TRACS_SITE_CLASSES": "0"}, {("consensus", "mfma"), ("general", "mfma-general")}),
     ({"TRACS_SITE_CLASSES": "1", "TRACS_KSPLIT": "3"}, {("consensus", "mfma"), ("general", "mfma-general")}),
     ({"TRACS_SITE_CLASSES": "1", "TRACS_MFMA_TILE": "2x2w4x2"}, {("consensus", "mfma"), ("general", "mfma-general")}),
+    ({"TRACS_MINORITY": "0"}, {("consensus", "mfma"), ("general", "mfma-general")}),
 ]
 
 

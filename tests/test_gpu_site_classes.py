@@ -41,7 +41,8 @@ def _check(dev, oracle, seqs, expect_classes=True, thresholds=True):
     cls = aln.site_classes
     assert (cls is not None) == expect_classes, cls
     if cls is not None:
-        assert cls[0] + cls[1] <= L
+        dense, counted, minority, full = cls
+        assert dense + counted + full <= L and minority <= counted + full
     assert np.array_equal(d.cpu().numpy()[ri, ci], ed.astype(np.int32))
     assert np.array_equal(nn.cpu().numpy()[ri, ci], enn.astype(np.int32))
     # d only (no compared-sites matrix): the counting pass is skipped
@@ -75,7 +76,7 @@ def test_site_classes_match_oracle(hiplib, oracle, n, L, p_partial):
     from tracs_amd import device as dev
     seqs = _structured(n, L, seed=n * 7 + L, p_partial=p_partial, mu=2e-4 if L > 1000 else 5e-3)
     cls = _check(dev, oracle, seqs)
-    assert 0 < cls[0] < L and cls[1] > 0
+    assert cls[0] + cls[2] > 0 and cls[0] < L and cls[1] > 0      # some site is variable (dense or minority), most are not
 
 
 def test_no_variable_site(hiplib, oracle):
@@ -83,7 +84,7 @@ def test_no_variable_site(hiplib, oracle):
     from tracs_amd import device as dev
     seqs = _structured(90, 7000, seed=3, identical=True)
     cls = _check(dev, oracle, seqs, thresholds=False)
-    assert cls[0] == 0 and cls[1] > 0
+    assert cls[0] == 0 and cls[2] == 0 and cls[1] > 0
 
 
 def test_single_variable_site_and_ragged_classes(hiplib, oracle):
@@ -92,7 +93,7 @@ def test_single_variable_site_and_ragged_classes(hiplib, oracle):
     seqs[7, 500] = ord("A") if seqs[0, 500] != ord("A") else ord("C")
     seqs[:, 500][seqs[:, 500] == ord("N")] = seqs[0, 0]           # keep the site comparable whatever row 0 holds
     cls = _check(dev, oracle, seqs)
-    assert cls[0] >= 1
+    assert cls[0] + cls[2] == 1
 
 
 def test_dense_alignment_stays_whole(hiplib, oracle):
@@ -124,3 +125,28 @@ def test_repack_redecides(hiplib, oracle):
         assert np.array_equal(d.cpu().numpy()[ri, ci], ed.astype(np.int32))
         assert np.array_equal(nn.cpu().numpy()[ri, ci], enn.astype(np.int32))
     aln.close()
+
+
+def test_every_class_at_once(hiplib, oracle):
+    """Lineage-structured columns (a fifth of the samples differ: dense), private substitutions (minority), columns without
+    any N (full), columns of N (empty), N elsewhere (counted) -- in one alignment, 1 000 samples so that the list budget
+    (k (cN + k) <= n^2 / 8000) separates one- and two-sample sites from the lineage sites."""
+    from tracs_amd import device as dev
+    n, L = 1000, 6000
+    rng = np.random.default_rng(77)
+    seqs = _structured(n, L, seed=78, mu=1e-4, p_n=0.0, p_empty=0.01)
+    cols = rng.choice(L, size=L // 2, replace=False)
+    sub = seqs[:, cols]
+    sub[rng.random(sub.shape) < 0.02] = ord("N")                     # half of the columns carry N, the others none
+    seqs[:, cols] = sub
+    lineage = rng.choice(L, size=40, replace=False)
+    members = rng.random(n) < 0.2
+    for c in lineage:
+        col = seqs[:, c]                                             # a view
+        bases = col[col != ord("N")]
+        if len(bases):
+            alt = BASES[(int(np.where(BASES == bases[0])[0][0]) + 1) % 4]
+            col[members & (col != ord("N"))] = alt
+    cls = _check(dev, oracle, seqs)
+    dense, counted, minority, full = cls
+    assert dense >= 30 and minority > 100 and full > 1000 and counted > 1000 and dense + counted + full < L

@@ -55,6 +55,9 @@ struct tracs_alignment {
     // of the compared-sites counts.  Sites at which every sample is N belong to neither.
     uint4 *vplanes = nullptr, *iplanes = nullptr;
     size_t L_var = 0, L_inv = 0, groups_var = 0, groups_inv = 0;
+    size_t L_minor = 0, L_full = 0;           // minority sites (listed in `minor`; they are part of L_inv or L_full as well);
+                                              // sites without any N outside vplanes: +1 to every compared-sites count
+    tracs::GeneralSparse *minor = nullptr;    // consensus alignments: lists of the minority sites (site_classes.hip)
     int classes_state = 0;       // 0 not decided, 1 in use, -1 not in use for this alignment
     tracs::GeneralSparse *sparse = nullptr;   // general matrix-core path: per-site / per-sample lists of N and partial codes
     int sparse_state = 0;        // 0 not built, 1 built, -1 not available for this alignment (too dense / too large / no memory)

@@ -26,7 +26,7 @@ namespace tracs {
 struct GeneralSparse {
     unsigned long long *s_off = nullptr, *p_off = nullptr, *n_off = nullptr;
     unsigned *s_ent = nullptr, *p_ent = nullptr, *n_ent = nullptr;
-    unsigned *c_n = nullptr;
+    unsigned *c_n = nullptr, *c_p = nullptr;      // per sample: its N sites, its partial-code sites
     double est_updates = 0.0;
 };
 
@@ -109,16 +109,18 @@ __global__ __launch_bounds__(1024) void gs_scan_kernel(const unsigned *__restric
     }
 }
 
-__global__ void gs_sample_totals_kernel(const unsigned *__restrict__ cn, size_t n, unsigned *__restrict__ c_n,
+__global__ void gs_sample_totals_kernel(const unsigned *__restrict__ cnt, const unsigned *__restrict__ cn, size_t n,
+                                        unsigned *__restrict__ c_n, unsigned *__restrict__ c_p,
                                         const unsigned long long *__restrict__ off, unsigned long long *__restrict__ s_off)
 {
     const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s > n) return;
     s_off[s] = off[s * GS_CHUNKS];                       // off has n * GS_CHUNKS + 1 entries
     if (s < n) {
-        unsigned t = 0;
-        for (int k = 0; k < GS_CHUNKS; k++) t += cn[s * GS_CHUNKS + k];
+        unsigned t = 0, all = 0;
+        for (int k = 0; k < GS_CHUNKS; k++) { t += cn[s * GS_CHUNKS + k]; all += cnt[s * GS_CHUNKS + k]; }
         c_n[s] = t;
+        c_p[s] = all - t;
     }
 }
 
@@ -182,10 +184,19 @@ __global__ __launch_bounds__(256) void gs_site_kernel(const uint4 *__restrict__ 
 }
 
 // Row i of the pair matrix: T1 + T2 accumulated in LDS, then added to dist; ncomp gets its c_i, c_j terms.
+//
+// MINOR: the same walk over the lists of a consensus alignment's MINORITY sites (site_classes.hip) -- sites at which only a
+// few samples differ from a reference base.  Those samples are listed as if they carried the two-allele code {reference,
+// own base}; a site then contributes to d(i, j):  1 when exactly one of the two is a minority sample and the other a base,
+// [own bases differ] when both are, 0 otherwise, i.e. over the sites S_i, S_j where i / j is a minority sample
+//     d += |S_i| + |S_j| - #(s in S_i: j is N) - #(s in S_j: i is N) - sum over S_i n S_j of |code_i n code_j|
+// (|code_i n code_j| = 2 when the own bases agree, 1 when only the reference is shared).  Negative terms wrap in the unsigned
+// row and cancel in the final sum.  ncomp is not touched (the counting pass covers these sites).
+template <bool MINOR>
 __global__ __launch_bounds__(1024) void general_fixup_kernel(const unsigned long long *__restrict__ s_off, const unsigned *__restrict__ s_ent,
                                                              const unsigned long long *__restrict__ p_off, const unsigned *__restrict__ p_ent,
                                                              const unsigned long long *__restrict__ n_off, const unsigned *__restrict__ n_ent,
-                                                             const unsigned *__restrict__ c_n, unsigned L, unsigned n, unsigned row_begin,
+                                                             const unsigned *__restrict__ c_n, const unsigned *__restrict__ c_p, unsigned L, unsigned n, unsigned row_begin,
                                                              unsigned col_begin, unsigned chunk, unsigned *__restrict__ dist,
                                                              unsigned *__restrict__ ncomp, size_t ld)
 {
@@ -234,11 +245,11 @@ __global__ __launch_bounds__(1024) void general_fixup_kernel(const unsigned long
             const unsigned kk = (unsigned)__popc(code) - 1u;           // |M_i| - 1 when i is partial here
             auto apply_p = [&](unsigned v) {                          // a partial j: i N -> |M_j| - 1; both partial -> (|M_i n M_j| - 1)^+
                 const unsigned j = v >> 4;
-                const int add = i_is_n ? __popc(v & 15u) - 1 : __popc(v & code) - 1;
-                if (add > 0 && j > i && j >= c0 && j < c1) atomicAdd(&row[j - c0], (unsigned)add);
+                const int add = MINOR ? (i_is_n ? -1 : -__popc(v & code)) : (i_is_n ? __popc(v & 15u) - 1 : __popc(v & code) - 1);
+                if ((MINOR || add > 0) && j > i && j >= c0 && j < c1) atomicAdd(&row[j - c0], (unsigned)add);
             };
-            auto apply_n = [&](unsigned j) {                          // an N j, i partial here: |M_i| - 1
-                if (j > i && j >= c0 && j < c1) atomicAdd(&row[j - c0], kk);
+            auto apply_n = [&](unsigned j) {                          // an N j, i partial here: |M_i| - 1  (MINOR: -1)
+                if (j > i && j >= c0 && j < c1) atomicAdd(&row[j - c0], MINOR ? 0xFFFFFFFFu : kk);
             };
 #pragma unroll
             for (int m = 0; m < 4; m++) {
@@ -262,45 +273,51 @@ __global__ __launch_bounds__(1024) void general_fixup_kernel(const unsigned long
         }
     }
     __syncthreads();
-    const unsigned ci = c_n[i];
+    const unsigned ci = MINOR ? c_p[i] : c_n[i];
     for (unsigned j = c0 + threadIdx.x; j < c1; j += blockDim.x)
         if (j > i && j >= col_begin) {
             const size_t o = (size_t)i * ld + j;
-            const unsigned t = row[j - c0];
+            const unsigned t = MINOR ? row[j - c0] + ci + c_p[j] : row[j - c0];
             if (t) dist[o] += t;
-            if (ncomp) ncomp[o] += L - ci - c_n[j];
+            if (!MINOR && ncomp) ncomp[o] += L - ci - c_n[j];
         }
+}
+
+static void gs_free(GeneralSparse *g)
+{
+    if (!g) return;
+    void *p[] = {g->s_off, g->p_off, g->n_off, g->s_ent, g->p_ent, g->n_ent, g->c_n, g->c_p};
+    for (void *q : p) if (q) (void)hipFree(q);
+    delete g;
 }
 
 void general_sparse_free(tracs_alignment *a)
 {
     if (!a) return;
-    if (a->sparse) {
-        GeneralSparse *g = a->sparse;
-        void *p[] = {g->s_off, g->p_off, g->n_off, g->s_ent, g->p_ent, g->n_ent, g->c_n};
-        for (void *q : p) if (q) (void)hipFree(q);
-        delete g;
-        a->sparse = nullptr;
-    }
+    gs_free(a->sparse);
+    a->sparse = nullptr;
     a->sparse_state = 0;
 }
 
-int general_sparse_get(tracs_alignment *a, hipStream_t stream, int *ok, double *est_updates)
+void minority_lists_free(tracs_alignment *a)
 {
-    *ok = 0;
-    if (a->sparse_state == -1) return TRACS_OK;
-    if (a->sparse_state == 1) { *ok = 1; *est_updates = a->sparse->est_updates; return TRACS_OK; }
-    a->sparse_state = -1;
-    const size_t n = a->n, L = pair_L(a), groups = pair_groups(a);      // the variable sites only when site classes are in use
-    const uint4 *planes = pair_planes(a, false);
-    if (L >= (1ull << 28) || n >= (1ull << 28)) return TRACS_OK;        // entries hold site << 4 / sample << 4
+    if (!a) return;
+    gs_free(a->minor);
+    a->minor = nullptr;
+}
+
+// The lists of a 5-plane alignment (planes, n samples, L sites).  *out = nullptr when the alignment is outside what the path
+// supports (too long, too many entries, no memory) -- not an error.
+static int gs_build(const uint4 *planes, size_t n, size_t n_pad, size_t L, size_t groups, hipStream_t stream, GeneralSparse **out)
+{
+    *out = nullptr;
+    if (L >= (1ull << 28) || n >= (1ull << 28) || L == 0) return TRACS_OK;        // entries hold site << 4 / sample << 4
     auto *g = new GeneralSparse();
-    a->sparse = g;
     unsigned *cnt = nullptr, *cn = nullptr, *cntP = nullptr, *cntN = nullptr;
     unsigned long long *off = nullptr;
     double *d_est = nullptr;
     auto tmp_free = [&]() { void *p[] = {cnt, cn, cntP, cntN, off, d_est}; for (void *q : p) if (q) (void)hipFree(q); };
-    auto fail_soft = [&]() { tmp_free(); (void)hipGetLastError(); general_sparse_free(a); a->sparse_state = -1; return TRACS_OK; };
+    auto fail_soft = [&]() { tmp_free(); (void)hipGetLastError(); gs_free(g); return TRACS_OK; };
 #define GS_TRY(x) do { if ((x) != hipSuccess) return fail_soft(); } while (0)
     const size_t nsc = n * GS_CHUNKS;
     const size_t gpc = (groups + GS_CHUNKS - 1) / GS_CHUNKS;
@@ -314,13 +331,14 @@ int general_sparse_get(tracs_alignment *a, hipStream_t stream, int *ok, double *
     GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->p_off), (L + 1) * 8));
     GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->n_off), (L + 1) * 8));
     GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->c_n), std::max<size_t>(n, 1) * 4));
+    GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->c_p), std::max<size_t>(n, 1) * 4));
     GS_TRY(hipMemsetAsync(d_est, 0, 8, stream));
 
     const dim3 sgrid((unsigned)((n + 63) / 64), GS_CHUNKS / 4);
-    hipLaunchKernelGGL((gs_sample_kernel<false>), sgrid, dim3(256), 0, stream, planes, a->n_pad, n, groups, gpc, cnt, cn, nullptr, nullptr);
+    hipLaunchKernelGGL((gs_sample_kernel<false>), sgrid, dim3(256), 0, stream, planes, n_pad, n, groups, gpc, cnt, cn, nullptr, nullptr);
     hipLaunchKernelGGL(gs_scan_kernel, dim3(1), dim3(1024), 0, stream, cnt, nsc, off);
-    hipLaunchKernelGGL(gs_sample_totals_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, stream, cn, n, g->c_n, off, g->s_off);
-    hipLaunchKernelGGL((gs_site_kernel<false>), dim3((unsigned)groups), dim3(256), 0, stream, planes, a->n_pad, n, L, cntP, cntN,
+    hipLaunchKernelGGL(gs_sample_totals_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, stream, cnt, cn, n, g->c_n, g->c_p, off, g->s_off);
+    hipLaunchKernelGGL((gs_site_kernel<false>), dim3((unsigned)groups), dim3(256), 0, stream, planes, n_pad, n, L, cntP, cntN,
                        nullptr, nullptr, nullptr, nullptr, d_est);
     hipLaunchKernelGGL(gs_scan_kernel, dim3(1), dim3(1024), 0, stream, cntP, L, g->p_off);
     hipLaunchKernelGGL(gs_scan_kernel, dim3(1), dim3(1024), 0, stream, cntN, L, g->n_off);
@@ -331,42 +349,81 @@ int general_sparse_get(tracs_alignment *a, hipStream_t stream, int *ok, double *
     GS_TRY(hipMemcpyAsync(&tot_n, g->n_off + L, 8, hipMemcpyDeviceToHost, stream));
     GS_TRY(hipMemcpyAsync(&est, d_est, 8, hipMemcpyDeviceToHost, stream));
     GS_TRY(hipStreamSynchronize(stream));
-    if (tot_s != tot_p + tot_n) { tmp_free(); general_sparse_free(a); set_error("general_sparse: list totals disagree (internal error)"); return TRACS_E_HIP; }
+    if (tot_s != tot_p + tot_n) { tmp_free(); gs_free(g); set_error("general_sparse: list totals disagree (internal error)"); return TRACS_E_HIP; }
     // the lists must stay a small fraction of the planes: beyond one entry per 8 sites the VALU kernel is the better tool anyway
     if ((double)tot_s > (double)n * (double)L / 8.0) return fail_soft();
     GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->s_ent), std::max<size_t>(tot_s, 1) * 4));
     GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->p_ent), std::max<size_t>(tot_p, 1) * 4));
     GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->n_ent), std::max<size_t>(tot_n, 1) * 4));
-    hipLaunchKernelGGL((gs_sample_kernel<true>), sgrid, dim3(256), 0, stream, planes, a->n_pad, n, groups, gpc, nullptr, nullptr, off, g->s_ent);
-    hipLaunchKernelGGL((gs_site_kernel<true>), dim3((unsigned)groups), dim3(256), 0, stream, planes, a->n_pad, n, L, nullptr, nullptr,
+    hipLaunchKernelGGL((gs_sample_kernel<true>), sgrid, dim3(256), 0, stream, planes, n_pad, n, groups, gpc, nullptr, nullptr, off, g->s_ent);
+    hipLaunchKernelGGL((gs_site_kernel<true>), dim3((unsigned)groups), dim3(256), 0, stream, planes, n_pad, n, L, nullptr, nullptr,
                        g->p_off, g->n_off, g->p_ent, g->n_ent, nullptr);
     GS_TRY(hipGetLastError());
     GS_TRY(hipStreamSynchronize(stream));
 #undef GS_TRY
     tmp_free();
     g->est_updates = est;
+    *out = g;
+    return TRACS_OK;
+}
+
+int general_sparse_get(tracs_alignment *a, hipStream_t stream, int *ok, double *est_updates)
+{
+    *ok = 0;
+    if (a->sparse_state == -1) return TRACS_OK;
+    if (a->sparse_state == 1) { *ok = 1; *est_updates = a->sparse->est_updates; return TRACS_OK; }
+    a->sparse_state = -1;
+    // the variable sites only when site classes are in use
+    const int rc = gs_build(pair_planes(a, false), a->n, a->n_pad, pair_L(a), pair_groups(a), stream, &a->sparse);
+    if (rc || !a->sparse) return rc;
     a->sparse_state = 1;
     *ok = 1;
-    *est_updates = est;
+    *est_updates = a->sparse->est_updates;
     return TRACS_OK;
+}
+
+// site_classes.hip: the lists of the minority sites, from their 5-plane image (minority samples carry {reference, own base})
+int minority_lists_build(tracs_alignment *a, const uint4 *planes, size_t sites, hipStream_t stream, int *ok)
+{
+    minority_lists_free(a);
+    const int rc = gs_build(planes, a->n, a->n_pad, sites, groups_for(sites), stream, &a->minor);
+    *ok = a->minor != nullptr;
+    return rc;
+}
+
+static int fixup_launch(const GeneralSparse *g, bool minor, unsigned L, size_t n, size_t row_begin, size_t row_end, size_t col_begin,
+                        unsigned *dist, unsigned *ncomp, size_t ld, hipStream_t stream)
+{
+    const unsigned chunk = (unsigned)std::min<size_t>((n + 63) / 64 * 64, 32768);
+    static bool attr_set = false;
+    if (!attr_set) {
+        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(general_fixup_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4));
+        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(general_fixup_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4));
+        attr_set = true;
+    }
+    const dim3 grid((unsigned)(row_end - row_begin), (unsigned)((n + chunk - 1) / chunk));
+    if (minor)
+        hipLaunchKernelGGL(general_fixup_kernel<true>, grid, dim3(1024), chunk * 4, stream, g->s_off, g->s_ent, g->p_off, g->p_ent, g->n_off,
+                           g->n_ent, g->c_n, g->c_p, L, (unsigned)n, (unsigned)row_begin, (unsigned)col_begin, chunk, dist, ncomp, ld);
+    else
+        hipLaunchKernelGGL(general_fixup_kernel<false>, grid, dim3(1024), chunk * 4, stream, g->s_off, g->s_ent, g->p_off, g->p_ent, g->n_off,
+                           g->n_ent, g->c_n, g->c_p, L, (unsigned)n, (unsigned)row_begin, (unsigned)col_begin, chunk, dist, ncomp, ld);
+    TRACS_HIP_CHECK(hipGetLastError());
+    return TRACS_OK;
+}
+
+// dist[i][j] += the minority sites' contribution (consensus alignments cut into site classes)
+int minority_fixup(tracs_alignment *a, size_t row_begin, size_t row_end, size_t col_begin, unsigned *dist, size_t ld, hipStream_t stream)
+{
+    if (!a->minor) return TRACS_OK;
+    return fixup_launch(a->minor, true, 0u, a->n, row_begin, row_end, col_begin, dist, nullptr, ld, stream);
 }
 
 int general_sparse_fixup(tracs_alignment *a, size_t row_begin, size_t row_end, size_t col_begin, unsigned *dist, unsigned *ncomp,
                          size_t ld, hipStream_t stream)
 {
     if (a->sparse_state != 1 || !a->sparse) { set_error("general_sparse_fixup: lists not built"); return TRACS_E_ARG; }
-    const GeneralSparse *g = a->sparse;
-    const unsigned chunk = (unsigned)std::min<size_t>((a->n + 63) / 64 * 64, 32768);
-    static bool attr_set = false;
-    if (!attr_set) {
-        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(general_fixup_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4));
-        attr_set = true;
-    }
-    const dim3 grid((unsigned)(row_end - row_begin), (unsigned)((a->n + chunk - 1) / chunk));
-    hipLaunchKernelGGL(general_fixup_kernel, grid, dim3(1024), chunk * 4, stream, g->s_off, g->s_ent, g->p_off, g->p_ent, g->n_off,
-                       g->n_ent, g->c_n, (unsigned)pair_L(a), (unsigned)a->n, (unsigned)row_begin, (unsigned)col_begin, chunk, dist, ncomp, ld);
-    TRACS_HIP_CHECK(hipGetLastError());
-    return TRACS_OK;
+    return fixup_launch(a->sparse, false, (unsigned)pair_L(a), a->n, row_begin, row_end, col_begin, dist, ncomp, ld, stream);
 }
 
 }  // namespace tracs

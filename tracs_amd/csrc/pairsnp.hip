@@ -396,6 +396,16 @@ __global__ void compact_live_kernel(const int2 *__restrict__ tiles, const unsign
     if (t < n_tiles && live[t]) out[atomicAdd(n_out, 1u)] = tiles[t];
 }
 
+// ncomp cells of the block += c (site classes: sites at which no sample is N, when no counting pass runs)
+__global__ void add_cells_kernel(unsigned *__restrict__ ncomp, size_t ld, unsigned n, unsigned row_begin, unsigned row_end,
+                                 unsigned col_begin, unsigned c)
+{
+    const unsigned i = row_begin + blockIdx.y;
+    if (i >= row_end) return;
+    for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
+        if (j > i && j >= col_begin) ncomp[(size_t)i * ld + j] += c;
+}
+
 __global__ void init_cells_kernel(unsigned *__restrict__ dist, unsigned *__restrict__ ncomp, size_t ld, unsigned n,
                                   unsigned row_begin, unsigned row_end, unsigned col_begin, unsigned L)
 {
@@ -736,7 +746,10 @@ int tracs_debug_alignment_kernel(const tracs_alignment *a) { return !a ? -1 : a-
 int tracs_debug_alignment_site_classes(const tracs_alignment *a, uint64_t *out)
 {
     if (!a) return 0;
-    if (out) { out[0] = a->classes_state == 1 ? a->L_var : 0; out[1] = a->classes_state == 1 ? a->L_inv : 0; }
+    if (out) {
+        const bool on = a->classes_state == 1;
+        out[0] = on ? a->L_var : 0; out[1] = on ? a->L_inv : 0; out[2] = on ? a->L_minor : 0; out[3] = on ? a->L_full : 0;
+    }
     return a->classes_state;
 }
 
@@ -947,6 +960,7 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
             A.n_pad = a->n_pad; A.groups = g_end; A.tiles = tl; A.n_tiles = ntl; A.gps = gps; A.ksplit = k;
             A.L = (unsigned)pair_L(a); A.n = (unsigned)a->n; A.row_end = (unsigned)row_end; A.col_begin = (unsigned)col_begin;
             A.dist = dist; A.ncomp = ncomp; A.ld = ld; A.thr = t; A.ph = ph;
+            A.keep_bound = (classes && a->minor) ? 1 : 0;      // terms are added to the cells afterwards: no flag values
             return launch_pairsnp_mfma(shape_id, mfma_general, nwg, stream, A);
         }
         V.launch[cons ? 1 : 0](ncomp != nullptr, nwg, stream, cons ? a->cplanes : a->planes, a->n_pad, g_end, tl, ntl, gps, k,
@@ -958,7 +972,13 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
     // a thresholded run).  Ranges of at most 2^23 sites keep the fp32 partial sums exact; the cells already hold the variable
     // sites' counts, so every range adds with integer atomics.
     auto count_pass = [&](const int2 *tl, size_t ntl) -> int {
-        if (!classes || !ncomp || a->L_inv == 0 || ntl == 0) return TRACS_OK;
+        if (!classes || !ncomp || ntl == 0 || (a->L_inv == 0 && a->L_full == 0)) return TRACS_OK;
+        if (a->L_inv == 0) {                                   // only sites without any N: a constant
+            dim3 grid(64, (unsigned)(row_end - row_begin));
+            hipLaunchKernelGGL(add_cells_kernel, grid, dim3(256), 0, stream, ncomp, ld, (unsigned)a->n, (unsigned)row_begin, (unsigned)row_end,
+                               (unsigned)col_begin, (unsigned)a->L_full);
+            return TRACS_OK;
+        }
         const int gi = (int)a->groups_inv, gcc = S.gc_cnt;
         int k = std::max(pick_split(ntl, gi, gcc), (gi + (1 << 16) - 1) >> 16);
         int g = (gi + k - 1) / k;
@@ -966,17 +986,27 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
         k = (gi + g - 1) / g;
         MfmaArgs A;
         A.P = a->iplanes; A.n_pad = a->n_pad; A.groups = gi; A.tiles = tl; A.n_tiles = (int)ntl; A.gps = g; A.ksplit = k;
-        A.L = (unsigned)a->L_inv; A.n = (unsigned)a->n; A.row_end = (unsigned)row_end; A.col_begin = (unsigned)col_begin;
+        A.L = (unsigned)a->L_full;                             // added once per cell (range 0): the sites without any N
+        A.n = (unsigned)a->n; A.row_end = (unsigned)row_end; A.col_begin = (unsigned)col_begin;
         A.dist = dist; A.ncomp = ncomp; A.ld = ld; A.thr = 0xFFFFFFFFu; A.ph = TilePhase{0, 0, nullptr};
         return launch_pairsnp_count(shape_id, (unsigned)(ntl * (size_t)k), stream, A);
     };
+    // Site classes, consensus form: the minority sites' distances from their lists (general_sparse.hip, general_fixup_kernel<MINOR>)
+    auto minor_pass = [&]() -> int {
+        return (classes && a->minor) ? minority_fixup(a, row_begin, row_end, col_begin, dist, ld, stream) : TRACS_OK;
+    };
     if (classes && groups == 0) {
-        // no variable site at all: every distance is 0, the compared-sites counts come from the invariant sites alone
+        // no dense site at all: the distances come from the lists, the compared-sites counts from the counting pass
         dim3 grid(64, (unsigned)(row_end - row_begin));
+        pair_mark(0, stream);
         hipLaunchKernelGGL(init_cells_kernel, grid, dim3(256), 0, stream, dist, ncomp, ld, (unsigned)a->n,
                            (unsigned)row_begin, (unsigned)row_end, (unsigned)col_begin, 0u);
-        const int rc = count_pass(a->d_tiles, a->n_tiles);
+        pair_mark(1, stream);
+        int rc = minor_pass();
         if (rc) return rc;
+        pair_mark(2, stream);
+        if ((rc = count_pass(a->d_tiles, a->n_tiles))) return rc;
+        pair_mark(3, stream);
         TRACS_HIP_CHECK(hipGetLastError());
         return TRACS_OK;
     }
@@ -1010,6 +1040,7 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
             if ((rc = launch(live_tiles, (unsigned)(n_live * (size_t)k2), (int)n_live, groups, gps2, k2, thr, TilePhase{2, prefix, nullptr}))) return rc;
         }
         if (mfma_general && (rc = general_sparse_fixup(a, row_begin, row_end, col_begin, dist, ncomp, ld, stream))) return rc;
+        if ((rc = minor_pass())) return rc;
         if ((rc = count_pass(live_tiles, n_live))) return rc;
         TRACS_HIP_CHECK(hipGetLastError());
         return TRACS_OK;
@@ -1028,6 +1059,7 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
     if (rc) return rc;
     pair_mark(1, stream);
     if (mfma_general && (rc = general_sparse_fixup(a, row_begin, row_end, col_begin, dist, ncomp, ld, stream))) return rc;
+    if ((rc = minor_pass())) return rc;
     pair_mark(2, stream);
     if ((rc = count_pass(a->d_tiles, a->n_tiles))) return rc;
     pair_mark(3, stream);

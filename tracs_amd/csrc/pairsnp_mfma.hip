@@ -390,8 +390,8 @@ __global__ __launch_bounds__(NWR * NWC * 64, (NBR * NBC > 4 ? 1 : 2)) void pairs
                 const unsigned i = cell_row(rb, r), j = cell_col(cb);
                 if (i < A.row_end && j < A.n && j > i && j >= A.col_begin) {
                     const int V = (int)accV[rb][cb][r];
-                    if constexpr (COUNT) {                     // the cells hold the variable sites' counts already
-                        atomicAdd(&A.ncomp[(size_t)i * A.ld + j], (unsigned)V);
+                    if constexpr (COUNT) {                     // the cells hold the variable sites' counts already;
+                        atomicAdd(&A.ncomp[(size_t)i * A.ld + j], (unsigned)V + (ks == 0 ? A.L : 0u));   // A.L: sites without any N
                         continue;
                     }
                     const int S = (int)accS[rb][cb][r];
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(NWR * NWC * 64, (NBR * NBC > 4 ? 1 : 2)) void pairs
                     if (dead) {
                         // consensus: flagged.  general: the prefix's lower bound itself (> threshold, and the sparse terms added
                         // later only raise it) -- a flag value could collide with a legitimately negative intermediate
-                        A.dist[o] = GENERAL ? d : 0xFFFFFFFFu;
+                        A.dist[o] = (GENERAL || A.keep_bound) ? d : 0xFFFFFFFFu;
                         if (A.ncomp) A.ncomp[o] = 0u;
                     } else if (single) {
                         A.dist[o] = d;

@@ -1,20 +1,27 @@
-// site_classes.hip -- variable / invariant site classes of a packed alignment, decided once per pack.
+// site_classes.hip -- site classes of a packed alignment, decided once per pack.
 //
 // Reference behaviour restated (never copied): /root/reference/src/pairsnp.hpp
 //   pair loop :395-420   d = L - popcount(match),  nn = L - popcount(Ni | Nj): every site is visited for every pair.
 //
 // A site at which every sample that is not N carries the SAME base never separates two samples: it adds 0 to d(i, j) and
-// [neither i nor j is N there] to nn(i, j), whatever the pair.  Real alignments are mostly such sites.  So the sites are cut
-// into three classes once per pack,
-//     variable    two samples carry different bases (or, general encoding, some sample carries a partial IUPAC code),
-//     invariant   not variable, and at least one sample is a base there,
-//     empty       every sample is N (or the tail bits behind L): contributes to nothing,
-// the alignment is re-packed per class -- `vplanes`: the variable sites in site order, same planes and layout as the pair
-// kernels' usual source; `iplanes`: ONE plane, v = "this sample is a base here", over the invariant sites -- and a pass becomes
-//     d, nn_var   the usual pair kernel over vplanes               (4 or 5 operand planes per site)
-//     nn += nn_inv = sum v_i v_j                                   (1 operand plane per site: pairsnp_mfma_kernel<COUNT>)
-// which is exact (the identity holds site by site; tests/test_host_logic.py::test_site_class_identity) and costs
-// (4 L_var + L_inv) / 4 L of the dense pass in the consensus form.  Chosen when that is < 0.92; TRACS_SITE_CLASSES=0/1 forces.
+// [neither i nor j is N there] to nn(i, j), whatever the pair; and a site at which only a FEW samples differ from the others
+// separates only the pairs that involve one of those few.  Real alignments are mostly such sites.  The sites are cut into
+// classes once per pack (k = samples whose base differs from a reference base of the site -- the base of one of its samples --,
+// cN = samples that are N there):
+//     empty      every sample is N (or the tail bits behind L): contributes to nothing;
+//     dense      k (cN + k) above the budget below (general encoding: two samples carry different bases, or some sample a
+//                partial IUPAC code): the usual pair kernel, over `vplanes` -- these sites re-packed in site order, same planes
+//                and layout as the kernels' usual source;
+//     counted    every other site with cN >= 1: nn += sum v_i v_j over `iplanes` (ONE plane, v = "this sample is a base
+//                here"; pairsnp_mfma_kernel<COUNT>, one operand plane instead of four or five);
+//     full       every other site with cN = 0: +1 to every nn, a constant;
+//     minority   the counted / full sites with k >= 1 (consensus encoding only): d gets their contribution from sparse lists
+//                -- the k samples, the cN samples -- exactly as general_sparse.hip handles partial IUPAC codes
+//                (general_fixup_kernel<MINOR>: +1 for a pair of which exactly one is a minority sample and the other a base,
+//                [bases differ] when both are).
+// The decomposition is exact site by site (tests/test_host_logic.py::test_site_class_identity); a pass costs
+// (4 L_dense + L_counted) / 4 L of the dense one in matrix instructions plus ~sum k (cN + k) list entries.  Chosen when that
+// is < 0.92; TRACS_SITE_CLASSES=0/1 forces, TRACS_MINORITY=0 keeps every site with k >= 1 dense.
 #include "pairsnp_kernels.h"
 
 #include <algorithm>
@@ -97,38 +104,115 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
     }
 }
 
-// exclusive prefix sums of the per-group class sizes (one workgroup walks the groups 1024 at a time); totals[0..1]
-__global__ __launch_bounds__(1024) void class_offsets_kernel(const uint4 *__restrict__ var_mask, const uint4 *__restrict__ inv_mask,
-                                                             size_t groups, unsigned *__restrict__ off_var, unsigned *__restrict__ off_inv,
-                                                             unsigned long long *__restrict__ totals)
+// Consensus encoding, one workgroup per 128-site group.  Pass 1: a reference base per site (the base of the first sample, in
+// thread order, that is a base there).  Pass 2: per site k = samples whose base differs from it and cN = samples that are N,
+// counted with LDS atomics (both are sparse).  Then the class masks of the group.
+__global__ __launch_bounds__(256) void classify_consensus_kernel(const uint4 *__restrict__ P, size_t n_pad, unsigned n, unsigned budget,
+                                                                 uint4 *__restrict__ dense_mask, uint4 *__restrict__ count_mask,
+                                                                 uint4 *__restrict__ minor_mask, uint4 *__restrict__ full_mask,
+                                                                 uint4 *__restrict__ ref_x, uint4 *__restrict__ ref_y)
 {
-    __shared__ unsigned sv[1024], si[1024];
-    unsigned long long base_v = 0, base_i = 0;
+    const size_t g = blockIdx.x;
+    __shared__ unsigned red[4][3][4];
+    __shared__ unsigned sref[3][4];                     // seen, ref X, ref Y
+    __shared__ unsigned cM[SITES_PER_GROUP], cN[SITES_PER_GROUP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < SITES_PER_GROUP) { cM[threadIdx.x] = 0; cN[threadIdx.x] = 0; }
+    unsigned seen[4] = {0, 0, 0, 0}, rx[4] = {0, 0, 0, 0}, ry[4] = {0, 0, 0, 0};
+    for (unsigned s = threadIdx.x; s < n; s += 256) {
+        const uint4 X = P[(g * 3 + 0) * n_pad + s], Y = P[(g * 3 + 1) * n_pad + s], V = P[(g * 3 + 2) * n_pad + s];
+        const unsigned x[4] = {X.x, X.y, X.z, X.w}, y[4] = {Y.x, Y.y, Y.z, Y.w}, v[4] = {V.x, V.y, V.z, V.w};
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const unsigned fresh = v[w] & ~seen[w];
+            rx[w] |= x[w] & fresh; ry[w] |= y[w] & fresh; seen[w] |= v[w];
+        }
+    }
+    // lower lanes first: the result is the same on every lane of the wave
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned os = __shfl_xor(seen[w], off, 64), ox = __shfl_xor(rx[w], off, 64), oy = __shfl_xor(ry[w], off, 64);
+            const bool me_first = (lane & off) == 0;
+            const unsigned fs = me_first ? seen[w] : os, fx = me_first ? rx[w] : ox, fy = me_first ? ry[w] : oy;
+            const unsigned ls = me_first ? os : seen[w], lx = me_first ? ox : rx[w], ly = me_first ? oy : ry[w];
+            rx[w] = fx | (lx & ~fs); ry[w] = fy | (ly & ~fs); seen[w] = fs | ls;
+        }
+        if (lane == 0) { red[wave][0][w] = seen[w]; red[wave][1][w] = rx[w]; red[wave][2][w] = ry[w]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int w = threadIdx.x;
+        unsigned fs = 0, fx = 0, fy = 0;
+        for (int k = 0; k < 4; k++) {
+            fx |= red[k][1][w] & ~fs; fy |= red[k][2][w] & ~fs; fs |= red[k][0][w];
+        }
+        sref[0][w] = fs; sref[1][w] = fx; sref[2][w] = fy;
+    }
+    __syncthreads();
+    const unsigned any[4] = {sref[0][0], sref[0][1], sref[0][2], sref[0][3]};
+    const unsigned refx[4] = {sref[1][0], sref[1][1], sref[1][2], sref[1][3]}, refy[4] = {sref[2][0], sref[2][1], sref[2][2], sref[2][3]};
+    for (unsigned s = threadIdx.x; s < n; s += 256) {
+        const uint4 X = P[(g * 3 + 0) * n_pad + s], Y = P[(g * 3 + 1) * n_pad + s], V = P[(g * 3 + 2) * n_pad + s];
+        const unsigned x[4] = {X.x, X.y, X.z, X.w}, y[4] = {Y.x, Y.y, Y.z, Y.w}, v[4] = {V.x, V.y, V.z, V.w};
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            unsigned diff = v[w] & ((x[w] ^ refx[w]) | (y[w] ^ refy[w]));
+            while (diff) { const int b = __ffs(diff) - 1; diff &= diff - 1; atomicAdd(&cM[w * 32 + b], 1u); }
+            unsigned isn = ~v[w] & any[w];                      // N at a site where somebody is a base
+            while (isn) { const int b = __ffs(isn) - 1; isn &= isn - 1; atomicAdd(&cN[w * 32 + b], 1u); }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < SITES_PER_GROUP) {
+        const int t = threadIdx.x, w = t >> 5, b = t & 31;
+        const bool some = (any[w] >> b) & 1u;
+        const unsigned long long k = cM[t], c = cN[t];
+        const bool minor = some && k >= 1 && budget > 0 && k * (c + k) <= (unsigned long long)budget;
+        const bool dense = some && k >= 1 && !minor;
+        const bool counted = some && !dense && c >= 1;
+        const bool full = some && !dense && c == 0;
+        const unsigned long long bd = __ballot(dense), bc = __ballot(counted), bm = __ballot(minor), bf = __ballot(full);
+        if (lane == 0) {
+            unsigned *pd = reinterpret_cast<unsigned *>(&dense_mask[g]), *pc = reinterpret_cast<unsigned *>(&count_mask[g]);
+            unsigned *pm = reinterpret_cast<unsigned *>(&minor_mask[g]), *pf = reinterpret_cast<unsigned *>(&full_mask[g]);
+            pd[2 * wave] = (unsigned)bd; pd[2 * wave + 1] = (unsigned)(bd >> 32);
+            pc[2 * wave] = (unsigned)bc; pc[2 * wave + 1] = (unsigned)(bc >> 32);
+            pm[2 * wave] = (unsigned)bm; pm[2 * wave + 1] = (unsigned)(bm >> 32);
+            pf[2 * wave] = (unsigned)bf; pf[2 * wave + 1] = (unsigned)(bf >> 32);
+        }
+    }
+    if (threadIdx.x < 4) {
+        reinterpret_cast<unsigned *>(&ref_x[g])[threadIdx.x] = refx[threadIdx.x];
+        reinterpret_cast<unsigned *>(&ref_y[g])[threadIdx.x] = refy[threadIdx.x];
+    }
+}
+
+// exclusive prefix sums of one class's per-group sizes (one workgroup walks the groups 1024 at a time); *total
+__global__ __launch_bounds__(1024) void class_offsets_kernel(const uint4 *__restrict__ mask, size_t groups, unsigned *__restrict__ off,
+                                                             unsigned long long *__restrict__ total)
+{
+    __shared__ unsigned sv[1024];
+    unsigned long long base = 0;
     const int t = threadIdx.x;
     for (size_t g0 = 0; g0 < groups; g0 += 1024) {
         const size_t g = g0 + t;
-        unsigned cv = 0, ci = 0;
-        if (g < groups) {
-            const uint4 a = var_mask[g], b = inv_mask[g];
-            cv = __popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w);
-            ci = __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w);
-        }
-        sv[t] = cv; si[t] = ci;
+        unsigned c = 0;
+        if (g < groups) { const uint4 a = mask[g]; c = __popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w); }
+        sv[t] = c;
         __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            const unsigned av = t >= off ? sv[t - off] : 0, ai = t >= off ? si[t - off] : 0;
+        for (int o = 1; o < 1024; o <<= 1) {
+            const unsigned av = t >= o ? sv[t - o] : 0;
             __syncthreads();
-            sv[t] += av; si[t] += ai;
+            sv[t] += av;
             __syncthreads();
         }
-        if (g < groups) {
-            off_var[g] = (unsigned)(base_v + sv[t] - cv);
-            off_inv[g] = (unsigned)(base_i + si[t] - ci);
-        }
-        base_v += sv[1023]; base_i += si[1023];
+        if (g < groups) off[g] = (unsigned)(base + sv[t] - c);
+        base += sv[1023];
         __syncthreads();
     }
-    if (t == 0) { totals[0] = base_v; totals[1] = base_i; }
+    if (t == 0) *total = base;
 }
 
 // the sites of a class in site order: list[off[g] ..] = the set bits of mask[g]
@@ -199,12 +283,61 @@ __global__ __launch_bounds__(256) void compact_sites_kernel(const uint4 *__restr
             dst[((size_t)G * NPO + p) * n_pad + s] = make_uint4(out[p][0], out[p][1], out[p][2], out[p][3]);
 }
 
+// The minority sites as a 5-plane (A, C, G, T, N) image for the list builder of general_sparse.hip: N stays N, a sample whose
+// base is the site's reference base carries that base, a minority sample carries {reference base, own base}.
+// Same thread geometry as compact_sites_kernel; bases are coded A = 00, C = 01, G = 10, T = 11 in (Y, X).
+__global__ __launch_bounds__(256) void minority_image_kernel(const uint4 *__restrict__ src, const uint4 *__restrict__ ref_x,
+                                                             const uint4 *__restrict__ ref_y, const unsigned *__restrict__ list, unsigned count,
+                                                             uint4 *__restrict__ dst, size_t n_pad, unsigned n, unsigned groups_dst)
+{
+    const unsigned s = blockIdx.y * 64 + (threadIdx.x & 63);
+    const unsigned G = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (G >= groups_dst) return;
+    const unsigned *__restrict__ srcw = reinterpret_cast<const unsigned *>(src);
+    const unsigned *__restrict__ rxw = reinterpret_cast<const unsigned *>(ref_x), *__restrict__ ryw = reinterpret_cast<const unsigned *>(ref_y);
+    unsigned out[NPLANES][4];
+    unsigned cx = 0, cy = 0, cv = 0, crx = 0, cry = 0, cw = 0xFFFFFFFFu;
+    const unsigned t0 = G * SITES_PER_GROUP;
+#pragma unroll
+    for (int ow = 0; ow < 4; ow++) {
+        unsigned acc[NPLANES] = {0, 0, 0, 0, 0};
+        const unsigned tb = t0 + ow * 32;
+        const unsigned kn = tb >= count ? 0u : min(32u, count - tb);
+        for (unsigned k = 0; k < kn; k++) {
+            const unsigned site = __builtin_amdgcn_readfirstlane(list[tb + k]);
+            const unsigned w = site >> 5;
+            if (w != cw) {                                      // wave-uniform
+                cw = w;
+                const size_t base = ((size_t)(site >> 7) * 3 * n_pad + s) * 4 + (w & 3u);
+                cx = srcw[base]; cy = srcw[base + n_pad * 4]; cv = srcw[base + n_pad * 8];
+                crx = rxw[w]; cry = ryw[w];
+            }
+            const unsigned b = site & 31u;
+            const unsigned v = (cv >> b) & 1u;
+            const unsigned own = 1u << (((cx >> b) & 1u) | (((cy >> b) & 1u) << 1));
+            const unsigned ref = 1u << (((crx >> b) & 1u) | (((cry >> b) & 1u) << 1));
+            const unsigned m = v ? (own | ref) : 15u;
+#pragma unroll
+            for (int p = 0; p < 4; p++) acc[p] |= ((m >> p) & 1u) << k;
+            acc[4] |= (v ^ 1u) << k;
+        }
+#pragma unroll
+        for (int p = 0; p < NPLANES; p++) out[p][ow] = acc[p];
+    }
+    if (s < n)
+#pragma unroll
+        for (int p = 0; p < NPLANES; p++)
+            dst[((size_t)G * NPLANES + p) * n_pad + s] = make_uint4(out[p][0], out[p][1], out[p][2], out[p][3]);
+}
+
 void site_classes_free(tracs_alignment *a)
 {
     if (a->vplanes) (void)hipFree(a->vplanes);
     if (a->iplanes) (void)hipFree(a->iplanes);
     a->vplanes = a->iplanes = nullptr;
     a->L_var = a->L_inv = a->groups_var = a->groups_inv = 0;
+    a->L_minor = a->L_full = 0;
+    minority_lists_free(a);
     a->classes_state = 0;
 }
 
@@ -213,83 +346,110 @@ static size_t class_plane_bytes(const tracs_alignment *a, size_t groups, int pla
     return ((groups + pad_groups) * (size_t)planes * a->n_pad + TAIL_PAD) * sizeof(uint4);
 }
 
-// Decides (once per pack) whether the pair kernels run on site classes and builds the two re-packed alignments if so.
+// Decides (once per pack) whether the pair kernels run on site classes and builds the re-packed alignments and lists if so.
 // `consensus`: the source is a->cplanes (3 planes), else a->planes (5).  Soft-fails (classes_state = -1) when memory is short.
 int site_classes_decide(tracs_alignment *a, bool consensus, hipStream_t stream)
 {
     if (a->classes_state != 0) return TRACS_OK;
     a->classes_state = -1;
     static const int force = [] { const char *e = std::getenv("TRACS_SITE_CLASSES"); return e ? std::atoi(e) : -1; }();
+    static const bool no_minor = [] { const char *e = std::getenv("TRACS_MINORITY"); return e && std::atoi(e) == 0; }();
     if (force == 0 || a->L == 0 || a->L >= (1ull << 32) || a->n < 2) return TRACS_OK;
     const uint4 *src = consensus ? a->cplanes : a->planes;
     if (!src) return TRACS_OK;
     const size_t groups = a->groups;
-    uint4 *masks = nullptr;
+    // sample blocks in grid.y of the re-pack kernels (<= 65535 x 64 samples per launch; beyond that the classes are not used)
+    const unsigned sblocks = (unsigned)(a->n_pad / 64);
+    if (sblocks > 65535u) return TRACS_OK;
+    uint4 *masks = nullptr, *image = nullptr;
     unsigned *offs = nullptr, *lists = nullptr;
     unsigned long long *totals = nullptr;
     auto cleanup = [&]() {
-        if (masks) (void)hipFree(masks);
-        if (offs) (void)hipFree(offs);
-        if (lists) (void)hipFree(lists);
-        if (totals) (void)hipFree(totals);
+        void *p[] = {masks, image, offs, lists, totals};
+        for (void *q : p) if (q) (void)hipFree(q);
     };
     auto soft_fail = [&]() { cleanup(); (void)hipGetLastError(); site_classes_free(a); a->classes_state = -1; return TRACS_OK; };
-    if (hipMalloc(reinterpret_cast<void **>(&masks), 2 * groups * sizeof(uint4)) != hipSuccess) return soft_fail();
-    if (hipMalloc(reinterpret_cast<void **>(&offs), 2 * groups * sizeof(unsigned)) != hipSuccess) return soft_fail();
-    if (hipMalloc(reinterpret_cast<void **>(&totals), 16) != hipSuccess) return soft_fail();
-    uint4 *var_mask = masks, *inv_mask = masks + groups;
-    unsigned *off_var = offs, *off_inv = offs + groups;
-    if (consensus)
-        hipLaunchKernelGGL((classify_sites_kernel<true>), dim3((unsigned)groups), dim3(256), 0, stream, src, a->n_pad, (unsigned)a->n, var_mask, inv_mask);
-    else
-        hipLaunchKernelGGL((classify_sites_kernel<false>), dim3((unsigned)groups), dim3(256), 0, stream, src, a->n_pad, (unsigned)a->n, var_mask, inv_mask);
-    hipLaunchKernelGGL(class_offsets_kernel, dim3(1), dim3(1024), 0, stream, var_mask, inv_mask, groups, off_var, off_inv, totals);
-    unsigned long long tot[2] = {0, 0};
-    if (hipMemcpyAsync(tot, totals, 16, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
+    if (hipMalloc(reinterpret_cast<void **>(&masks), 6 * groups * sizeof(uint4)) != hipSuccess) return soft_fail();
+    if (hipMalloc(reinterpret_cast<void **>(&offs), 4 * groups * sizeof(unsigned)) != hipSuccess) return soft_fail();
+    if (hipMalloc(reinterpret_cast<void **>(&totals), 32) != hipSuccess) return soft_fail();
+    uint4 *dense_mask = masks, *count_mask = masks + groups, *minor_mask = masks + 2 * groups, *full_mask = masks + 3 * groups;
+    uint4 *ref_x = masks + 4 * groups, *ref_y = masks + 5 * groups;
+    unsigned *off_dense = offs, *off_count = offs + groups, *off_minor = offs + 2 * groups, *off_full = offs + 3 * groups;
+    if (consensus) {
+        // a site goes to the lists while its k (cN + k) entries cost less than three operand planes over all pairs:
+        // ~51 ns per site at 10 000 samples (pair kernel) against ~2-4 ps per list entry (general_fixup_kernel)
+        const double b = (double)a->n * (double)a->n / 8000.0;
+        const unsigned budget = no_minor ? 0u : (unsigned)std::min(1.0e9, std::max(16.0, b));
+        hipLaunchKernelGGL(classify_consensus_kernel, dim3((unsigned)groups), dim3(256), 0, stream, src, a->n_pad, (unsigned)a->n, budget,
+                           dense_mask, count_mask, minor_mask, full_mask, ref_x, ref_y);
+    } else {
+        // general encoding: variable -> dense, invariant -> counted (v = complement of the N plane); no lists of its own
+        if (hipMemsetAsync(minor_mask, 0, 2 * groups * sizeof(uint4), stream) != hipSuccess) return soft_fail();
+        hipLaunchKernelGGL((classify_sites_kernel<false>), dim3((unsigned)groups), dim3(256), 0, stream, src, a->n_pad, (unsigned)a->n,
+                           dense_mask, count_mask);
+    }
+    hipLaunchKernelGGL(class_offsets_kernel, dim3(1), dim3(1024), 0, stream, dense_mask, groups, off_dense, totals + 0);
+    hipLaunchKernelGGL(class_offsets_kernel, dim3(1), dim3(1024), 0, stream, count_mask, groups, off_count, totals + 1);
+    hipLaunchKernelGGL(class_offsets_kernel, dim3(1), dim3(1024), 0, stream, minor_mask, groups, off_minor, totals + 2);
+    hipLaunchKernelGGL(class_offsets_kernel, dim3(1), dim3(1024), 0, stream, full_mask, groups, off_full, totals + 3);    // total only
+    unsigned long long tot[4] = {0, 0, 0, 0};
+    if (hipMemcpyAsync(tot, totals, 32, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
         cleanup();
         TRACS_HIP_CHECK(hipGetLastError());
         set_error("site_classes_decide: classification failed");
         return TRACS_E_HIP;
     }
-    const size_t L_var = (size_t)tot[0], L_inv = (size_t)tot[1];
-    // matrix instructions per pair: planes_full per site now; planes_full per variable site + one per invariant site with classes
+    const size_t L_dense = (size_t)tot[0], L_count = (size_t)tot[1], L_minor = (size_t)tot[2], L_full = (size_t)tot[3];
+    // matrix instructions per pair: planes_full per site now; planes_full per dense site + one per counted site with classes
     const double planes_full = consensus ? 4.0 : 5.0;
-    const double cost = (planes_full * (double)L_var + (double)L_inv) / (planes_full * (double)a->L);
-    if ((force != 1 && cost >= 0.92) || (!consensus && L_var == 0)) { cleanup(); return TRACS_OK; }
+    const double cost = (planes_full * (double)L_dense + (double)L_count) / (planes_full * (double)a->L);
+    if ((force != 1 && cost >= 0.92) || (!consensus && L_dense == 0)) { cleanup(); return TRACS_OK; }
 
     const int npv = consensus ? 3 : NPLANES;
-    const size_t gv = groups_for(L_var), gi = groups_for(L_inv);
+    const size_t gv = groups_for(L_dense), gi = groups_for(L_count), gm = groups_for(L_minor);
     const size_t vbytes = class_plane_bytes(a, gv, npv, PAD_GROUPS), ibytes = class_plane_bytes(a, gi, 1, COUNT_PAD_GROUPS);
-    if (hipMalloc(reinterpret_cast<void **>(&lists), (L_var + L_inv + 1) * sizeof(unsigned)) != hipSuccess) return soft_fail();
+    if (hipMalloc(reinterpret_cast<void **>(&lists), (L_dense + L_count + L_minor + 1) * sizeof(unsigned)) != hipSuccess) return soft_fail();
     if (hipMalloc(reinterpret_cast<void **>(&a->vplanes), vbytes) != hipSuccess) { a->vplanes = nullptr; return soft_fail(); }
     if (hipMalloc(reinterpret_cast<void **>(&a->iplanes), ibytes) != hipSuccess) { a->iplanes = nullptr; return soft_fail(); }
-    unsigned *list_var = lists, *list_inv = lists + L_var;
+    unsigned *list_dense = lists, *list_count = lists + L_dense, *list_minor = lists + L_dense + L_count;
     bool ok = hipMemsetAsync(a->vplanes, 0, vbytes, stream) == hipSuccess && hipMemsetAsync(a->iplanes, 0, ibytes, stream) == hipSuccess;
     const dim3 lgrid((unsigned)((groups + 255) / 256));
-    hipLaunchKernelGGL(class_list_kernel, lgrid, dim3(256), 0, stream, var_mask, off_var, groups, list_var);
-    hipLaunchKernelGGL(class_list_kernel, lgrid, dim3(256), 0, stream, inv_mask, off_inv, groups, list_inv);
-    // sample blocks in grid.y (<= 65535 x 64 samples per launch: n_pad < 2^22; beyond that the classes are not used)
-    const unsigned sblocks = (unsigned)(a->n_pad / 64);
-    if (sblocks > 65535u) return soft_fail();
+    hipLaunchKernelGGL(class_list_kernel, lgrid, dim3(256), 0, stream, dense_mask, off_dense, groups, list_dense);
+    hipLaunchKernelGGL(class_list_kernel, lgrid, dim3(256), 0, stream, count_mask, off_count, groups, list_count);
+    hipLaunchKernelGGL(class_list_kernel, lgrid, dim3(256), 0, stream, minor_mask, off_minor, groups, list_minor);
     if (gv) {
         const dim3 grid((unsigned)((gv + 3) / 4), sblocks);
         if (consensus)
-            hipLaunchKernelGGL((compact_sites_kernel<3>), grid, dim3(256), 0, stream, src, 3, 0, false, list_var, (unsigned)L_var, a->vplanes,
+            hipLaunchKernelGGL((compact_sites_kernel<3>), grid, dim3(256), 0, stream, src, 3, 0, false, list_dense, (unsigned)L_dense, a->vplanes,
                                a->n_pad, (unsigned)a->n, (unsigned)gv);
         else
-            hipLaunchKernelGGL((compact_sites_kernel<NPLANES>), grid, dim3(256), 0, stream, src, NPLANES, 0, false, list_var, (unsigned)L_var,
+            hipLaunchKernelGGL((compact_sites_kernel<NPLANES>), grid, dim3(256), 0, stream, src, NPLANES, 0, false, list_dense, (unsigned)L_dense,
                                a->vplanes, a->n_pad, (unsigned)a->n, (unsigned)gv);
     }
     if (gi) {
         const dim3 grid((unsigned)((gi + 3) / 4), sblocks);
         // consensus: plane 2 = V.  general: the complement of plane 4 = N (an invariant site holds bases and N only)
         hipLaunchKernelGGL((compact_sites_kernel<1>), grid, dim3(256), 0, stream, src, consensus ? 3 : NPLANES, consensus ? 2 : 4, !consensus,
-                           list_inv, (unsigned)L_inv, a->iplanes, a->n_pad, (unsigned)a->n, (unsigned)gi);
+                           list_count, (unsigned)L_count, a->iplanes, a->n_pad, (unsigned)a->n, (unsigned)gi);
+    }
+    if (gm) {
+        // the lists of the minority sites, through a temporary 5-plane image of those sites
+        const size_t mbytes = class_plane_bytes(a, gm, NPLANES, 0);
+        if (hipMalloc(reinterpret_cast<void **>(&image), mbytes) != hipSuccess) { image = nullptr; return soft_fail(); }
+        ok = ok && hipMemsetAsync(image, 0, mbytes, stream) == hipSuccess;
+        const dim3 grid((unsigned)((gm + 3) / 4), sblocks);
+        hipLaunchKernelGGL(minority_image_kernel, grid, dim3(256), 0, stream, src, ref_x, ref_y, list_minor, (unsigned)L_minor, image, a->n_pad,
+                           (unsigned)a->n, (unsigned)gm);
+        int built = 0;
+        const int rc = minority_lists_build(a, image, L_minor, stream, &built);
+        if (rc) { cleanup(); site_classes_free(a); a->classes_state = -1; return rc; }
+        if (!built) return soft_fail();
     }
     ok = ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(stream) == hipSuccess;
     cleanup();
     if (!ok) { site_classes_free(a); a->classes_state = -1; set_error("site_classes_decide: re-pack failed"); return TRACS_E_HIP; }
-    a->L_var = L_var; a->L_inv = L_inv; a->groups_var = gv; a->groups_inv = gi;
+    a->L_var = L_dense; a->L_inv = L_count; a->groups_var = gv; a->groups_inv = gi;
+    a->L_minor = L_minor; a->L_full = L_full;
     a->classes_state = 1;
     return TRACS_OK;
 }

@@ -95,13 +95,14 @@ class Alignment:
 
     @property
     def site_classes(self):
-        """(variable sites, invariant sites) when the last dense call ran on site classes (csrc/site_classes.hip): the pair
-        kernel read the variable sites only and a one-operand pass over the invariant sites completed the compared-sites
-        counts; None when the whole alignment was read."""
+        """(dense, counted, minority, full) sites when the last dense call ran on site classes (csrc/site_classes.hip): the
+        pair kernel read the dense sites only, a one-operand pass over the counted sites (and a constant for the full ones:
+        nobody is N there) completed the compared-sites counts, and the minority sites -- counted or full sites at which a few
+        samples differ -- added their distances from sparse lists; None when the whole alignment was read."""
         import ctypes as C
-        out = (C.c_uint64 * 2)()
+        out = (C.c_uint64 * 4)()
         state = self._L.tracs_debug_alignment_site_classes(self._h, out)
-        return (int(out[0]), int(out[1])) if state == 1 else None
+        return tuple(int(x) for x in out) if state == 1 else None
 
     @property
     def nbytes(self):
