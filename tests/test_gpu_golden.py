@@ -371,8 +371,12 @@ def test_thresholded_dense_early_out(dev, oracle, torch_mod):
             far = dh[ri[~keep], ci[~keep]]
             assert (far.astype(np.int64) > thr).all()                      # exact, 0xFFFFFFFF or bit 31 set: never <= thr
             if L > 100000:                                                 # two-pass run: most far tiles died in the prefix pass
-                if enc == "consensus":                                     # (short alignments take one plain pass: all exact)
+                cls = aln.site_classes
+                if enc == "consensus" and not (cls and cls[2]):            # (short alignments take one plain pass: all exact)
                     assert (far >= 0x80000000).mean() > 0.5                # dead tiles are flagged
+                elif enc == "consensus":                                   # minority lists add to the cells afterwards: dead tiles keep
+                    stopped = far != ed[~keep].astype(np.uint32)           # a lower bound (> thr) + their list terms, never a flag
+                    assert stopped.mean() > 0.5 and (far[stopped].astype(np.int64) < ed[~keep][stopped].astype(np.int64)).all()
                 else:                                                      # general: dead tiles keep a lower bound that is already > thr
                     stopped = far != ed[~keep].astype(np.uint32)
                     # (256 x 128-pair workgroups: with 70-sample lineages fewer tiles are wholly far than with 128 x 128)

@@ -125,8 +125,9 @@ def generate_device(n, L, seed, emit, mu_lineage=1e-5, mu_sample=1e-6, n_lineage
         k = int(host_rng.poisson(L * mu)) if mu > 0 else 0
         out = base.clone()
         if k:
-            pos = torch.randint(0, L, (k,), generator=g, device=dev)
-            out[pos] = (out[pos] + torch.randint(1, 4, (k,), generator=g, device=dev, dtype=torch.int8)) & 3
+            # distinct positions: an indexed store with a repeated index keeps whichever write lands last (not reproducible)
+            pos = torch.unique(torch.randint(0, L, (k,), generator=g, device=dev))
+            out[pos] = (out[pos] + torch.randint(1, 4, (k,), generator=g, device=dev, dtype=torch.int8)[:pos.numel()]) & 3
         return out
     founders = [mutate(anc, mu_lineage) for _ in range(n_lineages)]
     stop = n if limit is None else min(n, limit)
