@@ -137,8 +137,8 @@ int tracs_pairsnp_dense(const tracs_alignment *a, size_t row_begin, size_t row_e
 /* Thresholded form: identical (d and nn) for every pair with d <= dist_threshold.  A pair beyond the threshold (never
  * emitted, src/pairsnp.hpp:405) may come back with bit 31 of its distance set (0xFFFFFFFF, or a partial count | 2^31), or
  * (general alignments, and alignments cut into site classes) with a value > threshold that is not its distance, and an unspecified ncomp,
- * because workgroups stop reading the alignment once every pair of their tile is past the threshold: read every cell
- * that is not <= dist_threshold as a signed int32 as "> threshold" (tracs_coo_count/fill skip them).
+ * because workgroups stop reading the alignment once every pair of their tile is past the threshold: a pair is within the
+ * threshold iff its cell, read as an UNSIGNED 32-bit value, is <= dist_threshold (what tracs_coo_count/fill test).
  * Long alignments take two passes (a 1/8 prefix over all tiles, then the rest over the surviving tiles only); this call
  * synchronises the stream once between them.                                                                          */
 int tracs_pairsnp_dense_thr(const tracs_alignment *a, size_t row_begin, size_t row_end, size_t col_begin,

@@ -348,9 +348,8 @@ static size_t class_plane_bytes(const tracs_alignment *a, size_t groups, int pla
 
 // Decides (once per pack) whether the pair kernels run on site classes and builds the re-packed alignments and lists if so.
 // `consensus`: the source is a->cplanes (3 planes), else a->planes (5).  Soft-fails (classes_state = -1) when memory is short.
-int site_classes_decide(tracs_alignment *a, bool consensus, hipStream_t stream)
+static int decide(tracs_alignment *a, bool consensus, bool allow_minor, hipStream_t stream)
 {
-    if (a->classes_state != 0) return TRACS_OK;
     a->classes_state = -1;
     static const int force = [] { const char *e = std::getenv("TRACS_SITE_CLASSES"); return e ? std::atoi(e) : -1; }();
     static const bool no_minor = [] { const char *e = std::getenv("TRACS_MINORITY"); return e && std::atoi(e) == 0; }();
@@ -379,7 +378,7 @@ int site_classes_decide(tracs_alignment *a, bool consensus, hipStream_t stream)
         // a site goes to the lists while its k (cN + k) entries cost less than three operand planes over all pairs:
         // ~51 ns per site at 10 000 samples (pair kernel) against ~2-4 ps per list entry (general_fixup_kernel)
         const double b = (double)a->n * (double)a->n / 8000.0;
-        const unsigned budget = no_minor ? 0u : (unsigned)std::min(1.0e9, std::max(16.0, b));
+        const unsigned budget = (no_minor || !allow_minor) ? 0u : (unsigned)std::min(1.0e9, std::max(16.0, b));
         hipLaunchKernelGGL(classify_consensus_kernel, dim3((unsigned)groups), dim3(256), 0, stream, src, a->n_pad, (unsigned)a->n, budget,
                            dense_mask, count_mask, minor_mask, full_mask, ref_x, ref_y);
     } else {
@@ -443,7 +442,10 @@ int site_classes_decide(tracs_alignment *a, bool consensus, hipStream_t stream)
         int built = 0;
         const int rc = minority_lists_build(a, image, L_minor, stream, &built);
         if (rc) { cleanup(); site_classes_free(a); a->classes_state = -1; return rc; }
-        if (!built) return soft_fail();
+        if (!built) {                                          // lists too large / no memory: the same classes without them
+            soft_fail();
+            return decide(a, consensus, false, stream);
+        }
     }
     ok = ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(stream) == hipSuccess;
     cleanup();
@@ -452,6 +454,12 @@ int site_classes_decide(tracs_alignment *a, bool consensus, hipStream_t stream)
     a->L_minor = L_minor; a->L_full = L_full;
     a->classes_state = 1;
     return TRACS_OK;
+}
+
+int site_classes_decide(tracs_alignment *a, bool consensus, hipStream_t stream)
+{
+    if (a->classes_state != 0) return TRACS_OK;
+    return decide(a, consensus, true, stream);
 }
 
 }  // namespace tracs
