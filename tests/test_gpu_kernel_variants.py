@@ -62,6 +62,8 @@ VARIANTS = [
     ({"TRACS_SITE_CLASSES": "1", "TRACS_KSPLIT": "3"}, {("consensus", "mfma"), ("general", "mfma-general")}),
     ({"TRACS_SITE_CLASSES": "1", "TRACS_MFMA_TILE": "2x2w4x2"}, {("consensus", "mfma"), ("general", "mfma-general")}),
     ({"TRACS_MINORITY": "0"}, {("consensus", "mfma"), ("general", "mfma-general")}),
+    ({"TRACS_COUNT_TILE": "2x2", "TRACS_KSPLIT": "2"}, {("consensus", "mfma"), ("general", "mfma-general")}),
+    ({"TRACS_COUNT_TILE": "4x2", "TRACS_MINORITY": "0"}, {("consensus", "mfma"), ("general", "mfma-general")}),
 ]
 
 

@@ -61,11 +61,13 @@ struct tracs_alignment {
     int classes_state = 0;       // 0 not decided, 1 in use, -1 not in use for this alignment
     tracs::GeneralSparse *sparse = nullptr;   // general matrix-core path: per-site / per-sample lists of N and partial codes
     int sparse_state = 0;        // 0 not built, 1 built, -1 not available for this alignment (too dense / too large / no memory)
-    // cached tile schedule for the last dense region (device + host mirror)
-    int2 *d_tiles = nullptr;
-    size_t n_tiles = 0, tiles_cap = 0;
-    size_t key_rb = (size_t)-1, key_re = 0, key_cb = 0;
-    int key_ti = 0, key_tj = 0;
+    // cached tile schedules of the last dense region: the pair kernel's, and the counting pass's when its workgroup tile differs
+    struct TileCache {
+        int2 *d = nullptr;
+        size_t n = 0, cap = 0;
+        size_t rb = (size_t)-1, re = 0, cb = 0;
+        int ti = 0, tj = 0;
+    } tiles, ctiles;
 };
 
 namespace tracs {

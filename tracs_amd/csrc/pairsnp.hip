@@ -652,7 +652,8 @@ void tracs_alignment_free(tracs_alignment *a)
     if (a->planes) (void)hipFree(a->planes);
     if (a->cplanes) (void)hipFree(a->cplanes);
     if (a->d_flag) (void)hipFree(a->d_flag);
-    if (a->d_tiles) (void)hipFree(a->d_tiles);
+    if (a->tiles.d) (void)hipFree(a->tiles.d);
+    if (a->ctiles.d) (void)hipFree(a->ctiles.d);
     delete a;
 }
 
@@ -903,23 +904,26 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
     a->last_kernel = mfma_general ? 2 : mfma ? 1 : 0;
 
     // ---- (re)build the cached tile schedule ------------------------------------------------------------------------------
-    if (a->key_rb != row_begin || a->key_re != row_end || a->key_cb != col_begin || a->key_ti != kTI || a->key_tj != kTJ) {
+    auto ensure_tiles = [&](tracs_alignment::TileCache &c, int ti, int tj) -> int {
+        if (c.rb == row_begin && c.re == row_end && c.cb == col_begin && c.ti == ti && c.tj == tj) return TRACS_OK;
         std::vector<int2> tiles;
-        build_tiles(a->n, row_begin, row_end, col_begin, kTI, kTJ, tiles);
-        if (tiles.size() > a->tiles_cap) {
-            if (a->d_tiles) TRACS_HIP_CHECK(hipFree(a->d_tiles));
-            a->d_tiles = nullptr;
-            a->tiles_cap = tiles.size() * 2 + 64;
-            TRACS_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&a->d_tiles), a->tiles_cap * sizeof(int2)));
+        build_tiles(a->n, row_begin, row_end, col_begin, ti, tj, tiles);
+        if (tiles.size() > c.cap) {
+            if (c.d) TRACS_HIP_CHECK(hipFree(c.d));
+            c.d = nullptr;
+            c.cap = tiles.size() * 2 + 64;
+            TRACS_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&c.d), c.cap * sizeof(int2)));
         }
         if (!tiles.empty()) {
-            TRACS_HIP_CHECK(hipMemcpyAsync(a->d_tiles, tiles.data(), tiles.size() * sizeof(int2), hipMemcpyHostToDevice, stream));
+            TRACS_HIP_CHECK(hipMemcpyAsync(c.d, tiles.data(), tiles.size() * sizeof(int2), hipMemcpyHostToDevice, stream));
             TRACS_HIP_CHECK(hipStreamSynchronize(stream));   // `tiles` is a stack vector
         }
-        a->n_tiles = tiles.size();
-        a->key_rb = row_begin; a->key_re = row_end; a->key_cb = col_begin; a->key_ti = kTI; a->key_tj = kTJ;
-    }
-    if (a->n_tiles == 0) return TRACS_OK;
+        c.n = tiles.size();
+        c.rb = row_begin; c.re = row_end; c.cb = col_begin; c.ti = ti; c.tj = tj;
+        return TRACS_OK;
+    };
+    { const int rc = ensure_tiles(a->tiles, kTI, kTJ); if (rc) return rc; }
+    if (a->tiles.n == 0) return TRACS_OK;
 
     // Split the group range over workgroups (integer atomics, still exact) when that fills the chip better:
     // too few tiles (config 2), or a ragged last round of resident workgroups (tail effect).
@@ -943,7 +947,7 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
         if (const char *e = std::getenv("TRACS_KSPLIT")) { const int v = std::atoi(e); if (v >= 1 && v <= max_split) pick = v; }
         return pick;
     };
-    int ksplit = pick_split(a->n_tiles, groups, kGC);
+    int ksplit = pick_split(a->tiles.n, groups, kGC);
     auto stage_split = [&](int range, int k, int &gps_out) {       // k workgroups over `range` groups, stage aligned
         int g = (range + k - 1) / k;
         g = (g + kGC - 1) / kGC * kGC;
@@ -972,15 +976,29 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
     // a thresholded run).  Ranges of at most 2^23 sites keep the fp32 partial sums exact; the cells already hold the variable
     // sites' counts, so every range adds with integer atomics.
     auto count_pass = [&](const int2 *tl, size_t ntl) -> int {
-        if (!classes || !ncomp || ntl == 0 || (a->L_inv == 0 && a->L_full == 0)) return TRACS_OK;
+        if (!classes || !ncomp || (a->L_inv == 0 && a->L_full == 0)) return TRACS_OK;
         if (a->L_inv == 0) {                                   // only sites without any N: a constant
             dim3 grid(64, (unsigned)(row_end - row_begin));
             hipLaunchKernelGGL(add_cells_kernel, grid, dim3(256), 0, stream, ncomp, ld, (unsigned)a->n, (unsigned)row_begin, (unsigned)row_end,
                                (unsigned)col_begin, (unsigned)a->L_full);
             return TRACS_OK;
         }
-        const int gi = (int)a->groups_inv, gcc = S.gc_cnt;
+        // tl == nullptr: every tile of the region, in the counting pass's own workgroup tile (its own cached schedule);
+        // otherwise the given tiles (the live ones of a thresholded run) in the pair kernel's geometry
+        CountShape C = count_shape_like(kTI, kTJ);
+        if (tl && !C.fn) tl = nullptr;                         // no counting kernel with the pair kernel's tile: count every tile
+        if (!tl) {
+            C = count_shape_current();
+            const int rc = ensure_tiles(a->ctiles, C.ti, C.tj);
+            if (rc) return rc;
+            tl = a->ctiles.d; ntl = a->ctiles.n;
+        }
+        if (ntl == 0) return TRACS_OK;
+        const int gi = (int)a->groups_inv, gcc = C.gc;
+        const double keep_slots = slots;
+        slots = (double)C.wg_per_cu * (slots / (double)(mfma ? S.wg_per_cu : V.wg_per_cu[cons ? 1 : 0]));
         int k = std::max(pick_split(ntl, gi, gcc), (gi + (1 << 16) - 1) >> 16);
+        slots = keep_slots;
         int g = (gi + k - 1) / k;
         g = (g + gcc - 1) / gcc * gcc;
         k = (gi + g - 1) / g;
@@ -989,7 +1007,8 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
         A.L = (unsigned)a->L_full;                             // added once per cell (range 0): the sites without any N
         A.n = (unsigned)a->n; A.row_end = (unsigned)row_end; A.col_begin = (unsigned)col_begin;
         A.dist = dist; A.ncomp = ncomp; A.ld = ld; A.thr = 0xFFFFFFFFu; A.ph = TilePhase{0, 0, nullptr};
-        return launch_pairsnp_count(shape_id, (unsigned)(ntl * (size_t)k), stream, A);
+        C.fn((unsigned)(ntl * (size_t)k), stream, A);
+        return TRACS_OK;
     };
     // Site classes, consensus form: the minority sites' distances from their lists (general_sparse.hip, general_fixup_kernel<MINOR>)
     auto minor_pass = [&]() -> int {
@@ -1005,7 +1024,7 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
         int rc = minor_pass();
         if (rc) return rc;
         pair_mark(2, stream);
-        if ((rc = count_pass(a->d_tiles, a->n_tiles))) return rc;
+        if ((rc = count_pass(nullptr, 0))) return rc;
         pair_mark(3, stream);
         TRACS_HIP_CHECK(hipGetLastError());
         return TRACS_OK;
@@ -1022,13 +1041,13 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
         int2 *live_tiles = nullptr;
         unsigned *n_live_d = nullptr;
         int rc;
-        if ((rc = tracs::workspace_get(48, a->n_tiles, reinterpret_cast<void **>(&live)))) return rc;
-        if ((rc = tracs::workspace_get(49, a->n_tiles * sizeof(int2), reinterpret_cast<void **>(&live_tiles)))) return rc;
+        if ((rc = tracs::workspace_get(48, a->tiles.n, reinterpret_cast<void **>(&live)))) return rc;
+        if ((rc = tracs::workspace_get(49, a->tiles.n * sizeof(int2), reinterpret_cast<void **>(&live_tiles)))) return rc;
         if ((rc = tracs::workspace_get(50, 64, reinterpret_cast<void **>(&n_live_d)))) return rc;
         TRACS_HIP_CHECK(hipMemsetAsync(n_live_d, 0, 4, stream));
-        if ((rc = launch(a->d_tiles, (unsigned)a->n_tiles, (int)a->n_tiles, prefix, prefix, 1, thr, TilePhase{1, 0, live}))) return rc;
-        hipLaunchKernelGGL(compact_live_kernel, dim3((unsigned)((a->n_tiles + 255) / 256)), dim3(256), 0, stream, a->d_tiles, live,
-                           (unsigned)a->n_tiles, live_tiles, n_live_d);
+        if ((rc = launch(a->tiles.d, (unsigned)a->tiles.n, (int)a->tiles.n, prefix, prefix, 1, thr, TilePhase{1, 0, live}))) return rc;
+        hipLaunchKernelGGL(compact_live_kernel, dim3((unsigned)((a->tiles.n + 255) / 256)), dim3(256), 0, stream, a->tiles.d, live,
+                           (unsigned)a->tiles.n, live_tiles, n_live_d);
         unsigned n_live = 0;
         TRACS_HIP_CHECK(hipMemcpyAsync(&n_live, n_live_d, 4, hipMemcpyDeviceToHost, stream));
         TRACS_HIP_CHECK(hipStreamSynchronize(stream));
@@ -1055,13 +1074,13 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
         hipLaunchKernelGGL(init_cells_kernel, grid, dim3(256), 0, stream, dist, ncomp, ld, (unsigned)a->n,
                            (unsigned)row_begin, (unsigned)row_end, (unsigned)col_begin, (cons || mfma) ? 0u : (unsigned)a->L);
     }
-    int rc = launch(a->d_tiles, (unsigned)(a->n_tiles * (size_t)ksplit), (int)a->n_tiles, groups, gps, ksplit, thr, TilePhase{0, 0, nullptr});
+    int rc = launch(a->tiles.d, (unsigned)(a->tiles.n * (size_t)ksplit), (int)a->tiles.n, groups, gps, ksplit, thr, TilePhase{0, 0, nullptr});
     if (rc) return rc;
     pair_mark(1, stream);
     if (mfma_general && (rc = general_sparse_fixup(a, row_begin, row_end, col_begin, dist, ncomp, ld, stream))) return rc;
     if ((rc = minor_pass())) return rc;
     pair_mark(2, stream);
-    if ((rc = count_pass(a->d_tiles, a->n_tiles))) return rc;
+    if ((rc = count_pass(nullptr, 0))) return rc;
     pair_mark(3, stream);
     TRACS_HIP_CHECK(hipGetLastError());
     return TRACS_OK;

@@ -53,7 +53,6 @@ struct MfmaShape {
     int nbr, nbc;              // 32 x 32 blocks per wave: the workgroup (2 x 2 waves) owns a (64 nbr) x (64 nbc) tile
     int ti, tj;
     int gc_cons, gc_gen;       // groups per LDS stage, consensus / general encoding (0: shape not built for it)
-    int gc_cnt;                // groups per LDS stage of the counting form (site classes: invariant sites, one plane)
     int wg_per_cu;
 };
 // The shapes compiled into the library; one default per encoding.  TRACS_MFMA_TILE=<name> selects another for both (diagnostics).
@@ -62,8 +61,16 @@ const MfmaShape &mfma_shape(int idx);
 int mfma_shape_current(bool general);
 // general = false: consensus encoding (operands x, y, z, v);  true: general encoding (one-hot A, C, G, T + N).
 int launch_pairsnp_mfma(int shape, bool general, unsigned nwg, hipStream_t stream, const MfmaArgs &a);
-// the counting form: a.P = one plane per group ("is a base here"), ncomp[i][j] += sum v_i v_j over groups [g_base.., a.groups)
-int launch_pairsnp_count(int shape, unsigned nwg, hipStream_t stream, const MfmaArgs &a);
+// The counting form (site classes): a.P = one plane per group ("is a base here"), ncomp[i][j] += sum v_i v_j over the groups of
+// the launch (+ a.L once per cell).  Its own workgroup tiles: one accumulator set per wave leaves room for more waves per CU, and
+// the pass is the memory-hungrier per matrix instruction, so larger workgroup tiles pay.
+struct CountShape {
+    const char *name;
+    int ti, tj, gc, wg_per_cu;
+    void (*fn)(unsigned nwg, hipStream_t stream, const MfmaArgs &a);
+};
+CountShape count_shape_current();               // the default (TRACS_COUNT_TILE=<name> selects another: diagnostics)
+CountShape count_shape_like(int ti, int tj);    // the shape with this workgroup tile (fn == nullptr when there is none)
 
 // ---- site classes (site_classes.hip) --------------------------------------------------------------------------
 int site_classes_decide(tracs_alignment *a, bool consensus, hipStream_t stream);

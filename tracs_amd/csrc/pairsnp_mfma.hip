@@ -56,7 +56,7 @@ __device__ __forceinline__ mfma_v8i fp4_operand(const unsigned (&w)[4])
 // COUNT: the one-operand pass over the invariant sites of an alignment cut into site classes (site_classes.hip): a single
 // stored plane v ("this sample is a base here"), nn += sum v v' with the general form's residue-class operands, nothing else.
 template <bool GENERAL, int NBR, int NBC, int GC, int NWR = 2, int NWC = 2, bool COUNT = false>
-__global__ __launch_bounds__(NWR * NWC * 64, (NBR * NBC > 4 ? 1 : 2)) void pairsnp_mfma_kernel(const MfmaArgs A)
+__global__ __launch_bounds__(NWR * NWC * 64, (NBR * NBC > 4 ? 1 : COUNT ? 4 : 2)) void pairsnp_mfma_kernel(const MfmaArgs A)
 {
     // NP planes are staged per group, GP is the group's stride in the stored planes: the general form stages A, C, G, T only and
     // forms N = A & C & G & T in registers (3 VALU ops per word against a fifth of the staging traffic)
@@ -423,10 +423,9 @@ static void launch_one(unsigned nwg, hipStream_t stream, const MfmaArgs &a)
     hipLaunchKernelGGL((pairsnp_mfma_kernel<GENERAL, NBR, NBC, GC, NWR, NWC, COUNT>), dim3(nwg), dim3(NWR * NWC * 64), 0, stream, a);
 }
 
-constexpr int GC_COUNT = 4;                       // groups per stage of the counting form (two residue-class rounds per barrier)
-struct ShapeEntry { MfmaShape s; MfmaLaunchFn cons, gen, cnt; };
-#define TRACS_SHAPE_N(NAME, R, C, GCC, WPC) {{NAME, R, C, 64 * (R), 64 * (C), GCC, 2, GC_COUNT, WPC}, launch_one<false, R, C, GCC>, launch_one<true, R, C, 2>, launch_one<false, R, C, GC_COUNT, 2, 2, true>}
-#define TRACS_SHAPE_W(NAME, R, C, GCC, WR, WC, WPC) {{NAME, R, C, 32 * (R) * (WR), 32 * (C) * (WC), GCC, 2, GC_COUNT, WPC}, launch_one<false, R, C, GCC, WR, WC>, launch_one<true, R, C, 2, WR, WC>, launch_one<false, R, C, GC_COUNT, WR, WC, true>}
+struct ShapeEntry { MfmaShape s; MfmaLaunchFn cons, gen; };
+#define TRACS_SHAPE_N(NAME, R, C, GCC, WPC) {{NAME, R, C, 64 * (R), 64 * (C), GCC, 2, WPC}, launch_one<false, R, C, GCC>, launch_one<true, R, C, 2>}
+#define TRACS_SHAPE_W(NAME, R, C, GCC, WR, WC, WPC) {{NAME, R, C, 32 * (R) * (WR), 32 * (C) * (WC), GCC, 2, WPC}, launch_one<false, R, C, GCC, WR, WC>, launch_one<true, R, C, 2, WR, WC>}
 #define TRACS_SHAPE(R, C, GCC, WPC) TRACS_SHAPE_N(#R "x" #C, R, C, GCC, WPC)
 static const ShapeEntry kShapes[] = {
     TRACS_SHAPE(2, 2, 1, 2),                      // 0: 128 x 128 pairs per workgroup, four waves, two workgroups per CU -- consensus default
@@ -464,11 +463,33 @@ int launch_pairsnp_mfma(int shape, bool general, unsigned nwg, hipStream_t strea
     return TRACS_OK;
 }
 
-int launch_pairsnp_count(int shape, unsigned nwg, hipStream_t stream, const MfmaArgs &a)
+// ---- the counting form's workgroup tiles: wave tile 2 x 2 blocks (64 accumulator registers), NWR x NWC waves ------------
+constexpr int GC_COUNT = 4;                       // groups per stage (two residue-class rounds per barrier)
+#define TRACS_COUNT_SHAPE(NAME, R, C, WR, WC, WPC) {NAME, 32 * (R) * (WR), 32 * (C) * (WC), GC_COUNT, WPC, launch_one<false, R, C, GC_COUNT, WR, WC, true>}
+static const CountShape kCountShapes[] = {
+    TRACS_COUNT_SHAPE("4x4", 2, 2, 4, 4, 1),      // 256 x 256 pairs, sixteen waves
+    TRACS_COUNT_SHAPE("4x2", 2, 2, 4, 2, 2),      // 256 x 128, eight waves
+    TRACS_COUNT_SHAPE("2x2", 2, 2, 2, 2, 4),      // 128 x 128, four waves
+    TRACS_COUNT_SHAPE("3x2b", 3, 2, 2, 2, 2),     // 192 x 128 (the pair kernel's alternative tile: live tiles of a thresholded run)
+};
+#undef TRACS_COUNT_SHAPE
+
+CountShape count_shape_current()
 {
-    if (shape < 0 || shape >= mfma_shape_count() || !a.ncomp) { set_error("launch_pairsnp_count: bad argument"); return TRACS_E_ARG; }
-    kShapes[shape].cnt(nwg, stream, a);
-    return TRACS_OK;
+    static const int forced = [] {
+        if (const char *e = std::getenv("TRACS_COUNT_TILE"))
+            for (size_t i = 0; i < sizeof(kCountShapes) / sizeof(kCountShapes[0]); i++)
+                if (!std::strcmp(e, kCountShapes[i].name)) return (int)i;
+        return 0;
+    }();
+    return kCountShapes[forced];
+}
+
+CountShape count_shape_like(int ti, int tj)
+{
+    for (const CountShape &c : kCountShapes)
+        if (c.ti == ti && c.tj == tj) return c;
+    return CountShape{"none", ti, tj, GC_COUNT, 1, nullptr};
 }
 
 }  // namespace tracs
