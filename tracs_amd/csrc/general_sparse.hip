@@ -42,11 +42,83 @@ __device__ __forceinline__ void special_masks(unsigned A, unsigned C, unsigned G
 
 __device__ __forceinline__ unsigned word_of(const uint4 &v, int w) { return w == 0 ? v.x : w == 1 ? v.y : w == 2 ? v.z : v.w; }
 
+// What the list builders read.  A source hands out, per (group, sample): the N mask and the partial mask of each 32-site
+// word, the 4-bit code of a listed bit, and the list index of a site (its rank among the listed sites).
+//
+// GeneralSrc: the five planes of a general alignment; every site is listed under its own index.
+struct GeneralSrc {
+    const uint4 *P;
+    size_t n_pad;
+    struct Group { uint4 A, C, G, T, N; };
+    __device__ __forceinline__ Group load(size_t g, size_t s) const
+    {
+        const uint4 *base = P + (g * NPLANES) * n_pad + s;
+        return Group{base[0], base[n_pad], base[2 * n_pad], base[3 * n_pad], base[4 * n_pad]};
+    }
+    __device__ __forceinline__ void masks(const Group &q, int w, unsigned &nm, unsigned &pm) const
+    {
+        special_masks(word_of(q.A, w), word_of(q.C, w), word_of(q.G, w), word_of(q.T, w), word_of(q.N, w), nm, pm);
+    }
+    __device__ __forceinline__ unsigned code(const Group &q, int w, int b) const
+    {
+        return ((word_of(q.A, w) >> b) & 1u) | (((word_of(q.C, w) >> b) & 1u) << 1) | (((word_of(q.G, w) >> b) & 1u) << 2) |
+               (((word_of(q.T, w) >> b) & 1u) << 3);
+    }
+    __device__ __forceinline__ bool any_listed(size_t) const { return true; }
+    __device__ __forceinline__ unsigned listed(size_t, int) const { return 0xFFFFFFFFu; }
+    __device__ __forceinline__ size_t index(size_t g, int w, int b) const { return g * SITES_PER_GROUP + w * 32 + b; }
+};
+
+// MinorSrc: the minority sites of a consensus alignment (site_classes.hip), read in place from the three consensus planes:
+// only the sites of `minor_mask` are listed, under their rank (off[g] = listed sites before group g); a sample whose base
+// differs from the site's reference base counts as "partial" with the two-allele code {reference, own base}
+// (bases A = 0, C = 1, G = 2, T = 3 = X + 2 Y), a sample that is not a base as N (code 15).
+struct MinorSrc {
+    const uint4 *P;             // consensus planes X, Y, V
+    size_t n_pad;
+    const uint4 *minor_mask, *ref_x, *ref_y;
+    const unsigned *off;
+    struct Group { uint4 X, Y, V, M, RX, RY; };
+    __device__ __forceinline__ Group load(size_t g, size_t s) const
+    {
+        const uint4 *base = P + (g * 3) * n_pad + s;
+        return Group{base[0], base[n_pad], base[2 * n_pad], minor_mask[g], ref_x[g], ref_y[g]};
+    }
+    __device__ __forceinline__ void masks(const Group &q, int w, unsigned &nm, unsigned &pm) const
+    {
+        const unsigned x = word_of(q.X, w), y = word_of(q.Y, w), v = word_of(q.V, w), m = word_of(q.M, w);
+        nm = ~v & m;
+        pm = v & ((x ^ word_of(q.RX, w)) | (y ^ word_of(q.RY, w))) & m;
+    }
+    __device__ __forceinline__ unsigned code(const Group &q, int w, int b) const
+    {
+        if (!((word_of(q.V, w) >> b) & 1u)) return 15u;
+        const unsigned own = ((word_of(q.X, w) >> b) & 1u) | (((word_of(q.Y, w) >> b) & 1u) << 1);
+        const unsigned ref = ((word_of(q.RX, w) >> b) & 1u) | (((word_of(q.RY, w) >> b) & 1u) << 1);
+        return (1u << own) | (1u << ref);
+    }
+    __device__ __forceinline__ bool any_listed(size_t g) const
+    {
+        const uint4 m = minor_mask[g];
+        return (m.x | m.y | m.z | m.w) != 0u;
+    }
+    __device__ __forceinline__ unsigned listed(size_t g, int w) const { return word_of(minor_mask[g], w); }
+    __device__ __forceinline__ size_t index(size_t g, int w, int b) const
+    {
+        const uint4 m = minor_mask[g];
+        unsigned r = off[g];
+        if (w > 0) r += __popc(m.x);
+        if (w > 1) r += __popc(m.y);
+        if (w > 2) r += __popc(m.z);
+        return (size_t)r + __popc(word_of(m, w) & ((1u << b) - 1u));
+    }
+};
+
 // pass A / B over the planes, lanes over samples (coalesced), one thread = (sample, chunk of groups), walked in site order.
 // FILL = false: cnt[s * GS_CHUNKS + chunk] = special sites of the chunk, cn[s * GS_CHUNKS + chunk] = N sites of the chunk.
 // FILL = true : entries written from off[s * GS_CHUNKS + chunk] on.
-template <bool FILL>
-__global__ __launch_bounds__(256) void gs_sample_kernel(const uint4 *__restrict__ P, size_t n_pad, size_t n, size_t groups,
+template <bool FILL, class SRC>
+__global__ __launch_bounds__(256) void gs_sample_kernel(const SRC src, size_t n, size_t groups,
                                                         size_t gpc, unsigned *__restrict__ cnt, unsigned *__restrict__ cn,
                                                         const unsigned long long *__restrict__ off, unsigned *__restrict__ ent)
 {
@@ -57,20 +129,18 @@ __global__ __launch_bounds__(256) void gs_sample_kernel(const uint4 *__restrict_
     unsigned c_all = 0, c_n = 0;
     unsigned long long o = FILL ? off[s * GS_CHUNKS + chunk] : 0ull;
     for (size_t g = g0; g < g1; g++) {
-        const uint4 *base = P + (g * NPLANES) * n_pad + s;
-        const uint4 A = base[0], C = base[n_pad], G = base[2 * n_pad], T = base[3 * n_pad], N = base[4 * n_pad];
+        if (!src.any_listed(g)) continue;                     // wave-uniform
+        const typename SRC::Group q = src.load(g, s);
 #pragma unroll
         for (int w = 0; w < 4; w++) {
             unsigned nm, pm;
-            special_masks(word_of(A, w), word_of(C, w), word_of(G, w), word_of(T, w), word_of(N, w), nm, pm);
+            src.masks(q, w, nm, pm);
             if (!FILL) { c_all += __popc(nm | pm); c_n += __popc(nm); continue; }
             unsigned m = nm | pm;
             while (m) {
                 const int b = __ffs(m) - 1;
                 m &= m - 1;
-                const unsigned code = ((word_of(A, w) >> b) & 1u) | (((word_of(C, w) >> b) & 1u) << 1) | (((word_of(G, w) >> b) & 1u) << 2) |
-                                      (((word_of(T, w) >> b) & 1u) << 3);
-                ent[o++] = (unsigned)((g * SITES_PER_GROUP + w * 32 + b) << 4) | code;
+                ent[o++] = (unsigned)(src.index(g, w, b) << 4) | src.code(q, w, b);
             }
         }
     }
@@ -126,56 +196,54 @@ __global__ void gs_sample_totals_kernel(const unsigned *__restrict__ cnt, const 
 
 // pass C / D: one workgroup per 128-site group, threads over samples (coalesced).  FILL = false: per-site counts of partial
 // and N samples (+ the work estimate sum_s cP (cN + cP / 2)).  FILL = true: entries placed through LDS cursors.
-template <bool FILL>
-__global__ __launch_bounds__(256) void gs_site_kernel(const uint4 *__restrict__ P, size_t n_pad, size_t n, size_t L,
+// Per-site arrays (cntP, cntN, p_off, n_off) are indexed by the source's list index of the site.
+template <bool FILL, class SRC>
+__global__ __launch_bounds__(256) void gs_site_kernel(const SRC src, size_t n, size_t L,
                                                       unsigned *__restrict__ cntP, unsigned *__restrict__ cntN,
                                                       const unsigned long long *__restrict__ p_off, const unsigned long long *__restrict__ n_off,
                                                       unsigned *__restrict__ p_ent, unsigned *__restrict__ n_ent, double *__restrict__ est)
 {
     __shared__ unsigned cP[SITES_PER_GROUP], cN[SITES_PER_GROUP];
+    __shared__ unsigned long long bP[SITES_PER_GROUP], bN[SITES_PER_GROUP];     // FILL: first entry of every site's lists
     const size_t g = blockIdx.x;
-    const size_t site0 = g * SITES_PER_GROUP;
-    if (threadIdx.x < SITES_PER_GROUP) { cP[threadIdx.x] = 0; cN[threadIdx.x] = 0; }
-    __syncthreads();
-    const unsigned long long pb = FILL ? p_off[site0] : 0ull, nb = FILL ? n_off[site0] : 0ull;
-    if (FILL && threadIdx.x < SITES_PER_GROUP && site0 + threadIdx.x < L) {
-        cP[threadIdx.x] = (unsigned)(p_off[site0 + threadIdx.x] - pb);       // cursors relative to the group's first entry
-        cN[threadIdx.x] = (unsigned)(n_off[site0 + threadIdx.x] - nb);
+    if (!src.any_listed(g)) return;
+    const int tw = (threadIdx.x & 127) >> 5, tb = threadIdx.x & 31;
+    // this thread's site (threads 0..127): listed? under which index?
+    const bool mine = threadIdx.x < SITES_PER_GROUP && ((src.listed(g, tw) >> tb) & 1u);
+    const size_t my_index = mine ? src.index(g, tw, tb) : 0;
+    const bool valid = mine && my_index < L;
+    if (threadIdx.x < SITES_PER_GROUP) {
+        cP[threadIdx.x] = 0; cN[threadIdx.x] = 0;
+        if (FILL) { bP[threadIdx.x] = valid ? p_off[my_index] : 0ull; bN[threadIdx.x] = valid ? n_off[my_index] : 0ull; }
     }
-    if (FILL) __syncthreads();
+    __syncthreads();
     for (size_t s = threadIdx.x; s < n; s += blockDim.x) {
-        const uint4 *base = P + (g * NPLANES) * n_pad + s;
-        const uint4 A = base[0], C = base[n_pad], G = base[2 * n_pad], T = base[3 * n_pad], N = base[4 * n_pad];
+        const typename SRC::Group q = src.load(g, s);
 #pragma unroll
         for (int w = 0; w < 4; w++) {
             unsigned nm, pm;
-            special_masks(word_of(A, w), word_of(C, w), word_of(G, w), word_of(T, w), word_of(N, w), nm, pm);
+            src.masks(q, w, nm, pm);
             while (nm) {
                 const int b = __ffs(nm) - 1;
                 nm &= nm - 1;
                 const unsigned slot = atomicAdd(&cN[w * 32 + b], 1u);
-                if (FILL) n_ent[nb + slot] = (unsigned)s;
+                if (FILL) n_ent[bN[w * 32 + b] + slot] = (unsigned)s;
             }
             while (pm) {
                 const int b = __ffs(pm) - 1;
                 pm &= pm - 1;
                 const unsigned slot = atomicAdd(&cP[w * 32 + b], 1u);
-                if (FILL) {
-                    const unsigned code = ((word_of(A, w) >> b) & 1u) | (((word_of(C, w) >> b) & 1u) << 1) | (((word_of(G, w) >> b) & 1u) << 2) |
-                                          (((word_of(T, w) >> b) & 1u) << 3);
-                    p_ent[pb + slot] = ((unsigned)s << 4) | code;
-                }
+                if (FILL) p_ent[bP[w * 32 + b] + slot] = ((unsigned)s << 4) | src.code(q, w, b);
             }
         }
     }
     if (FILL) return;
     __syncthreads();
     if (threadIdx.x < SITES_PER_GROUP) {
-        const size_t site = site0 + threadIdx.x;
         double e = 0.0;
-        if (site < L) {
-            cntP[site] = cP[threadIdx.x];
-            cntN[site] = cN[threadIdx.x];
+        if (valid) {
+            cntP[my_index] = cP[threadIdx.x];
+            cntN[my_index] = cN[threadIdx.x];
             e = (double)cP[threadIdx.x] * ((double)cN[threadIdx.x] + 0.5 * (double)cP[threadIdx.x]);
         }
         for (int off = 32; off > 0; off >>= 1) e += __shfl_down(e, off, 64);
@@ -308,7 +376,8 @@ void minority_lists_free(tracs_alignment *a)
 
 // The lists of a 5-plane alignment (planes, n samples, L sites).  *out = nullptr when the alignment is outside what the path
 // supports (too long, too many entries, no memory) -- not an error.
-static int gs_build(const uint4 *planes, size_t n, size_t n_pad, size_t L, size_t groups, hipStream_t stream, GeneralSparse **out)
+template <class SRC>
+static int gs_build(const SRC src, size_t n, size_t L, size_t groups, hipStream_t stream, GeneralSparse **out)
 {
     *out = nullptr;
     if (L >= (1ull << 28) || n >= (1ull << 28) || L == 0) return TRACS_OK;        // entries hold site << 4 / sample << 4
@@ -335,10 +404,12 @@ static int gs_build(const uint4 *planes, size_t n, size_t n_pad, size_t L, size_
     GS_TRY(hipMemsetAsync(d_est, 0, 8, stream));
 
     const dim3 sgrid((unsigned)((n + 63) / 64), GS_CHUNKS / 4);
-    hipLaunchKernelGGL((gs_sample_kernel<false>), sgrid, dim3(256), 0, stream, planes, n_pad, n, groups, gpc, cnt, cn, nullptr, nullptr);
+    hipLaunchKernelGGL((gs_sample_kernel<false, SRC>), sgrid, dim3(256), 0, stream, src, n, groups, gpc, cnt, cn, nullptr, nullptr);
     hipLaunchKernelGGL(gs_scan_kernel, dim3(1), dim3(1024), 0, stream, cnt, nsc, off);
     hipLaunchKernelGGL(gs_sample_totals_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, stream, cnt, cn, n, g->c_n, g->c_p, off, g->s_off);
-    hipLaunchKernelGGL((gs_site_kernel<false>), dim3((unsigned)groups), dim3(256), 0, stream, planes, n_pad, n, L, cntP, cntN,
+    GS_TRY(hipMemsetAsync(cntP, 0, (L + 1) * 4, stream));
+    GS_TRY(hipMemsetAsync(cntN, 0, (L + 1) * 4, stream));
+    hipLaunchKernelGGL((gs_site_kernel<false, SRC>), dim3((unsigned)groups), dim3(256), 0, stream, src, n, L, cntP, cntN,
                        nullptr, nullptr, nullptr, nullptr, d_est);
     hipLaunchKernelGGL(gs_scan_kernel, dim3(1), dim3(1024), 0, stream, cntP, L, g->p_off);
     hipLaunchKernelGGL(gs_scan_kernel, dim3(1), dim3(1024), 0, stream, cntN, L, g->n_off);
@@ -355,8 +426,8 @@ static int gs_build(const uint4 *planes, size_t n, size_t n_pad, size_t L, size_
     GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->s_ent), std::max<size_t>(tot_s, 1) * 4));
     GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->p_ent), std::max<size_t>(tot_p, 1) * 4));
     GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->n_ent), std::max<size_t>(tot_n, 1) * 4));
-    hipLaunchKernelGGL((gs_sample_kernel<true>), sgrid, dim3(256), 0, stream, planes, n_pad, n, groups, gpc, nullptr, nullptr, off, g->s_ent);
-    hipLaunchKernelGGL((gs_site_kernel<true>), dim3((unsigned)groups), dim3(256), 0, stream, planes, n_pad, n, L, nullptr, nullptr,
+    hipLaunchKernelGGL((gs_sample_kernel<true, SRC>), sgrid, dim3(256), 0, stream, src, n, groups, gpc, nullptr, nullptr, off, g->s_ent);
+    hipLaunchKernelGGL((gs_site_kernel<true, SRC>), dim3((unsigned)groups), dim3(256), 0, stream, src, n, L, nullptr, nullptr,
                        g->p_off, g->n_off, g->p_ent, g->n_ent, nullptr);
     GS_TRY(hipGetLastError());
     GS_TRY(hipStreamSynchronize(stream));
@@ -374,7 +445,7 @@ int general_sparse_get(tracs_alignment *a, hipStream_t stream, int *ok, double *
     if (a->sparse_state == 1) { *ok = 1; *est_updates = a->sparse->est_updates; return TRACS_OK; }
     a->sparse_state = -1;
     // the variable sites only when site classes are in use
-    const int rc = gs_build(pair_planes(a, false), a->n, a->n_pad, pair_L(a), pair_groups(a), stream, &a->sparse);
+    const int rc = gs_build(GeneralSrc{pair_planes(a, false), a->n_pad}, a->n, pair_L(a), pair_groups(a), stream, &a->sparse);
     if (rc || !a->sparse) return rc;
     a->sparse_state = 1;
     *ok = 1;
@@ -382,11 +453,12 @@ int general_sparse_get(tracs_alignment *a, hipStream_t stream, int *ok, double *
     return TRACS_OK;
 }
 
-// site_classes.hip: the lists of the minority sites, from their 5-plane image (minority samples carry {reference, own base})
-int minority_lists_build(tracs_alignment *a, const uint4 *planes, size_t sites, hipStream_t stream, int *ok)
+// site_classes.hip: the lists of the `sites` minority sites of a consensus alignment, read in place from its planes
+int minority_lists_build(tracs_alignment *a, const uint4 *cplanes, const uint4 *minor_mask, const uint4 *ref_x, const uint4 *ref_y,
+                         const unsigned *off_minor, size_t sites, hipStream_t stream, int *ok)
 {
     minority_lists_free(a);
-    const int rc = gs_build(planes, a->n, a->n_pad, sites, groups_for(sites), stream, &a->minor);
+    const int rc = gs_build(MinorSrc{cplanes, a->n_pad, minor_mask, ref_x, ref_y, off_minor}, a->n, sites, a->groups, stream, &a->minor);
     *ok = a->minor != nullptr;
     return rc;
 }

@@ -25,6 +25,8 @@
 #include "pairsnp_kernels.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 
 namespace tracs {
@@ -283,53 +285,6 @@ __global__ __launch_bounds__(256) void compact_sites_kernel(const uint4 *__restr
             dst[((size_t)G * NPO + p) * n_pad + s] = make_uint4(out[p][0], out[p][1], out[p][2], out[p][3]);
 }
 
-// The minority sites as a 5-plane (A, C, G, T, N) image for the list builder of general_sparse.hip: N stays N, a sample whose
-// base is the site's reference base carries that base, a minority sample carries {reference base, own base}.
-// Same thread geometry as compact_sites_kernel; bases are coded A = 00, C = 01, G = 10, T = 11 in (Y, X).
-__global__ __launch_bounds__(256) void minority_image_kernel(const uint4 *__restrict__ src, const uint4 *__restrict__ ref_x,
-                                                             const uint4 *__restrict__ ref_y, const unsigned *__restrict__ list, unsigned count,
-                                                             uint4 *__restrict__ dst, size_t n_pad, unsigned n, unsigned groups_dst)
-{
-    const unsigned s = blockIdx.y * 64 + (threadIdx.x & 63);
-    const unsigned G = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (G >= groups_dst) return;
-    const unsigned *__restrict__ srcw = reinterpret_cast<const unsigned *>(src);
-    const unsigned *__restrict__ rxw = reinterpret_cast<const unsigned *>(ref_x), *__restrict__ ryw = reinterpret_cast<const unsigned *>(ref_y);
-    unsigned out[NPLANES][4];
-    unsigned cx = 0, cy = 0, cv = 0, crx = 0, cry = 0, cw = 0xFFFFFFFFu;
-    const unsigned t0 = G * SITES_PER_GROUP;
-#pragma unroll
-    for (int ow = 0; ow < 4; ow++) {
-        unsigned acc[NPLANES] = {0, 0, 0, 0, 0};
-        const unsigned tb = t0 + ow * 32;
-        const unsigned kn = tb >= count ? 0u : min(32u, count - tb);
-        for (unsigned k = 0; k < kn; k++) {
-            const unsigned site = __builtin_amdgcn_readfirstlane(list[tb + k]);
-            const unsigned w = site >> 5;
-            if (w != cw) {                                      // wave-uniform
-                cw = w;
-                const size_t base = ((size_t)(site >> 7) * 3 * n_pad + s) * 4 + (w & 3u);
-                cx = srcw[base]; cy = srcw[base + n_pad * 4]; cv = srcw[base + n_pad * 8];
-                crx = rxw[w]; cry = ryw[w];
-            }
-            const unsigned b = site & 31u;
-            const unsigned v = (cv >> b) & 1u;
-            const unsigned own = 1u << (((cx >> b) & 1u) | (((cy >> b) & 1u) << 1));
-            const unsigned ref = 1u << (((crx >> b) & 1u) | (((cry >> b) & 1u) << 1));
-            const unsigned m = v ? (own | ref) : 15u;
-#pragma unroll
-            for (int p = 0; p < 4; p++) acc[p] |= ((m >> p) & 1u) << k;
-            acc[4] |= (v ^ 1u) << k;
-        }
-#pragma unroll
-        for (int p = 0; p < NPLANES; p++) out[p][ow] = acc[p];
-    }
-    if (s < n)
-#pragma unroll
-        for (int p = 0; p < NPLANES; p++)
-            dst[((size_t)G * NPLANES + p) * n_pad + s] = make_uint4(out[p][0], out[p][1], out[p][2], out[p][3]);
-}
-
 void site_classes_free(tracs_alignment *a)
 {
     if (a->vplanes) (void)hipFree(a->vplanes);
@@ -356,15 +311,27 @@ static int decide(tracs_alignment *a, bool consensus, bool allow_minor, hipStrea
     if (force == 0 || a->L == 0 || a->L >= (1ull << 32) || a->n < 2) return TRACS_OK;
     const uint4 *src = consensus ? a->cplanes : a->planes;
     if (!src) return TRACS_OK;
+    // TRACS_CLASSES_TRACE=1: wall time of every stage on stderr (synchronises after each: diagnostics only)
+    static const bool trace = std::getenv("TRACS_CLASSES_TRACE") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto stage = [&](const char *what) {
+        if (!trace) return;
+        (void)hipStreamSynchronize(stream);
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[site classes] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
+    if (trace) (void)hipStreamSynchronize(stream);
+    t_last = std::chrono::steady_clock::now();
     const size_t groups = a->groups;
     // sample blocks in grid.y of the re-pack kernels (<= 65535 x 64 samples per launch; beyond that the classes are not used)
     const unsigned sblocks = (unsigned)(a->n_pad / 64);
     if (sblocks > 65535u) return TRACS_OK;
-    uint4 *masks = nullptr, *image = nullptr;
+    uint4 *masks = nullptr;
     unsigned *offs = nullptr, *lists = nullptr;
     unsigned long long *totals = nullptr;
     auto cleanup = [&]() {
-        void *p[] = {masks, image, offs, lists, totals};
+        void *p[] = {masks, offs, lists, totals};
         for (void *q : p) if (q) (void)hipFree(q);
     };
     auto soft_fail = [&]() { cleanup(); (void)hipGetLastError(); site_classes_free(a); a->classes_state = -1; return TRACS_OK; };
@@ -387,6 +354,7 @@ static int decide(tracs_alignment *a, bool consensus, bool allow_minor, hipStrea
         hipLaunchKernelGGL((classify_sites_kernel<false>), dim3((unsigned)groups), dim3(256), 0, stream, src, a->n_pad, (unsigned)a->n,
                            dense_mask, count_mask);
     }
+    stage("classify");
     hipLaunchKernelGGL(class_offsets_kernel, dim3(1), dim3(1024), 0, stream, dense_mask, groups, off_dense, totals + 0);
     hipLaunchKernelGGL(class_offsets_kernel, dim3(1), dim3(1024), 0, stream, count_mask, groups, off_count, totals + 1);
     hipLaunchKernelGGL(class_offsets_kernel, dim3(1), dim3(1024), 0, stream, minor_mask, groups, off_minor, totals + 2);
@@ -398,6 +366,7 @@ static int decide(tracs_alignment *a, bool consensus, bool allow_minor, hipStrea
         set_error("site_classes_decide: classification failed");
         return TRACS_E_HIP;
     }
+    stage("offsets");
     const size_t L_dense = (size_t)tot[0], L_count = (size_t)tot[1], L_minor = (size_t)tot[2], L_full = (size_t)tot[3];
     // matrix instructions per pair: planes_full per site now; planes_full per dense site + one per counted site with classes
     const double planes_full = consensus ? 4.0 : 5.0;
@@ -405,17 +374,17 @@ static int decide(tracs_alignment *a, bool consensus, bool allow_minor, hipStrea
     if ((force != 1 && cost >= 0.92) || (!consensus && L_dense == 0)) { cleanup(); return TRACS_OK; }
 
     const int npv = consensus ? 3 : NPLANES;
-    const size_t gv = groups_for(L_dense), gi = groups_for(L_count), gm = groups_for(L_minor);
+    const size_t gv = groups_for(L_dense), gi = groups_for(L_count), gm = L_minor;
     const size_t vbytes = class_plane_bytes(a, gv, npv, PAD_GROUPS), ibytes = class_plane_bytes(a, gi, 1, COUNT_PAD_GROUPS);
-    if (hipMalloc(reinterpret_cast<void **>(&lists), (L_dense + L_count + L_minor + 1) * sizeof(unsigned)) != hipSuccess) return soft_fail();
+    if (hipMalloc(reinterpret_cast<void **>(&lists), (L_dense + L_count + 1) * sizeof(unsigned)) != hipSuccess) return soft_fail();
     if (hipMalloc(reinterpret_cast<void **>(&a->vplanes), vbytes) != hipSuccess) { a->vplanes = nullptr; return soft_fail(); }
     if (hipMalloc(reinterpret_cast<void **>(&a->iplanes), ibytes) != hipSuccess) { a->iplanes = nullptr; return soft_fail(); }
-    unsigned *list_dense = lists, *list_count = lists + L_dense, *list_minor = lists + L_dense + L_count;
+    unsigned *list_dense = lists, *list_count = lists + L_dense;
     bool ok = hipMemsetAsync(a->vplanes, 0, vbytes, stream) == hipSuccess && hipMemsetAsync(a->iplanes, 0, ibytes, stream) == hipSuccess;
     const dim3 lgrid((unsigned)((groups + 255) / 256));
     hipLaunchKernelGGL(class_list_kernel, lgrid, dim3(256), 0, stream, dense_mask, off_dense, groups, list_dense);
     hipLaunchKernelGGL(class_list_kernel, lgrid, dim3(256), 0, stream, count_mask, off_count, groups, list_count);
-    hipLaunchKernelGGL(class_list_kernel, lgrid, dim3(256), 0, stream, minor_mask, off_minor, groups, list_minor);
+    stage("alloc + site lists");
     if (gv) {
         const dim3 grid((unsigned)((gv + 3) / 4), sblocks);
         if (consensus)
@@ -425,22 +394,19 @@ static int decide(tracs_alignment *a, bool consensus, bool allow_minor, hipStrea
             hipLaunchKernelGGL((compact_sites_kernel<NPLANES>), grid, dim3(256), 0, stream, src, NPLANES, 0, false, list_dense, (unsigned)L_dense,
                                a->vplanes, a->n_pad, (unsigned)a->n, (unsigned)gv);
     }
+    stage("re-pack dense");
     if (gi) {
         const dim3 grid((unsigned)((gi + 3) / 4), sblocks);
         // consensus: plane 2 = V.  general: the complement of plane 4 = N (an invariant site holds bases and N only)
         hipLaunchKernelGGL((compact_sites_kernel<1>), grid, dim3(256), 0, stream, src, consensus ? 3 : NPLANES, consensus ? 2 : 4, !consensus,
                            list_count, (unsigned)L_count, a->iplanes, a->n_pad, (unsigned)a->n, (unsigned)gi);
     }
+    stage("re-pack counted");
     if (gm) {
-        // the lists of the minority sites, through a temporary 5-plane image of those sites
-        const size_t mbytes = class_plane_bytes(a, gm, NPLANES, 0);
-        if (hipMalloc(reinterpret_cast<void **>(&image), mbytes) != hipSuccess) { image = nullptr; return soft_fail(); }
-        ok = ok && hipMemsetAsync(image, 0, mbytes, stream) == hipSuccess;
-        const dim3 grid((unsigned)((gm + 3) / 4), sblocks);
-        hipLaunchKernelGGL(minority_image_kernel, grid, dim3(256), 0, stream, src, ref_x, ref_y, list_minor, (unsigned)L_minor, image, a->n_pad,
-                           (unsigned)a->n, (unsigned)gm);
+        // the lists of the minority sites, read in place from the consensus planes (general_sparse.hip, MinorSrc)
         int built = 0;
-        const int rc = minority_lists_build(a, image, L_minor, stream, &built);
+        const int rc = minority_lists_build(a, src, minor_mask, ref_x, ref_y, off_minor, L_minor, stream, &built);
+        stage("minority lists");
         if (rc) { cleanup(); site_classes_free(a); a->classes_state = -1; return rc; }
         if (!built) {                                          // lists too large / no memory: the same classes without them
             soft_fail();
