@@ -78,7 +78,7 @@ static inline const uint4 *pair_planes(const tracs_alignment *a, bool consensus)
 }
 static inline size_t pair_L(const tracs_alignment *a) { return a->classes_state == 1 ? a->L_var : a->L; }
 static inline size_t pair_groups(const tracs_alignment *a) { return a->classes_state == 1 ? a->groups_var : a->groups; }
-constexpr int COUNT_PAD_GROUPS = 3;  // zero groups behind `iplanes`: the counting pass stages four groups at a time
+constexpr int COUNT_PAD_GROUPS = 7;  // zero groups behind `iplanes`: the counting pass stages four (sweeps: up to eight) groups at a time
 
 // Grow-only per-device scratch buffers (slot ids are small integers owned by each .hip file), shared by every entry point.
 // Entry points that use them, or the cached state of a tracs_alignment, hold a DeviceCall for their whole body:

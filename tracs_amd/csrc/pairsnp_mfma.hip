@@ -465,15 +465,24 @@ int launch_pairsnp_mfma(int shape, bool general, unsigned nwg, hipStream_t strea
 
 // ---- the counting form's workgroup tiles: wave tile 2 x 2 blocks (64 accumulator registers), NWR x NWC waves ------------
 constexpr int GC_COUNT = 4;                       // groups per stage (two residue-class rounds per barrier)
-#define TRACS_COUNT_SHAPE(NAME, R, C, WR, WC, WPC) {NAME, 32 * (R) * (WR), 32 * (C) * (WC), GC_COUNT, WPC, launch_one<false, R, C, GC_COUNT, WR, WC, true>}
+#define TRACS_COUNT_SHAPE_G(NAME, R, C, WR, WC, WPC, G) {NAME, 32 * (R) * (WR), 32 * (C) * (WC), G, WPC, launch_one<false, R, C, G, WR, WC, true>}
+#define TRACS_COUNT_SHAPE(NAME, R, C, WR, WC, WPC) TRACS_COUNT_SHAPE_G(NAME, R, C, WR, WC, WPC, GC_COUNT)
 static const CountShape kCountShapes[] = {
     // measured at 10 000 x 5 Mbp (profiles/r02/count_tile_sweep.txt): 4x2 73.7 ms, 2x2 75.8, 4x4 77.4 (sixteen-wave barriers)
     TRACS_COUNT_SHAPE("4x2", 2, 2, 4, 2, 2),      // 256 x 128 pairs, eight waves, two workgroups per CU -- default
     TRACS_COUNT_SHAPE("2x2", 2, 2, 2, 2, 4),      // 128 x 128, four waves
     TRACS_COUNT_SHAPE("4x4", 2, 2, 4, 4, 1),      // 256 x 256, sixteen waves
     TRACS_COUNT_SHAPE("3x2b", 3, 2, 2, 2, 2),     // 192 x 128 (the pair kernel's alternative tile: live tiles of a thresholded run)
+#ifdef TRACS_MFMA_SWEEP
+    TRACS_COUNT_SHAPE_G("4x2g2", 2, 2, 4, 2, 2, 2),
+    TRACS_COUNT_SHAPE_G("4x2g8", 2, 2, 4, 2, 1, 8),
+    TRACS_COUNT_SHAPE_G("2x2g2", 2, 2, 2, 2, 4, 2),
+    TRACS_COUNT_SHAPE_G("2x2g8", 2, 2, 2, 2, 2, 8),
+    TRACS_COUNT_SHAPE("2x4", 2, 2, 2, 4, 2),      // 128 x 256
+#endif
 };
 #undef TRACS_COUNT_SHAPE
+#undef TRACS_COUNT_SHAPE_G
 
 CountShape count_shape_current()
 {
