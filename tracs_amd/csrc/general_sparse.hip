@@ -289,8 +289,24 @@ __global__ __launch_bounds__(1024) void general_fixup_kernel(const unsigned long
             my_pa = p_off[site]; my_pz = p_off[site + 1];
             if (my_code != 15u) { my_na = n_off[site]; my_nz = n_off[site + 1]; }
         }
-        const int cnt = (int)min((unsigned long long)16, e1 - base);
-        // The 16 sites' lists are walked one site after the other, 64 list entries per memory round trip (each lane requests its
+        // Short lists stay in their lane: where i is N and at most four samples are partial there (the usual case on the minority
+        // lists: one or two), the lane applies its site's entries itself -- one round trip for the 16 sites together.
+        bool coop = e < e1;
+        if (coop && my_code == 15u && my_pz - my_pa <= 4) {
+            unsigned v[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) v[m] = my_pa + m < my_pz ? p_ent[my_pa + m] : 0xFFFFFFFFu;
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+                if (v[m] != 0xFFFFFFFFu) {
+                    const unsigned j = v[m] >> 4;
+                    const int add = MINOR ? -1 : __popc(v[m] & 15u) - 1;
+                    if ((MINOR || add > 0) && j > i && j >= c0 && j < c1) atomicAdd(&row[j - c0], (unsigned)add);
+                }
+            coop = false;
+        }
+        unsigned todo = (unsigned)(__ballot(coop) >> (threadIdx.x & 48)) & 0xFFFFu;     // this quarter wave's sites still to walk
+        // The other sites' lists are walked one site after the other, 64 list entries per memory round trip (each lane requests its
         // four entries before it touches the first) -- and the first round trip of site k + 1 (the head of its partial list, and
         // of its N list when i is partial there) is already in flight while site k's entries are applied.
         struct Head { unsigned p[4], n[4]; };
@@ -305,9 +321,12 @@ __global__ __launch_bounds__(1024) void general_fixup_kernel(const unsigned long
             }
         };
         Head cur, nxt;
-        fetch_head(0, cur);
-        for (int k = 0; k < cnt; k++) {
-            if (k + 1 < cnt) fetch_head(k + 1, nxt);
+        int k = todo ? __ffs(todo) - 1 : -1;
+        if (k >= 0) fetch_head(k, cur);
+        while (k >= 0) {
+            todo &= todo - 1;
+            const int kn = todo ? __ffs(todo) - 1 : -1;
+            if (kn >= 0) fetch_head(kn, nxt);
             const unsigned code = __shfl(my_code, k, 16);
             const bool i_is_n = code == 15u;
             const unsigned kk = (unsigned)__popc(code) - 1u;           // |M_i| - 1 when i is partial here
@@ -338,6 +357,7 @@ __global__ __launch_bounds__(1024) void general_fixup_kernel(const unsigned long
                     apply_n(v0); if (h1) apply_n(v1); if (h2) apply_n(v2); if (h3) apply_n(v3);
                 }
             cur = nxt;
+            k = kn;
         }
     }
     __syncthreads();
