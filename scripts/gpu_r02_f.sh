@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 2, site classes: full GPU suite, bench lines, rocprofv3 kernel trace of the same command, PMC passes
 cd "$GRAFT_REPO_ROOT" || exit 1
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r02s
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r02final
 mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 2400 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pytest rc $?" >> $OUT/pytest.log
@@ -10,6 +10,8 @@ timeout 1500 python bench.py --steps 3 --warmup 1 > $OUT/bench_c3.log 2>&1; tail
 TRACS_SITE_CLASSES=0 timeout 900 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras 2>&1 | tail -1 > $OUT/bench_c3_whole.json
 TRACS_MINORITY=0 timeout 900 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras 2>&1 | tail -1 > $OUT/bench_c3_nolists.json
 timeout 600 python bench.py --samples 1000 --sites 1000000 --steps 10 --warmup 2 --no-extras 2>&1 | tail -1 > $OUT/bench_c2.json
+timeout 900 python scripts/bench_distance_cli.py > $OUT/bench_distance_cli.json 2> $OUT/bench_distance_cli.log
+TRACS_CLASSES_TRACE=1 timeout 600 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras 2>&1 | grep "site classes" > $OUT/classes_trace.txt
 cd /tmp
 timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $OUT/trace.log 2>&1
 rm -f $OUT/trace/trace_kernel_trace.csv
