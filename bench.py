@@ -16,14 +16,19 @@ Strong scaling: the problem is fixed, `value` = total pairs / time; every step's
 before the clock stops.
 
 Prints ONE JSON line (rank 0):
-  roofline          the dominant kernel of the timed region (pairsnp_mfma_kernel, consensus operands) from HIP events on
-                    the launch stream: exact fp4 Gram products on the matrix cores, bound "mfma"; HBM view in roofline.hbm
+  roofline          the dominant kernel of the timed region from HIP events on the launch stream (recorded by the library around
+                    each kernel of a dense call): exact fp4 Gram products on the matrix cores, bound "mfma".  With site classes in
+                    use (the default on this workload, csrc/site_classes.hip) that is the one-operand counting pass over the
+                    counted sites; the four-operand pair kernel over the dense sites (`other_matrix_core_kernel`), the minority
+                    lists' kernel (`minority_lists_ms`) and the class sizes (`site_classes`) are reported beside it.  With
+                    TRACS_SITE_CLASSES=0 it is the pair kernel over every site; HBM view in roofline.hbm
   roofline_general  the same pass over the SAME alignment with 0.5 % partial IUPAC codes added (SURVEY.md 8d's C4 mix):
                     one-hot matrix-core kernel + sparse partial-code correction (N = 1 only; not part of `value`)
   dm_frontend       counts -> posterior filter -> 4-bit codes -> packed planes for a batch of samples (SURVEY.md 8d C3's
                     "counts->posterior->code fused front-end"), timed separately (N = 1 only)
   cpu_baseline      the oracle (CPU port of the reference algorithm) on the host cores on a bounded sample of the same
-                    workload, pair loop and trans_dist legs reported separately (rank 0, N = 1 only)
+                    workload, pair loop and trans_dist legs reported separately, the trans_dist leg also through the reference's
+                    own source compiled in place (oracle/_ref) (rank 0, N = 1 only)
 """
 import argparse
 import json

@@ -127,8 +127,9 @@ def test_repack_redecides(hiplib, oracle):
     aln.close()
 
 
-def test_every_class_at_once(hiplib, oracle):
-    """Lineage-structured columns (a fifth of the samples differ: dense), private substitutions (minority), columns without
+@pytest.mark.parametrize("p_partial", [0.0, 0.0004])
+def test_every_class_at_once(hiplib, oracle, p_partial):
+    """(consensus / general encoding) Lineage-structured columns (a fifth of the samples differ: dense), private substitutions (minority), columns without
     any N (full), columns of N (empty), N elsewhere (counted) -- in one alignment, 1 000 samples so that the list budget
     (k (cN + k) <= n^2 / 8000) separates one- and two-sample sites from the lineage sites."""
     from tracs_amd import device as dev
@@ -147,6 +148,19 @@ def test_every_class_at_once(hiplib, oracle):
         if len(bases):
             alt = BASES[(int(np.where(BASES == bases[0])[0][0]) + 1) % 4]
             col[members & (col != ord("N"))] = alt
+    if p_partial:
+        part = rng.random((n, L)) < p_partial
+        seqs[part] = PARTIAL[rng.integers(0, len(PARTIAL), size=int(part.sum()))]
     cls = _check(dev, oracle, seqs)
     dense, counted, minority, full = cls
-    assert dense >= 30 and minority > 100 and full > 1000 and counted > 1000 and dense + counted + full < L
+    assert dense >= 30 and minority > 100 and full > (1000 if not p_partial else 100) and counted > 1000 and dense + counted + full < L
+
+
+def test_general_alignment_without_dense_sites(hiplib, oracle):
+    """A general alignment (partial IUPAC codes) whose variable sites all fit the lists: no site is left for the pair kernel,
+    the lists and the counting pass produce everything."""
+    from tracs_amd import device as dev
+    n, L = 1200, 12000
+    seqs = _structured(n, L, seed=31, mu=5e-5, p_n=0.01, p_empty=0.0, p_partial=3e-5)
+    cls = _check(dev, oracle, seqs)
+    assert cls[0] == 0 and cls[2] > 0

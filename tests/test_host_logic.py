@@ -208,3 +208,30 @@ def test_site_class_identity():
                 both = ~is_n[i] & ~is_n[j]
                 assert int(miss.sum()) == int(miss[var].sum())
                 assert int(both.sum()) == int(both[var].sum()) + int(both[inv].sum())
+
+
+def test_minority_site_identity():
+    """The identity behind the minority lists (csrc/general_sparse.hip, general_fixup_kernel<MINOR>): at a site where every sample
+    is N, carries exactly the reference base r, or is LISTED with allele mask M and w = [r not in M], the site's contribution to
+    d(i, j) is  w_i [j carries r] + w_j [i carries r] + [M_i n M_j = {}] [both listed]  -- summed over sites in the kernel's form
+        sum_{S_i} w_i + sum_{S_j} w_j - sum_{S_i} w_i [j is N] - sum_{S_j} w_j [i is N] + sum_{S_i n S_j} ([M_i n M_j = {}] - w_i - w_j)
+    -- checked against the definition (src/pairsnp.hpp:398-403) on random code matrices with few listed samples per site."""
+    rng = np.random.default_rng(23)
+    n, L = 14, 3000
+    pc = np.array([bin(x).count("1") for x in range(16)])
+    ref = rng.integers(0, 4, size=L)
+    codes = np.tile(1 << ref, (n, 1))
+    listed = rng.random((n, L)) < 0.03
+    codes[listed] = rng.integers(1, 15, size=int(listed.sum()))           # another base or a partial code (may equal {r}: not listed then)
+    codes[rng.random((n, L)) < 0.05] = 15
+    is_n = codes == 15
+    is_listed = ~is_n & (codes != (1 << ref)[None, :])
+    w = (((codes >> ref[None, :]) & 1) == 0) & is_listed
+    for i in range(n):
+        for j in range(i + 1, n):
+            a, b = codes[i], codes[j]
+            d_true = int((pc[a & b] == 0).sum())
+            both = is_listed[i] & is_listed[j]
+            form = int(w[i].sum() + w[j].sum() - (w[i] & is_n[j]).sum() - (w[j] & is_n[i]).sum()
+                       + ((pc[a & b] == 0).astype(int) - w[i].astype(int) - w[j].astype(int))[both].sum())
+            assert form == d_true

@@ -10,8 +10,9 @@
 // so  d = L - G + 3 NN + T1 + T2  and  nn = L - c_i - c_j + NN  (c_i = number of N sites of sample i; tests/test_host_logic.py
 // checks the identity on random code matrices).  T1 and T2 only involve sites where a sample carries a partial code -- a
 // fraction of a percent of a real alignment -- so they are computed from sparse lists:
-//     per sample  : its sites that are N or partial, in site order            (s_off / s_ent: site << 4 | code, 15 = N)
-//     per site    : the samples that are partial there, with their code       (p_off / p_ent: sample << 4 | mask)
+//     per sample  : its sites that are N or partial, in site order            (s_off / s_ent: site << 5 | w << 4 | code, 15 = N)
+//     per site    : the samples that are partial there, with their code       (p_off / p_ent: sample << 5 | w << 4 | mask)
+//                   (w: only used by the minority lists of site_classes.hip, see general_fixup_kernel<MINOR>)
 //                   the samples that are N there                              (n_off / n_ent: sample)
 // general_fixup_kernel gives row i of the pair matrix to one workgroup: the row's correction is accumulated in LDS with
 // ds_add (for every special site of sample i, walk the site's lists), then added to dist, together with nn's c_i, c_j terms.
@@ -26,9 +27,10 @@ namespace tracs {
 struct GeneralSparse {
     unsigned long long *s_off = nullptr, *p_off = nullptr, *n_off = nullptr;
     unsigned *s_ent = nullptr, *p_ent = nullptr, *n_ent = nullptr;
-    unsigned *c_n = nullptr, *c_p = nullptr;      // per sample: its N sites, its partial-code sites
+    unsigned *c_n = nullptr, *c_p = nullptr;      // per sample: its N sites, the sum of w over its listed (partial) sites
     double est_updates = 0.0;
 };
+constexpr int ENT_SHIFT = 5;                      // entries: index << 5 | w << 4 | 4-bit code
 
 static constexpr int GS_CHUNKS = 64;          // per-sample list building: group chunks per sample
 
@@ -64,39 +66,19 @@ struct GeneralSrc {
         return ((word_of(q.A, w) >> b) & 1u) | (((word_of(q.C, w) >> b) & 1u) << 1) | (((word_of(q.G, w) >> b) & 1u) << 2) |
                (((word_of(q.T, w) >> b) & 1u) << 3);
     }
+    __device__ __forceinline__ unsigned wmask(const Group &, int) const { return 0u; }
     __device__ __forceinline__ bool any_listed(size_t) const { return true; }
     __device__ __forceinline__ unsigned listed(size_t, int) const { return 0xFFFFFFFFu; }
     __device__ __forceinline__ size_t index(size_t g, int w, int b) const { return g * SITES_PER_GROUP + w * 32 + b; }
 };
 
-// MinorSrc: the minority sites of a consensus alignment (site_classes.hip), read in place from the three consensus planes:
-// only the sites of `minor_mask` are listed, under their rank (off[g] = listed sites before group g); a sample whose base
-// differs from the site's reference base counts as "partial" with the two-allele code {reference, own base}
-// (bases A = 0, C = 1, G = 2, T = 3 = X + 2 Y), a sample that is not a base as N (code 15).
-struct MinorSrc {
-    const uint4 *P;             // consensus planes X, Y, V
-    size_t n_pad;
-    const uint4 *minor_mask, *ref_x, *ref_y;
+// The minority sites of an alignment cut into site classes (site_classes.hip), read in place from its planes: only the sites
+// of `minor_mask` are listed, under their rank (off[g] = listed sites before group g).  At such a site every sample is N, or
+// carries exactly the site's reference base (not listed), or is LISTED with its allele mask M and w = [reference base not in M]
+// -- what the sample adds to its distance to every sample that carries the reference base.
+struct MinorRank {
+    const uint4 *minor_mask;
     const unsigned *off;
-    struct Group { uint4 X, Y, V, M, RX, RY; };
-    __device__ __forceinline__ Group load(size_t g, size_t s) const
-    {
-        const uint4 *base = P + (g * 3) * n_pad + s;
-        return Group{base[0], base[n_pad], base[2 * n_pad], minor_mask[g], ref_x[g], ref_y[g]};
-    }
-    __device__ __forceinline__ void masks(const Group &q, int w, unsigned &nm, unsigned &pm) const
-    {
-        const unsigned x = word_of(q.X, w), y = word_of(q.Y, w), v = word_of(q.V, w), m = word_of(q.M, w);
-        nm = ~v & m;
-        pm = v & ((x ^ word_of(q.RX, w)) | (y ^ word_of(q.RY, w))) & m;
-    }
-    __device__ __forceinline__ unsigned code(const Group &q, int w, int b) const
-    {
-        if (!((word_of(q.V, w) >> b) & 1u)) return 15u;
-        const unsigned own = ((word_of(q.X, w) >> b) & 1u) | (((word_of(q.Y, w) >> b) & 1u) << 1);
-        const unsigned ref = ((word_of(q.RX, w) >> b) & 1u) | (((word_of(q.RY, w) >> b) & 1u) << 1);
-        return (1u << own) | (1u << ref);
-    }
     __device__ __forceinline__ bool any_listed(size_t g) const
     {
         const uint4 m = minor_mask[g];
@@ -114,19 +96,90 @@ struct MinorSrc {
     }
 };
 
+// consensus planes X, Y, V (bases A = 0, C = 1, G = 2, T = 3 = X + 2 Y): a listed sample carries one base other than the
+// reference, so M = {own base} and w = 1
+struct MinorSrc : MinorRank {
+    const uint4 *P;
+    size_t n_pad;
+    const uint4 *ref_x, *ref_y;
+    struct Group { uint4 X, Y, V, M, RX, RY; };
+    __device__ __forceinline__ Group load(size_t g, size_t s) const
+    {
+        const uint4 *base = P + (g * 3) * n_pad + s;
+        return Group{base[0], base[n_pad], base[2 * n_pad], minor_mask[g], ref_x[g], ref_y[g]};
+    }
+    __device__ __forceinline__ void masks(const Group &q, int w, unsigned &nm, unsigned &pm) const
+    {
+        const unsigned x = word_of(q.X, w), y = word_of(q.Y, w), v = word_of(q.V, w), m = word_of(q.M, w);
+        nm = ~v & m;
+        pm = v & ((x ^ word_of(q.RX, w)) | (y ^ word_of(q.RY, w))) & m;
+    }
+    __device__ __forceinline__ unsigned wmask(const Group &, int) const { return 0xFFFFFFFFu; }
+    __device__ __forceinline__ unsigned code(const Group &q, int w, int b) const
+    {
+        if (!((word_of(q.V, w) >> b) & 1u)) return 15u;
+        const unsigned own = ((word_of(q.X, w) >> b) & 1u) | (((word_of(q.Y, w) >> b) & 1u) << 1);
+        return 16u | (1u << own);
+    }
+};
+
+// general planes A, C, G, T, N: a listed sample carries another base or a partial IUPAC code
+struct GeneralMinorSrc : MinorRank {
+    const uint4 *P;
+    size_t n_pad;
+    const uint4 *ref_x, *ref_y;
+    struct Group { uint4 A, C, G, T, N, M, RX, RY; };
+    __device__ __forceinline__ Group load(size_t g, size_t s) const
+    {
+        const uint4 *base = P + (g * NPLANES) * n_pad + s;
+        return Group{base[0], base[n_pad], base[2 * n_pad], base[3 * n_pad], base[4 * n_pad], minor_mask[g], ref_x[g], ref_y[g]};
+    }
+    // bits whose allele mask holds the reference base / is exactly the reference base
+    __device__ __forceinline__ void ref_bits(const Group &q, int w, unsigned &has_ref, unsigned &only_ref) const
+    {
+        const unsigned a = word_of(q.A, w), c = word_of(q.C, w), g = word_of(q.G, w), t = word_of(q.T, w);
+        const unsigned rx = word_of(q.RX, w), ry = word_of(q.RY, w);
+        const unsigned ra = ~rx & ~ry, rc = rx & ~ry, rg = ~rx & ry, rt = rx & ry;
+        has_ref = (a & ra) | (c & rc) | (g & rg) | (t & rt);
+        only_ref = ~((a ^ ra) | (c ^ rc) | (g ^ rg) | (t ^ rt));
+    }
+    __device__ __forceinline__ void masks(const Group &q, int w, unsigned &nm, unsigned &pm) const
+    {
+        unsigned has_ref, only_ref;
+        ref_bits(q, w, has_ref, only_ref);
+        const unsigned m = word_of(q.M, w), isn = word_of(q.N, w);
+        nm = isn & m;
+        pm = ~isn & ~only_ref & m;
+    }
+    __device__ __forceinline__ unsigned wmask(const Group &q, int w) const
+    {
+        unsigned has_ref, only_ref;
+        ref_bits(q, w, has_ref, only_ref);
+        return ~has_ref;
+    }
+    __device__ __forceinline__ unsigned code(const Group &q, int w, int b) const
+    {
+        const unsigned m = ((word_of(q.A, w) >> b) & 1u) | (((word_of(q.C, w) >> b) & 1u) << 1) | (((word_of(q.G, w) >> b) & 1u) << 2) |
+                           (((word_of(q.T, w) >> b) & 1u) << 3);
+        if (m == 15u) return 15u;
+        const unsigned ref = ((word_of(q.RX, w) >> b) & 1u) | (((word_of(q.RY, w) >> b) & 1u) << 1);
+        return (((m >> ref) & 1u) ? 0u : 16u) | m;
+    }
+};
+
 // pass A / B over the planes, lanes over samples (coalesced), one thread = (sample, chunk of groups), walked in site order.
 // FILL = false: cnt[s * GS_CHUNKS + chunk] = special sites of the chunk, cn[s * GS_CHUNKS + chunk] = N sites of the chunk.
 // FILL = true : entries written from off[s * GS_CHUNKS + chunk] on.
 template <bool FILL, class SRC>
 __global__ __launch_bounds__(256) void gs_sample_kernel(const SRC src, size_t n, size_t groups,
-                                                        size_t gpc, unsigned *__restrict__ cnt, unsigned *__restrict__ cn,
+                                                        size_t gpc, unsigned *__restrict__ cnt, unsigned *__restrict__ cn, unsigned *__restrict__ cw,
                                                         const unsigned long long *__restrict__ off, unsigned *__restrict__ ent)
 {
     const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
     const size_t chunk = (size_t)blockIdx.y * 4 + (threadIdx.x >> 6);
     if (s >= n || chunk >= GS_CHUNKS) return;
     const size_t g0 = chunk * gpc, g1 = min(groups, g0 + gpc);
-    unsigned c_all = 0, c_n = 0;
+    unsigned c_all = 0, c_n = 0, c_w = 0;
     unsigned long long o = FILL ? off[s * GS_CHUNKS + chunk] : 0ull;
     for (size_t g = g0; g < g1; g++) {
         if (!src.any_listed(g)) continue;                     // wave-uniform
@@ -135,16 +188,16 @@ __global__ __launch_bounds__(256) void gs_sample_kernel(const SRC src, size_t n,
         for (int w = 0; w < 4; w++) {
             unsigned nm, pm;
             src.masks(q, w, nm, pm);
-            if (!FILL) { c_all += __popc(nm | pm); c_n += __popc(nm); continue; }
+            if (!FILL) { c_all += __popc(nm | pm); c_n += __popc(nm); c_w += __popc(pm & src.wmask(q, w)); continue; }
             unsigned m = nm | pm;
             while (m) {
                 const int b = __ffs(m) - 1;
                 m &= m - 1;
-                ent[o++] = (unsigned)(src.index(g, w, b) << 4) | src.code(q, w, b);
+                ent[o++] = (unsigned)(src.index(g, w, b) << ENT_SHIFT) | src.code(q, w, b);
             }
         }
     }
-    if (!FILL) { cnt[s * GS_CHUNKS + chunk] = c_all; cn[s * GS_CHUNKS + chunk] = c_n; }
+    if (!FILL) { cnt[s * GS_CHUNKS + chunk] = c_all; cn[s * GS_CHUNKS + chunk] = c_n; cw[s * GS_CHUNKS + chunk] = c_w; }
 }
 
 // per-sample totals -> c_n[s], and the exclusive scan of cnt over (sample, chunk) in row-major order -> off (u64).
@@ -179,7 +232,7 @@ __global__ __launch_bounds__(1024) void gs_scan_kernel(const unsigned *__restric
     }
 }
 
-__global__ void gs_sample_totals_kernel(const unsigned *__restrict__ cnt, const unsigned *__restrict__ cn, size_t n,
+__global__ void gs_sample_totals_kernel(const unsigned *__restrict__ cw, const unsigned *__restrict__ cn, size_t n,
                                         unsigned *__restrict__ c_n, unsigned *__restrict__ c_p,
                                         const unsigned long long *__restrict__ off, unsigned long long *__restrict__ s_off)
 {
@@ -187,10 +240,10 @@ __global__ void gs_sample_totals_kernel(const unsigned *__restrict__ cnt, const 
     if (s > n) return;
     s_off[s] = off[s * GS_CHUNKS];                       // off has n * GS_CHUNKS + 1 entries
     if (s < n) {
-        unsigned t = 0, all = 0;
-        for (int k = 0; k < GS_CHUNKS; k++) { t += cn[s * GS_CHUNKS + k]; all += cnt[s * GS_CHUNKS + k]; }
+        unsigned t = 0, wsum = 0;
+        for (int k = 0; k < GS_CHUNKS; k++) { t += cn[s * GS_CHUNKS + k]; wsum += cw[s * GS_CHUNKS + k]; }
         c_n[s] = t;
-        c_p[s] = all - t;
+        c_p[s] = wsum;
     }
 }
 
@@ -233,7 +286,7 @@ __global__ __launch_bounds__(256) void gs_site_kernel(const SRC src, size_t n, s
                 const int b = __ffs(pm) - 1;
                 pm &= pm - 1;
                 const unsigned slot = atomicAdd(&cP[w * 32 + b], 1u);
-                if (FILL) p_ent[bP[w * 32 + b] + slot] = ((unsigned)s << 4) | src.code(q, w, b);
+                if (FILL) p_ent[bP[w * 32 + b] + slot] = ((unsigned)s << ENT_SHIFT) | src.code(q, w, b);
             }
         }
     }
@@ -253,13 +306,14 @@ __global__ __launch_bounds__(256) void gs_site_kernel(const SRC src, size_t n, s
 
 // Row i of the pair matrix: T1 + T2 accumulated in LDS, then added to dist; ncomp gets its c_i, c_j terms.
 //
-// MINOR: the same walk over the lists of a consensus alignment's MINORITY sites (site_classes.hip) -- sites at which only a
-// few samples differ from a reference base.  Those samples are listed as if they carried the two-allele code {reference,
-// own base}; a site then contributes to d(i, j):  1 when exactly one of the two is a minority sample and the other a base,
-// [own bases differ] when both are, 0 otherwise, i.e. over the sites S_i, S_j where i / j is a minority sample
-//     d += |S_i| + |S_j| - #(s in S_i: j is N) - #(s in S_j: i is N) - sum over S_i n S_j of |code_i n code_j|
-// (|code_i n code_j| = 2 when the own bases agree, 1 when only the reference is shared).  Negative terms wrap in the unsigned
-// row and cancel in the final sum.  ncomp is not touched (the counting pass covers these sites).
+// MINOR: the same walk over the lists of the MINORITY sites of an alignment cut into site classes (site_classes.hip) -- sites
+// at which all but a few samples are N or carry the site's reference base.  The few are listed with their allele mask M and
+// w = [reference base not in M].  Such a site adds to d(i, j): w_i when i is listed and j carries the reference base,
+// [M_i n M_j = {}] when both are listed, 0 when either is N -- i.e. over the sites S_i, S_j at which i / j is listed
+//     d += sum_{S_i} w_i + sum_{S_j} w_j - sum_{s in S_i: j is N} w_i - sum_{s in S_j: i is N} w_j
+//          + sum over S_i n S_j of ([M_i n M_j = {}] - w_i - w_j)
+// (consensus alignments: M = {own base}, w = 1).  The first two sums are per-sample constants (c_p); negative terms wrap in the
+// unsigned row and cancel in the final sum.  ncomp is not touched (the counting pass covers these sites).
 template <bool MINOR>
 __global__ __launch_bounds__(1024) void general_fixup_kernel(const unsigned long long *__restrict__ s_off, const unsigned *__restrict__ s_ent,
                                                              const unsigned long long *__restrict__ p_off, const unsigned *__restrict__ p_ent,
@@ -284,24 +338,24 @@ __global__ __launch_bounds__(1024) void general_fixup_kernel(const unsigned long
         unsigned long long my_pa = 0, my_pz = 0, my_na = 0, my_nz = 0;
         if (e < e1) {
             const unsigned ent = s_ent[e];
-            const unsigned site = ent >> 4;
-            my_code = ent & 15u;
+            const unsigned site = ent >> ENT_SHIFT;
+            my_code = ent & 31u;                            // w << 4 | code
             my_pa = p_off[site]; my_pz = p_off[site + 1];
-            if (my_code != 15u) { my_na = n_off[site]; my_nz = n_off[site + 1]; }
+            if ((my_code & 15u) != 15u) { my_na = n_off[site]; my_nz = n_off[site + 1]; }
         }
         // Short lists stay in their lane: where i is N and at most four samples are partial there (the usual case on the minority
         // lists: one or two), the lane applies its site's entries itself -- one round trip for the 16 sites together.
         bool coop = e < e1;
-        if (coop && my_code == 15u && my_pz - my_pa <= 4) {
+        if (coop && (my_code & 15u) == 15u && my_pz - my_pa <= 4) {
             unsigned v[4];
 #pragma unroll
             for (int m = 0; m < 4; m++) v[m] = my_pa + m < my_pz ? p_ent[my_pa + m] : 0xFFFFFFFFu;
 #pragma unroll
             for (int m = 0; m < 4; m++)
                 if (v[m] != 0xFFFFFFFFu) {
-                    const unsigned j = v[m] >> 4;
-                    const int add = MINOR ? -1 : __popc(v[m] & 15u) - 1;
-                    if ((MINOR || add > 0) && j > i && j >= c0 && j < c1) atomicAdd(&row[j - c0], (unsigned)add);
+                    const unsigned j = v[m] >> ENT_SHIFT;
+                    const int add = MINOR ? -(int)((v[m] >> 4) & 1u) : __popc(v[m] & 15u) - 1;      // MINOR: -w_j
+                    if (add != 0 && (MINOR || add > 0) && j > i && j >= c0 && j < c1) atomicAdd(&row[j - c0], (unsigned)add);
                 }
             coop = false;
         }
@@ -317,7 +371,7 @@ __global__ __launch_bounds__(1024) void general_fixup_kernel(const unsigned long
 #pragma unroll
             for (int m = 0; m < 4; m++) {
                 h.p[m] = pa + 16 * m < pz ? p_ent[pa + 16 * m] : 0xFFFFFFFFu;
-                h.n[m] = (code != 15u && na + 16 * m < nz) ? n_ent[na + 16 * m] : 0xFFFFFFFFu;
+                h.n[m] = ((code & 15u) != 15u && na + 16 * m < nz) ? n_ent[na + 16 * m] : 0xFFFFFFFFu;
             }
         };
         Head cur, nxt;
@@ -327,16 +381,19 @@ __global__ __launch_bounds__(1024) void general_fixup_kernel(const unsigned long
             todo &= todo - 1;
             const int kn = todo ? __ffs(todo) - 1 : -1;
             if (kn >= 0) fetch_head(kn, nxt);
-            const unsigned code = __shfl(my_code, k, 16);
+            const unsigned code5 = __shfl(my_code, k, 16);
+            const unsigned code = code5 & 15u, wi = code5 >> 4;
             const bool i_is_n = code == 15u;
-            const unsigned kk = (unsigned)__popc(code) - 1u;           // |M_i| - 1 when i is partial here
+            const unsigned kk = MINOR ? 0u - wi : (unsigned)__popc(code) - 1u;       // an N j: |M_i| - 1 (MINOR: -w_i)
             auto apply_p = [&](unsigned v) {                          // a partial j: i N -> |M_j| - 1; both partial -> (|M_i n M_j| - 1)^+
-                const unsigned j = v >> 4;
-                const int add = MINOR ? (i_is_n ? -1 : -__popc(v & code)) : (i_is_n ? __popc(v & 15u) - 1 : __popc(v & code) - 1);
-                if ((MINOR || add > 0) && j > i && j >= c0 && j < c1) atomicAdd(&row[j - c0], (unsigned)add);
+                const unsigned j = v >> ENT_SHIFT, mj = v & 15u;
+                const int wj = (int)((v >> 4) & 1u);
+                const int add = MINOR ? (i_is_n ? -wj : ((mj & code) == 0u ? 1 : 0) - (int)wi - wj)
+                                      : (i_is_n ? __popc(mj) - 1 : __popc(mj & code) - 1);
+                if (add != 0 && (MINOR || add > 0) && j > i && j >= c0 && j < c1) atomicAdd(&row[j - c0], (unsigned)add);
             };
-            auto apply_n = [&](unsigned j) {                          // an N j, i partial here: |M_i| - 1  (MINOR: -1)
-                if (j > i && j >= c0 && j < c1) atomicAdd(&row[j - c0], MINOR ? 0xFFFFFFFFu : kk);
+            auto apply_n = [&](unsigned j) {                          // an N j, i partial here: |M_i| - 1  (MINOR: -w_i)
+                if (kk != 0u && j > i && j >= c0 && j < c1) atomicAdd(&row[j - c0], kk);
             };
 #pragma unroll
             for (int m = 0; m < 4; m++) {
@@ -396,22 +453,25 @@ void minority_lists_free(tracs_alignment *a)
 
 // The lists of a 5-plane alignment (planes, n samples, L sites).  *out = nullptr when the alignment is outside what the path
 // supports (too long, too many entries, no memory) -- not an error.
+// max_entries: the lists must stay a small fraction of the alignment's planes (one entry per 8 sites of the WHOLE alignment):
+// beyond that the VALU kernel / the dense pair kernel is the better tool anyway
 template <class SRC>
-static int gs_build(const SRC src, size_t n, size_t L, size_t groups, hipStream_t stream, GeneralSparse **out)
+static int gs_build(const SRC src, size_t n, size_t L, size_t groups, double max_entries, hipStream_t stream, GeneralSparse **out)
 {
     *out = nullptr;
-    if (L >= (1ull << 28) || n >= (1ull << 28) || L == 0) return TRACS_OK;        // entries hold site << 4 / sample << 4
+    if (L >= (1ull << 27) || n >= (1ull << 27) || L == 0) return TRACS_OK;        // entries hold site << 5 / sample << 5
     auto *g = new GeneralSparse();
-    unsigned *cnt = nullptr, *cn = nullptr, *cntP = nullptr, *cntN = nullptr;
+    unsigned *cnt = nullptr, *cn = nullptr, *cw = nullptr, *cntP = nullptr, *cntN = nullptr;
     unsigned long long *off = nullptr;
     double *d_est = nullptr;
-    auto tmp_free = [&]() { void *p[] = {cnt, cn, cntP, cntN, off, d_est}; for (void *q : p) if (q) (void)hipFree(q); };
+    auto tmp_free = [&]() { void *p[] = {cnt, cn, cw, cntP, cntN, off, d_est}; for (void *q : p) if (q) (void)hipFree(q); };
     auto fail_soft = [&]() { tmp_free(); (void)hipGetLastError(); gs_free(g); return TRACS_OK; };
 #define GS_TRY(x) do { if ((x) != hipSuccess) return fail_soft(); } while (0)
     const size_t nsc = n * GS_CHUNKS;
     const size_t gpc = (groups + GS_CHUNKS - 1) / GS_CHUNKS;
     GS_TRY(hipMalloc(reinterpret_cast<void **>(&cnt), nsc * 4));
     GS_TRY(hipMalloc(reinterpret_cast<void **>(&cn), nsc * 4));
+    GS_TRY(hipMalloc(reinterpret_cast<void **>(&cw), nsc * 4));
     GS_TRY(hipMalloc(reinterpret_cast<void **>(&off), (nsc + 1) * 8));
     GS_TRY(hipMalloc(reinterpret_cast<void **>(&cntP), (L + 1) * 4));
     GS_TRY(hipMalloc(reinterpret_cast<void **>(&cntN), (L + 1) * 4));
@@ -424,9 +484,9 @@ static int gs_build(const SRC src, size_t n, size_t L, size_t groups, hipStream_
     GS_TRY(hipMemsetAsync(d_est, 0, 8, stream));
 
     const dim3 sgrid((unsigned)((n + 63) / 64), GS_CHUNKS / 4);
-    hipLaunchKernelGGL((gs_sample_kernel<false, SRC>), sgrid, dim3(256), 0, stream, src, n, groups, gpc, cnt, cn, nullptr, nullptr);
+    hipLaunchKernelGGL((gs_sample_kernel<false, SRC>), sgrid, dim3(256), 0, stream, src, n, groups, gpc, cnt, cn, cw, nullptr, nullptr);
     hipLaunchKernelGGL(gs_scan_kernel, dim3(1), dim3(1024), 0, stream, cnt, nsc, off);
-    hipLaunchKernelGGL(gs_sample_totals_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, stream, cnt, cn, n, g->c_n, g->c_p, off, g->s_off);
+    hipLaunchKernelGGL(gs_sample_totals_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, stream, cw, cn, n, g->c_n, g->c_p, off, g->s_off);
     GS_TRY(hipMemsetAsync(cntP, 0, (L + 1) * 4, stream));
     GS_TRY(hipMemsetAsync(cntN, 0, (L + 1) * 4, stream));
     hipLaunchKernelGGL((gs_site_kernel<false, SRC>), dim3((unsigned)groups), dim3(256), 0, stream, src, n, L, cntP, cntN,
@@ -441,12 +501,11 @@ static int gs_build(const SRC src, size_t n, size_t L, size_t groups, hipStream_
     GS_TRY(hipMemcpyAsync(&est, d_est, 8, hipMemcpyDeviceToHost, stream));
     GS_TRY(hipStreamSynchronize(stream));
     if (tot_s != tot_p + tot_n) { tmp_free(); gs_free(g); set_error("general_sparse: list totals disagree (internal error)"); return TRACS_E_HIP; }
-    // the lists must stay a small fraction of the planes: beyond one entry per 8 sites the VALU kernel is the better tool anyway
-    if ((double)tot_s > (double)n * (double)L / 8.0) return fail_soft();
+    if ((double)tot_s > max_entries) return fail_soft();
     GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->s_ent), std::max<size_t>(tot_s, 1) * 4));
     GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->p_ent), std::max<size_t>(tot_p, 1) * 4));
     GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->n_ent), std::max<size_t>(tot_n, 1) * 4));
-    hipLaunchKernelGGL((gs_sample_kernel<true, SRC>), sgrid, dim3(256), 0, stream, src, n, groups, gpc, nullptr, nullptr, off, g->s_ent);
+    hipLaunchKernelGGL((gs_sample_kernel<true, SRC>), sgrid, dim3(256), 0, stream, src, n, groups, gpc, nullptr, nullptr, nullptr, off, g->s_ent);
     hipLaunchKernelGGL((gs_site_kernel<true, SRC>), dim3((unsigned)groups), dim3(256), 0, stream, src, n, L, nullptr, nullptr,
                        g->p_off, g->n_off, g->p_ent, g->n_ent, nullptr);
     GS_TRY(hipGetLastError());
@@ -465,7 +524,7 @@ int general_sparse_get(tracs_alignment *a, hipStream_t stream, int *ok, double *
     if (a->sparse_state == 1) { *ok = 1; *est_updates = a->sparse->est_updates; return TRACS_OK; }
     a->sparse_state = -1;
     // the variable sites only when site classes are in use
-    const int rc = gs_build(GeneralSrc{pair_planes(a, false), a->n_pad}, a->n, pair_L(a), pair_groups(a), stream, &a->sparse);
+    const int rc = gs_build(GeneralSrc{pair_planes(a, false), a->n_pad}, a->n, pair_L(a), pair_groups(a), (double)a->n * (double)a->L / 8.0, stream, &a->sparse);
     if (rc || !a->sparse) return rc;
     a->sparse_state = 1;
     *ok = 1;
@@ -473,12 +532,22 @@ int general_sparse_get(tracs_alignment *a, hipStream_t stream, int *ok, double *
     return TRACS_OK;
 }
 
-// site_classes.hip: the lists of the `sites` minority sites of a consensus alignment, read in place from its planes
-int minority_lists_build(tracs_alignment *a, const uint4 *cplanes, const uint4 *minor_mask, const uint4 *ref_x, const uint4 *ref_y,
-                         const unsigned *off_minor, size_t sites, hipStream_t stream, int *ok)
+// site_classes.hip: the lists of the `sites` minority sites of an alignment, read in place from its planes
+// (consensus: the three consensus planes; otherwise the five general planes)
+int minority_lists_build(tracs_alignment *a, bool consensus, const uint4 *planes, const uint4 *minor_mask, const uint4 *ref_x,
+                         const uint4 *ref_y, const unsigned *off_minor, size_t sites, hipStream_t stream, int *ok)
 {
     minority_lists_free(a);
-    const int rc = gs_build(MinorSrc{cplanes, a->n_pad, minor_mask, ref_x, ref_y, off_minor}, a->n, sites, a->groups, stream, &a->minor);
+    int rc;
+    if (consensus) {
+        MinorSrc src;
+        src.minor_mask = minor_mask; src.off = off_minor; src.P = planes; src.n_pad = a->n_pad; src.ref_x = ref_x; src.ref_y = ref_y;
+        rc = gs_build(src, a->n, sites, a->groups, (double)a->n * (double)a->L / 8.0, stream, &a->minor);
+    } else {
+        GeneralMinorSrc src;
+        src.minor_mask = minor_mask; src.off = off_minor; src.P = planes; src.n_pad = a->n_pad; src.ref_x = ref_x; src.ref_y = ref_y;
+        rc = gs_build(src, a->n, sites, a->groups, (double)a->n * (double)a->L / 8.0, stream, &a->minor);
+    }
     *ok = a->minor != nullptr;
     return rc;
 }

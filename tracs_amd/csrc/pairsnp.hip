@@ -870,7 +870,8 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
     }
     bool mfma = cons && !mfma_off;
     bool mfma_general = false;
-    for (int attempt = 0; attempt < 2 && !cons && !mfma_off && pair_L(a) < (1ull << 28); attempt++) {
+    static const int gen_force = env_flag("TRACS_GENERAL_MFMA");          // 1: always, 0: never the matrix cores for general alignments
+    for (int attempt = 0; attempt < 2 && !cons && !mfma_off && pair_L(a) < (1ull << 27) && pair_L(a) > 0; attempt++) {
         // general alignment: one-hot Gram on the matrix cores + the sparse partial-code terms, when the side lists exist (or
         // can be built) and the sparse work is small beside what the VALU kernel would cost.  Thresholded passes too: the
         // kernel's value bounds the distance from below, so tiles it declares dead are dead (pairsnp_mfma.hip)
@@ -884,8 +885,7 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
             const double t_valu = cells * (double)a->groups * 4.0 * 7.0 / 38e12;
             const double t_mfma = cells * ((double)pair_L(a) * 10.0 + (a->classes_state == 1 ? (double)a->L_inv * 2.0 : 0.0)) / 5.4e15
                                   + updates * frac / 3.0e11;                  // measured: 5.4 PFLOP/s, 4 x 10^11 list entries/s
-            static const int force = env_flag("TRACS_GENERAL_MFMA");          // 1: always, 0: never (diagnostics)
-            mfma_general = force == 1 || (force != 0 && t_mfma < t_valu);
+            mfma_general = gen_force == 1 || (gen_force != 0 && t_mfma < t_valu);
         }
         if (mfma_general || a->classes_state != 1) break;
         // the VALU kernel reads the whole alignment: drop the classes (and the lists built on them) and look again
@@ -893,15 +893,18 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
         site_classes_free(a);
         a->classes_state = -1;
     }
-    if (!cons && !mfma_general && a->classes_state == 1) { general_sparse_free(a); site_classes_free(a); a->classes_state = -1; }
-    mfma = mfma || mfma_general;
+    // (a general alignment whose variable sites all went to the minority lists has no dense site left: nothing for the pair
+    // kernel to read, the lists and the counting pass do everything)
+    const bool no_dense_site = !cons && !mfma_off && gen_force != 0 && a->classes_state == 1 && pair_L(a) == 0;
+    if (!cons && !mfma_general && !no_dense_site && a->classes_state == 1) { general_sparse_free(a); site_classes_free(a); a->classes_state = -1; }
+    mfma = mfma || mfma_general || no_dense_site;
     const bool classes = a->classes_state == 1;
     const int groups = (int)pair_groups(a);
     const int shape_id = mfma_shape_current(mfma_general);
     const MfmaShape &S = mfma_shape(shape_id);
     const int kGC = mfma ? (mfma_general ? S.gc_gen : S.gc_cons) : V.gc;
     const int kTI = mfma ? S.ti : V.ti, kTJ = mfma ? S.tj : V.tj;
-    a->last_kernel = mfma_general ? 2 : mfma ? 1 : 0;
+    a->last_kernel = (mfma_general || no_dense_site) ? 2 : mfma ? 1 : 0;
 
     // ---- (re)build the cached tile schedule ------------------------------------------------------------------------------
     auto ensure_tiles = [&](tracs_alignment::TileCache &c, int ti, int tj) -> int {

@@ -85,11 +85,11 @@ void general_sparse_free(tracs_alignment *a);
 // dist[i][j] += T1 + T2 (partial-code terms), ncomp[i][j] += L - c_i - c_j for the cells of the dense region.
 int general_sparse_fixup(tracs_alignment *a, size_t row_begin, size_t row_end, size_t col_begin, unsigned *dist,
                          unsigned *ncomp, size_t ld, hipStream_t stream);
-// The same lists for the MINORITY sites of a consensus alignment cut into site classes (site_classes.hip), read in place from
-// the consensus planes: a minority sample is listed with the two-allele code {reference base, own base}; minority_fixup adds
-// the sites' contribution to dist (weights: general_fixup_kernel<MINOR>).
-int minority_lists_build(tracs_alignment *a, const uint4 *cplanes, const uint4 *minor_mask, const uint4 *ref_x, const uint4 *ref_y,
-                         const unsigned *off_minor, size_t sites, hipStream_t stream, int *ok);
+// The same lists for the MINORITY sites of an alignment cut into site classes (site_classes.hip), read in place from its planes
+// (consensus or general): a sample that is neither N nor exactly the site's reference base is listed with its allele mask and
+// w = [reference base not in the mask]; minority_fixup adds the sites' contribution to dist (general_fixup_kernel<MINOR>).
+int minority_lists_build(tracs_alignment *a, bool consensus, const uint4 *planes, const uint4 *minor_mask, const uint4 *ref_x,
+                         const uint4 *ref_y, const unsigned *off_minor, size_t sites, hipStream_t stream, int *ok);
 void minority_lists_free(tracs_alignment *a);
 int minority_fixup(tracs_alignment *a, size_t row_begin, size_t row_end, size_t col_begin, unsigned *dist, size_t ld, hipStream_t stream);
 

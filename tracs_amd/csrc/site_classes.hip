@@ -6,19 +6,18 @@
 // A site at which every sample that is not N carries the SAME base never separates two samples: it adds 0 to d(i, j) and
 // [neither i nor j is N there] to nn(i, j), whatever the pair; and a site at which only a FEW samples differ from the others
 // separates only the pairs that involve one of those few.  Real alignments are mostly such sites.  The sites are cut into
-// classes once per pack (k = samples whose base differs from a reference base of the site -- the base of one of its samples --,
-// cN = samples that are N there):
+// classes once per pack (k = samples that are neither N nor exactly the site's reference base -- the base of one of its one-base
+// samples --, i.e. another base or a partial IUPAC code; cN = samples that are N there):
 //     empty      every sample is N (or the tail bits behind L): contributes to nothing;
-//     dense      k (cN + k) above the budget below (general encoding: two samples carry different bases, or some sample a
-//                partial IUPAC code): the usual pair kernel, over `vplanes` -- these sites re-packed in site order, same planes
-//                and layout as the kernels' usual source;
+//     dense      k (cN + k) above the budget below: the usual pair kernel, over `vplanes` -- these sites re-packed in site
+//                order, same planes and layout as the kernels' usual source;
 //     counted    every other site with cN >= 1: nn += sum v_i v_j over `iplanes` (ONE plane, v = "this sample is a base
 //                here"; pairsnp_mfma_kernel<COUNT>, one operand plane instead of four or five);
 //     full       every other site with cN = 0: +1 to every nn, a constant;
-//     minority   the counted / full sites with k >= 1 (consensus encoding only): d gets their contribution from sparse lists
-//                -- the k samples, the cN samples -- exactly as general_sparse.hip handles partial IUPAC codes
-//                (general_fixup_kernel<MINOR>: +1 for a pair of which exactly one is a minority sample and the other a base,
-//                [bases differ] when both are).
+//     minority   the counted / full sites with k >= 1: d gets their contribution from sparse lists -- the k samples with their
+//                allele masks, the cN samples -- with the machinery general_sparse.hip uses for partial IUPAC codes
+//                (general_fixup_kernel<MINOR>: [reference base not in the listed sample's mask] for a pair of a listed sample
+//                and a reference-base sample, [masks disjoint] for two listed samples, 0 when either is N).
 // The decomposition is exact site by site (tests/test_host_logic.py::test_site_class_identity); a pass costs
 // (4 L_dense + L_counted) / 4 L of the dense one in matrix instructions plus ~sum k (cN + k) list entries.  Chosen when that
 // is < 0.92; TRACS_SITE_CLASSES=0/1 forces, TRACS_MINORITY=0 keeps every site with k >= 1 dense.
@@ -38,32 +37,29 @@ __device__ __forceinline__ unsigned wave_or(unsigned v)
     return v;
 }
 
-// One workgroup per 128-site group: OR-reductions over the samples, then the two class masks of the group.
-// CONS: planes X, Y, V (3 per group).  !CONS: planes A, C, G, T, N (5 per group).
+// One workgroup per 128-site group.  Pass 1: a reference base per site -- the base of the first sample, in thread order, that
+// carries exactly one base there.  Pass 2: per site k = samples that are neither N nor exactly that base (another base, or a
+// partial IUPAC code) and cN = samples that are N, counted with LDS atomics (both are sparse).  Then the class masks of the group.
+// CONS: planes X, Y, V (3 per group; bases A = 0, C = 1, G = 2, T = 3 = X + 2 Y).  !CONS: planes A, C, G, T, N (5 per group).
 template <bool CONS>
-__global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__restrict__ P, size_t n_pad, unsigned n,
-                                                             uint4 *__restrict__ var_mask, uint4 *__restrict__ inv_mask)
+__global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__restrict__ P, size_t n_pad, unsigned n, unsigned budget,
+                                                             uint4 *__restrict__ dense_mask, uint4 *__restrict__ count_mask,
+                                                             uint4 *__restrict__ minor_mask, uint4 *__restrict__ full_mask,
+                                                             uint4 *__restrict__ ref_x, uint4 *__restrict__ ref_y)
 {
     const size_t g = blockIdx.x;
-    constexpr int NACC = 5;
-    // CONS: acc = {V&X, V&~X, V&Y, V&~Y, V};  general: {A, C, G, T (each & ~N), partial | -- see below}
-    unsigned acc[NACC][4], anyb[4];
-#pragma unroll
-    for (int k = 0; k < NACC; k++)
-#pragma unroll
-        for (int w = 0; w < 4; w++) acc[k][w] = 0;
-#pragma unroll
-    for (int w = 0; w < 4; w++) anyb[w] = 0;
-    for (unsigned s = threadIdx.x; s < n; s += 256) {
+    __shared__ unsigned red[4][4][4];
+    __shared__ unsigned sref[4][4];                     // one-base sample seen, ref X, ref Y, somebody is not N
+    __shared__ unsigned cM[SITES_PER_GROUP], cN[SITES_PER_GROUP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < SITES_PER_GROUP) { cM[threadIdx.x] = 0; cN[threadIdx.x] = 0; }
+    // per sample and word: x, y = the base's two bits where the sample carries exactly one base (`one`), `some` = not N
+    auto load = [&](unsigned s, unsigned (&x)[4], unsigned (&y)[4], unsigned (&one)[4], unsigned (&some)[4], unsigned (&isn)[4]) {
         if constexpr (CONS) {
             const uint4 X = P[(g * 3 + 0) * n_pad + s], Y = P[(g * 3 + 1) * n_pad + s], V = P[(g * 3 + 2) * n_pad + s];
-            const unsigned x[4] = {X.x, X.y, X.z, X.w}, y[4] = {Y.x, Y.y, Y.z, Y.w}, v[4] = {V.x, V.y, V.z, V.w};
+            const unsigned xx[4] = {X.x, X.y, X.z, X.w}, yy[4] = {Y.x, Y.y, Y.z, Y.w}, vv[4] = {V.x, V.y, V.z, V.w};
 #pragma unroll
-            for (int w = 0; w < 4; w++) {
-                acc[0][w] |= v[w] & x[w]; acc[1][w] |= v[w] & ~x[w];
-                acc[2][w] |= v[w] & y[w]; acc[3][w] |= v[w] & ~y[w];
-                anyb[w] |= v[w];
-            }
+            for (int w = 0; w < 4; w++) { x[w] = xx[w]; y[w] = yy[w]; one[w] = vv[w]; some[w] = vv[w]; isn[w] = ~vv[w]; }
         } else {
             const uint4 A = P[(g * NPLANES + 0) * n_pad + s], C = P[(g * NPLANES + 1) * n_pad + s];
             const uint4 G = P[(g * NPLANES + 2) * n_pad + s], T = P[(g * NPLANES + 3) * n_pad + s];
@@ -72,62 +68,24 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
             const unsigned t[4] = {T.x, T.y, T.z, T.w}, nn[4] = {N.x, N.y, N.z, N.w};
 #pragma unroll
             for (int w = 0; w < 4; w++) {
-                const unsigned k = ~nn[w];
                 const unsigned two = (a[w] & c[w]) | (a[w] & gg[w]) | (a[w] & t[w]) | (c[w] & gg[w]) | (c[w] & t[w]) | (gg[w] & t[w]);
-                acc[0][w] |= a[w] & k; acc[1][w] |= c[w] & k; acc[2][w] |= gg[w] & k; acc[3][w] |= t[w] & k;
-                acc[4][w] |= two & k;                           // a partial IUPAC code: the site is variable
-                anyb[w] |= (a[w] | c[w] | gg[w] | t[w]) & k;
+                const unsigned any = a[w] | c[w] | gg[w] | t[w];
+                one[w] = any & ~two;                            // exactly one allele
+                some[w] = any & ~nn[w];                         // a base or a partial code (tail bits: neither)
+                isn[w] = nn[w];
+                x[w] = (c[w] | t[w]) & one[w];
+                y[w] = (gg[w] | t[w]) & one[w];
             }
         }
-    }
-    __shared__ unsigned red[4][NACC + 1][4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-#pragma unroll
-        for (int k = 0; k < NACC; k++) {
-            const unsigned r = wave_or(acc[k][w]);
-            if (lane == 0) red[wave][k][w] = r;
-        }
-        const unsigned r = wave_or(anyb[w]);
-        if (lane == 0) red[wave][NACC][w] = r;
-    }
-    __syncthreads();
-    if (threadIdx.x < 4) {
-        const int w = threadIdx.x;
-        unsigned t[NACC + 1];
-#pragma unroll
-        for (int k = 0; k <= NACC; k++) t[k] = red[0][k][w] | red[1][k][w] | red[2][k][w] | red[3][k][w];
-        unsigned var;
-        if constexpr (CONS) var = (t[0] & t[1]) | (t[2] & t[3]);
-        else var = t[4] | (t[0] & t[1]) | (t[0] & t[2]) | (t[0] & t[3]) | (t[1] & t[2]) | (t[1] & t[3]) | (t[2] & t[3]);
-        reinterpret_cast<unsigned *>(&var_mask[g])[w] = var;
-        reinterpret_cast<unsigned *>(&inv_mask[g])[w] = t[NACC] & ~var;
-    }
-}
-
-// Consensus encoding, one workgroup per 128-site group.  Pass 1: a reference base per site (the base of the first sample, in
-// thread order, that is a base there).  Pass 2: per site k = samples whose base differs from it and cN = samples that are N,
-// counted with LDS atomics (both are sparse).  Then the class masks of the group.
-__global__ __launch_bounds__(256) void classify_consensus_kernel(const uint4 *__restrict__ P, size_t n_pad, unsigned n, unsigned budget,
-                                                                 uint4 *__restrict__ dense_mask, uint4 *__restrict__ count_mask,
-                                                                 uint4 *__restrict__ minor_mask, uint4 *__restrict__ full_mask,
-                                                                 uint4 *__restrict__ ref_x, uint4 *__restrict__ ref_y)
-{
-    const size_t g = blockIdx.x;
-    __shared__ unsigned red[4][3][4];
-    __shared__ unsigned sref[3][4];                     // seen, ref X, ref Y
-    __shared__ unsigned cM[SITES_PER_GROUP], cN[SITES_PER_GROUP];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x < SITES_PER_GROUP) { cM[threadIdx.x] = 0; cN[threadIdx.x] = 0; }
-    unsigned seen[4] = {0, 0, 0, 0}, rx[4] = {0, 0, 0, 0}, ry[4] = {0, 0, 0, 0};
+    };
+    unsigned seen[4] = {0, 0, 0, 0}, rx[4] = {0, 0, 0, 0}, ry[4] = {0, 0, 0, 0}, anyb[4] = {0, 0, 0, 0};
     for (unsigned s = threadIdx.x; s < n; s += 256) {
-        const uint4 X = P[(g * 3 + 0) * n_pad + s], Y = P[(g * 3 + 1) * n_pad + s], V = P[(g * 3 + 2) * n_pad + s];
-        const unsigned x[4] = {X.x, X.y, X.z, X.w}, y[4] = {Y.x, Y.y, Y.z, Y.w}, v[4] = {V.x, V.y, V.z, V.w};
+        unsigned x[4], y[4], one[4], some[4], isn[4];
+        load(s, x, y, one, some, isn);
 #pragma unroll
         for (int w = 0; w < 4; w++) {
-            const unsigned fresh = v[w] & ~seen[w];
-            rx[w] |= x[w] & fresh; ry[w] |= y[w] & fresh; seen[w] |= v[w];
+            const unsigned fresh = one[w] & ~seen[w];
+            rx[w] |= x[w] & fresh; ry[w] |= y[w] & fresh; seen[w] |= one[w]; anyb[w] |= some[w];
         }
     }
     // lower lanes first: the result is the same on every lane of the wave
@@ -140,30 +98,33 @@ __global__ __launch_bounds__(256) void classify_consensus_kernel(const uint4 *__
             const unsigned fs = me_first ? seen[w] : os, fx = me_first ? rx[w] : ox, fy = me_first ? ry[w] : oy;
             const unsigned ls = me_first ? os : seen[w], lx = me_first ? ox : rx[w], ly = me_first ? oy : ry[w];
             rx[w] = fx | (lx & ~fs); ry[w] = fy | (ly & ~fs); seen[w] = fs | ls;
+            anyb[w] |= __shfl_xor(anyb[w], off, 64);
         }
-        if (lane == 0) { red[wave][0][w] = seen[w]; red[wave][1][w] = rx[w]; red[wave][2][w] = ry[w]; }
+        if (lane == 0) { red[wave][0][w] = seen[w]; red[wave][1][w] = rx[w]; red[wave][2][w] = ry[w]; red[wave][3][w] = anyb[w]; }
     }
     __syncthreads();
     if (threadIdx.x < 4) {
         const int w = threadIdx.x;
-        unsigned fs = 0, fx = 0, fy = 0;
+        unsigned fs = 0, fx = 0, fy = 0, fa = 0;
         for (int k = 0; k < 4; k++) {
-            fx |= red[k][1][w] & ~fs; fy |= red[k][2][w] & ~fs; fs |= red[k][0][w];
+            fx |= red[k][1][w] & ~fs; fy |= red[k][2][w] & ~fs; fs |= red[k][0][w]; fa |= red[k][3][w];
         }
-        sref[0][w] = fs; sref[1][w] = fx; sref[2][w] = fy;
+        sref[0][w] = fs; sref[1][w] = fx; sref[2][w] = fy; sref[3][w] = fa;
     }
     __syncthreads();
-    const unsigned any[4] = {sref[0][0], sref[0][1], sref[0][2], sref[0][3]};
+    // (a site without any one-base sample keeps the reference A: every sample that is not N is listed there)
+    const unsigned any[4] = {sref[3][0], sref[3][1], sref[3][2], sref[3][3]};
     const unsigned refx[4] = {sref[1][0], sref[1][1], sref[1][2], sref[1][3]}, refy[4] = {sref[2][0], sref[2][1], sref[2][2], sref[2][3]};
     for (unsigned s = threadIdx.x; s < n; s += 256) {
-        const uint4 X = P[(g * 3 + 0) * n_pad + s], Y = P[(g * 3 + 1) * n_pad + s], V = P[(g * 3 + 2) * n_pad + s];
-        const unsigned x[4] = {X.x, X.y, X.z, X.w}, y[4] = {Y.x, Y.y, Y.z, Y.w}, v[4] = {V.x, V.y, V.z, V.w};
+        unsigned x[4], y[4], one[4], some[4], isn[4];
+        load(s, x, y, one, some, isn);
 #pragma unroll
         for (int w = 0; w < 4; w++) {
-            unsigned diff = v[w] & ((x[w] ^ refx[w]) | (y[w] ^ refy[w]));
+            // listed: not N and not exactly the reference base
+            unsigned diff = some[w] & ~(one[w] & ~((x[w] ^ refx[w]) | (y[w] ^ refy[w])));
             while (diff) { const int b = __ffs(diff) - 1; diff &= diff - 1; atomicAdd(&cM[w * 32 + b], 1u); }
-            unsigned isn = ~v[w] & any[w];                      // N at a site where somebody is a base
-            while (isn) { const int b = __ffs(isn) - 1; isn &= isn - 1; atomicAdd(&cN[w * 32 + b], 1u); }
+            unsigned nb = isn[w] & any[w];                      // N at a site where somebody is not
+            while (nb) { const int b = __ffs(nb) - 1; nb &= nb - 1; atomicAdd(&cN[w * 32 + b], 1u); }
         }
     }
     __syncthreads();
@@ -341,19 +302,16 @@ static int decide(tracs_alignment *a, bool consensus, bool allow_minor, hipStrea
     uint4 *dense_mask = masks, *count_mask = masks + groups, *minor_mask = masks + 2 * groups, *full_mask = masks + 3 * groups;
     uint4 *ref_x = masks + 4 * groups, *ref_y = masks + 5 * groups;
     unsigned *off_dense = offs, *off_count = offs + groups, *off_minor = offs + 2 * groups, *off_full = offs + 3 * groups;
-    if (consensus) {
-        // a site goes to the lists while its k (cN + k) entries cost less than three operand planes over all pairs:
-        // ~51 ns per site at 10 000 samples (pair kernel) against ~2-4 ps per list entry (general_fixup_kernel)
-        const double b = (double)a->n * (double)a->n / 8000.0;
-        const unsigned budget = (no_minor || !allow_minor) ? 0u : (unsigned)std::min(1.0e9, std::max(16.0, b));
-        hipLaunchKernelGGL(classify_consensus_kernel, dim3((unsigned)groups), dim3(256), 0, stream, src, a->n_pad, (unsigned)a->n, budget,
+    // a site goes to the lists while its k (cN + k) entries cost less than the extra operand planes over all pairs:
+    // ~51 ns per site at 10 000 samples (pair kernel) against ~2-4 ps per list entry (general_fixup_kernel)
+    const double bsites = (double)a->n * (double)a->n / 8000.0;
+    const unsigned budget = (no_minor || !allow_minor) ? 0u : (unsigned)std::min(1.0e9, std::max(16.0, bsites));
+    if (consensus)
+        hipLaunchKernelGGL((classify_sites_kernel<true>), dim3((unsigned)groups), dim3(256), 0, stream, src, a->n_pad, (unsigned)a->n, budget,
                            dense_mask, count_mask, minor_mask, full_mask, ref_x, ref_y);
-    } else {
-        // general encoding: variable -> dense, invariant -> counted (v = complement of the N plane); no lists of its own
-        if (hipMemsetAsync(minor_mask, 0, 2 * groups * sizeof(uint4), stream) != hipSuccess) return soft_fail();
-        hipLaunchKernelGGL((classify_sites_kernel<false>), dim3((unsigned)groups), dim3(256), 0, stream, src, a->n_pad, (unsigned)a->n,
-                           dense_mask, count_mask);
-    }
+    else
+        hipLaunchKernelGGL((classify_sites_kernel<false>), dim3((unsigned)groups), dim3(256), 0, stream, src, a->n_pad, (unsigned)a->n, budget,
+                           dense_mask, count_mask, minor_mask, full_mask, ref_x, ref_y);
     stage("classify");
     hipLaunchKernelGGL(class_offsets_kernel, dim3(1), dim3(1024), 0, stream, dense_mask, groups, off_dense, totals + 0);
     hipLaunchKernelGGL(class_offsets_kernel, dim3(1), dim3(1024), 0, stream, count_mask, groups, off_count, totals + 1);
@@ -371,7 +329,7 @@ static int decide(tracs_alignment *a, bool consensus, bool allow_minor, hipStrea
     // matrix instructions per pair: planes_full per site now; planes_full per dense site + one per counted site with classes
     const double planes_full = consensus ? 4.0 : 5.0;
     const double cost = (planes_full * (double)L_dense + (double)L_count) / (planes_full * (double)a->L);
-    if ((force != 1 && cost >= 0.92) || (!consensus && L_dense == 0)) { cleanup(); return TRACS_OK; }
+    if (force != 1 && cost >= 0.92) { cleanup(); return TRACS_OK; }
 
     const int npv = consensus ? 3 : NPLANES;
     const size_t gv = groups_for(L_dense), gi = groups_for(L_count), gm = L_minor;
@@ -403,9 +361,9 @@ static int decide(tracs_alignment *a, bool consensus, bool allow_minor, hipStrea
     }
     stage("re-pack counted");
     if (gm) {
-        // the lists of the minority sites, read in place from the consensus planes (general_sparse.hip, MinorSrc)
+        // the lists of the minority sites, read in place from the planes (general_sparse.hip, MinorSrc / GeneralMinorSrc)
         int built = 0;
-        const int rc = minority_lists_build(a, src, minor_mask, ref_x, ref_y, off_minor, L_minor, stream, &built);
+        const int rc = minority_lists_build(a, consensus, src, minor_mask, ref_x, ref_y, off_minor, L_minor, stream, &built);
         stage("minority lists");
         if (rc) { cleanup(); site_classes_free(a); a->classes_state = -1; return rc; }
         if (!built) {                                          // lists too large / no memory: the same classes without them
