@@ -369,14 +369,19 @@ def general_pass(args, n, L, seed, dev, synth, torch, device):
     split, classes, pairs = pair_split_ms(_lib.load()), aln.site_classes, n * (n - 1) // 2
     traffic = _traffic_from_profiles(n, L, 1, aln.kernel + ("+classes" if classes else ""))
     if classes and split:
-        r = roofline_of(aln.kernel, "general", pairs, classes[0], (split[0] + split[1]) / 1e3, traffic)
-        r["count_pass"] = count_roofline(pairs, classes[1], max(split[2], 1e-3) / 1e3)
-        r["site_classes"] = {"dense": classes[0], "counted": classes[1], "empty": L - classes[0] - classes[1]}
+        main = roofline_of(aln.kernel, "general", pairs, classes[0], max(split[0], 1e-3) / 1e3, None)
+        cnt = count_roofline(pairs, classes[1], max(split[2], 1e-3) / 1e3)
+        r, other = (cnt, main) if split[2] > split[0] else (main, cnt)
+        r["other_matrix_core_kernel"] = {k: other[k] for k in ("kernel", "kernel_ms", "achieved", "frac", "unit") if k in other}
+        r["lists_ms"] = split[1]
+        r["site_classes"] = {"dense": classes[0], "counted": classes[1], "minority": classes[2], "full": classes[3],
+                             "empty": L - classes[0] - classes[1] - classes[3]}
     else:
         r = roofline_of(aln.kernel, "general", pairs, L, kern_s, traffic)
     r["dense_call_ms"] = kern_s * 1e3
     if split:
-        r["kernels_ms"] = {"pairsnp_mfma_kernel": split[0], "general_fixup_kernel": split[1], "count_pass": split[2]}
+        r["kernels_ms"] = {"pairsnp_mfma_kernel": split[0], "general_fixup_kernel (partial codes of the dense sites + minority lists)": split[1],
+                           "count_pass": split[2]}
     r["workload"] = "the same alignment + %.3g partial IUPAC codes per site (uniformly random sites and codes)" % P_PARTIAL_C4
     r["mean_d"] = float(dmat.sum().item()) / (n * (n - 1) // 2)
     aln.close()
