@@ -20,6 +20,7 @@
 #include "pairsnp_kernels.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace tracs {
@@ -501,7 +502,9 @@ static int gs_build(const SRC src, size_t n, size_t L, size_t groups, double max
     GS_TRY(hipMemcpyAsync(&est, d_est, 8, hipMemcpyDeviceToHost, stream));
     GS_TRY(hipStreamSynchronize(stream));
     if (tot_s != tot_p + tot_n) { tmp_free(); gs_free(g); set_error("general_sparse: list totals disagree (internal error)"); return TRACS_E_HIP; }
-    if ((double)tot_s > max_entries) return fail_soft();
+    // TRACS_LIST_CAP=<entries>: a smaller cap (diagnostics: exercises the paths taken when the lists are refused)
+    static const double env_cap = [] { const char *e = std::getenv("TRACS_LIST_CAP"); return e ? std::atof(e) : -1.0; }();
+    if ((double)tot_s > (env_cap >= 0.0 ? std::min(env_cap, max_entries) : max_entries)) return fail_soft();
     GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->s_ent), std::max<size_t>(tot_s, 1) * 4));
     GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->p_ent), std::max<size_t>(tot_p, 1) * 4));
     GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->n_ent), std::max<size_t>(tot_n, 1) * 4));
