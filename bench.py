@@ -89,11 +89,16 @@ def pair_split_ms(lib):
 
 def count_roofline(pairs_per_launch, L_inv, count_s):
     flop = float(pairs_per_launch) * L_inv * COUNT_FLOP_PER_SITE
+    alg_bytes = float(pairs_per_launch) * L_inv * 0.25            # two samples x one bit plane = L / 4 bytes per pair
     return {"kernel": "pairsnp_mfma_kernel<COUNT>", "kernel_ms": count_s * 1e3, "sites": L_inv, "bound": "mfma", "traffic": None,
             "algorithmic_flop_per_pair": L_inv * COUNT_FLOP_PER_SITE, "measured_fp4_ceiling": MFMA_FP4_MEASURED / 1e12,
             "frac_of_measured_fp4_ceiling": flop / count_s / MFMA_FP4_MEASURED,
             "achieved": flop / count_s / 1e12, "peak": MFMA_FP4_PEAK / 1e12, "unit": "TFLOP/s", "frac": flop / count_s / MFMA_FP4_PEAK,
-            "note": "nn += sum v_i v_j over the invariant sites: one fp4 operand plane, %g flop per pair and site" % COUNT_FLOP_PER_SITE}
+            "hbm": {"achieved": alg_bytes / count_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg_bytes / count_s / HBM_PEAK,
+                    "algorithmic_bytes_per_pair": L_inv * 0.25,
+                    "note": "no-tile-reuse byte count in the manner of SURVEY 8d (one plane of two samples per pair); every byte fetched "
+                            "is shared by a whole tile from LDS, so achieved > peak and the matrix pipe is what binds"},
+            "note": "nn += sum v_i v_j over the counted sites: one fp4 operand plane, %g flop per pair and site" % COUNT_FLOP_PER_SITE}
 
 
 def roofline_of(kernel, enc, pairs_per_launch, L, kern_s, traffic):
