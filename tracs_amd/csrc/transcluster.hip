@@ -22,6 +22,7 @@
 namespace tracs {
 
 constexpr int LG_TABLE = 32768;     // lgamma(n) table, n < LG_TABLE; beyond: lgamma() inline
+constexpr int LK_TABLE = 10240;     // log(k) table behind it (the E(K) loop stops at k = 10 000): lg[LG_TABLE + k] = log(k)
 
 struct TcParams {
     double lamb, beta, thr;
@@ -131,73 +132,72 @@ __device__ bool tc_eval(int N, double delta, const TcParams &P, const double *__
 // are log-space prefix sums, so a step is: per-lane terms, three inclusive wave scans with logaddexp, the
 // reference's stopping test on every lane's prefix, and a ballot for the first lane that satisfies it.
 // Summation order differs from the serial loop by rounding only (all terms positive).
-// inclusive log-space prefix sum across the wave: ln sum_{l' <= l} exp(v_l').  Done in linear space relative to the
-// wave maximum (one exp and one log per lane instead of a logaddexp per scan step); terms more than ~700 below the
-// maximum underflow to 0, which is below double precision of the sum anyway.
-__device__ __forceinline__ double wave_scan_lae(double v, int lane)
-{
-    double m = v;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
-    if (m == -INFINITY) return -INFINITY;
-    double e = exp(v - m);
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const double o = __shfl_up(e, off, 64);
-        if (lane >= off) e += o;
-    }
-    return m + log(e);
-}
-
 // Resumes the serial loop of tc_eval at k = k_start from its running sums `state` = {pois, lnS, lprob, elprob}.
+// The three running sums (S, lprob's and elprob's) are kept in LINEAR space, each in units of exp(its running maximum): a step
+// costs one exp per lane and sum (exp(term - maximum)) and one log per lane for ln S; when a step's largest term exceeds the
+// running maximum the sum is rescaled once (wave-uniform).  All terms are positive, the scaled sums stay within [1, 64 x terms),
+// and only rounding differs from the reference's log-space fold (:207-232).  The stopping test upper - elprob_linear > thr is
+// evaluated in the same units: elprob_scaled < (upper - thr) exp(-maximum), the right-hand side refreshed when the maximum moves.
 __device__ void tc_eval_wave(int N, double delta, const TcParams &P, const double *__restrict__ lg, double &eK,
                              const double *__restrict__ state, int k_start)
 {
     const int lane = threadIdx.x & 63;
     const double n1 = (double)(N + 1);
     const double lg_n1 = lg_at(lg, (long long)N + 1);
+    const double *__restrict__ lkt = lg + LG_TABLE;                    // log(k), k < LK_TABLE
     const bool pos = delta > 0;
     const double pois = state[0];
-    double lnS = state[1], ld = 0.0, upper;
+    double ld = 0.0, upper;
     if (pos) {
         ld = log(delta);
         upper = exp(P.ln_beta + delta * P.lamb + log(n1) - (P.ln_lamb + pois));
     } else {
         upper = exp(P.ln_beta + log(n1) - P.ln_lamb);
     }
-    // lprob and elprob run in LINEAR space here (sums of positive terms: exp(t - max) per lane, one wave prefix sum, scaled back by
-    // exp(max)): a step costs one exp per lane and sum instead of an exp, a log and a logaddexp; the values stay far inside the double
-    // range (lprob's terms are k P(k | N) <= 1e4, elprob's are bounded by `upper`), and only rounding differs from the log-space fold.
-    double Lp = exp(state[2]), El = exp(state[3]);
-    auto scan_lin = [&](double t) {                                   // inclusive prefix sums of exp(t_l), this wave
-        double m = t;
+    auto wave_max = [&](double v) {
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
-        if (m == -INFINITY) return 0.0;
-        double e = exp(t - m);
+        for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+        return v;
+    };
+    auto wave_prefix = [&](double e) {                                // inclusive prefix sums across the wave
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const double o = __shfl_up(e, off, 64);
             if (lane >= off) e += o;
         }
-        return e * exp(m);
+        return e;
+    };
+    // sum = scaled * exp(mx); an empty sum is (0, -inf)
+    double Ms = state[1], Ss = Ms == -INFINITY ? 0.0 : 1.0;
+    double Mp = state[2], Lps = Mp == -INFINITY ? 0.0 : 1.0;
+    double Me = state[3], Els = Me == -INFINITY ? 0.0 : 1.0;
+    double lim = Me == -INFINITY ? INFINITY : (upper - P.thr) * exp(-Me);
+    // one more term batch into a scaled sum: returns every lane's inclusive prefix (in the possibly moved units)
+    auto accumulate = [&](double t, double &scaled, double &mx, bool &moved) {
+        const double m = wave_max(t);
+        moved = m > mx;
+        if (moved) { scaled = mx == -INFINITY ? 0.0 : scaled * exp(mx - m); mx = m; }
+        const double e = t == -INFINITY ? 0.0 : exp(t - mx);
+        return scaled + wave_prefix(e);
     };
     for (int k0 = k_start; k0 < 10000; k0 += 64) {
         const int k = k0 + lane;
         const bool live = k < 10000;
         const long long M = (long long)N + k;
         const double m1 = (double)(M + 1) * P.ln_lb;
-        const double lk = log((double)k);
+        const double lk = lkt[live ? k : 0];
         double t1, t2;
+        bool moved;
         if (pos) {
-            double a = live ? imul(M, ld) + (double)M * P.ln_lb - lg_at(lg, M + 1) : -INFINITY;
-            const double Sk = lae(lnS, wave_scan_lae(a, lane));
+            const double a = live ? imul(M, ld) + (double)M * P.ln_lb - lg_at(lg, M + 1) : -INFINITY;
+            const double Sl = accumulate(a, Ss, Ms, moved);
+            const double Sk = Ms + log(Sl);
             double lhs = (n1 * P.ln_lamb + (double)k * P.ln_beta + lg_at(lg, M + 1));
             lhs = lhs - lg_n1 - lg_at(lg, (long long)k + 1) - delta * P.beta;
             lhs -= pois;
             t1 = (lhs + (Sk - m1)) + lk;
             t2 = lhs + lk + delta * (P.lamb + P.beta) - m1;
-            lnS = __shfl(Sk, 63, 64);
+            Ss = __shfl(Sl, 63, 64);
         } else {
             const double lhs = (n1 * P.ln_lamb + (double)k * P.ln_beta + lg_at(lg, M + 1) - lg_n1 -
                                 lg_at(lg, (long long)k + 1) - m1);
@@ -205,26 +205,27 @@ __device__ void tc_eval_wave(int N, double delta, const TcParams &P, const doubl
             t2 = lhs + lk + delta * (P.lamb + P.beta) - m1;
         }
         if (!live) { t1 = -INFINITY; t2 = -INFINITY; }
-        const double lp = Lp + scan_lin(t1);
-        const double el = El + scan_lin(t2);
-        const double diff = upper - el;
-        const bool stop = live && !(diff > P.thr);                     // the while condition fails after this k
+        const double lp = accumulate(t1, Lps, Mp, moved);
+        const double el = accumulate(t2, Els, Me, moved);
+        if (moved) lim = (upper - P.thr) * exp(-Me);
+        const bool stop = live && !(el < lim);                         // the while condition (upper - elprob > thr) fails after this k
         const unsigned long long m = __ballot(stop);
         if (m) {
             const int f = __ffsll((long long)m) - 1;
-            eK = __shfl(lp, f, 64);
+            eK = __shfl(lp, f, 64) * exp(Mp);
             return;
         }
-        Lp = __shfl(lp, 63, 64);
-        El = __shfl(el, 63, 64);
+        Lps = __shfl(lp, 63, 64);
+        Els = __shfl(el, 63, 64);
     }
-    eK = Lp;                                                           // ran to k = 9999
+    eK = Lps * exp(Mp);                                                // ran to k = 9999
 }
 
 __global__ void lgamma_table_kernel(double *__restrict__ lg, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) lg[i] = lgamma((double)i);   // lg[0] = +inf like std::lgamma(0.0) (:255-257)
+    else if (i < n + LK_TABLE) lg[i] = log((double)(i - n));
 }
 
 // ---- key sources ------------------------------------------------------------------------
@@ -474,8 +475,8 @@ static int get_lgamma_table(hipStream_t stream, const double **out)
     if (dev < 0 || dev >= 64) { set_error("device index out of range"); return TRACS_E_HIP; }
     if (!g_lg[dev]) {
         double *p = nullptr;
-        TRACS_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p), LG_TABLE * sizeof(double)));
-        hipLaunchKernelGGL(lgamma_table_kernel, dim3((LG_TABLE + 255) / 256), dim3(256), 0, stream, p, LG_TABLE);
+        TRACS_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p), (LG_TABLE + LK_TABLE) * sizeof(double)));
+        hipLaunchKernelGGL(lgamma_table_kernel, dim3((LG_TABLE + LK_TABLE + 255) / 256), dim3(256), 0, stream, p, LG_TABLE);
         TRACS_HIP_CHECK(hipGetLastError());
         TRACS_HIP_CHECK(hipStreamSynchronize(stream));
         g_lg[dev] = p;
