@@ -138,22 +138,18 @@ __device__ bool tc_eval(int N, double delta, const TcParams &P, const double *__
 // running maximum the sum is rescaled once (wave-uniform).  All terms are positive, the scaled sums stay within [1, 64 x terms),
 // and only rounding differs from the reference's log-space fold (:207-232).  The stopping test upper - elprob_linear > thr is
 // evaluated in the same units: elprob_scaled < (upper - thr) exp(-maximum), the right-hand side refreshed when the maximum moves.
+// A key handed over without any term summed (state[0] is NaN: tc_keys_kernel does that for delta > 0 and N >= TC_WAVE_PREFIX_MIN)
+// starts here with the two O(N) prefix sums of the loop -- pois (:144-148) and S_N -- as wave sums of 64 terms per step instead of a
+// serial fold, and p0 (the k = 0 value, :276-282) comes back through `p0_out`.
 __device__ void tc_eval_wave(int N, double delta, const TcParams &P, const double *__restrict__ lg, double &eK,
-                             const double *__restrict__ state, int k_start)
+                             const double *__restrict__ state, int k_start, double *p0_out)
 {
     const int lane = threadIdx.x & 63;
     const double n1 = (double)(N + 1);
     const double lg_n1 = lg_at(lg, (long long)N + 1);
     const double *__restrict__ lkt = lg + LG_TABLE;                    // log(k), k < LK_TABLE
     const bool pos = delta > 0;
-    const double pois = state[0];
-    double ld = 0.0, upper;
-    if (pos) {
-        ld = log(delta);
-        upper = exp(P.ln_beta + delta * P.lamb + log(n1) - (P.ln_lamb + pois));
-    } else {
-        upper = exp(P.ln_beta + log(n1) - P.ln_lamb);
-    }
+    const bool fresh = state[0] != state[0];
     auto wave_max = [&](double v) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
@@ -167,11 +163,6 @@ __device__ void tc_eval_wave(int N, double delta, const TcParams &P, const doubl
         }
         return e;
     };
-    // sum = scaled * exp(mx); an empty sum is (0, -inf)
-    double Ms = state[1], Ss = Ms == -INFINITY ? 0.0 : 1.0;
-    double Mp = state[2], Lps = Mp == -INFINITY ? 0.0 : 1.0;
-    double Me = state[3], Els = Me == -INFINITY ? 0.0 : 1.0;
-    double lim = Me == -INFINITY ? INFINITY : (upper - P.thr) * exp(-Me);
     // one more term batch into a scaled sum: returns every lane's inclusive prefix (in the possibly moved units)
     auto accumulate = [&](double t, double &scaled, double &mx, bool &moved) {
         const double m = wave_max(t);
@@ -180,6 +171,43 @@ __device__ void tc_eval_wave(int N, double delta, const TcParams &P, const doubl
         const double e = t == -INFINITY ? 0.0 : exp(t - mx);
         return scaled + wave_prefix(e);
     };
+    // sum = scaled * exp(mx); an empty sum is (0, -inf)
+    double pois, ld = 0.0, upper;
+    double Ms, Ss, Mp, Lps, Me, Els;
+    if (fresh) {                                                       // (delta > 0)
+        const double lx = log(P.lamb * delta);
+        ld = log(delta);
+        // two sweeps over the lane's own terms (i = lane, lane + 64, ..): the largest term first, then sum exp(term - largest) --
+        // one exp per term and no cross-lane traffic until the two wave reductions at the end
+        auto term_q = [&](long long i) { return imul(i, lx) - lg_at(lg, i + 1); };
+        auto term_a = [&](long long i) { return imul(i, ld) + (double)i * P.ln_lb - lg_at(lg, i + 1); };
+        double Mq = -INFINITY;
+        Ms = -INFINITY;
+        for (long long i = lane; i <= N; i += 64) { Mq = fmax(Mq, term_q(i)); Ms = fmax(Ms, term_a(i)); }
+        Mq = wave_max(Mq); Ms = wave_max(Ms);
+        double Qs = 0.0;
+        Ss = 0.0;
+        for (long long i = lane; i <= N; i += 64) { Qs += exp(term_q(i) - Mq); Ss += exp(term_a(i) - Ms); }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { Qs += __shfl_xor(Qs, off, 64); Ss += __shfl_xor(Ss, off, 64); }
+        pois = Mq + log(Qs);
+        const double lnS = Ms + log(Ss);
+        double l0 = (n1 * P.ln_lamb + 0.0 * P.ln_beta + lg_n1);
+        l0 = l0 - lg_n1 - lg_at(lg, 1) - delta * P.beta;
+        l0 -= pois;
+        *p0_out = l0 + (lnS - n1 * P.ln_lb);
+        Mp = -INFINITY; Lps = 0.0; Me = -INFINITY; Els = 0.0;
+        k_start = 1;
+    } else {
+        pois = state[0];
+        Ms = state[1]; Ss = Ms == -INFINITY ? 0.0 : 1.0;
+        Mp = state[2]; Lps = Mp == -INFINITY ? 0.0 : 1.0;
+        Me = state[3]; Els = Me == -INFINITY ? 0.0 : 1.0;
+        if (pos) ld = log(delta);
+    }
+    if (pos) upper = exp(P.ln_beta + delta * P.lamb + log(n1) - (P.ln_lamb + pois));
+    else upper = exp(P.ln_beta + log(n1) - P.ln_lamb);
+    double lim = Me == -INFINITY ? INFINITY : (upper - P.thr) * exp(-Me);
     for (int k0 = k_start; k0 < 10000; k0 += 64) {
         const int k = k0 + lane;
         const bool live = k < 10000;
@@ -347,6 +375,7 @@ __global__ void dedup_collect_kernel(const unsigned *__restrict__ slots, unsigne
 }
 
 constexpr int TC_SERIAL_CAP = 192;      // terms evaluated by the one-thread-per-key kernel before a key is handed over
+constexpr int TC_WAVE_PREFIX_MIN = 128; // delta > 0 and N at least this: the whole key goes to the wave kernel (O(N) prefix included)
 
 template <class Src>
 __global__ void tc_keys_kernel(Src src, const unsigned *__restrict__ key_elem, unsigned nk, TcParams P,
@@ -364,6 +393,11 @@ __global__ void tc_keys_kernel(Src src, const unsigned *__restrict__ key_elem, u
             if (!kt.mine(N, gap)) { key_p0[id] = 0.0; key_eK[id] = 0.0; continue; }      // another rank's key
             slot = kt.index(N, gap);
         }
+        if (d > 0 && N >= TC_WAVE_PREFIX_MIN) {                       // nothing summed here: the wave kernel does the prefix too
+            key_state[4 * (size_t)id] = __builtin_nan("");
+            long_ids[atomicAdd(n_long, 1u)] = id;
+            continue;
+        }
         double p0, eK = 0.0; int ks;
         const bool done = tc_eval(N, d, P, lg, p0, eK, ks, TC_SERIAL_CAP, key_state + 4 * (size_t)id);
         key_p0[id] = p0;
@@ -377,8 +411,8 @@ template <class Src>
 __global__ __launch_bounds__(64) void tc_long_keys_kernel(Src src, const unsigned *__restrict__ key_elem,
                                                           const unsigned *__restrict__ long_ids,
                                                           const unsigned *__restrict__ n_long, TcParams P,
-                                                          const double *__restrict__ lg, double *__restrict__ key_eK,
-                                                          const double *__restrict__ key_state, KeyTable kt)
+                                                          const double *__restrict__ lg, double *__restrict__ key_p0,
+                                                          double *__restrict__ key_eK, const double *__restrict__ key_state, KeyTable kt)
 {
     P.ln_lamb = log(P.lamb); P.ln_beta = log(P.beta); P.ln_lb = log(P.lamb + P.beta);
     const unsigned nl = *n_long;
@@ -387,11 +421,17 @@ __global__ __launch_bounds__(64) void tc_long_keys_kernel(Src src, const unsigne
         int N; double d;
         const size_t elem = (size_t)key_elem[id];
         src.get(elem, N, d);
-        double eK;
-        tc_eval_wave(N, d, P, lg, eK, key_state + 4 * (size_t)id, TC_SERIAL_CAP);
+        double eK, p0 = 0.0;
+        const double *st = key_state + 4 * (size_t)id;
+        const bool fresh = st[0] != st[0];
+        tc_eval_wave(N, d, P, lg, eK, st, TC_SERIAL_CAP, &p0);
         if ((threadIdx.x & 63) == 0) {
             key_eK[id] = eK;
-            if (kt.p0) { const long long slot = kt.index(N, src.day_gap(elem)); if (slot >= 0) kt.eK[slot] = eK; }
+            if (fresh) key_p0[id] = p0;
+            if (kt.p0) {
+                const long long slot = kt.index(N, src.day_gap(elem));
+                if (slot >= 0) { kt.eK[slot] = eK; if (fresh) kt.p0[slot] = p0; }
+            }
         }
     }
 }
@@ -552,7 +592,7 @@ static int run_trans_dist(const Src &src, size_t total, double lamb, double beta
                        long_ids, n_keys + 1, key_state, kt);
     // long series (E(K) loop beyond TC_SERIAL_CAP terms): one wave per key
     hipLaunchKernelGGL((tc_long_keys_kernel<Src>), dim3(std::min<unsigned>(nk, 256u * 32u)), dim3(64), 0, stream, src, key_elem,
-                       long_ids, n_keys + 1, P, lg, key_eK, key_state, kt);
+                       long_ids, n_keys + 1, P, lg, key_p0, key_eK, key_state, kt);
     if (p0 && eK)                        // (the key-table form fills its table only)
         hipLaunchKernelGGL((tc_gather_kernel<Src>), dim3(blocks), dim3(256), 0, stream, src, eslot, slot_id, key_p0, key_eK,
                            exp_p0, p0, eK);
