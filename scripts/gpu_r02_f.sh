@@ -4,8 +4,8 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r02final
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 2400 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pytest rc $?" >> $OUT/pytest.log
-tail -4 $OUT/pytest.log
+timeout 2400 python -m pytest tests -m gpu -x -q --durations=30 > $OUT/pytest.log 2>&1; echo "pytest rc $?" >> $OUT/pytest.log
+grep -A34 "slowest" $OUT/pytest.log | head -40; tail -3 $OUT/pytest.log
 timeout 1500 python bench.py --steps 3 --warmup 1 > $OUT/bench_c3.log 2>&1; tail -1 $OUT/bench_c3.log > $OUT/bench_c3.json; cut -c1-300 $OUT/bench_c3.json
 TRACS_SITE_CLASSES=0 timeout 900 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras 2>&1 | tail -1 > $OUT/bench_c3_whole.json
 TRACS_MINORITY=0 timeout 900 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras 2>&1 | tail -1 > $OUT/bench_c3_nolists.json

@@ -74,6 +74,23 @@ def transcluster():
     jdump("transcluster_golden.json", out)
 
 
+def transcluster_large_n():
+    """Keys with hundreds to thousands of SNPs (the bench workload's range: mean d ~ 1 000) through oracle/_ref: these take the
+    device's wave-per-key kernel from their first term (csrc/transcluster.hip, TC_WAVE_PREFIX_MIN).  A file of its own so the
+    older fixtures stay byte-identical."""
+    rng = np.random.default_rng(20261002)
+    grids = []
+    for lamb, beta, thr in ((1e-3 * 29903, 73.0, 0.01), (5.3, 6.0, 0.01)):
+        N = np.concatenate([[128, 129, 191, 192, 193, 1000], rng.integers(128, 1600, 40)]).astype(int)
+        days = np.concatenate([[1, 30, 365, 700, 2, 3], rng.integers(1, 700, N.size - 6)])
+        delta = days.astype(np.float64) * 86400.0 / 31556952.0
+        p0, ek = R.ref_trans_dist(N.tolist(), delta.tolist(), lamb, beta, thr)
+        cls = [O.ek_conditioning(int(n), float(d), lamb, beta, thr)[0] for n, d in zip(N, delta)]
+        grids.append({"lamb": lamb, "beta": beta, "thr": thr, "N": N.tolist(), "days": days.tolist(),
+                      "delta": delta.tolist(), "p0": list(p0), "eK": list(ek), "conditioning": cls})
+    jdump("transcluster_golden_large_n.json", {"trans_dist": grids})
+
+
 def posteriors():
     counts = synth.allele_counts(4000, seed=11, depth=20, p_two=0.08).astype(np.float64)
     counts[:40] = 0
@@ -233,7 +250,11 @@ def python_reference():
 
 
 if __name__ == "__main__":
+    if sys.argv[1:] == ["large-n"]:              # only the fixture added in round 2
+        transcluster_large_n()
+        sys.exit(0)
     transcluster()
+    transcluster_large_n()
     posteriors()
     kseq()
     pairsnp_unpinned()

@@ -74,6 +74,24 @@ def test_trans_dist_golden(api, oracle, golden_dir):
         json.dump(summary, fh, indent=1)
 
 
+def test_trans_dist_golden_large_n(api, golden_dir):
+    """Keys with 128 .. 1 600 SNPs -- the ones the wave-per-key kernel takes from their first term (csrc/transcluster.hip) --
+    against oracle/_ref goldens (tests/golden/make_golden.py large-n): all 'well' conditioned, p0 and E(K) at 1e-6 relative
+    (BASELINE.json north_star), observed far tighter."""
+    g = _load(golden_dir, "transcluster_golden_large_n.json")
+    worst_p, worst_e = 0.0, 0.0
+    for grid in g["trans_dist"]:
+        N, delta = np.array(grid["N"], np.int32), np.array(grid["delta"])
+        assert set(grid["conditioning"]) == {"well"}
+        p0, ek = api.trans_dist_arrays(N, delta, grid["lamb"], grid["beta"], grid["thr"])
+        rp = np.abs(p0 - grid["p0"]) / np.abs(grid["p0"])
+        re = np.abs(ek - grid["eK"]) / np.abs(grid["eK"])
+        worst_p, worst_e = max(worst_p, float(rp.max())), max(worst_e, float(re.max()))
+        assert rp.max() < 1e-9 and re.max() < 1e-6, (float(rp.max()), float(re.max()))
+    print("large-N keys: max relative deviation from the reference build: p0 %.2e, E(K) %.2e" % (worst_p, worst_e))
+    assert worst_e < 1e-8
+
+
 def test_lprob_golden(api, golden_dir):
     from scipy.special import gammaln
     g = _load(golden_dir, "transcluster_golden.json")["lprob"]

@@ -95,16 +95,16 @@ def test_trans_dist_matches_oracle(api, oracle):
     rng = np.random.default_rng(11)
     total = {}
     for lamb, beta in ((1e-3 * 29903, 73.0), (5.3, 6.0), (3.0, 52.0)):
-        N = rng.integers(0, 80, 1500).astype(np.int32)
-        days = rng.integers(0, 500, 1500)
-        days[:100] = 0                                    # delta == 0 branch
+        N = rng.integers(0, 80, 700).astype(np.int32)     # (the oracle is serial like the reference: this test is CPU time)
+        days = rng.integers(0, 500, 700)
+        days[:50] = 0                                     # delta == 0 branch
         delta = days.astype(np.float64) * 86400.0 / 31556952.0
         p0, ek = api.trans_dist_arrays(N, delta, lamb, beta, 0.01)
         counts = check_trans_dist(oracle, N, delta, lamb, beta, 0.01, p0, ek)
         for k, v in counts.items():
             total[k] = total.get(k, 0) + v
     print("E(K) keys by conditioning:", total)
-    assert total.get("well", 0) > 1000 and total.get("saturated", 0) > 10
+    assert total.get("well", 0) > 450 and total.get("saturated", 0) > 4
 
 
 def test_trans_dist_reference_known_answers(api):

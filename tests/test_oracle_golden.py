@@ -51,6 +51,22 @@ def test_trans_dist_vs_reference_build(oracle, golden_dir):
     assert n_cmp > 250 and n_ill < 40 and n_sat > 20
 
 
+def test_trans_dist_large_n_vs_reference_build(oracle, golden_dir):
+    """Keys with hundreds to thousands of SNPs (the bench workload's range) against oracle/_ref goldens; a dozen of them here
+    (the oracle re-folds an O(N + k) sum for every k like the reference: ~0.3 s per key), all of them on the GPU
+    (tests/test_gpu_golden.py::test_trans_dist_golden_large_n)."""
+    g = _load(golden_dir, "transcluster_golden_large_n.json")
+    for grid in g["trans_dist"]:
+        sel = list(range(6)) + [10, 20, 30]
+        N = np.array(grid["N"], np.int32)[sel]
+        delta = np.array(grid["delta"])[sel]
+        p0, ek = oracle.trans_dist(N, delta, grid["lamb"], grid["beta"], grid["thr"])
+        assert np.allclose(p0, np.array(grid["p0"])[sel], rtol=1e-10, atol=0)
+        for k, i in enumerate(sel):
+            assert grid["conditioning"][i] == "well"
+            assert abs(ek[k] - grid["eK"][i]) <= 1e-9 * abs(grid["eK"][i]), (grid["lamb"], N[k], delta[k])
+
+
 def test_lprob_functions_vs_reference_build(oracle, golden_dir):
     from scipy.special import gammaln
     g = _load(golden_dir, "transcluster_golden.json")["lprob"]
