@@ -5,13 +5,18 @@
 //   pair loop :395-420  (match/popcount, compared sites)        -> pairsnp_mfma_kernel (pairsnp_mfma.hip), pairsnp_tile_kernel
 //   emit d <= dist :405, row-major order :451-455               -> coo_count/coo_fill
 //
-// Which kernel runs (pairsnp_dense_impl):
-//   consensus alignments (no partial IUPAC code anywhere)       matrix-core kernel, operands x, y, z, v (3 planes)
-//   general alignments, plain pass                              matrix-core kernel, one-hot operands (5 planes) + the sparse
+// What a dense call launches (pairsnp_dense_impl):
+//   once per pack                                               the encoding (consensus: no partial IUPAC code anywhere) and the
+//                                                               site classes (site_classes.hip): dense / counted / full / minority
+//   sites read by the pair kernel (the dense class, or every site when the classes are not used)
+//     consensus alignments                                      matrix-core kernel, operands x, y, z, v (3 planes)
+//     general alignments                                        matrix-core kernel, one-hot operands (5 planes) + the sparse
 //                                                               partial-code correction of general_sparse.hip
-//   general alignments, thresholded pass / fallbacks            pairsnp_tile_kernel: integer VALU, one workgroup per TI x TJ tile,
+//     lists unavailable / TRACS_MFMA=0                          pairsnp_tile_kernel: integer VALU, one workgroup per TI x TJ tile,
 //                                                               row and column samples staged HBM -> LDS directly, per 32 sites
 //                                                               and pair v_and, 3 x v_bitop3 (and-or), v_bcnt(+acc), v_or, v_bcnt
+//   minority sites                                              general_fixup_kernel<MINOR>: distances from sparse lists
+//   counted / full sites                                        pairsnp_mfma_kernel<COUNT>: compared-sites counts, one operand plane
 #include "pairsnp_kernels.h"
 
 #include <algorithm>

@@ -28,6 +28,10 @@
 //              onto 0100); the per-instruction block scale (2^+2, 2^0, 2^-2) makes every product exactly 1:
 //              5 VALU ops per (sample, plane, 32 sites).
 //
+//   COUNT form (site classes, site_classes.hip): one stored plane v = "this sample is not N here" over the sites that only need
+//     their compared-sites count: nn += sum v v' with the general form's residue-class operands; one accumulator set, so four
+//     waves fit a SIMD; its own workgroup tiles (CountShape).
+//
 // Structure: a workgroup = NWR x NWC waves (2 x 2 for the consensus form, 4 x 2 for the general one, which is the
 // memory-hungrier); each wave owns NBR x NBC blocks of 32 x 32 pairs (two fp32 accumulator sets).  The wave tile sets the
 // VALU : MFMA ratio -- (NBR + NBC) expansions feed 4 NBR NBC (5 NBR NBC) instructions -- but larger wave tiles mean one wave
