@@ -44,6 +44,7 @@ struct MfmaArgs {
     size_t ld;
     unsigned thr;
     TilePhase ph;
+    const unsigned *c_n = nullptr;   // counting form: per sample, its N sites among the counted sites
     int keep_bound = 0;        // consensus form, thresholded runs: dead cells keep their lower bound instead of the 0xFFFFFFFF flag
                                // (terms are added to the cells afterwards: minority sites)
 };

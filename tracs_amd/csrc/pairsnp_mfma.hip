@@ -28,9 +28,10 @@
 //              onto 0100); the per-instruction block scale (2^+2, 2^0, 2^-2) makes every product exactly 1:
 //              5 VALU ops per (sample, plane, 32 sites).
 //
-//   COUNT form (site classes, site_classes.hip): one stored plane v = "this sample is not N here" over the sites that only need
-//     their compared-sites count: nn += sum v v' with the general form's residue-class operands; one accumulator set, so four
-//     waves fit a SIMD; its own workgroup tiles (CountShape).
+//   COUNT form (site classes, site_classes.hip): one stored plane n = "this sample is N here" over the sites that only need
+//     their compared-sites count: NN = sum n n' with the general form's residue-class operands, nn += sites - c_i - c_j + NN
+//     (the complement plane "is a base here" would do without the c terms, but the matrix pipe holds a higher clock on
+//     mostly-zero operands); one accumulator set, so four waves fit a SIMD; its own workgroup tiles (CountShape).
 //
 // Structure: a workgroup = NWR x NWC waves (2 x 2 for the consensus form, 4 x 2 for the general one, which is the
 // memory-hungrier); each wave owns NBR x NBC blocks of 32 x 32 pairs (two fp32 accumulator sets).  The wave tile sets the
@@ -57,8 +58,8 @@ __device__ __forceinline__ mfma_v8i fp4_operand(const unsigned (&w)[4])
 #define TRACS_MFMA_FP4(ACC, A_, B_, SC) \
     ACC = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A_, B_, ACC, 4, 4, 0, SC, 0, SC)
 
-// COUNT: the one-operand pass over the invariant sites of an alignment cut into site classes (site_classes.hip): a single
-// stored plane v ("this sample is a base here"), nn += sum v v' with the general form's residue-class operands, nothing else.
+// COUNT: the one-operand pass over the counted sites of an alignment cut into site classes (site_classes.hip): a single
+// stored plane n ("this sample is N here"), NN = sum n n' with the general form's residue-class operands, nothing else.
 template <bool GENERAL, int NBR, int NBC, int GC, int NWR = 2, int NWC = 2, bool COUNT = false>
 __global__ __launch_bounds__(NWR * NWC * 64, (NBR * NBC > 4 ? 1 : COUNT ? 4 : 2)) void pairsnp_mfma_kernel(const MfmaArgs A)
 {
@@ -395,7 +396,9 @@ __global__ __launch_bounds__(NWR * NWC * 64, (NBR * NBC > 4 ? 1 : COUNT ? 4 : 2)
                 if (i < A.row_end && j < A.n && j > i && j >= A.col_begin) {
                     const int V = (int)accV[rb][cb][r];
                     if constexpr (COUNT) {                     // the cells hold the variable sites' counts already;
-                        atomicAdd(&A.ncomp[(size_t)i * A.ld + j], (unsigned)V + (ks == 0 ? A.L : 0u));   // A.L: sites without any N
+                        // operand plane n = "is N here" (mostly zero words): NN = sum n n', and nn = sites - c_i - c_j + NN
+                        // (A.L: the counted sites + the sites without any N, added once per cell by range 0)
+                        atomicAdd(&A.ncomp[(size_t)i * A.ld + j], (unsigned)V + (ks == 0 ? A.L - A.c_n[i] - A.c_n[j] : 0u));
                         continue;
                     }
                     const int S = (int)accS[rb][cb][r];

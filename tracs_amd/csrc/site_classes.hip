@@ -11,8 +11,8 @@
 //     empty      every sample is N (or the tail bits behind L): contributes to nothing;
 //     dense      k (cN + k) above the budget below: the usual pair kernel, over `vplanes` -- these sites re-packed in site
 //                order, same planes and layout as the kernels' usual source;
-//     counted    every other site with cN >= 1: nn += sum v_i v_j over `iplanes` (ONE plane, v = "this sample is a base
-//                here"; pairsnp_mfma_kernel<COUNT>, one operand plane instead of four or five);
+//     counted    every other site with cN >= 1: NN = sum n_i n_j over `iplanes` (ONE plane, n = "this sample is N here";
+//                pairsnp_mfma_kernel<COUNT>, one operand plane instead of four or five) and nn += sites - c_i - c_j + NN;
 //     full       every other site with cN = 0: +1 to every nn, a constant;
 //     minority   the counted / full sites with k >= 1: d gets their contribution from sparse lists -- the k samples with their
 //                allele masks, the cN samples -- with the machinery general_sparse.hip uses for partial IUPAC codes
@@ -246,8 +246,24 @@ __global__ __launch_bounds__(256) void compact_sites_kernel(const uint4 *__restr
             dst[((size_t)G * NPO + p) * n_pad + s] = make_uint4(out[p][0], out[p][1], out[p][2], out[p][3]);
 }
 
+// per sample: set bits of its one-plane row (lanes over samples: coalesced)
+__global__ __launch_bounds__(256) void plane_popcount_kernel(const uint4 *__restrict__ P, size_t n_pad, unsigned n, size_t groups,
+                                                             unsigned *__restrict__ out)
+{
+    const unsigned s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n) return;
+    unsigned c = 0;
+    for (size_t g = 0; g < groups; g++) {
+        const uint4 v = P[g * n_pad + s];
+        c += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+    }
+    out[s] = c;
+}
+
 void site_classes_free(tracs_alignment *a)
 {
+    if (a->c_counted) (void)hipFree(a->c_counted);
+    a->c_counted = nullptr;
     if (a->vplanes) (void)hipFree(a->vplanes);
     if (a->iplanes) (void)hipFree(a->iplanes);
     a->vplanes = a->iplanes = nullptr;
@@ -355,9 +371,13 @@ static int decide(tracs_alignment *a, bool consensus, bool allow_minor, hipStrea
     stage("re-pack dense");
     if (gi) {
         const dim3 grid((unsigned)((gi + 3) / 4), sblocks);
-        // consensus: plane 2 = V.  general: the complement of plane 4 = N (an invariant site holds bases and N only)
-        hipLaunchKernelGGL((compact_sites_kernel<1>), grid, dim3(256), 0, stream, src, consensus ? 3 : NPLANES, consensus ? 2 : 4, !consensus,
+        // the N plane of the counted sites: consensus: the complement of plane 2 = V; general: plane 4 = N
+        hipLaunchKernelGGL((compact_sites_kernel<1>), grid, dim3(256), 0, stream, src, consensus ? 3 : NPLANES, consensus ? 2 : 4, consensus,
                            list_count, (unsigned)L_count, a->iplanes, a->n_pad, (unsigned)a->n, (unsigned)gi);
+        if (hipMalloc(reinterpret_cast<void **>(&a->c_counted), a->n_pad * sizeof(unsigned)) != hipSuccess) { a->c_counted = nullptr; return soft_fail(); }
+        ok = ok && hipMemsetAsync(a->c_counted, 0, a->n_pad * sizeof(unsigned), stream) == hipSuccess;
+        hipLaunchKernelGGL(plane_popcount_kernel, dim3((unsigned)((a->n + 255) / 256)), dim3(256), 0, stream, a->iplanes, a->n_pad, (unsigned)a->n,
+                           gi, a->c_counted);
     }
     stage("re-pack counted");
     if (gm) {
