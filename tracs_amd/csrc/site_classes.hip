@@ -246,18 +246,20 @@ __global__ __launch_bounds__(256) void compact_sites_kernel(const uint4 *__restr
             dst[((size_t)G * NPO + p) * n_pad + s] = make_uint4(out[p][0], out[p][1], out[p][2], out[p][3]);
 }
 
-// per sample: set bits of its one-plane row (lanes over samples: coalesced)
+// per sample: set bits of its one-plane row (lanes over samples: coalesced; grid.y cuts the groups, partial counts are added)
 __global__ __launch_bounds__(256) void plane_popcount_kernel(const uint4 *__restrict__ P, size_t n_pad, unsigned n, size_t groups,
                                                              unsigned *__restrict__ out)
 {
     const unsigned s = blockIdx.x * 256 + threadIdx.x;
     if (s >= n) return;
+    const size_t per = (groups + gridDim.y - 1) / gridDim.y;
+    const size_t g0 = blockIdx.y * per, g1 = min(groups, g0 + per);
     unsigned c = 0;
-    for (size_t g = 0; g < groups; g++) {
+    for (size_t g = g0; g < g1; g++) {
         const uint4 v = P[g * n_pad + s];
         c += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
     }
-    out[s] = c;
+    if (c) atomicAdd(&out[s], c);
 }
 
 void site_classes_free(tracs_alignment *a)
@@ -376,7 +378,7 @@ static int decide(tracs_alignment *a, bool consensus, bool allow_minor, hipStrea
                            list_count, (unsigned)L_count, a->iplanes, a->n_pad, (unsigned)a->n, (unsigned)gi);
         if (hipMalloc(reinterpret_cast<void **>(&a->c_counted), a->n_pad * sizeof(unsigned)) != hipSuccess) { a->c_counted = nullptr; return soft_fail(); }
         ok = ok && hipMemsetAsync(a->c_counted, 0, a->n_pad * sizeof(unsigned), stream) == hipSuccess;
-        hipLaunchKernelGGL(plane_popcount_kernel, dim3((unsigned)((a->n + 255) / 256)), dim3(256), 0, stream, a->iplanes, a->n_pad, (unsigned)a->n,
+        hipLaunchKernelGGL(plane_popcount_kernel, dim3((unsigned)((a->n + 255) / 256), 128), dim3(256), 0, stream, a->iplanes, a->n_pad, (unsigned)a->n,
                            gi, a->c_counted);
     }
     stage("re-pack counted");
