@@ -69,7 +69,8 @@ def test_dense_entry_points_random_geometry(case, hiplib, oracle):
             assert np.array_equal(got_n[keep], want_n[keep])
         u = got_d[far] & 0xFFFFFFFF                                         # exact, or marked with bit 31: never <= thr
         assert ((u > thr) | (u >= 0x80000000)).all()
-        assert ((u == (want_d[far] & 0xFFFFFFFF)) | (u >= 0x80000000)).all()
+        if aln.site_classes is None and aln.encoding == "consensus":       # (otherwise a dead cell may hold any value > thr:
+            assert ((u == (want_d[far] & 0xFFFFFFFF)) | (u >= 0x80000000)).all()     # a lower bound + the terms added afterwards)
         rows, cols, dd, nc = dev.coo_from_dense(d, nn, n, dist_threshold=thr, row_begin=case["r0"], row_end=case["r1"],
                                                 col_begin=case["cb"])
         sel = keep[er.astype(np.int64), ec.astype(np.int64)]
