@@ -62,13 +62,15 @@ struct tracs_alignment {
     int classes_state = 0;       // 0 not decided, 1 in use, -1 not in use for this alignment
     tracs::GeneralSparse *sparse = nullptr;   // general matrix-core path: per-site / per-sample lists of N and partial codes
     int sparse_state = 0;        // 0 not built, 1 built, -1 not available for this alignment (too dense / too large / no memory)
-    // cached tile schedules of the last dense region: the pair kernel's, and the counting pass's when its workgroup tile differs
+    // cached tile schedules of the last dense regions (region x workgroup tile): the pair kernel's and the counting pass's, for
+    // the two row ranges a multi-GPU rank alternates between; replaced round-robin
     struct TileCache {
         int2 *d = nullptr;
         size_t n = 0, cap = 0;
         size_t rb = (size_t)-1, re = 0, cb = 0;
         int ti = 0, tj = 0;
-    } tiles, ctiles;
+    } tile_cache[4];
+    int tile_next = 0;
 };
 
 namespace tracs {

@@ -657,8 +657,8 @@ void tracs_alignment_free(tracs_alignment *a)
     if (a->planes) (void)hipFree(a->planes);
     if (a->cplanes) (void)hipFree(a->cplanes);
     if (a->d_flag) (void)hipFree(a->d_flag);
-    if (a->tiles.d) (void)hipFree(a->tiles.d);
-    if (a->ctiles.d) (void)hipFree(a->ctiles.d);
+    for (auto &c : a->tile_cache)
+        if (c.d) (void)hipFree(c.d);
     delete a;
 }
 
@@ -912,8 +912,12 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
     a->last_kernel = (mfma_general || no_dense_site) ? 2 : mfma ? 1 : 0;
 
     // ---- (re)build the cached tile schedule ------------------------------------------------------------------------------
-    auto ensure_tiles = [&](tracs_alignment::TileCache &c, int ti, int tj) -> int {
-        if (c.rb == row_begin && c.re == row_end && c.cb == col_begin && c.ti == ti && c.tj == tj) return TRACS_OK;
+    auto ensure_tiles = [&](int ti, int tj, tracs_alignment::TileCache **out) -> int {
+        for (auto &c : a->tile_cache)
+            if (c.rb == row_begin && c.re == row_end && c.cb == col_begin && c.ti == ti && c.tj == tj) { *out = &c; return TRACS_OK; }
+        tracs_alignment::TileCache &c = a->tile_cache[a->tile_next];
+        a->tile_next = (a->tile_next + 1) % 4;
+        c.rb = (size_t)-1;                                   // not valid until filled
         std::vector<int2> tiles;
         build_tiles(a->n, row_begin, row_end, col_begin, ti, tj, tiles);
         if (tiles.size() > c.cap) {
@@ -928,10 +932,13 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
         }
         c.n = tiles.size();
         c.rb = row_begin; c.re = row_end; c.cb = col_begin; c.ti = ti; c.tj = tj;
+        *out = &c;
         return TRACS_OK;
     };
-    { const int rc = ensure_tiles(a->tiles, kTI, kTJ); if (rc) return rc; }
-    if (a->tiles.n == 0) return TRACS_OK;
+    tracs_alignment::TileCache *main_tiles = nullptr;
+    { const int rc = ensure_tiles(kTI, kTJ, &main_tiles); if (rc) return rc; }
+    const tracs_alignment::TileCache &T = *main_tiles;
+    if (T.n == 0) return TRACS_OK;
 
     // Split the group range over workgroups (integer atomics, still exact) when that fills the chip better:
     // too few tiles (config 2), or a ragged last round of resident workgroups (tail effect).
@@ -955,7 +962,7 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
         if (const char *e = std::getenv("TRACS_KSPLIT")) { const int v = std::atoi(e); if (v >= 1 && v <= max_split) pick = v; }
         return pick;
     };
-    int ksplit = pick_split(a->tiles.n, groups, kGC);
+    int ksplit = pick_split(T.n, groups, kGC);
     auto stage_split = [&](int range, int k, int &gps_out) {       // k workgroups over `range` groups, stage aligned
         int g = (range + k - 1) / k;
         g = (g + kGC - 1) / kGC * kGC;
@@ -997,9 +1004,10 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
         if (tl && !C.fn) tl = nullptr;                         // no counting kernel with the pair kernel's tile: count every tile
         if (!tl) {
             C = count_shape_current();
-            const int rc = ensure_tiles(a->ctiles, C.ti, C.tj);
+            tracs_alignment::TileCache *ct = nullptr;
+            const int rc = ensure_tiles(C.ti, C.tj, &ct);
             if (rc) return rc;
-            tl = a->ctiles.d; ntl = a->ctiles.n;
+            tl = ct->d; ntl = ct->n;
         }
         if (ntl == 0) return TRACS_OK;
         const int gi = (int)a->groups_inv, gcc = C.gc;
@@ -1050,13 +1058,13 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
         int2 *live_tiles = nullptr;
         unsigned *n_live_d = nullptr;
         int rc;
-        if ((rc = tracs::workspace_get(48, a->tiles.n, reinterpret_cast<void **>(&live)))) return rc;
-        if ((rc = tracs::workspace_get(49, a->tiles.n * sizeof(int2), reinterpret_cast<void **>(&live_tiles)))) return rc;
+        if ((rc = tracs::workspace_get(48, T.n, reinterpret_cast<void **>(&live)))) return rc;
+        if ((rc = tracs::workspace_get(49, T.n * sizeof(int2), reinterpret_cast<void **>(&live_tiles)))) return rc;
         if ((rc = tracs::workspace_get(50, 64, reinterpret_cast<void **>(&n_live_d)))) return rc;
         TRACS_HIP_CHECK(hipMemsetAsync(n_live_d, 0, 4, stream));
-        if ((rc = launch(a->tiles.d, (unsigned)a->tiles.n, (int)a->tiles.n, prefix, prefix, 1, thr, TilePhase{1, 0, live}))) return rc;
-        hipLaunchKernelGGL(compact_live_kernel, dim3((unsigned)((a->tiles.n + 255) / 256)), dim3(256), 0, stream, a->tiles.d, live,
-                           (unsigned)a->tiles.n, live_tiles, n_live_d);
+        if ((rc = launch(T.d, (unsigned)T.n, (int)T.n, prefix, prefix, 1, thr, TilePhase{1, 0, live}))) return rc;
+        hipLaunchKernelGGL(compact_live_kernel, dim3((unsigned)((T.n + 255) / 256)), dim3(256), 0, stream, T.d, live,
+                           (unsigned)T.n, live_tiles, n_live_d);
         unsigned n_live = 0;
         TRACS_HIP_CHECK(hipMemcpyAsync(&n_live, n_live_d, 4, hipMemcpyDeviceToHost, stream));
         TRACS_HIP_CHECK(hipStreamSynchronize(stream));
@@ -1083,7 +1091,7 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
         hipLaunchKernelGGL(init_cells_kernel, grid, dim3(256), 0, stream, dist, ncomp, ld, (unsigned)a->n,
                            (unsigned)row_begin, (unsigned)row_end, (unsigned)col_begin, (cons || mfma) ? 0u : (unsigned)a->L);
     }
-    int rc = launch(a->tiles.d, (unsigned)(a->tiles.n * (size_t)ksplit), (int)a->tiles.n, groups, gps, ksplit, thr, TilePhase{0, 0, nullptr});
+    int rc = launch(T.d, (unsigned)(T.n * (size_t)ksplit), (int)T.n, groups, gps, ksplit, thr, TilePhase{0, 0, nullptr});
     if (rc) return rc;
     pair_mark(1, stream);
     if (mfma_general && (rc = general_sparse_fixup(a, row_begin, row_end, col_begin, dist, ncomp, ld, stream))) return rc;
