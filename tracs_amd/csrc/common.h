@@ -58,6 +58,7 @@ struct tracs_alignment {
     size_t L_minor = 0, L_full = 0;           // minority sites (listed in `minor`; they are part of L_inv or L_full as well);
                                               // sites without any N outside vplanes: +1 to every compared-sites count
     unsigned *c_counted = nullptr;            // per sample: its N sites among the counted sites (iplanes holds the N plane)
+    bool count_complement = false;            // diagnostics: iplanes holds the complement plane instead (TRACS_COUNT_COMPLEMENT)
     tracs::GeneralSparse *minor = nullptr;    // consensus alignments: lists of the minority sites (site_classes.hip)
     int classes_state = 0;       // 0 not decided, 1 in use, -1 not in use for this alignment
     tracs::GeneralSparse *sparse = nullptr;   // general matrix-core path: per-site / per-sample lists of N and partial codes

@@ -1022,6 +1022,7 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
         A.P = a->iplanes; A.n_pad = a->n_pad; A.groups = gi; A.tiles = tl; A.n_tiles = (int)ntl; A.gps = g; A.ksplit = k;
         A.L = (unsigned)(a->L_full + a->L_inv);                // range 0 adds sites - c_i - c_j once per cell (iplanes = the N plane)
         A.c_n = a->c_counted;
+        if (a->count_complement) { A.L = (unsigned)a->L_full; A.c_n = nullptr; }      // diagnostics: sum v v' needs no c terms
         A.n = (unsigned)a->n; A.row_end = (unsigned)row_end; A.col_begin = (unsigned)col_begin;
         A.dist = dist; A.ncomp = ncomp; A.ld = ld; A.thr = 0xFFFFFFFFu; A.ph = TilePhase{0, 0, nullptr};
         C.fn((unsigned)(ntl * (size_t)k), stream, A);

@@ -398,7 +398,7 @@ __global__ __launch_bounds__(NWR * NWC * 64, (NBR * NBC > 4 ? 1 : COUNT ? 4 : 2)
                     if constexpr (COUNT) {                     // the cells hold the variable sites' counts already;
                         // operand plane n = "is N here" (mostly zero words): NN = sum n n', and nn = sites - c_i - c_j + NN
                         // (A.L: the counted sites + the sites without any N, added once per cell by range 0)
-                        atomicAdd(&A.ncomp[(size_t)i * A.ld + j], (unsigned)V + (ks == 0 ? A.L - A.c_n[i] - A.c_n[j] : 0u));
+                        atomicAdd(&A.ncomp[(size_t)i * A.ld + j], (unsigned)V + (ks == 0 ? A.L - (A.c_n ? A.c_n[i] + A.c_n[j] : 0u) : 0u));
                         continue;
                     }
                     const int S = (int)accS[rb][cb][r];

@@ -374,8 +374,11 @@ static int decide(tracs_alignment *a, bool consensus, bool allow_minor, hipStrea
     if (gi) {
         const dim3 grid((unsigned)((gi + 3) / 4), sblocks);
         // the N plane of the counted sites: consensus: the complement of plane 2 = V; general: plane 4 = N
-        hipLaunchKernelGGL((compact_sites_kernel<1>), grid, dim3(256), 0, stream, src, consensus ? 3 : NPLANES, consensus ? 2 : 4, consensus,
-                           list_count, (unsigned)L_count, a->iplanes, a->n_pad, (unsigned)a->n, (unsigned)gi);
+        // (TRACS_COUNT_COMPLEMENT=1, diagnostics: the "is a base here" plane instead -- same counts, 99 % ones instead of 99 % zeros)
+        static const bool complement = std::getenv("TRACS_COUNT_COMPLEMENT") != nullptr;
+        a->count_complement = complement;
+        hipLaunchKernelGGL((compact_sites_kernel<1>), grid, dim3(256), 0, stream, src, consensus ? 3 : NPLANES, consensus ? 2 : 4,
+                           consensus != complement, list_count, (unsigned)L_count, a->iplanes, a->n_pad, (unsigned)a->n, (unsigned)gi);
         if (hipMalloc(reinterpret_cast<void **>(&a->c_counted), a->n_pad * sizeof(unsigned)) != hipSuccess) { a->c_counted = nullptr; return soft_fail(); }
         ok = ok && hipMemsetAsync(a->c_counted, 0, a->n_pad * sizeof(unsigned), stream) == hipSuccess;
         hipLaunchKernelGGL(plane_popcount_kernel, dim3((unsigned)((a->n + 255) / 256), 128), dim3(256), 0, stream, a->iplanes, a->n_pad, (unsigned)a->n,
