@@ -342,7 +342,8 @@ __global__ __launch_bounds__(1024) void general_fixup_kernel(const unsigned long
             const unsigned site = ent >> ENT_SHIFT;
             my_code = ent & 31u;                            // w << 4 | code
             my_pa = p_off[site]; my_pz = p_off[site + 1];
-            if ((my_code & 15u) != 15u) { my_na = n_off[site]; my_nz = n_off[site + 1]; }
+            // the N list of the site is only walked when i is listed there -- and, on the minority lists, adds something (w_i = 1)
+            if ((my_code & 15u) != 15u && (!MINOR || (my_code & 16u))) { my_na = n_off[site]; my_nz = n_off[site + 1]; }
         }
         // Short lists stay in their lane: where i is N and at most four samples are partial there (the usual case on the minority
         // lists: one or two), the lane applies its site's entries itself -- one round trip for the 16 sites together.
