@@ -208,3 +208,35 @@ def test_config5_edge_clustering_two_ranks_equals_one():
     assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-3000:]
     r2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
     assert r2["n_gpus"] == 2 and r2["components"] == r1["components"]
+
+
+def test_bench_line_contract_small():
+    """bench.py on one GPU at a small size: one JSON line with the fields the driver reads -- metric / value / unit / n_gpus /
+    steps / ms_per_step / scaling / dtype / config.workload, a `roofline` object (bound, achieved, peak, unit, frac, traffic) for
+    the dominant kernel with the site-class report beside it, `roofline_general`, `dm_frontend`, and a `cpu_baseline` (kind,
+    cores, sample, the two legs) whose block check -- GPU d / nn bit-equal to the oracle on the timed alignment -- has passed."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--samples", "700", "--sites",
+                          "200000", "--cpu-seconds", "0.5"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["unit"] == "pairs/s" and j["higher_is_better"] is True and j["vs_baseline"] is None
+    assert abs(j["value"] - 700 * 699 / 2 / (j["ms_per_step"] / 1e3)) < 1e-6 * j["value"]
+    assert "workload" in j["config"] and "model" not in j["config"] and j["config"]["encoding"] == "consensus"
+    r = j["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    sc = r["site_classes"]
+    assert sc["dense"] + sc["counted"] + sc["full"] + sc["empty"] == 200000 and sc["minority"] > 0
+    assert r["other_matrix_core_kernel"]["kernel_ms"] >= 0 and r["minority_lists_ms"] >= 0
+    g = j["roofline_general"]
+    assert g["bound"] == "mfma" and g["mean_d"] > j["config"]["mean_d"]
+    assert j["dm_frontend"]["encoding"] in ("general", "consensus")
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["unit"] == "pairs/s" and "sample" in c
+    assert c["pairsnp_pairs_per_s"] > 0 and c["trans_dist_keys_per_s"] > 0 and "bit-equal" in c["sample"]
