@@ -138,12 +138,30 @@ __device__ bool tc_eval(int N, double delta, const TcParams &P, const double *__
 // running maximum the sum is rescaled once (wave-uniform).  All terms are positive, the scaled sums stay within [1, 64 x terms),
 // and only rounding differs from the reference's log-space fold (:207-232).  The stopping test upper - elprob_linear > thr is
 // evaluated in the same units: elprob_scaled < (upper - thr) exp(-maximum), the right-hand side refreshed when the maximum moves.
+// Tables over (day gap, M) for sources whose delta is a whole number of days (DenseSource): both O(N) prefix sums of a key and
+// the running sum S of its loop depend on (delta, index) only --
+//     lnS[gap][M]  = ln sum_{j <= M} (delta (lamb + beta))^j / j!        (M <= largest N + 10 000)
+//     pois[gap][N] = ln sum_{i <= N} (lamb delta)^i / i!                  (:144-148)
+// -- so they are summed once per distinct gap (tc_tables_kernel, one wave per gap) instead of once per key, and a key's loop
+// reads S instead of carrying a third running sum.  Built per call when the table fits TC_TABLE_ELEMS (decided on the device:
+// no host round trip); `ok` = 0 otherwise, and for sources without day gaps.
+struct TcTables {
+    double *lnS, *pois;
+    unsigned n_max, gap_max;        // bounds of the keys of this call
+    unsigned ldm, ldn;              // row lengths: n_max + 10 001, n_max + 1
+    unsigned ok;
+};
+constexpr unsigned long long TC_TABLE_ELEMS = 48ull << 20;      // doubles in the lnS table (384 MB)
+
 // A key handed over without any term summed (state[0] is NaN: tc_keys_kernel does that for delta > 0 and N >= TC_WAVE_PREFIX_MIN)
 // starts here with the two O(N) prefix sums of the loop -- pois (:144-148) and S_N -- as wave sums of 64 terms per step instead of a
 // serial fold, and p0 (the k = 0 value, :276-282) comes back through `p0_out`.
 __device__ void tc_eval_wave(int N, double delta, const TcParams &P, const double *__restrict__ lg, double &eK,
-                             const double *__restrict__ state, int k_start, double *p0_out)
+                             const double *__restrict__ state, int k_start, double *p0_out, const TcTables *__restrict__ tab, long long gap)
 {
+    // this key's rows of the (gap, M) tables, when they exist and hold it
+    const bool tabled = tab && tab->ok && gap >= 1 && gap <= (long long)tab->gap_max && (unsigned)N <= tab->n_max;
+    const double *__restrict__ rowS = tabled ? tab->lnS + (size_t)gap * tab->ldm : nullptr;
     const int lane = threadIdx.x & 63;
     const double n1 = (double)(N + 1);
     const double lg_n1 = lg_at(lg, (long long)N + 1);
@@ -174,7 +192,17 @@ __device__ void tc_eval_wave(int N, double delta, const TcParams &P, const doubl
     // sum = scaled * exp(mx); an empty sum is (0, -inf)
     double pois, ld = 0.0, upper;
     double Ms, Ss, Mp, Lps, Me, Els;
-    if (fresh) {                                                       // (delta > 0)
+    if (fresh && tabled) {
+        pois = tab->pois[(size_t)gap * tab->ldn + N];
+        const double lnS = rowS[N];
+        double l0 = (n1 * P.ln_lamb + 0.0 * P.ln_beta + lg_n1);
+        l0 = l0 - lg_n1 - lg_at(lg, 1) - delta * P.beta;
+        l0 -= pois;
+        *p0_out = l0 + (lnS - n1 * P.ln_lb);
+        Ms = -INFINITY; Ss = 0.0;                                      // (unused: S comes from the table)
+        Mp = -INFINITY; Lps = 0.0; Me = -INFINITY; Els = 0.0;
+        k_start = 1;
+    } else if (fresh) {                                                // (delta > 0)
         const double lx = log(P.lamb * delta);
         ld = log(delta);
         // two sweeps over the lane's own terms (i = lane, lane + 64, ..): the largest term first, then sum exp(term - largest) --
@@ -217,15 +245,20 @@ __device__ void tc_eval_wave(int N, double delta, const TcParams &P, const doubl
         double t1, t2;
         bool moved;
         if (pos) {
-            const double a = live ? imul(M, ld) + (double)M * P.ln_lb - lg_at(lg, M + 1) : -INFINITY;
-            const double Sl = accumulate(a, Ss, Ms, moved);
-            const double Sk = Ms + log(Sl);
+            double Sk, Sl = 0.0;
+            if (tabled) {
+                Sk = live ? rowS[M] : 0.0;
+            } else {
+                const double a = live ? imul(M, ld) + (double)M * P.ln_lb - lg_at(lg, M + 1) : -INFINITY;
+                Sl = accumulate(a, Ss, Ms, moved);
+                Sk = Ms + log(Sl);
+            }
             double lhs = (n1 * P.ln_lamb + (double)k * P.ln_beta + lg_at(lg, M + 1));
             lhs = lhs - lg_n1 - lg_at(lg, (long long)k + 1) - delta * P.beta;
             lhs -= pois;
             t1 = (lhs + (Sk - m1)) + lk;
             t2 = lhs + lk + delta * (P.lamb + P.beta) - m1;
-            Ss = __shfl(Sl, 63, 64);
+            if (!tabled) Ss = __shfl(Sl, 63, 64);
         } else {
             const double lhs = (n1 * P.ln_lamb + (double)k * P.ln_beta + lg_at(lg, M + 1) - lg_n1 -
                                 lg_at(lg, (long long)k + 1) - m1);
@@ -271,6 +304,7 @@ struct ArraySource {            // trans_dist(snpdiff[], datediff[])
     __device__ bool get(size_t e, int &Nv, double &dv) const { Nv = N[e]; dv = delta[e]; return true; }
     __device__ size_t out_index(size_t e) const { return e; }
     __device__ long long day_gap(size_t) const { return -1; }
+    static constexpr bool HAS_GAPS = false;
 };
 
 struct DenseSource {            // cells of a dense distance block, delta from sampling days
@@ -300,6 +334,7 @@ struct DenseSource {            // cells of a dense distance block, delta from s
         const long long dd = (long long)days[row_of(e / n)] - (long long)days[e % n];
         return dd < 0 ? -dd : dd;
     }
+    static constexpr bool HAS_GAPS = true;
 };
 
 // Key table of the multi-GPU path: results of the distinct (N, day gap) keys in a dense [n_max + 1][d_max + 1] layout that
@@ -407,12 +442,79 @@ __global__ void tc_keys_kernel(Src src, const unsigned *__restrict__ key_elem, u
     }
 }
 
+// largest N and day gap among the keys of the call (bounds[0], bounds[1]); sources without day gaps leave bounds[1] = 0
+template <class Src>
+__global__ void tc_key_bounds_kernel(Src src, const unsigned *__restrict__ key_elem, const unsigned *__restrict__ n_keys, unsigned *__restrict__ bounds)
+{
+    const unsigned nk = *n_keys;
+    unsigned mn = 0, mg = 0;
+    for (unsigned id = blockIdx.x * blockDim.x + threadIdx.x; id < nk; id += gridDim.x * blockDim.x) {
+        int N; double d;
+        const size_t elem = (size_t)key_elem[id];
+        src.get(elem, N, d);
+        const long long gap = src.day_gap(elem);
+        mn = max(mn, (unsigned)N);
+        if (gap > 0) mg = max(mg, (unsigned)min(gap, 0x7FFFFFFFll));
+    }
+    for (int off = 32; off > 0; off >>= 1) { mn = max(mn, (unsigned)__shfl_xor((int)mn, off, 64)); mg = max(mg, (unsigned)__shfl_xor((int)mg, off, 64)); }
+    if ((threadIdx.x & 63) == 0) { atomicMax(&bounds[0], mn); atomicMax(&bounds[1], mg); }
+}
+
+// one wave per day gap: the two prefix-sum rows of the gap, 64 indices per step (scaled linear sums, like tc_eval_wave)
+__global__ __launch_bounds__(64) void tc_tables_kernel(TcTables *__restrict__ tab, const unsigned *__restrict__ bounds, double *lnS, double *pois,
+                                                       unsigned long long pois_cap, TcParams P, const double *__restrict__ lg)
+{
+    const unsigned n_max = bounds[0], gap_max = bounds[1];
+    const unsigned long long ldm = (unsigned long long)n_max + 10001ull, ldn = (unsigned long long)n_max + 1ull;
+    const bool ok = gap_max >= 1 && ((unsigned long long)gap_max + 1ull) * ldm <= TC_TABLE_ELEMS && ((unsigned long long)gap_max + 1ull) * ldn <= pois_cap;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        tab->lnS = lnS; tab->pois = pois; tab->n_max = n_max; tab->gap_max = gap_max; tab->ldm = (unsigned)ldm; tab->ldn = (unsigned)ldn;
+        tab->ok = ok ? 1u : 0u;
+    }
+    if (!ok) return;
+    P.ln_lamb = log(P.lamb); P.ln_beta = log(P.beta); P.ln_lb = log(P.lamb + P.beta);
+    const int lane = threadIdx.x & 63;
+    auto wave_max = [&](double v) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+        return v;
+    };
+    auto wave_prefix = [&](double e) {
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const double o = __shfl_up(e, off, 64);
+            if (lane >= off) e += o;
+        }
+        return e;
+    };
+    for (unsigned gap = 1 + blockIdx.x; gap <= gap_max; gap += gridDim.x) {
+        const double delta = (double)((long long)gap * 86400ll) / 31556952.0;        // the sources' expression (DenseSource::get)
+        const double ld = log(delta), lx = log(P.lamb * delta);
+        for (int which = 0; which < 2; which++) {
+            const unsigned long long len = which ? ldn : ldm;
+            double *__restrict__ row = (which ? pois + (size_t)gap * ldn : lnS + (size_t)gap * ldm);
+            double mx = -INFINITY, scaled = 0.0;
+            for (unsigned long long i0 = 0; i0 < len; i0 += 64) {
+                const long long i = (long long)(i0 + lane);
+                const bool in = (unsigned long long)i < len;
+                const double t = !in ? -INFINITY : which ? imul(i, lx) - lg_at(lg, i + 1) : imul(i, ld) + (double)i * P.ln_lb - lg_at(lg, i + 1);
+                const double m = wave_max(t);
+                if (m > mx) { scaled = mx == -INFINITY ? 0.0 : scaled * exp(mx - m); mx = m; }
+                const double pre = scaled + wave_prefix(t == -INFINITY ? 0.0 : exp(t - mx));
+                if (in) row[i] = mx + log(pre);
+                scaled = __shfl(pre, 63, 64);
+            }
+        }
+    }
+}
+
 template <class Src>
 __global__ __launch_bounds__(64) void tc_long_keys_kernel(Src src, const unsigned *__restrict__ key_elem,
                                                           const unsigned *__restrict__ long_ids,
                                                           const unsigned *__restrict__ n_long, TcParams P,
                                                           const double *__restrict__ lg, double *__restrict__ key_p0,
-                                                          double *__restrict__ key_eK, const double *__restrict__ key_state, KeyTable kt)
+                                                          double *__restrict__ key_eK, const double *__restrict__ key_state, KeyTable kt,
+                                                          const TcTables *__restrict__ tab)
 {
     P.ln_lamb = log(P.lamb); P.ln_beta = log(P.beta); P.ln_lb = log(P.lamb + P.beta);
     const unsigned nl = *n_long;
@@ -424,7 +526,7 @@ __global__ __launch_bounds__(64) void tc_long_keys_kernel(Src src, const unsigne
         double eK, p0 = 0.0;
         const double *st = key_state + 4 * (size_t)id;
         const bool fresh = st[0] != st[0];
-        tc_eval_wave(N, d, P, lg, eK, st, TC_SERIAL_CAP, &p0);
+        tc_eval_wave(N, d, P, lg, eK, st, TC_SERIAL_CAP, &p0, tab, src.day_gap(elem));
         if ((threadIdx.x & 63) == 0) {
             key_eK[id] = eK;
             if (fresh) key_p0[id] = p0;
@@ -527,7 +629,8 @@ static int get_lgamma_table(hipStream_t stream, const double **out)
 
 int get_lgamma_table_for_filter(hipStream_t stream, const double **out) { return get_lgamma_table(stream, out); }
 
-struct TcWorkspaceIds { enum { SLOTS = 0, ESLOT, SLOT_ID, NKEYS, KEY_ELEM, KEY_P0, KEY_EK, LONG_IDS, KEY_STATE }; };
+struct TcWorkspaceIds { enum { SLOTS = 0, ESLOT, SLOT_ID, NKEYS, KEY_ELEM, KEY_P0, KEY_EK, LONG_IDS, KEY_STATE, TAB, TAB_LNS, TAB_POIS }; };
+constexpr unsigned long long TC_POIS_ELEMS = 16ull << 20;        // doubles in the pois table (128 MB)
 
 static unsigned long long g_last_keys = 0;        // distinct (N, delta) keys of the last entry-point call (bench.py reports it)
 constexpr size_t TD_MAX_ELEMS = 1ull << 31;       // elements per pass: element indices and slots are 32-bit
@@ -590,9 +693,21 @@ static int run_trans_dist(const Src &src, size_t total, double lamb, double beta
     // one wave per block: keys differ widely in trip count, small blocks keep the SIMDs busy
     hipLaunchKernelGGL((tc_keys_kernel<Src>), dim3((nk + 63) / 64), dim3(64), 0, stream, src, key_elem, nk, P, lg, key_p0, key_eK,
                        long_ids, n_keys + 1, key_state, kt);
+    // (gap, M) tables of the prefix sums, when the source has day gaps and the keys' bounds fit (decided on the device)
+    TcTables *tab = nullptr;
+    double *tab_lnS = nullptr, *tab_pois = nullptr;
+    if ((rc = workspace_get(TcWorkspaceIds::TAB, 256, reinterpret_cast<void **>(&tab)))) return rc;
+    TRACS_HIP_CHECK(hipMemsetAsync(tab, 0, 256, stream));                 // ok = 0
+    if (Src::HAS_GAPS) {
+        if ((rc = workspace_get(TcWorkspaceIds::TAB_LNS, TC_TABLE_ELEMS * 8, reinterpret_cast<void **>(&tab_lnS)))) return rc;
+        if ((rc = workspace_get(TcWorkspaceIds::TAB_POIS, TC_POIS_ELEMS * 8, reinterpret_cast<void **>(&tab_pois)))) return rc;
+        unsigned *bounds = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(tab) + 128);
+        hipLaunchKernelGGL((tc_key_bounds_kernel<Src>), dim3(256), dim3(256), 0, stream, src, key_elem, n_keys, bounds);
+        hipLaunchKernelGGL(tc_tables_kernel, dim3(1024), dim3(64), 0, stream, tab, bounds, tab_lnS, tab_pois, TC_POIS_ELEMS, P, lg);
+    }
     // long series (E(K) loop beyond TC_SERIAL_CAP terms): one wave per key
     hipLaunchKernelGGL((tc_long_keys_kernel<Src>), dim3(std::min<unsigned>(nk, 256u * 32u)), dim3(64), 0, stream, src, key_elem,
-                       long_ids, n_keys + 1, P, lg, key_p0, key_eK, key_state, kt);
+                       long_ids, n_keys + 1, P, lg, key_p0, key_eK, key_state, kt, tab);
     if (p0 && eK)                        // (the key-table form fills its table only)
         hipLaunchKernelGGL((tc_gather_kernel<Src>), dim3(blocks), dim3(256), 0, stream, src, eslot, slot_id, key_p0, key_eK,
                            exp_p0, p0, eK);
