@@ -461,12 +461,14 @@ __global__ void tc_key_bounds_kernel(Src src, const unsigned *__restrict__ key_e
 }
 
 // one wave per day gap: the two prefix-sum rows of the gap, 64 indices per step (scaled linear sums, like tc_eval_wave)
-__global__ __launch_bounds__(64) void tc_tables_kernel(TcTables *__restrict__ tab, const unsigned *__restrict__ bounds, double *lnS, double *pois,
-                                                       unsigned long long pois_cap, TcParams P, const double *__restrict__ lg)
+__global__ __launch_bounds__(64) void tc_tables_kernel(TcTables *__restrict__ tab, const unsigned *__restrict__ bounds, const unsigned *__restrict__ n_keys,
+                                                       double *lnS, double *pois, unsigned long long pois_cap, TcParams P, const double *__restrict__ lg)
 {
     const unsigned n_max = bounds[0], gap_max = bounds[1];
     const unsigned long long ldm = (unsigned long long)n_max + 10001ull, ldn = (unsigned long long)n_max + 1ull;
-    const bool ok = gap_max >= 1 && ((unsigned long long)gap_max + 1ull) * ldm <= TC_TABLE_ELEMS && ((unsigned long long)gap_max + 1ull) * ldn <= pois_cap;
+    // the tables must fit, and must be less work than they save: a few thousand terms per key against one table entry per (gap, M)
+    const bool ok = gap_max >= 1 && ((unsigned long long)gap_max + 1ull) * ldm <= TC_TABLE_ELEMS && ((unsigned long long)gap_max + 1ull) * ldn <= pois_cap &&
+                    ((unsigned long long)gap_max + 1ull) * ldm <= (unsigned long long)*n_keys * 4096ull;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         tab->lnS = lnS; tab->pois = pois; tab->n_max = n_max; tab->gap_max = gap_max; tab->ldm = (unsigned)ldm; tab->ldn = (unsigned)ldn;
         tab->ok = ok ? 1u : 0u;
@@ -703,7 +705,7 @@ static int run_trans_dist(const Src &src, size_t total, double lamb, double beta
         if ((rc = workspace_get(TcWorkspaceIds::TAB_POIS, TC_POIS_ELEMS * 8, reinterpret_cast<void **>(&tab_pois)))) return rc;
         unsigned *bounds = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(tab) + 128);
         hipLaunchKernelGGL((tc_key_bounds_kernel<Src>), dim3(256), dim3(256), 0, stream, src, key_elem, n_keys, bounds);
-        hipLaunchKernelGGL(tc_tables_kernel, dim3(1024), dim3(64), 0, stream, tab, bounds, tab_lnS, tab_pois, TC_POIS_ELEMS, P, lg);
+        hipLaunchKernelGGL(tc_tables_kernel, dim3(1024), dim3(64), 0, stream, tab, bounds, n_keys, tab_lnS, tab_pois, TC_POIS_ELEMS, P, lg);
     }
     // long series (E(K) loop beyond TC_SERIAL_CAP terms): one wave per key
     hipLaunchKernelGGL((tc_long_keys_kernel<Src>), dim3(std::min<unsigned>(nk, 256u * 32u)), dim3(64), 0, stream, src, key_elem,
