@@ -295,13 +295,10 @@ def main():
             # site classes (csrc/site_classes.hip): pair kernel over the dense sites, lists for the minority sites, one-operand
             # counting pass over the counted sites.  `roofline` = whichever matrix-core kernel takes longer; the other beside it.
             dense, counted, minority, full = classes
-            main = roofline_of(aln.kernel, enc, last_pairs, dense, max(split[0], 1e-3) / 1e3, traffic if split[0] >= split[2] else None)
+            main = roofline_of(aln.kernel, enc, last_pairs, dense, max(split[0], 1e-3) / 1e3, None)
             cnt = count_roofline(last_pairs, counted, max(split[2], 1e-3) / 1e3)
-            if split[2] > split[0]:
-                cnt["traffic"] = traffic
-                roof, other = cnt, main
-            else:
-                roof, other = main, cnt
+            cnt["traffic"] = traffic                          # the "+classes" entry of the PMC summary is the counting pass's
+            roof, other = (cnt, main) if split[2] > split[0] else (main, cnt)
             roof["other_matrix_core_kernel"] = {k: other[k] for k in ("kernel", "kernel_ms", "achieved", "frac", "unit") if k in other}
             roof["minority_lists_ms"] = split[1]
             roof["dense_call_ms"] = kern_s * 1e3
@@ -314,6 +311,8 @@ def main():
                                             "TRACS_SITE_CLASSES=0 reads every site with the pair kernel, TRACS_MINORITY=0 keeps the minority sites dense"}
         else:
             roof = roofline_of(aln.kernel, enc, my_pairs_per_launch, L, kern_s, traffic)
+        roof["traffic_source"] = ("profiles/pmc_summary.json: FETCH_SIZE / WRITE_SIZE from separate rocprofv3 --pmc passes of this kernel on this "
+                                  "shape, committed with the profiles -- not measured by this run" if roof.get("traffic") is not None else None)
         enc_name = "consensus (ACGTN) alignment" if enc == "consensus" else "general IUPAC alignment (%.2g partial codes)" % args.partial
         out = {"metric": "sample-pairs/sec for 10kx5Mbp SNP+transcluster distance", "value": value,
                "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
