@@ -66,7 +66,10 @@ VARIANTS = [
     ({"TRACS_COUNT_TILE": "4x2", "TRACS_MINORITY": "0"}, {("consensus", "mfma"), ("general", "mfma-general")}),
     # lists refused (cap of 10 entries): consensus alignments keep their classes without minority lists, general ones the VALU kernel
     ({"TRACS_LIST_CAP": "10"}, {("consensus", "mfma"), ("general", "valu")}),
-    ({"TRACS_COUNT_COMPLEMENT": "1"}, {("consensus", "mfma"), ("general", "mfma-general")}),
+    # the counting pass's source: the stored N plane in place (every site) / the counted sites' N plane re-packed
+    ({"TRACS_COUNT_IN_PLACE": "1"}, {("consensus", "mfma"), ("general", "mfma-general")}),
+    ({"TRACS_COUNT_IN_PLACE": "1", "TRACS_KSPLIT": "3"}, {("consensus", "mfma"), ("general", "mfma-general")}),
+    ({"TRACS_COUNT_IN_PLACE": "0"}, {("consensus", "mfma"), ("general", "mfma-general")}),
 ]
 
 

@@ -200,6 +200,12 @@ def load():
     L.tracs_debug_alignment_kernel.argtypes = [vp]
     L.tracs_debug_alignment_site_classes.restype = C.c_int
     L.tracs_debug_alignment_site_classes.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.tracs_debug_alignment_count_source.restype = C.c_int
+    L.tracs_debug_alignment_count_source.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.tracs_debug_pack_timing.restype = None
+    L.tracs_debug_pack_timing.argtypes = [C.c_int]
+    L.tracs_debug_pack_stages.restype = C.c_int
+    L.tracs_debug_pack_stages.argtypes = [C.c_char_p, sz, C.POINTER(C.c_float), C.c_int]
     L.tracs_debug_pair_timing.restype = None
     L.tracs_debug_pair_timing.argtypes = [C.c_int]
     L.tracs_debug_last_pair_ms.restype = C.c_int

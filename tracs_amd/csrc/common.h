@@ -30,8 +30,9 @@ constexpr int NPLANES = 5;
 constexpr int SITES_PER_GROUP = 128;
 constexpr int SAMPLE_PAD = 64;       // n_pad is a multiple of one staging wave-instruction (64 samples x 16 B)
 constexpr int TAIL_PAD = 512;        // zeroed uint4 behind the last plane: tiles may read (never use) up to one tile edge past n_pad
-constexpr int PAD_GROUPS = 1;        // all-zero groups behind the last real one: the matrix-core kernels' two-group stages may
-                                     // overhang the alignment by one group (zero planes contribute nothing)
+constexpr int PAD_GROUPS = 7;        // all-zero groups behind the last real one: the matrix-core kernels' stages (two groups; the
+                                     // counting pass, which also reads the stored N plane in place: four, sweeps up to eight) may
+                                     // overhang the alignment (zero planes contribute nothing)
 
 static inline size_t groups_for(size_t L) { return (L + SITES_PER_GROUP - 1) / SITES_PER_GROUP; }
 static inline size_t pad_samples(size_t n) { return (n + SAMPLE_PAD - 1) / SAMPLE_PAD * SAMPLE_PAD; }
@@ -50,16 +51,18 @@ struct tracs_alignment {
     int last_kernel = -1;        // kernel of the last dense call: 0 VALU tile kernel, 1 / 2 matrix-core kernel (consensus / one-hot)
     // Site classes (site_classes.hip), decided once per pack: a site at which every sample that is not N carries the same
     // base adds 0 to every distance and [neither is N] to every compared-sites count.  When enough sites are like that the
-    // pair kernels read `vplanes` -- the alignment restricted to the VARIABLE sites, same encoding and layout as their usual
-    // source -- and a one-operand matrix-core pass over `iplanes` (the INVARIANT sites' "is a base here" plane) adds the rest
-    // of the compared-sites counts.  Sites at which every sample is N belong to neither.
+    // pair kernels read `vplanes` -- the alignment restricted to the DENSE sites, same encoding and layout as their usual
+    // source -- and a one-operand matrix-core pass over the N plane of the other sites (`iplanes`, or the stored N plane in
+    // place) completes the compared-sites counts.
     uint4 *vplanes = nullptr, *iplanes = nullptr;
     size_t L_var = 0, L_inv = 0, groups_var = 0, groups_inv = 0;
     size_t L_minor = 0, L_full = 0;           // minority sites (listed in `minor`; they are part of L_inv or L_full as well);
                                               // sites without any N outside vplanes: +1 to every compared-sites count
-    unsigned *c_counted = nullptr;            // per sample: its N sites among the counted sites (iplanes holds the N plane)
-    bool count_complement = false;            // diagnostics: iplanes holds the complement plane instead (TRACS_COUNT_COMPLEMENT)
-    tracs::GeneralSparse *minor = nullptr;    // consensus alignments: lists of the minority sites (site_classes.hip)
+    unsigned *c_counted = nullptr;            // per sample: its N sites among the sites the counting pass reads
+    bool count_in_place = false;              // the counting pass reads the stored N plane of `planes` (every site) instead of iplanes:
+                                              // nn = L - c_i - c_j + NN comes from it alone and the pair kernels write d only
+    bool classes_cons = false;                // vplanes hold consensus planes (X, Y, V) / the five general planes
+    tracs::GeneralSparse *minor = nullptr;    // lists of the minority sites (site_classes.hip)
     int classes_state = 0;       // 0 not decided, 1 in use, -1 not in use for this alignment
     tracs::GeneralSparse *sparse = nullptr;   // general matrix-core path: per-site / per-sample lists of N and partial codes
     int sparse_state = 0;        // 0 not built, 1 built, -1 not available for this alignment (too dense / too large / no memory)
@@ -82,7 +85,6 @@ static inline const uint4 *pair_planes(const tracs_alignment *a, bool consensus)
 }
 static inline size_t pair_L(const tracs_alignment *a) { return a->classes_state == 1 ? a->L_var : a->L; }
 static inline size_t pair_groups(const tracs_alignment *a) { return a->classes_state == 1 ? a->groups_var : a->groups; }
-constexpr int COUNT_PAD_GROUPS = 7;  // zero groups behind `iplanes`: the counting pass stages four (sweeps: up to eight) groups at a time
 
 // Grow-only per-device scratch buffers (slot ids are small integers owned by each .hip file), shared by every entry point.
 // Entry points that use them, or the cached state of a tracs_alignment, hold a DeviceCall for their whole body:

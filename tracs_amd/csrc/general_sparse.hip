@@ -73,101 +73,6 @@ struct GeneralSrc {
     __device__ __forceinline__ size_t index(size_t g, int w, int b) const { return g * SITES_PER_GROUP + w * 32 + b; }
 };
 
-// The minority sites of an alignment cut into site classes (site_classes.hip), read in place from its planes: only the sites
-// of `minor_mask` are listed, under their rank (off[g] = listed sites before group g).  At such a site every sample is N, or
-// carries exactly the site's reference base (not listed), or is LISTED with its allele mask M and w = [reference base not in M]
-// -- what the sample adds to its distance to every sample that carries the reference base.
-struct MinorRank {
-    const uint4 *minor_mask;
-    const unsigned *off;
-    __device__ __forceinline__ bool any_listed(size_t g) const
-    {
-        const uint4 m = minor_mask[g];
-        return (m.x | m.y | m.z | m.w) != 0u;
-    }
-    __device__ __forceinline__ unsigned listed(size_t g, int w) const { return word_of(minor_mask[g], w); }
-    __device__ __forceinline__ size_t index(size_t g, int w, int b) const
-    {
-        const uint4 m = minor_mask[g];
-        unsigned r = off[g];
-        if (w > 0) r += __popc(m.x);
-        if (w > 1) r += __popc(m.y);
-        if (w > 2) r += __popc(m.z);
-        return (size_t)r + __popc(word_of(m, w) & ((1u << b) - 1u));
-    }
-};
-
-// consensus planes X, Y, V (bases A = 0, C = 1, G = 2, T = 3 = X + 2 Y): a listed sample carries one base other than the
-// reference, so M = {own base} and w = 1
-struct MinorSrc : MinorRank {
-    const uint4 *P;
-    size_t n_pad;
-    const uint4 *ref_x, *ref_y;
-    struct Group { uint4 X, Y, V, M, RX, RY; };
-    __device__ __forceinline__ Group load(size_t g, size_t s) const
-    {
-        const uint4 *base = P + (g * 3) * n_pad + s;
-        return Group{base[0], base[n_pad], base[2 * n_pad], minor_mask[g], ref_x[g], ref_y[g]};
-    }
-    __device__ __forceinline__ void masks(const Group &q, int w, unsigned &nm, unsigned &pm) const
-    {
-        const unsigned x = word_of(q.X, w), y = word_of(q.Y, w), v = word_of(q.V, w), m = word_of(q.M, w);
-        nm = ~v & m;
-        pm = v & ((x ^ word_of(q.RX, w)) | (y ^ word_of(q.RY, w))) & m;
-    }
-    __device__ __forceinline__ unsigned wmask(const Group &, int) const { return 0xFFFFFFFFu; }
-    __device__ __forceinline__ unsigned code(const Group &q, int w, int b) const
-    {
-        if (!((word_of(q.V, w) >> b) & 1u)) return 15u;
-        const unsigned own = ((word_of(q.X, w) >> b) & 1u) | (((word_of(q.Y, w) >> b) & 1u) << 1);
-        return 16u | (1u << own);
-    }
-};
-
-// general planes A, C, G, T, N: a listed sample carries another base or a partial IUPAC code
-struct GeneralMinorSrc : MinorRank {
-    const uint4 *P;
-    size_t n_pad;
-    const uint4 *ref_x, *ref_y;
-    struct Group { uint4 A, C, G, T, N, M, RX, RY; };
-    __device__ __forceinline__ Group load(size_t g, size_t s) const
-    {
-        const uint4 *base = P + (g * NPLANES) * n_pad + s;
-        return Group{base[0], base[n_pad], base[2 * n_pad], base[3 * n_pad], base[4 * n_pad], minor_mask[g], ref_x[g], ref_y[g]};
-    }
-    // bits whose allele mask holds the reference base / is exactly the reference base
-    __device__ __forceinline__ void ref_bits(const Group &q, int w, unsigned &has_ref, unsigned &only_ref) const
-    {
-        const unsigned a = word_of(q.A, w), c = word_of(q.C, w), g = word_of(q.G, w), t = word_of(q.T, w);
-        const unsigned rx = word_of(q.RX, w), ry = word_of(q.RY, w);
-        const unsigned ra = ~rx & ~ry, rc = rx & ~ry, rg = ~rx & ry, rt = rx & ry;
-        has_ref = (a & ra) | (c & rc) | (g & rg) | (t & rt);
-        only_ref = ~((a ^ ra) | (c ^ rc) | (g ^ rg) | (t ^ rt));
-    }
-    __device__ __forceinline__ void masks(const Group &q, int w, unsigned &nm, unsigned &pm) const
-    {
-        unsigned has_ref, only_ref;
-        ref_bits(q, w, has_ref, only_ref);
-        const unsigned m = word_of(q.M, w), isn = word_of(q.N, w);
-        nm = isn & m;
-        pm = ~isn & ~only_ref & m;
-    }
-    __device__ __forceinline__ unsigned wmask(const Group &q, int w) const
-    {
-        unsigned has_ref, only_ref;
-        ref_bits(q, w, has_ref, only_ref);
-        return ~has_ref;
-    }
-    __device__ __forceinline__ unsigned code(const Group &q, int w, int b) const
-    {
-        const unsigned m = ((word_of(q.A, w) >> b) & 1u) | (((word_of(q.C, w) >> b) & 1u) << 1) | (((word_of(q.G, w) >> b) & 1u) << 2) |
-                           (((word_of(q.T, w) >> b) & 1u) << 3);
-        if (m == 15u) return 15u;
-        const unsigned ref = ((word_of(q.RX, w) >> b) & 1u) | (((word_of(q.RY, w) >> b) & 1u) << 1);
-        return (((m >> ref) & 1u) ? 0u : 16u) | m;
-    }
-};
-
 // pass A / B over the planes, lanes over samples (coalesced), one thread = (sample, chunk of groups), walked in site order.
 // FILL = false: cnt[s * GS_CHUNKS + chunk] = special sites of the chunk, cn[s * GS_CHUNKS + chunk] = N sites of the chunk.
 // FILL = true : entries written from off[s * GS_CHUNKS + chunk] on.
@@ -536,24 +441,195 @@ int general_sparse_get(tracs_alignment *a, hipStream_t stream, int *ok, double *
     return TRACS_OK;
 }
 
-// site_classes.hip: the lists of the `sites` minority sites of an alignment, read in place from its planes
-// (consensus: the three consensus planes; otherwise the five general planes)
-int minority_lists_build(tracs_alignment *a, bool consensus, const uint4 *planes, const uint4 *minor_mask, const uint4 *ref_x,
-                         const uint4 *ref_y, const unsigned *off_minor, size_t sites, hipStream_t stream, int *ok)
+// ---- the lists of the MINORITY sites of an alignment cut into site classes (site_classes.hip) ---------------------------
+// At such a site every sample is N, or carries exactly the site's reference base (not listed), or is LISTED with its allele
+// mask M and w = [reference base not in M] -- what the sample adds to its distance to every sample that carries the reference
+// base.  classify_sites_kernel has already counted the listed and the N samples of every site, summed them per group
+// (prefix sums: baseP / baseN) and flagged, per group, the samples that are listed somewhere in it; so the lists are built
+// from ONE plane: per-site lists = the N plane masked with the minority sites (+ the five planes of the flagged samples
+// only: ~1 % of them on a real alignment), per-sample lists = the N plane again (count, fill) + the listed entries the
+// per-site pass recorded.  Sites are listed under their rank among the minority sites (off_minor[g] = ranks before group g).
+__device__ __forceinline__ unsigned minor_rank(const uint4 &m, unsigned off_g, int w, int b)
 {
-    minority_lists_free(a);
-    int rc;
-    if (consensus) {
-        MinorSrc src;
-        src.minor_mask = minor_mask; src.off = off_minor; src.P = planes; src.n_pad = a->n_pad; src.ref_x = ref_x; src.ref_y = ref_y;
-        rc = gs_build(src, a->n, sites, a->groups, (double)a->n * (double)a->L / 8.0, stream, &a->minor);
-    } else {
-        GeneralMinorSrc src;
-        src.minor_mask = minor_mask; src.off = off_minor; src.P = planes; src.n_pad = a->n_pad; src.ref_x = ref_x; src.ref_y = ref_y;
-        rc = gs_build(src, a->n, sites, a->groups, (double)a->n * (double)a->L / 8.0, stream, &a->minor);
+    unsigned r = off_g;
+    if (w > 0) r += __popc(m.x);
+    if (w > 1) r += __popc(m.y);
+    if (w > 2) r += __popc(m.z);
+    return r + __popc(word_of(m, w) & ((1u << b) - 1u));
+}
+
+// one workgroup per 128-site group, threads over samples: p_off / n_off of the group's minority sites, their N samples, and
+// the listed samples (with code = w << 4 | allele mask); E[k] = (sample, rank << 5 | code) for the per-sample lists
+__global__ __launch_bounds__(256) void minor_site_lists_kernel(const MinorBuild mb, size_t n_pad, unsigned n,
+                                                               unsigned long long *__restrict__ p_off, unsigned long long *__restrict__ n_off,
+                                                               unsigned *__restrict__ p_ent, unsigned *__restrict__ n_ent, uint2 *__restrict__ E)
+{
+    __shared__ unsigned kp[SITES_PER_GROUP], kn[SITES_PER_GROUP], curP[SITES_PER_GROUP], curN[SITES_PER_GROUP], rk[SITES_PER_GROUP];
+    __shared__ unsigned long long bP[SITES_PER_GROUP], bN[SITES_PER_GROUP];
+    const size_t g = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (g == 0 && tid == 0) { p_off[mb.sites] = mb.tot_p; n_off[mb.sites] = mb.tot_n; }
+    const uint4 m4 = mb.minor_mask[g];
+    if ((m4.x | m4.y | m4.z | m4.w) == 0u) return;
+    const unsigned m[4] = {m4.x, m4.y, m4.z, m4.w};
+    const int tw = (tid & 127) >> 5, tb = tid & 31;
+    const bool mine = tid < SITES_PER_GROUP && ((m[tw] >> tb) & 1u);
+    if (tid < SITES_PER_GROUP) {
+        kp[tid] = mine ? mb.cntP[g * SITES_PER_GROUP + tid] : 0u;
+        kn[tid] = mine ? mb.cntN[g * SITES_PER_GROUP + tid] : 0u;
+        curP[tid] = 0; curN[tid] = 0;
     }
-    *ok = a->minor != nullptr;
-    return rc;
+    __syncthreads();
+    if (mine) {
+        unsigned long long pp = 0, pn = 0;
+        for (int t = 0; t < tid; t++) { pp += kp[t]; pn += kn[t]; }
+        const unsigned rank = minor_rank(m4, mb.off_minor[g], tw, tb);
+        bP[tid] = mb.baseP[g] + pp; bN[tid] = mb.baseN[g] + pn; rk[tid] = rank;
+        p_off[rank] = bP[tid]; n_off[rank] = bN[tid];
+    }
+    __syncthreads();
+    const uint4 RX = mb.ref_x[g], RY = mb.ref_y[g];
+    const uint4 *base = mb.planes + (g * NPLANES) * n_pad;
+    for (unsigned s = tid; s < n; s += 256) {
+        const uint4 N = base[4 * n_pad + s];
+        const bool flagged = (mb.flags[g * mb.flag_words + (s >> 6)] >> (s & 63u)) & 1ull;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            unsigned nm = word_of(N, w) & m[w];
+            while (nm) {
+                const int b = __ffs(nm) - 1;
+                nm &= nm - 1;
+                const unsigned slot = atomicAdd(&curN[w * 32 + b], 1u);
+                n_ent[bN[w * 32 + b] + slot] = s;
+            }
+        }
+        if (!flagged) continue;
+        const uint4 A = base[s], C = base[n_pad + s], G = base[2 * n_pad + s], T = base[3 * n_pad + s];
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const unsigned a = word_of(A, w), c = word_of(C, w), gg = word_of(G, w), t = word_of(T, w), isn = word_of(N, w);
+            const unsigned rx = word_of(RX, w), ry = word_of(RY, w);
+            const unsigned ra = ~rx & ~ry, rc = rx & ~ry, rg = ~rx & ry, rt = rx & ry;
+            const unsigned has_ref = (a & ra) | (c & rc) | (gg & rg) | (t & rt);
+            const unsigned only_ref = ~((a ^ ra) | (c ^ rc) | (gg ^ rg) | (t ^ rt));
+            unsigned pm = ~isn & ~only_ref & m[w];
+            while (pm) {
+                const int b = __ffs(pm) - 1;
+                pm &= pm - 1;
+                const unsigned mask = ((a >> b) & 1u) | (((c >> b) & 1u) << 1) | (((gg >> b) & 1u) << 2) | (((t >> b) & 1u) << 3);
+                const unsigned code = (((has_ref >> b) & 1u) ? 0u : 16u) | mask;
+                const unsigned slot = atomicAdd(&curP[w * 32 + b], 1u);
+                const unsigned long long pos = bP[w * 32 + b] + slot;
+                p_ent[pos] = (s << ENT_SHIFT) | code;
+                E[pos] = make_uint2(s, (rk[w * 32 + b] << ENT_SHIFT) | code);
+            }
+        }
+    }
+}
+
+// per-sample lists, N entries: thread = (sample, chunk of groups), lanes over samples.  FILL = false: cnt[s * NCH + chunk] =
+// the sample's N sites among the chunk's minority sites; FILL = true: entries rank << 5 | 15 from off[s * NCH + chunk] on.
+static constexpr int MS_NCH = GS_CHUNKS + 1;      // the last "chunk" of a sample's list holds its listed entries
+template <bool FILL>
+__global__ __launch_bounds__(256) void minor_sample_kernel(const MinorBuild mb, size_t n_pad, size_t n, size_t groups, size_t gpc,
+                                                           unsigned *__restrict__ cnt, const unsigned long long *__restrict__ off,
+                                                           unsigned *__restrict__ ent)
+{
+    const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    const size_t chunk = (size_t)blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (s >= n || chunk >= GS_CHUNKS) return;
+    const size_t g0 = chunk * gpc, g1 = min(groups, g0 + gpc);
+    const uint4 *nplane = mb.planes + 4 * n_pad + s;
+    unsigned c = 0;
+    unsigned long long o = FILL ? off[s * MS_NCH + chunk] : 0ull;
+    for (size_t g = g0; g < g1; g++) {
+        const uint4 m4 = mb.minor_mask[g];                    // wave-uniform
+        if ((m4.x | m4.y | m4.z | m4.w) == 0u) continue;
+        const uint4 N = nplane[g * NPLANES * n_pad];
+        if (!FILL) { c += __popc(N.x & m4.x) + __popc(N.y & m4.y) + __popc(N.z & m4.z) + __popc(N.w & m4.w); continue; }
+        const unsigned og = mb.off_minor[g];
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            unsigned nm = word_of(N, w) & word_of(m4, w);
+            while (nm) {
+                const int b = __ffs(nm) - 1;
+                nm &= nm - 1;
+                ent[o++] = (minor_rank(m4, og, w, b) << ENT_SHIFT) | 15u;
+            }
+        }
+    }
+    if (!FILL) cnt[s * MS_NCH + chunk] = c;
+}
+
+// per-sample lists, listed entries (from E).  FILL = false: cnt[s * NCH + GS_CHUNKS]++ and c_p[s] += w.
+template <bool FILL>
+__global__ __launch_bounds__(256) void minor_listed_kernel(const uint2 *__restrict__ E, unsigned long long count, unsigned *__restrict__ cnt,
+                                                           unsigned *__restrict__ c_p, const unsigned long long *__restrict__ off,
+                                                           unsigned *__restrict__ cur, unsigned *__restrict__ ent)
+{
+    const unsigned long long k = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= count) return;
+    const uint2 e = E[k];
+    if (!FILL) {
+        atomicAdd(&cnt[(size_t)e.x * MS_NCH + GS_CHUNKS], 1u);
+        if (e.y & 16u) atomicAdd(&c_p[e.x], 1u);
+    } else {
+        ent[off[(size_t)e.x * MS_NCH + GS_CHUNKS] + atomicAdd(&cur[e.x], 1u)] = e.y;
+    }
+}
+
+__global__ void minor_sample_offsets_kernel(const unsigned long long *__restrict__ off, size_t n, unsigned long long *__restrict__ s_off)
+{
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s <= n) s_off[s] = off[s * MS_NCH];               // off has n * NCH + 1 entries
+}
+
+int minority_lists_build(tracs_alignment *a, const MinorBuild &mb, hipStream_t stream, int *ok)
+{
+    *ok = 0;
+    minority_lists_free(a);
+    const size_t n = a->n, L = mb.sites, groups = a->groups;
+    if (L == 0 || L >= (1ull << 27) || n >= (1ull << 27)) return TRACS_OK;           // entries hold rank << 5 / sample << 5
+    auto *g = new GeneralSparse();
+    auto fail_soft = [&]() { (void)hipGetLastError(); gs_free(g); return TRACS_OK; };
+#define GS_TRY(x) do { if ((x) != hipSuccess) return fail_soft(); } while (0)
+    const unsigned long long tot_s = mb.tot_p + mb.tot_n;
+    GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->s_off), (n + 1) * 8));
+    GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->p_off), (L + 1) * 8));
+    GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->n_off), (L + 1) * 8));
+    GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->c_p), std::max<size_t>(n, 1) * 4));
+    GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->s_ent), std::max<size_t>(tot_s, 1) * 4));
+    GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->p_ent), std::max<size_t>(mb.tot_p, 1) * 4));
+    GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->n_ent), std::max<size_t>(mb.tot_n, 1) * 4));
+    unsigned *cnt = nullptr, *cur = nullptr;
+    unsigned long long *off = nullptr;
+    uint2 *E = nullptr;
+    const size_t nsc = n * MS_NCH;
+    int rc;
+    if ((rc = workspace_get(40, nsc * 4, reinterpret_cast<void **>(&cnt))) || (rc = workspace_get(41, (nsc + 1) * 8, reinterpret_cast<void **>(&off))) ||
+        (rc = workspace_get(42, std::max<size_t>(mb.tot_p, 1) * sizeof(uint2), reinterpret_cast<void **>(&E))) ||
+        (rc = workspace_get(43, std::max<size_t>(n, 1) * 4, reinterpret_cast<void **>(&cur)))) { gs_free(g); return rc; }
+    GS_TRY(hipMemsetAsync(cnt, 0, nsc * 4, stream));
+    GS_TRY(hipMemsetAsync(cur, 0, std::max<size_t>(n, 1) * 4, stream));
+    GS_TRY(hipMemsetAsync(g->c_p, 0, std::max<size_t>(n, 1) * 4, stream));
+    hipLaunchKernelGGL(minor_site_lists_kernel, dim3((unsigned)groups), dim3(256), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off, g->n_off,
+                       g->p_ent, g->n_ent, E);
+    pack_stage_mark("minority lists: per site", stream);
+    const size_t gpc = (groups + GS_CHUNKS - 1) / GS_CHUNKS;
+    const dim3 sgrid((unsigned)((n + 63) / 64), GS_CHUNKS / 4);
+    const unsigned egrid = (unsigned)((mb.tot_p + 255) / 256);
+    hipLaunchKernelGGL((minor_sample_kernel<false>), sgrid, dim3(256), 0, stream, mb, a->n_pad, n, groups, gpc, cnt, nullptr, nullptr);
+    if (egrid) hipLaunchKernelGGL((minor_listed_kernel<false>), dim3(egrid), dim3(256), 0, stream, E, mb.tot_p, cnt, g->c_p, nullptr, nullptr, nullptr);
+    hipLaunchKernelGGL(gs_scan_kernel, dim3(1), dim3(1024), 0, stream, cnt, nsc, off);
+    hipLaunchKernelGGL(minor_sample_offsets_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, stream, off, n, g->s_off);
+    hipLaunchKernelGGL((minor_sample_kernel<true>), sgrid, dim3(256), 0, stream, mb, a->n_pad, n, groups, gpc, nullptr, off, g->s_ent);
+    if (egrid) hipLaunchKernelGGL((minor_listed_kernel<true>), dim3(egrid), dim3(256), 0, stream, E, mb.tot_p, nullptr, nullptr, off, cur, g->s_ent);
+    GS_TRY(hipGetLastError());
+    pack_stage_mark("minority lists: per sample", stream);
+#undef GS_TRY
+    a->minor = g;
+    *ok = 1;
+    return TRACS_OK;
 }
 
 static int fixup_launch(const GeneralSparse *g, bool minor, unsigned L, size_t n, size_t row_begin, size_t row_end, size_t col_begin,

@@ -392,7 +392,6 @@ __global__ __launch_bounds__(256) void derive_consensus_kernel(const uint4 *__re
     if (bad) atomicOr(partial_flag, 1u);
 }
 
-// cells of the block <- L (only needed when the group range is split over workgroups)
 // live tiles of a prefix pass -> compact list (order does not matter: every tile owns its cells)
 __global__ void compact_live_kernel(const int2 *__restrict__ tiles, const unsigned char *__restrict__ live, unsigned n_tiles,
                                     int2 *__restrict__ out, unsigned *__restrict__ n_out)
@@ -401,26 +400,26 @@ __global__ void compact_live_kernel(const int2 *__restrict__ tiles, const unsign
     if (t < n_tiles && live[t]) out[atomicAdd(n_out, 1u)] = tiles[t];
 }
 
-// ncomp cells of the block += c (site classes: sites at which no sample is N, when no counting pass runs)
+// ncomp cells of the block += c (site classes: sites at which no sample is N, when no counting pass runs).  Rows go over
+// grid.y with a stride, so a region of any height fits one launch (grid.y <= 65535).
 __global__ void add_cells_kernel(unsigned *__restrict__ ncomp, size_t ld, unsigned n, unsigned row_begin, unsigned row_end,
                                  unsigned col_begin, unsigned c)
 {
-    const unsigned i = row_begin + blockIdx.y;
-    if (i >= row_end) return;
-    for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
-        if (j > i && j >= col_begin) ncomp[(size_t)i * ld + j] += c;
+    for (unsigned i = row_begin + blockIdx.y; i < row_end; i += gridDim.y)
+        for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
+            if (j > i && j >= col_begin) ncomp[(size_t)i * ld + j] += c;
 }
 
+// cells of the block <- L (dist and, if given, ncomp; dist may be NULL: ncomp only)
 __global__ void init_cells_kernel(unsigned *__restrict__ dist, unsigned *__restrict__ ncomp, size_t ld, unsigned n,
                                   unsigned row_begin, unsigned row_end, unsigned col_begin, unsigned L)
 {
-    const unsigned i = row_begin + blockIdx.y;
-    if (i >= row_end) return;
-    for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
-        if (j > i && j >= col_begin) {
-            dist[(size_t)i * ld + j] = L;
-            if (ncomp) ncomp[(size_t)i * ld + j] = L;
-        }
+    for (unsigned i = row_begin + blockIdx.y; i < row_end; i += gridDim.y)
+        for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
+            if (j > i && j >= col_begin) {
+                if (dist) dist[(size_t)i * ld + j] = L;
+                if (ncomp) ncomp[(size_t)i * ld + j] = L;
+            }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -759,6 +758,15 @@ int tracs_debug_alignment_site_classes(const tracs_alignment *a, uint64_t *out)
     return a->classes_state;
 }
 
+// what the counting pass of the last decided classes reads: out[0] = sites, out[1] = 1 when that is the stored N plane in place
+int tracs_debug_alignment_count_source(const tracs_alignment *a, uint64_t *out)
+{
+    if (!a || !out || a->classes_state != 1) return 0;
+    out[0] = a->count_in_place ? a->L : a->L_inv;
+    out[1] = a->count_in_place ? 1 : 0;
+    return 1;
+}
+
 // Diagnostics for bench.py: HIP events on the launch stream around the three parts of a dense call (pair kernel incl. its
 // cell initialisation / sparse partial-code correction / invariant-site counting pass).  Off by default.
 static bool g_pair_timing = false;
@@ -818,20 +826,37 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
     DeviceCall guard(stream);
 
     if (a->L == 0) {   // every pair: d = 0, nn = 0
-        dim3 grid(64, (unsigned)(row_end - row_begin));
+        dim3 grid(64, (unsigned)std::min<size_t>(row_end - row_begin, 65535));
         hipLaunchKernelGGL(init_cells_kernel, grid, dim3(256), 0, stream, dist, ncomp, ld, (unsigned)a->n,
                            (unsigned)row_begin, (unsigned)row_end, (unsigned)col_begin, 0u);
         TRACS_HIP_CHECK(hipGetLastError());
         return TRACS_OK;
     }
 
-    // ---- encoding: consensus (3 planes) when no sample carries a partial IUPAC code, decided once per pack --------------
+    // ---- kernel family: matrix cores unless switched off (TRACS_MFMA=0, or an explicit TRACS_TILE_VARIANT) ----------------------
+    // (the matrix-core kernels keep 32-bit element offsets inside a stage: n_pad < 2^28 samples)
+    static const bool mfma_env_off = env_flag("TRACS_MFMA") == 0 || std::getenv("TRACS_TILE_VARIANT") != nullptr;
+    const bool mfma_off = mfma_env_off || a->n_pad >= (1ull << 28);
+
+    // ---- once per pack: encoding and site classes, decided together from the general planes (site_classes.hip) -----------------
+    // Classes in use: the pair kernels read `vplanes` (consensus form when no sample carries a partial IUPAC code), nothing else
+    // is derived.  Classes not in use: the consensus planes (3 of 5: a second, smaller copy) are derived when the alignment has
+    // a consensus form and there is room for them; otherwise the general planes are read as they are.
     if (a->dirty) {
         a->enc = 0;
         general_sparse_free(a);
         site_classes_free(a);
+        pack_stage_begin(stream);
+        int partial = -1;
+        if (!mfma_off) {
+            const int rc = site_classes_decide(a, stream, &partial);
+            if (rc) return rc;
+        }
         static const bool force_general = std::getenv("TRACS_FORCE_GENERAL") != nullptr;
-        if (!force_general) {
+        if (a->classes_state == 1) {
+            a->enc = a->classes_cons ? 1 : 0;
+            if (a->cplanes) { TRACS_HIP_CHECK(hipFree(a->cplanes)); a->cplanes = nullptr; }
+        } else if (!force_general && partial != 1) {
             const size_t cbytes = plane_bytes(a, 3);
             bool have = a->cplanes != nullptr;
             if (!have) {
@@ -855,24 +880,18 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
                 if (flag == 0) a->enc = 1;
                 else { TRACS_HIP_CHECK(hipFree(a->cplanes)); a->cplanes = nullptr; }
             }
+            pack_stage_mark("consensus planes", stream);
+        } else if (a->cplanes) {
+            TRACS_HIP_CHECK(hipFree(a->cplanes));
+            a->cplanes = nullptr;
         }
+        pack_stage_end();
         a->dirty = false;
     }
     const bool cons = a->enc == 1;
     const TileVariant &V = current_variant(cons);
     const double cells = (double)(row_end - row_begin) * (double)a->n;      // upper bound of the cells of this call
 
-    // ---- kernel: matrix cores unless switched off (TRACS_MFMA=0, or an explicit TRACS_TILE_VARIANT) ------------------------
-    // (the matrix-core kernels keep 32-bit element offsets inside a stage: n_pad < 2^28 samples)
-    static const bool mfma_env_off = env_flag("TRACS_MFMA") == 0 || std::getenv("TRACS_TILE_VARIANT") != nullptr;
-    const bool mfma_off = mfma_env_off || a->n_pad >= (1ull << 28);
-    // ---- site classes (site_classes.hip), decided once per pack: the matrix-core kernels then read the variable sites only,
-    // and a one-operand pass over the invariant sites completes the compared-sites counts
-    if (!mfma_off && a->classes_state == 0) {
-        const int rc = site_classes_decide(a, cons, stream);
-        if (rc) return rc;
-        if (a->classes_state == 1 && cons) { TRACS_HIP_CHECK(hipFree(a->cplanes)); a->cplanes = nullptr; }   // replaced by vplanes
-    }
     bool mfma = cons && !mfma_off;
     bool mfma_general = false;
     static const int gen_force = env_flag("TRACS_GENERAL_MFMA");          // 1: always, 0: never the matrix cores for general alignments
@@ -972,13 +991,16 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
     // fp32 accumulators of the matrix-core kernels are exact while every partial sum stays below 2^24:
     // consensus |S| <= 3 sites -> 2^22 sites per range; general G <= 4 sites -> 2^21
     const int max_gps = mfma ? (1 << (mfma_general ? 21 : 22)) / SITES_PER_GROUP : groups;
+    // in-place counting source: the counting pass alone makes nn, the pair kernels (and the partial-code correction) write d only
+    unsigned *const ncomp_pair = (classes && a->count_in_place) ? nullptr : ncomp;
+    bool nn_zeroed = false;                                // this call has set the region's nn cells to 0
     auto launch = [&](const int2 *tl, unsigned nwg, int ntl, int g_end, int gps, int k, unsigned t, TilePhase ph) -> int {
         if (mfma) {
             MfmaArgs A;
             A.P = pair_planes(a, !mfma_general);
             A.n_pad = a->n_pad; A.groups = g_end; A.tiles = tl; A.n_tiles = ntl; A.gps = gps; A.ksplit = k;
             A.L = (unsigned)pair_L(a); A.n = (unsigned)a->n; A.row_end = (unsigned)row_end; A.col_begin = (unsigned)col_begin;
-            A.dist = dist; A.ncomp = ncomp; A.ld = ld; A.thr = t; A.ph = ph;
+            A.dist = dist; A.ncomp = ncomp_pair; A.ld = ld; A.thr = t; A.ph = ph;
             A.keep_bound = (classes && a->minor) ? 1 : 0;      // terms are added to the cells afterwards: no flag values
             return launch_pairsnp_mfma(shape_id, mfma_general, nwg, stream, A);
         }
@@ -987,13 +1009,14 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
         return TRACS_OK;
     };
 
-    // Site classes: nn += sum v v' over the invariant sites, for the tiles whose cells are complete (all, or the live ones of
-    // a thresholded run).  Ranges of at most 2^23 sites keep the fp32 partial sums exact; the cells already hold the variable
-    // sites' counts, so every range adds with integer atomics.
+    // Site classes: the compared-sites counts of every site the pair kernel does not read -- NN = sum n n' over the N plane of
+    // the counted sites and nn += sites - c_i - c_j + NN --, for the tiles whose cells are complete (all, or the live ones of a
+    // thresholded run).  Ranges of at most 2^23 sites keep the fp32 partial sums exact; ranges add with integer atomics.
+    // In-place source (the stored N plane of every site): the pair kernels wrote d only and this pass alone makes nn.
     auto count_pass = [&](const int2 *tl, size_t ntl) -> int {
         if (!classes || !ncomp || (a->L_inv == 0 && a->L_full == 0)) return TRACS_OK;
         if (a->L_inv == 0) {                                   // only sites without any N: a constant
-            dim3 grid(64, (unsigned)(row_end - row_begin));
+            dim3 grid(64, (unsigned)std::min<size_t>(row_end - row_begin, 65535));
             hipLaunchKernelGGL(add_cells_kernel, grid, dim3(256), 0, stream, ncomp, ld, (unsigned)a->n, (unsigned)row_begin, (unsigned)row_end,
                                (unsigned)col_begin, (unsigned)a->L_full);
             return TRACS_OK;
@@ -1009,20 +1032,31 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
             if (rc) return rc;
             tl = ct->d; ntl = ct->n;
         }
-        if (ntl == 0) return TRACS_OK;
-        const int gi = (int)a->groups_inv, gcc = C.gc;
+        const bool in_place = a->count_in_place;
+        if (ntl == 0 && !in_place) return TRACS_OK;
+        const int gi = (int)(in_place ? a->groups : a->groups_inv), gcc = C.gc;
         const double keep_slots = slots;
         slots = (double)C.wg_per_cu * (slots / (double)(mfma ? S.wg_per_cu : V.wg_per_cu[cons ? 1 : 0]));
-        int k = std::max(pick_split(ntl, gi, gcc), (gi + (1 << 16) - 1) >> 16);
+        int k = std::max(pick_split(std::max<size_t>(ntl, 1), gi, gcc), (gi + (1 << 16) - 1) >> 16);
         slots = keep_slots;
         int g = (gi + k - 1) / k;
         g = (g + gcc - 1) / gcc * gcc;
         k = (gi + g - 1) / g;
+        if (in_place && k > 1 && !nn_zeroed) {
+            // several ranges add onto the cells: zero them first (nothing else has written nn) -- unless the call already has
+            dim3 grid(64, (unsigned)std::min<size_t>(row_end - row_begin, 65535));
+            hipLaunchKernelGGL(init_cells_kernel, grid, dim3(256), 0, stream, (unsigned *)nullptr, ncomp, ld, (unsigned)a->n,
+                               (unsigned)row_begin, (unsigned)row_end, (unsigned)col_begin, 0u);
+        }
+        if (ntl == 0) return TRACS_OK;
         MfmaArgs A;
-        A.P = a->iplanes; A.n_pad = a->n_pad; A.groups = gi; A.tiles = tl; A.n_tiles = (int)ntl; A.gps = g; A.ksplit = k;
-        A.L = (unsigned)(a->L_full + a->L_inv);                // range 0 adds sites - c_i - c_j once per cell (iplanes = the N plane)
+        A.P = in_place ? a->planes + 4 * a->n_pad : a->iplanes;
+        A.count_gp = in_place ? NPLANES : 1;
+        A.count_store = (in_place && k == 1) ? 1 : 0;
+        A.n_pad = a->n_pad; A.groups = gi; A.tiles = tl; A.n_tiles = (int)ntl; A.gps = g; A.ksplit = k;
+        // range 0 adds sites - c_i - c_j once per cell: the counted sites + the sites without any N; in place: every site
+        A.L = (unsigned)(in_place ? a->L : a->L_full + a->L_inv);
         A.c_n = a->c_counted;
-        if (a->count_complement) { A.L = (unsigned)a->L_full; A.c_n = nullptr; }      // diagnostics: sum v v' needs no c terms
         A.n = (unsigned)a->n; A.row_end = (unsigned)row_end; A.col_begin = (unsigned)col_begin;
         A.dist = dist; A.ncomp = ncomp; A.ld = ld; A.thr = 0xFFFFFFFFu; A.ph = TilePhase{0, 0, nullptr};
         C.fn((unsigned)(ntl * (size_t)k), stream, A);
@@ -1034,10 +1068,11 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
     };
     if (classes && groups == 0) {
         // no dense site at all: the distances come from the lists, the compared-sites counts from the counting pass
-        dim3 grid(64, (unsigned)(row_end - row_begin));
+        dim3 grid(64, (unsigned)std::min<size_t>(row_end - row_begin, 65535));
         pair_mark(0, stream);
         hipLaunchKernelGGL(init_cells_kernel, grid, dim3(256), 0, stream, dist, ncomp, ld, (unsigned)a->n,
                            (unsigned)row_begin, (unsigned)row_end, (unsigned)col_begin, 0u);
+        nn_zeroed = true;
         pair_mark(1, stream);
         int rc = minor_pass();
         if (rc) return rc;
@@ -1076,7 +1111,7 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
             const int k2 = stage_split(groups - prefix, std::max({1, std::min({32, want, (groups - prefix) / (16 * kGC)}), (groups - prefix + max_gps - 1) / max_gps}), gps2);
             if ((rc = launch(live_tiles, (unsigned)(n_live * (size_t)k2), (int)n_live, groups, gps2, k2, thr, TilePhase{2, prefix, nullptr}))) return rc;
         }
-        if (mfma_general && (rc = general_sparse_fixup(a, row_begin, row_end, col_begin, dist, ncomp, ld, stream))) return rc;
+        if (mfma_general && (rc = general_sparse_fixup(a, row_begin, row_end, col_begin, dist, ncomp_pair, ld, stream))) return rc;
         if ((rc = minor_pass())) return rc;
         if ((rc = count_pass(live_tiles, n_live))) return rc;
         TRACS_HIP_CHECK(hipGetLastError());
@@ -1088,14 +1123,15 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
     ksplit = stage_split(groups, ksplit, gps);
     pair_mark(0, stream);
     if (ksplit > 1) {
-        dim3 grid(64, (unsigned)(row_end - row_begin));
+        dim3 grid(64, (unsigned)std::min<size_t>(row_end - row_begin, 65535));
         hipLaunchKernelGGL(init_cells_kernel, grid, dim3(256), 0, stream, dist, ncomp, ld, (unsigned)a->n,
                            (unsigned)row_begin, (unsigned)row_end, (unsigned)col_begin, (cons || mfma) ? 0u : (unsigned)a->L);
+        nn_zeroed = cons || mfma;
     }
     int rc = launch(T.d, (unsigned)(T.n * (size_t)ksplit), (int)T.n, groups, gps, ksplit, thr, TilePhase{0, 0, nullptr});
     if (rc) return rc;
     pair_mark(1, stream);
-    if (mfma_general && (rc = general_sparse_fixup(a, row_begin, row_end, col_begin, dist, ncomp, ld, stream))) return rc;
+    if (mfma_general && (rc = general_sparse_fixup(a, row_begin, row_end, col_begin, dist, ncomp_pair, ld, stream))) return rc;
     if ((rc = minor_pass())) return rc;
     pair_mark(2, stream);
     if ((rc = count_pass(nullptr, 0))) return rc;

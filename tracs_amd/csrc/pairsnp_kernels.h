@@ -44,7 +44,9 @@ struct MfmaArgs {
     size_t ld;
     unsigned thr;
     TilePhase ph;
-    const unsigned *c_n = nullptr;   // counting form: per sample, its N sites among the counted sites
+    const unsigned *c_n = nullptr;   // counting form: per sample, its N sites among the sites the pass reads
+    int count_gp = 1;          // counting form: planes per group of the source (1: iplanes; NPLANES: the stored N plane in place)
+    int count_store = 0;       // counting form: store nn instead of adding to the cells (in-place source, one range per tile)
     int keep_bound = 0;        // consensus form, thresholded runs: dead cells keep their lower bound instead of the 0xFFFFFFFF flag
                                // (terms are added to the cells afterwards: minority sites)
 };
@@ -73,9 +75,16 @@ struct CountShape {
 CountShape count_shape_current();               // the default (TRACS_COUNT_TILE=<name> selects another: diagnostics)
 CountShape count_shape_like(int ti, int tj);    // the shape with this workgroup tile (fn == nullptr when there is none)
 
-// ---- site classes (site_classes.hip) --------------------------------------------------------------------------
-int site_classes_decide(tracs_alignment *a, bool consensus, hipStream_t stream);
+// ---- site classes and the encoding decision (site_classes.hip) -------------------------------------------------------
+// Classifies the sites of the general planes once per pack.  *partial: 1 some sample carries a partial IUPAC code, 0 none
+// does (the alignment has a consensus form), -1 not determined (classification skipped).  On return a->classes_state is 1
+// (classes in use: vplanes in the encoding a->classes_cons says, counting pass source, minority lists) or -1.
+int site_classes_decide(tracs_alignment *a, hipStream_t stream, int *partial);
 void site_classes_free(tracs_alignment *a);
+// stage clock of the once-per-pack work (HIP events on the launch stream; tracs_debug_pack_stages, TRACS_CLASSES_TRACE)
+void pack_stage_begin(hipStream_t stream);
+void pack_stage_mark(const char *name, hipStream_t stream);
+void pack_stage_end();
 
 // ---- sparse side structures of the general matrix-core path (general_sparse.hip) -------------------------------
 struct GeneralSparse;
@@ -86,11 +95,21 @@ void general_sparse_free(tracs_alignment *a);
 // dist[i][j] += T1 + T2 (partial-code terms), ncomp[i][j] += L - c_i - c_j for the cells of the dense region.
 int general_sparse_fixup(tracs_alignment *a, size_t row_begin, size_t row_end, size_t col_begin, unsigned *dist,
                          unsigned *ncomp, size_t ld, hipStream_t stream);
-// The same lists for the MINORITY sites of an alignment cut into site classes (site_classes.hip), read in place from its planes
-// (consensus or general): a sample that is neither N nor exactly the site's reference base is listed with its allele mask and
-// w = [reference base not in the mask]; minority_fixup adds the sites' contribution to dist (general_fixup_kernel<MINOR>).
-int minority_lists_build(tracs_alignment *a, bool consensus, const uint4 *planes, const uint4 *minor_mask, const uint4 *ref_x,
-                         const uint4 *ref_y, const unsigned *off_minor, size_t sites, hipStream_t stream, int *ok);
+// The same lists for the MINORITY sites of an alignment cut into site classes (site_classes.hip): a sample that is neither N nor
+// exactly the site's reference base is listed with its allele mask and w = [reference base not in the mask]; minority_fixup
+// adds the sites' contribution to dist (general_fixup_kernel<MINOR>).  Built from what classify_sites_kernel left behind:
+struct MinorBuild {
+    const uint4 *planes;                     // the five general planes
+    const uint4 *minor_mask, *ref_x, *ref_y; // per group: minority sites, reference base bits
+    const unsigned *off_minor;               // per group: minority sites before it (a site's list index = its rank)
+    const unsigned *cntP, *cntN;             // per site: listed samples, N samples
+    const unsigned long long *baseP, *baseN; // per group: list entries of the minority sites before it
+    const unsigned long long *flags;         // per group and 64 samples: listed somewhere in the group
+    size_t flag_words;
+    size_t sites;                            // minority sites
+    unsigned long long tot_p, tot_n;         // list entries in all
+};
+int minority_lists_build(tracs_alignment *a, const MinorBuild &mb, hipStream_t stream, int *ok);
 void minority_lists_free(tracs_alignment *a);
 int minority_fixup(tracs_alignment *a, size_t row_begin, size_t row_end, size_t col_begin, unsigned *dist, size_t ld, hipStream_t stream);
 

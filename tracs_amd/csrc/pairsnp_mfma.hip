@@ -74,7 +74,7 @@ __global__ __launch_bounds__(NWR * NWC * 64, (NBR * NBC > 4 ? 1 : COUNT ? 4 : 2)
     static_assert(STAGE % 64 == 0, "stage must be whole wave-instructions");
     static_assert(!GENERAL || GC == 2, "the general form takes one residue class of four words: two groups per stage");
     static_assert(!COUNT || GC % 2 == 0, "the counting form takes one residue class of four words: pairs of groups");
-    static_assert(GC - 1 <= (COUNT ? COUNT_PAD_GROUPS : PAD_GROUPS), "stages may overhang the alignment by GC - 1 zero groups");
+    static_assert(GC - 1 <= PAD_GROUPS, "stages may overhang the alignment by GC - 1 zero groups");
     __shared__ uint4 lds[2][STAGE];
 
     const unsigned q = xcd_remap(blockIdx.x, gridDim.x);
@@ -90,6 +90,9 @@ __global__ __launch_bounds__(NWR * NWC * 64, (NBR * NBC > 4 ? 1 : COUNT ? 4 : 2)
     if (g_begin >= g_end) return;
     const uint4 *__restrict__ P = A.P;
     const size_t n_pad = A.n_pad;
+    // the counting form's plane is either its own array (one plane per group) or the stored N plane of the alignment, in place
+    // (five planes per group): a run-time stride, the runs themselves are the same
+    const int GPr = COUNT ? A.count_gp : GP;
 
     // One staging wave-instruction = 64 consecutive samples of one (group, plane) run: a wave-uniform base (kept in SGPRs)
     // plus lane * 16 bytes.  Ranges are whole stages except the last one of the alignment, which may run GC - 1 groups past
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(NWR * NWC * 64, (NBR * NBC > 4 ? 1 : COUNT ? 4 : 2)
     auto stage_glds = [&](int gs, int b) {
 #pragma unroll
         for (int r = 0; r < GC * NP; r++) {
-            const uint4 *run = P + ((size_t)(gs + r / NP) * GP + (r % NP)) * n_pad + lane;
+            const uint4 *run = P + ((size_t)(gs + r / NP) * GPr + (r % NP)) * n_pad + lane;
 #pragma unroll
             for (int cc = 0; cc < CPW; cc++) {
                 const int c = wave + cc * NW;
@@ -126,8 +129,8 @@ __global__ __launch_bounds__(NWR * NWC * 64, (NBR * NBC > 4 ? 1 : COUNT ? 4 : 2)
         const int r = t / CH, c = t - r * CH;
         const int s0 = c * 64;
         // 32-bit element offset inside the stage (n_pad < 2^28 samples): one SGPR per piece instead of an address pair
-        const unsigned off = (unsigned)((r / NP) * GP + (r % NP)) * (unsigned)n_pad + (unsigned)(s0 < TJ ? j0 + s0 : i0 + (s0 - TJ));
-        __builtin_amdgcn_global_load_lds((glb_void_t *)(P + (size_t)gs * GP * n_pad + off + lane),
+        const unsigned off = (unsigned)((r / NP) * GPr + (r % NP)) * (unsigned)n_pad + (unsigned)(s0 < TJ ? j0 + s0 : i0 + (s0 - TJ));
+        __builtin_amdgcn_global_load_lds((glb_void_t *)(P + (size_t)gs * GPr * n_pad + off + lane),
                                          (lds_void_t *)&lds[b][r * TS + c * 64], 16, 0, 0);
     };
     // this lane's sample inside a staged (group, plane) run, per row block / column block of the wave's tile; a lane takes
@@ -395,10 +398,13 @@ __global__ __launch_bounds__(NWR * NWC * 64, (NBR * NBC > 4 ? 1 : COUNT ? 4 : 2)
                 const unsigned i = cell_row(rb, r), j = cell_col(cb);
                 if (i < A.row_end && j < A.n && j > i && j >= A.col_begin) {
                     const int V = (int)accV[rb][cb][r];
-                    if constexpr (COUNT) {                     // the cells hold the variable sites' counts already;
+                    if constexpr (COUNT) {
                         // operand plane n = "is N here" (mostly zero words): NN = sum n n', and nn = sites - c_i - c_j + NN
-                        // (A.L: the counted sites + the sites without any N, added once per cell by range 0)
-                        atomicAdd(&A.ncomp[(size_t)i * A.ld + j], (unsigned)V + (ks == 0 ? A.L - (A.c_n ? A.c_n[i] + A.c_n[j] : 0u) : 0u));
+                        // (A.L: the sites this pass stands for, added once per cell by range 0).  The cells hold the dense sites'
+                        // counts already (or zeros: in-place source, split range); a single range over the in-place source stores.
+                        const unsigned val = (unsigned)V + (ks == 0 ? A.L - (A.c_n ? A.c_n[i] + A.c_n[j] : 0u) : 0u);
+                        if (A.count_store) A.ncomp[(size_t)i * A.ld + j] = val;
+                        else atomicAdd(&A.ncomp[(size_t)i * A.ld + j], val);
                         continue;
                     }
                     const int S = (int)accS[rb][cb][r];

@@ -1,4 +1,4 @@
-// site_classes.hip -- site classes of a packed alignment, decided once per pack.
+// site_classes.hip -- site classes of a packed alignment and the encoding decision, made together once per pack.
 //
 // Reference behaviour restated (never copied): /root/reference/src/pairsnp.hpp
 //   pair loop :395-420   d = L - popcount(match),  nn = L - popcount(Ni | Nj): every site is visited for every pair.
@@ -6,13 +6,14 @@
 // A site at which every sample that is not N carries the SAME base never separates two samples: it adds 0 to d(i, j) and
 // [neither i nor j is N there] to nn(i, j), whatever the pair; and a site at which only a FEW samples differ from the others
 // separates only the pairs that involve one of those few.  Real alignments are mostly such sites.  The sites are cut into
-// classes once per pack (k = samples that are neither N nor exactly the site's reference base -- the base of one of its one-base
-// samples --, i.e. another base or a partial IUPAC code; cN = samples that are N there):
+// classes once per pack (k = samples that are neither N nor exactly the site's reference base -- the base of its lowest-index
+// one-base sample --, i.e. another base or a partial IUPAC code; cN = samples that are N there):
 //     empty      every sample is N (or the tail bits behind L): contributes to nothing;
 //     dense      k (cN + k) above the budget below: the usual pair kernel, over `vplanes` -- these sites re-packed in site
-//                order, same planes and layout as the kernels' usual source;
-//     counted    every other site with cN >= 1: NN = sum n_i n_j over `iplanes` (ONE plane, n = "this sample is N here";
-//                pairsnp_mfma_kernel<COUNT>, one operand plane instead of four or five) and nn += sites - c_i - c_j + NN;
+//                order, in the encoding the pair kernel reads (consensus X, Y, V when no sample carries a partial IUPAC code
+//                anywhere, else the five general planes);
+//     counted    every other site with cN >= 1: NN = sum n_i n_j (ONE plane, n = "this sample is N here";
+//                pairsnp_mfma_kernel<COUNT>, one operand plane instead of four or five) and nn = sites - c_i - c_j + NN;
 //     full       every other site with cN = 0: +1 to every nn, a constant;
 //     minority   the counted / full sites with k >= 1: d gets their contribution from sparse lists -- the k samples with their
 //                allele masks, the cN samples -- with the machinery general_sparse.hip uses for partial IUPAC codes
@@ -21,117 +22,191 @@
 // The decomposition is exact site by site (tests/test_host_logic.py::test_site_class_identity); a pass costs
 // (4 L_dense + L_counted) / 4 L of the dense one in matrix instructions plus ~sum k (cN + k) list entries.  Chosen when that
 // is < 0.92; TRACS_SITE_CLASSES=0/1 forces, TRACS_MINORITY=0 keeps every site with k >= 1 dense.
+//
+// What a pack costs (round 3: one source, no second copy of the alignment).  Everything is read from the five general planes
+// load_seqs builds -- the consensus copy of round 2 (a 3/5-size second alignment, derived before classifying and dropped
+// afterwards) only exists when the classes are NOT used:
+//     classify_sites_kernel   one read of the planes: reference bases from the first samples that resolve every site, then
+//                             k and cN of every site with BIT-SLICED counters in registers (a carry-save adder per 32-site
+//                             word: data-independent, no LDS atomics -- a uniformly random alignment costs what an invariant
+//                             one does), the class masks, "some sample carries a partial code" (= the encoding decision),
+//                             per sample and group "listed somewhere here" (64 samples per word: what the list builder may
+//                             skip), per group the list sizes of its minority sites;
+//     counting pass source    the stored N plane IN PLACE (stride 5 planes) when nearly every site needs counting -- then
+//                             nn = L - c_i - c_j + NN over ALL sites and the pair kernel writes d only --, else the counted
+//                             sites' N plane re-packed into `iplanes` (runs of consecutive sites are funnel-shifted, not gathered
+//                             bit by bit);
+//     minority lists          general_sparse.hip: per-site lists from the N plane + the flagged samples only, per-sample
+//                             lists from the N plane: 3 reads of ONE plane instead of 4 reads of the alignment.
 #include "pairsnp_kernels.h"
 
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 namespace tracs {
 
-__device__ __forceinline__ unsigned wave_or(unsigned v)
+// add the 32 one-bit values of `m` to 32 bit-sliced counters (plane j holds bit j of every counter); <= 255 adds between flushes
+__device__ __forceinline__ void sliced_add(unsigned (&p)[8], unsigned m)
 {
+    unsigned c = m;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v |= __shfl_xor(v, off, 64);
-    return v;
+    for (int j = 0; j < 8; j++) { const unsigned t = p[j] & c; p[j] ^= c; c = t; }
 }
 
-// One workgroup per 128-site group.  Pass 1: a reference base per site -- the base of the first sample, in thread order, that
-// carries exactly one base there.  Pass 2: per site k = samples that are neither N nor exactly that base (another base, or a
-// partial IUPAC code) and cN = samples that are N, counted with LDS atomics (both are sparse).  Then the class masks of the group.
-// CONS: planes X, Y, V (3 per group; bases A = 0, C = 1, G = 2, T = 3 = X + 2 Y).  !CONS: planes A, C, G, T, N (5 per group).
-template <bool CONS>
+struct GroupWords { unsigned x[4], y[4], one[4], some[4], isn[4], bad[4]; };
+
+// per sample and 32-site word of group g: x, y = the base's two bits where the sample carries exactly one base (`one`),
+// `some` = a base or a partial code (not N; tail bits: neither), isn = N, bad = a partial IUPAC code (2 or 3 alleles)
+__device__ __forceinline__ void load_group_words(const uint4 *__restrict__ P, size_t n_pad, size_t g, unsigned s, GroupWords &q)
+{
+    const uint4 *base = P + (g * NPLANES) * n_pad + s;
+    const uint4 A = base[0], C = base[n_pad], G = base[2 * n_pad], T = base[3 * n_pad], N = base[4 * n_pad];
+    const unsigned a[4] = {A.x, A.y, A.z, A.w}, c[4] = {C.x, C.y, C.z, C.w}, gg[4] = {G.x, G.y, G.z, G.w};
+    const unsigned t[4] = {T.x, T.y, T.z, T.w}, nn[4] = {N.x, N.y, N.z, N.w};
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const unsigned two = (a[w] & c[w]) | (a[w] & gg[w]) | (a[w] & t[w]) | (c[w] & gg[w]) | (c[w] & t[w]) | (gg[w] & t[w]);
+        const unsigned any = a[w] | c[w] | gg[w] | t[w];
+        q.one[w] = any & ~two;
+        q.some[w] = any & ~nn[w];
+        q.isn[w] = nn[w];
+        q.bad[w] = two & ~nn[w];
+        q.x[w] = (c[w] | t[w]) & q.one[w];
+        q.y[w] = (gg[w] | t[w]) & q.one[w];
+    }
+}
+
+// One workgroup per 128-site group, threads over samples (coalesced 16-byte loads per plane).
+//   pass 1  reference base per site = the base of the LOWEST-INDEX sample that carries exactly one base there; samples are
+//           read 256 at a time until every site of the group is resolved (normally the first 256: 2.5 % of a pass at 10 000
+//           samples; a group with an all-N site reads everybody);
+//   pass 2  k (listed: not N and not exactly the reference base) and cN (N) per site over all samples, bit-sliced in
+//           registers, flushed through LDS every 255 samples per thread; partial-code flag; per (64 samples, group) the
+//           samples that are listed somewhere in the group.
+// Outputs per group: the four class masks, the reference base bits, k and cN of every site, the list sizes of its minority
+// sites (gP = sum k, gN = sum cN over them).
 __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__restrict__ P, size_t n_pad, unsigned n, unsigned budget,
                                                              uint4 *__restrict__ dense_mask, uint4 *__restrict__ count_mask,
                                                              uint4 *__restrict__ minor_mask, uint4 *__restrict__ full_mask,
-                                                             uint4 *__restrict__ ref_x, uint4 *__restrict__ ref_y)
+                                                             uint4 *__restrict__ ref_x, uint4 *__restrict__ ref_y,
+                                                             unsigned *__restrict__ cntP, unsigned *__restrict__ cntN,
+                                                             unsigned *__restrict__ gP, unsigned *__restrict__ gN,
+                                                             unsigned long long *__restrict__ flags, size_t flag_words,
+                                                             unsigned *__restrict__ partial_flag)
 {
     const size_t g = blockIdx.x;
     __shared__ unsigned red[4][4][4];
     __shared__ unsigned sref[4][4];                     // one-base sample seen, ref X, ref Y, somebody is not N
-    __shared__ unsigned cM[SITES_PER_GROUP], cN[SITES_PER_GROUP];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x < SITES_PER_GROUP) { cM[threadIdx.x] = 0; cN[threadIdx.x] = 0; }
-    // per sample and word: x, y = the base's two bits where the sample carries exactly one base (`one`), `some` = not N
-    auto load = [&](unsigned s, unsigned (&x)[4], unsigned (&y)[4], unsigned (&one)[4], unsigned (&some)[4], unsigned (&isn)[4]) {
-        if constexpr (CONS) {
-            const uint4 X = P[(g * 3 + 0) * n_pad + s], Y = P[(g * 3 + 1) * n_pad + s], V = P[(g * 3 + 2) * n_pad + s];
-            const unsigned xx[4] = {X.x, X.y, X.z, X.w}, yy[4] = {Y.x, Y.y, Y.z, Y.w}, vv[4] = {V.x, V.y, V.z, V.w};
+    __shared__ unsigned planes_lds[256][4][8];          // one counter's bit planes of every thread (32 KiB)
+    __shared__ unsigned tot[2][SITES_PER_GROUP];        // k, cN
+    __shared__ unsigned half_sum[SITES_PER_GROUP];
+    __shared__ unsigned wsum[2][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < SITES_PER_GROUP) { tot[0][tid] = 0; tot[1][tid] = 0; }
+    if (tid < 4) { sref[0][tid] = 0; sref[1][tid] = 0; sref[2][tid] = 0; sref[3][tid] = 0; }
+    __syncthreads();
+
+    // ---- pass 1: reference bases ----------------------------------------------------------------------------------------
+    for (unsigned base = 0; base < n; base += 256) {
+        unsigned seen[4] = {0, 0, 0, 0}, rx[4] = {0, 0, 0, 0}, ry[4] = {0, 0, 0, 0};
+        const unsigned s = base + tid;
+        if (s < n) {
+            GroupWords q;
+            load_group_words(P, n_pad, g, s, q);
 #pragma unroll
-            for (int w = 0; w < 4; w++) { x[w] = xx[w]; y[w] = yy[w]; one[w] = vv[w]; some[w] = vv[w]; isn[w] = ~vv[w]; }
-        } else {
-            const uint4 A = P[(g * NPLANES + 0) * n_pad + s], C = P[(g * NPLANES + 1) * n_pad + s];
-            const uint4 G = P[(g * NPLANES + 2) * n_pad + s], T = P[(g * NPLANES + 3) * n_pad + s];
-            const uint4 N = P[(g * NPLANES + 4) * n_pad + s];
-            const unsigned a[4] = {A.x, A.y, A.z, A.w}, c[4] = {C.x, C.y, C.z, C.w}, gg[4] = {G.x, G.y, G.z, G.w};
-            const unsigned t[4] = {T.x, T.y, T.z, T.w}, nn[4] = {N.x, N.y, N.z, N.w};
-#pragma unroll
-            for (int w = 0; w < 4; w++) {
-                const unsigned two = (a[w] & c[w]) | (a[w] & gg[w]) | (a[w] & t[w]) | (c[w] & gg[w]) | (c[w] & t[w]) | (gg[w] & t[w]);
-                const unsigned any = a[w] | c[w] | gg[w] | t[w];
-                one[w] = any & ~two;                            // exactly one allele
-                some[w] = any & ~nn[w];                         // a base or a partial code (tail bits: neither)
-                isn[w] = nn[w];
-                x[w] = (c[w] | t[w]) & one[w];
-                y[w] = (gg[w] | t[w]) & one[w];
-            }
+            for (int w = 0; w < 4; w++) { seen[w] = q.one[w]; rx[w] = q.x[w]; ry[w] = q.y[w]; }
         }
-    };
-    unsigned seen[4] = {0, 0, 0, 0}, rx[4] = {0, 0, 0, 0}, ry[4] = {0, 0, 0, 0}, anyb[4] = {0, 0, 0, 0};
-    for (unsigned s = threadIdx.x; s < n; s += 256) {
-        unsigned x[4], y[4], one[4], some[4], isn[4];
-        load(s, x, y, one, some, isn);
+        // lower lanes first: the result is the same on every lane of the wave
 #pragma unroll
         for (int w = 0; w < 4; w++) {
-            const unsigned fresh = one[w] & ~seen[w];
-            rx[w] |= x[w] & fresh; ry[w] |= y[w] & fresh; seen[w] |= one[w]; anyb[w] |= some[w];
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned os = __shfl_xor(seen[w], off, 64), ox = __shfl_xor(rx[w], off, 64), oy = __shfl_xor(ry[w], off, 64);
+                const bool me_first = (lane & off) == 0;
+                const unsigned fs = me_first ? seen[w] : os, fx = me_first ? rx[w] : ox, fy = me_first ? ry[w] : oy;
+                const unsigned ls = me_first ? os : seen[w], lx = me_first ? ox : rx[w], ly = me_first ? oy : ry[w];
+                rx[w] = fx | (lx & ~fs); ry[w] = fy | (ly & ~fs); seen[w] = fs | ls;
+            }
+            if (lane == 0) { red[wave][0][w] = seen[w]; red[wave][1][w] = rx[w]; red[wave][2][w] = ry[w]; }
         }
+        __syncthreads();
+        if (tid < 4) {
+            const int w = tid;
+            unsigned fs = sref[0][w], fx = sref[1][w], fy = sref[2][w];           // earlier chunks first
+            for (int k = 0; k < 4; k++) { fx |= red[k][1][w] & ~fs; fy |= red[k][2][w] & ~fs; fs |= red[k][0][w]; }
+            sref[0][w] = fs; sref[1][w] = fx; sref[2][w] = fy;
+        }
+        __syncthreads();
+        if ((sref[0][0] & sref[0][1] & sref[0][2] & sref[0][3]) == 0xFFFFFFFFu) break;     // block-uniform
     }
-    // lower lanes first: the result is the same on every lane of the wave
+    // (a site without any one-base sample keeps the reference A: every sample that is not N is listed there)
+    const unsigned refx[4] = {sref[1][0], sref[1][1], sref[1][2], sref[1][3]}, refy[4] = {sref[2][0], sref[2][1], sref[2][2], sref[2][3]};
+
+    // ---- pass 2: k and cN of every site -----------------------------------------------------------------------------------
+    unsigned anyb[4] = {0, 0, 0, 0}, bad = 0;
+    const int site = tid & 127, sw = site >> 5, sb = site & 31, half = tid >> 7;
+    // flush: the bit planes of all threads through LDS, one counter at a time; thread (site, half) sums 128 threads' planes
+    auto flush = [&](unsigned (&pl)[4][8], int which) {
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < 4; w++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) { planes_lds[tid][w][j] = pl[w][j]; pl[w][j] = 0; }
+        __syncthreads();
+        unsigned sum = 0;
+        for (int t = half * 128; t < half * 128 + 128; t++) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) sum += ((planes_lds[t][sw][j] >> sb) & 1u) << j;
+        }
+        if (half) half_sum[site] = sum;
+        __syncthreads();
+        if (!half) tot[which][site] += sum + half_sum[site];
+    };
+    unsigned kp[4][8], np[4][8];
+#pragma unroll
+    for (int w = 0; w < 4; w++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) { kp[w][j] = 0; np[w][j] = 0; }
+    unsigned since = 0;
+    for (unsigned base = 0; base < n; base += 256) {
+        const unsigned s = base + tid;
+        bool listed_here = false;
+        if (s < n) {
+            GroupWords q;
+            load_group_words(P, n_pad, g, s, q);
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                // listed: not N and not exactly the reference base
+                const unsigned diff = q.some[w] & ~(q.one[w] & ~((q.x[w] ^ refx[w]) | (q.y[w] ^ refy[w])));
+                sliced_add(kp[w], diff);
+                sliced_add(np[w], q.isn[w]);
+                anyb[w] |= q.some[w];
+                bad |= q.bad[w];
+                listed_here = listed_here || diff != 0u;
+            }
+        }
+        const unsigned long long fl = __ballot(listed_here);
+        if (lane == 0) flags[g * flag_words + (base >> 6) + wave] = fl;
+        if (++since == 255u) { flush(kp, 0); flush(np, 1); since = 0; }     // block-uniform
+    }
+    if (since) { flush(kp, 0); flush(np, 1); }
+    // somebody is not N, per site
 #pragma unroll
     for (int w = 0; w < 4; w++) {
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned os = __shfl_xor(seen[w], off, 64), ox = __shfl_xor(rx[w], off, 64), oy = __shfl_xor(ry[w], off, 64);
-            const bool me_first = (lane & off) == 0;
-            const unsigned fs = me_first ? seen[w] : os, fx = me_first ? rx[w] : ox, fy = me_first ? ry[w] : oy;
-            const unsigned ls = me_first ? os : seen[w], lx = me_first ? ox : rx[w], ly = me_first ? oy : ry[w];
-            rx[w] = fx | (lx & ~fs); ry[w] = fy | (ly & ~fs); seen[w] = fs | ls;
-            anyb[w] |= __shfl_xor(anyb[w], off, 64);
-        }
-        if (lane == 0) { red[wave][0][w] = seen[w]; red[wave][1][w] = rx[w]; red[wave][2][w] = ry[w]; red[wave][3][w] = anyb[w]; }
+        for (int off = 32; off > 0; off >>= 1) anyb[w] |= __shfl_xor(anyb[w], off, 64);
+        if (lane == 0) red[wave][3][w] = anyb[w];
     }
-    __syncthreads();
-    if (threadIdx.x < 4) {
-        const int w = threadIdx.x;
-        unsigned fs = 0, fx = 0, fy = 0, fa = 0;
-        for (int k = 0; k < 4; k++) {
-            fx |= red[k][1][w] & ~fs; fy |= red[k][2][w] & ~fs; fs |= red[k][0][w]; fa |= red[k][3][w];
-        }
-        sref[0][w] = fs; sref[1][w] = fx; sref[2][w] = fy; sref[3][w] = fa;
-    }
-    __syncthreads();
-    // (a site without any one-base sample keeps the reference A: every sample that is not N is listed there)
-    const unsigned any[4] = {sref[3][0], sref[3][1], sref[3][2], sref[3][3]};
-    const unsigned refx[4] = {sref[1][0], sref[1][1], sref[1][2], sref[1][3]}, refy[4] = {sref[2][0], sref[2][1], sref[2][2], sref[2][3]};
-    for (unsigned s = threadIdx.x; s < n; s += 256) {
-        unsigned x[4], y[4], one[4], some[4], isn[4];
-        load(s, x, y, one, some, isn);
-#pragma unroll
-        for (int w = 0; w < 4; w++) {
-            // listed: not N and not exactly the reference base
-            unsigned diff = some[w] & ~(one[w] & ~((x[w] ^ refx[w]) | (y[w] ^ refy[w])));
-            while (diff) { const int b = __ffs(diff) - 1; diff &= diff - 1; atomicAdd(&cM[w * 32 + b], 1u); }
-            unsigned nb = isn[w] & any[w];                      // N at a site where somebody is not
-            while (nb) { const int b = __ffs(nb) - 1; nb &= nb - 1; atomicAdd(&cN[w * 32 + b], 1u); }
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < SITES_PER_GROUP) {
-        const int t = threadIdx.x, w = t >> 5, b = t & 31;
-        const bool some = (any[w] >> b) & 1u;
-        const unsigned long long k = cM[t], c = cN[t];
+    const int any_bad = __syncthreads_or(bad != 0u);
+    if (tid == 0 && any_bad) atomicOr(partial_flag, 1u);
+    if (tid < SITES_PER_GROUP) {
+        const int w = sw, b = sb;
+        const unsigned anyw = red[0][3][w] | red[1][3][w] | red[2][3][w] | red[3][3][w];
+        const bool some = (anyw >> b) & 1u;
+        const unsigned long long k = tot[0][tid], c = some ? tot[1][tid] : 0ull;      // (an empty site: every sample is N)
         const bool minor = some && k >= 1 && budget > 0 && k * (c + k) <= (unsigned long long)budget;
         const bool dense = some && k >= 1 && !minor;
         const bool counted = some && !dense && c >= 1;
@@ -145,37 +220,54 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
             pm[2 * wave] = (unsigned)bm; pm[2 * wave + 1] = (unsigned)(bm >> 32);
             pf[2 * wave] = (unsigned)bf; pf[2 * wave + 1] = (unsigned)(bf >> 32);
         }
+        cntP[g * SITES_PER_GROUP + tid] = (unsigned)k;
+        cntN[g * SITES_PER_GROUP + tid] = (unsigned)c;
+        unsigned sp = minor ? (unsigned)k : 0u, sn = minor ? (unsigned)c : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { sp += __shfl_xor(sp, off, 64); sn += __shfl_xor(sn, off, 64); }
+        if (lane == 0) { wsum[wave][0] = sp; wsum[wave][1] = sn; }
     }
-    if (threadIdx.x < 4) {
-        reinterpret_cast<unsigned *>(&ref_x[g])[threadIdx.x] = refx[threadIdx.x];
-        reinterpret_cast<unsigned *>(&ref_y[g])[threadIdx.x] = refy[threadIdx.x];
+    __syncthreads();
+    if (tid == 0) { gP[g] = wsum[0][0] + wsum[1][0]; gN[g] = wsum[0][1] + wsum[1][1]; }
+    if (tid < 4) {
+        reinterpret_cast<unsigned *>(&ref_x[g])[tid] = refx[tid];
+        reinterpret_cast<unsigned *>(&ref_y[g])[tid] = refy[tid];
     }
 }
 
-// exclusive prefix sums of one class's per-group sizes (one workgroup walks the groups 1024 at a time); *total
-__global__ __launch_bounds__(1024) void class_offsets_kernel(const uint4 *__restrict__ mask, size_t groups, unsigned *__restrict__ off,
-                                                             unsigned long long *__restrict__ total)
+// Exclusive prefix sums over the groups, one workgroup per array (1024 groups at a time):
+//   blocks 0..3  sizes of the dense / counted / minority / full classes (popcount of the mask) -> off32[b][g], totals[b]
+//   blocks 4, 5  list sizes gP / gN of the groups' minority sites                              -> off64[b - 4][g], totals[b]
+__global__ __launch_bounds__(1024) void group_offsets_kernel(const uint4 *__restrict__ masks, const unsigned *__restrict__ gcounts, size_t groups,
+                                                             unsigned *__restrict__ off32, unsigned long long *__restrict__ off64,
+                                                             unsigned long long *__restrict__ totals)
 {
-    __shared__ unsigned sv[1024];
+    __shared__ unsigned long long sv[1024];
+    const int b = blockIdx.x, t = threadIdx.x;
     unsigned long long base = 0;
-    const int t = threadIdx.x;
     for (size_t g0 = 0; g0 < groups; g0 += 1024) {
         const size_t g = g0 + t;
-        unsigned c = 0;
-        if (g < groups) { const uint4 a = mask[g]; c = __popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w); }
+        unsigned long long c = 0;
+        if (g < groups) {
+            if (b < 4) { const uint4 a = masks[(size_t)b * groups + g]; c = __popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w); }
+            else c = gcounts[(size_t)(b - 4) * groups + g];
+        }
         sv[t] = c;
         __syncthreads();
         for (int o = 1; o < 1024; o <<= 1) {
-            const unsigned av = t >= o ? sv[t - o] : 0;
+            const unsigned long long av = t >= o ? sv[t - o] : 0;
             __syncthreads();
             sv[t] += av;
             __syncthreads();
         }
-        if (g < groups) off[g] = (unsigned)(base + sv[t] - c);
+        if (g < groups) {
+            if (b < 4) off32[(size_t)b * groups + g] = (unsigned)(base + sv[t] - c);
+            else off64[(size_t)(b - 4) * groups + g] = base + sv[t] - c;
+        }
         base += sv[1023];
         __syncthreads();
     }
-    if (t == 0) *total = base;
+    if (t == 0) totals[b] = base;
 }
 
 // the sites of a class in site order: list[off[g] ..] = the set bits of mask[g]
@@ -199,22 +291,35 @@ __global__ __launch_bounds__(256) void class_list_kernel(const uint4 *__restrict
 }
 
 // Re-pack: one thread = one (sample, OUTPUT group of 128 listed sites), lanes over samples like pack_kernel, so the source
-// site of every output bit is wave-uniform.  NPO output planes; out plane k = source plane `first_plane + k` of a source with
-// `gp_src` planes per group; `invert`: store the complement of the (single) source plane at the listed sites ("is a base" from N).
-template <int NPO>
-__global__ __launch_bounds__(256) void compact_sites_kernel(const uint4 *__restrict__ src, int gp_src, int first_plane, bool invert,
-                                                            const unsigned *__restrict__ list, unsigned count, uint4 *__restrict__ dst,
-                                                            size_t n_pad, unsigned n, unsigned groups_dst)
+// site of every output bit is wave-uniform.  The source is the five general planes.
+//   MODE 0  out = the five planes of the listed sites (general encoding's vplanes)
+//   MODE 1  out = consensus planes X, Y, V of the listed sites (A = 00, C = 01, G = 10, T = 11; V = exactly one base)
+//   MODE 2  out = the N plane of the listed sites (the counting pass's iplanes)
+// A 32-site output word whose listed sites are consecutive takes its bits with one funnel shift per plane; only words that
+// straddle a gap gather bit by bit.
+template <int MODE>
+__global__ __launch_bounds__(256) void compact_sites_kernel(const uint4 *__restrict__ src, const unsigned *__restrict__ list, unsigned count,
+                                                            uint4 *__restrict__ dst, size_t n_pad, unsigned n, unsigned groups_dst)
 {
+    constexpr int NPO = MODE == 0 ? NPLANES : MODE == 1 ? 3 : 1;
+    constexpr int NPI = MODE == 2 ? 1 : NPLANES, FIRST = MODE == 2 ? 4 : 0;
     const unsigned s = blockIdx.y * 64 + (threadIdx.x & 63);
     const unsigned G = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (G >= groups_dst) return;
     const unsigned *__restrict__ srcw = reinterpret_cast<const unsigned *>(src);
-    unsigned out[NPO][4];
-    unsigned cur[NPO];
+    auto word_at = [&](unsigned w, int p) -> unsigned {      // 32-site word w (absolute) of input plane p
+        return srcw[(((size_t)(w >> 2) * NPLANES + FIRST + p) * n_pad + s) * 4 + (w & 3u)];
+    };
+    auto convert = [&](const unsigned (&in)[NPI], unsigned (&o)[NPO]) {
+        if constexpr (MODE == 1) {
+            const unsigned v = (in[0] | in[1] | in[2] | in[3]) & ~in[4];
+            o[0] = (in[1] | in[3]) & v; o[1] = (in[2] | in[3]) & v; o[2] = v;
+        } else {
 #pragma unroll
-    for (int p = 0; p < NPO; p++) cur[p] = 0;
-    unsigned cw = 0xFFFFFFFFu;
+            for (int p = 0; p < NPO; p++) o[p] = in[p];
+        }
+    };
+    unsigned out[NPO][4];
     const unsigned t0 = G * SITES_PER_GROUP;
 #pragma unroll
     for (int ow = 0; ow < 4; ow++) {
@@ -223,19 +328,37 @@ __global__ __launch_bounds__(256) void compact_sites_kernel(const uint4 *__restr
         for (int p = 0; p < NPO; p++) accw[p] = 0;
         const unsigned tb = t0 + ow * 32;
         const unsigned kn = tb >= count ? 0u : min(32u, count - tb);
-        for (unsigned k = 0; k < kn; k++) {
-            const unsigned site = __builtin_amdgcn_readfirstlane(list[tb + k]);
-            const unsigned w = site >> 5;
-            if (w != cw) {                                      // wave-uniform
-                cw = w;
+        if (kn) {
+            const unsigned first = __builtin_amdgcn_readfirstlane(list[tb]), last = __builtin_amdgcn_readfirstlane(list[tb + kn - 1]);
+            if (last - first == kn - 1) {                       // a run of consecutive sites (wave-uniform): funnel shift
+                const unsigned w0 = first >> 5, sh = first & 31u, w1 = last >> 5;
+                unsigned lo[NPI], hi[NPI], cv_lo[NPO], cv_hi[NPO];
 #pragma unroll
-                for (int p = 0; p < NPO; p++) {
-                    const unsigned x = srcw[(((size_t)(site >> 7) * gp_src + first_plane + p) * n_pad + s) * 4 + (w & 3u)];
-                    cur[p] = invert ? ~x : x;
+                for (int p = 0; p < NPI; p++) { lo[p] = word_at(w0, p); hi[p] = w1 != w0 ? word_at(w1, p) : 0u; }
+                convert(lo, cv_lo);
+                convert(hi, cv_hi);
+                const unsigned keep = kn == 32u ? 0xFFFFFFFFu : ((1u << kn) - 1u);
+#pragma unroll
+                for (int p = 0; p < NPO; p++)
+                    accw[p] = (unsigned)((((unsigned long long)cv_hi[p] << 32) | cv_lo[p]) >> sh) & keep;
+            } else {
+                unsigned cw = 0xFFFFFFFFu, cur[NPO];
+#pragma unroll
+                for (int p = 0; p < NPO; p++) cur[p] = 0;
+                for (unsigned k = 0; k < kn; k++) {
+                    const unsigned site = __builtin_amdgcn_readfirstlane(list[tb + k]);
+                    const unsigned w = site >> 5;
+                    if (w != cw) {                              // wave-uniform
+                        cw = w;
+                        unsigned in[NPI];
+#pragma unroll
+                        for (int p = 0; p < NPI; p++) in[p] = word_at(w, p);
+                        convert(in, cur);
+                    }
+#pragma unroll
+                    for (int p = 0; p < NPO; p++) accw[p] |= ((cur[p] >> (site & 31u)) & 1u) << k;
                 }
             }
-#pragma unroll
-            for (int p = 0; p < NPO; p++) accw[p] |= ((cur[p] >> (site & 31u)) & 1u) << k;
         }
 #pragma unroll
         for (int p = 0; p < NPO; p++) out[p][ow] = accw[p];
@@ -246,8 +369,9 @@ __global__ __launch_bounds__(256) void compact_sites_kernel(const uint4 *__restr
             dst[((size_t)G * NPO + p) * n_pad + s] = make_uint4(out[p][0], out[p][1], out[p][2], out[p][3]);
 }
 
-// per sample: set bits of its one-plane row (lanes over samples: coalesced; grid.y cuts the groups, partial counts are added)
-__global__ __launch_bounds__(256) void plane_popcount_kernel(const uint4 *__restrict__ P, size_t n_pad, unsigned n, size_t groups,
+// per sample: set bits of one plane (stride `gp` planes per group; lanes over samples: coalesced; grid.y cuts the groups,
+// partial counts are added)
+__global__ __launch_bounds__(256) void plane_popcount_kernel(const uint4 *__restrict__ P, size_t n_pad, unsigned n, size_t groups, int gp,
                                                              unsigned *__restrict__ out)
 {
     const unsigned s = blockIdx.x * 256 + threadIdx.x;
@@ -256,7 +380,7 @@ __global__ __launch_bounds__(256) void plane_popcount_kernel(const uint4 *__rest
     const size_t g0 = blockIdx.y * per, g1 = min(groups, g0 + per);
     unsigned c = 0;
     for (size_t g = g0; g < g1; g++) {
-        const uint4 v = P[g * n_pad + s];
+        const uint4 v = P[g * gp * n_pad + s];
         c += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
     }
     if (c) atomicAdd(&out[s], c);
@@ -271,6 +395,8 @@ void site_classes_free(tracs_alignment *a)
     a->vplanes = a->iplanes = nullptr;
     a->L_var = a->L_inv = a->groups_var = a->groups_inv = 0;
     a->L_minor = a->L_full = 0;
+    a->count_in_place = false;
+    a->classes_cons = false;
     minority_lists_free(a);
     a->classes_state = 0;
 }
@@ -280,135 +406,210 @@ static size_t class_plane_bytes(const tracs_alignment *a, size_t groups, int pla
     return ((groups + pad_groups) * (size_t)planes * a->n_pad + TAIL_PAD) * sizeof(uint4);
 }
 
-// Decides (once per pack) whether the pair kernels run on site classes and builds the re-packed alignments and lists if so.
-// `consensus`: the source is a->cplanes (3 planes), else a->planes (5).  Soft-fails (classes_state = -1) when memory is short.
-static int decide(tracs_alignment *a, bool consensus, bool allow_minor, hipStream_t stream)
+// ---- stage clock of the once-per-pack work (diagnostics: bench.py's single_pass.stages, TRACS_CLASSES_TRACE) --------------
+// HIP events on the launch stream, read back afterwards: no synchronisation inside the build.
+static constexpr int kMaxStages = 12;
+static hipEvent_t g_stage_ev[kMaxStages + 1];
+static const char *g_stage_name[kMaxStages];
+static int g_stage_n = 0;
+static bool g_stage_on = false, g_stage_valid = false;
+
+static void stage_begin(hipStream_t stream)
+{
+    static const bool trace = std::getenv("TRACS_CLASSES_TRACE") != nullptr;
+    if (trace) g_stage_on = true;
+    g_stage_n = 0; g_stage_valid = false;
+    if (!g_stage_on) return;
+    if (!g_stage_ev[0]) for (auto &e : g_stage_ev) (void)hipEventCreate(&e);
+    (void)hipEventRecord(g_stage_ev[0], stream);
+}
+static void stage_mark(const char *name, hipStream_t stream)
+{
+    if (!g_stage_on || g_stage_n >= kMaxStages) return;
+    g_stage_name[g_stage_n++] = name;
+    (void)hipEventRecord(g_stage_ev[g_stage_n], stream);
+    g_stage_valid = true;
+}
+void pack_stage_mark(const char *name, hipStream_t stream) { stage_mark(name, stream); }
+void pack_stage_begin(hipStream_t stream) { stage_begin(stream); }
+void pack_stage_end()
+{
+    static const bool trace = std::getenv("TRACS_CLASSES_TRACE") != nullptr;
+    if (!trace || !g_stage_valid) return;
+    (void)hipEventSynchronize(g_stage_ev[g_stage_n]);
+    for (int k = 0; k < g_stage_n; k++) {
+        float ms = 0.0f;
+        (void)hipEventElapsedTime(&ms, g_stage_ev[k], g_stage_ev[k + 1]);
+        std::fprintf(stderr, "[once per pack] %-28s %8.2f ms\n", g_stage_name[k], ms);
+    }
+}
+
+// Decides (once per pack) the encoding and whether the pair kernels run on site classes, and builds the re-packed alignments
+// and lists if so.  *partial: some sample carries a partial IUPAC code (the alignment has no consensus form).  Soft-fails
+// (classes_state = -1) when memory is short.
+static int decide(tracs_alignment *a, bool allow_minor, hipStream_t stream, int *partial)
 {
     a->classes_state = -1;
     static const int force = [] { const char *e = std::getenv("TRACS_SITE_CLASSES"); return e ? std::atoi(e) : -1; }();
     static const bool no_minor = [] { const char *e = std::getenv("TRACS_MINORITY"); return e && std::atoi(e) == 0; }();
-    if (force == 0 || a->L == 0 || a->L >= (1ull << 32) || a->n < 2) return TRACS_OK;
-    const uint4 *src = consensus ? a->cplanes : a->planes;
-    if (!src) return TRACS_OK;
-    // TRACS_CLASSES_TRACE=1: wall time of every stage on stderr (synchronises after each: diagnostics only)
-    static const bool trace = std::getenv("TRACS_CLASSES_TRACE") != nullptr;
-    auto t_last = std::chrono::steady_clock::now();
-    auto stage = [&](const char *what) {
-        if (!trace) return;
-        (void)hipStreamSynchronize(stream);
-        const auto now = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "[site classes] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
-        t_last = now;
-    };
-    if (trace) (void)hipStreamSynchronize(stream);
-    t_last = std::chrono::steady_clock::now();
+    static const bool force_general = std::getenv("TRACS_FORCE_GENERAL") != nullptr;
     const size_t groups = a->groups;
     // sample blocks in grid.y of the re-pack kernels (<= 65535 x 64 samples per launch; beyond that the classes are not used)
     const unsigned sblocks = (unsigned)(a->n_pad / 64);
-    if (sblocks > 65535u) return TRACS_OK;
+    if (sblocks > 65535u || groups >= (1ull << 31)) { *partial = -1; return TRACS_OK; }
+    const size_t flag_words = (a->n_pad + 255) / 256 * 4;       // 64-sample words per group (whole 256-sample rounds)
+    // scratch (grow-only per-device buffers: a second pack in the same process allocates nothing here)
     uint4 *masks = nullptr;
-    unsigned *offs = nullptr, *lists = nullptr;
-    unsigned long long *totals = nullptr;
-    auto cleanup = [&]() {
-        void *p[] = {masks, offs, lists, totals};
-        for (void *q : p) if (q) (void)hipFree(q);
-    };
-    auto soft_fail = [&]() { cleanup(); (void)hipGetLastError(); site_classes_free(a); a->classes_state = -1; return TRACS_OK; };
-    if (hipMalloc(reinterpret_cast<void **>(&masks), 6 * groups * sizeof(uint4)) != hipSuccess) return soft_fail();
-    if (hipMalloc(reinterpret_cast<void **>(&offs), 4 * groups * sizeof(unsigned)) != hipSuccess) return soft_fail();
-    if (hipMalloc(reinterpret_cast<void **>(&totals), 32) != hipSuccess) return soft_fail();
+    unsigned *offs = nullptr, *cnts = nullptr, *gcnt = nullptr, *d_flag = nullptr;
+    unsigned long long *off64 = nullptr, *totals = nullptr, *flags = nullptr;
+    int rc;
+    if ((rc = workspace_get(32, 6 * groups * sizeof(uint4), reinterpret_cast<void **>(&masks)))) return rc;
+    if ((rc = workspace_get(33, 4 * groups * sizeof(unsigned), reinterpret_cast<void **>(&offs)))) return rc;
+    if ((rc = workspace_get(34, 2 * groups * SITES_PER_GROUP * sizeof(unsigned), reinterpret_cast<void **>(&cnts)))) return rc;
+    if ((rc = workspace_get(35, 2 * groups * sizeof(unsigned), reinterpret_cast<void **>(&gcnt)))) return rc;
+    if ((rc = workspace_get(36, 2 * (groups + 1) * sizeof(unsigned long long), reinterpret_cast<void **>(&off64)))) return rc;
+    if ((rc = workspace_get(37, 64, reinterpret_cast<void **>(&totals)))) return rc;
+    if ((rc = workspace_get(38, groups * flag_words * sizeof(unsigned long long), reinterpret_cast<void **>(&flags)))) return rc;
+    d_flag = reinterpret_cast<unsigned *>(totals + 7);
     uint4 *dense_mask = masks, *count_mask = masks + groups, *minor_mask = masks + 2 * groups, *full_mask = masks + 3 * groups;
     uint4 *ref_x = masks + 4 * groups, *ref_y = masks + 5 * groups;
-    unsigned *off_dense = offs, *off_count = offs + groups, *off_minor = offs + 2 * groups, *off_full = offs + 3 * groups;
+    unsigned *off_dense = offs, *off_count = offs + groups, *off_minor = offs + 2 * groups;
+    unsigned *cntP = cnts, *cntN = cnts + groups * SITES_PER_GROUP;
     // a site goes to the lists while its k (cN + k) entries cost less than the extra operand planes over all pairs:
     // ~51 ns per site at 10 000 samples (pair kernel) against ~2-4 ps per list entry (general_fixup_kernel)
     const double bsites = (double)a->n * (double)a->n / 8000.0;
     const unsigned budget = (no_minor || !allow_minor) ? 0u : (unsigned)std::min(1.0e9, std::max(16.0, bsites));
-    if (consensus)
-        hipLaunchKernelGGL((classify_sites_kernel<true>), dim3((unsigned)groups), dim3(256), 0, stream, src, a->n_pad, (unsigned)a->n, budget,
-                           dense_mask, count_mask, minor_mask, full_mask, ref_x, ref_y);
-    else
-        hipLaunchKernelGGL((classify_sites_kernel<false>), dim3((unsigned)groups), dim3(256), 0, stream, src, a->n_pad, (unsigned)a->n, budget,
-                           dense_mask, count_mask, minor_mask, full_mask, ref_x, ref_y);
-    stage("classify");
-    hipLaunchKernelGGL(class_offsets_kernel, dim3(1), dim3(1024), 0, stream, dense_mask, groups, off_dense, totals + 0);
-    hipLaunchKernelGGL(class_offsets_kernel, dim3(1), dim3(1024), 0, stream, count_mask, groups, off_count, totals + 1);
-    hipLaunchKernelGGL(class_offsets_kernel, dim3(1), dim3(1024), 0, stream, minor_mask, groups, off_minor, totals + 2);
-    hipLaunchKernelGGL(class_offsets_kernel, dim3(1), dim3(1024), 0, stream, full_mask, groups, off_full, totals + 3);    // total only
-    unsigned long long tot[4] = {0, 0, 0, 0};
-    if (hipMemcpyAsync(tot, totals, 32, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
-        cleanup();
-        TRACS_HIP_CHECK(hipGetLastError());
-        set_error("site_classes_decide: classification failed");
-        return TRACS_E_HIP;
-    }
-    stage("offsets");
+    TRACS_HIP_CHECK(hipMemsetAsync(totals, 0, 64, stream));
+    hipLaunchKernelGGL(classify_sites_kernel, dim3((unsigned)groups), dim3(256), 0, stream, a->planes, a->n_pad, (unsigned)a->n, budget,
+                       dense_mask, count_mask, minor_mask, full_mask, ref_x, ref_y, cntP, cntN, gcnt, gcnt + groups, flags, flag_words, d_flag);
+    stage_mark("classify", stream);
+    hipLaunchKernelGGL(group_offsets_kernel, dim3(6), dim3(1024), 0, stream, masks, gcnt, groups, offs, off64, totals);
+    unsigned long long tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    TRACS_HIP_CHECK(hipMemcpyAsync(tot, totals, 64, hipMemcpyDeviceToHost, stream));
+    TRACS_HIP_CHECK(hipStreamSynchronize(stream));
+    stage_mark("class sizes", stream);
+    *partial = (int)(reinterpret_cast<const unsigned *>(&tot[7])[0] & 1u);
+    const bool consensus = !*partial && !force_general;
     const size_t L_dense = (size_t)tot[0], L_count = (size_t)tot[1], L_minor = (size_t)tot[2], L_full = (size_t)tot[3];
+    const unsigned long long tot_p = tot[4], tot_n = tot[5];
+    if (force == 0 || a->L == 0 || a->n < 2) return TRACS_OK;
     // matrix instructions per pair: planes_full per site now; planes_full per dense site + one per counted site with classes
     const double planes_full = consensus ? 4.0 : 5.0;
     const double cost = (planes_full * (double)L_dense + (double)L_count) / (planes_full * (double)a->L);
-    if (force != 1 && cost >= 0.92) { cleanup(); return TRACS_OK; }
+    if (force != 1 && cost >= 0.92) return TRACS_OK;
+    // the lists must stay small beside the planes (<= one entry per 8 sites of the whole alignment; TRACS_LIST_CAP: diagnostics):
+    // otherwise the same classes without them (the minority sites stay dense)
+    if (L_minor) {
+        static const double env_cap = [] { const char *e = std::getenv("TRACS_LIST_CAP"); return e ? std::atof(e) : -1.0; }();
+        const double cap = (double)a->n * (double)a->L / 8.0;
+        const double entries = 2.0 * (double)tot_n + 2.0 * (double)tot_p;        // per-site and per-sample lists
+        if (L_minor >= (1ull << 27) || a->n >= (1ull << 27) || entries > (env_cap >= 0.0 ? std::min(env_cap, cap) : cap))
+            return decide(a, false, stream, partial);
+    }
 
+    auto soft_fail = [&]() { (void)hipGetLastError(); site_classes_free(a); a->classes_state = -1; return TRACS_OK; };
     const int npv = consensus ? 3 : NPLANES;
-    const size_t gv = groups_for(L_dense), gi = groups_for(L_count), gm = L_minor;
-    const size_t vbytes = class_plane_bytes(a, gv, npv, PAD_GROUPS), ibytes = class_plane_bytes(a, gi, 1, COUNT_PAD_GROUPS);
-    if (hipMalloc(reinterpret_cast<void **>(&lists), (L_dense + L_count + 1) * sizeof(unsigned)) != hipSuccess) return soft_fail();
+    // the counting pass reads the stored N plane in place when (nearly) every site needs counting anyway
+    // (TRACS_COUNT_IN_PLACE=0|1 forces the choice: diagnostics)
+    static const int force_in_place = [] { const char *e = std::getenv("TRACS_COUNT_IN_PLACE"); return e ? std::atoi(e) : -1; }();
+    const bool in_place = force_in_place >= 0 ? force_in_place == 1 : (double)(a->L - L_count) <= 0.02 * (double)a->L;
+    const size_t gv = groups_for(L_dense), gi = in_place ? 0 : groups_for(L_count);
+    const size_t vbytes = class_plane_bytes(a, gv, npv, PAD_GROUPS), ibytes = class_plane_bytes(a, gi, 1, PAD_GROUPS);
+    unsigned *lists = nullptr;
+    if ((rc = workspace_get(39, (L_dense + L_count + 1) * sizeof(unsigned), reinterpret_cast<void **>(&lists)))) return rc;
     if (hipMalloc(reinterpret_cast<void **>(&a->vplanes), vbytes) != hipSuccess) { a->vplanes = nullptr; return soft_fail(); }
-    if (hipMalloc(reinterpret_cast<void **>(&a->iplanes), ibytes) != hipSuccess) { a->iplanes = nullptr; return soft_fail(); }
+    if (gi && hipMalloc(reinterpret_cast<void **>(&a->iplanes), ibytes) != hipSuccess) { a->iplanes = nullptr; return soft_fail(); }
+    if (hipMalloc(reinterpret_cast<void **>(&a->c_counted), a->n_pad * sizeof(unsigned)) != hipSuccess) { a->c_counted = nullptr; return soft_fail(); }
     unsigned *list_dense = lists, *list_count = lists + L_dense;
-    bool ok = hipMemsetAsync(a->vplanes, 0, vbytes, stream) == hipSuccess && hipMemsetAsync(a->iplanes, 0, ibytes, stream) == hipSuccess;
+    bool ok = hipMemsetAsync(a->vplanes, 0, vbytes, stream) == hipSuccess &&
+              (!gi || hipMemsetAsync(a->iplanes, 0, ibytes, stream) == hipSuccess) &&
+              hipMemsetAsync(a->c_counted, 0, a->n_pad * sizeof(unsigned), stream) == hipSuccess;
     const dim3 lgrid((unsigned)((groups + 255) / 256));
-    hipLaunchKernelGGL(class_list_kernel, lgrid, dim3(256), 0, stream, dense_mask, off_dense, groups, list_dense);
-    hipLaunchKernelGGL(class_list_kernel, lgrid, dim3(256), 0, stream, count_mask, off_count, groups, list_count);
-    stage("alloc + site lists");
     if (gv) {
+        hipLaunchKernelGGL(class_list_kernel, lgrid, dim3(256), 0, stream, dense_mask, off_dense, groups, list_dense);
         const dim3 grid((unsigned)((gv + 3) / 4), sblocks);
         if (consensus)
-            hipLaunchKernelGGL((compact_sites_kernel<3>), grid, dim3(256), 0, stream, src, 3, 0, false, list_dense, (unsigned)L_dense, a->vplanes,
+            hipLaunchKernelGGL((compact_sites_kernel<1>), grid, dim3(256), 0, stream, a->planes, list_dense, (unsigned)L_dense, a->vplanes,
                                a->n_pad, (unsigned)a->n, (unsigned)gv);
         else
-            hipLaunchKernelGGL((compact_sites_kernel<NPLANES>), grid, dim3(256), 0, stream, src, NPLANES, 0, false, list_dense, (unsigned)L_dense,
-                               a->vplanes, a->n_pad, (unsigned)a->n, (unsigned)gv);
+            hipLaunchKernelGGL((compact_sites_kernel<0>), grid, dim3(256), 0, stream, a->planes, list_dense, (unsigned)L_dense, a->vplanes,
+                               a->n_pad, (unsigned)a->n, (unsigned)gv);
     }
-    stage("re-pack dense");
+    stage_mark("re-pack dense sites", stream);
     if (gi) {
+        hipLaunchKernelGGL(class_list_kernel, lgrid, dim3(256), 0, stream, count_mask, off_count, groups, list_count);
         const dim3 grid((unsigned)((gi + 3) / 4), sblocks);
-        // the N plane of the counted sites: consensus: the complement of plane 2 = V; general: plane 4 = N
-        // (TRACS_COUNT_COMPLEMENT=1, diagnostics: the "is a base here" plane instead -- same counts, 99 % ones instead of 99 % zeros)
-        static const bool complement = std::getenv("TRACS_COUNT_COMPLEMENT") != nullptr;
-        a->count_complement = complement;
-        hipLaunchKernelGGL((compact_sites_kernel<1>), grid, dim3(256), 0, stream, src, consensus ? 3 : NPLANES, consensus ? 2 : 4,
-                           consensus != complement, list_count, (unsigned)L_count, a->iplanes, a->n_pad, (unsigned)a->n, (unsigned)gi);
-        if (hipMalloc(reinterpret_cast<void **>(&a->c_counted), a->n_pad * sizeof(unsigned)) != hipSuccess) { a->c_counted = nullptr; return soft_fail(); }
-        ok = ok && hipMemsetAsync(a->c_counted, 0, a->n_pad * sizeof(unsigned), stream) == hipSuccess;
-        hipLaunchKernelGGL(plane_popcount_kernel, dim3((unsigned)((a->n + 255) / 256), 128), dim3(256), 0, stream, a->iplanes, a->n_pad, (unsigned)a->n,
-                           gi, a->c_counted);
+        hipLaunchKernelGGL((compact_sites_kernel<2>), grid, dim3(256), 0, stream, a->planes, list_count, (unsigned)L_count, a->iplanes,
+                           a->n_pad, (unsigned)a->n, (unsigned)gi);
+        hipLaunchKernelGGL(plane_popcount_kernel, dim3((unsigned)((a->n + 255) / 256), 128), dim3(256), 0, stream, a->iplanes, a->n_pad,
+                           (unsigned)a->n, gi, 1, a->c_counted);
+    } else if (L_count) {
+        // per sample: all its N sites (in place the counting pass covers every site of the alignment)
+        hipLaunchKernelGGL(plane_popcount_kernel, dim3((unsigned)((a->n + 255) / 256), 128), dim3(256), 0, stream, a->planes + 4 * a->n_pad,
+                           a->n_pad, (unsigned)a->n, groups, NPLANES, a->c_counted);
     }
-    stage("re-pack counted");
-    if (gm) {
-        // the lists of the minority sites, read in place from the planes (general_sparse.hip, MinorSrc / GeneralMinorSrc)
+    stage_mark(gi ? "re-pack counted sites" : "N counts per sample", stream);
+    if (L_minor) {
+        // the lists of the minority sites (general_sparse.hip): per-site lists from the N plane and the flagged samples,
+        // per-sample lists from the N plane
         int built = 0;
-        const int rc = minority_lists_build(a, consensus, src, minor_mask, ref_x, ref_y, off_minor, L_minor, stream, &built);
-        stage("minority lists");
-        if (rc) { cleanup(); site_classes_free(a); a->classes_state = -1; return rc; }
-        if (!built) {                                          // lists too large / no memory: the same classes without them
+        MinorBuild mb;
+        mb.planes = a->planes; mb.minor_mask = minor_mask; mb.ref_x = ref_x; mb.ref_y = ref_y; mb.off_minor = off_minor;
+        mb.cntP = cntP; mb.cntN = cntN; mb.baseP = off64; mb.baseN = off64 + groups; mb.flags = flags; mb.flag_words = flag_words;
+        mb.sites = L_minor; mb.tot_p = tot_p; mb.tot_n = tot_n;
+        rc = minority_lists_build(a, mb, stream, &built);
+        if (rc) { site_classes_free(a); a->classes_state = -1; return rc; }
+        if (!built) {                                          // no memory: the same classes without them
             soft_fail();
-            return decide(a, consensus, false, stream);
+            return decide(a, false, stream, partial);
         }
     }
     ok = ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(stream) == hipSuccess;
-    cleanup();
     if (!ok) { site_classes_free(a); a->classes_state = -1; set_error("site_classes_decide: re-pack failed"); return TRACS_E_HIP; }
     a->L_var = L_dense; a->L_inv = L_count; a->groups_var = gv; a->groups_inv = gi;
     a->L_minor = L_minor; a->L_full = L_full;
+    a->count_in_place = in_place && L_count > 0;
+    a->classes_cons = consensus;
     a->classes_state = 1;
     return TRACS_OK;
 }
 
-int site_classes_decide(tracs_alignment *a, bool consensus, hipStream_t stream)
+int site_classes_decide(tracs_alignment *a, hipStream_t stream, int *partial)
 {
+    *partial = -1;
     if (a->classes_state != 0) return TRACS_OK;
-    return decide(a, consensus, true, stream);
+    return decide(a, true, stream, partial);
 }
 
 }  // namespace tracs
+
+extern "C" {
+
+// Diagnostics (bench.py's single_pass.stages): record the stages of the once-per-pack work of later dense calls with HIP events
+void tracs_debug_pack_timing(int on) { tracs::g_stage_on = on != 0; }
+
+// The stages of the LAST once-per-pack build: names joined by '\n' into `names` (cap bytes), milliseconds into ms[0 .. max).
+// Returns the number of stages (0: nothing recorded).
+int tracs_debug_pack_stages(char *names, size_t cap, float *ms, int max_stages)
+{
+    using namespace tracs;
+    if (!g_stage_valid || g_stage_n == 0) return 0;
+    if (hipEventSynchronize(g_stage_ev[g_stage_n]) != hipSuccess) return 0;
+    size_t used = 0;
+    int k = 0;
+    for (; k < g_stage_n && k < max_stages; k++) {
+        float t = 0.0f;
+        (void)hipEventElapsedTime(&t, g_stage_ev[k], g_stage_ev[k + 1]);
+        if (ms) ms[k] = t;
+        const size_t len = std::strlen(g_stage_name[k]);
+        if (names && used + len + 2 <= cap) {
+            if (k) names[used++] = '\n';
+            std::memcpy(names + used, g_stage_name[k], len);
+            used += len;
+            names[used] = 0;
+        }
+    }
+    return k;
+}
+
+}  // extern "C"

@@ -105,6 +105,14 @@ class Alignment:
         return tuple(int(x) for x in out) if state == 1 else None
 
     @property
+    def count_source(self):
+        """(sites the counting pass reads, in_place) for an alignment on site classes: in_place = the stored N plane of every
+        site, read where it lies (the pair kernels then write d only); else the counted sites' N plane re-packed.  None
+        without classes."""
+        out = (C.c_uint64 * 2)()
+        return (int(out[0]), bool(out[1])) if self._L.tracs_debug_alignment_count_source(self._h, out) else None
+
+    @property
     def nbytes(self):
         return self._L.tracs_alignment_bytes(self._h)
 
@@ -121,6 +129,16 @@ class Alignment:
             self.close()
         except Exception:
             pass
+
+
+def pack_stages():
+    """[(stage, ms), ..] of the last once-per-pack build (encoding decision, site classes, lists), from HIP events on the launch
+    stream; recorded when tracs_debug_pack_timing(1) was set before the dense call (diagnostics: bench.py's single_pass)."""
+    lib = _lib.load()
+    names = C.create_string_buffer(1024)
+    ms = (C.c_float * 16)()
+    k = lib.tracs_debug_pack_stages(names, 1024, ms, 16)
+    return list(zip(names.value.decode().split("\n"), [float(x) for x in ms[:k]])) if k else []
 
 
 def pairsnp_dense(aln, dist, ncomp=None, row_begin=0, row_end=None, col_begin=0, dist_threshold=None, base_row=0):
