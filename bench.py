@@ -42,7 +42,11 @@ sys.path.insert(0, ROOT)
 HBM_PEAK = 8.0e12            # B/s, MI355X HBM3E spec (MI355X_MICROARCH.md "Chip-level parameters")
 VALU_PEAK = 256 * 4 * 32 * 2.4e9   # 32-bit lane-ops/s: 256 CU x 4 SIMD32 x 2.4 GHz (nominal FP32-vector issue rate)
 MFMA_FP4_PEAK = 10.0e15      # flop/s, dense fp4 MFMA (MI355X_MICROARCH.md: "~10 PF dense")
-MFMA_FP4_MEASURED = 7.1e15   # bare v_mfma_scale_f32_32x32x64_f8f6f4 loop on +-1 operands (clock-limited; profiles/r01/mfma_fp4_rate.txt)
+# bare v_mfma_scale_f32_32x32x64_f8f6f4 loop (clock-limited; scripts/micro/mfma_fp4_rate.hip, profiles/r01/mfma_fp4_rate.txt): the
+# rate depends on the operand data -- 7.1 PFLOP/s on +-1 operands (the four-operand pair kernel's), 7.9 on mostly-zero operands
+# (the counting pass's N plane: 99 % zeros on this workload)
+MFMA_FP4_MEASURED = 7.1e15
+MFMA_FP4_MEASURED_ZEROS = 7.9e15
 # Per encoding: VALU ops per 32 sites and pair, algorithmic bytes per pair as a fraction of L, and the
 # rate a register-only loop of exactly that instruction mix sustains on MI355X (scripts/micro/valu_ops.hip,
 # profiles/r01/valu_ops_microbench.txt) -- the practical issue ceiling of the VALU kernel.
@@ -65,6 +69,8 @@ def parse():
     ap.add_argument("--sites", type=int, default=int(os.environ.get("TRACS_BENCH_SITES", 5000000)))
     ap.add_argument("--partial", type=float, default=float(os.environ.get("TRACS_BENCH_PARTIAL", "0")),
                     help="fraction of partial IUPAC codes in the TIMED alignment (default 0: consensus, the metric's workload)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="sparse",
+                    help="synthetic alignment of the TIMED steps (default: sparse = SURVEY 8d's, the metric's workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline_general and dm_frontend")
     ap.add_argument("--cpu-seconds", type=float, default=6.0, help="minimum wall time of each CPU baseline leg")
@@ -74,9 +80,20 @@ def parse():
     return ap.parse_args()
 
 
-def synth_kw(p_partial=0.0):
-    """SURVEY.md 8d's generator: star phylogeny (one lineage = the ancestor itself), mu per sample, 1 % N."""
-    return dict(mu_lineage=0.0, mu_sample=MU, n_lineages=1, p_n=P_N, p_partial=p_partial)
+# The metric's workload ("sparse": SURVEY.md 8d's generator -- star phylogeny, mu per sample, 1 % N iid) and four others that
+# move the alignment across the site classes' cost model (--workload; `sensitivity` on the default line):
+WORKLOADS = {
+    "sparse": dict(mu_lineage=0.0, mu_sample=MU, n_lineages=1, p_n=P_N),
+    # 20 lineages (founders 1e-4 from the ancestor, samples 1e-5 from their founder), the same amount of N in 1 / 21 of the samples
+    "lineage": dict(mu_lineage=1e-4, mu_sample=1e-5, n_lineages=20, p_n=P_N, n_every=21),
+    "divergent": dict(mu_lineage=0.0, mu_sample=1e-3, n_lineages=1, p_n=P_N),
+    "clean": dict(mu_lineage=0.0, mu_sample=MU, n_lineages=1, p_n=0.0),
+    "gappy": dict(mu_lineage=0.0, mu_sample=MU, n_lineages=1, p_n=0.10),
+}
+
+
+def synth_kw(p_partial=0.0, workload="sparse"):
+    return dict(WORKLOADS[workload], p_partial=p_partial)
 
 
 def pair_split_ms(lib):
@@ -87,27 +104,32 @@ def pair_split_ms(lib):
     return [float(x) for x in out] if lib.tracs_debug_last_pair_ms(out) == 0 else None
 
 
-def count_roofline(pairs_per_launch, L_inv, count_s):
-    flop = float(pairs_per_launch) * L_inv * COUNT_FLOP_PER_SITE
-    alg_bytes = float(pairs_per_launch) * L_inv * 0.25            # two samples x one bit plane = L / 4 bytes per pair
-    return {"kernel": "pairsnp_mfma_kernel<COUNT>", "kernel_ms": count_s * 1e3, "sites": L_inv, "bound": "mfma", "traffic": None,
-            "algorithmic_flop_per_pair": L_inv * COUNT_FLOP_PER_SITE, "measured_fp4_ceiling": MFMA_FP4_MEASURED / 1e12,
-            "frac_of_measured_fp4_ceiling": flop / count_s / MFMA_FP4_MEASURED,
+def hbm_physical(traffic, kern_s, compulsory):
+    """What the kernel really moves: `traffic` (PMC FETCH_SIZE / WRITE_SIZE bytes per launch, gfx950-corrected) over its launch
+    time against the 8 TB/s peak, and over the bytes it has to move at least once.  SURVEY 8d's per-pair byte count assumes no
+    tile reuse and reads >> 1 of the HBM peak by construction on an LDS-tiled kernel, so it is not reported as a fraction."""
+    if traffic is None:
+        return None
+    return {"GBps": traffic / kern_s / 1e9, "frac_of_hbm_peak": traffic / kern_s / HBM_PEAK, "peak_GBps": HBM_PEAK / 1e9,
+            "compulsory_bytes": compulsory, "traffic_over_compulsory": traffic / compulsory if compulsory else None}
+
+
+def count_roofline(pairs_per_launch, sites, count_s, n, in_place):
+    flop = float(pairs_per_launch) * sites * COUNT_FLOP_PER_SITE
+    return {"kernel": "pairsnp_mfma_kernel<COUNT>", "kernel_ms": count_s * 1e3, "sites": sites, "bound": "mfma", "traffic": None,
+            "source": "the stored N plane of every site, read in place" if in_place else "the counted sites' N plane, re-packed",
+            "algorithmic_flop_per_pair": sites * COUNT_FLOP_PER_SITE, "measured_fp4_ceiling": MFMA_FP4_MEASURED_ZEROS / 1e12,
+            "frac_of_measured_fp4_ceiling": flop / count_s / MFMA_FP4_MEASURED_ZEROS,
             "achieved": flop / count_s / 1e12, "peak": MFMA_FP4_PEAK / 1e12, "unit": "TFLOP/s", "frac": flop / count_s / MFMA_FP4_PEAK,
-            "hbm": {"achieved": alg_bytes / count_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg_bytes / count_s / HBM_PEAK,
-                    "algorithmic_bytes_per_pair": L_inv * 0.25,
-                    "note": "no-tile-reuse byte count in the manner of SURVEY 8d (one plane of two samples per pair); every byte fetched "
-                            "is shared by a whole tile from LDS, so achieved > peak and the matrix pipe is what binds"},
-            "note": "nn += sum v_i v_j over the counted sites: one fp4 operand plane, %g flop per pair and site" % COUNT_FLOP_PER_SITE}
+            "compulsory_bytes": float(n) * sites / 8.0 + float(pairs_per_launch) * 4.0,      # the plane once + nn once
+            "algorithmic_bytes_per_pair_no_reuse": sites * 0.25,
+            "note": "nn = sites - c_i - c_j + sum n_i n_j: one fp4 operand plane (n = is N here; mostly zeros: the measured ceiling is "
+                    "the bare instruction's rate on zero operands), %g flop per pair and site" % COUNT_FLOP_PER_SITE}
 
 
-def roofline_of(kernel, enc, pairs_per_launch, L, kern_s, traffic):
+def roofline_of(kernel, enc, pairs_per_launch, L, kern_s, traffic, n):
     E = ENCODINGS[enc]
-    alg_bytes = float(pairs_per_launch) * L * E["bytes_per_site"]       # L (general) / 0.75 L (consensus) per pair
-    hbm = {"achieved": alg_bytes / kern_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg_bytes / kern_s / HBM_PEAK,
-           "algorithmic_bytes_per_pair": L * E["bytes_per_site"],
-           "note": "SURVEY 8d's byte count assumes no tile reuse; every byte fetched is shared by a whole tile from LDS, so "
-                   "achieved > peak here and the matrix pipe / VALU is what binds"}
+    compulsory = float(n) * L * E["bytes_per_site"] / 2.0 + float(pairs_per_launch) * 8.0     # the planes once + d, nn once
     if kernel in MFMA_FLOP_PER_SITE:
         fps = MFMA_FLOP_PER_SITE[kernel]
         flop = float(pairs_per_launch) * L * fps
@@ -116,17 +138,21 @@ def roofline_of(kernel, enc, pairs_per_launch, L, kern_s, traffic):
                 "kernel": "pairsnp_mfma_kernel" + ("<general> + general_fixup_kernel" if kernel == "mfma-general" else ""),
                 "kernel_ms": kern_s * 1e3, "encoding": enc, "algorithmic_flop_per_pair": L * fps,
                 "measured_fp4_ceiling": MFMA_FP4_MEASURED / 1e12, "frac_of_measured_fp4_ceiling": flop / kern_s / MFMA_FP4_MEASURED,
+                "compulsory_bytes": compulsory, "algorithmic_bytes_per_pair_no_reuse": L * E["bytes_per_site"],
+                "hbm_physical": hbm_physical(traffic, kern_s, compulsory),
                 "note": "v_mfma_scale_f32_32x32x64_f8f6f4 on fp4 operands; %g flop per pair and site is the flop count of THIS "
                         "formulation (%s), not an algorithm-intrinsic number; peak = dense fp4 (MI355X_MICROARCH.md); the "
                         "measured ceiling is the bare instruction rate on +-1 operand data (scripts/micro/mfma_fp4_rate.hip)"
-                        % (fps, "operand planes x, y, z = x*y, v" if kernel == "mfma" else "one-hot planes A, C, G, T and N"),
-                "hbm": hbm}
+                        % (fps, "operand planes x, y, z = x*y, v" if kernel == "mfma" else "one-hot planes A, C, G, T and N")}
     lane_ops = float(pairs_per_launch) * ((L + 127) // 128) * 4 * E["ops"]
-    return dict(hbm, bound="hbm", traffic=traffic, kernel="pairsnp_tile_kernel", kernel_ms=kern_s * 1e3, encoding=enc,
-                valu={"achieved": lane_ops / kern_s / 1e12, "peak": VALU_PEAK / 1e12, "unit": "Tlane-op/s",
-                      "frac": lane_ops / kern_s / VALU_PEAK, "ops_per_32_sites_per_pair": E["ops"],
-                      "measured_mix_ceiling": E["mix_ceiling"] / 1e12,
-                      "frac_of_measured_mix_ceiling": lane_ops / kern_s / E["mix_ceiling"]})
+    alg_bytes = float(pairs_per_launch) * L * E["bytes_per_site"]
+    return {"bound": "hbm", "achieved": alg_bytes / kern_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg_bytes / kern_s / HBM_PEAK,
+            "traffic": traffic, "kernel": "pairsnp_tile_kernel", "kernel_ms": kern_s * 1e3, "encoding": enc,
+            "compulsory_bytes": compulsory, "hbm_physical": hbm_physical(traffic, kern_s, compulsory),
+            "valu": {"achieved": lane_ops / kern_s / 1e12, "peak": VALU_PEAK / 1e12, "unit": "Tlane-op/s",
+                     "frac": lane_ops / kern_s / VALU_PEAK, "ops_per_32_sites_per_pair": E["ops"],
+                     "measured_mix_ceiling": E["mix_ceiling"] / 1e12,
+                     "frac_of_measured_mix_ceiling": lane_ops / kern_s / E["mix_ceiling"]}}
 
 
 def main():
@@ -158,7 +184,7 @@ def main():
     # ---- setup (untimed): packed alignment resident in HBM, sampling days -------------------
     t0 = time.time()
     aln = dev.Alignment(n, L)
-    synth.pack_synthetic_device(aln, seed=seed, **synth_kw(args.partial))
+    synth.pack_synthetic_device(aln, seed=seed, **synth_kw(args.partial, args.workload))
     _, days_np = synth.dates(n, seed=seed)
     days = torch.from_numpy(days_np).to(device)
     torch.cuda.synchronize()
@@ -231,15 +257,43 @@ def main():
 
     lib = _lib.load()
     lib.tracs_debug_pair_timing(1)
-    # The first dense call on a packed alignment also decides the encoding and the site classes and builds the derived planes
-    # and lists (once per pack; a `tracs distance` run pays it once).  Timed on its own, outside the steps.
-    torch.cuda.synchronize()
-    t_first = time.perf_counter()
-    scratch = torch.zeros((64, n), dtype=torch.int32, device=device)
-    dev.pairsnp_dense(aln, scratch, None, row_begin=0, row_end=min(64, n))
-    torch.cuda.synchronize()
-    t_first = time.perf_counter() - t_first
-    del scratch
+    lib.tracs_debug_pack_timing(1)
+    # ---- ONE pass per alignment is the reference's unit of work (src/pairsnp.hpp:320-457: one pairsnp call per alignment): packed
+    # planes resident -> d, nn, P, E(K), INCLUDING what the library decides and builds once per pack (encoding, site classes, the
+    # counting pass's source, minority lists; csrc/site_classes.hip).  cold = the first pass of the process (this alignment),
+    # warm = the same on a second, freshly packed handle.  Result matrices are allocated beforehand.  N = 1 only.
+    single = None
+    if world == 1:
+        def one_pass(a):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            dev.pairsnp_dense(a, sets[0][0], sets[0][1])
+            dev.trans_dist_dense_ranges(sets[0][0], n, days, args.lamb, args.beta, args.precision, pmat, emat, [(0, n)], exp_p0=True)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) * 1e3
+        cold_ms = one_pass(aln)
+        cold_stages = dev.pack_stages()
+        aln2 = dev.Alignment(n, L)
+        synth.pack_synthetic_device(aln2, seed=seed, **synth_kw(args.partial, args.workload))
+        warm_ms = one_pass(aln2)
+        warm_stages = dev.pack_stages()
+        aln2.close()
+        del aln2
+        single = {"cold_ms": cold_ms, "warm_ms": warm_ms, "value_single_pass": n * (n - 1) // 2 / (warm_ms / 1e3), "unit": "pairs/s",
+                  "per_pack_ms": sum(ms for _, ms in warm_stages),
+                  "stages_ms": {k: round(v, 3) for k, v in warm_stages}, "cold_stages_ms": {k: round(v, 3) for k, v in cold_stages},
+                  "note": "packed planes resident -> d, nn, P, E(K) for ONE pass over a freshly packed alignment, with everything the library "
+                          "decides and builds once per pack (stages: HIP events on the launch stream); cold = first pass of the process, warm = "
+                          "a second handle packed afterwards; `value` is the steady state of repeated passes over one packed alignment"}
+        t_first = cold_ms / 1e3
+    else:
+        torch.cuda.synchronize()
+        t_first = time.perf_counter()
+        scratch = torch.zeros((64, n), dtype=torch.int32, device=device)
+        dev.pairsnp_dense(aln, scratch, None, row_begin=0, row_end=min(64, n))
+        torch.cuda.synchronize()
+        t_first = time.perf_counter() - t_first
+        del scratch
     for it in range(args.warmup):
         step(it)
     drain(args.warmup)
@@ -295,39 +349,51 @@ def main():
             # site classes (csrc/site_classes.hip): pair kernel over the dense sites, lists for the minority sites, one-operand
             # counting pass over the counted sites.  `roofline` = whichever matrix-core kernel takes longer; the other beside it.
             dense, counted, minority, full = classes
-            main = roofline_of(aln.kernel, enc, last_pairs, dense, max(split[0], 1e-3) / 1e3, None)
-            cnt = count_roofline(last_pairs, counted, max(split[2], 1e-3) / 1e3)
+            count_sites, in_place = aln.count_source or (counted, False)
+            main = roofline_of(aln.kernel, enc, last_pairs, dense, max(split[0], 1e-3) / 1e3, None, n)
+            cnt = count_roofline(last_pairs, count_sites, max(split[2], 1e-3) / 1e3, n, in_place)
             cnt["traffic"] = traffic                          # the "+classes" entry of the PMC summary is the counting pass's
+            cnt["hbm_physical"] = hbm_physical(traffic, max(split[2], 1e-3) / 1e3, cnt["compulsory_bytes"])
             roof, other = (cnt, main) if split[2] > split[0] else (main, cnt)
             roof["other_matrix_core_kernel"] = {k: other[k] for k in ("kernel", "kernel_ms", "achieved", "frac", "unit") if k in other}
             roof["minority_lists_ms"] = split[1]
             roof["dense_call_ms"] = kern_s * 1e3
             roof["site_classes"] = {"dense": dense, "counted": counted, "minority": minority, "full": full,
-                                    "empty": L - dense - counted - full,
+                                    "empty": L - dense - counted - full, "counting_pass_sites": count_sites, "counting_pass_in_place": in_place,
                                     "note": "decided once per pack, results bit-identical (csrc/site_classes.hip): the pair kernel reads the dense "
                                             "sites only; sites at which <= a few samples differ from the others (minority) add their distances "
                                             "from sparse lists (general_fixup_kernel<MINOR>); nn of every non-dense site with an N comes from "
                                             "a one-operand matrix-core pass (counted), sites without any N add a constant (full). "
                                             "TRACS_SITE_CLASSES=0 reads every site with the pair kernel, TRACS_MINORITY=0 keeps the minority sites dense"}
         else:
-            roof = roofline_of(aln.kernel, enc, my_pairs_per_launch, L, kern_s, traffic)
-        roof["traffic_source"] = ("profiles/pmc_summary.json: FETCH_SIZE / WRITE_SIZE from separate rocprofv3 --pmc passes of this kernel on this "
-                                  "shape, committed with the profiles -- not measured by this run" if roof.get("traffic") is not None else None)
+            roof = roofline_of(aln.kernel, enc, my_pairs_per_launch, L, kern_s, traffic, n)
+        roof["traffic_source"] = ("profiles/pmc_summary.json: FETCH_SIZE / WRITE_SIZE (gfx950-corrected) from separate rocprofv3 --pmc passes of "
+                                  "`bench.py` itself on this workload and shape (scripts/gpu_pmc_bench.sh), committed with the profiles -- not "
+                                  "measured by this run" if roof.get("traffic") is not None else None)
         enc_name = "consensus (ACGTN) alignment" if enc == "consensus" else "general IUPAC alignment (%.2g partial codes)" % args.partial
+        W = WORKLOADS[args.workload]
         out = {"metric": "sample-pairs/sec for 10kx5Mbp SNP+transcluster distance", "value": value,
                "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "u32", "data": "synthetic",
-               "config": {"workload": "%d samples x %d sites, %s, mu = %g per sample + %g N (SURVEY 8d): pairsnp (d + compared "
-                                      "sites) + transcluster (P, E(K)), all %d pairs" % (n, L, enc_name, MU, P_N, pairs_total),
+               "config": {"workload": "%d samples x %d sites, %s, mu = %g per sample + %g N (%s): pairsnp (d + compared "
+                                      "sites) + transcluster (P, E(K)), all %d pairs"
+                                      % (n, L, enc_name, W["mu_sample"], W["p_n"], "SURVEY 8d" if args.workload == "sparse" else
+                                         "workload '%s': %s" % (args.workload, W), pairs_total),
                           "samples": n, "sites": L, "pairs": pairs_total, "encoding": enc, "kernel": aln.kernel,
                           "mean_d": checksum / float(pairs_total), "distinct_keys": keys[0],
                           "clock_rate": args.lamb, "trans_rate": args.beta, "precision": args.precision,
                           "transcluster_ms_per_step": sum(tc_ms) / len(tc_ms),
                           "partition": "row panels, fold pairing, %d rank(s); RCCL all-gather of the d / nn panels; P and E(K) derived on every "
                                        "rank from the gathered d, key evaluations split over the ranks (key-table all-reduce)" % world,
-                          "setup_seconds": round(setup_s, 1), "per_pack_decisions_ms": round(t_first * 1e3, 1), "checksum_d": checksum},
+                          "workload_name": args.workload,
+                          "setup_seconds": round(setup_s, 1), "first_call_ms": round(t_first * 1e3, 1), "checksum_d": checksum},
                "roofline": roof}
+        if single is not None:
+            out["single_pass"] = single
+        if world == 1 and not args.no_extras and args.partial == 0 and args.workload == "sparse":
+            out["sensitivity"] = sensitivity(args, n, L, seed, days, dev, synth, torch, device, lib, value)
+            out["value_worst_workload"] = min([value] + [w["pairs_per_s"] for w in out["sensitivity"]["workloads"].values()])
         if world == 1 and not args.no_extras and args.partial == 0:
             out["roofline_general"] = general_pass(args, n, L, seed, dev, synth, torch, device)
             out["dm_frontend"] = dm_frontend(args, L, dev, torch, device)
@@ -352,6 +418,57 @@ def _traffic_from_profiles(n, L, world, kernel):
         return None
 
 
+def sensitivity(args, n, L, seed, days, dev, synth, torch, device, lib, value_default):
+    """The same pass on four other synthetic alignments of the same shape (WORKLOADS), each with the site classes as the cost
+    model decides and with every site through the pair kernel (tracs_debug_force_site_classes(0), the same handle re-decided):
+    ms per pass in steady state (pairsnp + transcluster, 2 passes after one untimed), class sizes, and the two runs' checksums,
+    which must agree.  The reference's cost does not depend on the data (src/pairsnp.hpp:395-420 visits every site of every pair);
+    this path's does: the spread is reported, and the worst workload's rate goes beside `value` as value_worst_workload."""
+    pairs = n * (n - 1) // 2
+    dmat = torch.zeros((n, n), dtype=torch.int32, device=device)
+    nmat = torch.zeros((n, n), dtype=torch.int32, device=device)
+    pmat = torch.zeros((n, n), dtype=torch.float64, device=device)
+    emat = torch.zeros((n, n), dtype=torch.float64, device=device)
+
+    def timed(a):
+        def one():
+            dev.pairsnp_dense(a, dmat, nmat)
+            dev.trans_dist_dense_ranges(dmat, n, days, args.lamb, args.beta, args.precision, pmat, emat, [(0, n)], exp_p0=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        one()
+        torch.cuda.synchronize()
+        first = (time.perf_counter() - t0) * 1e3
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        one(); one()
+        e1.record()
+        torch.cuda.synchronize()
+        return first, e0.elapsed_time(e1) / 2, int(dmat.sum().item()), int(nmat.sum().item())
+    out = {}
+    for name in ("lineage", "divergent", "clean", "gappy"):
+        a = dev.Alignment(n, L)
+        synth.pack_synthetic_device(a, seed=seed, **synth_kw(0.0, name))
+        first, ms, cd, cn = timed(a)
+        classes, kernel, split = a.site_classes, a.kernel, pair_split_ms(lib)
+        lib.tracs_debug_force_site_classes(0)
+        a.mark_packed()
+        first0, ms0, cd0, cn0 = timed(a)
+        lib.tracs_debug_force_site_classes(-2)
+        a.close()
+        if (cd, cn) != (cd0, cn0):
+            raise SystemExit("PARITY FAILURE: workload %s, site classes change the result (%d, %d) vs (%d, %d)" % (name, cd, cn, cd0, cn0))
+        out[name] = {"ms_per_pass": ms, "pairs_per_s": pairs / (ms / 1e3), "single_pass_ms": first,
+                     "ms_per_pass_classes_off": ms0, "single_pass_ms_classes_off": first0,
+                     "site_classes": None if classes is None else dict(zip(("dense", "counted", "minority", "full"), classes)),
+                     "kernel": kernel, "kernels_ms": None if not split else dict(zip(("pair", "lists", "count"), split)),
+                     "mean_d": cd / float(pairs), "checksum_d": cd, "checksum_nn": cn, "generator": WORKLOADS[name]}
+    worst = min(out, key=lambda k: out[k]["pairs_per_s"])
+    return {"workloads": out, "worst": worst,
+            "spread": max([value_default] + [w["pairs_per_s"] for w in out.values()]) / min([value_default] + [w["pairs_per_s"] for w in out.values()]),
+            "note": "10k x 5 Mbp each; default run vs every site through the pair kernel (same handle, re-decided); checksums of d and nn equal"}
+
+
 def general_pass(args, n, L, seed, dev, synth, torch, device):
     """The general-encoding path on the same workload with SURVEY 8d's C4 mix of partial codes: its own alignment handle,
     2 passes timed with HIP events (not part of `value`)."""
@@ -373,15 +490,16 @@ def general_pass(args, n, L, seed, dev, synth, torch, device):
     split, classes, pairs = pair_split_ms(_lib.load()), aln.site_classes, n * (n - 1) // 2
     traffic = _traffic_from_profiles(n, L, 1, aln.kernel + ("+classes" if classes else ""))
     if classes and split:
-        main = roofline_of(aln.kernel, "general", pairs, classes[0], max(split[0], 1e-3) / 1e3, None)
-        cnt = count_roofline(pairs, classes[1], max(split[2], 1e-3) / 1e3)
+        count_sites, in_place = aln.count_source or (classes[1], False)
+        main = roofline_of(aln.kernel, "general", pairs, classes[0], max(split[0], 1e-3) / 1e3, None, n)
+        cnt = count_roofline(pairs, count_sites, max(split[2], 1e-3) / 1e3, n, in_place)
         r, other = (cnt, main) if split[2] > split[0] else (main, cnt)
         r["other_matrix_core_kernel"] = {k: other[k] for k in ("kernel", "kernel_ms", "achieved", "frac", "unit") if k in other}
         r["lists_ms"] = split[1]
         r["site_classes"] = {"dense": classes[0], "counted": classes[1], "minority": classes[2], "full": classes[3],
                              "empty": L - classes[0] - classes[1] - classes[3]}
     else:
-        r = roofline_of(aln.kernel, "general", pairs, L, kern_s, traffic)
+        r = roofline_of(aln.kernel, "general", pairs, L, kern_s, traffic, n)
     r["dense_call_ms"] = kern_s * 1e3
     if split:
         r["kernels_ms"] = {"pairsnp_mfma_kernel": split[0], "general_fixup_kernel (partial codes of the dense sites + minority lists)": split[1],
@@ -464,7 +582,7 @@ def cpu_baseline(n, L, seed, days_np, args, dmat, nmat, n_keys_full):
     from tracs_amd import synth
     cores = O.lib().orc_num_threads()
     m = int(max(16, min(n, 128)))
-    seqs = synth.first_samples_host(n, L, seed, m, **synth_kw(args.partial))
+    seqs = synth.first_samples_host(n, L, seed, m, **synth_kw(args.partial, args.workload))
     planes = O.pack(seqs)                                   # untimed, like the GPU side's resident planes
     pairs = m * (m - 1) // 2
     reps, t_snp = 0, 0.0

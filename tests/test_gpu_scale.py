@@ -233,6 +233,15 @@ def test_bench_line_contract_small():
     assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     sc = r["site_classes"]
     assert sc["dense"] + sc["counted"] + sc["full"] + sc["empty"] == 200000 and sc["minority"] > 0
+    assert r["frac_of_measured_fp4_ceiling"] <= 1.0 and "hbm" not in r          # no fraction above 1 on the line
+    # one pass per alignment (the reference's unit of work), cold and warm, with the once-per-pack stages
+    sp = j["single_pass"]
+    assert sp["cold_ms"] > 0 and sp["warm_ms"] > 0 and sp["per_pack_ms"] > 0 and "classify" in sp["stages_ms"]
+    assert sp["warm_ms"] >= j["ms_per_step"] * 0.8 and abs(sp["value_single_pass"] - 700 * 699 / 2 / (sp["warm_ms"] / 1e3)) < 1e-6 * sp["value_single_pass"]
+    # the other workloads: classes on / off agree (bench.py exits non-zero otherwise), the worst one is beside `value`
+    sw = j["sensitivity"]["workloads"]
+    assert set(sw) == {"lineage", "divergent", "clean", "gappy"}
+    assert j["value_worst_workload"] <= j["value"] and j["value_worst_workload"] == min([j["value"]] + [w["pairs_per_s"] for w in sw.values()])
     assert r["other_matrix_core_kernel"]["kernel_ms"] >= 0 and r["minority_lists_ms"] >= 0
     g = j["roofline_general"]
     assert g["bound"] == "mfma" and g["mean_d"] > j["config"]["mean_d"]

@@ -202,6 +202,8 @@ def load():
     L.tracs_debug_alignment_site_classes.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.tracs_debug_alignment_count_source.restype = C.c_int
     L.tracs_debug_alignment_count_source.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.tracs_debug_force_site_classes.restype = None
+    L.tracs_debug_force_site_classes.argtypes = [C.c_int]
     L.tracs_debug_pack_timing.restype = None
     L.tracs_debug_pack_timing.argtypes = [C.c_int]
     L.tracs_debug_pack_stages.restype = C.c_int

@@ -272,6 +272,7 @@ int tracs_pairsnp(const char *const *fasta, int n_fasta, int n_threads, int dist
                 std::vector<long long> poff;
                 size_t t0 = 0;
                 while (t0 < (size_t)total) {
+                    if (g_sigint) { cleanup(); delete res; set_error("Interrupted by user!"); return TRACS_E_INTERRUPTED; }
                     poff.assign(1, 0);
                     size_t t1 = t0;
                     while (t1 < (size_t)total && (t1 == t0 || (size_t)poff.back() + res->dist[base + t1] <= kMaxPos)) {
@@ -310,6 +311,8 @@ int tracs_pairsnp(const char *const *fasta, int n_fasta, int n_threads, int dist
     }
 #undef PS_CHECK
 #undef PS_RC
+    // a Ctrl-C that arrived during the last panel / filter batch is not swallowed (the reference looks at its flag on every row)
+    if (g_sigint) { cleanup(); delete res; set_error("Interrupted by user!"); return TRACS_E_INTERRUPTED; }
     if (!filter) res->filt.assign(res->rows.size(), 0);      // filter off: `len` zeros (:452 via combine_vectors :31)
     cleanup();
     *out = res;

@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <vector>
 
 #include "../../include/tracs_hip.h"
 
@@ -64,6 +65,12 @@ struct tracs_alignment {
     bool classes_cons = false;                // vplanes hold consensus planes (X, Y, V) / the five general planes
     tracs::GeneralSparse *minor = nullptr;    // lists of the minority sites (site_classes.hip)
     int classes_state = 0;       // 0 not decided, 1 in use, -1 not in use for this alignment
+    // Arena for what is built once per pack (vplanes, iplanes, N counts, minority lists): reserved together with the planes at
+    // tracs_alignment_create, because a fresh device allocation costs ~24 ms per GB on this platform (the driver clears VRAM) and
+    // would otherwise land inside the first pass.  pack_alloc falls back to hipMalloc when the arena is too small.
+    uint8_t *arena = nullptr;
+    size_t arena_bytes = 0, arena_used = 0;
+    std::vector<void *> pack_extra;
     tracs::GeneralSparse *sparse = nullptr;   // general matrix-core path: per-site / per-sample lists of N and partial codes
     int sparse_state = 0;        // 0 not built, 1 built, -1 not available for this alignment (too dense / too large / no memory)
     // cached tile schedules of the last dense regions (region x workgroup tile): the pair kernel's and the counting pass's, for
@@ -85,6 +92,10 @@ static inline const uint4 *pair_planes(const tracs_alignment *a, bool consensus)
 }
 static inline size_t pair_L(const tracs_alignment *a) { return a->classes_state == 1 ? a->L_var : a->L; }
 static inline size_t pair_groups(const tracs_alignment *a) { return a->classes_state == 1 ? a->groups_var : a->groups; }
+
+// device memory that lives until the alignment is packed again (site_classes_free releases all of it at once)
+hipError_t pack_alloc(tracs_alignment *a, size_t bytes, void **out);
+void pack_release(tracs_alignment *a);
 
 // Grow-only per-device scratch buffers (slot ids are small integers owned by each .hip file), shared by every entry point.
 // Entry points that use them, or the cached state of a tracs_alignment, hold a DeviceCall for their whole body:

@@ -20,6 +20,8 @@
 #include "pairsnp_kernels.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -30,6 +32,7 @@ struct GeneralSparse {
     unsigned *s_ent = nullptr, *p_ent = nullptr, *n_ent = nullptr;
     unsigned *c_n = nullptr, *c_p = nullptr;      // per sample: its N sites, the sum of w over its listed (partial) sites
     double est_updates = 0.0;
+    bool in_arena = false;                        // the arrays live in the alignment's pack arena (released with it, not one by one)
 };
 constexpr int ENT_SHIFT = 5;                      // entries: index << 5 | w << 4 | 4-bit code
 
@@ -339,7 +342,7 @@ static void gs_free(GeneralSparse *g)
 {
     if (!g) return;
     void *p[] = {g->s_off, g->p_off, g->n_off, g->s_ent, g->p_ent, g->n_ent, g->c_n, g->c_p};
-    for (void *q : p) if (q) (void)hipFree(q);
+    if (!g->in_arena) for (void *q : p) if (q) (void)hipFree(q);
     delete g;
 }
 
@@ -591,16 +594,23 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb, hipStream_t s
     const size_t n = a->n, L = mb.sites, groups = a->groups;
     if (L == 0 || L >= (1ull << 27) || n >= (1ull << 27)) return TRACS_OK;           // entries hold rank << 5 / sample << 5
     auto *g = new GeneralSparse();
+    g->in_arena = true;                                    // (pack_alloc: the alignment's arena, or hipMalloc tracked by it)
     auto fail_soft = [&]() { (void)hipGetLastError(); gs_free(g); return TRACS_OK; };
 #define GS_TRY(x) do { if ((x) != hipSuccess) return fail_soft(); } while (0)
     const unsigned long long tot_s = mb.tot_p + mb.tot_n;
-    GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->s_off), (n + 1) * 8));
-    GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->p_off), (L + 1) * 8));
-    GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->n_off), (L + 1) * 8));
-    GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->c_p), std::max<size_t>(n, 1) * 4));
-    GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->s_ent), std::max<size_t>(tot_s, 1) * 4));
-    GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->p_ent), std::max<size_t>(mb.tot_p, 1) * 4));
-    GS_TRY(hipMalloc(reinterpret_cast<void **>(&g->n_ent), std::max<size_t>(mb.tot_n, 1) * 4));
+    static const bool trace = std::getenv("TRACS_CLASSES_TRACE") != nullptr;
+    const auto t_host0 = std::chrono::steady_clock::now();
+    const size_t before = a->pack_extra.size();
+    GS_TRY(pack_alloc(a, (n + 1) * 8, reinterpret_cast<void **>(&g->s_off)));
+    GS_TRY(pack_alloc(a, (L + 1) * 8, reinterpret_cast<void **>(&g->p_off)));
+    GS_TRY(pack_alloc(a, (L + 1) * 8, reinterpret_cast<void **>(&g->n_off)));
+    GS_TRY(pack_alloc(a, std::max<size_t>(n, 1) * 4, reinterpret_cast<void **>(&g->c_p)));
+    GS_TRY(pack_alloc(a, std::max<size_t>(tot_s, 1) * 4, reinterpret_cast<void **>(&g->s_ent)));
+    GS_TRY(pack_alloc(a, std::max<size_t>(mb.tot_p, 1) * 4, reinterpret_cast<void **>(&g->p_ent)));
+    GS_TRY(pack_alloc(a, std::max<size_t>(mb.tot_n, 1) * 4, reinterpret_cast<void **>(&g->n_ent)));
+    if (trace) std::fprintf(stderr, "[once per pack] host: list storage %.2f GB (%zu of 7 arrays outside the arena) %.2f ms\n",
+                            (double)(tot_s + mb.tot_p + mb.tot_n) * 4e-9, a->pack_extra.size() - before,
+                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count());
     unsigned *cnt = nullptr, *cur = nullptr;
     unsigned long long *off = nullptr;
     uint2 *E = nullptr;

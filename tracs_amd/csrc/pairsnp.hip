@@ -626,6 +626,28 @@ static size_t plane_bytes(const tracs_alignment *a, int planes)
     return ((a->groups + PAD_GROUPS) * (size_t)planes * a->n_pad + TAIL_PAD) * sizeof(uint4);
 }
 
+namespace tracs {
+hipError_t pack_alloc(tracs_alignment *a, size_t bytes, void **out)
+{
+    const size_t need = (bytes + 255) / 256 * 256;
+    if (a->arena && a->arena_used + need <= a->arena_bytes) {
+        *out = a->arena + a->arena_used;
+        a->arena_used += need;
+        return hipSuccess;
+    }
+    const hipError_t e = hipMalloc(out, std::max<size_t>(bytes, 256));
+    if (e == hipSuccess) a->pack_extra.push_back(*out);
+    else *out = nullptr;
+    return e;
+}
+void pack_release(tracs_alignment *a)
+{
+    for (void *p : a->pack_extra) (void)hipFree(p);
+    a->pack_extra.clear();
+    a->arena_used = 0;
+}
+}  // namespace tracs
+
 extern "C" {
 
 int tracs_debug_iupac_mask(int ch) { return (int)iupac_mask((unsigned)ch & 0xFFu); }
@@ -643,6 +665,14 @@ int tracs_alignment_create(size_t n, size_t L, tracs_alignment **out)
         if (e != hipSuccess) { set_error(std::string("hipMalloc(planes): ") + hipGetErrorString(e)); delete a; return TRACS_E_NOMEM; }
         e = hipMemset(a->planes, 0, bytes);
         if (e != hipSuccess) { set_error(std::string("hipMemset(planes): ") + hipGetErrorString(e)); (void)hipFree(a->planes); delete a; return TRACS_E_HIP; }
+        // the arena of the once-per-pack structures: 12 % of the planes + 64 MiB covers the lists of alignments with up to ~3 % of
+        // N / minority entries (TRACS_PACK_ARENA=<fraction> overrides; 0: none).  Not getting it is not an error.
+        static const double frac = [] { const char *v = std::getenv("TRACS_PACK_ARENA"); return v ? std::atof(v) : 0.12; }();
+        if (frac > 0.0 && n >= 2) {
+            const size_t want = (size_t)((double)bytes * frac) + std::min<size_t>(64u << 20, 2 * bytes + (1u << 20));
+            if (hipMalloc(reinterpret_cast<void **>(&a->arena), want) == hipSuccess) a->arena_bytes = want;
+            else { a->arena = nullptr; (void)hipGetLastError(); }
+        }
     }
     *out = a;
     return TRACS_OK;
@@ -653,6 +683,7 @@ void tracs_alignment_free(tracs_alignment *a)
     if (!a) return;
     general_sparse_free(a);
     site_classes_free(a);
+    if (a->arena) (void)hipFree(a->arena);
     if (a->planes) (void)hipFree(a->planes);
     if (a->cplanes) (void)hipFree(a->cplanes);
     if (a->d_flag) (void)hipFree(a->d_flag);

@@ -388,16 +388,14 @@ __global__ __launch_bounds__(256) void plane_popcount_kernel(const uint4 *__rest
 
 void site_classes_free(tracs_alignment *a)
 {
-    if (a->c_counted) (void)hipFree(a->c_counted);
+    minority_lists_free(a);
     a->c_counted = nullptr;
-    if (a->vplanes) (void)hipFree(a->vplanes);
-    if (a->iplanes) (void)hipFree(a->iplanes);
     a->vplanes = a->iplanes = nullptr;
+    pack_release(a);                                       // vplanes, iplanes, N counts, minority lists: one arena
     a->L_var = a->L_inv = a->groups_var = a->groups_inv = 0;
     a->L_minor = a->L_full = 0;
     a->count_in_place = false;
     a->classes_cons = false;
-    minority_lists_free(a);
     a->classes_state = 0;
 }
 
@@ -405,6 +403,8 @@ static size_t class_plane_bytes(const tracs_alignment *a, size_t groups, int pla
 {
     return ((groups + pad_groups) * (size_t)planes * a->n_pad + TAIL_PAD) * sizeof(uint4);
 }
+
+static int g_force_classes = -2;          // tracs_debug_force_site_classes: -2 follow TRACS_SITE_CLASSES, -1 cost model, 0 never, 1 always
 
 // ---- stage clock of the once-per-pack work (diagnostics: bench.py's single_pass.stages, TRACS_CLASSES_TRACE) --------------
 // HIP events on the launch stream, read back afterwards: no synchronisation inside the build.
@@ -450,7 +450,8 @@ void pack_stage_end()
 static int decide(tracs_alignment *a, bool allow_minor, hipStream_t stream, int *partial)
 {
     a->classes_state = -1;
-    static const int force = [] { const char *e = std::getenv("TRACS_SITE_CLASSES"); return e ? std::atoi(e) : -1; }();
+    static const int env_force = [] { const char *e = std::getenv("TRACS_SITE_CLASSES"); return e ? std::atoi(e) : -1; }();
+    const int force = g_force_classes >= -1 ? g_force_classes : env_force;
     static const bool no_minor = [] { const char *e = std::getenv("TRACS_MINORITY"); return e && std::atoi(e) == 0; }();
     static const bool force_general = std::getenv("TRACS_FORCE_GENERAL") != nullptr;
     const size_t groups = a->groups;
@@ -517,9 +518,9 @@ static int decide(tracs_alignment *a, bool allow_minor, hipStream_t stream, int 
     const size_t vbytes = class_plane_bytes(a, gv, npv, PAD_GROUPS), ibytes = class_plane_bytes(a, gi, 1, PAD_GROUPS);
     unsigned *lists = nullptr;
     if ((rc = workspace_get(39, (L_dense + L_count + 1) * sizeof(unsigned), reinterpret_cast<void **>(&lists)))) return rc;
-    if (hipMalloc(reinterpret_cast<void **>(&a->vplanes), vbytes) != hipSuccess) { a->vplanes = nullptr; return soft_fail(); }
-    if (gi && hipMalloc(reinterpret_cast<void **>(&a->iplanes), ibytes) != hipSuccess) { a->iplanes = nullptr; return soft_fail(); }
-    if (hipMalloc(reinterpret_cast<void **>(&a->c_counted), a->n_pad * sizeof(unsigned)) != hipSuccess) { a->c_counted = nullptr; return soft_fail(); }
+    if (pack_alloc(a, vbytes, reinterpret_cast<void **>(&a->vplanes)) != hipSuccess) return soft_fail();
+    if (gi && pack_alloc(a, ibytes, reinterpret_cast<void **>(&a->iplanes)) != hipSuccess) return soft_fail();
+    if (pack_alloc(a, a->n_pad * sizeof(unsigned), reinterpret_cast<void **>(&a->c_counted)) != hipSuccess) return soft_fail();
     unsigned *list_dense = lists, *list_count = lists + L_dense;
     bool ok = hipMemsetAsync(a->vplanes, 0, vbytes, stream) == hipSuccess &&
               (!gi || hipMemsetAsync(a->iplanes, 0, ibytes, stream) == hipSuccess) &&
@@ -584,6 +585,10 @@ int site_classes_decide(tracs_alignment *a, hipStream_t stream, int *partial)
 }  // namespace tracs
 
 extern "C" {
+
+// Diagnostics (bench.py's sensitivity legs: the same alignment with and without site classes in one process): overrides
+// TRACS_SITE_CLASSES for alignments decided from now on.  -2 environment, -1 cost model, 0 never, 1 always.
+void tracs_debug_force_site_classes(int mode) { tracs::g_force_classes = mode; }
 
 // Diagnostics (bench.py's single_pass.stages): record the stages of the once-per-pack work of later dense calls with HIP events
 void tracs_debug_pack_timing(int on) { tracs::g_stage_on = on != 0; }

@@ -700,12 +700,19 @@ static int run_trans_dist(const Src &src, size_t total, double lamb, double beta
     double *tab_lnS = nullptr, *tab_pois = nullptr;
     if ((rc = workspace_get(TcWorkspaceIds::TAB, 256, reinterpret_cast<void **>(&tab)))) return rc;
     TRACS_HIP_CHECK(hipMemsetAsync(tab, 0, 256, stream));                 // ok = 0
-    if (Src::HAS_GAPS) {
-        if ((rc = workspace_get(TcWorkspaceIds::TAB_LNS, TC_TABLE_ELEMS * 8, reinterpret_cast<void **>(&tab_lnS)))) return rc;
-        if ((rc = workspace_get(TcWorkspaceIds::TAB_POIS, TC_POIS_ELEMS * 8, reinterpret_cast<void **>(&tab_pois)))) return rc;
-        unsigned *bounds = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(tab) + 128);
-        hipLaunchKernelGGL((tc_key_bounds_kernel<Src>), dim3(256), dim3(256), 0, stream, src, key_elem, n_keys, bounds);
-        hipLaunchKernelGGL(tc_tables_kernel, dim3(1024), dim3(64), 0, stream, tab, bounds, n_keys, tab_lnS, tab_pois, TC_POIS_ELEMS, P, lg);
+    // The tables are an optional speed-up (ok = 0 is a working path): only worth their 512 MB of workspace when there are enough
+    // keys to share the per-gap sums, and not getting the memory -- e.g. beside a rank's alignment, panels and lists -- is not an error.
+    if (Src::HAS_GAPS && nk >= 2048) {
+        const bool have = workspace_get(TcWorkspaceIds::TAB_LNS, TC_TABLE_ELEMS * 8, reinterpret_cast<void **>(&tab_lnS)) == TRACS_OK &&
+                          workspace_get(TcWorkspaceIds::TAB_POIS, TC_POIS_ELEMS * 8, reinterpret_cast<void **>(&tab_pois)) == TRACS_OK;
+        if (have) {
+            unsigned *bounds = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(tab) + 128);
+            hipLaunchKernelGGL((tc_key_bounds_kernel<Src>), dim3(256), dim3(256), 0, stream, src, key_elem, n_keys, bounds);
+            hipLaunchKernelGGL(tc_tables_kernel, dim3(1024), dim3(64), 0, stream, tab, bounds, n_keys, tab_lnS, tab_pois, TC_POIS_ELEMS, P, lg);
+        } else {
+            (void)hipGetLastError();
+            set_error("");
+        }
     }
     // long series (E(K) loop beyond TC_SERIAL_CAP terms): one wave per key
     hipLaunchKernelGGL((tc_long_keys_kernel<Src>), dim3(std::min<unsigned>(nk, 256u * 32u)), dim3(64), 0, stream, src, key_elem,

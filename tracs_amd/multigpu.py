@@ -19,7 +19,9 @@ from . import partition
 
 
 def in_worker():
-    return int(os.environ.get("WORLD_SIZE", "1")) > 1 and "RANK" in os.environ
+    """True in a process spawn() started.  The ambient WORLD_SIZE / RANK of somebody else's torchrun or SLURM job do not
+    count: a plain `tracs distance` run inside such a job stays a single-GPU run."""
+    return os.environ.get("TRACS_MULTIGPU_WORKER") == "1" and int(os.environ.get("WORLD_SIZE", "1")) > 1 and "RANK" in os.environ
 
 
 def spawn(module, argv, gpus):
@@ -30,7 +32,7 @@ def spawn(module, argv, gpus):
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(gpus)), "--master-addr", "127.0.0.1",
            "--master-port", str(port), "-m", module] + list(argv)
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), TRACS_MULTIGPU_WORKER="1")
     return subprocess.run(cmd, env=env).returncode
 
 

@@ -107,10 +107,11 @@ def allele_counts(L, seed, depth=30, eps=0.01, p_two=0.01):
 
 # ---- on-device generation for the benchmark (torch) -------------------------------------
 def generate_device(n, L, seed, emit, mu_lineage=1e-5, mu_sample=1e-6, n_lineages=None, p_n=0.01, batch=32,
-                    limit=None, p_partial=0.0):
+                    limit=None, p_partial=0.0, n_every=1):
     """The same two-level model generated on the GPU in batches of `batch` samples; every batch
     (uint8 [cnt, L] ASCII on the device) is handed to emit(rows, first).  Deterministic in `seed`;
-    `limit` stops after the first `limit` samples (same values as a full run).  Setup code, untimed."""
+    `limit` stops after the first `limit` samples (same values as a full run).  n_every = k: only every k-th sample carries
+    N, at k p_n sites (the same amount of N, concentrated in 1 / k of the samples).  Setup code, untimed."""
     import torch
     dev = torch.device("cuda", torch.cuda.current_device())
     g = torch.Generator(device=dev)
@@ -137,8 +138,8 @@ def generate_device(n, L, seed, emit, mu_lineage=1e-5, mu_sample=1e-6, n_lineage
         for b in range(cnt):
             idx = mutate(founders[(s0 + b) % n_lineages], mu_sample)
             rows[b] = lut[idx.long()]
-            if p_n > 0:
-                m = torch.rand(L, generator=g, device=dev) < p_n
+            if p_n > 0 and (s0 + b) % n_every == 0:
+                m = torch.rand(L, generator=g, device=dev) < min(1.0, p_n * n_every)
                 rows[b][m] = ord("N")
             if p_partial > 0:       # two/three-allele IUPAC codes at uniformly random sites (SURVEY.md 8d, config 4 mix)
                 m = torch.rand(L, generator=g, device=dev) < p_partial
