@@ -539,17 +539,21 @@ def dm_frontend(args, L, dev, torch, device):
     dmat = torch.zeros((batch, batch), dtype=torch.int32, device=device)
     nmat = torch.zeros((batch, batch), dtype=torch.int32, device=device)
 
-    def chain():
+    thr = max(5.0 / 30.0, 0.01)          # tracs align's rule at its defaults: max(min_cov / median coverage, error threshold), align.py:521
+
+    def posterior():
         for b in range(batch):
-            codes[b, :(L + 1) // 2] = dev.posterior_codes_device(counts[b], alphas, False, 0.05)
+            dev.posterior_codes_device(counts[b], alphas, False, thr, out=codes[b])     # straight into the batch buffer
+
+    def chain():
+        posterior()
         aln.pack_codes(codes, 0)
         dev.pairsnp_dense(aln, dmat, nmat)
     chain()
     torch.cuda.synchronize()
     e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     e[0].record()
-    for b in range(batch):
-        codes[b, :(L + 1) // 2] = dev.posterior_codes_device(counts[b], alphas, False, 0.05)
+    posterior()
     e[1].record()
     aln.pack_codes(codes, 0)
     e[2].record()
@@ -562,8 +566,9 @@ def dm_frontend(args, L, dev, torch, device):
            "posterior_codes_ms": t_post, "pack_codes_ms": t_pack, "pairsnp_ms": t_pair, "encoding": aln.encoding,
            "posterior_codes_GBps": sites * 8.5 / (t_post / 1e3) / 1e9, "pack_codes_GBps": sites * (0.5 + 0.625) / (t_pack / 1e3) / 1e9,
            "site_rows_per_s": sites / ((t_post + t_pack) / 1e3),
-           "note": "posterior_codes includes one device-to-device copy of each sample's codes into the batch buffer; "
-                   "algorithmic bytes: 8.5 B per site-row (posterior), 1.125 B (pack)"}
+           "posterior_threshold": thr,
+           "note": "one posterior_codes launch per sample (5 M site-rows each: launch-sized; scripts/bench_config4.py streams 250 samples "
+                   "per launch), codes written straight into the batch buffer; algorithmic bytes: 8.5 B per site-row (posterior), 1.125 B (pack)"}
     aln.close()
     return out
 

@@ -350,6 +350,52 @@ def test_posterior_codes_and_device_posteriors(dev, oracle, torch_mod):
         assert np.array_equal(codes, exp)
 
 
+def test_posterior_codes_on_the_threshold(dev, oracle, torch_mod):
+    """posterior_codes_kernel screens `post > threshold` in single precision and sends a site to the exact f64 route (the
+    reference's own divide and `<=`, src/dmultinomial.hpp:59-82) only when a cell lies within 2^-14 of the threshold.  Thresholds
+    that ARE posterior values of the table (so `post <= threshold` holds with equality for every site with that row), thresholds
+    one ulp either side, and parameters outside the screen's assumptions (zero alphas from the degenerate fit, zero / negative
+    thresholds, uint32 counts beyond 2^24) must all give the oracle's mask."""
+    from tracs_amd import synth
+    torch = torch_mod
+    L = 40001
+    counts = synth.allele_counts(L, seed=9, depth=25, p_two=0.1)
+    counts[:7] = 0
+    cases = [([20.8156311152126, 4.38181182238621, 0.889048781117318, 0.1], None),
+             ([1.0, 0.0, 0.0, 0.0], 0.05), ([0.0, 0.0, 0.0, 1.0], 0.3),           # find_dirichlet_priors' degenerate answer, any order
+             ([20.8, 4.4, 0.9, 0.1], 0.0), ([20.8, 4.4, 0.9, 0.1], -0.5), ([3.0, 3.0, 3.0, 3.0], 0.25)]
+    bits = np.array([1, 2, 4, 8], np.uint8)
+
+    def expect(c, alphas, keep, thr):
+        post = oracle.calculate_posteriors(c.astype(np.float64), alphas, keep, thr)
+        mask = ((post > 0).astype(np.uint8) * bits).sum(1).astype(np.uint8)
+        exp = np.zeros((len(c) + 1) // 2, np.uint8)
+        exp |= mask[0::2]
+        exp[:len(c) // 2] |= (mask[1::2] << 4)
+        return exp
+    c16 = torch.from_numpy(counts.view(np.int16)).cuda()
+    c32 = torch.from_numpy(counts.astype(np.int32)).cuda()
+    for alphas, thr in cases:
+        if thr is None:
+            post = oracle.calculate_posteriors(counts.astype(np.float64), alphas, False, 0.0)
+            vals = np.unique(post[post > 0])
+            pick = vals[np.linspace(0, len(vals) - 1, 12).astype(int)]
+            thrs = sorted(set(float(v) for v in pick) | set(float(np.nextafter(v, 0)) for v in pick[:4]) | set(float(np.nextafter(v, 1)) for v in pick[:4]))
+        else:
+            thrs = [thr]
+        for t in thrs:
+            for keep in (False, True):
+                exp = expect(counts, alphas, keep, t)
+                assert np.array_equal(dev.posterior_codes_device(c16, alphas, keep, t).cpu().numpy(), exp), (alphas, t, keep)
+                assert np.array_equal(dev.posterior_codes_device(c32, alphas, keep, t).cpu().numpy(), exp), (alphas, t, keep, "wide")
+    # deep counts (uint32 route): beyond what a float holds exactly
+    rng = np.random.default_rng(10)
+    deep = (rng.integers(0, 1 << 29, size=(5000, 4)) * (rng.random((5000, 4)) < 0.6)).astype(np.int32)
+    alphas = [20.8156311152126, 4.38181182238621, 0.889048781117318, 0.1]
+    for t in (0.01, 0.24999, float(deep[7, 0] + alphas[0]) / float(deep[7].sum() + sum(alphas))):
+        assert np.array_equal(dev.posterior_codes_device(torch.from_numpy(deep).cuda(), alphas, True, t).cpu().numpy(), expect(deep, alphas, True, t))
+
+
 def test_connected_components_device(dev, torch_mod):
     from scipy.sparse import csr_matrix
     from scipy.sparse.csgraph import connected_components

@@ -616,9 +616,9 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb, hipStream_t s
     uint2 *E = nullptr;
     const size_t nsc = n * MS_NCH;
     int rc;
-    if ((rc = workspace_get(40, nsc * 4, reinterpret_cast<void **>(&cnt))) || (rc = workspace_get(41, (nsc + 1) * 8, reinterpret_cast<void **>(&off))) ||
-        (rc = workspace_get(42, std::max<size_t>(mb.tot_p, 1) * sizeof(uint2), reinterpret_cast<void **>(&E))) ||
-        (rc = workspace_get(43, std::max<size_t>(n, 1) * 4, reinterpret_cast<void **>(&cur)))) { gs_free(g); return rc; }
+    if ((rc = workspace_get(60, nsc * 4, reinterpret_cast<void **>(&cnt))) || (rc = workspace_get(61, (nsc + 1) * 8, reinterpret_cast<void **>(&off))) ||
+        (rc = workspace_get(62, std::max<size_t>(mb.tot_p, 1) * sizeof(uint2), reinterpret_cast<void **>(&E))) ||
+        (rc = workspace_get(63, std::max<size_t>(n, 1) * 4, reinterpret_cast<void **>(&cur)))) { gs_free(g); return rc; }
     GS_TRY(hipMemsetAsync(cnt, 0, nsc * 4, stream));
     GS_TRY(hipMemsetAsync(cur, 0, std::max<size_t>(n, 1) * 4, stream));
     GS_TRY(hipMemsetAsync(g->c_p, 0, std::max<size_t>(n, 1) * 4, stream));

@@ -464,13 +464,13 @@ static int decide(tracs_alignment *a, bool allow_minor, hipStream_t stream, int 
     unsigned *offs = nullptr, *cnts = nullptr, *gcnt = nullptr, *d_flag = nullptr;
     unsigned long long *off64 = nullptr, *totals = nullptr, *flags = nullptr;
     int rc;
-    if ((rc = workspace_get(32, 6 * groups * sizeof(uint4), reinterpret_cast<void **>(&masks)))) return rc;
-    if ((rc = workspace_get(33, 4 * groups * sizeof(unsigned), reinterpret_cast<void **>(&offs)))) return rc;
-    if ((rc = workspace_get(34, 2 * groups * SITES_PER_GROUP * sizeof(unsigned), reinterpret_cast<void **>(&cnts)))) return rc;
-    if ((rc = workspace_get(35, 2 * groups * sizeof(unsigned), reinterpret_cast<void **>(&gcnt)))) return rc;
-    if ((rc = workspace_get(36, 2 * (groups + 1) * sizeof(unsigned long long), reinterpret_cast<void **>(&off64)))) return rc;
-    if ((rc = workspace_get(37, 64, reinterpret_cast<void **>(&totals)))) return rc;
-    if ((rc = workspace_get(38, groups * flag_words * sizeof(unsigned long long), reinterpret_cast<void **>(&flags)))) return rc;
+    if ((rc = workspace_get(52, 6 * groups * sizeof(uint4), reinterpret_cast<void **>(&masks)))) return rc;
+    if ((rc = workspace_get(53, 4 * groups * sizeof(unsigned), reinterpret_cast<void **>(&offs)))) return rc;
+    if ((rc = workspace_get(54, 2 * groups * SITES_PER_GROUP * sizeof(unsigned), reinterpret_cast<void **>(&cnts)))) return rc;
+    if ((rc = workspace_get(55, 2 * groups * sizeof(unsigned), reinterpret_cast<void **>(&gcnt)))) return rc;
+    if ((rc = workspace_get(56, 2 * (groups + 1) * sizeof(unsigned long long), reinterpret_cast<void **>(&off64)))) return rc;
+    if ((rc = workspace_get(57, 64, reinterpret_cast<void **>(&totals)))) return rc;
+    if ((rc = workspace_get(58, groups * flag_words * sizeof(unsigned long long), reinterpret_cast<void **>(&flags)))) return rc;
     d_flag = reinterpret_cast<unsigned *>(totals + 7);
     uint4 *dense_mask = masks, *count_mask = masks + groups, *minor_mask = masks + 2 * groups, *full_mask = masks + 3 * groups;
     uint4 *ref_x = masks + 4 * groups, *ref_y = masks + 5 * groups;
@@ -517,7 +517,7 @@ static int decide(tracs_alignment *a, bool allow_minor, hipStream_t stream, int 
     const size_t gv = groups_for(L_dense), gi = in_place ? 0 : groups_for(L_count);
     const size_t vbytes = class_plane_bytes(a, gv, npv, PAD_GROUPS), ibytes = class_plane_bytes(a, gi, 1, PAD_GROUPS);
     unsigned *lists = nullptr;
-    if ((rc = workspace_get(39, (L_dense + L_count + 1) * sizeof(unsigned), reinterpret_cast<void **>(&lists)))) return rc;
+    if ((rc = workspace_get(59, (L_dense + L_count + 1) * sizeof(unsigned), reinterpret_cast<void **>(&lists)))) return rc;
     if (pack_alloc(a, vbytes, reinterpret_cast<void **>(&a->vplanes)) != hipSuccess) return soft_fail();
     if (gi && pack_alloc(a, ibytes, reinterpret_cast<void **>(&a->iplanes)) != hipSuccess) return soft_fail();
     if (pack_alloc(a, a->n_pad * sizeof(unsigned), reinterpret_cast<void **>(&a->c_counted)) != hipSuccess) return soft_fail();

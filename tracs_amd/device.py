@@ -279,14 +279,18 @@ def calculate_posteriors_device(counts, alphas, keep, threshold):
     return out
 
 
-def posterior_codes_device(counts_u16, alphas, keep, threshold, min_cov=0, cov_band=None):
+def posterior_codes_device(counts_u16, alphas, keep, threshold, min_cov=0, cov_band=None, out=None):
     """counts_u16: torch.int16/uint16 [L,4] (or int32 [L,4] for depths above 65535) -> torch.uint8 [(L+1)//2] packed allele
     masks (low nibble = even site).  min_cov / cov_band=(lo, hi): the align stage's coverage rules (sites below min_cov or
-    inside the band become N)."""
+    inside the band become N).  out: a contiguous uint8 view of at least (L+1)//2 bytes to write into (e.g. the sample's row
+    of a batch buffer for Alignment.pack_codes)."""
     L = _lib.require_gpu()
     a = np.ascontiguousarray(alphas, dtype=np.float64)
     n = counts_u16.shape[0]
-    out = torch.empty((n + 1) // 2, dtype=torch.uint8, device=counts_u16.device)
+    if out is None:
+        out = torch.empty((n + 1) // 2, dtype=torch.uint8, device=counts_u16.device)
+    else:
+        assert out.dtype == torch.uint8 and out.is_contiguous() and out.numel() >= (n + 1) // 2 and out.device == counts_u16.device
     lo, hi = cov_band if cov_band is not None else (1.0, 0.0)
     assert counts_u16.is_contiguous() and counts_u16.element_size() in (2, 4)
     fn = L.tracs_posterior_codes_cov_device32 if counts_u16.element_size() == 4 else L.tracs_posterior_codes_cov_device
