@@ -46,22 +46,39 @@ def test_config2_full_size_bit_exact(dev, oracle):
 
 
 def test_config4_shape_posterior_codes(dev, oracle):
-    """configs[3] shape: per-site 4-allele uint16 counts -> posterior filter -> 4-bit codes.  100 M sites in one launch
-    (100 samples' worth of 1 Mbp); the oracle checks a strided sample, the rest by consistency with the f64 kernel."""
+    """configs[3] shape: per-site 4-allele uint16 counts -> posterior filter -> 4-bit codes, 10^9 site-rows in one launch (1 000
+    samples' worth of 1 Mbp: 8 GB of counts; scripts/bench_config4.py streams the full 5 x 10^10).  The oracle checks the
+    1 M-row block the input repeats (a strided sample of the launch: every 1000th block is that block), the rest by properties:
+    equal input blocks give equal output blocks, and rotating the allele columns rotates the mask bits (alphas go by rank, not
+    by column: src/dmultinomial.hpp:45-64); the f64 kernel agrees on 2 M rows."""
     import torch
     from tracs_amd import synth
-    L = 100_000_000
+    reps = 1000
+    L = reps * 1_000_000
     base = synth.allele_counts(1_000_000, seed=44, depth=30, p_two=0.01)
-    counts = torch.from_numpy(base.view(np.int16)).cuda().repeat(100, 1)
+    base[:1000] = 0                                                     # uncovered sites
+    base[1000:1200, 0] = 5000                                           # totals beyond the kernel's per-total table
+    counts = torch.from_numpy(base.view(np.int16)).cuda().repeat(reps, 1)
     alphas = [20.8156, 4.3818, 0.8890, 0.1]
+    for thr, keep, min_cov in ((0.01, False, 0), (5.0 / 30.0, True, 5)):
+        codes = dev.posterior_codes_device(counts, alphas, keep, thr, min_cov=min_cov)
+        assert codes.shape[0] == L // 2
+        per = codes.view(reps, -1)
+        assert bool((per == per[0]).all())                              # same input block -> same output block
+        post = oracle.calculate_posteriors(base.astype(np.float64), alphas, keep, thr)
+        mask = ((post > 0).astype(np.uint8) * np.array([1, 2, 4, 8], np.uint8)).sum(1).astype(np.uint8)
+        mask[base.astype(np.int64).sum(1) < min_cov] = 15               # tracs/align.py:613
+        exp = (mask[0::2] | (mask[1::2] << 4)).astype(np.uint8)
+        assert np.array_equal(per[0].cpu().numpy(), exp)
+        del per
+        # allele columns rotated by one (A -> C -> G -> T -> A): every nibble's bits rotate the same way
+        part = counts[:100_000_000]
+        rot = dev.posterior_codes_device(torch.roll(part, 1, dims=1).contiguous(), alphas, keep, thr, min_cov=min_cov)
+        c0 = codes[:50_000_000]
+        lo, hi = c0 & 15, c0 >> 4
+        assert bool(torch.equal(rot, (((lo << 1) | (lo >> 3)) & 15) | ((((hi << 1) | (hi >> 3)) & 15) << 4)))
+        del rot, part
     codes = dev.posterior_codes_device(counts, alphas, False, 0.01)
-    assert codes.shape[0] == L // 2
-    per = codes.view(100, -1)
-    assert bool((per == per[0]).all())                                  # same input block -> same output block
-    post = oracle.calculate_posteriors(base.astype(np.float64), alphas, False, 0.01)
-    mask = ((post > 0).astype(np.uint8) * np.array([1, 2, 4, 8], np.uint8)).sum(1).astype(np.uint8)
-    exp = (mask[0::2] | (mask[1::2] << 4)).astype(np.uint8)
-    assert np.array_equal(per[0].cpu().numpy(), exp)
     f64 = dev.calculate_posteriors_device(counts[:2_000_000].to(torch.float64), alphas, False, 0.01)
     m2 = ((f64 > 0).to(torch.uint8) * torch.tensor([1, 2, 4, 8], dtype=torch.uint8, device="cuda")).sum(1).to(torch.uint8)
     assert bool(torch.equal(m2[0::2] | (m2[1::2] << 4), codes[:1_000_000]))

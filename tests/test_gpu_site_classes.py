@@ -2,6 +2,8 @@
 sites only and complete the compared-sites counts with a one-operand pass over the invariant sites.  Results must stay
 bit-identical to the oracle's pair loop (src/pairsnp.hpp:395-420) in every geometry: both encodings, plain / thresholded /
 panel calls, class sizes that are not multiples of a group, no variable site at all, no invariant site at all."""
+import time
+
 import numpy as np
 import pytest
 
@@ -193,3 +195,79 @@ def test_site_classes_fuzz(case, hiplib, oracle):
     for c in rng.choice(L, size=min(L, case["nrich_cols"]), replace=False):
         seqs[rng.random(n) < 0.9, c] = ord("N")
     _check(dev, oracle, seqs, expect_classes=None)
+
+
+# ---- the cost model's decision against the dense pass, on the regimes bench.py's `sensitivity` legs report at full size -------
+REGIMES = {
+    "sparse": dict(mu_lineage=0.0, mu_sample=1e-4, n_lineages=1, p_n=0.01),
+    "lineage": dict(mu_lineage=1e-4, mu_sample=1e-5, n_lineages=20, p_n=0.01, n_every=21),
+    "divergent": dict(mu_lineage=0.0, mu_sample=1e-3, n_lineages=1, p_n=0.01),
+    "clean": dict(mu_lineage=0.0, mu_sample=1e-4, n_lineages=1, p_n=0.0),
+    "gappy": dict(mu_lineage=0.0, mu_sample=1e-4, n_lineages=1, p_n=0.10),
+    "random": None,                                        # uniformly random bases: no site is invariant, the classes must stand down
+}
+
+
+@pytest.mark.parametrize("regime", sorted(REGIMES))
+def test_cost_model_never_loses_to_the_dense_pass(regime, hiplib, oracle):
+    """2 000 samples x 1 Mbp per regime: whatever the cost model decides (csrc/site_classes.hip: classes when
+    (4 L_dense + L_counted) / 4 L < 0.92, minority lists within n^2 / 8000 entries per site) must (a) give the oracle's d and nn
+    bit for bit -- checked on a 300-sample block, and over the whole matrix against the run with every site through the pair
+    kernel -- and (b) not be slower than that run: a steady-state pass <= 1.1 x the dense pass, and one pass INCLUDING the
+    once-per-pack work <= 1.1 x the dense run's.  The reference's cost is the same on all of them (src/pairsnp.hpp:395-420)."""
+    import torch
+    from tracs_amd import device as dev, synth
+    n, L = 2000, 1_000_000
+    aln = dev.Alignment(n, L)
+    if REGIMES[regime] is None:
+        g = torch.Generator(device="cuda")
+        g.manual_seed(5)
+        lut = torch.tensor(list(b"ACGTN"), dtype=torch.uint8, device="cuda")
+        for s0 in range(0, n, 100):
+            idx = torch.randint(0, 4, (100, L), generator=g, device="cuda")
+            idx[torch.rand((100, L), generator=g, device="cuda") < 0.01] = 4
+            aln.pack(lut[idx], first=s0)
+        head = None
+    else:
+        synth.pack_synthetic_device(aln, seed=31, **REGIMES[regime])
+        head = synth.first_samples_host(n, L, 31, 300, **REGIMES[regime])
+    d = torch.zeros((n, n), dtype=torch.int32, device="cuda")
+    nn = torch.zeros_like(d)
+
+    def run():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dev.pairsnp_dense(aln, d, nn)
+        torch.cuda.synchronize()
+        first = time.perf_counter() - t0
+        best = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            dev.pairsnp_dense(aln, d, nn)
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        return first, best
+    try:
+        first_on, pass_on = run()
+        classes = aln.site_classes
+        d_on, nn_on = d.clone(), nn.clone()
+        hiplib.tracs_debug_force_site_classes(0)
+        aln.mark_packed()
+        d.zero_(); nn.zero_()
+        first_off, pass_off = run()
+        assert aln.site_classes is None
+    finally:
+        hiplib.tracs_debug_force_site_classes(-2)
+    assert bool(torch.equal(torch.triu(d_on, 1), torch.triu(d, 1))) and bool(torch.equal(torch.triu(nn_on, 1), torch.triu(nn, 1)))
+    if head is not None:
+        er, ec, ed, enn = oracle.pairsnp_arrays(head, n_threads=16)
+        ri, ci = er.astype(np.int64), ec.astype(np.int64)
+        assert np.array_equal(d_on[:300, :300].cpu().numpy()[ri, ci], ed.astype(np.int32))
+        assert np.array_equal(nn_on[:300, :300].cpu().numpy()[ri, ci], enn.astype(np.int32))
+    assert (classes is None) == (regime == "random"), (regime, classes)
+    print("%s: classes %s  pass %.2f ms vs dense %.2f ms; first pass %.2f vs %.2f ms" %
+          (regime, classes, pass_on * 1e3, pass_off * 1e3, first_on * 1e3, first_off * 1e3))
+    if classes is not None:
+        assert pass_on <= 1.1 * pass_off, (regime, pass_on, pass_off)
+        assert first_on <= 1.1 * first_off, (regime, first_on, first_off)
+    aln.close()
