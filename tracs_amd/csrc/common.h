@@ -57,8 +57,10 @@ struct tracs_alignment {
     // place) completes the compared-sites counts.
     uint4 *vplanes = nullptr, *iplanes = nullptr;
     size_t L_var = 0, L_inv = 0, groups_var = 0, groups_inv = 0;
-    size_t L_minor = 0, L_full = 0;           // minority sites (listed in `minor`; they are part of L_inv or L_full as well);
+    size_t L_minor = 0, L_full = 0;           // minority sites (listed in `minor`; they are part of L_un or L_full as well);
                                               // sites without any N outside vplanes: +1 to every compared-sites count
+    size_t L_un = 0, L_nnl = 0;               // sites outside vplanes with an N sample (L_inv of them on the matrix cores, L_nnl
+                                              // through their N lists, the rest with a single N sample: no co-occurrence)
     unsigned *c_counted = nullptr;            // per sample: its N sites among the sites the counting pass reads
     bool count_in_place = false;              // the counting pass reads the stored N plane of `planes` (every site) instead of iplanes:
                                               // nn = L - c_i - c_j + NN comes from it alone and the pair kernels write d only

@@ -100,17 +100,21 @@ int general_sparse_fixup(tracs_alignment *a, size_t row_begin, size_t row_end, s
 // adds the sites' contribution to dist (general_fixup_kernel<MINOR>).  Built from what classify_sites_kernel left behind:
 struct MinorBuild {
     const uint4 *planes;                     // the five general planes
-    const uint4 *minor_mask, *ref_x, *ref_y; // per group: minority sites, reference base bits
-    const unsigned *off_minor;               // per group: minority sites before it (a site's list index = its rank)
+    const uint4 *minor_mask, *nnl_mask, *lst_mask;   // per group: minority sites, N co-occurrence list sites, their union
+    const uint4 *ref_x, *ref_y;              // per group: reference base bits
+    const unsigned *off_lst;                 // per group: sites with lists before it (a site's list index = its rank among them)
     const unsigned *cntP, *cntN;             // per site: listed samples, N samples
-    const unsigned long long *baseP, *baseN; // per group: list entries of the minority sites before it
+    const unsigned long long *baseP, *baseN; // per group: list entries (listed samples / N samples) of the sites before it
     const unsigned long long *flags;         // per group and 64 samples: listed somewhere in the group
     size_t flag_words;
-    size_t sites;                            // minority sites
+    size_t sites;                            // sites with lists
     unsigned long long tot_p, tot_n;         // list entries in all
 };
 int minority_lists_build(tracs_alignment *a, const MinorBuild &mb, hipStream_t stream, int *ok);
 void minority_lists_free(tracs_alignment *a);
 int minority_fixup(tracs_alignment *a, size_t row_begin, size_t row_end, size_t col_begin, unsigned *dist, size_t ld, hipStream_t stream);
+// ncomp[i][j] += NN over the sites whose N co-occurrences come from lists (+ lu - c_i - c_j when add_terms: nobody else adds them)
+int nn_rows_add(tracs_alignment *a, size_t row_begin, size_t row_end, size_t col_begin, unsigned *ncomp, size_t ld, int add_terms,
+                unsigned lu, hipStream_t stream);
 
 }  // namespace tracs

@@ -86,12 +86,16 @@ __device__ __forceinline__ void load_group_words(const uint4 *__restrict__ P, si
 //   pass 2  k (listed: not N and not exactly the reference base) and cN (N) per site over all samples, bit-sliced in
 //           registers, flushed through LDS every 255 samples per thread; partial-code flag; per (64 samples, group) the
 //           samples that are listed somewhere in the group.
-// Outputs per group: the four class masks, the reference base bits, k and cN of every site, the list sizes of its minority
-// sites (gP = sum k, gN = sum cN over them).
+// Outputs per group: the class masks, the reference base bits, k and cN of every site, the list sizes of its sites that
+// carry lists (gP = sum of k over the minority sites, gN = sum of cN over the minority and NNL sites).
+// Mask slots of a group (masks[slot * groups + g], one uint4 = 128 sites each):
+enum { M_DENSE = 0, M_COUNT, M_MINOR, M_FULL, M_NNL, M_LST, M_UN, M_REFX, M_REFY, M_SLOTS };
+//   M_COUNT  sites whose N co-occurrences go through the matrix cores (cN > nn_list_max, or lists not in use)
+//   M_NNL    sites whose N co-occurrences come from their N lists (2 <= cN <= nn_list_max: nn_rows_kernel, general_sparse.hip)
+//   M_LST    sites that carry lists at all (minority or NNL): list index = rank among these
+//   M_UN     every site outside the dense class with cN >= 1 (M_COUNT, M_NNL and the cN = 1 sites, which have no co-occurrence)
 __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__restrict__ P, size_t n_pad, unsigned n, unsigned budget,
-                                                             uint4 *__restrict__ dense_mask, uint4 *__restrict__ count_mask,
-                                                             uint4 *__restrict__ minor_mask, uint4 *__restrict__ full_mask,
-                                                             uint4 *__restrict__ ref_x, uint4 *__restrict__ ref_y,
+                                                             unsigned nn_list_max, uint4 *__restrict__ masks, size_t groups,
                                                              unsigned *__restrict__ cntP, unsigned *__restrict__ cntN,
                                                              unsigned *__restrict__ gP, unsigned *__restrict__ gN,
                                                              unsigned long long *__restrict__ flags, size_t flag_words,
@@ -209,20 +213,23 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
         const unsigned long long k = tot[0][tid], c = some ? tot[1][tid] : 0ull;      // (an empty site: every sample is N)
         const bool minor = some && k >= 1 && budget > 0 && k * (c + k) <= (unsigned long long)budget;
         const bool dense = some && k >= 1 && !minor;
-        const bool counted = some && !dense && c >= 1;
+        const bool un = some && !dense && c >= 1;
+        const bool nnl = un && c >= 2 && c <= (unsigned long long)nn_list_max;
+        const bool counted = un && c >= 2 && !nnl;          // (a site with one N sample has no pair of N samples)
         const bool full = some && !dense && c == 0;
-        const unsigned long long bd = __ballot(dense), bc = __ballot(counted), bm = __ballot(minor), bf = __ballot(full);
-        if (lane == 0) {
-            unsigned *pd = reinterpret_cast<unsigned *>(&dense_mask[g]), *pc = reinterpret_cast<unsigned *>(&count_mask[g]);
-            unsigned *pm = reinterpret_cast<unsigned *>(&minor_mask[g]), *pf = reinterpret_cast<unsigned *>(&full_mask[g]);
-            pd[2 * wave] = (unsigned)bd; pd[2 * wave + 1] = (unsigned)(bd >> 32);
-            pc[2 * wave] = (unsigned)bc; pc[2 * wave + 1] = (unsigned)(bc >> 32);
-            pm[2 * wave] = (unsigned)bm; pm[2 * wave + 1] = (unsigned)(bm >> 32);
-            pf[2 * wave] = (unsigned)bf; pf[2 * wave + 1] = (unsigned)(bf >> 32);
+        const bool lst = minor || nnl;
+        const bool cls[7] = {dense, counted, minor, full, nnl, lst, un};
+#pragma unroll
+        for (int m = 0; m < 7; m++) {
+            const unsigned long long bal = __ballot(cls[m]);
+            if (lane == 0) {
+                unsigned *pm = reinterpret_cast<unsigned *>(&masks[(size_t)m * groups + g]);
+                pm[2 * wave] = (unsigned)bal; pm[2 * wave + 1] = (unsigned)(bal >> 32);
+            }
         }
         cntP[g * SITES_PER_GROUP + tid] = (unsigned)k;
         cntN[g * SITES_PER_GROUP + tid] = (unsigned)c;
-        unsigned sp = minor ? (unsigned)k : 0u, sn = minor ? (unsigned)c : 0u;
+        unsigned sp = minor ? (unsigned)k : 0u, sn = lst ? (unsigned)c : 0u;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { sp += __shfl_xor(sp, off, 64); sn += __shfl_xor(sn, off, 64); }
         if (lane == 0) { wsum[wave][0] = sp; wsum[wave][1] = sn; }
@@ -230,14 +237,14 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
     __syncthreads();
     if (tid == 0) { gP[g] = wsum[0][0] + wsum[1][0]; gN[g] = wsum[0][1] + wsum[1][1]; }
     if (tid < 4) {
-        reinterpret_cast<unsigned *>(&ref_x[g])[tid] = refx[tid];
-        reinterpret_cast<unsigned *>(&ref_y[g])[tid] = refy[tid];
+        reinterpret_cast<unsigned *>(&masks[(size_t)M_REFX * groups + g])[tid] = refx[tid];
+        reinterpret_cast<unsigned *>(&masks[(size_t)M_REFY * groups + g])[tid] = refy[tid];
     }
 }
 
 // Exclusive prefix sums over the groups, one workgroup per array (1024 groups at a time):
-//   blocks 0..3  sizes of the dense / counted / minority / full classes (popcount of the mask) -> off32[b][g], totals[b]
-//   blocks 4, 5  list sizes gP / gN of the groups' minority sites                              -> off64[b - 4][g], totals[b]
+//   blocks 0..6  sizes of the mask slots M_DENSE .. M_UN (popcount of the mask) -> off32[b][g], totals[b]
+//   blocks 7, 8  list sizes gP / gN of the groups' sites                       -> off64[b - 7][g], totals[b]
 __global__ __launch_bounds__(1024) void group_offsets_kernel(const uint4 *__restrict__ masks, const unsigned *__restrict__ gcounts, size_t groups,
                                                              unsigned *__restrict__ off32, unsigned long long *__restrict__ off64,
                                                              unsigned long long *__restrict__ totals)
@@ -249,8 +256,8 @@ __global__ __launch_bounds__(1024) void group_offsets_kernel(const uint4 *__rest
         const size_t g = g0 + t;
         unsigned long long c = 0;
         if (g < groups) {
-            if (b < 4) { const uint4 a = masks[(size_t)b * groups + g]; c = __popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w); }
-            else c = gcounts[(size_t)(b - 4) * groups + g];
+            if (b < 7) { const uint4 a = masks[(size_t)b * groups + g]; c = __popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w); }
+            else c = gcounts[(size_t)(b - 7) * groups + g];
         }
         sv[t] = c;
         __syncthreads();
@@ -261,8 +268,8 @@ __global__ __launch_bounds__(1024) void group_offsets_kernel(const uint4 *__rest
             __syncthreads();
         }
         if (g < groups) {
-            if (b < 4) off32[(size_t)b * groups + g] = (unsigned)(base + sv[t] - c);
-            else off64[(size_t)(b - 4) * groups + g] = base + sv[t] - c;
+            if (b < 7) off32[(size_t)b * groups + g] = (unsigned)(base + sv[t] - c);
+            else off64[(size_t)(b - 7) * groups + g] = base + sv[t] - c;
         }
         base += sv[1023];
         __syncthreads();
@@ -386,6 +393,24 @@ __global__ __launch_bounds__(256) void plane_popcount_kernel(const uint4 *__rest
     if (c) atomicAdd(&out[s], c);
 }
 
+// per sample: its N sites among the sites of `mask` (the stored N plane, in place; lanes over samples, grid.y cuts the groups)
+__global__ __launch_bounds__(256) void plane_popcount_masked_kernel(const uint4 *__restrict__ Nplane, const uint4 *__restrict__ mask, size_t n_pad,
+                                                                    unsigned n, size_t groups, unsigned *__restrict__ out)
+{
+    const unsigned s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n) return;
+    const size_t per = (groups + gridDim.y - 1) / gridDim.y;
+    const size_t g0 = blockIdx.y * per, g1 = min(groups, g0 + per);
+    unsigned c = 0;
+    for (size_t g = g0; g < g1; g++) {
+        const uint4 m = mask[g];                               // wave-uniform
+        if ((m.x | m.y | m.z | m.w) == 0u) continue;
+        const uint4 v = Nplane[g * NPLANES * n_pad + s];
+        c += __popc(v.x & m.x) + __popc(v.y & m.y) + __popc(v.z & m.z) + __popc(v.w & m.w);
+    }
+    if (c) atomicAdd(&out[s], c);
+}
+
 void site_classes_free(tracs_alignment *a)
 {
     minority_lists_free(a);
@@ -393,7 +418,7 @@ void site_classes_free(tracs_alignment *a)
     a->vplanes = a->iplanes = nullptr;
     pack_release(a);                                       // vplanes, iplanes, N counts, minority lists: one arena
     a->L_var = a->L_inv = a->groups_var = a->groups_inv = 0;
-    a->L_minor = a->L_full = 0;
+    a->L_minor = a->L_full = a->L_un = a->L_nnl = 0;
     a->count_in_place = false;
     a->classes_cons = false;
     a->classes_state = 0;
@@ -447,7 +472,7 @@ void pack_stage_end()
 // Decides (once per pack) the encoding and whether the pair kernels run on site classes, and builds the re-packed alignments
 // and lists if so.  *partial: some sample carries a partial IUPAC code (the alignment has no consensus form).  Soft-fails
 // (classes_state = -1) when memory is short.
-static int decide(tracs_alignment *a, bool allow_minor, hipStream_t stream, int *partial)
+static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStream_t stream, int *partial)
 {
     a->classes_state = -1;
     static const int env_force = [] { const char *e = std::getenv("TRACS_SITE_CLASSES"); return e ? std::atoi(e) : -1; }();
@@ -464,56 +489,63 @@ static int decide(tracs_alignment *a, bool allow_minor, hipStream_t stream, int 
     unsigned *offs = nullptr, *cnts = nullptr, *gcnt = nullptr, *d_flag = nullptr;
     unsigned long long *off64 = nullptr, *totals = nullptr, *flags = nullptr;
     int rc;
-    if ((rc = workspace_get(52, 6 * groups * sizeof(uint4), reinterpret_cast<void **>(&masks)))) return rc;
-    if ((rc = workspace_get(53, 4 * groups * sizeof(unsigned), reinterpret_cast<void **>(&offs)))) return rc;
+    if ((rc = workspace_get(52, M_SLOTS * groups * sizeof(uint4), reinterpret_cast<void **>(&masks)))) return rc;
+    if ((rc = workspace_get(53, 7 * groups * sizeof(unsigned), reinterpret_cast<void **>(&offs)))) return rc;
     if ((rc = workspace_get(54, 2 * groups * SITES_PER_GROUP * sizeof(unsigned), reinterpret_cast<void **>(&cnts)))) return rc;
     if ((rc = workspace_get(55, 2 * groups * sizeof(unsigned), reinterpret_cast<void **>(&gcnt)))) return rc;
     if ((rc = workspace_get(56, 2 * (groups + 1) * sizeof(unsigned long long), reinterpret_cast<void **>(&off64)))) return rc;
-    if ((rc = workspace_get(57, 64, reinterpret_cast<void **>(&totals)))) return rc;
+    if ((rc = workspace_get(57, 128, reinterpret_cast<void **>(&totals)))) return rc;
     if ((rc = workspace_get(58, groups * flag_words * sizeof(unsigned long long), reinterpret_cast<void **>(&flags)))) return rc;
-    d_flag = reinterpret_cast<unsigned *>(totals + 7);
-    uint4 *dense_mask = masks, *count_mask = masks + groups, *minor_mask = masks + 2 * groups, *full_mask = masks + 3 * groups;
-    uint4 *ref_x = masks + 4 * groups, *ref_y = masks + 5 * groups;
-    unsigned *off_dense = offs, *off_count = offs + groups, *off_minor = offs + 2 * groups;
+    d_flag = reinterpret_cast<unsigned *>(totals + 15);
+    auto mask_of = [&](int slot) { return masks + (size_t)slot * groups; };
+    auto off_of = [&](int slot) { return offs + (size_t)slot * groups; };
     unsigned *cntP = cnts, *cntN = cnts + groups * SITES_PER_GROUP;
-    // a site goes to the lists while its k (cN + k) entries cost less than the extra operand planes over all pairs:
+    // a site goes to the minority lists while its k (cN + k) entries cost less than the extra operand planes over all pairs:
     // ~51 ns per site at 10 000 samples (pair kernel) against ~2-4 ps per list entry (general_fixup_kernel)
     const double bsites = (double)a->n * (double)a->n / 8000.0;
     const unsigned budget = (no_minor || !allow_minor) ? 0u : (unsigned)std::min(1.0e9, std::max(16.0, bsites));
-    TRACS_HIP_CHECK(hipMemsetAsync(totals, 0, 64, stream));
+    // the N co-occurrences of a site with cN N samples cost cN^2 list entries (nn_rows_kernel) against n^2 / 2 pairs on the matrix
+    // cores, whatever cN: lists up to cN = TRACS_NN_LIST_FRAC x n (default: measured crossover); TRACS_NN_LISTS=0: never
+    static const bool no_nnl = [] { const char *e = std::getenv("TRACS_NN_LISTS"); return e && std::atoi(e) == 0; }();
+    static const double nnl_frac = [] { const char *e = std::getenv("TRACS_NN_LIST_FRAC"); return e ? std::atof(e) : 0.02; }();
+    const unsigned nn_list_max = (no_nnl || !allow_nnl) ? 0u : (unsigned)std::min(1.0e6, std::max(2.0, nnl_frac * (double)a->n));
+    TRACS_HIP_CHECK(hipMemsetAsync(totals, 0, 128, stream));
     hipLaunchKernelGGL(classify_sites_kernel, dim3((unsigned)groups), dim3(256), 0, stream, a->planes, a->n_pad, (unsigned)a->n, budget,
-                       dense_mask, count_mask, minor_mask, full_mask, ref_x, ref_y, cntP, cntN, gcnt, gcnt + groups, flags, flag_words, d_flag);
+                       nn_list_max, masks, groups, cntP, cntN, gcnt, gcnt + groups, flags, flag_words, d_flag);
     stage_mark("classify", stream);
-    hipLaunchKernelGGL(group_offsets_kernel, dim3(6), dim3(1024), 0, stream, masks, gcnt, groups, offs, off64, totals);
-    unsigned long long tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    TRACS_HIP_CHECK(hipMemcpyAsync(tot, totals, 64, hipMemcpyDeviceToHost, stream));
+    hipLaunchKernelGGL(group_offsets_kernel, dim3(9), dim3(1024), 0, stream, masks, gcnt, groups, offs, off64, totals);
+    unsigned long long tot[16] = {0};
+    TRACS_HIP_CHECK(hipMemcpyAsync(tot, totals, 128, hipMemcpyDeviceToHost, stream));
     TRACS_HIP_CHECK(hipStreamSynchronize(stream));
     stage_mark("class sizes", stream);
-    *partial = (int)(reinterpret_cast<const unsigned *>(&tot[7])[0] & 1u);
+    *partial = (int)(reinterpret_cast<const unsigned *>(&tot[15])[0] & 1u);
     const bool consensus = !*partial && !force_general;
-    const size_t L_dense = (size_t)tot[0], L_count = (size_t)tot[1], L_minor = (size_t)tot[2], L_full = (size_t)tot[3];
-    const unsigned long long tot_p = tot[4], tot_n = tot[5];
+    const size_t L_dense = (size_t)tot[M_DENSE], L_count = (size_t)tot[M_COUNT], L_minor = (size_t)tot[M_MINOR], L_full = (size_t)tot[M_FULL];
+    const size_t L_nnl = (size_t)tot[M_NNL], L_lst = (size_t)tot[M_LST], L_un = (size_t)tot[M_UN];
+    const unsigned long long tot_p = tot[7], tot_n = tot[8];
     if (force == 0 || a->L == 0 || a->n < 2) return TRACS_OK;
     // matrix instructions per pair: planes_full per site now; planes_full per dense site + one per counted site with classes
     const double planes_full = consensus ? 4.0 : 5.0;
     const double cost = (planes_full * (double)L_dense + (double)L_count) / (planes_full * (double)a->L);
     if (force != 1 && cost >= 0.92) return TRACS_OK;
     // the lists must stay small beside the planes (<= one entry per 8 sites of the whole alignment; TRACS_LIST_CAP: diagnostics):
-    // otherwise the same classes without them (the minority sites stay dense)
-    if (L_minor) {
+    // otherwise first without the N co-occurrence lists (those sites are counted on the matrix cores), then without any list
+    // (the minority sites stay dense)
+    if (L_lst) {
         static const double env_cap = [] { const char *e = std::getenv("TRACS_LIST_CAP"); return e ? std::atof(e) : -1.0; }();
         const double cap = (double)a->n * (double)a->L / 8.0;
         const double entries = 2.0 * (double)tot_n + 2.0 * (double)tot_p;        // per-site and per-sample lists
-        if (L_minor >= (1ull << 27) || a->n >= (1ull << 27) || entries > (env_cap >= 0.0 ? std::min(env_cap, cap) : cap))
-            return decide(a, false, stream, partial);
+        if (L_lst >= (1ull << 27) || a->n >= (1ull << 27) || entries > (env_cap >= 0.0 ? std::min(env_cap, cap) : cap))
+            return L_nnl ? decide(a, allow_minor, false, stream, partial) : decide(a, false, false, stream, partial);
     }
 
     auto soft_fail = [&]() { (void)hipGetLastError(); site_classes_free(a); a->classes_state = -1; return TRACS_OK; };
     const int npv = consensus ? 3 : NPLANES;
-    // the counting pass reads the stored N plane in place when (nearly) every site needs counting anyway
-    // (TRACS_COUNT_IN_PLACE=0|1 forces the choice: diagnostics)
+    // The counting pass reads the stored N plane in place when (nearly) every site needs the matrix cores anyway -- then it covers
+    // every site and nothing may come from lists (TRACS_COUNT_IN_PLACE=0|1 forces the choice when there are no NNL sites: diagnostics)
     static const int force_in_place = [] { const char *e = std::getenv("TRACS_COUNT_IN_PLACE"); return e ? std::atoi(e) : -1; }();
-    const bool in_place = force_in_place >= 0 ? force_in_place == 1 : (double)(a->L - L_count) <= 0.02 * (double)a->L;
+    const bool in_place = L_nnl == 0 && L_count > 0 &&
+                          (force_in_place >= 0 ? force_in_place == 1 : (double)(a->L - L_count) <= 0.02 * (double)a->L);
     const size_t gv = groups_for(L_dense), gi = in_place ? 0 : groups_for(L_count);
     const size_t vbytes = class_plane_bytes(a, gv, npv, PAD_GROUPS), ibytes = class_plane_bytes(a, gi, 1, PAD_GROUPS);
     unsigned *lists = nullptr;
@@ -527,7 +559,7 @@ static int decide(tracs_alignment *a, bool allow_minor, hipStream_t stream, int 
               hipMemsetAsync(a->c_counted, 0, a->n_pad * sizeof(unsigned), stream) == hipSuccess;
     const dim3 lgrid((unsigned)((groups + 255) / 256));
     if (gv) {
-        hipLaunchKernelGGL(class_list_kernel, lgrid, dim3(256), 0, stream, dense_mask, off_dense, groups, list_dense);
+        hipLaunchKernelGGL(class_list_kernel, lgrid, dim3(256), 0, stream, mask_of(M_DENSE), off_of(M_DENSE), groups, list_dense);
         const dim3 grid((unsigned)((gv + 3) / 4), sblocks);
         if (consensus)
             hipLaunchKernelGGL((compact_sites_kernel<1>), grid, dim3(256), 0, stream, a->planes, list_dense, (unsigned)L_dense, a->vplanes,
@@ -538,38 +570,40 @@ static int decide(tracs_alignment *a, bool allow_minor, hipStream_t stream, int 
     }
     stage_mark("re-pack dense sites", stream);
     if (gi) {
-        hipLaunchKernelGGL(class_list_kernel, lgrid, dim3(256), 0, stream, count_mask, off_count, groups, list_count);
+        hipLaunchKernelGGL(class_list_kernel, lgrid, dim3(256), 0, stream, mask_of(M_COUNT), off_of(M_COUNT), groups, list_count);
         const dim3 grid((unsigned)((gi + 3) / 4), sblocks);
         hipLaunchKernelGGL((compact_sites_kernel<2>), grid, dim3(256), 0, stream, a->planes, list_count, (unsigned)L_count, a->iplanes,
                            a->n_pad, (unsigned)a->n, (unsigned)gi);
-        hipLaunchKernelGGL(plane_popcount_kernel, dim3((unsigned)((a->n + 255) / 256), 128), dim3(256), 0, stream, a->iplanes, a->n_pad,
-                           (unsigned)a->n, gi, 1, a->c_counted);
-    } else if (L_count) {
-        // per sample: all its N sites (in place the counting pass covers every site of the alignment)
+    }
+    // per sample: its N sites among the sites the compared-sites formula stands for: every site (in place), or every site
+    // outside the dense class (re-packed counting pass and / or lists: nn = |U| - c_i - c_j + NN over U)
+    if (in_place)
         hipLaunchKernelGGL(plane_popcount_kernel, dim3((unsigned)((a->n + 255) / 256), 128), dim3(256), 0, stream, a->planes + 4 * a->n_pad,
                            a->n_pad, (unsigned)a->n, groups, NPLANES, a->c_counted);
-    }
+    else if (L_un)
+        hipLaunchKernelGGL(plane_popcount_masked_kernel, dim3((unsigned)((a->n + 255) / 256), 128), dim3(256), 0, stream,
+                           a->planes + 4 * a->n_pad, mask_of(M_UN), a->n_pad, (unsigned)a->n, groups, a->c_counted);
     stage_mark(gi ? "re-pack counted sites" : "N counts per sample", stream);
-    if (L_minor) {
-        // the lists of the minority sites (general_sparse.hip): per-site lists from the N plane and the flagged samples,
-        // per-sample lists from the N plane
+    if (L_lst) {
+        // the lists (general_sparse.hip): per-site lists from the N plane and the flagged samples, per-sample lists from the N plane
         int built = 0;
         MinorBuild mb;
-        mb.planes = a->planes; mb.minor_mask = minor_mask; mb.ref_x = ref_x; mb.ref_y = ref_y; mb.off_minor = off_minor;
+        mb.planes = a->planes; mb.minor_mask = mask_of(M_MINOR); mb.nnl_mask = mask_of(M_NNL); mb.lst_mask = mask_of(M_LST);
+        mb.ref_x = mask_of(M_REFX); mb.ref_y = mask_of(M_REFY); mb.off_lst = off_of(M_LST);
         mb.cntP = cntP; mb.cntN = cntN; mb.baseP = off64; mb.baseN = off64 + groups; mb.flags = flags; mb.flag_words = flag_words;
-        mb.sites = L_minor; mb.tot_p = tot_p; mb.tot_n = tot_n;
+        mb.sites = L_lst; mb.tot_p = tot_p; mb.tot_n = tot_n;
         rc = minority_lists_build(a, mb, stream, &built);
         if (rc) { site_classes_free(a); a->classes_state = -1; return rc; }
-        if (!built) {                                          // no memory: the same classes without them
+        if (!built) {                                          // no memory: the same classes with fewer lists
             soft_fail();
-            return decide(a, false, stream, partial);
+            return L_nnl ? decide(a, allow_minor, false, stream, partial) : decide(a, false, false, stream, partial);
         }
     }
     ok = ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(stream) == hipSuccess;
     if (!ok) { site_classes_free(a); a->classes_state = -1; set_error("site_classes_decide: re-pack failed"); return TRACS_E_HIP; }
     a->L_var = L_dense; a->L_inv = L_count; a->groups_var = gv; a->groups_inv = gi;
-    a->L_minor = L_minor; a->L_full = L_full;
-    a->count_in_place = in_place && L_count > 0;
+    a->L_minor = L_minor; a->L_full = L_full; a->L_un = L_un; a->L_nnl = L_nnl;
+    a->count_in_place = in_place;
     a->classes_cons = consensus;
     a->classes_state = 1;
     return TRACS_OK;
@@ -579,7 +613,7 @@ int site_classes_decide(tracs_alignment *a, hipStream_t stream, int *partial)
 {
     *partial = -1;
     if (a->classes_state != 0) return TRACS_OK;
-    return decide(a, true, stream, partial);
+    return decide(a, true, true, stream, partial);
 }
 
 }  // namespace tracs
