@@ -97,10 +97,10 @@ def synth_kw(p_partial=0.0, workload="sparse"):
 
 
 def pair_split_ms(lib):
-    """(pair kernel, sparse partial-code correction, invariant-site counting pass) of the LAST dense call, from HIP events the
-    library records on the launch stream (tracs_debug_pair_timing)."""
+    """(pair kernel, sparse partial-code correction + minority lists, counting pass on the matrix cores, N co-occurrence lists) of
+    the LAST dense call, from HIP events the library records on the launch stream (tracs_debug_pair_timing)."""
     import ctypes as C
-    out = (C.c_float * 3)()
+    out = (C.c_float * 4)()
     return [float(x) for x in out] if lib.tracs_debug_last_pair_ms(out) == 0 else None
 
 
@@ -349,7 +349,7 @@ def main():
             # site classes (csrc/site_classes.hip): pair kernel over the dense sites, lists for the minority sites, one-operand
             # counting pass over the counted sites.  `roofline` = whichever matrix-core kernel takes longer; the other beside it.
             dense, counted, minority, full = classes
-            count_sites, in_place = aln.count_source or (counted, False)
+            count_sites, in_place, nn_listed = aln.count_source or (counted, False, 0)
             main = roofline_of(aln.kernel, enc, last_pairs, dense, max(split[0], 1e-3) / 1e3, None, n)
             cnt = count_roofline(last_pairs, count_sites, max(split[2], 1e-3) / 1e3, n, in_place)
             cnt["traffic"] = traffic                          # the "+classes" entry of the PMC summary is the counting pass's
@@ -490,7 +490,7 @@ def general_pass(args, n, L, seed, dev, synth, torch, device):
     split, classes, pairs = pair_split_ms(_lib.load()), aln.site_classes, n * (n - 1) // 2
     traffic = _traffic_from_profiles(n, L, 1, aln.kernel + ("+classes" if classes else ""))
     if classes and split:
-        count_sites, in_place = aln.count_source or (classes[1], False)
+        count_sites, in_place, nn_listed = aln.count_source or (classes[1], False, 0)
         main = roofline_of(aln.kernel, "general", pairs, classes[0], max(split[0], 1e-3) / 1e3, None, n)
         cnt = count_roofline(pairs, count_sites, max(split[2], 1e-3) / 1e3, n, in_place)
         r, other = (cnt, main) if split[2] > split[0] else (main, cnt)

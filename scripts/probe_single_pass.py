@@ -42,6 +42,12 @@ def one_pass(tag):
     dev.trans_dist_dense_ranges(dm, n, days, 29.903, 73.0, 0.01, pm, em, [(0, n)], exp_p0=True)
     torch.cuda.synchronize()
     print("%s: repeat pass %.1f ms" % (tag, (time.perf_counter() - t0) * 1e3), flush=True)
+    import ctypes as C
+    out = (C.c_float * 4)()
+    lib = _lib.load(); lib.tracs_debug_pair_timing(1)
+    dev.pairsnp_dense(aln, dm, nm); torch.cuda.synchronize()
+    if lib.tracs_debug_last_pair_ms(out) == 0:
+        print("   kernels: pair %.2f  fixup %.2f  count %.2f  nn lists %.2f ms   checksum nn %d" % (out[0], out[1], out[2], out[3], int(nm.sum().item())), flush=True)
     aln.close()
 
 

@@ -66,6 +66,12 @@ VARIANTS = [
     ({"TRACS_COUNT_TILE": "4x2", "TRACS_MINORITY": "0"}, {("consensus", "mfma"), ("general", "mfma-general")}),
     # lists refused (cap of 10 entries): consensus alignments keep their classes without minority lists, general ones the VALU kernel
     ({"TRACS_LIST_CAP": "10"}, {("consensus", "mfma"), ("general", "valu")}),
+    # N co-occurrences from lists (nn_rows_kernel) for every site that has two N samples, whatever the cost model says at this size;
+    # never; with the threshold at a few N samples (both sources at once)
+    ({"TRACS_NN_LIST_K": "1"}, {("consensus", "mfma"), ("general", "mfma-general")}),
+    ({"TRACS_NN_LIST_K": "1", "TRACS_MINORITY": "0"}, {("consensus", "mfma"), ("general", "mfma-general")}),
+    ({"TRACS_NN_LIST_K": "1e-4", "TRACS_KSPLIT": "2"}, {("consensus", "mfma"), ("general", "mfma-general")}),
+    ({"TRACS_NN_LISTS": "0"}, {("consensus", "mfma"), ("general", "mfma-general")}),
     # the counting pass's source: the stored N plane in place (every site) / the counted sites' N plane re-packed
     ({"TRACS_COUNT_IN_PLACE": "1"}, {("consensus", "mfma"), ("general", "mfma-general")}),
     ({"TRACS_COUNT_IN_PLACE": "1", "TRACS_KSPLIT": "3"}, {("consensus", "mfma"), ("general", "mfma-general")}),

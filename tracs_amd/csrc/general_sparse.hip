@@ -32,7 +32,10 @@ struct GeneralSparse {
     unsigned *s_ent = nullptr, *p_ent = nullptr, *n_ent = nullptr;
     unsigned *c_n = nullptr, *c_p = nullptr;      // per sample: its N sites, the sum of w over its listed (partial) sites
     double est_updates = 0.0;
+    unsigned long long tot_s = 0;                 // entries of the per-sample lists
+    unsigned long long max_row = 0;               // the longest per-sample list
     bool in_arena = false;                        // the arrays live in the alignment's pack arena (released with it, not one by one)
+    bool n16 = false;                             // n_ent holds 16-bit sample numbers (site-class lists of alignments below 65 536 samples)
 };
 constexpr int ENT_SHIFT = 5;                      // entries: index << 5 | w << 4 | 4-bit code
 
@@ -223,10 +226,10 @@ __global__ __launch_bounds__(256) void gs_site_kernel(const SRC src, size_t n, s
 //          + sum over S_i n S_j of ([M_i n M_j = {}] - w_i - w_j)
 // (consensus alignments: M = {own base}, w = 1).  The first two sums are per-sample constants (c_p); negative terms wrap in the
 // unsigned row and cancel in the final sum.  ncomp is not touched (the counting pass covers these sites).
-template <bool MINOR>
+template <bool MINOR, class NT>
 __global__ __launch_bounds__(1024) void general_fixup_kernel(const unsigned long long *__restrict__ s_off, const unsigned *__restrict__ s_ent,
                                                              const unsigned long long *__restrict__ p_off, const unsigned *__restrict__ p_ent,
-                                                             const unsigned long long *__restrict__ n_off, const unsigned *__restrict__ n_ent,
+                                                             const unsigned long long *__restrict__ n_off, const NT *__restrict__ n_ent,
                                                              const unsigned *__restrict__ c_n, const unsigned *__restrict__ c_p, unsigned L, unsigned n, unsigned row_begin,
                                                              unsigned col_begin, unsigned chunk, unsigned *__restrict__ dist,
                                                              unsigned *__restrict__ ncomp, size_t ld)
@@ -245,17 +248,19 @@ __global__ __launch_bounds__(1024) void general_fixup_kernel(const unsigned long
         const unsigned long long e = base + l16;
         unsigned my_code = 0;
         unsigned long long my_pa = 0, my_pz = 0, my_na = 0, my_nz = 0;
-        if (e < e1) {
+        bool live = e < e1;
+        if (live && MINOR && (s_ent[e] & 15u) == 0u) live = false;     // an N entry at a site without listed samples (nn_rows_kernel's)
+        if (live) {
             const unsigned ent = s_ent[e];
             const unsigned site = ent >> ENT_SHIFT;
-            my_code = ent & 31u;                            // w << 4 | code
+            my_code = ent & 31u;                            // w << 4 | code (an N entry, code 15: bit 4 = NNL site, not a w)
             my_pa = p_off[site]; my_pz = p_off[site + 1];
             // the N list of the site is only walked when i is listed there -- and, on the minority lists, adds something (w_i = 1)
             if ((my_code & 15u) != 15u && (!MINOR || (my_code & 16u))) { my_na = n_off[site]; my_nz = n_off[site + 1]; }
         }
         // Short lists stay in their lane: where i is N and at most four samples are partial there (the usual case on the minority
         // lists: one or two), the lane applies its site's entries itself -- one round trip for the 16 sites together.
-        bool coop = e < e1;
+        bool coop = live;
         if (coop && (my_code & 15u) == 15u && my_pz - my_pa <= 4) {
             unsigned v[4];
 #pragma unroll
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(1024) void general_fixup_kernel(const unsigned long
 #pragma unroll
             for (int m = 0; m < 4; m++) {
                 h.p[m] = pa + 16 * m < pz ? p_ent[pa + 16 * m] : 0xFFFFFFFFu;
-                h.n[m] = ((code & 15u) != 15u && na + 16 * m < nz) ? n_ent[na + 16 * m] : 0xFFFFFFFFu;
+                h.n[m] = ((code & 15u) != 15u && na + 16 * m < nz) ? (unsigned)n_ent[na + 16 * m] : 0xFFFFFFFFu;
             }
         };
         Head cur, nxt;
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(1024) void general_fixup_kernel(const unsigned long
                 if (add != 0 && (MINOR || add > 0) && j > i && j >= c0 && j < c1) atomicAdd(&row[j - c0], (unsigned)add);
             };
             auto apply_n = [&](unsigned j) {                          // an N j, i partial here: |M_i| - 1  (MINOR: -w_i)
-                if (kk != 0u && j > i && j >= c0 && j < c1) atomicAdd(&row[j - c0], kk);
+                if (kk != 0u && j > i && j >= c0 && j < c1) atomicAdd(&row[j - c0], kk);      // (0xFFFFFFFF: no entry)
             };
 #pragma unroll
             for (int m = 0; m < 4; m++) {
@@ -444,14 +449,19 @@ int general_sparse_get(tracs_alignment *a, hipStream_t stream, int *ok, double *
     return TRACS_OK;
 }
 
-// ---- the lists of the MINORITY sites of an alignment cut into site classes (site_classes.hip) ---------------------------
-// At such a site every sample is N, or carries exactly the site's reference base (not listed), or is LISTED with its allele
+// ---- the lists of an alignment cut into site classes (site_classes.hip) ------------------------------------------------
+// Two kinds of site carry lists, under one rank space (off_lst[g] = sites with lists before group g):
+//   MINORITY sites  their listed samples (p lists) and their N samples (n lists): general_fixup_kernel<MINOR> adds their distances;
+//   NNL sites       (2 <= cN <= a bound) only their N samples: nn_rows_kernel adds their N co-occurrences NN = sum n_i n_j to the
+//                   compared-sites counts -- cN^2 list entries per site instead of n^2 / 2 pairs on the matrix cores.
+// A sample's list holds its N entries at every site with lists (code 15; bit 4 = the site is an NNL site) and its listed entries.
+// At a minority site every sample is N, or carries exactly the site's reference base (not listed), or is LISTED with its allele
 // mask M and w = [reference base not in M] -- what the sample adds to its distance to every sample that carries the reference
 // base.  classify_sites_kernel has already counted the listed and the N samples of every site, summed them per group
 // (prefix sums: baseP / baseN) and flagged, per group, the samples that are listed somewhere in it; so the lists are built
 // from ONE plane: per-site lists = the N plane masked with the minority sites (+ the five planes of the flagged samples
 // only: ~1 % of them on a real alignment), per-sample lists = the N plane again (count, fill) + the listed entries the
-// per-site pass recorded.  Sites are listed under their rank among the minority sites (off_minor[g] = ranks before group g).
+// per-site pass recorded.
 __device__ __forceinline__ unsigned minor_rank(const uint4 &m, unsigned off_g, int w, int b)
 {
     unsigned r = off_g;
@@ -463,22 +473,25 @@ __device__ __forceinline__ unsigned minor_rank(const uint4 &m, unsigned off_g, i
 
 // one workgroup per 128-site group, threads over samples: p_off / n_off of the group's minority sites, their N samples, and
 // the listed samples (with code = w << 4 | allele mask); E[k] = (sample, rank << 5 | code) for the per-sample lists
+template <class NT>
 __global__ __launch_bounds__(256) void minor_site_lists_kernel(const MinorBuild mb, size_t n_pad, unsigned n,
                                                                unsigned long long *__restrict__ p_off, unsigned long long *__restrict__ n_off,
-                                                               unsigned *__restrict__ p_ent, unsigned *__restrict__ n_ent, uint2 *__restrict__ E)
+                                                               unsigned *__restrict__ p_ent, NT *__restrict__ n_ent, uint2 *__restrict__ E)
 {
     __shared__ unsigned kp[SITES_PER_GROUP], kn[SITES_PER_GROUP], curP[SITES_PER_GROUP], curN[SITES_PER_GROUP], rk[SITES_PER_GROUP];
     __shared__ unsigned long long bP[SITES_PER_GROUP], bN[SITES_PER_GROUP];
     const size_t g = blockIdx.x;
     const int tid = threadIdx.x;
     if (g == 0 && tid == 0) { p_off[mb.sites] = mb.tot_p; n_off[mb.sites] = mb.tot_n; }
-    const uint4 m4 = mb.minor_mask[g];
+    const uint4 m4 = mb.lst_mask[g], q4 = mb.minor_mask[g];
     if ((m4.x | m4.y | m4.z | m4.w) == 0u) return;
-    const unsigned m[4] = {m4.x, m4.y, m4.z, m4.w};
+    const unsigned m[4] = {m4.x, m4.y, m4.z, m4.w};          // sites with lists (N entries)
+    const unsigned mp[4] = {q4.x, q4.y, q4.z, q4.w};         // minority sites among them (listed entries)
+    const bool any_minor = (q4.x | q4.y | q4.z | q4.w) != 0u;
     const int tw = (tid & 127) >> 5, tb = tid & 31;
     const bool mine = tid < SITES_PER_GROUP && ((m[tw] >> tb) & 1u);
     if (tid < SITES_PER_GROUP) {
-        kp[tid] = mine ? mb.cntP[g * SITES_PER_GROUP + tid] : 0u;
+        kp[tid] = (mine && ((mp[tw] >> tb) & 1u)) ? mb.cntP[g * SITES_PER_GROUP + tid] : 0u;
         kn[tid] = mine ? mb.cntN[g * SITES_PER_GROUP + tid] : 0u;
         curP[tid] = 0; curN[tid] = 0;
     }
@@ -486,7 +499,7 @@ __global__ __launch_bounds__(256) void minor_site_lists_kernel(const MinorBuild 
     if (mine) {
         unsigned long long pp = 0, pn = 0;
         for (int t = 0; t < tid; t++) { pp += kp[t]; pn += kn[t]; }
-        const unsigned rank = minor_rank(m4, mb.off_minor[g], tw, tb);
+        const unsigned rank = minor_rank(m4, mb.off_lst[g], tw, tb);
         bP[tid] = mb.baseP[g] + pp; bN[tid] = mb.baseN[g] + pn; rk[tid] = rank;
         p_off[rank] = bP[tid]; n_off[rank] = bN[tid];
     }
@@ -495,7 +508,7 @@ __global__ __launch_bounds__(256) void minor_site_lists_kernel(const MinorBuild 
     const uint4 *base = mb.planes + (g * NPLANES) * n_pad;
     for (unsigned s = tid; s < n; s += 256) {
         const uint4 N = base[4 * n_pad + s];
-        const bool flagged = (mb.flags[g * mb.flag_words + (s >> 6)] >> (s & 63u)) & 1ull;
+        const bool flagged = any_minor && ((mb.flags[g * mb.flag_words + (s >> 6)] >> (s & 63u)) & 1ull);
 #pragma unroll
         for (int w = 0; w < 4; w++) {
             unsigned nm = word_of(N, w) & m[w];
@@ -503,7 +516,7 @@ __global__ __launch_bounds__(256) void minor_site_lists_kernel(const MinorBuild 
                 const int b = __ffs(nm) - 1;
                 nm &= nm - 1;
                 const unsigned slot = atomicAdd(&curN[w * 32 + b], 1u);
-                n_ent[bN[w * 32 + b] + slot] = s;
+                n_ent[bN[w * 32 + b] + slot] = (NT)s;
             }
         }
         if (!flagged) continue;
@@ -515,7 +528,7 @@ __global__ __launch_bounds__(256) void minor_site_lists_kernel(const MinorBuild 
             const unsigned ra = ~rx & ~ry, rc = rx & ~ry, rg = ~rx & ry, rt = rx & ry;
             const unsigned has_ref = (a & ra) | (c & rc) | (gg & rg) | (t & rt);
             const unsigned only_ref = ~((a ^ ra) | (c ^ rc) | (gg ^ rg) | (t ^ rt));
-            unsigned pm = ~isn & ~only_ref & m[w];
+            unsigned pm = ~isn & ~only_ref & mp[w];
             while (pm) {
                 const int b = __ffs(pm) - 1;
                 pm &= pm - 1;
@@ -531,7 +544,10 @@ __global__ __launch_bounds__(256) void minor_site_lists_kernel(const MinorBuild 
 }
 
 // per-sample lists, N entries: thread = (sample, chunk of groups), lanes over samples.  FILL = false: cnt[s * NCH + chunk] =
-// the sample's N sites among the chunk's minority sites; FILL = true: entries rank << 5 | 15 from off[s * NCH + chunk] on.
+// the sample's N sites among the chunk's sites with lists; FILL = true: entries from off[s * NCH + chunk] on:
+//     rank << 5 | 15        N at a minority site                                (general_fixup_kernel<MINOR>)
+//     rank << 5 | 16 | 15   N at a minority site that is an NNL site as well    (both kernels)
+//     rank << 5 | 16 | 0    N at an NNL site without listed samples             (nn_rows_kernel only: the fixup kernel skips code 0)
 static constexpr int MS_NCH = GS_CHUNKS + 1;      // the last "chunk" of a sample's list holds its listed entries
 template <bool FILL>
 __global__ __launch_bounds__(256) void minor_sample_kernel(const MinorBuild mb, size_t n_pad, size_t n, size_t groups, size_t gpc,
@@ -546,18 +562,20 @@ __global__ __launch_bounds__(256) void minor_sample_kernel(const MinorBuild mb, 
     unsigned c = 0;
     unsigned long long o = FILL ? off[s * MS_NCH + chunk] : 0ull;
     for (size_t g = g0; g < g1; g++) {
-        const uint4 m4 = mb.minor_mask[g];                    // wave-uniform
+        const uint4 m4 = mb.lst_mask[g];                      // wave-uniform
         if ((m4.x | m4.y | m4.z | m4.w) == 0u) continue;
         const uint4 N = nplane[g * NPLANES * n_pad];
         if (!FILL) { c += __popc(N.x & m4.x) + __popc(N.y & m4.y) + __popc(N.z & m4.z) + __popc(N.w & m4.w); continue; }
-        const unsigned og = mb.off_minor[g];
+        const unsigned og = mb.off_lst[g];
+        const uint4 l4 = mb.nnl_mask[g], q4 = mb.minor_mask[g];
 #pragma unroll
         for (int w = 0; w < 4; w++) {
             unsigned nm = word_of(N, w) & word_of(m4, w);
             while (nm) {
                 const int b = __ffs(nm) - 1;
                 nm &= nm - 1;
-                ent[o++] = (minor_rank(m4, og, w, b) << ENT_SHIFT) | 15u;
+                ent[o++] = (minor_rank(m4, og, w, b) << ENT_SHIFT) | (((word_of(l4, w) >> b) & 1u) << 4) |
+                           (((word_of(q4, w) >> b) & 1u) ? 15u : 0u);
             }
         }
     }
@@ -581,10 +599,12 @@ __global__ __launch_bounds__(256) void minor_listed_kernel(const uint2 *__restri
     }
 }
 
-__global__ void minor_sample_offsets_kernel(const unsigned long long *__restrict__ off, size_t n, unsigned long long *__restrict__ s_off)
+__global__ void minor_sample_offsets_kernel(const unsigned long long *__restrict__ off, size_t n, unsigned long long *__restrict__ s_off,
+                                            unsigned long long *__restrict__ max_row)
 {
     const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s <= n) s_off[s] = off[s * MS_NCH];               // off has n * NCH + 1 entries
+    if (s < n) atomicMax(max_row, off[(s + 1) * MS_NCH] - off[s * MS_NCH]);
 }
 
 int minority_lists_build(tracs_alignment *a, const MinorBuild &mb, hipStream_t stream, int *ok)
@@ -607,9 +627,10 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb, hipStream_t s
     GS_TRY(pack_alloc(a, std::max<size_t>(n, 1) * 4, reinterpret_cast<void **>(&g->c_p)));
     GS_TRY(pack_alloc(a, std::max<size_t>(tot_s, 1) * 4, reinterpret_cast<void **>(&g->s_ent)));
     GS_TRY(pack_alloc(a, std::max<size_t>(mb.tot_p, 1) * 4, reinterpret_cast<void **>(&g->p_ent)));
-    GS_TRY(pack_alloc(a, std::max<size_t>(mb.tot_n, 1) * 4, reinterpret_cast<void **>(&g->n_ent)));
+    g->n16 = a->n_pad <= 65536;                            // sample numbers fit 16 bits: half the bytes of every list walk
+    GS_TRY(pack_alloc(a, std::max<size_t>(mb.tot_n, 1) * (g->n16 ? 2 : 4), reinterpret_cast<void **>(&g->n_ent)));
     if (trace) std::fprintf(stderr, "[once per pack] host: list storage %.2f GB (%zu of 7 arrays outside the arena) %.2f ms\n",
-                            (double)(tot_s + mb.tot_p + mb.tot_n) * 4e-9, a->pack_extra.size() - before,
+                            ((double)(tot_s + mb.tot_p) * 4 + (double)mb.tot_n * (g->n16 ? 2 : 4)) * 1e-9, a->pack_extra.size() - before,
                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count());
     unsigned *cnt = nullptr, *cur = nullptr;
     unsigned long long *off = nullptr;
@@ -618,12 +639,16 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb, hipStream_t s
     int rc;
     if ((rc = workspace_get(60, nsc * 4, reinterpret_cast<void **>(&cnt))) || (rc = workspace_get(61, (nsc + 1) * 8, reinterpret_cast<void **>(&off))) ||
         (rc = workspace_get(62, std::max<size_t>(mb.tot_p, 1) * sizeof(uint2), reinterpret_cast<void **>(&E))) ||
-        (rc = workspace_get(63, std::max<size_t>(n, 1) * 4, reinterpret_cast<void **>(&cur)))) { gs_free(g); return rc; }
+        (rc = workspace_get(63, (std::max<size_t>(n, 1) + 8) * 4, reinterpret_cast<void **>(&cur)))) { gs_free(g); return rc; }
     GS_TRY(hipMemsetAsync(cnt, 0, nsc * 4, stream));
     GS_TRY(hipMemsetAsync(cur, 0, std::max<size_t>(n, 1) * 4, stream));
     GS_TRY(hipMemsetAsync(g->c_p, 0, std::max<size_t>(n, 1) * 4, stream));
-    hipLaunchKernelGGL(minor_site_lists_kernel, dim3((unsigned)groups), dim3(256), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off, g->n_off,
-                       g->p_ent, g->n_ent, E);
+    if (g->n16)
+        hipLaunchKernelGGL(minor_site_lists_kernel<unsigned short>, dim3((unsigned)groups), dim3(256), 0, stream, mb, a->n_pad, (unsigned)n,
+                           g->p_off, g->n_off, g->p_ent, reinterpret_cast<unsigned short *>(g->n_ent), E);
+    else
+        hipLaunchKernelGGL(minor_site_lists_kernel<unsigned>, dim3((unsigned)groups), dim3(256), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off,
+                           g->n_off, g->p_ent, g->n_ent, E);
     pack_stage_mark("minority lists: per site", stream);
     const size_t gpc = (groups + GS_CHUNKS - 1) / GS_CHUNKS;
     const dim3 sgrid((unsigned)((n + 63) / 64), GS_CHUNKS / 4);
@@ -631,14 +656,125 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb, hipStream_t s
     hipLaunchKernelGGL((minor_sample_kernel<false>), sgrid, dim3(256), 0, stream, mb, a->n_pad, n, groups, gpc, cnt, nullptr, nullptr);
     if (egrid) hipLaunchKernelGGL((minor_listed_kernel<false>), dim3(egrid), dim3(256), 0, stream, E, mb.tot_p, cnt, g->c_p, nullptr, nullptr, nullptr);
     hipLaunchKernelGGL(gs_scan_kernel, dim3(1), dim3(1024), 0, stream, cnt, nsc, off);
-    hipLaunchKernelGGL(minor_sample_offsets_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, stream, off, n, g->s_off);
+    unsigned long long *d_max = reinterpret_cast<unsigned long long *>(cur + ((std::max<size_t>(n, 1) + 1) & ~(size_t)1));     // behind `cur`
+    GS_TRY(hipMemsetAsync(d_max, 0, 8, stream));
+    hipLaunchKernelGGL(minor_sample_offsets_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, stream, off, n, g->s_off, d_max);
     hipLaunchKernelGGL((minor_sample_kernel<true>), sgrid, dim3(256), 0, stream, mb, a->n_pad, n, groups, gpc, nullptr, off, g->s_ent);
     if (egrid) hipLaunchKernelGGL((minor_listed_kernel<true>), dim3(egrid), dim3(256), 0, stream, E, mb.tot_p, nullptr, nullptr, off, cur, g->s_ent);
+    GS_TRY(hipMemcpyAsync(&g->max_row, d_max, 8, hipMemcpyDeviceToHost, stream));       // (read after the caller's synchronisation)
     GS_TRY(hipGetLastError());
     pack_stage_mark("minority lists: per sample", stream);
 #undef GS_TRY
+    g->tot_s = tot_s;
     a->minor = g;
     *ok = 1;
+    return TRACS_OK;
+}
+
+// ---- N co-occurrences from lists (site classes: the NNL sites) -----------------------------------------------------------
+// Row i of the pair matrix: NN(i, j) = number of NNL sites at which both i and j are N.  The row lives in LDS; every wave
+// takes 64 entries of sample i's list at a time, keeps its N entries at NNL sites (code 15, bit 4), fetches their lists'
+// bounds in one round trip and walks the lists 64 samples per load, two sites in flight; ds_add per j > i.  Work =
+// sum over the NNL sites of cN^2 list entries, whatever the number of samples -- against n^2 / 2 pairs per site on the matrix
+// cores.  The row is then added to ncomp -- with lu - c_i - c_j when no counting pass adds those terms.
+// A sample with many N entries (N concentrated in few samples) would leave most of the chip idle behind a few rows: a row's
+// entries are cut over up to NN_MAX_SPLITS workgroups of `target` entries (grid.z; the others exit at once), which then add their
+// rows with atomics.
+constexpr unsigned NN_MAX_SPLITS = 32;
+#ifndef TRACS_NN_FLIGHT
+#define TRACS_NN_FLIGHT 2
+#endif
+#ifndef TRACS_NN_THREADS
+#define TRACS_NN_THREADS 1024
+#endif
+constexpr int NN_FLIGHT = TRACS_NN_FLIGHT;          // sites per memory round trip and wave (sweep: profiles/r03/nn_rows_sweep.txt)
+template <class NT>
+__global__ __launch_bounds__(TRACS_NN_THREADS) void nn_rows_kernel(const unsigned long long *__restrict__ s_off, const unsigned *__restrict__ s_ent,
+                                                       const unsigned long long *__restrict__ n_off, const NT *__restrict__ n_ent,
+                                                       const unsigned *__restrict__ c_u, unsigned n, unsigned row_begin, unsigned col_begin,
+                                                       unsigned chunk, unsigned long long target, unsigned *__restrict__ ncomp, size_t ld,
+                                                       int add_terms, unsigned lu)
+{
+    extern __shared__ unsigned row[];
+    const unsigned i = row_begin + blockIdx.x;
+    const unsigned c0 = blockIdx.y * chunk, c1 = min(n, c0 + chunk);
+    if (c1 <= i + 1 || c1 <= col_begin) return;            // no cell (i, j > i) in this column chunk
+    const unsigned long long e_first = s_off[i], e_last = s_off[i + 1];
+    const unsigned long long len = e_last - e_first;
+    const unsigned nz = (unsigned)min((unsigned long long)NN_MAX_SPLITS, max(1ull, (len + target - 1) / target));
+    if (blockIdx.z >= nz) return;
+    const unsigned long long per = ((len + nz - 1) / nz + 63) / 64 * 64;
+    const unsigned long long e0 = e_first + blockIdx.z * per, e1 = min(e_last, e0 + per);
+    for (unsigned j = threadIdx.x; j < c1 - c0; j += blockDim.x) row[j] = 0;
+    __syncthreads();
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const unsigned lo = max(max(i + 1, col_begin), c0);     // columns [lo, c1) of this chunk are cells of row i
+    auto bump = [&](unsigned j) { if (j >= lo && j < c1) atomicAdd(&row[j - c0], 1u); };
+    for (unsigned long long base = e0 + (unsigned long long)wave * 64; base < e1; base += (unsigned long long)nwaves * 64) {
+        const unsigned long long e = base + lane;
+        const unsigned ent = e < e1 ? s_ent[e] : 0u;
+        const bool want = (ent & 16u) != 0u && ((ent & 15u) == 15u || (ent & 15u) == 0u);     // an N entry at an NNL site
+        unsigned long long na = 0, nz_ = 0;
+        if (want) { const unsigned r = ent >> ENT_SHIFT; na = n_off[r]; nz_ = n_off[r + 1]; }
+        unsigned long long todo = __ballot(want);
+        // NN_FLIGHT sites per round trip: every site's first 128 entries are requested before any is applied (the walk is bound by
+        // memory round trips per wave, not by bytes: PMC)
+        while (todo) {
+            unsigned v[NN_FLIGHT][2];
+            unsigned long long ta[NN_FLIGHT], tz[NN_FLIGHT];
+#pragma unroll
+            for (int q = 0; q < NN_FLIGHT; q++) {
+                const int k = todo ? __ffsll((long long)todo) - 1 : -1;    // wave-uniform
+                if (k >= 0) todo &= todo - 1;
+                ta[q] = k >= 0 ? __shfl(na, k, 64) + lane : 0ull;
+                tz[q] = k >= 0 ? __shfl(nz_, k, 64) : 0ull;
+                v[q][0] = ta[q] < tz[q] ? (unsigned)n_ent[ta[q]] : 0xFFFFFFFFu;
+                v[q][1] = ta[q] + 64 < tz[q] ? (unsigned)n_ent[ta[q] + 64] : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int q = 0; q < NN_FLIGHT; q++) { bump(v[q][0]); bump(v[q][1]); }      // (0xFFFFFFFF >= c1: no bump)
+#pragma unroll
+            for (int q = 0; q < NN_FLIGHT; q++)
+                for (unsigned long long t = ta[q] + 128; t < tz[q]; t += 64) bump((unsigned)n_ent[t]);
+        }
+    }
+    __syncthreads();
+    const bool terms = add_terms && blockIdx.z == 0;
+    const unsigned ci = terms ? c_u[i] : 0u;
+    for (unsigned j = lo + threadIdx.x; j < c1; j += blockDim.x) {
+        const unsigned v = row[j - c0] + (terms ? lu - ci - c_u[j] : 0u);
+        if (v) {
+            if (nz > 1) atomicAdd(&ncomp[(size_t)i * ld + j], v);
+            else ncomp[(size_t)i * ld + j] += v;
+        }
+    }
+}
+
+int nn_rows_add(tracs_alignment *a, size_t row_begin, size_t row_end, size_t col_begin, unsigned *ncomp, size_t ld, int add_terms,
+                unsigned lu, hipStream_t stream)
+{
+    const GeneralSparse *g = a->minor;
+    if (!g) { set_error("nn_rows_add: lists not built"); return TRACS_E_ARG; }
+    const size_t n = a->n;
+    const unsigned chunk = (unsigned)std::min<size_t>((n + 63) / 64 * 64, 32768);
+    static bool attr_set = false;
+    if (!attr_set) {
+        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(nn_rows_kernel<unsigned>), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4));
+        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(nn_rows_kernel<unsigned short>), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4));
+        attr_set = true;
+    }
+    // ~2048 workgroups' worth of entries each, never less than 8192 entries (a workgroup's fixed cost: its row in LDS)
+    const unsigned long long target = std::max<unsigned long long>(8192ull, g->tot_s / 2048ull);
+    const unsigned splits = (unsigned)std::min<unsigned long long>(NN_MAX_SPLITS, std::max<unsigned long long>(1, (g->max_row + target - 1) / target));
+    const dim3 grid((unsigned)(row_end - row_begin), (unsigned)((n + chunk - 1) / chunk), splits);
+    if (g->n16)
+        hipLaunchKernelGGL(nn_rows_kernel<unsigned short>, grid, dim3(TRACS_NN_THREADS), chunk * 4, stream, g->s_off, g->s_ent, g->n_off,
+                           reinterpret_cast<const unsigned short *>(g->n_ent), a->c_counted, (unsigned)n, (unsigned)row_begin, (unsigned)col_begin,
+                           chunk, target, ncomp, ld, add_terms, lu);
+    else
+        hipLaunchKernelGGL(nn_rows_kernel<unsigned>, grid, dim3(TRACS_NN_THREADS), chunk * 4, stream, g->s_off, g->s_ent, g->n_off, g->n_ent, a->c_counted,
+                           (unsigned)n, (unsigned)row_begin, (unsigned)col_begin, chunk, target, ncomp, ld, add_terms, lu);
+    TRACS_HIP_CHECK(hipGetLastError());
     return TRACS_OK;
 }
 
@@ -648,16 +784,21 @@ static int fixup_launch(const GeneralSparse *g, bool minor, unsigned L, size_t n
     const unsigned chunk = (unsigned)std::min<size_t>((n + 63) / 64 * 64, 32768);
     static bool attr_set = false;
     if (!attr_set) {
-        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(general_fixup_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4));
-        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(general_fixup_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4));
+        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(general_fixup_kernel<false, unsigned>), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4));
+        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(general_fixup_kernel<true, unsigned>), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4));
+        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(general_fixup_kernel<true, unsigned short>), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4));
         attr_set = true;
     }
     const dim3 grid((unsigned)(row_end - row_begin), (unsigned)((n + chunk - 1) / chunk));
-    if (minor)
-        hipLaunchKernelGGL(general_fixup_kernel<true>, grid, dim3(1024), chunk * 4, stream, g->s_off, g->s_ent, g->p_off, g->p_ent, g->n_off,
+    if (minor && g->n16)
+        hipLaunchKernelGGL((general_fixup_kernel<true, unsigned short>), grid, dim3(1024), chunk * 4, stream, g->s_off, g->s_ent, g->p_off, g->p_ent,
+                           g->n_off, reinterpret_cast<const unsigned short *>(g->n_ent), g->c_n, g->c_p, L, (unsigned)n, (unsigned)row_begin,
+                           (unsigned)col_begin, chunk, dist, ncomp, ld);
+    else if (minor)
+        hipLaunchKernelGGL((general_fixup_kernel<true, unsigned>), grid, dim3(1024), chunk * 4, stream, g->s_off, g->s_ent, g->p_off, g->p_ent, g->n_off,
                            g->n_ent, g->c_n, g->c_p, L, (unsigned)n, (unsigned)row_begin, (unsigned)col_begin, chunk, dist, ncomp, ld);
     else
-        hipLaunchKernelGGL(general_fixup_kernel<false>, grid, dim3(1024), chunk * 4, stream, g->s_off, g->s_ent, g->p_off, g->p_ent, g->n_off,
+        hipLaunchKernelGGL((general_fixup_kernel<false, unsigned>), grid, dim3(1024), chunk * 4, stream, g->s_off, g->s_ent, g->p_off, g->p_ent, g->n_off,
                            g->n_ent, g->c_n, g->c_p, L, (unsigned)n, (unsigned)row_begin, (unsigned)col_begin, chunk, dist, ncomp, ld);
     TRACS_HIP_CHECK(hipGetLastError());
     return TRACS_OK;

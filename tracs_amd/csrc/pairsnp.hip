@@ -400,14 +400,17 @@ __global__ void compact_live_kernel(const int2 *__restrict__ tiles, const unsign
     if (t < n_tiles && live[t]) out[atomicAdd(n_out, 1u)] = tiles[t];
 }
 
-// ncomp cells of the block += c (site classes: sites at which no sample is N, when no counting pass runs).  Rows go over
-// grid.y with a stride, so a region of any height fits one launch (grid.y <= 65535).
-__global__ void add_cells_kernel(unsigned *__restrict__ ncomp, size_t ld, unsigned n, unsigned row_begin, unsigned row_end,
-                                 unsigned col_begin, unsigned c)
+// ncomp cells of the block += lu - c_i - c_j (site classes: the sites outside the pair kernel's, when neither the counting pass nor
+// the list pass adds those terms; c == nullptr: no sample is N at any of them).  Rows go over grid.y with a stride, so a region
+// of any height fits one launch (grid.y <= 65535).
+__global__ void add_terms_kernel(unsigned *__restrict__ ncomp, size_t ld, unsigned n, unsigned row_begin, unsigned row_end,
+                                 unsigned col_begin, unsigned lu, const unsigned *__restrict__ c)
 {
-    for (unsigned i = row_begin + blockIdx.y; i < row_end; i += gridDim.y)
+    for (unsigned i = row_begin + blockIdx.y; i < row_end; i += gridDim.y) {
+        const unsigned ci = c ? c[i] : 0u;
         for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
-            if (j > i && j >= col_begin) ncomp[(size_t)i * ld + j] += c;
+            if (j > i && j >= col_begin) ncomp[(size_t)i * ld + j] += lu - ci - (c ? c[j] : 0u);
+    }
 }
 
 // cells of the block <- L (dist and, if given, ncomp; dist may be NULL: ncomp only)
@@ -665,9 +668,9 @@ int tracs_alignment_create(size_t n, size_t L, tracs_alignment **out)
         if (e != hipSuccess) { set_error(std::string("hipMalloc(planes): ") + hipGetErrorString(e)); delete a; return TRACS_E_NOMEM; }
         e = hipMemset(a->planes, 0, bytes);
         if (e != hipSuccess) { set_error(std::string("hipMemset(planes): ") + hipGetErrorString(e)); (void)hipFree(a->planes); delete a; return TRACS_E_HIP; }
-        // the arena of the once-per-pack structures: 12 % of the planes + 64 MiB covers the lists of alignments with up to ~3 % of
+        // the arena of the once-per-pack structures: 15 % of the planes + 64 MiB covers the lists of alignments with up to ~1.5 % of
         // N / minority entries (TRACS_PACK_ARENA=<fraction> overrides; 0: none).  Not getting it is not an error.
-        static const double frac = [] { const char *v = std::getenv("TRACS_PACK_ARENA"); return v ? std::atof(v) : 0.12; }();
+        static const double frac = [] { const char *v = std::getenv("TRACS_PACK_ARENA"); return v ? std::atof(v) : 0.15; }();
         if (frac > 0.0 && n >= 2) {
             const size_t want = (size_t)((double)bytes * frac) + std::min<size_t>(64u << 20, 2 * bytes + (1u << 20));
             if (hipMalloc(reinterpret_cast<void **>(&a->arena), want) == hipSuccess) a->arena_bytes = want;
@@ -784,24 +787,27 @@ int tracs_debug_alignment_site_classes(const tracs_alignment *a, uint64_t *out)
     if (!a) return 0;
     if (out) {
         const bool on = a->classes_state == 1;
-        out[0] = on ? a->L_var : 0; out[1] = on ? a->L_inv : 0; out[2] = on ? a->L_minor : 0; out[3] = on ? a->L_full : 0;
+        out[0] = on ? a->L_var : 0; out[1] = on ? a->L_un : 0; out[2] = on ? a->L_minor : 0; out[3] = on ? a->L_full : 0;
     }
     return a->classes_state;
 }
 
-// what the counting pass of the last decided classes reads: out[0] = sites, out[1] = 1 when that is the stored N plane in place
+// what completes the compared-sites counts of the last decided classes: out[0] = sites the counting pass reads on the matrix
+// cores, out[1] = 1 when that is the stored N plane in place, out[2] = sites whose N co-occurrences come from lists
 int tracs_debug_alignment_count_source(const tracs_alignment *a, uint64_t *out)
 {
     if (!a || !out || a->classes_state != 1) return 0;
     out[0] = a->count_in_place ? a->L : a->L_inv;
     out[1] = a->count_in_place ? 1 : 0;
+    out[2] = a->L_nnl;
     return 1;
 }
 
-// Diagnostics for bench.py: HIP events on the launch stream around the three parts of a dense call (pair kernel incl. its
-// cell initialisation / sparse partial-code correction / invariant-site counting pass).  Off by default.
+// Diagnostics for bench.py: HIP events on the launch stream around the four parts of a dense call (pair kernel incl. its cell
+// initialisation / sparse partial-code correction + minority lists / counting pass on the matrix cores / N co-occurrence lists).
+// Off by default.
 static bool g_pair_timing = false;
-static hipEvent_t g_pair_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+static hipEvent_t g_pair_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 static bool g_pair_ev_valid = false;
 void tracs_debug_pair_timing(int on)
 {
@@ -812,14 +818,14 @@ void tracs_debug_pair_timing(int on)
 int tracs_debug_last_pair_ms(float *out)
 {
     if (!out || !g_pair_ev_valid) return TRACS_E_ARG;
-    if (hipEventSynchronize(g_pair_ev[3]) != hipSuccess) return TRACS_E_HIP;
-    for (int k = 0; k < 3; k++)
+    if (hipEventSynchronize(g_pair_ev[4]) != hipSuccess) return TRACS_E_HIP;
+    for (int k = 0; k < 4; k++)
         if (hipEventElapsedTime(&out[k], g_pair_ev[k], g_pair_ev[k + 1]) != hipSuccess) return TRACS_E_HIP;
     return TRACS_OK;
 }
 static inline void pair_mark(int k, hipStream_t stream)
 {
-    if (g_pair_timing && g_pair_ev[k]) { (void)hipEventRecord(g_pair_ev[k], stream); if (k == 3) g_pair_ev_valid = true; }
+    if (g_pair_timing && g_pair_ev[k]) { (void)hipEventRecord(g_pair_ev[k], stream); if (k == 4) g_pair_ev_valid = true; }
 }
 
 static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_t row_end, size_t col_begin, uint32_t *dist,
@@ -1040,57 +1046,71 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
         return TRACS_OK;
     };
 
-    // Site classes: the compared-sites counts of every site the pair kernel does not read -- NN = sum n n' over the N plane of
-    // the counted sites and nn += sites - c_i - c_j + NN --, for the tiles whose cells are complete (all, or the live ones of a
-    // thresholded run).  Ranges of at most 2^23 sites keep the fp32 partial sums exact; ranges add with integer atomics.
-    // In-place source (the stored N plane of every site): the pair kernels wrote d only and this pass alone makes nn.
+    // Site classes: the compared-sites counts of every site the pair kernel does not read.  Over those sites U (in place: over
+    // every site, and the pair kernels wrote d only)   nn = |U| - c_i - c_j + NN,   NN = sum n_i n_j  (n = "is N here"):
+    //   matrix cores  pairsnp_mfma_kernel<COUNT> over the N plane of the sites with many N samples (or of every site, in place),
+    //                 for the tiles whose cells are complete (all, or the live ones of a thresholded run); ranges of at most 2^23
+    //                 sites keep the fp32 partial sums exact, ranges add with integer atomics; range 0 adds |U| - c_i - c_j;
+    //   lists         nn_rows_kernel over the sites with few N samples (cN^2 list entries per site);
+    //   neither       sites with one N sample or none only add their part of |U| - c_i - c_j.
     auto count_pass = [&](const int2 *tl, size_t ntl) -> int {
-        if (!classes || !ncomp || (a->L_inv == 0 && a->L_full == 0)) return TRACS_OK;
-        if (a->L_inv == 0) {                                   // only sites without any N: a constant
-            dim3 grid(64, (unsigned)std::min<size_t>(row_end - row_begin, 65535));
-            hipLaunchKernelGGL(add_cells_kernel, grid, dim3(256), 0, stream, ncomp, ld, (unsigned)a->n, (unsigned)row_begin, (unsigned)row_end,
-                               (unsigned)col_begin, (unsigned)a->L_full);
-            return TRACS_OK;
-        }
-        // tl == nullptr: every tile of the region, in the counting pass's own workgroup tile (its own cached schedule);
-        // otherwise the given tiles (the live ones of a thresholded run) in the pair kernel's geometry
-        CountShape C = count_shape_like(kTI, kTJ);
-        if (tl && !C.fn) tl = nullptr;                         // no counting kernel with the pair kernel's tile: count every tile
-        if (!tl) {
-            C = count_shape_current();
-            tracs_alignment::TileCache *ct = nullptr;
-            const int rc = ensure_tiles(C.ti, C.tj, &ct);
-            if (rc) return rc;
-            tl = ct->d; ntl = ct->n;
-        }
+        if (!classes || !ncomp || (a->L_un == 0 && a->L_full == 0)) { pair_mark(3, stream); return TRACS_OK; }
         const bool in_place = a->count_in_place;
-        if (ntl == 0 && !in_place) return TRACS_OK;
-        const int gi = (int)(in_place ? a->groups : a->groups_inv), gcc = C.gc;
-        const double keep_slots = slots;
-        slots = (double)C.wg_per_cu * (slots / (double)(mfma ? S.wg_per_cu : V.wg_per_cu[cons ? 1 : 0]));
-        int k = std::max(pick_split(std::max<size_t>(ntl, 1), gi, gcc), (gi + (1 << 16) - 1) >> 16);
-        slots = keep_slots;
-        int g = (gi + k - 1) / k;
-        g = (g + gcc - 1) / gcc * gcc;
-        k = (gi + g - 1) / g;
-        if (in_place && k > 1 && !nn_zeroed) {
-            // several ranges add onto the cells: zero them first (nothing else has written nn) -- unless the call already has
-            dim3 grid(64, (unsigned)std::min<size_t>(row_end - row_begin, 65535));
-            hipLaunchKernelGGL(init_cells_kernel, grid, dim3(256), 0, stream, (unsigned *)nullptr, ncomp, ld, (unsigned)a->n,
-                               (unsigned)row_begin, (unsigned)row_end, (unsigned)col_begin, 0u);
+        const unsigned lu = (unsigned)(in_place ? a->L : a->L_full + a->L_un);
+        bool terms_added = false;
+        if (a->L_inv > 0) {
+            // tl == nullptr: every tile of the region, in the counting pass's own workgroup tile (its own cached schedule);
+            // otherwise the given tiles (the live ones of a thresholded run) in the pair kernel's geometry
+            CountShape C = count_shape_like(kTI, kTJ);
+            if (tl && !C.fn) tl = nullptr;                     // no counting kernel with the pair kernel's tile: count every tile
+            if (!tl) {
+                C = count_shape_current();
+                tracs_alignment::TileCache *ct = nullptr;
+                const int rc = ensure_tiles(C.ti, C.tj, &ct);
+                if (rc) return rc;
+                tl = ct->d; ntl = ct->n;
+            }
+            const int gi = (int)(in_place ? a->groups : a->groups_inv), gcc = C.gc;
+            const double keep_slots = slots;
+            slots = (double)C.wg_per_cu * (slots / (double)(mfma ? S.wg_per_cu : V.wg_per_cu[cons ? 1 : 0]));
+            int k = std::max(pick_split(std::max<size_t>(ntl, 1), gi, gcc), (gi + (1 << 16) - 1) >> 16);
+            slots = keep_slots;
+            int g = (gi + k - 1) / k;
+            g = (g + gcc - 1) / gcc * gcc;
+            k = (gi + g - 1) / g;
+            if (in_place && k > 1 && !nn_zeroed) {
+                // several ranges add onto the cells: zero them first (nothing else has written nn) -- unless the call already has
+                dim3 grid(64, (unsigned)std::min<size_t>(row_end - row_begin, 65535));
+                hipLaunchKernelGGL(init_cells_kernel, grid, dim3(256), 0, stream, (unsigned *)nullptr, ncomp, ld, (unsigned)a->n,
+                                   (unsigned)row_begin, (unsigned)row_end, (unsigned)col_begin, 0u);
+            }
+            if (ntl) {
+                MfmaArgs A;
+                A.P = in_place ? a->planes + 4 * a->n_pad : a->iplanes;
+                A.count_gp = in_place ? NPLANES : 1;
+                A.count_store = (in_place && k == 1) ? 1 : 0;
+                A.n_pad = a->n_pad; A.groups = gi; A.tiles = tl; A.n_tiles = (int)ntl; A.gps = g; A.ksplit = k;
+                A.L = lu;                                      // range 0 adds |U| - c_i - c_j once per cell
+                A.c_n = a->c_counted;
+                A.n = (unsigned)a->n; A.row_end = (unsigned)row_end; A.col_begin = (unsigned)col_begin;
+                A.dist = dist; A.ncomp = ncomp; A.ld = ld; A.thr = 0xFFFFFFFFu; A.ph = TilePhase{0, 0, nullptr};
+                C.fn((unsigned)(ntl * (size_t)k), stream, A);
+            }
+            // (a thresholded run counts its live tiles only: the cells of the others keep whatever the pair kernel left -- ncomp of a
+            // pair beyond the threshold is unspecified -- and the list pass below adds to every cell of the region all the same)
+            terms_added = true;
         }
-        if (ntl == 0) return TRACS_OK;
-        MfmaArgs A;
-        A.P = in_place ? a->planes + 4 * a->n_pad : a->iplanes;
-        A.count_gp = in_place ? NPLANES : 1;
-        A.count_store = (in_place && k == 1) ? 1 : 0;
-        A.n_pad = a->n_pad; A.groups = gi; A.tiles = tl; A.n_tiles = (int)ntl; A.gps = g; A.ksplit = k;
-        // range 0 adds sites - c_i - c_j once per cell: the counted sites + the sites without any N; in place: every site
-        A.L = (unsigned)(in_place ? a->L : a->L_full + a->L_inv);
-        A.c_n = a->c_counted;
-        A.n = (unsigned)a->n; A.row_end = (unsigned)row_end; A.col_begin = (unsigned)col_begin;
-        A.dist = dist; A.ncomp = ncomp; A.ld = ld; A.thr = 0xFFFFFFFFu; A.ph = TilePhase{0, 0, nullptr};
-        C.fn((unsigned)(ntl * (size_t)k), stream, A);
+        pair_mark(3, stream);
+        if (a->L_nnl > 0) {
+            const int rc = nn_rows_add(a, row_begin, row_end, col_begin, ncomp, ld, terms_added ? 0 : 1, lu, stream);
+            if (rc) return rc;
+            terms_added = true;
+        }
+        if (!terms_added) {                                    // no pair of N samples anywhere outside the dense sites
+            dim3 grid(64, (unsigned)std::min<size_t>(row_end - row_begin, 65535));
+            hipLaunchKernelGGL(add_terms_kernel, grid, dim3(256), 0, stream, ncomp, ld, (unsigned)a->n, (unsigned)row_begin, (unsigned)row_end,
+                               (unsigned)col_begin, lu, a->L_un ? a->c_counted : (const unsigned *)nullptr);
+        }
         return TRACS_OK;
     };
     // Site classes, consensus form: the minority sites' distances from their lists (general_sparse.hip, general_fixup_kernel<MINOR>)
@@ -1109,7 +1129,7 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
         if (rc) return rc;
         pair_mark(2, stream);
         if ((rc = count_pass(nullptr, 0))) return rc;
-        pair_mark(3, stream);
+        pair_mark(4, stream);
         TRACS_HIP_CHECK(hipGetLastError());
         return TRACS_OK;
     }
@@ -1166,7 +1186,7 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
     if ((rc = minor_pass())) return rc;
     pair_mark(2, stream);
     if ((rc = count_pass(nullptr, 0))) return rc;
-    pair_mark(3, stream);
+    pair_mark(4, stream);
     TRACS_HIP_CHECK(hipGetLastError());
     return TRACS_OK;
 }

@@ -91,7 +91,7 @@ __device__ __forceinline__ void load_group_words(const uint4 *__restrict__ P, si
 // Mask slots of a group (masks[slot * groups + g], one uint4 = 128 sites each):
 enum { M_DENSE = 0, M_COUNT, M_MINOR, M_FULL, M_NNL, M_LST, M_UN, M_REFX, M_REFY, M_SLOTS };
 //   M_COUNT  sites whose N co-occurrences go through the matrix cores (cN > nn_list_max, or lists not in use)
-//   M_NNL    sites whose N co-occurrences come from their N lists (2 <= cN <= nn_list_max: nn_rows_kernel, general_sparse.hip)
+//   M_NNL    sites whose N co-occurrences come from their N lists (cN >= 2, cN ceil(cN / 64) <= nn_list_max: nn_rows_kernel, general_sparse.hip)
 //   M_LST    sites that carry lists at all (minority or NNL): list index = rank among these
 //   M_UN     every site outside the dense class with cN >= 1 (M_COUNT, M_NNL and the cN = 1 sites, which have no co-occurrence)
 __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__restrict__ P, size_t n_pad, unsigned n, unsigned budget,
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
         const bool minor = some && k >= 1 && budget > 0 && k * (c + k) <= (unsigned long long)budget;
         const bool dense = some && k >= 1 && !minor;
         const bool un = some && !dense && c >= 1;
-        const bool nnl = un && c >= 2 && c <= (unsigned long long)nn_list_max;
+        const bool nnl = un && c >= 2 && c * ((c + 63) / 64) <= (unsigned long long)nn_list_max;     // 64 list entries per wave and load
         const bool counted = un && c >= 2 && !nnl;          // (a site with one N sample has no pair of N samples)
         const bool full = some && !dense && c == 0;
         const bool lst = minor || nnl;
@@ -504,11 +504,13 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     // ~51 ns per site at 10 000 samples (pair kernel) against ~2-4 ps per list entry (general_fixup_kernel)
     const double bsites = (double)a->n * (double)a->n / 8000.0;
     const unsigned budget = (no_minor || !allow_minor) ? 0u : (unsigned)std::min(1.0e9, std::max(16.0, bsites));
-    // the N co-occurrences of a site with cN N samples cost cN^2 list entries (nn_rows_kernel) against n^2 / 2 pairs on the matrix
-    // cores, whatever cN: lists up to cN = TRACS_NN_LIST_FRAC x n (default: measured crossover); TRACS_NN_LISTS=0: never
+    // The N co-occurrences of a site with cN N samples cost cN list walks of ceil(cN / 64) wave loads each (nn_rows_kernel) against
+    // n^2 / 2 pairs on the matrix cores, whatever cN: lists while cN ceil(cN / 64) <= TRACS_NN_LIST_K x n^2 (default 3.3e-6: a wave
+    // load of the list walk costs ~33 ps of the chip's time, a pair and site of the counting pass 2 / 7.4e15 s -- crossover at
+    // 4e-6, taken with a margin for the lists' share of the once-per-pack work); TRACS_NN_LISTS=0: never
     static const bool no_nnl = [] { const char *e = std::getenv("TRACS_NN_LISTS"); return e && std::atoi(e) == 0; }();
-    static const double nnl_frac = [] { const char *e = std::getenv("TRACS_NN_LIST_FRAC"); return e ? std::atof(e) : 0.02; }();
-    const unsigned nn_list_max = (no_nnl || !allow_nnl) ? 0u : (unsigned)std::min(1.0e6, std::max(2.0, nnl_frac * (double)a->n));
+    static const double nnl_k = [] { const char *e = std::getenv("TRACS_NN_LIST_K"); return e ? std::atof(e) : 3.3e-6; }();
+    const unsigned nn_list_max = (no_nnl || !allow_nnl) ? 0u : (unsigned)std::min(4.0e9, nnl_k * (double)a->n * (double)a->n);
     TRACS_HIP_CHECK(hipMemsetAsync(totals, 0, 128, stream));
     hipLaunchKernelGGL(classify_sites_kernel, dim3((unsigned)groups), dim3(256), 0, stream, a->planes, a->n_pad, (unsigned)a->n, budget,
                        nn_list_max, masks, groups, cntP, cntN, gcnt, gcnt + groups, flags, flag_words, d_flag);

@@ -106,11 +106,11 @@ class Alignment:
 
     @property
     def count_source(self):
-        """(sites the counting pass reads, in_place) for an alignment on site classes: in_place = the stored N plane of every
-        site, read where it lies (the pair kernels then write d only); else the counted sites' N plane re-packed.  None
-        without classes."""
-        out = (C.c_uint64 * 2)()
-        return (int(out[0]), bool(out[1])) if self._L.tracs_debug_alignment_count_source(self._h, out) else None
+        """(sites the counting pass reads on the matrix cores, in_place, sites whose N co-occurrences come from lists) for an
+        alignment on site classes: in_place = the stored N plane of every site, read where it lies (the pair kernels then write d
+        only); else the N plane of the sites with many N samples, re-packed.  None without classes."""
+        out = (C.c_uint64 * 3)()
+        return (int(out[0]), bool(out[1]), int(out[2])) if self._L.tracs_debug_alignment_count_source(self._h, out) else None
 
     @property
     def nbytes(self):
