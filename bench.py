@@ -17,11 +17,12 @@ before the clock stops.
 
 Prints ONE JSON line (rank 0):
   roofline          the dominant kernel of the timed region from HIP events on the launch stream (recorded by the library around
-                    each kernel of a dense call): exact fp4 Gram products on the matrix cores, bound "mfma".  With site classes in
-                    use (the default on this workload, csrc/site_classes.hip) that is the one-operand counting pass over the
-                    counted sites; the four-operand pair kernel over the dense sites (`other_matrix_core_kernel`), the minority
-                    lists' kernel (`minority_lists_ms`) and the class sizes (`site_classes`) are reported beside it.  With
-                    TRACS_SITE_CLASSES=0 it is the pair kernel over every site; HBM view in roofline.hbm
+                    each part of a dense call).  With site classes in use (the default on this workload, csrc/site_classes.hip) a call
+                    is: the four-operand pair kernel over the dense sites (matrix cores), the minority lists' kernel, the one-operand
+                    counting pass over the sites with many N samples (matrix cores) and the N co-occurrence walk over the lists of the
+                    sites with few (nn_rows_kernel, memory-bound: `bound` "hbm") -- whichever takes longest is reported, the others
+                    beside it (`other_kernels`, `kernels_ms`), with the class sizes (`site_classes`).  With TRACS_SITE_CLASSES=0 it is
+                    the pair kernel over every site
   roofline_general  the same pass over the SAME alignment with 0.5 % partial IUPAC codes added (SURVEY.md 8d's C4 mix):
                     one-hot matrix-core kernel + sparse partial-code correction (N = 1 only; not part of `value`)
   dm_frontend       counts -> posterior filter -> 4-bit codes -> packed planes for a batch of samples (SURVEY.md 8d C3's
@@ -125,6 +126,22 @@ def count_roofline(pairs_per_launch, sites, count_s, n, in_place):
             "algorithmic_bytes_per_pair_no_reuse": sites * 0.25,
             "note": "nn = sites - c_i - c_j + sum n_i n_j: one fp4 operand plane (n = is N here; mostly zeros: the measured ceiling is "
                     "the bare instruction's rate on zero operands), %g flop per pair and site" % COUNT_FLOP_PER_SITE}
+
+
+def nn_list_roofline(ls, sites, kern_s, rows, n):
+    """nn_rows_kernel (csrc/general_sparse.hip): the N co-occurrences NN = sum n_i n_j of the sites with few N samples, from their N
+    lists -- memory-bound.  Algorithmic bytes per launch: every visited list entry once (cN entries per N sample and site: the
+    sum of cN^2 over those sites, 2 or 4 B each) + per N sample and site its 4-byte entry of the per-sample list and the 16 bytes
+    of list bounds it looks up.  Scaled by the rows of the launch (a rank's panel walks its rows' lists only)."""
+    frac_rows = rows / float(n)
+    alg = (ls["nn_visits"] * ls["n_entry_bytes"] + ls["n_entries"] * 20.0) * frac_rows
+    return {"kernel": "nn_rows_kernel", "kernel_ms": kern_s * 1e3, "sites": sites, "bound": "hbm", "traffic": None,
+            "achieved": alg / kern_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg / kern_s / HBM_PEAK,
+            "algorithmic_bytes": alg, "list_entries_visited": ls["nn_visits"] * frac_rows, "bytes_per_list_entry": ls["n_entry_bytes"],
+            "entries_per_s": ls["nn_visits"] * frac_rows / kern_s,
+            "note": "row i of the pair matrix in LDS; for every site at which sample i is N (and that has few N samples) the site's list "
+                    "of N samples is walked, ds_add per j > i: sum of cN^2 list entries instead of n^2 / 2 pairs per site on the matrix "
+                    "cores; random list reads of ~2 cN bytes: HBM / fabric-bound"}
 
 
 def roofline_of(kernel, enc, pairs_per_launch, L, kern_s, traffic, n):
@@ -350,20 +367,30 @@ def main():
             # counting pass over the counted sites.  `roofline` = whichever matrix-core kernel takes longer; the other beside it.
             dense, counted, minority, full = classes
             count_sites, in_place, nn_listed = aln.count_source or (counted, False, 0)
+            ls = aln.list_stats
+            last_rows = ranges[-1][1] - ranges[-1][0]
             main = roofline_of(aln.kernel, enc, last_pairs, dense, max(split[0], 1e-3) / 1e3, None, n)
             cnt = count_roofline(last_pairs, count_sites, max(split[2], 1e-3) / 1e3, n, in_place)
-            cnt["traffic"] = traffic                          # the "+classes" entry of the PMC summary is the counting pass's
-            cnt["hbm_physical"] = hbm_physical(traffic, max(split[2], 1e-3) / 1e3, cnt["compulsory_bytes"])
-            roof, other = (cnt, main) if split[2] > split[0] else (main, cnt)
-            roof["other_matrix_core_kernel"] = {k: other[k] for k in ("kernel", "kernel_ms", "achieved", "frac", "unit") if k in other}
+            nnl = nn_list_roofline(ls, nn_listed, max(split[3], 1e-3) / 1e3, last_rows, n) if nn_listed else None
+            cands = [(split[0], main, ""), (split[2], cnt, "+classes"), (split[3], nnl, "+nnlists")]
+            cands = sorted([c for c in cands if c[1] is not None], key=lambda c: -c[0])
+            roof, tag = cands[0][1], cands[0][2]
+            traffic = _traffic_from_profiles(n, L, world, aln.kernel + tag) if tag else None
+            roof["traffic"] = traffic
+            roof["hbm_physical"] = hbm_physical(traffic, roof["kernel_ms"] / 1e3, roof.get("compulsory_bytes") or roof.get("algorithmic_bytes"))
+            roof["other_kernels"] = [{k: c[1][k] for k in ("kernel", "kernel_ms", "bound", "achieved", "frac", "unit", "sites") if k in c[1]} for c in cands[1:]]
             roof["minority_lists_ms"] = split[1]
             roof["dense_call_ms"] = kern_s * 1e3
+            roof["kernels_ms"] = {"pair kernel (dense sites)": split[0], "general_fixup_kernel (minority lists)": split[1],
+                                  "counting pass (matrix cores)": split[2], "nn_rows_kernel (N co-occurrence lists)": split[3]}
             roof["site_classes"] = {"dense": dense, "counted": counted, "minority": minority, "full": full,
                                     "empty": L - dense - counted - full, "counting_pass_sites": count_sites, "counting_pass_in_place": in_place,
+                                    "nn_list_sites": nn_listed, "lists": ls,
                                     "note": "decided once per pack, results bit-identical (csrc/site_classes.hip): the pair kernel reads the dense "
                                             "sites only; sites at which <= a few samples differ from the others (minority) add their distances "
                                             "from sparse lists (general_fixup_kernel<MINOR>); nn of every non-dense site with an N comes from "
-                                            "a one-operand matrix-core pass (counted), sites without any N add a constant (full). "
+                                            "the N lists of the sites with few N samples (nn_rows_kernel) and a one-operand matrix-core pass over the "
+                                            "others (counted = both + the sites with a single N), sites without any N add a constant (full). "
                                             "TRACS_SITE_CLASSES=0 reads every site with the pair kernel, TRACS_MINORITY=0 keeps the minority sites dense"}
         else:
             roof = roofline_of(aln.kernel, enc, my_pairs_per_launch, L, kern_s, traffic, n)
@@ -450,7 +477,7 @@ def sensitivity(args, n, L, seed, days, dev, synth, torch, device, lib, value_de
         a = dev.Alignment(n, L)
         synth.pack_synthetic_device(a, seed=seed, **synth_kw(0.0, name))
         first, ms, cd, cn = timed(a)
-        classes, kernel, split = a.site_classes, a.kernel, pair_split_ms(lib)
+        classes, kernel, split, a_count = a.site_classes, a.kernel, pair_split_ms(lib), a.count_source
         lib.tracs_debug_force_site_classes(0)
         a.mark_packed()
         first0, ms0, cd0, cn0 = timed(a)
@@ -461,7 +488,8 @@ def sensitivity(args, n, L, seed, days, dev, synth, torch, device, lib, value_de
         out[name] = {"ms_per_pass": ms, "pairs_per_s": pairs / (ms / 1e3), "single_pass_ms": first,
                      "ms_per_pass_classes_off": ms0, "single_pass_ms_classes_off": first0,
                      "site_classes": None if classes is None else dict(zip(("dense", "counted", "minority", "full"), classes)),
-                     "kernel": kernel, "kernels_ms": None if not split else dict(zip(("pair", "lists", "count"), split)),
+                     "kernel": kernel, "kernels_ms": None if not split else dict(zip(("pair", "lists", "count", "nn_lists"), split)),
+                     "count_source": a_count,
                      "mean_d": cd / float(pairs), "checksum_d": cd, "checksum_nn": cn, "generator": WORKLOADS[name]}
     worst = min(out, key=lambda k: out[k]["pairs_per_s"])
     return {"workloads": out, "worst": worst,
@@ -493,8 +521,10 @@ def general_pass(args, n, L, seed, dev, synth, torch, device):
         count_sites, in_place, nn_listed = aln.count_source or (classes[1], False, 0)
         main = roofline_of(aln.kernel, "general", pairs, classes[0], max(split[0], 1e-3) / 1e3, None, n)
         cnt = count_roofline(pairs, count_sites, max(split[2], 1e-3) / 1e3, n, in_place)
-        r, other = (cnt, main) if split[2] > split[0] else (main, cnt)
-        r["other_matrix_core_kernel"] = {k: other[k] for k in ("kernel", "kernel_ms", "achieved", "frac", "unit") if k in other}
+        nnl = nn_list_roofline(aln.list_stats, nn_listed, max(split[3], 1e-3) / 1e3, n, n) if nn_listed else None
+        cands = sorted([c for c in ((split[0], main), (split[2], cnt), (split[3], nnl)) if c[1] is not None], key=lambda c: -c[0])
+        r = cands[0][1]
+        r["other_kernels"] = [{k: c[1][k] for k in ("kernel", "kernel_ms", "bound", "achieved", "frac", "unit", "sites") if k in c[1]} for c in cands[1:]]
         r["lists_ms"] = split[1]
         r["site_classes"] = {"dense": classes[0], "counted": classes[1], "minority": classes[2], "full": classes[3],
                              "empty": L - classes[0] - classes[1] - classes[3]}
@@ -503,7 +533,7 @@ def general_pass(args, n, L, seed, dev, synth, torch, device):
     r["dense_call_ms"] = kern_s * 1e3
     if split:
         r["kernels_ms"] = {"pairsnp_mfma_kernel": split[0], "general_fixup_kernel (partial codes of the dense sites + minority lists)": split[1],
-                           "count_pass": split[2]}
+                           "count_pass": split[2], "nn_rows_kernel": split[3]}
     r["workload"] = "the same alignment + %.3g partial IUPAC codes per site (uniformly random sites and codes)" % P_PARTIAL_C4
     r["mean_d"] = float(dmat.sum().item()) / (n * (n - 1) // 2)
     aln.close()

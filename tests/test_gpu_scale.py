@@ -247,10 +247,10 @@ def test_bench_line_contract_small():
     r = j["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms"):
         assert k in r, k
-    assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["bound"] in ("mfma", "hbm") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["frac"] <= 1.0
     sc = r["site_classes"]
     assert sc["dense"] + sc["counted"] + sc["full"] + sc["empty"] == 200000 and sc["minority"] > 0
-    assert r["frac_of_measured_fp4_ceiling"] <= 1.0 and "hbm" not in r          # no fraction above 1 on the line
+    assert r.get("frac_of_measured_fp4_ceiling", 0.0) <= 1.0 and "hbm" not in r    # no fraction above 1 on the line
     # one pass per alignment (the reference's unit of work), cold and warm, with the once-per-pack stages
     sp = j["single_pass"]
     assert sp["cold_ms"] > 0 and sp["warm_ms"] > 0 and sp["per_pack_ms"] > 0 and "classify" in sp["stages_ms"]
@@ -259,9 +259,9 @@ def test_bench_line_contract_small():
     sw = j["sensitivity"]["workloads"]
     assert set(sw) == {"lineage", "divergent", "clean", "gappy"}
     assert j["value_worst_workload"] <= j["value"] and j["value_worst_workload"] == min([j["value"]] + [w["pairs_per_s"] for w in sw.values()])
-    assert r["other_matrix_core_kernel"]["kernel_ms"] >= 0 and r["minority_lists_ms"] >= 0
+    assert all(o["kernel_ms"] >= 0 for o in r["other_kernels"]) and r["minority_lists_ms"] >= 0 and len(r["kernels_ms"]) == 4
     g = j["roofline_general"]
-    assert g["bound"] == "mfma" and g["mean_d"] > j["config"]["mean_d"]
+    assert g["bound"] in ("mfma", "hbm") and g["mean_d"] > j["config"]["mean_d"]
     assert j["dm_frontend"]["encoding"] in ("general", "consensus")
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["unit"] == "pairs/s" and "sample" in c

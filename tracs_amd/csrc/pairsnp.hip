@@ -793,13 +793,18 @@ int tracs_debug_alignment_site_classes(const tracs_alignment *a, uint64_t *out)
 }
 
 // what completes the compared-sites counts of the last decided classes: out[0] = sites the counting pass reads on the matrix
-// cores, out[1] = 1 when that is the stored N plane in place, out[2] = sites whose N co-occurrences come from lists
+// cores, out[1] = 1 when that is the stored N plane in place, out[2] = sites whose N co-occurrences come from lists, out[3] = list
+// entries one pass of that walk visits, out[4], out[5] = entries of the N lists / the listed-sample lists, out[6] = bytes per N entry
 int tracs_debug_alignment_count_source(const tracs_alignment *a, uint64_t *out)
 {
     if (!a || !out || a->classes_state != 1) return 0;
     out[0] = a->count_in_place ? a->L : a->L_inv;
     out[1] = a->count_in_place ? 1 : 0;
     out[2] = a->L_nnl;
+    out[3] = a->nn_visits;
+    out[4] = a->list_entries_n;
+    out[5] = a->list_entries_p;
+    out[6] = a->n_pad <= 65536 ? 2 : 4;                      // bytes per N list entry
     return 1;
 }
 

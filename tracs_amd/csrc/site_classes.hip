@@ -97,7 +97,7 @@ enum { M_DENSE = 0, M_COUNT, M_MINOR, M_FULL, M_NNL, M_LST, M_UN, M_REFX, M_REFY
 __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__restrict__ P, size_t n_pad, unsigned n, unsigned budget,
                                                              unsigned nn_list_max, uint4 *__restrict__ masks, size_t groups,
                                                              unsigned *__restrict__ cntP, unsigned *__restrict__ cntN,
-                                                             unsigned *__restrict__ gP, unsigned *__restrict__ gN,
+                                                             unsigned *__restrict__ gP, unsigned *__restrict__ gN, unsigned *__restrict__ gQ,
                                                              unsigned long long *__restrict__ flags, size_t flag_words,
                                                              unsigned *__restrict__ partial_flag)
 {
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
     __shared__ unsigned planes_lds[256][4][8];          // one counter's bit planes of every thread (32 KiB)
     __shared__ unsigned tot[2][SITES_PER_GROUP];        // k, cN
     __shared__ unsigned half_sum[SITES_PER_GROUP];
-    __shared__ unsigned wsum[2][2];
+    __shared__ unsigned wsum[2][3];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < SITES_PER_GROUP) { tot[0][tid] = 0; tot[1][tid] = 0; }
     if (tid < 4) { sref[0][tid] = 0; sref[1][tid] = 0; sref[2][tid] = 0; sref[3][tid] = 0; }
@@ -229,13 +229,14 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
         }
         cntP[g * SITES_PER_GROUP + tid] = (unsigned)k;
         cntN[g * SITES_PER_GROUP + tid] = (unsigned)c;
-        unsigned sp = minor ? (unsigned)k : 0u, sn = lst ? (unsigned)c : 0u;
+        // (sq: list entries the N co-occurrence walk visits at this site, cN per N sample; an NNL site has cN < 2^16)
+        unsigned sp = minor ? (unsigned)k : 0u, sn = lst ? (unsigned)c : 0u, sq = nnl ? (unsigned)(c * c) : 0u;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { sp += __shfl_xor(sp, off, 64); sn += __shfl_xor(sn, off, 64); }
-        if (lane == 0) { wsum[wave][0] = sp; wsum[wave][1] = sn; }
+        for (int off = 32; off > 0; off >>= 1) { sp += __shfl_xor(sp, off, 64); sn += __shfl_xor(sn, off, 64); sq += __shfl_xor(sq, off, 64); }
+        if (lane == 0) { wsum[wave][0] = sp; wsum[wave][1] = sn; wsum[wave][2] = sq; }
     }
     __syncthreads();
-    if (tid == 0) { gP[g] = wsum[0][0] + wsum[1][0]; gN[g] = wsum[0][1] + wsum[1][1]; }
+    if (tid == 0) { gP[g] = wsum[0][0] + wsum[1][0]; gN[g] = wsum[0][1] + wsum[1][1]; gQ[g] = wsum[0][2] + wsum[1][2]; }
     if (tid < 4) {
         reinterpret_cast<unsigned *>(&masks[(size_t)M_REFX * groups + g])[tid] = refx[tid];
         reinterpret_cast<unsigned *>(&masks[(size_t)M_REFY * groups + g])[tid] = refy[tid];
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
 
 // Exclusive prefix sums over the groups, one workgroup per array (1024 groups at a time):
 //   blocks 0..6  sizes of the mask slots M_DENSE .. M_UN (popcount of the mask) -> off32[b][g], totals[b]
-//   blocks 7, 8  list sizes gP / gN of the groups' sites                       -> off64[b - 7][g], totals[b]
+//   blocks 7..9  list sizes gP / gN of the groups' sites, gQ (entries the N co-occurrence walk visits) -> off64[b - 7][g], totals[b]
 __global__ __launch_bounds__(1024) void group_offsets_kernel(const uint4 *__restrict__ masks, const unsigned *__restrict__ gcounts, size_t groups,
                                                              unsigned *__restrict__ off32, unsigned long long *__restrict__ off64,
                                                              unsigned long long *__restrict__ totals)
@@ -492,8 +493,8 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     if ((rc = workspace_get(52, M_SLOTS * groups * sizeof(uint4), reinterpret_cast<void **>(&masks)))) return rc;
     if ((rc = workspace_get(53, 7 * groups * sizeof(unsigned), reinterpret_cast<void **>(&offs)))) return rc;
     if ((rc = workspace_get(54, 2 * groups * SITES_PER_GROUP * sizeof(unsigned), reinterpret_cast<void **>(&cnts)))) return rc;
-    if ((rc = workspace_get(55, 2 * groups * sizeof(unsigned), reinterpret_cast<void **>(&gcnt)))) return rc;
-    if ((rc = workspace_get(56, 2 * (groups + 1) * sizeof(unsigned long long), reinterpret_cast<void **>(&off64)))) return rc;
+    if ((rc = workspace_get(55, 3 * groups * sizeof(unsigned), reinterpret_cast<void **>(&gcnt)))) return rc;
+    if ((rc = workspace_get(56, 3 * (groups + 1) * sizeof(unsigned long long), reinterpret_cast<void **>(&off64)))) return rc;
     if ((rc = workspace_get(57, 128, reinterpret_cast<void **>(&totals)))) return rc;
     if ((rc = workspace_get(58, groups * flag_words * sizeof(unsigned long long), reinterpret_cast<void **>(&flags)))) return rc;
     d_flag = reinterpret_cast<unsigned *>(totals + 15);
@@ -513,9 +514,9 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     const unsigned nn_list_max = (no_nnl || !allow_nnl) ? 0u : (unsigned)std::min(4.0e9, nnl_k * (double)a->n * (double)a->n);
     TRACS_HIP_CHECK(hipMemsetAsync(totals, 0, 128, stream));
     hipLaunchKernelGGL(classify_sites_kernel, dim3((unsigned)groups), dim3(256), 0, stream, a->planes, a->n_pad, (unsigned)a->n, budget,
-                       nn_list_max, masks, groups, cntP, cntN, gcnt, gcnt + groups, flags, flag_words, d_flag);
+                       nn_list_max, masks, groups, cntP, cntN, gcnt, gcnt + groups, gcnt + 2 * groups, flags, flag_words, d_flag);
     stage_mark("classify", stream);
-    hipLaunchKernelGGL(group_offsets_kernel, dim3(9), dim3(1024), 0, stream, masks, gcnt, groups, offs, off64, totals);
+    hipLaunchKernelGGL(group_offsets_kernel, dim3(10), dim3(1024), 0, stream, masks, gcnt, groups, offs, off64, totals);
     unsigned long long tot[16] = {0};
     TRACS_HIP_CHECK(hipMemcpyAsync(tot, totals, 128, hipMemcpyDeviceToHost, stream));
     TRACS_HIP_CHECK(hipStreamSynchronize(stream));
@@ -605,6 +606,7 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     if (!ok) { site_classes_free(a); a->classes_state = -1; set_error("site_classes_decide: re-pack failed"); return TRACS_E_HIP; }
     a->L_var = L_dense; a->L_inv = L_count; a->groups_var = gv; a->groups_inv = gi;
     a->L_minor = L_minor; a->L_full = L_full; a->L_un = L_un; a->L_nnl = L_nnl;
+    a->nn_visits = tot[9]; a->list_entries_n = tot_n; a->list_entries_p = tot_p;
     a->count_in_place = in_place;
     a->classes_cons = consensus;
     a->classes_state = 1;
