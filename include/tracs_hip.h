@@ -115,6 +115,11 @@ void *tracs_alignment_planes(const tracs_alignment *a);   /* device pointer of t
 /* The planes were written through that pointer from outside the library (e.g. an RCCL broadcast from the rank that packed):
  * forget every cached derived form (consensus planes, sparse lists, tile schedule stay valid per geometry).          */
 int tracs_alignment_touch(tracs_alignment *a);
+/* Multi-GPU ranks (every rank holds the whole alignment and computes its row panels): this handle will only be
+ * asked for rows inside the given [begin, end) ranges (up to 2; n_ranges = 0 lifts the promise).  What is built once per pack
+ * PER ROW -- the per-sample lists of the site classes -- is then built for those rows only (1 / ranks of that work); a dense
+ * call for other rows fails with TRACS_E_ARG rather than returning results from lists that were never built.                */
+int tracs_alignment_hint_rows(tracs_alignment *a, const size_t *ranges, int n_ranges);
 /* Pack `count` samples of ASCII (IUPAC, any case; load_seqs pairsnp.hpp:107-199) into samples
  * [first, first+count).  `ascii` is count*L bytes, row-major; host or device pointer
  * (ascii_on_device).  The pack itself is a HIP kernel either way.                           */

@@ -1,6 +1,7 @@
 """BASELINE.json's parity configs at (or near) full size, through exact oracle checks where the oracle finishes in
 seconds on the GPU box's host cores and through size-independent properties otherwise."""
 import os
+import socket
 import sys
 
 import numpy as np
@@ -141,6 +142,50 @@ def test_multirank_driver_path_on_one_gpu():
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "VERIFY gathered == single-pass: True" in out.stderr
     assert '"n_gpus": 2' in out.stdout and '"scaling": "strong"' in out.stdout
+    assert "4 bytes per cell" in out.stdout                    # d and nn both fit the 16-bit exchange at this size
+
+
+def test_rccl_communicator_world_one():
+    """The collectives of the N > 1 paths through the RCCL backend itself ("nccl" on ROCm), on a world of one rank: the only
+    RCCL configuration a single-GPU box can run.  A communicator is created, and the calls partition.py / bench.py make --
+    all_gather into row slices of a matrix (int32 panels and the byte views of the 16-bit exchange), all_reduce (SUM of a key
+    table, MAX of the exchange's three scalars), send-free gather_coo -- execute on it."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from tracs_amd import partition
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="%d", RANK="0", WORLD_SIZE="1")
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+m = torch.arange(128 * 50, dtype=torch.int32, device=dev).reshape(128, 50)
+out = torch.zeros_like(m)
+w = dist.all_gather([out[0:64]], m[0:64], async_op=True); w.wait()
+dist.all_gather([out[64:128].view(torch.uint8)], m[64:128].view(torch.uint8))
+assert bool(torch.equal(out, m))
+t = torch.ones((2, 7, 9), dtype=torch.float64, device=dev)
+dist.all_reduce(t); assert float(t.sum()) == 126.0
+v = torch.tensor([3, -5, 9], dtype=torch.int64, device=dev)
+dist.all_reduce(v, op=dist.ReduceOp.MAX); assert v.tolist() == [3, -5, 9]
+cp = partition.CompactPanels(100, 0, 1, dist)
+d = torch.triu(torch.randint(0, 60000, (128, 100), dtype=torch.int32, device=dev), 1)
+nn = torch.triu(torch.randint(4000000, 4060000, (128, 100), dtype=torch.int32, device=dev), 1)
+assert cp.decide(d, nn)[:2] == (True, True) and cp.check(d, nn)
+got = partition.gather_coo({0: (torch.arange(4, device=dev),), 1: (torch.arange(3, device=dev),)}, 1, 0, dist)
+assert got[0].tolist() == [0, 1, 2, 3, 0, 1, 2]
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL OK", torch.cuda.nccl.version() if hasattr(torch.cuda, "nccl") else "")
+"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = subprocess.run([sys.executable, "-c", code % (root, port)], capture_output=True, text=True, timeout=600, cwd=root,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
+    assert out.returncode == 0 and "RCCL OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
 @pytest.mark.parametrize("mode", ["plain", "thresholded+filter+db"])

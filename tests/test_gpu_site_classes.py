@@ -271,3 +271,39 @@ def test_cost_model_never_loses_to_the_dense_pass(regime, hiplib, oracle):
         assert pass_on <= 1.1 * pass_off, (regime, pass_on, pass_off)
         assert first_on <= 1.1 * first_off, (regime, first_on, first_off)
     aln.close()
+
+
+def test_row_hint_builds_lists_for_those_rows_only(hiplib, oracle):
+    """tracs_alignment_hint_rows (multi-GPU ranks): the per-sample lists of the site classes exist for the promised rows only --
+    results on those rows are the oracle's, a call for other rows fails, lifting the promise rebuilds."""
+    import torch
+    from tracs_amd import device as dev
+    n, L = 700, 9000
+    seqs = _structured(n, L, seed=91, mu=3e-4, p_n=0.01)
+    er, ec, ed, enn = oracle.pairsnp_arrays(seqs, n_threads=8)
+    ri, ci = er.astype(np.int64), ec.astype(np.int64)
+    aln = dev.Alignment(n, L)
+    aln.pack(seqs)
+    d = torch.zeros((n, n), dtype=torch.int32, device="cuda")
+    nn = torch.zeros_like(d)
+    try:
+        hiplib.tracs_debug_force_site_classes(1)
+        ranges = [(64, 192), (500, 700)]
+        aln.hint_rows(ranges)
+        for r0, r1 in ranges:
+            dev.pairsnp_dense(aln, d, nn, row_begin=r0, row_end=r1)
+        assert aln.site_classes is not None and aln.site_classes[2] > 0
+        sel = ((ri >= 64) & (ri < 192)) | (ri >= 500)
+        assert np.array_equal(d.cpu().numpy()[ri[sel], ci[sel]], ed[sel].astype(np.int32))
+        assert np.array_equal(nn.cpu().numpy()[ri[sel], ci[sel]], enn[sel].astype(np.int32))
+        with pytest.raises(RuntimeError, match="hint_rows"):
+            dev.pairsnp_dense(aln, d, nn, row_begin=0, row_end=64)
+        with pytest.raises(RuntimeError, match="hint_rows"):
+            dev.pairsnp_dense(aln, d, nn)
+        aln.hint_rows([])
+        d.zero_(); nn.zero_()
+        dev.pairsnp_dense(aln, d, nn)
+        assert np.array_equal(d.cpu().numpy()[ri, ci], ed.astype(np.int32)) and np.array_equal(nn.cpu().numpy()[ri, ci], enn.astype(np.int32))
+    finally:
+        hiplib.tracs_debug_force_site_classes(-2)
+    aln.close()

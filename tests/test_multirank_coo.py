@@ -61,7 +61,7 @@ def _worker(rank, world, port, n, L, thr, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,thr", [(2, 41, 2147483647), (2, 64, 9), (3, 50, 12)])
+@pytest.mark.parametrize("world,n,thr", [(2, 41, 2147483647), (2, 64, 9), (3, 50, 12), (4, 70, 2147483647), (8, 129, 14)])
 def test_coo_gather_and_edge_clustering_gloo(world, n, thr):
     import torch.multiprocessing as mp
     port = _free_port()

@@ -1,5 +1,5 @@
-"""The N > 1 path on CPU: two gloo ranks run the row-panel partition and the panel all-gather that
-bench.py / the multi-GPU driver use (tracs_amd/partition.py), with the oracle standing in for the kernel."""
+"""The N > 1 path on CPU: 2, 3, 4 and 8 gloo ranks run the row-panel partition and the panel all-gather that bench.py / the
+multi-GPU driver use (tracs_amd/partition.py) -- 32-bit panels and the 16-bit exchange --, with the oracle standing in for the kernel."""
 import os
 import socket
 import sys
@@ -41,20 +41,30 @@ def _worker(rank, world, port, n, L, seed, ret):
             nmat[r[sel].astype(np.int64), c[sel].astype(np.int64)] = torch.from_numpy(nn[sel].astype(np.int32))
             mine += int(sel.sum())
             assert int(sel.sum()) == partition.pairs_in_rows(n, r0, r1)
-        for w in partition.gather_panels((dmat, nmat), n, rank, world, dist, align=8, async_op=(n % 2 == 0)):
-            w.wait()
+        if n % 3 == 1:
+            # the 16-bit exchange (partition.CompactPanels): d < 65 536 here; nn spans less than 65 536 around L
+            cp = partition.CompactPanels(n, rank, world, dist, align=8)
+            mode = cp.decide(dmat, nmat)
+            assert mode[0] and mode[1] and cp.bytes_per_cell() == 4 and cp.check(dmat, nmat)
+            cp.post(0, dmat, nmat, async_op=(n % 2 == 0))
+            cp.finish(0, dmat, nmat)
+        else:
+            for w in partition.gather_panels((dmat, nmat), n, rank, world, dist, align=8, async_op=(n % 2 == 0)):
+                w.wait()
         r, c, d, nn = O.pairsnp_planes(planes, L)
         full_d = torch.zeros((cs * nchunk, n), dtype=torch.int32)
         full_n = torch.zeros((cs * nchunk, n), dtype=torch.int32)
         full_d[r.astype(np.int64), c.astype(np.int64)] = torch.from_numpy(d.astype(np.int32))
         full_n[r.astype(np.int64), c.astype(np.int64)] = torch.from_numpy(nn.astype(np.int32))
-        ok = bool(torch.equal(dmat, full_d) and torch.equal(nmat, full_n))
+        # (the 16-bit exchange carries the cells (i, j > i) only: whatever sits on or below the diagonal is not part of the result)
+        up = torch.triu(torch.ones((cs * nchunk, n), dtype=torch.bool), diagonal=1)
+        ok = bool(torch.equal(dmat[up], full_d[up]) and torch.equal(nmat[up], full_n[up]))
         ret[rank] = (ok, mine)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n", [(2, 37), (2, 64), (3, 50)])
+@pytest.mark.parametrize("world,n", [(2, 37), (2, 64), (3, 50), (4, 128), (4, 61), (8, 130), (8, 256)])
 def test_partition_and_gather_gloo(world, n):
     import torch.multiprocessing as mp
     port = _free_port()

@@ -68,6 +68,8 @@ struct tracs_alignment {
                                               // nn = L - c_i - c_j + NN comes from it alone and the pair kernels write d only
     bool classes_cons = false;                // vplanes hold consensus planes (X, Y, V) / the five general planes
     tracs::GeneralSparse *minor = nullptr;    // lists of the minority sites (site_classes.hip)
+    size_t row_hint[4] = {0, 0, 0, 0};   // tracs_alignment_hint_rows: the only rows this handle will be asked for
+    int n_row_hint = 0;
     int classes_state = 0;       // 0 not decided, 1 in use, -1 not in use for this alignment
     // Arena for what is built once per pack (vplanes, iplanes, N counts, minority lists): reserved together with the planes at
     // tracs_alignment_create, because a fresh device allocation costs ~24 ms per GB on this platform (the driver clears VRAM) and

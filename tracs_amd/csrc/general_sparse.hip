@@ -543,6 +543,12 @@ __global__ __launch_bounds__(256) void minor_site_lists_kernel(const MinorBuild 
     }
 }
 
+__device__ __forceinline__ bool minor_row_wanted(const MinorBuild &mb, size_t s)
+{
+    if (mb.n_rows == 0) return true;
+    return (s >= mb.rows[0] && s < mb.rows[1]) || (mb.n_rows > 1 && s >= mb.rows[2] && s < mb.rows[3]);
+}
+
 // per-sample lists, N entries: thread = (sample, chunk of groups), lanes over samples.  FILL = false: cnt[s * NCH + chunk] =
 // the sample's N sites among the chunk's sites with lists; FILL = true: entries from off[s * NCH + chunk] on:
 //     rank << 5 | 15        N at a minority site                                (general_fixup_kernel<MINOR>)
@@ -556,7 +562,7 @@ __global__ __launch_bounds__(256) void minor_sample_kernel(const MinorBuild mb, 
 {
     const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
     const size_t chunk = (size_t)blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (s >= n || chunk >= GS_CHUNKS) return;
+    if (s >= n || chunk >= GS_CHUNKS || !minor_row_wanted(mb, s)) return;      // (cnt was zeroed: an unwanted sample's list is empty)
     const size_t g0 = chunk * gpc, g1 = min(groups, g0 + gpc);
     const uint4 *nplane = mb.planes + 4 * n_pad + s;
     unsigned c = 0;
@@ -582,19 +588,21 @@ __global__ __launch_bounds__(256) void minor_sample_kernel(const MinorBuild mb, 
     if (!FILL) cnt[s * MS_NCH + chunk] = c;
 }
 
-// per-sample lists, listed entries (from E).  FILL = false: cnt[s * NCH + GS_CHUNKS]++ and c_p[s] += w.
+// per-sample lists, listed entries (from E).  FILL = false: cnt[s * NCH + GS_CHUNKS]++ and c_p[s] += w (c_p of EVERY sample: a
+// row's cells need their column samples' sums too, whichever rows the lists are built for).
 template <bool FILL>
-__global__ __launch_bounds__(256) void minor_listed_kernel(const uint2 *__restrict__ E, unsigned long long count, unsigned *__restrict__ cnt,
+__global__ __launch_bounds__(256) void minor_listed_kernel(const MinorBuild mb, const uint2 *__restrict__ E, unsigned long long count, unsigned *__restrict__ cnt,
                                                            unsigned *__restrict__ c_p, const unsigned long long *__restrict__ off,
                                                            unsigned *__restrict__ cur, unsigned *__restrict__ ent)
 {
     const unsigned long long k = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (k >= count) return;
     const uint2 e = E[k];
+    const bool wanted = minor_row_wanted(mb, e.x);
     if (!FILL) {
-        atomicAdd(&cnt[(size_t)e.x * MS_NCH + GS_CHUNKS], 1u);
+        if (wanted) atomicAdd(&cnt[(size_t)e.x * MS_NCH + GS_CHUNKS], 1u);
         if (e.y & 16u) atomicAdd(&c_p[e.x], 1u);
-    } else {
+    } else if (wanted) {
         ent[off[(size_t)e.x * MS_NCH + GS_CHUNKS] + atomicAdd(&cur[e.x], 1u)] = e.y;
     }
 }
@@ -654,13 +662,13 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb, hipStream_t s
     const dim3 sgrid((unsigned)((n + 63) / 64), GS_CHUNKS / 4);
     const unsigned egrid = (unsigned)((mb.tot_p + 255) / 256);
     hipLaunchKernelGGL((minor_sample_kernel<false>), sgrid, dim3(256), 0, stream, mb, a->n_pad, n, groups, gpc, cnt, nullptr, nullptr);
-    if (egrid) hipLaunchKernelGGL((minor_listed_kernel<false>), dim3(egrid), dim3(256), 0, stream, E, mb.tot_p, cnt, g->c_p, nullptr, nullptr, nullptr);
+    if (egrid) hipLaunchKernelGGL((minor_listed_kernel<false>), dim3(egrid), dim3(256), 0, stream, mb, E, mb.tot_p, cnt, g->c_p, nullptr, nullptr, nullptr);
     hipLaunchKernelGGL(gs_scan_kernel, dim3(1), dim3(1024), 0, stream, cnt, nsc, off);
     unsigned long long *d_max = reinterpret_cast<unsigned long long *>(cur + ((std::max<size_t>(n, 1) + 1) & ~(size_t)1));     // behind `cur`
     GS_TRY(hipMemsetAsync(d_max, 0, 8, stream));
     hipLaunchKernelGGL(minor_sample_offsets_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, stream, off, n, g->s_off, d_max);
     hipLaunchKernelGGL((minor_sample_kernel<true>), sgrid, dim3(256), 0, stream, mb, a->n_pad, n, groups, gpc, nullptr, off, g->s_ent);
-    if (egrid) hipLaunchKernelGGL((minor_listed_kernel<true>), dim3(egrid), dim3(256), 0, stream, E, mb.tot_p, nullptr, nullptr, off, cur, g->s_ent);
+    if (egrid) hipLaunchKernelGGL((minor_listed_kernel<true>), dim3(egrid), dim3(256), 0, stream, mb, E, mb.tot_p, nullptr, nullptr, off, cur, g->s_ent);
     GS_TRY(hipMemcpyAsync(&g->max_row, d_max, 8, hipMemcpyDeviceToHost, stream));       // (read after the caller's synchronisation)
     GS_TRY(hipGetLastError());
     pack_stage_mark("minority lists: per sample", stream);

@@ -714,6 +714,21 @@ int tracs_alignment_touch(tracs_alignment *a)
     return TRACS_OK;
 }
 
+int tracs_alignment_hint_rows(tracs_alignment *a, const size_t *ranges, int n_ranges)
+{
+    if (!a || n_ranges < 0 || n_ranges > 2 || (n_ranges && !ranges)) { set_error("tracs_alignment_hint_rows: 0 to 2 row ranges"); return TRACS_E_ARG; }
+    for (int k = 0; k < n_ranges; k++)
+        if (ranges[2 * k] > ranges[2 * k + 1]) { set_error("tracs_alignment_hint_rows: bad range"); return TRACS_E_ARG; }
+    DeviceCall guard(nullptr);
+    bool same = n_ranges == a->n_row_hint;
+    for (int k = 0; same && k < 2 * n_ranges; k++) same = ranges[k] == a->row_hint[k];
+    if (same) return TRACS_OK;
+    a->n_row_hint = n_ranges;
+    for (int k = 0; k < 4; k++) a->row_hint[k] = k < 2 * n_ranges ? ranges[k] : 0;
+    a->dirty = true;                   // lists built for other rows (or for all of them) are re-decided
+    return TRACS_OK;
+}
+
 int tracs_alignment_pack(tracs_alignment *a, const uint8_t *ascii, size_t first, size_t count, int ascii_on_device,
                          void *stream_)
 {
@@ -864,6 +879,11 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
     if (row_end > a->n) row_end = a->n;
     if (row_begin >= row_end || a->n < 2) return TRACS_OK;
     if (ld < a->n) { set_error("tracs_pairsnp_dense: ld < n"); return TRACS_E_ARG; }
+    if (a->n_row_hint) {
+        bool inside = false;
+        for (int k = 0; k < a->n_row_hint; k++) inside = inside || (row_begin >= a->row_hint[2 * k] && row_end <= std::min(a->n, a->row_hint[2 * k + 1]));
+        if (!inside) { set_error("tracs_pairsnp_dense: rows outside the ranges given to tracs_alignment_hint_rows"); return TRACS_E_ARG; }
+    }
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     DeviceCall guard(stream);
 

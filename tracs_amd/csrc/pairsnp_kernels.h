@@ -107,6 +107,8 @@ struct MinorBuild {
     const unsigned long long *baseP, *baseN; // per group: list entries (listed samples / N samples) of the sites before it
     const unsigned long long *flags;         // per group and 64 samples: listed somewhere in the group
     size_t flag_words;
+    unsigned rows[4];                        // per-sample lists only for the samples of these [begin, end) ranges (n_rows of them;
+    int n_rows;                              //  0: every sample) -- tracs_alignment_hint_rows
     size_t sites;                            // sites with lists
     unsigned long long tot_p, tot_n;         // list entries in all
 };

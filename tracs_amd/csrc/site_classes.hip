@@ -595,6 +595,8 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
         mb.ref_x = mask_of(M_REFX); mb.ref_y = mask_of(M_REFY); mb.off_lst = off_of(M_LST);
         mb.cntP = cntP; mb.cntN = cntN; mb.baseP = off64; mb.baseN = off64 + groups; mb.flags = flags; mb.flag_words = flag_words;
         mb.sites = L_lst; mb.tot_p = tot_p; mb.tot_n = tot_n;
+        mb.n_rows = a->n_row_hint;
+        for (int k = 0; k < 4; k++) mb.rows[k] = (unsigned)std::min<size_t>(a->row_hint[k], a->n);
         rc = minority_lists_build(a, mb, stream, &built);
         if (rc) { site_classes_free(a); a->classes_state = -1; return rc; }
         if (!built) {                                          // no memory: the same classes with fewer lists

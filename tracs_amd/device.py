@@ -69,6 +69,13 @@ class Alignment:
         """The planes were written from outside the library (a broadcast from another rank): drop every cached derived form."""
         _lib.check(self._L.tracs_alignment_touch(self._h))
 
+    def hint_rows(self, ranges):
+        """A multi-GPU rank's promise: this handle will only be asked for rows inside `ranges` ([(begin, end), ..], at most two;
+        [] lifts it), so what is built per row once per pack is built for those rows only.  Dense calls for other rows fail."""
+        flat = [int(x) for r in ranges for x in r]
+        arr = (C.c_size_t * max(len(flat), 1))(*flat)
+        _lib.check(self._L.tracs_alignment_hint_rows(self._h, arr, len(ranges)))
+
     def pack_codes(self, codes, sample):
         """Pack samples straight from their packed 4-bit allele masks (posterior_codes_device output):
         codes uint8 [(L+1)//2] -> one sample, or uint8 [count, stride >= (L+1)//2] -> samples sample..sample+count-1."""

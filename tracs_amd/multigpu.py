@@ -106,6 +106,9 @@ def pairs_of_rank(aln, i_end, j_start, dist_threshold, rank, world, recomb_filte
     npan = torch.empty_like(dpan)
     parts = {}
     k = 5 if recomb_filter else 4
+    own = [(c * cs, min(i_end, (c + 1) * cs)) for c in sorted(set(partition.rank_chunks(rank, world))) if c * cs < min(i_end, (c + 1) * cs)]
+    if world > 1 and 1 <= len(own) <= 2:
+        aln.hint_rows(own)                                    # per-row structures of the site classes: this rank's rows only
     for c in sorted(set(partition.rank_chunks(rank, world))):
         r0c, r1c = c * cs, min(i_end, (c + 1) * cs)
         acc = [[] for _ in range(k)]

@@ -65,6 +65,128 @@ def gather_panels(mats, n, rank, world, dist, align=64, async_op=False):
     return works
 
 
+class CompactPanels:
+    """The same exchange in 16 bits per cell where the values allow it (half the bytes of the d / nn panels: at 8 ranks the
+    exchange is as long as the compute it hides behind).  d travels as uint16 when every distance is below 65 536; nn travels as
+    uint16 offsets from the smallest count when the counts span less than 65 536 (the compared-sites counts of an alignment
+    cluster near L - 2 p_N L).  Decided once by `decide()` from the first pass's panels (an all-reduce of three scalars), int32
+    whenever a matrix does not fit -- and a later pass that no longer fits is caught (`check`) rather than truncated.
+
+    Two staging buffers of int16 per matrix and set; `post(k)` narrows this rank's rows and enqueues the all-gathers,
+    `finish(k)` waits and widens the other ranks' rows into the int32 matrices."""
+
+    def __init__(self, n, rank, world, dist, align=64):
+        self.n, self.rank, self.world, self.dist, self.align = n, rank, world, dist, align
+        self.cs, self.nchunk = row_chunks(n, world, align)
+        self.mode = None                       # (d16, nn16, nn_base) after decide()
+        self.stage = {}
+        self.pending = {}
+
+    def _mine(self, m):
+        return [m[c * self.cs:(c + 1) * self.cs] for c in rank_chunks(self.rank, self.world)]
+
+    def _valid_rows(self, c):
+        return max(0, min(self.n, (c + 1) * self.cs) - c * self.cs)
+
+    def decide(self, dmat, nmat):
+        """From this rank's panels (upper-triangle cells only): d16 / nn16 / nn_base, agreed over the ranks."""
+        import torch
+        big = 2 ** 31 - 1
+        dmax = torch.zeros((), dtype=torch.int64, device=dmat.device)
+        nmin = torch.full((), big, dtype=torch.int64, device=dmat.device)
+        nmax = torch.zeros((), dtype=torch.int64, device=dmat.device)
+        for c in rank_chunks(self.rank, self.world):
+            rows = self._valid_rows(c)
+            if rows <= 0:
+                continue
+            r0 = c * self.cs
+            upper = torch.triu(torch.ones((rows, self.n), dtype=torch.bool, device=dmat.device), diagonal=r0 + 1)
+            if bool(upper.any()):
+                dmax = torch.maximum(dmax, dmat[r0:r0 + rows][upper].max().to(torch.int64))
+                nmin = torch.minimum(nmin, nmat[r0:r0 + rows][upper].min().to(torch.int64))
+                nmax = torch.maximum(nmax, nmat[r0:r0 + rows][upper].max().to(torch.int64))
+        v = torch.stack([dmax, -nmin, nmax])
+        if self.world > 1:
+            self.dist.all_reduce(v, op=self.dist.ReduceOp.MAX)
+        dmax, nmin, nmax = int(v[0]), -int(v[1]), int(v[2])
+        d16 = 0 <= dmax < 65536
+        nn16 = nmin <= nmax and nmax - nmin < 65536
+        self.mode = (d16, nn16, nmin if nn16 else 0)
+        return self.mode
+
+    def bytes_per_cell(self):
+        d16, nn16, _ = self.mode
+        return (2 if d16 else 4) + (2 if nn16 else 4)
+
+    def _buf(self, k, which, like):
+        import torch
+        key = (k, which)
+        if key not in self.stage:
+            self.stage[key] = torch.zeros((self.cs * self.nchunk, like.shape[1]), dtype=torch.int16, device=like.device)
+        return self.stage[key]
+
+    def post(self, k, dmat, nmat, async_op=True):
+        """Enqueue the exchange of set k's panels; matrices that do not fit 16 bits go as they are (gather_panels)."""
+        import torch
+        d16, nn16, base = self.mode
+        works, wide = [], []
+        for which, m, narrow, off in (("d", dmat, d16, 0), ("n", nmat, nn16, base)):
+            if not narrow:
+                wide.append(m)
+                continue
+            st = self._buf(k, which, m)
+            for c in rank_chunks(self.rank, self.world):
+                rows = self._valid_rows(c)
+                if rows > 0:
+                    blk = m[c * self.cs:c * self.cs + rows]
+                    # cells on or below the diagonal are never written by the kernels: whatever they hold is masked to 16 bits
+                    st[c * self.cs:c * self.cs + rows] = ((blk - off) & 0xFFFF).to(torch.int16)
+            # (neither RCCL nor gloo has a 16-bit integer type: the panels travel as bytes -- an all-gather only copies)
+            works += gather_panels((st.view(torch.uint8),), self.n, self.rank, self.world, self.dist, self.align, async_op=async_op)
+        if wide:
+            works += gather_panels(tuple(wide), self.n, self.rank, self.world, self.dist, self.align, async_op=async_op)
+        self.pending[k] = works
+        return works
+
+    def finish(self, k, dmat, nmat):
+        """Wait for set k's exchange and widen the other ranks' rows into the int32 matrices."""
+        import torch
+        for w in self.pending.pop(k, []):
+            if w is not None:
+                w.wait()
+        d16, nn16, base = self.mode
+        mine = set(rank_chunks(self.rank, self.world))
+        for which, m, narrow, off in (("d", dmat, d16, 0), ("n", nmat, nn16, base)):
+            if not narrow:
+                continue
+            st = self._buf(k, which, m)
+            for c in range(self.nchunk):
+                rows = self._valid_rows(c)
+                if c in mine or rows <= 0:
+                    continue
+                m[c * self.cs:c * self.cs + rows] = (st[c * self.cs:c * self.cs + rows].to(torch.int32) & 0xFFFF) + off
+
+    def check(self, dmat, nmat):
+        """True while this rank's panels still fit the decided widths (upper-triangle cells)."""
+        import torch
+        d16, nn16, base = self.mode
+        ok = True
+        for c in rank_chunks(self.rank, self.world):
+            rows = self._valid_rows(c)
+            if rows <= 0:
+                continue
+            r0 = c * self.cs
+            upper = torch.triu(torch.ones((rows, self.n), dtype=torch.bool, device=dmat.device), diagonal=r0 + 1)
+            if not bool(upper.any()):
+                continue
+            if d16:
+                ok = ok and int(dmat[r0:r0 + rows][upper].max()) < 65536
+            if nn16:
+                v = nmat[r0:r0 + rows][upper]
+                ok = ok and int(v.min()) >= base and int(v.max()) - base < 65536
+        return ok
+
+
 def chunk_owner(c, world):
     """Rank that owns row chunk c (0 <= c < 2 * world) under the fold pairing."""
     return c if c < world else 2 * world - 1 - c
