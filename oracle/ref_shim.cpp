@@ -34,7 +34,10 @@ static std::vector<double> ref_lgamma_table()
     return lg;
 }
 
-PYBIND11_MODULE(_tracs_ref, m)
+#ifndef REF_MODULE_NAME
+#define REF_MODULE_NAME _tracs_ref
+#endif
+PYBIND11_MODULE(REF_MODULE_NAME, m)
 {
     m.doc() = "reference TRACS transcluster/dmultinomial, compiled in place (oracle/_ref)";
     m.def("ref_trans_dist", [](const std::vector<int> &n, const std::vector<double> &d, double lamb,

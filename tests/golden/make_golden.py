@@ -91,6 +91,45 @@ def transcluster_large_n():
     jdump("transcluster_golden_large_n.json", {"trans_dist": grids})
 
 
+def transcluster_outbreak():
+    """4 000 outbreak-scale keys at the CLI defaults (N <= 80 SNPs, 1..730 days, lamb = 29.903, beta = 73, precision 0.01) -- the
+    regime TRACS is used in, where a few percent of the keys have their E(K) stopping point decided by rounding ('ill').  Three
+    columns: the reference as shipped (oracle/_ref: setup.py's -ffast-math), the SAME source compiled IEEE-strict
+    (oracle/_ref/_tracs_ref_strict), and the oracle's conditioning class.  Each build runs in its own child process (loading the
+    fast-math library switches a process to flush-to-zero)."""
+    rng = np.random.default_rng(20261003)
+    n_keys = 4000
+    N = rng.integers(0, 81, n_keys)
+    days = rng.integers(1, 731, n_keys)
+    lamb, beta, thr = 1e-3 * 29903, 73.0, 0.01
+    with tempfile.TemporaryDirectory() as tmp:
+        f = os.path.join(tmp, "keys.npz")
+        np.savez(f, N=N, days=days)
+        code = ("import sys, json, numpy as np\n"
+                "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+                "import importlib; M = importlib.import_module(sys.argv[2])\n"
+                "z = np.load(sys.argv[1]); N = z['N'].tolist(); d = (z['days'].astype(np.float64) * 86400.0 / 31556952.0).tolist()\n"
+                "p0, ek = M.ref_trans_dist(N, d, %r, %r, %r)\n"
+                "out = {'p0': list(p0), 'eK': list(ek)}\n"
+                "if sys.argv[2].endswith('strict'):\n"
+                "    from oracle import oracle as O\n"
+                "    out['cls'] = [O.ek_conditioning(int(n), float(x), %r, %r, %r)[0] for n, x in zip(N, d)]\n"
+                "print(json.dumps(out))\n" % (ROOT, os.path.join(ROOT, "oracle", "_ref"), lamb, beta, thr, lamb, beta, thr))
+        res = {}
+        for mod in ("_tracs_ref", "_tracs_ref_strict"):
+            o = subprocess.run([sys.executable, "-c", code, f, mod], capture_output=True, text=True, timeout=7200)
+            assert o.returncode == 0, o.stderr[-2000:]
+            res[mod] = json.loads(o.stdout.strip().splitlines()[-1])
+    fast, strict = res["_tracs_ref"], res["_tracs_ref_strict"]
+
+    def clean(v):
+        return [x if np.isfinite(x) else None for x in v]
+    jdump("transcluster_outbreak_golden.json",
+          {"lamb": lamb, "beta": beta, "thr": thr, "N": N.tolist(), "days": days.tolist(),
+           "p0": fast["p0"], "eK": clean(fast["eK"]), "eK_strict_build": clean(strict["eK"]), "conditioning": strict["cls"],
+           "note": "eK: the reference as shipped (-ffast-math); eK_strict_build: the same headers compiled without it; null = inf / nan"})
+
+
 def posteriors():
     counts = synth.allele_counts(4000, seed=11, depth=20, p_two=0.08).astype(np.float64)
     counts[:40] = 0
@@ -250,6 +289,9 @@ def python_reference():
 
 
 if __name__ == "__main__":
+    if sys.argv[1:] == ["outbreak"]:             # only the fixture added in round 3
+        transcluster_outbreak()
+        sys.exit(0)
     if sys.argv[1:] == ["large-n"]:              # only the fixture added in round 2
         transcluster_large_n()
         sys.exit(0)

@@ -255,7 +255,7 @@ def test_config5_edge_clustering_two_ranks_equals_one():
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = os.path.join(root, "scripts", "bench_config5.py")
-    one = subprocess.run([sys.executable, script, "--samples", "6100", "--check", "6100"], capture_output=True, text=True, cwd=root, timeout=600)
+    one = subprocess.run([sys.executable, script, "--samples", "6100", "--check", "6100", "--clusters", "1500"], capture_output=True, text=True, cwd=root, timeout=600)
     assert one.returncode == 0, one.stderr[-3000:]
     r1 = json.loads(one.stdout.strip().splitlines()[-1])
     assert r1["scipy_check"] is True and r1["edges_rank0_chunks"] > 1000 and 1 < r1["components"] < 6100
@@ -265,7 +265,7 @@ def test_config5_edge_clustering_two_ranks_equals_one():
     s.close()
     env = dict(os.environ, TRACS_DIST_BACKEND="gloo")
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(port), script, "--samples", "6100", "--gpus", "2"], capture_output=True, text=True,
+                          "--master-port", str(port), script, "--samples", "6100", "--gpus", "2", "--clusters", "1500"], capture_output=True, text=True,
                          cwd=root, env=env, timeout=600)
     assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-3000:]
     r2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])

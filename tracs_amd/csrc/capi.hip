@@ -7,7 +7,9 @@
 #include "fasta.h"
 
 #include <algorithm>
+#include <chrono>
 #include <csignal>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -66,6 +68,24 @@ void workspace_release_all()
 }  // namespace tracs
 
 using namespace tracs;
+
+// TRACS_STAGE_TRACE=1: wall time of the stages of the host-level entry points on stderr, one "[stage] name seconds" line each
+// (scripts/bench_e2e.py collects them into the end-to-end table of DESIGN.md 5)
+struct StageClock {
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    StageClock() : on(std::getenv("TRACS_STAGE_TRACE") != nullptr), t(std::chrono::steady_clock::now()) {}
+    void mark(const char *name, double bytes = 0.0)
+    {
+        if (!on) return;
+        (void)hipDeviceSynchronize();
+        const auto now = std::chrono::steady_clock::now();
+        const double s = std::chrono::duration<double>(now - t).count();
+        if (bytes > 0.0) std::fprintf(stderr, "[stage] %s %.4f s (%.2f GB/s)\n", name, s, bytes / s / 1e9);
+        else std::fprintf(stderr, "[stage] %s %.4f s\n", name, s);
+        t = std::chrono::steady_clock::now();
+    }
+};
 
 // dst[base + t] = src[t] (uint32 -> uint64) on several host threads: at 5 x 10^7 pairs the five result columns are 2 GB
 static void widen_append(std::vector<uint64_t> &dst, const unsigned *src, size_t count)
@@ -153,6 +173,7 @@ int tracs_alignment_from_fasta(const char *const *fasta, int n_fasta, tracs_alig
     if (!fasta || !out || n_fasta < 1 || n_fasta > 2) { set_error("Invalid number of fasta files!"); return TRACS_E_ARG; }
     FastaData fd;
     size_t n0 = 0;
+    StageClock clock;
     for (int f = 0; f < n_fasta; f++) {
         std::string err;
         FastaData one;
@@ -169,9 +190,11 @@ int tracs_alignment_from_fasta(const char *const *fasta, int n_fasta, tracs_alig
             fd.n += one.n;
         }
     }
+    clock.mark("read FASTA (host)", (double)fd.n * (double)fd.L);
     tracs_alignment *a = nullptr;
     int rc = tracs_alignment_create(fd.n, fd.L, &a);
     if (rc) return rc;
+    clock.mark("allocate planes + arena");
     // pack in sample batches of <= 1 GiB of ASCII
     const size_t batch = fd.L ? std::max<size_t>(1, (1ull << 30) / fd.L) : fd.n;
     for (size_t s = 0; s < fd.n && fd.L; s += batch) {
@@ -179,6 +202,7 @@ int tracs_alignment_from_fasta(const char *const *fasta, int n_fasta, tracs_alig
         rc = tracs_alignment_pack(a, fd.seq.data() + s * fd.L, s, cnt, 0, nullptr);
         if (rc) { tracs_alignment_free(a); return rc; }
     }
+    clock.mark("H2D + pack", (double)fd.n * (double)fd.L);
     if (names_out) {
         size_t bytes = 0;
         for (auto &nm : fd.names) bytes += nm.size() + 1;
@@ -225,6 +249,15 @@ int tracs_pairsnp(const char *const *fasta, int n_fasta, int n_threads, int dist
     };
 #define PS_CHECK(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { cleanup(); delete res; set_error(std::string(#x ": ") + hipGetErrorString(e__)); return TRACS_E_HIP; } } while (0)
 #define PS_RC(x) do { int r__ = (x); if (r__) { cleanup(); delete res; return r__; } } while (0)
+    StageClock clock;
+    double t_dense = 0.0, t_coo = 0.0, t_pull = 0.0, t_filter = 0.0;
+    auto lap = [&](double &acc) {
+        if (!clock.on) return;
+        (void)hipDeviceSynchronize();
+        const auto now = std::chrono::steady_clock::now();
+        acc += std::chrono::duration<double>(now - clock.t).count();
+        clock.t = now;
+    };
     if (n >= 2 && i_end > 0) {
         // row panels bounded to ~1 GiB per dense matrix
         const size_t panel = std::max<size_t>(64, std::min<size_t>(i_end, (1ull << 28) / std::max<size_t>(n, 1)));
@@ -238,7 +271,9 @@ int tracs_pairsnp(const char *const *fasta, int n_fasta, int n_threads, int dist
             const size_t r1 = std::min(i_end, r0 + panel);
             // the dense block is addressed as base[(i) * ld + j] with i absolute: shift the base
             unsigned *bd = d_dist - r0 * n, *bn = d_nn - r0 * n;
+            lap(t_pull);
             PS_RC(tracs_pairsnp_dense_thr(a, r0, r1, j_start, bd, bn, n, dist, nullptr));   // early out beyond `dist`
+            lap(t_dense);
             PS_RC(tracs_coo_count(bd, n, n, r0, r1, j_start, dist, reinterpret_cast<int64_t *>(d_off), nullptr));
             long long total = 0;
             PS_CHECK(hipMemcpy(&total, d_off + (r1 - r0), 8, hipMemcpyDeviceToHost));
@@ -254,6 +289,7 @@ int tracs_pairsnp(const char *const *fasta, int n_fasta, int n_threads, int dist
                 PS_CHECK(hipMalloc(reinterpret_cast<void **>(&d_n), cap * 4));
             }
             PS_RC(tracs_coo_fill(bd, bn, n, n, r0, r1, j_start, dist, reinterpret_cast<int64_t *>(d_off), d_rows, d_cols, d_d, d_n, nullptr));
+            lap(t_coo);
             h32.resize((size_t)total);
             auto pull = [&](unsigned *src, std::vector<uint64_t> &dst) -> hipError_t {
                 hipError_t e = hipMemcpy(h32.data(), src, (size_t)total * 4, hipMemcpyDeviceToHost);
@@ -265,6 +301,7 @@ int tracs_pairsnp(const char *const *fasta, int n_fasta, int n_threads, int dist
             PS_CHECK(pull(d_cols, res->cols));
             PS_CHECK(pull(d_d, res->dist));
             PS_CHECK(pull(d_n, res->ncomp));
+            lap(t_pull);
             if (filter) {
                 // recombination filter on the pairs just emitted, in sub-batches whose SNP-site lists fit 2^28 entries
                 const size_t base = res->dist.size() - (size_t)total;
@@ -306,9 +343,14 @@ int tracs_pairsnp(const char *const *fasta, int n_fasta, int n_threads, int dist
                     widen_append(res->filt, h32.data(), np);
                     t0 = t1;
                 }
+                lap(t_filter);
             }
         }
     }
+    if (clock.on)
+        std::fprintf(stderr, "[stage] dense panels (once-per-pack work + pair kernels) %.4f s\n[stage] COO extraction (device) %.4f s\n"
+                             "[stage] COO D2H + widening to uint64 (%zu pairs) %.4f s\n[stage] recombination filter %.4f s\n",
+                     t_dense, t_coo, res->rows.size(), t_pull, t_filter);
 #undef PS_CHECK
 #undef PS_RC
     // a Ctrl-C that arrived during the last panel / filter batch is not swallowed (the reference looks at its flag on every row)

@@ -17,6 +17,7 @@
 #include "common.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 namespace tracs {
@@ -26,6 +27,7 @@ constexpr int LK_TABLE = 10240;     // log(k) table behind it (the E(K) loop sto
 
 struct TcParams {
     double lamb, beta, thr;
+
     double ln_lamb, ln_beta, ln_lb;   // log(lamb), log(beta), log(lamb+beta): filled on the device
 };
 
@@ -692,6 +694,7 @@ static int run_trans_dist(const Src &src, size_t total, double lamb, double beta
     TcParams P;
     P.lamb = lamb; P.beta = beta; P.thr = thr;
     P.ln_lamb = P.ln_beta = P.ln_lb = 0.0;
+
     // one wave per block: keys differ widely in trip count, small blocks keep the SIMDs busy
     hipLaunchKernelGGL((tc_keys_kernel<Src>), dim3((nk + 63) / 64), dim3(64), 0, stream, src, key_elem, nk, P, lg, key_p0, key_eK,
                        long_ids, n_keys + 1, key_state, kt);

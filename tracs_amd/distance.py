@@ -8,6 +8,7 @@ import argparse
 import ctypes as C
 import logging
 import os
+import sys
 from datetime import date
 
 import numpy as np
@@ -153,13 +154,31 @@ def distance(args):
     if lead:
         with open(args.output_file, "w") as out:
             out.write(HEADER)
+    import time
+    trace = os.environ.get("TRACS_STAGE_TRACE") is not None      # "[stage] name seconds" lines on stderr (scripts/bench_e2e.py)
+    t_stage = [time.perf_counter()]
+    if trace and lead:
+        try:
+            import psutil
+            sys.stderr.write("[stage] process start -> first alignment (interpreter, imports, metadata) %.4f s\n"
+                             % (time.time() - psutil.Process().create_time()))
+        except Exception:
+            pass
+
+    def stage(name):
+        if trace and lead:
+            now = time.perf_counter()
+            sys.stderr.write("[stage] %s %.4f s\n" % (name, now - t_stage[0]))
+            t_stage[0] = now
     for msa in args.msa_files:
         logging.info("Calculating pairwise snp distances for %s", msa)
         msas = [msa, args.msa_db] if args.msa_db is not None else [msa]
+        t_stage[0] = time.perf_counter()
         if ctx is None:
             res = pairsnp_arrays(fasta=msas, n_threads=args.n_cpu, dist=args.snp_threshold, filter=args.recomb_filter)
         else:
             res = _pairs_multi_gpu(msas, args, ctx)
+        stage("pairsnp (total, incl. the copy of the result into numpy arrays)")
         if not lead:
             continue
         rows, cols, snpd, names, filt, ncomp = res
@@ -174,10 +193,12 @@ def distance(args):
                                                     log=False, precision=args.precision)
             if not args.recomb_filter:
                 filt = None                                                     # a column of "NA" (:204)
+            stage("transcluster (dates -> delta, H2D, keys, gather, D2H)")
         logging.info("Saving distances for %s", msa)
         ref = os.path.basename(msa).split(".")[0].replace("_combined", "")      # (:208-209)
         _append_rows(args.output_file, names, rows, cols, snpd, filt, ncomp, ddiff, tdist, ek,
                      args.trans_threshold if with_dates else None, ref)
+        stage("CSV rows (format + write, %d rows)" % len(rows))
     if ctx is not None:
         ctx[0].barrier()
         ctx[0].destroy_process_group()
