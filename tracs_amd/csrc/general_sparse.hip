@@ -690,7 +690,7 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb, hipStream_t s
 // rows with atomics.
 constexpr unsigned NN_MAX_SPLITS = 32;
 #ifndef TRACS_NN_FLIGHT
-#define TRACS_NN_FLIGHT 2
+#define TRACS_NN_FLIGHT 8
 #endif
 #ifndef TRACS_NN_THREADS
 #define TRACS_NN_THREADS 1024
@@ -730,15 +730,29 @@ __global__ __launch_bounds__(TRACS_NN_THREADS) void nn_rows_kernel(const unsigne
         while (todo) {
             unsigned v[NN_FLIGHT][2];
             unsigned long long ta[NN_FLIGHT], tz[NN_FLIGHT];
+            // (1) the list bounds of the next NN_FLIGHT entries of the batch, through the scalar unit (v_readlane with a wave-uniform
+            // lane: a __shfl would be four ds_bpermute -- LDS instructions, on the pipe the ds_add of the walk already fills) and ALL
+            // of them before the first list load goes out: a readlane issued after a load makes hipcc drain vmcnt(0) first, which
+            // serialises the lists; (2) every list's first 128 entries requested; (3) applied
 #pragma unroll
             for (int q = 0; q < NN_FLIGHT; q++) {
-                const int k = todo ? __ffsll((long long)todo) - 1 : -1;    // wave-uniform
-                if (k >= 0) todo &= todo - 1;
-                ta[q] = k >= 0 ? __shfl(na, k, 64) + lane : 0ull;
-                tz[q] = k >= 0 ? __shfl(nz_, k, 64) : 0ull;
+                const int k = __builtin_amdgcn_readfirstlane(todo ? __ffsll((long long)todo) - 1 : -1);
+                unsigned long long sa = 0, sz = 0;
+                if (k >= 0) {
+                    todo &= todo - 1;
+                    sa = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(na >> 32), k) << 32) | (unsigned)__builtin_amdgcn_readlane((int)na, k);
+                    sz = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(nz_ >> 32), k) << 32) | (unsigned)__builtin_amdgcn_readlane((int)nz_, k);
+                }
+                ta[q] = sa + lane;
+                tz[q] = sz;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < NN_FLIGHT; q++) {
                 v[q][0] = ta[q] < tz[q] ? (unsigned)n_ent[ta[q]] : 0xFFFFFFFFu;
                 v[q][1] = ta[q] + 64 < tz[q] ? (unsigned)n_ent[ta[q] + 64] : 0xFFFFFFFFu;
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < NN_FLIGHT; q++) { bump(v[q][0]); bump(v[q][1]); }      // (0xFFFFFFFF >= c1: no bump)
 #pragma unroll
