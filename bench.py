@@ -250,6 +250,14 @@ def main():
     # the panels travel in 16 bits per cell where the values allow it (partition.CompactPanels: decided from the first pass)
     cp = partition.CompactPanels(n, rank, world, dist) if world > 1 else None
 
+    # One GPU: transcluster (f64 key evaluations: compute-bound) only reads the distances, which are final before the compared-
+    # sites counts are -- the rest of the dense call (the N co-occurrence walk over the lists: memory-bound) runs beside it on a
+    # second stream.  TRACS_BENCH_OVERLAP=0: one stream, one after the other.
+    overlap = world == 1 and os.environ.get("TRACS_BENCH_OVERLAP", "1") != "0"
+    side = torch.cuda.Stream(device=device) if overlap else None
+    d_ready = torch.cuda.Event() if overlap else None
+    main_stream = torch.cuda.current_stream()
+
     def step(it):
         k = it % nsets
         dmat, nmat = sets[k]
@@ -258,12 +266,19 @@ def main():
             finish(k)
             pending[k] = None
         # pairsnp: the dominant kernel, bracketed by HIP events on the launch stream
+        if overlap:
+            main_stream.wait_stream(side)                     # the previous step's transcluster has read the distances
+            dev.notify_distances(d_ready)
         ev0[it].record()
         for r0, r1 in ranges:
             dev.pairsnp_dense(aln, dmat, nmat, row_begin=r0, row_end=r1)
         ev1[it].record()
         if world > 1:                                         # the d / nn panels travel while the next step's pair kernel runs
             pending[k] = cp.post(k, dmat, nmat, async_op=True)
+        elif overlap:
+            with torch.cuda.stream(side):
+                side.wait_event(d_ready)
+                finish(k)
         else:
             finish(k)
 
@@ -278,6 +293,8 @@ def main():
     lib = _lib.load()
     lib.tracs_debug_pair_timing(1)
     lib.tracs_debug_pack_timing(1)
+    if overlap:
+        dev.set_stream_policy(True)                           # this script orders its two streams with events
     # ---- ONE pass per alignment is the reference's unit of work (src/pairsnp.hpp:320-457: one pairsnp call per alignment): packed
     # planes resident -> d, nn, P, E(K), INCLUDING what the library decides and builds once per pack (encoding, site classes, the
     # counting pass's source, minority lists; csrc/site_classes.hip).  cold = the first pass of the process (this alignment),
@@ -287,8 +304,13 @@ def main():
         def one_pass(a):
             torch.cuda.synchronize()
             t = time.perf_counter()
+            if overlap:
+                dev.notify_distances(d_ready)
             dev.pairsnp_dense(a, sets[0][0], sets[0][1])
-            dev.trans_dist_dense_ranges(sets[0][0], n, days, args.lamb, args.beta, args.precision, pmat, emat, [(0, n)], exp_p0=True)
+            with torch.cuda.stream(side if overlap else main_stream):
+                if overlap:
+                    side.wait_event(d_ready)
+                dev.trans_dist_dense_ranges(sets[0][0], n, days, args.lamb, args.beta, args.precision, pmat, emat, [(0, n)], exp_p0=True)
             torch.cuda.synchronize()
             return (time.perf_counter() - t) * 1e3
         cold_ms = one_pass(aln)
@@ -328,7 +350,7 @@ def main():
     for it in range(args.warmup, args.warmup + args.steps):
         step(it)
     drain(args.warmup + args.steps)                           # every step's panels have arrived and every matrix is complete on every rank
-    torch.cuda.synchronize()
+    torch.cuda.synchronize()                                  # (both streams)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -424,6 +446,8 @@ def main():
                                        "rank from the gathered d, key evaluations split over the ranks (key-table all-reduce)"
                                        % (world, "" if cp is None else " (%d bytes per cell: 16 bits where the values fit)" % cp.bytes_per_cell()),
                           "workload_name": args.workload,
+                          "streams": ("2: transcluster on a second stream beside the rest of the dense call, from the moment the distances "
+                                      "are final (tracs_pairsnp_notify_distances)") if overlap else "1",
                           "setup_seconds": round(setup_s, 1), "first_call_ms": round(t_first * 1e3, 1), "checksum_d": checksum},
                "roofline": roof}
         if single is not None:

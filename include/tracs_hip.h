@@ -139,6 +139,20 @@ void tracs_free(void *p);
 int tracs_pairsnp_dense(const tracs_alignment *a, size_t row_begin, size_t row_end, size_t col_begin,
                         uint32_t *dist, uint32_t *ncomp, size_t ld, void *stream);
 
+/* Two streams.  The distances of a dense call are final before its compared-sites counts are (site classes: the counting pass and
+ * the N co-occurrence walk only touch ncomp), and transcluster reads distances only.
+ *   tracs_pairsnp_notify_distances(event)  the NEXT dense call on this thread's device records `event` (a hipEvent_t) on its
+ *                                          stream once `dist` is final; a second stream that waits on it can run
+ *                                          tracs_trans_dist_dense* beside the rest of the call (bench.py: memory-bound list walk and
+ *                                          f64-bound key evaluation overlap);
+ *   tracs_set_stream_policy(1)             the caller orders its streams itself (events).  Default 0: a call that arrives on another
+ *                                          stream than the previous call on the device synchronises the device first, because the
+ *                                          library's scratch buffers are only stream-ordered.  With policy 1 calls that share
+ *                                          scratch (two transcluster calls; two first-calls on freshly packed handles) must be
+ *                                          ordered by the caller; a dense call on a decided handle and a transcluster call share none. */
+void tracs_pairsnp_notify_distances(void *event);
+void tracs_set_stream_policy(int caller_orders_streams);
+
 /* Thresholded form: identical (d and nn) for every pair with d <= dist_threshold.  A pair beyond the threshold (never
  * emitted, src/pairsnp.hpp:405) may come back with bit 31 of its distance set (0xFFFFFFFF, or a partial count | 2^31), or
  * (general alignments, and alignments cut into site classes) with a value > threshold that is not its distance, and an unspecified ncomp,

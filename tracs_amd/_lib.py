@@ -19,7 +19,7 @@ SYMBOLS = [
     "tracs_trans_dist", "tracs_lprob_k_given_N", "tracs_calculate_posteriors", "tracs_connected_components",
     "tracs_find_dirichlet_priors", "tracs_find_dirichlet_priors_device",
     "tracs_alignment_create", "tracs_alignment_free", "tracs_alignment_n", "tracs_alignment_len",
-    "tracs_alignment_bytes", "tracs_alignment_planes", "tracs_alignment_touch", "tracs_alignment_hint_rows", "tracs_alignment_pack", "tracs_alignment_from_fasta",
+    "tracs_alignment_bytes", "tracs_alignment_planes", "tracs_alignment_touch", "tracs_alignment_hint_rows", "tracs_pairsnp_notify_distances", "tracs_set_stream_policy", "tracs_alignment_pack", "tracs_alignment_from_fasta",
     "tracs_free",
     "tracs_pairsnp_dense", "tracs_pairsnp_dense_thr", "tracs_coo_count", "tracs_coo_fill", "tracs_filter_recomb_device",
     "tracs_trans_dist_device", "tracs_trans_dist_dense", "tracs_trans_dist_dense2", "tracs_trans_table_dense", "tracs_trans_table_gather",
@@ -200,6 +200,10 @@ def load():
     L.tracs_debug_alignment_kernel.argtypes = [vp]
     L.tracs_debug_alignment_site_classes.restype = C.c_int
     L.tracs_debug_alignment_site_classes.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.tracs_pairsnp_notify_distances.restype = None
+    L.tracs_pairsnp_notify_distances.argtypes = [vp]
+    L.tracs_set_stream_policy.restype = None
+    L.tracs_set_stream_policy.argtypes = [C.c_int]
     L.tracs_alignment_hint_rows.restype = C.c_int
     L.tracs_alignment_hint_rows.argtypes = [vp, C.POINTER(sz), C.c_int]
     L.tracs_debug_alignment_count_source.restype = C.c_int

@@ -46,12 +46,13 @@ int workspace_get(int slot, size_t bytes, void **out)
 static std::recursive_mutex g_call_mu[8];
 static hipStream_t g_last_stream[8];
 static bool g_have_stream[8];
+static bool g_caller_orders_streams = false;     // tracs_set_stream_policy
 
 DeviceCall::DeviceCall(hipStream_t stream) : dev(0)
 {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 8) dev = 0;
     g_call_mu[dev].lock();
-    if (g_have_stream[dev] && g_last_stream[dev] != stream) (void)hipDeviceSynchronize();
+    if (g_have_stream[dev] && g_last_stream[dev] != stream && !g_caller_orders_streams) (void)hipDeviceSynchronize();
     g_last_stream[dev] = stream;
     g_have_stream[dev] = true;
 }
@@ -133,6 +134,8 @@ struct tracs_pairsnp_result {
 };
 
 extern "C" {
+
+void tracs_set_stream_policy(int caller_orders_streams) { g_caller_orders_streams = caller_orders_streams != 0; }
 
 const char *tracs_last_error(void) { return g_error.c_str(); }
 int tracs_abi_version(void) { return 1; }

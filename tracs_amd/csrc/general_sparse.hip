@@ -750,7 +750,11 @@ __global__ __launch_bounds__(TRACS_NN_THREADS) void nn_rows_kernel(const unsigne
 #pragma unroll
             for (int q = 0; q < NN_FLIGHT; q++) {
                 v[q][0] = ta[q] < tz[q] ? (unsigned)n_ent[ta[q]] : 0xFFFFFFFFu;
+#ifdef TRACS_NN_EXPERIMENT_SKIP2
+                v[q][1] = 0xFFFFFFFFu;                         // (timing experiment only: wrong counts)
+#else
                 v[q][1] = ta[q] + 64 < tz[q] ? (unsigned)n_ent[ta[q] + 64] : 0xFFFFFFFFu;
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

@@ -843,6 +843,14 @@ int tracs_debug_last_pair_ms(float *out)
         if (hipEventElapsedTime(&out[k], g_pair_ev[k], g_pair_ev[k + 1]) != hipSuccess) return TRACS_E_HIP;
     return TRACS_OK;
 }
+// tracs_pairsnp_notify_distances: recorded by the next dense call once its distances are final
+static thread_local hipEvent_t g_dist_event = nullptr;
+void tracs_pairsnp_notify_distances(void *event) { g_dist_event = static_cast<hipEvent_t>(event); }
+static inline void dist_final(hipStream_t stream)
+{
+    if (g_dist_event) { (void)hipEventRecord(g_dist_event, stream); g_dist_event = nullptr; }
+}
+
 static inline void pair_mark(int k, hipStream_t stream)
 {
     if (g_pair_timing && g_pair_ev[k]) { (void)hipEventRecord(g_pair_ev[k], stream); if (k == 4) g_pair_ev_valid = true; }
@@ -877,7 +885,7 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
     tracs_alignment *a = const_cast<tracs_alignment *>(a_);
     if (!a || !dist) { set_error("tracs_pairsnp_dense: NULL argument"); return TRACS_E_ARG; }
     if (row_end > a->n) row_end = a->n;
-    if (row_begin >= row_end || a->n < 2) return TRACS_OK;
+    if (row_begin >= row_end || a->n < 2) { dist_final(static_cast<hipStream_t>(stream_)); return TRACS_OK; }
     if (ld < a->n) { set_error("tracs_pairsnp_dense: ld < n"); return TRACS_E_ARG; }
     if (a->n_row_hint) {
         bool inside = false;
@@ -891,6 +899,7 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
         dim3 grid(64, (unsigned)std::min<size_t>(row_end - row_begin, 65535));
         hipLaunchKernelGGL(init_cells_kernel, grid, dim3(256), 0, stream, dist, ncomp, ld, (unsigned)a->n,
                            (unsigned)row_begin, (unsigned)row_end, (unsigned)col_begin, 0u);
+        dist_final(stream);
         TRACS_HIP_CHECK(hipGetLastError());
         return TRACS_OK;
     }
@@ -1019,7 +1028,7 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
     tracs_alignment::TileCache *main_tiles = nullptr;
     { const int rc = ensure_tiles(kTI, kTJ, &main_tiles); if (rc) return rc; }
     const tracs_alignment::TileCache &T = *main_tiles;
-    if (T.n == 0) return TRACS_OK;
+    if (T.n == 0) { dist_final(stream); return TRACS_OK; }
 
     // Split the group range over workgroups (integer atomics, still exact) when that fills the chip better:
     // too few tiles (config 2), or a ragged last round of resident workgroups (tail effect).
@@ -1153,6 +1162,7 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
         int rc = minor_pass();
         if (rc) return rc;
         pair_mark(2, stream);
+        dist_final(stream);
         if ((rc = count_pass(nullptr, 0))) return rc;
         pair_mark(4, stream);
         TRACS_HIP_CHECK(hipGetLastError());
@@ -1189,6 +1199,7 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
         }
         if (mfma_general && (rc = general_sparse_fixup(a, row_begin, row_end, col_begin, dist, ncomp_pair, ld, stream))) return rc;
         if ((rc = minor_pass())) return rc;
+        dist_final(stream);
         if ((rc = count_pass(live_tiles, n_live))) return rc;
         TRACS_HIP_CHECK(hipGetLastError());
         return TRACS_OK;
@@ -1210,6 +1221,7 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
     if (mfma_general && (rc = general_sparse_fixup(a, row_begin, row_end, col_begin, dist, ncomp_pair, ld, stream))) return rc;
     if ((rc = minor_pass())) return rc;
     pair_mark(2, stream);
+    dist_final(stream);
     if ((rc = count_pass(nullptr, 0))) return rc;
     pair_mark(4, stream);
     TRACS_HIP_CHECK(hipGetLastError());

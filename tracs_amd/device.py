@@ -148,6 +148,16 @@ class Alignment:
             pass
 
 
+def notify_distances(event):
+    """The next pairsnp_dense call records `event` (torch.cuda.Event) on its stream once the distances are final -- before the
+    compared-sites counts are (include/tracs_hip.h, "Two streams")."""
+    _lib.load().tracs_pairsnp_notify_distances(C.c_void_p(event.cuda_event))
+
+
+def set_stream_policy(caller_orders_streams):
+    _lib.load().tracs_set_stream_policy(1 if caller_orders_streams else 0)
+
+
 def pack_stages():
     """[(stage, ms), ..] of the last once-per-pack build (encoding decision, site classes, lists), from HIP events on the launch
     stream; recorded when tracs_debug_pack_timing(1) was set before the dense call (diagnostics: bench.py's single_pass)."""
