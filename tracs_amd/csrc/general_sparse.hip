@@ -34,8 +34,14 @@ struct GeneralSparse {
     double est_updates = 0.0;
     unsigned long long tot_s = 0;                 // entries of the per-sample lists
     unsigned long long max_row = 0;               // the longest per-sample list
+    // site-class lists: what nn_rows_kernel walks -- per sample, for every NNL site at which it is N, where the site's N list
+    // starts (in units of 8 entries; the list ends at its sentinel): no lookup of list bounds during the walk
+    unsigned *s_nn = nullptr;
+    unsigned long long *snn_off = nullptr;
+    unsigned long long tot_nn = 0, max_row_nn = 0;
     bool in_arena = false;                        // the arrays live in the alignment's pack arena (released with it, not one by one)
-    bool n16 = false;                             // n_ent holds 16-bit sample numbers (site-class lists of alignments below 65 536 samples)
+    bool n16 = false;                             // n_ent holds 16-bit sample numbers (site-class lists of alignments below 65 535 samples)
+    bool padded = false;                          // N lists start on 16-byte boundaries, padded with all-ones sentinels to 8 entries
 };
 constexpr int ENT_SHIFT = 5;                      // entries: index << 5 | w << 4 | 4-bit code
 
@@ -249,7 +255,7 @@ __global__ __launch_bounds__(1024) void general_fixup_kernel(const unsigned long
         unsigned my_code = 0;
         unsigned long long my_pa = 0, my_pz = 0, my_na = 0, my_nz = 0;
         bool live = e < e1;
-        if (live && MINOR && (s_ent[e] & 15u) == 0u) live = false;     // an N entry at a site without listed samples (nn_rows_kernel's)
+        if (live && MINOR && s_ent[e] == 0xFFFFFFFFu) live = false;    // padding of the stream (written 16 bytes at a time)
         if (live) {
             const unsigned ent = s_ent[e];
             const unsigned site = ent >> ENT_SHIFT;
@@ -346,7 +352,7 @@ __global__ __launch_bounds__(1024) void general_fixup_kernel(const unsigned long
 static void gs_free(GeneralSparse *g)
 {
     if (!g) return;
-    void *p[] = {g->s_off, g->p_off, g->n_off, g->s_ent, g->p_ent, g->n_ent, g->c_n, g->c_p};
+    void *p[] = {g->s_off, g->p_off, g->n_off, g->s_ent, g->p_ent, g->n_ent, g->c_n, g->c_p, g->s_nn, g->snn_off};
     if (!g->in_arena) for (void *q : p) if (q) (void)hipFree(q);
     delete g;
 }
@@ -492,7 +498,7 @@ __global__ __launch_bounds__(256) void minor_site_lists_kernel(const MinorBuild 
     const bool mine = tid < SITES_PER_GROUP && ((m[tw] >> tb) & 1u);
     if (tid < SITES_PER_GROUP) {
         kp[tid] = (mine && ((mp[tw] >> tb) & 1u)) ? mb.cntP[g * SITES_PER_GROUP + tid] : 0u;
-        kn[tid] = mine ? mb.cntN[g * SITES_PER_GROUP + tid] : 0u;
+        kn[tid] = mine ? nn_list_padded(mb.cntN[g * SITES_PER_GROUP + tid]) : 0u;     // (sentinel + padding: see the builder)
         curP[tid] = 0; curN[tid] = 0;
     }
     __syncthreads();
@@ -549,43 +555,95 @@ __device__ __forceinline__ bool minor_row_wanted(const MinorBuild &mb, size_t s)
     return (s >= mb.rows[0] && s < mb.rows[1]) || (mb.n_rows > 1 && s >= mb.rows[2] && s < mb.rows[3]);
 }
 
-// per-sample lists, N entries: thread = (sample, chunk of groups), lanes over samples.  FILL = false: cnt[s * NCH + chunk] =
-// the sample's N sites among the chunk's sites with lists; FILL = true: entries from off[s * NCH + chunk] on:
-//     rank << 5 | 15        N at a minority site                                (general_fixup_kernel<MINOR>)
-//     rank << 5 | 16 | 15   N at a minority site that is an NNL site as well    (both kernels)
-//     rank << 5 | 16 | 0    N at an NNL site without listed samples             (nn_rows_kernel only: the fixup kernel skips code 0)
-static constexpr int MS_NCH = GS_CHUNKS + 1;      // the last "chunk" of a sample's list holds its listed entries
+// per-sample lists: thread = (sample, chunk of groups), lanes over samples.  Two streams per sample:
+//   s_ent  what general_fixup_kernel<MINOR> walks: rank << 5 | 15 for every minority site at which the sample is N (FILL = false:
+//          cnt[s * NCH + chunk] of them), then -- minor_listed_kernel -- its listed entries;
+//   s_nn   what nn_rows_kernel walks: for every NNL site at which the sample is N, the start of the site's N list in units of 8
+//          entries (cntq[s * GS_CHUNKS + chunk] of them).  The list starts of a group's 128 sites are summed once
+//          per wave and group from the sites' (padded) N counts -- a wave prefix sum parked in LDS -- instead of being looked up.
+static constexpr int MS_NCH = GS_CHUNKS + 1;      // the last "chunk" of a sample's s_ent list holds its listed entries
+constexpr unsigned NULL_ENTRY = 0xFFFFFFFFu;      // padding of the per-sample streams: no site (both walks skip it)
 template <bool FILL>
 __global__ __launch_bounds__(256) void minor_sample_kernel(const MinorBuild mb, size_t n_pad, size_t n, size_t groups, size_t gpc,
-                                                           unsigned *__restrict__ cnt, const unsigned long long *__restrict__ off,
-                                                           unsigned *__restrict__ ent)
+                                                           unsigned *__restrict__ cnt, unsigned *__restrict__ cntq,
+                                                           const unsigned long long *__restrict__ off, const unsigned long long *__restrict__ offq,
+                                                           unsigned *__restrict__ ent, unsigned *__restrict__ entq)
 {
+    __shared__ unsigned start8[4][SITES_PER_GROUP];
     const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
-    const size_t chunk = (size_t)blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (s >= n || chunk >= GS_CHUNKS || !minor_row_wanted(mb, s)) return;      // (cnt was zeroed: an unwanted sample's list is empty)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t chunk = (size_t)blockIdx.y * 4 + wave;
+    if (chunk >= GS_CHUNKS) return;                          // (wave-uniform)
+    const bool mine = s < n && minor_row_wanted(mb, s);      // (cnt was zeroed: an unwanted sample's list is empty)
     const size_t g0 = chunk * gpc, g1 = min(groups, g0 + gpc);
-    const uint4 *nplane = mb.planes + 4 * n_pad + s;
-    unsigned c = 0;
-    unsigned long long o = FILL ? off[s * MS_NCH + chunk] : 0ull;
+    const uint4 *nplane = mb.planes + 4 * n_pad + min(s, n_pad - 1);
+    unsigned c = 0, cq = 0;
+    // a thread's entries leave four at a time (one 16-byte store instead of four scattered 4-byte ones: the fill is bound by the
+    // number of store transactions, ~17 ps each, not by bytes)
+    struct Stream4 {
+        uint4 *out;
+        unsigned b0, b1, b2, b3, nb;
+        __device__ __forceinline__ void push(unsigned v)
+        {
+            b0 = b1; b1 = b2; b2 = b3; b3 = v;
+            if (++nb == 4u) { *out++ = make_uint4(b0, b1, b2, b3); nb = 0; }
+        }
+        __device__ __forceinline__ void flush()              // the last 1..3 entries, then null entries
+        {
+            if (nb == 1u) *out = make_uint4(b3, NULL_ENTRY, NULL_ENTRY, NULL_ENTRY);
+            else if (nb == 2u) *out = make_uint4(b2, b3, NULL_ENTRY, NULL_ENTRY);
+            else if (nb == 3u) *out = make_uint4(b1, b2, b3, NULL_ENTRY);
+        }
+    };
+    Stream4 es{(FILL && mine) ? reinterpret_cast<uint4 *>(ent + off[s * MS_NCH + chunk]) : nullptr, 0u, 0u, 0u, 0u, 0u};
+    Stream4 qs{(FILL && mine) ? reinterpret_cast<uint4 *>(entq + offq[s * GS_CHUNKS + chunk]) : nullptr, 0u, 0u, 0u, 0u, 0u};
     for (size_t g = g0; g < g1; g++) {
         const uint4 m4 = mb.lst_mask[g];                      // wave-uniform
         if ((m4.x | m4.y | m4.z | m4.w) == 0u) continue;
-        const uint4 N = nplane[g * NPLANES * n_pad];
-        if (!FILL) { c += __popc(N.x & m4.x) + __popc(N.y & m4.y) + __popc(N.z & m4.z) + __popc(N.w & m4.w); continue; }
-        const unsigned og = mb.off_lst[g];
         const uint4 l4 = mb.nnl_mask[g], q4 = mb.minor_mask[g];
+        const uint4 N = mine ? nplane[g * NPLANES * n_pad] : make_uint4(0u, 0u, 0u, 0u);
+        if (!FILL) {
+            c += __popc(N.x & q4.x) + __popc(N.y & q4.y) + __popc(N.z & q4.z) + __popc(N.w & q4.w);
+            cq += __popc(N.x & l4.x) + __popc(N.y & l4.y) + __popc(N.z & l4.z) + __popc(N.w & l4.w);
+            continue;
+        }
+        if ((l4.x | l4.y | l4.z | l4.w) != 0u) {
+            // list starts of the group's sites: lane l sums the padded counts of sites l and 64 + l
+            auto padded = [&](int t) {
+                const bool in = (word_of(m4, t >> 5) >> (t & 31)) & 1u;
+                return in ? nn_list_padded(mb.cntN[g * SITES_PER_GROUP + t]) : 0u;
+            };
+            const unsigned v0 = padded(lane), v1 = padded(64 + lane);
+            unsigned p0 = v0, p1 = v1;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned a0 = __shfl_up(p0, d, 64), a1 = __shfl_up(p1, d, 64);
+                if (lane >= d) { p0 += a0; p1 += a1; }
+            }
+            const unsigned tot0 = __shfl(p0, 63, 64);
+            const unsigned long long base = mb.baseN[g];
+            __builtin_amdgcn_wave_barrier();
+            start8[wave][lane] = (unsigned)((base + p0 - v0) / 8ull);
+            start8[wave][64 + lane] = (unsigned)((base + tot0 + p1 - v1) / 8ull);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        const unsigned og = mb.off_lst[g];
 #pragma unroll
         for (int w = 0; w < 4; w++) {
             unsigned nm = word_of(N, w) & word_of(m4, w);
             while (nm) {
                 const int b = __ffs(nm) - 1;
                 nm &= nm - 1;
-                ent[o++] = (minor_rank(m4, og, w, b) << ENT_SHIFT) | (((word_of(l4, w) >> b) & 1u) << 4) |
-                           (((word_of(q4, w) >> b) & 1u) ? 15u : 0u);
+                if ((word_of(q4, w) >> b) & 1u) es.push((minor_rank(m4, og, w, b) << ENT_SHIFT) | 15u);
+                if ((word_of(l4, w) >> b) & 1u) qs.push(start8[wave][w * 32 + b]);
             }
         }
     }
-    if (!FILL) cnt[s * MS_NCH + chunk] = c;
+    if (FILL && mine) { es.flush(); qs.flush(); }
+    // (a chunk's entries are padded to a multiple of four with null entries: 16-byte stores on 16-byte boundaries)
+    if (!FILL && mine) { cnt[s * MS_NCH + chunk] = (c + 3u) & ~3u; cntq[s * GS_CHUNKS + chunk] = (cq + 3u) & ~3u; }
 }
 
 // per-sample lists, listed entries (from E).  FILL = false: cnt[s * NCH + GS_CHUNKS]++ and c_p[s] += w (c_p of EVERY sample: a
@@ -607,12 +665,20 @@ __global__ __launch_bounds__(256) void minor_listed_kernel(const MinorBuild mb, 
     }
 }
 
-__global__ void minor_sample_offsets_kernel(const unsigned long long *__restrict__ off, size_t n, unsigned long long *__restrict__ s_off,
+// the listed entries of a sample (its last "chunk", counted with atomics) padded to a multiple of four like the other chunks
+__global__ void minor_pad_listed_kernel(unsigned *__restrict__ cnt, size_t n)
+{
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n) cnt[s * MS_NCH + GS_CHUNKS] = (cnt[s * MS_NCH + GS_CHUNKS] + 3u) & ~3u;
+}
+
+// per-sample offsets of a stream from the scan over its (sample, chunk) counts; the longest sample's length
+__global__ void minor_sample_offsets_kernel(const unsigned long long *__restrict__ off, size_t n, int nch, unsigned long long *__restrict__ s_off,
                                             unsigned long long *__restrict__ max_row)
 {
     const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s <= n) s_off[s] = off[s * MS_NCH];               // off has n * NCH + 1 entries
-    if (s < n) atomicMax(max_row, off[(s + 1) * MS_NCH] - off[s * MS_NCH]);
+    if (s <= n) s_off[s] = off[s * nch];                   // off has n * nch + 1 entries
+    if (s < n) atomicMax(max_row, off[(s + 1) * nch] - off[s * nch]);
 }
 
 int minority_lists_build(tracs_alignment *a, const MinorBuild &mb, hipStream_t stream, int *ok)
@@ -625,31 +691,44 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb, hipStream_t s
     g->in_arena = true;                                    // (pack_alloc: the alignment's arena, or hipMalloc tracked by it)
     auto fail_soft = [&]() { (void)hipGetLastError(); gs_free(g); return TRACS_OK; };
 #define GS_TRY(x) do { if ((x) != hipSuccess) return fail_soft(); } while (0)
-    const unsigned long long tot_s = mb.tot_p + mb.tot_n;
+    const unsigned long long tot_s = mb.tot_p + mb.tot_minor_n, tot_nn = mb.tot_nnl;
     static const bool trace = std::getenv("TRACS_CLASSES_TRACE") != nullptr;
     const auto t_host0 = std::chrono::steady_clock::now();
     const size_t before = a->pack_extra.size();
     GS_TRY(pack_alloc(a, (n + 1) * 8, reinterpret_cast<void **>(&g->s_off)));
+    GS_TRY(pack_alloc(a, (n + 1) * 8, reinterpret_cast<void **>(&g->snn_off)));
     GS_TRY(pack_alloc(a, (L + 1) * 8, reinterpret_cast<void **>(&g->p_off)));
     GS_TRY(pack_alloc(a, (L + 1) * 8, reinterpret_cast<void **>(&g->n_off)));
     GS_TRY(pack_alloc(a, std::max<size_t>(n, 1) * 4, reinterpret_cast<void **>(&g->c_p)));
-    GS_TRY(pack_alloc(a, std::max<size_t>(tot_s, 1) * 4, reinterpret_cast<void **>(&g->s_ent)));
+    // (+ up to three null entries per sample and chunk: the streams are written 16 bytes at a time)
+    GS_TRY(pack_alloc(a, (tot_s + 3 * n * MS_NCH + 4) * 4, reinterpret_cast<void **>(&g->s_ent)));
+    GS_TRY(hipMemsetAsync(g->s_ent, 0xFF, (tot_s + 3 * n * MS_NCH + 4) * 4, stream));      // (the listed entries' padding is never written)
+    GS_TRY(pack_alloc(a, (tot_nn + 3 * n * GS_CHUNKS + 4) * 4, reinterpret_cast<void **>(&g->s_nn)));
     GS_TRY(pack_alloc(a, std::max<size_t>(mb.tot_p, 1) * 4, reinterpret_cast<void **>(&g->p_ent)));
-    g->n16 = a->n_pad <= 65536;                            // sample numbers fit 16 bits: half the bytes of every list walk
-    GS_TRY(pack_alloc(a, std::max<size_t>(mb.tot_n, 1) * (g->n16 ? 2 : 4), reinterpret_cast<void **>(&g->n_ent)));
-    if (trace) std::fprintf(stderr, "[once per pack] host: list storage %.2f GB (%zu of 7 arrays outside the arena) %.2f ms\n",
-                            ((double)(tot_s + mb.tot_p) * 4 + (double)mb.tot_n * (g->n16 ? 2 : 4)) * 1e-9, a->pack_extra.size() - before,
+    // sample numbers (and the all-ones sentinel) fit 16 bits: half the bytes of every list walk.  Every N list starts on a
+    // cache-line boundary, ends with a sentinel and is padded with more to a multiple of NN_LIST_PAD entries (mb.tot_n counts the
+    // padded sizes): a 16-lane group takes a whole list of up to 127 (63) samples with one 16-byte load per lane, a list of ~100
+    // samples lies in 2 lines instead of 2.6, and the walk needs neither a length nor a look-up of list bounds
+    g->n16 = a->n < 65535;
+    g->padded = true;
+    const size_t n_ent_bytes = (std::max<size_t>(mb.tot_n, 8) + 64) * (g->n16 ? 2 : 4);
+    GS_TRY(pack_alloc(a, n_ent_bytes, reinterpret_cast<void **>(&g->n_ent)));
+    GS_TRY(hipMemsetAsync(g->n_ent, 0xFF, n_ent_bytes, stream));
+    if (trace) std::fprintf(stderr, "[once per pack] host: list storage %.2f GB (%zu of 9 arrays outside the arena) %.2f ms\n",
+                            ((double)(tot_s + mb.tot_p + tot_nn) * 4 + (double)n_ent_bytes) * 1e-9, a->pack_extra.size() - before,
                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count());
-    unsigned *cnt = nullptr, *cur = nullptr;
-    unsigned long long *off = nullptr;
+    unsigned *cnt = nullptr, *cur = nullptr, *cntq = nullptr;
+    unsigned long long *off = nullptr, *offq = nullptr;
     uint2 *E = nullptr;
-    const size_t nsc = n * MS_NCH;
+    const size_t nsc = n * MS_NCH, nsq = n * GS_CHUNKS;
     int rc;
-    if ((rc = workspace_get(60, nsc * 4, reinterpret_cast<void **>(&cnt))) || (rc = workspace_get(61, (nsc + 1) * 8, reinterpret_cast<void **>(&off))) ||
+    if ((rc = workspace_get(60, (nsc + nsq) * 4, reinterpret_cast<void **>(&cnt))) ||
+        (rc = workspace_get(61, (nsc + nsq + 2) * 8, reinterpret_cast<void **>(&off))) ||
         (rc = workspace_get(62, std::max<size_t>(mb.tot_p, 1) * sizeof(uint2), reinterpret_cast<void **>(&E))) ||
         (rc = workspace_get(63, (std::max<size_t>(n, 1) + 8) * 4, reinterpret_cast<void **>(&cur)))) { gs_free(g); return rc; }
-    GS_TRY(hipMemsetAsync(cnt, 0, nsc * 4, stream));
-    GS_TRY(hipMemsetAsync(cur, 0, std::max<size_t>(n, 1) * 4, stream));
+    cntq = cnt + nsc; offq = off + nsc + 1;
+    GS_TRY(hipMemsetAsync(cnt, 0, (nsc + nsq) * 4, stream));
+    GS_TRY(hipMemsetAsync(cur, 0, (std::max<size_t>(n, 1) + 8) * 4, stream));
     GS_TRY(hipMemsetAsync(g->c_p, 0, std::max<size_t>(n, 1) * 4, stream));
     if (g->n16)
         hipLaunchKernelGGL(minor_site_lists_kernel<unsigned short>, dim3((unsigned)groups), dim3(256), 0, stream, mb, a->n_pad, (unsigned)n,
@@ -657,53 +736,59 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb, hipStream_t s
     else
         hipLaunchKernelGGL(minor_site_lists_kernel<unsigned>, dim3((unsigned)groups), dim3(256), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off,
                            g->n_off, g->p_ent, g->n_ent, E);
-    pack_stage_mark("minority lists: per site", stream);
+    pack_stage_mark("lists: per site", stream);
     const size_t gpc = (groups + GS_CHUNKS - 1) / GS_CHUNKS;
     const dim3 sgrid((unsigned)((n + 63) / 64), GS_CHUNKS / 4);
     const unsigned egrid = (unsigned)((mb.tot_p + 255) / 256);
-    hipLaunchKernelGGL((minor_sample_kernel<false>), sgrid, dim3(256), 0, stream, mb, a->n_pad, n, groups, gpc, cnt, nullptr, nullptr);
+    hipLaunchKernelGGL((minor_sample_kernel<false>), sgrid, dim3(256), 0, stream, mb, a->n_pad, n, groups, gpc, cnt, cntq, nullptr, nullptr, nullptr, nullptr);
     if (egrid) hipLaunchKernelGGL((minor_listed_kernel<false>), dim3(egrid), dim3(256), 0, stream, mb, E, mb.tot_p, cnt, g->c_p, nullptr, nullptr, nullptr);
+    hipLaunchKernelGGL(minor_pad_listed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, cnt, n);
     hipLaunchKernelGGL(gs_scan_kernel, dim3(1), dim3(1024), 0, stream, cnt, nsc, off);
-    unsigned long long *d_max = reinterpret_cast<unsigned long long *>(cur + ((std::max<size_t>(n, 1) + 1) & ~(size_t)1));     // behind `cur`
-    GS_TRY(hipMemsetAsync(d_max, 0, 8, stream));
-    hipLaunchKernelGGL(minor_sample_offsets_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, stream, off, n, g->s_off, d_max);
-    hipLaunchKernelGGL((minor_sample_kernel<true>), sgrid, dim3(256), 0, stream, mb, a->n_pad, n, groups, gpc, nullptr, off, g->s_ent);
+    hipLaunchKernelGGL(gs_scan_kernel, dim3(1), dim3(1024), 0, stream, cntq, nsq, offq);
+    unsigned long long *d_max = reinterpret_cast<unsigned long long *>(cur + ((std::max<size_t>(n, 1) + 1) & ~(size_t)1));     // behind `cur` (zeroed with it)
+    hipLaunchKernelGGL(minor_sample_offsets_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, stream, off, n, MS_NCH, g->s_off, d_max);
+    hipLaunchKernelGGL(minor_sample_offsets_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, stream, offq, n, GS_CHUNKS, g->snn_off, d_max + 1);
+    hipLaunchKernelGGL((minor_sample_kernel<true>), sgrid, dim3(256), 0, stream, mb, a->n_pad, n, groups, gpc, nullptr, nullptr, off, offq, g->s_ent, g->s_nn);
     if (egrid) hipLaunchKernelGGL((minor_listed_kernel<true>), dim3(egrid), dim3(256), 0, stream, mb, E, mb.tot_p, nullptr, nullptr, off, cur, g->s_ent);
     GS_TRY(hipMemcpyAsync(&g->max_row, d_max, 8, hipMemcpyDeviceToHost, stream));       // (read after the caller's synchronisation)
+    GS_TRY(hipMemcpyAsync(&g->max_row_nn, d_max + 1, 8, hipMemcpyDeviceToHost, stream));
     GS_TRY(hipGetLastError());
-    pack_stage_mark("minority lists: per sample", stream);
+    pack_stage_mark("lists: per sample", stream);
 #undef GS_TRY
-    g->tot_s = tot_s;
+    g->tot_s = tot_s; g->tot_nn = tot_nn;
     a->minor = g;
     *ok = 1;
     return TRACS_OK;
 }
 
 // ---- N co-occurrences from lists (site classes: the NNL sites) -----------------------------------------------------------
-// Row i of the pair matrix: NN(i, j) = number of NNL sites at which both i and j are N.  The row lives in LDS; every wave
-// takes 64 entries of sample i's list at a time, keeps its N entries at NNL sites (code 15, bit 4), fetches their lists'
-// bounds in one round trip and walks the lists 64 samples per load, two sites in flight; ds_add per j > i.  Work =
-// sum over the NNL sites of cN^2 list entries, whatever the number of samples -- against n^2 / 2 pairs per site on the matrix
-// cores.  The row is then added to ncomp -- with lu - c_i - c_j when no counting pass adds those terms.
+// Row i of the pair matrix: NN(i, j) = number of NNL sites at which both i and j are N.  The row lives in LDS.  Every wave
+// takes 64 entries of sample i's stream at a time -- each says where the N list of a site at which i is N starts and how long it
+// is -- and parks them in its LDS scratch; then its four 16-LANE GROUPS each take one list per round -- 16 bytes per lane, i.e.
+// a whole list of up to 128 samples (64 with 32-bit sample numbers) in ONE load instruction for four lists, NN_FLIGHT rounds
+// in flight -- and ds_add every sample j > i they read.  (What bound the first form of this kernel was neither bytes nor LDS
+// but the NUMBER of 64-lane load instructions of 2 bytes per lane: profiles/r03/nn_rows_sorted_lists_rejected.txt.)
+// Work = sum over the NNL sites of cN^2 list entries, whatever the number of samples -- against n^2 / 2 pairs per site on the
+// matrix cores.  The row is then added to ncomp -- with lu - c_i - c_j when no counting pass adds those terms.
 // A sample with many N entries (N concentrated in few samples) would leave most of the chip idle behind a few rows: a row's
 // entries are cut over up to NN_MAX_SPLITS workgroups of `target` entries (grid.z; the others exit at once), which then add their
 // rows with atomics.
 constexpr unsigned NN_MAX_SPLITS = 32;
 #ifndef TRACS_NN_FLIGHT
-#define TRACS_NN_FLIGHT 8
+#define TRACS_NN_FLIGHT 2
 #endif
 #ifndef TRACS_NN_THREADS
 #define TRACS_NN_THREADS 1024
 #endif
-constexpr int NN_FLIGHT = TRACS_NN_FLIGHT;          // sites per memory round trip and wave (sweep: profiles/r03/nn_rows_sweep.txt)
+constexpr int NN_FLIGHT = TRACS_NN_FLIGHT;          // rounds (of four lists) per memory round trip and wave
 template <class NT>
-__global__ __launch_bounds__(TRACS_NN_THREADS) void nn_rows_kernel(const unsigned long long *__restrict__ s_off, const unsigned *__restrict__ s_ent,
-                                                       const unsigned long long *__restrict__ n_off, const NT *__restrict__ n_ent,
-                                                       const unsigned *__restrict__ c_u, unsigned n, unsigned row_begin, unsigned col_begin,
-                                                       unsigned chunk, unsigned long long target, unsigned *__restrict__ ncomp, size_t ld,
-                                                       int add_terms, unsigned lu)
+__global__ __launch_bounds__(TRACS_NN_THREADS) void nn_rows_kernel(const unsigned long long *__restrict__ s_off, const unsigned *__restrict__ s_nn,
+                                                                   const NT *__restrict__ n_ent, const unsigned *__restrict__ c_u, unsigned n, unsigned row_begin, unsigned col_begin,
+                                                                   unsigned chunk, unsigned long long target, unsigned *__restrict__ ncomp, size_t ld,
+                                                                   int add_terms, unsigned lu)
 {
-    extern __shared__ unsigned row[];
+    extern __shared__ unsigned row[];                        // `chunk` counters, then 64 list starts per wave
+    constexpr unsigned EPL = 16 / sizeof(NT);                // entries per lane and load
     const unsigned i = row_begin + blockIdx.x;
     const unsigned c0 = blockIdx.y * chunk, c1 = min(n, c0 + chunk);
     if (c1 <= i + 1 || c1 <= col_begin) return;            // no cell (i, j > i) in this column chunk
@@ -716,53 +801,73 @@ __global__ __launch_bounds__(TRACS_NN_THREADS) void nn_rows_kernel(const unsigne
     for (unsigned j = threadIdx.x; j < c1 - c0; j += blockDim.x) row[j] = 0;
     __syncthreads();
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const unsigned grp = lane >> 4, l16 = lane & 15u;
+    unsigned *scratch = row + chunk + wave * 64;
+    constexpr unsigned SENT = (unsigned)(NT)~(NT)0;
     const unsigned lo = max(max(i + 1, col_begin), c0);     // columns [lo, c1) of this chunk are cells of row i
-    auto bump = [&](unsigned j) { if (j >= lo && j < c1) atomicAdd(&row[j - c0], 1u); };
+    // The entries of one 16-lane group load.  A list occupies whole pads of NN_LIST_PAD entries (LP lanes) and the pad behind its
+    // last sample-holding pad belongs to the next list: a group load of two pads (16-bit sample numbers) takes its second pad only
+    // if the first one ends without a sentinel (one compare on one lane and a ballot -- not a compare per entry).  Sentinels fail
+    // the column-range test by themselves.  Returns true when the load's last entry is no sentinel: the list goes on.
+    constexpr unsigned LP = NN_LIST_PAD / EPL;               // lanes per pad: 8 (16-bit) or 16 (32-bit)
+    auto bump_all = [&](const uint4 &d) -> bool {
+        const unsigned w[4] = {d.x, d.y, d.z, d.w};
+        const unsigned tail = sizeof(NT) == 2 ? (w[3] >> 16) : w[3];
+        bool take = true;
+        if (LP < 16u) {
+            const unsigned long long full = __ballot(l16 == LP - 1u && tail != SENT);       // first pad without a sentinel
+            take = l16 < LP || ((full >> (grp * 16 + LP - 1u)) & 1ull);
+        }
+        const unsigned long long on = __ballot(l16 == 15u && tail != SENT && take);
+        if (take) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (sizeof(NT) == 2) {
+                    const unsigned a = w[k] & 0xFFFFu, b = w[k] >> 16;
+                    if (a >= lo && a < c1) atomicAdd(&row[a - c0], 1u);
+                    if (b >= lo && b < c1) atomicAdd(&row[b - c0], 1u);
+                } else if (w[k] >= lo && w[k] < c1) atomicAdd(&row[w[k] - c0], 1u);
+            }
+        }
+        return (on >> (grp * 16 + 15)) & 1ull;
+    };
+    const uint4 *__restrict__ lists = reinterpret_cast<const uint4 *>(n_ent);      // (every list starts on a 16-byte boundary)
     for (unsigned long long base = e0 + (unsigned long long)wave * 64; base < e1; base += (unsigned long long)nwaves * 64) {
         const unsigned long long e = base + lane;
-        const unsigned ent = e < e1 ? s_ent[e] : 0u;
-        const bool want = (ent & 16u) != 0u && ((ent & 15u) == 15u || (ent & 15u) == 0u);     // an N entry at an NNL site
-        unsigned long long na = 0, nz_ = 0;
-        if (want) { const unsigned r = ent >> ENT_SHIFT; na = n_off[r]; nz_ = n_off[r + 1]; }
-        unsigned long long todo = __ballot(want);
-        // NN_FLIGHT sites per round trip: every site's first 128 entries are requested before any is applied (the walk is bound by
-        // memory round trips per wave, not by bytes: PMC)
-        while (todo) {
-            unsigned v[NN_FLIGHT][2];
-            unsigned long long ta[NN_FLIGHT], tz[NN_FLIGHT];
-            // (1) the list bounds of the next NN_FLIGHT entries of the batch, through the scalar unit (v_readlane with a wave-uniform
-            // lane: a __shfl would be four ds_bpermute -- LDS instructions, on the pipe the ds_add of the walk already fills) and ALL
-            // of them before the first list load goes out: a readlane issued after a load makes hipcc drain vmcnt(0) first, which
-            // serialises the lists; (2) every list's first 128 entries requested; (3) applied
+        // this lane's entry of the batch -- the start of a list, in units of 16 bytes -- parked in the wave's LDS scratch
+        const unsigned st = e < e1 ? s_nn[e] : 0xFFFFFFFFu;   // (0xFFFFFFFF: padding of the stream)
+        scratch[lane] = st == 0xFFFFFFFFu ? 0xFFFFFFFFu : (unsigned)((unsigned long long)st * 8ull / EPL);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const unsigned cnt = (unsigned)min(64ull, e1 - base);
+        for (unsigned t0 = 0; t0 < cnt; t0 += 4 * NN_FLIGHT) {
+            unsigned sl[NN_FLIGHT];
+            bool has[NN_FLIGHT];
+            uint4 d[NN_FLIGHT];
 #pragma unroll
-            for (int q = 0; q < NN_FLIGHT; q++) {
-                const int k = __builtin_amdgcn_readfirstlane(todo ? __ffsll((long long)todo) - 1 : -1);
-                unsigned long long sa = 0, sz = 0;
-                if (k >= 0) {
-                    todo &= todo - 1;
-                    sa = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(na >> 32), k) << 32) | (unsigned)__builtin_amdgcn_readlane((int)na, k);
-                    sz = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(nz_ >> 32), k) << 32) | (unsigned)__builtin_amdgcn_readlane((int)nz_, k);
+            for (int u = 0; u < NN_FLIGHT; u++) {
+                const unsigned idx = t0 + 4 * u + grp;
+                sl[u] = idx < cnt ? scratch[idx] : 0xFFFFFFFFu;
+                has[u] = sl[u] != 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int u = 0; u < NN_FLIGHT; u++)
+                d[u] = has[u] ? lists[(size_t)sl[u] + l16] : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+#pragma unroll
+            for (int u = 0; u < NN_FLIGHT; u++) {
+                // a list goes on behind its first 16 x 16 bytes while the group has seen no sentinel (rare: lists of 128 (64)
+                // samples and more); which of the wave's four groups go on is a ballot away
+                bool on = bump_all(d[u]);
+                for (unsigned step = 1;; step++) {
+                    if (!__ballot(on)) break;                // wave-uniform
+                    const uint4 nx = on ? lists[(size_t)sl[u] + 16u * step + l16] : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+                    const bool more = bump_all(nx);
+                    on = on && more;
                 }
-                ta[q] = sa + lane;
-                tz[q] = sz;
             }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < NN_FLIGHT; q++) {
-                v[q][0] = ta[q] < tz[q] ? (unsigned)n_ent[ta[q]] : 0xFFFFFFFFu;
-#ifdef TRACS_NN_EXPERIMENT_SKIP2
-                v[q][1] = 0xFFFFFFFFu;                         // (timing experiment only: wrong counts)
-#else
-                v[q][1] = ta[q] + 64 < tz[q] ? (unsigned)n_ent[ta[q] + 64] : 0xFFFFFFFFu;
-#endif
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < NN_FLIGHT; q++) { bump(v[q][0]); bump(v[q][1]); }      // (0xFFFFFFFF >= c1: no bump)
-#pragma unroll
-            for (int q = 0; q < NN_FLIGHT; q++)
-                for (unsigned long long t = ta[q] + 128; t < tz[q]; t += 64) bump((unsigned)n_ent[t]);
         }
+        __builtin_amdgcn_wave_barrier();                   // (the scratch is rewritten by the next batch)
     }
     __syncthreads();
     const bool terms = add_terms && blockIdx.z == 0;
@@ -780,25 +885,25 @@ int nn_rows_add(tracs_alignment *a, size_t row_begin, size_t row_end, size_t col
                 unsigned lu, hipStream_t stream)
 {
     const GeneralSparse *g = a->minor;
-    if (!g) { set_error("nn_rows_add: lists not built"); return TRACS_E_ARG; }
+    if (!g || !g->s_nn) { set_error("nn_rows_add: lists not built"); return TRACS_E_ARG; }
     const size_t n = a->n;
     const unsigned chunk = (unsigned)std::min<size_t>((n + 63) / 64 * 64, 32768);
     static bool attr_set = false;
     if (!attr_set) {
-        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(nn_rows_kernel<unsigned>), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4));
-        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(nn_rows_kernel<unsigned short>), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4));
+        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(nn_rows_kernel<unsigned>), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4 + TRACS_NN_THREADS * 4));
+        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(nn_rows_kernel<unsigned short>), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4 + TRACS_NN_THREADS * 4));
         attr_set = true;
     }
     // ~2048 workgroups' worth of entries each, never less than 8192 entries (a workgroup's fixed cost: its row in LDS)
-    const unsigned long long target = std::max<unsigned long long>(8192ull, g->tot_s / 2048ull);
-    const unsigned splits = (unsigned)std::min<unsigned long long>(NN_MAX_SPLITS, std::max<unsigned long long>(1, (g->max_row + target - 1) / target));
+    const unsigned long long target = std::max<unsigned long long>(8192ull, g->tot_nn / 2048ull);
+    const unsigned splits = (unsigned)std::min<unsigned long long>(NN_MAX_SPLITS, std::max<unsigned long long>(1, (g->max_row_nn + target - 1) / target));
     const dim3 grid((unsigned)(row_end - row_begin), (unsigned)((n + chunk - 1) / chunk), splits);
     if (g->n16)
-        hipLaunchKernelGGL(nn_rows_kernel<unsigned short>, grid, dim3(TRACS_NN_THREADS), chunk * 4, stream, g->s_off, g->s_ent, g->n_off,
+        hipLaunchKernelGGL(nn_rows_kernel<unsigned short>, grid, dim3(TRACS_NN_THREADS), chunk * 4 + TRACS_NN_THREADS * 4, stream, g->snn_off, g->s_nn,
                            reinterpret_cast<const unsigned short *>(g->n_ent), a->c_counted, (unsigned)n, (unsigned)row_begin, (unsigned)col_begin,
                            chunk, target, ncomp, ld, add_terms, lu);
     else
-        hipLaunchKernelGGL(nn_rows_kernel<unsigned>, grid, dim3(TRACS_NN_THREADS), chunk * 4, stream, g->s_off, g->s_ent, g->n_off, g->n_ent, a->c_counted,
+        hipLaunchKernelGGL(nn_rows_kernel<unsigned>, grid, dim3(TRACS_NN_THREADS), chunk * 4 + TRACS_NN_THREADS * 4, stream, g->snn_off, g->s_nn, g->n_ent, a->c_counted,
                            (unsigned)n, (unsigned)row_begin, (unsigned)col_begin, chunk, target, ncomp, ld, add_terms, lu);
     TRACS_HIP_CHECK(hipGetLastError());
     return TRACS_OK;

@@ -98,6 +98,10 @@ int general_sparse_fixup(tracs_alignment *a, size_t row_begin, size_t row_end, s
 // The same lists for the MINORITY sites of an alignment cut into site classes (site_classes.hip): a sample that is neither N nor
 // exactly the site's reference base is listed with its allele mask and w = [reference base not in the mask]; minority_fixup
 // adds the sites' contribution to dist (general_fixup_kernel<MINOR>).  Built from what classify_sites_kernel left behind:
+// N lists of the site classes: at least one all-ones sentinel behind the last sample, padded to a multiple of this many entries
+// (one cache line of 16-bit sample numbers): every list starts on a line boundary and its end needs no length
+constexpr unsigned NN_LIST_PAD = 64;
+__host__ __device__ inline unsigned nn_list_padded(unsigned c) { return (c / NN_LIST_PAD + 1u) * NN_LIST_PAD; }
 struct MinorBuild {
     const uint4 *planes;                     // the five general planes
     const uint4 *minor_mask, *nnl_mask, *lst_mask;   // per group: minority sites, N co-occurrence list sites, their union
@@ -110,7 +114,8 @@ struct MinorBuild {
     unsigned rows[4];                        // per-sample lists only for the samples of these [begin, end) ranges (n_rows of them;
     int n_rows;                              //  0: every sample) -- tracs_alignment_hint_rows
     size_t sites;                            // sites with lists
-    unsigned long long tot_p, tot_n;         // list entries in all
+    unsigned long long tot_p, tot_n;         // list entries in all: listed samples, N samples
+    unsigned long long tot_nnl, tot_minor_n; // N samples at the NNL sites / at the minority sites (per-sample stream sizes)
 };
 int minority_lists_build(tracs_alignment *a, const MinorBuild &mb, hipStream_t stream, int *ok);
 void minority_lists_free(tracs_alignment *a);

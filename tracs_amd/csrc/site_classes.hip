@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
                                                              unsigned nn_list_max, uint4 *__restrict__ masks, size_t groups,
                                                              unsigned *__restrict__ cntP, unsigned *__restrict__ cntN,
                                                              unsigned *__restrict__ gP, unsigned *__restrict__ gN, unsigned *__restrict__ gQ,
+                                                             unsigned *__restrict__ gR, unsigned *__restrict__ gS,
                                                              unsigned long long *__restrict__ flags, size_t flag_words,
                                                              unsigned *__restrict__ partial_flag)
 {
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
     __shared__ unsigned planes_lds[256][4][8];          // one counter's bit planes of every thread (32 KiB)
     __shared__ unsigned tot[2][SITES_PER_GROUP];        // k, cN
     __shared__ unsigned half_sum[SITES_PER_GROUP];
-    __shared__ unsigned wsum[2][3];
+    __shared__ unsigned wsum[2][5];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < SITES_PER_GROUP) { tot[0][tid] = 0; tot[1][tid] = 0; }
     if (tid < 4) { sref[0][tid] = 0; sref[1][tid] = 0; sref[2][tid] = 0; sref[3][tid] = 0; }
@@ -230,13 +231,23 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
         cntP[g * SITES_PER_GROUP + tid] = (unsigned)k;
         cntN[g * SITES_PER_GROUP + tid] = (unsigned)c;
         // (sq: list entries the N co-occurrence walk visits at this site, cN per N sample; an NNL site has cN < 2^16)
-        unsigned sp = minor ? (unsigned)k : 0u, sn = lst ? (unsigned)c : 0u, sq = nnl ? (unsigned)(c * c) : 0u;
+        // (an N list ends with at least one sentinel and is padded with more to a multiple of NN_LIST_PAD entries: 16-byte loads of
+        // whole lists that start on a cache-line boundary and need no length, general_sparse.hip; sq: list entries the N co-occurrence
+        // walk visits at this site, cN per N sample)
+        const unsigned cpad = nn_list_padded((unsigned)c);
+        unsigned sv[5] = {minor ? (unsigned)k : 0u, lst ? cpad : 0u, nnl ? (unsigned)(c * c) : 0u, nnl ? (unsigned)c : 0u, minor ? (unsigned)c : 0u};
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { sp += __shfl_xor(sp, off, 64); sn += __shfl_xor(sn, off, 64); sq += __shfl_xor(sq, off, 64); }
-        if (lane == 0) { wsum[wave][0] = sp; wsum[wave][1] = sn; wsum[wave][2] = sq; }
+        for (int m = 0; m < 5; m++) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) sv[m] += __shfl_xor(sv[m], off, 64);
+            if (lane == 0) wsum[wave][m] = sv[m];
+        }
     }
     __syncthreads();
-    if (tid == 0) { gP[g] = wsum[0][0] + wsum[1][0]; gN[g] = wsum[0][1] + wsum[1][1]; gQ[g] = wsum[0][2] + wsum[1][2]; }
+    if (tid == 0) {
+        gP[g] = wsum[0][0] + wsum[1][0]; gN[g] = wsum[0][1] + wsum[1][1]; gQ[g] = wsum[0][2] + wsum[1][2];
+        gR[g] = wsum[0][3] + wsum[1][3]; gS[g] = wsum[0][4] + wsum[1][4];
+    }
     if (tid < 4) {
         reinterpret_cast<unsigned *>(&masks[(size_t)M_REFX * groups + g])[tid] = refx[tid];
         reinterpret_cast<unsigned *>(&masks[(size_t)M_REFY * groups + g])[tid] = refy[tid];
@@ -245,7 +256,8 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
 
 // Exclusive prefix sums over the groups, one workgroup per array (1024 groups at a time):
 //   blocks 0..6  sizes of the mask slots M_DENSE .. M_UN (popcount of the mask) -> off32[b][g], totals[b]
-//   blocks 7..9  list sizes gP / gN of the groups' sites, gQ (entries the N co-occurrence walk visits) -> off64[b - 7][g], totals[b]
+//   blocks 7..11 per-group sums: gP / gN (list sizes), gQ (entries the N co-occurrence walk visits), gR / gS (N samples at the NNL /
+//                minority sites) -> off64[b - 7][g], totals[b]
 __global__ __launch_bounds__(1024) void group_offsets_kernel(const uint4 *__restrict__ masks, const unsigned *__restrict__ gcounts, size_t groups,
                                                              unsigned *__restrict__ off32, unsigned long long *__restrict__ off64,
                                                              unsigned long long *__restrict__ totals)
@@ -493,8 +505,8 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     if ((rc = workspace_get(52, M_SLOTS * groups * sizeof(uint4), reinterpret_cast<void **>(&masks)))) return rc;
     if ((rc = workspace_get(53, 7 * groups * sizeof(unsigned), reinterpret_cast<void **>(&offs)))) return rc;
     if ((rc = workspace_get(54, 2 * groups * SITES_PER_GROUP * sizeof(unsigned), reinterpret_cast<void **>(&cnts)))) return rc;
-    if ((rc = workspace_get(55, 3 * groups * sizeof(unsigned), reinterpret_cast<void **>(&gcnt)))) return rc;
-    if ((rc = workspace_get(56, 3 * (groups + 1) * sizeof(unsigned long long), reinterpret_cast<void **>(&off64)))) return rc;
+    if ((rc = workspace_get(55, 5 * groups * sizeof(unsigned), reinterpret_cast<void **>(&gcnt)))) return rc;
+    if ((rc = workspace_get(56, 5 * (groups + 1) * sizeof(unsigned long long), reinterpret_cast<void **>(&off64)))) return rc;
     if ((rc = workspace_get(57, 128, reinterpret_cast<void **>(&totals)))) return rc;
     if ((rc = workspace_get(58, groups * flag_words * sizeof(unsigned long long), reinterpret_cast<void **>(&flags)))) return rc;
     d_flag = reinterpret_cast<unsigned *>(totals + 15);
@@ -514,9 +526,9 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     const unsigned nn_list_max = (no_nnl || !allow_nnl) ? 0u : (unsigned)std::min(4.0e9, nnl_k * (double)a->n * (double)a->n);
     TRACS_HIP_CHECK(hipMemsetAsync(totals, 0, 128, stream));
     hipLaunchKernelGGL(classify_sites_kernel, dim3((unsigned)groups), dim3(256), 0, stream, a->planes, a->n_pad, (unsigned)a->n, budget,
-                       nn_list_max, masks, groups, cntP, cntN, gcnt, gcnt + groups, gcnt + 2 * groups, flags, flag_words, d_flag);
+                       nn_list_max, masks, groups, cntP, cntN, gcnt, gcnt + groups, gcnt + 2 * groups, gcnt + 3 * groups, gcnt + 4 * groups, flags, flag_words, d_flag);
     stage_mark("classify", stream);
-    hipLaunchKernelGGL(group_offsets_kernel, dim3(10), dim3(1024), 0, stream, masks, gcnt, groups, offs, off64, totals);
+    hipLaunchKernelGGL(group_offsets_kernel, dim3(12), dim3(1024), 0, stream, masks, gcnt, groups, offs, off64, totals);
     unsigned long long tot[16] = {0};
     TRACS_HIP_CHECK(hipMemcpyAsync(tot, totals, 128, hipMemcpyDeviceToHost, stream));
     TRACS_HIP_CHECK(hipStreamSynchronize(stream));
@@ -525,7 +537,7 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     const bool consensus = !*partial && !force_general;
     const size_t L_dense = (size_t)tot[M_DENSE], L_count = (size_t)tot[M_COUNT], L_minor = (size_t)tot[M_MINOR], L_full = (size_t)tot[M_FULL];
     const size_t L_nnl = (size_t)tot[M_NNL], L_lst = (size_t)tot[M_LST], L_un = (size_t)tot[M_UN];
-    const unsigned long long tot_p = tot[7], tot_n = tot[8];
+    const unsigned long long tot_p = tot[7], tot_n = tot[8], tot_nnl = tot[10], tot_minor_n = tot[11];
     if (force == 0 || a->L == 0 || a->n < 2) return TRACS_OK;
     // matrix instructions per pair: planes_full per site now; planes_full per dense site + one per counted site with classes
     const double planes_full = consensus ? 4.0 : 5.0;
@@ -537,8 +549,10 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     if (L_lst) {
         static const double env_cap = [] { const char *e = std::getenv("TRACS_LIST_CAP"); return e ? std::atof(e) : -1.0; }();
         const double cap = (double)a->n * (double)a->L / 8.0;
-        const double entries = 2.0 * (double)tot_n + 2.0 * (double)tot_p;        // per-site and per-sample lists
-        if (L_lst >= (1ull << 27) || a->n >= (1ull << 27) || entries > (env_cap >= 0.0 ? std::min(env_cap, cap) : cap))
+        // per-site lists (N lists padded) and per-sample streams
+        const double entries = (double)tot_n + (double)tot_nnl + (double)tot_minor_n + 2.0 * (double)tot_p;
+        if (L_lst >= (1ull << 27) || a->n >= (1ull << 27) || entries > (env_cap >= 0.0 ? std::min(env_cap, cap) : cap) ||
+            (L_nnl && tot_n / 8 >= (1ull << 32)))        // (the per-sample stream holds list starts in units of 8 entries, 32 bits)
             return L_nnl ? decide(a, allow_minor, false, stream, partial) : decide(a, false, false, stream, partial);
     }
 
@@ -594,7 +608,7 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
         mb.planes = a->planes; mb.minor_mask = mask_of(M_MINOR); mb.nnl_mask = mask_of(M_NNL); mb.lst_mask = mask_of(M_LST);
         mb.ref_x = mask_of(M_REFX); mb.ref_y = mask_of(M_REFY); mb.off_lst = off_of(M_LST);
         mb.cntP = cntP; mb.cntN = cntN; mb.baseP = off64; mb.baseN = off64 + groups; mb.flags = flags; mb.flag_words = flag_words;
-        mb.sites = L_lst; mb.tot_p = tot_p; mb.tot_n = tot_n;
+        mb.sites = L_lst; mb.tot_p = tot_p; mb.tot_n = tot_n; mb.tot_nnl = tot_nnl; mb.tot_minor_n = tot_minor_n;
         mb.n_rows = a->n_row_hint;
         for (int k = 0; k < 4; k++) mb.rows[k] = (unsigned)std::min<size_t>(a->row_hint[k], a->n);
         rc = minority_lists_build(a, mb, stream, &built);
