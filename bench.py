@@ -130,18 +130,20 @@ def count_roofline(pairs_per_launch, sites, count_s, n, in_place):
 
 def nn_list_roofline(ls, sites, kern_s, rows, n):
     """nn_rows_kernel (csrc/general_sparse.hip): the N co-occurrences NN = sum n_i n_j of the sites with few N samples, from their N
-    lists -- memory-bound.  Algorithmic bytes per launch: every visited list entry once (cN entries per N sample and site: the
-    sum of cN^2 over those sites, 2 or 4 B each) + per N sample and site its 4-byte entry of the per-sample list and the 16 bytes
-    of list bounds it looks up.  Scaled by the rows of the launch (a rank's panel walks its rows' lists only)."""
+    lists -- memory-bound.  Algorithmic bytes per launch: every visited list entry once (cN entries per walk -- one walk per N
+    sample and site: the sum of cN^2 over those sites, 2 or 4 B each) + the walk's 4-byte entry of the per-sample stream.  Scaled by
+    the rows of the launch (a rank's panel walks its rows' lists only).  What the kernel physically moves is more: a list of ~100
+    samples lies in two 128-byte lines (`traffic`)."""
     frac_rows = rows / float(n)
-    alg = (ls["nn_visits"] * ls["n_entry_bytes"] + ls["n_entries"] * 20.0) * frac_rows
+    alg = (ls["nn_visits"] * ls["n_entry_bytes"] + ls["nn_walks"] * 4.0) * frac_rows
     return {"kernel": "nn_rows_kernel", "kernel_ms": kern_s * 1e3, "sites": sites, "bound": "hbm", "traffic": None,
             "achieved": alg / kern_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg / kern_s / HBM_PEAK,
-            "algorithmic_bytes": alg, "list_entries_visited": ls["nn_visits"] * frac_rows, "bytes_per_list_entry": ls["n_entry_bytes"],
+            "algorithmic_bytes": alg, "list_entries_visited": ls["nn_visits"] * frac_rows, "list_walks": ls["nn_walks"] * frac_rows,
+            "bytes_per_list_entry": ls["n_entry_bytes"],
             "entries_per_s": ls["nn_visits"] * frac_rows / kern_s,
             "note": "row i of the pair matrix in LDS; for every site at which sample i is N (and that has few N samples) the site's list "
-                    "of N samples is walked, ds_add per j > i: sum of cN^2 list entries instead of n^2 / 2 pairs per site on the matrix "
-                    "cores; random list reads of ~2 cN bytes: HBM / fabric-bound"}
+                    "of N samples is read (16 bytes per lane, four lists per load instruction), ds_add per j > i: sum of cN^2 list "
+                    "entries instead of n^2 / 2 pairs per site on the matrix cores; random reads of whole cache lines: HBM / fabric-bound"}
 
 
 def roofline_of(kernel, enc, pairs_per_launch, L, kern_s, traffic, n):

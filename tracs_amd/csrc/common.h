@@ -62,7 +62,8 @@ struct tracs_alignment {
     size_t L_un = 0, L_nnl = 0;               // sites outside vplanes with an N sample (L_inv of them on the matrix cores, L_nnl
                                               // through their N lists, the rest with a single N sample: no co-occurrence)
     unsigned long long nn_visits = 0;         // list entries one pass of the N co-occurrence walk visits (sum of cN^2 over the L_nnl sites)
-    unsigned long long list_entries_n = 0, list_entries_p = 0;     // entries of the per-site N lists / listed-sample lists
+    unsigned long long list_entries_n = 0, list_entries_p = 0;     // entries of the per-site N lists (padded) / listed-sample lists
+    unsigned long long nn_walks = 0;          // list walks of one pass of the N co-occurrence walk (sum of cN over the L_nnl sites)
     unsigned *c_counted = nullptr;            // per sample: its N sites among the sites the counting pass reads
     bool count_in_place = false;              // the counting pass reads the stored N plane of `planes` (every site) instead of iplanes:
                                               // nn = L - c_i - c_j + NN comes from it alone and the pair kernels write d only

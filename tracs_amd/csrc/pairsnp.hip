@@ -809,7 +809,8 @@ int tracs_debug_alignment_site_classes(const tracs_alignment *a, uint64_t *out)
 
 // what completes the compared-sites counts of the last decided classes: out[0] = sites the counting pass reads on the matrix
 // cores, out[1] = 1 when that is the stored N plane in place, out[2] = sites whose N co-occurrences come from lists, out[3] = list
-// entries one pass of that walk visits, out[4], out[5] = entries of the N lists / the listed-sample lists, out[6] = bytes per N entry
+// entries one pass of that walk visits, out[4], out[5] = entries of the N lists / the listed-sample lists, out[6] = bytes per N entry,
+// out[7] = list walks of one pass (one per N sample and site)
 int tracs_debug_alignment_count_source(const tracs_alignment *a, uint64_t *out)
 {
     if (!a || !out || a->classes_state != 1) return 0;
@@ -819,7 +820,8 @@ int tracs_debug_alignment_count_source(const tracs_alignment *a, uint64_t *out)
     out[3] = a->nn_visits;
     out[4] = a->list_entries_n;
     out[5] = a->list_entries_p;
-    out[6] = a->n_pad <= 65536 ? 2 : 4;                      // bytes per N list entry
+    out[6] = a->n < 65535 ? 2 : 4;                           // bytes per N list entry
+    out[7] = a->nn_walks;
     return 1;
 }
 

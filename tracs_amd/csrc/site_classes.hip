@@ -622,7 +622,7 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     if (!ok) { site_classes_free(a); a->classes_state = -1; set_error("site_classes_decide: re-pack failed"); return TRACS_E_HIP; }
     a->L_var = L_dense; a->L_inv = L_count; a->groups_var = gv; a->groups_inv = gi;
     a->L_minor = L_minor; a->L_full = L_full; a->L_un = L_un; a->L_nnl = L_nnl;
-    a->nn_visits = tot[9]; a->list_entries_n = tot_n; a->list_entries_p = tot_p;
+    a->nn_visits = tot[9]; a->list_entries_n = tot_n; a->list_entries_p = tot_p; a->nn_walks = tot_nnl;
     a->count_in_place = in_place;
     a->classes_cons = consensus;
     a->classes_state = 1;

@@ -116,18 +116,19 @@ class Alignment:
         """(sites the counting pass reads on the matrix cores, in_place, sites whose N co-occurrences come from lists) for an
         alignment on site classes: in_place = the stored N plane of every site, read where it lies (the pair kernels then write d
         only); else the N plane of the sites with many N samples, re-packed.  None without classes."""
-        out = (C.c_uint64 * 7)()
+        out = (C.c_uint64 * 8)()
         return (int(out[0]), bool(out[1]), int(out[2])) if self._L.tracs_debug_alignment_count_source(self._h, out) else None
 
     @property
     def list_stats(self):
-        """{nn_visits, n_entries, p_entries, n_entry_bytes}: list entries one pass of the N co-occurrence walk visits (sum of cN^2 over
-        the sites whose co-occurrences come from lists), entries of the per-site N lists and of the listed-sample lists, bytes per N
-        list entry; None without classes."""
-        out = (C.c_uint64 * 7)()
+        """{nn_visits, nn_walks, n_entries, p_entries, n_entry_bytes}: list entries one pass of the N co-occurrence walk visits (sum of
+        cN^2 over the sites whose co-occurrences come from lists) in how many list walks (sum of cN), entries of the per-site N lists
+        (padded) and of the listed-sample lists, bytes per N list entry; None without classes."""
+        out = (C.c_uint64 * 8)()
         if not self._L.tracs_debug_alignment_count_source(self._h, out):
             return None
-        return {"nn_visits": int(out[3]), "n_entries": int(out[4]), "p_entries": int(out[5]), "n_entry_bytes": int(out[6])}
+        return {"nn_visits": int(out[3]), "n_entries": int(out[4]), "p_entries": int(out[5]), "n_entry_bytes": int(out[6]),
+                "nn_walks": int(out[7])}
 
     @property
     def nbytes(self):
