@@ -76,6 +76,7 @@ VARIANTS = [
     ({"TRACS_COUNT_IN_PLACE": "1"}, {("consensus", "mfma"), ("general", "mfma-general")}),
     ({"TRACS_COUNT_IN_PLACE": "1", "TRACS_KSPLIT": "3"}, {("consensus", "mfma"), ("general", "mfma-general")}),
     ({"TRACS_COUNT_IN_PLACE": "0"}, {("consensus", "mfma"), ("general", "mfma-general")}),
+    ({"TRACS_LIST_INLINE": "0"}, {("consensus", "mfma"), ("general", "mfma-general")}),
 ]
 
 

@@ -235,11 +235,14 @@ def test_cost_model_never_loses_to_the_dense_pass(regime, hiplib, oracle):
     nn = torch.zeros_like(d)
 
     def run():
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        dev.pairsnp_dense(aln, d, nn)
-        torch.cuda.synchronize()
-        first = time.perf_counter() - t0
+        first = 1e9
+        for _ in range(2):                                    # (twice: the process's first launch of a kernel loads its code)
+            aln.mark_packed()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dev.pairsnp_dense(aln, d, nn)
+            torch.cuda.synchronize()
+            first = min(first, time.perf_counter() - t0)
         best = 1e9
         for _ in range(3):
             t0 = time.perf_counter()

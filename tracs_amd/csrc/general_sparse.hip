@@ -39,6 +39,11 @@ struct GeneralSparse {
     unsigned *s_nn = nullptr;
     unsigned long long *snn_off = nullptr;
     unsigned long long tot_nn = 0, max_row_nn = 0;
+    // ... and per sample, for every minority site with one or two listed samples at which it is N, those samples themselves
+    // (16 bits each, 0xFFFF: none): general_fixup_kernel<MINOR> applies them without looking at the site's list
+    unsigned *s_inl = nullptr;
+    unsigned long long *inl_off = nullptr;
+    unsigned long long tot_inl = 0;
     bool in_arena = false;                        // the arrays live in the alignment's pack arena (released with it, not one by one)
     bool n16 = false;                             // n_ent holds 16-bit sample numbers (site-class lists of alignments below 65 535 samples)
     bool padded = false;                          // N lists start on 16-byte boundaries, padded with all-ones sentinels to 8 entries
@@ -238,7 +243,8 @@ __global__ __launch_bounds__(1024) void general_fixup_kernel(const unsigned long
                                                              const unsigned long long *__restrict__ n_off, const NT *__restrict__ n_ent,
                                                              const unsigned *__restrict__ c_n, const unsigned *__restrict__ c_p, unsigned L, unsigned n, unsigned row_begin,
                                                              unsigned col_begin, unsigned chunk, unsigned *__restrict__ dist,
-                                                             unsigned *__restrict__ ncomp, size_t ld)
+                                                             unsigned *__restrict__ ncomp, size_t ld,
+                                                             const unsigned long long *__restrict__ inl_off, const unsigned *__restrict__ s_inl)
 {
     extern __shared__ unsigned row[];
     const unsigned i = row_begin + blockIdx.x;
@@ -246,6 +252,17 @@ __global__ __launch_bounds__(1024) void general_fixup_kernel(const unsigned long
     if (c1 <= i + 1 || c1 <= col_begin) return;            // no cell (i, j > i) in this column chunk
     for (unsigned j = threadIdx.x; j < c1 - c0; j += blockDim.x) row[j] = 0;
     __syncthreads();
+    if (MINOR && s_inl) {
+        // the row's N entries at sites with one or two listed samples carry those samples themselves (w = 1 each: a consensus
+        // alignment): -1 for every listed j > i, straight from a coalesced stream -- no list bounds, no list
+        const unsigned long long q1 = inl_off[i + 1];
+        for (unsigned long long q = inl_off[i] + threadIdx.x; q < q1; q += blockDim.x) {
+            const unsigned v = s_inl[q];
+            const unsigned j1 = v & 0xFFFFu, j2 = v >> 16;       // (0xFFFF: none / padding)
+            if (j1 > i && j1 >= c0 && j1 < c1) atomicAdd(&row[j1 - c0], 0xFFFFFFFFu);
+            if (j2 > i && j2 >= c0 && j2 < c1) atomicAdd(&row[j2 - c0], 0xFFFFFFFFu);
+        }
+    }
     // A quarter wave takes 16 special sites of sample i at a time: lane l fetches entry l and its site's list bounds (one memory
     // round trip for the 16 of them), then the 16 lanes walk the 16 sites' lists together.
     const unsigned sub = threadIdx.x >> 4, nsub = blockDim.x >> 4, l16 = threadIdx.x & 15;
@@ -352,7 +369,7 @@ __global__ __launch_bounds__(1024) void general_fixup_kernel(const unsigned long
 static void gs_free(GeneralSparse *g)
 {
     if (!g) return;
-    void *p[] = {g->s_off, g->p_off, g->n_off, g->s_ent, g->p_ent, g->n_ent, g->c_n, g->c_p, g->s_nn, g->snn_off};
+    void *p[] = {g->s_off, g->p_off, g->n_off, g->s_ent, g->p_ent, g->n_ent, g->c_n, g->c_p, g->s_nn, g->snn_off, g->s_inl, g->inl_off};
     if (!g->in_arena) for (void *q : p) if (q) (void)hipFree(q);
     delete g;
 }
@@ -482,7 +499,8 @@ __device__ __forceinline__ unsigned minor_rank(const uint4 &m, unsigned off_g, i
 template <class NT>
 __global__ __launch_bounds__(256) void minor_site_lists_kernel(const MinorBuild mb, size_t n_pad, unsigned n,
                                                                unsigned long long *__restrict__ p_off, unsigned long long *__restrict__ n_off,
-                                                               unsigned *__restrict__ p_ent, NT *__restrict__ n_ent, uint2 *__restrict__ E)
+                                                               unsigned *__restrict__ p_ent, NT *__restrict__ n_ent, uint2 *__restrict__ E,
+                                                               unsigned *__restrict__ site_inl)
 {
     __shared__ unsigned kp[SITES_PER_GROUP], kn[SITES_PER_GROUP], curP[SITES_PER_GROUP], curN[SITES_PER_GROUP], rk[SITES_PER_GROUP];
     __shared__ unsigned long long bP[SITES_PER_GROUP], bN[SITES_PER_GROUP];
@@ -547,6 +565,20 @@ __global__ __launch_bounds__(256) void minor_site_lists_kernel(const MinorBuild 
             }
         }
     }
+    // the one or two listed samples of a minority site, for the inline entries of the per-sample streams (0xFFFFFFFF: the site's N
+    // entries point at its list instead)
+    if (site_inl) {
+        __threadfence_block();
+        __syncthreads();
+        if (tid < SITES_PER_GROUP) {
+            unsigned v = 0xFFFFFFFFu;
+            if (mine && ((mp[tw] >> tb) & 1u) && kp[tid] >= 1u && kp[tid] <= 2u) {
+                const unsigned j1 = p_ent[bP[tid]] >> ENT_SHIFT, j2 = kp[tid] == 2u ? p_ent[bP[tid] + 1] >> ENT_SHIFT : 0xFFFFu;
+                v = j1 | (j2 << 16);
+            }
+            site_inl[g * SITES_PER_GROUP + tid] = v;
+        }
+    }
 }
 
 __device__ __forceinline__ bool minor_row_wanted(const MinorBuild &mb, size_t s)
@@ -559,17 +591,21 @@ __device__ __forceinline__ bool minor_row_wanted(const MinorBuild &mb, size_t s)
 //   s_ent  what general_fixup_kernel<MINOR> walks: rank << 5 | 15 for every minority site at which the sample is N (FILL = false:
 //          cnt[s * NCH + chunk] of them), then -- minor_listed_kernel -- its listed entries;
 //   s_nn   what nn_rows_kernel walks: for every NNL site at which the sample is N, the start of the site's N list in units of 8
-//          entries (cntq[s * GS_CHUNKS + chunk] of them).  The list starts of a group's 128 sites are summed once
+//          entries (cntq[s * GS_CHUNKS + chunk] of them);
+//   s_inl  (consensus alignments below 65 535 samples) the N entries at minority sites with one or two listed samples, as those
+//          samples themselves (site_inl, written by the per-site pass) instead of a pointer to the site: they leave s_ent.  The list starts of a group's 128 sites are summed once
 //          per wave and group from the sites' (padded) N counts -- a wave prefix sum parked in LDS -- instead of being looked up.
 static constexpr int MS_NCH = GS_CHUNKS + 1;      // the last "chunk" of a sample's s_ent list holds its listed entries
 constexpr unsigned NULL_ENTRY = 0xFFFFFFFFu;      // padding of the per-sample streams: no site (both walks skip it)
 template <bool FILL>
 __global__ __launch_bounds__(256) void minor_sample_kernel(const MinorBuild mb, size_t n_pad, size_t n, size_t groups, size_t gpc,
-                                                           unsigned *__restrict__ cnt, unsigned *__restrict__ cntq,
+                                                           unsigned *__restrict__ cnt, unsigned *__restrict__ cntq, unsigned *__restrict__ cnti,
                                                            const unsigned long long *__restrict__ off, const unsigned long long *__restrict__ offq,
-                                                           unsigned *__restrict__ ent, unsigned *__restrict__ entq)
+                                                           const unsigned long long *__restrict__ offi, const unsigned *__restrict__ site_inl,
+                                                           unsigned *__restrict__ ent, unsigned *__restrict__ entq, unsigned *__restrict__ enti)
 {
     __shared__ unsigned start8[4][SITES_PER_GROUP];
+    __shared__ unsigned inl8[FILL ? 4 : 1][SITES_PER_GROUP];   // the group's site_inl words (FILL)
     const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t chunk = (size_t)blockIdx.y * 4 + wave;
@@ -577,7 +613,7 @@ __global__ __launch_bounds__(256) void minor_sample_kernel(const MinorBuild mb, 
     const bool mine = s < n && minor_row_wanted(mb, s);      // (cnt was zeroed: an unwanted sample's list is empty)
     const size_t g0 = chunk * gpc, g1 = min(groups, g0 + gpc);
     const uint4 *nplane = mb.planes + 4 * n_pad + min(s, n_pad - 1);
-    unsigned c = 0, cq = 0;
+    unsigned c = 0, cq = 0, ci = 0;
     // a thread's entries leave four at a time (one 16-byte store instead of four scattered 4-byte ones: the fill is bound by the
     // number of store transactions, ~17 ps each, not by bytes)
     struct Stream4 {
@@ -597,14 +633,18 @@ __global__ __launch_bounds__(256) void minor_sample_kernel(const MinorBuild mb, 
     };
     Stream4 es{(FILL && mine) ? reinterpret_cast<uint4 *>(ent + off[s * MS_NCH + chunk]) : nullptr, 0u, 0u, 0u, 0u, 0u};
     Stream4 qs{(FILL && mine) ? reinterpret_cast<uint4 *>(entq + offq[s * GS_CHUNKS + chunk]) : nullptr, 0u, 0u, 0u, 0u, 0u};
+    Stream4 is{(FILL && mine && site_inl) ? reinterpret_cast<uint4 *>(enti + offi[s * GS_CHUNKS + chunk]) : nullptr, 0u, 0u, 0u, 0u, 0u};
     for (size_t g = g0; g < g1; g++) {
         const uint4 m4 = mb.lst_mask[g];                      // wave-uniform
         if ((m4.x | m4.y | m4.z | m4.w) == 0u) continue;
         const uint4 l4 = mb.nnl_mask[g], q4 = mb.minor_mask[g];
         const uint4 N = mine ? nplane[g * NPLANES * n_pad] : make_uint4(0u, 0u, 0u, 0u);
         if (!FILL) {
-            c += __popc(N.x & q4.x) + __popc(N.y & q4.y) + __popc(N.z & q4.z) + __popc(N.w & q4.w);
             cq += __popc(N.x & l4.x) + __popc(N.y & l4.y) + __popc(N.z & l4.z) + __popc(N.w & l4.w);
+            // (which of the sample's N entries at minority sites travel inline: the sites of M_INL)
+            const uint4 i4 = site_inl ? mb.inl_mask[g] : make_uint4(0u, 0u, 0u, 0u);
+            ci += __popc(N.x & q4.x & i4.x) + __popc(N.y & q4.y & i4.y) + __popc(N.z & q4.z & i4.z) + __popc(N.w & q4.w & i4.w);
+            c += __popc(N.x & q4.x & ~i4.x) + __popc(N.y & q4.y & ~i4.y) + __popc(N.z & q4.z & ~i4.z) + __popc(N.w & q4.w & ~i4.w);
             continue;
         }
         if ((l4.x | l4.y | l4.z | l4.w) != 0u) {
@@ -630,20 +670,35 @@ __global__ __launch_bounds__(256) void minor_sample_kernel(const MinorBuild mb, 
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         const unsigned og = mb.off_lst[g];
+        const uint4 i4 = site_inl ? mb.inl_mask[g] : make_uint4(0u, 0u, 0u, 0u);
+        if ((i4.x | i4.y | i4.z | i4.w) != 0u) {              // (wave-uniform) two coalesced loads instead of one dependent load per entry
+            const unsigned a0 = site_inl[g * SITES_PER_GROUP + lane], a1 = site_inl[g * SITES_PER_GROUP + 64 + lane];
+            __builtin_amdgcn_wave_barrier();
+            inl8[wave][lane] = a0; inl8[wave][64 + lane] = a1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
 #pragma unroll
         for (int w = 0; w < 4; w++) {
             unsigned nm = word_of(N, w) & word_of(m4, w);
             while (nm) {
                 const int b = __ffs(nm) - 1;
                 nm &= nm - 1;
-                if ((word_of(q4, w) >> b) & 1u) es.push((minor_rank(m4, og, w, b) << ENT_SHIFT) | 15u);
+                if ((word_of(q4, w) >> b) & 1u) {
+                    if ((word_of(i4, w) >> b) & 1u) is.push(inl8[wave][w * 32 + b]);
+                    else es.push((minor_rank(m4, og, w, b) << ENT_SHIFT) | 15u);
+                }
                 if ((word_of(l4, w) >> b) & 1u) qs.push(start8[wave][w * 32 + b]);
             }
         }
     }
-    if (FILL && mine) { es.flush(); qs.flush(); }
+    if (FILL && mine) { es.flush(); qs.flush(); if (site_inl) is.flush(); }
     // (a chunk's entries are padded to a multiple of four with null entries: 16-byte stores on 16-byte boundaries)
-    if (!FILL && mine) { cnt[s * MS_NCH + chunk] = (c + 3u) & ~3u; cntq[s * GS_CHUNKS + chunk] = (cq + 3u) & ~3u; }
+    if (!FILL && mine) {
+        cnt[s * MS_NCH + chunk] = (c + 3u) & ~3u; cntq[s * GS_CHUNKS + chunk] = (cq + 3u) & ~3u;
+        if (site_inl) cnti[s * GS_CHUNKS + chunk] = (ci + 3u) & ~3u;
+    }
 }
 
 // per-sample lists, listed entries (from E).  FILL = false: cnt[s * NCH + GS_CHUNKS]++ and c_p[s] += w (c_p of EVERY sample: a
@@ -691,7 +746,8 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb, hipStream_t s
     g->in_arena = true;                                    // (pack_alloc: the alignment's arena, or hipMalloc tracked by it)
     auto fail_soft = [&]() { (void)hipGetLastError(); gs_free(g); return TRACS_OK; };
 #define GS_TRY(x) do { if ((x) != hipSuccess) return fail_soft(); } while (0)
-    const unsigned long long tot_s = mb.tot_p + mb.tot_minor_n, tot_nn = mb.tot_nnl;
+    const unsigned long long tot_s = mb.tot_p + mb.tot_minor_n - mb.tot_inl, tot_nn = mb.tot_nnl, tot_inl = mb.tot_inl;
+    const bool inl = mb.inline_ok && tot_inl > 0;
     static const bool trace = std::getenv("TRACS_CLASSES_TRACE") != nullptr;
     const auto t_host0 = std::chrono::steady_clock::now();
     const size_t before = a->pack_extra.size();
@@ -704,6 +760,10 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb, hipStream_t s
     GS_TRY(pack_alloc(a, (tot_s + 3 * n * MS_NCH + 4) * 4, reinterpret_cast<void **>(&g->s_ent)));
     GS_TRY(hipMemsetAsync(g->s_ent, 0xFF, (tot_s + 3 * n * MS_NCH + 4) * 4, stream));      // (the listed entries' padding is never written)
     GS_TRY(pack_alloc(a, (tot_nn + 3 * n * GS_CHUNKS + 4) * 4, reinterpret_cast<void **>(&g->s_nn)));
+    if (inl) {
+        GS_TRY(pack_alloc(a, (n + 1) * 8, reinterpret_cast<void **>(&g->inl_off)));
+        GS_TRY(pack_alloc(a, (tot_inl + 3 * n * GS_CHUNKS + 4) * 4, reinterpret_cast<void **>(&g->s_inl)));
+    }
     GS_TRY(pack_alloc(a, std::max<size_t>(mb.tot_p, 1) * 4, reinterpret_cast<void **>(&g->p_ent)));
     // sample numbers (and the all-ones sentinel) fit 16 bits: half the bytes of every list walk.  Every N list starts on a
     // cache-line boundary, ends with a sentinel and is padded with more to a multiple of NN_LIST_PAD entries (mb.tot_n counts the
@@ -717,45 +777,51 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb, hipStream_t s
     if (trace) std::fprintf(stderr, "[once per pack] host: list storage %.2f GB (%zu of 9 arrays outside the arena) %.2f ms\n",
                             ((double)(tot_s + mb.tot_p + tot_nn) * 4 + (double)n_ent_bytes) * 1e-9, a->pack_extra.size() - before,
                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count());
-    unsigned *cnt = nullptr, *cur = nullptr, *cntq = nullptr;
-    unsigned long long *off = nullptr, *offq = nullptr;
+    unsigned *cnt = nullptr, *cur = nullptr, *cntq = nullptr, *cnti = nullptr, *site_inl = nullptr;
+    unsigned long long *off = nullptr, *offq = nullptr, *offi = nullptr;
     uint2 *E = nullptr;
     const size_t nsc = n * MS_NCH, nsq = n * GS_CHUNKS;
     int rc;
-    if ((rc = workspace_get(60, (nsc + nsq) * 4, reinterpret_cast<void **>(&cnt))) ||
-        (rc = workspace_get(61, (nsc + nsq + 2) * 8, reinterpret_cast<void **>(&off))) ||
+    if ((rc = workspace_get(60, (nsc + 2 * nsq) * 4, reinterpret_cast<void **>(&cnt))) ||
+        (rc = workspace_get(61, (nsc + 2 * nsq + 3) * 8, reinterpret_cast<void **>(&off))) ||
+        (inl && (rc = workspace_get(51, groups * SITES_PER_GROUP * 4, reinterpret_cast<void **>(&site_inl)))) ||
         (rc = workspace_get(62, std::max<size_t>(mb.tot_p, 1) * sizeof(uint2), reinterpret_cast<void **>(&E))) ||
         (rc = workspace_get(63, (std::max<size_t>(n, 1) + 8) * 4, reinterpret_cast<void **>(&cur)))) { gs_free(g); return rc; }
     cntq = cnt + nsc; offq = off + nsc + 1;
-    GS_TRY(hipMemsetAsync(cnt, 0, (nsc + nsq) * 4, stream));
+    cnti = cntq + nsq; offi = offq + nsq + 1;
+    GS_TRY(hipMemsetAsync(cnt, 0, (nsc + 2 * nsq) * 4, stream));
     GS_TRY(hipMemsetAsync(cur, 0, (std::max<size_t>(n, 1) + 8) * 4, stream));
     GS_TRY(hipMemsetAsync(g->c_p, 0, std::max<size_t>(n, 1) * 4, stream));
     if (g->n16)
         hipLaunchKernelGGL(minor_site_lists_kernel<unsigned short>, dim3((unsigned)groups), dim3(256), 0, stream, mb, a->n_pad, (unsigned)n,
-                           g->p_off, g->n_off, g->p_ent, reinterpret_cast<unsigned short *>(g->n_ent), E);
+                           g->p_off, g->n_off, g->p_ent, reinterpret_cast<unsigned short *>(g->n_ent), E, site_inl);
     else
         hipLaunchKernelGGL(minor_site_lists_kernel<unsigned>, dim3((unsigned)groups), dim3(256), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off,
-                           g->n_off, g->p_ent, g->n_ent, E);
+                           g->n_off, g->p_ent, g->n_ent, E, (unsigned *)nullptr);
     pack_stage_mark("lists: per site", stream);
     const size_t gpc = (groups + GS_CHUNKS - 1) / GS_CHUNKS;
     const dim3 sgrid((unsigned)((n + 63) / 64), GS_CHUNKS / 4);
     const unsigned egrid = (unsigned)((mb.tot_p + 255) / 256);
-    hipLaunchKernelGGL((minor_sample_kernel<false>), sgrid, dim3(256), 0, stream, mb, a->n_pad, n, groups, gpc, cnt, cntq, nullptr, nullptr, nullptr, nullptr);
+    hipLaunchKernelGGL((minor_sample_kernel<false>), sgrid, dim3(256), 0, stream, mb, a->n_pad, n, groups, gpc, cnt, cntq, cnti, nullptr, nullptr, nullptr,
+                       site_inl, nullptr, nullptr, nullptr);
     if (egrid) hipLaunchKernelGGL((minor_listed_kernel<false>), dim3(egrid), dim3(256), 0, stream, mb, E, mb.tot_p, cnt, g->c_p, nullptr, nullptr, nullptr);
     hipLaunchKernelGGL(minor_pad_listed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, cnt, n);
     hipLaunchKernelGGL(gs_scan_kernel, dim3(1), dim3(1024), 0, stream, cnt, nsc, off);
     hipLaunchKernelGGL(gs_scan_kernel, dim3(1), dim3(1024), 0, stream, cntq, nsq, offq);
+    if (inl) hipLaunchKernelGGL(gs_scan_kernel, dim3(1), dim3(1024), 0, stream, cnti, nsq, offi);
     unsigned long long *d_max = reinterpret_cast<unsigned long long *>(cur + ((std::max<size_t>(n, 1) + 1) & ~(size_t)1));     // behind `cur` (zeroed with it)
     hipLaunchKernelGGL(minor_sample_offsets_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, stream, off, n, MS_NCH, g->s_off, d_max);
     hipLaunchKernelGGL(minor_sample_offsets_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, stream, offq, n, GS_CHUNKS, g->snn_off, d_max + 1);
-    hipLaunchKernelGGL((minor_sample_kernel<true>), sgrid, dim3(256), 0, stream, mb, a->n_pad, n, groups, gpc, nullptr, nullptr, off, offq, g->s_ent, g->s_nn);
+    if (inl) hipLaunchKernelGGL(minor_sample_offsets_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, stream, offi, n, GS_CHUNKS, g->inl_off, d_max + 2);
+    hipLaunchKernelGGL((minor_sample_kernel<true>), sgrid, dim3(256), 0, stream, mb, a->n_pad, n, groups, gpc, nullptr, nullptr, nullptr, off, offq, offi,
+                       site_inl, g->s_ent, g->s_nn, g->s_inl);
     if (egrid) hipLaunchKernelGGL((minor_listed_kernel<true>), dim3(egrid), dim3(256), 0, stream, mb, E, mb.tot_p, nullptr, nullptr, off, cur, g->s_ent);
     GS_TRY(hipMemcpyAsync(&g->max_row, d_max, 8, hipMemcpyDeviceToHost, stream));       // (read after the caller's synchronisation)
     GS_TRY(hipMemcpyAsync(&g->max_row_nn, d_max + 1, 8, hipMemcpyDeviceToHost, stream));
     GS_TRY(hipGetLastError());
     pack_stage_mark("lists: per sample", stream);
 #undef GS_TRY
-    g->tot_s = tot_s; g->tot_nn = tot_nn;
+    g->tot_s = tot_s; g->tot_nn = tot_nn; g->tot_inl = inl ? tot_inl : 0;
     a->minor = g;
     *ok = 1;
     return TRACS_OK;
@@ -924,13 +990,13 @@ static int fixup_launch(const GeneralSparse *g, bool minor, unsigned L, size_t n
     if (minor && g->n16)
         hipLaunchKernelGGL((general_fixup_kernel<true, unsigned short>), grid, dim3(1024), chunk * 4, stream, g->s_off, g->s_ent, g->p_off, g->p_ent,
                            g->n_off, reinterpret_cast<const unsigned short *>(g->n_ent), g->c_n, g->c_p, L, (unsigned)n, (unsigned)row_begin,
-                           (unsigned)col_begin, chunk, dist, ncomp, ld);
+                           (unsigned)col_begin, chunk, dist, ncomp, ld, g->inl_off, g->s_inl);
     else if (minor)
         hipLaunchKernelGGL((general_fixup_kernel<true, unsigned>), grid, dim3(1024), chunk * 4, stream, g->s_off, g->s_ent, g->p_off, g->p_ent, g->n_off,
-                           g->n_ent, g->c_n, g->c_p, L, (unsigned)n, (unsigned)row_begin, (unsigned)col_begin, chunk, dist, ncomp, ld);
+                           g->n_ent, g->c_n, g->c_p, L, (unsigned)n, (unsigned)row_begin, (unsigned)col_begin, chunk, dist, ncomp, ld, g->inl_off, g->s_inl);
     else
         hipLaunchKernelGGL((general_fixup_kernel<false, unsigned>), grid, dim3(1024), chunk * 4, stream, g->s_off, g->s_ent, g->p_off, g->p_ent, g->n_off,
-                           g->n_ent, g->c_n, g->c_p, L, (unsigned)n, (unsigned)row_begin, (unsigned)col_begin, chunk, dist, ncomp, ld);
+                           g->n_ent, g->c_n, g->c_p, L, (unsigned)n, (unsigned)row_begin, (unsigned)col_begin, chunk, dist, ncomp, ld, g->inl_off, g->s_inl);
     TRACS_HIP_CHECK(hipGetLastError());
     return TRACS_OK;
 }

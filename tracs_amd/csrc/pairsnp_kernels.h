@@ -116,6 +116,9 @@ struct MinorBuild {
     size_t sites;                            // sites with lists
     unsigned long long tot_p, tot_n;         // list entries in all: listed samples, N samples
     unsigned long long tot_nnl, tot_minor_n; // N samples at the NNL sites / at the minority sites (per-sample stream sizes)
+    unsigned long long tot_inl;              // ... at the minority sites whose (one or two) listed samples travel inline (0: not in use)
+    bool inline_ok;
+    const uint4 *inl_mask;                   // those sites (M_INL)
 };
 int minority_lists_build(tracs_alignment *a, const MinorBuild &mb, hipStream_t stream, int *ok);
 void minority_lists_free(tracs_alignment *a);

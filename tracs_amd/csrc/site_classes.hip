@@ -89,7 +89,7 @@ __device__ __forceinline__ void load_group_words(const uint4 *__restrict__ P, si
 // Outputs per group: the class masks, the reference base bits, k and cN of every site, the list sizes of its sites that
 // carry lists (gP = sum of k over the minority sites, gN = sum of cN over the minority and NNL sites).
 // Mask slots of a group (masks[slot * groups + g], one uint4 = 128 sites each):
-enum { M_DENSE = 0, M_COUNT, M_MINOR, M_FULL, M_NNL, M_LST, M_UN, M_REFX, M_REFY, M_SLOTS };
+enum { M_DENSE = 0, M_COUNT, M_MINOR, M_FULL, M_NNL, M_LST, M_UN, M_REFX, M_REFY, M_INL, M_SLOTS };
 //   M_COUNT  sites whose N co-occurrences go through the matrix cores (cN > nn_list_max, or lists not in use)
 //   M_NNL    sites whose N co-occurrences come from their N lists (cN >= 2, cN ceil(cN / 64) <= nn_list_max: nn_rows_kernel, general_sparse.hip)
 //   M_LST    sites that carry lists at all (minority or NNL): list index = rank among these
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
                                                              unsigned nn_list_max, uint4 *__restrict__ masks, size_t groups,
                                                              unsigned *__restrict__ cntP, unsigned *__restrict__ cntN,
                                                              unsigned *__restrict__ gP, unsigned *__restrict__ gN, unsigned *__restrict__ gQ,
-                                                             unsigned *__restrict__ gR, unsigned *__restrict__ gS,
+                                                             unsigned *__restrict__ gR, unsigned *__restrict__ gS, unsigned *__restrict__ gI,
                                                              unsigned long long *__restrict__ flags, size_t flag_words,
                                                              unsigned *__restrict__ partial_flag)
 {
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
     __shared__ unsigned planes_lds[256][4][8];          // one counter's bit planes of every thread (32 KiB)
     __shared__ unsigned tot[2][SITES_PER_GROUP];        // k, cN
     __shared__ unsigned half_sum[SITES_PER_GROUP];
-    __shared__ unsigned wsum[2][5];
+    __shared__ unsigned wsum[2][6];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < SITES_PER_GROUP) { tot[0][tid] = 0; tot[1][tid] = 0; }
     if (tid < 4) { sref[0][tid] = 0; sref[1][tid] = 0; sref[2][tid] = 0; sref[3][tid] = 0; }
@@ -219,12 +219,14 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
         const bool counted = un && c >= 2 && !nnl;          // (a site with one N sample has no pair of N samples)
         const bool full = some && !dense && c == 0;
         const bool lst = minor || nnl;
-        const bool cls[7] = {dense, counted, minor, full, nnl, lst, un};
+        // (M_INL: minority sites with one or two listed samples -- the N samples' entries carry those samples inline)
+        const bool cls[8] = {dense, counted, minor, full, nnl, lst, un, minor && k <= 2};
+        constexpr int slot[8] = {M_DENSE, M_COUNT, M_MINOR, M_FULL, M_NNL, M_LST, M_UN, M_INL};
 #pragma unroll
-        for (int m = 0; m < 7; m++) {
+        for (int m = 0; m < 8; m++) {
             const unsigned long long bal = __ballot(cls[m]);
             if (lane == 0) {
-                unsigned *pm = reinterpret_cast<unsigned *>(&masks[(size_t)m * groups + g]);
+                unsigned *pm = reinterpret_cast<unsigned *>(&masks[(size_t)slot[m] * groups + g]);
                 pm[2 * wave] = (unsigned)bal; pm[2 * wave + 1] = (unsigned)(bal >> 32);
             }
         }
@@ -235,9 +237,12 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
         // whole lists that start on a cache-line boundary and need no length, general_sparse.hip; sq: list entries the N co-occurrence
         // walk visits at this site, cN per N sample)
         const unsigned cpad = nn_list_padded((unsigned)c);
-        unsigned sv[5] = {minor ? (unsigned)k : 0u, lst ? cpad : 0u, nnl ? (unsigned)(c * c) : 0u, nnl ? (unsigned)c : 0u, minor ? (unsigned)c : 0u};
+        // (the last: N samples at minority sites with one or two listed samples -- their entries of the per-sample streams carry the
+        // listed samples inline, general_sparse.hip)
+        unsigned sv[6] = {minor ? (unsigned)k : 0u, lst ? cpad : 0u, nnl ? (unsigned)(c * c) : 0u, nnl ? (unsigned)c : 0u, minor ? (unsigned)c : 0u,
+                          (minor && k <= 2) ? (unsigned)c : 0u};
 #pragma unroll
-        for (int m = 0; m < 5; m++) {
+        for (int m = 0; m < 6; m++) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) sv[m] += __shfl_xor(sv[m], off, 64);
             if (lane == 0) wsum[wave][m] = sv[m];
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
     __syncthreads();
     if (tid == 0) {
         gP[g] = wsum[0][0] + wsum[1][0]; gN[g] = wsum[0][1] + wsum[1][1]; gQ[g] = wsum[0][2] + wsum[1][2];
-        gR[g] = wsum[0][3] + wsum[1][3]; gS[g] = wsum[0][4] + wsum[1][4];
+        gR[g] = wsum[0][3] + wsum[1][3]; gS[g] = wsum[0][4] + wsum[1][4]; gI[g] = wsum[0][5] + wsum[1][5];
     }
     if (tid < 4) {
         reinterpret_cast<unsigned *>(&masks[(size_t)M_REFX * groups + g])[tid] = refx[tid];
@@ -256,8 +261,8 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
 
 // Exclusive prefix sums over the groups, one workgroup per array (1024 groups at a time):
 //   blocks 0..6  sizes of the mask slots M_DENSE .. M_UN (popcount of the mask) -> off32[b][g], totals[b]
-//   blocks 7..11 per-group sums: gP / gN (list sizes), gQ (entries the N co-occurrence walk visits), gR / gS (N samples at the NNL /
-//                minority sites) -> off64[b - 7][g], totals[b]
+//   blocks 7..12 per-group sums: gP / gN (list sizes), gQ (entries the N co-occurrence walk visits), gR / gS / gI (N samples at the
+//                NNL / minority / inline-able minority sites) -> off64[b - 7][g], totals[b]
 __global__ __launch_bounds__(1024) void group_offsets_kernel(const uint4 *__restrict__ masks, const unsigned *__restrict__ gcounts, size_t groups,
                                                              unsigned *__restrict__ off32, unsigned long long *__restrict__ off64,
                                                              unsigned long long *__restrict__ totals)
@@ -505,8 +510,8 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     if ((rc = workspace_get(52, M_SLOTS * groups * sizeof(uint4), reinterpret_cast<void **>(&masks)))) return rc;
     if ((rc = workspace_get(53, 7 * groups * sizeof(unsigned), reinterpret_cast<void **>(&offs)))) return rc;
     if ((rc = workspace_get(54, 2 * groups * SITES_PER_GROUP * sizeof(unsigned), reinterpret_cast<void **>(&cnts)))) return rc;
-    if ((rc = workspace_get(55, 5 * groups * sizeof(unsigned), reinterpret_cast<void **>(&gcnt)))) return rc;
-    if ((rc = workspace_get(56, 5 * (groups + 1) * sizeof(unsigned long long), reinterpret_cast<void **>(&off64)))) return rc;
+    if ((rc = workspace_get(55, 6 * groups * sizeof(unsigned), reinterpret_cast<void **>(&gcnt)))) return rc;
+    if ((rc = workspace_get(56, 6 * (groups + 1) * sizeof(unsigned long long), reinterpret_cast<void **>(&off64)))) return rc;
     if ((rc = workspace_get(57, 128, reinterpret_cast<void **>(&totals)))) return rc;
     if ((rc = workspace_get(58, groups * flag_words * sizeof(unsigned long long), reinterpret_cast<void **>(&flags)))) return rc;
     d_flag = reinterpret_cast<unsigned *>(totals + 15);
@@ -526,9 +531,9 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     const unsigned nn_list_max = (no_nnl || !allow_nnl) ? 0u : (unsigned)std::min(4.0e9, nnl_k * (double)a->n * (double)a->n);
     TRACS_HIP_CHECK(hipMemsetAsync(totals, 0, 128, stream));
     hipLaunchKernelGGL(classify_sites_kernel, dim3((unsigned)groups), dim3(256), 0, stream, a->planes, a->n_pad, (unsigned)a->n, budget,
-                       nn_list_max, masks, groups, cntP, cntN, gcnt, gcnt + groups, gcnt + 2 * groups, gcnt + 3 * groups, gcnt + 4 * groups, flags, flag_words, d_flag);
+                       nn_list_max, masks, groups, cntP, cntN, gcnt, gcnt + groups, gcnt + 2 * groups, gcnt + 3 * groups, gcnt + 4 * groups, gcnt + 5 * groups, flags, flag_words, d_flag);
     stage_mark("classify", stream);
-    hipLaunchKernelGGL(group_offsets_kernel, dim3(12), dim3(1024), 0, stream, masks, gcnt, groups, offs, off64, totals);
+    hipLaunchKernelGGL(group_offsets_kernel, dim3(13), dim3(1024), 0, stream, masks, gcnt, groups, offs, off64, totals);
     unsigned long long tot[16] = {0};
     TRACS_HIP_CHECK(hipMemcpyAsync(tot, totals, 128, hipMemcpyDeviceToHost, stream));
     TRACS_HIP_CHECK(hipStreamSynchronize(stream));
@@ -537,7 +542,7 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     const bool consensus = !*partial && !force_general;
     const size_t L_dense = (size_t)tot[M_DENSE], L_count = (size_t)tot[M_COUNT], L_minor = (size_t)tot[M_MINOR], L_full = (size_t)tot[M_FULL];
     const size_t L_nnl = (size_t)tot[M_NNL], L_lst = (size_t)tot[M_LST], L_un = (size_t)tot[M_UN];
-    const unsigned long long tot_p = tot[7], tot_n = tot[8], tot_nnl = tot[10], tot_minor_n = tot[11];
+    const unsigned long long tot_p = tot[7], tot_n = tot[8], tot_nnl = tot[10], tot_minor_n = tot[11], tot_inl = tot[12];
     if (force == 0 || a->L == 0 || a->n < 2) return TRACS_OK;
     // matrix instructions per pair: planes_full per site now; planes_full per dense site + one per counted site with classes
     const double planes_full = consensus ? 4.0 : 5.0;
@@ -606,9 +611,14 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
         int built = 0;
         MinorBuild mb;
         mb.planes = a->planes; mb.minor_mask = mask_of(M_MINOR); mb.nnl_mask = mask_of(M_NNL); mb.lst_mask = mask_of(M_LST);
-        mb.ref_x = mask_of(M_REFX); mb.ref_y = mask_of(M_REFY); mb.off_lst = off_of(M_LST);
+        mb.ref_x = mask_of(M_REFX); mb.ref_y = mask_of(M_REFY); mb.inl_mask = mask_of(M_INL); mb.off_lst = off_of(M_LST);
         mb.cntP = cntP; mb.cntN = cntN; mb.baseP = off64; mb.baseN = off64 + groups; mb.flags = flags; mb.flag_words = flag_words;
         mb.sites = L_lst; mb.tot_p = tot_p; mb.tot_n = tot_n; mb.tot_nnl = tot_nnl; mb.tot_minor_n = tot_minor_n;
+        // a consensus alignment's listed samples all differ from the reference base (w = 1): an N entry at a site with one or two
+        // of them can carry them in its 32 bits (16-bit sample numbers) instead of pointing at the site's list
+        static const bool no_inline = [] { const char *e = std::getenv("TRACS_LIST_INLINE"); return e && std::atoi(e) == 0; }();
+        mb.inline_ok = consensus && a->n < 65535 && !no_inline;
+        mb.tot_inl = mb.inline_ok ? tot_inl : 0;
         mb.n_rows = a->n_row_hint;
         for (int k = 0; k < 4; k++) mb.rows[k] = (unsigned)std::min<size_t>(a->row_hint[k], a->n);
         rc = minority_lists_build(a, mb, stream, &built);
