@@ -961,7 +961,8 @@ int nn_rows_add(tracs_alignment *a, size_t row_begin, size_t row_end, size_t col
         attr_set = true;
     }
     // ~2048 workgroups' worth of entries each, never less than 8192 entries (a workgroup's fixed cost: its row in LDS)
-    const unsigned long long target = std::max<unsigned long long>(8192ull, g->tot_nn / 2048ull);
+    static const unsigned long long target_env = [] { const char *e = std::getenv("TRACS_NN_TARGET"); return e ? std::strtoull(e, nullptr, 10) : 0ull; }();
+    const unsigned long long target = target_env ? target_env : std::max<unsigned long long>(8192ull, g->tot_nn / 2048ull);
     const unsigned splits = (unsigned)std::min<unsigned long long>(NN_MAX_SPLITS, std::max<unsigned long long>(1, (g->max_row_nn + target - 1) / target));
     const dim3 grid((unsigned)(row_end - row_begin), (unsigned)((n + chunk - 1) / chunk), splits);
     if (g->n16)

@@ -22,6 +22,12 @@
 
 namespace tracs {
 
+#ifndef TRACS_TC_TPL
+#define TRACS_TC_TPL 4       // E(K) wave loop: consecutive k per lane and step
+#endif
+#ifndef TRACS_TC_WAVES
+#define TRACS_TC_WAVES 3     // ... its register budget, as waves per SIMD
+#endif
 constexpr int LG_TABLE = 32768;     // lgamma(n) table, n < LG_TABLE; beyond: lgamma() inline
 constexpr int LK_TABLE = 10240;     // log(k) table behind it (the E(K) loop stops at k = 10 000): lg[LG_TABLE + k] = log(k)
 
@@ -40,9 +46,12 @@ __device__ __forceinline__ double lae(double x, double y)   // logaddexpd, trans
     return tmp;
 }
 
+// (beyond the table -- SNP distances of 22 000 and more -- and out of line: inlined at every use, lgamma's registers cost the E(K)
+// kernels their occupancy: 284 VGPRs against 128)
+__device__ __noinline__ double lgamma_beyond(double x) { return lgamma(x); }
 __device__ __forceinline__ double lg_at(const double *__restrict__ lg, long long n)
 {
-    return n < LG_TABLE ? lg[n] : lgamma((double)n);
+    return n < LG_TABLE ? lg[n] : lgamma_beyond((double)n);
 }
 
 // i * log(x) as the shipped -ffast-math build evaluates it: the i == 0 term is 0 even when
@@ -158,7 +167,7 @@ constexpr unsigned long long TC_TABLE_ELEMS = 48ull << 20;      // doubles in th
 // A key handed over without any term summed (state[0] is NaN: tc_keys_kernel does that for delta > 0 and N >= TC_WAVE_PREFIX_MIN)
 // starts here with the two O(N) prefix sums of the loop -- pois (:144-148) and S_N -- as wave sums of 64 terms per step instead of a
 // serial fold, and p0 (the k = 0 value, :276-282) comes back through `p0_out`.
-__device__ void tc_eval_wave(int N, double delta, const TcParams &P, const double *__restrict__ lg, double &eK,
+__device__ __forceinline__ void tc_eval_wave(int N, double delta, const TcParams &P, const double *__restrict__ lg, double &eK,
                              const double *__restrict__ state, int k_start, double *p0_out, const TcTables *__restrict__ tab, long long gap)
 {
     // this key's rows of the (gap, M) tables, when they exist and hold it
@@ -182,14 +191,6 @@ __device__ void tc_eval_wave(int N, double delta, const TcParams &P, const doubl
             if (lane >= off) e += o;
         }
         return e;
-    };
-    // one more term batch into a scaled sum: returns every lane's inclusive prefix (in the possibly moved units)
-    auto accumulate = [&](double t, double &scaled, double &mx, bool &moved) {
-        const double m = wave_max(t);
-        moved = m > mx;
-        if (moved) { scaled = mx == -INFINITY ? 0.0 : scaled * exp(mx - m); mx = m; }
-        const double e = t == -INFINITY ? 0.0 : exp(t - mx);
-        return scaled + wave_prefix(e);
     };
     // sum = scaled * exp(mx); an empty sum is (0, -inf)
     double pois, ld = 0.0, upper;
@@ -238,48 +239,118 @@ __device__ void tc_eval_wave(int N, double delta, const TcParams &P, const doubl
     if (pos) upper = exp(P.ln_beta + delta * P.lamb + log(n1) - (P.ln_lamb + pois));
     else upper = exp(P.ln_beta + log(n1) - P.ln_lamb);
     double lim = Me == -INFINITY ? INFINITY : (upper - P.thr) * exp(-Me);
-    for (int k0 = k_start; k0 < 10000; k0 += 64) {
-        const int k = k0 + lane;
-        const bool live = k < 10000;
-        const long long M = (long long)N + k;
-        const double m1 = (double)(M + 1) * P.ln_lb;
-        const double lk = lkt[live ? k : 0];
-        double t1, t2;
+    // TPL consecutive k per lane and step (lane-major: the terms of a step stay in k order): the TPL x 2 exponentials of a lane are
+    // independent, and the two wave scans and two wave maxima of a step are paid once per 64 x TPL terms
+    constexpr int TPL = TRACS_TC_TPL;
+    // Where the loop starts.  The elprob terms t2(k) = C + k ln(beta / (lamb + beta)) + lgG(N + k + 1) - lgG(k + 1) + ln k grow while
+    // k < k* = beta (N + 1) / lamb (t2(k + 1) - t2(k) = ln(beta (N + k + 1) / ((lamb + beta) k))) and fall behind it, and the lprob
+    // terms are t1(k) = t2(k) + c(k) with c(k) = ln S_{N+k} - delta (lamb + beta) <= 0 growing with k.  Every term before
+    // k_lo <= min(k*, 9999) with t2(k_lo) <= t2(min(k*, 9999)) - 60 is therefore below e^-60 of the largest term of its sum: all of them
+    // together change neither sum by an ulp, and they are skipped -- at N = 1 000 (k* = 2 440, the loop stops near 3 000) the first
+    // 1 500 terms, at N = 10 000 (k* beyond the loop's 10 000 terms) all but the last ~ 200.  The stopping test cannot fire among the
+    // skipped terms when their sum, at most k_lo exp(t2(k_lo)), is below upper - thr: checked.  Needs S from the table (the running sum
+    // S cannot skip), so tabled keys with delta > 0 only; k_lo is looked for at 64 probes between the start and the peak.
+    if (pos && tabled && upper - P.thr > 0.0) {
+        const double c2 = n1 * P.ln_lamb - lg_n1 - delta * P.beta - pois + delta * (P.lamb + P.beta);
+        auto t2_at = [&](int k) {
+            const long long M = (long long)N + k;
+            return c2 + (double)k * P.ln_beta + lg_at(lg, M + 1) - lg_at(lg, (long long)k + 1) + lkt[k] - (double)(M + 1) * P.ln_lb;
+        };
+        const double kstar = floor(P.beta * n1 / P.lamb);
+        const int k_peak = (int)fmin(9999.0, fmax(1.0, kstar));
+        if (k_peak > k_start + 64 * TPL) {
+            const double t_peak = t2_at(k_peak);
+            const int kj = k_start + (int)(((long long)(k_peak - k_start) * lane) >> 6);
+            const double tj = t2_at(kj);
+            const unsigned long long low = __ballot(tj <= t_peak - 60.0);
+            if (low) {
+                const int j = 63 - __clzll((long long)low);
+                const int k_lo = __shfl(kj, j, 64);
+                const double t_lo = __shfl(tj, j, 64);
+                if (log((double)k_lo) + t_lo < log(upper - P.thr)) k_start = k_lo;
+            }
+        }
+    }
+    auto accumulate_n = [&](const double (&t)[TPL], double &scaled, double &mx, bool &moved, double (&out)[TPL]) {
+        double m = t[0];
+#pragma unroll
+        for (int q = 1; q < TPL; q++) m = fmax(m, t[q]);
+        m = wave_max(m);
+        moved = m > mx;
+        if (moved) { scaled = mx == -INFINITY ? 0.0 : scaled * exp(mx - m); mx = m; }
+        double run = 0.0;
+#pragma unroll
+        for (int q = 0; q < TPL; q++) { run += t[q] == -INFINITY ? 0.0 : exp(t[q] - mx); out[q] = run; }
+        const double incl = wave_prefix(run);
+        const double before = __shfl_up(incl, 1, 64);
+        const double base = scaled + (lane ? before : 0.0);
+#pragma unroll
+        for (int q = 0; q < TPL; q++) out[q] += base;
+        scaled = __shfl(out[TPL - 1], 63, 64);                         // (every term of the step included)
+    };
+    for (int k0 = k_start; k0 < 10000; k0 += 64 * TPL) {
+        const int kb = k0 + lane * TPL;
+        double t1[TPL], t2[TPL], lp[TPL], el[TPL];
+        bool live[TPL];
         bool moved;
         if (pos) {
-            double Sk, Sl = 0.0;
+            double Sk[TPL];
             if (tabled) {
-                Sk = live ? rowS[M] : 0.0;
+#pragma unroll
+                for (int q = 0; q < TPL; q++) Sk[q] = kb + q < 10000 ? rowS[(long long)N + kb + q] : 0.0;
             } else {
-                const double a = live ? imul(M, ld) + (double)M * P.ln_lb - lg_at(lg, M + 1) : -INFINITY;
-                Sl = accumulate(a, Ss, Ms, moved);
-                Sk = Ms + log(Sl);
+                double a[TPL], Sl[TPL];
+#pragma unroll
+                for (int q = 0; q < TPL; q++) {
+                    const long long M = (long long)N + kb + q;
+                    a[q] = kb + q < 10000 ? imul(M, ld) + (double)M * P.ln_lb - lg_at(lg, M + 1) : -INFINITY;
+                }
+                accumulate_n(a, Ss, Ms, moved, Sl);
+#pragma unroll
+                for (int q = 0; q < TPL; q++) Sk[q] = Ms + log(Sl[q]);
             }
-            double lhs = (n1 * P.ln_lamb + (double)k * P.ln_beta + lg_at(lg, M + 1));
-            lhs = lhs - lg_n1 - lg_at(lg, (long long)k + 1) - delta * P.beta;
-            lhs -= pois;
-            t1 = (lhs + (Sk - m1)) + lk;
-            t2 = lhs + lk + delta * (P.lamb + P.beta) - m1;
-            if (!tabled) Ss = __shfl(Sl, 63, 64);
+#pragma unroll
+            for (int q = 0; q < TPL; q++) {
+                const int k = kb + q;
+                live[q] = k < 10000;
+                const long long M = (long long)N + k;
+                const double m1 = (double)(M + 1) * P.ln_lb;
+                const double lk = lkt[live[q] ? k : 0];
+                double lhs = (n1 * P.ln_lamb + (double)k * P.ln_beta + lg_at(lg, M + 1));
+                lhs = lhs - lg_n1 - lg_at(lg, (long long)k + 1) - delta * P.beta;
+                lhs -= pois;
+                t1[q] = live[q] ? (lhs + (Sk[q] - m1)) + lk : -INFINITY;
+                t2[q] = live[q] ? lhs + lk + delta * (P.lamb + P.beta) - m1 : -INFINITY;
+            }
         } else {
-            const double lhs = (n1 * P.ln_lamb + (double)k * P.ln_beta + lg_at(lg, M + 1) - lg_n1 -
-                                lg_at(lg, (long long)k + 1) - m1);
-            t1 = lhs + lk;
-            t2 = lhs + lk + delta * (P.lamb + P.beta) - m1;
+#pragma unroll
+            for (int q = 0; q < TPL; q++) {
+                const int k = kb + q;
+                live[q] = k < 10000;
+                const long long M = (long long)N + k;
+                const double m1 = (double)(M + 1) * P.ln_lb;
+                const double lk = lkt[live[q] ? k : 0];
+                const double lhs = (n1 * P.ln_lamb + (double)k * P.ln_beta + lg_at(lg, M + 1) - lg_n1 -
+                                    lg_at(lg, (long long)k + 1) - m1);
+                t1[q] = live[q] ? lhs + lk : -INFINITY;
+                t2[q] = live[q] ? lhs + lk + delta * (P.lamb + P.beta) - m1 : -INFINITY;
+            }
         }
-        if (!live) { t1 = -INFINITY; t2 = -INFINITY; }
-        const double lp = accumulate(t1, Lps, Mp, moved);
-        const double el = accumulate(t2, Els, Me, moved);
+        accumulate_n(t1, Lps, Mp, moved, lp);
+        accumulate_n(t2, Els, Me, moved, el);
         if (moved) lim = (upper - P.thr) * exp(-Me);
-        const bool stop = live && !(el < lim);                         // the while condition (upper - elprob > thr) fails after this k
+        // the while condition (upper - elprob > thr) fails after the first k whose prefix reaches lim (the prefixes grow with k)
+        bool stop = false;
+        double val = lp[TPL - 1];
+#pragma unroll
+        for (int q = TPL - 1; q >= 0; q--)
+            if (live[q] && !(el[q] < lim)) { stop = true; val = lp[q]; }
         const unsigned long long m = __ballot(stop);
         if (m) {
             const int f = __ffsll((long long)m) - 1;
-            eK = __shfl(lp, f, 64) * exp(Mp);
+            eK = __shfl(val, f, 64) * exp(Mp);
             return;
         }
-        Lps = __shfl(lp, 63, 64);
-        Els = __shfl(el, 63, 64);
     }
     eK = Lps * exp(Mp);                                                // ran to k = 9999
 }
@@ -513,7 +584,7 @@ __global__ __launch_bounds__(64) void tc_tables_kernel(TcTables *__restrict__ ta
 }
 
 template <class Src>
-__global__ __launch_bounds__(64) void tc_long_keys_kernel(Src src, const unsigned *__restrict__ key_elem,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TRACS_TC_WAVES, TRACS_TC_WAVES))) void tc_long_keys_kernel(Src src, const unsigned *__restrict__ key_elem,
                                                           const unsigned *__restrict__ long_ids,
                                                           const unsigned *__restrict__ n_long, TcParams P,
                                                           const double *__restrict__ lg, double *__restrict__ key_p0,
