@@ -44,6 +44,7 @@ struct GeneralSparse {
     unsigned *s_inl = nullptr;
     unsigned long long *inl_off = nullptr;
     unsigned long long tot_inl = 0;
+    unsigned split_at = 0;                 // N lists of 64 samples and more are in two parts (pairsnp_kernels.h: nn_list_is_split)
     bool in_arena = false;                        // the arrays live in the alignment's pack arena (released with it, not one by one)
     bool n16 = false;                             // n_ent holds 16-bit sample numbers (site-class lists of alignments below 65 535 samples)
     bool padded = false;                          // N lists start on 16-byte boundaries, padded with all-ones sentinels to 8 entries
@@ -503,6 +504,7 @@ __global__ __launch_bounds__(256) void minor_site_lists_kernel(const MinorBuild 
                                                                unsigned *__restrict__ site_inl)
 {
     __shared__ unsigned kp[SITES_PER_GROUP], kn[SITES_PER_GROUP], curP[SITES_PER_GROUP], curN[SITES_PER_GROUP], rk[SITES_PER_GROUP];
+    __shared__ unsigned curB[SITES_PER_GROUP], partB[SITES_PER_GROUP];      // a split list's second part: cursor, first entry
     __shared__ unsigned long long bP[SITES_PER_GROUP], bN[SITES_PER_GROUP];
     const size_t g = blockIdx.x;
     const int tid = threadIdx.x;
@@ -516,8 +518,11 @@ __global__ __launch_bounds__(256) void minor_site_lists_kernel(const MinorBuild 
     const bool mine = tid < SITES_PER_GROUP && ((m[tw] >> tb) & 1u);
     if (tid < SITES_PER_GROUP) {
         kp[tid] = (mine && ((mp[tw] >> tb) & 1u)) ? mb.cntP[g * SITES_PER_GROUP + tid] : 0u;
-        kn[tid] = mine ? nn_list_padded(mb.cntN[g * SITES_PER_GROUP + tid]) : 0u;     // (sentinel + padding: see the builder)
-        curP[tid] = 0; curN[tid] = 0;
+        const unsigned cn = mine ? mb.cntN[g * SITES_PER_GROUP + tid] : 0u, ca = mine ? mb.cntA[g * SITES_PER_GROUP + tid] : 0u;
+        kn[tid] = mine ? nn_list_padded(cn, ca, mb.split_at) : 0u;                      // (sentinel + padding: see the builder)
+        // (an unsplit list has no second part: no sample passes `s >= n`)
+        partB[tid] = nn_list_is_split(cn, mb.split_at) ? nn_list_first_part(ca) : 0u;
+        curP[tid] = 0; curN[tid] = 0; curB[tid] = 0;
     }
     __syncthreads();
     if (mine) {
@@ -526,8 +531,12 @@ __global__ __launch_bounds__(256) void minor_site_lists_kernel(const MinorBuild 
         const unsigned rank = minor_rank(m4, mb.off_lst[g], tw, tb);
         bP[tid] = mb.baseP[g] + pp; bN[tid] = mb.baseN[g] + pn; rk[tid] = rank;
         p_off[rank] = bP[tid]; n_off[rank] = bN[tid];
+        // the first part's last pad ends without a sentinel: the walk goes on into the second part
+        const unsigned ca = mb.cntA[g * SITES_PER_GROUP + tid];
+        if (partB[tid] && ca % NN_LIST_PAD) n_ent[bN[tid] + partB[tid] - 1u] = (NT)(sizeof(NT) == 2 ? NN_LIST_FILL16 : NN_LIST_FILL32);
     }
     __syncthreads();
+    const unsigned split_at = mb.split_at;
     const uint4 RX = mb.ref_x[g], RY = mb.ref_y[g];
     const uint4 *base = mb.planes + (g * NPLANES) * n_pad;
     for (unsigned s = tid; s < n; s += 256) {
@@ -539,8 +548,10 @@ __global__ __launch_bounds__(256) void minor_site_lists_kernel(const MinorBuild 
             while (nm) {
                 const int b = __ffs(nm) - 1;
                 nm &= nm - 1;
-                const unsigned slot = atomicAdd(&curN[w * 32 + b], 1u);
-                n_ent[bN[w * 32 + b] + slot] = (NT)s;
+                const int t = w * 32 + b;
+                const bool second = partB[t] && s >= split_at;
+                const unsigned slot = second ? partB[t] + atomicAdd(&curB[t], 1u) : atomicAdd(&curN[t], 1u);
+                n_ent[bN[t] + slot] = (NT)s;
             }
         }
         if (!flagged) continue;
@@ -609,6 +620,7 @@ __global__ __launch_bounds__(256) void minor_sample_kernel(const MinorBuild mb, 
     const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t chunk = (size_t)blockIdx.y * 4 + wave;
+    const bool upper_half = mb.split_at && (size_t)blockIdx.x * 64 >= mb.split_at;      // (split_at is a multiple of 256: the wave's 64 samples agree)
     if (chunk >= GS_CHUNKS) return;                          // (wave-uniform)
     const bool mine = s < n && minor_row_wanted(mb, s);      // (cnt was zeroed: an unwanted sample's list is empty)
     const size_t g0 = chunk * gpc, g1 = min(groups, g0 + gpc);
@@ -651,7 +663,13 @@ __global__ __launch_bounds__(256) void minor_sample_kernel(const MinorBuild mb, 
             // list starts of the group's sites: lane l sums the padded counts of sites l and 64 + l
             auto padded = [&](int t) {
                 const bool in = (word_of(m4, t >> 5) >> (t & 31)) & 1u;
-                return in ? nn_list_padded(mb.cntN[g * SITES_PER_GROUP + t]) : 0u;
+                return in ? nn_list_padded(mb.cntN[g * SITES_PER_GROUP + t], mb.cntA[g * SITES_PER_GROUP + t], mb.split_at) : 0u;
+            };
+            // where a row at or beyond split_at starts: the second part of a split list
+            auto second = [&](int t) {
+                const bool in = (word_of(m4, t >> 5) >> (t & 31)) & 1u;
+                const unsigned cn = in ? mb.cntN[g * SITES_PER_GROUP + t] : 0u;
+                return (upper_half && nn_list_is_split(cn, mb.split_at)) ? nn_list_first_part(mb.cntA[g * SITES_PER_GROUP + t]) : 0u;
             };
             const unsigned v0 = padded(lane), v1 = padded(64 + lane);
             unsigned p0 = v0, p1 = v1;
@@ -663,8 +681,8 @@ __global__ __launch_bounds__(256) void minor_sample_kernel(const MinorBuild mb, 
             const unsigned tot0 = __shfl(p0, 63, 64);
             const unsigned long long base = mb.baseN[g];
             __builtin_amdgcn_wave_barrier();
-            start8[wave][lane] = (unsigned)((base + p0 - v0) / 8ull);
-            start8[wave][64 + lane] = (unsigned)((base + tot0 + p1 - v1) / 8ull);
+            start8[wave][lane] = (unsigned)((base + p0 - v0 + second(lane)) / 8ull);
+            start8[wave][64 + lane] = (unsigned)((base + tot0 + p1 - v1 + second(64 + lane)) / 8ull);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -821,7 +839,7 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb, hipStream_t s
     GS_TRY(hipGetLastError());
     pack_stage_mark("lists: per sample", stream);
 #undef GS_TRY
-    g->tot_s = tot_s; g->tot_nn = tot_nn; g->tot_inl = inl ? tot_inl : 0;
+    g->tot_s = tot_s; g->tot_nn = tot_nn; g->tot_inl = inl ? tot_inl : 0; g->split_at = mb.split_at;
     a->minor = g;
     *ok = 1;
     return TRACS_OK;
@@ -851,9 +869,10 @@ template <class NT>
 __global__ __launch_bounds__(TRACS_NN_THREADS) void nn_rows_kernel(const unsigned long long *__restrict__ s_off, const unsigned *__restrict__ s_nn,
                                                                    const NT *__restrict__ n_ent, const unsigned *__restrict__ c_u, unsigned n, unsigned row_begin, unsigned col_begin,
                                                                    unsigned chunk, unsigned long long target, unsigned *__restrict__ ncomp, size_t ld,
-                                                                   int add_terms, unsigned lu)
+                                                                   int add_terms, unsigned lu, unsigned split_at)
 {
-    extern __shared__ unsigned row[];                        // `chunk` counters, then 64 list starts per wave
+    // `chunk` counters -- row[0] is column `lo`, the first cell of the row in this chunk --, 64 slots nobody reads, 64 list starts per wave
+    extern __shared__ unsigned row[];
     constexpr unsigned EPL = 16 / sizeof(NT);                // entries per lane and load
     const unsigned i = row_begin + blockIdx.x;
     const unsigned c0 = blockIdx.y * chunk, c1 = min(n, c0 + chunk);
@@ -864,82 +883,123 @@ __global__ __launch_bounds__(TRACS_NN_THREADS) void nn_rows_kernel(const unsigne
     if (blockIdx.z >= nz) return;
     const unsigned long long per = ((len + nz - 1) / nz + 63) / 64 * 64;
     const unsigned long long e0 = e_first + blockIdx.z * per, e1 = min(e_last, e0 + per);
-    for (unsigned j = threadIdx.x; j < c1 - c0; j += blockDim.x) row[j] = 0;
+    const unsigned lo = max(max(i + 1, col_begin), c0);     // columns [lo, c1) of this chunk are cells of row i
+    const unsigned span = c1 - lo;
+    if (sizeof(NT) == 2 && (unsigned)(size_t)row != 0u) __builtin_trap();       // (the walk's LDS adds address row[] from 0)
+    for (unsigned j = threadIdx.x; j < span + 64u; j += blockDim.x) row[j] = 0;
     __syncthreads();
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    const unsigned grp = lane >> 4, l16 = lane & 15u;
-    unsigned *scratch = row + chunk + wave * 64;
-    constexpr unsigned SENT = (unsigned)(NT)~(NT)0;
-    const unsigned lo = max(max(i + 1, col_begin), c0);     // columns [lo, c1) of this chunk are cells of row i
-    // The entries of one 16-lane group load.  A list occupies whole pads of NN_LIST_PAD entries (LP lanes) and the pad behind its
-    // last sample-holding pad belongs to the next list: a group load of two pads (16-bit sample numbers) takes its second pad only
-    // if the first one ends without a sentinel (one compare on one lane and a ballot -- not a compare per entry).  Sentinels fail
-    // the column-range test by themselves.  Returns true when the load's last entry is no sentinel: the list goes on.
     constexpr unsigned LP = NN_LIST_PAD / EPL;               // lanes per pad: 8 (16-bit) or 16 (32-bit)
+    // Lanes per list and load.  A row at or beyond split_at walks second parts and unsplit lists only -- one pad each, but for the
+    // rare list of 64 and more samples in a part --, so eight lanes (one pad) take a list and a wave load covers eight lists; the
+    // rows below split_at take two pads at once with sixteen lanes.  (What the walk is bound by is the number of LDS add
+    // instructions, ~10 cycles each whatever their active lanes: DESIGN.md 3.1.)
+    const unsigned lgs = (LP < 16u && split_at && i >= split_at) ? 3u : 4u, LG = 1u << lgs, lists_per_load = 64u >> lgs;
+    const unsigned grp = lane >> lgs, l16 = lane & (LG - 1u);
+    unsigned *scratch = row + chunk + 64 + wave * 64;
+    constexpr unsigned SENT = (unsigned)(NT)~(NT)0;
+    // The entries of one group load.  A list occupies whole pads of NN_LIST_PAD entries (LP lanes) and the pad behind its last
+    // sample-holding pad belongs to the next list: a group load of two pads takes its second pad only if the first one ends
+    // without a sentinel (one compare per lane and one ballot -- not a compare per entry).
+    // Every entry of a pad taken adds to LDS, without a branch: column j goes to row[j - lo], and whatever is no cell of the row
+    // (j <= i, another column chunk, the sentinels) wraps beyond `span` in j - lo and is clamped to the lane's own slot behind the
+    // row, row[span + lane] -- two packed 16-bit instructions per pair of entries and a shift each.
+    // Returns true when the load's last entry is no sentinel: the list goes on.
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    const us2 lo2 = {(unsigned short)lo, (unsigned short)lo}, out2 = {(unsigned short)(span + lane), (unsigned short)(span + lane)};
     auto bump_all = [&](const uint4 &d) -> bool {
         const unsigned w[4] = {d.x, d.y, d.z, d.w};
         const unsigned tail = sizeof(NT) == 2 ? (w[3] >> 16) : w[3];
-        bool take = true;
-        if (LP < 16u) {
-            const unsigned long long full = __ballot(l16 == LP - 1u && tail != SENT);       // first pad without a sentinel
-            take = l16 < LP || ((full >> (grp * 16 + LP - 1u)) & 1ull);
-        }
-        const unsigned long long on = __ballot(l16 == 15u && tail != SENT && take);
+        const unsigned long long goes_on = __ballot(tail != SENT) >> (grp << lgs);      // this group's lanes from bit 0
+        const bool first_full = (goes_on >> (LP - 1u)) & 1ull;                           // first pad without a sentinel
+        const bool take = l16 < LP || first_full;
+        const bool on = ((goes_on >> (LG - 1u)) & 1ull) && first_full;
         if (take) {
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 if (sizeof(NT) == 2) {
-                    const unsigned a = w[k] & 0xFFFFu, b = w[k] >> 16;
-                    if (a >= lo && a < c1) atomicAdd(&row[a - c0], 1u);
-                    if (b >= lo && b < c1) atomicAdd(&row[b - c0], 1u);
-                } else if (w[k] >= lo && w[k] < c1) atomicAdd(&row[w[k] - c0], 1u);
+                    us2 v = __builtin_bit_cast(us2, w[k]);
+                    v = __builtin_elementwise_min((us2)(v - lo2), out2);
+                    // (byte offsets of the two counters: one SDWA shift per half -- the compiler takes a mask / bit-field extract
+                    // and a shift each)
+                    const unsigned pair = __builtin_bit_cast(unsigned, v);
+                    unsigned b0, b1;
+                    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(b0) : "v"(2u), "v"(pair));
+                    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(b1) : "v"(2u), "v"(pair));
+                    // (row[] is the kernel's only LDS object: byte offset = LDS address, checked at the top)
+                    asm volatile("ds_add_u32 %0, %1" : : "v"(b0), "v"(1u) : "memory");
+                    asm volatile("ds_add_u32 %0, %1" : : "v"(b1), "v"(1u) : "memory");
+                } else atomicAdd(&row[min(w[k] - lo, span + lane)], 1u);
             }
         }
-        return (on >> (grp * 16 + 15)) & 1ull;
+        return on;
     };
     const uint4 *__restrict__ lists = reinterpret_cast<const uint4 *>(n_ent);      // (every list starts on a 16-byte boundary)
-    for (unsigned long long base = e0 + (unsigned long long)wave * 64; base < e1; base += (unsigned long long)nwaves * 64) {
-        const unsigned long long e = base + lane;
+    // The walk is a chain of dependent round trips (stream entry -> list -> LDS adds): what it is bound by is how many of them a
+    // wave keeps in flight, not bytes or instructions (PMC: 3.7 TB/s fetched, VALU and LDS under half busy).  So the loop is
+    // software-pipelined twice over: the NEXT batch's stream entries are requested when a batch starts, and the NEXT round's lists
+    // (NN_FLIGHT x 4 of them) before the current round's entries are added.
+    const uint4 none = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    // (every load is issued unconditionally -- a lane without a list reads the head of the array and drops it when the round is
+    // applied --: straight-line code, so that the compiler waits for the current round with the next one still in flight)
+    struct Round { unsigned sl[NN_FLIGHT]; uint4 d[NN_FLIGHT]; };
+    auto fetch = [&](unsigned t0, unsigned cnt, Round &r) {
+#pragma unroll
+        for (int u = 0; u < NN_FLIGHT; u++) {
+            const unsigned idx = t0 + lists_per_load * u + grp;
+            r.sl[u] = scratch[min(idx, 63u)];
+            if (idx >= cnt) r.sl[u] = 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int u = 0; u < NN_FLIGHT; u++) r.d[u] = lists[(size_t)(r.sl[u] != 0xFFFFFFFFu ? r.sl[u] : 0u) + l16];
+    };
+    auto apply = [&](const Round &r) {
+#pragma unroll
+        for (int u = 0; u < NN_FLIGHT; u++) {
+            // a list goes on behind its first 16 x 16 bytes while the group has seen no sentinel (rare: lists of 128 (64)
+            // samples and more); which of the wave's four groups go on is a ballot away
+            const bool has = r.sl[u] != 0xFFFFFFFFu;
+            bool on = bump_all(make_uint4(has ? r.d[u].x : 0xFFFFFFFFu, has ? r.d[u].y : 0xFFFFFFFFu, has ? r.d[u].z : 0xFFFFFFFFu, has ? r.d[u].w : 0xFFFFFFFFu));
+            for (unsigned step = 1;; step++) {
+                if (!__ballot(on)) break;                // wave-uniform
+                const uint4 nx = on ? lists[(size_t)r.sl[u] + LG * step + l16] : none;
+                const bool more = bump_all(nx);
+                on = on && more;
+            }
+        }
+    };
+    const unsigned long long first = e0 + (unsigned long long)wave * 64, stride = (unsigned long long)nwaves * 64;
+    unsigned st_next = first + lane < e1 ? s_nn[first + lane] : 0xFFFFFFFFu;          // (0xFFFFFFFF: padding of the stream)
+    for (unsigned long long base = first; base < e1; base += stride) {
         // this lane's entry of the batch -- the start of a list, in units of 16 bytes -- parked in the wave's LDS scratch
-        const unsigned st = e < e1 ? s_nn[e] : 0xFFFFFFFFu;   // (0xFFFFFFFF: padding of the stream)
+        const unsigned st = st_next;
+        const unsigned long long en = base + stride + lane;
+        unsigned st_load = s_nn[min(en, e_last - 1)];        // (unconditional, like the list loads; dropped below when beyond the end)
         scratch[lane] = st == 0xFFFFFFFFu ? 0xFFFFFFFFu : (unsigned)((unsigned long long)st * 8ull / EPL);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const unsigned cnt = (unsigned)min(64ull, e1 - base);
-        for (unsigned t0 = 0; t0 < cnt; t0 += 4 * NN_FLIGHT) {
-            unsigned sl[NN_FLIGHT];
-            bool has[NN_FLIGHT];
-            uint4 d[NN_FLIGHT];
-#pragma unroll
-            for (int u = 0; u < NN_FLIGHT; u++) {
-                const unsigned idx = t0 + 4 * u + grp;
-                sl[u] = idx < cnt ? scratch[idx] : 0xFFFFFFFFu;
-                has[u] = sl[u] != 0xFFFFFFFFu;
-            }
-#pragma unroll
-            for (int u = 0; u < NN_FLIGHT; u++)
-                d[u] = has[u] ? lists[(size_t)sl[u] + l16] : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-#pragma unroll
-            for (int u = 0; u < NN_FLIGHT; u++) {
-                // a list goes on behind its first 16 x 16 bytes while the group has seen no sentinel (rare: lists of 128 (64)
-                // samples and more); which of the wave's four groups go on is a ballot away
-                bool on = bump_all(d[u]);
-                for (unsigned step = 1;; step++) {
-                    if (!__ballot(on)) break;                // wave-uniform
-                    const uint4 nx = on ? lists[(size_t)sl[u] + 16u * step + l16] : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-                    const bool more = bump_all(nx);
-                    on = on && more;
-                }
-            }
+        // (two rounds per trip, each in its own registers: handing a round over by copy would wait for its loads.  A fetch beyond
+        // the batch finds no list and loads the head of the array, which stays in cache)
+        Round ra, rb;
+        fetch(0, cnt, ra);
+        const unsigned per_round = lists_per_load * NN_FLIGHT;
+        for (unsigned t0 = 0; t0 < cnt; t0 += 2 * per_round) {
+            fetch(t0 + per_round, cnt, rb);
+            apply(ra);
+            fetch(t0 + 2 * per_round, cnt, ra);
+            apply(rb);
         }
+        st_next = en < e1 ? st_load : 0xFFFFFFFFu;
         __builtin_amdgcn_wave_barrier();                   // (the scratch is rewritten by the next batch)
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");   // (the adds issued from inline assembly are not in the compiler's count)
     __syncthreads();
     const bool terms = add_terms && blockIdx.z == 0;
     const unsigned ci = terms ? c_u[i] : 0u;
     for (unsigned j = lo + threadIdx.x; j < c1; j += blockDim.x) {
-        const unsigned v = row[j - c0] + (terms ? lu - ci - c_u[j] : 0u);
+        const unsigned v = row[j - lo] + (terms ? lu - ci - c_u[j] : 0u);
         if (v) {
             if (nz > 1) atomicAdd(&ncomp[(size_t)i * ld + j], v);
             else ncomp[(size_t)i * ld + j] += v;
@@ -956,8 +1016,8 @@ int nn_rows_add(tracs_alignment *a, size_t row_begin, size_t row_end, size_t col
     const unsigned chunk = (unsigned)std::min<size_t>((n + 63) / 64 * 64, 32768);
     static bool attr_set = false;
     if (!attr_set) {
-        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(nn_rows_kernel<unsigned>), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4 + TRACS_NN_THREADS * 4));
-        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(nn_rows_kernel<unsigned short>), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4 + TRACS_NN_THREADS * 4));
+        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(nn_rows_kernel<unsigned>), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4 + 256 + TRACS_NN_THREADS * 4));
+        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(nn_rows_kernel<unsigned short>), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4 + 256 + TRACS_NN_THREADS * 4));
         attr_set = true;
     }
     // ~2048 workgroups' worth of entries each, never less than 8192 entries (a workgroup's fixed cost: its row in LDS)
@@ -966,12 +1026,12 @@ int nn_rows_add(tracs_alignment *a, size_t row_begin, size_t row_end, size_t col
     const unsigned splits = (unsigned)std::min<unsigned long long>(NN_MAX_SPLITS, std::max<unsigned long long>(1, (g->max_row_nn + target - 1) / target));
     const dim3 grid((unsigned)(row_end - row_begin), (unsigned)((n + chunk - 1) / chunk), splits);
     if (g->n16)
-        hipLaunchKernelGGL(nn_rows_kernel<unsigned short>, grid, dim3(TRACS_NN_THREADS), chunk * 4 + TRACS_NN_THREADS * 4, stream, g->snn_off, g->s_nn,
+        hipLaunchKernelGGL(nn_rows_kernel<unsigned short>, grid, dim3(TRACS_NN_THREADS), chunk * 4 + 256 + TRACS_NN_THREADS * 4, stream, g->snn_off, g->s_nn,
                            reinterpret_cast<const unsigned short *>(g->n_ent), a->c_counted, (unsigned)n, (unsigned)row_begin, (unsigned)col_begin,
-                           chunk, target, ncomp, ld, add_terms, lu);
+                           chunk, target, ncomp, ld, add_terms, lu, g->split_at);
     else
-        hipLaunchKernelGGL(nn_rows_kernel<unsigned>, grid, dim3(TRACS_NN_THREADS), chunk * 4 + TRACS_NN_THREADS * 4, stream, g->snn_off, g->s_nn, g->n_ent, a->c_counted,
-                           (unsigned)n, (unsigned)row_begin, (unsigned)col_begin, chunk, target, ncomp, ld, add_terms, lu);
+        hipLaunchKernelGGL(nn_rows_kernel<unsigned>, grid, dim3(TRACS_NN_THREADS), chunk * 4 + 256 + TRACS_NN_THREADS * 4, stream, g->snn_off, g->s_nn, g->n_ent, a->c_counted,
+                           (unsigned)n, (unsigned)row_begin, (unsigned)col_begin, chunk, target, ncomp, ld, add_terms, lu, g->split_at);
     TRACS_HIP_CHECK(hipGetLastError());
     return TRACS_OK;
 }

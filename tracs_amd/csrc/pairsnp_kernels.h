@@ -102,6 +102,18 @@ int general_sparse_fixup(tracs_alignment *a, size_t row_begin, size_t row_end, s
 // (one cache line of 16-bit sample numbers): every list starts on a line boundary and its end needs no length
 constexpr unsigned NN_LIST_PAD = 64;
 __host__ __device__ inline unsigned nn_list_padded(unsigned c) { return (c / NN_LIST_PAD + 1u) * NN_LIST_PAD; }
+// A list that needs two pads anyway (c >= NN_LIST_PAD) is laid out in two parts, each on its own cache line(s): the N samples below
+// `split_at` (a multiple of 256 near n / 2), then the others.  Row i counts only the columns j > i, so a row at or beyond split_at
+// starts its walk at the second part: it never reads the first part's lines.  The first part is padded to whole pads and the LAST
+// entry of its last pad is NN_LIST_FILL, not the sentinel (the walk goes on into the second part: nn_rows_kernel stops at a pad
+// whose last entry is the sentinel); the second part ends like an unsplit list.  split_at = 0: no list is split.
+constexpr unsigned NN_LIST_FILL16 = 0xFFFEu, NN_LIST_FILL32 = 0xFFFFFFFEu;
+__host__ __device__ inline bool nn_list_is_split(unsigned c, unsigned split_at) { return split_at != 0u && c >= NN_LIST_PAD; }
+__host__ __device__ inline unsigned nn_list_first_part(unsigned c_first) { return (c_first + NN_LIST_PAD - 1u) / NN_LIST_PAD * NN_LIST_PAD; }
+__host__ __device__ inline unsigned nn_list_padded(unsigned c, unsigned c_first, unsigned split_at)
+{
+    return nn_list_is_split(c, split_at) ? nn_list_first_part(c_first) + nn_list_padded(c - c_first) : nn_list_padded(c);
+}
 struct MinorBuild {
     const uint4 *planes;                     // the five general planes
     const uint4 *minor_mask, *nnl_mask, *lst_mask;   // per group: minority sites, N co-occurrence list sites, their union
@@ -118,7 +130,9 @@ struct MinorBuild {
     unsigned long long tot_nnl, tot_minor_n; // N samples at the NNL sites / at the minority sites (per-sample stream sizes)
     unsigned long long tot_inl;              // ... at the minority sites whose (one or two) listed samples travel inline (0: not in use)
     bool inline_ok;
-    const uint4 *inl_mask;                   // those sites (M_INL)
+    const uint4 *inl_mask;
+    const unsigned *cntA;                    // N samples below split_at, per site (see nn_list_is_split)
+    unsigned split_at;                   // those sites (M_INL)
 };
 int minority_lists_build(tracs_alignment *a, const MinorBuild &mb, hipStream_t stream, int *ok);
 void minority_lists_free(tracs_alignment *a);

@@ -96,8 +96,8 @@ enum { M_DENSE = 0, M_COUNT, M_MINOR, M_FULL, M_NNL, M_LST, M_UN, M_REFX, M_REFY
 //   M_UN     every site outside the dense class with cN >= 1 (M_COUNT, M_NNL and the cN = 1 sites, which have no co-occurrence)
 __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__restrict__ P, size_t n_pad, unsigned n, unsigned budget,
                                                              unsigned nn_list_max, uint4 *__restrict__ masks, size_t groups,
-                                                             unsigned *__restrict__ cntP, unsigned *__restrict__ cntN,
-                                                             unsigned *__restrict__ gP, unsigned *__restrict__ gN, unsigned *__restrict__ gQ,
+                                                             unsigned *__restrict__ cntP, unsigned *__restrict__ cntN, unsigned *__restrict__ cntA,
+                                                             unsigned split_at, unsigned *__restrict__ gP, unsigned *__restrict__ gN, unsigned *__restrict__ gQ,
                                                              unsigned *__restrict__ gR, unsigned *__restrict__ gS, unsigned *__restrict__ gI,
                                                              unsigned long long *__restrict__ flags, size_t flag_words,
                                                              unsigned *__restrict__ partial_flag)
@@ -107,10 +107,11 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
     __shared__ unsigned sref[4][4];                     // one-base sample seen, ref X, ref Y, somebody is not N
     __shared__ unsigned planes_lds[256][4][8];          // one counter's bit planes of every thread (32 KiB)
     __shared__ unsigned tot[2][SITES_PER_GROUP];        // k, cN
+    __shared__ unsigned tot_first[SITES_PER_GROUP];     // cN among the samples below split_at
     __shared__ unsigned half_sum[SITES_PER_GROUP];
     __shared__ unsigned wsum[2][6];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < SITES_PER_GROUP) { tot[0][tid] = 0; tot[1][tid] = 0; }
+    if (tid < SITES_PER_GROUP) { tot[0][tid] = 0; tot[1][tid] = 0; tot_first[tid] = 0; }
     if (tid < 4) { sref[0][tid] = 0; sref[1][tid] = 0; sref[2][tid] = 0; sref[3][tid] = 0; }
     __syncthreads();
 
@@ -177,6 +178,10 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
         for (int j = 0; j < 8; j++) { kp[w][j] = 0; np[w][j] = 0; }
     unsigned since = 0;
     for (unsigned base = 0; base < n; base += 256) {
+        if (base == split_at && base) {                       // (block-uniform) the N counts so far: the first part of a split list
+            flush(np, 1);
+            if (!half) tot_first[site] = tot[1][site];
+        }
         const unsigned s = base + tid;
         bool listed_here = false;
         if (s < n) {
@@ -230,16 +235,20 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
                 pm[2 * wave] = (unsigned)bal; pm[2 * wave + 1] = (unsigned)(bal >> 32);
             }
         }
+        const unsigned long long ca = some ? tot_first[tid] : 0ull;
         cntP[g * SITES_PER_GROUP + tid] = (unsigned)k;
         cntN[g * SITES_PER_GROUP + tid] = (unsigned)c;
+        cntA[g * SITES_PER_GROUP + tid] = (unsigned)ca;
         // (sq: list entries the N co-occurrence walk visits at this site, cN per N sample; an NNL site has cN < 2^16)
         // (an N list ends with at least one sentinel and is padded with more to a multiple of NN_LIST_PAD entries: 16-byte loads of
         // whole lists that start on a cache-line boundary and need no length, general_sparse.hip; sq: list entries the N co-occurrence
         // walk visits at this site, cN per N sample)
-        const unsigned cpad = nn_list_padded((unsigned)c);
+        const unsigned cpad = nn_list_padded((unsigned)c, (unsigned)ca, split_at);
+        // (a split list: the rows of its first part walk all of it, the others the second part only)
+        const unsigned long long walked = nn_list_is_split((unsigned)c, split_at) ? ca * c + (c - ca) * (c - ca) : c * c;
         // (the last: N samples at minority sites with one or two listed samples -- their entries of the per-sample streams carry the
         // listed samples inline, general_sparse.hip)
-        unsigned sv[6] = {minor ? (unsigned)k : 0u, lst ? cpad : 0u, nnl ? (unsigned)(c * c) : 0u, nnl ? (unsigned)c : 0u, minor ? (unsigned)c : 0u,
+        unsigned sv[6] = {minor ? (unsigned)k : 0u, lst ? cpad : 0u, nnl ? (unsigned)walked : 0u, nnl ? (unsigned)c : 0u, minor ? (unsigned)c : 0u,
                           (minor && k <= 2) ? (unsigned)c : 0u};
 #pragma unroll
         for (int m = 0; m < 6; m++) {
@@ -509,7 +518,7 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     int rc;
     if ((rc = workspace_get(52, M_SLOTS * groups * sizeof(uint4), reinterpret_cast<void **>(&masks)))) return rc;
     if ((rc = workspace_get(53, 7 * groups * sizeof(unsigned), reinterpret_cast<void **>(&offs)))) return rc;
-    if ((rc = workspace_get(54, 2 * groups * SITES_PER_GROUP * sizeof(unsigned), reinterpret_cast<void **>(&cnts)))) return rc;
+    if ((rc = workspace_get(54, 3 * groups * SITES_PER_GROUP * sizeof(unsigned), reinterpret_cast<void **>(&cnts)))) return rc;
     if ((rc = workspace_get(55, 6 * groups * sizeof(unsigned), reinterpret_cast<void **>(&gcnt)))) return rc;
     if ((rc = workspace_get(56, 6 * (groups + 1) * sizeof(unsigned long long), reinterpret_cast<void **>(&off64)))) return rc;
     if ((rc = workspace_get(57, 128, reinterpret_cast<void **>(&totals)))) return rc;
@@ -517,7 +526,10 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     d_flag = reinterpret_cast<unsigned *>(totals + 15);
     auto mask_of = [&](int slot) { return masks + (size_t)slot * groups; };
     auto off_of = [&](int slot) { return offs + (size_t)slot * groups; };
-    unsigned *cntP = cnts, *cntN = cnts + groups * SITES_PER_GROUP;
+    unsigned *cntP = cnts, *cntN = cnts + groups * SITES_PER_GROUP, *cntA = cnts + 2 * groups * SITES_PER_GROUP;
+    // lists of 64 and more N samples in two parts, by sample halves (pairsnp_kernels.h: nn_list_is_split); TRACS_NN_SPLIT=0: never
+    static const bool no_split = [] { const char *e = std::getenv("TRACS_NN_SPLIT"); return e && std::atoi(e) == 0; }();
+    const unsigned split_at = (no_split || a->n < 512) ? 0u : (unsigned)((a->n / 2 + 255) / 256 * 256);
     // a site goes to the minority lists while its k (cN + k) entries cost less than the extra operand planes over all pairs:
     // ~51 ns per site at 10 000 samples (pair kernel) against ~2-4 ps per list entry (general_fixup_kernel)
     const double bsites = (double)a->n * (double)a->n / 8000.0;
@@ -531,7 +543,7 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     const unsigned nn_list_max = (no_nnl || !allow_nnl) ? 0u : (unsigned)std::min(4.0e9, nnl_k * (double)a->n * (double)a->n);
     TRACS_HIP_CHECK(hipMemsetAsync(totals, 0, 128, stream));
     hipLaunchKernelGGL(classify_sites_kernel, dim3((unsigned)groups), dim3(256), 0, stream, a->planes, a->n_pad, (unsigned)a->n, budget,
-                       nn_list_max, masks, groups, cntP, cntN, gcnt, gcnt + groups, gcnt + 2 * groups, gcnt + 3 * groups, gcnt + 4 * groups, gcnt + 5 * groups, flags, flag_words, d_flag);
+                       nn_list_max, masks, groups, cntP, cntN, cntA, split_at, gcnt, gcnt + groups, gcnt + 2 * groups, gcnt + 3 * groups, gcnt + 4 * groups, gcnt + 5 * groups, flags, flag_words, d_flag);
     stage_mark("classify", stream);
     hipLaunchKernelGGL(group_offsets_kernel, dim3(13), dim3(1024), 0, stream, masks, gcnt, groups, offs, off64, totals);
     unsigned long long tot[16] = {0};
@@ -612,6 +624,7 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
         MinorBuild mb;
         mb.planes = a->planes; mb.minor_mask = mask_of(M_MINOR); mb.nnl_mask = mask_of(M_NNL); mb.lst_mask = mask_of(M_LST);
         mb.ref_x = mask_of(M_REFX); mb.ref_y = mask_of(M_REFY); mb.inl_mask = mask_of(M_INL); mb.off_lst = off_of(M_LST);
+        mb.cntA = cntA; mb.split_at = split_at;
         mb.cntP = cntP; mb.cntN = cntN; mb.baseP = off64; mb.baseN = off64 + groups; mb.flags = flags; mb.flag_words = flag_words;
         mb.sites = L_lst; mb.tot_p = tot_p; mb.tot_n = tot_n; mb.tot_nnl = tot_nnl; mb.tot_minor_n = tot_minor_n;
         // a consensus alignment's listed samples all differ from the reference base (w = 1): an N entry at a site with one or two
