@@ -501,7 +501,7 @@ template <class NT>
 __global__ __launch_bounds__(256) void minor_site_lists_kernel(const MinorBuild mb, size_t n_pad, unsigned n,
                                                                unsigned long long *__restrict__ p_off, unsigned long long *__restrict__ n_off,
                                                                unsigned *__restrict__ p_ent, NT *__restrict__ n_ent, uint2 *__restrict__ E,
-                                                               unsigned *__restrict__ site_inl)
+                                                               unsigned *__restrict__ site_inl, unsigned *__restrict__ site_start)
 {
     __shared__ unsigned kp[SITES_PER_GROUP], kn[SITES_PER_GROUP], curP[SITES_PER_GROUP], curN[SITES_PER_GROUP], rk[SITES_PER_GROUP];
     __shared__ unsigned curB[SITES_PER_GROUP], partB[SITES_PER_GROUP];      // a split list's second part: cursor, first entry
@@ -534,6 +534,10 @@ __global__ __launch_bounds__(256) void minor_site_lists_kernel(const MinorBuild 
         // the first part's last pad ends without a sentinel: the walk goes on into the second part
         const unsigned ca = mb.cntA[g * SITES_PER_GROUP + tid];
         if (partB[tid] && ca % NN_LIST_PAD) n_ent[bN[tid] + partB[tid] - 1u] = (NT)(sizeof(NT) == 2 ? NN_LIST_FILL16 : NN_LIST_FILL32);
+        // where a row's walk of this list starts, in units of 8 entries: [0] rows below split_at, [1] the others (the per-sample
+        // pass looks these up instead of summing the group's padded sizes again)
+        site_start[g * SITES_PER_GROUP + tid] = (unsigned)(bN[tid] / 8ull);
+        site_start[(gridDim.x + g) * SITES_PER_GROUP + tid] = (unsigned)((bN[tid] + partB[tid]) / 8ull);
     }
     __syncthreads();
     const unsigned split_at = mb.split_at;
@@ -613,6 +617,7 @@ __global__ __launch_bounds__(256) void minor_sample_kernel(const MinorBuild mb, 
                                                            unsigned *__restrict__ cnt, unsigned *__restrict__ cntq, unsigned *__restrict__ cnti,
                                                            const unsigned long long *__restrict__ off, const unsigned long long *__restrict__ offq,
                                                            const unsigned long long *__restrict__ offi, const unsigned *__restrict__ site_inl,
+                                                           const unsigned *__restrict__ site_start,
                                                            unsigned *__restrict__ ent, unsigned *__restrict__ entq, unsigned *__restrict__ enti)
 {
     __shared__ unsigned start8[4][SITES_PER_GROUP];
@@ -660,29 +665,12 @@ __global__ __launch_bounds__(256) void minor_sample_kernel(const MinorBuild mb, 
             continue;
         }
         if ((l4.x | l4.y | l4.z | l4.w) != 0u) {
-            // list starts of the group's sites: lane l sums the padded counts of sites l and 64 + l
-            auto padded = [&](int t) {
-                const bool in = (word_of(m4, t >> 5) >> (t & 31)) & 1u;
-                return in ? nn_list_padded(mb.cntN[g * SITES_PER_GROUP + t], mb.cntA[g * SITES_PER_GROUP + t], mb.split_at) : 0u;
-            };
-            // where a row at or beyond split_at starts: the second part of a split list
-            auto second = [&](int t) {
-                const bool in = (word_of(m4, t >> 5) >> (t & 31)) & 1u;
-                const unsigned cn = in ? mb.cntN[g * SITES_PER_GROUP + t] : 0u;
-                return (upper_half && nn_list_is_split(cn, mb.split_at)) ? nn_list_first_part(mb.cntA[g * SITES_PER_GROUP + t]) : 0u;
-            };
-            const unsigned v0 = padded(lane), v1 = padded(64 + lane);
-            unsigned p0 = v0, p1 = v1;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const unsigned a0 = __shfl_up(p0, d, 64), a1 = __shfl_up(p1, d, 64);
-                if (lane >= d) { p0 += a0; p1 += a1; }
-            }
-            const unsigned tot0 = __shfl(p0, 63, 64);
-            const unsigned long long base = mb.baseN[g];
+            // list starts of the group's sites (written by the per-site pass; the second table for rows from split_at on)
+            const unsigned *st = site_start + ((upper_half ? groups : 0) + g) * SITES_PER_GROUP;
+            const unsigned a0 = st[lane], a1 = st[64 + lane];
             __builtin_amdgcn_wave_barrier();
-            start8[wave][lane] = (unsigned)((base + p0 - v0 + second(lane)) / 8ull);
-            start8[wave][64 + lane] = (unsigned)((base + tot0 + p1 - v1 + second(64 + lane)) / 8ull);
+            start8[wave][lane] = a0;
+            start8[wave][64 + lane] = a1;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -795,7 +783,7 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb, hipStream_t s
     if (trace) std::fprintf(stderr, "[once per pack] host: list storage %.2f GB (%zu of 9 arrays outside the arena) %.2f ms\n",
                             ((double)(tot_s + mb.tot_p + tot_nn) * 4 + (double)n_ent_bytes) * 1e-9, a->pack_extra.size() - before,
                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count());
-    unsigned *cnt = nullptr, *cur = nullptr, *cntq = nullptr, *cnti = nullptr, *site_inl = nullptr;
+    unsigned *cnt = nullptr, *cur = nullptr, *cntq = nullptr, *cnti = nullptr, *site_inl = nullptr, *site_start = nullptr;
     unsigned long long *off = nullptr, *offq = nullptr, *offi = nullptr;
     uint2 *E = nullptr;
     const size_t nsc = n * MS_NCH, nsq = n * GS_CHUNKS;
@@ -803,6 +791,7 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb, hipStream_t s
     if ((rc = workspace_get(60, (nsc + 2 * nsq) * 4, reinterpret_cast<void **>(&cnt))) ||
         (rc = workspace_get(61, (nsc + 2 * nsq + 3) * 8, reinterpret_cast<void **>(&off))) ||
         (inl && (rc = workspace_get(51, groups * SITES_PER_GROUP * 4, reinterpret_cast<void **>(&site_inl)))) ||
+        (rc = workspace_get(47, 2 * groups * SITES_PER_GROUP * 4, reinterpret_cast<void **>(&site_start))) ||
         (rc = workspace_get(62, std::max<size_t>(mb.tot_p, 1) * sizeof(uint2), reinterpret_cast<void **>(&E))) ||
         (rc = workspace_get(63, (std::max<size_t>(n, 1) + 8) * 4, reinterpret_cast<void **>(&cur)))) { gs_free(g); return rc; }
     cntq = cnt + nsc; offq = off + nsc + 1;
@@ -812,16 +801,16 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb, hipStream_t s
     GS_TRY(hipMemsetAsync(g->c_p, 0, std::max<size_t>(n, 1) * 4, stream));
     if (g->n16)
         hipLaunchKernelGGL(minor_site_lists_kernel<unsigned short>, dim3((unsigned)groups), dim3(256), 0, stream, mb, a->n_pad, (unsigned)n,
-                           g->p_off, g->n_off, g->p_ent, reinterpret_cast<unsigned short *>(g->n_ent), E, site_inl);
+                           g->p_off, g->n_off, g->p_ent, reinterpret_cast<unsigned short *>(g->n_ent), E, site_inl, site_start);
     else
         hipLaunchKernelGGL(minor_site_lists_kernel<unsigned>, dim3((unsigned)groups), dim3(256), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off,
-                           g->n_off, g->p_ent, g->n_ent, E, (unsigned *)nullptr);
+                           g->n_off, g->p_ent, g->n_ent, E, (unsigned *)nullptr, site_start);
     pack_stage_mark("lists: per site", stream);
     const size_t gpc = (groups + GS_CHUNKS - 1) / GS_CHUNKS;
     const dim3 sgrid((unsigned)((n + 63) / 64), GS_CHUNKS / 4);
     const unsigned egrid = (unsigned)((mb.tot_p + 255) / 256);
     hipLaunchKernelGGL((minor_sample_kernel<false>), sgrid, dim3(256), 0, stream, mb, a->n_pad, n, groups, gpc, cnt, cntq, cnti, nullptr, nullptr, nullptr,
-                       site_inl, nullptr, nullptr, nullptr);
+                       site_inl, site_start, nullptr, nullptr, nullptr);
     if (egrid) hipLaunchKernelGGL((minor_listed_kernel<false>), dim3(egrid), dim3(256), 0, stream, mb, E, mb.tot_p, cnt, g->c_p, nullptr, nullptr, nullptr);
     hipLaunchKernelGGL(minor_pad_listed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, cnt, n);
     hipLaunchKernelGGL(gs_scan_kernel, dim3(1), dim3(1024), 0, stream, cnt, nsc, off);
@@ -832,7 +821,7 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb, hipStream_t s
     hipLaunchKernelGGL(minor_sample_offsets_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, stream, offq, n, GS_CHUNKS, g->snn_off, d_max + 1);
     if (inl) hipLaunchKernelGGL(minor_sample_offsets_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, stream, offi, n, GS_CHUNKS, g->inl_off, d_max + 2);
     hipLaunchKernelGGL((minor_sample_kernel<true>), sgrid, dim3(256), 0, stream, mb, a->n_pad, n, groups, gpc, nullptr, nullptr, nullptr, off, offq, offi,
-                       site_inl, g->s_ent, g->s_nn, g->s_inl);
+                       site_inl, site_start, g->s_ent, g->s_nn, g->s_inl);
     if (egrid) hipLaunchKernelGGL((minor_listed_kernel<true>), dim3(egrid), dim3(256), 0, stream, mb, E, mb.tot_p, nullptr, nullptr, off, cur, g->s_ent);
     GS_TRY(hipMemcpyAsync(&g->max_row, d_max, 8, hipMemcpyDeviceToHost, stream));       // (read after the caller's synchronisation)
     GS_TRY(hipMemcpyAsync(&g->max_row_nn, d_max + 1, 8, hipMemcpyDeviceToHost, stream));
