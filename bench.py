@@ -133,7 +133,8 @@ def nn_list_roofline(ls, sites, kern_s, rows, n):
     lists -- memory-bound.  Algorithmic bytes per launch: every visited list entry once (cN entries per walk -- one walk per N
     sample and site: the sum of cN^2 over those sites, 2 or 4 B each) + the walk's 4-byte entry of the per-sample stream.  Scaled by
     the rows of the launch (a rank's panel walks its rows' lists only).  What the kernel physically moves is more: a list of ~100
-    samples lies in two 128-byte lines (`traffic`)."""
+    samples lies in two 128-byte lines (`traffic`).  With split lists (csrc/pairsnp_kernels.h: nn_list_is_split) a row of the upper
+    sample half visits the second part only: nn_visits counts cA c + cB^2 per site."""
     frac_rows = rows / float(n)
     alg = (ls["nn_visits"] * ls["n_entry_bytes"] + ls["nn_walks"] * 4.0) * frac_rows
     return {"kernel": "nn_rows_kernel", "kernel_ms": kern_s * 1e3, "sites": sites, "bound": "hbm", "traffic": None,
@@ -142,8 +143,10 @@ def nn_list_roofline(ls, sites, kern_s, rows, n):
             "bytes_per_list_entry": ls["n_entry_bytes"],
             "entries_per_s": ls["nn_visits"] * frac_rows / kern_s,
             "note": "row i of the pair matrix in LDS; for every site at which sample i is N (and that has few N samples) the site's list "
-                    "of N samples is read (16 bytes per lane, four lists per load instruction), ds_add per j > i: sum of cN^2 list "
-                    "entries instead of n^2 / 2 pairs per site on the matrix cores; random reads of whole cache lines: HBM / fabric-bound"}
+                    "of N samples is read (16 bytes per lane, four or eight lists per load instruction), ds_add per j > i: sum of cN^2 list "
+                    "entries instead of n^2 / 2 pairs per site on the matrix cores.  Lists of 64 and more samples lie in two parts by "
+                    "sample halves: a row of the upper half reads the second part only (list_entries_visited counts what a row must look at).  "
+                    "Random reads of whole 128-byte lines: bound by the requests it pulls through the fabric (`traffic`, `hbm_physical`)"}
 
 
 def roofline_of(kernel, enc, pairs_per_launch, L, kern_s, traffic, n):
@@ -607,7 +610,12 @@ def dm_frontend(args, L, dev, torch, device):
 
     thr = max(5.0 / 30.0, 0.01)          # tracs align's rule at its defaults: max(min_cov / median coverage, error threshold), align.py:521
 
+    one_launch = stride * 2 == L         # the batch's codes are one contiguous run of site-rows: one launch for the batch
+
     def posterior():
+        if one_launch:
+            dev.posterior_codes_device(counts.view(batch * L, 4), alphas, False, thr, out=codes.view(-1))
+            return
         for b in range(batch):
             dev.posterior_codes_device(counts[b], alphas, False, thr, out=codes[b])     # straight into the batch buffer
 
@@ -633,8 +641,10 @@ def dm_frontend(args, L, dev, torch, device):
            "posterior_codes_GBps": sites * 8.5 / (t_post / 1e3) / 1e9, "pack_codes_GBps": sites * (0.5 + 0.625) / (t_pack / 1e3) / 1e9,
            "site_rows_per_s": sites / ((t_post + t_pack) / 1e3),
            "posterior_threshold": thr,
-           "note": "one posterior_codes launch per sample (5 M site-rows each: launch-sized; scripts/bench_config4.py streams 250 samples "
-                   "per launch), codes written straight into the batch buffer; algorithmic bytes: 8.5 B per site-row (posterior), 1.125 B (pack)"}
+           "launches": 1 if one_launch else batch,
+           "note": "posterior_codes over the batch's site-rows (one launch when a sample's codes fill whole 16-byte rows of the batch "
+                   "buffer, else one per sample; scripts/bench_config4.py streams 250 samples per launch), codes written straight into "
+                   "the batch buffer; algorithmic bytes: 8.5 B per site-row (posterior), 1.125 B (pack)"}
     aln.close()
     return out
 

@@ -880,9 +880,10 @@ __global__ __launch_bounds__(TRACS_NN_THREADS) void nn_rows_kernel(const unsigne
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     constexpr unsigned LP = NN_LIST_PAD / EPL;               // lanes per pad: 8 (16-bit) or 16 (32-bit)
     // Lanes per list and load.  A row at or beyond split_at walks second parts and unsplit lists only -- one pad each, but for the
-    // rare list of 64 and more samples in a part --, so eight lanes (one pad) take a list and a wave load covers eight lists; the
-    // rows below split_at take two pads at once with sixteen lanes.  (What the walk is bound by is the number of LDS add
-    // instructions, ~10 cycles each whatever their active lanes: DESIGN.md 3.1.)
+    // rare list of 64 and more samples in a part --, so eight lanes (one pad = one cache line) take a list and a wave load covers
+    // eight lists; the rows below split_at take two pads at once with sixteen lanes.  What the walk is bound by is the lines it
+    // pulls through the fabric (PMC: ~7.3 TB/s of requests with sixteen lanes for every row): the second pad of a
+    // sixteen-lane load is fetched whether its entries are taken or not, so the upper rows must not ask for it.
     const unsigned lgs = (LP < 16u && split_at && i >= split_at) ? 3u : 4u, LG = 1u << lgs, lists_per_load = 64u >> lgs;
     const unsigned grp = lane >> lgs, l16 = lane & (LG - 1u);
     unsigned *scratch = row + chunk + 64 + wave * 64;
@@ -924,10 +925,10 @@ __global__ __launch_bounds__(TRACS_NN_THREADS) void nn_rows_kernel(const unsigne
         return on;
     };
     const uint4 *__restrict__ lists = reinterpret_cast<const uint4 *>(n_ent);      // (every list starts on a 16-byte boundary)
-    // The walk is a chain of dependent round trips (stream entry -> list -> LDS adds): what it is bound by is how many of them a
-    // wave keeps in flight, not bytes or instructions (PMC: 3.7 TB/s fetched, VALU and LDS under half busy).  So the loop is
-    // software-pipelined twice over: the NEXT batch's stream entries are requested when a batch starts, and the NEXT round's lists
-    // (NN_FLIGHT x 4 of them) before the current round's entries are added.
+    // The walk is a chain of dependent round trips (stream entry -> list -> LDS adds); the loop is software-pipelined twice over:
+    // the NEXT batch's stream entries are requested when a batch starts, and the NEXT round's lists (NN_FLIGHT x 4 or 8 of them)
+    // before the current round's entries are added.  (Measured: no faster than without -- at 32 waves per CU the fabric is
+    // already kept full -- but no slower, and it does not depend on the occupancy.)
     const uint4 none = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
     // (every load is issued unconditionally -- a lane without a list reads the head of the array and drops it when the round is
     // applied --: straight-line code, so that the compiler waits for the current round with the next one still in flight)
