@@ -97,12 +97,13 @@ def synth_kw(p_partial=0.0, workload="sparse"):
     return dict(WORKLOADS[workload], p_partial=p_partial)
 
 
-def pair_split_ms(lib):
-    """(pair kernel, sparse partial-code correction + minority lists, counting pass on the matrix cores, N co-occurrence lists) of
-    the LAST dense call, from HIP events the library records on the launch stream (tracs_debug_pair_timing)."""
+def pair_split_ms(lib, calls=1):
+    """(pair kernel, sparse partial-code correction + minority lists, counting pass on the matrix cores, N co-occurrence lists):
+    mean over the last `calls` dense calls (the library keeps the events of the last 64), from HIP events the library records on
+    the launch stream around each part (tracs_debug_pair_timing) -- over the timed steps, what rocprofv3's average reports."""
     import ctypes as C
     out = (C.c_float * 4)()
-    return [float(x) for x in out] if lib.tracs_debug_last_pair_ms(out) == 0 else None
+    return [float(x) for x in out] if lib.tracs_debug_pair_ms_mean(max(1, int(calls)), out) == 0 else None
 
 
 def hbm_physical(traffic, kern_s, compulsory):
@@ -257,8 +258,10 @@ def main():
 
     # One GPU: transcluster (f64 key evaluations: compute-bound) only reads the distances, which are final before the compared-
     # sites counts are -- the rest of the dense call (the N co-occurrence walk over the lists: memory-bound) runs beside it on a
-    # second stream.  TRACS_BENCH_OVERLAP=0: one stream, one after the other.
-    overlap = world == 1 and os.environ.get("TRACS_BENCH_OVERLAP", "1") != "0"
+    # second stream (tracs_pairsnp_notify_distances).  Off by default: the step is 4 % shorter with it (21.6 vs 22.5 ms), but
+    # every kernel of the dense call then runs stretched beside the other stream's (the walk 17 instead of 14 ms) and the
+    # per-kernel figures of `roofline` stop meaning the kernel.  TRACS_BENCH_OVERLAP=1: two streams.
+    overlap = world == 1 and os.environ.get("TRACS_BENCH_OVERLAP", "0") == "1"
     side = torch.cuda.Stream(device=device) if overlap else None
     d_ready = torch.cuda.Event() if overlap else None
     main_stream = torch.cuda.current_stream()
@@ -372,7 +375,9 @@ def main():
     tc_ms = [a.elapsed_time(b) for a, b in tc_ev] or [0.0]
     kern_s = sum(kern_ms) / len(kern_ms) / 1e3 / len(ranges)      # average duration of ONE dense call (all its kernels)
     my_pairs_per_launch = my_pairs / len(ranges)
-    split = pair_split_ms(lib)                                    # the last call's kernels, one by one
+    # the timed steps' dense calls, kernel by kernel (mean; a rank with two row ranges per step: its last call)
+    split_calls = args.steps if len(ranges) == 1 else 1
+    split = pair_split_ms(lib, split_calls)
     classes = aln.site_classes                                    # (variable, invariant) sites, or None: whole alignment read
 
     dmat, nmat = sets[(args.warmup + args.steps - 1) % nsets]    # the last step's results
@@ -415,6 +420,8 @@ def main():
             roof["traffic"] = traffic
             roof["hbm_physical"] = hbm_physical(traffic, roof["kernel_ms"] / 1e3, roof.get("compulsory_bytes") or roof.get("algorithmic_bytes"))
             roof["other_kernels"] = [{k: c[1][k] for k in ("kernel", "kernel_ms", "bound", "achieved", "frac", "unit", "sites") if k in c[1]} for c in cands[1:]]
+            roof["kernel_ms_over"] = ("mean over the %d dense calls of the timed steps (HIP events around each part on the launch stream); "
+                                      "transcluster runs beside them on a second stream%s" % (split_calls, "" if overlap else " -- not in this run"))
             roof["minority_lists_ms"] = split[1]
             roof["dense_call_ms"] = kern_s * 1e3
             roof["kernels_ms"] = {"pair kernel (dense sites)": split[0], "general_fixup_kernel (minority lists)": split[1],

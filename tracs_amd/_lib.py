@@ -217,6 +217,8 @@ def load():
     L.tracs_debug_pair_timing.restype = None
     L.tracs_debug_pair_timing.argtypes = [C.c_int]
     L.tracs_debug_last_pair_ms.restype = C.c_int
+    L.tracs_debug_pair_ms_mean.restype = C.c_int
+    L.tracs_debug_pair_ms_mean.argtypes = [C.c_int, C.POINTER(C.c_float)]
     L.tracs_debug_last_pair_ms.argtypes = [C.POINTER(C.c_float)]
     L.tracs_debug_tile_variant.restype = C.c_char_p
     L.tracs_debug_mfma_shape.restype = C.c_char_p

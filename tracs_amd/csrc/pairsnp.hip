@@ -829,22 +829,36 @@ int tracs_debug_alignment_count_source(const tracs_alignment *a, uint64_t *out)
 // initialisation / sparse partial-code correction + minority lists / counting pass on the matrix cores / N co-occurrence lists).
 // Off by default.
 static bool g_pair_timing = false;
-static hipEvent_t g_pair_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-static bool g_pair_ev_valid = false;
+constexpr int PAIR_EV_RING = 64;                       // the last 64 calls keep their events (bench.py averages over its timed steps)
+static hipEvent_t g_pair_ev[PAIR_EV_RING][5] = {};
+static unsigned long long g_pair_calls = 0;            // dense calls whose five events have all been recorded
+static int g_pair_slot = 0;
 void tracs_debug_pair_timing(int on)
 {
     g_pair_timing = on != 0;
-    if (g_pair_timing && !g_pair_ev[0])
-        for (auto &e : g_pair_ev) (void)hipEventCreate(&e);
+    if (g_pair_timing && !g_pair_ev[0][0])
+        for (auto &set : g_pair_ev)
+            for (auto &e : set) (void)hipEventCreate(&e);
 }
-int tracs_debug_last_pair_ms(float *out)
+// mean over the last `n_last` dense calls (at most PAIR_EV_RING, at most the calls made); n_last = 1: the last call
+int tracs_debug_pair_ms_mean(int n_last, float *out)
 {
-    if (!out || !g_pair_ev_valid) return TRACS_E_ARG;
-    if (hipEventSynchronize(g_pair_ev[4]) != hipSuccess) return TRACS_E_HIP;
-    for (int k = 0; k < 4; k++)
-        if (hipEventElapsedTime(&out[k], g_pair_ev[k], g_pair_ev[k + 1]) != hipSuccess) return TRACS_E_HIP;
+    if (!out || n_last < 1 || g_pair_calls == 0) return TRACS_E_ARG;
+    const int cnt = (int)std::min<unsigned long long>({(unsigned long long)n_last, g_pair_calls, (unsigned long long)PAIR_EV_RING});
+    double acc[4] = {0, 0, 0, 0};
+    for (int c = 0; c < cnt; c++) {
+        const int slot = (int)((g_pair_calls - 1 - c) % PAIR_EV_RING);
+        if (hipEventSynchronize(g_pair_ev[slot][4]) != hipSuccess) return TRACS_E_HIP;
+        for (int k = 0; k < 4; k++) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, g_pair_ev[slot][k], g_pair_ev[slot][k + 1]) != hipSuccess) return TRACS_E_HIP;
+            acc[k] += ms;
+        }
+    }
+    for (int k = 0; k < 4; k++) out[k] = (float)(acc[k] / cnt);
     return TRACS_OK;
 }
+int tracs_debug_last_pair_ms(float *out) { return tracs_debug_pair_ms_mean(1, out); }
 // tracs_pairsnp_notify_distances: recorded by the next dense call once its distances are final
 static thread_local hipEvent_t g_dist_event = nullptr;
 void tracs_pairsnp_notify_distances(void *event) { g_dist_event = static_cast<hipEvent_t>(event); }
@@ -855,7 +869,10 @@ static inline void dist_final(hipStream_t stream)
 
 static inline void pair_mark(int k, hipStream_t stream)
 {
-    if (g_pair_timing && g_pair_ev[k]) { (void)hipEventRecord(g_pair_ev[k], stream); if (k == 4) g_pair_ev_valid = true; }
+    if (!g_pair_timing || !g_pair_ev[0][0]) return;
+    if (k == 0) g_pair_slot = (int)(g_pair_calls % PAIR_EV_RING);
+    (void)hipEventRecord(g_pair_ev[g_pair_slot][k], stream);
+    if (k == 4) g_pair_calls++;
 }
 
 static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_t row_end, size_t col_begin, uint32_t *dist,
