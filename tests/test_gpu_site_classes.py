@@ -2,6 +2,7 @@
 sites only and complete the compared-sites counts with a one-operand pass over the invariant sites.  Results must stay
 bit-identical to the oracle's pair loop (src/pairsnp.hpp:395-420) in every geometry: both encodings, plain / thresholded /
 panel calls, class sizes that are not multiples of a group, no variable site at all, no invariant site at all."""
+import os
 import time
 
 import numpy as np
@@ -309,4 +310,81 @@ def test_row_hint_builds_lists_for_those_rows_only(hiplib, oracle):
         assert np.array_equal(d.cpu().numpy()[ri, ci], ed.astype(np.int32)) and np.array_equal(nn.cpu().numpy()[ri, ci], enn.astype(np.int32))
     finally:
         hiplib.tracs_debug_force_site_classes(-2)
+    aln.close()
+
+
+LONG_LISTS_CHILD = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %(root)r)
+from oracle import oracle as O
+from tracs_amd import device as dev, synth
+n, L = 1500, 6000
+seqs = synth.alignment(n, L, seed=77, mu_lineage=1e-3, mu_sample=2e-4, n_lineages=7, p_n=0.002)
+rng = np.random.default_rng(78)
+gappy = rng.choice(L, L // 10, replace=False)                      # a tenth of the sites with many N samples (the lists' cap: n L / 8 entries)
+mask = rng.random((n, gappy.size)) < %(p_n)g
+sub = seqs[:, gappy]; sub[mask] = ord("N"); seqs[:, gappy] = sub
+aln = dev.Alignment(n, L)
+aln.pack(seqs)
+er, ec, ed, enn = O.pairsnp_arrays(seqs, n_threads=16)
+ri, ci = er.astype(np.int64), ec.astype(np.int64)
+d = torch.zeros((n, n), dtype=torch.int32, device="cuda"); nn = torch.zeros_like(d)
+dev.pairsnp_dense(aln, d, nn)
+src = aln.count_source
+assert aln.site_classes is not None and src is not None and src[2] > L // 2, (aln.site_classes, src)      # N co-occurrences from lists
+assert aln.list_stats["nn_visits"] > (L // 10) * (%(p_n)g * n) ** 2 / 2, aln.list_stats              # ... the long ones too
+assert np.array_equal(d.cpu().numpy()[ri, ci], ed.astype(np.int32))
+assert np.array_equal(nn.cpu().numpy()[ri, ci], enn.astype(np.int32))
+# row panels on either side of the lists' split point, and one across it
+for r0, r1 in ((0, 64), (700, 830), (1400, n)):
+    dp = torch.zeros((r1 - r0, n), dtype=torch.int32, device="cuda"); npn = torch.zeros_like(dp)
+    dev.pairsnp_dense(aln, dp, npn, row_begin=r0, row_end=r1, base_row=r0)
+    sel = (ri >= r0) & (ri < r1)
+    assert np.array_equal(dp.cpu().numpy()[ri[sel] - r0, ci[sel]], ed[sel].astype(np.int32)), (r0, r1)
+    assert np.array_equal(npn.cpu().numpy()[ri[sel] - r0, ci[sel]], enn[sel].astype(np.int32)), (r0, r1)
+print("LISTS", aln.list_stats)
+aln.close()
+'''
+
+
+@pytest.mark.parametrize("env", [{"TRACS_NN_LIST_K": "1"}, {"TRACS_NN_LIST_K": "1", "TRACS_NN_SPLIT": "0"},
+                                 {"TRACS_NN_LIST_K": "1", "TRACS_LIST_INLINE": "0", "TRACS_NN_TARGET": "2048"}],
+                         ids=lambda e: "+".join("%s=%s" % kv for kv in e.items()))
+@pytest.mark.parametrize("p_n", [0.15, 0.05])
+def test_long_n_lists_in_two_parts(hiplib, oracle, env, p_n):
+    """N lists of ~ 225 (75) samples at 1 500 samples -- several 64-entry pads per part, so the walk of nn_rows_kernel goes on
+    behind its first load in both lane-group widths (16 lanes below the split point, 8 from it on) -- forced onto the lists whatever
+    the cost model says; every pair against the oracle, whole matrix and row panels on either side of the split point."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", LONG_LISTS_CHILD % {"root": root, "p_n": p_n}], capture_output=True, text=True,
+                         env=dict(os.environ, **env), timeout=900, cwd=root)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+
+
+def test_lists_with_32_bit_sample_numbers(hiplib, oracle):
+    """65 600 samples: list entries are 32-bit sample numbers (no inline entries, 16 lanes per pad).  Row panels below and beyond
+    the lists' split point against the oracle on a subset of the columns (the panel rows + 1 500 random samples)."""
+    import torch
+    from tracs_amd import device as dev, synth
+    n, L = 65600, 512
+    seqs = synth.alignment(n, L, seed=123, mu_lineage=2e-3, mu_sample=3e-4, n_lineages=9, p_n=0.004)
+    aln = dev.Alignment(n, L)
+    aln.pack(seqs)
+    rng = np.random.default_rng(5)
+    others = np.sort(rng.choice(n, 1500, replace=False))
+    for r0, r1 in ((10, 26), (40000, 40016), (n - 16, n)):
+        dp = torch.zeros((r1 - r0, n), dtype=torch.int32, device="cuda")
+        npn = torch.zeros_like(dp)
+        dev.pairsnp_dense(aln, dp, npn, row_begin=r0, row_end=r1, base_row=r0)
+        assert aln.site_classes is not None and aln.count_source[2] > 0, (aln.site_classes, aln.count_source)
+        rows = np.arange(r0, r1)
+        sub = np.unique(np.concatenate([rows, others]))
+        er, ec, ed, enn = oracle.pairsnp_arrays(seqs[sub], n_threads=16)
+        gi, gj = sub[er.astype(np.int64)], sub[ec.astype(np.int64)]             # (i < j in the subset's order = the global order)
+        sel = (gi >= r0) & (gi < r1)
+        dh, nh = dp.cpu().numpy(), npn.cpu().numpy()
+        assert np.array_equal(dh[gi[sel] - r0, gj[sel]], ed[sel].astype(np.int32)), (r0, r1)
+        assert np.array_equal(nh[gi[sel] - r0, gj[sel]], enn[sel].astype(np.int32)), (r0, r1)
     aln.close()
