@@ -348,7 +348,8 @@ aln.close()
 
 
 @pytest.mark.parametrize("env", [{"TRACS_NN_LIST_K": "1"}, {"TRACS_NN_LIST_K": "1", "TRACS_NN_SPLIT": "0"},
-                                 {"TRACS_NN_LIST_K": "1", "TRACS_LIST_INLINE": "0", "TRACS_NN_TARGET": "2048"}],
+                                 {"TRACS_NN_LIST_K": "1", "TRACS_LIST_INLINE": "0", "TRACS_NN_TARGET": "2048"},
+                                 {"TRACS_NN_LIST_K": "1", "TRACS_LIST_STAGE": "0"}],
                          ids=lambda e: "+".join("%s=%s" % kv for kv in e.items()))
 @pytest.mark.parametrize("p_n", [0.15, 0.05])
 def test_long_n_lists_in_two_parts(hiplib, oracle, env, p_n):

@@ -501,8 +501,16 @@ template <class NT>
 __global__ __launch_bounds__(256) void minor_site_lists_kernel(const MinorBuild mb, size_t n_pad, unsigned n,
                                                                unsigned long long *__restrict__ p_off, unsigned long long *__restrict__ n_off,
                                                                unsigned *__restrict__ p_ent, NT *__restrict__ n_ent, uint2 *__restrict__ E,
-                                                               unsigned *__restrict__ site_inl, unsigned *__restrict__ site_start)
+                                                               unsigned *__restrict__ site_inl, unsigned *__restrict__ site_start,
+                                                               unsigned stage_entries)
 {
+    // The group's N lists are one contiguous run of n_ent (whole pads, sentinels included): they are built in LDS and leave with
+    // 16-byte stores when the run fits `stage_entries` -- 5 x 10^8 scattered 2-byte stores were what the kernel was bound by --;
+    // a longer run is initialised with sentinels in place and filled entry by entry.
+    extern __shared__ uint4 stage_raw[];
+    NT *stage = reinterpret_cast<NT *>(stage_raw);
+    __shared__ unsigned long long lN[SITES_PER_GROUP];                       // a list's first entry within the group's run
+    __shared__ unsigned long long run_entries;
     __shared__ unsigned kp[SITES_PER_GROUP], kn[SITES_PER_GROUP], curP[SITES_PER_GROUP], curN[SITES_PER_GROUP], rk[SITES_PER_GROUP];
     __shared__ unsigned curB[SITES_PER_GROUP], partB[SITES_PER_GROUP];      // a split list's second part: cursor, first entry
     __shared__ unsigned long long bP[SITES_PER_GROUP], bN[SITES_PER_GROUP];
@@ -525,15 +533,34 @@ __global__ __launch_bounds__(256) void minor_site_lists_kernel(const MinorBuild 
         curP[tid] = 0; curN[tid] = 0; curB[tid] = 0;
     }
     __syncthreads();
+    if (tid == SITES_PER_GROUP - 1) {
+        unsigned long long tot = 0;
+        for (int t = 0; t < SITES_PER_GROUP; t++) tot += kn[t];
+        run_entries = tot;
+    }
     if (mine) {
         unsigned long long pp = 0, pn = 0;
         for (int t = 0; t < tid; t++) { pp += kp[t]; pn += kn[t]; }
         const unsigned rank = minor_rank(m4, mb.off_lst[g], tw, tb);
-        bP[tid] = mb.baseP[g] + pp; bN[tid] = mb.baseN[g] + pn; rk[tid] = rank;
+        bP[tid] = mb.baseP[g] + pp; bN[tid] = mb.baseN[g] + pn; rk[tid] = rank; lN[tid] = pn;
         p_off[rank] = bP[tid]; n_off[rank] = bN[tid];
+    }
+    __syncthreads();
+    const unsigned long long run = run_entries;
+    const bool staged = run <= stage_entries;                 // (block-uniform)
+    constexpr unsigned EP16 = 16 / sizeof(NT);                // entries per 16 bytes (a run is whole pads: a multiple of it)
+    {
+        const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        uint4 *dst = staged ? stage_raw : reinterpret_cast<uint4 *>(n_ent + mb.baseN[g]);
+        for (unsigned long long q = tid; q < run / EP16; q += 256) dst[q] = ones;
+        if (!staged) __threadfence_block();
+    }
+    __syncthreads();
+    NT *const out = staged ? stage : n_ent + mb.baseN[g];     // entry e of the group's run
+    if (mine) {
         // the first part's last pad ends without a sentinel: the walk goes on into the second part
         const unsigned ca = mb.cntA[g * SITES_PER_GROUP + tid];
-        if (partB[tid] && ca % NN_LIST_PAD) n_ent[bN[tid] + partB[tid] - 1u] = (NT)(sizeof(NT) == 2 ? NN_LIST_FILL16 : NN_LIST_FILL32);
+        if (partB[tid] && ca % NN_LIST_PAD) out[lN[tid] + partB[tid] - 1u] = (NT)(sizeof(NT) == 2 ? NN_LIST_FILL16 : NN_LIST_FILL32);
         // where a row's walk of this list starts, in units of 8 entries: [0] rows below split_at, [1] the others (the per-sample
         // pass looks these up instead of summing the group's padded sizes again)
         site_start[g * SITES_PER_GROUP + tid] = (unsigned)(bN[tid] / 8ull);
@@ -555,7 +582,7 @@ __global__ __launch_bounds__(256) void minor_site_lists_kernel(const MinorBuild 
                 const int t = w * 32 + b;
                 const bool second = partB[t] && s >= split_at;
                 const unsigned slot = second ? partB[t] + atomicAdd(&curB[t], 1u) : atomicAdd(&curN[t], 1u);
-                n_ent[bN[t] + slot] = (NT)s;
+                out[lN[t] + slot] = (NT)s;
             }
         }
         if (!flagged) continue;
@@ -580,11 +607,15 @@ __global__ __launch_bounds__(256) void minor_site_lists_kernel(const MinorBuild 
             }
         }
     }
+    __threadfence_block();
+    __syncthreads();
+    if (staged) {
+        uint4 *dst = reinterpret_cast<uint4 *>(n_ent + mb.baseN[g]);
+        for (unsigned long long q = tid; q < run / EP16; q += 256) dst[q] = stage_raw[q];
+    }
     // the one or two listed samples of a minority site, for the inline entries of the per-sample streams (0xFFFFFFFF: the site's N
     // entries point at its list instead)
     if (site_inl) {
-        __threadfence_block();
-        __syncthreads();
         if (tid < SITES_PER_GROUP) {
             unsigned v = 0xFFFFFFFFu;
             if (mine && ((mp[tw] >> tb) & 1u) && kp[tid] >= 1u && kp[tid] <= 2u) {
@@ -779,7 +810,8 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb, hipStream_t s
     g->padded = true;
     const size_t n_ent_bytes = (std::max<size_t>(mb.tot_n, 8) + 64) * (g->n16 ? 2 : 4);
     GS_TRY(pack_alloc(a, n_ent_bytes, reinterpret_cast<void **>(&g->n_ent)));
-    GS_TRY(hipMemsetAsync(g->n_ent, 0xFF, n_ent_bytes, stream));
+    // (minor_site_lists_kernel writes every entry of every list's pads, sentinels included; the 64 entries behind the last list are
+    // only ever loaded, never taken)
     if (trace) std::fprintf(stderr, "[once per pack] host: list storage %.2f GB (%zu of 9 arrays outside the arena) %.2f ms\n",
                             ((double)(tot_s + mb.tot_p + tot_nn) * 4 + (double)n_ent_bytes) * 1e-9, a->pack_extra.size() - before,
                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count());
@@ -799,12 +831,15 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb, hipStream_t s
     GS_TRY(hipMemsetAsync(cnt, 0, (nsc + 2 * nsq) * 4, stream));
     GS_TRY(hipMemsetAsync(cur, 0, (std::max<size_t>(n, 1) + 8) * 4, stream));
     GS_TRY(hipMemsetAsync(g->c_p, 0, std::max<size_t>(n, 1) * 4, stream));
+    // LDS for a group's N lists: 34 KiB beside the kernel's ~6 KiB of cursors: four workgroups per CU (TRACS_LIST_STAGE=0: off)
+    constexpr unsigned SITE_STAGE_BYTES = 34816;
+    static const bool stage_on = [] { const char *e = std::getenv("TRACS_LIST_STAGE"); return !(e && std::atoi(e) == 0); }();
     if (g->n16)
-        hipLaunchKernelGGL(minor_site_lists_kernel<unsigned short>, dim3((unsigned)groups), dim3(256), 0, stream, mb, a->n_pad, (unsigned)n,
-                           g->p_off, g->n_off, g->p_ent, reinterpret_cast<unsigned short *>(g->n_ent), E, site_inl, site_start);
+        hipLaunchKernelGGL(minor_site_lists_kernel<unsigned short>, dim3((unsigned)groups), dim3(256), SITE_STAGE_BYTES, stream, mb, a->n_pad, (unsigned)n,
+                           g->p_off, g->n_off, g->p_ent, reinterpret_cast<unsigned short *>(g->n_ent), E, site_inl, site_start, stage_on ? SITE_STAGE_BYTES / 2 : 0u);
     else
-        hipLaunchKernelGGL(minor_site_lists_kernel<unsigned>, dim3((unsigned)groups), dim3(256), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off,
-                           g->n_off, g->p_ent, g->n_ent, E, (unsigned *)nullptr, site_start);
+        hipLaunchKernelGGL(minor_site_lists_kernel<unsigned>, dim3((unsigned)groups), dim3(256), SITE_STAGE_BYTES, stream, mb, a->n_pad, (unsigned)n, g->p_off,
+                           g->n_off, g->p_ent, g->n_ent, E, (unsigned *)nullptr, site_start, stage_on ? SITE_STAGE_BYTES / 4 : 0u);
     pack_stage_mark("lists: per site", stream);
     const size_t gpc = (groups + GS_CHUNKS - 1) / GS_CHUNKS;
     const dim3 sgrid((unsigned)((n + 63) / 64), GS_CHUNKS / 4);
