@@ -156,6 +156,41 @@ __global__ __launch_bounds__(1024) void gs_scan_kernel(const unsigned *__restric
     }
 }
 
+// Up to three such scans at once, one workgroup each (the per-sample streams' counts: three arrays of n x 32 elements, 0.7 ms
+// each through gs_scan_kernel's LDS ladder, one after the other); wave scans through shuffles, one barrier pair per 16 384 elements.
+struct ScanJob { const unsigned *v; size_t count; unsigned long long *out; };
+__global__ __launch_bounds__(1024) void gs_scan_jobs_kernel(ScanJob j0, ScanJob j1, ScanJob j2)
+{
+    const ScanJob job = blockIdx.x == 0 ? j0 : blockIdx.x == 1 ? j1 : j2;
+    if (!job.v) return;
+    __shared__ unsigned long long wave_tot[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int RUN = 16;
+    unsigned long long carry = 0;                            // (the same on every thread)
+    for (size_t base = 0; base <= job.count; base += 1024 * RUN) {
+        const size_t b0 = base + (size_t)threadIdx.x * RUN;
+        unsigned long long local[RUN], sum = 0;
+#pragma unroll
+        for (int k = 0; k < RUN; k++) { local[k] = sum; sum += (b0 + k < job.count) ? job.v[b0 + k] : 0u; }
+        unsigned long long incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        unsigned long long before = carry, all = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) { const unsigned long long t = wave_tot[w]; if (w < wave) before += t; all += t; }
+        const unsigned long long excl = before + incl - sum;
+#pragma unroll
+        for (int k = 0; k < RUN; k++) if (b0 + k <= job.count) job.out[b0 + k] = excl + local[k];
+        carry += all;
+        __syncthreads();
+    }
+}
+
 __global__ void gs_sample_totals_kernel(const unsigned *__restrict__ cw, const unsigned *__restrict__ cn, size_t n,
                                         unsigned *__restrict__ c_n, unsigned *__restrict__ c_p,
                                         const unsigned long long *__restrict__ off, unsigned long long *__restrict__ s_off)
@@ -848,9 +883,8 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb, hipStream_t s
                        site_inl, site_start, nullptr, nullptr, nullptr);
     if (egrid) hipLaunchKernelGGL((minor_listed_kernel<false>), dim3(egrid), dim3(256), 0, stream, mb, E, mb.tot_p, cnt, g->c_p, nullptr, nullptr, nullptr);
     hipLaunchKernelGGL(minor_pad_listed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, cnt, n);
-    hipLaunchKernelGGL(gs_scan_kernel, dim3(1), dim3(1024), 0, stream, cnt, nsc, off);
-    hipLaunchKernelGGL(gs_scan_kernel, dim3(1), dim3(1024), 0, stream, cntq, nsq, offq);
-    if (inl) hipLaunchKernelGGL(gs_scan_kernel, dim3(1), dim3(1024), 0, stream, cnti, nsq, offi);
+    hipLaunchKernelGGL(gs_scan_jobs_kernel, dim3(inl ? 3 : 2), dim3(1024), 0, stream, ScanJob{cnt, nsc, off}, ScanJob{cntq, nsq, offq},
+                       inl ? ScanJob{cnti, nsq, offi} : ScanJob{nullptr, 0, nullptr});
     unsigned long long *d_max = reinterpret_cast<unsigned long long *>(cur + ((std::max<size_t>(n, 1) + 1) & ~(size_t)1));     // behind `cur` (zeroed with it)
     hipLaunchKernelGGL(minor_sample_offsets_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, stream, off, n, MS_NCH, g->s_off, d_max);
     hipLaunchKernelGGL(minor_sample_offsets_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, stream, offq, n, GS_CHUNKS, g->snn_off, d_max + 1);
