@@ -164,7 +164,7 @@ struct TcTables {
 };
 constexpr unsigned long long TC_TABLE_ELEMS = 48ull << 20;      // doubles in the lnS table (384 MB)
 
-// A key handed over without any term summed (state[0] is NaN: tc_keys_kernel does that for delta > 0 and N >= TC_WAVE_PREFIX_MIN)
+// A key handed over without any term summed (state[0] is NaN: tc_keys_kernel does that for N >= TC_WAVE_PREFIX_MIN)
 // starts here with the two O(N) prefix sums of the loop -- pois (:144-148) and S_N -- as wave sums of 64 terms per step instead of a
 // serial fold, and p0 (the k = 0 value, :276-282) comes back through `p0_out`.
 __device__ __forceinline__ void tc_eval_wave(int N, double delta, const TcParams &P, const double *__restrict__ lg, double &eK,
@@ -204,6 +204,11 @@ __device__ __forceinline__ void tc_eval_wave(int N, double delta, const TcParams
         *p0_out = l0 + (lnS - n1 * P.ln_lb);
         Ms = -INFINITY; Ss = 0.0;                                      // (unused: S comes from the table)
         Mp = -INFINITY; Lps = 0.0; Me = -INFINITY; Els = 0.0;
+        k_start = 1;
+    } else if (fresh && !pos) {                                        // delta = 0: closed forms, no prefix (:163-167)
+        pois = 0.0;
+        *p0_out = (n1 * P.ln_lamb + 0.0 * P.ln_beta + lg_n1 - lg_n1 - lg_at(lg, 1) - n1 * P.ln_lb);
+        Ms = -INFINITY; Ss = 0.0; Mp = -INFINITY; Lps = 0.0; Me = -INFINITY; Els = 0.0;
         k_start = 1;
     } else if (fresh) {                                                // (delta > 0)
         const double lx = log(P.lamb * delta);
@@ -501,7 +506,9 @@ __global__ void tc_keys_kernel(Src src, const unsigned *__restrict__ key_elem, u
             if (!kt.mine(N, gap)) { key_p0[id] = 0.0; key_eK[id] = 0.0; continue; }      // another rank's key
             slot = kt.index(N, gap);
         }
-        if (d > 0 && N >= TC_WAVE_PREFIX_MIN) {                       // nothing summed here: the wave kernel does the prefix too
+        // nothing summed here: the wave kernel does the prefix too.  (Same-day pairs as well: their series is as long, and one thread
+        // folding its first TC_SERIAL_CAP terms kept this kernel's last waves running 0.6 ms after the others.)
+        if (N >= TC_WAVE_PREFIX_MIN) {
             key_state[4 * (size_t)id] = __builtin_nan("");
             long_ids[atomicAdd(n_long, 1u)] = id;
             continue;
