@@ -179,7 +179,9 @@ def roofline_of(kernel, enc, pairs_per_launch, L, kern_s, traffic, n):
 
 
 def main():
+    global _WORKLOAD_OF_PROFILES
     args = parse()
+    _WORKLOAD_OF_PROFILES = args.workload if args.partial == 0 else "partial"
     import torch
     import torch.distributed as dist
     from tracs_amd import _lib
@@ -478,10 +480,15 @@ def main():
         dist.destroy_process_group()
 
 
+_WORKLOAD_OF_PROFILES = None        # set by main(): the workload of this run
+
+
 def _traffic_from_profiles(n, L, world, kernel):
     """HBM bytes per launch of the kernel that ran, from the COMMITTED PMC summary (profiles/pmc_summary.json) if it holds an
     entry for this size and kernel: a figure from separate --pmc passes of the same kernel on the same shape (FETCH_SIZE /
     WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes), not from this run; None when there is no such entry."""
+    if _WORKLOAD_OF_PROFILES is not None and _WORKLOAD_OF_PROFILES != "sparse":
+        return None                                           # (the committed passes are of the default workload)
     p = os.path.join(ROOT, "profiles", "pmc_summary.json")
     try:
         with open(p) as fh:
