@@ -534,12 +534,14 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     // ~51 ns per site at 10 000 samples (pair kernel) against ~2-4 ps per list entry (general_fixup_kernel)
     const double bsites = (double)a->n * (double)a->n / 8000.0;
     const unsigned budget = (no_minor || !allow_minor) ? 0u : (unsigned)std::min(1.0e9, std::max(16.0, bsites));
-    // The N co-occurrences of a site with cN N samples cost cN list walks of ceil(cN / 64) wave loads each (nn_rows_kernel) against
-    // n^2 / 2 pairs on the matrix cores, whatever cN: lists while cN ceil(cN / 64) <= TRACS_NN_LIST_K x n^2 (default 3.3e-6: a wave
-    // load of the list walk costs ~33 ps of the chip's time, a pair and site of the counting pass 2 / 7.4e15 s -- crossover at
-    // 4e-6, taken with a margin for the lists' share of the once-per-pack work); TRACS_NN_LISTS=0: never
+    // The N co-occurrences of a site with cN N samples cost cN list walks of ~ceil(cN / 64) cache lines each (nn_rows_kernel: bound
+    // by the lines it pulls through the fabric) against n^2 / 2 pairs on the matrix cores, whatever cN: lists while
+    // cN ceil(cN / 64) <= TRACS_NN_LIST_K x n^2.  Measured at 10 000 x 5 Mbp (profiles/r03/nn_list_threshold.txt): lists 29 / 41 /
+    // 53 / 92 ms at cN = 130 / 160 / 200 / 250 against 66-67 ms on the matrix cores -- crossover near cN = 220, K = 8.8e-6; at
+    // 2 000 samples every K up to 8e-6 is faster than the one before.  Default 6e-6, the rest being the lists' share of the
+    // once-per-pack work; TRACS_NN_LISTS=0: never
     static const bool no_nnl = [] { const char *e = std::getenv("TRACS_NN_LISTS"); return e && std::atoi(e) == 0; }();
-    static const double nnl_k = [] { const char *e = std::getenv("TRACS_NN_LIST_K"); return e ? std::atof(e) : 3.3e-6; }();
+    static const double nnl_k = [] { const char *e = std::getenv("TRACS_NN_LIST_K"); return e ? std::atof(e) : 6e-6; }();
     const unsigned nn_list_max = (no_nnl || !allow_nnl) ? 0u : (unsigned)std::min(4.0e9, nnl_k * (double)a->n * (double)a->n);
     TRACS_HIP_CHECK(hipMemsetAsync(totals, 0, 128, stream));
     hipLaunchKernelGGL(classify_sites_kernel, dim3((unsigned)groups), dim3(256), 0, stream, a->planes, a->n_pad, (unsigned)a->n, budget,
