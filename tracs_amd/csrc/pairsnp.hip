@@ -668,9 +668,10 @@ int tracs_alignment_create(size_t n, size_t L, tracs_alignment **out)
         if (e != hipSuccess) { set_error(std::string("hipMalloc(planes): ") + hipGetErrorString(e)); delete a; return TRACS_E_NOMEM; }
         e = hipMemset(a->planes, 0, bytes);
         if (e != hipSuccess) { set_error(std::string("hipMemset(planes): ") + hipGetErrorString(e)); (void)hipFree(a->planes); delete a; return TRACS_E_HIP; }
-        // the arena of the once-per-pack structures: 15 % of the planes + 64 MiB covers the lists of alignments with up to ~1.5 % of
-        // N / minority entries (TRACS_PACK_ARENA=<fraction> overrides; 0: none).  Not getting it is not an error.
-        static const double frac = [] { const char *v = std::getenv("TRACS_PACK_ARENA"); return v ? std::atof(v) : 0.25; }();
+        // the arena of the once-per-pack structures: 30 % of the planes + up to 128 MiB covers the lists of alignments with N lists of
+        // up to ~190 samples at every site of 10 000 samples -- as far as the cost model takes lists (TRACS_PACK_ARENA=<fraction>
+        // overrides; 0: none).  Not getting it is not an error; what does not fit is allocated on its own.
+        static const double frac = [] { const char *v = std::getenv("TRACS_PACK_ARENA"); return v ? std::atof(v) : 0.30; }();
         if (frac > 0.0 && n >= 2) {
             const size_t want = (size_t)((double)bytes * frac) + std::min<size_t>(128u << 20, 2 * bytes + (1u << 20));
             if (hipMalloc(reinterpret_cast<void **>(&a->arena), want) == hipSuccess) a->arena_bytes = want;
