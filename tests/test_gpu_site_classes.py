@@ -364,18 +364,20 @@ def test_long_n_lists_in_two_parts(hiplib, oracle, env, p_n):
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
 
 
-def test_lists_with_32_bit_sample_numbers(hiplib, oracle):
-    """65 600 samples: list entries are 32-bit sample numbers (no inline entries, 16 lanes per pad).  Row panels below and beyond
-    the lists' split point against the oracle on a subset of the columns (the panel rows + 1 500 random samples)."""
+@pytest.mark.parametrize("n", [65534, 65600])
+def test_lists_at_the_16_bit_boundary(hiplib, oracle, n):
+    """65 534 samples: the most that 16-bit sample numbers hold (0xFFFE and 0xFFFF are the filler and the sentinel), two column
+    chunks per row; 65 600: list entries are 32-bit sample numbers (no inline entries, 16 lanes per pad).  Row panels below and
+    beyond the lists' split point against the oracle on a subset of the columns (the panel rows + 1 500 random samples)."""
     import torch
     from tracs_amd import device as dev, synth
-    n, L = 65600, 512
+    L = 512
     seqs = synth.alignment(n, L, seed=123, mu_lineage=2e-3, mu_sample=3e-4, n_lineages=9, p_n=0.004)
     aln = dev.Alignment(n, L)
     aln.pack(seqs)
     rng = np.random.default_rng(5)
     others = np.sort(rng.choice(n, 1500, replace=False))
-    for r0, r1 in ((10, 26), (40000, 40016), (n - 16, n)):
+    for r0, r1 in ((10, 26), (32760, 32776), (40000, 40016), (n - 16, n)):
         dp = torch.zeros((r1 - r0, n), dtype=torch.int32, device="cuda")
         npn = torch.zeros_like(dp)
         dev.pairsnp_dense(aln, dp, npn, row_begin=r0, row_end=r1, base_row=r0)
