@@ -4,5 +4,5 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 for v in "1 1024" "2 1024" "4 1024" "2 512" "4 512"; do
   set -- $v
   TRACS_EXTRA_HIPCC_FLAGS="-DTRACS_NN_FLIGHT=$1 -DTRACS_NN_THREADS=$2" python -m tracs_amd.build --force > /dev/null 2>&1
-  echo "rounds in flight $1 threads $2: $(TRACS_NN_LIST_K=6e-6 timeout 300 python scripts/probe_single_pass.py 2>&1 | grep -E "kernels" | tail -1)"
+  echo "rounds in flight $1 threads $2: $(timeout 300 python scripts/probe_single_pass.py 2>&1 | grep -E "kernels" | tail -1)"
 done | tee gpurun_out/nn_rows_sweep.txt
