@@ -875,7 +875,9 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb, hipStream_t s
     else
         hipLaunchKernelGGL(minor_site_lists_kernel<unsigned>, dim3((unsigned)groups), dim3(256), SITE_STAGE_BYTES, stream, mb, a->n_pad, (unsigned)n, g->p_off,
                            g->n_off, g->p_ent, g->n_ent, E, (unsigned *)nullptr, site_start, stage_on ? SITE_STAGE_BYTES / 4 : 0u);
-    pack_stage_mark("lists: per site", stream);
+    const double plane_b = (double)groups * (double)a->n_pad * sizeof(uint4);      // the N plane
+    pack_stage_mark("lists: per site", stream, plane_b + (double)groups * SITES_PER_GROUP * 8.0,
+                    (double)n_ent_bytes + (double)mb.tot_p * 12.0 + (double)groups * SITES_PER_GROUP * (inl ? 12.0 : 8.0) + (double)L * 16.0);
     const size_t gpc = (groups + GS_CHUNKS - 1) / GS_CHUNKS;
     const dim3 sgrid((unsigned)((n + 63) / 64), GS_CHUNKS / 4);
     const unsigned egrid = (unsigned)((mb.tot_p + 255) / 256);
@@ -895,7 +897,8 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb, hipStream_t s
     GS_TRY(hipMemcpyAsync(&g->max_row, d_max, 8, hipMemcpyDeviceToHost, stream));       // (read after the caller's synchronisation)
     GS_TRY(hipMemcpyAsync(&g->max_row_nn, d_max + 1, 8, hipMemcpyDeviceToHost, stream));
     GS_TRY(hipGetLastError());
-    pack_stage_mark("lists: per sample", stream);
+    pack_stage_mark("lists: per sample", stream, 2.0 * plane_b + (double)groups * SITES_PER_GROUP * (inl ? 12.0 : 8.0) + (double)mb.tot_p * 16.0,
+                    ((double)tot_s + (double)tot_nn + (double)(inl ? tot_inl : 0)) * 4.0 + (double)(nsc + 2 * nsq) * 12.0);
 #undef GS_TRY
     g->tot_s = tot_s; g->tot_nn = tot_nn; g->tot_inl = inl ? tot_inl : 0; g->split_at = mb.split_at;
     a->minor = g;

@@ -905,15 +905,18 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
     tracs_alignment *a = const_cast<tracs_alignment *>(a_);
     if (!a || !dist) { set_error("tracs_pairsnp_dense: NULL argument"); return TRACS_E_ARG; }
     if (row_end > a->n) row_end = a->n;
-    if (row_begin >= row_end || a->n < 2) { dist_final(static_cast<hipStream_t>(stream_)); return TRACS_OK; }
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    // an event armed by tracs_pairsnp_notify_distances belongs to THIS call: recorded when the distances are final, or -- on every
+    // other way out, errors included -- recorded at the exit, never left armed for an unrelated later call
+    struct DistEventGuard { hipStream_t s; ~DistEventGuard() { dist_final(s); } } dist_guard{stream};
+    if (row_begin >= row_end || a->n < 2) return TRACS_OK;
     if (ld < a->n) { set_error("tracs_pairsnp_dense: ld < n"); return TRACS_E_ARG; }
+    DeviceCall guard(stream);
     if (a->n_row_hint) {
         bool inside = false;
         for (int k = 0; k < a->n_row_hint; k++) inside = inside || (row_begin >= a->row_hint[2 * k] && row_end <= std::min(a->n, a->row_hint[2 * k + 1]));
         if (!inside) { set_error("tracs_pairsnp_dense: rows outside the ranges given to tracs_alignment_hint_rows"); return TRACS_E_ARG; }
     }
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
-    DeviceCall guard(stream);
 
     if (a->L == 0) {   // every pair: d = 0, nn = 0
         dim3 grid(64, (unsigned)std::min<size_t>(row_end - row_begin, 65535));
@@ -941,7 +944,7 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
         int partial = -1;
         if (!mfma_off) {
             const int rc = site_classes_decide(a, stream, &partial);
-            if (rc) return rc;
+            if (rc) { pack_stage_end(); return rc; }
         }
         static const bool force_general = std::getenv("TRACS_FORCE_GENERAL") != nullptr;
         if (a->classes_state == 1) {
@@ -1204,6 +1207,7 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
         if ((rc = tracs::workspace_get(49, T.n * sizeof(int2), reinterpret_cast<void **>(&live_tiles)))) return rc;
         if ((rc = tracs::workspace_get(50, 64, reinterpret_cast<void **>(&n_live_d)))) return rc;
         TRACS_HIP_CHECK(hipMemsetAsync(n_live_d, 0, 4, stream));
+        pair_mark(0, stream);
         if ((rc = launch(T.d, (unsigned)T.n, (int)T.n, prefix, prefix, 1, thr, TilePhase{1, 0, live}))) return rc;
         hipLaunchKernelGGL(compact_live_kernel, dim3((unsigned)((T.n + 255) / 256)), dim3(256), 0, stream, T.d, live,
                            (unsigned)T.n, live_tiles, n_live_d);
@@ -1217,10 +1221,13 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
             const int k2 = stage_split(groups - prefix, std::max({1, std::min({32, want, (groups - prefix) / (16 * kGC)}), (groups - prefix + max_gps - 1) / max_gps}), gps2);
             if ((rc = launch(live_tiles, (unsigned)(n_live * (size_t)k2), (int)n_live, groups, gps2, k2, thr, TilePhase{2, prefix, nullptr}))) return rc;
         }
+        pair_mark(1, stream);
         if (mfma_general && (rc = general_sparse_fixup(a, row_begin, row_end, col_begin, dist, ncomp_pair, ld, stream))) return rc;
         if ((rc = minor_pass())) return rc;
+        pair_mark(2, stream);
         dist_final(stream);
         if ((rc = count_pass(live_tiles, n_live))) return rc;
+        pair_mark(4, stream);
         TRACS_HIP_CHECK(hipGetLastError());
         return TRACS_OK;
     }

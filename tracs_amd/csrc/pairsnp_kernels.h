@@ -83,7 +83,7 @@ int site_classes_decide(tracs_alignment *a, hipStream_t stream, int *partial);
 void site_classes_free(tracs_alignment *a);
 // stage clock of the once-per-pack work (HIP events on the launch stream; tracs_debug_pack_stages, TRACS_CLASSES_TRACE)
 void pack_stage_begin(hipStream_t stream);
-void pack_stage_mark(const char *name, hipStream_t stream);
+void pack_stage_mark(const char *name, hipStream_t stream, double bytes_read = 0.0, double bytes_written = 0.0);
 void pack_stage_end();
 
 // ---- sparse side structures of the general matrix-core path (general_sparse.hip) -------------------------------

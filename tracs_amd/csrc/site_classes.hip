@@ -63,9 +63,11 @@ struct GroupWords { unsigned x[4], y[4], one[4], some[4], isn[4], bad[4]; };
 __device__ __forceinline__ void load_group_words(const uint4 *__restrict__ P, size_t n_pad, size_t g, unsigned s, GroupWords &q)
 {
     const uint4 *base = P + (g * NPLANES) * n_pad + s;
-    const uint4 A = base[0], C = base[n_pad], G = base[2 * n_pad], T = base[3 * n_pad], N = base[4 * n_pad];
+    // (the stored N plane is A & C & G & T by construction -- pack_kernel, pack_codes_kernel --: four planes are read, not five)
+    const uint4 A = base[0], C = base[n_pad], G = base[2 * n_pad], T = base[3 * n_pad];
     const unsigned a[4] = {A.x, A.y, A.z, A.w}, c[4] = {C.x, C.y, C.z, C.w}, gg[4] = {G.x, G.y, G.z, G.w};
-    const unsigned t[4] = {T.x, T.y, T.z, T.w}, nn[4] = {N.x, N.y, N.z, N.w};
+    const unsigned t[4] = {T.x, T.y, T.z, T.w};
+    const unsigned nn[4] = {a[0] & c[0] & gg[0] & t[0], a[1] & c[1] & gg[1] & t[1], a[2] & c[2] & gg[2] & t[2], a[3] & c[3] & gg[3] & t[3]};
 #pragma unroll
     for (int w = 0; w < 4; w++) {
         const unsigned two = (a[w] & c[w]) | (a[w] & gg[w]) | (a[w] & t[w]) | (c[w] & gg[w]) | (c[w] & t[w]) | (gg[w] & t[w]);
@@ -463,6 +465,7 @@ static int g_force_classes = -2;          // tracs_debug_force_site_classes: -2 
 static constexpr int kMaxStages = 12;
 static hipEvent_t g_stage_ev[kMaxStages + 1];
 static const char *g_stage_name[kMaxStages];
+static double g_stage_rd[kMaxStages], g_stage_wr[kMaxStages];     // bytes the stage reads / writes (its arrays, once per pass over them)
 static int g_stage_n = 0;
 static bool g_stage_on = false, g_stage_valid = false;
 
@@ -475,14 +478,15 @@ static void stage_begin(hipStream_t stream)
     if (!g_stage_ev[0]) for (auto &e : g_stage_ev) (void)hipEventCreate(&e);
     (void)hipEventRecord(g_stage_ev[0], stream);
 }
-static void stage_mark(const char *name, hipStream_t stream)
+static void stage_mark(const char *name, hipStream_t stream, double rd = 0.0, double wr = 0.0)
 {
     if (!g_stage_on || g_stage_n >= kMaxStages) return;
+    g_stage_rd[g_stage_n] = rd; g_stage_wr[g_stage_n] = wr;
     g_stage_name[g_stage_n++] = name;
     (void)hipEventRecord(g_stage_ev[g_stage_n], stream);
     g_stage_valid = true;
 }
-void pack_stage_mark(const char *name, hipStream_t stream) { stage_mark(name, stream); }
+void pack_stage_mark(const char *name, hipStream_t stream, double rd, double wr) { stage_mark(name, stream, rd, wr); }
 void pack_stage_begin(hipStream_t stream) { stage_begin(stream); }
 void pack_stage_end()
 {
@@ -546,7 +550,8 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     TRACS_HIP_CHECK(hipMemsetAsync(totals, 0, 128, stream));
     hipLaunchKernelGGL(classify_sites_kernel, dim3((unsigned)groups), dim3(256), 0, stream, a->planes, a->n_pad, (unsigned)a->n, budget,
                        nn_list_max, masks, groups, cntP, cntN, cntA, split_at, gcnt, gcnt + groups, gcnt + 2 * groups, gcnt + 3 * groups, gcnt + 4 * groups, gcnt + 5 * groups, flags, flag_words, d_flag);
-    stage_mark("classify", stream);
+    const double plane_b = (double)groups * (double)a->n_pad * sizeof(uint4);      // one bit plane of the alignment
+    stage_mark("classify", stream, 4.0 * plane_b, (double)groups * (M_SLOTS * 16.0 + 3.0 * SITES_PER_GROUP * 4.0 + flag_words * 8.0));
     hipLaunchKernelGGL(group_offsets_kernel, dim3(13), dim3(1024), 0, stream, masks, gcnt, groups, offs, off64, totals);
     unsigned long long tot[16] = {0};
     TRACS_HIP_CHECK(hipMemcpyAsync(tot, totals, 128, hipMemcpyDeviceToHost, stream));
@@ -604,7 +609,7 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
             hipLaunchKernelGGL((compact_sites_kernel<0>), grid, dim3(256), 0, stream, a->planes, list_dense, (unsigned)L_dense, a->vplanes,
                                a->n_pad, (unsigned)a->n, (unsigned)gv);
     }
-    stage_mark("re-pack dense sites", stream);
+    stage_mark("re-pack dense sites", stream, (double)gv * NPLANES * a->n_pad * 16.0, (double)vbytes);
     if (gi) {
         hipLaunchKernelGGL(class_list_kernel, lgrid, dim3(256), 0, stream, mask_of(M_COUNT), off_of(M_COUNT), groups, list_count);
         const dim3 grid((unsigned)((gi + 3) / 4), sblocks);
@@ -619,7 +624,7 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     else if (L_un)
         hipLaunchKernelGGL(plane_popcount_masked_kernel, dim3((unsigned)((a->n + 255) / 256), 128), dim3(256), 0, stream,
                            a->planes + 4 * a->n_pad, mask_of(M_UN), a->n_pad, (unsigned)a->n, groups, a->c_counted);
-    stage_mark(gi ? "re-pack counted sites" : "N counts per sample", stream);
+    stage_mark(gi ? "re-pack counted sites" : "N counts per sample", stream, plane_b, (double)ibytes);
     if (L_lst) {
         // the lists (general_sparse.hip): per-site lists from the N plane and the flagged samples, per-sample lists from the N plane
         int built = 0;
@@ -693,6 +698,17 @@ int tracs_debug_pack_stages(char *names, size_t cap, float *ms, int max_stages)
             names[used] = 0;
         }
     }
+    return k;
+}
+
+// bytes read / written by the stages of the last once-per-pack build (the library's own accounting: each array once per pass
+// over it) -- bench.py's roofline_per_pack.  Returns the number of stages.
+int tracs_debug_pack_stage_bytes(double *rd, double *wr, int max_stages)
+{
+    using namespace tracs;
+    if (!g_stage_valid) return 0;
+    int k = 0;
+    for (; k < g_stage_n && k < max_stages; k++) { if (rd) rd[k] = g_stage_rd[k]; if (wr) wr[k] = g_stage_wr[k]; }
     return k;
 }
 

@@ -152,6 +152,12 @@ class Alignment:
 def notify_distances(event):
     """The next pairsnp_dense call records `event` (torch.cuda.Event) on its stream once the distances are final -- before the
     compared-sites counts are (include/tracs_hip.h, "Two streams")."""
+    if not event.cuda_event:
+        # torch creates the hipEvent lazily, on the first record: force it into existence (the handle of an unrecorded
+        # torch.cuda.Event is 0 -- the library would then record nothing and a wait on the event would not wait)
+        event.record(torch.cuda.current_stream())
+    if not event.cuda_event:
+        raise _lib.TracsError("notify_distances: the event has no HIP handle")
     _lib.load().tracs_pairsnp_notify_distances(C.c_void_p(event.cuda_event))
 
 
@@ -167,6 +173,16 @@ def pack_stages():
     ms = (C.c_float * 16)()
     k = lib.tracs_debug_pack_stages(names, 1024, ms, 16)
     return list(zip(names.value.decode().split("\n"), [float(x) for x in ms[:k]])) if k else []
+
+
+def pack_stages_bytes():
+    """[(stage, ms, bytes read, bytes written), ..] of the last once-per-pack build: pack_stages() with the library's own
+    accounting of what each stage reads and writes (bench.py's roofline_per_pack)."""
+    lib = _lib.load()
+    st = pack_stages()
+    rd, wr = (C.c_double * 16)(), (C.c_double * 16)()
+    k = lib.tracs_debug_pack_stage_bytes(rd, wr, 16)
+    return [(name, ms, float(rd[i]) if i < k else 0.0, float(wr[i]) if i < k else 0.0) for i, (name, ms) in enumerate(st)]
 
 
 def pairsnp_dense(aln, dist, ncomp=None, row_begin=0, row_end=None, col_begin=0, dist_threshold=None, base_row=0):

@@ -107,20 +107,24 @@ def pairs_of_rank(aln, i_end, j_start, dist_threshold, rank, world, recomb_filte
     parts = {}
     k = 5 if recomb_filter else 4
     own = [(c * cs, min(i_end, (c + 1) * cs)) for c in sorted(set(partition.rank_chunks(rank, world))) if c * cs < min(i_end, (c + 1) * cs)]
-    if world > 1 and 1 <= len(own) <= 2:
-        aln.hint_rows(own)                                    # per-row structures of the site classes: this rank's rows only
-    for c in sorted(set(partition.rank_chunks(rank, world))):
-        r0c, r1c = c * cs, min(i_end, (c + 1) * cs)
-        acc = [[] for _ in range(k)]
-        for r0 in range(r0c, max(r0c, r1c), dpan.shape[0]):
-            r1 = min(r1c, r0 + dpan.shape[0])
-            dev.pairsnp_dense(aln, dpan, npan, row_begin=r0, row_end=r1, col_begin=j_start, dist_threshold=dist_threshold, base_row=r0)
-            got = dev.coo_from_dense(dpan, npan, n, dist_threshold, row_begin=r0, row_end=r1, col_begin=j_start, base_row=r0)
-            if recomb_filter:
-                got = list(got) + [dev.filter_recomb_device(aln, got[0], got[1], got[2])[0].clone()]
-            for t in range(k):
-                acc[t].append(got[t])
-        parts[c] = tuple(torch.cat(a) if a else torch.empty(0, dtype=torch.int32, device=dev_) for a in acc)
+    # per-row structures of the site classes: this rank's rows only -- set on entry whatever the handle was used for before, and
+    # lifted on the way out (a handle reused with another rank / world, or for other rows, must not keep a stale promise)
+    aln.hint_rows(own if (world > 1 and 1 <= len(own) <= 2) else [])
+    try:
+        for c in sorted(set(partition.rank_chunks(rank, world))):
+            r0c, r1c = c * cs, min(i_end, (c + 1) * cs)
+            acc = [[] for _ in range(k)]
+            for r0 in range(r0c, max(r0c, r1c), dpan.shape[0]):
+                r1 = min(r1c, r0 + dpan.shape[0])
+                dev.pairsnp_dense(aln, dpan, npan, row_begin=r0, row_end=r1, col_begin=j_start, dist_threshold=dist_threshold, base_row=r0)
+                got = dev.coo_from_dense(dpan, npan, n, dist_threshold, row_begin=r0, row_end=r1, col_begin=j_start, base_row=r0)
+                if recomb_filter:
+                    got = list(got) + [dev.filter_recomb_device(aln, got[0], got[1], got[2])[0].clone()]
+                for t in range(k):
+                    acc[t].append(got[t])
+            parts[c] = tuple(torch.cat(a) if a else torch.empty(0, dtype=torch.int32, device=dev_) for a in acc)
+    finally:
+        aln.hint_rows([])
     return parts
 
 
