@@ -147,25 +147,30 @@ def count_roofline(pairs_per_launch, sites, count_s, n, in_place):
                     "the bare instruction's rate on zero operands), %g flop per pair and site" % COUNT_FLOP_PER_SITE}
 
 
-def nn_list_roofline(ls, sites, kern_s, rows, n):
-    """nn_rows_kernel (csrc/general_sparse.hip): the N co-occurrences NN = sum n_i n_j of the sites with few N samples, from their N
-    lists -- memory-bound.  Algorithmic bytes per launch: every visited list entry once (cN entries per walk -- one walk per N
-    sample and site: the sum of cN^2 over those sites, 2 or 4 B each) + the walk's 4-byte entry of the per-sample stream.  Scaled by
-    the rows of the launch (a rank's panel walks its rows' lists only).  What the kernel physically moves is more: a list of ~100
-    samples lies in two 128-byte lines (`traffic`).  With split lists (csrc/pairsnp_kernels.h: nn_list_is_split) a row of the upper
-    sample half visits the second part only: nn_visits counts cA c + cB^2 per site."""
+def nn_list_roofline(ls, sites, kern_s, rows, n, L=None):
+    """nn_rows_kernel (csrc/site_lists.hip): the N co-occurrences NN = sum n_i n_j of the sites with few N samples, from their N
+    lists -- memory-bound.  Algorithmic bytes per launch: every list entry a walk decodes, one byte each (n8 lines: byte deltas;
+    cN entries per walk, one walk per N sample and site: the sum of cN^2 over those sites) + the rows' N bitmaps (L / 8 bytes per
+    row), scaled by the rows of the launch (a rank's panel walks its rows' lists only).  `frac_needed` counts only the entries
+    with j > i (half of them: row i needs no other).  What the kernel physically moves is whole 128-byte lines: one per walk and
+    ~115 samples of the list (`lines_bytes`; measured: `traffic`)."""
     frac_rows = rows / float(n)
-    alg = (ls["nn_visits"] * ls["n_entry_bytes"] + ls["nn_walks"] * 4.0) * frac_rows
+    bitmap = rows * (L / 8.0) if L else 0.0
+    alg = ls["nn_visits"] * ls["n_entry_bytes"] * frac_rows + bitmap
+    needed = 0.5 * ls["nn_visits"] * ls["n_entry_bytes"] * frac_rows + bitmap
+    lines = ls["nn_walks"] * 128.0 * frac_rows + bitmap
     return {"kernel": "nn_rows_kernel", "kernel_ms": kern_s * 1e3, "sites": sites, "bound": "hbm", "traffic": None,
             "achieved": alg / kern_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg / kern_s / HBM_PEAK,
-            "algorithmic_bytes": alg, "list_entries_visited": ls["nn_visits"] * frac_rows, "list_walks": ls["nn_walks"] * frac_rows,
-            "bytes_per_list_entry": ls["n_entry_bytes"],
+            "algorithmic_bytes": alg, "frac_needed": needed / kern_s / HBM_PEAK, "needed_bytes": needed,
+            "lines_bytes": lines, "frac_lines": lines / kern_s / HBM_PEAK,
+            "list_entries_visited": ls["nn_visits"] * frac_rows, "list_walks": ls["nn_walks"] * frac_rows,
+            "bytes_per_list_entry": ls["n_entry_bytes"], "bitmap_bytes": bitmap,
             "entries_per_s": ls["nn_visits"] * frac_rows / kern_s,
-            "note": "row i of the pair matrix in LDS; for every site at which sample i is N (and that has few N samples) the site's list "
-                    "of N samples is read (16 bytes per lane, four or eight lists per load instruction), ds_add per j > i: sum of cN^2 list "
-                    "entries instead of n^2 / 2 pairs per site on the matrix cores.  Lists of 64 and more samples lie in two parts by "
-                    "sample halves: a row of the upper half reads the second part only (list_entries_visited counts what a row must look at).  "
-                    "Random reads of whole 128-byte lines: bound by the requests it pulls through the fabric (`traffic`, `hbm_physical`)"}
+            "note": "row i of the pair matrix in LDS; every N site of sample i (a set bit of its N bitmap) is a walk of the site's N list "
+                    "-- byte deltas in sample order, 124 per 128-byte line: a site of ~100 N samples among 10 000 is ONE line --, decoded by "
+                    "eight lanes (byte sums, an 8-lane DPP prefix, one SDWA add per byte), ds_add per j > i: sum of cN^2 list entries "
+                    "instead of n^2 / 2 pairs per site on the matrix cores.  Random reads of whole 128-byte lines: bound by the requests "
+                    "it pulls through the fabric (`frac_lines`, `traffic`, `hbm_physical`)"}
 
 
 def roofline_of(kernel, enc, pairs_per_launch, L, kern_s, traffic, n):
@@ -447,7 +452,7 @@ def main():
             last_rows = ranges[-1][1] - ranges[-1][0]
             main = roofline_of(aln.kernel, enc, last_pairs, dense, max(split[0], 1e-3) / 1e3, None, n)
             cnt = count_roofline(last_pairs, count_sites, max(split[2], 1e-3) / 1e3, n, in_place)
-            nnl = nn_list_roofline(ls, nn_listed, max(split[3], 1e-3) / 1e3, last_rows, n) if nn_listed else None
+            nnl = nn_list_roofline(ls, nn_listed, max(split[3], 1e-3) / 1e3, last_rows, n, L) if nn_listed else None
             cands = [(split[0], main, ""), (split[2], cnt, "+classes"), (split[3], nnl, "+nnlists")]
             cands = sorted([c for c in cands if c[1] is not None], key=lambda c: -c[0])
             roof, tag = cands[0][1], cands[0][2]
@@ -614,7 +619,7 @@ def general_pass(args, n, L, seed, dev, synth, torch, device):
         count_sites, in_place, nn_listed = aln.count_source or (classes[1], False, 0)
         main = roofline_of(aln.kernel, "general", pairs, classes[0], max(split[0], 1e-3) / 1e3, None, n)
         cnt = count_roofline(pairs, count_sites, max(split[2], 1e-3) / 1e3, n, in_place)
-        nnl = nn_list_roofline(aln.list_stats, nn_listed, max(split[3], 1e-3) / 1e3, n, n) if nn_listed else None
+        nnl = nn_list_roofline(aln.list_stats, nn_listed, max(split[3], 1e-3) / 1e3, n, n, L) if nn_listed else None
         cands = sorted([c for c in ((split[0], main), (split[2], cnt), (split[3], nnl)) if c[1] is not None], key=lambda c: -c[0])
         r = cands[0][1]
         r["other_kernels"] = [{k: c[1][k] for k in ("kernel", "kernel_ms", "bound", "achieved", "frac", "unit", "sites") if k in c[1]} for c in cands[1:]]

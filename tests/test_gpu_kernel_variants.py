@@ -76,12 +76,6 @@ VARIANTS = [
     ({"TRACS_COUNT_IN_PLACE": "1"}, {("consensus", "mfma"), ("general", "mfma-general")}),
     ({"TRACS_COUNT_IN_PLACE": "1", "TRACS_KSPLIT": "3"}, {("consensus", "mfma"), ("general", "mfma-general")}),
     ({"TRACS_COUNT_IN_PLACE": "0"}, {("consensus", "mfma"), ("general", "mfma-general")}),
-    ({"TRACS_LIST_INLINE": "0"}, {("consensus", "mfma"), ("general", "mfma-general")}),
-    # N lists of 64 samples and more in one part (default: two, by sample halves); with lists at every site that has two N samples
-    ({"TRACS_NN_SPLIT": "0"}, {("consensus", "mfma"), ("general", "mfma-general")}),
-    ({"TRACS_NN_SPLIT": "0", "TRACS_NN_LIST_K": "1"}, {("consensus", "mfma"), ("general", "mfma-general")}),
-    # a group's N lists written entry by entry (default: built in LDS, 16-byte stores)
-    ({"TRACS_LIST_STAGE": "0", "TRACS_NN_LIST_K": "1"}, {("consensus", "mfma"), ("general", "mfma-general")}),
 ]
 
 

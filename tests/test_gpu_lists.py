@@ -1,0 +1,147 @@
+"""The lists of an alignment cut into site classes (csrc/site_lists.hip), structure by structure against numpy: the n8 lines of
+the per-site N lists (byte deltas, sorted, 124 payload bytes + next line), the p lists, the per-sample listed entries, the
+rows' N bitmaps.  The pair results built on them are checked against the oracle in test_gpu_site_classes.py."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CODES = {c: m for c, m in zip(b"ACGTMRWSYKVHDB", (1, 2, 4, 8, 3, 5, 9, 6, 10, 12, 7, 11, 13, 14))}
+
+
+def _masks(seqs):
+    up = np.where((seqs >= 97) & (seqs <= 122), seqs - 32, seqs)
+    lut = np.full(256, 15, dtype=np.uint8)
+    for c, m in CODES.items():
+        lut[c] = m
+    return lut[up]
+
+
+def _dump(lib, aln, what, dtype, count):
+    buf = np.empty(count, dtype=dtype)
+    got = lib.tracs_debug_lists(aln._h, what, buf.ctypes.data_as(C.c_void_p), buf.nbytes)
+    assert got == buf.nbytes, (what, got, buf.nbytes)
+    return buf
+
+
+def _decode(lines, r):
+    """the samples of the list whose primary line is r (reference decoder of the n8 format, csrc/pairsnp_kernels.h)"""
+    out, p, line, hops = [], -1, int(r), 0
+    while True:
+        payload = lines[line, :124]
+        pad = np.nonzero(payload == 255)[0]
+        if pad.size:
+            assert (payload[pad[0]:] == 255).all(), "padding inside a line"
+            assert (lines[line, 124:] == 255).all(), "a padded line goes on"
+        for b in payload.tolist():
+            if b < 253:
+                p += b
+                out.append(p)
+            elif b == 253:
+                p += 253
+            else:
+                assert b == 255
+        nxt = int(lines[line, 124:].view(np.uint32)[0])
+        if nxt == 0xFFFFFFFF:
+            return out
+        line, hops = nxt, hops + 1
+        assert hops < 100000
+
+
+CASES = [
+    dict(n=300, L=5000, p_n=0.02, mu=3e-4, seed=1),                     # short lists, one piece
+    dict(n=700, L=3000, p_n=0.30, mu=3e-4, seed=2),                     # ~210 N samples per site: two lines per list, several pieces per group
+    dict(n=2000, L=1500, p_n=0.002, mu=2e-4, seed=3),                   # gaps beyond 253: skip bytes
+    dict(n=130, L=4000, p_n=0.05, mu=2e-3, seed=4, p_partial=0.002),    # partial codes among the listed samples
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "n%d_L%d_pn%g" % (c["n"], c["L"], c["p_n"]))
+def test_lists_against_numpy(hiplib, case):
+    import torch
+    from tracs_amd import device as dev
+    n, L = case["n"], case["L"]
+    rng = np.random.default_rng(case["seed"])
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seqs = np.tile(bases[rng.integers(0, 4, size=L)], (n, 1))
+    mut = rng.random((n, L)) < case["mu"]
+    seqs[mut] = bases[rng.integers(0, 4, size=int(mut.sum()))]
+    seqs[rng.random((n, L)) < case["p_n"]] = ord("N")
+    if case.get("p_partial"):
+        part = rng.random((n, L)) < case["p_partial"]
+        seqs[part] = np.frombuffer(b"MRWSYKVHDB", dtype=np.uint8)[rng.integers(0, 10, size=int(part.sum()))]
+    seqs[:, rng.random(L) < 0.01] = ord("N")                              # empty sites
+    aln = dev.Alignment(n, L)
+    aln.pack(seqs)
+    d = torch.zeros((n, n), dtype=torch.int32, device="cuda")
+    nn = torch.zeros_like(d)
+    os.environ.pop("TRACS_NN_LIST_K", None)
+    try:
+        hiplib.tracs_debug_force_site_classes(1)
+        dev.pairsnp_dense(aln, d, nn)
+    finally:
+        hiplib.tracs_debug_force_site_classes(-2)
+    assert aln.site_classes is not None
+    sizes = _dump(hiplib, aln, 0, np.uint64, 8)
+    sites, n_lines, tot_p, tgroups, groups, has_T = (int(x) for x in sizes[:6])
+    assert sites > 0 and groups == (L + 127) // 128
+    lines = _dump(hiplib, aln, 1, np.uint8, n_lines * 128).reshape(n_lines, 128)
+    lst_mask = _dump(hiplib, aln, 2, np.uint32, groups * 4)
+    off_lst = _dump(hiplib, aln, 3, np.uint32, groups)
+    listed_site = np.unpackbits(lst_mask.view(np.uint8), bitorder="little")[:L].astype(bool)
+    assert int(listed_site.sum()) == sites
+    rank = np.cumsum(listed_site) - 1
+    before = np.concatenate([[0], np.cumsum(listed_site)])
+    assert (off_lst == before[np.minimum(np.arange(groups) * 128, L)]).all()
+    M = _masks(seqs)
+    isN = M == 15
+    # ---- N lists: every listed site's line chain decodes to its N samples, in order
+    for t in np.nonzero(listed_site)[0]:
+        got = _decode(lines, rank[t])
+        want = np.nonzero(isN[:, t])[0].tolist()
+        assert got == want, (t, got[:10], want[:10])
+    # ---- p lists and the per-sample listed entries
+    p_off = _dump(hiplib, aln, 4, np.uint64, sites + 1)
+    assert int(p_off[-1]) == tot_p
+    if tot_p:
+        p_ent = _dump(hiplib, aln, 5, np.uint32, tot_p)
+        s_off = _dump(hiplib, aln, 6, np.uint64, n + 1)
+        s_ent = _dump(hiplib, aln, 7, np.uint32, tot_p)
+        c_p = _dump(hiplib, aln, 9, np.uint32, n)
+        site_of_rank = np.nonzero(listed_site)[0]
+        pairs_site = set()
+        for r in range(sites):
+            t = site_of_rank[r]
+            ents = p_ent[int(p_off[r]):int(p_off[r + 1])]
+            if ents.size == 0:
+                continue
+            samp, w, mask = ents >> 5, (ents >> 4) & 1, ents & 15
+            assert len(set(samp.tolist())) == samp.size
+            assert (M[samp, t] == mask).all() and (mask != 15).all()
+            rest = np.setdiff1d(np.arange(n), np.concatenate([samp, np.nonzero(isN[:, t])[0]]))
+            if rest.size:                                                 # everybody else carries the one reference base
+                ref = M[rest, t]
+                assert (ref == ref[0]).all() and ref[0] in (1, 2, 4, 8)
+                assert (mask != ref[0]).all()
+                assert (w == ((mask & ref[0]) == 0)).all()
+            for s_, w_, m_ in zip(samp.tolist(), w.tolist(), mask.tolist()):
+                pairs_site.add((s_, r, w_, m_))
+        pairs_sample = set()
+        for s_ in range(n):
+            ents = s_ent[int(s_off[s_]):int(s_off[s_ + 1])]
+            for e in ents.tolist():
+                pairs_sample.add((s_, e >> 5, (e >> 4) & 1, e & 15))
+            assert int(c_p[s_]) == int(((ents >> 4) & 1).sum())
+        assert pairs_site == pairs_sample
+    # ---- the rows' N bitmaps: per site either the N plane's column (an NNL site) or nothing
+    if has_T:
+        T = _dump(hiplib, aln, 8, np.uint32, n * tgroups * 4).reshape(n, tgroups * 4)
+        bits = np.unpackbits(T.view(np.uint8).reshape(n, -1), axis=1, bitorder="little")[:, :L].astype(bool)
+        col_any = bits.any(axis=0)
+        assert (bits[:, col_any] == isN[:, col_any]).all()
+        assert (listed_site[col_any]).all()
+        assert (isN[:, col_any].sum(axis=0) >= 2).all()
+    aln.close()

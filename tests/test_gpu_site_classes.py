@@ -335,7 +335,7 @@ assert aln.site_classes is not None and src is not None and src[2] > L // 2, (al
 assert aln.list_stats["nn_visits"] > (L // 10) * (%(p_n)g * n) ** 2 / 2, aln.list_stats              # ... the long ones too
 assert np.array_equal(d.cpu().numpy()[ri, ci], ed.astype(np.int32))
 assert np.array_equal(nn.cpu().numpy()[ri, ci], enn.astype(np.int32))
-# row panels on either side of the lists' split point, and one across it
+# row panels at both ends and in the middle
 for r0, r1 in ((0, 64), (700, 830), (1400, n)):
     dp = torch.zeros((r1 - r0, n), dtype=torch.int32, device="cuda"); npn = torch.zeros_like(dp)
     dev.pairsnp_dense(aln, dp, npn, row_begin=r0, row_end=r1, base_row=r0)
@@ -347,15 +347,12 @@ aln.close()
 '''
 
 
-@pytest.mark.parametrize("env", [{"TRACS_NN_LIST_K": "1"}, {"TRACS_NN_LIST_K": "1", "TRACS_NN_SPLIT": "0"},
-                                 {"TRACS_NN_LIST_K": "1", "TRACS_LIST_INLINE": "0", "TRACS_NN_TARGET": "2048"},
-                                 {"TRACS_NN_LIST_K": "1", "TRACS_LIST_STAGE": "0"}],
-                         ids=lambda e: "+".join("%s=%s" % kv for kv in e.items()))
+@pytest.mark.parametrize("env", [{"TRACS_NN_LIST_K": "1"}], ids=lambda e: "+".join("%s=%s" % kv for kv in e.items()))
 @pytest.mark.parametrize("p_n", [0.15, 0.05])
-def test_long_n_lists_in_two_parts(hiplib, oracle, env, p_n):
-    """N lists of ~ 225 (75) samples at 1 500 samples -- several 64-entry pads per part, so the walk of nn_rows_kernel goes on
-    behind its first load in both lane-group widths (16 lanes below the split point, 8 from it on) -- forced onto the lists whatever
-    the cost model says; every pair against the oracle, whole matrix and row panels on either side of the split point."""
+def test_long_n_lists(hiplib, oracle, env, p_n):
+    """N lists of ~ 225 (75) samples at 1 500 samples -- two 124-byte lines per list at the higher rate, so the walks of
+    nn_rows_kernel and minor_fixup_kernel go on into overflow lines, and the per-site pass takes its groups in several pieces --
+    forced onto the lists whatever the cost model says; every pair against the oracle, whole matrix and row panels."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -366,9 +363,9 @@ def test_long_n_lists_in_two_parts(hiplib, oracle, env, p_n):
 
 @pytest.mark.parametrize("n", [65534, 65600])
 def test_lists_at_the_16_bit_boundary(hiplib, oracle, n):
-    """65 534 samples: the most that 16-bit sample numbers hold (0xFFFE and 0xFFFF are the filler and the sentinel), two column
-    chunks per row; 65 600: list entries are 32-bit sample numbers (no inline entries, 16 lanes per pad).  Row panels below and
-    beyond the lists' split point against the oracle on a subset of the columns (the panel rows + 1 500 random samples)."""
+    """65 534 / 65 600 samples: two column chunks per row, and -- beyond 65 536 samples -- the per-site pass takes every group in
+    pieces (its LDS staging holds 16-bit offsets from a piece's first sample); lists of a few N samples among 65 000: long runs of
+    skip bytes.  Row panels against the oracle on a subset of the columns (the panel rows + 1 500 random samples)."""
     import torch
     from tracs_amd import device as dev, synth
     L = 512

@@ -216,6 +216,8 @@ def load():
     L.tracs_debug_pack_stages.argtypes = [C.c_char_p, sz, C.POINTER(C.c_float), C.c_int]
     L.tracs_debug_pack_stage_bytes.restype = C.c_int
     L.tracs_debug_pack_stage_bytes.argtypes = [dp, dp, C.c_int]
+    L.tracs_debug_lists.restype = sz
+    L.tracs_debug_lists.argtypes = [vp, C.c_int, vp, sz]
     L.tracs_debug_pair_timing.restype = None
     L.tracs_debug_pair_timing.argtypes = [C.c_int]
     L.tracs_debug_last_pair_ms.restype = C.c_int

@@ -40,7 +40,7 @@ static inline size_t pad_samples(size_t n) { return (n + SAMPLE_PAD - 1) / SAMPL
 
 }  // namespace tracs
 
-namespace tracs { struct GeneralSparse; }
+namespace tracs { struct GeneralSparse; struct SiteLists; }
 
 struct tracs_alignment {
     size_t n = 0, L = 0, n_pad = 0, groups = 0;
@@ -62,13 +62,14 @@ struct tracs_alignment {
     size_t L_un = 0, L_nnl = 0;               // sites outside vplanes with an N sample (L_inv of them on the matrix cores, L_nnl
                                               // through their N lists, the rest with a single N sample: no co-occurrence)
     unsigned long long nn_visits = 0;         // list entries one pass of the N co-occurrence walk visits (sum of cN^2 over the L_nnl sites)
-    unsigned long long list_entries_n = 0, list_entries_p = 0;     // entries of the per-site N lists (padded) / listed-sample lists
+    unsigned long long list_entries_n = 0, list_entries_p = 0;     // 128-byte lines of the per-site N lists (primary + overflow reserve) / listed-sample entries
     unsigned long long nn_walks = 0;          // list walks of one pass of the N co-occurrence walk (sum of cN over the L_nnl sites)
+    unsigned long long fix_walks = 0;         // N-list walks of one pass of the minority fix-up (listed samples of minority sites with an N sample)
     unsigned *c_counted = nullptr;            // per sample: its N sites among the sites the counting pass reads
     bool count_in_place = false;              // the counting pass reads the stored N plane of `planes` (every site) instead of iplanes:
                                               // nn = L - c_i - c_j + NN comes from it alone and the pair kernels write d only
     bool classes_cons = false;                // vplanes hold consensus planes (X, Y, V) / the five general planes
-    tracs::GeneralSparse *minor = nullptr;    // lists of the minority sites (site_classes.hip)
+    tracs::SiteLists *lists = nullptr;        // lists of the sites with lists: minority and NNL sites (site_lists.hip)
     size_t row_hint[4] = {0, 0, 0, 0};   // tracs_alignment_hint_rows: the only rows this handle will be asked for
     int n_row_hint = 0;
     int classes_state = 0;       // 0 not decided, 1 in use, -1 not in use for this alignment

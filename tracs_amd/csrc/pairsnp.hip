@@ -821,7 +821,7 @@ int tracs_debug_alignment_count_source(const tracs_alignment *a, uint64_t *out)
     out[3] = a->nn_visits;
     out[4] = a->list_entries_n;
     out[5] = a->list_entries_p;
-    out[6] = a->n < 65535 ? 2 : 4;                           // bytes per N list entry
+    out[6] = 1;                                             // bytes per N list entry (n8 lines: byte deltas)
     out[7] = a->nn_walks;
     return 1;
 }
@@ -1095,7 +1095,7 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
             A.n_pad = a->n_pad; A.groups = g_end; A.tiles = tl; A.n_tiles = ntl; A.gps = gps; A.ksplit = k;
             A.L = (unsigned)pair_L(a); A.n = (unsigned)a->n; A.row_end = (unsigned)row_end; A.col_begin = (unsigned)col_begin;
             A.dist = dist; A.ncomp = ncomp_pair; A.ld = ld; A.thr = t; A.ph = ph;
-            A.keep_bound = (classes && a->minor) ? 1 : 0;      // terms are added to the cells afterwards: no flag values
+            A.keep_bound = (classes && a->lists) ? 1 : 0;      // terms are added to the cells afterwards: no flag values
             return launch_pairsnp_mfma(shape_id, mfma_general, nwg, stream, A);
         }
         V.launch[cons ? 1 : 0](ncomp != nullptr, nwg, stream, cons ? a->cplanes : a->planes, a->n_pad, g_end, tl, ntl, gps, k,
@@ -1172,7 +1172,7 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
     };
     // Site classes, consensus form: the minority sites' distances from their lists (general_sparse.hip, general_fixup_kernel<MINOR>)
     auto minor_pass = [&]() -> int {
-        return (classes && a->minor) ? minority_fixup(a, row_begin, row_end, col_begin, dist, ld, stream) : TRACS_OK;
+        return (classes && a->lists) ? minority_fixup(a, row_begin, row_end, col_begin, dist, ld, stream) : TRACS_OK;
     };
     if (classes && groups == 0) {
         // no dense site at all: the distances come from the lists, the compared-sites counts from the counting pass

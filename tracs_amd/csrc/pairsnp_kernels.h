@@ -95,44 +95,44 @@ void general_sparse_free(tracs_alignment *a);
 // dist[i][j] += T1 + T2 (partial-code terms), ncomp[i][j] += L - c_i - c_j for the cells of the dense region.
 int general_sparse_fixup(tracs_alignment *a, size_t row_begin, size_t row_end, size_t col_begin, unsigned *dist,
                          unsigned *ncomp, size_t ld, hipStream_t stream);
-// The same lists for the MINORITY sites of an alignment cut into site classes (site_classes.hip): a sample that is neither N nor
-// exactly the site's reference base is listed with its allele mask and w = [reference base not in the mask]; minority_fixup
-// adds the sites' contribution to dist (general_fixup_kernel<MINOR>).  Built from what classify_sites_kernel left behind:
-// N lists of the site classes: at least one all-ones sentinel behind the last sample, padded to a multiple of this many entries
-// (one cache line of 16-bit sample numbers): every list starts on a line boundary and its end needs no length
-constexpr unsigned NN_LIST_PAD = 64;
-__host__ __device__ inline unsigned nn_list_padded(unsigned c) { return (c / NN_LIST_PAD + 1u) * NN_LIST_PAD; }
-// A list that needs two pads anyway (c >= NN_LIST_PAD) is laid out in two parts, each on its own cache line(s): the N samples below
-// `split_at` (a multiple of 256 near n / 2), then the others.  Row i counts only the columns j > i, so a row at or beyond split_at
-// starts its walk at the second part: it never reads the first part's lines.  The first part is padded to whole pads and the LAST
-// entry of its last pad is NN_LIST_FILL, not the sentinel (the walk goes on into the second part: nn_rows_kernel stops at a pad
-// whose last entry is the sentinel); the second part ends like an unsplit list.  split_at = 0: no list is split.
-constexpr unsigned NN_LIST_FILL16 = 0xFFFEu, NN_LIST_FILL32 = 0xFFFFFFFEu;
-__host__ __device__ inline bool nn_list_is_split(unsigned c, unsigned split_at) { return split_at != 0u && c >= NN_LIST_PAD; }
-__host__ __device__ inline unsigned nn_list_first_part(unsigned c_first) { return (c_first + NN_LIST_PAD - 1u) / NN_LIST_PAD * NN_LIST_PAD; }
-__host__ __device__ inline unsigned nn_list_padded(unsigned c, unsigned c_first, unsigned split_at)
+// ---- lists of an alignment cut into site classes (site_lists.hip) ---------------------------------------------------------
+// Two kinds of site carry lists, under one rank space (the sites of M_LST in site order):
+//   MINORITY sites  a sample that is neither N nor exactly the site's reference base is LISTED with its allele mask M and
+//                   w = [reference base not in M] (p lists); minority_fixup adds the sites' contribution to dist;
+//   NNL sites       few N samples: nn_rows_add takes their N co-occurrences NN = sum n_i n_j from the sites' N lists.
+// N LISTS ("n8" lines).  The N samples of a site, in sample order, as byte deltas in 128-byte lines: line r of `lines` is the
+// primary line of the site of rank r; 124 payload bytes, then the index of the list's next line (0xFFFFFFFF: none).  With p the
+// position before a byte b (-1 at the head of a list):
+//     b <= 252   p += b, sample p is N here           (b = 0 only straight behind a skip)
+//     b == 253   p += 253, no sample                   (a gap g is g / 253 skips and the byte g % 253)
+//     b == 255   padding behind the last sample (nothing follows it in the line)
+// A site of ~100 N samples among 10 000 is ONE cache line (two 128-byte lines of 16-bit sample numbers before); a row's walk
+// decodes a line with eight lanes, 16 bytes each: byte sums per lane, an 8-lane prefix, one SDWA add per byte.
+constexpr unsigned N8_PAYLOAD = 124, N8_SKIP = 253, N8_NONE = 0xFFFFFFFFu;
+// lines a list of c samples among n can need at most (its gaps sum to <= n: at most n / 253 skip bytes in all)
+__host__ __device__ inline unsigned n8_lines_max(unsigned c, unsigned n) { const unsigned b = c + n / N8_SKIP; return b <= N8_PAYLOAD ? 1u : (b + N8_PAYLOAD - 1u) / N8_PAYLOAD; }
+// ... and will need on average (cost model: uniformly placed samples -- a gap exceeds 253 with probability q = (1 - c / n)^253)
+__host__ __device__ inline float n8_lines_expected(unsigned c, unsigned n)
 {
-    return nn_list_is_split(c, split_at) ? nn_list_first_part(c_first) + nn_list_padded(c - c_first) : nn_list_padded(c);
+    const float q = __builtin_expf(-253.0f * (float)c / (float)(n ? n : 1u));
+    const float bytes = (float)c + (float)(c + 1u) * q / (1.0f - (q < 0.99f ? q : 0.99f));
+    const float cap = (float)c + (float)(n / N8_SKIP);
+    return __builtin_ceilf((bytes < cap ? bytes : cap) / (float)N8_PAYLOAD);
 }
 struct MinorBuild {
     const uint4 *planes;                     // the five general planes
-    const uint4 *minor_mask, *nnl_mask, *lst_mask;   // per group: minority sites, N co-occurrence list sites, their union
+    const uint4 *minor_mask, *nnl_mask, *lst_mask, *un_mask;   // per group: minority sites, N co-occurrence list sites, their union; sites outside the dense class with an N
     const uint4 *ref_x, *ref_y;              // per group: reference base bits
     const unsigned *off_lst;                 // per group: sites with lists before it (a site's list index = its rank among them)
     const unsigned *cntP, *cntN;             // per site: listed samples, N samples
-    const unsigned long long *baseP, *baseN; // per group: list entries (listed samples / N samples) of the sites before it
+    const unsigned long long *baseP, *baseO; // per group: p-list entries / overflow lines (upper bounds) of the groups before it
     const unsigned long long *flags;         // per group and 64 samples: listed somewhere in the group
     size_t flag_words;
-    unsigned rows[4];                        // per-sample lists only for the samples of these [begin, end) ranges (n_rows of them;
-    int n_rows;                              //  0: every sample) -- tracs_alignment_hint_rows
+    unsigned rows[4];                        // the N bitmap rows (nn_rows_add) only for the samples of these [begin, end) ranges
+    int n_rows;                              //  (n_rows of them; 0: every sample) -- tracs_alignment_hint_rows
     size_t sites;                            // sites with lists
-    unsigned long long tot_p, tot_n;         // list entries in all: listed samples, N samples
-    unsigned long long tot_nnl, tot_minor_n; // N samples at the NNL sites / at the minority sites (per-sample stream sizes)
-    unsigned long long tot_inl;              // ... at the minority sites whose (one or two) listed samples travel inline (0: not in use)
-    bool inline_ok;
-    const uint4 *inl_mask;
-    const unsigned *cntA;                    // N samples below split_at, per site (see nn_list_is_split)
-    unsigned split_at;                   // those sites (M_INL)
+    unsigned long long tot_p, tot_o;         // p-list entries, overflow lines (upper bound) in all
+    unsigned long long tot_nnl;              // N samples at the NNL sites: list walks of one pass of nn_rows_add
 };
 int minority_lists_build(tracs_alignment *a, const MinorBuild &mb, hipStream_t stream, int *ok);
 void minority_lists_free(tracs_alignment *a);

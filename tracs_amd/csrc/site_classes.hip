@@ -91,15 +91,15 @@ __device__ __forceinline__ void load_group_words(const uint4 *__restrict__ P, si
 // Outputs per group: the class masks, the reference base bits, k and cN of every site, the list sizes of its sites that
 // carry lists (gP = sum of k over the minority sites, gN = sum of cN over the minority and NNL sites).
 // Mask slots of a group (masks[slot * groups + g], one uint4 = 128 sites each):
-enum { M_DENSE = 0, M_COUNT, M_MINOR, M_FULL, M_NNL, M_LST, M_UN, M_REFX, M_REFY, M_INL, M_SLOTS };
+enum { M_DENSE = 0, M_COUNT, M_MINOR, M_FULL, M_NNL, M_LST, M_UN, M_REFX, M_REFY, M_SLOTS };
 //   M_COUNT  sites whose N co-occurrences go through the matrix cores (cN > nn_list_max, or lists not in use)
-//   M_NNL    sites whose N co-occurrences come from their N lists (cN >= 2, cN ceil(cN / 64) <= nn_list_max: nn_rows_kernel, general_sparse.hip)
+//   M_NNL    sites whose N co-occurrences come from their N lists (cN >= 2, cN x the lines of the list <= nn_list_max: nn_rows_kernel, site_lists.hip)
 //   M_LST    sites that carry lists at all (minority or NNL): list index = rank among these
 //   M_UN     every site outside the dense class with cN >= 1 (M_COUNT, M_NNL and the cN = 1 sites, which have no co-occurrence)
 __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__restrict__ P, size_t n_pad, unsigned n, unsigned budget,
                                                              unsigned nn_list_max, uint4 *__restrict__ masks, size_t groups,
-                                                             unsigned *__restrict__ cntP, unsigned *__restrict__ cntN, unsigned *__restrict__ cntA,
-                                                             unsigned split_at, unsigned *__restrict__ gP, unsigned *__restrict__ gN, unsigned *__restrict__ gQ,
+                                                             unsigned *__restrict__ cntP, unsigned *__restrict__ cntN,
+                                                             unsigned *__restrict__ gP, unsigned *__restrict__ gN, unsigned *__restrict__ gQ,
                                                              unsigned *__restrict__ gR, unsigned *__restrict__ gS, unsigned *__restrict__ gI,
                                                              unsigned long long *__restrict__ flags, size_t flag_words,
                                                              unsigned *__restrict__ partial_flag)
@@ -109,11 +109,10 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
     __shared__ unsigned sref[4][4];                     // one-base sample seen, ref X, ref Y, somebody is not N
     __shared__ unsigned planes_lds[256][4][8];          // one counter's bit planes of every thread (32 KiB)
     __shared__ unsigned tot[2][SITES_PER_GROUP];        // k, cN
-    __shared__ unsigned tot_first[SITES_PER_GROUP];     // cN among the samples below split_at
     __shared__ unsigned half_sum[SITES_PER_GROUP];
     __shared__ unsigned wsum[2][6];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < SITES_PER_GROUP) { tot[0][tid] = 0; tot[1][tid] = 0; tot_first[tid] = 0; }
+    if (tid < SITES_PER_GROUP) { tot[0][tid] = 0; tot[1][tid] = 0; }
     if (tid < 4) { sref[0][tid] = 0; sref[1][tid] = 0; sref[2][tid] = 0; sref[3][tid] = 0; }
     __syncthreads();
 
@@ -180,10 +179,6 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
         for (int j = 0; j < 8; j++) { kp[w][j] = 0; np[w][j] = 0; }
     unsigned since = 0;
     for (unsigned base = 0; base < n; base += 256) {
-        if (base == split_at && base) {                       // (block-uniform) the N counts so far: the first part of a split list
-            flush(np, 1);
-            if (!half) tot_first[site] = tot[1][site];
-        }
         const unsigned s = base + tid;
         bool listed_here = false;
         if (s < n) {
@@ -222,36 +217,28 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
         const bool minor = some && k >= 1 && budget > 0 && k * (c + k) <= (unsigned long long)budget;
         const bool dense = some && k >= 1 && !minor;
         const bool un = some && !dense && c >= 1;
-        const bool nnl = un && c >= 2 && c * ((c + 63) / 64) <= (unsigned long long)nn_list_max;     // 64 list entries per wave and load
+        // (a walk costs the lines of the list: pairsnp_kernels.h, n8 lines)
+        const bool nnl = un && c >= 2 && (float)c * n8_lines_expected((unsigned)c, n) <= (float)nn_list_max;
         const bool counted = un && c >= 2 && !nnl;          // (a site with one N sample has no pair of N samples)
         const bool full = some && !dense && c == 0;
         const bool lst = minor || nnl;
-        // (M_INL: minority sites with one or two listed samples -- the N samples' entries carry those samples inline)
-        const bool cls[8] = {dense, counted, minor, full, nnl, lst, un, minor && k <= 2};
-        constexpr int slot[8] = {M_DENSE, M_COUNT, M_MINOR, M_FULL, M_NNL, M_LST, M_UN, M_INL};
+        const bool cls[7] = {dense, counted, minor, full, nnl, lst, un};
+        constexpr int slot[7] = {M_DENSE, M_COUNT, M_MINOR, M_FULL, M_NNL, M_LST, M_UN};
 #pragma unroll
-        for (int m = 0; m < 8; m++) {
+        for (int m = 0; m < 7; m++) {
             const unsigned long long bal = __ballot(cls[m]);
             if (lane == 0) {
                 unsigned *pm = reinterpret_cast<unsigned *>(&masks[(size_t)slot[m] * groups + g]);
                 pm[2 * wave] = (unsigned)bal; pm[2 * wave + 1] = (unsigned)(bal >> 32);
             }
         }
-        const unsigned long long ca = some ? tot_first[tid] : 0ull;
         cntP[g * SITES_PER_GROUP + tid] = (unsigned)k;
         cntN[g * SITES_PER_GROUP + tid] = (unsigned)c;
-        cntA[g * SITES_PER_GROUP + tid] = (unsigned)ca;
-        // (sq: list entries the N co-occurrence walk visits at this site, cN per N sample; an NNL site has cN < 2^16)
-        // (an N list ends with at least one sentinel and is padded with more to a multiple of NN_LIST_PAD entries: 16-byte loads of
-        // whole lists that start on a cache-line boundary and need no length, general_sparse.hip; sq: list entries the N co-occurrence
-        // walk visits at this site, cN per N sample)
-        const unsigned cpad = nn_list_padded((unsigned)c, (unsigned)ca, split_at);
-        // (a split list: the rows of its first part walk all of it, the others the second part only)
-        const unsigned long long walked = nn_list_is_split((unsigned)c, split_at) ? ca * c + (c - ca) * (c - ca) : c * c;
-        // (the last: N samples at minority sites with one or two listed samples -- their entries of the per-sample streams carry the
-        // listed samples inline, general_sparse.hip)
-        unsigned sv[6] = {minor ? (unsigned)k : 0u, lst ? cpad : 0u, nnl ? (unsigned)walked : 0u, nnl ? (unsigned)c : 0u, minor ? (unsigned)c : 0u,
-                          (minor && k <= 2) ? (unsigned)c : 0u};
+        // per group: p-list entries; overflow lines the N lists of its listed sites can need at most (each has its primary line);
+        // list entries one pass of the N co-occurrence walk decodes (cN per walk, cN walks) and its walks; N-list walks of the
+        // minority fix-up (one per listed sample of a site with an N sample)
+        unsigned sv[6] = {minor ? (unsigned)k : 0u, lst ? n8_lines_max((unsigned)c, n) - 1u : 0u, nnl ? (unsigned)min(c * c, 33554431ull) : 0u, nnl ? (unsigned)c : 0u,
+                          (minor && c) ? (unsigned)k : 0u, 0u};
 #pragma unroll
         for (int m = 0; m < 6; m++) {
 #pragma unroll
@@ -272,8 +259,8 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
 
 // Exclusive prefix sums over the groups, one workgroup per array (1024 groups at a time):
 //   blocks 0..6  sizes of the mask slots M_DENSE .. M_UN (popcount of the mask) -> off32[b][g], totals[b]
-//   blocks 7..12 per-group sums: gP / gN (list sizes), gQ (entries the N co-occurrence walk visits), gR / gS / gI (N samples at the
-//                NNL / minority / inline-able minority sites) -> off64[b - 7][g], totals[b]
+//   blocks 7..12 per-group sums: gP (p-list entries), gN (overflow lines of the N lists, upper bound), gQ (entries the N co-occurrence
+//                walk decodes), gR (its walks), gS (N-list walks of the minority fix-up), gI (unused) -> off64[b - 7][g], totals[b]
 __global__ __launch_bounds__(1024) void group_offsets_kernel(const uint4 *__restrict__ masks, const unsigned *__restrict__ gcounts, size_t groups,
                                                              unsigned *__restrict__ off32, unsigned long long *__restrict__ off64,
                                                              unsigned long long *__restrict__ totals)
@@ -522,7 +509,7 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     int rc;
     if ((rc = workspace_get(52, M_SLOTS * groups * sizeof(uint4), reinterpret_cast<void **>(&masks)))) return rc;
     if ((rc = workspace_get(53, 7 * groups * sizeof(unsigned), reinterpret_cast<void **>(&offs)))) return rc;
-    if ((rc = workspace_get(54, 3 * groups * SITES_PER_GROUP * sizeof(unsigned), reinterpret_cast<void **>(&cnts)))) return rc;
+    if ((rc = workspace_get(54, 2 * groups * SITES_PER_GROUP * sizeof(unsigned), reinterpret_cast<void **>(&cnts)))) return rc;
     if ((rc = workspace_get(55, 6 * groups * sizeof(unsigned), reinterpret_cast<void **>(&gcnt)))) return rc;
     if ((rc = workspace_get(56, 6 * (groups + 1) * sizeof(unsigned long long), reinterpret_cast<void **>(&off64)))) return rc;
     if ((rc = workspace_get(57, 128, reinterpret_cast<void **>(&totals)))) return rc;
@@ -530,26 +517,20 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     d_flag = reinterpret_cast<unsigned *>(totals + 15);
     auto mask_of = [&](int slot) { return masks + (size_t)slot * groups; };
     auto off_of = [&](int slot) { return offs + (size_t)slot * groups; };
-    unsigned *cntP = cnts, *cntN = cnts + groups * SITES_PER_GROUP, *cntA = cnts + 2 * groups * SITES_PER_GROUP;
-    // lists of 64 and more N samples in two parts, by sample halves (pairsnp_kernels.h: nn_list_is_split); TRACS_NN_SPLIT=0: never
-    static const bool no_split = [] { const char *e = std::getenv("TRACS_NN_SPLIT"); return e && std::atoi(e) == 0; }();
-    const unsigned split_at = (no_split || a->n < 512) ? 0u : (unsigned)((a->n / 2 + 255) / 256 * 256);
+    unsigned *cntP = cnts, *cntN = cnts + groups * SITES_PER_GROUP;
     // a site goes to the minority lists while its k (cN + k) entries cost less than the extra operand planes over all pairs:
     // ~51 ns per site at 10 000 samples (pair kernel) against ~2-4 ps per list entry (general_fixup_kernel)
     const double bsites = (double)a->n * (double)a->n / 8000.0;
     const unsigned budget = (no_minor || !allow_minor) ? 0u : (unsigned)std::min(1.0e9, std::max(16.0, bsites));
-    // The N co-occurrences of a site with cN N samples cost cN list walks of ~ceil(cN / 64) cache lines each (nn_rows_kernel: bound
-    // by the lines it pulls through the fabric) against n^2 / 2 pairs on the matrix cores, whatever cN: lists while
-    // cN ceil(cN / 64) <= TRACS_NN_LIST_K x n^2.  Measured at 10 000 x 5 Mbp (profiles/r03/nn_list_threshold.txt): lists 29 / 41 /
-    // 53 / 92 ms at cN = 130 / 160 / 200 / 250 against 66-67 ms on the matrix cores -- crossover near cN = 220, K = 8.8e-6; at
-    // 2 000 samples every K up to 8e-6 is faster than the one before.  Default 6e-6, the rest being the lists' share of the
-    // once-per-pack work; TRACS_NN_LISTS=0: never
+    // The N co-occurrences of a site with cN N samples cost cN list walks of one cache line per ~115 samples of the list (n8 lines,
+    // pairsnp_kernels.h; nn_rows_kernel is bound by the lines it pulls through the fabric) against n^2 / 2 pairs on the matrix
+    // cores, whatever cN: lists while cN x lines <= TRACS_NN_LIST_K x n^2 (default 6e-6: DESIGN.md 3.1); TRACS_NN_LISTS=0: never
     static const bool no_nnl = [] { const char *e = std::getenv("TRACS_NN_LISTS"); return e && std::atoi(e) == 0; }();
     static const double nnl_k = [] { const char *e = std::getenv("TRACS_NN_LIST_K"); return e ? std::atof(e) : 6e-6; }();
     const unsigned nn_list_max = (no_nnl || !allow_nnl) ? 0u : (unsigned)std::min(4.0e9, nnl_k * (double)a->n * (double)a->n);
     TRACS_HIP_CHECK(hipMemsetAsync(totals, 0, 128, stream));
     hipLaunchKernelGGL(classify_sites_kernel, dim3((unsigned)groups), dim3(256), 0, stream, a->planes, a->n_pad, (unsigned)a->n, budget,
-                       nn_list_max, masks, groups, cntP, cntN, cntA, split_at, gcnt, gcnt + groups, gcnt + 2 * groups, gcnt + 3 * groups, gcnt + 4 * groups, gcnt + 5 * groups, flags, flag_words, d_flag);
+                       nn_list_max, masks, groups, cntP, cntN, gcnt, gcnt + groups, gcnt + 2 * groups, gcnt + 3 * groups, gcnt + 4 * groups, gcnt + 5 * groups, flags, flag_words, d_flag);
     const double plane_b = (double)groups * (double)a->n_pad * sizeof(uint4);      // one bit plane of the alignment
     stage_mark("classify", stream, 4.0 * plane_b, (double)groups * (M_SLOTS * 16.0 + 3.0 * SITES_PER_GROUP * 4.0 + flag_words * 8.0));
     hipLaunchKernelGGL(group_offsets_kernel, dim3(13), dim3(1024), 0, stream, masks, gcnt, groups, offs, off64, totals);
@@ -561,7 +542,7 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     const bool consensus = !*partial && !force_general;
     const size_t L_dense = (size_t)tot[M_DENSE], L_count = (size_t)tot[M_COUNT], L_minor = (size_t)tot[M_MINOR], L_full = (size_t)tot[M_FULL];
     const size_t L_nnl = (size_t)tot[M_NNL], L_lst = (size_t)tot[M_LST], L_un = (size_t)tot[M_UN];
-    const unsigned long long tot_p = tot[7], tot_n = tot[8], tot_nnl = tot[10], tot_minor_n = tot[11], tot_inl = tot[12];
+    const unsigned long long tot_p = tot[7], tot_o = tot[8], tot_nnl = tot[10];
     if (force == 0 || a->L == 0 || a->n < 2) return TRACS_OK;
     // matrix instructions per pair: planes_full per site now; planes_full per dense site + one per counted site with classes
     const double planes_full = consensus ? 4.0 : 5.0;
@@ -571,12 +552,14 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     // otherwise first without the N co-occurrence lists (those sites are counted on the matrix cores), then without any list
     // (the minority sites stay dense)
     if (L_lst) {
-        static const double env_cap = [] { const char *e = std::getenv("TRACS_LIST_CAP"); return e ? std::atof(e) : -1.0; }();
-        const double cap = (double)a->n * (double)a->L / 8.0;
-        // per-site lists (N lists padded) and per-sample streams
-        const double entries = (double)tot_n + (double)tot_nnl + (double)tot_minor_n + 2.0 * (double)tot_p;
-        if (L_lst >= (1ull << 27) || a->n >= (1ull << 27) || entries > (env_cap >= 0.0 ? std::min(env_cap, cap) : cap) ||
-            (L_nnl && tot_n / 8 >= (1ull << 32)))        // (the per-sample stream holds list starts in units of 8 entries, 32 bits)
+        // (TRACS_LIST_CAP=<entries of four bytes>: diagnostics)
+        static const double env_cap = [] { const char *e = std::getenv("TRACS_LIST_CAP"); return e ? 4.0 * std::atof(e) : -1.0; }();
+        const double cap = 0.8 * (double)NPLANES * (double)groups * (double)a->n_pad * sizeof(uint4);
+        // N-list lines (primary + the overflow lines they can need at most), p lists and their per-sample form, the rows' N bitmaps
+        const double bytes = ((double)L_lst + (double)tot_o) * 128.0 + 16.0 * (double)tot_p +
+                             (L_nnl ? (double)a->n * (double)((groups + 7) / 8 * 8) * sizeof(uint4) : 0.0);
+        if (L_lst >= (1ull << 27) || a->n >= (1ull << 27) || bytes > (env_cap >= 0.0 ? std::min(env_cap, cap) : cap) ||
+            L_lst + tot_o >= (1ull << 32))                  // (line indices are 32 bits)
             return L_nnl ? decide(a, allow_minor, false, stream, partial) : decide(a, false, false, stream, partial);
     }
 
@@ -617,28 +600,25 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
                            a->n_pad, (unsigned)a->n, (unsigned)gi);
     }
     // per sample: its N sites among the sites the compared-sites formula stands for: every site (in place), or every site
-    // outside the dense class (re-packed counting pass and / or lists: nn = |U| - c_i - c_j + NN over U)
+    // outside the dense class (re-packed counting pass and / or lists: nn = |U| - c_i - c_j + NN over U).  With N co-occurrence
+    // lists the kernel that writes the rows' N bitmaps counts on its way (site_lists.hip); a build without them counts here.
+    const bool counts_with_bitmaps = !in_place && L_nnl > 0;
     if (in_place)
         hipLaunchKernelGGL(plane_popcount_kernel, dim3((unsigned)((a->n + 255) / 256), 128), dim3(256), 0, stream, a->planes + 4 * a->n_pad,
                            a->n_pad, (unsigned)a->n, groups, NPLANES, a->c_counted);
-    else if (L_un)
+    else if (L_un && !counts_with_bitmaps)
         hipLaunchKernelGGL(plane_popcount_masked_kernel, dim3((unsigned)((a->n + 255) / 256), 128), dim3(256), 0, stream,
                            a->planes + 4 * a->n_pad, mask_of(M_UN), a->n_pad, (unsigned)a->n, groups, a->c_counted);
-    stage_mark(gi ? "re-pack counted sites" : "N counts per sample", stream, plane_b, (double)ibytes);
+    if (gi) stage_mark("re-pack counted sites", stream, plane_b, (double)ibytes);
+    else if (in_place || (L_un && !counts_with_bitmaps)) stage_mark("N counts per sample", stream, plane_b, 0.0);
     if (L_lst) {
-        // the lists (general_sparse.hip): per-site lists from the N plane and the flagged samples, per-sample lists from the N plane
+        // the lists (site_lists.hip): per-site lists from the N plane and the flagged samples, the rows' N bitmaps from the N plane
         int built = 0;
         MinorBuild mb;
         mb.planes = a->planes; mb.minor_mask = mask_of(M_MINOR); mb.nnl_mask = mask_of(M_NNL); mb.lst_mask = mask_of(M_LST);
-        mb.ref_x = mask_of(M_REFX); mb.ref_y = mask_of(M_REFY); mb.inl_mask = mask_of(M_INL); mb.off_lst = off_of(M_LST);
-        mb.cntA = cntA; mb.split_at = split_at;
-        mb.cntP = cntP; mb.cntN = cntN; mb.baseP = off64; mb.baseN = off64 + groups; mb.flags = flags; mb.flag_words = flag_words;
-        mb.sites = L_lst; mb.tot_p = tot_p; mb.tot_n = tot_n; mb.tot_nnl = tot_nnl; mb.tot_minor_n = tot_minor_n;
-        // a consensus alignment's listed samples all differ from the reference base (w = 1): an N entry at a site with one or two
-        // of them can carry them in its 32 bits (16-bit sample numbers) instead of pointing at the site's list
-        static const bool no_inline = [] { const char *e = std::getenv("TRACS_LIST_INLINE"); return e && std::atoi(e) == 0; }();
-        mb.inline_ok = consensus && a->n < 65535 && !no_inline;
-        mb.tot_inl = mb.inline_ok ? tot_inl : 0;
+        mb.ref_x = mask_of(M_REFX); mb.ref_y = mask_of(M_REFY); mb.un_mask = mask_of(M_UN); mb.off_lst = off_of(M_LST);
+        mb.cntP = cntP; mb.cntN = cntN; mb.baseP = off64; mb.baseO = off64 + groups; mb.flags = flags; mb.flag_words = flag_words;
+        mb.sites = L_lst; mb.tot_p = tot_p; mb.tot_o = tot_o; mb.tot_nnl = tot_nnl;
         mb.n_rows = a->n_row_hint;
         for (int k = 0; k < 4; k++) mb.rows[k] = (unsigned)std::min<size_t>(a->row_hint[k], a->n);
         rc = minority_lists_build(a, mb, stream, &built);
@@ -652,7 +632,7 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     if (!ok) { site_classes_free(a); a->classes_state = -1; set_error("site_classes_decide: re-pack failed"); return TRACS_E_HIP; }
     a->L_var = L_dense; a->L_inv = L_count; a->groups_var = gv; a->groups_inv = gi;
     a->L_minor = L_minor; a->L_full = L_full; a->L_un = L_un; a->L_nnl = L_nnl;
-    a->nn_visits = tot[9]; a->list_entries_n = tot_n; a->list_entries_p = tot_p; a->nn_walks = tot_nnl;
+    a->nn_visits = tot[9]; a->list_entries_n = (L_lst ? (unsigned long long)L_lst + tot_o : 0ull); a->list_entries_p = tot_p; a->nn_walks = tot_nnl; a->fix_walks = tot[11];
     a->count_in_place = in_place;
     a->classes_cons = consensus;
     a->classes_state = 1;

@@ -1,0 +1,813 @@
+// site_lists.hip -- the lists of an alignment cut into site classes (site_classes.hip), and the two kernels that walk them.
+//
+// Reference behaviour restated (never copied): /root/reference/src/pairsnp.hpp:395-420 -- every site is visited for every pair.
+// Here a site at which only a few samples differ from the others (MINORITY) or are N (NNL) contributes through lists:
+//
+//   per site     N LIST ("n8" lines, pairsnp_kernels.h): its N samples in sample order, byte deltas, 124 per 128-byte line -- the site
+//                of rank r (among the sites with lists) owns line r; a list that needs more goes on in overflow lines of its group;
+//                P LIST: its listed samples (sample << 5 | w << 4 | allele mask), minority sites only;
+//   per sample   its LISTED entries (rank << 5 | w << 4 | mask) -- few: a sample differs from the others at a few hundred sites;
+//                its N BITMAP over the NNL sites, sample-major (T: 16 bytes per 128-site group, the transposed N plane): what
+//                nn_rows_kernel reads instead of a stream of list addresses.
+//
+// Built from the N plane alone (+ the five planes of the flagged samples, ~1 %): site_lists_kernel reads it once, group by group
+// (lists sorted in LDS, encoded by the site's own thread), n_bitmap_kernel once more, sample by sample (+ each sample's N count).
+//
+// The walks.  nn_rows_kernel: row i of the pair matrix in LDS; every N site of sample i (a set bit of its bitmap) is a work item --
+// the site's line, decoded by eight lanes: NN(i, j) += 1 for every listed j > i.  minor_fixup_kernel: row x; every listed entry
+// of sample x walks its site's P list (both listed: [masks disjoint] - w_x - w_j, for j > x) and, when w_x = 1, the site's N LIST:
+// -w_x for EVERY N sample y -- y > x lands in row x of dist, y < x in cell (y, x): a scratch row that transpose_add_kernel folds into
+// the rows above.  So an N sample never looks at the p list of a site: the walks go from the few listed samples to the many N
+// samples (k walks of a cN-entry list, not cN walks of a k-entry list), and the per-sample streams of N entries that rounds 2-3
+// built (s_nn, s_inl: 3.3 GB written once per pack from two more reads of the N plane) do not exist.
+#include "pairsnp_kernels.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+namespace tracs {
+
+struct SiteLists {
+    uint4 *lines = nullptr;                    // n8 lines: [0, sites) primary, then each group's overflow block
+    unsigned long long n_lines = 0;
+    unsigned long long *p_off = nullptr;       // [sites + 1]
+    unsigned *p_ent = nullptr;
+    unsigned long long *s_off = nullptr;       // [n + 1]
+    unsigned *s_ent = nullptr;
+    unsigned *c_p = nullptr;                   // per sample: sum of w over its listed entries
+    uint4 *T = nullptr;                        // N bitmaps of the rows over the NNL sites: T[s * tgroups + g]
+    size_t tgroups = 0;
+    uint4 *lst_mask = nullptr;                 // per group: sites with lists (copies: the classification's own live in shared scratch)
+    unsigned *off_lst = nullptr;               // per group: rank of its first site with lists
+    size_t sites = 0, groups = 0;
+    unsigned long long tot_p = 0, tot_nnl = 0;
+    unsigned max_row = 0;                      // the most N sites (outside the dense class) any sample has: row splits of nn_rows_kernel
+    unsigned rows[4] = {0, 0, 0, 0};           // T holds the rows of these ranges only (n_rows of them; 0: all)
+    int n_rows = 0;
+};
+constexpr int ENT_SHIFT = 5;                   // entries: index << 5 | w << 4 | 4-bit allele mask
+
+__device__ __forceinline__ unsigned word_of(const uint4 &v, int w) { return w == 0 ? v.x : w == 1 ? v.y : w == 2 ? v.z : v.w; }
+
+__device__ __forceinline__ unsigned lst_rank(const uint4 &m, unsigned off_g, int w, int b)
+{
+    unsigned r = off_g;
+    if (w > 0) r += __popc(m.x);
+    if (w > 1) r += __popc(m.y);
+    if (w > 2) r += __popc(m.z);
+    return r + __popc(word_of(m, w) & ((1u << b) - 1u));
+}
+
+__device__ __forceinline__ bool row_wanted(const MinorBuild &mb, size_t s)
+{
+    if (mb.n_rows == 0) return true;
+    return (s >= mb.rows[0] && s < mb.rows[1]) || (mb.n_rows > 1 && s >= mb.rows[2] && s < mb.rows[3]);
+}
+
+// ---- per site: N lists (n8 lines) and p lists ---------------------------------------------------------------------------------
+// One workgroup per 128-site group, threads over samples (coalesced 16-byte loads of the N plane).  The group's N samples are
+// dropped into per-site runs of an LDS staging area (u16, relative to the piece's first sample) through LDS cursors; then the
+// site's own thread sorts its run (it is sorted but for the order inside a 256-sample slab), encodes it and writes its line(s) 16
+// bytes at a time.  A group whose entries do not fit the staging area (many N samples per site: 16 384 entries), or an alignment
+// beyond 65 536 samples, is taken in PIECES of consecutive samples -- whole 128-sample slabs while their entries fit --, the encoder
+// state (last position, the line's fill, the pending 16 bytes) carried in the site thread's registers from piece to piece.
+constexpr unsigned STAGE_ENTRIES = 16384;      // (a 128-sample slab of a 128-site group holds at most this many)
+
+struct N8Encoder {
+    uint4 *lines;
+    unsigned line, next_ovf, fill, prev;
+    unsigned a0, a1, a2, a3;                   // the pending bytes, shifted in from the top
+    __device__ __forceinline__ void put(unsigned b)
+    {
+        if (fill == N8_PAYLOAD) {              // the line is full and more follows: its last piece leaves with the next line's index
+            lines[(size_t)line * 8 + 7] = make_uint4(a1, a2, a3, next_ovf);
+            line = next_ovf++;
+            fill = 0;
+        }
+        a0 = __builtin_amdgcn_alignbit(a1, a0, 8); a1 = __builtin_amdgcn_alignbit(a2, a1, 8); a2 = __builtin_amdgcn_alignbit(a3, a2, 8);
+        a3 = (a3 >> 8) | (b << 24);
+        fill++;
+        if ((fill & 15u) == 0u) lines[(size_t)line * 8 + (fill >> 4) - 1u] = make_uint4(a0, a1, a2, a3);
+    }
+    __device__ __forceinline__ void sample(unsigned s)
+    {
+        unsigned gap = s - prev;               // (prev = 0xFFFFFFFF before the first: s + 1)
+        while (gap >= N8_SKIP) { put(N8_SKIP); gap -= N8_SKIP; }
+        put(gap);
+        prev = s;
+    }
+    __device__ __forceinline__ void finish()
+    {
+        const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        while ((fill & 15u) != 0u && fill < N8_PAYLOAD) put(0xFFu);            // the piece under way
+        if (fill == N8_PAYLOAD) { lines[(size_t)line * 8 + 7] = make_uint4(a1, a2, a3, N8_NONE); return; }
+        for (unsigned q = fill >> 4; q < 8u; q++) lines[(size_t)line * 8 + q] = ones;     // (the last: padding + N8_NONE)
+    }
+};
+
+__global__ __launch_bounds__(256) void site_lists_kernel(const MinorBuild mb, size_t n_pad, unsigned n,
+                                                         unsigned long long *__restrict__ p_off, unsigned *__restrict__ p_ent,
+                                                         uint2 *__restrict__ E, uint4 *__restrict__ lines)
+{
+    __shared__ unsigned short stage[STAGE_ENTRIES];
+    __shared__ unsigned cn[SITES_PER_GROUP], kp[SITES_PER_GROUP], ovf[SITES_PER_GROUP], lN[SITES_PER_GROUP], cur[SITES_PER_GROUP];
+    __shared__ unsigned curP[SITES_PER_GROUP], rk[SITES_PER_GROUP];
+    __shared__ unsigned long long bP[SITES_PER_GROUP];
+    __shared__ unsigned red[4], piece_total;
+    const size_t g = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (g == 0 && tid == 0) p_off[mb.sites] = mb.tot_p;
+    const uint4 m4 = mb.lst_mask[g], q4 = mb.minor_mask[g];
+    if ((m4.x | m4.y | m4.z | m4.w) == 0u) return;
+    const unsigned m[4] = {m4.x, m4.y, m4.z, m4.w};          // sites with lists
+    const unsigned mp[4] = {q4.x, q4.y, q4.z, q4.w};         // minority sites among them (p lists)
+    const bool any_minor = (q4.x | q4.y | q4.z | q4.w) != 0u;
+    const int tw = (tid & 127) >> 5, tb = tid & 31;
+    const bool mine = tid < SITES_PER_GROUP && ((m[tw] >> tb) & 1u);
+    if (tid < SITES_PER_GROUP) {
+        const unsigned c = mine ? mb.cntN[g * SITES_PER_GROUP + tid] : 0u;
+        cn[tid] = c;
+        kp[tid] = (mine && ((mp[tw] >> tb) & 1u)) ? mb.cntP[g * SITES_PER_GROUP + tid] : 0u;
+        ovf[tid] = mine ? n8_lines_max(c, n) - 1u : 0u;
+        cur[tid] = 0; curP[tid] = 0;
+    }
+    __syncthreads();
+    N8Encoder enc{lines, 0u, 0u, 0u, 0xFFFFFFFFu, 0u, 0u, 0u, 0u};
+    unsigned total = 0;
+    if (tid < SITES_PER_GROUP) {
+        unsigned long long pp = 0;
+        unsigned po = 0, pn = 0;
+        for (int t = 0; t < tid; t++) { pp += kp[t]; po += ovf[t]; pn += cn[t]; }
+        if (mine) {
+            const unsigned rank = lst_rank(m4, mb.off_lst[g], tw, tb);
+            bP[tid] = mb.baseP[g] + pp; rk[tid] = rank;
+            p_off[rank] = bP[tid];
+            enc.line = rank;
+            enc.next_ovf = (unsigned)(mb.sites + mb.baseO[g] + po);
+        }
+        lN[tid] = pn;                                         // (one piece: the runs are as long as the lists)
+        if (tid == SITES_PER_GROUP - 1) piece_total = pn + cn[tid];
+    }
+    __syncthreads();
+    total = piece_total;
+    const bool one_piece = total <= STAGE_ENTRIES && n <= 65536u;      // (block-uniform)
+    const uint4 RX = mb.ref_x[g], RY = mb.ref_y[g];
+    const uint4 *base = mb.planes + (g * NPLANES) * n_pad;
+    unsigned s_begin = 0;
+    while (s_begin < n) {                                     // pieces (block-uniform control flow)
+        unsigned s_end = n;
+        if (!one_piece) {
+            // whole 128-sample slabs while their entries fit the staging area (and 16-bit offsets): counted per site on the way
+            __syncthreads();
+            if (tid < SITES_PER_GROUP) cur[tid] = 0;
+            __syncthreads();
+            unsigned acc = 0;
+            s_end = s_begin;
+            while (s_end < n && s_end - s_begin < 65536u - 128u) {
+                const unsigned s = s_end + tid;
+                uint4 N = make_uint4(0u, 0u, 0u, 0u);
+                if (tid < 128 && s < n) N = base[4 * n_pad + s];
+                unsigned c = __popc(N.x & m[0]) + __popc(N.y & m[1]) + __popc(N.z & m[2]) + __popc(N.w & m[3]);
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+                if (lane == 0) red[wave] = c;
+                __syncthreads();
+                const unsigned slab = red[0] + red[1];        // (threads 128.. hold no sample)
+                __syncthreads();
+                if (acc + slab > STAGE_ENTRIES) break;        // (a single slab always fits)
+                acc += slab;
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    unsigned nm = word_of(N, w) & m[w];
+                    while (nm) { const int b = __ffs(nm) - 1; nm &= nm - 1; atomicAdd(&cur[w * 32 + b], 1u); }
+                }
+                s_end += 128u;
+            }
+            s_end = min(s_end, n);
+            __syncthreads();
+            if (tid < SITES_PER_GROUP) {
+                unsigned pn = 0;
+                for (int t = 0; t < tid; t++) pn += cur[t];
+                lN[tid] = pn;
+            }
+            __syncthreads();
+            if (tid < SITES_PER_GROUP) cur[tid] = 0;
+            __syncthreads();
+        }
+        // ---- fill: the piece's N samples into their sites' runs; the listed samples (each sample is seen in exactly one piece)
+        for (unsigned s = s_begin + tid; s < s_end; s += 256) {
+            const uint4 N = base[4 * n_pad + s];
+            const unsigned rel = s - s_begin;
+            unsigned nm0 = N.x & m[0], nm1 = N.y & m[1], nm2 = N.z & m[2], nm3 = N.w & m[3];
+            // (one bit of each 32-site word per round: four independent cursor round trips in flight)
+            while (nm0 | nm1 | nm2 | nm3) {
+                if (nm0) { const int b = __ffs(nm0) - 1; nm0 &= nm0 - 1; stage[lN[b] + atomicAdd(&cur[b], 1u)] = (unsigned short)rel; }
+                if (nm1) { const int b = __ffs(nm1) + 31; nm1 &= nm1 - 1; stage[lN[b] + atomicAdd(&cur[b], 1u)] = (unsigned short)rel; }
+                if (nm2) { const int b = __ffs(nm2) + 63; nm2 &= nm2 - 1; stage[lN[b] + atomicAdd(&cur[b], 1u)] = (unsigned short)rel; }
+                if (nm3) { const int b = __ffs(nm3) + 95; nm3 &= nm3 - 1; stage[lN[b] + atomicAdd(&cur[b], 1u)] = (unsigned short)rel; }
+            }
+            const bool flagged = any_minor && ((mb.flags[g * mb.flag_words + (s >> 6)] >> (s & 63u)) & 1ull);
+            if (!flagged) continue;
+            const uint4 A = base[s], C = base[n_pad + s], G = base[2 * n_pad + s], T = base[3 * n_pad + s];
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const unsigned a = word_of(A, w), c = word_of(C, w), gg = word_of(G, w), t = word_of(T, w), isn = word_of(N, w);
+                const unsigned rx = word_of(RX, w), ry = word_of(RY, w);
+                const unsigned ra = ~rx & ~ry, rc = rx & ~ry, rg = ~rx & ry, rt = rx & ry;
+                const unsigned has_ref = (a & ra) | (c & rc) | (gg & rg) | (t & rt);
+                const unsigned only_ref = ~((a ^ ra) | (c ^ rc) | (gg ^ rg) | (t ^ rt));
+                unsigned pm = ~isn & ~only_ref & mp[w];
+                while (pm) {
+                    const int b = __ffs(pm) - 1;
+                    pm &= pm - 1;
+                    const unsigned mask = ((a >> b) & 1u) | (((c >> b) & 1u) << 1) | (((gg >> b) & 1u) << 2) | (((t >> b) & 1u) << 3);
+                    const unsigned code = (((has_ref >> b) & 1u) ? 0u : 16u) | mask;
+                    const unsigned slot = atomicAdd(&curP[w * 32 + b], 1u);
+                    const unsigned long long pos = bP[w * 32 + b] + slot;
+                    p_ent[pos] = (s << ENT_SHIFT) | code;
+                    E[pos] = make_uint2(s, (rk[w * 32 + b] << ENT_SHIFT) | code);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- the site's thread: sort its run (disorder only inside a 256-sample slab), encode it
+        if (mine) {
+            unsigned short *st = stage + lN[tid];
+            const unsigned c = cur[tid];
+            for (unsigned k = 1; k < c; k++) {
+                const unsigned short v = st[k];
+                unsigned j = k;
+                while (j > 0 && st[j - 1] > v) { st[j] = st[j - 1]; j--; }
+                st[j] = v;
+            }
+            for (unsigned k = 0; k < c; k++) enc.sample(s_begin + st[k]);
+        }
+        s_begin = s_end;
+        if (one_piece) break;
+    }
+    if (mine) enc.finish();
+}
+
+// ---- per sample: listed entries (from E) ---------------------------------------------------------------------------------------
+// FILL = false: cnt[s]++ and c_p[s] += w;  FILL = true: entries placed through per-sample cursors.
+template <bool FILL>
+__global__ __launch_bounds__(256) void listed_entries_kernel(const uint2 *__restrict__ E, unsigned long long count, unsigned *__restrict__ cnt,
+                                                             unsigned *__restrict__ c_p, const unsigned long long *__restrict__ off,
+                                                             unsigned *__restrict__ cur, unsigned *__restrict__ ent)
+{
+    const unsigned long long k = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= count) return;
+    const uint2 e = E[k];
+    if (!FILL) {
+        atomicAdd(&cnt[e.x], 1u);
+        if (e.y & 16u) atomicAdd(&c_p[e.x], 1u);
+    } else {
+        ent[off[e.x] + atomicAdd(&cur[e.x], 1u)] = e.y;
+    }
+}
+
+// exclusive scan of v[0 .. count) -> out[0 .. count] (one workgroup; wave scans through shuffles); the largest element -> *vmax
+__global__ __launch_bounds__(1024) void scan_counts_kernel(const unsigned *__restrict__ v, size_t count, unsigned long long *__restrict__ out)
+{
+    __shared__ unsigned long long wave_tot[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int RUN = 8;
+    unsigned long long carry = 0;                            // (the same on every thread)
+    for (size_t base = 0; base <= count; base += 1024 * RUN) {
+        const size_t b0 = base + (size_t)threadIdx.x * RUN;
+        unsigned long long local[RUN], sum = 0;
+#pragma unroll
+        for (int k = 0; k < RUN; k++) { local[k] = sum; sum += (b0 + k < count) ? v[b0 + k] : 0u; }
+        unsigned long long incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        unsigned long long before = carry, all = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) { const unsigned long long t = wave_tot[w]; if (w < wave) before += t; all += t; }
+        const unsigned long long excl = before + incl - sum;
+#pragma unroll
+        for (int k = 0; k < RUN; k++) if (b0 + k <= count) out[b0 + k] = excl + local[k];
+        carry += all;
+        __syncthreads();
+    }
+}
+
+// ---- per sample: its N bitmap over the NNL sites (the N plane transposed), and its N count ---------------------------------------
+// thread = sample, eight consecutive groups at a time: eight coalesced 16-byte loads (one per group), one 128-byte run of the
+// sample's row of T.  c_counted[s] += its N sites among the sites of un_mask (what the compared-sites formula needs).
+__global__ __launch_bounds__(256) void n_bitmap_kernel(const MinorBuild mb, size_t n_pad, unsigned n, size_t groups, size_t tgroups,
+                                                       size_t oct_per_chunk, uint4 *__restrict__ T, unsigned *__restrict__ c_counted,
+                                                       unsigned *__restrict__ max_row)
+{
+    const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t o0 = (size_t)blockIdx.y * oct_per_chunk, o1 = min(tgroups / 8, o0 + oct_per_chunk);
+    const bool live = s < n;
+    const bool row = live && T != nullptr && row_wanted(mb, s);
+    const uint4 *np = mb.planes + 4 * n_pad + min(s, n_pad - 1);
+    unsigned cnt = 0;
+    for (size_t o = o0; o < o1; o++) {
+        uint4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const size_t g = o * 8 + k;                       // (wave-uniform)
+            v[k] = (g < groups && live) ? np[g * NPLANES * n_pad] : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const size_t g = min(o * 8 + k, groups - 1);
+            const uint4 um = mb.un_mask[g], lm = mb.nnl_mask[g];
+            cnt += __popc(v[k].x & um.x) + __popc(v[k].y & um.y) + __popc(v[k].z & um.z) + __popc(v[k].w & um.w);
+            v[k].x &= lm.x; v[k].y &= lm.y; v[k].z &= lm.z; v[k].w &= lm.w;
+        }
+        if (row) {
+            uint4 *dst = T + s * tgroups + o * 8;
+#pragma unroll
+            for (int k = 0; k < 8; k++) dst[k] = v[k];
+        }
+    }
+    if (live && cnt) {
+        const unsigned before = atomicAdd(&c_counted[s], cnt);
+        if (gridDim.y == 1) atomicMax(max_row, before + cnt);
+    }
+}
+
+__global__ void max_count_kernel(const unsigned *__restrict__ c, size_t n, unsigned *__restrict__ out)
+{
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n) atomicMax(out, c[s]);
+}
+
+// ---- the walk of n8 lines ---------------------------------------------------------------------------------------------------------
+// A wave keeps a ring of work items (line, position before the line's first byte) in LDS.  A round takes up to 32 of them: lane
+// group grp = lane >> 3 (eight lanes) decodes one line per flight, 16 bytes per lane -- byte sums per lane, an exclusive prefix over
+// the group's eight lanes (DPP), one add per byte -- and adds `val` to the LDS counter of every sample it decodes: column j goes
+// to row[j - lo], and whatever is no cell of the row (j < lo, another column chunk, skips and padding) to the lane's own slot
+// behind the row.  A line that goes on (its `next`) becomes a new item.
+constexpr int WALK_FLIGHT = 4;                 // lines per lane group and round
+constexpr unsigned WALK_RING = 128;            // items: < 32 left over + 64 pushed + 32 continuations
+
+struct Walk {
+    const uint4 *lines;
+    uint2 *ring;                               // this wave's ring (LDS)
+    unsigned head, count;                      // (wave-uniform)
+    unsigned lane, grp, l8;
+    unsigned neg4lo, dump4, val;               // row[] starts at LDS byte 0: counter of column j at 4 (j - lo); the lane's dump slot
+    bool ge1, ge2, ge4;
+
+    __device__ __forceinline__ void push(bool has, unsigned line, unsigned base)
+    {
+        const unsigned long long m = __ballot(has);
+        const unsigned pos = (head + count + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))) & (WALK_RING - 1u);
+        if (has) ring[pos] = make_uint2(line, base);
+        count += (unsigned)__popcll(m);
+    }
+    // the bytes of one lane: positions, validity, adds.  w3 of the group's last lane is the line's `next`, not payload.
+    __device__ __forceinline__ unsigned apply(const uint4 &d, unsigned p0)
+    {
+        const unsigned w0 = d.x, w1 = d.y, w2 = d.z;
+        const unsigned w3 = l8 == 7u ? 0xFFFFFFFFu : d.w, w3s = l8 == 7u ? 0u : d.w;
+        const unsigned S = __builtin_amdgcn_sad_u8(w0, 0u, __builtin_amdgcn_sad_u8(w1, 0u, __builtin_amdgcn_sad_u8(w2, 0u, __builtin_amdgcn_sad_u8(w3s, 0u, 0u))));
+        unsigned x = S, t;
+        t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true); x += ge1 ? t : 0u;      // row_shr:1
+        t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true); x += ge2 ? t : 0u;      // row_shr:2
+        t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true); x += ge4 ? t : 0u;      // row_shr:4
+        unsigned p = p0 + x - S;
+        const unsigned w[4] = {w0, w1, w2, w3};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const unsigned b = (w[k] >> (8 * q)) & 0xFFu;
+                p += b;
+                unsigned a = min((p << 2) + neg4lo, dump4);
+                a = b < N8_SKIP ? a : dump4;
+                asm volatile("ds_add_u32 %0, %1" : : "v"(a), "v"(val) : "memory");
+            }
+        }
+        return p0 + x;                          // on the group's last lane: the position behind the line's payload
+    }
+    __device__ __forceinline__ void round()
+    {
+        const unsigned k = min(count, (unsigned)(8 * WALK_FLIGHT));
+        uint2 it[WALK_FLIGHT];
+        uint4 d[WALK_FLIGHT];
+        bool has[WALK_FLIGHT];
+#pragma unroll
+        for (int u = 0; u < WALK_FLIGHT; u++) {
+            const unsigned idx = u * 8 + grp;
+            has[u] = idx < k;
+            it[u] = ring[(head + idx) & (WALK_RING - 1u)];
+        }
+#pragma unroll
+        for (int u = 0; u < WALK_FLIGHT; u++) d[u] = lines[(size_t)(has[u] ? it[u].x : 0u) * 8 + l8];
+        head = (head + k) & (WALK_RING - 1u);
+        count -= k;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+        for (int u = 0; u < WALK_FLIGHT; u++) {
+            const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+            const uint4 dd = has[u] ? d[u] : ones;
+            const unsigned p_end = apply(dd, it[u].y);
+            push(l8 == 7u && dd.w != N8_NONE, dd.w, p_end);
+        }
+    }
+    __device__ __forceinline__ void drain_to(unsigned keep)
+    {
+        while (count > keep) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            round();
+        }
+    }
+};
+
+// ---- N co-occurrences from lists (the NNL sites) ----------------------------------------------------------------------------------
+// Row i of the pair matrix: NN(i, j) = number of NNL sites at which both i and j are N.  The row's counters live in LDS; a wave
+// takes 64 groups of sample i's bitmap at a time (16 bytes per lane), every set bit is a site whose line goes into the wave's ring
+// (one bit per lane and step: the ring's slots come from a ballot), and the ring is walked 32 lines at a time.  Work = sum over the
+// NNL sites of cN walks of the site's line(s), whatever the number of samples -- against n^2 / 2 pairs per site on the matrix cores.
+// A sample with many N sites would leave most of the chip idle behind a few rows: a row's groups are cut over up to NN_MAX_SPLITS
+// workgroups (grid.z; a row with few N sites uses one and the others exit at once), which then add their rows with atomics.
+constexpr unsigned NN_MAX_SPLITS = 32;
+#ifndef TRACS_NN_THREADS
+#define TRACS_NN_THREADS 1024
+#endif
+__global__ __launch_bounds__(TRACS_NN_THREADS) void nn_rows_kernel(const uint4 *__restrict__ T, size_t tgroups, const uint4 *__restrict__ lst_mask,
+                                                                   const unsigned *__restrict__ off_lst, size_t groups, const uint4 *__restrict__ lines,
+                                                                   const unsigned *__restrict__ c_u, unsigned n, unsigned row_begin, unsigned col_begin,
+                                                                   unsigned chunk, unsigned target, unsigned *__restrict__ ncomp, size_t ld,
+                                                                   int add_terms, unsigned lu)
+{
+    // `chunk` counters -- row[0] is column `lo`, the first cell of the row in this chunk --, 64 slots nobody reads, the waves' rings
+    extern __shared__ unsigned row[];
+    const unsigned i = row_begin + blockIdx.x;
+    const unsigned c0 = blockIdx.y * chunk, c1 = min(n, c0 + chunk);
+    if (c1 <= i + 1 || c1 <= col_begin) return;            // no cell (i, j > i) in this column chunk
+    const unsigned ci = c_u[i];
+    const unsigned nz = min(NN_MAX_SPLITS, max(1u, (ci + target - 1u) / target));
+    if (blockIdx.z >= nz) return;
+    const unsigned lo = max(max(i + 1, col_begin), c0);     // columns [lo, c1) of this chunk are cells of row i
+    const unsigned span = c1 - lo;
+    if ((unsigned)(size_t)row != 0u) __builtin_trap();      // (the walk's LDS adds address row[] from 0)
+    for (unsigned j = threadIdx.x; j < span + 64u; j += blockDim.x) row[j] = 0;
+    __syncthreads();
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    Walk W;
+    W.lines = lines;
+    W.ring = reinterpret_cast<uint2 *>(row + chunk + 64) + wave * WALK_RING;
+    W.head = 0; W.count = 0;
+    W.lane = lane; W.grp = lane >> 3; W.l8 = lane & 7u;
+    W.neg4lo = 0u - 4u * lo; W.dump4 = 4u * (span + lane); W.val = 1u;
+    W.ge1 = W.l8 >= 1u; W.ge2 = W.l8 >= 2u; W.ge4 = W.l8 >= 4u;
+    const size_t batches = (tgroups + 63) / 64;
+    const size_t per = (batches + nz - 1) / nz;
+    const size_t b_first = (size_t)blockIdx.z * per, b_last = min(batches, b_first + per);
+    const uint4 *Trow = T + (size_t)i * tgroups;
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    size_t b = b_first + wave;
+    uint4 tw_next = (b < b_last && b * 64 + lane < tgroups) ? Trow[b * 64 + lane] : zero4;
+    for (; b < b_last; b += nwaves) {
+        const size_t g = b * 64 + lane;
+        const uint4 tw = tw_next;
+        const size_t bn = b + nwaves;
+        tw_next = (bn < b_last && bn * 64 + lane < tgroups) ? Trow[bn * 64 + lane] : zero4;     // the next batch's bitmap: in flight during this one
+        unsigned r0 = tw.x, r1 = tw.y, r2 = tw.z, r3 = tw.w;
+        if (!__ballot((r0 | r1 | r2 | r3) != 0u)) continue;
+        const size_t gm = min(g, groups - 1);
+        const uint4 lm = lst_mask[gm];
+        const unsigned og = off_lst[gm];
+        const unsigned pre1 = og + __popc(lm.x), pre2 = pre1 + __popc(lm.y), pre3 = pre2 + __popc(lm.z);
+        for (;;) {
+            W.drain_to(8 * WALK_FLIGHT - 1);                 // room for 64 more
+            const bool has = (r0 | r1 | r2 | r3) != 0u;
+            if (!__ballot(has)) break;
+            unsigned rank = 0;
+            if (r0) { const unsigned bit = __ffs(r0) - 1; r0 &= r0 - 1; rank = og + __popc(lm.x & ((1u << bit) - 1u)); }
+            else if (r1) { const unsigned bit = __ffs(r1) - 1; r1 &= r1 - 1; rank = pre1 + __popc(lm.y & ((1u << bit) - 1u)); }
+            else if (r2) { const unsigned bit = __ffs(r2) - 1; r2 &= r2 - 1; rank = pre2 + __popc(lm.z & ((1u << bit) - 1u)); }
+            else if (r3) { const unsigned bit = __ffs(r3) - 1; r3 &= r3 - 1; rank = pre3 + __popc(lm.w & ((1u << bit) - 1u)); }
+            W.push(has, rank, 0xFFFFFFFFu);
+        }
+    }
+    W.drain_to(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");   // (the adds issued from inline assembly are not in the compiler's count)
+    __syncthreads();
+    const bool terms = add_terms && blockIdx.z == 0;
+    for (unsigned j = lo + threadIdx.x; j < c1; j += blockDim.x) {
+        const unsigned v = row[j - lo] + (terms ? lu - ci - c_u[j] : 0u);
+        if (v) {
+            if (nz > 1) atomicAdd(&ncomp[(size_t)i * ld + j], v);
+            else ncomp[(size_t)i * ld + j] += v;
+        }
+    }
+}
+
+// ---- the minority sites' distances --------------------------------------------------------------------------------------------------
+// At a minority site every sample is N, or carries exactly the site's reference base (not listed), or is LISTED with its allele
+// mask M and w = [reference base not in M].  Such a site adds to d(i, j): w_i when i is listed and j carries the reference base,
+// [M_i n M_j = {}] when both are listed, 0 when either is N -- i.e. over the sites S_i, S_j at which i / j is listed
+//     d += sum_{S_i} w_i + sum_{S_j} w_j - sum_{s in S_i: j is N} w_i - sum_{s in S_j: i is N} w_j
+//          + sum over S_i n S_j of ([M_i n M_j = {}] - w_i - w_j)
+// (consensus alignments: M = {own base}, w = 1).  The first two sums are per-sample constants (c_p).  Row x (one workgroup):
+//     phase A  x in the call's rows: every listed entry of x walks its site's p list: the last sum, for j > x;
+//     phase B  every listed entry of x with w = 1 walks its site's N list: -1 for EVERY N sample y there -- the third sum for y > x
+//              (row x of dist), the fourth for y < x (cell (y, x): a scratch row, folded in by transpose_add_kernel).
+// Negative terms wrap in the unsigned row and cancel in the final sum.
+__global__ __launch_bounds__(1024) void minor_fixup_kernel(const unsigned long long *__restrict__ s_off, const unsigned *__restrict__ s_ent,
+                                                           const unsigned long long *__restrict__ p_off, const unsigned *__restrict__ p_ent,
+                                                           const uint4 *__restrict__ lines, const unsigned *__restrict__ c_p, unsigned n,
+                                                           unsigned row_begin, unsigned row_end, unsigned col_begin, unsigned chunk,
+                                                           unsigned *__restrict__ dist, size_t ld, unsigned *__restrict__ S, size_t s_pitch)
+{
+    extern __shared__ unsigned row[];
+    const unsigned x = row_begin + blockIdx.x;
+    const unsigned c0 = blockIdx.y * chunk, c1 = min(n, c0 + chunk);
+    const bool in_rows = x < row_end;
+    // cells this workgroup feeds: (x, y) for y in [max(x + 1, col_begin, c0), c1) when x is a row of the call; (y, x) for y in
+    // [max(row_begin, c0), min(x, row_end, c1)) when column x is wanted
+    const unsigned up0 = max(max(x + 1, col_begin), c0), up1 = in_rows ? c1 : 0u;
+    const unsigned lw0 = max(row_begin, c0), lw1 = x >= col_begin ? min(min(x, row_end), c1) : 0u;
+    const bool upper = up0 < up1, lower = lw0 < lw1;
+    if (!upper && !lower) return;
+    const unsigned long long e0 = s_off[x], e1 = s_off[x + 1];
+    if ((unsigned)(size_t)row != 0u) __builtin_trap();
+    const unsigned span = c1 - c0;
+    for (unsigned j = threadIdx.x; j < span + 64u; j += blockDim.x) row[j] = 0;
+    __syncthreads();
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    if (upper && e1 > e0) {
+        // phase A.  A quarter wave takes 16 listed entries of sample x at a time: lane l fetches entry l and its site's list bounds
+        // (one memory round trip for the 16 of them); lists of at most four samples (the usual case: one or two) stay in their
+        // lane, the others are walked by the 16 lanes together.
+        const unsigned sub = threadIdx.x >> 4, nsub = blockDim.x >> 4, l16 = threadIdx.x & 15;
+        for (unsigned long long base = e0 + (unsigned long long)sub * 16; base < e1; base += (unsigned long long)nsub * 16) {
+            const unsigned long long e = base + l16;
+            unsigned my_code = 0;
+            unsigned long long my_pa = 0, my_pz = 0;
+            const bool live = e < e1;
+            if (live) {
+                const unsigned ent = s_ent[e];
+                my_code = ent & 31u;
+                my_pa = p_off[ent >> ENT_SHIFT]; my_pz = p_off[(ent >> ENT_SHIFT) + 1];
+            }
+            auto apply_p = [&](unsigned v, unsigned code5) {          // both listed: [masks disjoint] - w_x - w_j
+                const unsigned j = v >> ENT_SHIFT;
+                const int add = (((v & 15u) & (code5 & 15u)) == 0u ? 1 : 0) - (int)(code5 >> 4) - (int)((v >> 4) & 1u);
+                if (add != 0 && j >= up0 && j < up1) atomicAdd(&row[j - c0], (unsigned)add);
+            };
+            bool coop = live;
+            if (live && my_pz - my_pa <= 4) {
+                unsigned v[4];
+#pragma unroll
+                for (int m = 0; m < 4; m++) v[m] = my_pa + m < my_pz ? p_ent[my_pa + m] : 0xFFFFFFFFu;
+#pragma unroll
+                for (int m = 0; m < 4; m++) if (v[m] != 0xFFFFFFFFu) apply_p(v[m], my_code);
+                coop = false;
+            }
+            unsigned todo = (unsigned)(__ballot(coop) >> (threadIdx.x & 48)) & 0xFFFFu;     // this quarter wave's entries still to walk
+            while (todo) {
+                const int k = __ffs(todo) - 1;
+                todo &= todo - 1;
+                const unsigned code5 = __shfl(my_code, k, 16);
+                const unsigned long long pa = __shfl(my_pa, k, 16), pz = __shfl(my_pz, k, 16);
+                for (unsigned long long t = pa + l16; t < pz; t += 64) {
+                    const bool h1 = t + 16 < pz, h2 = t + 32 < pz, h3 = t + 48 < pz;
+                    const unsigned v0 = p_ent[t], v1 = h1 ? p_ent[t + 16] : 0u, v2 = h2 ? p_ent[t + 32] : 0u, v3 = h3 ? p_ent[t + 48] : 0u;
+                    apply_p(v0, code5); if (h1) apply_p(v1, code5); if (h2) apply_p(v2, code5); if (h3) apply_p(v3, code5);
+                }
+            }
+        }
+    }
+    // phase B: N-list walks, both triangles: column y goes to row[y - c0]
+    {
+        Walk W;
+        W.lines = lines;
+        W.ring = reinterpret_cast<uint2 *>(row + chunk + 64) + wave * WALK_RING;
+        W.head = 0; W.count = 0;
+        W.lane = lane; W.grp = lane >> 3; W.l8 = lane & 7u;
+        W.neg4lo = 0u - 4u * c0; W.dump4 = 4u * (span + lane); W.val = 0xFFFFFFFFu;
+        W.ge1 = W.l8 >= 1u; W.ge2 = W.l8 >= 2u; W.ge4 = W.l8 >= 4u;
+        for (unsigned long long base = e0 + (unsigned long long)wave * 64; base < e1; base += (unsigned long long)nwaves * 64) {
+            const unsigned long long e = base + lane;
+            const unsigned ent = e < e1 ? s_ent[e] : 0u;
+            W.drain_to(8 * WALK_FLIGHT - 1);
+            W.push(e < e1 && (ent & 16u), ent >> ENT_SHIFT, 0xFFFFFFFFu);
+        }
+        W.drain_to(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
+    __syncthreads();
+    if (upper) {
+        const unsigned cx = c_p[x];
+        for (unsigned j = up0 + threadIdx.x; j < up1; j += blockDim.x) {
+            const unsigned t = row[j - c0] + cx + c_p[j];
+            if (t) dist[(size_t)x * ld + j] += t;
+        }
+    }
+    if (lower) {
+        unsigned *dst = S + (size_t)(x - row_begin) * s_pitch;
+        for (unsigned y = lw0 + threadIdx.x; y < lw1; y += blockDim.x) dst[y - row_begin] = row[y - c0];
+    }
+}
+
+// dist[y][x] += S[x - row_begin][y - row_begin] for the cells (y, x > y) of the call: 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_add_kernel(const unsigned *__restrict__ S, size_t s_pitch, unsigned n, unsigned row_begin,
+                                                            unsigned row_end, unsigned col_begin, unsigned *__restrict__ dist, size_t ld)
+{
+    __shared__ unsigned tile[32][33];
+    const unsigned xb = row_begin + blockIdx.x * 32, yb = row_begin + blockIdx.y * 32;
+    if (xb + 31 <= yb) return;                              // every x of the tile <= every y: no cell above the diagonal
+    const unsigned tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const unsigned x = xb + ty + 8 * k, y = yb + tx;
+        tile[ty + 8 * k][tx] = (x < n && y < row_end && y < x) ? S[(size_t)(x - row_begin) * s_pitch + (y - row_begin)] : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const unsigned y = yb + ty + 8 * k, x = xb + tx;
+        const unsigned v = tile[tx][ty + 8 * k];
+        if (v && x < n && y < row_end && y < x && x >= col_begin) dist[(size_t)y * ld + x] += v;
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------------------
+void minority_lists_free(tracs_alignment *a)
+{
+    if (!a) return;
+    delete a->lists;                               // (the arrays live in the alignment's pack arena: released with it)
+    a->lists = nullptr;
+}
+
+int minority_lists_build(tracs_alignment *a, const MinorBuild &mb_, hipStream_t stream, int *ok)
+{
+    *ok = 0;
+    minority_lists_free(a);
+    MinorBuild mb = mb_;
+    const size_t n = a->n, L = mb.sites, groups = a->groups;
+    if (L == 0 || L >= (1ull << 27) || n >= (1ull << 27)) return TRACS_OK;           // entries hold rank << 5 / sample << 5
+    auto *g = new SiteLists();
+    auto fail_soft = [&]() { (void)hipGetLastError(); delete g; return TRACS_OK; };
+#define SL_TRY(x) do { if ((x) != hipSuccess) return fail_soft(); } while (0)
+    g->sites = L; g->groups = groups; g->tot_p = mb.tot_p; g->tot_nnl = mb.tot_nnl;
+    g->n_rows = mb.n_rows;
+    for (int k = 0; k < 4; k++) g->rows[k] = mb.rows[k];
+    g->n_lines = (unsigned long long)L + mb.tot_o;
+    g->tgroups = (groups + 7) / 8 * 8;
+    SL_TRY(pack_alloc(a, (g->n_lines + 1) * 128, reinterpret_cast<void **>(&g->lines)));
+    SL_TRY(pack_alloc(a, (L + 1) * 8, reinterpret_cast<void **>(&g->p_off)));
+    SL_TRY(pack_alloc(a, std::max<size_t>(mb.tot_p, 1) * 4, reinterpret_cast<void **>(&g->p_ent)));
+    SL_TRY(pack_alloc(a, (n + 1) * 8, reinterpret_cast<void **>(&g->s_off)));
+    SL_TRY(pack_alloc(a, std::max<size_t>(mb.tot_p, 1) * 4, reinterpret_cast<void **>(&g->s_ent)));
+    SL_TRY(pack_alloc(a, std::max<size_t>(n, 1) * 4, reinterpret_cast<void **>(&g->c_p)));
+    SL_TRY(pack_alloc(a, groups * sizeof(uint4), reinterpret_cast<void **>(&g->lst_mask)));
+    SL_TRY(pack_alloc(a, groups * sizeof(unsigned), reinterpret_cast<void **>(&g->off_lst)));
+    const bool bitmaps = mb.tot_nnl > 0;
+    if (bitmaps) SL_TRY(pack_alloc(a, n * g->tgroups * sizeof(uint4), reinterpret_cast<void **>(&g->T)));
+    unsigned *cnt = nullptr;
+    uint2 *E = nullptr;
+    int rc;
+    if ((rc = workspace_get(60, (2 * std::max<size_t>(n, 1) + 8) * 4, reinterpret_cast<void **>(&cnt))) ||
+        (rc = workspace_get(62, std::max<size_t>(mb.tot_p, 1) * sizeof(uint2), reinterpret_cast<void **>(&E)))) { delete g; return rc; }
+    unsigned *cur = cnt + std::max<size_t>(n, 1), *d_max = cur + std::max<size_t>(n, 1);
+    SL_TRY(hipMemsetAsync(cnt, 0, (2 * std::max<size_t>(n, 1) + 8) * 4, stream));
+    SL_TRY(hipMemsetAsync(g->c_p, 0, std::max<size_t>(n, 1) * 4, stream));
+    SL_TRY(hipMemcpyAsync(g->lst_mask, mb.lst_mask, groups * sizeof(uint4), hipMemcpyDeviceToDevice, stream));
+    SL_TRY(hipMemcpyAsync(g->off_lst, mb.off_lst, groups * sizeof(unsigned), hipMemcpyDeviceToDevice, stream));
+    const double plane_b = (double)groups * (double)a->n_pad * sizeof(uint4);      // the N plane
+    hipLaunchKernelGGL(site_lists_kernel, dim3((unsigned)groups), dim3(256), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off, g->p_ent, E, g->lines);
+    pack_stage_mark("lists: per site", stream, plane_b + (double)groups * SITES_PER_GROUP * 8.0,
+                    (double)L * 128.0 + (double)mb.tot_p * 12.0 + (double)L * 8.0);
+    const unsigned egrid = (unsigned)((mb.tot_p + 255) / 256);
+    if (egrid) hipLaunchKernelGGL((listed_entries_kernel<false>), dim3(egrid), dim3(256), 0, stream, E, mb.tot_p, cnt, g->c_p, nullptr, nullptr, nullptr);
+    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, cnt, n, g->s_off);
+    if (egrid) hipLaunchKernelGGL((listed_entries_kernel<true>), dim3(egrid), dim3(256), 0, stream, E, mb.tot_p, nullptr, nullptr, g->s_off, cur, g->s_ent);
+    pack_stage_mark("listed entries per sample", stream, (double)mb.tot_p * 16.0 + (double)n * 4.0, (double)mb.tot_p * 4.0 + (double)n * 20.0);
+    if (bitmaps) {
+        // (a->c_counted was zeroed by the caller: this kernel is what fills it when the rows' bitmaps are built)
+        const size_t octs = g->tgroups / 8;
+        const unsigned chunks = (unsigned)std::min<size_t>(64, std::max<size_t>(1, octs / 16));
+        const size_t opc = (octs + chunks - 1) / chunks;
+        const dim3 grid((unsigned)((n + 255) / 256), (unsigned)((octs + opc - 1) / opc));
+        hipLaunchKernelGGL(n_bitmap_kernel, grid, dim3(256), 0, stream, mb, a->n_pad, (unsigned)n, groups, g->tgroups, opc, g->T, a->c_counted, d_max);
+        hipLaunchKernelGGL(max_count_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a->c_counted, n, d_max);
+        double rows = (double)n;
+        if (mb.n_rows) { rows = 0.0; for (int k = 0; k < mb.n_rows; k++) rows += (double)(std::min<size_t>(mb.rows[2 * k + 1], n) - std::min<size_t>(mb.rows[2 * k], n)); }
+        pack_stage_mark("N bitmaps of the rows", stream, plane_b, rows * (double)g->tgroups * sizeof(uint4));
+        SL_TRY(hipMemcpyAsync(&g->max_row, d_max, 4, hipMemcpyDeviceToHost, stream));       // (read after the caller's synchronisation)
+    }
+    SL_TRY(hipGetLastError());
+#undef SL_TRY
+    a->lists = g;
+    *ok = 1;
+    return TRACS_OK;
+}
+
+static unsigned row_chunk(size_t n) { return (unsigned)std::min<size_t>((n + 63) / 64 * 64, 32768); }
+static constexpr size_t kWalkLds = (size_t)(TRACS_NN_THREADS / 64) * WALK_RING * sizeof(uint2);
+
+int nn_rows_add(tracs_alignment *a, size_t row_begin, size_t row_end, size_t col_begin, unsigned *ncomp, size_t ld, int add_terms,
+                unsigned lu, hipStream_t stream)
+{
+    const SiteLists *g = a->lists;
+    if (!g || !g->T) { set_error("nn_rows_add: lists not built"); return TRACS_E_ARG; }
+    const size_t n = a->n;
+    const unsigned chunk = row_chunk(n);
+    const size_t lds = (size_t)chunk * 4 + 256 + kWalkLds;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static bool attr_set[64] = {false};
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(nn_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4 + 256 + (int)kWalkLds));
+        attr_set[dev] = true;
+    }
+    // ~2048 workgroups' worth of walks each, never less than 8192 (a workgroup's fixed cost: its row in LDS)
+    const unsigned target = (unsigned)std::min<unsigned long long>(1u << 30, std::max<unsigned long long>(8192ull, g->tot_nnl / 2048ull));
+    const unsigned splits = (unsigned)std::min<unsigned long long>(NN_MAX_SPLITS, std::max<unsigned long long>(1, ((unsigned long long)g->max_row + target - 1) / target));
+    const dim3 grid((unsigned)(row_end - row_begin), (unsigned)((n + chunk - 1) / chunk), splits);
+    hipLaunchKernelGGL(nn_rows_kernel, grid, dim3(TRACS_NN_THREADS), lds, stream, g->T, g->tgroups, g->lst_mask, g->off_lst, g->groups, g->lines,
+                       a->c_counted, (unsigned)n, (unsigned)row_begin, (unsigned)col_begin, chunk, target, ncomp, ld, add_terms, lu);
+    TRACS_HIP_CHECK(hipGetLastError());
+    return TRACS_OK;
+}
+
+// dist[i][j] += the minority sites' contribution (alignments cut into site classes)
+int minority_fixup(tracs_alignment *a, size_t row_begin, size_t row_end, size_t col_begin, unsigned *dist, size_t ld, hipStream_t stream)
+{
+    const SiteLists *g = a->lists;
+    if (!g || g->tot_p == 0) return TRACS_OK;
+    const size_t n = a->n;
+    const unsigned chunk = row_chunk(n);
+    const size_t lds = (size_t)chunk * 4 + 256 + (size_t)16 * WALK_RING * sizeof(uint2);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static bool attr_set[64] = {false};
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(minor_fixup_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4 + 256 + 16 * (int)WALK_RING * 8));
+        attr_set[dev] = true;
+    }
+    // scratch rows for the cells (y, x) with y < x that row x's walks feed: (n - row_begin) rows of (row_end - row_begin) columns
+    const size_t s_pitch = (row_end - row_begin + 63) / 64 * 64;
+    unsigned *S = nullptr;
+    const int rc = workspace_get(46, (n - row_begin) * s_pitch * sizeof(unsigned), reinterpret_cast<void **>(&S));
+    if (rc) return rc;
+    const dim3 grid((unsigned)(n - row_begin), (unsigned)((n + chunk - 1) / chunk));
+    hipLaunchKernelGGL(minor_fixup_kernel, grid, dim3(1024), lds, stream, g->s_off, g->s_ent, g->p_off, g->p_ent, g->lines, g->c_p, (unsigned)n,
+                       (unsigned)row_begin, (unsigned)row_end, (unsigned)col_begin, chunk, dist, ld, S, s_pitch);
+    const dim3 tgrid((unsigned)((n - row_begin + 31) / 32), (unsigned)((row_end - row_begin + 31) / 32));
+    hipLaunchKernelGGL(transpose_add_kernel, tgrid, dim3(256), 0, stream, S, s_pitch, (unsigned)n, (unsigned)row_begin, (unsigned)row_end,
+                       (unsigned)col_begin, dist, ld);
+    TRACS_HIP_CHECK(hipGetLastError());
+    return TRACS_OK;
+}
+
+}  // namespace tracs
+
+extern "C" {
+
+// Diagnostics (tests/test_gpu_lists.py): the lists of an alignment on site classes, copied to the host.
+//   what 0  sizes: out64[0..7] = sites with lists, lines, p entries, tgroups, groups, bitmap present, n, 0
+//   what 1  lines (n_lines x 128 bytes)     what 2  lst_mask (groups x 16 bytes)     what 3  off_lst (groups x 4 bytes)
+//   what 4  p_off ((sites + 1) x 8)          what 5  p_ent (tot_p x 4)                what 6  s_off ((n + 1) x 8)
+//   what 7  s_ent (tot_p x 4)                what 8  T (n x tgroups x 16)             what 9  c_p (n x 4)
+// Returns the bytes copied (what >= 1), 0 when the lists do not exist or `cap` is too small.
+size_t tracs_debug_lists(const tracs_alignment *a, int what, void *out, size_t cap)
+{
+    using namespace tracs;
+    if (!a || !a->lists || !out) return 0;
+    const SiteLists *g = a->lists;
+    const void *src = nullptr;
+    size_t bytes = 0;
+    switch (what) {
+    case 0: {
+        if (cap < 64) return 0;
+        uint64_t *o = static_cast<uint64_t *>(out);
+        o[0] = g->sites; o[1] = g->n_lines; o[2] = g->tot_p; o[3] = g->tgroups; o[4] = g->groups; o[5] = g->T ? 1 : 0; o[6] = a->n; o[7] = 0;
+        return 64;
+    }
+    case 1: src = g->lines; bytes = g->n_lines * 128; break;
+    case 2: src = g->lst_mask; bytes = g->groups * 16; break;
+    case 3: src = g->off_lst; bytes = g->groups * 4; break;
+    case 4: src = g->p_off; bytes = (g->sites + 1) * 8; break;
+    case 5: src = g->p_ent; bytes = g->tot_p * 4; break;
+    case 6: src = g->s_off; bytes = (a->n + 1) * 8; break;
+    case 7: src = g->s_ent; bytes = g->tot_p * 4; break;
+    case 8: src = g->T; bytes = g->T ? a->n * g->tgroups * 16 : 0; break;
+    case 9: src = g->c_p; bytes = a->n * 4; break;
+    default: return 0;
+    }
+    if (!src || bytes == 0 || bytes > cap) return 0;
+    if (hipDeviceSynchronize() != hipSuccess) return 0;
+    if (hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return bytes;
+}
+
+}  // extern "C"
