@@ -90,6 +90,10 @@ WORKLOADS = {
     "divergent": dict(mu_lineage=0.0, mu_sample=1e-3, n_lineages=1, p_n=P_N),
     "clean": dict(mu_lineage=0.0, mu_sample=MU, n_lineages=1, p_n=0.0),
     "gappy": dict(mu_lineage=0.0, mu_sample=MU, n_lineages=1, p_n=0.10),
+    # coverage gaps as real consensus alignments have them: N in runs of consecutive sites (geometric lengths, mean 500), each lost by
+    # a random 0.5-30 % of the samples, 1 % N overall (tracs_amd/synth.py: coverage_runs) -- the reference's cost does not care
+    # (src/pairsnp.hpp:417-420), the site classes' does
+    "runs": dict(mu_lineage=0.0, mu_sample=MU, n_lineages=1, p_n=0.0, runs=dict(p_n=P_N, mean_len=500, frac_lo=0.005, frac_hi=0.30)),
 }
 
 
@@ -544,7 +548,7 @@ def _traffic_from_profiles(n, L, world, kernel):
 
 
 def sensitivity(args, n, L, seed, days, dev, synth, torch, device, lib, value_default):
-    """The same pass on four other synthetic alignments of the same shape (WORKLOADS), each with the site classes as the cost
+    """The same pass on five other synthetic alignments of the same shape (WORKLOADS), each with the site classes as the cost
     model decides and with every site through the pair kernel (tracs_debug_force_site_classes(0), the same handle re-decided):
     ms per pass in steady state (pairsnp + transcluster, 2 passes after one untimed), class sizes, and the two runs' checksums,
     which must agree.  The reference's cost does not depend on the data (src/pairsnp.hpp:395-420 visits every site of every pair);
@@ -571,7 +575,7 @@ def sensitivity(args, n, L, seed, days, dev, synth, torch, device, lib, value_de
         torch.cuda.synchronize()
         return first, e0.elapsed_time(e1) / 2, int(dmat.sum().item()), int(nmat.sum().item())
     out = {}
-    for name in ("lineage", "divergent", "clean", "gappy"):
+    for name in ("lineage", "divergent", "clean", "gappy", "runs"):
         a = dev.Alignment(n, L)
         synth.pack_synthetic_device(a, seed=seed, **synth_kw(0.0, name))
         first, ms, cd, cn = timed(a)

@@ -133,6 +133,51 @@ def test_config3_full_size(dev, oracle, p_partial):
     aln.close()
 
 
+# what each workload of bench.py's `sensitivity` must exercise at 10 000 x 5 Mbp (the cost model's decisions at the metric's size)
+FULL_SIZE_PATHS = {
+    "lineage": lambda c, src, ls: src[2] > 4_000_000 and ls["row_splits"] > 1,                   # N in 1 / 21 of the samples: long rows, cut over workgroups
+    "divergent": lambda c, src, ls: c[2] > 4_000_000 and src[2] > 4_000_000 and ls["p_entries"] > 40_000_000,   # ~10 listed samples at every site
+    "clean": lambda c, src, ls: src[2] == 0 and src[0] == 0 and c[3] > 4_000_000 and not ls.get("bitmaps", False),   # no N: neither lists nor counting pass for nn
+    "gappy": lambda c, src, ls: src[1] is True and src[2] == 0 and c[2] > 2_000_000,              # every site on the matrix cores, in place; minority lists of ~1000 N samples
+    "runs": lambda c, src, ls: src[0] > 50_000 and src[1] is False and src[2] > 10_000,           # counted (re-packed) and listed sites side by side
+}
+
+
+@pytest.mark.parametrize("workload", sorted(FULL_SIZE_PATHS))
+def test_config3_full_size_other_workloads(dev, oracle, workload):
+    """The other workloads of bench.py's `sensitivity` at the metric's size, against the ORACLE (the bench compares them with the
+    library's own dense pass only): three 64-sample blocks -- the first rows, the rows around the middle, the last -- and all their
+    cross pairs, 18 336 pairs at full length (src/pairsnp.hpp:395-420), and which paths the cost model took there."""
+    import torch
+    import bench
+    from tracs_amd import synth
+    n, L = 10000, 5000000
+    blocks = [(0, 64), (4968, 5032), (n - 64, n)]
+    aln, idx, host = _generate_with_blocks(dev, synth, n, L, 20241022 + 2, blocks, **bench.synth_kw(0.0, workload))
+    d = torch.zeros((n, n), dtype=torch.int32, device="cuda")
+    nn = torch.zeros((n, n), dtype=torch.int32, device="cuda")
+    dev.pairsnp_dense(aln, d, nn)
+    torch.cuda.synchronize()
+    classes, src, ls = aln.site_classes, aln.count_source, aln.list_stats
+    assert classes is not None and aln.kernel == "mfma", (classes, aln.kernel)
+    assert FULL_SIZE_PATHS[workload](classes, src, ls), (workload, classes, src, ls)
+    er, ec, ed, enn = oracle.pairsnp_arrays(host, n_threads=max(1, os.cpu_count() or 1))
+    sub = torch.from_numpy(idx).cuda()
+    dsub, nsub = d[sub][:, sub].cpu().numpy(), nn[sub][:, sub].cpu().numpy()
+    li, lj = er.astype(np.int64), ec.astype(np.int64)
+    assert len(ed) == len(idx) * (len(idx) - 1) // 2
+    assert np.array_equal(dsub[li, lj], ed.astype(np.int32)), "SNP distances differ from the oracle"
+    assert np.array_equal(nsub[li, lj], enn.astype(np.int32)), "compared-site counts differ from the oracle"
+    # the same cells from row panels computed on their own (a multi-GPU rank's call): one around the middle, the last rows
+    for r0, r1 in ((4900, 5100), (n - 300, n)):
+        dp = torch.zeros((r1 - r0, n), dtype=torch.int32, device="cuda")
+        npn = torch.zeros_like(dp)
+        dev.pairsnp_dense(aln, dp, npn, row_begin=r0, row_end=r1, base_row=r0)
+        up = torch.triu(torch.ones((r1 - r0, n), dtype=torch.bool, device="cuda"), diagonal=r0 + 1)
+        assert bool(torch.equal(dp[up], d[r0:r1][up])) and bool(torch.equal(npn[up], nn[r0:r1][up])), (r0, r1)
+    aln.close()
+
+
 def test_config3_dm_frontend_chain(dev, oracle):
     """counts -> posterior filter -> 4-bit codes -> planes -> pairsnp on a batch of full-length samples, against the same
     chain through the oracle (calculate_posteriors -> IUPAC letters -> pack -> pair loop)."""

@@ -52,17 +52,34 @@ def _decode(lines, r):
 
 
 CASES = [
-    dict(n=300, L=5000, p_n=0.02, mu=3e-4, seed=1),                     # short lists, one piece
-    dict(n=700, L=3000, p_n=0.30, mu=3e-4, seed=2),                     # ~210 N samples per site: two lines per list, several pieces per group
-    dict(n=2000, L=1500, p_n=0.002, mu=2e-4, seed=3),                   # gaps beyond 253: skip bytes
+    dict(n=640, L=5000, p_n=0.02, mu=3e-4, seed=1, bitmaps=True),        # short lists, one piece
+    dict(n=700, L=3000, p_n=0.30, mu=3e-4, seed=2, bitmaps=True),       # ~210 N samples per site: two lines per list, several pieces per group
+    dict(n=2000, L=1500, p_n=0.002, mu=2e-4, seed=3, bitmaps=True),     # gaps beyond 253: skip bytes
     dict(n=130, L=4000, p_n=0.05, mu=2e-3, seed=4, p_partial=0.002),    # partial codes among the listed samples
 ]
 
 
-@pytest.mark.parametrize("case", CASES, ids=lambda c: "n%d_L%d_pn%g" % (c["n"], c["L"], c["p_n"]))
-def test_lists_against_numpy(hiplib, case):
+@pytest.mark.parametrize("nn_lists", ["always", "cost-model"])
+@pytest.mark.parametrize("case", range(len(CASES)), ids=lambda k: "n%d_L%d_pn%g" % (CASES[k]["n"], CASES[k]["L"], CASES[k]["p_n"]))
+def test_lists_against_numpy(hiplib, case, nn_lists):
+    """(a child process per case: the list threshold TRACS_NN_LIST_K is read once per process)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("TRACS_NN_LIST_K", None)
+    if nn_lists == "always":
+        env["TRACS_NN_LIST_K"] = "1"
+    code = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_lists as T; T.run_case(T.CASES[%d], %r)" % (
+        root, os.path.join(root, "tests"), case, nn_lists)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+
+
+def run_case(case, nn_lists):
     import torch
-    from tracs_amd import device as dev
+    from tracs_amd import _lib, device as dev
+    hiplib = _lib.load()
     n, L = case["n"], case["L"]
     rng = np.random.default_rng(case["seed"])
     bases = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -78,7 +95,6 @@ def test_lists_against_numpy(hiplib, case):
     aln.pack(seqs)
     d = torch.zeros((n, n), dtype=torch.int32, device="cuda")
     nn = torch.zeros_like(d)
-    os.environ.pop("TRACS_NN_LIST_K", None)
     try:
         hiplib.tracs_debug_force_site_classes(1)
         dev.pairsnp_dense(aln, d, nn)
@@ -144,4 +160,13 @@ def test_lists_against_numpy(hiplib, case):
         assert (bits[:, col_any] == isN[:, col_any]).all()
         assert (listed_site[col_any]).all()
         assert (isN[:, col_any].sum(axis=0) >= 2).all()
+    # (small alignments: the lists are refused when they would outweigh the planes -- 128 bytes per site against 5 n / 8)
+    assert has_T or nn_lists != "always" or not case.get("bitmaps")
+    # ---- and the results built on them
+    from oracle import oracle as O
+    er, ec, ed, enn = O.pairsnp_arrays(seqs, n_threads=8)
+    ri, ci = er.astype(np.int64), ec.astype(np.int64)
+    assert np.array_equal(d.cpu().numpy()[ri, ci], ed.astype(np.int32))
+    assert np.array_equal(nn.cpu().numpy()[ri, ci], enn.astype(np.int32))
+    print("lists ok:", dict(sites=sites, lines=n_lines, p=tot_p, bitmaps=has_T), flush=True)
     aln.close()

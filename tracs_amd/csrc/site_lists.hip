@@ -231,17 +231,31 @@ __global__ __launch_bounds__(256) void site_lists_kernel(const MinorBuild mb, si
             }
         }
         __syncthreads();
-        // ---- the site's thread: sort its run (disorder only inside a 256-sample slab), encode it
+        // ---- the site's thread: sort its run -- it is nearly sorted (the waves drift a few slabs apart at most): four entries at a
+        // time are only looked at (independent LDS reads), an entry out of place is inserted --, then encode it
         if (mine) {
             unsigned short *st = stage + lN[tid];
             const unsigned c = cur[tid];
-            for (unsigned k = 1; k < c; k++) {
+            unsigned prev = 0;
+            unsigned k = 0;
+            while (k < c) {
+                if (k + 4 <= c) {
+                    const unsigned v0 = st[k], v1 = st[k + 1], v2 = st[k + 2], v3 = st[k + 3];
+                    if (prev <= v0 && v0 <= v1 && v1 <= v2 && v2 <= v3) { prev = v3; k += 4; continue; }
+                }
                 const unsigned short v = st[k];
                 unsigned j = k;
                 while (j > 0 && st[j - 1] > v) { st[j] = st[j - 1]; j--; }
                 st[j] = v;
+                prev = st[k];
+                k++;
             }
-            for (unsigned k = 0; k < c; k++) enc.sample(s_begin + st[k]);
+            k = 0;
+            for (; k + 4 <= c; k += 4) {
+                const unsigned v0 = st[k], v1 = st[k + 1], v2 = st[k + 2], v3 = st[k + 3];
+                enc.sample(s_begin + v0); enc.sample(s_begin + v1); enc.sample(s_begin + v2); enc.sample(s_begin + v3);
+            }
+            for (; k < c; k++) enc.sample(s_begin + st[k]);
         }
         s_begin = s_end;
         if (one_piece) break;
@@ -299,42 +313,37 @@ __global__ __launch_bounds__(1024) void scan_counts_kernel(const unsigned *__res
 }
 
 // ---- per sample: its N bitmap over the NNL sites (the N plane transposed), and its N count ---------------------------------------
-// thread = sample, eight consecutive groups at a time: eight coalesced 16-byte loads (one per group), one 128-byte run of the
-// sample's row of T.  c_counted[s] += its N sites among the sites of un_mask (what the compared-sites formula needs).
+// A wave takes 8 samples x 8 consecutive groups at a time: lane = (sample s0 + lane / 8, group g0 + lane % 8).  Its load touches, per
+// group, the 128 contiguous bytes of the 8 samples; its store, per sample, the 128 contiguous bytes of the 8 groups: whole cache
+// lines on both sides of the transposition, no LDS.  c_counted[s] += the sample's N sites among the sites of un_mask (what the
+// compared-sites formula needs), summed over the wave's octets in registers, then over the 8 lanes of a sample.
 __global__ __launch_bounds__(256) void n_bitmap_kernel(const MinorBuild mb, size_t n_pad, unsigned n, size_t groups, size_t tgroups,
-                                                       size_t oct_per_chunk, uint4 *__restrict__ T, unsigned *__restrict__ c_counted,
-                                                       unsigned *__restrict__ max_row)
+                                                       size_t oct_per_chunk, uint4 *__restrict__ T, unsigned *__restrict__ c_counted)
 {
-    const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const size_t s = ((size_t)blockIdx.x * 4 + wave) * 8 + (lane >> 3);
     const size_t o0 = (size_t)blockIdx.y * oct_per_chunk, o1 = min(tgroups / 8, o0 + oct_per_chunk);
     const bool live = s < n;
     const bool row = live && T != nullptr && row_wanted(mb, s);
     const uint4 *np = mb.planes + 4 * n_pad + min(s, n_pad - 1);
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
     unsigned cnt = 0;
-    for (size_t o = o0; o < o1; o++) {
-        uint4 v[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const size_t g = o * 8 + k;                       // (wave-uniform)
-            v[k] = (g < groups && live) ? np[g * NPLANES * n_pad] : make_uint4(0u, 0u, 0u, 0u);
-        }
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const size_t g = min(o * 8 + k, groups - 1);
-            const uint4 um = mb.un_mask[g], lm = mb.nnl_mask[g];
-            cnt += __popc(v[k].x & um.x) + __popc(v[k].y & um.y) + __popc(v[k].z & um.z) + __popc(v[k].w & um.w);
-            v[k].x &= lm.x; v[k].y &= lm.y; v[k].z &= lm.z; v[k].w &= lm.w;
-        }
-        if (row) {
-            uint4 *dst = T + s * tgroups + o * 8;
-#pragma unroll
-            for (int k = 0; k < 8; k++) dst[k] = v[k];
-        }
+    size_t o = o0;
+    uint4 v_next = zero4;
+    { const size_t g = o * 8 + (lane & 7u); if (o < o1 && g < groups && live) v_next = np[g * NPLANES * n_pad]; }
+    for (; o < o1; o++) {
+        const size_t g = o * 8 + (lane & 7u);
+        uint4 v = v_next;
+        const size_t gn = g + 8;
+        v_next = (o + 1 < o1 && gn < groups && live) ? np[gn * NPLANES * n_pad] : zero4;      // (the next octet: in flight during this one)
+        const size_t gm = min(g, groups - 1);
+        const uint4 um = mb.un_mask[gm], lm = mb.nnl_mask[gm];
+        cnt += __popc(v.x & um.x) + __popc(v.y & um.y) + __popc(v.z & um.z) + __popc(v.w & um.w);
+        v.x &= lm.x; v.y &= lm.y; v.z &= lm.z; v.w &= lm.w;
+        if (row) T[s * tgroups + g] = g < groups ? v : zero4;
     }
-    if (live && cnt) {
-        const unsigned before = atomicAdd(&c_counted[s], cnt);
-        if (gridDim.y == 1) atomicMax(max_row, before + cnt);
-    }
+    cnt += __shfl_xor(cnt, 1, 64); cnt += __shfl_xor(cnt, 2, 64); cnt += __shfl_xor(cnt, 4, 64);
+    if (live && (lane & 7u) == 0u && cnt) atomicAdd(&c_counted[s], cnt);
 }
 
 __global__ void max_count_kernel(const unsigned *__restrict__ c, size_t n, unsigned *__restrict__ out)
@@ -349,6 +358,7 @@ __global__ void max_count_kernel(const unsigned *__restrict__ c, size_t n, unsig
 // the group's eight lanes (DPP), one add per byte -- and adds `val` to the LDS counter of every sample it decodes: column j goes
 // to row[j - lo], and whatever is no cell of the row (j < lo, another column chunk, skips and padding) to the lane's own slot
 // behind the row.  A line that goes on (its `next`) becomes a new item.
+typedef __attribute__((address_space(3))) unsigned lds_u32;
 constexpr int WALK_FLIGHT = 4;                 // lines per lane group and round
 constexpr unsigned WALK_RING = 128;            // items: < 32 left over + 64 pushed + 32 continuations
 
@@ -387,7 +397,8 @@ struct Walk {
                 p += b;
                 unsigned a = min((p << 2) + neg4lo, dump4);
                 a = b < N8_SKIP ? a : dump4;
-                asm volatile("ds_add_u32 %0, %1" : : "v"(a), "v"(val) : "memory");
+                // (row[] starts at LDS byte 0: the byte offset IS the address -- one ds_add_u32, no address arithmetic)
+                __hip_atomic_fetch_add(reinterpret_cast<lds_u32 *>((size_t)a), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
         return p0 + x;                          // on the group's last lane: the position behind the line's payload
@@ -497,7 +508,6 @@ __global__ __launch_bounds__(TRACS_NN_THREADS) void nn_rows_kernel(const uint4 *
         }
     }
     W.drain_to(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");   // (the adds issued from inline assembly are not in the compiler's count)
     __syncthreads();
     const bool terms = add_terms && blockIdx.z == 0;
     for (unsigned j = lo + threadIdx.x; j < c1; j += blockDim.x) {
@@ -602,7 +612,6 @@ __global__ __launch_bounds__(1024) void minor_fixup_kernel(const unsigned long l
         }
         W.drain_to(0);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
     __syncthreads();
     if (upper) {
         const unsigned cx = c_p[x];
@@ -696,8 +705,8 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb_, hipStream_t 
         const size_t octs = g->tgroups / 8;
         const unsigned chunks = (unsigned)std::min<size_t>(64, std::max<size_t>(1, octs / 16));
         const size_t opc = (octs + chunks - 1) / chunks;
-        const dim3 grid((unsigned)((n + 255) / 256), (unsigned)((octs + opc - 1) / opc));
-        hipLaunchKernelGGL(n_bitmap_kernel, grid, dim3(256), 0, stream, mb, a->n_pad, (unsigned)n, groups, g->tgroups, opc, g->T, a->c_counted, d_max);
+        const dim3 grid((unsigned)((n + 31) / 32), (unsigned)((octs + opc - 1) / opc));
+        hipLaunchKernelGGL(n_bitmap_kernel, grid, dim3(256), 0, stream, mb, a->n_pad, (unsigned)n, groups, g->tgroups, opc, g->T, a->c_counted);
         hipLaunchKernelGGL(max_count_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a->c_counted, n, d_max);
         double rows = (double)n;
         if (mb.n_rows) { rows = 0.0; for (int k = 0; k < mb.n_rows; k++) rows += (double)(std::min<size_t>(mb.rows[2 * k + 1], n) - std::min<size_t>(mb.rows[2 * k], n)); }
@@ -774,7 +783,7 @@ int minority_fixup(tracs_alignment *a, size_t row_begin, size_t row_end, size_t 
 extern "C" {
 
 // Diagnostics (tests/test_gpu_lists.py): the lists of an alignment on site classes, copied to the host.
-//   what 0  sizes: out64[0..7] = sites with lists, lines, p entries, tgroups, groups, bitmap present, n, 0
+//   what 0  sizes: out64[0..7] = sites with lists, lines, p entries, tgroups, groups, bitmap present, n, the most N sites of a sample
 //   what 1  lines (n_lines x 128 bytes)     what 2  lst_mask (groups x 16 bytes)     what 3  off_lst (groups x 4 bytes)
 //   what 4  p_off ((sites + 1) x 8)          what 5  p_ent (tot_p x 4)                what 6  s_off ((n + 1) x 8)
 //   what 7  s_ent (tot_p x 4)                what 8  T (n x tgroups x 16)             what 9  c_p (n x 4)
@@ -790,7 +799,7 @@ size_t tracs_debug_lists(const tracs_alignment *a, int what, void *out, size_t c
     case 0: {
         if (cap < 64) return 0;
         uint64_t *o = static_cast<uint64_t *>(out);
-        o[0] = g->sites; o[1] = g->n_lines; o[2] = g->tot_p; o[3] = g->tgroups; o[4] = g->groups; o[5] = g->T ? 1 : 0; o[6] = a->n; o[7] = 0;
+        o[0] = g->sites; o[1] = g->n_lines; o[2] = g->tot_p; o[3] = g->tgroups; o[4] = g->groups; o[5] = g->T ? 1 : 0; o[6] = a->n; o[7] = g->max_row;
         return 64;
     }
     case 1: src = g->lines; bytes = g->n_lines * 128; break;

@@ -121,14 +121,21 @@ class Alignment:
 
     @property
     def list_stats(self):
-        """{nn_visits, nn_walks, n_entries, p_entries, n_entry_bytes}: list entries one pass of the N co-occurrence walk visits (sum of
-        cN^2 over the sites whose co-occurrences come from lists) in how many list walks (sum of cN), entries of the per-site N lists
-        (padded) and of the listed-sample lists, bytes per N list entry; None without classes."""
+        """{nn_visits, nn_walks, n_lines, p_entries, n_entry_bytes[, max_row_n, bitmaps, row_splits]}: list entries one pass of the N
+        co-occurrence walk decodes (sum of cN^2 over the sites whose co-occurrences come from lists) in how many list walks (sum of
+        cN), 128-byte lines reserved for the per-site N lists, entries of the listed-sample lists, bytes per N list entry; the most N
+        sites any sample has and the workgroups its row is cut over; None without classes."""
         out = (C.c_uint64 * 8)()
         if not self._L.tracs_debug_alignment_count_source(self._h, out):
             return None
-        return {"nn_visits": int(out[3]), "n_entries": int(out[4]), "p_entries": int(out[5]), "n_entry_bytes": int(out[6]),
-                "nn_walks": int(out[7])}
+        st = {"nn_visits": int(out[3]), "n_lines": int(out[4]), "p_entries": int(out[5]), "n_entry_bytes": int(out[6]),
+              "nn_walks": int(out[7])}
+        sizes = (C.c_uint64 * 8)()
+        if self._L.tracs_debug_lists(self._h, 0, sizes, 64) == 64:
+            # (nn_rows_kernel cuts a row over up to 32 workgroups by its N sites: csrc/site_lists.hip)
+            target = max(8192, st["nn_walks"] // 2048)
+            st.update(max_row_n=int(sizes[7]), bitmaps=bool(sizes[5]), row_splits=min(32, max(1, -(-int(sizes[7]) // target))))
+        return st
 
     @property
     def nbytes(self):

@@ -106,12 +106,33 @@ def allele_counts(L, seed, depth=30, eps=0.01, p_two=0.01):
 
 
 # ---- on-device generation for the benchmark (torch) -------------------------------------
+def coverage_runs(L, seed, p_n=0.01, mean_len=500, frac_lo=0.005, frac_hi=0.30):
+    """Coverage gaps as real consensus alignments have them: RUNS of consecutive sites (geometric lengths, mean `mean_len`), each
+    lost by a random fraction of the samples (uniform in [frac_lo, frac_hi]) -- runs are drawn until a sample is N at p_n of the
+    sites on average.  -> (start, end, fraction) arrays, in draw order; sample s loses run r iff member(s)[r] (below)."""
+    rng = np.random.default_rng([int(seed), 7919])
+    starts, ends, fracs, covered = [], [], [], 0.0
+    while covered < p_n * L:
+        ln = int(min(L, rng.geometric(1.0 / mean_len)))
+        st = int(rng.integers(0, L - ln + 1))
+        fr = float(rng.uniform(frac_lo, frac_hi))
+        starts.append(st); ends.append(st + ln); fracs.append(fr)
+        covered += ln * fr
+    return np.array(starts, dtype=np.int64), np.array(ends, dtype=np.int64), np.array(fracs)
+
+
+def run_members(seed, s, fracs):
+    """which runs sample s loses (deterministic in seed and s, whatever the batch it is generated in)"""
+    return np.random.default_rng([int(seed), 104729, int(s)]).random(len(fracs)) < fracs
+
+
 def generate_device(n, L, seed, emit, mu_lineage=1e-5, mu_sample=1e-6, n_lineages=None, p_n=0.01, batch=32,
-                    limit=None, p_partial=0.0, n_every=1):
+                    limit=None, p_partial=0.0, n_every=1, runs=None):
     """The same two-level model generated on the GPU in batches of `batch` samples; every batch
     (uint8 [cnt, L] ASCII on the device) is handed to emit(rows, first).  Deterministic in `seed`;
     `limit` stops after the first `limit` samples (same values as a full run).  n_every = k: only every k-th sample carries
-    N, at k p_n sites (the same amount of N, concentrated in 1 / k of the samples).  Setup code, untimed."""
+    N, at k p_n sites (the same amount of N, concentrated in 1 / k of the samples).  runs = dict(p_n=, mean_len=, frac_lo=,
+    frac_hi=): N in runs of consecutive sites shared by subsets of the samples (coverage_runs).  Setup code, untimed."""
     import torch
     dev = torch.device("cuda", torch.cuda.current_device())
     g = torch.Generator(device=dev)
@@ -131,6 +152,9 @@ def generate_device(n, L, seed, emit, mu_lineage=1e-5, mu_sample=1e-6, n_lineage
             out[pos] = (out[pos] + torch.randint(1, 4, (k,), generator=g, device=dev, dtype=torch.int8)[:pos.numel()]) & 3
         return out
     founders = [mutate(anc, mu_lineage) for _ in range(n_lineages)]
+    if runs:                                  # N in runs of sites shared by subsets of the samples (coverage_runs) -- beside p_n's iid N
+        r_start, r_end, r_frac = coverage_runs(L, seed, **runs)
+        r_start_d, r_end_d = torch.from_numpy(r_start).to(dev), torch.from_numpy(r_end).to(dev)
     stop = n if limit is None else min(n, limit)
     for s0 in range(0, stop, batch):
         cnt = min(batch, n - s0)
@@ -141,6 +165,13 @@ def generate_device(n, L, seed, emit, mu_lineage=1e-5, mu_sample=1e-6, n_lineage
             if p_n > 0 and (s0 + b) % n_every == 0:
                 m = torch.rand(L, generator=g, device=dev) < min(1.0, p_n * n_every)
                 rows[b][m] = ord("N")
+            if runs:
+                mem = torch.from_numpy(run_members(seed, s0 + b, r_frac)).to(dev)
+                edge = torch.zeros(L + 1, dtype=torch.int32, device=dev)
+                one = torch.ones(int(mem.sum().item()), dtype=torch.int32, device=dev)
+                edge.index_add_(0, r_start_d[mem], one)
+                edge.index_add_(0, r_end_d[mem], -one)
+                rows[b][torch.cumsum(edge, 0)[:L] > 0] = ord("N")
             if p_partial > 0:       # two/three-allele IUPAC codes at uniformly random sites (SURVEY.md 8d, config 4 mix)
                 m = torch.rand(L, generator=g, device=dev) < p_partial
                 k = int(m.sum().item())
