@@ -225,11 +225,28 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
-        backend = os.environ.get("TRACS_BENCH_BACKEND", "nccl")      # "nccl" IS RCCL on ROCm
+        # the exchange: the library's own RCCL entry points (include/tracs_hip.h part 4, csrc/comm.cpp) behind tracs_amd.rccl.RcclDist
+        # -- torch only launched the processes and lends the rendezvous store --; TRACS_BENCH_BACKEND=nccl: torch.distributed over
+        # RCCL; gloo: torch.distributed over gloo (several ranks on one GPU: the smoke test)
+        from tracs_amd import rccl
+        backend = rccl.backend_choice(world, ndev, "TRACS_BENCH_BACKEND")
+        if backend == "rccl":
+            try:
+                cand = rccl.RcclDist(device)
+                if not cand.self_test():
+                    raise RuntimeError("self-test failed")
+                dist = cand
+            except Exception as e:                                # noqa: BLE001
+                print("bench: no RCCL communicator through libtracs_hip (%s); torch.distributed instead" % e, file=sys.stderr, flush=True)
+                backend = "nccl"
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
-        else:
+        elif backend != "rccl":
             dist.init_process_group(backend)
+        exchange = {"rccl": "libtracs_hip.so: RCCL behind the C ABI (tracs_allgather_panels, tracs_allreduce)",
+                    "nccl": "torch.distributed over RCCL", "gloo": "torch.distributed over gloo"}.get(backend, backend)
+    else:
+        exchange = None
 
     n, L = args.samples, args.sites
     seed = 20241022 + 2
@@ -508,7 +525,7 @@ def main():
                           "partition": "row panels, fold pairing, %d rank(s); RCCL all-gather of the d / nn panels%s; P and E(K) derived on every "
                                        "rank from the gathered d, key evaluations split over the ranks (key-table all-reduce)"
                                        % (world, "" if cp is None else " (%d bytes per cell: 16 bits where the values fit)" % cp.bytes_per_cell()),
-                          "workload_name": args.workload,
+                          "workload_name": args.workload, "exchange": exchange,
                           "streams": ("2: transcluster on a second stream beside the rest of the dense call, from the moment the distances "
                                       "are final (tracs_pairsnp_notify_distances)") if overlap else "1",
                           "setup_seconds": round(setup_s, 1), "first_call_ms": round(t_first * 1e3, 1), "checksum_d": checksum},

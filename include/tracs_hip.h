@@ -324,6 +324,38 @@ void tracs_edges_free(tracs_edge_list *e);
 int tracs_combine_fasta(const char *out_path, const char *const *sample_names, const char *const *fasta_paths,
                         size_t n, int n_threads, int gzip_level, double *frac_n, uint64_t *lengths);
 
+/* ===================================================================================== */
+/* (4) MULTI-GPU EXCHANGE -- RCCL over xGMI, one communicator rank per process             */
+/* ===================================================================================== */
+
+/* The reference is one process (OpenMP, src/pairsnp.hpp:380-382); SURVEY.md 8e / north_star: the pair space is block-
+ * partitioned over the GPUs of one node, every rank holds the packed alignment, no collective during compute, the per-rank
+ * distance panels are exchanged at the end.  These entry points are that exchange (csrc/comm.cpp over rccl.h; RCCL is opened
+ * when the first communicator is made, so a single-GPU host needs none).  Every call enqueues on `stream` of the CURRENT
+ * device (hipSetDevice before tracs_comm_create) and returns; results are valid once the stream has reached them.
+ *   tracs_comm_unique_id   rank 0 draws an id (TRACS_COMM_ID_BYTES bytes) and hands it to the other ranks by any host means
+ *   tracs_comm_create      collective: every rank of the job calls it with the same id and its own rank
+ *   tracs_bcast_planes     the packed planes of `root` (the rank that read the FASTA) -> every rank's handle of the same
+ *                          shape; the receiving handles forget every derived form (tracs_alignment_touch)
+ *   tracs_allgather_panels in place: every rank lays out `base` alike, rank q's block is the `bytes` bytes at
+ *                          base + offsets[q] (offsets: host array of `world` entries); afterwards every rank holds every block.
+ *                          Row panels of a row-major pair matrix are such blocks (tracs_amd/partition.py)
+ *   tracs_allreduce        dtype 0 int64, 1 float64, 2 uint32, 3 uint8; op 0 sum, 1 max, 2 min; in place
+ *   tracs_send / _recv     `bytes` bytes to / from rank `peer` (variable-length COO payloads to the rank that writes the CSV) */
+#define TRACS_COMM_ID_BYTES 128
+typedef struct tracs_comm tracs_comm;
+int tracs_comm_unique_id(void *id, size_t cap);
+int tracs_comm_create(const void *id, int rank, int world, tracs_comm **out);
+void tracs_comm_free(tracs_comm *c);
+int tracs_comm_rank(const tracs_comm *c);
+int tracs_comm_world(const tracs_comm *c);
+int tracs_bcast(tracs_comm *c, void *buf, size_t bytes, int root, void *stream);
+int tracs_bcast_planes(tracs_comm *c, tracs_alignment *a, int root, void *stream);
+int tracs_allgather_panels(tracs_comm *c, void *base, const size_t *offsets, size_t bytes, void *stream);
+int tracs_allreduce(tracs_comm *c, void *buf, size_t count, int dtype, int op, void *stream);
+int tracs_send(tracs_comm *c, const void *buf, size_t bytes, int peer, void *stream);
+int tracs_recv(tracs_comm *c, void *buf, size_t bytes, int peer, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -164,3 +164,41 @@ def test_connected_components_matches_scipy_order(api, oracle):
         enc, elab = connected_components(csgraph=G, directed=False, return_labels=True)
         assert nc == enc and np.array_equal(lab, elab)
         assert np.array_equal(lab, oracle.connected_components(n, I, J))
+
+
+GRID_CHILD = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %(root)r)
+from tracs_amd import device as dev, synth
+n = 1500
+g = torch.Generator(device="cuda"); g.manual_seed(5)
+d = torch.randint(0, 400, (n, n), generator=g, device="cuda", dtype=torch.int32)
+d[torch.rand((n, n), generator=g, device="cuda") < 0.3] = 7            # many repeated keys
+_, days_np = synth.dates(n, seed=11)
+days = torch.from_numpy(days_np).cuda()
+out = []
+for ranges, thr, col in (([(0, n)], 2147483647, 0), ([(100, 333), (901, 1500)], 250, 64)):
+    p = torch.full((n, n), -7.0, dtype=torch.float64, device="cuda"); e = torch.full((n, n), -7.0, dtype=torch.float64, device="cuda")
+    dev.trans_dist_dense_ranges(d, n, days, 29.903, 73.0, 0.01, p, e, ranges, exp_p0=True, dist_threshold=thr, col_begin=col)
+    out += [p.cpu().numpy(), e.cpu().numpy()]
+np.savez(sys.argv[1], *out)
+'''
+
+
+def test_trans_dist_dense_grid_route_equals_hash_route(hiplib, tmp_path):
+    """Dense blocks mark their distinct (N, day gap) keys in a grid (csrc/transcluster.hip: tc_mark_kernel) instead of hashing
+    them; TRACS_TC_GRID=0 keeps the hash route.  Same keys, same evaluation: every cell bit-equal, untouched cells untouched --
+    whole matrix, and two row panels with a distance threshold and a column bound."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for name, env in (("grid", {}), ("hash", {"TRACS_TC_GRID": "0"})):
+        f = os.path.join(str(tmp_path), name + ".npz")
+        out = subprocess.run([sys.executable, "-c", GRID_CHILD % {"root": root}, f], capture_output=True, text=True,
+                             env=dict(os.environ, **env), timeout=900, cwd=root)
+        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+        got[name] = np.load(f)
+    for k in got["grid"].files:
+        a, b = got["grid"][k], got["hash"][k]
+        assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), k
+    assert (got["grid"]["arr_0"] != -7.0).sum() == 1500 * 1499 // 2

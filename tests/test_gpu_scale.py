@@ -188,6 +188,55 @@ print("RCCL OK", torch.cuda.nccl.version() if hasattr(torch.cuda, "nccl") else "
     assert out.returncode == 0 and "RCCL OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
+def test_rccl_through_the_c_abi_world_one():
+    """The same calls through the LIBRARY's RCCL entry points (include/tracs_hip.h part 4: tracs_comm_create,
+    tracs_allgather_panels, tracs_allreduce, tracs_bcast_planes) behind tracs_amd.rccl.RcclDist, on a world of one rank with the
+    communicator id carried by a store -- what bench.py --gpus N and `tracs distance --gpus N` use when every rank has a GPU."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys, numpy as np, torch, torch.distributed as tdist
+sys.path.insert(0, %r)
+from tracs_amd import partition, rccl, device as dev_, synth
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist = rccl.RcclDist(dev, store=tdist.HashStore(), rank=0, world=1)
+assert dist.self_test()
+m = torch.arange(128 * 50, dtype=torch.int32, device=dev).reshape(128, 50)
+out = torch.zeros_like(m)
+w = dist.all_gather([out[0:64]], m[0:64], async_op=True); w.wait()
+dist.all_gather([out[64:128].view(torch.uint8)], m[64:128].view(torch.uint8))
+torch.cuda.synchronize()
+assert bool(torch.equal(out, m))
+t = torch.ones((2, 7, 9), dtype=torch.float64, device=dev)
+dist.all_reduce(t); torch.cuda.synchronize(); assert float(t.sum()) == 126.0
+v = torch.tensor([3, -5, 9], dtype=torch.int64, device=dev)
+dist.all_reduce(v, op=dist.ReduceOp.MAX); torch.cuda.synchronize(); assert v.tolist() == [3, -5, 9]
+cp = partition.CompactPanels(100, 0, 1, dist)
+d = torch.triu(torch.randint(0, 60000, (128, 100), dtype=torch.int32, device=dev), 1)
+nn = torch.triu(torch.randint(4000000, 4060000, (128, 100), dtype=torch.int32, device=dev), 1)
+assert cp.decide(d, nn)[:2] == (True, True) and cp.check(d, nn)
+got = partition.gather_coo({0: (torch.arange(4, device=dev),), 1: (torch.arange(3, device=dev),)}, 1, 0, dist)
+assert got[0].tolist() == [0, 1, 2, 3, 0, 1, 2]
+objs = [("n", 5), None]
+dist.broadcast_object_list(objs, src=0); assert objs == [("n", 5), None]
+# the packed planes through tracs_bcast_planes (root = this rank: the handle stays as it is), then a dense call on it
+seqs = synth.alignment(70, 3000, seed=3, mu_lineage=1e-3, mu_sample=1e-3, p_n=0.02)
+aln = dev_.Alignment(70, 3000); aln.pack(seqs)
+dist.broadcast_planes(aln, src=0)
+dm = torch.zeros((70, 70), dtype=torch.int32, device=dev); dev_.pairsnp_dense(aln, dm, None)
+from oracle import oracle as O
+er, ec, ed, enn = O.pairsnp_arrays(seqs)
+assert np.array_equal(dm.cpu().numpy()[er.astype(np.int64), ec.astype(np.int64)], ed.astype(np.int32))
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL C ABI OK")
+"""
+    out = subprocess.run([sys.executable, "-c", code % root], capture_output=True, text=True, timeout=600, cwd=root,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
+    assert out.returncode == 0 and "RCCL C ABI OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
 @pytest.mark.parametrize("mode", ["plain", "thresholded+filter+db"])
 def test_distance_cli_two_ranks_equals_one(mode, tmp_path):
     """`tracs distance --gpus 2` (one process per rank, row-chunk partition, COO gather on rank 0; two gloo ranks sharing the

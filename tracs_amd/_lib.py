@@ -31,6 +31,8 @@ SYMBOLS = [
     "tracs_pileup_counts", "tracs_write_posterior_csv", "tracs_combine_fasta", "tracs_write_distance_rows",
     "tracs_read_distance_edges", "tracs_edges_count", "tracs_edges_rows", "tracs_edges_n_names", "tracs_edges_name", "tracs_edges_i",
     "tracs_edges_j", "tracs_edges_free",
+    "tracs_comm_unique_id", "tracs_comm_create", "tracs_comm_free", "tracs_comm_rank", "tracs_comm_world", "tracs_bcast",
+    "tracs_bcast_planes", "tracs_allgather_panels", "tracs_allreduce", "tracs_send", "tracs_recv",
 ]
 
 
@@ -216,6 +218,28 @@ def load():
     L.tracs_debug_pack_stages.argtypes = [C.c_char_p, sz, C.POINTER(C.c_float), C.c_int]
     L.tracs_debug_pack_stage_bytes.restype = C.c_int
     L.tracs_debug_pack_stage_bytes.argtypes = [dp, dp, C.c_int]
+    L.tracs_comm_unique_id.restype = C.c_int
+    L.tracs_comm_unique_id.argtypes = [vp, sz]
+    L.tracs_comm_create.restype = C.c_int
+    L.tracs_comm_create.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
+    L.tracs_comm_free.restype = None
+    L.tracs_comm_free.argtypes = [vp]
+    L.tracs_comm_rank.restype = C.c_int
+    L.tracs_comm_rank.argtypes = [vp]
+    L.tracs_comm_world.restype = C.c_int
+    L.tracs_comm_world.argtypes = [vp]
+    L.tracs_bcast.restype = C.c_int
+    L.tracs_bcast.argtypes = [vp, vp, sz, C.c_int, vp]
+    L.tracs_bcast_planes.restype = C.c_int
+    L.tracs_bcast_planes.argtypes = [vp, vp, C.c_int, vp]
+    L.tracs_allgather_panels.restype = C.c_int
+    L.tracs_allgather_panels.argtypes = [vp, vp, C.POINTER(sz), sz, vp]
+    L.tracs_allreduce.restype = C.c_int
+    L.tracs_allreduce.argtypes = [vp, vp, sz, C.c_int, C.c_int, vp]
+    L.tracs_send.restype = C.c_int
+    L.tracs_send.argtypes = [vp, vp, sz, C.c_int, vp]
+    L.tracs_recv.restype = C.c_int
+    L.tracs_recv.argtypes = [vp, vp, sz, C.c_int, vp]
     L.tracs_debug_lists.restype = sz
     L.tracs_debug_lists.argtypes = [vp, C.c_int, vp, sz]
     L.tracs_debug_pair_timing.restype = None

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libtracs_hip.so")
-SOURCES = ["capi.hip", "pairsnp.hip", "pairsnp_mfma.hip", "general_sparse.hip", "site_lists.hip", "site_classes.hip", "transcluster.hip", "dmultinomial.hip", "cluster.hip", "filter.hip", "dirichlet.hip", "fasta.cpp", "alignio.cpp"]
+SOURCES = ["capi.hip", "pairsnp.hip", "pairsnp_mfma.hip", "general_sparse.hip", "site_lists.hip", "site_classes.hip", "transcluster.hip", "dmultinomial.hip", "cluster.hip", "filter.hip", "dirichlet.hip", "fasta.cpp", "alignio.cpp", "comm.cpp"]
 HEADERS = ["common.h", "pairsnp_kernels.h", "fasta.h", os.path.join("..", "..", "include", "tracs_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fgpu-rdc" if False else "-fno-gpu-rdc",
@@ -53,7 +53,7 @@ def build(force=False, verbose=False, extra_flags=(), libdir=None):
         raise RuntimeError("libtracs_hip.so: compilation failed")
     # link next to the target and rename over it: a process that has the old file mapped keeps its own copy
     tmp = lib + ".tmp.%d" % os.getpid()
-    cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", tmp] + objs + ["-lz"]
+    cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", tmp] + objs + ["-lz", "-ldl"]
     out = subprocess.run(cmd, capture_output=True, text=True)
     if out.returncode != 0:
         raise RuntimeError("libtracs_hip.so: link failed:\n" + out.stdout + out.stderr)

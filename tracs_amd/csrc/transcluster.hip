@@ -415,6 +415,24 @@ struct DenseSource {            // cells of a dense distance block, delta from s
     static constexpr bool HAS_GAPS = true;
 };
 
+// The keys themselves as a source: element e of the (N, day gap) grid of stride `stride` = gap_max + 1.  What the key kernels read
+// when the distinct keys of a dense block were MARKED in that grid (tc_mark_kernel) instead of found by hashing: key_elem holds
+// grid indices, N and delta come from the index -- delta by the same expression as DenseSource::get, bit for bit.
+struct GridSource {
+    unsigned stride;
+    size_t cells;
+    __device__ size_t size() const { return cells; }
+    __device__ bool get(size_t e, int &Nv, double &dv) const
+    {
+        Nv = (int)(e / stride);
+        dv = (double)((long long)(e % stride) * 86400ll) / 31556952.0;
+        return true;
+    }
+    __device__ size_t out_index(size_t e) const { return e; }
+    __device__ long long day_gap(size_t e) const { return (long long)(e % stride); }
+    static constexpr bool HAS_GAPS = true;
+};
+
 // Key table of the multi-GPU path: results of the distinct (N, day gap) keys in a dense [n_max + 1][d_max + 1] layout that
 // every rank indexes the same way.  A rank evaluates the keys of its hash class (part of parts) and leaves the others 0, so an
 // all-reduce (sum) of the tables completes them: 16 bytes per key travel instead of 16 bytes per pair, and a rank pays for
@@ -653,6 +671,107 @@ __global__ void tc_gather_kernel(Src src, const unsigned *__restrict__ eslot, co
     }
 }
 
+// ---- dense blocks whose keys fit a grid: no hash table, no per-cell slot array ---------------------------------------------------
+// trans_dist memoises per (N, delta) key (src/transcluster.hpp:245-246,265-282).  The keys of a dense block are (SNP distance, day
+// gap): when (largest distance + 1) x (largest gap + 1) <= TC_GRID_BITS they are marked in a bitmap indexed by the key itself (2 MB,
+// L2-resident; a cell whose bit is set already costs one cached read), the set bits ARE the distinct keys, their results go into
+// the dense (N, gap) tables the multi-GPU path already uses, and every cell reads its values from there -- round 3 wrote a 4-byte
+// hash slot per cell (400 MB at 10 000 samples), claimed slots with atomicCAS and read the slots back to gather.
+constexpr unsigned long long TC_GRID_BITS = 1ull << 24;
+
+// cb[0] = largest distance of a valid cell, cb[1] = smallest day + 2^31, cb[2] = largest day + 2^31 (over all samples)
+__global__ void tc_cell_bounds_kernel(DenseSource src, unsigned *__restrict__ cb)
+{
+    const size_t total = src.size();
+    unsigned mn = 0;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        int N; double d;
+        if (src.get(e, N, d)) mn = max(mn, (unsigned)N);
+    }
+    unsigned lo = 0xFFFFFFFFu, hi = 0u;
+    if (blockIdx.x == 0)
+        for (size_t s = threadIdx.x; s < src.n; s += blockDim.x) { const unsigned v = (unsigned)src.days[s] + 0x80000000u; lo = min(lo, v); hi = max(hi, v); }
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = max(mn, (unsigned)__shfl_xor((int)mn, off, 64));
+        lo = min(lo, (unsigned)__shfl_xor((int)lo, off, 64)); hi = max(hi, (unsigned)__shfl_xor((int)hi, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { atomicMax(&cb[0], mn); if (blockIdx.x == 0) { atomicMin(&cb[1], lo); atomicMax(&cb[2], hi); } }
+}
+
+// cb[3] = 1 when the grid does not fit; otherwise bit N * stride + gap of every valid cell's key
+__global__ void tc_mark_kernel(DenseSource src, unsigned *__restrict__ cb, unsigned *__restrict__ bits)
+{
+    const unsigned long long stride = (unsigned long long)(cb[2] - cb[1]) + 1ull;
+    if (((unsigned long long)cb[0] + 1ull) * stride > TC_GRID_BITS || cb[2] < cb[1]) { if (blockIdx.x == 0 && threadIdx.x == 0) cb[3] = 1u; return; }
+    const size_t total = src.size();
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        int N; double d;
+        if (!src.get(e, N, d)) continue;
+        const unsigned idx = (unsigned)((unsigned long long)N * stride + (unsigned long long)src.day_gap(e));
+        const unsigned bit = 1u << (idx & 31u);
+        if (!(bits[idx >> 5] & bit)) atomicOr(&bits[idx >> 5], bit);
+    }
+}
+
+__global__ void tc_bits_count_kernel(const unsigned *__restrict__ bits, unsigned words, unsigned *__restrict__ n_keys)
+{
+    unsigned c = 0;
+    for (unsigned w = blockIdx.x * blockDim.x + threadIdx.x; w < words; w += gridDim.x * blockDim.x) c += __popc(bits[w]);
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(n_keys, c);
+}
+
+__global__ void tc_bits_collect_kernel(const unsigned *__restrict__ bits, unsigned words, unsigned *__restrict__ key_elem, unsigned *__restrict__ n_keys)
+{
+    for (unsigned w = blockIdx.x * blockDim.x + threadIdx.x; w < words; w += gridDim.x * blockDim.x) {
+        unsigned x = bits[w];
+        if (!x) continue;
+        unsigned id = atomicAdd(n_keys, (unsigned)__popc(x));
+        while (x) { key_elem[id++] = w * 32u + (unsigned)(__ffs(x) - 1); x &= x - 1; }
+    }
+}
+
+// P / E(K) of every cell from the completed key tables, two cells of a row per thread: 8-byte loads of d, 16-byte stores of P and
+// E(K) where both cells are cells of the block (the pair straddling the diagonal or the column bound stores singly)
+__global__ void tc_table_gather2_kernel(DenseSource src, KeyTable kt, int exp_p0, double *__restrict__ p0, double *__restrict__ eK)
+{
+    const size_t half = (src.n + 1) / 2, rows = src.rows1() + (src.row_end2 - src.row_begin2);
+    const size_t total = rows * half;
+    const bool wide_ok = (src.ld % 2 == 0) && ((reinterpret_cast<size_t>(p0) | reinterpret_cast<size_t>(eK)) % 16 == 0) &&
+                         (reinterpret_cast<size_t>(src.dist) % 8 == 0);
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = src.row_of(t / half), j0 = (t % half) * 2;
+        if (j0 + 1 <= i || j0 + 1 < src.col_begin) continue;                 // neither cell is a cell of the block
+        double vp[2], ve[2];
+        bool ok[2];
+        unsigned dd[2];
+        const bool two = j0 + 1 < src.n;
+        if (wide_ok && two) { const uint2 q = *reinterpret_cast<const uint2 *>(src.dist + i * src.ld + j0); dd[0] = q.x; dd[1] = q.y; }
+        else { dd[0] = src.dist[i * src.ld + j0]; dd[1] = two ? src.dist[i * src.ld + j0 + 1] : 0u; }
+        const long long di = (long long)src.days[i];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const size_t j = j0 + k;
+            ok[k] = j < src.n && j > i && j >= src.col_begin && (long long)dd[k] <= (long long)src.thr;
+            vp[k] = ve[k] = 0.0;
+            if (ok[k]) {
+                const long long g = di - (long long)src.days[j];
+                const long long slot = kt.index((int)dd[k], g < 0 ? -g : g);
+                ok[k] = slot >= 0;
+                if (ok[k]) { const double v = kt.p0[slot]; vp[k] = exp_p0 ? exp(v) : v; ve[k] = kt.eK[slot]; }
+            }
+        }
+        const size_t o = i * src.ld + j0;
+        if (wide_ok && ok[0] && ok[1]) {
+            *reinterpret_cast<double2 *>(p0 + o) = make_double2(vp[0], vp[1]);
+            *reinterpret_cast<double2 *>(eK + o) = make_double2(ve[0], ve[1]);
+        } else {
+            if (ok[0]) { p0[o] = vp[0]; eK[o] = ve[0]; }
+            if (ok[1]) { p0[o + 1] = vp[1]; eK[o + 1] = ve[1]; }
+        }
+    }
+}
+
 // lprob_k_given_N (older formulation, exported for tests/test_llk.py): transcluster.hpp:90-129
 __global__ void lprob_k_given_N_kernel(const unsigned long long *__restrict__ Ns, const unsigned long long *__restrict__ ks,
                                        const double *__restrict__ deltas, size_t n, double lamb, double beta,
@@ -711,64 +830,27 @@ static int get_lgamma_table(hipStream_t stream, const double **out)
 
 int get_lgamma_table_for_filter(hipStream_t stream, const double **out) { return get_lgamma_table(stream, out); }
 
-struct TcWorkspaceIds { enum { SLOTS = 0, ESLOT, SLOT_ID, NKEYS, KEY_ELEM, KEY_P0, KEY_EK, LONG_IDS, KEY_STATE, TAB, TAB_LNS, TAB_POIS }; };
+struct TcWorkspaceIds { enum { SLOTS = 0, ESLOT, SLOT_ID, NKEYS, KEY_ELEM, KEY_P0, KEY_EK, LONG_IDS, KEY_STATE, TAB, TAB_LNS, TAB_POIS, GRID_BITS, GRID_TABLES }; };
 constexpr unsigned long long TC_POIS_ELEMS = 16ull << 20;        // doubles in the pois table (128 MB)
 
 static unsigned long long g_last_keys = 0;        // distinct (N, delta) keys of the last entry-point call (bench.py reports it)
 constexpr size_t TD_MAX_ELEMS = 1ull << 31;       // elements per pass: element indices and slots are 32-bit
 
+// The distinct keys are known (key_elem[0 .. nk): elements of `src` that carry them; n_keys[0] = nk on the device, n_keys[1] = 0):
+// evaluate each once -- short series by one thread, long ones by a wave, dense blocks with the (gap, M) tables of their prefix sums.
+// Results in key_p0 / key_eK (by key id) and, when kt has tables, at kt.index(N, gap).
 template <class Src>
-static int run_trans_dist(const Src &src, size_t total, double lamb, double beta, double thr, int exp_p0, double *p0,
-                          double *eK, hipStream_t stream, const KeyTable &kt = KeyTable())
+static int tc_evaluate_keys(const Src &src, const unsigned *key_elem, unsigned nk, unsigned *n_keys, double lamb, double beta, double thr,
+                            const double *lg, double **key_p0_out, double **key_eK_out, const KeyTable &kt, hipStream_t stream)
 {
-    if (total == 0) return TRACS_OK;
-    DeviceCall guard(stream);
-    if (total > TD_MAX_ELEMS) { set_error("trans_dist: more than 2^31 elements per pass (internal error)"); return TRACS_E_ARG; }
-    const double *lg = nullptr;
-    int rc = get_lgamma_table(stream, &lg);
-    if (rc) return rc;
-    unsigned cap_max = 1024;
-    while ((size_t)cap_max < 2 * total && cap_max < (1u << 31)) cap_max <<= 1;
-    unsigned cap = std::min(cap_max, 1u << 20);
-    unsigned *slots, *eslot, *slot_id, *n_keys, *key_elem, *long_ids;
+    int rc;
+    unsigned *long_ids;
     double *key_p0, *key_eK;
-    if ((rc = workspace_get(TcWorkspaceIds::ESLOT, total * 4, reinterpret_cast<void **>(&eslot)))) return rc;
-    if ((rc = workspace_get(TcWorkspaceIds::NKEYS, 64, reinterpret_cast<void **>(&n_keys)))) return rc;
-    const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 32);
-    unsigned nk = 0;
-    for (;;) {
-        if ((rc = workspace_get(TcWorkspaceIds::SLOTS, (size_t)cap * 4, reinterpret_cast<void **>(&slots)))) return rc;
-        if ((rc = workspace_get(TcWorkspaceIds::SLOT_ID, (size_t)cap * 4, reinterpret_cast<void **>(&slot_id)))) return rc;
-        TRACS_HIP_CHECK(hipMemsetAsync(slots, 0xFF, (size_t)cap * 4, stream));
-        TRACS_HIP_CHECK(hipMemsetAsync(n_keys, 0, 16, stream));     // [0] keys, [1] long keys, [2] overflow flag
-        hipLaunchKernelGGL((dedup_insert_kernel<Src>), dim3(blocks), dim3(256), 0, stream, src, slots, cap - 1, eslot, n_keys + 2);
-        TRACS_HIP_CHECK(hipGetLastError());
-        // first pass over the table only counts the claimed slots so the key arrays can be sized
-        // exactly (one small readback per call), the second assigns ids.
-        hipLaunchKernelGGL(dedup_count_kernel, dim3((unsigned)std::min<size_t>((cap + 255) / 256, 256 * 32)), dim3(256), 0, stream,
-                           slots, cap, n_keys);
-        unsigned h3[3] = {0, 0, 0};
-        TRACS_HIP_CHECK(hipMemcpyAsync(h3, n_keys, 12, hipMemcpyDeviceToHost, stream));
-        TRACS_HIP_CHECK(hipStreamSynchronize(stream));
-        nk = h3[0];
-        if (!h3[2] && (size_t)nk * 2 <= cap) break;                 // fits with load factor <= 0.5
-        if (cap >= cap_max) {
-            if (h3[2]) { set_error("trans_dist: key table overflow"); return TRACS_E_HIP; }
-            break;
-        }
-        cap = (unsigned)std::min<unsigned long long>((unsigned long long)cap * 16ull, cap_max);
-    }
-    g_last_keys += nk;
-    if (nk == 0) return TRACS_OK;
-    if ((rc = workspace_get(TcWorkspaceIds::KEY_ELEM, (size_t)nk * 4, reinterpret_cast<void **>(&key_elem)))) return rc;
     if ((rc = workspace_get(TcWorkspaceIds::KEY_P0, (size_t)nk * 8, reinterpret_cast<void **>(&key_p0)))) return rc;
     if ((rc = workspace_get(TcWorkspaceIds::KEY_EK, (size_t)nk * 8, reinterpret_cast<void **>(&key_eK)))) return rc;
     if ((rc = workspace_get(TcWorkspaceIds::LONG_IDS, (size_t)nk * 4, reinterpret_cast<void **>(&long_ids)))) return rc;
     double *key_state = nullptr;
     if ((rc = workspace_get(TcWorkspaceIds::KEY_STATE, (size_t)nk * 32, reinterpret_cast<void **>(&key_state)))) return rc;
-    TRACS_HIP_CHECK(hipMemsetAsync(n_keys, 0, 8, stream));          // [0] key counter, [1] long-key counter
-    hipLaunchKernelGGL(dedup_collect_kernel, dim3((unsigned)std::min<size_t>((cap + 255) / 256, 256 * 32)), dim3(256), 0, stream,
-                       slots, cap, slot_id, key_elem, n_keys);
     TcParams P;
     P.lamb = lamb; P.beta = beta; P.thr = thr;
     P.ln_lamb = P.ln_beta = P.ln_lb = 0.0;
@@ -798,9 +880,116 @@ static int run_trans_dist(const Src &src, size_t total, double lamb, double beta
     // long series (E(K) loop beyond TC_SERIAL_CAP terms): one wave per key
     hipLaunchKernelGGL((tc_long_keys_kernel<Src>), dim3(std::min<unsigned>(nk, 256u * 32u)), dim3(64), 0, stream, src, key_elem,
                        long_ids, n_keys + 1, P, lg, key_p0, key_eK, key_state, kt, tab);
+    *key_p0_out = key_p0; *key_eK_out = key_eK;
+    return TRACS_OK;
+}
+
+template <class Src>
+static int run_trans_dist(const Src &src, size_t total, double lamb, double beta, double thr, int exp_p0, double *p0,
+                          double *eK, hipStream_t stream, const KeyTable &kt = KeyTable())
+{
+    if (total == 0) return TRACS_OK;
+    DeviceCall guard(stream);
+    if (total > TD_MAX_ELEMS) { set_error("trans_dist: more than 2^31 elements per pass (internal error)"); return TRACS_E_ARG; }
+    const double *lg = nullptr;
+    int rc = get_lgamma_table(stream, &lg);
+    if (rc) return rc;
+    unsigned cap_max = 1024;
+    while ((size_t)cap_max < 2 * total && cap_max < (1u << 31)) cap_max <<= 1;
+    unsigned cap = std::min(cap_max, 1u << 20);
+    unsigned *slots, *eslot, *slot_id, *n_keys, *key_elem;
+    if ((rc = workspace_get(TcWorkspaceIds::ESLOT, total * 4, reinterpret_cast<void **>(&eslot)))) return rc;
+    if ((rc = workspace_get(TcWorkspaceIds::NKEYS, 64, reinterpret_cast<void **>(&n_keys)))) return rc;
+    const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 32);
+    unsigned nk = 0;
+    for (;;) {
+        if ((rc = workspace_get(TcWorkspaceIds::SLOTS, (size_t)cap * 4, reinterpret_cast<void **>(&slots)))) return rc;
+        if ((rc = workspace_get(TcWorkspaceIds::SLOT_ID, (size_t)cap * 4, reinterpret_cast<void **>(&slot_id)))) return rc;
+        TRACS_HIP_CHECK(hipMemsetAsync(slots, 0xFF, (size_t)cap * 4, stream));
+        TRACS_HIP_CHECK(hipMemsetAsync(n_keys, 0, 16, stream));     // [0] keys, [1] long keys, [2] overflow flag
+        hipLaunchKernelGGL((dedup_insert_kernel<Src>), dim3(blocks), dim3(256), 0, stream, src, slots, cap - 1, eslot, n_keys + 2);
+        TRACS_HIP_CHECK(hipGetLastError());
+        // first pass over the table only counts the claimed slots so the key arrays can be sized
+        // exactly (one small readback per call), the second assigns ids.
+        hipLaunchKernelGGL(dedup_count_kernel, dim3((unsigned)std::min<size_t>((cap + 255) / 256, 256 * 32)), dim3(256), 0, stream,
+                           slots, cap, n_keys);
+        unsigned h3[3] = {0, 0, 0};
+        TRACS_HIP_CHECK(hipMemcpyAsync(h3, n_keys, 12, hipMemcpyDeviceToHost, stream));
+        TRACS_HIP_CHECK(hipStreamSynchronize(stream));
+        nk = h3[0];
+        if (!h3[2] && (size_t)nk * 2 <= cap) break;                 // fits with load factor <= 0.5
+        if (cap >= cap_max) {
+            if (h3[2]) { set_error("trans_dist: key table overflow"); return TRACS_E_HIP; }
+            break;
+        }
+        cap = (unsigned)std::min<unsigned long long>((unsigned long long)cap * 16ull, cap_max);
+    }
+    g_last_keys += nk;
+    if (nk == 0) return TRACS_OK;
+    if ((rc = workspace_get(TcWorkspaceIds::KEY_ELEM, (size_t)nk * 4, reinterpret_cast<void **>(&key_elem)))) return rc;
+    TRACS_HIP_CHECK(hipMemsetAsync(n_keys, 0, 8, stream));          // [0] key counter, [1] long-key counter
+    hipLaunchKernelGGL(dedup_collect_kernel, dim3((unsigned)std::min<size_t>((cap + 255) / 256, 256 * 32)), dim3(256), 0, stream,
+                       slots, cap, slot_id, key_elem, n_keys);
+    double *key_p0 = nullptr, *key_eK = nullptr;
+    if ((rc = tc_evaluate_keys(src, key_elem, nk, n_keys, lamb, beta, thr, lg, &key_p0, &key_eK, kt, stream))) return rc;
     if (p0 && eK)                        // (the key-table form fills its table only)
         hipLaunchKernelGGL((tc_gather_kernel<Src>), dim3(blocks), dim3(256), 0, stream, src, eslot, slot_id, key_p0, key_eK,
                            exp_p0, p0, eK);
+    TRACS_HIP_CHECK(hipGetLastError());
+    return TRACS_OK;
+}
+
+// A dense block whose keys fit the (N, day gap) grid: marked, evaluated into dense tables, gathered (see tc_mark_kernel).  *done = 0
+// when the grid does not fit (or its tables cannot be had): the caller takes the hash route.
+static int run_trans_dist_grid(const DenseSource &src, size_t total, double lamb, double beta, double thr, int exp_p0, double *p0,
+                               double *eK, hipStream_t stream, int *done)
+{
+    *done = 0;
+    if (total == 0) { *done = 1; return TRACS_OK; }
+    static const bool off = [] { const char *e = std::getenv("TRACS_TC_GRID"); return e && std::atoi(e) == 0; }();
+    if (off) return TRACS_OK;
+    DeviceCall guard(stream);
+    const double *lg = nullptr;
+    int rc = get_lgamma_table(stream, &lg);
+    if (rc) return rc;
+    unsigned *n_keys = nullptr, *bits = nullptr, *key_elem = nullptr;
+    constexpr unsigned words = (unsigned)(TC_GRID_BITS / 32);
+    if ((rc = workspace_get(TcWorkspaceIds::NKEYS, 64, reinterpret_cast<void **>(&n_keys)))) return rc;
+    if ((rc = workspace_get(TcWorkspaceIds::GRID_BITS, (size_t)words * 4, reinterpret_cast<void **>(&bits)))) return rc;
+    unsigned *cb = n_keys + 4;                                       // [4] max N, [5] min day, [6] max day, [7] does not fit
+    const unsigned init[8] = {0u, 0u, 0u, 0u, 0u, 0xFFFFFFFFu, 0u, 0u};
+    TRACS_HIP_CHECK(hipMemcpyAsync(n_keys, init, 32, hipMemcpyHostToDevice, stream));
+    TRACS_HIP_CHECK(hipMemsetAsync(bits, 0, (size_t)words * 4, stream));
+    const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(tc_cell_bounds_kernel, dim3(blocks), dim3(256), 0, stream, src, cb);
+    hipLaunchKernelGGL(tc_mark_kernel, dim3(blocks), dim3(256), 0, stream, src, cb, bits);
+    hipLaunchKernelGGL(tc_bits_count_kernel, dim3(1024), dim3(256), 0, stream, bits, words, n_keys);
+    unsigned h[8] = {0};
+    TRACS_HIP_CHECK(hipMemcpyAsync(h, n_keys, 32, hipMemcpyDeviceToHost, stream));
+    TRACS_HIP_CHECK(hipStreamSynchronize(stream));
+    if (h[7]) return TRACS_OK;                                       // the grid does not fit: hash route
+    const unsigned nk = h[0];
+    g_last_keys += nk;
+    *done = 1;
+    if (nk == 0) return TRACS_OK;
+    const unsigned n_max = h[4], d_max = h[6] - h[5];
+    const size_t cells = ((size_t)n_max + 1) * ((size_t)d_max + 1);
+    double *tables = nullptr;
+    if (workspace_get(TcWorkspaceIds::GRID_TABLES, cells * 16, reinterpret_cast<void **>(&tables)) != TRACS_OK) {
+        (void)hipGetLastError(); set_error(""); g_last_keys -= nk; *done = 0; return TRACS_OK;
+    }
+    if ((rc = workspace_get(TcWorkspaceIds::KEY_ELEM, (size_t)nk * 4, reinterpret_cast<void **>(&key_elem)))) return rc;
+    TRACS_HIP_CHECK(hipMemsetAsync(n_keys, 0, 8, stream));          // [0] key counter, [1] long-key counter
+    hipLaunchKernelGGL(tc_bits_collect_kernel, dim3(1024), dim3(256), 0, stream, bits, words, key_elem, n_keys);
+    KeyTable kt;
+    kt.n_max = n_max; kt.d_max = d_max; kt.p0 = tables; kt.eK = tables + cells;
+    kt.overflow = n_keys + 7;                                        // (cannot happen: every cell's key was marked inside the grid)
+    GridSource grid{d_max + 1u, cells};
+    double *key_p0 = nullptr, *key_eK = nullptr;
+    if ((rc = tc_evaluate_keys(grid, key_elem, nk, n_keys, lamb, beta, thr, lg, &key_p0, &key_eK, kt, stream))) return rc;
+    const size_t pairs2 = (src.rows1() + (src.row_end2 - src.row_begin2)) * ((src.n + 1) / 2);
+    hipLaunchKernelGGL(tc_table_gather2_kernel, dim3((unsigned)std::min<size_t>((pairs2 + 255) / 256, 256 * 32)), dim3(256), 0, stream,
+                       src, kt, exp_p0, p0, eK);
     TRACS_HIP_CHECK(hipGetLastError());
     return TRACS_OK;
 }
@@ -838,8 +1027,13 @@ static int dense_passes(DenseSource src, double lamb, double beta, double thr, i
     const size_t ranges[2][2] = {{src.row_begin, src.row_end}, {src.row_begin2, src.row_end2}};
     g_last_keys = 0;
     // both panels in one pass (one key table) when they fit; else panel by panel, chunk by chunk
-    if ((ranges[0][1] - ranges[0][0]) + (ranges[1][1] - ranges[1][0]) <= rows_max)
-        return run_trans_dist(src, ((ranges[0][1] - ranges[0][0]) + (ranges[1][1] - ranges[1][0])) * src.n, lamb, beta, thr, exp_p0, p0, eK, stream);
+    if ((ranges[0][1] - ranges[0][0]) + (ranges[1][1] - ranges[1][0]) <= rows_max) {
+        const size_t total = ((ranges[0][1] - ranges[0][0]) + (ranges[1][1] - ranges[1][0])) * src.n;
+        int done = 0;
+        const int rc = run_trans_dist_grid(src, total, lamb, beta, thr, exp_p0, p0, eK, stream, &done);
+        if (rc || done) return rc;
+        return run_trans_dist(src, total, lamb, beta, thr, exp_p0, p0, eK, stream);
+    }
     for (int k = 0; k < 2; k++)
         for (size_t r0 = ranges[k][0]; r0 < ranges[k][1]; r0 += rows_max) {
             DenseSource part = src;

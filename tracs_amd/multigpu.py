@@ -37,16 +37,28 @@ def spawn(module, argv, gpus):
 
 
 def init():
-    """-> (torch.distributed, rank, world, device).  Backend: RCCL ("nccl") when every rank has its own GPU, gloo when ranks
-    share a device (smoke tests) or TRACS_DIST_BACKEND says so."""
+    """-> (dist, rank, world, device).  `dist` is the exchange: the library's own RCCL entry points behind tracs_amd.rccl.RcclDist
+    when every rank has its own GPU ("rccl": include/tracs_hip.h part 4 -- torch only launched the processes), torch.distributed
+    over gloo when ranks share a device (smoke tests), or whatever TRACS_DIST_BACKEND says ("rccl", "nccl" = torch.distributed over
+    RCCL, "gloo").  A communicator that cannot be made or fails its self-test falls back to torch.distributed's."""
     import torch
     import torch.distributed as dist
+    from . import rccl
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     ndev = torch.cuda.device_count()
     torch.cuda.set_device(local % max(ndev, 1))
     device = torch.device("cuda", local % max(ndev, 1))
-    backend = os.environ.get("TRACS_DIST_BACKEND", "nccl" if ndev >= world else "gloo")
+    backend = rccl.backend_choice(world, ndev, "TRACS_DIST_BACKEND")
+    if backend == "rccl":
+        try:
+            d = rccl.RcclDist(device)
+            if d.self_test():
+                return d, rank, world, device
+            sys.stderr.write("tracs: the RCCL communicator failed its self-test; using torch.distributed\n")
+        except Exception as e:                                   # noqa: BLE001  (every rank fails alike: RCCL missing, id not delivered)
+            sys.stderr.write("tracs: no RCCL communicator through libtracs_hip (%s); using torch.distributed\n" % e)
+        backend = "nccl"
     if not dist.is_initialized():
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
