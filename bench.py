@@ -72,6 +72,10 @@ def parse():
                     help="fraction of partial IUPAC codes in the TIMED alignment (default 0: consensus, the metric's workload)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="sparse",
                     help="synthetic alignment of the TIMED steps (default: sparse = SURVEY 8d's, the metric's workload)")
+    ap.add_argument("--partition", choices=["sites", "pairs"], default=os.environ.get("TRACS_BENCH_PARTITION", "sites"),
+                    help="N > 1: `sites` -- every rank holds a slice of the SITES and counts all pairs over it, the sums arrive as row panels "
+                         "(reduce-scatter): every stage of a call shrinks with N; `pairs` -- every rank holds the whole alignment and computes "
+                         "its row panels (all-gather): what is built once per pack is repeated on every rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline_general and dm_frontend")
     ap.add_argument("--cpu-seconds", type=float, default=6.0, help="minimum wall time of each CPU baseline leg")
@@ -250,6 +254,8 @@ def main():
 
     n, L = args.samples, args.sites
     seed = 20241022 + 2
+    if world > 1 and args.partition == "sites":
+        return site_sharded(args, n, L, seed, world, rank, device, dist, exchange)
     # ---- setup (untimed): packed alignment resident in HBM, sampling days -------------------
     t0 = time.time()
     aln = dev.Alignment(n, L)
@@ -544,6 +550,141 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def site_sharded(args, n, L, seed, world, rank, device, dist, exchange):
+    """N ranks, each with a slice of the SITES (whole 128-site groups: a contiguous 1 / N of the packed planes).  d(i, j) and the
+    compared-sites count nn(i, j) are sums over sites (src/pairsnp.hpp:398-403,417-420), so a rank runs the single-GPU call on its
+    slice for ALL pairs -- classification, lists, walks: every stage works on 1 / N of the sites -- and the N partial matrices are
+    summed with a reduce-scatter (rank q receives rows q: tracs_reduce_scatter), the row panels all-gathered, and transcluster
+    runs on the complete d with its key evaluations split over the ranks (key-table all-reduce), as in the pair partition.
+    One step = one call: the slice counts as freshly packed, everything once-per-pack is redone."""
+    import torch
+    from tracs_amd import _lib
+    from tracs_amd import device as dev
+    from tracs_amd import synth
+    groups = (L + 127) // 128
+    g0, g1 = groups * rank // world, groups * (rank + 1) // world
+    l0, l1 = g0 * 128, min(L, g1 * 128)
+    t0 = time.time()
+    aln = dev.Alignment(n, l1 - l0)
+    synth.generate_device(n, L, seed, lambda rows, first: aln.pack(rows[:, l0:l1].contiguous(), first=first), **synth_kw(args.partial, args.workload))
+    _, days_np = synth.dates(n, seed=seed)
+    days = torch.from_numpy(days_np).to(device)
+    torch.cuda.synchronize()
+    setup_s = time.time() - t0
+    cs = ((n + world - 1) // world + 63) // 64 * 64
+    rows_pad = cs * world
+    dmat = torch.zeros((rows_pad, n), dtype=torch.int32, device=device)
+    nmat = torch.zeros((rows_pad, n), dtype=torch.int32, device=device)
+    pmat = torch.zeros((rows_pad, n), dtype=torch.float64, device=device)
+    emat = torch.zeros((rows_pad, n), dtype=torch.float64, device=device)
+    lib = _lib.load()
+    lib.tracs_debug_pair_timing(1)
+    lib.tracs_debug_pack_timing(1)
+    d_gap = int((days.max() - days.min()).item())
+    n_max = [None]
+    ev = {k: [] for k in ("dense", "reduce", "gather", "trans")}
+
+    def reduce_rows(m):
+        if hasattr(dist, "reduce_scatter_rows"):
+            dist.reduce_scatter_rows(m, cs)
+        else:                                                  # torch.distributed (gloo has no reduce-scatter): sum the whole matrix
+            dist.all_reduce(m)
+
+    def gather_rows(m):
+        dist.all_gather([m[q * cs:(q + 1) * cs] for q in range(world)], m[rank * cs:(rank + 1) * cs])
+
+    def step(per_call=True):
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        if per_call:
+            aln.mark_packed()
+        marks[0].record()
+        dev.pairsnp_dense(aln, dmat, nmat)                     # all pairs over this rank's sites
+        marks[1].record()
+        reduce_rows(dmat); reduce_rows(nmat)
+        marks[2].record()
+        gather_rows(dmat); gather_rows(nmat)
+        marks[3].record()
+        if n_max[0] is None:
+            n_max[0] = int(torch.triu(dmat[:n], diagonal=1).max().item())          # same data every step: taken once (untimed warm-up)
+        dev.trans_dist_dense_partitioned(dmat, n, days, args.lamb, args.beta, args.precision, pmat, emat, rank, world,
+                                         lambda t: dist.all_reduce(t), exp_p0=True, n_max=n_max[0], d_max=d_gap)
+        marks[4].record()
+        return marks
+
+    def timed_run(count, per_call):
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t = time.perf_counter()
+        got = [step(per_call) for _ in range(count)]
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        el = torch.tensor([time.perf_counter() - t], dtype=torch.float64, device=device)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return float(el.item()), got
+
+    torch.cuda.synchronize()
+    t_first = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    t_first = time.perf_counter() - t_first
+    for _ in range(args.warmup):
+        step()
+    elapsed, marks = timed_run(args.steps, True)
+    stages = dev.pack_stages_bytes()
+    split = pair_split_ms(lib, args.steps)
+    elapsed_steady, _ = timed_run(args.steps, False)
+    pairs_total = n * (n - 1) // 2
+    checksum = int(torch.triu(dmat[:n], diagonal=1).sum().item())
+    if os.environ.get("TRACS_BENCH_VERIFY") and rank == 0:
+        # the summed matrices must equal a single call over the whole alignment on this rank
+        full = dev.Alignment(n, L)
+        synth.pack_synthetic_device(full, seed=seed, **synth_kw(args.partial, args.workload))
+        d1, n1 = torch.zeros_like(dmat), torch.zeros_like(nmat)
+        p1, e1 = torch.zeros_like(pmat), torch.zeros_like(emat)
+        dev.pairsnp_dense(full, d1, n1)
+        dev.trans_dist_dense_ranges(d1, n, days, args.lamb, args.beta, args.precision, p1, e1, [(0, n)], exp_p0=True)
+        up = torch.triu(torch.ones((n, n), dtype=torch.bool, device=device), diagonal=1)
+        ok = bool(torch.equal(d1[:n][up], dmat[:n][up]) and torch.equal(n1[:n][up], nmat[:n][up]) and
+                  torch.equal(p1[:n][up], pmat[:n][up]) and torch.equal(e1[:n][up], emat[:n][up]))
+        print("VERIFY site shards == single call:", ok, file=sys.stderr, flush=True)
+        full.close()
+        if not ok:
+            raise SystemExit("VERIFY FAILED")
+    if rank == 0:
+        def mean_ms(a, b):
+            return sum(m[a].elapsed_time(m[b]) for m in marks) / len(marks)
+        W = WORKLOADS[args.workload]
+        out = {"metric": "sample-pairs/sec for 10kx5Mbp SNP+transcluster distance", "value": pairs_total * args.steps / elapsed,
+               "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "u32", "data": "synthetic",
+               "step": "ONE CALL per step (as at N = 1): every rank's slice counts as freshly packed, the once-per-pack work is redone in every "
+                       "step; value_steady_state: repeated passes, nothing rebuilt",
+               "value_steady_state": pairs_total * args.steps / elapsed_steady,
+               "ms_per_step_steady_state": elapsed_steady / args.steps * 1e3,
+               "config": {"workload": "%d samples x %d sites, mu = %g per sample + %g N (%s): pairsnp (d + compared sites) + transcluster (P, E(K)), "
+                                      "all %d pairs" % (n, L, W["mu_sample"], W["p_n"], "SURVEY 8d" if args.workload == "sparse" else
+                                                         "workload '%s'" % args.workload, pairs_total),
+                          "samples": n, "sites": L, "pairs": pairs_total, "workload_name": args.workload, "exchange": exchange,
+                          "partition": "SITE shards: rank r holds groups [%d r / %d, ..) of the packed planes (%d of %d sites on rank 0) and counts all "
+                                       "pairs over them; d and nn summed with a reduce-scatter of row panels (%d rows per rank), panels "
+                                       "all-gathered, P and E(K) derived on every rank with the key evaluations split over the ranks"
+                                       % (groups, world, l1 - l0, L, cs),
+                          "rank0_ms": {"dense call over the slice (once-per-pack work included)": mean_ms(0, 1),
+                                       "reduce-scatter of d and nn": mean_ms(1, 2), "all-gather of the row panels": mean_ms(2, 3),
+                                       "transcluster (keys split, table all-reduce, gather)": mean_ms(3, 4)},
+                          "exchange_bytes_per_rank_per_call": 2 * 4.0 * rows_pad * n * (world - 1) / world * 2,
+                          "kernels_ms": None if not split else dict(zip(("pair", "lists", "count", "nn_lists"), split)),
+                          "mean_d": checksum / float(pairs_total), "checksum_d": checksum,
+                          "clock_rate": args.lamb, "trans_rate": args.beta, "precision": args.precision,
+                          "setup_seconds": round(setup_s, 1), "first_call_ms": round(t_first * 1e3, 1)},
+               "roofline_per_pack": per_pack_roofline(stages),
+               "roofline": {"bound": "hbm", "kernel": "the list kernels of a rank's slice (see roofline_per_pack and the N = 1 line); at N > 1 the "
+                                                      "step is shared between the slice's call and the exchange (config.rank0_ms)",
+                            "achieved": None, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": None, "traffic": None}}
+        print(json.dumps(out), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 _WORKLOAD_OF_PROFILES = None        # set by main(): the workload of this run

@@ -341,6 +341,10 @@ int tracs_combine_fasta(const char *out_path, const char *const *sample_names, c
  *                          base + offsets[q] (offsets: host array of `world` entries); afterwards every rank holds every block.
  *                          Row panels of a row-major pair matrix are such blocks (tracs_amd/partition.py)
  *   tracs_allreduce        dtype 0 int64, 1 float64, 2 uint32, 3 uint8; op 0 sum, 1 max, 2 min; in place
+ *   tracs_reduce_scatter   in place: buf holds world blocks of count_per_rank elements; afterwards block `rank` of this rank's buf
+ *                          is the reduction of every rank's block `rank`.  The site-sharded form of the path: d and the
+ *                          compared-sites counts are sums over sites (pairsnp.hpp:398-403,417-420), so ranks that each hold a slice
+ *                          of the sites compute all pairs over their slice and the sums arrive as row panels
  *   tracs_send / _recv     `bytes` bytes to / from rank `peer` (variable-length COO payloads to the rank that writes the CSV) */
 #define TRACS_COMM_ID_BYTES 128
 typedef struct tracs_comm tracs_comm;
@@ -353,6 +357,7 @@ int tracs_bcast(tracs_comm *c, void *buf, size_t bytes, int root, void *stream);
 int tracs_bcast_planes(tracs_comm *c, tracs_alignment *a, int root, void *stream);
 int tracs_allgather_panels(tracs_comm *c, void *base, const size_t *offsets, size_t bytes, void *stream);
 int tracs_allreduce(tracs_comm *c, void *buf, size_t count, int dtype, int op, void *stream);
+int tracs_reduce_scatter(tracs_comm *c, void *buf, size_t count_per_rank, int dtype, int op, void *stream);
 int tracs_send(tracs_comm *c, const void *buf, size_t bytes, int peer, void *stream);
 int tracs_recv(tracs_comm *c, void *buf, size_t bytes, int peer, void *stream);
 

@@ -53,4 +53,5 @@ def one_pass(tag):
 
 one_pass("cold")
 one_pass("warm")
-one_pass("warm2")
+if len(sys.argv) <= 3:
+    one_pass("warm2")

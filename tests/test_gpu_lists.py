@@ -101,6 +101,18 @@ def run_case(case, nn_lists):
     finally:
         hiplib.tracs_debug_force_site_classes(-2)
     assert aln.site_classes is not None
+    from oracle import oracle as O
+    er, ec, ed, enn = O.pairsnp_arrays(seqs, n_threads=8)
+    ri, ci = er.astype(np.int64), ec.astype(np.int64)
+    assert np.array_equal(d.cpu().numpy()[ri, ci], ed.astype(np.int32))
+    assert np.array_equal(nn.cpu().numpy()[ri, ci], enn.astype(np.int32))
+    probe = np.empty(8, dtype=np.uint64)
+    if hiplib.tracs_debug_lists(aln._h, 0, probe.ctypes.data_as(C.c_void_p), 64) != 64:
+        # the lists were refused (they would outweigh the planes): classes without lists -- nothing to look at
+        assert not case.get("bitmaps") or nn_lists != "always"
+        print("lists refused", flush=True)
+        aln.close()
+        return
     sizes = _dump(hiplib, aln, 0, np.uint64, 8)
     sites, n_lines, tot_p, tgroups, groups, has_T = (int(x) for x in sizes[:6])
     assert sites > 0 and groups == (L + 127) // 128
@@ -162,11 +174,5 @@ def run_case(case, nn_lists):
         assert (isN[:, col_any].sum(axis=0) >= 2).all()
     # (small alignments: the lists are refused when they would outweigh the planes -- 128 bytes per site against 5 n / 8)
     assert has_T or nn_lists != "always" or not case.get("bitmaps")
-    # ---- and the results built on them
-    from oracle import oracle as O
-    er, ec, ed, enn = O.pairsnp_arrays(seqs, n_threads=8)
-    ri, ci = er.astype(np.int64), ec.astype(np.int64)
-    assert np.array_equal(d.cpu().numpy()[ri, ci], ed.astype(np.int32))
-    assert np.array_equal(nn.cpu().numpy()[ri, ci], enn.astype(np.int32))
     print("lists ok:", dict(sites=sites, lines=n_lines, p=tot_p, bitmaps=has_T), flush=True)
     aln.close()

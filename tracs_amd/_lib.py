@@ -32,7 +32,7 @@ SYMBOLS = [
     "tracs_read_distance_edges", "tracs_edges_count", "tracs_edges_rows", "tracs_edges_n_names", "tracs_edges_name", "tracs_edges_i",
     "tracs_edges_j", "tracs_edges_free",
     "tracs_comm_unique_id", "tracs_comm_create", "tracs_comm_free", "tracs_comm_rank", "tracs_comm_world", "tracs_bcast",
-    "tracs_bcast_planes", "tracs_allgather_panels", "tracs_allreduce", "tracs_send", "tracs_recv",
+    "tracs_bcast_planes", "tracs_allgather_panels", "tracs_allreduce", "tracs_reduce_scatter", "tracs_send", "tracs_recv",
 ]
 
 
@@ -236,6 +236,8 @@ def load():
     L.tracs_allgather_panels.argtypes = [vp, vp, C.POINTER(sz), sz, vp]
     L.tracs_allreduce.restype = C.c_int
     L.tracs_allreduce.argtypes = [vp, vp, sz, C.c_int, C.c_int, vp]
+    L.tracs_reduce_scatter.restype = C.c_int
+    L.tracs_reduce_scatter.argtypes = [vp, vp, sz, C.c_int, C.c_int, vp]
     L.tracs_send.restype = C.c_int
     L.tracs_send.argtypes = [vp, vp, sz, C.c_int, vp]
     L.tracs_recv.restype = C.c_int

@@ -11,6 +11,8 @@
 //                                                  rank q's two chunks at offsets that are NOT in rank order, so this is a group of
 //                                                  in-place ncclBroadcasts -- one per rank -- instead of an ncclAllGather + copies)
 //     tracs_allreduce                              small agreements (key tables of transcluster, value ranges of the panels)
+//     tracs_reduce_scatter                         SITE shards: every rank counts its slice of the sites for ALL pairs (d and the
+//                                                  compared-sites counts are sums over sites), rank q receives rows q of the sums
 //     tracs_send / tracs_recv                      variable-length COO payloads to the rank that writes the CSV
 // RCCL is opened when the first communicator is made (dlopen of librccl.so.1: a process that already holds an RCCL -- PyTorch's --
 // gets that one), so a single-GPU host needs no RCCL at all.
@@ -31,6 +33,7 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*ReduceScatter)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -60,6 +63,7 @@ int rccl_open()
     TRACS_SYM(CommDestroy, "ncclCommDestroy");
     TRACS_SYM(Broadcast, "ncclBroadcast");
     TRACS_SYM(AllReduce, "ncclAllReduce");
+    TRACS_SYM(ReduceScatter, "ncclReduceScatter");
     TRACS_SYM(Send, "ncclSend");
     TRACS_SYM(Recv, "ncclRecv");
     TRACS_SYM(GroupStart, "ncclGroupStart");
@@ -171,6 +175,20 @@ int tracs_allreduce(tracs_comm *c, void *buf, size_t count, int dtype, int op, v
     if (dtype < 0 || dtype > 3 || op < 0 || op > 2) { tracs::set_error("tracs_allreduce: dtype 0..3 (i64, f64, u32, u8), op 0..2 (sum, max, min)"); return TRACS_E_ARG; }
     if (count == 0) return TRACS_OK;
     TRACS_NCCL_CHECK(g_rccl.AllReduce(buf, buf, count, types[dtype], ops[op], c->comm, static_cast<hipStream_t>(stream_)));
+    return TRACS_OK;
+}
+
+int tracs_reduce_scatter(tracs_comm *c, void *buf, size_t count_per_rank, int dtype, int op, void *stream_)
+{
+    if (!c || (!buf && count_per_rank)) { tracs::set_error("tracs_reduce_scatter: NULL argument"); return TRACS_E_ARG; }
+    static const ncclDataType_t types[] = {ncclInt64, ncclFloat64, ncclUint32, ncclUint8};
+    static const size_t widths[] = {8, 8, 4, 1};
+    static const ncclRedOp_t ops[] = {ncclSum, ncclMax, ncclMin};
+    if (dtype < 0 || dtype > 3 || op < 0 || op > 2) { tracs::set_error("tracs_reduce_scatter: dtype 0..3 (i64, f64, u32, u8), op 0..2 (sum, max, min)"); return TRACS_E_ARG; }
+    if (count_per_rank == 0) return TRACS_OK;
+    // in place: rank q's reduced block replaces block q of its own buffer (the other blocks keep this rank's partial values)
+    char *mine = static_cast<char *>(buf) + (size_t)c->rank * count_per_rank * widths[dtype];
+    TRACS_NCCL_CHECK(g_rccl.ReduceScatter(buf, mine, count_per_rank, types[dtype], ops[op], c->comm, static_cast<hipStream_t>(stream_)));
     return TRACS_OK;
 }
 

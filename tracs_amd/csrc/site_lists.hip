@@ -108,7 +108,7 @@ struct N8Encoder {
 
 __global__ __launch_bounds__(256) void site_lists_kernel(const MinorBuild mb, size_t n_pad, unsigned n,
                                                          unsigned long long *__restrict__ p_off, unsigned *__restrict__ p_ent,
-                                                         uint2 *__restrict__ E, uint4 *__restrict__ lines)
+                                                         uint2 *__restrict__ E, uint4 *__restrict__ lines, int dbg)
 {
     __shared__ unsigned short stage[STAGE_ENTRIES];
     __shared__ unsigned cn[SITES_PER_GROUP], kp[SITES_PER_GROUP], ovf[SITES_PER_GROUP], lN[SITES_PER_GROUP], cur[SITES_PER_GROUP];
@@ -196,8 +196,16 @@ __global__ __launch_bounds__(256) void site_lists_kernel(const MinorBuild mb, si
             __syncthreads();
         }
         // ---- fill: the piece's N samples into their sites' runs; the listed samples (each sample is seen in exactly one piece)
-        for (unsigned s = s_begin + tid; s < s_end; s += 256) {
-            const uint4 N = base[4 * n_pad + s];
+        // (the next slab's N words and flag word are requested before this slab's bits are placed: the loop was bound by the
+        // latency of one global load per iteration)
+        unsigned s = s_begin + tid;
+        uint4 N_next = make_uint4(0u, 0u, 0u, 0u);
+        unsigned long long fl_next = 0ull;
+        if (s < s_end) { N_next = base[4 * n_pad + s]; if (any_minor) fl_next = mb.flags[g * mb.flag_words + (s >> 6)]; }
+        for (; s < s_end; s += 256) {
+            const uint4 N = N_next;
+            const unsigned long long fl = fl_next;
+            if (s + 256 < s_end) { N_next = base[4 * n_pad + s + 256]; if (any_minor) fl_next = mb.flags[g * mb.flag_words + ((s + 256) >> 6)]; }
             const unsigned rel = s - s_begin;
             unsigned nm0 = N.x & m[0], nm1 = N.y & m[1], nm2 = N.z & m[2], nm3 = N.w & m[3];
             // (one bit of each 32-site word per round: four independent cursor round trips in flight)
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(256) void site_lists_kernel(const MinorBuild mb, si
                 if (nm2) { const int b = __ffs(nm2) + 63; nm2 &= nm2 - 1; stage[lN[b] + atomicAdd(&cur[b], 1u)] = (unsigned short)rel; }
                 if (nm3) { const int b = __ffs(nm3) + 95; nm3 &= nm3 - 1; stage[lN[b] + atomicAdd(&cur[b], 1u)] = (unsigned short)rel; }
             }
-            const bool flagged = any_minor && ((mb.flags[g * mb.flag_words + (s >> 6)] >> (s & 63u)) & 1ull);
+            const bool flagged = (fl >> (s & 63u)) & 1ull;
             if (!flagged) continue;
             const uint4 A = base[s], C = base[n_pad + s], G = base[2 * n_pad + s], T = base[3 * n_pad + s];
 #pragma unroll
@@ -237,7 +245,7 @@ __global__ __launch_bounds__(256) void site_lists_kernel(const MinorBuild mb, si
             unsigned short *st = stage + lN[tid];
             const unsigned c = cur[tid];
             unsigned prev = 0;
-            unsigned k = 0;
+            unsigned k = (dbg & 1) ? c : 0u;
             while (k < c) {
                 if (k + 4 <= c) {
                     const unsigned v0 = st[k], v1 = st[k + 1], v2 = st[k + 2], v3 = st[k + 3];
@@ -250,7 +258,7 @@ __global__ __launch_bounds__(256) void site_lists_kernel(const MinorBuild mb, si
                 prev = st[k];
                 k++;
             }
-            k = 0;
+            k = (dbg & 2) ? c : 0u;
             for (; k + 4 <= c; k += 4) {
                 const unsigned v0 = st[k], v1 = st[k + 1], v2 = st[k + 2], v3 = st[k + 3];
                 enc.sample(s_begin + v0); enc.sample(s_begin + v1); enc.sample(s_begin + v2); enc.sample(s_begin + v3);
@@ -328,19 +336,23 @@ __global__ __launch_bounds__(256) void n_bitmap_kernel(const MinorBuild mb, size
     const uint4 *np = mb.planes + 4 * n_pad + min(s, n_pad - 1);
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
     unsigned cnt = 0;
-    size_t o = o0;
-    uint4 v_next = zero4;
-    { const size_t g = o * 8 + (lane & 7u); if (o < o1 && g < groups && live) v_next = np[g * NPLANES * n_pad]; }
-    for (; o < o1; o++) {
-        const size_t g = o * 8 + (lane & 7u);
-        uint4 v = v_next;
-        const size_t gn = g + 8;
-        v_next = (o + 1 < o1 && gn < groups && live) ? np[gn * NPLANES * n_pad] : zero4;      // (the next octet: in flight during this one)
-        const size_t gm = min(g, groups - 1);
-        const uint4 um = mb.un_mask[gm], lm = mb.nnl_mask[gm];
-        cnt += __popc(v.x & um.x) + __popc(v.y & um.y) + __popc(v.z & um.z) + __popc(v.w & um.w);
-        v.x &= lm.x; v.y &= lm.y; v.z &= lm.z; v.w &= lm.w;
-        if (row) T[s * tgroups + g] = g < groups ? v : zero4;
+    constexpr int INF = 4;                                   // octets in flight per thread (64 bytes: the loop is bound by what is in flight)
+    for (size_t o = o0; o < o1; o += INF) {
+        uint4 v[INF];
+#pragma unroll
+        for (int k = 0; k < INF; k++) {
+            const size_t g = (o + k) * 8 + (lane & 7u);
+            v[k] = (o + k < o1 && g < groups && live) ? np[g * NPLANES * n_pad] : zero4;
+        }
+#pragma unroll
+        for (int k = 0; k < INF; k++) {
+            if (o + k >= o1) break;
+            const size_t g = (o + k) * 8 + (lane & 7u);
+            const size_t gm = min(g, groups - 1);
+            const uint4 um = mb.un_mask[gm], lm = mb.nnl_mask[gm];
+            cnt += __popc(v[k].x & um.x) + __popc(v[k].y & um.y) + __popc(v[k].z & um.z) + __popc(v[k].w & um.w);
+            if (row) T[s * tgroups + g] = g < groups ? make_uint4(v[k].x & lm.x, v[k].y & lm.y, v[k].z & lm.z, v[k].w & lm.w) : zero4;
+        }
     }
     cnt += __shfl_xor(cnt, 1, 64); cnt += __shfl_xor(cnt, 2, 64); cnt += __shfl_xor(cnt, 4, 64);
     if (live && (lane & 7u) == 0u && cnt) atomicAdd(&c_counted[s], cnt);
@@ -490,12 +502,33 @@ __global__ __launch_bounds__(TRACS_NN_THREADS) void nn_rows_kernel(const uint4 *
         const size_t bn = b + nwaves;
         tw_next = (bn < b_last && bn * 64 + lane < tgroups) ? Trow[bn * 64 + lane] : zero4;     // the next batch's bitmap: in flight during this one
         unsigned r0 = tw.x, r1 = tw.y, r2 = tw.z, r3 = tw.w;
-        if (!__ballot((r0 | r1 | r2 | r3) != 0u)) continue;
+        // this lane's set bits, and where its items go in the ring: an inclusive wave scan of the counts (DPP)
+        const unsigned cnt = __popc(r0) + __popc(r1) + __popc(r2) + __popc(r3);
+        unsigned x = cnt;
+        x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);      // row_shr:1 .. 8: scan inside the rows of 16
+        x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);
+        x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);
+        x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);
+        x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);     // row_bcast:15 -> rows 1, 3
+        x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);     // row_bcast:31 -> rows 2, 3
+        const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)x, 63);
+        if (total == 0u) continue;
         const size_t gm = min(g, groups - 1);
         const uint4 lm = lst_mask[gm];
         const unsigned og = off_lst[gm];
         const unsigned pre1 = og + __popc(lm.x), pre2 = pre1 + __popc(lm.y), pre3 = pre2 + __popc(lm.z);
-        for (;;) {
+        W.drain_to(8 * WALK_FLIGHT - 1);
+        if (total <= WALK_RING - 8 * WALK_FLIGHT) {
+            // (the usual case: all of the batch's sites fit the ring at once -- every lane drops its own, word by word)
+            unsigned pos = W.head + W.count + x - cnt;
+            while (r0) { const unsigned bit = __ffs(r0) - 1; r0 &= r0 - 1; W.ring[pos++ & (WALK_RING - 1u)] = make_uint2(og + __popc(lm.x & ((1u << bit) - 1u)), 0xFFFFFFFFu); }
+            while (r1) { const unsigned bit = __ffs(r1) - 1; r1 &= r1 - 1; W.ring[pos++ & (WALK_RING - 1u)] = make_uint2(pre1 + __popc(lm.y & ((1u << bit) - 1u)), 0xFFFFFFFFu); }
+            while (r2) { const unsigned bit = __ffs(r2) - 1; r2 &= r2 - 1; W.ring[pos++ & (WALK_RING - 1u)] = make_uint2(pre2 + __popc(lm.z & ((1u << bit) - 1u)), 0xFFFFFFFFu); }
+            while (r3) { const unsigned bit = __ffs(r3) - 1; r3 &= r3 - 1; W.ring[pos++ & (WALK_RING - 1u)] = make_uint2(pre3 + __popc(lm.w & ((1u << bit) - 1u)), 0xFFFFFFFFu); }
+            W.count += total;
+            continue;
+        }
+        for (;;) {                                            // a sample that is N nearly everywhere: one bit per lane and step
             W.drain_to(8 * WALK_FLIGHT - 1);                 // room for 64 more
             const bool has = (r0 | r1 | r2 | r3) != 0u;
             if (!__ballot(has)) break;
@@ -692,7 +725,8 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb_, hipStream_t 
     SL_TRY(hipMemcpyAsync(g->lst_mask, mb.lst_mask, groups * sizeof(uint4), hipMemcpyDeviceToDevice, stream));
     SL_TRY(hipMemcpyAsync(g->off_lst, mb.off_lst, groups * sizeof(unsigned), hipMemcpyDeviceToDevice, stream));
     const double plane_b = (double)groups * (double)a->n_pad * sizeof(uint4);      // the N plane
-    hipLaunchKernelGGL(site_lists_kernel, dim3((unsigned)groups), dim3(256), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off, g->p_ent, E, g->lines);
+    const int dbg_site = [] { const char *e = std::getenv("TRACS_DBG_SITE"); return e ? std::atoi(e) : 0; }();      // (timing experiments: wrong lists)
+    hipLaunchKernelGGL(site_lists_kernel, dim3((unsigned)groups), dim3(256), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off, g->p_ent, E, g->lines, dbg_site);
     pack_stage_mark("lists: per site", stream, plane_b + (double)groups * SITES_PER_GROUP * 8.0,
                     (double)L * 128.0 + (double)mb.tot_p * 12.0 + (double)L * 8.0);
     const unsigned egrid = (unsigned)((mb.tot_p + 255) / 256);

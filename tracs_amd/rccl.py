@@ -108,6 +108,17 @@ class RcclDist:
         _lib.check(self._L.tracs_allreduce(self._h, C.c_void_p(t.data_ptr()), t.numel(), code, int(op), s))
         return self._leave(async_op)
 
+    def reduce_scatter_rows(self, m, rows_per_rank, op=_ReduceOp.SUM, async_op=False):
+        """m: [world * rows_per_rank, ld] (contiguous); afterwards rows [rank * rows_per_rank, (rank + 1) * rows_per_rank) of this
+        rank's m hold the reduction over the ranks of those rows (tracs_reduce_scatter, in place)."""
+        assert m.is_contiguous() and m.shape[0] == self.world * rows_per_rank
+        code = self._DTYPES.get(str(m.dtype))
+        if code is None:
+            raise TypeError("RcclDist.reduce_scatter_rows: int64, float64, int32 or uint8")
+        s = self._enter()
+        _lib.check(self._L.tracs_reduce_scatter(self._h, C.c_void_p(m.data_ptr()), rows_per_rank * m.shape[1], code, int(op), s))
+        return self._leave(async_op)
+
     def broadcast(self, t, src=0, async_op=False):
         assert t.is_contiguous()
         s = self._enter()
