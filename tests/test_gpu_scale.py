@@ -124,9 +124,12 @@ def test_config5_shape_transcluster_and_clustering(dev, oracle):
     assert nc == enc and np.array_equal(lab.cpu().numpy(), elab)
 
 
-def test_multirank_driver_path_on_one_gpu():
-    """bench.py's N > 1 path (row-panel partition, two-panel transcluster pass, async panel all-gathers) with two gloo ranks
-    sharing the GPU: the gathered d / nn / P / E(K) matrices must equal a single-pass recomputation (TRACS_BENCH_VERIFY)."""
+@pytest.mark.parametrize("part", ["sites", "pairs"])
+def test_multirank_driver_path_on_one_gpu(part):
+    """bench.py's N > 1 paths with two gloo ranks sharing the GPU (TRACS_BENCH_VERIFY: the ranks' d / nn / P / E(K) must equal a
+    single call over the whole alignment).  `sites`: every rank holds a slice of the sites and counts all pairs over it, the sums
+    arrive as row panels (reduce-scatter; summed whole over gloo); `pairs`: row-panel partition, every rank holds the alignment,
+    two-panel transcluster pass, async panel all-gathers in 16 bits per cell."""
     import socket
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -137,12 +140,16 @@ def test_multirank_driver_path_on_one_gpu():
     env = dict(os.environ, TRACS_BENCH_BACKEND="gloo", TRACS_BENCH_VERIFY="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3",
-                          "--warmup", "1", "--samples", "1501", "--sites", "100000"], capture_output=True, text=True, env=env,
+                          "--warmup", "1", "--samples", "1501", "--sites", "100000", "--partition", part], capture_output=True, text=True, env=env,
                          timeout=600, cwd=root)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert "VERIFY gathered == single-pass: True" in out.stderr
     assert '"n_gpus": 2' in out.stdout and '"scaling": "strong"' in out.stdout
-    assert "4 bytes per cell" in out.stdout                    # d and nn both fit the 16-bit exchange at this size
+    if part == "pairs":
+        assert "VERIFY gathered == single-pass: True" in out.stderr
+        assert "4 bytes per cell" in out.stdout                    # d and nn both fit the 16-bit exchange at this size
+    else:
+        assert "VERIFY site shards == single call: True" in out.stderr
+        assert "SITE shards" in out.stdout and '"value_steady_state"' in out.stdout
 
 
 def test_rccl_communicator_world_one():

@@ -374,12 +374,15 @@ typedef __attribute__((address_space(3))) unsigned lds_u32;
 constexpr int WALK_FLIGHT = 4;                 // lines per lane group and round
 constexpr unsigned WALK_RING = 128;            // items: < 32 left over + 64 pushed + 32 continuations
 
+// CLAMP = false: the row's counters cover every sample (one column chunk: n <= 32 768): a decoded position needs no range check.
+template <bool CLAMP>
 struct Walk {
     const uint4 *lines;
     uint2 *ring;                               // this wave's ring (LDS)
     unsigned head, count;                      // (wave-uniform)
     unsigned lane, grp, l8;
-    unsigned neg4lo, dump4, val;               // row[] starts at LDS byte 0: counter of column j at 4 (j - lo); the lane's dump slot
+    unsigned neg4lo, dump4, val;               // row[] starts at LDS byte 0: counter of column j at 4 (j - c0); the lane's dump slot
+    unsigned cut;                              // a lane whose 16 bytes end below this position has nothing to add (sorted lists: row i needs j > i)
     bool ge1, ge2, ge4;
 
     __device__ __forceinline__ void push(bool has, unsigned line, unsigned base)
@@ -401,16 +404,20 @@ struct Walk {
         t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true); x += ge4 ? t : 0u;      // row_shr:4
         unsigned p = p0 + x - S;
         const unsigned w[4] = {w0, w1, w2, w3};
+        // (lanes below the cut, padding and absent items issue nothing: half the adds of a row in the middle of the matrix)
+        if ((int)(p0 + x) >= (int)cut && (w0 & 0xFFu) != 0xFFu) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < 4; k++) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const unsigned b = (w[k] >> (8 * q)) & 0xFFu;
-                p += b;
-                unsigned a = min((p << 2) + neg4lo, dump4);
-                a = b < N8_SKIP ? a : dump4;
-                // (row[] starts at LDS byte 0: the byte offset IS the address -- one ds_add_u32, no address arithmetic)
-                __hip_atomic_fetch_add(reinterpret_cast<lds_u32 *>((size_t)a), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                for (int q = 0; q < 4; q++) {
+                    const unsigned b = (w[k] >> (8 * q)) & 0xFFu;
+                    p += b;
+                    unsigned a = (p << 2) + neg4lo;
+                    if (CLAMP) a = min(a, dump4);
+                    a = b < N8_SKIP ? a : dump4;
+                    // (row[] starts at LDS byte 0: the byte offset IS the address -- one ds_add_u32, no address arithmetic)
+                    __hip_atomic_fetch_add(reinterpret_cast<lds_u32 *>((size_t)a), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
         }
         return p0 + x;                          // on the group's last lane: the position behind the line's payload
@@ -462,13 +469,14 @@ constexpr unsigned NN_MAX_SPLITS = 32;
 #ifndef TRACS_NN_THREADS
 #define TRACS_NN_THREADS 1024
 #endif
+template <bool CLAMP>
 __global__ __launch_bounds__(TRACS_NN_THREADS) void nn_rows_kernel(const uint4 *__restrict__ T, size_t tgroups, const uint4 *__restrict__ lst_mask,
                                                                    const unsigned *__restrict__ off_lst, size_t groups, const uint4 *__restrict__ lines,
                                                                    const unsigned *__restrict__ c_u, unsigned n, unsigned row_begin, unsigned col_begin,
                                                                    unsigned chunk, unsigned target, unsigned *__restrict__ ncomp, size_t ld,
                                                                    int add_terms, unsigned lu)
 {
-    // `chunk` counters -- row[0] is column `lo`, the first cell of the row in this chunk --, 64 slots nobody reads, the waves' rings
+    // `chunk` counters -- row[0] is column c0 --, 64 slots nobody reads, the waves' rings
     extern __shared__ unsigned row[];
     const unsigned i = row_begin + blockIdx.x;
     const unsigned c0 = blockIdx.y * chunk, c1 = min(n, c0 + chunk);
@@ -477,17 +485,17 @@ __global__ __launch_bounds__(TRACS_NN_THREADS) void nn_rows_kernel(const uint4 *
     const unsigned nz = min(NN_MAX_SPLITS, max(1u, (ci + target - 1u) / target));
     if (blockIdx.z >= nz) return;
     const unsigned lo = max(max(i + 1, col_begin), c0);     // columns [lo, c1) of this chunk are cells of row i
-    const unsigned span = c1 - lo;
+    const unsigned span = c1 - c0;
     if ((unsigned)(size_t)row != 0u) __builtin_trap();      // (the walk's LDS adds address row[] from 0)
     for (unsigned j = threadIdx.x; j < span + 64u; j += blockDim.x) row[j] = 0;
     __syncthreads();
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    Walk W;
+    Walk<CLAMP> W;
     W.lines = lines;
     W.ring = reinterpret_cast<uint2 *>(row + chunk + 64) + wave * WALK_RING;
     W.head = 0; W.count = 0;
     W.lane = lane; W.grp = lane >> 3; W.l8 = lane & 7u;
-    W.neg4lo = 0u - 4u * lo; W.dump4 = 4u * (span + lane); W.val = 1u;
+    W.neg4lo = 0u - 4u * c0; W.dump4 = 4u * (span + lane); W.val = 1u; W.cut = lo;
     W.ge1 = W.l8 >= 1u; W.ge2 = W.l8 >= 2u; W.ge4 = W.l8 >= 4u;
     const size_t batches = (tgroups + 63) / 64;
     const size_t per = (batches + nz - 1) / nz;
@@ -544,7 +552,7 @@ __global__ __launch_bounds__(TRACS_NN_THREADS) void nn_rows_kernel(const uint4 *
     __syncthreads();
     const bool terms = add_terms && blockIdx.z == 0;
     for (unsigned j = lo + threadIdx.x; j < c1; j += blockDim.x) {
-        const unsigned v = row[j - lo] + (terms ? lu - ci - c_u[j] : 0u);
+        const unsigned v = row[j - c0] + (terms ? lu - ci - c_u[j] : 0u);
         if (v) {
             if (nz > 1) atomicAdd(&ncomp[(size_t)i * ld + j], v);
             else ncomp[(size_t)i * ld + j] += v;
@@ -563,6 +571,7 @@ __global__ __launch_bounds__(TRACS_NN_THREADS) void nn_rows_kernel(const uint4 *
 //     phase B  every listed entry of x with w = 1 walks its site's N list: -1 for EVERY N sample y there -- the third sum for y > x
 //              (row x of dist), the fourth for y < x (cell (y, x): a scratch row, folded in by transpose_add_kernel).
 // Negative terms wrap in the unsigned row and cancel in the final sum.
+template <bool CLAMP>
 __global__ __launch_bounds__(1024) void minor_fixup_kernel(const unsigned long long *__restrict__ s_off, const unsigned *__restrict__ s_ent,
                                                            const unsigned long long *__restrict__ p_off, const unsigned *__restrict__ p_ent,
                                                            const uint4 *__restrict__ lines, const unsigned *__restrict__ c_p, unsigned n,
@@ -630,12 +639,12 @@ __global__ __launch_bounds__(1024) void minor_fixup_kernel(const unsigned long l
     }
     // phase B: N-list walks, both triangles: column y goes to row[y - c0]
     {
-        Walk W;
+        Walk<CLAMP> W;
         W.lines = lines;
         W.ring = reinterpret_cast<uint2 *>(row + chunk + 64) + wave * WALK_RING;
         W.head = 0; W.count = 0;
         W.lane = lane; W.grp = lane >> 3; W.l8 = lane & 7u;
-        W.neg4lo = 0u - 4u * c0; W.dump4 = 4u * (span + lane); W.val = 0xFFFFFFFFu;
+        W.neg4lo = 0u - 4u * c0; W.dump4 = 4u * (span + lane); W.val = 0xFFFFFFFFu; W.cut = 0u;
         W.ge1 = W.l8 >= 1u; W.ge2 = W.l8 >= 2u; W.ge4 = W.l8 >= 4u;
         for (unsigned long long base = e0 + (unsigned long long)wave * 64; base < e1; base += (unsigned long long)nwaves * 64) {
             const unsigned long long e = base + lane;
@@ -769,15 +778,20 @@ int nn_rows_add(tracs_alignment *a, size_t row_begin, size_t row_end, size_t col
     (void)hipGetDevice(&dev);
     static bool attr_set[64] = {false};
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(nn_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4 + 256 + (int)kWalkLds));
+        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(nn_rows_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4 + 256 + (int)kWalkLds));
+        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(nn_rows_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4 + 256 + (int)kWalkLds));
         attr_set[dev] = true;
     }
     // ~2048 workgroups' worth of walks each, never less than 8192 (a workgroup's fixed cost: its row in LDS)
     const unsigned target = (unsigned)std::min<unsigned long long>(1u << 30, std::max<unsigned long long>(8192ull, g->tot_nnl / 2048ull));
     const unsigned splits = (unsigned)std::min<unsigned long long>(NN_MAX_SPLITS, std::max<unsigned long long>(1, ((unsigned long long)g->max_row + target - 1) / target));
     const dim3 grid((unsigned)(row_end - row_begin), (unsigned)((n + chunk - 1) / chunk), splits);
-    hipLaunchKernelGGL(nn_rows_kernel, grid, dim3(TRACS_NN_THREADS), lds, stream, g->T, g->tgroups, g->lst_mask, g->off_lst, g->groups, g->lines,
-                       a->c_counted, (unsigned)n, (unsigned)row_begin, (unsigned)col_begin, chunk, target, ncomp, ld, add_terms, lu);
+    if (grid.y == 1)                                       // one column chunk: every decoded position is a counter of the row
+        hipLaunchKernelGGL(nn_rows_kernel<false>, grid, dim3(TRACS_NN_THREADS), lds, stream, g->T, g->tgroups, g->lst_mask, g->off_lst, g->groups, g->lines,
+                           a->c_counted, (unsigned)n, (unsigned)row_begin, (unsigned)col_begin, chunk, target, ncomp, ld, add_terms, lu);
+    else
+        hipLaunchKernelGGL(nn_rows_kernel<true>, grid, dim3(TRACS_NN_THREADS), lds, stream, g->T, g->tgroups, g->lst_mask, g->off_lst, g->groups, g->lines,
+                           a->c_counted, (unsigned)n, (unsigned)row_begin, (unsigned)col_begin, chunk, target, ncomp, ld, add_terms, lu);
     TRACS_HIP_CHECK(hipGetLastError());
     return TRACS_OK;
 }
@@ -794,7 +808,8 @@ int minority_fixup(tracs_alignment *a, size_t row_begin, size_t row_end, size_t 
     (void)hipGetDevice(&dev);
     static bool attr_set[64] = {false};
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(minor_fixup_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4 + 256 + 16 * (int)WALK_RING * 8));
+        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(minor_fixup_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4 + 256 + 16 * (int)WALK_RING * 8));
+        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(minor_fixup_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4 + 256 + 16 * (int)WALK_RING * 8));
         attr_set[dev] = true;
     }
     // scratch rows for the cells (y, x) with y < x that row x's walks feed: (n - row_begin) rows of (row_end - row_begin) columns
@@ -803,8 +818,12 @@ int minority_fixup(tracs_alignment *a, size_t row_begin, size_t row_end, size_t 
     const int rc = workspace_get(46, (n - row_begin) * s_pitch * sizeof(unsigned), reinterpret_cast<void **>(&S));
     if (rc) return rc;
     const dim3 grid((unsigned)(n - row_begin), (unsigned)((n + chunk - 1) / chunk));
-    hipLaunchKernelGGL(minor_fixup_kernel, grid, dim3(1024), lds, stream, g->s_off, g->s_ent, g->p_off, g->p_ent, g->lines, g->c_p, (unsigned)n,
-                       (unsigned)row_begin, (unsigned)row_end, (unsigned)col_begin, chunk, dist, ld, S, s_pitch);
+    if (grid.y == 1)
+        hipLaunchKernelGGL(minor_fixup_kernel<false>, grid, dim3(1024), lds, stream, g->s_off, g->s_ent, g->p_off, g->p_ent, g->lines, g->c_p, (unsigned)n,
+                           (unsigned)row_begin, (unsigned)row_end, (unsigned)col_begin, chunk, dist, ld, S, s_pitch);
+    else
+        hipLaunchKernelGGL(minor_fixup_kernel<true>, grid, dim3(1024), lds, stream, g->s_off, g->s_ent, g->p_off, g->p_ent, g->lines, g->c_p, (unsigned)n,
+                           (unsigned)row_begin, (unsigned)row_end, (unsigned)col_begin, chunk, dist, ld, S, s_pitch);
     const dim3 tgrid((unsigned)((n - row_begin + 31) / 32), (unsigned)((row_end - row_begin + 31) / 32));
     hipLaunchKernelGGL(transpose_add_kernel, tgrid, dim3(256), 0, stream, S, s_pitch, (unsigned)n, (unsigned)row_begin, (unsigned)row_end,
                        (unsigned)col_begin, dist, ld);
