@@ -244,10 +244,11 @@ print("RCCL C ABI OK")
     assert out.returncode == 0 and "RCCL C ABI OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
-@pytest.mark.parametrize("mode", ["plain", "thresholded+filter+db"])
+@pytest.mark.parametrize("mode", ["plain", "thresholded+db", "thresholded+filter+db"])
 def test_distance_cli_two_ranks_equals_one(mode, tmp_path):
-    """`tracs distance --gpus 2` (one process per rank, row-chunk partition, COO gather on rank 0; two gloo ranks sharing the
-    GPU here) writes byte for byte the CSV of the single-GPU run."""
+    """`tracs distance --gpus 2` (one process per rank; two gloo ranks sharing the GPU here) writes byte for byte the CSV of the
+    single-GPU run: site shards (every rank counts all pairs over its slice of the sites, the sums arrive as row panels) in the
+    first two modes, the row-chunk partition of the pair matrix with --filter."""
     import subprocess
     from tracs_amd import synth
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -261,7 +262,8 @@ def test_distance_cli_two_ranks_equals_one(mode, tmp_path):
     iso, _ = synth.dates(n, seed=31, span_days=300)
     meta = tmp_path / "dates.csv"
     meta.write_text("name,date\n" + "".join("%s,%s\n" % (a, b) for a, b in zip(names, iso)))
-    extra = [] if mode == "plain" else ["-D", "200", "--filter", "--msa-db", str(db), "-K", "400"]
+    extra = {"plain": [], "thresholded+db": ["-D", "200", "--msa-db", str(db), "-K", "400"],
+             "thresholded+filter+db": ["-D", "200", "--filter", "--msa-db", str(db), "-K", "400"]}[mode]
     outs = []
     for gpus in (1, 2):
         out = tmp_path / ("out%d.csv" % gpus)

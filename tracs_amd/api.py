@@ -31,23 +31,49 @@ def pairsnp_arrays(fasta, n_threads=1, dist=2147483647, filter=False):
     arr = (C.c_char_p * len(paths))(*paths)
     h = C.c_void_p()
     _lib.check(L.tracs_pairsnp(arr, len(paths), int(n_threads), int(dist), int(bool(filter)), C.byref(h)))
-    try:
-        n = L.tracs_pairsnp_len(h)
-        nseq = L.tracs_pairsnp_nseq(h)
+    owner = _ResultOwner(L, h)
+    n = L.tracs_pairsnp_len(h)
+    nseq = L.tracs_pairsnp_nseq(h)
 
-        def grab(fn):
-            if n == 0:
-                return np.zeros(0, np.uint64)
-            return np.ctypeslib.as_array(fn(h), shape=(n,)).copy()
-        rows = grab(L.tracs_pairsnp_rows)
-        cols = grab(L.tracs_pairsnp_cols)
-        d = grab(L.tracs_pairsnp_distances)
-        filt = grab(L.tracs_pairsnp_filt_distances)
-        nn = grab(L.tracs_pairsnp_ncompared)
-        names = [L.tracs_pairsnp_name(h, i).decode("utf-8", "replace") for i in range(nseq)]
-    finally:
-        L.tracs_pairsnp_free(h)
+    def grab(fn):
+        # a VIEW of the library's result (five arrays of 8 bytes per emitted pair: copying them was a second of a 10 000-sample
+        # run); the result handle lives as long as any of the views does
+        if n == 0:
+            return np.zeros(0, np.uint64)
+        v = np.ctypeslib.as_array(fn(h), shape=(n,)).view(_OwnedArray)
+        v._tracs_owner = owner
+        return v
+    rows = grab(L.tracs_pairsnp_rows)
+    cols = grab(L.tracs_pairsnp_cols)
+    d = grab(L.tracs_pairsnp_distances)
+    filt = grab(L.tracs_pairsnp_filt_distances)
+    nn = grab(L.tracs_pairsnp_ncompared)
+    names = [L.tracs_pairsnp_name(h, i).decode("utf-8", "replace") for i in range(nseq)]
     return rows, cols, d, names, filt, nn
+
+
+class _ResultOwner:
+    """Frees a tracs_pairsnp_result when the last array that views it is gone."""
+
+    def __init__(self, lib, handle):
+        self._lib, self._h = lib, handle
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.tracs_pairsnp_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class _OwnedArray(np.ndarray):
+    """ndarray view that keeps its owner alive (views and slices of it inherit the reference through `base`)."""
+    _tracs_owner = None
+
+    def __array_finalize__(self, obj):
+        if obj is not None and getattr(obj, "_tracs_owner", None) is not None:
+            self._tracs_owner = obj._tracs_owner
 
 
 def pairsnp(fasta, n_threads, dist, filter):

@@ -281,10 +281,60 @@ int tracs_write_posterior_csv(const char *path, const double *post, size_t L, si
     return rc;
 }
 
+// str(float) memoised over a call: delta, P and E(K) take a few hundred thousand distinct values over tens of millions of rows
+// (one per distinct (SNP distance, day gap) key: src/transcluster.hpp:245-246), and Python's shortest round-trip repr costs ten
+// times a table look-up.  Open addressing on the bit pattern, lock-free: a slot is claimed (0 -> 1), filled, published (2); a
+// reader that finds a slot being filled, or a full neighbourhood, formats for itself.
+namespace {
+struct FloatMemo {
+    struct Slot { std::atomic<uint32_t> state; uint32_t len; uint64_t bits; char str[32]; };
+    std::vector<Slot> slots;
+    size_t mask;
+    explicit FloatMemo(size_t log2_slots) : slots((size_t)1 << log2_slots), mask(((size_t)1 << log2_slots) - 1)
+    {
+        for (auto &x : slots) x.state.store(0, std::memory_order_relaxed);
+    }
+    // appends str(x) at out, returns its length
+    size_t put(double x, char *out)
+    {
+        uint64_t bits;
+        std::memcpy(&bits, &x, 8);
+        uint64_t h = bits * 0x9E3779B97F4A7C15ull;
+        h ^= h >> 29;
+        for (int probe = 0; probe < 8; probe++) {
+            Slot &sl = slots[(h + (uint64_t)probe) & mask];
+            uint32_t st = sl.state.load(std::memory_order_acquire);
+            if (st == 2u) {
+                if (sl.bits == bits) { std::memcpy(out, sl.str, 32); return sl.len; }
+                continue;
+            }
+            if (st == 0u) {
+                uint32_t expect = 0u;
+                if (sl.state.compare_exchange_strong(expect, 1u, std::memory_order_acq_rel)) {
+                    char tmp[64];
+                    const size_t len = format_py_float(x, tmp);
+                    if (len <= 32) {
+                        sl.bits = bits; sl.len = (uint32_t)len;
+                        std::memcpy(sl.str, tmp, len);
+                        sl.state.store(2u, std::memory_order_release);
+                    }                                            // (a longer string never gets published: the slot stays claimed)
+                    std::memcpy(out, tmp, len);
+                    return len;
+                }
+            }
+            break;                                               // being filled by somebody else: format here
+        }
+        return format_py_float(x, out);
+    }
+};
+}  // namespace
+
 // Rows of `tracs distance`'s CSV (tracs/distance.py:206-258), appended to `path`:
 //   nameA,nameB,str(delta),str(int(d)),str(P),str(E(K)),filtered,str(nn),ref
 // with_dates = 0 writes "NA" for delta, P and E(K).  filt == NULL writes "NA" in the filtered column (metadata on, --filter
 // off, :204), otherwise the integers.  k_max < 0 means no -K filter; else only rows with k_max >= E(K) are written (:222).
+// Rows are formatted by all cores into raw buffers (names copied, floats through the memo) and the buffers of a batch are written
+// in parallel at their offsets (pwrite): the 5 GB of a 10 000-sample run neither queue behind one formatter nor behind one writer.
 int tracs_write_distance_rows(const char *path, const char *const *names, const uint64_t *rows, const uint64_t *cols,
                               const uint64_t *snpd, const uint64_t *filt, const uint64_t *ncomp, const double *delta,
                               const double *p_direct, const double *e_k, size_t n, int with_dates, double k_max,
@@ -294,53 +344,77 @@ int tracs_write_distance_rows(const char *path, const char *const *names, const 
         set_error("tracs_write_distance_rows: NULL argument");
         return TRACS_E_ARG;
     }
-    FILE *fo = std::fopen(path, "ab");
-    if (!fo) { set_error(std::string("cannot open '") + path + "' for writing"); return TRACS_E_OPEN; }
+    const int fd = open(path, O_WRONLY | O_CREAT, 0644);
+    if (fd < 0) { set_error(std::string("cannot open '") + path + "' for writing"); return TRACS_E_OPEN; }
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); set_error(std::string("cannot stat '") + path + "'"); return TRACS_E_OPEN; }
+    off_t file_off = st.st_size;                              // append
     const size_t ref_len = std::strlen(ref);
+    size_t max_row = 0;
+    for (size_t r = 0; r < n; r++) max_row = std::max<size_t>(max_row, std::max(rows[r], cols[r]));
+    std::vector<uint32_t> name_len(n ? max_row + 1 : 0);
+    size_t longest = 0;
+    for (size_t k = 0; k < name_len.size(); k++) { name_len[k] = (uint32_t)std::strlen(names[k]); longest = std::max<size_t>(longest, name_len[k]); }
+    const size_t row_cap = 2 * longest + ref_len + 3 * 32 + 3 * 20 + 16;      // two names, three floats, three integers, separators
     const unsigned T = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
-    const size_t chunk = 1u << 15;
+    const size_t chunk = std::max<size_t>(1024, std::min<size_t>(1u << 17, (n + T - 1) / T));
+    std::unique_ptr<FloatMemo> memo(with_dates ? new FloatMemo(n >= (1u << 20) ? 21 : 16) : nullptr);
+    std::vector<std::vector<char>> buf(T);
+    std::vector<size_t> used(T, 0);
+    std::vector<uint64_t> cnt(T, 0);
     uint64_t written = 0;
     int rc = TRACS_OK;
     for (size_t base = 0; base < n && rc == TRACS_OK; base += chunk * T) {
-        std::vector<std::string> out(T);
-        std::vector<uint64_t> cnt(T, 0);
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < T; t++)
-            th.emplace_back([&, t]() {
-                const size_t r0 = std::min(n, base + (size_t)t * chunk), r1 = std::min(n, r0 + chunk);
-                std::string &s = out[t];
-                s.reserve((r1 - r0) * 96);
-                char tmp[64];
-                for (size_t r = r0; r < r1; r++) {
-                    if (with_dates && k_max >= 0.0 && !(k_max >= e_k[r])) continue;
-                    s += names[rows[r]]; s.push_back(',');
-                    s += names[cols[r]]; s.push_back(',');
-                    if (with_dates) s.append(tmp, format_py_float(delta[r], tmp)); else s += "NA";
-                    s.push_back(',');
-                    s.append(tmp, format_u64(snpd[r], tmp)); s.push_back(',');
-                    if (with_dates) s.append(tmp, format_py_float(p_direct[r], tmp)); else s += "NA";
-                    s.push_back(',');
-                    if (with_dates) s.append(tmp, format_py_float(e_k[r], tmp)); else s += "NA";
-                    s.push_back(',');
-                    if (filt) s.append(tmp, format_u64(filt[r], tmp)); else s += "NA";
-                    s.push_back(',');
-                    s.append(tmp, format_u64(ncomp[r], tmp)); s.push_back(',');
-                    s.append(ref, ref_len);
-                    s.push_back('\n');
-                    cnt[t]++;
-                }
-            });
-        for (auto &x : th) x.join();
-        for (unsigned t = 0; t < T; t++) {
-            written += cnt[t];
-            if (!out[t].empty() && std::fwrite(out[t].data(), 1, out[t].size(), fo) != out[t].size()) {
-                set_error(std::string("error writing '") + path + "'");
-                rc = TRACS_E_OPEN;
-                break;
-            }
+        {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < T; t++)
+                th.emplace_back([&, t]() {
+                    const size_t r0 = std::min(n, base + (size_t)t * chunk), r1 = std::min(n, r0 + chunk);
+                    if (buf[t].size() < (r1 - r0) * row_cap + 64) buf[t].resize((r1 - r0) * row_cap + 64);
+                    char *o = buf[t].data();
+                    uint64_t c = 0;
+                    for (size_t r = r0; r < r1; r++) {
+                        if (with_dates && k_max >= 0.0 && !(k_max >= e_k[r])) continue;
+                        std::memcpy(o, names[rows[r]], name_len[rows[r]]); o += name_len[rows[r]]; *o++ = ',';
+                        std::memcpy(o, names[cols[r]], name_len[cols[r]]); o += name_len[cols[r]]; *o++ = ',';
+                        if (with_dates) o += memo->put(delta[r], o); else { *o++ = 'N'; *o++ = 'A'; }
+                        *o++ = ',';
+                        o += format_u64(snpd[r], o); *o++ = ',';
+                        if (with_dates) o += memo->put(p_direct[r], o); else { *o++ = 'N'; *o++ = 'A'; }
+                        *o++ = ',';
+                        if (with_dates) o += memo->put(e_k[r], o); else { *o++ = 'N'; *o++ = 'A'; }
+                        *o++ = ',';
+                        if (filt) o += format_u64(filt[r], o); else { *o++ = 'N'; *o++ = 'A'; }
+                        *o++ = ',';
+                        o += format_u64(ncomp[r], o); *o++ = ',';
+                        std::memcpy(o, ref, ref_len); o += ref_len;
+                        *o++ = '\n';
+                        c++;
+                    }
+                    used[t] = (size_t)(o - buf[t].data());
+                    cnt[t] = c;
+                });
+            for (auto &x : th) x.join();
         }
+        std::vector<off_t> at(T);
+        for (unsigned t = 0; t < T; t++) { at[t] = file_off; file_off += (off_t)used[t]; written += cnt[t]; }
+        std::atomic<int> bad{0};
+        {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < T; t++)
+                th.emplace_back([&, t]() {
+                    size_t done = 0;
+                    while (done < used[t]) {
+                        const ssize_t w = pwrite(fd, buf[t].data() + done, used[t] - done, at[t] + (off_t)done);
+                        if (w <= 0) { bad.store(1); return; }
+                        done += (size_t)w;
+                    }
+                });
+            for (auto &x : th) x.join();
+        }
+        if (bad.load()) { set_error(std::string("error writing '") + path + "'"); rc = TRACS_E_OPEN; }
     }
-    if (std::fclose(fo) != 0 && rc == TRACS_OK) { set_error(std::string("error closing '") + path + "'"); rc = TRACS_E_OPEN; }
+    if (close(fd) != 0 && rc == TRACS_OK) { set_error(std::string("error closing '") + path + "'"); rc = TRACS_E_OPEN; }
     if (rows_written) *rows_written = written;
     return rc;
 }

@@ -56,7 +56,51 @@ __device__ __forceinline__ void sliced_add(unsigned (&p)[8], unsigned m)
     for (int j = 0; j < 8; j++) { const unsigned t = p[j] & c; p[j] ^= c; c = t; }
 }
 
+// carry-save adder over 32 one-bit lanes: three addends of weight w -> sum (weight w) and carry (weight 2w); gfx950's v_bitop3_b32
+// evaluates either in one instruction (truth tables 0x96 = a ^ b ^ c, 0xE8 = majority)
+__device__ __forceinline__ void csa(unsigned &hi, unsigned &lo, unsigned a, unsigned b, unsigned c)
+{
+    lo = __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+    hi = __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8);
+}
+
+// add eight 32-lane one-bit values to the bit-sliced counters: a Harley-Seal tree folds them into the planes of weight 1, 2, 4 and
+// ONE carry of weight 8, which then ripples through planes 3..7 -- 24 instructions for eight addends (sliced_add: 16 each)
+__device__ __forceinline__ void sliced_add8(unsigned (&p)[8], const unsigned (&x)[8])
+{
+    unsigned twos_a, twos_b, fours_a, fours_b, eights;
+    csa(twos_a, p[0], p[0], x[0], x[1]);
+    csa(twos_b, p[0], p[0], x[2], x[3]);
+    csa(fours_a, p[1], p[1], twos_a, twos_b);
+    csa(twos_a, p[0], p[0], x[4], x[5]);
+    csa(twos_b, p[0], p[0], x[6], x[7]);
+    csa(fours_b, p[1], p[1], twos_a, twos_b);
+    csa(eights, p[2], p[2], fours_a, fours_b);
+    unsigned c = eights;
+#pragma unroll
+    for (int j = 3; j < 8; j++) { const unsigned t = p[j] & c; p[j] ^= c; c = t; }
+}
+
 struct GroupWords { unsigned x[4], y[4], one[4], some[4], isn[4], bad[4]; };
+
+// what pass 2 needs of a sample's 32-site word: diff = listed (not N and not exactly the reference base, given one-hot in ra..rt),
+// isn = N, some = a base or a partial code, bad = a partial IUPAC code -- 3-input boolean instructions throughout
+__device__ __forceinline__ void classify_word(unsigned a, unsigned c, unsigned g, unsigned t, unsigned ra, unsigned rc, unsigned rg, unsigned rt,
+                                              unsigned &diff, unsigned &isn, unsigned &some, unsigned &bad)
+{
+    isn = __builtin_amdgcn_bitop3_b32(a, c, g, 0x80) & t;                                  // a & c & g & t
+    const unsigned any = __builtin_amdgcn_bitop3_b32(a, c, g, 0xFE) | t;
+    some = any & ~isn;
+    unsigned d = a ^ ra;
+    d = __builtin_amdgcn_bitop3_b32(c, rc, d, 0xBE);                                       // (c ^ rc) | d
+    d = __builtin_amdgcn_bitop3_b32(g, rg, d, 0xBE);
+    d = __builtin_amdgcn_bitop3_b32(t, rt, d, 0xBE);
+    diff = some & d;
+    // two or more alleles: (a & c) | (g & t) | ((a | c) & (g | t))
+    unsigned two = __builtin_amdgcn_bitop3_b32(g, t, a & c, 0xEA);                         // (g & t) | (a & c)
+    two = __builtin_amdgcn_bitop3_b32(a | c, g | t, two, 0xEA);
+    bad = two & ~isn;
+}
 
 // per sample and 32-site word of group g: x, y = the base's two bits where the sample carries exactly one base (`one`),
 // `some` = a base or a partial code (not N; tail bits: neither), isn = N, bad = a partial IUPAC code (2 or 3 alleles)
@@ -177,27 +221,47 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
     for (int w = 0; w < 4; w++)
 #pragma unroll
         for (int j = 0; j < 8; j++) { kp[w][j] = 0; np[w][j] = 0; }
-    unsigned since = 0;
-    for (unsigned base = 0; base < n; base += 256) {
-        const unsigned s = base + tid;
-        bool listed_here = false;
-        if (s < n) {
-            GroupWords q;
-            load_group_words(P, n_pad, g, s, q);
+    // the reference bases one-hot per 32-site word
+    unsigned ra[4], rc[4], rg[4], rt[4];
 #pragma unroll
-            for (int w = 0; w < 4; w++) {
-                // listed: not N and not exactly the reference base
-                const unsigned diff = q.some[w] & ~(q.one[w] & ~((q.x[w] ^ refx[w]) | (q.y[w] ^ refy[w])));
-                sliced_add(kp[w], diff);
-                sliced_add(np[w], q.isn[w]);
-                anyb[w] |= q.some[w];
-                bad |= q.bad[w];
-                listed_here = listed_here || diff != 0u;
+    for (int w = 0; w < 4; w++) { ra[w] = ~refx[w] & ~refy[w]; rc[w] = refx[w] & ~refy[w]; rg[w] = ~refx[w] & refy[w]; rt[w] = refx[w] & refy[w]; }
+    // Eight samples per thread and step: their words are classified as they arrive (32 16-byte loads in flight per thread), then
+    // added to the bit-sliced counters eight at a time (sliced_add8).  The counters hold 8 bits: flushed every 31 steps.
+    unsigned since = 0;
+    for (unsigned base = 0; base < n; base += 256 * 8) {
+        unsigned db[8][4], nb[8][4];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const unsigned s = base + k * 256 + tid;
+            bool listed_here = false;
+#pragma unroll
+            for (int w = 0; w < 4; w++) { db[k][w] = 0; nb[k][w] = 0; }
+            if (s < n) {
+                const uint4 *bp = P + (g * NPLANES) * n_pad + s;
+                const uint4 A = bp[0], C = bp[n_pad], G = bp[2 * n_pad], T = bp[3 * n_pad];
+                const unsigned a[4] = {A.x, A.y, A.z, A.w}, c[4] = {C.x, C.y, C.z, C.w}, gg[4] = {G.x, G.y, G.z, G.w}, t[4] = {T.x, T.y, T.z, T.w};
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    unsigned some, bd;
+                    classify_word(a[w], c[w], gg[w], t[w], ra[w], rc[w], rg[w], rt[w], db[k][w], nb[k][w], some, bd);
+                    anyb[w] |= some;
+                    bad |= bd;
+                    listed_here = listed_here || db[k][w] != 0u;
+                }
+            }
+            if (base + k * 256 < n) {                          // (block-uniform)
+                const unsigned long long fl = __ballot(listed_here);
+                if (lane == 0) flags[g * flag_words + ((base + k * 256) >> 6) + wave] = fl;
             }
         }
-        const unsigned long long fl = __ballot(listed_here);
-        if (lane == 0) flags[g * flag_words + (base >> 6) + wave] = fl;
-        if (++since == 255u) { flush(kp, 0); flush(np, 1); since = 0; }     // block-uniform
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const unsigned xd[8] = {db[0][w], db[1][w], db[2][w], db[3][w], db[4][w], db[5][w], db[6][w], db[7][w]};
+            const unsigned xn[8] = {nb[0][w], nb[1][w], nb[2][w], nb[3][w], nb[4][w], nb[5][w], nb[6][w], nb[7][w]};
+            sliced_add8(kp[w], xd);
+            sliced_add8(np[w], xn);
+        }
+        if (++since == 31u) { flush(kp, 0); flush(np, 1); since = 0; }     // block-uniform
     }
     if (since) { flush(kp, 0); flush(np, 1); }
     // somebody is not N, per site

@@ -66,13 +66,14 @@ __device__ __forceinline__ bool row_wanted(const MinorBuild &mb, size_t s)
 }
 
 // ---- per site: N lists (n8 lines) and p lists ---------------------------------------------------------------------------------
-// One workgroup per 128-site group, threads over samples (coalesced 16-byte loads of the N plane).  The group's N samples are
-// dropped into per-site runs of an LDS staging area (u16, relative to the piece's first sample) through LDS cursors; then the
-// site's own thread sorts its run (it is sorted but for the order inside a 256-sample slab), encodes it and writes its line(s) 16
-// bytes at a time.  A group whose entries do not fit the staging area (many N samples per site: 16 384 entries), or an alignment
-// beyond 65 536 samples, is taken in PIECES of consecutive samples -- whole 128-sample slabs while their entries fit --, the encoder
-// state (last position, the line's fill, the pending 16 bytes) carried in the site thread's registers from piece to piece.
-constexpr unsigned STAGE_ENTRIES = 16384;      // (a 128-sample slab of a 128-site group holds at most this many)
+// One workgroup per 128-site group.  The group's N bits are TRANSPOSED -- samples x sites, as the plane holds them, into sites x
+// samples -- through LDS, 2 048 samples (a PIECE) at a time: a wave takes 64 samples (coalesced 16-byte loads), transposes each
+// 32 x 32 bit block in registers (five butterfly steps of lane exchanges: transpose32) and writes the site-major words; then the
+// site's own thread reads its 64 words of the piece in order and feeds every set bit to its encoder -- the samples come out sorted,
+// no cursor, no atomic, no sort, and the work does not depend on how many samples are N (rounds 3-4a dropped sample numbers
+// into per-site runs through LDS cursors and sorted the runs: quadratic in the drift of the waves, 114 ms per pack at 10 % N).
+// The encoder state (last position, the line's fill, the pending 16 bytes) stays in the site thread's registers from piece to piece.
+constexpr unsigned PIECE_SAMPLES = 2048, PIECE_WORDS = PIECE_SAMPLES / 32, BM_STRIDE = PIECE_WORDS + 1;     // (odd stride: conflict-free column writes)
 
 struct N8Encoder {
     uint4 *lines;
@@ -106,17 +107,32 @@ struct N8Encoder {
     }
 };
 
+// 32 x 32 bit transpose across the 32 lanes of a half wave: lane k holds row k; afterwards bit j of lane k is bit k of what lane j held
+__device__ __forceinline__ unsigned transpose32(unsigned a, unsigned lane)
+{
+    constexpr unsigned masks[5] = {0x0000FFFFu, 0x00FF00FFu, 0x0F0F0F0Fu, 0x33333333u, 0x55555555u};
+#pragma unroll
+    for (int step = 0; step < 5; step++) {
+        const unsigned j = 16u >> step;
+        const unsigned v = (unsigned)__shfl_xor((int)a, (int)j, 64);
+        const bool hi = (lane & j) != 0u;
+        const unsigned lo_w = hi ? v : a, hi_w = hi ? a : v;          // the pair's words: lower lane, higher lane
+        const unsigned t = ((lo_w >> j) ^ hi_w) & masks[step];        // swap the high half-blocks of the lower with the low ones of the higher
+        a ^= hi ? t : (t << j);
+    }
+    return a;
+}
+
 __global__ __launch_bounds__(256) void site_lists_kernel(const MinorBuild mb, size_t n_pad, unsigned n,
                                                          unsigned long long *__restrict__ p_off, unsigned *__restrict__ p_ent,
-                                                         uint2 *__restrict__ E, uint4 *__restrict__ lines, int dbg)
+                                                         uint2 *__restrict__ E, uint4 *__restrict__ lines)
 {
-    __shared__ unsigned short stage[STAGE_ENTRIES];
-    __shared__ unsigned cn[SITES_PER_GROUP], kp[SITES_PER_GROUP], ovf[SITES_PER_GROUP], lN[SITES_PER_GROUP], cur[SITES_PER_GROUP];
-    __shared__ unsigned curP[SITES_PER_GROUP], rk[SITES_PER_GROUP];
+    __shared__ unsigned bm[SITES_PER_GROUP * BM_STRIDE];     // the piece's N bits, site-major: bm[site * BM_STRIDE + 32-sample word]
+    __shared__ unsigned cn[SITES_PER_GROUP], kp[SITES_PER_GROUP], ovf[SITES_PER_GROUP], curP[SITES_PER_GROUP], rk[SITES_PER_GROUP];
     __shared__ unsigned long long bP[SITES_PER_GROUP];
-    __shared__ unsigned red[4], piece_total;
     const size_t g = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
+    const unsigned lane = tid & 63u, wave = tid >> 6;
     if (g == 0 && tid == 0) p_off[mb.sites] = mb.tot_p;
     const uint4 m4 = mb.lst_mask[g], q4 = mb.minor_mask[g];
     if ((m4.x | m4.y | m4.z | m4.w) == 0u) return;
@@ -130,92 +146,56 @@ __global__ __launch_bounds__(256) void site_lists_kernel(const MinorBuild mb, si
         cn[tid] = c;
         kp[tid] = (mine && ((mp[tw] >> tb) & 1u)) ? mb.cntP[g * SITES_PER_GROUP + tid] : 0u;
         ovf[tid] = mine ? n8_lines_max(c, n) - 1u : 0u;
-        cur[tid] = 0; curP[tid] = 0;
+        curP[tid] = 0;
     }
     __syncthreads();
     N8Encoder enc{lines, 0u, 0u, 0u, 0xFFFFFFFFu, 0u, 0u, 0u, 0u};
-    unsigned total = 0;
-    if (tid < SITES_PER_GROUP) {
+    if (mine) {
         unsigned long long pp = 0;
-        unsigned po = 0, pn = 0;
-        for (int t = 0; t < tid; t++) { pp += kp[t]; po += ovf[t]; pn += cn[t]; }
-        if (mine) {
-            const unsigned rank = lst_rank(m4, mb.off_lst[g], tw, tb);
-            bP[tid] = mb.baseP[g] + pp; rk[tid] = rank;
-            p_off[rank] = bP[tid];
-            enc.line = rank;
-            enc.next_ovf = (unsigned)(mb.sites + mb.baseO[g] + po);
-        }
-        lN[tid] = pn;                                         // (one piece: the runs are as long as the lists)
-        if (tid == SITES_PER_GROUP - 1) piece_total = pn + cn[tid];
+        unsigned po = 0;
+        for (int t = 0; t < tid; t++) { pp += kp[t]; po += ovf[t]; }
+        const unsigned rank = lst_rank(m4, mb.off_lst[g], tw, tb);
+        bP[tid] = mb.baseP[g] + pp; rk[tid] = rank;
+        p_off[rank] = bP[tid];
+        enc.line = rank;
+        enc.next_ovf = (unsigned)(mb.sites + mb.baseO[g] + po);
     }
     __syncthreads();
-    total = piece_total;
-    const bool one_piece = total <= STAGE_ENTRIES && n <= 65536u;      // (block-uniform)
+    const bool any_n = true;
     const uint4 RX = mb.ref_x[g], RY = mb.ref_y[g];
     const uint4 *base = mb.planes + (g * NPLANES) * n_pad;
-    unsigned s_begin = 0;
-    while (s_begin < n) {                                     // pieces (block-uniform control flow)
-        unsigned s_end = n;
-        if (!one_piece) {
-            // whole 128-sample slabs while their entries fit the staging area (and 16-bit offsets): counted per site on the way
-            __syncthreads();
-            if (tid < SITES_PER_GROUP) cur[tid] = 0;
-            __syncthreads();
-            unsigned acc = 0;
-            s_end = s_begin;
-            while (s_end < n && s_end - s_begin < 65536u - 128u) {
-                const unsigned s = s_end + tid;
-                uint4 N = make_uint4(0u, 0u, 0u, 0u);
-                if (tid < 128 && s < n) N = base[4 * n_pad + s];
-                unsigned c = __popc(N.x & m[0]) + __popc(N.y & m[1]) + __popc(N.z & m[2]) + __popc(N.w & m[3]);
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
-                if (lane == 0) red[wave] = c;
-                __syncthreads();
-                const unsigned slab = red[0] + red[1];        // (threads 128.. hold no sample)
-                __syncthreads();
-                if (acc + slab > STAGE_ENTRIES) break;        // (a single slab always fits)
-                acc += slab;
-#pragma unroll
-                for (int w = 0; w < 4; w++) {
-                    unsigned nm = word_of(N, w) & m[w];
-                    while (nm) { const int b = __ffs(nm) - 1; nm &= nm - 1; atomicAdd(&cur[w * 32 + b], 1u); }
-                }
-                s_end += 128u;
-            }
-            s_end = min(s_end, n);
-            __syncthreads();
-            if (tid < SITES_PER_GROUP) {
-                unsigned pn = 0;
-                for (int t = 0; t < tid; t++) pn += cur[t];
-                lN[tid] = pn;
-            }
-            __syncthreads();
-            if (tid < SITES_PER_GROUP) cur[tid] = 0;
-            __syncthreads();
-        }
-        // ---- fill: the piece's N samples into their sites' runs; the listed samples (each sample is seen in exactly one piece)
-        // (the next slab's N words and flag word are requested before this slab's bits are placed: the loop was bound by the
-        // latency of one global load per iteration)
-        unsigned s = s_begin + tid;
-        uint4 N_next = make_uint4(0u, 0u, 0u, 0u);
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    for (unsigned piece = 0; piece < n; piece += PIECE_SAMPLES) {
+        // ---- the piece's samples, 64 per wave and step (the next step's N words and flag word are requested before this step's
+        // are transposed): N bits into bm, listed samples into the p lists (every sample is seen in exactly one piece)
+        unsigned sl = wave;
+        uint4 N_next = zero4;
         unsigned long long fl_next = 0ull;
-        if (s < s_end) { N_next = base[4 * n_pad + s]; if (any_minor) fl_next = mb.flags[g * mb.flag_words + (s >> 6)]; }
-        for (; s < s_end; s += 256) {
+        {
+            const unsigned s = piece + sl * 64u + lane;
+            if (s < n) { N_next = base[4 * n_pad + s]; if (any_minor) fl_next = mb.flags[g * mb.flag_words + (s >> 6)]; }
+        }
+        for (; sl < PIECE_SAMPLES / 64u; sl += 4u) {
+            const unsigned s = piece + sl * 64u + lane;
             const uint4 N = N_next;
             const unsigned long long fl = fl_next;
-            if (s + 256 < s_end) { N_next = base[4 * n_pad + s + 256]; if (any_minor) fl_next = mb.flags[g * mb.flag_words + ((s + 256) >> 6)]; }
-            const unsigned rel = s - s_begin;
-            unsigned nm0 = N.x & m[0], nm1 = N.y & m[1], nm2 = N.z & m[2], nm3 = N.w & m[3];
-            // (one bit of each 32-site word per round: four independent cursor round trips in flight)
-            while (nm0 | nm1 | nm2 | nm3) {
-                if (nm0) { const int b = __ffs(nm0) - 1; nm0 &= nm0 - 1; stage[lN[b] + atomicAdd(&cur[b], 1u)] = (unsigned short)rel; }
-                if (nm1) { const int b = __ffs(nm1) + 31; nm1 &= nm1 - 1; stage[lN[b] + atomicAdd(&cur[b], 1u)] = (unsigned short)rel; }
-                if (nm2) { const int b = __ffs(nm2) + 63; nm2 &= nm2 - 1; stage[lN[b] + atomicAdd(&cur[b], 1u)] = (unsigned short)rel; }
-                if (nm3) { const int b = __ffs(nm3) + 95; nm3 &= nm3 - 1; stage[lN[b] + atomicAdd(&cur[b], 1u)] = (unsigned short)rel; }
+            {
+                const unsigned sn = s + 256u;
+                N_next = zero4; fl_next = 0ull;
+                if (sl + 4u < PIECE_SAMPLES / 64u && sn < n) { N_next = base[4 * n_pad + sn]; if (any_minor) fl_next = mb.flags[g * mb.flag_words + (sn >> 6)]; }
             }
-            const bool flagged = (fl >> (s & 63u)) & 1ull;
+            if (piece + sl * 64u < n) {                        // (wave-uniform: a slab beyond the last sample leaves its words zero below)
+                const unsigned col = sl * 2u + (lane >> 5), r = lane & 31u;
+                bm[(0u + r) * BM_STRIDE + col] = transpose32(N.x & m[0], lane);
+                bm[(32u + r) * BM_STRIDE + col] = transpose32(N.y & m[1], lane);
+                bm[(64u + r) * BM_STRIDE + col] = transpose32(N.z & m[2], lane);
+                bm[(96u + r) * BM_STRIDE + col] = transpose32(N.w & m[3], lane);
+            } else {
+                const unsigned col = sl * 2u + (lane >> 5), r = lane & 31u;
+                bm[(0u + r) * BM_STRIDE + col] = 0u; bm[(32u + r) * BM_STRIDE + col] = 0u;
+                bm[(64u + r) * BM_STRIDE + col] = 0u; bm[(96u + r) * BM_STRIDE + col] = 0u;
+            }
+            const bool flagged = s < n && ((fl >> (s & 63u)) & 1ull);
             if (!flagged) continue;
             const uint4 A = base[s], C = base[n_pad + s], G = base[2 * n_pad + s], T = base[3 * n_pad + s];
 #pragma unroll
@@ -239,35 +219,21 @@ __global__ __launch_bounds__(256) void site_lists_kernel(const MinorBuild mb, si
             }
         }
         __syncthreads();
-        // ---- the site's thread: sort its run -- it is nearly sorted (the waves drift a few slabs apart at most): four entries at a
-        // time are only looked at (independent LDS reads), an entry out of place is inserted --, then encode it
-        if (mine) {
-            unsigned short *st = stage + lN[tid];
-            const unsigned c = cur[tid];
-            unsigned prev = 0;
-            unsigned k = (dbg & 1) ? c : 0u;
-            while (k < c) {
-                if (k + 4 <= c) {
-                    const unsigned v0 = st[k], v1 = st[k + 1], v2 = st[k + 2], v3 = st[k + 3];
-                    if (prev <= v0 && v0 <= v1 && v1 <= v2 && v2 <= v3) { prev = v3; k += 4; continue; }
-                }
-                const unsigned short v = st[k];
-                unsigned j = k;
-                while (j > 0 && st[j - 1] > v) { st[j] = st[j - 1]; j--; }
-                st[j] = v;
-                prev = st[k];
-                k++;
+        // ---- the site's thread: its 64 words of the piece in order (four independent reads at a time), every set bit a sample
+        if (mine && cn[tid] != 0u) {
+            const unsigned *rowp = bm + (unsigned)tid * BM_STRIDE;
+            for (unsigned c = 0; c < PIECE_WORDS; c += 4) {
+                unsigned w0 = rowp[c], w1 = rowp[c + 1], w2 = rowp[c + 2], w3 = rowp[c + 3];
+                const unsigned s0 = piece + 32u * c;
+                while (w0) { const unsigned b = __ffs(w0) - 1; w0 &= w0 - 1; enc.sample(s0 + b); }
+                while (w1) { const unsigned b = __ffs(w1) - 1; w1 &= w1 - 1; enc.sample(s0 + 32u + b); }
+                while (w2) { const unsigned b = __ffs(w2) - 1; w2 &= w2 - 1; enc.sample(s0 + 64u + b); }
+                while (w3) { const unsigned b = __ffs(w3) - 1; w3 &= w3 - 1; enc.sample(s0 + 96u + b); }
             }
-            k = (dbg & 2) ? c : 0u;
-            for (; k + 4 <= c; k += 4) {
-                const unsigned v0 = st[k], v1 = st[k + 1], v2 = st[k + 2], v3 = st[k + 3];
-                enc.sample(s_begin + v0); enc.sample(s_begin + v1); enc.sample(s_begin + v2); enc.sample(s_begin + v3);
-            }
-            for (; k < c; k++) enc.sample(s_begin + st[k]);
         }
-        s_begin = s_end;
-        if (one_piece) break;
+        __syncthreads();
     }
+    (void)any_n;
     if (mine) enc.finish();
 }
 
@@ -734,8 +700,7 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb_, hipStream_t 
     SL_TRY(hipMemcpyAsync(g->lst_mask, mb.lst_mask, groups * sizeof(uint4), hipMemcpyDeviceToDevice, stream));
     SL_TRY(hipMemcpyAsync(g->off_lst, mb.off_lst, groups * sizeof(unsigned), hipMemcpyDeviceToDevice, stream));
     const double plane_b = (double)groups * (double)a->n_pad * sizeof(uint4);      // the N plane
-    const int dbg_site = [] { const char *e = std::getenv("TRACS_DBG_SITE"); return e ? std::atoi(e) : 0; }();      // (timing experiments: wrong lists)
-    hipLaunchKernelGGL(site_lists_kernel, dim3((unsigned)groups), dim3(256), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off, g->p_ent, E, g->lines, dbg_site);
+    hipLaunchKernelGGL(site_lists_kernel, dim3((unsigned)groups), dim3(256), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off, g->p_ent, E, g->lines);
     pack_stage_mark("lists: per site", stream, plane_b + (double)groups * SITES_PER_GROUP * 8.0,
                     (double)L * 128.0 + (double)mb.tot_p * 12.0 + (double)L * 8.0);
     const unsigned egrid = (unsigned)((mb.tot_p + 255) / 256);

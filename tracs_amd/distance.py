@@ -55,8 +55,9 @@ def distance_parser(parser):
     parser.add_argument("--loglevel", type=str.upper, default="INFO",
                         choices=["DEBUG", "INFO", "WARNING", "ERROR", "CRITICAL"], help="Set the logging threshold.")
     parser.add_argument("--gpus", dest="gpus", type=check_positive_int, default=1,
-                        help="number of GPUs of this node to spread the pair matrix over (default=1; one process per GPU, "
-                             "row-panel partition, results gathered on the first; not in the reference)")
+                        help="number of GPUs of this node to spread the work over (default=1; one process per GPU, each with a slice "
+                             "of the sites -- with --filter: with its row panels of the pair matrix --, results gathered on the "
+                             "first; not in the reference)")
     parser.set_defaults(func=distance)
     return parser
 
@@ -120,6 +121,21 @@ def _pairs_multi_gpu(msas, args, ctx):
     from . import device as dev
     from . import multigpu, partition
     dist, rank, world, device = ctx
+    if not args.recomb_filter and os.environ.get("TRACS_DIST_PARTITION", "sites") == "sites":
+        # SITE shards (the default): every rank holds 1 / P of the sites and counts all pairs over them -- every stage of the call,
+        # what is built once per alignment included, works on 1 / P of the data; the sums arrive as row panels (reduce-scatter)
+        aln = multigpu.site_sharded_alignment(msas, dist, rank, world, device)
+        n = aln.n
+        i_end, j_start = (n, 0) if len(msas) == 1 else (aln.n_first, aln.n_first)      # src/pairsnp.hpp:348-360
+        got = multigpu.pairs_site_sharded(aln, i_end, j_start, args.snp_threshold, rank, world, dist)
+        names = aln.names
+        aln.close()
+        if rank != 0:
+            return None
+        host = [g.cpu().numpy().astype(np.uint32).astype(np.uint64) for g in got]
+        return host[0], host[1], host[2], names, np.zeros(len(host[0]), np.uint64), host[3]      # filter off: `len` zeros (:452)
+    # PAIR partition (with --filter: the recombination filter wants every site of a pair in one place): every rank holds the whole
+    # alignment and computes its row panels
     if os.environ.get("TRACS_DIST_PARSE_ALL"):
         aln = dev.Alignment.from_fasta(msas)              # every rank parses and packs
     else:

@@ -99,6 +99,107 @@ def shared_alignment(paths, dist, rank, world, device):
     return aln
 
 
+def site_sharded_alignment(paths, dist, rank, world, device):
+    """One rank reads and packs the FASTA(s); every rank then receives ITS SLICE OF THE SITES -- the whole 128-site groups
+    [groups r / P, groups (r + 1) / P), a contiguous 1 / P of the packed planes (group-major layout: csrc/common.h) -- as an
+    alignment of its own.  d and the compared-sites counts are sums over sites (src/pairsnp.hpp:398-403,417-420), so a rank
+    runs the whole single-GPU call -- classification, lists, walks -- on 1 / P of the sites for ALL pairs (pairs_site_sharded).
+    -> Alignment (n samples x this rank's sites) with .names, .n_first and .L_total on every rank."""
+    import torch
+    from . import device as dev
+    full = dev.Alignment.from_fasta(paths) if rank == 0 else None
+    meta = [(full.n, full.L, full.n_first, full.names)] if rank == 0 else [None]
+    dist.broadcast_object_list(meta, src=0)
+    n, L, n_first, names = meta[0]
+    groups = (L + 127) // 128
+    n_pad = (n + 63) // 64 * 64
+    gbytes = 5 * n_pad * 16                                   # one group of the packed planes
+    cut = [groups * q // world for q in range(world + 1)]
+    g0, g1 = cut[rank], cut[rank + 1]
+    mine = dev.Alignment(n, max(0, min(L, g1 * 128) - g0 * 128))
+    mine.names, mine.n_first, mine.L_total = names, n_first, L
+    step = 1 << 30
+    if rank == 0:
+        src = torch.as_tensor(_DeviceBytes(full.planes_ptr(), full.nbytes), device=device)
+        for q in range(world):
+            lo, hi = cut[q] * gbytes, cut[q + 1] * gbytes
+            if q == 0:
+                if hi > lo:
+                    torch.as_tensor(_DeviceBytes(mine.planes_ptr(), mine.nbytes), device=device)[:hi - lo].copy_(src[lo:hi])
+            else:
+                for o in range(lo, hi, step):
+                    dist.send(src[o:min(hi, o + step)], dst=q)
+        torch.cuda.synchronize()
+        full.close()
+    elif g1 > g0:
+        dst = torch.as_tensor(_DeviceBytes(mine.planes_ptr(), mine.nbytes), device=device)
+        nbytes = (g1 - g0) * gbytes
+        for o in range(0, nbytes, step):
+            dist.recv(dst[o:min(nbytes, o + step)], src=0)
+        torch.cuda.synchronize()
+    mine.mark_packed()
+    return mine
+
+
+def _sum_rows(dist, m, rows_per_rank):
+    """rows [rank * rows_per_rank, ..) of m summed over the ranks (reduce-scatter through the library's RCCL entry point; the
+    whole panel summed over torch.distributed, which has no reduce-scatter on gloo)."""
+    if hasattr(dist, "reduce_scatter_rows"):
+        dist.reduce_scatter_rows(m, rows_per_rank)
+    else:
+        dist.all_reduce(m)
+
+
+def pairs_site_sharded(aln, i_end, j_start, dist_threshold, rank, world, dist):
+    """pairsnp's output (rows, cols, d, nn: int32 device tensors, row-major) on rank 0, None elsewhere, from ranks that each hold
+    a slice of the sites (site_sharded_alignment).  Row panel by row panel: every rank counts the panel's pairs over its sites,
+    the partial panels are summed with a reduce-scatter (rank q receives its 1 / P of the panel's rows), every rank extracts the
+    pairs within the threshold from its rows, and the pieces reach rank 0 in row order."""
+    import torch
+    from . import device as dev
+    n = aln.n
+    dev_ = torch.device("cuda", torch.cuda.current_device())
+    cs = max(64, (panel_rows(n) // world) // 64 * 64)         # rows of a panel per rank
+    cs = min(cs, ((i_end + world - 1) // world + 63) // 64 * 64)
+    R = cs * world
+    dpan = torch.zeros((R, n), dtype=torch.int32, device=dev_)
+    npan = torch.zeros_like(dpan)
+    out = [[] for _ in range(4)]
+    for r0 in range(0, i_end, R):
+        r1 = min(i_end, r0 + R)
+        if aln.L > 0:
+            dev.pairsnp_dense(aln, dpan, npan, row_begin=r0, row_end=r1, col_begin=j_start, base_row=r0)
+        else:
+            dpan.zero_(); npan.zero_()
+        _sum_rows(dist, dpan, cs)
+        _sum_rows(dist, npan, cs)
+        q0, q1 = min(r1, r0 + rank * cs), min(r1, r0 + (rank + 1) * cs)
+        got = dev.coo_from_dense(dpan, npan, n, dist_threshold, row_begin=q0, row_end=q1, col_begin=j_start, base_row=r0) if q1 > q0 \
+            else [torch.empty(0, dtype=torch.int32, device=dev_) for _ in range(4)]
+        counts = torch.zeros(world, dtype=torch.int64, device=dev_)
+        counts[rank] = got[0].numel()
+        dist.all_reduce(counts)
+        counts = [int(x) for x in counts.cpu().tolist()]
+        for q in range(world):                                # the panel's pieces in rank (= row) order
+            if counts[q] == 0:
+                continue
+            if q == 0:
+                if rank == 0:
+                    for t in range(4):
+                        out[t].append(got[t])
+            elif rank == q:
+                for t in range(4):
+                    dist.send(got[t].contiguous(), dst=0)
+            elif rank == 0:
+                for t in range(4):
+                    buf = torch.empty(counts[q], dtype=torch.int32, device=dev_)
+                    dist.recv(buf, src=q)
+                    out[t].append(buf)
+    if rank != 0:
+        return None
+    return [torch.cat(o) if o else torch.empty(0, dtype=torch.int32, device=dev_) for o in out]
+
+
 def panel_rows(n, budget_bytes=1 << 30):
     """Rows per dense panel so that one uint32 panel stays within budget_bytes (a multiple of 64, at least 64)."""
     return max(64, (budget_bytes // (4 * max(n, 1))) // 64 * 64)
