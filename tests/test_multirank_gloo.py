@@ -97,3 +97,52 @@ def test_partition_properties():
     # 10k samples on 8 GPUs: per-rank work within 2 % of the mean
     w = [sum(partition.pairs_in_rows(10000, a, b) for a, b in partition.rank_ranges(10000, r, 8)) for r in range(8)]
     assert (max(w) - min(w)) / (sum(w) / 8) < 0.02
+
+
+def _site_worker(rank, world, port, n, L, seed, ret):
+    """Site shards (bench.py --partition sites, multigpu.pairs_site_sharded): rank r holds the sites of its whole 128-site groups,
+    counts ALL pairs over them (the oracle standing in for the kernel), the partial matrices are summed over the ranks."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle as O
+    from tracs_amd import multigpu, synth
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        seqs = synth.alignment(n, L, seed=seed, mu_lineage=0.02, mu_sample=0.01, p_n=0.05, p_partial=0.02, p_other=0.01)
+        groups = (L + 127) // 128
+        g0, g1 = groups * rank // world, groups * (rank + 1) // world
+        l0, l1 = g0 * 128, min(L, g1 * 128)
+        cs = ((n + world - 1) // world + 7) // 8 * 8
+        dmat = torch.zeros((cs * world, n), dtype=torch.int32)
+        nmat = torch.zeros((cs * world, n), dtype=torch.int32)
+        if l1 > l0:
+            r, c, d, nn = O.pairsnp_arrays(seqs[:, l0:l1])
+            dmat[r.astype(np.int64), c.astype(np.int64)] = torch.from_numpy(d.astype(np.int32))
+            nmat[r.astype(np.int64), c.astype(np.int64)] = torch.from_numpy(nn.astype(np.int32))
+        multigpu._sum_rows(dist, dmat, cs)
+        multigpu._sum_rows(dist, nmat, cs)
+        r, c, d, nn = O.pairsnp_arrays(seqs)
+        ri, ci = r.astype(np.int64), c.astype(np.int64)
+        own = (ri >= rank * cs) & (ri < (rank + 1) * cs)            # (what a reduce-scatter leaves on this rank; gloo sums everything)
+        ok = bool(np.array_equal(dmat.numpy()[ri[own], ci[own]], d[own].astype(np.int32)) and
+                  np.array_equal(nmat.numpy()[ri[own], ci[own]], nn[own].astype(np.int32)))
+        ret[rank] = (ok, int(own.sum()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,L", [(2, 41, 700), (3, 50, 1000), (4, 33, 520), (8, 24, 300)])
+def test_site_shards_sum_to_the_whole(world, n, L):
+    """d and the compared-sites counts are sums over sites (src/pairsnp.hpp:398-403,417-420): ranks that each count a slice of the
+    sites for all pairs, summed, give the whole alignment's matrices -- ragged last group, a rank without any site (8 ranks, 3
+    groups), every IUPAC code."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_site_worker, args=(world, port, n, L, 20241022 + world, ret), nprocs=world, join=True)
+        got = dict(ret)
+    assert len(got) == world and all(ok for ok, _ in got.values()), got
+    assert sum(k for _, k in got.values()) == n * (n - 1) // 2
