@@ -148,8 +148,10 @@ int tracs_pairsnp_dense(const tracs_alignment *a, size_t row_begin, size_t row_e
  *   tracs_set_stream_policy(1)             the caller orders its streams itself (events).  Default 0: a call that arrives on another
  *                                          stream than the previous call on the device synchronises the device first, because the
  *                                          library's scratch buffers are only stream-ordered.  With policy 1 calls that share
- *                                          scratch (two transcluster calls; two first-calls on freshly packed handles) must be
- *                                          ordered by the caller; a dense call on a decided handle and a transcluster call share none. */
+ *                                          scratch (two transcluster calls; two first-calls on freshly packed handles; two
+ *                                          posterior-codes calls with different parameters: their per-total table; two dense calls
+ *                                          on alignments with minority lists: the fix-up's scratch rows) must be ordered by the
+ *                                          caller; a dense call on a decided handle and a transcluster call share none. */
 void tracs_pairsnp_notify_distances(void *event);
 void tracs_set_stream_policy(int caller_orders_streams);
 

@@ -7,10 +7,10 @@ batches are generated on the device (SURVEY 8d's C4 mix: depth ~ Poisson(30) on 
 sites at 0.7 / 0.3), a small pool of distinct batches is cycled -- generating every batch afresh would time torch's RNG, not
 the kernel -- and every batch's codes are written to their own place in a [pool] ring (0.5 B per site-row).  Timed region: all
 launches of the stream, counts resident in HBM (through PCIe the same stream is bounded by the link: 400 GB at ~60 GB/s).
---gpus N: replicas only -- rank r takes the samples r, r + N, ..; no collective in the data path (torch.distributed only for the
+N ranks (launched under torch.distributed.run: WORLD_SIZE / RANK): replicas only -- rank r takes the samples r, r + N, ..; no collective in the data path (torch.distributed only for the
 barrier and the max-over-ranks time).
 
-usage: python scripts/bench_config4.py [--samples 50000] [--sites 1000000] [--batch 250] [--gpus N]
+usage: python scripts/bench_config4.py [--samples 50000] [--sites 1000000] [--batch 250]   (N GPUs: python -m torch.distributed.run --nproc-per-node N scripts/bench_config4.py ...)
 """
 import argparse
 import json
@@ -29,7 +29,6 @@ ap.add_argument("--samples", type=int, default=50000)
 ap.add_argument("--sites", type=int, default=1000000)
 ap.add_argument("--batch", type=int, default=250)
 ap.add_argument("--pool", type=int, default=4)
-ap.add_argument("--gpus", type=int, default=1)
 ap.add_argument("--check", type=int, default=200000, help="site-rows of the first batch checked against the f64 kernel")
 args = ap.parse_args()
 

@@ -67,13 +67,14 @@ __device__ __forceinline__ bool row_wanted(const MinorBuild &mb, size_t s)
 
 // ---- per site: N lists (n8 lines) and p lists ---------------------------------------------------------------------------------
 // One workgroup per 128-site group.  The group's N bits are TRANSPOSED -- samples x sites, as the plane holds them, into sites x
-// samples -- through LDS, 2 048 samples (a PIECE) at a time: a wave takes 64 samples (coalesced 16-byte loads), transposes each
-// 32 x 32 bit block in registers (five butterfly steps of lane exchanges: transpose32) and writes the site-major words; then the
-// site's own thread reads its 64 words of the piece in order and feeds every set bit to its encoder -- the samples come out sorted,
+// samples -- through LDS, 1 024 samples (a PIECE) at a time: a wave takes 64 samples (coalesced 16-byte loads), transposes each
+// 32 x 32 bit block in registers (five butterfly steps of lane exchanges: Transpose32) and writes the site-major words; then the
+// site's own thread reads its 32 words of the piece in order and feeds every set bit to its encoder -- the samples come out sorted,
 // no cursor, no atomic, no sort, and the work does not depend on how many samples are N (rounds 3-4a dropped sample numbers
 // into per-site runs through LDS cursors and sorted the runs: quadratic in the drift of the waves, 114 ms per pack at 10 % N).
 // The encoder state (last position, the line's fill, the pending 16 bytes) stays in the site thread's registers from piece to piece.
-constexpr unsigned PIECE_SAMPLES = 2048, PIECE_WORDS = PIECE_SAMPLES / 32, BM_STRIDE = PIECE_WORDS + 1;     // (odd stride: conflict-free column writes)
+constexpr unsigned PIECE_SAMPLES = 1024, PIECE_WORDS = PIECE_SAMPLES / 32, BM_STRIDE = PIECE_WORDS + 1;     // (odd stride: conflict-free column writes)
+constexpr unsigned SITE_THREADS = 128;         // one thread per site of the group: both waves busy in both phases, eight workgroups per CU (17 KiB of LDS each)
 
 struct N8Encoder {
     uint4 *lines;
@@ -107,23 +108,37 @@ struct N8Encoder {
     }
 };
 
-// 32 x 32 bit transpose across the 32 lanes of a half wave: lane k holds row k; afterwards bit j of lane k is bit k of what lane j held
-__device__ __forceinline__ unsigned transpose32(unsigned a, unsigned lane)
-{
-    constexpr unsigned masks[5] = {0x0000FFFFu, 0x00FF00FFu, 0x0F0F0F0Fu, 0x33333333u, 0x55555555u};
+// 32 x 32 bit transpose across the 32 lanes of a half wave: lane k holds row k; afterwards bit j of lane k is bit k of what lane j
+// held.  Five butterfly steps (j = 16, 8, 4, 2, 1): lanes k and k ^ j exchange words (ds_swizzle, bit mode) and swap the high
+// half-blocks of the lower lane's word with the low half-blocks of the higher lane's -- per lane: keep the bits of K, take the
+// partner's word rotated by R everywhere else: one rotate (v_alignbit_b32) and one bitfield insert (v_bfi_b32).
+struct Transpose32 {
+    unsigned K[5], R[5];                       // per lane and step: bits kept, rotation of the partner's word
+    __device__ __forceinline__ explicit Transpose32(unsigned lane)
+    {
+        constexpr unsigned masks[5] = {0x0000FFFFu, 0x00FF00FFu, 0x0F0F0F0Fu, 0x33333333u, 0x55555555u};
 #pragma unroll
-    for (int step = 0; step < 5; step++) {
-        const unsigned j = 16u >> step;
-        const unsigned v = (unsigned)__shfl_xor((int)a, (int)j, 64);
-        const bool hi = (lane & j) != 0u;
-        const unsigned lo_w = hi ? v : a, hi_w = hi ? a : v;          // the pair's words: lower lane, higher lane
-        const unsigned t = ((lo_w >> j) ^ hi_w) & masks[step];        // swap the high half-blocks of the lower with the low ones of the higher
-        a ^= hi ? t : (t << j);
+        for (int st = 0; st < 5; st++) {
+            const unsigned j = 16u >> st;
+            const bool hi = (lane & j) != 0u;
+            K[st] = hi ? (masks[st] << j) : masks[st];
+            R[st] = hi ? j : 32u - j;          // v_alignbit(v, v, R) = rotate right by R: the higher lane takes v >> j, the lower v << j
+        }
     }
-    return a;
-}
+    __device__ __forceinline__ unsigned operator()(unsigned a) const
+    {
+        unsigned v;
+        // (ds_swizzle bit mode: offset = xor_mask << 10 | or_mask << 5 | and_mask, inside groups of 32 lanes)
+        v = (unsigned)__builtin_amdgcn_ds_swizzle((int)a, (16 << 10) | 0x1F); a = (a & K[0]) | (__builtin_amdgcn_alignbit(v, v, R[0]) & ~K[0]);
+        v = (unsigned)__builtin_amdgcn_ds_swizzle((int)a, (8 << 10) | 0x1F);  a = (a & K[1]) | (__builtin_amdgcn_alignbit(v, v, R[1]) & ~K[1]);
+        v = (unsigned)__builtin_amdgcn_ds_swizzle((int)a, (4 << 10) | 0x1F);  a = (a & K[2]) | (__builtin_amdgcn_alignbit(v, v, R[2]) & ~K[2]);
+        v = (unsigned)__builtin_amdgcn_ds_swizzle((int)a, (2 << 10) | 0x1F);  a = (a & K[3]) | (__builtin_amdgcn_alignbit(v, v, R[3]) & ~K[3]);
+        v = (unsigned)__builtin_amdgcn_ds_swizzle((int)a, (1 << 10) | 0x1F);  a = (a & K[4]) | (__builtin_amdgcn_alignbit(v, v, R[4]) & ~K[4]);
+        return a;
+    }
+};
 
-__global__ __launch_bounds__(256) void site_lists_kernel(const MinorBuild mb, size_t n_pad, unsigned n,
+__global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBuild mb, size_t n_pad, unsigned n,
                                                          unsigned long long *__restrict__ p_off, unsigned *__restrict__ p_ent,
                                                          uint2 *__restrict__ E, uint4 *__restrict__ lines)
 {
@@ -139,9 +154,10 @@ __global__ __launch_bounds__(256) void site_lists_kernel(const MinorBuild mb, si
     const unsigned m[4] = {m4.x, m4.y, m4.z, m4.w};          // sites with lists
     const unsigned mp[4] = {q4.x, q4.y, q4.z, q4.w};         // minority sites among them (p lists)
     const bool any_minor = (q4.x | q4.y | q4.z | q4.w) != 0u;
-    const int tw = (tid & 127) >> 5, tb = tid & 31;
-    const bool mine = tid < SITES_PER_GROUP && ((m[tw] >> tb) & 1u);
-    if (tid < SITES_PER_GROUP) {
+    static_assert(SITE_THREADS == SITES_PER_GROUP, "thread = site");
+    const int tw = tid >> 5, tb = tid & 31;
+    const bool mine = (m[tw] >> tb) & 1u;
+    {
         const unsigned c = mine ? mb.cntN[g * SITES_PER_GROUP + tid] : 0u;
         cn[tid] = c;
         kp[tid] = (mine && ((mp[tw] >> tb) & 1u)) ? mb.cntP[g * SITES_PER_GROUP + tid] : 0u;
@@ -149,6 +165,7 @@ __global__ __launch_bounds__(256) void site_lists_kernel(const MinorBuild mb, si
         curP[tid] = 0;
     }
     __syncthreads();
+    const Transpose32 transpose(lane);
     N8Encoder enc{lines, 0u, 0u, 0u, 0xFFFFFFFFu, 0u, 0u, 0u, 0u};
     if (mine) {
         unsigned long long pp = 0;
@@ -175,21 +192,21 @@ __global__ __launch_bounds__(256) void site_lists_kernel(const MinorBuild mb, si
             const unsigned s = piece + sl * 64u + lane;
             if (s < n) { N_next = base[4 * n_pad + s]; if (any_minor) fl_next = mb.flags[g * mb.flag_words + (s >> 6)]; }
         }
-        for (; sl < PIECE_SAMPLES / 64u; sl += 4u) {
+        for (; sl < PIECE_SAMPLES / 64u; sl += SITE_THREADS / 64u) {
             const unsigned s = piece + sl * 64u + lane;
             const uint4 N = N_next;
             const unsigned long long fl = fl_next;
             {
-                const unsigned sn = s + 256u;
+                const unsigned sn = s + SITE_THREADS;
                 N_next = zero4; fl_next = 0ull;
-                if (sl + 4u < PIECE_SAMPLES / 64u && sn < n) { N_next = base[4 * n_pad + sn]; if (any_minor) fl_next = mb.flags[g * mb.flag_words + (sn >> 6)]; }
+                if (sl + SITE_THREADS / 64u < PIECE_SAMPLES / 64u && sn < n) { N_next = base[4 * n_pad + sn]; if (any_minor) fl_next = mb.flags[g * mb.flag_words + (sn >> 6)]; }
             }
             if (piece + sl * 64u < n) {                        // (wave-uniform: a slab beyond the last sample leaves its words zero below)
                 const unsigned col = sl * 2u + (lane >> 5), r = lane & 31u;
-                bm[(0u + r) * BM_STRIDE + col] = transpose32(N.x & m[0], lane);
-                bm[(32u + r) * BM_STRIDE + col] = transpose32(N.y & m[1], lane);
-                bm[(64u + r) * BM_STRIDE + col] = transpose32(N.z & m[2], lane);
-                bm[(96u + r) * BM_STRIDE + col] = transpose32(N.w & m[3], lane);
+                bm[(0u + r) * BM_STRIDE + col] = transpose(N.x & m[0]);
+                bm[(32u + r) * BM_STRIDE + col] = transpose(N.y & m[1]);
+                bm[(64u + r) * BM_STRIDE + col] = transpose(N.z & m[2]);
+                bm[(96u + r) * BM_STRIDE + col] = transpose(N.w & m[3]);
             } else {
                 const unsigned col = sl * 2u + (lane >> 5), r = lane & 31u;
                 bm[(0u + r) * BM_STRIDE + col] = 0u; bm[(32u + r) * BM_STRIDE + col] = 0u;
@@ -219,7 +236,7 @@ __global__ __launch_bounds__(256) void site_lists_kernel(const MinorBuild mb, si
             }
         }
         __syncthreads();
-        // ---- the site's thread: its 64 words of the piece in order (four independent reads at a time), every set bit a sample
+        // ---- the site's thread: its 32 words of the piece in order (four independent reads at a time), every set bit a sample
         if (mine && cn[tid] != 0u) {
             const unsigned *rowp = bm + (unsigned)tid * BM_STRIDE;
             for (unsigned c = 0; c < PIECE_WORDS; c += 4) {
@@ -331,52 +348,119 @@ __global__ void max_count_kernel(const unsigned *__restrict__ c, size_t n, unsig
 }
 
 // ---- the walk of n8 lines ---------------------------------------------------------------------------------------------------------
-// A wave keeps a ring of work items (line, position before the line's first byte) in LDS.  A round takes up to 32 of them: lane
-// group grp = lane >> 3 (eight lanes) decodes one line per flight, 16 bytes per lane -- byte sums per lane, an exclusive prefix over
-// the group's eight lanes (DPP), one add per byte -- and adds `val` to the LDS counter of every sample it decodes: column j goes
-// to row[j - lo], and whatever is no cell of the row (j < lo, another column chunk, skips and padding) to the lane's own slot
-// behind the row.  A line that goes on (its `next`) becomes a new item.
+// A wave keeps three rings in LDS: lines to look at (the sites of the row's bitmap), lines that go on (with the position their first
+// byte starts from), and PIECES to decode.  Two kinds of round:
+//   scan    16 lines, eight lanes per line, 16 bytes per lane: byte sums per lane (v_sad_u8), an exclusive prefix over the line's
+//           eight lanes (DPP) -- now every lane knows the positions its piece spans.  A piece that ends below the row's cut (sorted
+//           lists: row i needs j > i) or holds padding only is dropped; the others are queued (ballot + mbcnt): on a row in the middle
+//           of the matrix half of them.  A line that goes on (its `next`) is queued as a line;
+//   decode  64 queued pieces, one per lane -- every lane busy: 16 bytes, per byte one SDWA add (position), one shift-add (LDS
+//           address), one SDWA compare + select (skips and padding go to the lane's own slot behind the row), one ds_add_u32.
+// The first form of the round decoded every piece of every line behind its scan (half the lanes adding to their dump slots): the
+// kernel was bound by instruction issue and by the LDS pipe together (profiles/r04/nn_rows_n8.txt); the two-phase form issues the
+// per-byte instructions and the LDS adds for the pieces that count only.
 typedef __attribute__((address_space(3))) unsigned lds_u32;
-constexpr int WALK_FLIGHT = 4;                 // lines per lane group and round
-constexpr unsigned WALK_RING = 128;            // items: < 32 left over + 64 pushed + 32 continuations
+constexpr unsigned LINE_RING = 128, CONT_RING = 32, PIECE_RING = 192;
+constexpr unsigned WALK_LDS_PER_WAVE = LINE_RING * 4 + CONT_RING * 8 + PIECE_RING * 8;
 
 // CLAMP = false: the row's counters cover every sample (one column chunk: n <= 32 768): a decoded position needs no range check.
 template <bool CLAMP>
 struct Walk {
     const uint4 *lines;
-    uint2 *ring;                               // this wave's ring (LDS)
-    unsigned head, count;                      // (wave-uniform)
+    unsigned *lring;                           // this wave's rings (LDS): lines (index)
+    uint2 *cring, *pring;                      //   lines that go on (index, position before their first byte); pieces (uint4 index, position before the piece)
+    unsigned lhead, lcount, chead, ccount, phead, pcount;      // (wave-uniform)
     unsigned lane, grp, l8;
     unsigned neg4lo, dump4, val;               // row[] starts at LDS byte 0: counter of column j at 4 (j - c0); the lane's dump slot
-    unsigned cut;                              // a lane whose 16 bytes end below this position has nothing to add (sorted lists: row i needs j > i)
+    unsigned cut;                              // a piece that ends below this position has nothing to add
     bool ge1, ge2, ge4;
 
-    __device__ __forceinline__ void push(bool has, unsigned line, unsigned base)
+    __device__ __forceinline__ void init(const uint4 *lines_, unsigned *lds, unsigned lane_)
     {
-        const unsigned long long m = __ballot(has);
-        const unsigned pos = (head + count + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))) & (WALK_RING - 1u);
-        if (has) ring[pos] = make_uint2(line, base);
-        count += (unsigned)__popcll(m);
+        lines = lines_;
+        lring = lds; cring = reinterpret_cast<uint2 *>(lds + LINE_RING); pring = cring + CONT_RING;
+        lhead = lcount = chead = ccount = phead = pcount = 0;
+        lane = lane_; grp = lane_ >> 3; l8 = lane_ & 7u;
+        ge1 = l8 >= 1u; ge2 = l8 >= 2u; ge4 = l8 >= 4u;
     }
-    // the bytes of one lane: positions, validity, adds.  w3 of the group's last lane is the line's `next`, not payload.
-    __device__ __forceinline__ unsigned apply(const uint4 &d, unsigned p0)
+    __device__ __forceinline__ unsigned rank_of(bool has, unsigned long long &m) const
     {
-        const unsigned w0 = d.x, w1 = d.y, w2 = d.z;
-        const unsigned w3 = l8 == 7u ? 0xFFFFFFFFu : d.w, w3s = l8 == 7u ? 0u : d.w;
-        const unsigned S = __builtin_amdgcn_sad_u8(w0, 0u, __builtin_amdgcn_sad_u8(w1, 0u, __builtin_amdgcn_sad_u8(w2, 0u, __builtin_amdgcn_sad_u8(w3s, 0u, 0u))));
-        unsigned x = S, t;
-        t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true); x += ge1 ? t : 0u;      // row_shr:1
-        t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true); x += ge2 ? t : 0u;      // row_shr:2
-        t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true); x += ge4 ? t : 0u;      // row_shr:4
-        unsigned p = p0 + x - S;
-        const unsigned w[4] = {w0, w1, w2, w3};
-        // (lanes below the cut, padding and absent items issue nothing: half the adds of a row in the middle of the matrix)
-        if ((int)(p0 + x) >= (int)cut && (w0 & 0xFFu) != 0xFFu) {
+        m = __ballot(has);
+        return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    }
+    __device__ __forceinline__ void push_line(bool has, unsigned line)
+    {
+        unsigned long long m;
+        const unsigned r = rank_of(has, m);
+        if (has) lring[(lhead + lcount + r) & (LINE_RING - 1u)] = line;
+        lcount += (unsigned)__popcll(m);
+    }
+    __device__ __forceinline__ void sync_wave() const
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    __device__ __forceinline__ void scan_round()
+    {
+        const unsigned kc = min(ccount, 16u), kl = min(lcount, 16u - kc), k = kc + kl;      // lines that go on first
+        unsigned line[2], base[2];
+        bool has[2];
+        uint4 d[2];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+        for (int u = 0; u < 2; u++) {
+            const unsigned idx = u * 8 + grp;
+            has[u] = idx < k;
+            const uint2 c = cring[(chead + idx) & (CONT_RING - 1u)];
+            const unsigned l = lring[(lhead + idx - kc) & (LINE_RING - 1u)];
+            line[u] = idx < kc ? c.x : l;
+            base[u] = idx < kc ? c.y : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) d[u] = lines[(size_t)(has[u] ? line[u] : 0u) * 8 + l8];
+        chead = (chead + kc) & (CONT_RING - 1u); ccount -= kc;
+        lhead = (lhead + kl) & (LINE_RING - 1u); lcount -= kl;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            // (w3 of the line's last lane is the line's `next`, not payload)
+            const unsigned w3s = l8 == 7u ? 0u : d[u].w;
+            const unsigned S = __builtin_amdgcn_sad_u8(d[u].x, 0u, __builtin_amdgcn_sad_u8(d[u].y, 0u, __builtin_amdgcn_sad_u8(d[u].z, 0u, __builtin_amdgcn_sad_u8(w3s, 0u, 0u))));
+            unsigned x = S, t;
+            t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true); x += ge1 ? t : 0u;      // row_shr:1
+            t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true); x += ge2 ? t : 0u;      // row_shr:2
+            t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true); x += ge4 ? t : 0u;      // row_shr:4
+            const unsigned p_end = base[u] + x;             // the position behind this lane's bytes
+            const bool wanted = has[u] && (int)p_end >= (int)cut && (d[u].x & 0xFFu) != 0xFFu;
+            unsigned long long m;
+            unsigned r = rank_of(wanted, m);
+            unsigned pos = phead + pcount + r;
+            if (pos >= PIECE_RING) pos -= PIECE_RING;
+            if (wanted) pring[pos] = make_uint2(line[u] * 8u + l8, p_end - S);
+            pcount += (unsigned)__popcll(m);
+            const bool goes_on = has[u] && l8 == 7u && d[u].w != N8_NONE;
+            r = rank_of(goes_on, m);
+            if (goes_on) cring[(chead + ccount + r) & (CONT_RING - 1u)] = make_uint2(d[u].w, p_end);
+            ccount += (unsigned)__popcll(m);
+        }
+    }
+    __device__ __forceinline__ void decode_round()
+    {
+        const unsigned k = min(pcount, 64u);
+        const bool has = lane < k;
+        unsigned idx = phead + lane;
+        if (idx >= PIECE_RING) idx -= PIECE_RING;
+        const uint2 ref = pring[idx];
+        phead += k; if (phead >= PIECE_RING) phead -= PIECE_RING;
+        pcount -= k;
+        const uint4 d = lines[has ? ref.x : 0u];
+        if (has) {
+            const unsigned w[4] = {d.x, d.y, d.z, (ref.x & 7u) == 7u ? 0xFFFFFFFFu : d.w};
+            unsigned p = ref.y;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; q4++) {
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    const unsigned b = (w[k] >> (8 * q)) & 0xFFu;
+                    const unsigned b = (w[q4] >> (8 * q)) & 0xFFu;
                     p += b;
                     unsigned a = (p << 2) + neg4lo;
                     if (CLAMP) a = min(a, dump4);
@@ -386,41 +470,20 @@ struct Walk {
                 }
             }
         }
-        return p0 + x;                          // on the group's last lane: the position behind the line's payload
     }
-    __device__ __forceinline__ void round()
+    // scan while more than `keep` lines wait (decoding whenever 64 pieces are queued)
+    __device__ __forceinline__ void drain_lines_to(unsigned keep)
     {
-        const unsigned k = min(count, (unsigned)(8 * WALK_FLIGHT));
-        uint2 it[WALK_FLIGHT];
-        uint4 d[WALK_FLIGHT];
-        bool has[WALK_FLIGHT];
-#pragma unroll
-        for (int u = 0; u < WALK_FLIGHT; u++) {
-            const unsigned idx = u * 8 + grp;
-            has[u] = idx < k;
-            it[u] = ring[(head + idx) & (WALK_RING - 1u)];
-        }
-#pragma unroll
-        for (int u = 0; u < WALK_FLIGHT; u++) d[u] = lines[(size_t)(has[u] ? it[u].x : 0u) * 8 + l8];
-        head = (head + k) & (WALK_RING - 1u);
-        count -= k;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-#pragma unroll
-        for (int u = 0; u < WALK_FLIGHT; u++) {
-            const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-            const uint4 dd = has[u] ? d[u] : ones;
-            const unsigned p_end = apply(dd, it[u].y);
-            push(l8 == 7u && dd.w != N8_NONE, dd.w, p_end);
+        while (lcount + ccount > keep) {
+            sync_wave();
+            scan_round();
+            while (pcount >= 64u) { sync_wave(); decode_round(); }
         }
     }
-    __device__ __forceinline__ void drain_to(unsigned keep)
+    __device__ __forceinline__ void finish()
     {
-        while (count > keep) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            round();
-        }
+        drain_lines_to(0);
+        while (pcount) { sync_wave(); decode_round(); }
     }
 };
 
@@ -457,12 +520,8 @@ __global__ __launch_bounds__(TRACS_NN_THREADS) void nn_rows_kernel(const uint4 *
     __syncthreads();
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     Walk<CLAMP> W;
-    W.lines = lines;
-    W.ring = reinterpret_cast<uint2 *>(row + chunk + 64) + wave * WALK_RING;
-    W.head = 0; W.count = 0;
-    W.lane = lane; W.grp = lane >> 3; W.l8 = lane & 7u;
+    W.init(lines, row + chunk + 64 + wave * (WALK_LDS_PER_WAVE / 4), lane);
     W.neg4lo = 0u - 4u * c0; W.dump4 = 4u * (span + lane); W.val = 1u; W.cut = lo;
-    W.ge1 = W.l8 >= 1u; W.ge2 = W.l8 >= 2u; W.ge4 = W.l8 >= 4u;
     const size_t batches = (tgroups + 63) / 64;
     const size_t per = (batches + nz - 1) / nz;
     const size_t b_first = (size_t)blockIdx.z * per, b_last = min(batches, b_first + per);
@@ -491,19 +550,19 @@ __global__ __launch_bounds__(TRACS_NN_THREADS) void nn_rows_kernel(const uint4 *
         const uint4 lm = lst_mask[gm];
         const unsigned og = off_lst[gm];
         const unsigned pre1 = og + __popc(lm.x), pre2 = pre1 + __popc(lm.y), pre3 = pre2 + __popc(lm.z);
-        W.drain_to(8 * WALK_FLIGHT - 1);
-        if (total <= WALK_RING - 8 * WALK_FLIGHT) {
+        W.drain_lines_to(31);
+        if (total <= LINE_RING - 32u) {
             // (the usual case: all of the batch's sites fit the ring at once -- every lane drops its own, word by word)
-            unsigned pos = W.head + W.count + x - cnt;
-            while (r0) { const unsigned bit = __ffs(r0) - 1; r0 &= r0 - 1; W.ring[pos++ & (WALK_RING - 1u)] = make_uint2(og + __popc(lm.x & ((1u << bit) - 1u)), 0xFFFFFFFFu); }
-            while (r1) { const unsigned bit = __ffs(r1) - 1; r1 &= r1 - 1; W.ring[pos++ & (WALK_RING - 1u)] = make_uint2(pre1 + __popc(lm.y & ((1u << bit) - 1u)), 0xFFFFFFFFu); }
-            while (r2) { const unsigned bit = __ffs(r2) - 1; r2 &= r2 - 1; W.ring[pos++ & (WALK_RING - 1u)] = make_uint2(pre2 + __popc(lm.z & ((1u << bit) - 1u)), 0xFFFFFFFFu); }
-            while (r3) { const unsigned bit = __ffs(r3) - 1; r3 &= r3 - 1; W.ring[pos++ & (WALK_RING - 1u)] = make_uint2(pre3 + __popc(lm.w & ((1u << bit) - 1u)), 0xFFFFFFFFu); }
-            W.count += total;
+            unsigned pos = W.lhead + W.lcount + x - cnt;
+            while (r0) { const unsigned bit = __ffs(r0) - 1; r0 &= r0 - 1; W.lring[pos++ & (LINE_RING - 1u)] = og + __popc(lm.x & ((1u << bit) - 1u)); }
+            while (r1) { const unsigned bit = __ffs(r1) - 1; r1 &= r1 - 1; W.lring[pos++ & (LINE_RING - 1u)] = pre1 + __popc(lm.y & ((1u << bit) - 1u)); }
+            while (r2) { const unsigned bit = __ffs(r2) - 1; r2 &= r2 - 1; W.lring[pos++ & (LINE_RING - 1u)] = pre2 + __popc(lm.z & ((1u << bit) - 1u)); }
+            while (r3) { const unsigned bit = __ffs(r3) - 1; r3 &= r3 - 1; W.lring[pos++ & (LINE_RING - 1u)] = pre3 + __popc(lm.w & ((1u << bit) - 1u)); }
+            W.lcount += total;
             continue;
         }
         for (;;) {                                            // a sample that is N nearly everywhere: one bit per lane and step
-            W.drain_to(8 * WALK_FLIGHT - 1);                 // room for 64 more
+            W.drain_lines_to(31);                            // room for 64 more
             const bool has = (r0 | r1 | r2 | r3) != 0u;
             if (!__ballot(has)) break;
             unsigned rank = 0;
@@ -511,10 +570,10 @@ __global__ __launch_bounds__(TRACS_NN_THREADS) void nn_rows_kernel(const uint4 *
             else if (r1) { const unsigned bit = __ffs(r1) - 1; r1 &= r1 - 1; rank = pre1 + __popc(lm.y & ((1u << bit) - 1u)); }
             else if (r2) { const unsigned bit = __ffs(r2) - 1; r2 &= r2 - 1; rank = pre2 + __popc(lm.z & ((1u << bit) - 1u)); }
             else if (r3) { const unsigned bit = __ffs(r3) - 1; r3 &= r3 - 1; rank = pre3 + __popc(lm.w & ((1u << bit) - 1u)); }
-            W.push(has, rank, 0xFFFFFFFFu);
+            W.push_line(has, rank);
         }
     }
-    W.drain_to(0);
+    W.finish();
     __syncthreads();
     const bool terms = add_terms && blockIdx.z == 0;
     for (unsigned j = lo + threadIdx.x; j < c1; j += blockDim.x) {
@@ -606,19 +665,15 @@ __global__ __launch_bounds__(1024) void minor_fixup_kernel(const unsigned long l
     // phase B: N-list walks, both triangles: column y goes to row[y - c0]
     {
         Walk<CLAMP> W;
-        W.lines = lines;
-        W.ring = reinterpret_cast<uint2 *>(row + chunk + 64) + wave * WALK_RING;
-        W.head = 0; W.count = 0;
-        W.lane = lane; W.grp = lane >> 3; W.l8 = lane & 7u;
+        W.init(lines, row + chunk + 64 + wave * (WALK_LDS_PER_WAVE / 4), lane);
         W.neg4lo = 0u - 4u * c0; W.dump4 = 4u * (span + lane); W.val = 0xFFFFFFFFu; W.cut = 0u;
-        W.ge1 = W.l8 >= 1u; W.ge2 = W.l8 >= 2u; W.ge4 = W.l8 >= 4u;
         for (unsigned long long base = e0 + (unsigned long long)wave * 64; base < e1; base += (unsigned long long)nwaves * 64) {
             const unsigned long long e = base + lane;
             const unsigned ent = e < e1 ? s_ent[e] : 0u;
-            W.drain_to(8 * WALK_FLIGHT - 1);
-            W.push(e < e1 && (ent & 16u), ent >> ENT_SHIFT, 0xFFFFFFFFu);
+            W.drain_lines_to(31);
+            W.push_line(e < e1 && (ent & 16u), ent >> ENT_SHIFT);
         }
-        W.drain_to(0);
+        W.finish();
     }
     __syncthreads();
     if (upper) {
@@ -700,7 +755,7 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb_, hipStream_t 
     SL_TRY(hipMemcpyAsync(g->lst_mask, mb.lst_mask, groups * sizeof(uint4), hipMemcpyDeviceToDevice, stream));
     SL_TRY(hipMemcpyAsync(g->off_lst, mb.off_lst, groups * sizeof(unsigned), hipMemcpyDeviceToDevice, stream));
     const double plane_b = (double)groups * (double)a->n_pad * sizeof(uint4);      // the N plane
-    hipLaunchKernelGGL(site_lists_kernel, dim3((unsigned)groups), dim3(256), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off, g->p_ent, E, g->lines);
+    hipLaunchKernelGGL(site_lists_kernel, dim3((unsigned)groups), dim3(SITE_THREADS), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off, g->p_ent, E, g->lines);
     pack_stage_mark("lists: per site", stream, plane_b + (double)groups * SITES_PER_GROUP * 8.0,
                     (double)L * 128.0 + (double)mb.tot_p * 12.0 + (double)L * 8.0);
     const unsigned egrid = (unsigned)((mb.tot_p + 255) / 256);
@@ -729,7 +784,7 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb_, hipStream_t 
 }
 
 static unsigned row_chunk(size_t n) { return (unsigned)std::min<size_t>((n + 63) / 64 * 64, 32768); }
-static constexpr size_t kWalkLds = (size_t)(TRACS_NN_THREADS / 64) * WALK_RING * sizeof(uint2);
+static constexpr size_t kWalkLds = (size_t)(TRACS_NN_THREADS / 64) * WALK_LDS_PER_WAVE;
 
 int nn_rows_add(tracs_alignment *a, size_t row_begin, size_t row_end, size_t col_begin, unsigned *ncomp, size_t ld, int add_terms,
                 unsigned lu, hipStream_t stream)
@@ -768,13 +823,13 @@ int minority_fixup(tracs_alignment *a, size_t row_begin, size_t row_end, size_t 
     if (!g || g->tot_p == 0) return TRACS_OK;
     const size_t n = a->n;
     const unsigned chunk = row_chunk(n);
-    const size_t lds = (size_t)chunk * 4 + 256 + (size_t)16 * WALK_RING * sizeof(uint2);
+    const size_t lds = (size_t)chunk * 4 + 256 + (size_t)16 * WALK_LDS_PER_WAVE;
     int dev = 0;
     (void)hipGetDevice(&dev);
     static bool attr_set[64] = {false};
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(minor_fixup_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4 + 256 + 16 * (int)WALK_RING * 8));
-        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(minor_fixup_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4 + 256 + 16 * (int)WALK_RING * 8));
+        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(minor_fixup_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4 + 256 + 16 * (int)WALK_LDS_PER_WAVE));
+        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(minor_fixup_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4 + 256 + 16 * (int)WALK_LDS_PER_WAVE));
         attr_set[dev] = true;
     }
     // scratch rows for the cells (y, x) with y < x that row x's walks feed: (n - row_begin) rows of (row_end - row_begin) columns
