@@ -363,7 +363,7 @@ typedef __attribute__((address_space(3))) unsigned lds_u32;
 constexpr unsigned LINE_RING = 128, CONT_RING = 32, PIECE_RING = 192;
 constexpr unsigned WALK_LDS_PER_WAVE = LINE_RING * 4 + CONT_RING * 8 + PIECE_RING * 8;
 
-// CLAMP = false: the row's counters cover every sample (one column chunk: n <= 32 768): a decoded position needs no range check.
+// CLAMP = false: the row's counters cover every sample (one column chunk: n <= 30 720): a decoded position needs no range check.
 template <bool CLAMP>
 struct Walk {
     const uint4 *lines;
@@ -783,7 +783,9 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb_, hipStream_t 
     return TRACS_OK;
 }
 
-static unsigned row_chunk(size_t n) { return (unsigned)std::min<size_t>((n + 63) / 64 * 64, 32768); }
+// columns of the pair matrix per LDS row: the row's counters + 64 dump slots + the waves' rings must fit the CU's 160 KiB
+constexpr unsigned ROW_CHUNK_MAX = 30720;
+static unsigned row_chunk(size_t n) { return (unsigned)std::min<size_t>((n + 63) / 64 * 64, ROW_CHUNK_MAX); }
 static constexpr size_t kWalkLds = (size_t)(TRACS_NN_THREADS / 64) * WALK_LDS_PER_WAVE;
 
 int nn_rows_add(tracs_alignment *a, size_t row_begin, size_t row_end, size_t col_begin, unsigned *ncomp, size_t ld, int add_terms,
@@ -798,8 +800,8 @@ int nn_rows_add(tracs_alignment *a, size_t row_begin, size_t row_end, size_t col
     (void)hipGetDevice(&dev);
     static bool attr_set[64] = {false};
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(nn_rows_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4 + 256 + (int)kWalkLds));
-        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(nn_rows_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4 + 256 + (int)kWalkLds));
+        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(nn_rows_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ROW_CHUNK_MAX * 4 + 256 + (int)kWalkLds));
+        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(nn_rows_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ROW_CHUNK_MAX * 4 + 256 + (int)kWalkLds));
         attr_set[dev] = true;
     }
     // ~2048 workgroups' worth of walks each, never less than 8192 (a workgroup's fixed cost: its row in LDS)
@@ -828,8 +830,8 @@ int minority_fixup(tracs_alignment *a, size_t row_begin, size_t row_end, size_t 
     (void)hipGetDevice(&dev);
     static bool attr_set[64] = {false};
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(minor_fixup_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4 + 256 + 16 * (int)WALK_LDS_PER_WAVE));
-        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(minor_fixup_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4 + 256 + 16 * (int)WALK_LDS_PER_WAVE));
+        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(minor_fixup_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ROW_CHUNK_MAX * 4 + 256 + 16 * (int)WALK_LDS_PER_WAVE));
+        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(minor_fixup_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ROW_CHUNK_MAX * 4 + 256 + 16 * (int)WALK_LDS_PER_WAVE));
         attr_set[dev] = true;
     }
     // scratch rows for the cells (y, x) with y < x that row x's walks feed: (n - row_begin) rows of (row_end - row_begin) columns
