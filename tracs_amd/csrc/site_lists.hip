@@ -380,6 +380,7 @@ struct Walk {
         lines = lines_;
         lring = lds; cring = reinterpret_cast<uint2 *>(lds + LINE_RING); pring = cring + CONT_RING;
         lhead = lcount = chead = ccount = phead = pcount = 0;
+        pending = 0;
         lane = lane_; grp = lane_ >> 3; l8 = lane_ & 7u;
         ge1 = l8 >= 1u; ge2 = l8 >= 2u; ge4 = l8 >= 4u;
     }
@@ -401,47 +402,62 @@ struct Walk {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    __device__ __forceinline__ void scan_round()
+    // a scan round in two halves, so that the loads of two rounds are in flight while pieces are decoded (the walk is a chain of
+    // random 128-byte reads: what it needs is lines in flight, ~12 per wave to cover the latency at the chip's line rate)
+    struct Scan { unsigned line[2], base[2], k; uint4 d[2]; };
+    Scan sa, sb;
+    unsigned pending;                          // scan rounds issued and not finished: 0..2 (sa is the older)
+
+    __device__ __forceinline__ void scan_issue(Scan &sc)
     {
-        const unsigned kc = min(ccount, 16u), kl = min(lcount, 16u - kc), k = kc + kl;      // lines that go on first
-        unsigned line[2], base[2];
-        bool has[2];
-        uint4 d[2];
+        const unsigned kc = min(ccount, 16u), kl = min(lcount, 16u - kc);      // lines that go on first
+        sc.k = kc + kl;
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             const unsigned idx = u * 8 + grp;
-            has[u] = idx < k;
             const uint2 c = cring[(chead + idx) & (CONT_RING - 1u)];
             const unsigned l = lring[(lhead + idx - kc) & (LINE_RING - 1u)];
-            line[u] = idx < kc ? c.x : l;
-            base[u] = idx < kc ? c.y : 0xFFFFFFFFu;
+            sc.line[u] = idx < kc ? c.x : l;
+            sc.base[u] = idx < kc ? c.y : 0xFFFFFFFFu;
         }
 #pragma unroll
-        for (int u = 0; u < 2; u++) d[u] = lines[(size_t)(has[u] ? line[u] : 0u) * 8 + l8];
+        for (int u = 0; u < 2; u++) sc.d[u] = lines[(size_t)((unsigned)(u * 8) + grp < sc.k ? sc.line[u] : 0u) * 8 + l8];
         chead = (chead + kc) & (CONT_RING - 1u); ccount -= kc;
         lhead = (lhead + kl) & (LINE_RING - 1u); lcount -= kl;
+    }
+    __device__ __forceinline__ void scan_finish(const Scan &sc)
+    {
 #pragma unroll
         for (int u = 0; u < 2; u++) {
+            const bool has = (unsigned)(u * 8) + grp < sc.k;
             // (w3 of the line's last lane is the line's `next`, not payload)
-            const unsigned w3s = l8 == 7u ? 0u : d[u].w;
-            const unsigned S = __builtin_amdgcn_sad_u8(d[u].x, 0u, __builtin_amdgcn_sad_u8(d[u].y, 0u, __builtin_amdgcn_sad_u8(d[u].z, 0u, __builtin_amdgcn_sad_u8(w3s, 0u, 0u))));
+            const unsigned w3s = l8 == 7u ? 0u : sc.d[u].w;
+            const unsigned S = __builtin_amdgcn_sad_u8(sc.d[u].x, 0u, __builtin_amdgcn_sad_u8(sc.d[u].y, 0u, __builtin_amdgcn_sad_u8(sc.d[u].z, 0u, __builtin_amdgcn_sad_u8(w3s, 0u, 0u))));
             unsigned x = S, t;
             t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true); x += ge1 ? t : 0u;      // row_shr:1
             t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true); x += ge2 ? t : 0u;      // row_shr:2
             t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true); x += ge4 ? t : 0u;      // row_shr:4
-            const unsigned p_end = base[u] + x;             // the position behind this lane's bytes
-            const bool wanted = has[u] && (int)p_end >= (int)cut && (d[u].x & 0xFFu) != 0xFFu;
+            const unsigned p_end = sc.base[u] + x;          // the position behind this lane's bytes
+            const bool wanted = has && (int)p_end >= (int)cut && (sc.d[u].x & 0xFFu) != 0xFFu;
             unsigned long long m;
             unsigned r = rank_of(wanted, m);
             unsigned pos = phead + pcount + r;
             if (pos >= PIECE_RING) pos -= PIECE_RING;
-            if (wanted) pring[pos] = make_uint2(line[u] * 8u + l8, p_end - S);
+            if (wanted) pring[pos] = make_uint2(sc.line[u] * 8u + l8, p_end - S);
             pcount += (unsigned)__popcll(m);
-            const bool goes_on = has[u] && l8 == 7u && d[u].w != N8_NONE;
+            const bool goes_on = has && l8 == 7u && sc.d[u].w != N8_NONE;
             r = rank_of(goes_on, m);
-            if (goes_on) cring[(chead + ccount + r) & (CONT_RING - 1u)] = make_uint2(d[u].w, p_end);
+            if (goes_on) cring[(chead + ccount + r) & (CONT_RING - 1u)] = make_uint2(sc.d[u].w, p_end);
             ccount += (unsigned)__popcll(m);
         }
+    }
+    // the oldest round in flight: room for its pieces first (at most 128 more), then its sums, pieces and lines that go on
+    __device__ __forceinline__ void retire()
+    {
+        while (pcount >= 64u) { sync_wave(); decode_round(); }
+        scan_finish(sa);
+        sa = sb;
+        pending--;
     }
     __device__ __forceinline__ void decode_round()
     {
@@ -471,18 +487,23 @@ struct Walk {
             }
         }
     }
-    // scan while more than `keep` lines wait (decoding whenever 64 pieces are queued)
+    // issue scan rounds while more than `keep` lines wait -- two rounds stay in flight, also when this returns
     __device__ __forceinline__ void drain_lines_to(unsigned keep)
     {
         while (lcount + ccount > keep) {
+            if (pending == 2u) retire();
             sync_wave();
-            scan_round();
-            while (pcount >= 64u) { sync_wave(); decode_round(); }
+            if (pending == 0u) scan_issue(sa); else scan_issue(sb);
+            pending++;
         }
     }
     __device__ __forceinline__ void finish()
     {
-        drain_lines_to(0);
+        for (;;) {
+            drain_lines_to(0);
+            if (!pending) break;
+            retire();                          // (may queue lines that go on)
+        }
         while (pcount) { sync_wave(); decode_round(); }
     }
 };
