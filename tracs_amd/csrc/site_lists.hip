@@ -238,14 +238,23 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
         __syncthreads();
         // ---- the site's thread: its 32 words of the piece in order (four independent reads at a time), every set bit a sample
         if (mine && cn[tid] != 0u) {
+            // (one loop over the lane's own set bits: the wave runs as many rounds as its busiest lane has samples in the piece --
+            // word by word it ran the busiest lane of every word, four times as many)
+            static_assert(PIECE_WORDS == 32, "one bit per word of the piece");
             const unsigned *rowp = bm + (unsigned)tid * BM_STRIDE;
-            for (unsigned c = 0; c < PIECE_WORDS; c += 4) {
-                unsigned w0 = rowp[c], w1 = rowp[c + 1], w2 = rowp[c + 2], w3 = rowp[c + 3];
-                const unsigned s0 = piece + 32u * c;
-                while (w0) { const unsigned b = __ffs(w0) - 1; w0 &= w0 - 1; enc.sample(s0 + b); }
-                while (w1) { const unsigned b = __ffs(w1) - 1; w1 &= w1 - 1; enc.sample(s0 + 32u + b); }
-                while (w2) { const unsigned b = __ffs(w2) - 1; w2 &= w2 - 1; enc.sample(s0 + 64u + b); }
-                while (w3) { const unsigned b = __ffs(w3) - 1; w3 &= w3 - 1; enc.sample(s0 + 96u + b); }
+            unsigned nz = 0;
+#pragma unroll
+            for (unsigned c = 0; c < PIECE_WORDS; c++) nz |= (rowp[c] != 0u ? 1u : 0u) << c;
+            unsigned w = 0, c = 0;
+            for (;;) {
+                if (w == 0u) {
+                    if (nz == 0u) break;
+                    c = __ffs(nz) - 1; nz &= nz - 1;
+                    w = rowp[c];
+                }
+                const unsigned b = __ffs(w) - 1;
+                w &= w - 1;
+                enc.sample(piece + 32u * c + b);
             }
         }
         __syncthreads();
@@ -325,16 +334,16 @@ __global__ __launch_bounds__(256) void n_bitmap_kernel(const MinorBuild mb, size
 #pragma unroll
         for (int k = 0; k < INF; k++) {
             const size_t g = (o + k) * 8 + (lane & 7u);
-            v[k] = (o + k < o1 && g < groups && live) ? np[g * NPLANES * n_pad] : zero4;
+            v[k] = make_uint4(0u, 0u, 0u, 0u);
+            if (o + k < o1 && g < groups && live) v[k] = np[g * NPLANES * n_pad];
         }
 #pragma unroll
         for (int k = 0; k < INF; k++) {
-            if (o + k >= o1) break;
             const size_t g = (o + k) * 8 + (lane & 7u);
             const size_t gm = min(g, groups - 1);
             const uint4 um = mb.un_mask[gm], lm = mb.nnl_mask[gm];
-            cnt += __popc(v[k].x & um.x) + __popc(v[k].y & um.y) + __popc(v[k].z & um.z) + __popc(v[k].w & um.w);
-            if (row) T[s * tgroups + g] = g < groups ? make_uint4(v[k].x & lm.x, v[k].y & lm.y, v[k].z & lm.z, v[k].w & lm.w) : zero4;
+            cnt += __popc(v[k].x & um.x) + __popc(v[k].y & um.y) + __popc(v[k].z & um.z) + __popc(v[k].w & um.w);      // (zero past o1)
+            if (row && o + k < o1) T[s * tgroups + g] = g < groups ? make_uint4(v[k].x & lm.x, v[k].y & lm.y, v[k].z & lm.z, v[k].w & lm.w) : zero4;
         }
     }
     cnt += __shfl_xor(cnt, 1, 64); cnt += __shfl_xor(cnt, 2, 64); cnt += __shfl_xor(cnt, 4, 64);
@@ -404,58 +413,63 @@ struct Walk {
     }
     // a scan round in two halves, so that the loads of two rounds are in flight while pieces are decoded (the walk is a chain of
     // random 128-byte reads: what it needs is lines in flight, ~12 per wave to cover the latency at the chip's line rate)
-    struct Scan { unsigned line[2], base[2], k; uint4 d[2]; };
+    struct Scan { unsigned line0, line1, base0, base1, k; uint4 d0, d1; };      // (scalars: the two rounds must stay in registers)
     Scan sa, sb;
     unsigned pending;                          // scan rounds issued and not finished: 0..2 (sa is the older)
 
-    __device__ __forceinline__ void scan_issue(Scan &sc)
+    __device__ __forceinline__ Scan scan_issue()
     {
+        Scan sc;
         const unsigned kc = min(ccount, 16u), kl = min(lcount, 16u - kc);      // lines that go on first
         sc.k = kc + kl;
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const unsigned idx = u * 8 + grp;
+        {
+            const unsigned idx = grp;
             const uint2 c = cring[(chead + idx) & (CONT_RING - 1u)];
             const unsigned l = lring[(lhead + idx - kc) & (LINE_RING - 1u)];
-            sc.line[u] = idx < kc ? c.x : l;
-            sc.base[u] = idx < kc ? c.y : 0xFFFFFFFFu;
+            sc.line0 = idx < kc ? c.x : l;
+            sc.base0 = idx < kc ? c.y : 0xFFFFFFFFu;
         }
-#pragma unroll
-        for (int u = 0; u < 2; u++) sc.d[u] = lines[(size_t)((unsigned)(u * 8) + grp < sc.k ? sc.line[u] : 0u) * 8 + l8];
+        {
+            const unsigned idx = 8u + grp;
+            const uint2 c = cring[(chead + idx) & (CONT_RING - 1u)];
+            const unsigned l = lring[(lhead + idx - kc) & (LINE_RING - 1u)];
+            sc.line1 = idx < kc ? c.x : l;
+            sc.base1 = idx < kc ? c.y : 0xFFFFFFFFu;
+        }
+        sc.d0 = lines[(size_t)(grp < sc.k ? sc.line0 : 0u) * 8 + l8];
+        sc.d1 = lines[(size_t)(8u + grp < sc.k ? sc.line1 : 0u) * 8 + l8];
         chead = (chead + kc) & (CONT_RING - 1u); ccount -= kc;
         lhead = (lhead + kl) & (LINE_RING - 1u); lcount -= kl;
+        return sc;
     }
-    __device__ __forceinline__ void scan_finish(const Scan &sc)
+    __device__ __forceinline__ void scan_finish_one(bool has, unsigned line, unsigned base, const uint4 &d)
     {
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const bool has = (unsigned)(u * 8) + grp < sc.k;
-            // (w3 of the line's last lane is the line's `next`, not payload)
-            const unsigned w3s = l8 == 7u ? 0u : sc.d[u].w;
-            const unsigned S = __builtin_amdgcn_sad_u8(sc.d[u].x, 0u, __builtin_amdgcn_sad_u8(sc.d[u].y, 0u, __builtin_amdgcn_sad_u8(sc.d[u].z, 0u, __builtin_amdgcn_sad_u8(w3s, 0u, 0u))));
-            unsigned x = S, t;
-            t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true); x += ge1 ? t : 0u;      // row_shr:1
-            t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true); x += ge2 ? t : 0u;      // row_shr:2
-            t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true); x += ge4 ? t : 0u;      // row_shr:4
-            const unsigned p_end = sc.base[u] + x;          // the position behind this lane's bytes
-            const bool wanted = has && (int)p_end >= (int)cut && (sc.d[u].x & 0xFFu) != 0xFFu;
-            unsigned long long m;
-            unsigned r = rank_of(wanted, m);
-            unsigned pos = phead + pcount + r;
-            if (pos >= PIECE_RING) pos -= PIECE_RING;
-            if (wanted) pring[pos] = make_uint2(sc.line[u] * 8u + l8, p_end - S);
-            pcount += (unsigned)__popcll(m);
-            const bool goes_on = has && l8 == 7u && sc.d[u].w != N8_NONE;
-            r = rank_of(goes_on, m);
-            if (goes_on) cring[(chead + ccount + r) & (CONT_RING - 1u)] = make_uint2(sc.d[u].w, p_end);
-            ccount += (unsigned)__popcll(m);
-        }
+        // (w3 of the line's last lane is the line's `next`, not payload)
+        const unsigned w3s = l8 == 7u ? 0u : d.w;
+        const unsigned S = __builtin_amdgcn_sad_u8(d.x, 0u, __builtin_amdgcn_sad_u8(d.y, 0u, __builtin_amdgcn_sad_u8(d.z, 0u, __builtin_amdgcn_sad_u8(w3s, 0u, 0u))));
+        unsigned x = S, t;
+        t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true); x += ge1 ? t : 0u;      // row_shr:1
+        t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true); x += ge2 ? t : 0u;      // row_shr:2
+        t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true); x += ge4 ? t : 0u;      // row_shr:4
+        const unsigned p_end = base + x;                    // the position behind this lane's bytes
+        const bool wanted = has && (int)p_end >= (int)cut && (d.x & 0xFFu) != 0xFFu;
+        unsigned long long m;
+        unsigned r = rank_of(wanted, m);
+        unsigned pos = phead + pcount + r;
+        if (pos >= PIECE_RING) pos -= PIECE_RING;
+        if (wanted) pring[pos] = make_uint2(line * 8u + l8, p_end - S);
+        pcount += (unsigned)__popcll(m);
+        const bool goes_on = has && l8 == 7u && d.w != N8_NONE;
+        r = rank_of(goes_on, m);
+        if (goes_on) cring[(chead + ccount + r) & (CONT_RING - 1u)] = make_uint2(d.w, p_end);
+        ccount += (unsigned)__popcll(m);
     }
     // the oldest round in flight: room for its pieces first (at most 128 more), then its sums, pieces and lines that go on
     __device__ __forceinline__ void retire()
     {
         while (pcount >= 64u) { sync_wave(); decode_round(); }
-        scan_finish(sa);
+        scan_finish_one(grp < sa.k, sa.line0, sa.base0, sa.d0);
+        scan_finish_one(8u + grp < sa.k, sa.line1, sa.base1, sa.d1);
         sa = sb;
         pending--;
     }
@@ -493,7 +507,8 @@ struct Walk {
         while (lcount + ccount > keep) {
             if (pending == 2u) retire();
             sync_wave();
-            if (pending == 0u) scan_issue(sa); else scan_issue(sb);
+            const Scan sc = scan_issue();
+            if (pending == 0u) sa = sc; else sb = sc;
             pending++;
         }
     }
