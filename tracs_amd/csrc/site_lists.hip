@@ -389,7 +389,6 @@ struct Walk {
         lines = lines_;
         lring = lds; cring = reinterpret_cast<uint2 *>(lds + LINE_RING); pring = cring + CONT_RING;
         lhead = lcount = chead = ccount = phead = pcount = 0;
-        pending = 0;
         lane = lane_; grp = lane_ >> 3; l8 = lane_ & 7u;
         ge1 = l8 >= 1u; ge2 = l8 >= 2u; ge4 = l8 >= 4u;
     }
@@ -411,67 +410,47 @@ struct Walk {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    // a scan round in two halves, so that the loads of two rounds are in flight while pieces are decoded (the walk is a chain of
-    // random 128-byte reads: what it needs is lines in flight, ~12 per wave to cover the latency at the chip's line rate)
-    struct Scan { unsigned line0, line1, base0, base1, k; uint4 d0, d1; };      // (scalars: the two rounds must stay in registers)
-    Scan sa, sb;
-    unsigned pending;                          // scan rounds issued and not finished: 0..2 (sa is the older)
-
-    __device__ __forceinline__ Scan scan_issue()
+    __device__ __forceinline__ void scan_round()
     {
-        Scan sc;
-        const unsigned kc = min(ccount, 16u), kl = min(lcount, 16u - kc);      // lines that go on first
-        sc.k = kc + kl;
-        {
-            const unsigned idx = grp;
+        const unsigned kc = min(ccount, 16u), kl = min(lcount, 16u - kc), k = kc + kl;      // lines that go on first
+        unsigned line[2], base[2];
+        bool has[2];
+        uint4 d[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const unsigned idx = u * 8 + grp;
+            has[u] = idx < k;
             const uint2 c = cring[(chead + idx) & (CONT_RING - 1u)];
             const unsigned l = lring[(lhead + idx - kc) & (LINE_RING - 1u)];
-            sc.line0 = idx < kc ? c.x : l;
-            sc.base0 = idx < kc ? c.y : 0xFFFFFFFFu;
+            line[u] = idx < kc ? c.x : l;
+            base[u] = idx < kc ? c.y : 0xFFFFFFFFu;
         }
-        {
-            const unsigned idx = 8u + grp;
-            const uint2 c = cring[(chead + idx) & (CONT_RING - 1u)];
-            const unsigned l = lring[(lhead + idx - kc) & (LINE_RING - 1u)];
-            sc.line1 = idx < kc ? c.x : l;
-            sc.base1 = idx < kc ? c.y : 0xFFFFFFFFu;
-        }
-        sc.d0 = lines[(size_t)(grp < sc.k ? sc.line0 : 0u) * 8 + l8];
-        sc.d1 = lines[(size_t)(8u + grp < sc.k ? sc.line1 : 0u) * 8 + l8];
+#pragma unroll
+        for (int u = 0; u < 2; u++) d[u] = lines[(size_t)(has[u] ? line[u] : 0u) * 8 + l8];
         chead = (chead + kc) & (CONT_RING - 1u); ccount -= kc;
         lhead = (lhead + kl) & (LINE_RING - 1u); lcount -= kl;
-        return sc;
-    }
-    __device__ __forceinline__ void scan_finish_one(bool has, unsigned line, unsigned base, const uint4 &d)
-    {
-        // (w3 of the line's last lane is the line's `next`, not payload)
-        const unsigned w3s = l8 == 7u ? 0u : d.w;
-        const unsigned S = __builtin_amdgcn_sad_u8(d.x, 0u, __builtin_amdgcn_sad_u8(d.y, 0u, __builtin_amdgcn_sad_u8(d.z, 0u, __builtin_amdgcn_sad_u8(w3s, 0u, 0u))));
-        unsigned x = S, t;
-        t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true); x += ge1 ? t : 0u;      // row_shr:1
-        t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true); x += ge2 ? t : 0u;      // row_shr:2
-        t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true); x += ge4 ? t : 0u;      // row_shr:4
-        const unsigned p_end = base + x;                    // the position behind this lane's bytes
-        const bool wanted = has && (int)p_end >= (int)cut && (d.x & 0xFFu) != 0xFFu;
-        unsigned long long m;
-        unsigned r = rank_of(wanted, m);
-        unsigned pos = phead + pcount + r;
-        if (pos >= PIECE_RING) pos -= PIECE_RING;
-        if (wanted) pring[pos] = make_uint2(line * 8u + l8, p_end - S);
-        pcount += (unsigned)__popcll(m);
-        const bool goes_on = has && l8 == 7u && d.w != N8_NONE;
-        r = rank_of(goes_on, m);
-        if (goes_on) cring[(chead + ccount + r) & (CONT_RING - 1u)] = make_uint2(d.w, p_end);
-        ccount += (unsigned)__popcll(m);
-    }
-    // the oldest round in flight: room for its pieces first (at most 128 more), then its sums, pieces and lines that go on
-    __device__ __forceinline__ void retire()
-    {
-        while (pcount >= 64u) { sync_wave(); decode_round(); }
-        scan_finish_one(grp < sa.k, sa.line0, sa.base0, sa.d0);
-        scan_finish_one(8u + grp < sa.k, sa.line1, sa.base1, sa.d1);
-        sa = sb;
-        pending--;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            // (w3 of the line's last lane is the line's `next`, not payload)
+            const unsigned w3s = l8 == 7u ? 0u : d[u].w;
+            const unsigned S = __builtin_amdgcn_sad_u8(d[u].x, 0u, __builtin_amdgcn_sad_u8(d[u].y, 0u, __builtin_amdgcn_sad_u8(d[u].z, 0u, __builtin_amdgcn_sad_u8(w3s, 0u, 0u))));
+            unsigned x = S, t;
+            t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true); x += ge1 ? t : 0u;      // row_shr:1
+            t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true); x += ge2 ? t : 0u;      // row_shr:2
+            t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true); x += ge4 ? t : 0u;      // row_shr:4
+            const unsigned p_end = base[u] + x;             // the position behind this lane's bytes
+            const bool wanted = has[u] && (int)p_end >= (int)cut && (d[u].x & 0xFFu) != 0xFFu;
+            unsigned long long m;
+            unsigned r = rank_of(wanted, m);
+            unsigned pos = phead + pcount + r;
+            if (pos >= PIECE_RING) pos -= PIECE_RING;
+            if (wanted) pring[pos] = make_uint2(line[u] * 8u + l8, p_end - S);
+            pcount += (unsigned)__popcll(m);
+            const bool goes_on = has[u] && l8 == 7u && d[u].w != N8_NONE;
+            r = rank_of(goes_on, m);
+            if (goes_on) cring[(chead + ccount + r) & (CONT_RING - 1u)] = make_uint2(d[u].w, p_end);
+            ccount += (unsigned)__popcll(m);
+        }
     }
     __device__ __forceinline__ void decode_round()
     {
@@ -501,24 +480,18 @@ struct Walk {
             }
         }
     }
-    // issue scan rounds while more than `keep` lines wait -- two rounds stay in flight, also when this returns
+    // scan while more than `keep` lines wait (decoding whenever 64 pieces are queued)
     __device__ __forceinline__ void drain_lines_to(unsigned keep)
     {
         while (lcount + ccount > keep) {
-            if (pending == 2u) retire();
             sync_wave();
-            const Scan sc = scan_issue();
-            if (pending == 0u) sa = sc; else sb = sc;
-            pending++;
+            scan_round();
+            while (pcount >= 64u) { sync_wave(); decode_round(); }
         }
     }
     __device__ __forceinline__ void finish()
     {
-        for (;;) {
-            drain_lines_to(0);
-            if (!pending) break;
-            retire();                          // (may queue lines that go on)
-        }
+        drain_lines_to(0);
         while (pcount) { sync_wave(); decode_round(); }
     }
 };
@@ -538,8 +511,8 @@ template <bool CLAMP>
 __global__ __launch_bounds__(TRACS_NN_THREADS) void nn_rows_kernel(const uint4 *__restrict__ T, size_t tgroups, const uint4 *__restrict__ lst_mask,
                                                                    const unsigned *__restrict__ off_lst, size_t groups, const uint4 *__restrict__ lines,
                                                                    const unsigned *__restrict__ c_u, unsigned n, unsigned row_begin, unsigned col_begin,
-                                                                   unsigned chunk, unsigned target, unsigned *__restrict__ ncomp, size_t ld,
-                                                                   int add_terms, unsigned lu)
+                                                                   unsigned chunk, unsigned target, unsigned segments, unsigned *__restrict__ ncomp,
+                                                                   size_t ld, int add_terms, unsigned lu)
 {
     // `chunk` counters -- row[0] is column c0 --, 64 slots nobody reads, the waves' rings
     extern __shared__ unsigned row[];
@@ -547,7 +520,7 @@ __global__ __launch_bounds__(TRACS_NN_THREADS) void nn_rows_kernel(const uint4 *
     const unsigned c0 = blockIdx.y * chunk, c1 = min(n, c0 + chunk);
     if (c1 <= i + 1 || c1 <= col_begin) return;            // no cell (i, j > i) in this column chunk
     const unsigned ci = c_u[i];
-    const unsigned nz = min(NN_MAX_SPLITS, max(1u, (ci + target - 1u) / target));
+    const unsigned nz = min(NN_MAX_SPLITS, max(segments, (ci + target - 1u) / target));
     if (blockIdx.z >= nz) return;
     const unsigned lo = max(max(i + 1, col_begin), c0);     // columns [lo, c1) of this chunk are cells of row i
     const unsigned span = c1 - c0;
@@ -842,14 +815,23 @@ int nn_rows_add(tracs_alignment *a, size_t row_begin, size_t row_end, size_t col
     }
     // ~2048 workgroups' worth of walks each, never less than 8192 (a workgroup's fixed cost: its row in LDS)
     const unsigned target = (unsigned)std::min<unsigned long long>(1u << 30, std::max<unsigned long long>(8192ull, g->tot_nnl / 2048ull));
-    const unsigned splits = (unsigned)std::min<unsigned long long>(NN_MAX_SPLITS, std::max<unsigned long long>(1, ((unsigned long long)g->max_row + target - 1) / target));
+    // Every row walks the sites in order, and the rows in flight are anywhere along the genome: a line is re-read (by the ~cN rows
+    // that are N at its site) long after it left the caches -- the walk then runs at the rate of random 128-byte reads from HBM.
+    // Cut into SEGMENTS of sites that all rows walk before any row starts on the next (grid.z is the slowest dimension of the
+    // dispatch order), the lines of a segment stay in the 256 MiB Infinity Cache between their uses.  The price is one flush of
+    // the row per segment (atomic adds): 10 000 x 5 Mbp, 1.2 GB of lines: 14.4 ms in one segment, 13.2 in 5, 16.3 in 32
+    // (profiles/r04/nn_rows_n8.txt).  TRACS_NN_SEGMENT_MB overrides the segment size (0: one segment) for that measurement.
+    const char *seg_env = getenv("TRACS_NN_SEGMENT_MB");
+    const unsigned long long seg_bytes = (seg_env ? strtoull(seg_env, nullptr, 10) : 256ull) << 20;
+    const unsigned segments = seg_bytes ? (unsigned)std::min<unsigned long long>(NN_MAX_SPLITS, std::max<unsigned long long>(1, (g->n_lines * 128ull + seg_bytes - 1) / seg_bytes)) : 1u;
+    const unsigned splits = (unsigned)std::min<unsigned long long>(NN_MAX_SPLITS, std::max<unsigned long long>(segments, ((unsigned long long)g->max_row + target - 1) / target));
     const dim3 grid((unsigned)(row_end - row_begin), (unsigned)((n + chunk - 1) / chunk), splits);
     if (grid.y == 1)                                       // one column chunk: every decoded position is a counter of the row
         hipLaunchKernelGGL(nn_rows_kernel<false>, grid, dim3(TRACS_NN_THREADS), lds, stream, g->T, g->tgroups, g->lst_mask, g->off_lst, g->groups, g->lines,
-                           a->c_counted, (unsigned)n, (unsigned)row_begin, (unsigned)col_begin, chunk, target, ncomp, ld, add_terms, lu);
+                           a->c_counted, (unsigned)n, (unsigned)row_begin, (unsigned)col_begin, chunk, target, segments, ncomp, ld, add_terms, lu);
     else
         hipLaunchKernelGGL(nn_rows_kernel<true>, grid, dim3(TRACS_NN_THREADS), lds, stream, g->T, g->tgroups, g->lst_mask, g->off_lst, g->groups, g->lines,
-                           a->c_counted, (unsigned)n, (unsigned)row_begin, (unsigned)col_begin, chunk, target, ncomp, ld, add_terms, lu);
+                           a->c_counted, (unsigned)n, (unsigned)row_begin, (unsigned)col_begin, chunk, target, segments, ncomp, ld, add_terms, lu);
     TRACS_HIP_CHECK(hipGetLastError());
     return TRACS_OK;
 }
