@@ -140,7 +140,8 @@ struct Transpose32 {
 
 __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBuild mb, size_t n_pad, unsigned n,
                                                          unsigned long long *__restrict__ p_off, unsigned *__restrict__ p_ent,
-                                                         uint2 *__restrict__ E, uint4 *__restrict__ lines)
+                                                         uint2 *__restrict__ E, uint4 *__restrict__ lines,
+                                                         unsigned *__restrict__ cnt, unsigned *__restrict__ c_p)
 {
     __shared__ unsigned bm[SITES_PER_GROUP * BM_STRIDE];     // the piece's N bits, site-major: bm[site * BM_STRIDE + 32-sample word]
     __shared__ unsigned cn[SITES_PER_GROUP], kp[SITES_PER_GROUP], ovf[SITES_PER_GROUP], curP[SITES_PER_GROUP], rk[SITES_PER_GROUP];
@@ -215,6 +216,7 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
             const bool flagged = s < n && ((fl >> (s & 63u)) & 1ull);
             if (!flagged) continue;
             const uint4 A = base[s], C = base[n_pad + s], G = base[2 * n_pad + s], T = base[3 * n_pad + s];
+            unsigned listed = 0, listed_w = 0;               // this sample's listed entries in the group, and their w's
 #pragma unroll
             for (int w = 0; w < 4; w++) {
                 const unsigned a = word_of(A, w), c = word_of(C, w), gg = word_of(G, w), t = word_of(T, w), isn = word_of(N, w);
@@ -232,8 +234,11 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
                     const unsigned long long pos = bP[w * 32 + b] + slot;
                     p_ent[pos] = (s << ENT_SHIFT) | code;
                     E[pos] = make_uint2(s, (rk[w * 32 + b] << ENT_SHIFT) | code);
+                    listed++; listed_w += code >> 4;
                 }
             }
+            if (listed) atomicAdd(&cnt[s], listed);
+            if (listed_w) atomicAdd(&c_p[s], listed_w);
         }
         __syncthreads();
         // ---- the site's thread: its 32 words of the piece in order (four independent reads at a time), every set bit a sample
@@ -264,21 +269,16 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
 }
 
 // ---- per sample: listed entries (from E) ---------------------------------------------------------------------------------------
-// FILL = false: cnt[s]++ and c_p[s] += w;  FILL = true: entries placed through per-sample cursors.
-template <bool FILL>
-__global__ __launch_bounds__(256) void listed_entries_kernel(const uint2 *__restrict__ E, unsigned long long count, unsigned *__restrict__ cnt,
-                                                             unsigned *__restrict__ c_p, const unsigned long long *__restrict__ off,
-                                                             unsigned *__restrict__ cur, unsigned *__restrict__ ent)
+// (their number per sample, cnt[s], and c_p[s] = the sum of their w's come from the per-site pass.)  The entries of E are placed
+// through per-sample cursors.
+__global__ __launch_bounds__(256) void listed_entries_kernel(const uint2 *__restrict__ E, unsigned long long count,
+                                                             const unsigned long long *__restrict__ off, unsigned *__restrict__ cur,
+                                                             unsigned *__restrict__ ent)
 {
     const unsigned long long k = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (k >= count) return;
     const uint2 e = E[k];
-    if (!FILL) {
-        atomicAdd(&cnt[e.x], 1u);
-        if (e.y & 16u) atomicAdd(&c_p[e.x], 1u);
-    } else {
-        ent[off[e.x] + atomicAdd(&cur[e.x], 1u)] = e.y;
-    }
+    ent[off[e.x] + atomicAdd(&cur[e.x], 1u)] = e.y;
 }
 
 // exclusive scan of v[0 .. count) -> out[0 .. count] (one workgroup; wave scans through shuffles); the largest element -> *vmax
@@ -369,28 +369,30 @@ __global__ void max_count_kernel(const unsigned *__restrict__ c, size_t n, unsig
 // kernel was bound by instruction issue and by the LDS pipe together (profiles/r04/nn_rows_n8.txt); the two-phase form issues the
 // per-byte instructions and the LDS adds for the pieces that count only.
 typedef __attribute__((address_space(3))) unsigned lds_u32;
-constexpr unsigned LINE_RING = 128, CONT_RING = 32, PIECE_RING = 192;
-constexpr unsigned WALK_LDS_PER_WAVE = LINE_RING * 4 + CONT_RING * 8 + PIECE_RING * 8;
+constexpr unsigned LINE_RING = 128, PIECE_RING = 192;
+constexpr unsigned WALK_LDS_PER_WAVE = LINE_RING * 8 + PIECE_RING * 8;
 
 // CLAMP = false: the row's counters cover every sample (one column chunk: n <= 30 720): a decoded position needs no range check.
 template <bool CLAMP>
 struct Walk {
     const uint4 *lines;
-    unsigned *lring;                           // this wave's rings (LDS): lines (index)
-    uint2 *cring, *pring;                      //   lines that go on (index, position before their first byte); pieces (uint4 index, position before the piece)
-    unsigned lhead, lcount, chead, ccount, phead, pcount;      // (wave-uniform)
+    uint2 *lring, *pring;                      // this wave's rings (LDS): lines (index, position before the line's first byte: -1 at a site's
+                                               //   first line); pieces (uint4 index, position before the piece)
+    unsigned lhead, lcount, phead, pcount;     // (wave-uniform)
     unsigned lane, grp, l8;
     unsigned neg4lo, dump4, val;               // row[] starts at LDS byte 0: counter of column j at 4 (j - c0); the lane's dump slot
     unsigned cut;                              // a piece that ends below this position has nothing to add
-    bool ge1, ge2, ge4;
+    bool lt7, lt6, lt4;
 
     __device__ __forceinline__ void init(const uint4 *lines_, unsigned *lds, unsigned lane_)
     {
         lines = lines_;
-        lring = lds; cring = reinterpret_cast<uint2 *>(lds + LINE_RING); pring = cring + CONT_RING;
-        lhead = lcount = chead = ccount = phead = pcount = 0;
+        lring = reinterpret_cast<uint2 *>(lds); pring = lring + LINE_RING;
+        lhead = lcount = phead = pcount = 0;
         lane = lane_; grp = lane_ >> 3; l8 = lane_ & 7u;
-        ge1 = l8 >= 1u; ge2 = l8 >= 2u; ge4 = l8 >= 4u;
+        lt7 = l8 < 7u; lt6 = l8 < 6u; lt4 = l8 < 4u;
+        // (a scan round reads 16 slots whatever the count: every slot holds a line that exists)
+        lring[lane] = make_uint2(0u, 0u); lring[64 + lane] = make_uint2(0u, 0u);
     }
     __device__ __forceinline__ unsigned rank_of(bool has, unsigned long long &m) const
     {
@@ -401,7 +403,7 @@ struct Walk {
     {
         unsigned long long m;
         const unsigned r = rank_of(has, m);
-        if (has) lring[(lhead + lcount + r) & (LINE_RING - 1u)] = line;
+        if (has) lring[(lhead + lcount + r) & (LINE_RING - 1u)] = make_uint2(line, 0xFFFFFFFFu);
         lcount += (unsigned)__popcll(m);
     }
     __device__ __forceinline__ void sync_wave() const
@@ -412,44 +414,38 @@ struct Walk {
     }
     __device__ __forceinline__ void scan_round()
     {
-        const unsigned kc = min(ccount, 16u), kl = min(lcount, 16u - kc), k = kc + kl;      // lines that go on first
-        unsigned line[2], base[2];
-        bool has[2];
+        const unsigned k = min(lcount, 16u);
+        uint2 ref[2];
         uint4 d[2];
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const unsigned idx = u * 8 + grp;
-            has[u] = idx < k;
-            const uint2 c = cring[(chead + idx) & (CONT_RING - 1u)];
-            const unsigned l = lring[(lhead + idx - kc) & (LINE_RING - 1u)];
-            line[u] = idx < kc ? c.x : l;
-            base[u] = idx < kc ? c.y : 0xFFFFFFFFu;
-        }
+        for (int u = 0; u < 2; u++) ref[u] = lring[(lhead + u * 8 + grp) & (LINE_RING - 1u)];
 #pragma unroll
-        for (int u = 0; u < 2; u++) d[u] = lines[(size_t)(has[u] ? line[u] : 0u) * 8 + l8];
-        chead = (chead + kc) & (CONT_RING - 1u); ccount -= kc;
-        lhead = (lhead + kl) & (LINE_RING - 1u); lcount -= kl;
+        for (int u = 0; u < 2; u++) d[u] = lines[(size_t)ref[u].x * 8 + l8];
+        __builtin_amdgcn_sched_barrier(0);                  // (both loads on their way before anything waits for the first)
+        lhead = (lhead + k) & (LINE_RING - 1u); lcount -= k;
 #pragma unroll
         for (int u = 0; u < 2; u++) {
+            const bool has = u * 8 + grp < k;
             // (w3 of the line's last lane is the line's `next`, not payload)
-            const unsigned w3s = l8 == 7u ? 0u : d[u].w;
+            const unsigned w3s = lt7 ? d[u].w : 0u;
             const unsigned S = __builtin_amdgcn_sad_u8(d[u].x, 0u, __builtin_amdgcn_sad_u8(d[u].y, 0u, __builtin_amdgcn_sad_u8(d[u].z, 0u, __builtin_amdgcn_sad_u8(w3s, 0u, 0u))));
-            unsigned x = S, t;
-            t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true); x += ge1 ? t : 0u;      // row_shr:1
-            t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true); x += ge2 ? t : 0u;      // row_shr:2
-            t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true); x += ge4 ? t : 0u;      // row_shr:4
-            const unsigned p_end = base[u] + x;             // the position behind this lane's bytes
-            const bool wanted = has[u] && (int)p_end >= (int)cut && (d[u].x & 0xFFu) != 0xFFu;
+            // inclusive prefix over the line's eight lanes: what a step hands on is zeroed where it would cross into the next line
+            unsigned x = S;
+            x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)(lt7 ? x : 0u), 0x111, 0xF, 0xF, true);      // row_shr:1
+            x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)(lt6 ? x : 0u), 0x112, 0xF, 0xF, true);      // row_shr:2
+            x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)(lt4 ? x : 0u), 0x114, 0xF, 0xF, true);      // row_shr:4
+            const unsigned p_end = ref[u].y + x;            // the position behind this lane's bytes
+            const bool wanted = has && (int)p_end >= (int)cut && (d[u].x & 0xFFu) != 0xFFu;
             unsigned long long m;
             unsigned r = rank_of(wanted, m);
             unsigned pos = phead + pcount + r;
             if (pos >= PIECE_RING) pos -= PIECE_RING;
-            if (wanted) pring[pos] = make_uint2(line[u] * 8u + l8, p_end - S);
+            if (wanted) pring[pos] = make_uint2(ref[u].x * 8u + l8, p_end - S);
             pcount += (unsigned)__popcll(m);
-            const bool goes_on = has[u] && l8 == 7u && d[u].w != N8_NONE;
+            const bool goes_on = has && !lt7 && d[u].w != N8_NONE;
             r = rank_of(goes_on, m);
-            if (goes_on) cring[(chead + ccount + r) & (CONT_RING - 1u)] = make_uint2(d[u].w, p_end);
-            ccount += (unsigned)__popcll(m);
+            if (goes_on) lring[(lhead + lcount + r) & (LINE_RING - 1u)] = make_uint2(d[u].w, p_end);
+            lcount += (unsigned)__popcll(m);
         }
     }
     __device__ __forceinline__ void decode_round()
@@ -483,7 +479,7 @@ struct Walk {
     // scan while more than `keep` lines wait (decoding whenever 64 pieces are queued)
     __device__ __forceinline__ void drain_lines_to(unsigned keep)
     {
-        while (lcount + ccount > keep) {
+        while (lcount > keep) {
             sync_wave();
             scan_round();
             while (pcount >= 64u) { sync_wave(); decode_round(); }
@@ -563,10 +559,10 @@ __global__ __launch_bounds__(TRACS_NN_THREADS) void nn_rows_kernel(const uint4 *
         if (total <= LINE_RING - 32u) {
             // (the usual case: all of the batch's sites fit the ring at once -- every lane drops its own, word by word)
             unsigned pos = W.lhead + W.lcount + x - cnt;
-            while (r0) { const unsigned bit = __ffs(r0) - 1; r0 &= r0 - 1; W.lring[pos++ & (LINE_RING - 1u)] = og + __popc(lm.x & ((1u << bit) - 1u)); }
-            while (r1) { const unsigned bit = __ffs(r1) - 1; r1 &= r1 - 1; W.lring[pos++ & (LINE_RING - 1u)] = pre1 + __popc(lm.y & ((1u << bit) - 1u)); }
-            while (r2) { const unsigned bit = __ffs(r2) - 1; r2 &= r2 - 1; W.lring[pos++ & (LINE_RING - 1u)] = pre2 + __popc(lm.z & ((1u << bit) - 1u)); }
-            while (r3) { const unsigned bit = __ffs(r3) - 1; r3 &= r3 - 1; W.lring[pos++ & (LINE_RING - 1u)] = pre3 + __popc(lm.w & ((1u << bit) - 1u)); }
+            while (r0) { const unsigned bit = __ffs(r0) - 1; r0 &= r0 - 1; W.lring[pos++ & (LINE_RING - 1u)] = make_uint2(og + __popc(lm.x & ((1u << bit) - 1u)), 0xFFFFFFFFu); }
+            while (r1) { const unsigned bit = __ffs(r1) - 1; r1 &= r1 - 1; W.lring[pos++ & (LINE_RING - 1u)] = make_uint2(pre1 + __popc(lm.y & ((1u << bit) - 1u)), 0xFFFFFFFFu); }
+            while (r2) { const unsigned bit = __ffs(r2) - 1; r2 &= r2 - 1; W.lring[pos++ & (LINE_RING - 1u)] = make_uint2(pre2 + __popc(lm.z & ((1u << bit) - 1u)), 0xFFFFFFFFu); }
+            while (r3) { const unsigned bit = __ffs(r3) - 1; r3 &= r3 - 1; W.lring[pos++ & (LINE_RING - 1u)] = make_uint2(pre3 + __popc(lm.w & ((1u << bit) - 1u)), 0xFFFFFFFFu); }
             W.lcount += total;
             continue;
         }
@@ -764,14 +760,13 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb_, hipStream_t 
     SL_TRY(hipMemcpyAsync(g->lst_mask, mb.lst_mask, groups * sizeof(uint4), hipMemcpyDeviceToDevice, stream));
     SL_TRY(hipMemcpyAsync(g->off_lst, mb.off_lst, groups * sizeof(unsigned), hipMemcpyDeviceToDevice, stream));
     const double plane_b = (double)groups * (double)a->n_pad * sizeof(uint4);      // the N plane
-    hipLaunchKernelGGL(site_lists_kernel, dim3((unsigned)groups), dim3(SITE_THREADS), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off, g->p_ent, E, g->lines);
+    hipLaunchKernelGGL(site_lists_kernel, dim3((unsigned)groups), dim3(SITE_THREADS), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off, g->p_ent, E, g->lines, cnt, g->c_p);
     pack_stage_mark("lists: per site", stream, plane_b + (double)groups * SITES_PER_GROUP * 8.0,
                     (double)L * 128.0 + (double)mb.tot_p * 12.0 + (double)L * 8.0);
     const unsigned egrid = (unsigned)((mb.tot_p + 255) / 256);
-    if (egrid) hipLaunchKernelGGL((listed_entries_kernel<false>), dim3(egrid), dim3(256), 0, stream, E, mb.tot_p, cnt, g->c_p, nullptr, nullptr, nullptr);
     hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, cnt, n, g->s_off);
-    if (egrid) hipLaunchKernelGGL((listed_entries_kernel<true>), dim3(egrid), dim3(256), 0, stream, E, mb.tot_p, nullptr, nullptr, g->s_off, cur, g->s_ent);
-    pack_stage_mark("listed entries per sample", stream, (double)mb.tot_p * 16.0 + (double)n * 4.0, (double)mb.tot_p * 4.0 + (double)n * 20.0);
+    if (egrid) hipLaunchKernelGGL(listed_entries_kernel, dim3(egrid), dim3(256), 0, stream, E, mb.tot_p, g->s_off, cur, g->s_ent);
+    pack_stage_mark("listed entries per sample", stream, (double)mb.tot_p * 8.0 + (double)n * 4.0, (double)mb.tot_p * 4.0 + (double)n * 12.0);
     if (bitmaps) {
         // (a->c_counted was zeroed by the caller: this kernel is what fills it when the rows' bitmaps are built)
         const size_t octs = g->tgroups / 8;
@@ -793,7 +788,7 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb_, hipStream_t 
 }
 
 // columns of the pair matrix per LDS row: the row's counters + 64 dump slots + the waves' rings must fit the CU's 160 KiB
-constexpr unsigned ROW_CHUNK_MAX = 30720;
+constexpr unsigned ROW_CHUNK_MAX = 30656;
 static unsigned row_chunk(size_t n) { return (unsigned)std::min<size_t>((n + 63) / 64 * 64, ROW_CHUNK_MAX); }
 static constexpr size_t kWalkLds = (size_t)(TRACS_NN_THREADS / 64) * WALK_LDS_PER_WAVE;
 
