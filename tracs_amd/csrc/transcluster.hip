@@ -441,6 +441,7 @@ struct KeyTable {
     int part = 0, parts = 1;
     unsigned n_max = 0, d_max = 0;
     double *p0 = nullptr, *eK = nullptr;
+    unsigned step = 1;                     // doubles between consecutive slots: 1 two arrays, 2 one array of (p0, eK) pairs (eK = p0 + 1)
     unsigned *overflow = nullptr;          // set when a key falls outside the table
     __device__ bool mine(int N, long long gap) const
     {
@@ -534,8 +535,8 @@ __global__ void tc_keys_kernel(Src src, const unsigned *__restrict__ key_elem, u
         double p0, eK = 0.0; int ks;
         const bool done = tc_eval(N, d, P, lg, p0, eK, ks, TC_SERIAL_CAP, key_state + 4 * (size_t)id);
         key_p0[id] = p0;
-        if (slot >= 0) kt.p0[slot] = p0;
-        if (done) { key_eK[id] = eK; if (slot >= 0) kt.eK[slot] = eK; }
+        if (slot >= 0) kt.p0[slot * kt.step] = p0;
+        if (done) { key_eK[id] = eK; if (slot >= 0) kt.eK[slot * kt.step] = eK; }
         else long_ids[atomicAdd(n_long, 1u)] = id;
     }
 }
@@ -632,25 +633,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TRACS_TC_WAV
             if (fresh) key_p0[id] = p0;
             if (kt.p0) {
                 const long long slot = kt.index(N, src.day_gap(elem));
-                if (slot >= 0) { kt.eK[slot] = eK; if (fresh) kt.p0[slot] = p0; }
+                if (slot >= 0) { kt.eK[slot * kt.step] = eK; if (fresh) kt.p0[slot * kt.step] = p0; }
             }
         }
-    }
-}
-
-// multi-GPU path: P / E(K) of every cell from the completed key table
-__global__ void tc_table_gather_kernel(DenseSource src, KeyTable kt, int exp_p0, double *__restrict__ p0, double *__restrict__ eK)
-{
-    const size_t total = src.size();
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-        int N; double d;
-        if (!src.get(e, N, d)) continue;
-        const long long slot = kt.index(N, src.day_gap(e));
-        if (slot < 0) continue;
-        const size_t o = src.out_index(e);
-        const double v = kt.p0[slot];
-        p0[o] = exp_p0 ? exp(v) : v;
-        eK[o] = kt.eK[slot];
     }
 }
 
@@ -679,38 +664,90 @@ __global__ void tc_gather_kernel(Src src, const unsigned *__restrict__ eslot, co
 // hash slot per cell (400 MB at 10 000 samples), claimed slots with atomicCAS and read the slots back to gather.
 constexpr unsigned long long TC_GRID_BITS = 1ull << 24;
 
-// cb[0] = largest distance of a valid cell, cb[1] = smallest day + 2^31, cb[2] = largest day + 2^31 (over all samples)
-__global__ void tc_cell_bounds_kernel(DenseSource src, unsigned *__restrict__ cb)
+// Row-structured passes over a dense block (bounds, marking, gather): workgroup (x, y) is row x of the block and slice y of its
+// columns; a thread takes four consecutive columns at a time (16-byte loads of the distances and of the days), starting at the
+// row's first cell: no division per cell, nothing issued below the diagonal.
+struct RowQuad {
+    size_t i, j0;                // row (sample index), first column of the quad (a multiple of 4)
+    unsigned d[4];
+    int day[4];
+    bool ok[4];                  // column j0 + k is a cell of the block within the threshold
+};
+constexpr unsigned TC_ROW_THREADS = 256;
+__device__ __forceinline__ bool tc_wide(const DenseSource &src)
 {
-    const size_t total = src.size();
-    unsigned mn = 0;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-        int N; double d;
-        if (src.get(e, N, d)) mn = max(mn, (unsigned)N);
+    return src.ld % 4 == 0 && (reinterpret_cast<size_t>(src.dist) | reinterpret_cast<size_t>(src.days)) % 16 == 0;
+}
+template <class F>
+__device__ __forceinline__ void tc_for_row_quads(const DenseSource &src, F f)
+{
+    const size_t i = src.row_of(blockIdx.x);
+    const size_t jlo = max(i + 1, src.col_begin);
+    const bool wide = tc_wide(src);
+    const unsigned *row = src.dist + i * src.ld;
+    for (size_t q = jlo / 4 + (size_t)blockIdx.y * TC_ROW_THREADS + threadIdx.x; q * 4 < src.n; q += (size_t)gridDim.y * TC_ROW_THREADS) {
+        RowQuad c;
+        c.i = i; c.j0 = q * 4;
+        if (wide && c.j0 + 3 < src.n) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(row + c.j0);
+            const int4 t = *reinterpret_cast<const int4 *>(src.days + c.j0);
+            c.d[0] = v.x; c.d[1] = v.y; c.d[2] = v.z; c.d[3] = v.w;
+            c.day[0] = t.x; c.day[1] = t.y; c.day[2] = t.z; c.day[3] = t.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const bool in = c.j0 + k < src.n; c.d[k] = in ? row[c.j0 + k] : 0u; c.day[k] = in ? src.days[c.j0 + k] : 0; }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) c.ok[k] = c.j0 + k >= jlo && c.j0 + k < src.n && (long long)c.d[k] <= (long long)src.thr;
+        f(c);
     }
+}
+static dim3 tc_row_grid(const DenseSource &src)
+{
+    const size_t rows = src.rows1() + (src.row_end2 - src.row_begin2);
+    const size_t quads = (src.n + 3) / 4;
+    return dim3((unsigned)rows, (unsigned)std::min<size_t>(4, std::max<size_t>(1, (quads + TC_ROW_THREADS - 1) / TC_ROW_THREADS)));
+}
+
+// cb[0] = largest distance of a valid cell, cb[1] = smallest day + 2^31, cb[2] = largest day + 2^31 (over all samples)
+__global__ __launch_bounds__(TC_ROW_THREADS) void tc_cell_bounds_kernel(DenseSource src, unsigned *__restrict__ cb)
+{
+    unsigned mn = 0;
+    tc_for_row_quads(src, [&](const RowQuad &c) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (c.ok[k]) mn = max(mn, c.d[k]);
+    });
     unsigned lo = 0xFFFFFFFFu, hi = 0u;
-    if (blockIdx.x == 0)
+    const bool first = blockIdx.x == 0 && blockIdx.y == 0;
+    if (first)
         for (size_t s = threadIdx.x; s < src.n; s += blockDim.x) { const unsigned v = (unsigned)src.days[s] + 0x80000000u; lo = min(lo, v); hi = max(hi, v); }
     for (int off = 32; off > 0; off >>= 1) {
         mn = max(mn, (unsigned)__shfl_xor((int)mn, off, 64));
         lo = min(lo, (unsigned)__shfl_xor((int)lo, off, 64)); hi = max(hi, (unsigned)__shfl_xor((int)hi, off, 64));
     }
-    if ((threadIdx.x & 63) == 0) { atomicMax(&cb[0], mn); if (blockIdx.x == 0) { atomicMin(&cb[1], lo); atomicMax(&cb[2], hi); } }
+    // (one address for every workgroup of the grid: an atomic only from a wave that would raise what is there)
+    if ((threadIdx.x & 63) == 0) {
+        if (mn > __hip_atomic_load(&cb[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&cb[0], mn);
+        if (first) { atomicMin(&cb[1], lo); atomicMax(&cb[2], hi); }
+    }
 }
 
 // cb[3] = 1 when the grid does not fit; otherwise bit N * stride + gap of every valid cell's key
-__global__ void tc_mark_kernel(DenseSource src, unsigned *__restrict__ cb, unsigned *__restrict__ bits)
+__global__ __launch_bounds__(TC_ROW_THREADS) void tc_mark_kernel(DenseSource src, unsigned *__restrict__ cb, unsigned *__restrict__ bits)
 {
     const unsigned long long stride = (unsigned long long)(cb[2] - cb[1]) + 1ull;
-    if (((unsigned long long)cb[0] + 1ull) * stride > TC_GRID_BITS || cb[2] < cb[1]) { if (blockIdx.x == 0 && threadIdx.x == 0) cb[3] = 1u; return; }
-    const size_t total = src.size();
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-        int N; double d;
-        if (!src.get(e, N, d)) continue;
-        const unsigned idx = (unsigned)((unsigned long long)N * stride + (unsigned long long)src.day_gap(e));
-        const unsigned bit = 1u << (idx & 31u);
-        if (!(bits[idx >> 5] & bit)) atomicOr(&bits[idx >> 5], bit);
-    }
+    if (((unsigned long long)cb[0] + 1ull) * stride > TC_GRID_BITS || cb[2] < cb[1]) { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) cb[3] = 1u; return; }
+    const int di = src.days[src.row_of(blockIdx.x)];
+    tc_for_row_quads(src, [&](const RowQuad &c) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (!c.ok[k]) continue;
+            const long long g = (long long)di - (long long)c.day[k];
+            const unsigned idx = (unsigned)((unsigned long long)c.d[k] * stride + (unsigned long long)(g < 0 ? -g : g));
+            const unsigned bit = 1u << (idx & 31u);
+            if (!(bits[idx >> 5] & bit)) atomicOr(&bits[idx >> 5], bit);
+        }
+    });
 }
 
 __global__ void tc_bits_count_kernel(const unsigned *__restrict__ bits, unsigned words, unsigned *__restrict__ n_keys)
@@ -731,45 +768,45 @@ __global__ void tc_bits_collect_kernel(const unsigned *__restrict__ bits, unsign
     }
 }
 
-// P / E(K) of every cell from the completed key tables, two cells of a row per thread: 8-byte loads of d, 16-byte stores of P and
-// E(K) where both cells are cells of the block (the pair straddling the diagonal or the column bound stores singly)
-__global__ void tc_table_gather2_kernel(DenseSource src, KeyTable kt, int exp_p0, double *__restrict__ p0, double *__restrict__ eK)
+// P / E(K) of every cell from the completed key tables, four cells of a row per thread: 16-byte loads of d and the days, 16-byte
+// stores of P and E(K) where both cells of a pair are cells of the block (a pair straddling the diagonal, the column bound or the
+// threshold stores singly)
+__global__ __launch_bounds__(TC_ROW_THREADS) void tc_table_gather2_kernel(DenseSource src, KeyTable kt, int exp_p0, double *__restrict__ p0,
+                                                                          double *__restrict__ eK)
 {
-    const size_t half = (src.n + 1) / 2, rows = src.rows1() + (src.row_end2 - src.row_begin2);
-    const size_t total = rows * half;
-    const bool wide_ok = (src.ld % 2 == 0) && ((reinterpret_cast<size_t>(p0) | reinterpret_cast<size_t>(eK)) % 16 == 0) &&
-                         (reinterpret_cast<size_t>(src.dist) % 8 == 0);
-    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
-        const size_t i = src.row_of(t / half), j0 = (t % half) * 2;
-        if (j0 + 1 <= i || j0 + 1 < src.col_begin) continue;                 // neither cell is a cell of the block
-        double vp[2], ve[2];
-        bool ok[2];
-        unsigned dd[2];
-        const bool two = j0 + 1 < src.n;
-        if (wide_ok && two) { const uint2 q = *reinterpret_cast<const uint2 *>(src.dist + i * src.ld + j0); dd[0] = q.x; dd[1] = q.y; }
-        else { dd[0] = src.dist[i * src.ld + j0]; dd[1] = two ? src.dist[i * src.ld + j0 + 1] : 0u; }
-        const long long di = (long long)src.days[i];
+    const bool wide_out = tc_wide(src) && (reinterpret_cast<size_t>(p0) | reinterpret_cast<size_t>(eK)) % 16 == 0;
+    const int di = src.days[src.row_of(blockIdx.x)];
+    tc_for_row_quads(src, [&](const RowQuad &c) {
+        double vp[4], ve[4];
+        bool ok[4];
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const size_t j = j0 + k;
-            ok[k] = j < src.n && j > i && j >= src.col_begin && (long long)dd[k] <= (long long)src.thr;
+        for (int k = 0; k < 4; k++) {
+            ok[k] = c.ok[k];
             vp[k] = ve[k] = 0.0;
             if (ok[k]) {
-                const long long g = di - (long long)src.days[j];
-                const long long slot = kt.index((int)dd[k], g < 0 ? -g : g);
+                const long long g = (long long)di - (long long)c.day[k];
+                const long long slot = kt.index((int)c.d[k], g < 0 ? -g : g);
                 ok[k] = slot >= 0;
-                if (ok[k]) { const double v = kt.p0[slot]; vp[k] = exp_p0 ? exp(v) : v; ve[k] = kt.eK[slot]; }
+                if (ok[k]) {
+                    double v;
+                    if (kt.step == 2) { const double2 pe = *reinterpret_cast<const double2 *>(kt.p0 + 2 * slot); v = pe.x; ve[k] = pe.y; }      // one 16-byte read per cell
+                    else { v = kt.p0[slot]; ve[k] = kt.eK[slot]; }
+                    vp[k] = exp_p0 ? exp(v) : v;
+                }
             }
         }
-        const size_t o = i * src.ld + j0;
-        if (wide_ok && ok[0] && ok[1]) {
-            *reinterpret_cast<double2 *>(p0 + o) = make_double2(vp[0], vp[1]);
-            *reinterpret_cast<double2 *>(eK + o) = make_double2(ve[0], ve[1]);
-        } else {
-            if (ok[0]) { p0[o] = vp[0]; eK[o] = ve[0]; }
-            if (ok[1]) { p0[o + 1] = vp[1]; eK[o + 1] = ve[1]; }
+        const size_t o = c.i * src.ld + c.j0;
+#pragma unroll
+        for (int h = 0; h < 4; h += 2) {
+            if (wide_out && ok[h] && ok[h + 1]) {
+                *reinterpret_cast<double2 *>(p0 + o + h) = make_double2(vp[h], vp[h + 1]);
+                *reinterpret_cast<double2 *>(eK + o + h) = make_double2(ve[h], ve[h + 1]);
+            } else {
+                if (ok[h]) { p0[o + h] = vp[h]; eK[o + h] = ve[h]; }
+                if (ok[h + 1]) { p0[o + h + 1] = vp[h + 1]; eK[o + h + 1] = ve[h + 1]; }
+            }
         }
-    }
+    });
 }
 
 // lprob_k_given_N (older formulation, exported for tests/test_llk.py): transcluster.hpp:90-129
@@ -960,9 +997,9 @@ static int run_trans_dist_grid(const DenseSource &src, size_t total, double lamb
     const unsigned init[8] = {0u, 0u, 0u, 0u, 0u, 0xFFFFFFFFu, 0u, 0u};
     TRACS_HIP_CHECK(hipMemcpyAsync(n_keys, init, 32, hipMemcpyHostToDevice, stream));
     TRACS_HIP_CHECK(hipMemsetAsync(bits, 0, (size_t)words * 4, stream));
-    const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 32);
-    hipLaunchKernelGGL(tc_cell_bounds_kernel, dim3(blocks), dim3(256), 0, stream, src, cb);
-    hipLaunchKernelGGL(tc_mark_kernel, dim3(blocks), dim3(256), 0, stream, src, cb, bits);
+    const dim3 row_grid = tc_row_grid(src);
+    hipLaunchKernelGGL(tc_cell_bounds_kernel, row_grid, dim3(TC_ROW_THREADS), 0, stream, src, cb);
+    hipLaunchKernelGGL(tc_mark_kernel, row_grid, dim3(TC_ROW_THREADS), 0, stream, src, cb, bits);
     hipLaunchKernelGGL(tc_bits_count_kernel, dim3(1024), dim3(256), 0, stream, bits, words, n_keys);
     unsigned h[8] = {0};
     TRACS_HIP_CHECK(hipMemcpyAsync(h, n_keys, 32, hipMemcpyDeviceToHost, stream));
@@ -982,14 +1019,12 @@ static int run_trans_dist_grid(const DenseSource &src, size_t total, double lamb
     TRACS_HIP_CHECK(hipMemsetAsync(n_keys, 0, 8, stream));          // [0] key counter, [1] long-key counter
     hipLaunchKernelGGL(tc_bits_collect_kernel, dim3(1024), dim3(256), 0, stream, bits, words, key_elem, n_keys);
     KeyTable kt;
-    kt.n_max = n_max; kt.d_max = d_max; kt.p0 = tables; kt.eK = tables + cells;
+    kt.n_max = n_max; kt.d_max = d_max; kt.p0 = tables; kt.eK = tables + 1; kt.step = 2;      // (p0, eK) pairs: what a cell reads is 16 contiguous bytes
     kt.overflow = n_keys + 7;                                        // (cannot happen: every cell's key was marked inside the grid)
     GridSource grid{d_max + 1u, cells};
     double *key_p0 = nullptr, *key_eK = nullptr;
     if ((rc = tc_evaluate_keys(grid, key_elem, nk, n_keys, lamb, beta, thr, lg, &key_p0, &key_eK, kt, stream))) return rc;
-    const size_t pairs2 = (src.rows1() + (src.row_end2 - src.row_begin2)) * ((src.n + 1) / 2);
-    hipLaunchKernelGGL(tc_table_gather2_kernel, dim3((unsigned)std::min<size_t>((pairs2 + 255) / 256, 256 * 32)), dim3(256), 0, stream,
-                       src, kt, exp_p0, p0, eK);
+    hipLaunchKernelGGL(tc_table_gather2_kernel, row_grid, dim3(TC_ROW_THREADS), 0, stream, src, kt, exp_p0, p0, eK);
     TRACS_HIP_CHECK(hipGetLastError());
     return TRACS_OK;
 }
@@ -1095,9 +1130,7 @@ int tracs_trans_table_gather(const uint32_t *dist, size_t ld, size_t n, size_t r
     DenseSource src{dist, days, ld, n, row_begin, row_end, col_begin, dist_threshold};
     KeyTable kt;
     kt.n_max = n_max; kt.d_max = d_max; kt.p0 = const_cast<double *>(table_p0); kt.eK = const_cast<double *>(table_eK); kt.overflow = overflow;
-    const size_t total = (row_end - row_begin) * n;
-    hipLaunchKernelGGL(tc_table_gather_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 256 * 32)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), src, kt, exp_p0, p0, eK);
+    hipLaunchKernelGGL(tc_table_gather2_kernel, tc_row_grid(src), dim3(TC_ROW_THREADS), 0, static_cast<hipStream_t>(stream), src, kt, exp_p0, p0, eK);
     TRACS_HIP_CHECK(hipGetLastError());
     return TRACS_OK;
 }
