@@ -151,9 +151,8 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
     const size_t g = blockIdx.x;
     __shared__ unsigned red[4][4][4];
     __shared__ unsigned sref[4][4];                     // one-base sample seen, ref X, ref Y, somebody is not N
-    __shared__ unsigned planes_lds[256][4][8];          // one counter's bit planes of every thread (32 KiB)
+    __shared__ unsigned planes_lds[4][8][256];          // one counter's bit planes of every thread (32 KiB): [word][plane][thread]
     __shared__ unsigned tot[2][SITES_PER_GROUP];        // k, cN
-    __shared__ unsigned half_sum[SITES_PER_GROUP];
     __shared__ unsigned wsum[2][6];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < SITES_PER_GROUP) { tot[0][tid] = 0; tot[1][tid] = 0; }
@@ -199,22 +198,25 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
     // ---- pass 2: k and cN of every site -----------------------------------------------------------------------------------
     unsigned anyb[4] = {0, 0, 0, 0}, bad = 0;
     const int site = tid & 127, sw = site >> 5, sb = site & 31, half = tid >> 7;
-    // flush: the bit planes of all threads through LDS, one counter at a time; thread (site, half) sums 128 threads' planes
+    // flush: the bit planes of all threads through LDS, one counter at a time.  Wave w takes word w (32 sites): for every plane and
+    // every 64 threads, a 32 x 32 bit transpose across the half waves turns "bit b of thread t" into "bit t of lane b", whose
+    // popcount is the site's count over those 32 threads -- 18 instructions per 64 words where summing bit by bit took 4 per bit
+    // (at 10 000 samples the counters are flushed once per group: the flush was two thirds of the kernel's instructions)
+    const Transpose32 tr((unsigned)lane);
     auto flush = [&](unsigned (&pl)[4][8], int which) {
         __syncthreads();
 #pragma unroll
         for (int w = 0; w < 4; w++)
 #pragma unroll
-            for (int j = 0; j < 8; j++) { planes_lds[tid][w][j] = pl[w][j]; pl[w][j] = 0; }
+            for (int j = 0; j < 8; j++) { planes_lds[w][j][tid] = pl[w][j]; pl[w][j] = 0; }
         __syncthreads();
-        unsigned sum = 0;
-        for (int t = half * 128; t < half * 128 + 128; t++) {
+        unsigned acc = 0;
 #pragma unroll
-            for (int j = 0; j < 8; j++) sum += ((planes_lds[t][sw][j] >> sb) & 1u) << j;
-        }
-        if (half) half_sum[site] = sum;
-        __syncthreads();
-        if (!half) tot[which][site] += sum + half_sum[site];
+        for (int j = 0; j < 8; j++)
+#pragma unroll
+            for (int blk = 0; blk < 4; blk++) acc += (unsigned)__popc(tr(planes_lds[wave][j][blk * 64 + lane])) << j;
+        acc += __shfl_xor(acc, 32, 64);
+        if (lane < 32) tot[which][wave * 32 + lane] += acc;
     };
     unsigned kp[4][8], np[4][8];
 #pragma unroll

@@ -108,36 +108,6 @@ struct N8Encoder {
     }
 };
 
-// 32 x 32 bit transpose across the 32 lanes of a half wave: lane k holds row k; afterwards bit j of lane k is bit k of what lane j
-// held.  Five butterfly steps (j = 16, 8, 4, 2, 1): lanes k and k ^ j exchange words (ds_swizzle, bit mode) and swap the high
-// half-blocks of the lower lane's word with the low half-blocks of the higher lane's -- per lane: keep the bits of K, take the
-// partner's word rotated by R everywhere else: one rotate (v_alignbit_b32) and one bitfield insert (v_bfi_b32).
-struct Transpose32 {
-    unsigned K[5], R[5];                       // per lane and step: bits kept, rotation of the partner's word
-    __device__ __forceinline__ explicit Transpose32(unsigned lane)
-    {
-        constexpr unsigned masks[5] = {0x0000FFFFu, 0x00FF00FFu, 0x0F0F0F0Fu, 0x33333333u, 0x55555555u};
-#pragma unroll
-        for (int st = 0; st < 5; st++) {
-            const unsigned j = 16u >> st;
-            const bool hi = (lane & j) != 0u;
-            K[st] = hi ? (masks[st] << j) : masks[st];
-            R[st] = hi ? j : 32u - j;          // v_alignbit(v, v, R) = rotate right by R: the higher lane takes v >> j, the lower v << j
-        }
-    }
-    __device__ __forceinline__ unsigned operator()(unsigned a) const
-    {
-        unsigned v;
-        // (ds_swizzle bit mode: offset = xor_mask << 10 | or_mask << 5 | and_mask, inside groups of 32 lanes)
-        v = (unsigned)__builtin_amdgcn_ds_swizzle((int)a, (16 << 10) | 0x1F); a = (a & K[0]) | (__builtin_amdgcn_alignbit(v, v, R[0]) & ~K[0]);
-        v = (unsigned)__builtin_amdgcn_ds_swizzle((int)a, (8 << 10) | 0x1F);  a = (a & K[1]) | (__builtin_amdgcn_alignbit(v, v, R[1]) & ~K[1]);
-        v = (unsigned)__builtin_amdgcn_ds_swizzle((int)a, (4 << 10) | 0x1F);  a = (a & K[2]) | (__builtin_amdgcn_alignbit(v, v, R[2]) & ~K[2]);
-        v = (unsigned)__builtin_amdgcn_ds_swizzle((int)a, (2 << 10) | 0x1F);  a = (a & K[3]) | (__builtin_amdgcn_alignbit(v, v, R[3]) & ~K[3]);
-        v = (unsigned)__builtin_amdgcn_ds_swizzle((int)a, (1 << 10) | 0x1F);  a = (a & K[4]) | (__builtin_amdgcn_alignbit(v, v, R[4]) & ~K[4]);
-        return a;
-    }
-};
-
 __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBuild mb, size_t n_pad, unsigned n,
                                                          unsigned long long *__restrict__ p_off, unsigned *__restrict__ p_ent,
                                                          uint2 *__restrict__ E, uint4 *__restrict__ lines,
