@@ -79,31 +79,33 @@ constexpr unsigned SITE_THREADS = 128;         // one thread per site of the gro
 struct N8Encoder {
     uint4 *lines;
     unsigned line, next_ovf, fill, prev;
+    unsigned left;                             // samples of the site still to come
     unsigned a0, a1, a2, a3;                   // the pending bytes, shifted in from the top
-    __device__ __forceinline__ void put(unsigned b)
+    static constexpr unsigned DONE = 0xFFFFu;  // fill once the list has left with its last line
+    // one byte; `more`: something of the list follows it (a skip byte, or a sample's byte with samples still to come).  One store
+    // site for both kinds of piece -- a full 16 bytes, and the line's last 12 with the index of the line that goes on -- : the
+    // wave runs it whenever one of its 64 sites stores, i.e. nearly every time, so it is run once per byte, not twice
+    __device__ __forceinline__ void put(unsigned b, bool more)
     {
-        if (fill == N8_PAYLOAD) {              // the line is full and more follows: its last piece leaves with the next line's index
-            lines[(size_t)line * 8 + 7] = make_uint4(a1, a2, a3, next_ovf);
-            line = next_ovf++;
-            fill = 0;
-        }
         a0 = __builtin_amdgcn_alignbit(a1, a0, 8); a1 = __builtin_amdgcn_alignbit(a2, a1, 8); a2 = __builtin_amdgcn_alignbit(a3, a2, 8);
         a3 = (a3 >> 8) | (b << 24);
         fill++;
-        if ((fill & 15u) == 0u) lines[(size_t)line * 8 + (fill >> 4) - 1u] = make_uint4(a0, a1, a2, a3);
-    }
-    __device__ __forceinline__ void sample(unsigned s)
-    {
-        unsigned gap = s - prev;               // (prev = 0xFFFFFFFF before the first: s + 1)
-        while (gap >= N8_SKIP) { put(N8_SKIP); gap -= N8_SKIP; }
-        put(gap);
-        prev = s;
+        const bool full = fill == N8_PAYLOAD;
+        if ((fill & 15u) == 0u || full) {
+            const unsigned nx = more ? next_ovf : N8_NONE;
+            lines[(size_t)line * 8 + (full ? 7u : (fill >> 4) - 1u)] = full ? make_uint4(a1, a2, a3, nx) : make_uint4(a0, a1, a2, a3);
+            if (full) {
+                if (more) { line = next_ovf++; fill = 0; }
+                else fill = DONE;
+            }
+        }
     }
     __device__ __forceinline__ void finish()
     {
+        if (fill == DONE) return;              // (the list ended with the last byte of a line)
         const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-        while ((fill & 15u) != 0u && fill < N8_PAYLOAD) put(0xFFu);            // the piece under way
-        if (fill == N8_PAYLOAD) { lines[(size_t)line * 8 + 7] = make_uint4(a1, a2, a3, N8_NONE); return; }
+        while ((fill & 15u) != 0u && fill != DONE) put(0xFFu, false);          // the piece under way (at 124 bytes: the line's last)
+        if (fill == DONE) return;
         for (unsigned q = fill >> 4; q < 8u; q++) lines[(size_t)line * 8 + q] = ones;     // (the last: padding + N8_NONE)
     }
 };
@@ -116,6 +118,8 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
     __shared__ unsigned bm[SITES_PER_GROUP * BM_STRIDE];     // the piece's N bits, site-major: bm[site * BM_STRIDE + 32-sample word]
     __shared__ unsigned cn[SITES_PER_GROUP], kp[SITES_PER_GROUP], ovf[SITES_PER_GROUP], curP[SITES_PER_GROUP], rk[SITES_PER_GROUP];
     __shared__ unsigned long long bP[SITES_PER_GROUP];
+    __shared__ unsigned short queue[PIECE_SAMPLES];          // the piece's samples with listed sites in this group (offsets into the piece)
+    __shared__ unsigned qn[2];                               // (by parity of the piece: the other one is reset while this one is read)
     const size_t g = blockIdx.x;
     const int tid = threadIdx.x;
     const unsigned lane = tid & 63u, wave = tid >> 6;
@@ -134,10 +138,11 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
         kp[tid] = (mine && ((mp[tw] >> tb) & 1u)) ? mb.cntP[g * SITES_PER_GROUP + tid] : 0u;
         ovf[tid] = mine ? n8_lines_max(c, n) - 1u : 0u;
         curP[tid] = 0;
+        if (tid < 2) qn[tid] = 0;
     }
     __syncthreads();
     const Transpose32 transpose(lane);
-    N8Encoder enc{lines, 0u, 0u, 0u, 0xFFFFFFFFu, 0u, 0u, 0u, 0u};
+    N8Encoder enc{lines, 0u, 0u, 0u, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
     if (mine) {
         unsigned long long pp = 0;
         unsigned po = 0;
@@ -146,6 +151,7 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
         bP[tid] = mb.baseP[g] + pp; rk[tid] = rank;
         p_off[rank] = bP[tid];
         enc.line = rank;
+        enc.left = cn[tid];
         enc.next_ovf = (unsigned)(mb.sites + mb.baseO[g] + po);
     }
     __syncthreads();
@@ -154,6 +160,7 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
     const uint4 *base = mb.planes + (g * NPLANES) * n_pad;
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
     for (unsigned piece = 0; piece < n; piece += PIECE_SAMPLES) {
+        const unsigned par = (piece / PIECE_SAMPLES) & 1u;
         // ---- the piece's samples, 64 per wave and step (the next step's N words and flag word are requested before this step's
         // are transposed): N bits into bm, listed samples into the p lists (every sample is seen in exactly one piece)
         unsigned sl = wave;
@@ -183,9 +190,24 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
                 bm[(0u + r) * BM_STRIDE + col] = 0u; bm[(32u + r) * BM_STRIDE + col] = 0u;
                 bm[(64u + r) * BM_STRIDE + col] = 0u; bm[(96u + r) * BM_STRIDE + col] = 0u;
             }
+            // a sample that is listed somewhere in this group (~1 % of them on the bench workload): queued, so that the p-list work
+            // below runs with full waves instead of once per slab with a lane or two
             const bool flagged = s < n && ((fl >> (s & 63u)) & 1ull);
-            if (!flagged) continue;
-            const uint4 A = base[s], C = base[n_pad + s], G = base[2 * n_pad + s], T = base[3 * n_pad + s];
+            const unsigned long long fm = __ballot(flagged);
+            if (fm) {                                          // (wave-uniform)
+                unsigned qb = 0;
+                if (lane == 0) qb = atomicAdd(&qn[par], (unsigned)__popcll(fm));
+                qb = __shfl(qb, 0, 64);
+                if (flagged) queue[qb + __builtin_amdgcn_mbcnt_hi((unsigned)(fm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fm, 0u))] = (unsigned short)(s - piece);
+            }
+        }
+        __syncthreads();
+        // ---- the queued samples: their listed sites go into the p lists
+        const unsigned qcount = qn[par];
+        if (tid == 0) qn[par ^ 1u] = 0;
+        for (unsigned k = tid; k < qcount; k += SITE_THREADS) {
+            const unsigned s = piece + queue[k];
+            const uint4 A = base[s], C = base[n_pad + s], G = base[2 * n_pad + s], T = base[3 * n_pad + s], N = base[4 * n_pad + s];
             unsigned listed = 0, listed_w = 0;               // this sample's listed entries in the group, and their w's
 #pragma unroll
             for (int w = 0; w < 4; w++) {
@@ -210,7 +232,6 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
             if (listed) atomicAdd(&cnt[s], listed);
             if (listed_w) atomicAdd(&c_p[s], listed_w);
         }
-        __syncthreads();
         // ---- the site's thread: its 32 words of the piece in order (four independent reads at a time), every set bit a sample
         if (mine && cn[tid] != 0u) {
             // (one loop over the lane's own set bits: the wave runs as many rounds as its busiest lane has samples in the piece --
@@ -220,16 +241,27 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
             unsigned nz = 0;
 #pragma unroll
             for (unsigned c = 0; c < PIECE_WORDS; c++) nz |= (rowp[c] != 0u ? 1u : 0u) << c;
-            unsigned w = 0, c = 0;
+            // one byte per round: a sample whose gap needs skip bytes stays for as many rounds (the wave runs the encoder once per
+            // round whatever the lanes emit)
+            unsigned w = 0, c = 0, gap = 0;
+            bool have = false;
             for (;;) {
-                if (w == 0u) {
-                    if (nz == 0u) break;
-                    c = __ffs(nz) - 1; nz &= nz - 1;
-                    w = rowp[c];
+                if (!have) {
+                    if (w == 0u) {
+                        if (nz == 0u) break;
+                        c = __ffs(nz) - 1; nz &= nz - 1;
+                        w = rowp[c];
+                    }
+                    const unsigned b = __ffs(w) - 1;
+                    w &= w - 1;
+                    const unsigned smp = piece + 32u * c + b;
+                    gap = smp - enc.prev;      // (prev = 0xFFFFFFFF before the first: smp + 1)
+                    enc.prev = smp; enc.left--;
+                    have = true;
                 }
-                const unsigned b = __ffs(w) - 1;
-                w &= w - 1;
-                enc.sample(piece + 32u * c + b);
+                const bool skip = gap >= N8_SKIP;
+                enc.put(skip ? N8_SKIP : gap, skip || enc.left != 0u);
+                if (skip) gap -= N8_SKIP; else have = false;
             }
         }
         __syncthreads();
