@@ -556,8 +556,9 @@ def site_sharded(args, n, L, seed, world, rank, device, dist, exchange):
     """N ranks, each with a slice of the SITES (whole 128-site groups: a contiguous 1 / N of the packed planes).  d(i, j) and the
     compared-sites count nn(i, j) are sums over sites (src/pairsnp.hpp:398-403,417-420), so a rank runs the single-GPU call on its
     slice for ALL pairs -- classification, lists, walks: every stage works on 1 / N of the sites -- and the N partial matrices are
-    summed with a reduce-scatter (rank q receives rows q: tracs_reduce_scatter), the row panels all-gathered, and transcluster
-    runs on the complete d with its key evaluations split over the ranks (key-table all-reduce), as in the pair partition.
+    summed with a reduce-scatter (rank q receives rows q: tracs_reduce_scatter).  The result STAYS distributed: rank q owns rows
+    [q cs, (q + 1) cs) of d, nn, P and E(K) -- what `tracs distance --gpus N` does with the rows it then extracts -- so there is no
+    all-gather, and transcluster runs on a rank's own rows (its keys evaluated there; no table exchange).
     One step = one call: the slice counts as freshly packed, everything once-per-pack is redone."""
     import torch
     from tracs_amd import _lib
@@ -582,21 +583,17 @@ def site_sharded(args, n, L, seed, world, rank, device, dist, exchange):
     lib = _lib.load()
     lib.tracs_debug_pair_timing(1)
     lib.tracs_debug_pack_timing(1)
-    d_gap = int((days.max() - days.min()).item())
-    n_max = [None]
-    ev = {k: [] for k in ("dense", "reduce", "gather", "trans")}
+    r0, r1 = min(n, rank * cs), min(n, (rank + 1) * cs)       # the rows this rank owns of every result
+    has_rs = hasattr(dist, "reduce_scatter_rows")
 
     def reduce_rows(m):
-        if hasattr(dist, "reduce_scatter_rows"):
+        if has_rs:
             dist.reduce_scatter_rows(m, cs)
         else:                                                  # torch.distributed (gloo has no reduce-scatter): sum the whole matrix
             dist.all_reduce(m)
 
-    def gather_rows(m):
-        dist.all_gather([m[q * cs:(q + 1) * cs] for q in range(world)], m[rank * cs:(rank + 1) * cs])
-
     def step(per_call=True):
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         if per_call:
             aln.mark_packed()
         marks[0].record()
@@ -604,13 +601,9 @@ def site_sharded(args, n, L, seed, world, rank, device, dist, exchange):
         marks[1].record()
         reduce_rows(dmat); reduce_rows(nmat)
         marks[2].record()
-        gather_rows(dmat); gather_rows(nmat)
+        if r1 > r0:
+            dev.trans_dist_dense_ranges(dmat, n, days, args.lamb, args.beta, args.precision, pmat, emat, [(r0, r1)], exp_p0=True)
         marks[3].record()
-        if n_max[0] is None:
-            n_max[0] = int(torch.triu(dmat[:n], diagonal=1).max().item())          # same data every step: taken once (untimed warm-up)
-        dev.trans_dist_dense_partitioned(dmat, n, days, args.lamb, args.beta, args.precision, pmat, emat, rank, world,
-                                         lambda t: dist.all_reduce(t), exp_p0=True, n_max=n_max[0], d_max=d_gap)
-        marks[4].record()
         return marks
 
     def timed_run(count, per_call):
@@ -634,21 +627,28 @@ def site_sharded(args, n, L, seed, world, rank, device, dist, exchange):
     split = pair_split_ms(lib, args.steps)
     elapsed_steady, _ = timed_run(args.steps, False)
     pairs_total = n * (n - 1) // 2
-    checksum = int(torch.triu(dmat[:n], diagonal=1).sum().item())
-    if os.environ.get("TRACS_BENCH_VERIFY") and rank == 0:
-        # the summed matrices must equal a single call over the whole alignment on this rank
+    # (every rank holds the sums of its own rows only: the checksum of d is a sum over the ranks)
+    own = torch.triu(torch.ones((rows_pad, n), dtype=torch.bool, device=device), diagonal=1)
+    own[:r0] = False; own[r1:] = False
+    cks = torch.tensor([int(dmat[own].sum().item())], dtype=torch.int64, device=device)
+    dist.all_reduce(cks)
+    checksum = int(cks.item())
+    if os.environ.get("TRACS_BENCH_VERIFY"):
+        # this rank's rows must equal the same rows of a single call over the whole alignment
         full = dev.Alignment(n, L)
         synth.pack_synthetic_device(full, seed=seed, **synth_kw(args.partial, args.workload))
         d1, n1 = torch.zeros_like(dmat), torch.zeros_like(nmat)
         p1, e1 = torch.zeros_like(pmat), torch.zeros_like(emat)
         dev.pairsnp_dense(full, d1, n1)
         dev.trans_dist_dense_ranges(d1, n, days, args.lamb, args.beta, args.precision, p1, e1, [(0, n)], exp_p0=True)
-        up = torch.triu(torch.ones((n, n), dtype=torch.bool, device=device), diagonal=1)
-        ok = bool(torch.equal(d1[:n][up], dmat[:n][up]) and torch.equal(n1[:n][up], nmat[:n][up]) and
-                  torch.equal(p1[:n][up], pmat[:n][up]) and torch.equal(e1[:n][up], emat[:n][up]))
-        print("VERIFY site shards == single call:", ok, file=sys.stderr, flush=True)
+        ok = bool(torch.equal(d1[own], dmat[own]) and torch.equal(n1[own], nmat[own]) and
+                  torch.equal(p1[own], pmat[own]) and torch.equal(e1[own], emat[own]))
+        okt = torch.tensor([1 if ok else 0], dtype=torch.int64, device=device)
+        dist.all_reduce(okt)
+        if rank == 0:
+            print("VERIFY site shards == single call:", int(okt.item()) == world, file=sys.stderr, flush=True)
         full.close()
-        if not ok:
+        if int(okt.item()) != world:
             raise SystemExit("VERIFY FAILED")
     if rank == 0:
         def mean_ms(a, b):
@@ -667,13 +667,12 @@ def site_sharded(args, n, L, seed, world, rank, device, dist, exchange):
                                                          "workload '%s'" % args.workload, pairs_total),
                           "samples": n, "sites": L, "pairs": pairs_total, "workload_name": args.workload, "exchange": exchange,
                           "partition": "SITE shards: rank r holds groups [%d r / %d, ..) of the packed planes (%d of %d sites on rank 0) and counts all "
-                                       "pairs over them; d and nn summed with a reduce-scatter of row panels (%d rows per rank), panels "
-                                       "all-gathered, P and E(K) derived on every rank with the key evaluations split over the ranks"
+                                       "pairs over them; d and nn summed with a reduce-scatter of row panels (%d rows per rank): rank q "
+                                       "owns rows q of d, nn, P, E(K) (no all-gather; transcluster on a rank's own rows)"
                                        % (groups, world, l1 - l0, L, cs),
                           "rank0_ms": {"dense call over the slice (once-per-pack work included)": mean_ms(0, 1),
-                                       "reduce-scatter of d and nn": mean_ms(1, 2), "all-gather of the row panels": mean_ms(2, 3),
-                                       "transcluster (keys split, table all-reduce, gather)": mean_ms(3, 4)},
-                          "exchange_bytes_per_rank_per_call": 2 * 4.0 * rows_pad * n * (world - 1) / world * 2,
+                                       "reduce-scatter of d and nn": mean_ms(1, 2), "transcluster over the rank's own rows": mean_ms(2, 3)},
+                          "exchange_bytes_per_rank_per_call": 2 * 4.0 * rows_pad * n * (world - 1) / world,
                           "kernels_ms": None if not split else dict(zip(("pair", "lists", "count", "nn_lists"), split)),
                           "mean_d": checksum / float(pairs_total), "checksum_d": checksum,
                           "clock_rate": args.lamb, "trans_rate": args.beta, "precision": args.precision,
