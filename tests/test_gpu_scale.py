@@ -347,6 +347,14 @@ def test_bench_line_contract_small():
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["unit"] == "pairs/s" and j["higher_is_better"] is True and j["vs_baseline"] is None
     assert abs(j["value"] - 700 * 699 / 2 / (j["ms_per_step"] / 1e3)) < 1e-6 * j["value"]
     assert "workload" in j["config"] and "model" not in j["config"] and j["config"]["encoding"] == "consensus"
+    # `value` is ONE CALL per step (once-per-pack work redone in every step); the repeated pass is beside it and cannot be slower;
+    # the stages of the once-per-call work carry their bytes and their fraction of the HBM peak, none above 1
+    assert j["value_steady_state"] >= j["value"] * 0.98 and j["ms_per_step_steady_state"] <= j["ms_per_step"] * 1.02
+    assert "ONE CALL per step" in j["step"]
+    rp = j["roofline_per_pack"]
+    assert rp["bound"] == "hbm" and rp["per_pack_ms"] > 0 and rp["per_pack_ms"] <= j["ms_per_step"] * 1.05
+    assert {"classify", "lists: per site"} <= {st["stage"] for st in rp["stages"]}
+    assert all(st["ms"] >= 0 and st["read_GB"] >= 0 and st["written_GB"] >= 0 and (st["frac"] is None or st["frac"] <= 1.0) for st in rp["stages"])
     r = j["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms"):
         assert k in r, k
