@@ -370,6 +370,14 @@ __global__ void max_count_kernel(const unsigned *__restrict__ c, size_t n, unsig
 // The first form of the round decoded every piece of every line behind its scan (half the lanes adding to their dump slots): the
 // kernel was bound by instruction issue and by the LDS pipe together (profiles/r04/nn_rows_n8.txt); the two-phase form issues the
 // per-byte instructions and the LDS adds for the pieces that count only.
+// a 16-byte load of data read once (a row's bitmap): non-temporal, so that it does not push the lines of the current segment --
+// read a hundred times over -- out of the Infinity Cache
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 load_stream(const uint4 *p)
+{
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
 typedef __attribute__((address_space(3))) unsigned lds_u32;
 constexpr unsigned LINE_RING = 128, PIECE_RING = 192;
 constexpr unsigned WALK_LDS_PER_WAVE = LINE_RING * 8 + PIECE_RING * 8;
@@ -535,12 +543,12 @@ __global__ __launch_bounds__(TRACS_NN_THREADS) void nn_rows_kernel(const uint4 *
     const uint4 *Trow = T + (size_t)i * tgroups;
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
     size_t b = b_first + wave;
-    uint4 tw_next = (b < b_last && b * 64 + lane < tgroups) ? Trow[b * 64 + lane] : zero4;
+    uint4 tw_next = (b < b_last && b * 64 + lane < tgroups) ? load_stream(Trow + b * 64 + lane) : zero4;
     for (; b < b_last; b += nwaves) {
         const size_t g = b * 64 + lane;
         const uint4 tw = tw_next;
         const size_t bn = b + nwaves;
-        tw_next = (bn < b_last && bn * 64 + lane < tgroups) ? Trow[bn * 64 + lane] : zero4;     // the next batch's bitmap: in flight during this one
+        tw_next = (bn < b_last && bn * 64 + lane < tgroups) ? load_stream(Trow + bn * 64 + lane) : zero4;     // the next batch's bitmap: in flight during this one
         unsigned r0 = tw.x, r1 = tw.y, r2 = tw.z, r3 = tw.w;
         // this lane's set bits, and where its items go in the ring: an inclusive wave scan of the counts (DPP)
         const unsigned cnt = __popc(r0) + __popc(r1) + __popc(r2) + __popc(r3);
@@ -815,11 +823,12 @@ int nn_rows_add(tracs_alignment *a, size_t row_begin, size_t row_end, size_t col
     // Every row walks the sites in order, and the rows in flight are anywhere along the genome: a line is re-read (by the ~cN rows
     // that are N at its site) long after it left the caches -- the walk then runs at the rate of random 128-byte reads from HBM.
     // Cut into SEGMENTS of sites that all rows walk before any row starts on the next (grid.z is the slowest dimension of the
-    // dispatch order), the lines of a segment stay in the 256 MiB Infinity Cache between their uses.  The price is one flush of
-    // the row per segment (atomic adds): 10 000 x 5 Mbp, 1.2 GB of lines: 14.4 ms in one segment, 13.2 in 5, 16.3 in 32
-    // (profiles/r04/nn_rows_n8.txt).  TRACS_NN_SEGMENT_MB overrides the segment size (0: one segment) for that measurement.
+    // dispatch order), the lines of a segment stay in the 256 MiB Infinity Cache between their uses (the rows' bitmaps, read once,
+    // are loaded non-temporally).  The price is one flush of the row per segment (atomic adds): 10 000 x 5 Mbp, 1.2 GB of lines:
+    // 13.5 ms in one segment, 12.55 in 10 (128 MiB), 14.1 in 32 (profiles/r04/nn_rows_n8.txt).  TRACS_NN_SEGMENT_MB overrides the
+    // segment size (0: one segment) for that measurement.
     const char *seg_env = getenv("TRACS_NN_SEGMENT_MB");
-    const unsigned long long seg_bytes = (seg_env ? strtoull(seg_env, nullptr, 10) : 256ull) << 20;
+    const unsigned long long seg_bytes = (seg_env ? strtoull(seg_env, nullptr, 10) : 128ull) << 20;
     const unsigned segments = seg_bytes ? (unsigned)std::min<unsigned long long>(NN_MAX_SPLITS, std::max<unsigned long long>(1, (g->n_lines * 128ull + seg_bytes - 1) / seg_bytes)) : 1u;
     const unsigned splits = (unsigned)std::min<unsigned long long>(NN_MAX_SPLITS, std::max<unsigned long long>(segments, ((unsigned long long)g->max_row + target - 1) / target));
     const dim3 grid((unsigned)(row_end - row_begin), (unsigned)((n + chunk - 1) / chunk), splits);
