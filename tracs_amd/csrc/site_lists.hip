@@ -389,18 +389,18 @@ struct Walk {
     uint2 *lring, *pring;                      // this wave's rings (LDS): lines (index, position before the line's first byte: -1 at a site's
                                                //   first line); pieces (uint4 index, position before the piece)
     unsigned lhead, lcount, phead, pcount;     // (wave-uniform)
-    unsigned lane, grp, l8;
+    unsigned lane, grp, l4;                    // the scan's view of the wave: 16 lines x 4 lanes
     unsigned neg4lo, dump4, val;               // row[] starts at LDS byte 0: counter of column j at 4 (j - c0); the lane's dump slot
     unsigned cut;                              // a piece that ends below this position has nothing to add
-    bool lt7, lt6, lt4;
+    bool lt3, lt2;
 
     __device__ __forceinline__ void init(const uint4 *lines_, unsigned *lds, unsigned lane_)
     {
         lines = lines_;
         lring = reinterpret_cast<uint2 *>(lds); pring = lring + LINE_RING;
         lhead = lcount = phead = pcount = 0;
-        lane = lane_; grp = lane_ >> 3; l8 = lane_ & 7u;
-        lt7 = l8 < 7u; lt6 = l8 < 6u; lt4 = l8 < 4u;
+        lane = lane_; grp = lane_ >> 2; l4 = lane_ & 3u;
+        lt3 = l4 < 3u; lt2 = l4 < 2u;
         // (a scan round reads 16 slots whatever the count: every slot holds a line that exists)
         lring[lane] = make_uint2(0u, 0u); lring[64 + lane] = make_uint2(0u, 0u);
     }
@@ -424,39 +424,45 @@ struct Walk {
     }
     __device__ __forceinline__ void scan_round()
     {
+        // 16 lines, FOUR lanes per line, two pieces per lane (k4 and 4 + k4: each load instruction reads 64 contiguous bytes of a
+        // line): one ring read, one address, one follow-on step per round where eight lanes per line took two of each
         const unsigned k = min(lcount, 16u);
-        uint2 ref[2];
-        uint4 d[2];
-#pragma unroll
-        for (int u = 0; u < 2; u++) ref[u] = lring[(lhead + u * 8 + grp) & (LINE_RING - 1u)];
-#pragma unroll
-        for (int u = 0; u < 2; u++) d[u] = lines[(size_t)ref[u].x * 8 + l8];
+        const uint2 ref = lring[(lhead + grp) & (LINE_RING - 1u)];
+        const uint4 *lp = lines + (size_t)ref.x * 8 + l4;
+        const uint4 d0 = lp[0], d1 = lp[4];
         __builtin_amdgcn_sched_barrier(0);                  // (both loads on their way before anything waits for the first)
         lhead = (lhead + k) & (LINE_RING - 1u); lcount -= k;
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const bool has = u * 8 + grp < k;
-            // (w3 of the line's last lane is the line's `next`, not payload)
-            const unsigned w3s = lt7 ? d[u].w : 0u;
-            const unsigned S = __builtin_amdgcn_sad_u8(d[u].x, 0u, __builtin_amdgcn_sad_u8(d[u].y, 0u, __builtin_amdgcn_sad_u8(d[u].z, 0u, __builtin_amdgcn_sad_u8(w3s, 0u, 0u))));
-            // inclusive prefix over the line's eight lanes: what a step hands on is zeroed where it would cross into the next line
-            unsigned x = S;
-            x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)(lt7 ? x : 0u), 0x111, 0xF, 0xF, true);      // row_shr:1
-            x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)(lt6 ? x : 0u), 0x112, 0xF, 0xF, true);      // row_shr:2
-            x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)(lt4 ? x : 0u), 0x114, 0xF, 0xF, true);      // row_shr:4
-            const unsigned p_end = ref[u].y + x;            // the position behind this lane's bytes
-            const bool wanted = has && (int)p_end >= (int)cut && (d[u].x & 0xFFu) != 0xFFu;
-            unsigned long long m;
-            unsigned r = rank_of(wanted, m);
-            unsigned pos = phead + pcount + r;
-            if (pos >= PIECE_RING) pos -= PIECE_RING;
-            if (wanted) pring[pos] = make_uint2(ref[u].x * 8u + l8, p_end - S);
-            pcount += (unsigned)__popcll(m);
-            const bool goes_on = has && !lt7 && d[u].w != N8_NONE;
-            r = rank_of(goes_on, m);
-            if (goes_on) lring[(lhead + lcount + r) & (LINE_RING - 1u)] = make_uint2(d[u].w, p_end);
-            lcount += (unsigned)__popcll(m);
-        }
+        const bool has = grp < k;
+        // (w3 of the line's last piece is the line's `next`, not payload)
+        const unsigned S0 = __builtin_amdgcn_sad_u8(d0.x, 0u, __builtin_amdgcn_sad_u8(d0.y, 0u, __builtin_amdgcn_sad_u8(d0.z, 0u, __builtin_amdgcn_sad_u8(d0.w, 0u, 0u))));
+        const unsigned S1 = __builtin_amdgcn_sad_u8(d1.x, 0u, __builtin_amdgcn_sad_u8(d1.y, 0u, __builtin_amdgcn_sad_u8(d1.z, 0u, __builtin_amdgcn_sad_u8(lt3 ? d1.w : 0u, 0u, 0u))));
+        // inclusive prefixes over the line's four lanes (what a step hands on is zeroed where it would cross into the next line);
+        // the second four pieces start behind the first four: the total of those, from the line's last lane
+        unsigned x0 = S0, x1 = S1;
+        x0 += (unsigned)__builtin_amdgcn_update_dpp(0, (int)(lt3 ? x0 : 0u), 0x111, 0xF, 0xF, true);      // row_shr:1
+        x1 += (unsigned)__builtin_amdgcn_update_dpp(0, (int)(lt3 ? x1 : 0u), 0x111, 0xF, 0xF, true);
+        x0 += (unsigned)__builtin_amdgcn_update_dpp(0, (int)(lt2 ? x0 : 0u), 0x112, 0xF, 0xF, true);      // row_shr:2
+        x1 += (unsigned)__builtin_amdgcn_update_dpp(0, (int)(lt2 ? x1 : 0u), 0x112, 0xF, 0xF, true);
+        const unsigned t0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x0, 0xFF, 0xF, 0xF, false);      // quad_perm:[3,3,3,3]
+        const unsigned e0 = ref.y + x0, e1 = ref.y + t0 + x1;          // the positions behind this lane's two pieces
+        const int icut = (int)cut;
+        const bool w0 = has && (int)e0 >= icut && (d0.x & 0xFFu) != 0xFFu;
+        const bool w1 = has && (int)e1 >= icut && (d1.x & 0xFFu) != 0xFFu;
+        unsigned long long m;
+        unsigned r = rank_of(w0, m);
+        unsigned pos = phead + pcount + r;
+        if (pos >= PIECE_RING) pos -= PIECE_RING;
+        if (w0) pring[pos] = make_uint2(ref.x * 8u + l4, e0 - S0);
+        pcount += (unsigned)__popcll(m);
+        r = rank_of(w1, m);
+        pos = phead + pcount + r;
+        if (pos >= PIECE_RING) pos -= PIECE_RING;
+        if (w1) pring[pos] = make_uint2(ref.x * 8u + 4u + l4, e1 - S1);
+        pcount += (unsigned)__popcll(m);
+        const bool goes_on = has && !lt3 && d1.w != N8_NONE;
+        r = rank_of(goes_on, m);
+        if (goes_on) lring[(lhead + lcount + r) & (LINE_RING - 1u)] = make_uint2(d1.w, e1);
+        lcount += (unsigned)__popcll(m);
     }
     __device__ __forceinline__ void decode_round()
     {
