@@ -331,32 +331,36 @@ __global__ __launch_bounds__(1024) void group_offsets_kernel(const uint4 *__rest
                                                              unsigned *__restrict__ off32, unsigned long long *__restrict__ off64,
                                                              unsigned long long *__restrict__ totals)
 {
-    __shared__ unsigned long long sv[1024];
-    const int b = blockIdx.x, t = threadIdx.x;
-    unsigned long long base = 0;
-    for (size_t g0 = 0; g0 < groups; g0 += 1024) {
-        const size_t g = g0 + t;
-        unsigned long long c = 0;
-        if (g < groups) {
-            if (b < 7) { const uint4 a = masks[(size_t)b * groups + g]; c = __popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w); }
-            else c = gcounts[(size_t)(b - 7) * groups + g];
-        }
-        sv[t] = c;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            const unsigned long long av = t >= o ? sv[t - o] : 0;
-            __syncthreads();
-            sv[t] += av;
-            __syncthreads();
-        }
-        if (g < groups) {
-            if (b < 7) off32[(size_t)b * groups + g] = (unsigned)(base + sv[t] - c);
-            else off64[(size_t)(b - 7) * groups + g] = base + sv[t] - c;
-        }
-        base += sv[1023];
-        __syncthreads();
+    // thread t takes the run of groups [t run, (t + 1) run): its own sum, one scan of the 1 024 run sums (wave shuffles + 16 wave
+    // totals through LDS), then its run again -- three barriers where a Hillis-Steele scan per 1 024 groups took a thousand
+    __shared__ unsigned long long wave_tot[16];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const size_t run = (groups + 1023) / 1024;
+    const size_t g0 = min(groups, (size_t)t * run), g1 = min(groups, g0 + run);
+    auto count_of = [&](size_t g) -> unsigned long long {
+        if (b < 7) { const uint4 a = masks[(size_t)b * groups + g]; return (unsigned long long)(__popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w)); }
+        return gcounts[(size_t)(b - 7) * groups + g];
+    };
+    unsigned long long sum = 0;
+    for (size_t g = g0; g < g1; g++) sum += count_of(g);
+    unsigned long long incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
     }
-    if (t == 0) totals[b] = base;
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    unsigned long long before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) { const unsigned long long v = wave_tot[w]; if (w < wave) before += v; all += v; }
+    unsigned long long at = before + incl - sum;
+    for (size_t g = g0; g < g1; g++) {
+        if (b < 7) off32[(size_t)b * groups + g] = (unsigned)at;
+        else off64[(size_t)(b - 7) * groups + g] = at;
+        at += count_of(g);
+    }
+    if (t == 0) totals[b] = all;
 }
 
 // the sites of a class in site order: list[off[g] ..] = the set bits of mask[g]
@@ -431,21 +435,25 @@ __global__ __launch_bounds__(256) void compact_sites_kernel(const uint4 *__restr
                 for (int p = 0; p < NPO; p++)
                     accw[p] = (unsigned)((((unsigned long long)cv_hi[p] << 32) | cv_lo[p]) >> sh) & keep;
             } else {
-                unsigned cw = 0xFFFFFFFFu, cur[NPO];
+                // scattered sites: their words are loaded eight sites at a time (independent loads in flight: one site at a time
+                // paid a memory latency per site -- 100 us for the 476 dense sites of the bench workload)
+                for (unsigned k0 = 0; k0 < kn; k0 += 8) {
+                    unsigned site[8], in[8][NPI];
 #pragma unroll
-                for (int p = 0; p < NPO; p++) cur[p] = 0;
-                for (unsigned k = 0; k < kn; k++) {
-                    const unsigned site = __builtin_amdgcn_readfirstlane(list[tb + k]);
-                    const unsigned w = site >> 5;
-                    if (w != cw) {                              // wave-uniform
-                        cw = w;
-                        unsigned in[NPI];
+                    for (int q = 0; q < 8; q++) {
+                        site[q] = __builtin_amdgcn_readfirstlane(list[tb + min(k0 + q, kn - 1u)]);
 #pragma unroll
-                        for (int p = 0; p < NPI; p++) in[p] = word_at(w, p);
-                        convert(in, cur);
+                        for (int p = 0; p < NPI; p++) in[q][p] = word_at(site[q] >> 5, p);
                     }
 #pragma unroll
-                    for (int p = 0; p < NPO; p++) accw[p] |= ((cur[p] >> (site & 31u)) & 1u) << k;
+                    for (int q = 0; q < 8; q++) {
+                        unsigned cur[NPO];
+                        convert(in[q], cur);
+                        if (k0 + q < kn) {                          // (wave-uniform)
+#pragma unroll
+                            for (int p = 0; p < NPO; p++) accw[p] |= ((cur[p] >> (site[q] & 31u)) & 1u) << (k0 + q);
+                        }
+                    }
                 }
             }
         }
