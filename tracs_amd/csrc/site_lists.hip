@@ -11,11 +11,11 @@
 //                nn_rows_kernel reads instead of a stream of list addresses.
 //
 // Built from the N plane alone (+ the five planes of the flagged samples, ~1 %): site_lists_kernel reads it once, group by group
-// (lists sorted in LDS, encoded by the site's own thread), n_bitmap_kernel once more, sample by sample (+ each sample's N count).
+// (bits transposed through LDS, encoded by the site's own thread), n_bitmap_kernel once more, sample by sample (+ each sample's N count).
 //
 // The walks.  nn_rows_kernel: row i of the pair matrix in LDS; every N site of sample i (a set bit of its bitmap) is a work item --
-// the site's line, decoded by eight lanes: NN(i, j) += 1 for every listed j > i.  minor_fixup_kernel: row x; every listed entry
-// of sample x walks its site's P list (both listed: [masks disjoint] - w_x - w_j, for j > x) and, when w_x = 1, the site's N LIST:
+// the site's line(s), scanned by four lanes and decoded piece by piece: NN(i, j) += 1 for every listed j > i.  minor_fixup_kernel:
+// row x; every listed entry of sample x walks its site's P list (both listed: [masks disjoint] - w_x - w_j, for j > x) and, when w_x = 1, the site's N LIST:
 // -w_x for EVERY N sample y -- y > x lands in row x of dist, y < x in cell (y, x): a scratch row that transpose_add_kernel folds into
 // the rows above.  So an N sample never looks at the p list of a site: the walks go from the few listed samples to the many N
 // samples (k walks of a cN-entry list, not cN walks of a k-entry list), and the per-sample streams of N entries that rounds 2-3
@@ -155,7 +155,6 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
         enc.next_ovf = (unsigned)(mb.sites + mb.baseO[g] + po);
     }
     __syncthreads();
-    const bool any_n = true;
     const uint4 RX = mb.ref_x[g], RY = mb.ref_y[g];
     const uint4 *base = mb.planes + (g * NPLANES) * n_pad;
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
@@ -266,7 +265,6 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
         }
         __syncthreads();
     }
-    (void)any_n;
     if (mine) enc.finish();
 }
 
@@ -359,12 +357,12 @@ __global__ void max_count_kernel(const unsigned *__restrict__ c, size_t n, unsig
 }
 
 // ---- the walk of n8 lines ---------------------------------------------------------------------------------------------------------
-// A wave keeps three rings in LDS: lines to look at (the sites of the row's bitmap), lines that go on (with the position their first
-// byte starts from), and PIECES to decode.  Two kinds of round:
-//   scan    16 lines, eight lanes per line, 16 bytes per lane: byte sums per lane (v_sad_u8), an exclusive prefix over the line's
-//           eight lanes (DPP) -- now every lane knows the positions its piece spans.  A piece that ends below the row's cut (sorted
-//           lists: row i needs j > i) or holds padding only is dropped; the others are queued (ballot + mbcnt): on a row in the middle
-//           of the matrix half of them.  A line that goes on (its `next`) is queued as a line;
+// A wave keeps two rings in LDS: LINES to look at (index, position before the line's first byte: the sites of the row's bitmap, and
+// the lines that go on behind them) and PIECES to decode.  Two kinds of round:
+//   scan    16 lines, four lanes per line, two 16-byte pieces per lane: byte sums per piece (v_sad_u8), inclusive prefixes over the
+//           line's four lanes (DPP) -- now every lane knows the positions its pieces span.  A piece that ends below the row's cut
+//           (sorted lists: row i needs j > i) or holds padding only is dropped; the others are queued (ballot + mbcnt): on a row in
+//           the middle of the matrix half of them.  A line that goes on (its `next`) is queued as a line;
 //   decode  64 queued pieces, one per lane -- every lane busy: 16 bytes, per byte one SDWA add (position), one shift-add (LDS
 //           address), one SDWA compare + select (skips and padding go to the lane's own slot behind the row), one ds_add_u32.
 // The first form of the round decoded every piece of every line behind its scan (half the lanes adding to their dump slots): the
@@ -511,8 +509,8 @@ struct Walk {
 // ---- N co-occurrences from lists (the NNL sites) ----------------------------------------------------------------------------------
 // Row i of the pair matrix: NN(i, j) = number of NNL sites at which both i and j are N.  The row's counters live in LDS; a wave
 // takes 64 groups of sample i's bitmap at a time (16 bytes per lane), every set bit is a site whose line goes into the wave's ring
-// (one bit per lane and step: the ring's slots come from a ballot), and the ring is walked 32 lines at a time.  Work = sum over the
-// NNL sites of cN walks of the site's line(s), whatever the number of samples -- against n^2 / 2 pairs per site on the matrix cores.
+// (slots from a prefix scan of the lanes' bit counts), and the ring is worked off 16 lines at a time (Walk).  Work = sum over the NNL
+// sites of cN walks of the site's line(s), whatever the number of samples -- against n^2 / 2 pairs per site on the matrix cores.
 // A sample with many N sites would leave most of the chip idle behind a few rows: a row's groups are cut over up to NN_MAX_SPLITS
 // workgroups (grid.z; a row with few N sites uses one and the others exit at once), which then add their rows with atomics.
 constexpr unsigned NN_MAX_SPLITS = 32;
