@@ -56,6 +56,21 @@ CASES = [
     dict(n=700, L=3000, p_n=0.30, mu=3e-4, seed=2, bitmaps=True),       # ~210 N samples per site: two lines per list, several pieces per group
     dict(n=2000, L=1500, p_n=0.002, mu=2e-4, seed=3, bitmaps=True),     # gaps beyond 253: skip bytes
     dict(n=130, L=4000, p_n=0.05, mu=2e-3, seed=4, p_partial=0.002),    # partial codes among the listed samples
+    dict(n=700, L=3000, p_n=0.01, mu=3e-4, seed=5, bitmaps=True, edges=True),      # lists that end exactly at the encoder's boundaries
+]
+
+# N samples of hand-made sites (case `edges`): the byte counts the encoder's branches turn on
+EDGE_LISTS = [
+    list(range(124)),            # 124 bytes: a full line and nothing behind it (no padding, no next line)
+    list(range(123)),            # one byte short of it
+    list(range(125)),            # one byte into a follow-on line
+    list(range(248)),            # two full lines exactly
+    list(range(16)),             # one piece exactly
+    list(range(112)),            # seven pieces exactly: the line's last piece is padding + "no next line"
+    [0, 300, 600],               # gaps beyond 253: skip bytes
+    [252, 505, 699],             # gaps of exactly 253: a skip byte, then a byte 0
+    [5, 699],                    # the last sample
+    list(range(0, 700, 2)),      # 350 bytes of 2: three lines
 ]
 
 
@@ -91,6 +106,11 @@ def run_case(case, nn_lists):
         part = rng.random((n, L)) < case["p_partial"]
         seqs[part] = np.frombuffer(b"MRWSYKVHDB", dtype=np.uint8)[rng.integers(0, 10, size=int(part.sum()))]
     seqs[:, rng.random(L) < 0.01] = ord("N")                              # empty sites
+    if case.get("edges"):
+        for k, samples in enumerate(EDGE_LISTS):
+            t = 200 + 37 * k                                              # (sites of several groups)
+            seqs[:, t] = ord("A")
+            seqs[samples, t] = ord("N")
     aln = dev.Alignment(n, L)
     aln.pack(seqs)
     d = torch.zeros((n, n), dtype=torch.int32, device="cuda")
@@ -126,6 +146,8 @@ def run_case(case, nn_lists):
     assert (off_lst == before[np.minimum(np.arange(groups) * 128, L)]).all()
     M = _masks(seqs)
     isN = M == 15
+    if case.get("edges") and nn_lists == "always":
+        assert all(listed_site[200 + 37 * k] for k in range(len(EDGE_LISTS))), "a hand-made site has no list"
     # ---- N lists: every listed site's line chain decodes to its N samples, in order
     for t in np.nonzero(listed_site)[0]:
         got = _decode(lines, rank[t])
