@@ -357,17 +357,16 @@ __global__ void max_count_kernel(const unsigned *__restrict__ c, size_t n, unsig
 }
 
 // ---- the walk of n8 lines ---------------------------------------------------------------------------------------------------------
-// A wave keeps two rings in LDS: LINES to look at (index, position before the line's first byte: the sites of the row's bitmap, and
-// the lines that go on behind them) and PIECES to decode.  Two kinds of round:
-//   scan    16 lines, four lanes per line, two 16-byte pieces per lane: byte sums per piece (v_sad_u8), inclusive prefixes over the
-//           line's four lanes (DPP) -- now every lane knows the positions its pieces span.  A piece that ends below the row's cut
-//           (sorted lists: row i needs j > i) or holds padding only is dropped; the others are queued (ballot + mbcnt): on a row in
-//           the middle of the matrix half of them.  A line that goes on (its `next`) is queued as a line;
-//   decode  64 queued pieces, one per lane -- every lane busy: 16 bytes, per byte one SDWA add (position), one shift-add (LDS
-//           address), one SDWA compare + select (skips and padding go to the lane's own slot behind the row), one ds_add_u32.
-// The first form of the round decoded every piece of every line behind its scan (half the lanes adding to their dump slots): the
-// kernel was bound by instruction issue and by the LDS pipe together (profiles/r04/nn_rows_n8.txt); the two-phase form issues the
-// per-byte instructions and the LDS adds for the pieces that count only.
+// A wave keeps a ring of LINES in LDS (index, position before the line's first byte): the sites of the row's bitmap, and the lines
+// that go on behind them.  A round takes 16 lines, four lanes per line, two 16-byte pieces per lane:
+//   scan    byte sums per piece (v_sad_u8), inclusive prefixes over the line's four lanes (DPP) -- now every lane knows the positions
+//           its pieces span.  A piece that ends below the row's cut (sorted lists: row i needs j > i) or holds padding only is left
+//           alone: on a row in the middle of the matrix half of them.  A line that goes on (its `next`) is queued as a line;
+//   decode  the pieces that count, where they are (exec mask): per byte one SDWA add (position), one shift-add (LDS byte address),
+//           one SDWA compare (skip and padding bytes sit the add out), one ds_add_u32.
+// Forms that were slower (profiles/r04/nn_rows_n8.txt): every piece decoded with skips and padding added to dump slots (LDS pipe);
+// the pieces that count queued and decoded 64 at a time with every lane busy -- fewer instructions, but a second load per piece,
+// 64 different cache lines per instruction through the CU's L1; two scan rounds in flight per wave (registers: half the waves).
 // a 16-byte load of data read once (a row's bitmap): non-temporal, so that it does not push the lines of the current segment --
 // read a hundred times over -- out of the Infinity Cache
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -377,16 +376,16 @@ __device__ __forceinline__ uint4 load_stream(const uint4 *p)
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 typedef __attribute__((address_space(3))) unsigned lds_u32;
-constexpr unsigned LINE_RING = 128, PIECE_RING = 192;
-constexpr unsigned WALK_LDS_PER_WAVE = LINE_RING * 8 + PIECE_RING * 8;
+constexpr unsigned LINE_RING = 128;
+constexpr unsigned WALK_LDS_PER_WAVE = LINE_RING * 8;
 
-// CLAMP = false: the row's counters cover every sample (one column chunk: n <= 30 720): a decoded position needs no range check.
+// CLAMP = false: the row's counters cover every sample (one column chunk: n <= 36 800): a decoded position needs no range check.
 template <bool CLAMP>
 struct Walk {
     const uint4 *lines;
-    uint2 *lring, *pring;                      // this wave's rings (LDS): lines (index, position before the line's first byte: -1 at a site's
-                                               //   first line); pieces (uint4 index, position before the piece)
-    unsigned lhead, lcount, phead, pcount;     // (wave-uniform)
+    uint2 *lring;                              // this wave's ring of lines (LDS): index, position before the line's first byte (-1 at a
+                                               //   site's first line)
+    unsigned lhead, lcount;                    // (wave-uniform)
     unsigned lane, grp, l4;                    // the scan's view of the wave: 16 lines x 4 lanes
     unsigned neg4lo, dump4, val;               // row[] starts at LDS byte 0: counter of column j at 4 (j - c0); the lane's dump slot
     unsigned cut;                              // a piece that ends below this position has nothing to add
@@ -395,8 +394,8 @@ struct Walk {
     __device__ __forceinline__ void init(const uint4 *lines_, unsigned *lds, unsigned lane_)
     {
         lines = lines_;
-        lring = reinterpret_cast<uint2 *>(lds); pring = lring + LINE_RING;
-        lhead = lcount = phead = pcount = 0;
+        lring = reinterpret_cast<uint2 *>(lds);
+        lhead = lcount = 0;
         lane = lane_; grp = lane_ >> 2; l4 = lane_ & 3u;
         lt3 = l4 < 3u; lt2 = l4 < 2u;
         // (a scan round reads 16 slots whatever the count: every slot holds a line that exists)
@@ -419,6 +418,22 @@ struct Walk {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // one 16-byte piece: per byte the position (SDWA add), the LDS byte address (shift-add), the add -- sat out by skip and padding bytes
+    __device__ __forceinline__ void decode_piece(unsigned w0, unsigned w1, unsigned w2, unsigned w3, unsigned p) const
+    {
+        const unsigned w[4] = {w0, w1, w2, w3};
+#pragma unroll
+        for (int q4 = 0; q4 < 4; q4++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const unsigned b = (w[q4] >> (8 * q)) & 0xFFu;
+                p += b;
+                unsigned a = (p << 2) + neg4lo;
+                if (CLAMP) a = min(a, dump4);
+                if (b < N8_SKIP) __hip_atomic_fetch_add(reinterpret_cast<lds_u32 *>((size_t)a), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
     }
     __device__ __forceinline__ void scan_round()
     {
@@ -446,64 +461,27 @@ struct Walk {
         const int icut = (int)cut;
         const bool w0 = has && (int)e0 >= icut && (d0.x & 0xFFu) != 0xFFu;
         const bool w1 = has && (int)e1 >= icut && (d1.x & 0xFFu) != 0xFFu;
+        // the pieces are decoded where they are, by the lanes whose piece counts (exec mask).  Queueing the pieces that count and
+        // decoding 64 of them per round with every lane busy (the round's first half) cost a second load per piece -- 64 different
+        // cache lines per instruction through the CU's L1: 12.4 ms against 10.6 (profiles/r04/nn_rows_n8.txt)
+        if (w0) decode_piece(d0.x, d0.y, d0.z, d0.w, e0 - S0);
+        if (w1) decode_piece(d1.x, d1.y, d1.z, lt3 ? d1.w : 0xFFFFFFFFu, e1 - S1);
         unsigned long long m;
-        unsigned r = rank_of(w0, m);
-        unsigned pos = phead + pcount + r;
-        if (pos >= PIECE_RING) pos -= PIECE_RING;
-        if (w0) pring[pos] = make_uint2(ref.x * 8u + l4, e0 - S0);
-        pcount += (unsigned)__popcll(m);
-        r = rank_of(w1, m);
-        pos = phead + pcount + r;
-        if (pos >= PIECE_RING) pos -= PIECE_RING;
-        if (w1) pring[pos] = make_uint2(ref.x * 8u + 4u + l4, e1 - S1);
-        pcount += (unsigned)__popcll(m);
+        unsigned r;
         const bool goes_on = has && !lt3 && d1.w != N8_NONE;
         r = rank_of(goes_on, m);
         if (goes_on) lring[(lhead + lcount + r) & (LINE_RING - 1u)] = make_uint2(d1.w, e1);
         lcount += (unsigned)__popcll(m);
     }
-    __device__ __forceinline__ void decode_round()
-    {
-        const unsigned k = min(pcount, 64u);
-        const bool has = lane < k;
-        unsigned idx = phead + lane;
-        if (idx >= PIECE_RING) idx -= PIECE_RING;
-        const uint2 ref = pring[idx];
-        phead += k; if (phead >= PIECE_RING) phead -= PIECE_RING;
-        pcount -= k;
-        const uint4 d = lines[has ? ref.x : 0u];
-        if (has) {
-            const unsigned w[4] = {d.x, d.y, d.z, (ref.x & 7u) == 7u ? 0xFFFFFFFFu : d.w};
-            unsigned p = ref.y;
-#pragma unroll
-            for (int q4 = 0; q4 < 4; q4++) {
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const unsigned b = (w[q4] >> (8 * q)) & 0xFFu;
-                    p += b;
-                    unsigned a = (p << 2) + neg4lo;
-                    if (CLAMP) a = min(a, dump4);
-                    a = b < N8_SKIP ? a : dump4;
-                    // (row[] starts at LDS byte 0: the byte offset IS the address -- one ds_add_u32, no address arithmetic)
-                    __hip_atomic_fetch_add(reinterpret_cast<lds_u32 *>((size_t)a), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-            }
-        }
-    }
-    // scan while more than `keep` lines wait (decoding whenever 64 pieces are queued)
+    // rounds while more than `keep` lines wait
     __device__ __forceinline__ void drain_lines_to(unsigned keep)
     {
         while (lcount > keep) {
             sync_wave();
             scan_round();
-            while (pcount >= 64u) { sync_wave(); decode_round(); }
         }
     }
-    __device__ __forceinline__ void finish()
-    {
-        drain_lines_to(0);
-        while (pcount) { sync_wave(); decode_round(); }
-    }
+    __device__ __forceinline__ void finish() { drain_lines_to(0); }
 };
 
 // ---- N co-occurrences from lists (the NNL sites) ----------------------------------------------------------------------------------
@@ -802,7 +780,7 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb_, hipStream_t 
 }
 
 // columns of the pair matrix per LDS row: the row's counters + 64 dump slots + the waves' rings must fit the CU's 160 KiB
-constexpr unsigned ROW_CHUNK_MAX = 30656;
+constexpr unsigned ROW_CHUNK_MAX = 36800;
 static unsigned row_chunk(size_t n) { return (unsigned)std::min<size_t>((n + 63) / 64 * 64, ROW_CHUNK_MAX); }
 static constexpr size_t kWalkLds = (size_t)(TRACS_NN_THREADS / 64) * WALK_LDS_PER_WAVE;
 
