@@ -807,10 +807,10 @@ int nn_rows_add(tracs_alignment *a, size_t row_begin, size_t row_end, size_t col
     // Cut into SEGMENTS of sites that all rows walk before any row starts on the next (grid.z is the slowest dimension of the
     // dispatch order), the lines of a segment stay in the 256 MiB Infinity Cache between their uses (the rows' bitmaps, read once,
     // are loaded non-temporally).  The price is one flush of the row per segment (atomic adds): 10 000 x 5 Mbp, 1.2 GB of lines:
-    // 13.5 ms in one segment, 12.55 in 10 (128 MiB), 14.1 in 32 (profiles/r04/nn_rows_n8.txt).  TRACS_NN_SEGMENT_MB overrides the
-    // segment size (0: one segment) for that measurement.
+    // 10.9 ms in one segment, 10.2 in 3 to 5 (512 / 256 MiB), 10.6 in 10, 12.9 in 32 (profiles/r04/nn_rows_n8.txt).
+    // TRACS_NN_SEGMENT_MB overrides the segment size (0: one segment) for that measurement.
     const char *seg_env = getenv("TRACS_NN_SEGMENT_MB");
-    const unsigned long long seg_bytes = (seg_env ? strtoull(seg_env, nullptr, 10) : 128ull) << 20;
+    const unsigned long long seg_bytes = (seg_env ? strtoull(seg_env, nullptr, 10) : 256ull) << 20;
     const unsigned segments = seg_bytes ? (unsigned)std::min<unsigned long long>(NN_MAX_SPLITS, std::max<unsigned long long>(1, (g->n_lines * 128ull + seg_bytes - 1) / seg_bytes)) : 1u;
     const unsigned splits = (unsigned)std::min<unsigned long long>(NN_MAX_SPLITS, std::max<unsigned long long>(segments, ((unsigned long long)g->max_row + target - 1) / target));
     const dim3 grid((unsigned)(row_end - row_begin), (unsigned)((n + chunk - 1) / chunk), splits);
