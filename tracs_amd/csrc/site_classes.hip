@@ -331,36 +331,39 @@ __global__ __launch_bounds__(1024) void group_offsets_kernel(const uint4 *__rest
                                                              unsigned *__restrict__ off32, unsigned long long *__restrict__ off64,
                                                              unsigned long long *__restrict__ totals)
 {
-    // thread t takes the run of groups [t run, (t + 1) run): its own sum, one scan of the 1 024 run sums (wave shuffles + 16 wave
-    // totals through LDS), then its run again -- three barriers where a Hillis-Steele scan per 1 024 groups took a thousand
-    __shared__ unsigned long long wave_tot[16];
+    // 1 024 consecutive groups per step (coalesced loads, the next step's already under way): a wave scan through shuffles, the 16
+    // wave totals through LDS -- two barriers per step where a Hillis-Steele scan in LDS took twenty
+    __shared__ unsigned long long wave_tot[2][16];
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const size_t run = (groups + 1023) / 1024;
-    const size_t g0 = min(groups, (size_t)t * run), g1 = min(groups, g0 + run);
     auto count_of = [&](size_t g) -> unsigned long long {
+        if (g >= groups) return 0ull;
         if (b < 7) { const uint4 a = masks[(size_t)b * groups + g]; return (unsigned long long)(__popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w)); }
         return gcounts[(size_t)(b - 7) * groups + g];
     };
-    unsigned long long sum = 0;
-    for (size_t g = g0; g < g1; g++) sum += count_of(g);
-    unsigned long long incl = sum;
+    unsigned long long base = 0, c_next = count_of((size_t)t);
+    int par = 0;
+    for (size_t g0 = 0; g0 < groups; g0 += 1024, par ^= 1) {
+        const size_t g = g0 + t;
+        const unsigned long long c = c_next;
+        c_next = count_of(g + 1024);
+        unsigned long long incl = c;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned long long o = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += o;
-    }
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    unsigned long long before = 0, all = 0;
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) wave_tot[par][wave] = incl;
+        __syncthreads();                                  // (wave_tot[par ^ 1] was last read before the previous step's barrier)
+        unsigned long long before = 0, all = 0;
 #pragma unroll
-    for (int w = 0; w < 16; w++) { const unsigned long long v = wave_tot[w]; if (w < wave) before += v; all += v; }
-    unsigned long long at = before + incl - sum;
-    for (size_t g = g0; g < g1; g++) {
-        if (b < 7) off32[(size_t)b * groups + g] = (unsigned)at;
-        else off64[(size_t)(b - 7) * groups + g] = at;
-        at += count_of(g);
+        for (int w = 0; w < 16; w++) { const unsigned long long v = wave_tot[par][w]; if (w < wave) before += v; all += v; }
+        if (g < groups) {
+            if (b < 7) off32[(size_t)b * groups + g] = (unsigned)(base + before + incl - c);
+            else off64[(size_t)(b - 7) * groups + g] = base + before + incl - c;
+        }
+        base += all;
     }
-    if (t == 0) totals[b] = all;
+    if (t == 0) totals[b] = base;
 }
 
 // the sites of a class in site order: list[off[g] ..] = the set bits of mask[g]
