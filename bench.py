@@ -773,6 +773,16 @@ def general_pass(args, n, L, seed, dev, synth, torch, device):
     e1.record()
     torch.cuda.synchronize()
     kern_s = e0.elapsed_time(e1) / 1e3 / reps
+    # ONE CALL on this alignment (what `value` measures on the default one): the planes count as freshly packed, the once-per-pack
+    # work is redone -- with partial codes every sample is listed at tens of thousands of sites, so the lists weigh more here
+    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    c0.record()
+    for _ in range(reps):
+        aln.mark_packed()
+        dev.pairsnp_dense(aln, dmat, nmat)
+    c1.record()
+    torch.cuda.synchronize()
+    call_s = c0.elapsed_time(c1) / 1e3 / reps
     from tracs_amd import _lib
     split, classes, pairs = pair_split_ms(_lib.load()), aln.site_classes, n * (n - 1) // 2
     traffic = _traffic_from_profiles(n, L, 1, aln.kernel + ("+classes" if classes else ""))
@@ -790,6 +800,7 @@ def general_pass(args, n, L, seed, dev, synth, torch, device):
     else:
         r = roofline_of(aln.kernel, "general", pairs, L, kern_s, traffic, n)
     r["dense_call_ms"] = kern_s * 1e3
+    r["one_call_ms"] = call_s * 1e3                          # (pairsnp only: once-per-pack work + the dense call, no transcluster)
     if split:
         r["kernels_ms"] = {"pairsnp_mfma_kernel": split[0], "general_fixup_kernel (partial codes of the dense sites + minority lists)": split[1],
                            "count_pass": split[2], "nn_rows_kernel": split[3]}
