@@ -57,6 +57,7 @@ CASES = [
     dict(n=2000, L=1500, p_n=0.002, mu=2e-4, seed=3, bitmaps=True),     # gaps beyond 253: skip bytes
     dict(n=130, L=4000, p_n=0.05, mu=2e-3, seed=4, p_partial=0.002),    # partial codes among the listed samples
     dict(n=700, L=3000, p_n=0.01, mu=3e-4, seed=5, bitmaps=True, edges=True),      # lists that end exactly at the encoder's boundaries
+    dict(n=900, L=6000, p_n=0.01, mu=6e-3, seed=6, bitmaps=True),       # ~30 000 listed entries: the bucketed fill of the per-sample lists
 ]
 
 # N samples of hand-made sites (case `edges`): the byte counts the encoder's branches turn on
