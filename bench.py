@@ -175,10 +175,10 @@ def nn_list_roofline(ls, sites, kern_s, rows, n, L=None):
             "bytes_per_list_entry": ls["n_entry_bytes"], "bitmap_bytes": bitmap,
             "entries_per_s": ls["nn_visits"] * frac_rows / kern_s,
             "note": "row i of the pair matrix in LDS; every N site of sample i (a set bit of its N bitmap) is a walk of the site's N list "
-                    "-- byte deltas in sample order, 124 per 128-byte line: a site of ~100 N samples among 10 000 is ONE line --, decoded by "
-                    "eight lanes (byte sums, an 8-lane DPP prefix, one SDWA add per byte), ds_add per j > i: sum of cN^2 list entries "
-                    "instead of n^2 / 2 pairs per site on the matrix cores.  Random reads of whole 128-byte lines: bound by the requests "
-                    "it pulls through the fabric (`frac_lines`, `traffic`, `hbm_physical`)"}
+                    "-- byte deltas in sample order, 124 per 128-byte line: a site of ~100 N samples among 10 000 is ONE line --, scanned by "
+                    "four lanes (byte sums, a DPP prefix) and decoded where it lies (one SDWA add and one ds_add per byte, for j > i): sum "
+                    "of cN^2 list entries instead of n^2 / 2 pairs per site on the matrix cores.  Random reads of whole 128-byte lines "
+                    "(`frac_lines`, `traffic`, `hbm_physical`); instruction issue is the first wall (DESIGN.md 3.1)"}
 
 
 def roofline_of(kernel, enc, pairs_per_launch, L, kern_s, traffic, n):
