@@ -833,7 +833,7 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb_, hipStream_t 
         unsigned shift = 0;
         while (((n - 1) >> shift) >= 256u) shift++;                                   // at most 256 buckets of 2^shift samples
         uint2 *tmp = nullptr;
-        two_pass = mb.tot_p >= ENT_TILE && shift <= 10 &&
+        two_pass = mb.tot_p >= ENT_TILE && mb.tot_p < (1ull << 32) && shift <= 10 &&      // (32-bit run cursors; at most 1 024 samples per bucket)
                               workspace_get(63, (size_t)mb.tot_p * sizeof(uint2), reinterpret_cast<void **>(&tmp)) == TRACS_OK;
         if (two_pass) {
             const unsigned buckets = (unsigned)(((n - 1) >> shift) + 1);
