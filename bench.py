@@ -9,11 +9,17 @@ Workload (BASELINE.json configs[2], the configuration the metric is quoted on; S
 Bernoulli(mu = 1e-4) sites (E[d] ~ 2 mu L ~ 1 000 before masking) and 'N' at Bernoulli(0.01) sites: a consensus (ACGTN)
 alignment -- packed planes RESIDENT IN HBM before the timed region.  One step = one full pass: pairsnp (d and compared
 sites for all N(N-1)/2 pairs) + transcluster (P(direct), E(K) for every pair from SNP distance and sampling-date gap).
-With N ranks the row panels of the pair matrix are dealt to the ranks (fold pairing: chunk r and chunk 2N-1-r, equal
-work), every rank holds the whole packed alignment, and the per-rank d / nn panels are exchanged with RCCL all-gathers
-(P and E(K) are re-derived from d on the consumer: tc gather is ~1 ms, the f64 panels would be 2/3 of the bytes).
-Strong scaling: the problem is fixed, `value` = total pairs / time; every step's panels have arrived on every rank
-before the clock stops.
+`--gpus N` with N > 1 and no launcher around it starts its own N ranks (`python -m torch.distributed.run --nproc-per-node N bench.py
+...` as a child process, before anything here has touched a GPU) and relays their line; under a launcher WORLD_SIZE must equal N.
+With N ranks (one per GPU) the default partition is by SITES (--partition sites): rank r holds a contiguous 1 / N of the packed
+planes (whole 128-site groups) and runs the single-GPU call on it for ALL pairs -- classification, lists, walks: every stage of a
+call works on 1 / N of the data --; d and the compared-sites counts are sums over sites, so the partial matrices are summed by the
+compact exchange (tracs_amd/partition.py TriExchange, csrc/exchange.hip: the upper-triangle cells only, 16 bits per cell where a
+slice's values fit, RCCL all-to-all over every xGMI link at once) and rank q ends up with the rows it owns (fold pairing) of d, nn,
+P and E(K): nothing is gathered, transcluster runs on a rank's own rows.  `--partition pairs` is north_star's wording: every rank
+holds the whole alignment and computes its row panels (fold pairing), RCCL all-gather of the d / nn panels (16 bits per cell where
+the values allow), P and E(K) re-derived from the gathered d on every rank.  Strong scaling either way: the problem is fixed,
+`value` = total pairs / time (max over ranks, barrier + synchronize on both sides).
 
 Prints ONE JSON line (rank 0):
   roofline          the dominant kernel of the timed region from HIP events on the launch stream (recorded by the library around
@@ -29,7 +35,8 @@ Prints ONE JSON line (rank 0):
                     "counts->posterior->code fused front-end"), timed separately (N = 1 only)
   cpu_baseline      the oracle (CPU port of the reference algorithm) on the host cores on a bounded sample of the same
                     workload, pair loop and trans_dist legs reported separately, the trans_dist leg also through the reference's
-                    own source compiled in place (oracle/_ref) (rank 0, N = 1 only)
+                    own source compiled in place (oracle/_ref) (rank 0, every N); its sample block doubles as the ALWAYS-ON
+                    result check: the GPU's d / nn of those pairs -- at N > 1: rows rank 0 owns after the exchange -- must be bit-equal
 """
 import argparse
 import json
@@ -82,7 +89,45 @@ def parse():
     ap.add_argument("--lamb", type=float, default=1e-3 * 29903)     # tracs distance defaults (distance.py:76-90)
     ap.add_argument("--beta", type=float, default=73.0)
     ap.add_argument("--precision", type=float, default=0.01)
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only check the launch: the ranks rendezvous (gloo, no GPU touched), rank 0 prints {\"n_gpus\": ranks that answered}")
     return ap.parse_args()
+
+
+def in_launcher():
+    """True when a launcher (torch.distributed.run) started this process as one rank of a job."""
+    return "RANK" in os.environ and "WORLD_SIZE" in os.environ
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: start the N ranks as a CHILD process -- never a re-exec, and before this
+    process has touched a GPU -- with the same arguments; their stdout (rank 0's JSON line) is this process's, their exit code too."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def launch_check(args, world, rank):
+    """--launch-check: the ranks find each other (gloo; no GPU is touched) and rank 0 reports how many answered."""
+    import torch
+    import torch.distributed as dist
+    n_seen = 1
+    if world > 1:
+        dist.init_process_group("gloo")
+        t = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(t)
+        n_seen = int(t.item())
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": n_seen, "world_size_env": world, "gpus_arg": args.gpus}), flush=True)
+    return 0 if n_seen == args.gpus else 1
 
 
 # The metric's workload ("sparse": SURVEY.md 8d's generator -- star phylogeny, mu per sample, 1 % N iid) and four others that
@@ -209,53 +254,116 @@ def roofline_of(kernel, enc, pairs_per_launch, L, kern_s, traffic, n):
                      "frac_of_measured_mix_ceiling": lane_ops / kern_s / E["mix_ceiling"]}}
 
 
+def dense_call_roofline(aln, split, n, L, world, last_pairs, last_rows, my_pairs_per_launch, kern_s, split_calls, overlap=False):
+    """`roofline` of a dense call: whichever of its kernels takes longest (HIP events the library records around its parts on the
+    launch stream: `split`), the others beside it.  last_pairs / last_rows: the cells and rows of the call `split` belongs to (a rank
+    of the pair partition: its last panel; a rank of the site partition: all rows over its slice of L sites)."""
+    enc = aln.encoding or "general"
+    classes = aln.site_classes
+    traffic = _traffic_from_profiles(n, L, world, aln.kernel + ("+classes" if classes else ""))
+    if classes and split:
+        # site classes (csrc/site_classes.hip): pair kernel over the dense sites, lists for the minority sites, one-operand
+        # counting pass over the counted sites.  `roofline` = whichever matrix-core kernel takes longer; the other beside it.
+        dense, counted, minority, full = classes
+        count_sites, in_place, nn_listed = aln.count_source or (counted, False, 0)
+        ls = aln.list_stats
+        main = roofline_of(aln.kernel, enc, last_pairs, dense, max(split[0], 1e-3) / 1e3, None, n)
+        cnt = count_roofline(last_pairs, count_sites, max(split[2], 1e-3) / 1e3, n, in_place)
+        nnl = nn_list_roofline(ls, nn_listed, max(split[3], 1e-3) / 1e3, last_rows, n, L) if nn_listed else None
+        cands = [(split[0], main, ""), (split[2], cnt, "+classes"), (split[3], nnl, "+nnlists")]
+        cands = sorted([c for c in cands if c[1] is not None], key=lambda c: -c[0])
+        roof, tag = cands[0][1], cands[0][2]
+        traffic = _traffic_from_profiles(n, L, world, aln.kernel + tag) if tag else None
+        roof["traffic"] = traffic
+        roof["hbm_physical"] = hbm_physical(traffic, roof["kernel_ms"] / 1e3, roof.get("compulsory_bytes") or roof.get("algorithmic_bytes"))
+        roof["other_kernels"] = [{k: c[1][k] for k in ("kernel", "kernel_ms", "bound", "achieved", "frac", "unit", "sites") if k in c[1]} for c in cands[1:]]
+        roof["kernel_ms_over"] = ("mean over the %d dense calls of the timed steps (HIP events around each part on the launch stream); "
+                                  "transcluster runs beside them on a second stream%s" % (split_calls, "" if overlap else " -- not in this run"))
+        roof["minority_lists_ms"] = split[1]
+        roof["dense_call_ms"] = kern_s * 1e3
+        roof["kernels_ms"] = {"pair kernel (dense sites)": split[0], "general_fixup_kernel (minority lists)": split[1],
+                              "counting pass (matrix cores)": split[2], "nn_rows_kernel (N co-occurrence lists)": split[3]}
+        roof["site_classes"] = {"dense": dense, "counted": counted, "minority": minority, "full": full,
+                                "empty": L - dense - counted - full, "counting_pass_sites": count_sites, "counting_pass_in_place": in_place,
+                                "nn_list_sites": nn_listed, "lists": ls,
+                                "note": "decided once per pack, results bit-identical (csrc/site_classes.hip): the pair kernel reads the dense "
+                                        "sites only; sites at which <= a few samples differ from the others (minority) add their distances "
+                                        "from sparse lists (general_fixup_kernel<MINOR>); nn of every non-dense site with an N comes from "
+                                        "the N lists of the sites with few N samples (nn_rows_kernel) and a one-operand matrix-core pass over the "
+                                        "others (counted = both + the sites with a single N), sites without any N add a constant (full). "
+                                        "TRACS_SITE_CLASSES=0 reads every site with the pair kernel, TRACS_MINORITY=0 keeps the minority sites dense"}
+    else:
+        roof = roofline_of(aln.kernel, enc, my_pairs_per_launch, L, kern_s, traffic, n)
+    roof["traffic_source"] = ("profiles/pmc_summary.json: FETCH_SIZE / WRITE_SIZE (gfx950-corrected) from separate rocprofv3 --pmc passes of "
+                              "`bench.py` itself on this workload and shape (scripts/gpu_pmc_bench.sh), committed with the profiles -- not "
+                              "measured by this run" if roof.get("traffic") is not None else None)
+    return roof
+
+
 def main():
     global _WORKLOAD_OF_PROFILES
     args = parse()
     _WORKLOAD_OF_PROFILES = args.workload if args.partial == 0 else "partial"
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if not in_launcher():
+        if args.gpus > 1:
+            raise SystemExit(launch_ranks(args))              # N ranks as a child process; nothing here has touched a GPU
+        world, rank, local = 1, 0, 0
+    else:
+        world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+        local = int(os.environ.get("LOCAL_RANK", str(rank)))
+        if world != args.gpus:                                # never a silent run on a different number of GPUs than the line says
+            raise SystemExit("--gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    if args.launch_check:
+        raise SystemExit(launch_check(args, world, rank))
     import torch
     import torch.distributed as dist
     from tracs_amd import _lib
     from tracs_amd import device as dev
     from tracs_amd import partition, synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world != 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     ndev = torch.cuda.device_count()
-    local = local % max(ndev, 1)          # (several ranks on one GPU only happens in the gloo smoke test)
+    local = local % max(ndev, 1)          # (several ranks on one GPU only happens in the gloo tests)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    comm_info = None
     if world > 1:
         # the exchange: the library's own RCCL entry points (include/tracs_hip.h part 4, csrc/comm.cpp) behind tracs_amd.rccl.RcclDist
         # -- torch only launched the processes and lends the rendezvous store --; TRACS_BENCH_BACKEND=nccl: torch.distributed over
-        # RCCL; gloo: torch.distributed over gloo (several ranks on one GPU: the smoke test)
+        # RCCL; gloo: torch.distributed over gloo (several ranks on one GPU: the tests; the default when GPUs < ranks).
+        # NO fallback: a communicator that cannot be made or fails its self-test ends this rank non-zero (the launcher ends the rest).
         from tracs_amd import rccl
         backend = rccl.backend_choice(world, ndev, "TRACS_BENCH_BACKEND")
         if backend == "rccl":
             try:
                 cand = rccl.RcclDist(device)
-                if not cand.self_test():
-                    raise RuntimeError("self-test failed")
-                dist = cand
+                ok = cand.self_test()
             except Exception as e:                                # noqa: BLE001
-                print("bench: no RCCL communicator through libtracs_hip (%s); torch.distributed instead" % e, file=sys.stderr, flush=True)
-                backend = "nccl"
-        if backend == "nccl":
+                print("bench: rank %d: no RCCL communicator through libtracs_hip (%s)" % (rank, e), file=sys.stderr, flush=True)
+                raise SystemExit(3)
+            if not ok:
+                print("bench: rank %d: the RCCL communicator failed its self-test" % rank, file=sys.stderr, flush=True)
+                raise SystemExit(3)
+            dist = cand
+            seen = cand.ranks_seen()
+            comm_info = {"ranks_seen": seen[1], "rank_seen": seen[0], "rccl_version": cand.rccl_version(), "self_test": "passed"}
+        elif backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
-        elif backend != "rccl":
+            comm_info = {"ranks_seen": dist.get_world_size(), "rccl_version": ".".join(str(x) for x in torch.cuda.nccl.version())}
+        else:
             dist.init_process_group(backend)
-        exchange = {"rccl": "libtracs_hip.so: RCCL behind the C ABI (tracs_allgather_panels, tracs_allreduce)",
+            comm_info = {"ranks_seen": dist.get_world_size(), "rccl_version": None}
+        exchange = {"rccl": "libtracs_hip.so: RCCL behind the C ABI (csrc/comm.cpp)",
                     "nccl": "torch.distributed over RCCL", "gloo": "torch.distributed over gloo"}.get(backend, backend)
+        comm_info["gpus_visible"] = ndev
     else:
         exchange = None
 
     n, L = args.samples, args.sites
     seed = 20241022 + 2
     if world > 1 and args.partition == "sites":
-        return site_sharded(args, n, L, seed, world, rank, device, dist, exchange)
+        return site_sharded(args, n, L, seed, world, rank, device, dist, exchange, comm_info)
     # ---- setup (untimed): packed alignment resident in HBM, sampling days -------------------
     t0 = time.time()
     aln = dev.Alignment(n, L)
@@ -468,45 +576,8 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = pairs_total * args.steps / elapsed
         enc = aln.encoding or "general"
-        traffic = _traffic_from_profiles(n, L, world, aln.kernel + ("+classes" if classes else ""))
-        last_pairs = partition.pairs_in_rows(n, *ranges[-1])      # `split` belongs to the last call of the step
-        if classes and split:
-            # site classes (csrc/site_classes.hip): pair kernel over the dense sites, lists for the minority sites, one-operand
-            # counting pass over the counted sites.  `roofline` = whichever matrix-core kernel takes longer; the other beside it.
-            dense, counted, minority, full = classes
-            count_sites, in_place, nn_listed = aln.count_source or (counted, False, 0)
-            ls = aln.list_stats
-            last_rows = ranges[-1][1] - ranges[-1][0]
-            main = roofline_of(aln.kernel, enc, last_pairs, dense, max(split[0], 1e-3) / 1e3, None, n)
-            cnt = count_roofline(last_pairs, count_sites, max(split[2], 1e-3) / 1e3, n, in_place)
-            nnl = nn_list_roofline(ls, nn_listed, max(split[3], 1e-3) / 1e3, last_rows, n, L) if nn_listed else None
-            cands = [(split[0], main, ""), (split[2], cnt, "+classes"), (split[3], nnl, "+nnlists")]
-            cands = sorted([c for c in cands if c[1] is not None], key=lambda c: -c[0])
-            roof, tag = cands[0][1], cands[0][2]
-            traffic = _traffic_from_profiles(n, L, world, aln.kernel + tag) if tag else None
-            roof["traffic"] = traffic
-            roof["hbm_physical"] = hbm_physical(traffic, roof["kernel_ms"] / 1e3, roof.get("compulsory_bytes") or roof.get("algorithmic_bytes"))
-            roof["other_kernels"] = [{k: c[1][k] for k in ("kernel", "kernel_ms", "bound", "achieved", "frac", "unit", "sites") if k in c[1]} for c in cands[1:]]
-            roof["kernel_ms_over"] = ("mean over the %d dense calls of the timed steps (HIP events around each part on the launch stream); "
-                                      "transcluster runs beside them on a second stream%s" % (split_calls, "" if overlap else " -- not in this run"))
-            roof["minority_lists_ms"] = split[1]
-            roof["dense_call_ms"] = kern_s * 1e3
-            roof["kernels_ms"] = {"pair kernel (dense sites)": split[0], "general_fixup_kernel (minority lists)": split[1],
-                                  "counting pass (matrix cores)": split[2], "nn_rows_kernel (N co-occurrence lists)": split[3]}
-            roof["site_classes"] = {"dense": dense, "counted": counted, "minority": minority, "full": full,
-                                    "empty": L - dense - counted - full, "counting_pass_sites": count_sites, "counting_pass_in_place": in_place,
-                                    "nn_list_sites": nn_listed, "lists": ls,
-                                    "note": "decided once per pack, results bit-identical (csrc/site_classes.hip): the pair kernel reads the dense "
-                                            "sites only; sites at which <= a few samples differ from the others (minority) add their distances "
-                                            "from sparse lists (general_fixup_kernel<MINOR>); nn of every non-dense site with an N comes from "
-                                            "the N lists of the sites with few N samples (nn_rows_kernel) and a one-operand matrix-core pass over the "
-                                            "others (counted = both + the sites with a single N), sites without any N add a constant (full). "
-                                            "TRACS_SITE_CLASSES=0 reads every site with the pair kernel, TRACS_MINORITY=0 keeps the minority sites dense"}
-        else:
-            roof = roofline_of(aln.kernel, enc, my_pairs_per_launch, L, kern_s, traffic, n)
-        roof["traffic_source"] = ("profiles/pmc_summary.json: FETCH_SIZE / WRITE_SIZE (gfx950-corrected) from separate rocprofv3 --pmc passes of "
-                                  "`bench.py` itself on this workload and shape (scripts/gpu_pmc_bench.sh), committed with the profiles -- not "
-                                  "measured by this run" if roof.get("traffic") is not None else None)
+        roof = dense_call_roofline(aln, split, n, L, world, partition.pairs_in_rows(n, *ranges[-1]), ranges[-1][1] - ranges[-1][0],
+                                   my_pairs_per_launch, kern_s, split_calls, overlap)
         enc_name = "consensus (ACGTN) alignment" if enc == "consensus" else "general IUPAC alignment (%.2g partial codes)" % args.partial
         W = WORKLOADS[args.workload]
         out = {"metric": "sample-pairs/sec for 10kx5Mbp SNP+transcluster distance", "value": value,
@@ -544,26 +615,63 @@ def main():
         if world == 1 and not args.no_extras and args.partial == 0:
             out["roofline_general"] = general_pass(args, n, L, seed, dev, synth, torch, device)
             out["dm_frontend"] = dm_frontend(args, L, dev, torch, device)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n, L, seed, days_np, args, dmat, nmat, keys[0])
+        if world > 1:
+            out["config"]["communicator"], out["config"]["ranks_seen"] = comm_info, comm_info["ranks_seen"]
+            if not args.no_cpu_baseline:                       # (the gathered matrix is whole on every rank)
+                keys[0] = distinct_keys(torch, dmat, n, days, [(0, n)])
+                out["config"]["distinct_keys"] = keys[0]
+        # ALWAYS: the first 128 samples' block against the oracle (full length, bit-equal), with or without the timed CPU legs
+        out["cpu_baseline"] = cpu_baseline(n, L, seed, days_np, args, dmat, nmat, keys[0], check_only=args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def site_sharded(args, n, L, seed, world, rank, device, dist, exchange):
+def distinct_keys(torch, dmat, n, days, ranges, dist=None, world=1):
+    """Distinct (SNP distance, day gap) keys over the cells (i, j > i) of the rows `ranges` of dmat -- over every rank's rows when
+    `dist` is given (each rank marks its rows' keys in a bitmap indexed by the key, one all-reduce MAX merges them).  Untimed: what
+    the cpu_baseline leg needs to know about the whole matrix when the ranks each hold only their rows."""
+    device = dmat.device
+    gmax = int((days.max() - days.min()).item())
+    top = torch.zeros(1, dtype=torch.int64, device=device)
+    step = 1024
+    col = torch.arange(n, device=device)[None, :]
+
+    def panels():
+        for r0, r1 in ranges:
+            for a in range(r0, r1, step):
+                b = min(r1, a + step)
+                row = torch.arange(a, b, device=device)[:, None]
+                yield dmat[a:b, :n].to(torch.int64), (days[a:b, None] - days[None, :]).abs().to(torch.int64), col > row
+    for d, _, up in panels():
+        if bool(up.any()):
+            top = torch.maximum(top, d[up].max().reshape(1))
+    if dist is not None and world > 1:
+        dist.all_reduce(top, op=dist.ReduceOp.MAX)
+    dmax = int(top.item())
+    marks = torch.zeros((dmax + 1) * (gmax + 1), dtype=torch.uint8, device=device)
+    for d, gap, up in panels():
+        marks[(d * (gmax + 1) + gap)[up]] = 1
+    if dist is not None and world > 1:
+        dist.all_reduce(marks, op=dist.ReduceOp.MAX)
+    return int(marks.sum(dtype=torch.int64).item())
+
+
+def site_sharded(args, n, L, seed, world, rank, device, dist, exchange, comm_info):
     """N ranks, each with a slice of the SITES (whole 128-site groups: a contiguous 1 / N of the packed planes).  d(i, j) and the
     compared-sites count nn(i, j) are sums over sites (src/pairsnp.hpp:398-403,417-420), so a rank runs the single-GPU call on its
     slice for ALL pairs -- classification, lists, walks: every stage works on 1 / N of the sites -- and the N partial matrices are
-    summed with a reduce-scatter (rank q receives rows q: tracs_reduce_scatter).  The result STAYS distributed: rank q owns rows
-    [q cs, (q + 1) cs) of d, nn, P and E(K) -- what `tracs distance --gpus N` does with the rows it then extracts -- so there is no
-    all-gather, and transcluster runs on a rank's own rows (its keys evaluated there; no table exchange).
+    summed by the compact exchange (tracs_amd/partition.py TriExchange, csrc/exchange.hip): the cells (i, j > i) only, 16 bits per
+    cell where the slice's values fit (d as it is, nn as its deficit below the slice's length), one all-to-all (every pair of ranks
+    over its own xGMI link), summed by the receiver.  The result STAYS distributed: rank q owns the rows of chunks q and 2N-1-q (fold
+    pairing: equal cell counts) of d, nn, P and E(K) -- what `tracs distance --gpus N` does with the rows it then extracts -- so
+    there is no all-gather, and transcluster runs on a rank's own rows (its keys evaluated there; no table exchange).
     One step = one call: the slice counts as freshly packed, everything once-per-pack is redone."""
     import torch
     from tracs_amd import _lib
     from tracs_amd import device as dev
-    from tracs_amd import synth
+    from tracs_amd import partition, synth
     groups = (L + 127) // 128
     g0, g1 = groups * rank // world, groups * (rank + 1) // world
     l0, l1 = g0 * 128, min(L, g1 * 128)
@@ -574,8 +682,7 @@ def site_sharded(args, n, L, seed, world, rank, device, dist, exchange):
     days = torch.from_numpy(days_np).to(device)
     torch.cuda.synchronize()
     setup_s = time.time() - t0
-    cs = ((n + world - 1) // world + 63) // 64 * 64
-    rows_pad = cs * world
+    rows_pad = (n + 63) // 64 * 64
     dmat = torch.zeros((rows_pad, n), dtype=torch.int32, device=device)
     nmat = torch.zeros((rows_pad, n), dtype=torch.int32, device=device)
     pmat = torch.zeros((rows_pad, n), dtype=torch.float64, device=device)
@@ -583,14 +690,8 @@ def site_sharded(args, n, L, seed, world, rank, device, dist, exchange):
     lib = _lib.load()
     lib.tracs_debug_pair_timing(1)
     lib.tracs_debug_pack_timing(1)
-    r0, r1 = min(n, rank * cs), min(n, (rank + 1) * cs)       # the rows this rank owns of every result
-    has_rs = hasattr(dist, "reduce_scatter_rows")
-
-    def reduce_rows(m):
-        if has_rs:
-            dist.reduce_scatter_rows(m, cs)
-        else:                                                  # torch.distributed (gloo has no reduce-scatter): sum the whole matrix
-            dist.all_reduce(m)
+    ex = partition.TriExchange(n, 0, n, 0, rank, world, dist, device)
+    own = ex.own_ranges                                        # the rows this rank owns of every result (at most two ranges)
 
     def step(per_call=True):
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -599,10 +700,10 @@ def site_sharded(args, n, L, seed, world, rank, device, dist, exchange):
         marks[0].record()
         dev.pairsnp_dense(aln, dmat, nmat)                     # all pairs over this rank's sites
         marks[1].record()
-        reduce_rows(dmat); reduce_rows(nmat)
+        ex.run(dmat, nmat, l1 - l0, L)                         # pack -> all-to-all -> sum into the own rows
         marks[2].record()
-        if r1 > r0:
-            dev.trans_dist_dense_ranges(dmat, n, days, args.lamb, args.beta, args.precision, pmat, emat, [(r0, r1)], exp_p0=True)
+        if own:
+            dev.trans_dist_dense_ranges(dmat, n, days, args.lamb, args.beta, args.precision, pmat, emat, own, exp_p0=True)
         marks[3].record()
         return marks
 
@@ -615,9 +716,14 @@ def site_sharded(args, n, L, seed, world, rank, device, dist, exchange):
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         return float(el.item()), got
 
+    # first call (untimed): the once-per-pack work, and what the exchange needs to know -- do a slice's partial distances and the
+    # deficits of its compared-sites counts fit 16 bits (agreed over the ranks; a later call that does not fit is caught: ex.check)
     torch.cuda.synchronize()
     t_first = time.perf_counter()
-    step()
+    aln.mark_packed()
+    dev.pairsnp_dense(aln, dmat, nmat)
+    ex.decide(dmat, nmat, l1 - l0)
+    ex.run(dmat, nmat, l1 - l0, L)
     torch.cuda.synchronize()
     t_first = time.perf_counter() - t_first
     for _ in range(args.warmup):
@@ -625,14 +731,20 @@ def site_sharded(args, n, L, seed, world, rank, device, dist, exchange):
     elapsed, marks = timed_run(args.steps, True)
     stages = dev.pack_stages_bytes()
     split = pair_split_ms(lib, args.steps)
+    kern_ms = sum(m[0].elapsed_time(m[1]) for m in marks) / len(marks)
     elapsed_steady, _ = timed_run(args.steps, False)
+    if not ex.check():
+        raise SystemExit("the exchange overflowed its 16-bit cells in a later call (rank %d)" % rank)
     pairs_total = n * (n - 1) // 2
     # (every rank holds the sums of its own rows only: the checksum of d is a sum over the ranks)
-    own = torch.triu(torch.ones((rows_pad, n), dtype=torch.bool, device=device), diagonal=1)
-    own[:r0] = False; own[r1:] = False
-    cks = torch.tensor([int(dmat[own].sum().item())], dtype=torch.int64, device=device)
+    mine = torch.zeros((rows_pad, n), dtype=torch.bool, device=device)
+    for q0, q1 in own:
+        mine[q0:q1] = True
+    mine &= torch.triu(torch.ones((rows_pad, n), dtype=torch.bool, device=device), diagonal=1)
+    cks = torch.tensor([int(dmat[mine].sum().item())], dtype=torch.int64, device=device)
     dist.all_reduce(cks)
     checksum = int(cks.item())
+    n_keys = distinct_keys(torch, dmat, n, days, own, dist, world) if not args.no_cpu_baseline else 0
     if os.environ.get("TRACS_BENCH_VERIFY"):
         # this rank's rows must equal the same rows of a single call over the whole alignment
         full = dev.Alignment(n, L)
@@ -641,8 +753,8 @@ def site_sharded(args, n, L, seed, world, rank, device, dist, exchange):
         p1, e1 = torch.zeros_like(pmat), torch.zeros_like(emat)
         dev.pairsnp_dense(full, d1, n1)
         dev.trans_dist_dense_ranges(d1, n, days, args.lamb, args.beta, args.precision, p1, e1, [(0, n)], exp_p0=True)
-        ok = bool(torch.equal(d1[own], dmat[own]) and torch.equal(n1[own], nmat[own]) and
-                  torch.equal(p1[own], pmat[own]) and torch.equal(e1[own], emat[own]))
+        ok = bool(torch.equal(d1[mine], dmat[mine]) and torch.equal(n1[mine], nmat[mine]) and
+                  torch.equal(p1[mine], pmat[mine]) and torch.equal(e1[mine], emat[mine]))
         okt = torch.tensor([1 if ok else 0], dtype=torch.int64, device=device)
         dist.all_reduce(okt)
         if rank == 0:
@@ -654,6 +766,11 @@ def site_sharded(args, n, L, seed, world, rank, device, dist, exchange):
         def mean_ms(a, b):
             return sum(m[a].elapsed_time(m[b]) for m in marks) / len(marks)
         W = WORKLOADS[args.workload]
+        # rank 0's dense call over its slice: all pairs, all rows, L = the slice's sites
+        roof = dense_call_roofline(aln, split, n, l1 - l0, world, pairs_total, n, pairs_total, kern_ms / 1e3, args.steps)
+        roof["scope"] = ("rank 0's dense call over its slice of the sites (%d of %d): every rank runs the same kernels on 1 / %d of the "
+                         "sites for all pairs; the step is shared between the slice's call, the exchange and transcluster (config.rank0_ms)"
+                         % (l1 - l0, L, world))
         out = {"metric": "sample-pairs/sec for 10kx5Mbp SNP+transcluster distance", "value": pairs_total * args.steps / elapsed,
                "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -666,21 +783,26 @@ def site_sharded(args, n, L, seed, world, rank, device, dist, exchange):
                                       "all %d pairs" % (n, L, W["mu_sample"], W["p_n"], "SURVEY 8d" if args.workload == "sparse" else
                                                          "workload '%s'" % args.workload, pairs_total),
                           "samples": n, "sites": L, "pairs": pairs_total, "workload_name": args.workload, "exchange": exchange,
+                          "communicator": comm_info, "ranks_seen": comm_info["ranks_seen"],
                           "partition": "SITE shards: rank r holds groups [%d r / %d, ..) of the packed planes (%d of %d sites on rank 0) and counts all "
-                                       "pairs over them; d and nn summed with a reduce-scatter of row panels (%d rows per rank): rank q "
-                                       "owns rows q of d, nn, P, E(K) (no all-gather; transcluster on a rank's own rows)"
-                                       % (groups, world, l1 - l0, L, cs),
+                                       "pairs over them; d and nn summed by the compact exchange -- upper-triangle cells, %d + %d bytes per cell "
+                                       "(d; nn as its deficit below the slice's length), all-to-all, summed by the receiver --: rank q owns the rows "
+                                       "of chunks q and %d - q (%d rows each; no all-gather; transcluster on a rank's own rows)"
+                                       % (groups, world, l1 - l0, L, ex.widths[0], ex.widths[1], 2 * world - 1, ex.cs),
                           "rank0_ms": {"dense call over the slice (once-per-pack work included)": mean_ms(0, 1),
-                                       "reduce-scatter of d and nn": mean_ms(1, 2), "transcluster over the rank's own rows": mean_ms(2, 3)},
-                          "exchange_bytes_per_rank_per_call": 2 * 4.0 * rows_pad * n * (world - 1) / world,
+                                       "exchange (pack, all-to-all, sum)": mean_ms(1, 2), "transcluster over the rank's own rows": mean_ms(2, 3)},
+                          "exchange_bytes_per_rank_per_call": ex.bytes_sent_per_call(), "exchange_bytes_per_cell": ex.bytes_per_cell(),
                           "kernels_ms": None if not split else dict(zip(("pair", "lists", "count", "nn_lists"), split)),
-                          "mean_d": checksum / float(pairs_total), "checksum_d": checksum,
+                          "mean_d": checksum / float(pairs_total), "checksum_d": checksum, "distinct_keys": n_keys or None,
                           "clock_rate": args.lamb, "trans_rate": args.beta, "precision": args.precision,
                           "setup_seconds": round(setup_s, 1), "first_call_ms": round(t_first * 1e3, 1)},
                "roofline_per_pack": per_pack_roofline(stages),
-               "roofline": {"bound": "hbm", "kernel": "the list kernels of a rank's slice (see roofline_per_pack and the N = 1 line); at N > 1 the "
-                                                      "step is shared between the slice's call and the exchange (config.rank0_ms)",
-                            "achieved": None, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": None, "traffic": None}}
+               "roofline": roof}
+        # ALWAYS: the first samples' block of the rows rank 0 owns against the oracle (full length, bit-equal), with or without the
+        # timed CPU legs
+        m = min(128, own[0][1] - own[0][0]) if own and own[0][0] == 0 else 0
+        if m >= 2:
+            out["cpu_baseline"] = cpu_baseline(n, L, seed, days_np, args, dmat, nmat, n_keys, m_max=m, check_only=args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
     dist.barrier()
     dist.destroy_process_group()
@@ -882,7 +1004,7 @@ def dm_frontend(args, L, dev, torch, device):
     return out
 
 
-def cpu_baseline(n, L, seed, days_np, args, dmat, nmat, n_keys_full):
+def cpu_baseline(n, L, seed, days_np, args, dmat, nmat, n_keys_full, m_max=128, check_only=False):
     """The oracle (C/OpenMP port of the reference algorithm) on the host cores, on a bounded sample of the same workload.
     Two legs, reported separately and never extrapolated through each other:
       pair loop   the first m samples of the SAME alignment, all m(m-1)/2 pairs at full length L, both passes, as the
@@ -894,13 +1016,16 @@ def cpu_baseline(n, L, seed, days_np, args, dmat, nmat, n_keys_full):
     import numpy as np
     from oracle import oracle as O
     from tracs_amd import synth
-    cores = O.lib().orc_num_threads()
-    m = int(max(16, min(n, 128)))
+    # (torch.distributed.run exports OMP_NUM_THREADS=1 to its ranks: under a launcher the leg takes the cores this process may run on)
+    cores = len(os.sched_getaffinity(0)) if in_launcher() else O.lib().orc_num_threads()
+    m = int(max(2, min(n, m_max)))
+    if check_only:
+        m = min(m, 64)
     seqs = synth.first_samples_host(n, L, seed, m, **synth_kw(args.partial, args.workload))
     planes = O.pack(seqs)                                   # untimed, like the GPU side's resident planes
     pairs = m * (m - 1) // 2
     reps, t_snp = 0, 0.0
-    while t_snp < args.cpu_seconds and reps < 1000:
+    while (t_snp < args.cpu_seconds and reps < 1000) and not (check_only and reps >= 1):
         t0 = time.perf_counter()
         r, c, d, nn = O.pairsnp_planes(planes, L, dist=2147483647, n_threads=cores)
         t_snp += time.perf_counter() - t0
@@ -912,6 +1037,9 @@ def cpu_baseline(n, L, seed, days_np, args, dmat, nmat, n_keys_full):
     gn = nmat[:m, :m].cpu().numpy().astype(np.int64)[ri, ci]
     if not (np.array_equal(gd, d.astype(np.int64)) and np.array_equal(gn, nn.astype(np.int64))):
         raise SystemExit("PARITY FAILURE: GPU d/nn differ from the oracle on the %d x %d sample block" % (m, m))
+    if check_only:
+        return {"value": None, "kind": "port", "cores": cores, "unit": "pairs/s",
+                "sample": "--no-cpu-baseline: only the result check ran -- first %d samples x %d sites, GPU d/nn bit-equal to the oracle" % (m, L)}
     delta = np.abs(days_np[ri] - days_np[ci]).astype(np.float64) * 86400.0 / 31556952.0
     # distinct keys in first-appearance order; time them in growing batches until the budget is spent
     _, first = np.unique(np.stack([d.astype(np.float64), delta]), axis=1, return_index=True)

@@ -347,7 +347,18 @@ int tracs_combine_fasta(const char *out_path, const char *const *sample_names, c
  *                          is the reduction of every rank's block `rank`.  The site-sharded form of the path: d and the
  *                          compared-sites counts are sums over sites (pairsnp.hpp:398-403,417-420), so ranks that each hold a slice
  *                          of the sites compute all pairs over their slice and the sums arrive as row panels
- *   tracs_send / _recv     `bytes` bytes to / from rank `peer` (variable-length COO payloads to the rank that writes the CSV) */
+ *   tracs_alltoall         send / recv hold `world` blocks of block_bytes bytes: block q of send -> rank q, where it becomes block
+ *                          `rank` of recv (ncclAllToAll: every pair of ranks over its own xGMI link)
+ *   tracs_tri_pack / _sum  the compact form of the site-sharded exchange (csrc/exchange.hip): the cells (i, j >= max(col_begin,
+ *                          i + 1)) of the rows [row_begin, row_end) of a uint32 panel (mat indexed by ABSOLUTE row, leading
+ *                          dimension ld) packed in `width` = 2 or 4 bytes per cell at element row_slot[i - row_begin] of `packed` (NULL: statistics only)
+ *                          (device array; UINT64_MAX: skip the row), as mat[i][j] or, negate != 0, as base - mat[i][j] (the
+ *                          compared-sites counts travel as their deficit below the slice's length); stats[0] = largest value
+ *                          packed (atomic max), stats[1] += values that did not fit 16 bits.  _sum: mat[i][j] += add +/- the sum
+ *                          over the blocks b != skip_block of recv[b * block_elems + row_slot[i - row_begin] + j - first column]
+ *   tracs_send / _recv     `bytes` bytes to / from rank `peer` (variable-length COO payloads to the rank that writes the CSV)
+ *   tracs_comm_rank / _world  what RCCL reports for the communicator (ncclCommUserRank / ncclCommCount); tracs_rccl_version:
+ *                          ncclGetVersion (0: RCCL not available) */
 #define TRACS_COMM_ID_BYTES 128
 typedef struct tracs_comm tracs_comm;
 int tracs_comm_unique_id(void *id, size_t cap);
@@ -360,6 +371,12 @@ int tracs_bcast_planes(tracs_comm *c, tracs_alignment *a, int root, void *stream
 int tracs_allgather_panels(tracs_comm *c, void *base, const size_t *offsets, size_t bytes, void *stream);
 int tracs_allreduce(tracs_comm *c, void *buf, size_t count, int dtype, int op, void *stream);
 int tracs_reduce_scatter(tracs_comm *c, void *buf, size_t count_per_rank, int dtype, int op, void *stream);
+int tracs_alltoall(tracs_comm *c, const void *send, void *recv, size_t block_bytes, void *stream);
+int tracs_tri_pack(const void *mat, size_t ld, size_t n, size_t row_begin, size_t row_end, size_t col_begin, const uint64_t *row_slot,
+                   int width, uint32_t base, int negate, void *packed, uint32_t *stats, void *stream);
+int tracs_tri_sum(void *mat, size_t ld, size_t n, size_t row_begin, size_t row_end, size_t col_begin, const uint64_t *row_slot, int width,
+                  const void *recv, size_t block_elems, int n_blocks, int skip_block, uint32_t add, int negate, void *stream);
+int tracs_rccl_version(void);
 int tracs_send(tracs_comm *c, const void *buf, size_t bytes, int peer, void *stream);
 int tracs_recv(tracs_comm *c, void *buf, size_t bytes, int peer, void *stream);
 

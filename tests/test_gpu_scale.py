@@ -124,9 +124,10 @@ def test_config5_shape_transcluster_and_clustering(dev, oracle):
     assert nc == enc and np.array_equal(lab.cpu().numpy(), elab)
 
 
-@pytest.mark.parametrize("part", ["sites", "pairs"])
+@pytest.mark.parametrize("part", ["sites"])
 def test_multirank_driver_path_on_one_gpu(part):
-    """bench.py's N > 1 paths with two gloo ranks sharing the GPU (TRACS_BENCH_VERIFY: the ranks' d / nn / P / E(K) must equal a
+    """bench.py under the driver's N > 1 launcher (python -m torch.distributed.run ... bench.py --gpus 2; the form without a launcher and
+    the pair partition: tests/test_gpu_exchange.py) with two gloo ranks sharing the GPU (TRACS_BENCH_VERIFY: the ranks' d / nn / P / E(K) must equal a
     single call over the whole alignment).  `sites`: every rank holds a slice of the sites and counts all pairs over it, the sums
     arrive as row panels (reduce-scatter; summed whole over gloo); `pairs`: row-panel partition, every rank holds the alignment,
     two-panel transcluster pass, async panel all-gathers in 16 bits per cell."""
@@ -235,6 +236,18 @@ dm = torch.zeros((70, 70), dtype=torch.int32, device=dev); dev_.pairsnp_dense(al
 from oracle import oracle as O
 er, ec, ed, enn = O.pairsnp_arrays(seqs)
 assert np.array_equal(dm.cpu().numpy()[er.astype(np.int64), ec.astype(np.int64)], ed.astype(np.int32))
+# the compact exchange of the site shards on a world of one: ranks_seen / version from RCCL itself, an all-to-all of one block, and
+# TriExchange end to end (nothing travels: the rank owns every row; nn = nn + (L - L_own) - 0)
+assert dist.ranks_seen() == (0, 1) and dist.rccl_version() > 20000
+a = torch.arange(256, dtype=torch.uint8, device=dev); b = torch.zeros_like(a)
+dist.all_to_all_blocks(a, b, 256); torch.cuda.synchronize(); assert bool(torch.equal(a, b))
+ex = partition.TriExchange(70, 0, 70, 0, 0, 1, dist, dev)
+nm = torch.zeros((70, 70), dtype=torch.int32, device=dev); dev_.pairsnp_dense(aln, dm, nm)
+assert ex.decide(dm, nm, 3000) == (2, 2)
+ex.run(dm, nm, 3000, 3000); torch.cuda.synchronize()
+assert ex.check() and ex.own_ranges == [(0, 70)] and ex.bytes_sent_per_call() == 0
+assert np.array_equal(dm.cpu().numpy()[er.astype(np.int64), ec.astype(np.int64)], ed.astype(np.int32))
+assert np.array_equal(nm.cpu().numpy()[er.astype(np.int64), ec.astype(np.int64)], enn.astype(np.int32))
 dist.barrier()
 dist.destroy_process_group()
 print("RCCL C ABI OK")

@@ -33,6 +33,7 @@ SYMBOLS = [
     "tracs_edges_j", "tracs_edges_free",
     "tracs_comm_unique_id", "tracs_comm_create", "tracs_comm_free", "tracs_comm_rank", "tracs_comm_world", "tracs_bcast",
     "tracs_bcast_planes", "tracs_allgather_panels", "tracs_allreduce", "tracs_reduce_scatter", "tracs_send", "tracs_recv",
+    "tracs_alltoall", "tracs_tri_pack", "tracs_tri_sum", "tracs_rccl_version",
 ]
 
 
@@ -238,6 +239,14 @@ def load():
     L.tracs_allreduce.argtypes = [vp, vp, sz, C.c_int, C.c_int, vp]
     L.tracs_reduce_scatter.restype = C.c_int
     L.tracs_reduce_scatter.argtypes = [vp, vp, sz, C.c_int, C.c_int, vp]
+    L.tracs_alltoall.restype = C.c_int
+    L.tracs_alltoall.argtypes = [vp, vp, vp, sz, vp]
+    L.tracs_tri_pack.restype = C.c_int
+    L.tracs_tri_pack.argtypes = [vp, sz, sz, sz, sz, sz, vp, C.c_int, C.c_uint32, C.c_int, vp, vp, vp]
+    L.tracs_tri_sum.restype = C.c_int
+    L.tracs_tri_sum.argtypes = [vp, sz, sz, sz, sz, sz, vp, C.c_int, vp, sz, C.c_int, C.c_int, C.c_uint32, C.c_int, vp]
+    L.tracs_rccl_version.restype = C.c_int
+    L.tracs_rccl_version.argtypes = []
     L.tracs_send.restype = C.c_int
     L.tracs_send.argtypes = [vp, vp, sz, C.c_int, vp]
     L.tracs_recv.restype = C.c_int

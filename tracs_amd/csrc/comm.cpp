@@ -13,6 +13,10 @@
 //     tracs_allreduce                              small agreements (key tables of transcluster, value ranges of the panels)
 //     tracs_reduce_scatter                         SITE shards: every rank counts its slice of the sites for ALL pairs (d and the
 //                                                  compared-sites counts are sums over sites), rank q receives rows q of the sums
+//     tracs_alltoall                               SITE shards, the compact form: every rank packs the upper-triangle cells of every
+//                                                  other rank's rows (exchange.hip: 16 bits per cell where the slice's values fit)
+//                                                  and block q goes to rank q -- point to point over every xGMI link at once,
+//                                                  summed by the receiver (a ring reduce-scatter moves the same bytes over ONE link)
 //     tracs_send / tracs_recv                      variable-length COO payloads to the rank that writes the CSV
 // RCCL is opened when the first communicator is made (dlopen of librccl.so.1: a process that already holds an RCCL -- PyTorch's --
 // gets that one), so a single-GPU host needs no RCCL at all.
@@ -38,6 +42,10 @@ struct Rccl {
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*AllToAll)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -68,6 +76,10 @@ int rccl_open()
     TRACS_SYM(Recv, "ncclRecv");
     TRACS_SYM(GroupStart, "ncclGroupStart");
     TRACS_SYM(GroupEnd, "ncclGroupEnd");
+    TRACS_SYM(AllToAll, "ncclAllToAll");
+    TRACS_SYM(CommCount, "ncclCommCount");
+    TRACS_SYM(CommUserRank, "ncclCommUserRank");
+    TRACS_SYM(GetVersion, "ncclGetVersion");
     TRACS_SYM(GetErrorString, "ncclGetErrorString");
 #undef TRACS_SYM
     g_rccl = r;
@@ -127,8 +139,27 @@ void tracs_comm_free(tracs_comm *c)
     delete c;
 }
 
-int tracs_comm_rank(const tracs_comm *c) { return c ? c->rank : -1; }
-int tracs_comm_world(const tracs_comm *c) { return c ? c->world : 0; }
+// what RCCL itself reports for the communicator (ncclCommUserRank / ncclCommCount), not what the caller passed in
+int tracs_comm_rank(const tracs_comm *c)
+{
+    int r = -1;
+    if (!c || !c->comm || !g_rccl.CommUserRank || g_rccl.CommUserRank(c->comm, &r) != ncclSuccess) return -1;
+    return r;
+}
+
+int tracs_comm_world(const tracs_comm *c)
+{
+    int w = 0;
+    if (!c || !c->comm || !g_rccl.CommCount || g_rccl.CommCount(c->comm, &w) != ncclSuccess) return 0;
+    return w;
+}
+
+int tracs_rccl_version(void)
+{
+    int v = 0;
+    if (rccl_open() != TRACS_OK || g_rccl.GetVersion(&v) != ncclSuccess) return 0;
+    return v;
+}
 
 int tracs_bcast(tracs_comm *c, void *buf, size_t bytes, int root, void *stream_)
 {
@@ -189,6 +220,15 @@ int tracs_reduce_scatter(tracs_comm *c, void *buf, size_t count_per_rank, int dt
     // in place: rank q's reduced block replaces block q of its own buffer (the other blocks keep this rank's partial values)
     char *mine = static_cast<char *>(buf) + (size_t)c->rank * count_per_rank * widths[dtype];
     TRACS_NCCL_CHECK(g_rccl.ReduceScatter(buf, mine, count_per_rank, types[dtype], ops[op], c->comm, static_cast<hipStream_t>(stream_)));
+    return TRACS_OK;
+}
+
+int tracs_alltoall(tracs_comm *c, const void *send, void *recv, size_t block_bytes, void *stream_)
+{
+    if (!c || ((!send || !recv) && block_bytes)) { tracs::set_error("tracs_alltoall: NULL argument"); return TRACS_E_ARG; }
+    if (block_bytes == 0) return TRACS_OK;
+    // block q of `send` -> rank q, where it lands as block `rank` of `recv`: every pair of ranks talks over its own xGMI link
+    TRACS_NCCL_CHECK(g_rccl.AllToAll(send, recv, block_bytes, ncclChar, c->comm, static_cast<hipStream_t>(stream_)));
     return TRACS_OK;
 }
 

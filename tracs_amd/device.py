@@ -364,3 +364,23 @@ def connected_components_device(I, J, n_nodes):
     nc = C.c_int32(0)
     _lib.check(L.tracs_connected_components_device(_ptr(I), _ptr(J), I.numel(), n_nodes, _ptr(labels), C.byref(nc), _stream()))
     return int(nc.value), labels
+
+
+def tri_pack(mat, n, row_begin, row_end, col_begin, slots, width, base, negate, packed_ptr, stats, base_row=0):
+    """csrc/exchange.hip: the cells (i, j >= max(col_begin, i + 1)) of rows [row_begin, row_end) of the uint32 panel `mat` (rows
+    base_row..) -> `width` bytes per cell at element slots[i - row_begin] of the buffer at packed_ptr (None: only the statistics);
+    stats: int32[2] (largest value, values beyond 16 bits)."""
+    L = _lib.require_gpu()
+    assert slots.dtype == torch.int64 and slots.is_contiguous() and slots.numel() == row_end - row_begin
+    _lib.check(L.tracs_tri_pack(_panel_ptr(mat, base_row), int(mat.stride(0)), int(n), int(row_begin), int(row_end), int(col_begin), _ptr(slots),
+                                int(width), int(base) & 0xFFFFFFFF, int(negate), C.c_void_p(packed_ptr or 0), _ptr(stats), _stream()))
+
+
+def tri_sum(mat, n, row_begin, row_end, col_begin, slots, width, recv_ptr, block_elems, n_blocks, skip_block, add, negate, base_row=0):
+    """csrc/exchange.hip: mat[i][j] += add +/- the sum over the blocks b != skip_block of recv[b * block_elems + slots[i - row_begin] + j - first
+    column] for the rows whose slot is not -1."""
+    L = _lib.require_gpu()
+    assert slots.dtype == torch.int64 and slots.is_contiguous() and slots.numel() == row_end - row_begin
+    _lib.check(L.tracs_tri_sum(_panel_ptr(mat, base_row), int(mat.stride(0)), int(n), int(row_begin), int(row_end), int(col_begin), _ptr(slots),
+                               int(width), C.c_void_p(recv_ptr), int(block_elems), int(n_blocks), int(skip_block), int(add) & 0xFFFFFFFF,
+                               int(negate), _stream()))

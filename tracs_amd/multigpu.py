@@ -40,7 +40,7 @@ def init():
     """-> (dist, rank, world, device).  `dist` is the exchange: the library's own RCCL entry points behind tracs_amd.rccl.RcclDist
     when every rank has its own GPU ("rccl": include/tracs_hip.h part 4 -- torch only launched the processes), torch.distributed
     over gloo when ranks share a device (smoke tests), or whatever TRACS_DIST_BACKEND says ("rccl", "nccl" = torch.distributed over
-    RCCL, "gloo").  A communicator that cannot be made or fails its self-test falls back to torch.distributed's."""
+    RCCL, "gloo").  A communicator that cannot be made or fails its self-test ends the rank non-zero (no silent fallback)."""
     import torch
     import torch.distributed as dist
     from . import rccl
@@ -51,14 +51,19 @@ def init():
     device = torch.device("cuda", local % max(ndev, 1))
     backend = rccl.backend_choice(world, ndev, "TRACS_DIST_BACKEND")
     if backend == "rccl":
+        # No fallback: a communicator that cannot be made, or fails its self-test, ends this rank non-zero -- the launcher
+        # (torch.distributed.run) then ends the others --, so ranks never disagree about the exchange and no result is ever computed
+        # over an exchange that was not checked.  TRACS_DIST_BACKEND=nccl|gloo asks for torch.distributed's explicitly.
         try:
             d = rccl.RcclDist(device)
-            if d.self_test():
-                return d, rank, world, device
-            sys.stderr.write("tracs: the RCCL communicator failed its self-test; using torch.distributed\n")
-        except Exception as e:                                   # noqa: BLE001  (every rank fails alike: RCCL missing, id not delivered)
-            sys.stderr.write("tracs: no RCCL communicator through libtracs_hip (%s); using torch.distributed\n" % e)
-        backend = "nccl"
+            ok = d.self_test()
+        except Exception as e:                                   # noqa: BLE001
+            sys.stderr.write("tracs: rank %d: no RCCL communicator through libtracs_hip (%s)\n" % (rank, e))
+            raise SystemExit(3)
+        if not ok:
+            sys.stderr.write("tracs: rank %d: the RCCL communicator failed its self-test\n" % rank)
+            raise SystemExit(3)
+        return d, rank, world, device
     if not dist.is_initialized():
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
@@ -141,29 +146,23 @@ def site_sharded_alignment(paths, dist, rank, world, device):
     return mine
 
 
-def _sum_rows(dist, m, rows_per_rank):
-    """rows [rank * rows_per_rank, ..) of m summed over the ranks (reduce-scatter through the library's RCCL entry point; the
-    whole panel summed over torch.distributed, which has no reduce-scatter on gloo)."""
-    if hasattr(dist, "reduce_scatter_rows"):
-        dist.reduce_scatter_rows(m, rows_per_rank)
-    else:
-        dist.all_reduce(m)
-
-
 def pairs_site_sharded(aln, i_end, j_start, dist_threshold, rank, world, dist):
     """pairsnp's output (rows, cols, d, nn: int32 device tensors, row-major) on rank 0, None elsewhere, from ranks that each hold
     a slice of the sites (site_sharded_alignment).  Row panel by row panel: every rank counts the panel's pairs over its sites,
-    the partial panels are summed with a reduce-scatter (rank q receives its 1 / P of the panel's rows), every rank extracts the
+    the partial panels are summed by the compact exchange (partition.TriExchange: the upper-triangle cells only, 16 bits per cell
+    where the slice's values fit, all-to-all; a rank receives the rows it owns under the fold pairing), every rank extracts the
     pairs within the threshold from its rows, and the pieces reach rank 0 in row order."""
     import torch
     from . import device as dev
     n = aln.n
     dev_ = torch.device("cuda", torch.cuda.current_device())
-    cs = max(64, (panel_rows(n) // world) // 64 * 64)         # rows of a panel per rank
-    cs = min(cs, ((i_end + world - 1) // world + 63) // 64 * 64)
-    R = cs * world
+    empty = [torch.empty(0, dtype=torch.int32, device=dev_) for _ in range(4)]
+    if i_end <= 0 or n == 0:                                   # nothing to compare (an empty first file): pairsnp.hpp:383 runs no row
+        return empty if rank == 0 else None
+    R = min(panel_rows(n), (i_end + 63) // 64 * 64)            # rows of a panel
     dpan = torch.zeros((R, n), dtype=torch.int32, device=dev_)
     npan = torch.zeros_like(dpan)
+    L_total = getattr(aln, "L_total", aln.L)
     out = [[] for _ in range(4)]
     for r0 in range(0, i_end, R):
         r1 = min(i_end, r0 + R)
@@ -171,33 +170,40 @@ def pairs_site_sharded(aln, i_end, j_start, dist_threshold, rank, world, dist):
             dev.pairsnp_dense(aln, dpan, npan, row_begin=r0, row_end=r1, col_begin=j_start, base_row=r0)
         else:
             dpan.zero_(); npan.zero_()
-        _sum_rows(dist, dpan, cs)
-        _sum_rows(dist, npan, cs)
-        q0, q1 = min(r1, r0 + rank * cs), min(r1, r0 + (rank + 1) * cs)
-        got = dev.coo_from_dense(dpan, npan, n, dist_threshold, row_begin=q0, row_end=q1, col_begin=j_start, base_row=r0) if q1 > q0 \
-            else [torch.empty(0, dtype=torch.int32, device=dev_) for _ in range(4)]
-        counts = torch.zeros(world, dtype=torch.int64, device=dev_)
-        counts[rank] = got[0].numel()
+        ex = partition.TriExchange(n, r0, r1, j_start, rank, world, dist, dev_)
+        ex.decide(dpan, npan, aln.L, base_row=r0)
+        ex.run(dpan, npan, aln.L, L_total, base_row=r0)
+        got = [[] for _ in range(4)]
+        for q0, q1 in ex.own_ranges:
+            g = dev.coo_from_dense(dpan, npan, n, dist_threshold, row_begin=q0, row_end=q1, col_begin=j_start, base_row=r0)
+            for t in range(4):
+                got[t].append(g[t])
+        # the panel's pieces in row order: (first row, owner, index among the owner's ranges)
+        pieces = sorted((rng[0], q, k) for q in range(world) for k, rng in enumerate(partition.own_row_ranges(r0, r1, q, world)))
+        counts = torch.zeros(len(pieces), dtype=torch.int64, device=dev_)
+        for p, (_, q, k) in enumerate(pieces):
+            if q == rank:
+                counts[p] = got[0][k].numel()
         dist.all_reduce(counts)
         counts = [int(x) for x in counts.cpu().tolist()]
-        for q in range(world):                                # the panel's pieces in rank (= row) order
-            if counts[q] == 0:
+        for p, (_, q, k) in enumerate(pieces):
+            if counts[p] == 0:
                 continue
             if q == 0:
                 if rank == 0:
                     for t in range(4):
-                        out[t].append(got[t])
+                        out[t].append(got[t][k])
             elif rank == q:
                 for t in range(4):
-                    dist.send(got[t].contiguous(), dst=0)
+                    dist.send(got[t][k].contiguous(), dst=0)
             elif rank == 0:
                 for t in range(4):
-                    buf = torch.empty(counts[q], dtype=torch.int32, device=dev_)
+                    buf = torch.empty(counts[p], dtype=torch.int32, device=dev_)
                     dist.recv(buf, src=q)
                     out[t].append(buf)
     if rank != 0:
         return None
-    return [torch.cat(o) if o else torch.empty(0, dtype=torch.int32, device=dev_) for o in out]
+    return [torch.cat(o) if o else empty[0] for o in out]
 
 
 def panel_rows(n, budget_bytes=1 << 30):

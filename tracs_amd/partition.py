@@ -246,3 +246,162 @@ def gather_coo(parts, world, rank, dist, dst=0):
     if rank != dst:
         return None
     return [torch.cat(out[t]) if out[t] else torch.empty(0, dtype=proto[t].dtype, device=proto[t].device) for t in range(k)]
+
+
+# ---- SITE shards: the compact exchange --------------------------------------------------------------------------------------------
+# Ranks that each hold a slice of the SITES compute partial d / nn matrices for ALL pairs (both are sums over sites,
+# src/pairsnp.hpp:398-403,417-420) and rank q needs the sums of the rows it owns.  Rows are owned under the fold pairing (chunk q and
+# chunk 2P-1-q of 2P equal chunks: equal cell counts), only the cells (i, j >= max(col_begin, i + 1)) travel, in 16 bits where a
+# slice's values fit (d as it is; nn as its deficit L_slice - nn), point to point (all-to-all: every xGMI link at once), and the
+# receiver sums in 32 bits (csrc/exchange.hip, tracs_alltoall).  Against the reduce-scatter of two full uint32 matrices of round 4:
+# half the cells, half the bytes per cell, and P - 1 links instead of one.
+
+def tri_layout(row_begin, row_end, n, col_begin, world, align=64):
+    """The packed layout of the rows [row_begin, row_end) of an n-column pair matrix over `world` ranks.
+    -> (cs, owner, off, block_elems): chunk rows; per row (numpy, index i - row_begin) the owning rank and the element offset of the
+    row's first cell (column max(col_begin, i + 1)) inside the owner's block -- the rows of its lower chunk first, then of its upper
+    chunk --; elements per block (the largest block, rounded up to `align`: every block has this stride)."""
+    import numpy as np
+    R = max(0, row_end - row_begin)
+    cs = max(1, -(-R // (2 * world)))
+    cs = -(-cs // align) * align
+    i = np.arange(row_begin, row_begin + R, dtype=np.int64)
+    cells = np.maximum(0, n - np.maximum(col_begin, i + 1))
+    chunk = (i - row_begin) // cs
+    owner = np.where(chunk < world, chunk, 2 * world - 1 - chunk).astype(np.int64)
+    off = np.zeros(R, dtype=np.int64)
+    most = 0
+    for q in range(world):
+        sel = np.nonzero(owner == q)[0]                   # ascending rows: the lower chunk first
+        c = cells[sel]
+        off[sel] = np.cumsum(c) - c
+        most = max(most, int(c.sum()))
+    block_elems = max(align, -(-most // align) * align)
+    return cs, owner, off, block_elems
+
+
+def own_row_ranges(row_begin, row_end, rank, world, align=64):
+    """[(r0, r1), ..] (at most two, ascending, clipped to row_end, empty ones dropped): the rows of [row_begin, row_end) that
+    `rank` owns under tri_layout's fold pairing."""
+    R = max(0, row_end - row_begin)
+    cs = max(1, -(-R // (2 * world)))
+    cs = -(-cs // align) * align
+    out = []
+    for c in sorted(rank_chunks(rank, world)):
+        r0, r1 = row_begin + c * cs, min(row_end, row_begin + (c + 1) * cs)
+        if r0 < r1:
+            if out and out[-1][1] == r0:
+                out[-1] = (out[-1][0], r1)
+            else:
+                out.append((r0, r1))
+    return out
+
+
+class TriExchange:
+    """The compact exchange of one panel geometry (rows [row_begin, row_end) x columns [col_begin, n)): `decide()` once per data
+    (the widths: an all-reduce of two maxima), `run()` per call: pack -> all-to-all -> sum into this rank's own rows of d and nn.
+    d / nn: torch.int32 device panels [rows, ld] holding rows base_row.. of the partial matrices."""
+
+    def __init__(self, n, row_begin, row_end, col_begin, rank, world, dist, device, align=64):
+        import numpy as np
+        import torch
+        self.n, self.rb, self.re, self.cb, self.rank, self.world, self.dist, self.device = n, row_begin, row_end, col_begin, rank, world, dist, device
+        self.cs, owner, off, self.block_elems = tri_layout(row_begin, row_end, n, col_begin, world, align)
+        self._owner = torch.from_numpy(owner).to(device)
+        self._off = torch.from_numpy(off).to(device)
+        mine = owner == rank
+        self.own_ranges = own_row_ranges(row_begin, row_end, rank, world, align)
+        self.own_cells = int(np.maximum(0, n - np.maximum(col_begin, np.arange(row_begin, row_end, dtype=np.int64) + 1))[mine].sum())
+        self._recv_slot = torch.where(self._owner == rank, self._off, torch.full_like(self._off, -1))
+        self.widths = None                       # (bytes per cell of d, of nn) after decide()
+        self._slots = {}
+        self._buf = {}
+        self.stats = torch.zeros((2, 2), dtype=torch.int32, device=device)      # per matrix: largest value packed, values that did not fit
+
+    # ---- the kernels (libtracs_hip.so: csrc/exchange.hip) -----------------------------------------------------------------------
+    def _pack(self, mat, base_row, slots, width, base, negate, packed_ptr, stats):
+        from . import device as dev
+        dev.tri_pack(mat, self.n, self.rb, self.re, self.cb, slots, width, base, negate, packed_ptr, stats, base_row)
+
+    def _sum(self, mat, base_row, slots, width, recv_ptr, block_elems, add, negate):
+        from . import device as dev
+        dev.tri_sum(mat, self.n, self.rb, self.re, self.cb, slots, width, recv_ptr, block_elems, self.world, self.rank, add, negate, base_row)
+
+    def _max(self, t):
+        """all-reduce MAX of a small int64 tensor"""
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return t
+
+    def _alltoall(self, send, recv, block_bytes):
+        """block q of `send` -> rank q, landing as block `rank` of its `recv` (uint8 tensors of world * block_bytes)."""
+        import torch
+        d = self.dist
+        if hasattr(d, "all_to_all_blocks"):                # tracs_amd.rccl.RcclDist: tracs_alltoall
+            d.all_to_all_blocks(send, recv, block_bytes)
+        elif send.is_cuda and d.get_backend() == "nccl":
+            d.all_to_all_single(recv, send)
+        else:                                              # gloo (ranks sharing a GPU, CPU tests): P - 1 rounds of send / recv
+            recv[self.rank * block_bytes:(self.rank + 1) * block_bytes].copy_(send[self.rank * block_bytes:(self.rank + 1) * block_bytes])
+            for k in range(1, self.world):
+                to, frm = (self.rank + k) % self.world, (self.rank - k) % self.world
+                w = d.isend(send[to * block_bytes:(to + 1) * block_bytes].contiguous(), dst=to)
+                got = torch.empty(block_bytes, dtype=torch.uint8, device=send.device)
+                d.recv(got, src=frm)
+                recv[frm * block_bytes:(frm + 1) * block_bytes].copy_(got)
+                w.wait()
+
+    # ---- protocol ---------------------------------------------------------------------------------------------------------------
+    def _send_slots(self, stride_elems):
+        import torch
+        if stride_elems not in self._slots:
+            s = self._owner * stride_elems + self._off
+            self._slots[stride_elems] = torch.where(self._owner == self.rank, torch.full_like(s, -1), s).contiguous()
+        return self._slots[stride_elems]
+
+    def decide(self, dmat, nmat, L_own, base_row=0):
+        """The widths from this call's partial matrices, agreed over the ranks: 2 bytes per cell where every rank's largest value
+        (d; L_own - nn) stays below 65 536."""
+        import torch
+        self.stats.zero_()
+        slots = self._send_slots(self.block_elems)
+        self._pack(dmat, base_row, slots, 4, 0, 0, None, self.stats[0])
+        self._pack(nmat, base_row, slots, 4, int(L_own), 1, None, self.stats[1])
+        m = self._max((self.stats[:, 0].to(torch.int64) & 0xFFFFFFFF).clone())
+        dmax, nmax = int(m[0].item()), int(m[1].item())
+        self.widths = (2 if dmax < 65536 else 4, 2 if nmax < 65536 else 4)
+        self.stats.zero_()
+        return self.widths
+
+    def bytes_per_cell(self):
+        return self.widths[0] + self.widths[1]
+
+    def bytes_sent_per_call(self):
+        """bytes this rank hands to the other ranks per call (P - 1 blocks of both matrices)"""
+        return (self.world - 1) * self.block_elems * self.bytes_per_cell()
+
+    def run(self, dmat, nmat, L_own, L_total, base_row=0):
+        """pack -> all-to-all -> sum: afterwards the rows `own_ranges` of dmat / nmat hold the sums over the ranks.  A value that no
+        longer fits the decided width is counted in `stats` (see check()), never truncated silently into a result that passes."""
+        import torch
+        wd, wn = self.widths
+        be = self.block_elems
+        block_bytes = (wd + wn) * be
+        key = (wd, wn)
+        if key not in self._buf:
+            self._buf = {key: (torch.empty(self.world * block_bytes, dtype=torch.uint8, device=self.device),
+                               torch.empty(self.world * block_bytes, dtype=torch.uint8, device=self.device))}
+        send, recv = self._buf[key]
+        sd, sn = block_bytes // wd, block_bytes // wn          # block stride in elements of each matrix's cell type
+        self._pack(dmat, base_row, self._send_slots(sd), wd, 0, 0, send.data_ptr(), self.stats[0])
+        self._pack(nmat, base_row, self._send_slots(sn), wn, int(L_own), 1, send.data_ptr() + wd * be, self.stats[1])
+        self._alltoall(send, recv, block_bytes)
+        self._sum(dmat, base_row, self._recv_slot, wd, recv.data_ptr(), sd, 0, 0)
+        self._sum(nmat, base_row, self._recv_slot, wn, recv.data_ptr() + wd * be, sn, int(L_total) - int(L_own), 1)
+
+    def check(self):
+        """True while no value of any call since decide() overflowed its width, on any rank."""
+        import torch
+        bad = self._max((self.stats[:, 1].to(torch.int64) & 0xFFFFFFFF).clone() * torch.tensor(
+            [1 if self.widths[0] == 2 else 0, 1 if self.widths[1] == 2 else 0], dtype=torch.int64, device=self.device))
+        return int(bad.sum().item()) == 0

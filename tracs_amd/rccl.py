@@ -119,6 +119,25 @@ class RcclDist:
         _lib.check(self._L.tracs_reduce_scatter(self._h, C.c_void_p(m.data_ptr()), rows_per_rank * m.shape[1], code, int(op), s))
         return self._leave(async_op)
 
+    def all_to_all_blocks(self, send, recv, block_bytes, async_op=False):
+        """send / recv: contiguous uint8 device tensors of world * block_bytes; block q of send -> rank q, where it becomes block
+        `rank` of recv (tracs_alltoall: every pair of ranks over its own xGMI link)."""
+        assert send.is_contiguous() and recv.is_contiguous()
+        assert send.numel() * send.element_size() == self.world * block_bytes == recv.numel() * recv.element_size()
+        s = self._enter()
+        _lib.check(self._L.tracs_alltoall(self._h, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()), int(block_bytes), s))
+        return self._leave(async_op)
+
+    def ranks_seen(self):
+        """(rank, world) as RCCL itself reports them for this communicator (ncclCommUserRank / ncclCommCount)."""
+        return int(self._L.tracs_comm_rank(self._h)), int(self._L.tracs_comm_world(self._h))
+
+    def rccl_version(self):
+        return int(self._L.tracs_rccl_version())
+
+    def get_backend(self):
+        return "rccl"
+
     def broadcast(self, t, src=0, async_op=False):
         assert t.is_contiguous()
         s = self._enter()
@@ -163,9 +182,28 @@ class RcclDist:
             objs[k] = got[k]
 
     def self_test(self):
-        """One all-reduce, one in-place all-gather and one broadcast on tiny buffers, checked: a broken exchange is found before
-        any result depends on it."""
+        """One all-reduce, one in-place all-gather, one broadcast, one in-place reduce-scatter (with a uint32 wrap) and one all-to-all
+        on tiny buffers, checked, and the communicator's own idea of its size: a broken exchange is found before any result depends
+        on it."""
         import torch
+        if self.ranks_seen() != (self.rank, self.world):
+            return False
+        W = self.world
+        rs = torch.full((W * 4, 8), self.rank + 1, dtype=torch.int32, device=self.device)
+        self.reduce_scatter_rows(rs, 4)
+        wrap = torch.full((W * 2, 4), -1 if self.rank == 0 else 3, dtype=torch.int32, device=self.device)     # 0xFFFFFFFF + 3 (W - 1) wraps
+        self.reduce_scatter_rows(wrap, 2)
+        a2a_s = (torch.arange(W, device=self.device, dtype=torch.int32)[:, None] * 100 + self.rank).repeat(1, 16).contiguous()
+        a2a_r = torch.zeros_like(a2a_s)
+        self.all_to_all_blocks(a2a_s.view(torch.uint8).view(-1), a2a_r.view(torch.uint8).view(-1), 64)
+        torch.cuda.synchronize()
+        if not bool((rs[self.rank * 4:(self.rank + 1) * 4] == W * (W + 1) // 2).all()):
+            return False
+        want = (0xFFFFFFFF + 3 * (W - 1)) & 0xFFFFFFFF
+        if not bool(((wrap[self.rank * 2:(self.rank + 1) * 2].to(torch.int64) & 0xFFFFFFFF) == want).all()):
+            return False
+        if not bool((a2a_r == (torch.arange(W, device=self.device, dtype=torch.int32)[:, None] + self.rank * 100)).all()):
+            return False
         v = torch.tensor([self.rank + 1], dtype=torch.int64, device=self.device)
         self.all_reduce(v)
         ok = int(v.item()) == self.world * (self.world + 1) // 2
