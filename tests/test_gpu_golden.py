@@ -499,7 +499,9 @@ def test_thresholded_dense_early_out(dev, oracle, torch_mod):
 def test_dense_source_tables_match_array_path(api, torch_mod):
     """Dense blocks take their prefix sums from (day gap, M) tables (csrc/transcluster.hip, TcTables); element arrays do not.  The
     same (N, delta) keys through both entry points -- the array path is pinned to the reference build's goldens above -- at SNP
-    distances that go to the wave-per-key kernel (N >= 128) and below."""
+    distances that go to the wave-per-key kernel (N >= 128) and below.  The dense keys with N >= 128 and a day gap run the term-ratio
+    loop over the LINEAR tables (one exponential per lane and step: tc_eval_wave), the array path the log-space fold; a block whose
+    days span 6.5 years falls back to the log-space tables (x beyond TC_LINEAR_X_MAX)."""
     from tracs_amd import device as dev
     torch = torch_mod
     n = 96
@@ -511,7 +513,13 @@ def test_dense_source_tables_match_array_path(api, torch_mod):
     d = torch.from_numpy(dmat).cuda()
     p = torch.zeros((n, n), dtype=torch.float64, device="cuda")
     e = torch.zeros((n, n), dtype=torch.float64, device="cuda")
-    for lamb, beta in ((1e-3 * 29903, 73.0), (5.3, 6.0)):
+    for lamb, beta, shape in ((1e-3 * 29903, 73.0, "wide"), (5.3, 6.0, "wide"), (1e-3 * 29903, 73.0, "bench"), (1e-3 * 29903, 73.0, "long")):
+        if shape == "bench":                                                     # bench.py's keys: distances near 1 000, two years of days
+            dmat = rng.integers(850, 1150, size=(n, n)).astype(np.int32)
+            days = rng.integers(0, 730, size=n).astype(np.int32)
+            d = torch.from_numpy(dmat).cuda()
+        if shape == "long":                                                      # six and a half years: x = delta (lamb + beta) beyond the linear tables
+            days = rng.integers(0, 2400, size=n).astype(np.int32)
         dev.trans_dist_dense_ranges(d, n, torch.from_numpy(days).cuda(), lamb, beta, 0.01, p, e, [(0, n)], exp_p0=False)
         ii, jj = np.triu_indices(n, 1)
         N = dmat[ii, jj]

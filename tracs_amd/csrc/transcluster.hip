@@ -28,8 +28,15 @@ namespace tracs {
 #ifndef TRACS_TC_WAVES
 #define TRACS_TC_WAVES 3     // ... its register budget, as waves per SIMD
 #endif
+#ifndef TRACS_TC_FT
+#define TRACS_TC_FT 4        // term-ratio loop: consecutive k per lane and step
+#endif
+#ifndef TRACS_TC_RW
+#define TRACS_TC_RW 4        // ... its register budget, as waves per SIMD
+#endif
 constexpr int LG_TABLE = 32768;     // lgamma(n) table, n < LG_TABLE; beyond: lgamma() inline
-constexpr int LK_TABLE = 10240;     // log(k) table behind it (the E(K) loop stops at k = 10 000): lg[LG_TABLE + k] = log(k)
+constexpr int LK_TABLE = 10240;     // log(k) table behind it (the E(K) loop stops at k = 10 000): lg[LG_TABLE + k] = log(k),
+                                    // and 1 / k behind that: lg[LG_TABLE + LK_TABLE + k] = 1 / k (the term-ratio recurrence of tc_eval_wave)
 
 struct TcParams {
     double lamb, beta, thr;
@@ -158,10 +165,14 @@ __device__ bool tc_eval(int N, double delta, const TcParams &P, const double *__
 // no host round trip); `ok` = 0 otherwise, and for sources without day gaps.
 struct TcTables {
     double *lnS, *pois;
+    double *lnS_n;                  // linear tables: ln S_N for N <= n_max (rows of ldn), what p0 needs in log space
     unsigned n_max, gap_max;        // bounds of the keys of this call
     unsigned ldm, ldn;              // row lengths: n_max + 10 001, n_max + 1
     unsigned ok;
+    unsigned linear;                // lnS[gap][M] holds F = S_M exp(-x), x = delta (lamb + beta): the Poisson(x) distribution function at M,
+                                    // in LINEAR space (x <= TC_LINEAR_X_MAX over the call's gaps: F >= exp(-x) stays far from underflow)
 };
+constexpr double TC_LINEAR_X_MAX = 600.0;
 constexpr unsigned long long TC_TABLE_ELEMS = 48ull << 20;      // doubles in the lnS table (384 MB)
 
 // A key handed over without any term summed (state[0] is NaN: tc_keys_kernel does that for N >= TC_WAVE_PREFIX_MIN)
@@ -195,9 +206,10 @@ __device__ __forceinline__ void tc_eval_wave(int N, double delta, const TcParams
     // sum = scaled * exp(mx); an empty sum is (0, -inf)
     double pois, ld = 0.0, upper;
     double Ms, Ss, Mp, Lps, Me, Els;
+    const bool linear = tabled && tab->linear;
     if (fresh && tabled) {
         pois = tab->pois[(size_t)gap * tab->ldn + N];
-        const double lnS = rowS[N];
+        const double lnS = linear ? tab->lnS_n[(size_t)gap * tab->ldn + N] : rowS[N];
         double l0 = (n1 * P.ln_lamb + 0.0 * P.ln_beta + lg_n1);
         l0 = l0 - lg_n1 - lg_at(lg, 1) - delta * P.beta;
         l0 -= pois;
@@ -255,14 +267,13 @@ __device__ __forceinline__ void tc_eval_wave(int N, double delta, const TcParams
     // 1 500 terms, at N = 10 000 (k* beyond the loop's 10 000 terms) all but the last ~ 200.  The stopping test cannot fire among the
     // skipped terms when their sum, at most k_lo exp(t2(k_lo)), is below upper - thr: checked.  Needs S from the table (the running sum
     // S cannot skip), so tabled keys with delta > 0 only; k_lo is looked for at 64 probes between the start and the peak.
+    const double c2 = n1 * P.ln_lamb - lg_n1 - delta * P.beta - pois + delta * (P.lamb + P.beta);
+    auto t2_at = [&](int k) {
+        const long long M = (long long)N + k;
+        return c2 + (double)k * P.ln_beta + lg_at(lg, M + 1) - lg_at(lg, (long long)k + 1) + lkt[k] - (double)(M + 1) * P.ln_lb;
+    };
+    const int k_peak = (int)fmin(9999.0, fmax(1.0, floor(P.beta * n1 / P.lamb)));
     if (pos && tabled && upper - P.thr > 0.0) {
-        const double c2 = n1 * P.ln_lamb - lg_n1 - delta * P.beta - pois + delta * (P.lamb + P.beta);
-        auto t2_at = [&](int k) {
-            const long long M = (long long)N + k;
-            return c2 + (double)k * P.ln_beta + lg_at(lg, M + 1) - lg_at(lg, (long long)k + 1) + lkt[k] - (double)(M + 1) * P.ln_lb;
-        };
-        const double kstar = floor(P.beta * n1 / P.lamb);
-        const int k_peak = (int)fmin(9999.0, fmax(1.0, kstar));
         if (k_peak > k_start + 64 * TPL) {
             const double t_peak = t2_at(k_peak);
             const int kj = k_start + (int)(((long long)(k_peak - k_start) * lane) >> 6);
@@ -302,7 +313,7 @@ __device__ __forceinline__ void tc_eval_wave(int N, double delta, const TcParams
             double Sk[TPL];
             if (tabled) {
 #pragma unroll
-                for (int q = 0; q < TPL; q++) Sk[q] = kb + q < 10000 ? rowS[(long long)N + kb + q] : 0.0;
+                for (int q = 0; q < TPL; q++) Sk[q] = kb + q < 10000 ? (linear ? log(rowS[(long long)N + kb + q]) + delta * (P.lamb + P.beta) : rowS[(long long)N + kb + q]) : 0.0;
             } else {
                 double a[TPL], Sl[TPL];
 #pragma unroll
@@ -360,11 +371,126 @@ __device__ __forceinline__ void tc_eval_wave(int N, double delta, const TcParams
     eK = Lps * exp(Mp);                                                // ran to k = 9999
 }
 
+// ---- the term-ratio loop: keys of a dense block with N >= TC_WAVE_PREFIX_MIN, a day gap >= 1 and LINEAR tables ----------------------
+// exp(t2(k + 1) - t2(k)) = beta (N + k + 1) / ((lamb + beta) k) is rational in k, and t1(k) = t2(k) + ln F(N + k) with F the table's
+// Poisson distribution function in linear space: a lane evaluates ONE exponential per step -- its first term, in units of exp(ref),
+// ref = t2 at its peak k* = beta (N + 1) / lamb: every term is <= ~1, nothing overflows, terms 700 below the peak vanish as they do in
+// the reference's log-space fold -- and walks its FT consecutive k with two multiplications per term (1 / k from a table), where the
+// log-space form took two exponentials per term.  Per step the lanes' two run sums are prefix-summed over the wave and the reference's
+// stopping test (upper - exp(elprob) > thr, :207,232) is made on every term's prefix.  Rounding only.  The head of the series is
+// skipped as in tc_eval_wave (terms e^-60 below the peak, their sum checked against the stopping bound).  One wave per key; a kernel
+// of its own so that its small register budget buys the occupancy that hides the loads' latency (a key is a chain of ~10 dependent
+// memory round trips: the log-space kernel ran three waves per SIMD and spent 20 us per key waiting).
+// -> false when the key is not eligible (tables absent or in log space, gap 0, N beyond the tables): the caller hands it to the wave kernel.
+__device__ __forceinline__ bool tc_eval_ratio(int N, double delta, long long gap, const TcParams &P, const double *__restrict__ lg,
+                                              const TcTables *__restrict__ tab, double &eK, double &p0)
+{
+    // (every lgamma of the loop from the table -- N + 10 000 < LG_TABLE --: no call in this kernel, its register count is the loop's own)
+    if (!(tab->ok && tab->linear && gap >= 1 && gap <= (long long)tab->gap_max && (unsigned)N <= tab->n_max && delta > 0 && N + 10001 < LG_TABLE)) return false;
+    const double *__restrict__ rowF = tab->lnS + (size_t)gap * tab->ldm;
+    const double *__restrict__ lkt = lg + LG_TABLE;
+    const double *__restrict__ invk = lg + LG_TABLE + LK_TABLE;
+    const int lane = threadIdx.x & 63;
+    const double n1 = (double)(N + 1);
+    const double lg_n1 = lg[N + 1];
+    const double pois = tab->pois[(size_t)gap * tab->ldn + N];
+    const double lnS = tab->lnS_n[(size_t)gap * tab->ldn + N];
+    {
+        double l0 = (n1 * P.ln_lamb + 0.0 * P.ln_beta + lg_n1);
+        l0 = l0 - lg_n1 - lg[1] - delta * P.beta;
+        l0 -= pois;
+        p0 = l0 + (lnS - n1 * P.ln_lb);
+    }
+    const double upper = exp(P.ln_beta + delta * P.lamb + log(n1) - (P.ln_lamb + pois));
+    const double c2 = n1 * P.ln_lamb - lg_n1 - delta * P.beta - pois + delta * (P.lamb + P.beta);
+    auto t2_at = [&](int k) {
+        const long long M = (long long)N + k;
+        return c2 + (double)k * P.ln_beta + lg[M + 1] - lg[k + 1] + lkt[k] - (double)(M + 1) * P.ln_lb;
+    };
+    constexpr int FT = TRACS_TC_FT;
+    const int k_peak = (int)fmin(9999.0, fmax(1.0, floor(P.beta * n1 / P.lamb)));
+    const bool bounded = upper - P.thr > 0.0;
+    int k_start = 1;
+    const double t_peak = t2_at(k_peak);
+    if (bounded && k_peak > 1 + 64 * FT) {
+        const int kj = 1 + (int)(((long long)(k_peak - 1) * lane) >> 6);
+        const double tj = t2_at(kj);
+        const unsigned long long low = __ballot(tj <= t_peak - 60.0);
+        if (low) {
+            const int j = 63 - __clzll((long long)low);
+            const int k_lo = __shfl(kj, j, 64);
+            const double t_lo = __shfl(tj, j, 64);
+            if (log((double)k_lo) + t_lo < log(upper - P.thr)) k_start = k_lo;
+        }
+    }
+    auto wave_prefix = [&](double e) {                                // inclusive prefix sums across the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const double o = __shfl_up(e, off, 64);
+            if (lane >= off) e += o;
+        }
+        return e;
+    };
+    const double ref = bounded ? t_peak : t2_at(1);                   // (a loop that stops at its first term: that term is 1)
+    const double flim = (upper - P.thr) * exp(-ref);
+    const double qb = P.beta / (P.lamb + P.beta);
+    double S1 = 0.0, S2 = 0.0;                                        // sums of the steps before this one (wave-uniform)
+    for (int k0 = k_start; k0 < 10000; k0 += 64 * FT) {
+        const int kb = k0 + lane * FT;
+        double F[FT], rk[FT];
+#pragma unroll
+        for (int q = 0; q < FT; q++) {                                // (the step's loads first: they do not wait for the exponential)
+            const int k = kb + q;
+            const bool in = k < 10000;
+            F[q] = in ? rowF[(long long)N + k] : 0.0;
+            rk[q] = invk[in ? k : 1];
+        }
+        const double e0 = kb < 10000 ? exp(t2_at(kb) - ref) : 0.0;
+        double e = e0, r1 = 0.0, r2 = 0.0;
+#pragma unroll
+        for (int q = 0; q < FT; q++) {
+            const int k = kb + q;
+            const double ee = k < 10000 ? e : 0.0;
+            r2 += ee; r1 += ee * F[q];
+            e *= qb * (double)(N + k + 1) * rk[q];
+        }
+        const double i1 = wave_prefix(r1), i2 = wave_prefix(r2);
+        const double b1 = S1 + (i1 - r1), b2 = S2 + (i2 - r2);
+        // the lane whose run crosses the bound walks its terms once more for the exact one (once per key)
+        const unsigned long long m = __ballot(kb < 10000 && !(b2 + r2 < flim));
+        if (m) {
+            const int f = __ffsll((long long)m) - 1;
+            double val = 0.0;
+            if (lane == f) {
+                double a1 = b1, a2 = b2;
+                e = e0;
+                bool found = false;
+#pragma unroll
+                for (int q = 0; q < FT; q++) {
+                    const int k = kb + q;
+                    if (k < 10000 && !found) {
+                        a2 += e; a1 += e * F[q];
+                        val = a1;
+                        found = !(a2 < flim);
+                    }
+                    e *= qb * (double)(N + k + 1) * rk[q];
+                }
+            }
+            eK = __shfl(val, f, 64) * exp(ref);
+            return true;
+        }
+        S1 = __shfl(b1 + r1, 63, 64); S2 = __shfl(b2 + r2, 63, 64);
+    }
+    eK = S1 * exp(ref);                                               // ran to k = 9999
+    return true;
+}
+
 __global__ void lgamma_table_kernel(double *__restrict__ lg, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) lg[i] = lgamma((double)i);   // lg[0] = +inf like std::lgamma(0.0) (:255-257)
     else if (i < n + LK_TABLE) lg[i] = log((double)(i - n));
+    else if (i < n + 2 * LK_TABLE) lg[i] = 1.0 / (double)(i - n - LK_TABLE);
 }
 
 // ---- key sources ------------------------------------------------------------------------
@@ -561,16 +687,19 @@ __global__ void tc_key_bounds_kernel(Src src, const unsigned *__restrict__ key_e
 
 // one wave per day gap: the two prefix-sum rows of the gap, 64 indices per step (scaled linear sums, like tc_eval_wave)
 __global__ __launch_bounds__(64) void tc_tables_kernel(TcTables *__restrict__ tab, const unsigned *__restrict__ bounds, const unsigned *__restrict__ n_keys,
-                                                       double *lnS, double *pois, unsigned long long pois_cap, TcParams P, const double *__restrict__ lg)
+                                                       double *lnS, double *pois, double *lnS_n, unsigned long long pois_cap, TcParams P,
+                                                       const double *__restrict__ lg)
 {
     const unsigned n_max = bounds[0], gap_max = bounds[1];
     const unsigned long long ldm = (unsigned long long)n_max + 10001ull, ldn = (unsigned long long)n_max + 1ull;
     // the tables must fit, and must be less work than they save: a few thousand terms per key against one table entry per (gap, M)
     const bool ok = gap_max >= 1 && ((unsigned long long)gap_max + 1ull) * ldm <= TC_TABLE_ELEMS && ((unsigned long long)gap_max + 1ull) * ldn <= pois_cap &&
                     ((unsigned long long)gap_max + 1ull) * ldm <= (unsigned long long)*n_keys * 4096ull;
+    // linear form (what the term-ratio loop of tc_eval_wave reads) while the largest x of the call keeps exp(-x) a normal double
+    const bool linear = lnS_n != nullptr && (double)((long long)gap_max * 86400ll) / 31556952.0 * (P.lamb + P.beta) <= TC_LINEAR_X_MAX;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        tab->lnS = lnS; tab->pois = pois; tab->n_max = n_max; tab->gap_max = gap_max; tab->ldm = (unsigned)ldm; tab->ldn = (unsigned)ldn;
-        tab->ok = ok ? 1u : 0u;
+        tab->lnS = lnS; tab->pois = pois; tab->lnS_n = lnS_n; tab->n_max = n_max; tab->gap_max = gap_max; tab->ldm = (unsigned)ldm; tab->ldn = (unsigned)ldn;
+        tab->ok = ok ? 1u : 0u; tab->linear = linear ? 1u : 0u;
     }
     if (!ok) return;
     P.ln_lamb = log(P.lamb); P.ln_beta = log(P.beta); P.ln_lb = log(P.lamb + P.beta);
@@ -591,18 +720,24 @@ __global__ __launch_bounds__(64) void tc_tables_kernel(TcTables *__restrict__ ta
     for (unsigned gap = 1 + blockIdx.x; gap <= gap_max; gap += gridDim.x) {
         const double delta = (double)((long long)gap * 86400ll) / 31556952.0;        // the sources' expression (DenseSource::get)
         const double ld = log(delta), lx = log(P.lamb * delta);
+        const double x = delta * (P.lamb + P.beta);
         for (int which = 0; which < 2; which++) {
             const unsigned long long len = which ? ldn : ldm;
             double *__restrict__ row = (which ? pois + (size_t)gap * ldn : lnS + (size_t)gap * ldm);
-            double mx = -INFINITY, scaled = 0.0;
+            double *__restrict__ row_n = lnS_n + (size_t)gap * ldn;
+            const bool lin = linear && which == 0;
+            double mx = -INFINITY, scaled = 0.0, unit = 0.0;      // unit = exp(mx - x): F = S exp(-x) = pre * unit
             for (unsigned long long i0 = 0; i0 < len; i0 += 64) {
                 const long long i = (long long)(i0 + lane);
                 const bool in = (unsigned long long)i < len;
                 const double t = !in ? -INFINITY : which ? imul(i, lx) - lg_at(lg, i + 1) : imul(i, ld) + (double)i * P.ln_lb - lg_at(lg, i + 1);
                 const double m = wave_max(t);
-                if (m > mx) { scaled = mx == -INFINITY ? 0.0 : scaled * exp(mx - m); mx = m; }
+                if (m > mx) { scaled = mx == -INFINITY ? 0.0 : scaled * exp(mx - m); mx = m; if (lin) unit = exp(mx - x); }
                 const double pre = scaled + wave_prefix(t == -INFINITY ? 0.0 : exp(t - mx));
-                if (in) row[i] = mx + log(pre);
+                if (in) {
+                    if (lin) { row[i] = pre * unit; if ((unsigned long long)i < ldn) row_n[i] = mx + log(pre); }
+                    else row[i] = mx + log(pre);
+                }
                 scaled = __shfl(pre, 63, 64);
             }
         }
@@ -635,6 +770,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TRACS_TC_WAV
                 const long long slot = kt.index(N, src.day_gap(elem));
                 if (slot >= 0) { kt.eK[slot * kt.step] = eK; if (fresh) kt.p0[slot * kt.step] = p0; }
             }
+        }
+    }
+}
+
+// the fresh long keys (nothing summed yet: N >= TC_WAVE_PREFIX_MIN) through the term-ratio loop; the others, and the keys it does not
+// take, go on to tc_long_keys_kernel through rest_ids
+template <class Src>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TRACS_TC_RW, TRACS_TC_RW))) void tc_ratio_keys_kernel(Src src, const unsigned *__restrict__ key_elem, const unsigned *__restrict__ long_ids,
+                                                           const unsigned *__restrict__ n_long, TcParams P, const double *__restrict__ lg,
+                                                           double *__restrict__ key_p0, double *__restrict__ key_eK,
+                                                           const double *__restrict__ key_state, KeyTable kt, const TcTables *__restrict__ tab,
+                                                           unsigned *__restrict__ rest_ids, unsigned *__restrict__ n_rest)
+{
+    P.ln_lamb = log(P.lamb); P.ln_beta = log(P.beta); P.ln_lb = log(P.lamb + P.beta);
+    const unsigned nl = *n_long;
+    for (unsigned w = blockIdx.x; w < nl; w += gridDim.x) {
+        const unsigned id = long_ids[w];
+        int N; double d;
+        const size_t elem = (size_t)key_elem[id];
+        src.get(elem, N, d);
+        const long long gap = src.day_gap(elem);
+        const double *st = key_state + 4 * (size_t)id;
+        const bool fresh = st[0] != st[0];
+        double eK = 0.0, p0 = 0.0;
+        const bool took = fresh && tc_eval_ratio(N, d, gap, P, lg, tab, eK, p0);          // (wave-uniform)
+        if ((threadIdx.x & 63) != 0) continue;
+        if (!took) { rest_ids[atomicAdd(n_rest, 1u)] = id; continue; }
+        key_eK[id] = eK; key_p0[id] = p0;
+        if (kt.p0) {
+            const long long slot = kt.index(N, gap);
+            if (slot >= 0) { kt.eK[slot * kt.step] = eK; kt.p0[slot * kt.step] = p0; }
         }
     }
 }
@@ -689,7 +855,10 @@ __device__ __forceinline__ void tc_for_row_quads(const DenseSource &src, F f)
         RowQuad c;
         c.i = i; c.j0 = q * 4;
         if (wide && c.j0 + 3 < src.n) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(row + c.j0);
+            // (the distances stream by once: non-temporal, so that they do not push the key tables / the key bitmap -- read at random by
+            // every cell -- out of L2)
+            typedef unsigned tc_u32x4 __attribute__((ext_vector_type(4)));
+            const tc_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const tc_u32x4 *>(row + c.j0));
             const int4 t = *reinterpret_cast<const int4 *>(src.days + c.j0);
             c.d[0] = v.x; c.d[1] = v.y; c.d[2] = v.z; c.d[3] = v.w;
             c.day[0] = t.x; c.day[1] = t.y; c.day[2] = t.z; c.day[3] = t.w;
@@ -709,45 +878,53 @@ static dim3 tc_row_grid(const DenseSource &src)
     return dim3((unsigned)rows, (unsigned)std::min<size_t>(4, std::max<size_t>(1, (quads + TC_ROW_THREADS - 1) / TC_ROW_THREADS)));
 }
 
-// cb[0] = largest distance of a valid cell, cb[1] = smallest day + 2^31, cb[2] = largest day + 2^31 (over all samples)
-__global__ __launch_bounds__(TC_ROW_THREADS) void tc_cell_bounds_kernel(DenseSource src, unsigned *__restrict__ cb)
+// cb[1] = smallest day + 2^31, cb[2] = largest day + 2^31 (over all samples): one workgroup
+__global__ __launch_bounds__(1024) void tc_day_bounds_kernel(const int *__restrict__ days, size_t n, unsigned *__restrict__ cb)
 {
-    unsigned mn = 0;
-    tc_for_row_quads(src, [&](const RowQuad &c) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) if (c.ok[k]) mn = max(mn, c.d[k]);
-    });
     unsigned lo = 0xFFFFFFFFu, hi = 0u;
-    const bool first = blockIdx.x == 0 && blockIdx.y == 0;
-    if (first)
-        for (size_t s = threadIdx.x; s < src.n; s += blockDim.x) { const unsigned v = (unsigned)src.days[s] + 0x80000000u; lo = min(lo, v); hi = max(hi, v); }
-    for (int off = 32; off > 0; off >>= 1) {
-        mn = max(mn, (unsigned)__shfl_xor((int)mn, off, 64));
-        lo = min(lo, (unsigned)__shfl_xor((int)lo, off, 64)); hi = max(hi, (unsigned)__shfl_xor((int)hi, off, 64));
-    }
-    // (one address for every workgroup of the grid: an atomic only from a wave that would raise what is there)
-    if ((threadIdx.x & 63) == 0) {
-        if (mn > __hip_atomic_load(&cb[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&cb[0], mn);
-        if (first) { atomicMin(&cb[1], lo); atomicMax(&cb[2], hi); }
-    }
+    for (size_t s = threadIdx.x; s < n; s += blockDim.x) { const unsigned v = (unsigned)days[s] + 0x80000000u; lo = min(lo, v); hi = max(hi, v); }
+    for (int off = 32; off > 0; off >>= 1) { lo = min(lo, (unsigned)__shfl_xor((int)lo, off, 64)); hi = max(hi, (unsigned)__shfl_xor((int)hi, off, 64)); }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&cb[1], lo); atomicMax(&cb[2], hi); }
 }
 
-// cb[3] = 1 when the grid does not fit; otherwise bit N * stride + gap of every valid cell's key
+// One pass over the cells: cb[0] = largest distance of a valid cell, and bit N * stride + gap of every valid cell's key (stride = the
+// span of the days + 1, known before the pass: tc_day_bounds_kernel); cb[3] = 1 when a key falls outside the grid's TC_GRID_BITS bits --
+// then the marks are incomplete and the caller takes the hash route.  (Round 4 swept the cells twice: the bounds first.)
 __global__ __launch_bounds__(TC_ROW_THREADS) void tc_mark_kernel(DenseSource src, unsigned *__restrict__ cb, unsigned *__restrict__ bits)
 {
+    if (cb[2] < cb[1]) { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) cb[3] = 1u; return; }
     const unsigned long long stride = (unsigned long long)(cb[2] - cb[1]) + 1ull;
-    if (((unsigned long long)cb[0] + 1ull) * stride > TC_GRID_BITS || cb[2] < cb[1]) { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) cb[3] = 1u; return; }
     const int di = src.days[src.row_of(blockIdx.x)];
+    unsigned mn = 0;
+    bool beyond = false;
     tc_for_row_quads(src, [&](const RowQuad &c) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             if (!c.ok[k]) continue;
+            mn = max(mn, c.d[k]);
             const long long g = (long long)di - (long long)c.day[k];
-            const unsigned idx = (unsigned)((unsigned long long)c.d[k] * stride + (unsigned long long)(g < 0 ? -g : g));
+            const unsigned long long key = (unsigned long long)c.d[k] * stride + (unsigned long long)(g < 0 ? -g : g);
+            if (key >= TC_GRID_BITS) { beyond = true; continue; }
+            const unsigned idx = (unsigned)key;
             const unsigned bit = 1u << (idx & 31u);
             if (!(bits[idx >> 5] & bit)) atomicOr(&bits[idx >> 5], bit);
         }
     });
+    for (int off = 32; off > 0; off >>= 1) mn = max(mn, (unsigned)__shfl_xor((int)mn, off, 64));
+    // (one address for every workgroup of the grid: an atomic only from a wave that would raise what is there)
+    if ((threadIdx.x & 63) == 0 && mn > __hip_atomic_load(&cb[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&cb[0], mn);
+    if (__ballot(beyond) && (threadIdx.x & 63) == 0) cb[3] = 1u;
+}
+
+// the keys' log probabilities in a (p0, eK) pair table -> probabilities, once per KEY (the gather then copies: an exponential per cell
+// was 50 M of them at 10 000 samples)
+__global__ void tc_exp_keys_kernel(const unsigned *__restrict__ key_elem, const unsigned *__restrict__ n_keys, double *__restrict__ tables)
+{
+    const unsigned nk = *n_keys;
+    for (unsigned id = blockIdx.x * blockDim.x + threadIdx.x; id < nk; id += gridDim.x * blockDim.x) {
+        double *p = tables + 2 * (size_t)key_elem[id];
+        *p = exp(*p);
+    }
 }
 
 __global__ void tc_bits_count_kernel(const unsigned *__restrict__ bits, unsigned words, unsigned *__restrict__ n_keys)
@@ -799,8 +976,11 @@ __global__ __launch_bounds__(TC_ROW_THREADS) void tc_table_gather2_kernel(DenseS
 #pragma unroll
         for (int h = 0; h < 4; h += 2) {
             if (wide_out && ok[h] && ok[h + 1]) {
-                *reinterpret_cast<double2 *>(p0 + o + h) = make_double2(vp[h], vp[h + 1]);
-                *reinterpret_cast<double2 *>(eK + o + h) = make_double2(ve[h], ve[h + 1]);
+                typedef double tc_f64x2 __attribute__((ext_vector_type(2)));
+                tc_f64x2 a, b;
+                a.x = vp[h]; a.y = vp[h + 1]; b.x = ve[h]; b.y = ve[h + 1];
+                __builtin_nontemporal_store(a, reinterpret_cast<tc_f64x2 *>(p0 + o + h));
+                __builtin_nontemporal_store(b, reinterpret_cast<tc_f64x2 *>(eK + o + h));
             } else {
                 if (ok[h]) { p0[o + h] = vp[h]; eK[o + h] = ve[h]; }
                 if (ok[h + 1]) { p0[o + h + 1] = vp[h + 1]; eK[o + h + 1] = ve[h + 1]; }
@@ -855,8 +1035,8 @@ static int get_lgamma_table(hipStream_t stream, const double **out)
     if (dev < 0 || dev >= 64) { set_error("device index out of range"); return TRACS_E_HIP; }
     if (!g_lg[dev]) {
         double *p = nullptr;
-        TRACS_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p), (LG_TABLE + LK_TABLE) * sizeof(double)));
-        hipLaunchKernelGGL(lgamma_table_kernel, dim3((LG_TABLE + LK_TABLE + 255) / 256), dim3(256), 0, stream, p, LG_TABLE);
+        TRACS_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p), (LG_TABLE + 2 * LK_TABLE) * sizeof(double)));
+        hipLaunchKernelGGL(lgamma_table_kernel, dim3((LG_TABLE + 2 * LK_TABLE + 255) / 256), dim3(256), 0, stream, p, LG_TABLE);
         TRACS_HIP_CHECK(hipGetLastError());
         TRACS_HIP_CHECK(hipStreamSynchronize(stream));
         g_lg[dev] = p;
@@ -867,7 +1047,7 @@ static int get_lgamma_table(hipStream_t stream, const double **out)
 
 int get_lgamma_table_for_filter(hipStream_t stream, const double **out) { return get_lgamma_table(stream, out); }
 
-struct TcWorkspaceIds { enum { SLOTS = 0, ESLOT, SLOT_ID, NKEYS, KEY_ELEM, KEY_P0, KEY_EK, LONG_IDS, KEY_STATE, TAB, TAB_LNS, TAB_POIS, GRID_BITS, GRID_TABLES }; };
+struct TcWorkspaceIds { enum { SLOTS = 0, ESLOT, SLOT_ID, NKEYS, KEY_ELEM, KEY_P0, KEY_EK, LONG_IDS, KEY_STATE, TAB, TAB_LNS, TAB_POIS, GRID_BITS, GRID_TABLES, TAB_LNS_N, REST_IDS }; };
 constexpr unsigned long long TC_POIS_ELEMS = 16ull << 20;        // doubles in the pois table (128 MB)
 
 static unsigned long long g_last_keys = 0;        // distinct (N, delta) keys of the last entry-point call (bench.py reports it)
@@ -897,7 +1077,7 @@ static int tc_evaluate_keys(const Src &src, const unsigned *key_elem, unsigned n
                        long_ids, n_keys + 1, key_state, kt);
     // (gap, M) tables of the prefix sums, when the source has day gaps and the keys' bounds fit (decided on the device)
     TcTables *tab = nullptr;
-    double *tab_lnS = nullptr, *tab_pois = nullptr;
+    double *tab_lnS = nullptr, *tab_pois = nullptr, *tab_lnS_n = nullptr;
     if ((rc = workspace_get(TcWorkspaceIds::TAB, 256, reinterpret_cast<void **>(&tab)))) return rc;
     TRACS_HIP_CHECK(hipMemsetAsync(tab, 0, 256, stream));                 // ok = 0
     // The tables are an optional speed-up (ok = 0 is a working path): only worth their 512 MB of workspace when there are enough
@@ -906,17 +1086,27 @@ static int tc_evaluate_keys(const Src &src, const unsigned *key_elem, unsigned n
         const bool have = workspace_get(TcWorkspaceIds::TAB_LNS, TC_TABLE_ELEMS * 8, reinterpret_cast<void **>(&tab_lnS)) == TRACS_OK &&
                           workspace_get(TcWorkspaceIds::TAB_POIS, TC_POIS_ELEMS * 8, reinterpret_cast<void **>(&tab_pois)) == TRACS_OK;
         if (have) {
+            // (the linear form needs ln S_N beside it; without that workspace the tables stay in log space)
+            if (workspace_get(TcWorkspaceIds::TAB_LNS_N, TC_POIS_ELEMS * 8, reinterpret_cast<void **>(&tab_lnS_n)) != TRACS_OK) {
+                (void)hipGetLastError(); set_error(""); tab_lnS_n = nullptr;
+            }
             unsigned *bounds = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(tab) + 128);
             hipLaunchKernelGGL((tc_key_bounds_kernel<Src>), dim3(256), dim3(256), 0, stream, src, key_elem, n_keys, bounds);
-            hipLaunchKernelGGL(tc_tables_kernel, dim3(1024), dim3(64), 0, stream, tab, bounds, n_keys, tab_lnS, tab_pois, TC_POIS_ELEMS, P, lg);
+            hipLaunchKernelGGL(tc_tables_kernel, dim3(1024), dim3(64), 0, stream, tab, bounds, n_keys, tab_lnS, tab_pois, tab_lnS_n, TC_POIS_ELEMS, P, lg);
         } else {
             (void)hipGetLastError();
             set_error("");
         }
     }
-    // long series (E(K) loop beyond TC_SERIAL_CAP terms): one wave per key
+    // long series (E(K) loop beyond TC_SERIAL_CAP terms): one wave per key -- the term-ratio loop where the linear tables hold the key,
+    // the log-space loop for the rest (n_keys[3] of them, listed by the first kernel)
+    unsigned *rest_ids = nullptr;
+    if ((rc = workspace_get(TcWorkspaceIds::REST_IDS, (size_t)nk * 4, reinterpret_cast<void **>(&rest_ids)))) return rc;
+    TRACS_HIP_CHECK(hipMemsetAsync(n_keys + 3, 0, 4, stream));
+    hipLaunchKernelGGL((tc_ratio_keys_kernel<Src>), dim3(std::min<unsigned>(nk, 256u * 32u)), dim3(64), 0, stream, src, key_elem,
+                       long_ids, n_keys + 1, P, lg, key_p0, key_eK, key_state, kt, tab, rest_ids, n_keys + 3);
     hipLaunchKernelGGL((tc_long_keys_kernel<Src>), dim3(std::min<unsigned>(nk, 256u * 32u)), dim3(64), 0, stream, src, key_elem,
-                       long_ids, n_keys + 1, P, lg, key_p0, key_eK, key_state, kt, tab);
+                       rest_ids, n_keys + 3, P, lg, key_p0, key_eK, key_state, kt, tab);
     *key_p0_out = key_p0; *key_eK_out = key_eK;
     return TRACS_OK;
 }
@@ -998,7 +1188,7 @@ static int run_trans_dist_grid(const DenseSource &src, size_t total, double lamb
     TRACS_HIP_CHECK(hipMemcpyAsync(n_keys, init, 32, hipMemcpyHostToDevice, stream));
     TRACS_HIP_CHECK(hipMemsetAsync(bits, 0, (size_t)words * 4, stream));
     const dim3 row_grid = tc_row_grid(src);
-    hipLaunchKernelGGL(tc_cell_bounds_kernel, row_grid, dim3(TC_ROW_THREADS), 0, stream, src, cb);
+    hipLaunchKernelGGL(tc_day_bounds_kernel, dim3(1), dim3(1024), 0, stream, src.days, src.n, cb);
     hipLaunchKernelGGL(tc_mark_kernel, row_grid, dim3(TC_ROW_THREADS), 0, stream, src, cb, bits);
     hipLaunchKernelGGL(tc_bits_count_kernel, dim3(1024), dim3(256), 0, stream, bits, words, n_keys);
     unsigned h[8] = {0};
@@ -1024,7 +1214,9 @@ static int run_trans_dist_grid(const DenseSource &src, size_t total, double lamb
     GridSource grid{d_max + 1u, cells};
     double *key_p0 = nullptr, *key_eK = nullptr;
     if ((rc = tc_evaluate_keys(grid, key_elem, nk, n_keys, lamb, beta, thr, lg, &key_p0, &key_eK, kt, stream))) return rc;
-    hipLaunchKernelGGL(tc_table_gather2_kernel, row_grid, dim3(TC_ROW_THREADS), 0, stream, src, kt, exp_p0, p0, eK);
+    // (GridSource: key_elem holds the keys' grid indices = their slots in `tables`; n_keys[0] = nk again after the collect)
+    if (exp_p0) hipLaunchKernelGGL(tc_exp_keys_kernel, dim3(256), dim3(256), 0, stream, key_elem, n_keys, tables);
+    hipLaunchKernelGGL(tc_table_gather2_kernel, row_grid, dim3(TC_ROW_THREADS), 0, stream, src, kt, 0, p0, eK);
     TRACS_HIP_CHECK(hipGetLastError());
     return TRACS_OK;
 }
