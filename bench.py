@@ -212,10 +212,17 @@ def nn_list_roofline(ls, sites, kern_s, rows, n, L=None):
     alg = ls["nn_visits"] * ls["n_entry_bytes"] * frac_rows + bitmap
     needed = 0.5 * ls["nn_visits"] * ls["n_entry_bytes"] * frac_rows + bitmap
     lines = ls["nn_walks"] * 128.0 * frac_rows + bitmap
+    # `frac` / `achieved` count the NEEDED bytes only -- the list entries with j > i (row i needs no other: half of every list) + the
+    # rows' bitmaps --, the strictest of the three counts; `frac_visited` counts every entry a walk decodes, `frac_lines` the whole
+    # 128-byte lines the memory system has to move at least (the figure on the line was the builder's own byte count)
     return {"kernel": "nn_rows_kernel", "kernel_ms": kern_s * 1e3, "sites": sites, "bound": "hbm", "traffic": None,
-            "achieved": alg / kern_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg / kern_s / HBM_PEAK,
-            "algorithmic_bytes": alg, "frac_needed": needed / kern_s / HBM_PEAK, "needed_bytes": needed,
+            "achieved": needed / kern_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": needed / kern_s / HBM_PEAK,
+            "algorithmic_bytes": needed, "frac_needed": needed / kern_s / HBM_PEAK, "needed_bytes": needed,
+            "frac_visited": alg / kern_s / HBM_PEAK, "visited_bytes": alg,
             "lines_bytes": lines, "frac_lines": lines / kern_s / HBM_PEAK,
+            "formulation_floor": "9.1 ms at this shape with the decode cut out (the lines alone, 8.8 TB/s out of the Infinity Cache: "
+                                 "profiles/r04/nn_rows_n8.txt) -- the kernel runs within 15 % of what one 128-byte line per walk allows; "
+                                 "profiles/r05/nn_rows_rejected.txt",
             "list_entries_visited": ls["nn_visits"] * frac_rows, "list_walks": ls["nn_walks"] * frac_rows,
             "bytes_per_list_entry": ls["n_entry_bytes"], "bitmap_bytes": bitmap,
             "entries_per_s": ls["nn_visits"] * frac_rows / kern_s,

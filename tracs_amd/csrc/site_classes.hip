@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
         // list entries one pass of the N co-occurrence walk decodes (cN per walk, cN walks) and its walks; N-list walks of the
         // minority fix-up (one per listed sample of a site with an N sample)
         unsigned sv[6] = {minor ? (unsigned)k : 0u, lst ? n8_lines_max((unsigned)c, n) - 1u : 0u, nnl ? (unsigned)min(c * c, 33554431ull) : 0u, nnl ? (unsigned)c : 0u,
-                          (minor && c) ? (unsigned)k : 0u, 0u};
+                          (minor && c) ? (unsigned)k : 0u, minor ? n8_lines_max((unsigned)c, n) - 1u : 0u};
 #pragma unroll
         for (int m = 0; m < 6; m++) {
 #pragma unroll
@@ -326,7 +326,8 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
 // Exclusive prefix sums over the groups, one workgroup per array (1024 groups at a time):
 //   blocks 0..6  sizes of the mask slots M_DENSE .. M_UN (popcount of the mask) -> off32[b][g], totals[b]
 //   blocks 7..12 per-group sums: gP (p-list entries), gN (overflow lines of the N lists, upper bound), gQ (entries the N co-occurrence
-//                walk decodes), gR (its walks), gS (N-list walks of the minority fix-up), gI (unused) -> off64[b - 7][g], totals[b]
+//                walk decodes), gR (its walks), gS (N-list walks of the minority fix-up), gI (overflow lines of the minority sites' N lists
+//                alone) -> off64[b - 7][g], totals[b]
 __global__ __launch_bounds__(1024) void group_offsets_kernel(const uint4 *__restrict__ masks, const unsigned *__restrict__ gcounts, size_t groups,
                                                              unsigned *__restrict__ off32, unsigned long long *__restrict__ off64,
                                                              unsigned long long *__restrict__ totals)
@@ -617,13 +618,32 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     stage_mark("class sizes", stream);
     *partial = (int)(reinterpret_cast<const unsigned *>(&tot[15])[0] & 1u);
     const bool consensus = !*partial && !force_general;
-    const size_t L_dense = (size_t)tot[M_DENSE], L_count = (size_t)tot[M_COUNT], L_minor = (size_t)tot[M_MINOR], L_full = (size_t)tot[M_FULL];
-    const size_t L_nnl = (size_t)tot[M_NNL], L_lst = (size_t)tot[M_LST], L_un = (size_t)tot[M_UN];
-    const unsigned long long tot_p = tot[7], tot_o = tot[8], tot_nnl = tot[10];
+    const size_t L_dense = (size_t)tot[M_DENSE], L_minor = (size_t)tot[M_MINOR], L_full = (size_t)tot[M_FULL];
+    size_t L_count = (size_t)tot[M_COUNT], L_nnl = (size_t)tot[M_NNL], L_lst = (size_t)tot[M_LST], L_un = (size_t)tot[M_UN];
+    const unsigned long long tot_p = tot[7];
+    unsigned long long tot_o = tot[8], tot_nnl = tot[10];
+    int lst_slot = M_LST, ovf_slot = 1;                      // which mask / per-group overflow bound the lists are built from
     if (force == 0 || a->L == 0 || a->n < 2) return TRACS_OK;
+    // The counting pass reads the stored N plane IN PLACE -- every site, nothing re-packed, nothing from N co-occurrence lists: nn =
+    // L - c_i - c_j + NN over all sites and the pair kernels write d only -- when that is cheaper than re-packing the counted sites'
+    // N plane: counting the other sites too costs ~1.5e-13 ms per site and pair of samples on the matrix cores (75 ms for 5 Mbp x 10 000
+    // samples), the re-pack ~4e-10 ms per counted site and sample (compact_sites_kernel<2>: a bit gather).  Always the case when nearly
+    // every site is counted (10 % N); and for SMALL alignments (config 2: 1 000 samples -- 87 % of the sites counted, the re-pack 0.75 of
+    // the call's 2.4 ms), whose NNL sites then go to the matrix cores as well: the lists are built for the minority sites alone
+    // (TRACS_COUNT_IN_PLACE=0|1 forces the choice: diagnostics).
+    static const int force_in_place = [] { const char *e = std::getenv("TRACS_COUNT_IN_PLACE"); return e ? std::atoi(e) : -1; }();
+    const double t_extra = 1.5e-13 * (double)(a->L - L_count) * (double)a->n * (double)a->n;
+    const double t_repack = 4.0e-10 * (double)L_count * (double)a->n_pad;
+    const bool in_place = L_count > 0 && (force_in_place >= 0 ? force_in_place == 1 : t_extra < t_repack);
+    if (in_place && L_nnl) {
+        // the same classes with the NNL sites counted: lists = the minority sites (their masks, ranks and overflow bounds exist)
+        L_count += L_nnl; L_lst = L_minor; L_nnl = 0;
+        tot_o = tot[12]; tot_nnl = 0;
+        lst_slot = M_MINOR; ovf_slot = 5;
+    }
     // matrix instructions per pair: planes_full per site now; planes_full per dense site + one per counted site with classes
     const double planes_full = consensus ? 4.0 : 5.0;
-    const double cost = (planes_full * (double)L_dense + (double)L_count) / (planes_full * (double)a->L);
+    const double cost = (planes_full * (double)L_dense + (double)(in_place ? a->L : L_count)) / (planes_full * (double)a->L);
     if (force != 1 && cost >= 0.92) return TRACS_OK;
     // the lists must stay small beside the planes (<= one entry per 8 sites of the whole alignment; TRACS_LIST_CAP: diagnostics):
     // otherwise first without the N co-occurrence lists (those sites are counted on the matrix cores), then without any list
@@ -642,11 +662,6 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
 
     auto soft_fail = [&]() { (void)hipGetLastError(); site_classes_free(a); a->classes_state = -1; return TRACS_OK; };
     const int npv = consensus ? 3 : NPLANES;
-    // The counting pass reads the stored N plane in place when (nearly) every site needs the matrix cores anyway -- then it covers
-    // every site and nothing may come from lists (TRACS_COUNT_IN_PLACE=0|1 forces the choice when there are no NNL sites: diagnostics)
-    static const int force_in_place = [] { const char *e = std::getenv("TRACS_COUNT_IN_PLACE"); return e ? std::atoi(e) : -1; }();
-    const bool in_place = L_nnl == 0 && L_count > 0 &&
-                          (force_in_place >= 0 ? force_in_place == 1 : (double)(a->L - L_count) <= 0.02 * (double)a->L);
     const size_t gv = groups_for(L_dense), gi = in_place ? 0 : groups_for(L_count);
     const size_t vbytes = class_plane_bytes(a, gv, npv, PAD_GROUPS), ibytes = class_plane_bytes(a, gi, 1, PAD_GROUPS);
     unsigned *lists = nullptr;
@@ -692,9 +707,9 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
         // the lists (site_lists.hip): per-site lists from the N plane and the flagged samples, the rows' N bitmaps from the N plane
         int built = 0;
         MinorBuild mb;
-        mb.planes = a->planes; mb.minor_mask = mask_of(M_MINOR); mb.nnl_mask = mask_of(M_NNL); mb.lst_mask = mask_of(M_LST);
-        mb.ref_x = mask_of(M_REFX); mb.ref_y = mask_of(M_REFY); mb.un_mask = mask_of(M_UN); mb.off_lst = off_of(M_LST);
-        mb.cntP = cntP; mb.cntN = cntN; mb.baseP = off64; mb.baseO = off64 + groups; mb.flags = flags; mb.flag_words = flag_words;
+        mb.planes = a->planes; mb.minor_mask = mask_of(M_MINOR); mb.nnl_mask = mask_of(M_NNL); mb.lst_mask = mask_of(lst_slot);
+        mb.ref_x = mask_of(M_REFX); mb.ref_y = mask_of(M_REFY); mb.un_mask = mask_of(M_UN); mb.off_lst = off_of(lst_slot);
+        mb.cntP = cntP; mb.cntN = cntN; mb.baseP = off64; mb.baseO = off64 + (size_t)ovf_slot * groups; mb.flags = flags; mb.flag_words = flag_words;
         mb.sites = L_lst; mb.tot_p = tot_p; mb.tot_o = tot_o; mb.tot_nnl = tot_nnl;
         mb.n_rows = a->n_row_hint;
         for (int k = 0; k < 4; k++) mb.rows[k] = (unsigned)std::min<size_t>(a->row_hint[k], a->n);

@@ -215,7 +215,9 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
                 const unsigned ra = ~rx & ~ry, rc = rx & ~ry, rg = ~rx & ry, rt = rx & ry;
                 const unsigned has_ref = (a & ra) | (c & rc) | (gg & rg) | (t & rt);
                 const unsigned only_ref = ~((a ^ ra) | (c ^ rc) | (gg ^ rg) | (t ^ rt));
-                unsigned pm = ~isn & ~only_ref & mp[w];
+                // (the classification's predicate exactly -- `diff` = carries some allele bit, is not N, is not exactly the reference base:
+                // the p lists' sizes come from there; a sample whose four planes are all zero at a site is listed by neither)
+                unsigned pm = (a | c | gg | t) & ~isn & ~only_ref & mp[w];
                 while (pm) {
                     const int b = __ffs(pm) - 1;
                     pm &= pm - 1;
