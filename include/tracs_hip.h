@@ -173,6 +173,10 @@ int tracs_coo_count(const uint32_t *dist, size_t ld, size_t n, size_t row_begin,
 int tracs_coo_fill(const uint32_t *dist, const uint32_t *ncomp, size_t ld, size_t n, size_t row_begin,
                    size_t row_end, size_t col_begin, int32_t dist_threshold, const int64_t *offsets,
                    uint32_t *rows, uint32_t *cols, uint32_t *d, uint32_t *nn, void *stream);
+/* ... and two float64 panels of the same geometry (P(direct), E(K) as tracs_trans_dist_dense writes them) into the same positions */
+int tracs_coo_fill_f64(const uint32_t *dist, size_t ld, size_t n, size_t row_begin, size_t row_end, size_t col_begin,
+                       int32_t dist_threshold, const int64_t *offsets, const double *a, const double *b, double *out_a,
+                       double *out_b, void *stream);
 
 /* Threshold edges of a float64 panel (E(K) or P(direct) as written by tracs_trans_dist_dense; what `tracs cluster -D
  * expectedK|direct -c T` keeps, tracs/cluster.py:110-112): cells (i, j) of the same cell set whose SNP distance was emitted
@@ -294,6 +298,24 @@ int tracs_pileup_counts(const char *path, const char *const *contig_names, const
 /* posterior [L][K] f64 -> gzip CSV exactly as np.savetxt(fmt="%0.5f", delimiter=",") + the trailing "\n" the
  * reference appends (tracs/align.py:580-596).  gzip_level 0..9.                                                   */
 int tracs_write_posterior_csv(const char *path, const double *post, size_t L, size_t K, int gzip_level);
+
+/* `tracs distance` for one alignment (tracs/distance.py:159-258) with the results on the device until the CSV rows.
+ *   tracs_distance_open   read + pack the FASTA file(s) (1 file: all pairs; 2: file 0 x file 1, src/pairsnp.hpp:348-360); the names
+ *                         (tracs_distance_nseq / _name) are what the caller looks the sampling dates up by
+ *   tracs_distance_run    row panel by row panel: tracs_pairsnp_dense_thr, tracs_trans_dist_dense when `days` (host, one whole day
+ *                         number per sample: delta = |day_i - day_j| x 86400 / 31556952.0 years, tracs/transcluster.py:26-33) is
+ *                         given, COO extraction incl. P(direct) and E(K), one device-to-host pass in batches, rows formatted and
+ *                         appended to `path` (the caller has written the header) in the reference's format and order.  days == NULL:
+ *                         no metadata ("NA" for delta / P / E(K), 0 in the filtered column, :240-258); else "NA" in the filtered
+ *                         column (:204) and, k_max >= 0, only rows with k_max >= E(K) (:222).  The recombination filter (--filter)
+ *                         is not part of this path (tracs_pairsnp).                                                             */
+typedef struct tracs_distance tracs_distance;
+int tracs_distance_open(const char *const *fasta, int n_fasta, tracs_distance **out);
+size_t tracs_distance_nseq(const tracs_distance *h);
+const char *tracs_distance_name(const tracs_distance *h, size_t i);
+int tracs_distance_run(tracs_distance *h, int dist, const int32_t *days, double lamb, double beta, double precision, double k_max,
+                       const char *path, const char *ref, uint64_t *rows_written, uint64_t *n_pairs);
+void tracs_distance_free(tracs_distance *h);
 
 /* Rows of `tracs distance`'s CSV appended to path (tracs/distance.py:206-258; the caller writes the header, :157):
  *   names[rows[t]],names[cols[t]],str(delta),str(int(snpd)),str(P),str(E(K)),filtered,str(nn),ref

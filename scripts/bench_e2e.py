@@ -73,7 +73,7 @@ pairs = n * (n - 1) // 2
 fasta_bytes = os.path.getsize(fa)
 out = {"samples": n, "sites": L, "pairs": pairs, "snp_threshold": args.thr, "fasta_GB": fasta_bytes / 1e9, "csv_GB": os.path.getsize(csv) / 1e9,
        "csv_rows": rows, "command_seconds": wall, "command_seconds_first_run_on_the_box": wall_first, "pairs_per_s_end_to_end": pairs / wall, "stages": stages,
-       "accounted_seconds": sum(s["seconds"] for s in stages if not s["stage"].startswith("pairsnp (total")),
+       "accounted_seconds": sum(s["seconds"] for s in stages if not s["stage"].startswith(("pairsnp (total", "[sum]"))),
        "fasta_write_seconds_setup": t_write,
        "note": "stage lines: library (tracs_pairsnp: read, allocate, pack, panels, COO, D2H) then driver (pairsnp total, transcluster, CSV); "
                "the rest of command_seconds is interpreter + torch-free library start-up and reading the dates"}

@@ -196,8 +196,15 @@ def test_pairsnp_fixture(api, golden_dir, tmp_path):
         assert out[0] == c["rows"] and out[1] == c["cols"] and out[2] == c["d"] and out[5] == c["nn"], name
 
 
-def test_cli_end_to_end_vs_reference_driver(api, golden_dir, tmp_path, monkeypatch):
-    """`tracs distance` + `tracs cluster` on the GPU against the CSVs the reference's own drivers wrote."""
+@pytest.mark.parametrize("path", ["device", "arrays"])
+def test_cli_end_to_end_vs_reference_driver(api, golden_dir, tmp_path, monkeypatch, path):
+    """`tracs distance` + `tracs cluster` on the GPU against the CSVs the reference's own drivers wrote -- through the device-resident
+    path of the single-GPU command (tracs_distance_open / _run: results on the device until the CSV rows; the --filter runs take the
+    array path either way) and through the array path (TRACS.pairsnp-shaped arrays -> calculate_trans_prob -> rows)."""
+    if path == "arrays":
+        monkeypatch.setenv("TRACS_DISTANCE_ARRAYS", "1")
+    else:
+        monkeypatch.delenv("TRACS_DISTANCE_ARRAYS", raising=False)
     from test_host_logic import _materialise, _rows_equal
     from tracs_amd import cluster, distance
     pyref = _load(golden_dir, "python_reference_golden.json")

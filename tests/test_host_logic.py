@@ -27,6 +27,9 @@ def oracle_kernels(monkeypatch, oracle):
         r, c, d, names, f, nn = oracle.pairsnp(fasta, n_threads, dist, filter)
         u = lambda x: np.asarray(x, dtype=np.uint64)
         return u(r), u(c), u(d), names, u(f), u(nn)
+    # (the single-GPU command keeps its results on the device until the CSV rows -- tracs_distance_run, GPU tests; here the array
+    # path, which --filter, --gpus N and incomplete metadata take, runs with the oracle behind its three kernel calls)
+    monkeypatch.setenv("TRACS_DISTANCE_ARRAYS", "1")
     monkeypatch.setattr(di, "pairsnp_arrays", pairsnp_arrays)
     monkeypatch.setattr(tc, "trans_dist_arrays", oracle.trans_dist)
     monkeypatch.setattr(cl, "connected_components",

@@ -34,6 +34,7 @@ SYMBOLS = [
     "tracs_comm_unique_id", "tracs_comm_create", "tracs_comm_free", "tracs_comm_rank", "tracs_comm_world", "tracs_bcast",
     "tracs_bcast_planes", "tracs_allgather_panels", "tracs_allreduce", "tracs_reduce_scatter", "tracs_send", "tracs_recv",
     "tracs_alltoall", "tracs_tri_pack", "tracs_tri_sum", "tracs_rccl_version",
+    "tracs_coo_fill_f64", "tracs_distance_open", "tracs_distance_nseq", "tracs_distance_name", "tracs_distance_run", "tracs_distance_free",
 ]
 
 
@@ -128,6 +129,18 @@ def load():
     L.tracs_coo_count.argtypes = [vp, sz, sz, sz, sz, sz, i32, vp, vp]
     L.tracs_coo_fill.restype = C.c_int
     L.tracs_coo_fill.argtypes = [vp, vp, sz, sz, sz, sz, sz, i32, vp, vp, vp, vp, vp, vp]
+    L.tracs_coo_fill_f64.restype = C.c_int
+    L.tracs_coo_fill_f64.argtypes = [vp, sz, sz, sz, sz, sz, i32, vp, vp, vp, vp, vp, vp]
+    L.tracs_distance_open.restype = C.c_int
+    L.tracs_distance_open.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.POINTER(vp)]
+    L.tracs_distance_nseq.restype = sz
+    L.tracs_distance_nseq.argtypes = [vp]
+    L.tracs_distance_name.restype = C.c_char_p
+    L.tracs_distance_name.argtypes = [vp, sz]
+    L.tracs_distance_run.restype = C.c_int
+    L.tracs_distance_run.argtypes = [vp, C.c_int, C.POINTER(C.c_int32), dbl, dbl, dbl, dbl, C.c_char_p, C.c_char_p, u64p, u64p]
+    L.tracs_distance_free.restype = None
+    L.tracs_distance_free.argtypes = [vp]
     L.tracs_edges_count_f64.restype = C.c_int
     L.tracs_edges_count_f64.argtypes = [vp, vp, sz, sz, sz, sz, sz, C.c_int32, dbl, vp, vp]
     L.tracs_edges_fill_f64.restype = C.c_int

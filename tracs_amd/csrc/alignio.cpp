@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "fasta.h"
+#include "rowwriter.h"
 
 namespace tracs {
 void set_error(const std::string &msg);
@@ -335,6 +336,138 @@ struct FloatMemo {
 // off, :204), otherwise the integers.  k_max < 0 means no -K filter; else only rows with k_max >= E(K) are written (:222).
 // Rows are formatted by all cores into raw buffers (names copied, floats through the memo) and the buffers of a batch are written
 // in parallel at their offsets (pwrite): the 5 GB of a 10 000-sample run neither queue behind one formatter nor behind one writer.
+// One writer serves a whole run: the file stays open and the memo of formatted floats lives across its batches
+// (tracs_distance_run hands the rows over a few million at a time, as they arrive from the device).
+}  // extern "C"
+
+namespace tracs {
+
+struct DistanceRowWriter::Impl {
+    int fd = -1;
+    off_t file_off = 0;
+    std::string path, ref;
+    const char *const *names = nullptr;
+    std::vector<uint32_t> name_len;
+    size_t longest = 0;
+    std::unique_ptr<FloatMemo> memo;
+    std::vector<std::vector<char>> buf;
+    uint64_t written = 0;
+};
+
+DistanceRowWriter::DistanceRowWriter() : p(new Impl()) {}
+DistanceRowWriter::~DistanceRowWriter() { if (p->fd >= 0) (void)::close(p->fd); delete p; }
+uint64_t DistanceRowWriter::written() const { return p->written; }
+
+int DistanceRowWriter::open(const char *path, const char *const *names, size_t n_names, const char *ref)
+{
+    p->fd = ::open(path, O_WRONLY | O_CREAT, 0644);
+    if (p->fd < 0) { set_error(std::string("cannot open '") + path + "' for writing"); return TRACS_E_OPEN; }
+    struct stat st;
+    if (fstat(p->fd, &st) != 0) { set_error(std::string("cannot stat '") + path + "'"); return TRACS_E_OPEN; }
+    p->file_off = st.st_size;                                 // append
+    p->path = path; p->ref = ref; p->names = names;
+    p->name_len.resize(n_names);
+    for (size_t k = 0; k < n_names; k++) { p->name_len[k] = (uint32_t)std::strlen(names[k]); p->longest = std::max<size_t>(p->longest, p->name_len[k]); }
+    return TRACS_OK;
+}
+
+int DistanceRowWriter::close()
+{
+    if (p->fd < 0) return TRACS_OK;
+    const int rc = ::close(p->fd);
+    p->fd = -1;
+    if (rc != 0) { set_error(std::string("error closing '") + p->path + "'"); return TRACS_E_OPEN; }
+    return TRACS_OK;
+}
+
+// T: the integer columns' type (uint64_t: the pybind-shaped arrays of TRACS.pairsnp; uint32_t: as they leave the device);
+// delta_of(r): the row's date difference in years
+template <class T, class DeltaOf>
+int DistanceRowWriter::append(const T *rows, const T *cols, const T *snpd, const T *filt, const T *ncomp, DeltaOf delta_of,
+                              const double *p_direct, const double *e_k, size_t n, int with_dates, double k_max)
+{
+    Impl &w = *p;
+    for (size_t r = 0; r < n; r++)
+        if ((size_t)rows[r] >= w.name_len.size() || (size_t)cols[r] >= w.name_len.size()) { set_error("distance rows: sample index beyond the names"); return TRACS_E_ARG; }
+    const size_t ref_len = w.ref.size();
+    const char *ref = w.ref.c_str();
+    const size_t row_cap = 2 * w.longest + ref_len + 3 * 32 + 3 * 20 + 16;      // two names, three floats, three integers, separators
+    const unsigned TH = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    const size_t chunk = std::max<size_t>(1024, std::min<size_t>(1u << 17, (n + TH - 1) / TH));
+    if (with_dates && !w.memo) w.memo.reset(new FloatMemo(n >= (1u << 20) ? 21 : 16));
+    FloatMemo *memo = w.memo.get();
+    if (w.buf.size() < TH) w.buf.resize(TH);
+    std::vector<size_t> used(TH, 0);
+    std::vector<uint64_t> cnt(TH, 0);
+    int rc = TRACS_OK;
+    for (size_t base = 0; base < n && rc == TRACS_OK; base += chunk * TH) {
+        {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < TH; t++)
+                th.emplace_back([&, t]() {
+                    const size_t r0 = std::min(n, base + (size_t)t * chunk), r1 = std::min(n, r0 + chunk);
+                    if (w.buf[t].size() < (r1 - r0) * row_cap + 64) w.buf[t].resize((r1 - r0) * row_cap + 64);
+                    char *o = w.buf[t].data();
+                    uint64_t c = 0;
+                    for (size_t r = r0; r < r1; r++) {
+                        if (with_dates && k_max >= 0.0 && !(k_max >= e_k[r])) continue;
+                        std::memcpy(o, w.names[rows[r]], w.name_len[rows[r]]); o += w.name_len[rows[r]]; *o++ = ',';
+                        std::memcpy(o, w.names[cols[r]], w.name_len[cols[r]]); o += w.name_len[cols[r]]; *o++ = ',';
+                        if (with_dates) o += memo->put(delta_of(r), o); else { *o++ = 'N'; *o++ = 'A'; }
+                        *o++ = ',';
+                        o += format_u64((uint64_t)snpd[r], o); *o++ = ',';
+                        if (with_dates) o += memo->put(p_direct[r], o); else { *o++ = 'N'; *o++ = 'A'; }
+                        *o++ = ',';
+                        if (with_dates) o += memo->put(e_k[r], o); else { *o++ = 'N'; *o++ = 'A'; }
+                        *o++ = ',';
+                        if (filt) o += format_u64((uint64_t)filt[r], o); else { *o++ = 'N'; *o++ = 'A'; }
+                        *o++ = ',';
+                        o += format_u64((uint64_t)ncomp[r], o); *o++ = ',';
+                        std::memcpy(o, ref, ref_len); o += ref_len;
+                        *o++ = '\n';
+                        c++;
+                    }
+                    used[t] = (size_t)(o - w.buf[t].data());
+                    cnt[t] = c;
+                });
+            for (auto &x : th) x.join();
+        }
+        std::vector<off_t> at(TH);
+        for (unsigned t = 0; t < TH; t++) { at[t] = w.file_off; w.file_off += (off_t)used[t]; w.written += cnt[t]; }
+        std::atomic<int> bad{0};
+        {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < TH; t++)
+                th.emplace_back([&, t]() {
+                    size_t done = 0;
+                    while (done < used[t]) {
+                        const ssize_t wr = pwrite(w.fd, w.buf[t].data() + done, used[t] - done, at[t] + (off_t)done);
+                        if (wr <= 0) { bad.store(1); return; }
+                        done += (size_t)wr;
+                    }
+                });
+            for (auto &x : th) x.join();
+        }
+        if (bad.load()) { set_error(std::string("error writing '") + w.path + "'"); rc = TRACS_E_OPEN; }
+    }
+    return rc;
+}
+
+int DistanceRowWriter::append_u32(const uint32_t *rows, const uint32_t *cols, const uint32_t *snpd, const uint32_t *filt, const uint32_t *ncomp,
+                                  const int32_t *days, const double *p_direct, const double *e_k, size_t n, int with_dates, double k_max)
+{
+    // tracs/transcluster.py:26-33: |t_i - t_j| / 31556952.0 with t = whole days in seconds (exact in f64): DenseSource::get's expression
+    auto delta_of = [=](size_t r) {
+        const long long dd = (long long)days[rows[r]] - (long long)days[cols[r]];
+        return (double)((dd < 0 ? -dd : dd) * 86400ll) / 31556952.0;
+    };
+    return append<uint32_t>(rows, cols, snpd, filt, ncomp, delta_of, p_direct, e_k, n, with_dates, k_max);
+}
+
+}  // namespace tracs
+
+extern "C" {
+
 int tracs_write_distance_rows(const char *path, const char *const *names, const uint64_t *rows, const uint64_t *cols,
                               const uint64_t *snpd, const uint64_t *filt, const uint64_t *ncomp, const double *delta,
                               const double *p_direct, const double *e_k, size_t n, int with_dates, double k_max,
@@ -344,79 +477,14 @@ int tracs_write_distance_rows(const char *path, const char *const *names, const 
         set_error("tracs_write_distance_rows: NULL argument");
         return TRACS_E_ARG;
     }
-    const int fd = open(path, O_WRONLY | O_CREAT, 0644);
-    if (fd < 0) { set_error(std::string("cannot open '") + path + "' for writing"); return TRACS_E_OPEN; }
-    struct stat st;
-    if (fstat(fd, &st) != 0) { close(fd); set_error(std::string("cannot stat '") + path + "'"); return TRACS_E_OPEN; }
-    off_t file_off = st.st_size;                              // append
-    const size_t ref_len = std::strlen(ref);
     size_t max_row = 0;
     for (size_t r = 0; r < n; r++) max_row = std::max<size_t>(max_row, std::max(rows[r], cols[r]));
-    std::vector<uint32_t> name_len(n ? max_row + 1 : 0);
-    size_t longest = 0;
-    for (size_t k = 0; k < name_len.size(); k++) { name_len[k] = (uint32_t)std::strlen(names[k]); longest = std::max<size_t>(longest, name_len[k]); }
-    const size_t row_cap = 2 * longest + ref_len + 3 * 32 + 3 * 20 + 16;      // two names, three floats, three integers, separators
-    const unsigned T = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
-    const size_t chunk = std::max<size_t>(1024, std::min<size_t>(1u << 17, (n + T - 1) / T));
-    std::unique_ptr<FloatMemo> memo(with_dates ? new FloatMemo(n >= (1u << 20) ? 21 : 16) : nullptr);
-    std::vector<std::vector<char>> buf(T);
-    std::vector<size_t> used(T, 0);
-    std::vector<uint64_t> cnt(T, 0);
-    uint64_t written = 0;
-    int rc = TRACS_OK;
-    for (size_t base = 0; base < n && rc == TRACS_OK; base += chunk * T) {
-        {
-            std::vector<std::thread> th;
-            for (unsigned t = 0; t < T; t++)
-                th.emplace_back([&, t]() {
-                    const size_t r0 = std::min(n, base + (size_t)t * chunk), r1 = std::min(n, r0 + chunk);
-                    if (buf[t].size() < (r1 - r0) * row_cap + 64) buf[t].resize((r1 - r0) * row_cap + 64);
-                    char *o = buf[t].data();
-                    uint64_t c = 0;
-                    for (size_t r = r0; r < r1; r++) {
-                        if (with_dates && k_max >= 0.0 && !(k_max >= e_k[r])) continue;
-                        std::memcpy(o, names[rows[r]], name_len[rows[r]]); o += name_len[rows[r]]; *o++ = ',';
-                        std::memcpy(o, names[cols[r]], name_len[cols[r]]); o += name_len[cols[r]]; *o++ = ',';
-                        if (with_dates) o += memo->put(delta[r], o); else { *o++ = 'N'; *o++ = 'A'; }
-                        *o++ = ',';
-                        o += format_u64(snpd[r], o); *o++ = ',';
-                        if (with_dates) o += memo->put(p_direct[r], o); else { *o++ = 'N'; *o++ = 'A'; }
-                        *o++ = ',';
-                        if (with_dates) o += memo->put(e_k[r], o); else { *o++ = 'N'; *o++ = 'A'; }
-                        *o++ = ',';
-                        if (filt) o += format_u64(filt[r], o); else { *o++ = 'N'; *o++ = 'A'; }
-                        *o++ = ',';
-                        o += format_u64(ncomp[r], o); *o++ = ',';
-                        std::memcpy(o, ref, ref_len); o += ref_len;
-                        *o++ = '\n';
-                        c++;
-                    }
-                    used[t] = (size_t)(o - buf[t].data());
-                    cnt[t] = c;
-                });
-            for (auto &x : th) x.join();
-        }
-        std::vector<off_t> at(T);
-        for (unsigned t = 0; t < T; t++) { at[t] = file_off; file_off += (off_t)used[t]; written += cnt[t]; }
-        std::atomic<int> bad{0};
-        {
-            std::vector<std::thread> th;
-            for (unsigned t = 0; t < T; t++)
-                th.emplace_back([&, t]() {
-                    size_t done = 0;
-                    while (done < used[t]) {
-                        const ssize_t w = pwrite(fd, buf[t].data() + done, used[t] - done, at[t] + (off_t)done);
-                        if (w <= 0) { bad.store(1); return; }
-                        done += (size_t)w;
-                    }
-                });
-            for (auto &x : th) x.join();
-        }
-        if (bad.load()) { set_error(std::string("error writing '") + path + "'"); rc = TRACS_E_OPEN; }
-    }
-    if (close(fd) != 0 && rc == TRACS_OK) { set_error(std::string("error closing '") + path + "'"); rc = TRACS_E_OPEN; }
-    if (rows_written) *rows_written = written;
-    return rc;
+    tracs::DistanceRowWriter w;
+    int rc = w.open(path, names, n ? max_row + 1 : 0, ref);
+    if (rc == TRACS_OK) rc = w.append<uint64_t>(rows, cols, snpd, filt, ncomp, [=](size_t r) { return delta[r]; }, p_direct, e_k, n, with_dates, k_max);
+    const int rc2 = w.close();
+    if (rows_written) *rows_written = w.written();
+    return rc ? rc : rc2;
 }
 
 // test hook: str(float) of n doubles, '\n'-separated, into buf (cap bytes); returns the bytes used or -1

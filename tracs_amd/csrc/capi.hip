@@ -5,6 +5,7 @@
 // The arithmetic is in pairsnp.hip.
 #include "common.h"
 #include "fasta.h"
+#include "rowwriter.h"
 
 #include <algorithm>
 #include <chrono>
@@ -177,6 +178,9 @@ int tracs_alignment_from_fasta(const char *const *fasta, int n_fasta, tracs_alig
     FastaData fd;
     size_t n0 = 0;
     StageClock clock;
+    // the HIP runtime comes up (first call of the process: ~0.3-0.5 s) while the host threads read the text
+    std::thread warm([]() { int nd = 0; (void)hipGetDeviceCount(&nd); if (nd > 0) (void)hipFree(nullptr); });
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } join_warm{warm};
     for (int f = 0; f < n_fasta; f++) {
         std::string err;
         FastaData one;
@@ -193,6 +197,7 @@ int tracs_alignment_from_fasta(const char *const *fasta, int n_fasta, tracs_alig
             fd.n += one.n;
         }
     }
+    if (warm.joinable()) warm.join();
     clock.mark("read FASTA (host)", (double)fd.n * (double)fd.L);
     tracs_alignment *a = nullptr;
     int rc = tracs_alignment_create(fd.n, fd.L, &a);
@@ -217,6 +222,12 @@ int tracs_alignment_from_fasta(const char *const *fasta, int n_fasta, tracs_alig
     }
     if (n_first_file) *n_first_file = n0;
     *out = a;
+    // the host copy of the text (n L bytes: 5 GB at 10 000 x 500 kbp) goes back to the system on a thread of its own: unmapping a few
+    // million touched pages takes a few tenths of a second that the dense panels and the rows do not have to wait for
+    if (fd.seq.size() >= ((size_t)64 << 20)) {
+        auto *gone = new ByteVec(std::move(fd.seq));
+        std::thread([gone]() { delete gone; }).detach();
+    }
     return TRACS_OK;
 }
 
@@ -362,6 +373,182 @@ int tracs_pairsnp(const char *const *fasta, int n_fasta, int n_threads, int dist
     cleanup();
     *out = res;
     return TRACS_OK;
+}
+
+// ---- `tracs distance` for one alignment, results on the device until the CSV rows (tracs/distance.py:159-258) --------------------------
+// open: read + pack the FASTA(s) (the names are what the caller needs to look the sampling dates up); run: row panel by row panel --
+// dense call (d, compared sites; early out beyond the threshold), transcluster on the panel (P(direct), E(K): src/transcluster.hpp:
+// 240-287 through the dense route, delta from the day numbers), the pairs within the threshold extracted in row-major order
+// (src/pairsnp.hpp:451-455) with their P and E(K) -- then ONE device-to-host pass, a few million rows at a time, each batch formatted
+// and written by the host threads while the next one arrives.  Nothing widens to uint64, nothing goes back to the device.
+struct tracs_distance {
+    tracs_alignment *a = nullptr;
+    std::vector<std::string> names;
+    std::vector<const char *> name_ptr;
+    size_t n0 = 0;
+    int n_fasta = 0;
+};
+
+int tracs_distance_open(const char *const *fasta, int n_fasta, tracs_distance **out)
+{
+    if (!out) { set_error("tracs_distance_open: out is NULL"); return TRACS_E_ARG; }
+    *out = nullptr;
+    if (n_fasta < 1 || n_fasta > 2 || !fasta) { set_error("Invalid number of fasta files!"); return TRACS_E_ARG; }   // :340-343
+    auto *h = new tracs_distance();
+    char *names = nullptr;
+    size_t names_bytes = 0;
+    const int rc = tracs_alignment_from_fasta(fasta, n_fasta, &h->a, &names, &names_bytes, &h->n0);
+    if (rc) { delete h; return rc; }
+    h->n_fasta = n_fasta;
+    { size_t o = 0; for (size_t i = 0; i < h->a->n; i++) { h->names.emplace_back(names + o); o += h->names.back().size() + 1; } }
+    tracs_free(names);
+    for (auto &s : h->names) h->name_ptr.push_back(s.c_str());
+    *out = h;
+    return TRACS_OK;
+}
+
+size_t tracs_distance_nseq(const tracs_distance *h) { return h ? h->names.size() : 0; }
+const char *tracs_distance_name(const tracs_distance *h, size_t i) { return (h && i < h->names.size()) ? h->names[i].c_str() : nullptr; }
+void tracs_distance_free(tracs_distance *h) { if (h) { if (h->a) tracs_alignment_free(h->a); delete h; } }
+
+int tracs_distance_run(tracs_distance *h, int dist, const int32_t *days, double lamb, double beta, double precision, double k_max,
+                       const char *path, const char *ref, uint64_t *rows_written, uint64_t *n_pairs)
+{
+    if (rows_written) *rows_written = 0;
+    if (n_pairs) *n_pairs = 0;
+    if (!h || !h->a || !path || !ref) { set_error("tracs_distance_run: NULL argument"); return TRACS_E_ARG; }
+    SigintScope sigint;
+    tracs_alignment *a = h->a;
+    const size_t n = a->n;
+    const size_t i_end = h->n_fasta == 1 ? n : h->n0;               // pair ranges (:348-360)
+    const size_t j_start = h->n_fasta == 1 ? 0 : h->n0;
+    const bool with_dates = days != nullptr;
+    constexpr size_t CH = (size_t)1 << 22;                          // rows per device-to-host batch
+    unsigned *d_dist = nullptr, *d_nn = nullptr, *d_coo = nullptr;
+    double *d_p = nullptr, *d_e = nullptr, *d_cp = nullptr;
+    int *d_days = nullptr;
+    long long *d_off = nullptr;
+    char *pin[2] = {nullptr, nullptr};
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr}, ready = nullptr;
+    tracs::DistanceRowWriter writer;
+    auto cleanup = [&]() {
+        void *p[] = {d_dist, d_nn, d_coo, d_p, d_e, d_cp, d_days, d_off};
+        for (void *q : p) if (q) (void)hipFree(q);
+        for (char *q : pin) if (q) (void)hipHostFree(q);
+        for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+        if (ready) (void)hipEventDestroy(ready);
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    };
+#define DR_CHECK(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { cleanup(); set_error(std::string(#x ": ") + hipGetErrorString(e__)); return TRACS_E_HIP; } } while (0)
+#define DR_RC(x) do { int r__ = (x); if (r__) { cleanup(); return r__; } } while (0)
+    DR_RC(writer.open(path, h->name_ptr.data(), h->name_ptr.size(), ref));
+    StageClock clock;
+    double t_dense = 0.0, t_tc = 0.0, t_coo = 0.0, t_rows = 0.0;
+    auto lap = [&](double &acc) {
+        if (!clock.on) return;
+        (void)hipDeviceSynchronize();
+        const auto now = std::chrono::steady_clock::now();
+        acc += std::chrono::duration<double>(now - clock.t).count();
+        clock.t = now;
+    };
+    uint64_t pairs = 0;
+    if (n >= 2 && i_end > 0) {
+        // row panels bounded to ~1 GiB per uint32 matrix (2 GiB per f64 one)
+        const size_t panel = std::max<size_t>(64, std::min<size_t>(i_end, (1ull << 28) / std::max<size_t>(n, 1)));
+        DR_CHECK(hipMalloc(reinterpret_cast<void **>(&d_dist), panel * n * 4));
+        DR_CHECK(hipMalloc(reinterpret_cast<void **>(&d_nn), panel * n * 4));
+        DR_CHECK(hipMalloc(reinterpret_cast<void **>(&d_off), (panel + 1) * 8));
+        if (with_dates) {
+            DR_CHECK(hipMalloc(reinterpret_cast<void **>(&d_p), panel * n * 8));
+            DR_CHECK(hipMalloc(reinterpret_cast<void **>(&d_e), panel * n * 8));
+            DR_CHECK(hipMalloc(reinterpret_cast<void **>(&d_days), n * 4));
+            DR_CHECK(hipMemcpy(d_days, days, n * 4, hipMemcpyHostToDevice));
+        }
+        // a batch on the host: four uint32 columns, then two f64 ones; two of them, so that one is formatted while the next arrives
+        const size_t batch_bytes = CH * (16 + (with_dates ? 16 : 0));
+        for (auto &q : pin) DR_CHECK(hipHostMalloc(reinterpret_cast<void **>(&q), batch_bytes, hipHostMallocDefault));
+        DR_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+        for (auto &e : ev) DR_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        DR_CHECK(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+        std::vector<uint32_t> zeros;                                  // the filtered column without metadata: `len` zeros (:240-258)
+        if (!with_dates) zeros.assign(CH, 0u);
+        size_t cap = 0;
+        for (size_t r0 = 0; r0 < i_end; r0 += panel) {
+            if (g_sigint) { cleanup(); set_error("Interrupted by user!"); return TRACS_E_INTERRUPTED; }
+            const size_t r1 = std::min(i_end, r0 + panel);
+            unsigned *bd = d_dist - r0 * n, *bn = d_nn - r0 * n;     // addressed as base[i * ld + j] with i absolute
+            double *bp = with_dates ? d_p - r0 * n : nullptr, *be = with_dates ? d_e - r0 * n : nullptr;
+            DR_RC(tracs_pairsnp_dense_thr(a, r0, r1, j_start, bd, bn, n, dist, nullptr));
+            lap(t_dense);
+            if (with_dates)
+                DR_RC(tracs_trans_dist_dense(bd, n, n, r0, r1, j_start, dist, d_days, lamb, beta, precision, 1, bp, be, nullptr));
+            lap(t_tc);
+            DR_RC(tracs_coo_count(bd, n, n, r0, r1, j_start, dist, reinterpret_cast<int64_t *>(d_off), nullptr));
+            long long total = 0;
+            DR_CHECK(hipMemcpy(&total, d_off + (r1 - r0), 8, hipMemcpyDeviceToHost));
+            if (total <= 0) continue;
+            if ((size_t)total > cap) {
+                if (d_coo) DR_CHECK(hipFree(d_coo));
+                if (d_cp) DR_CHECK(hipFree(d_cp));
+                d_coo = nullptr; d_cp = nullptr;
+                cap = (size_t)total;
+                DR_CHECK(hipMalloc(reinterpret_cast<void **>(&d_coo), cap * 16));
+                if (with_dates) DR_CHECK(hipMalloc(reinterpret_cast<void **>(&d_cp), cap * 16));
+            }
+            unsigned *c_rows = d_coo, *c_cols = d_coo + cap, *c_d = d_coo + 2 * cap, *c_n = d_coo + 3 * cap;
+            double *c_p = d_cp, *c_e = with_dates ? d_cp + cap : nullptr;
+            DR_RC(tracs_coo_fill(bd, bn, n, n, r0, r1, j_start, dist, reinterpret_cast<int64_t *>(d_off), c_rows, c_cols, c_d, c_n, nullptr));
+            if (with_dates)
+                DR_RC(tracs_coo_fill_f64(bd, n, n, r0, r1, j_start, dist, reinterpret_cast<int64_t *>(d_off), bp, be, c_p, c_e, nullptr));
+            DR_CHECK(hipEventRecord(ready, nullptr));
+            DR_CHECK(hipStreamWaitEvent(copy_stream, ready, 0));
+            lap(t_coo);
+            const size_t nb = ((size_t)total + CH - 1) / CH;
+            auto post = [&](size_t k) -> hipError_t {                 // batch k -> pinned set k % 2
+                const size_t o = k * CH, cnt = std::min(CH, (size_t)total - o);
+                char *dst = pin[k & 1];
+                const unsigned *src32[4] = {c_rows, c_cols, c_d, c_n};
+                for (int q = 0; q < 4; q++) {
+                    const hipError_t e = hipMemcpyAsync(dst + (size_t)q * CH * 4, src32[q] + o, cnt * 4, hipMemcpyDeviceToHost, copy_stream);
+                    if (e != hipSuccess) return e;
+                }
+                if (with_dates) {
+                    hipError_t e = hipMemcpyAsync(dst + CH * 16, c_p + o, cnt * 8, hipMemcpyDeviceToHost, copy_stream);
+                    if (e == hipSuccess) e = hipMemcpyAsync(dst + CH * 24, c_e + o, cnt * 8, hipMemcpyDeviceToHost, copy_stream);
+                    if (e != hipSuccess) return e;
+                }
+                return hipEventRecord(ev[k & 1], copy_stream);
+            };
+            DR_CHECK(post(0));
+            for (size_t k = 0; k < nb; k++) {
+                if (g_sigint) { (void)hipStreamSynchronize(copy_stream); cleanup(); set_error("Interrupted by user!"); return TRACS_E_INTERRUPTED; }
+                DR_CHECK(hipEventSynchronize(ev[k & 1]));
+                if (k + 1 < nb) DR_CHECK(post(k + 1));
+                const size_t cnt = std::min(CH, (size_t)total - k * CH);
+                const char *src = pin[k & 1];
+                const uint32_t *hr = reinterpret_cast<const uint32_t *>(src), *hc = hr + CH, *hd = hr + 2 * CH, *hn = hr + 3 * CH;
+                const double *hp = reinterpret_cast<const double *>(src + CH * 16), *he = reinterpret_cast<const double *>(src + CH * 24);
+                // metadata on, --filter off: a column of "NA" (:204); metadata off: zeros (:240-258)
+                DR_RC(writer.append_u32(hr, hc, hd, with_dates ? nullptr : zeros.data(), hn, days, with_dates ? hp : nullptr, with_dates ? he : nullptr,
+                                        cnt, with_dates ? 1 : 0, with_dates ? k_max : -1.0));
+            }
+            pairs += (uint64_t)total;
+            lap(t_rows);
+        }
+    }
+    if (clock.on)
+        std::fprintf(stderr, "[stage] dense panels (once-per-pack work + pair kernels) %.4f s\n[stage] transcluster on the panels (device) %.4f s\n"
+                             "[stage] COO extraction (device) %.4f s\n[stage] rows: device -> host, format, write (%llu pairs) %.4f s\n",
+                     t_dense, t_tc, t_coo, (unsigned long long)pairs, t_rows);
+#undef DR_CHECK
+#undef DR_RC
+    cleanup();
+    const int rc = writer.close();
+    if (rows_written) *rows_written = writer.written();
+    if (n_pairs) *n_pairs = pairs;
+    if (g_sigint) { set_error("Interrupted by user!"); return TRACS_E_INTERRUPTED; }
+    return rc;
 }
 
 size_t tracs_pairsnp_len(const tracs_pairsnp_result *r) { return r ? r->rows.size() : 0; }

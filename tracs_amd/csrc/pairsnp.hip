@@ -499,6 +499,28 @@ __global__ __launch_bounds__(64) void coo_fill_kernel(const unsigned *__restrict
     }
 }
 
+// two f64 panels (P(direct), E(K)) of the same cells, into the same COO positions as coo_fill_kernel's
+__global__ __launch_bounds__(64) void coo_fill_f64_kernel(const unsigned *__restrict__ dist, size_t ld, unsigned n, unsigned row_begin, unsigned row_end,
+                                                          unsigned col_begin, int thr, const long long *__restrict__ offsets,
+                                                          const double *__restrict__ a, const double *__restrict__ b,
+                                                          double *__restrict__ oa, double *__restrict__ ob)
+{
+    const unsigned i = row_begin + blockIdx.x;
+    if (i >= row_end) return;
+    const unsigned jb = max(col_begin, i + 1);
+    long long o = offsets[blockIdx.x];
+    for (unsigned j0 = jb; j0 < n; j0 += 64) {
+        const unsigned j = j0 + threadIdx.x;
+        const bool keep = j < n && (long long)dist[(size_t)i * ld + j] <= (long long)thr;
+        const unsigned long long mask = __ballot(keep);
+        if (keep) {
+            const long long pos = o + __popcll(mask & ((1ull << threadIdx.x) - 1ull));
+            oa[pos] = a[(size_t)i * ld + j]; ob[pos] = b[(size_t)i * ld + j];
+        }
+        o += __popcll(mask);
+    }
+}
+
 // Threshold edges of a float64 matrix (E(K) or P(direct) panels; `tracs cluster -D expectedK|direct`, tracs/cluster.py:110-112):
 // cells (i, j > i) whose SNP distance was emitted (dist <= dist_thr) and whose value is <= thr, row-major, one wave per row.
 __global__ __launch_bounds__(64) void edge_count_f64_kernel(const double *__restrict__ val, const unsigned *__restrict__ dist, size_t ld,
@@ -1283,6 +1305,20 @@ int tracs_coo_fill(const uint32_t *dist, const uint32_t *ncomp, size_t ld, size_
     hipLaunchKernelGGL(coo_fill_kernel, dim3((unsigned)nrows), dim3(64), 0, stream, dist, ncomp, ld, (unsigned)n,
                        (unsigned)row_begin, (unsigned)row_end, (unsigned)col_begin, (int)thr,
                        reinterpret_cast<const long long *>(offsets), rows, cols, d, nn);
+    TRACS_HIP_CHECK(hipGetLastError());
+    return TRACS_OK;
+}
+
+int tracs_coo_fill_f64(const uint32_t *dist, size_t ld, size_t n, size_t row_begin, size_t row_end, size_t col_begin, int32_t thr,
+                       const int64_t *offsets, const double *a, const double *b, double *out_a, double *out_b, void *stream_)
+{
+    if (!dist || !offsets || !a || !b || !out_a || !out_b) { set_error("tracs_coo_fill_f64: NULL argument"); return TRACS_E_ARG; }
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (row_end > n) row_end = n;
+    const size_t nrows = row_end > row_begin ? row_end - row_begin : 0;
+    if (!nrows) return TRACS_OK;
+    hipLaunchKernelGGL(coo_fill_f64_kernel, dim3((unsigned)nrows), dim3(64), 0, stream, dist, ld, (unsigned)n, (unsigned)row_begin, (unsigned)row_end,
+                       (unsigned)col_begin, (int)thr, reinterpret_cast<const long long *>(offsets), a, b, out_a, out_b);
     TRACS_HIP_CHECK(hipGetLastError());
     return TRACS_OK;
 }

@@ -99,6 +99,39 @@ def _append_rows(path, names, rows, cols, snpd, filt, ncomp, ddiff, tdist, ek, k
     return written.value
 
 
+def _rows_on_device(msas, args, dates, ref, stage):
+    """One alignment through libtracs_hip.so's device-resident path (tracs_distance_open / _run: include/tracs_hip.h): FASTA -> packed
+    planes -> dense panels -> transcluster on the panels -> the pairs within the threshold with their P and E(K) -> ONE device-to-host
+    pass, in batches -> the CSV rows, formatted and appended by the library's host threads.  Nothing comes back to Python but the
+    sample names (to look the dates up).  -> False when the path does not apply: a sample without a date (the reference raises KeyError
+    only if that sample's index is at most the largest index among the emitted pairs, tracs/transcluster.py:23-32: left to the
+    array path below, which reproduces that)."""
+    L = _lib.require_gpu()
+    arr = (C.c_char_p * len(msas))(*[os.fsencode(p) for p in msas])
+    h = C.c_void_p()
+    _lib.check(L.tracs_distance_open(arr, len(msas), C.byref(h)))
+    try:
+        stage("[sum] tracs_distance_open (read FASTA, allocate, H2D + pack)")
+        days = None
+        if dates is not None:
+            n = L.tracs_distance_nseq(h)
+            epoch = date(1970, 1, 1)
+            try:
+                days = (C.c_int32 * max(n, 1))(*[(dates[L.tracs_distance_name(h, i).decode("utf-8", "replace")][1] - epoch).days for i in range(n)])
+            except KeyError:
+                return False
+        written, pairs = C.c_uint64(0), C.c_uint64(0)
+        if dates is not None:
+            logging.info("Inferring transmission probabilities for %s", msas[0])
+        kmax = -1.0 if (args.trans_threshold is None or dates is None) else float(args.trans_threshold)
+        _lib.check(L.tracs_distance_run(h, int(args.snp_threshold), days, float(args.clock_rate), float(args.trans_rate), float(args.precision),
+                                        kmax, os.fsencode(args.output_file), ref.encode(), C.byref(written), C.byref(pairs)))
+        stage("[sum] tracs_distance_run (dense panels, transcluster, rows: %d pairs, %d rows written)" % (pairs.value, written.value))
+        return True
+    finally:
+        L.tracs_distance_free(h)
+
+
 def _cli_of(args):
     """The command line that reproduces `args` (the multi-GPU path re-launches itself, one process per GPU)."""
     argv = ["distance", "--msa"] + list(args.msa_files) + ["-o", args.output_file, "-D", str(args.snp_threshold),
@@ -190,6 +223,15 @@ def distance(args):
         logging.info("Calculating pairwise snp distances for %s", msa)
         msas = [msa, args.msa_db] if args.msa_db is not None else [msa]
         t_stage[0] = time.perf_counter()
+        ref = os.path.basename(msa).split(".")[0].replace("_combined", "")      # (:208-209)
+        if ctx is None and not args.recomb_filter and os.environ.get("TRACS_DISTANCE_ARRAYS") is None:
+            # one GPU, no recombination filter: the results stay on the device until the CSV rows
+            for p in msas:
+                if not os.path.exists(p):
+                    raise FileNotFoundError(p)               # (api.pairsnp_arrays's diagnosis; the reference passes a NULL gzFile on)
+            if _rows_on_device(msas, args, dates, ref, stage):
+                logging.info("Saving distances for %s", msa)
+                continue
         if ctx is None:
             res = pairsnp_arrays(fasta=msas, n_threads=args.n_cpu, dist=args.snp_threshold, filter=args.recomb_filter)
         else:
@@ -211,7 +253,6 @@ def distance(args):
                 filt = None                                                     # a column of "NA" (:204)
             stage("transcluster (dates -> delta, H2D, keys, gather, D2H)")
         logging.info("Saving distances for %s", msa)
-        ref = os.path.basename(msa).split(".")[0].replace("_combined", "")      # (:208-209)
         _append_rows(args.output_file, names, rows, cols, snpd, filt, ncomp, ddiff, tdist, ek,
                      args.trans_threshold if with_dates else None, ref)
         stage("CSV rows (format + write, %d rows)" % len(rows))
