@@ -162,6 +162,7 @@ def run_case(case, nn_lists):
         s_off = _dump(hiplib, aln, 6, np.uint64, n + 1)
         s_ent = _dump(hiplib, aln, 7, np.uint32, tot_p)
         c_p = _dump(hiplib, aln, 9, np.uint32, n)
+        p_w1 = _dump(hiplib, aln, 10, np.uint32, sites)
         site_of_rank = np.nonzero(listed_site)[0]
         pairs_site = set()
         for r in range(sites):
@@ -171,6 +172,8 @@ def run_case(case, nn_lists):
                 continue
             samp, w, mask = ents >> 5, (ents >> 4) & 1, ents & 15
             assert len(set(samp.tolist())) == samp.size
+            # the w = 1 entries first, p_w1 of them (minor_fixup_kernel walks only those from a listed sample with w = 0)
+            assert int(p_w1[r]) == int(w.sum()) and (w[:int(p_w1[r])] == 1).all() and (w[int(p_w1[r]):] == 0).all()
             assert (M[samp, t] == mask).all() and (mask != 15).all()
             rest = np.setdiff1d(np.arange(n), np.concatenate([samp, np.nonzero(isN[:, t])[0]]))
             if rest.size:                                                 # everybody else carries the one reference base

@@ -33,6 +33,8 @@ struct SiteLists {
     unsigned long long n_lines = 0;
     unsigned long long *p_off = nullptr;       // [sites + 1]
     unsigned *p_ent = nullptr;
+    unsigned *p_w1 = nullptr;                  // [sites]: a site's p list holds its w = 1 entries first -- this many (a listed sample whose mask
+                                               //   contains the reference base only ever pairs up with those: minor_fixup_kernel)
     unsigned long long *s_off = nullptr;       // [n + 1]
     unsigned *s_ent = nullptr;
     unsigned *c_p = nullptr;                   // per sample: sum of w over its listed entries
@@ -113,10 +115,10 @@ struct N8Encoder {
 __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBuild mb, size_t n_pad, unsigned n,
                                                          unsigned long long *__restrict__ p_off, unsigned *__restrict__ p_ent,
                                                          uint2 *__restrict__ E, uint4 *__restrict__ lines,
-                                                         unsigned *__restrict__ cnt, unsigned *__restrict__ c_p)
+                                                         unsigned *__restrict__ cnt, unsigned *__restrict__ c_p, unsigned *__restrict__ p_w1)
 {
     __shared__ unsigned bm[SITES_PER_GROUP * BM_STRIDE];     // the piece's N bits, site-major: bm[site * BM_STRIDE + 32-sample word]
-    __shared__ unsigned cn[SITES_PER_GROUP], kp[SITES_PER_GROUP], ovf[SITES_PER_GROUP], curP[SITES_PER_GROUP], rk[SITES_PER_GROUP];
+    __shared__ unsigned cn[SITES_PER_GROUP], kp[SITES_PER_GROUP], ovf[SITES_PER_GROUP], curP[SITES_PER_GROUP], curQ[SITES_PER_GROUP], rk[SITES_PER_GROUP];
     __shared__ unsigned long long bP[SITES_PER_GROUP];
     __shared__ unsigned short queue[PIECE_SAMPLES];          // the piece's samples with listed sites in this group (offsets into the piece)
     __shared__ unsigned qn[2];                               // (by parity of the piece: the other one is reset while this one is read)
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
         cn[tid] = c;
         kp[tid] = (mine && ((mp[tw] >> tb) & 1u)) ? mb.cntP[g * SITES_PER_GROUP + tid] : 0u;
         ovf[tid] = mine ? n8_lines_max(c, n) - 1u : 0u;
-        curP[tid] = 0;
+        curP[tid] = 0; curQ[tid] = 0;
         if (tid < 2) qn[tid] = 0;
     }
     __syncthreads();
@@ -223,7 +225,8 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
                     pm &= pm - 1;
                     const unsigned mask = ((a >> b) & 1u) | (((c >> b) & 1u) << 1) | (((gg >> b) & 1u) << 2) | (((t >> b) & 1u) << 3);
                     const unsigned code = (((has_ref >> b) & 1u) ? 0u : 16u) | mask;
-                    const unsigned slot = atomicAdd(&curP[w * 32 + b], 1u);
+                    // the site's w = 1 entries from the front of its run, the others from the back
+                    const unsigned slot = (code & 16u) ? atomicAdd(&curP[w * 32 + b], 1u) : kp[w * 32 + b] - 1u - atomicAdd(&curQ[w * 32 + b], 1u);
                     const unsigned long long pos = bP[w * 32 + b] + slot;
                     p_ent[pos] = (s << ENT_SHIFT) | code;
                     E[pos] = make_uint2(s, (rk[w * 32 + b] << ENT_SHIFT) | code);
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
         }
         __syncthreads();
     }
-    if (mine) enc.finish();
+    if (mine) { enc.finish(); p_w1[rk[tid]] = curP[tid]; }
 }
 
 // ---- per sample: listed entries (from E) ---------------------------------------------------------------------------------------
@@ -669,6 +672,7 @@ __global__ __launch_bounds__(TRACS_NN_THREADS) void nn_rows_kernel(const uint4 *
 template <bool CLAMP>
 __global__ __launch_bounds__(1024) void minor_fixup_kernel(const unsigned long long *__restrict__ s_off, const unsigned *__restrict__ s_ent,
                                                            const unsigned long long *__restrict__ p_off, const unsigned *__restrict__ p_ent,
+                                                           const unsigned *__restrict__ p_w1,
                                                            const uint4 *__restrict__ lines, const unsigned *__restrict__ c_p, unsigned n,
                                                            unsigned row_begin, unsigned row_end, unsigned col_begin, unsigned chunk,
                                                            unsigned *__restrict__ dist, size_t ld, unsigned *__restrict__ S, size_t s_pitch)
@@ -702,7 +706,10 @@ __global__ __launch_bounds__(1024) void minor_fixup_kernel(const unsigned long l
             if (live) {
                 const unsigned ent = s_ent[e];
                 my_code = ent & 31u;
-                my_pa = p_off[ent >> ENT_SHIFT]; my_pz = p_off[(ent >> ENT_SHIFT) + 1];
+                // (x's mask contains the reference base: [masks disjoint] - w_x - w_j is 0 against every listed j whose mask does too --
+                // only the site's w = 1 entries, at the front of its p list, can add anything)
+                my_pa = p_off[ent >> ENT_SHIFT];
+                my_pz = (my_code & 16u) ? p_off[(ent >> ENT_SHIFT) + 1] : my_pa + p_w1[ent >> ENT_SHIFT];
             }
             auto apply_p = [&](unsigned v, unsigned code5) {          // both listed: [masks disjoint] - w_x - w_j
                 const unsigned j = v >> ENT_SHIFT;
@@ -807,6 +814,7 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb_, hipStream_t 
     SL_TRY(pack_alloc(a, (g->n_lines + 1) * 128, reinterpret_cast<void **>(&g->lines)));
     SL_TRY(pack_alloc(a, (L + 1) * 8, reinterpret_cast<void **>(&g->p_off)));
     SL_TRY(pack_alloc(a, std::max<size_t>(mb.tot_p, 1) * 4, reinterpret_cast<void **>(&g->p_ent)));
+    SL_TRY(pack_alloc(a, (L + 1) * 4, reinterpret_cast<void **>(&g->p_w1)));
     SL_TRY(pack_alloc(a, (n + 1) * 8, reinterpret_cast<void **>(&g->s_off)));
     SL_TRY(pack_alloc(a, std::max<size_t>(mb.tot_p, 1) * 4, reinterpret_cast<void **>(&g->s_ent)));
     SL_TRY(pack_alloc(a, std::max<size_t>(n, 1) * 4, reinterpret_cast<void **>(&g->c_p)));
@@ -825,7 +833,7 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb_, hipStream_t 
     SL_TRY(hipMemcpyAsync(g->lst_mask, mb.lst_mask, groups * sizeof(uint4), hipMemcpyDeviceToDevice, stream));
     SL_TRY(hipMemcpyAsync(g->off_lst, mb.off_lst, groups * sizeof(unsigned), hipMemcpyDeviceToDevice, stream));
     const double plane_b = (double)groups * (double)a->n_pad * sizeof(uint4);      // the N plane
-    hipLaunchKernelGGL(site_lists_kernel, dim3((unsigned)groups), dim3(SITE_THREADS), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off, g->p_ent, E, g->lines, cnt, g->c_p);
+    hipLaunchKernelGGL(site_lists_kernel, dim3((unsigned)groups), dim3(SITE_THREADS), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off, g->p_ent, E, g->lines, cnt, g->c_p, g->p_w1);
     pack_stage_mark("lists: per site", stream, plane_b + (double)groups * SITES_PER_GROUP * 8.0,
                     (double)L * 128.0 + (double)mb.tot_p * 12.0 + (double)L * 8.0);
     const unsigned egrid = (unsigned)((mb.tot_p + 255) / 256);
@@ -938,10 +946,10 @@ int minority_fixup(tracs_alignment *a, size_t row_begin, size_t row_end, size_t 
     if (rc) return rc;
     const dim3 grid((unsigned)(n - row_begin), (unsigned)((n + chunk - 1) / chunk));
     if (grid.y == 1)
-        hipLaunchKernelGGL(minor_fixup_kernel<false>, grid, dim3(1024), lds, stream, g->s_off, g->s_ent, g->p_off, g->p_ent, g->lines, g->c_p, (unsigned)n,
+        hipLaunchKernelGGL(minor_fixup_kernel<false>, grid, dim3(1024), lds, stream, g->s_off, g->s_ent, g->p_off, g->p_ent, g->p_w1, g->lines, g->c_p, (unsigned)n,
                            (unsigned)row_begin, (unsigned)row_end, (unsigned)col_begin, chunk, dist, ld, S, s_pitch);
     else
-        hipLaunchKernelGGL(minor_fixup_kernel<true>, grid, dim3(1024), lds, stream, g->s_off, g->s_ent, g->p_off, g->p_ent, g->lines, g->c_p, (unsigned)n,
+        hipLaunchKernelGGL(minor_fixup_kernel<true>, grid, dim3(1024), lds, stream, g->s_off, g->s_ent, g->p_off, g->p_ent, g->p_w1, g->lines, g->c_p, (unsigned)n,
                            (unsigned)row_begin, (unsigned)row_end, (unsigned)col_begin, chunk, dist, ld, S, s_pitch);
     const dim3 tgrid((unsigned)((n - row_begin + 31) / 32), (unsigned)((row_end - row_begin + 31) / 32));
     hipLaunchKernelGGL(transpose_add_kernel, tgrid, dim3(256), 0, stream, S, s_pitch, (unsigned)n, (unsigned)row_begin, (unsigned)row_end,
@@ -959,6 +967,7 @@ extern "C" {
 //   what 1  lines (n_lines x 128 bytes)     what 2  lst_mask (groups x 16 bytes)     what 3  off_lst (groups x 4 bytes)
 //   what 4  p_off ((sites + 1) x 8)          what 5  p_ent (tot_p x 4)                what 6  s_off ((n + 1) x 8)
 //   what 7  s_ent (tot_p x 4)                what 8  T (n x tgroups x 16)             what 9  c_p (n x 4)
+//   what 10 p_w1 (sites x 4)
 // Returns the bytes copied (what >= 1), 0 when the lists do not exist or `cap` is too small.
 size_t tracs_debug_lists(const tracs_alignment *a, int what, void *out, size_t cap)
 {
@@ -983,6 +992,7 @@ size_t tracs_debug_lists(const tracs_alignment *a, int what, void *out, size_t c
     case 7: src = g->s_ent; bytes = g->tot_p * 4; break;
     case 8: src = g->T; bytes = g->T ? a->n * g->tgroups * 16 : 0; break;
     case 9: src = g->c_p; bytes = a->n * 4; break;
+    case 10: src = g->p_w1; bytes = g->sites * 4; break;
     default: return 0;
     }
     if (!src || bytes == 0 || bytes > cap) return 0;
