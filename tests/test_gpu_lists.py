@@ -58,6 +58,7 @@ CASES = [
     dict(n=130, L=4000, p_n=0.05, mu=2e-3, seed=4, p_partial=0.002),    # partial codes among the listed samples
     dict(n=700, L=3000, p_n=0.01, mu=3e-4, seed=5, bitmaps=True, edges=True),      # lists that end exactly at the encoder's boundaries
     dict(n=900, L=6000, p_n=0.01, mu=6e-3, seed=6, bitmaps=True),       # ~30 000 listed entries: the bucketed fill of the per-sample lists
+    dict(n=4000, L=1024, p_n=0.001, mu=1e-4, seed=7, p_partial=0.009, long_p=True),      # ~36 partial codes per site: p lists beyond one q line
 ]
 
 # N samples of hand-made sites (case `edges`): the byte counts the encoder's branches turn on
@@ -158,22 +159,34 @@ def run_case(case, nn_lists):
     p_off = _dump(hiplib, aln, 4, np.uint64, sites + 1)
     assert int(p_off[-1]) == tot_p
     if tot_p:
-        p_ent = _dump(hiplib, aln, 5, np.uint32, tot_p)
+        nq = np.zeros(1, np.uint64)
+        assert hiplib.tracs_debug_lists(aln._h, 11, nq.ctypes.data_as(C.c_void_p), 8) == 8
+        q = _dump(hiplib, aln, 10, np.uint32, int(nq[0]) * 32).reshape(-1, 32)      # the p lists: q lines of 32 dwords
+        assert int(nq[0]) >= sites
         s_off = _dump(hiplib, aln, 6, np.uint64, n + 1)
         s_ent = _dump(hiplib, aln, 7, np.uint32, tot_p)
         c_p = _dump(hiplib, aln, 9, np.uint32, n)
-        p_w1 = _dump(hiplib, aln, 10, np.uint32, sites)
         site_of_rank = np.nonzero(listed_site)[0]
         pairs_site = set()
+        if case.get("long_p"):
+            ks = np.diff(p_off.astype(np.int64))
+            assert (ks > 31).sum() > 50 and (ks > 62).sum() >= 0, ks.max()              # lists with one overflow line (and more)
         for r in range(sites):
             t = site_of_rank[r]
-            ents = p_ent[int(p_off[r]):int(p_off[r + 1])]
-            if ents.size == 0:
+            k = int(p_off[r + 1]) - int(p_off[r])
+            if k == 0:
                 continue
+            # site r's q lines: line r = header (k | w1 << 16), entries 0..29, index of the first overflow line; then 31 entries a line
+            hdr, ovf = int(q[r, 0]), int(q[r, 31])
+            assert hdr & 0xFFFF == k and (k <= 30 or sites <= ovf <= int(nq[0]) - (k // 31))
+            slot = np.arange(k) + 1
+            line = np.where(slot < 31, r, ovf + slot // 31 - 1)
+            ents = q[line, slot % 31]
             samp, w, mask = ents >> 5, (ents >> 4) & 1, ents & 15
             assert len(set(samp.tolist())) == samp.size
-            # the w = 1 entries first, p_w1 of them (minor_fixup_kernel walks only those from a listed sample with w = 0)
-            assert int(p_w1[r]) == int(w.sum()) and (w[:int(p_w1[r])] == 1).all() and (w[int(p_w1[r]):] == 0).all()
+            # the w = 1 entries first, w1 of them (minor_fixup_kernel walks only those from a listed sample with w = 0)
+            w1 = hdr >> 16
+            assert w1 == int(w.sum()) and (w[:w1] == 1).all() and (w[w1:] == 0).all()
             assert (M[samp, t] == mask).all() and (mask != 15).all()
             rest = np.setdiff1d(np.arange(n), np.concatenate([samp, np.nonzero(isN[:, t])[0]]))
             if rest.size:                                                 # everybody else carries the one reference base

@@ -392,7 +392,7 @@ int DistanceRowWriter::append(const T *rows, const T *cols, const T *snpd, const
     const size_t ref_len = w.ref.size();
     const char *ref = w.ref.c_str();
     const size_t row_cap = 2 * w.longest + ref_len + 3 * 32 + 3 * 20 + 16;      // two names, three floats, three integers, separators
-    const unsigned TH = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    const unsigned TH = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
     const size_t chunk = std::max<size_t>(1024, std::min<size_t>(1u << 17, (n + TH - 1) / TH));
     if (with_dates && !w.memo) w.memo.reset(new FloatMemo(n >= (1u << 20) ? 21 : 16));
     FloatMemo *memo = w.memo.get();

@@ -126,12 +126,14 @@ struct MinorBuild {
     const unsigned *off_lst;                 // per group: sites with lists before it (a site's list index = its rank among them)
     const unsigned *cntP, *cntN;             // per site: listed samples, N samples
     const unsigned long long *baseP, *baseO; // per group: p-list entries / overflow lines (upper bounds) of the groups before it
+    const unsigned long long *baseQ;         // per group: overflow lines of the p lists (q lines) of the groups before it
     const unsigned long long *flags;         // per group and 64 samples: listed somewhere in the group
     size_t flag_words;
     unsigned rows[4];                        // the N bitmap rows (nn_rows_add) only for the samples of these [begin, end) ranges
     int n_rows;                              //  (n_rows of them; 0: every sample) -- tracs_alignment_hint_rows
     size_t sites;                            // sites with lists
     unsigned long long tot_p, tot_o;         // p-list entries, overflow lines (upper bound) in all
+    unsigned long long tot_q;                // overflow lines of the p lists in all
     unsigned long long tot_nnl;              // N samples at the NNL sites: list walks of one pass of nn_rows_add
 };
 int minority_lists_build(tracs_alignment *a, const MinorBuild &mb, hipStream_t stream, int *ok);

@@ -145,6 +145,7 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
                                                              unsigned *__restrict__ cntP, unsigned *__restrict__ cntN,
                                                              unsigned *__restrict__ gP, unsigned *__restrict__ gN, unsigned *__restrict__ gQ,
                                                              unsigned *__restrict__ gR, unsigned *__restrict__ gS, unsigned *__restrict__ gI,
+                                                             unsigned *__restrict__ gJ,
                                                              unsigned long long *__restrict__ flags, size_t flag_words,
                                                              unsigned *__restrict__ partial_flag)
 {
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
     __shared__ unsigned sref[4][4];                     // one-base sample seen, ref X, ref Y, somebody is not N
     __shared__ unsigned planes_lds[4][8][256];          // one counter's bit planes of every thread (32 KiB): [word][plane][thread]
     __shared__ unsigned tot[2][SITES_PER_GROUP];        // k, cN
-    __shared__ unsigned wsum[2][6];
+    __shared__ unsigned wsum[2][7];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < SITES_PER_GROUP) { tot[0][tid] = 0; tot[1][tid] = 0; }
     if (tid < 4) { sref[0][tid] = 0; sref[1][tid] = 0; sref[2][tid] = 0; sref[3][tid] = 0; }
@@ -303,10 +304,11 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
         // per group: p-list entries; overflow lines the N lists of its listed sites can need at most (each has its primary line);
         // list entries one pass of the N co-occurrence walk decodes (cN per walk, cN walks) and its walks; N-list walks of the
         // minority fix-up (one per listed sample of a site with an N sample)
-        unsigned sv[6] = {minor ? (unsigned)k : 0u, lst ? n8_lines_max((unsigned)c, n) - 1u : 0u, nnl ? (unsigned)min(c * c, 33554431ull) : 0u, nnl ? (unsigned)c : 0u,
-                          (minor && c) ? (unsigned)k : 0u, minor ? n8_lines_max((unsigned)c, n) - 1u : 0u};
+        // (gJ: lines a minority site's p list needs beyond its own: 31 dwords a line, the first one of the list its header -- q lines, site_lists.hip)
+        unsigned sv[7] = {minor ? (unsigned)k : 0u, lst ? n8_lines_max((unsigned)c, n) - 1u : 0u, nnl ? (unsigned)min(c * c, 33554431ull) : 0u, nnl ? (unsigned)c : 0u,
+                          (minor && c) ? (unsigned)k : 0u, minor ? n8_lines_max((unsigned)c, n) - 1u : 0u, minor ? (unsigned)(k / 31ull) : 0u};
 #pragma unroll
-        for (int m = 0; m < 6; m++) {
+        for (int m = 0; m < 7; m++) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) sv[m] += __shfl_xor(sv[m], off, 64);
             if (lane == 0) wsum[wave][m] = sv[m];
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
     __syncthreads();
     if (tid == 0) {
         gP[g] = wsum[0][0] + wsum[1][0]; gN[g] = wsum[0][1] + wsum[1][1]; gQ[g] = wsum[0][2] + wsum[1][2];
-        gR[g] = wsum[0][3] + wsum[1][3]; gS[g] = wsum[0][4] + wsum[1][4]; gI[g] = wsum[0][5] + wsum[1][5];
+        gR[g] = wsum[0][3] + wsum[1][3]; gS[g] = wsum[0][4] + wsum[1][4]; gI[g] = wsum[0][5] + wsum[1][5]; gJ[g] = wsum[0][6] + wsum[1][6];
     }
     if (tid < 4) {
         reinterpret_cast<unsigned *>(&masks[(size_t)M_REFX * groups + g])[tid] = refx[tid];
@@ -325,9 +327,9 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
 
 // Exclusive prefix sums over the groups, one workgroup per array (1024 groups at a time):
 //   blocks 0..6  sizes of the mask slots M_DENSE .. M_UN (popcount of the mask) -> off32[b][g], totals[b]
-//   blocks 7..12 per-group sums: gP (p-list entries), gN (overflow lines of the N lists, upper bound), gQ (entries the N co-occurrence
+//   blocks 7..13 per-group sums: gP (p-list entries), gN (overflow lines of the N lists, upper bound), gQ (entries the N co-occurrence
 //                walk decodes), gR (its walks), gS (N-list walks of the minority fix-up), gI (overflow lines of the minority sites' N lists
-//                alone) -> off64[b - 7][g], totals[b]
+//                alone), gJ (overflow lines of the p lists) -> off64[b - 7][g], totals[b]
 __global__ __launch_bounds__(1024) void group_offsets_kernel(const uint4 *__restrict__ masks, const unsigned *__restrict__ gcounts, size_t groups,
                                                              unsigned *__restrict__ off32, unsigned long long *__restrict__ off64,
                                                              unsigned long long *__restrict__ totals)
@@ -588,8 +590,8 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     if ((rc = workspace_get(52, M_SLOTS * groups * sizeof(uint4), reinterpret_cast<void **>(&masks)))) return rc;
     if ((rc = workspace_get(53, 7 * groups * sizeof(unsigned), reinterpret_cast<void **>(&offs)))) return rc;
     if ((rc = workspace_get(54, 2 * groups * SITES_PER_GROUP * sizeof(unsigned), reinterpret_cast<void **>(&cnts)))) return rc;
-    if ((rc = workspace_get(55, 6 * groups * sizeof(unsigned), reinterpret_cast<void **>(&gcnt)))) return rc;
-    if ((rc = workspace_get(56, 6 * (groups + 1) * sizeof(unsigned long long), reinterpret_cast<void **>(&off64)))) return rc;
+    if ((rc = workspace_get(55, 7 * groups * sizeof(unsigned), reinterpret_cast<void **>(&gcnt)))) return rc;
+    if ((rc = workspace_get(56, 7 * (groups + 1) * sizeof(unsigned long long), reinterpret_cast<void **>(&off64)))) return rc;
     if ((rc = workspace_get(57, 128, reinterpret_cast<void **>(&totals)))) return rc;
     if ((rc = workspace_get(58, groups * flag_words * sizeof(unsigned long long), reinterpret_cast<void **>(&flags)))) return rc;
     d_flag = reinterpret_cast<unsigned *>(totals + 15);
@@ -608,10 +610,10 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     const unsigned nn_list_max = (no_nnl || !allow_nnl) ? 0u : (unsigned)std::min(4.0e9, nnl_k * (double)a->n * (double)a->n);
     TRACS_HIP_CHECK(hipMemsetAsync(totals, 0, 128, stream));
     hipLaunchKernelGGL(classify_sites_kernel, dim3((unsigned)groups), dim3(256), 0, stream, a->planes, a->n_pad, (unsigned)a->n, budget,
-                       nn_list_max, masks, groups, cntP, cntN, gcnt, gcnt + groups, gcnt + 2 * groups, gcnt + 3 * groups, gcnt + 4 * groups, gcnt + 5 * groups, flags, flag_words, d_flag);
+                       nn_list_max, masks, groups, cntP, cntN, gcnt, gcnt + groups, gcnt + 2 * groups, gcnt + 3 * groups, gcnt + 4 * groups, gcnt + 5 * groups, gcnt + 6 * groups, flags, flag_words, d_flag);
     const double plane_b = (double)groups * (double)a->n_pad * sizeof(uint4);      // one bit plane of the alignment
     stage_mark("classify", stream, 4.0 * plane_b, (double)groups * (M_SLOTS * 16.0 + 3.0 * SITES_PER_GROUP * 4.0 + flag_words * 8.0));
-    hipLaunchKernelGGL(group_offsets_kernel, dim3(13), dim3(1024), 0, stream, masks, gcnt, groups, offs, off64, totals);
+    hipLaunchKernelGGL(group_offsets_kernel, dim3(14), dim3(1024), 0, stream, masks, gcnt, groups, offs, off64, totals);
     unsigned long long tot[16] = {0};
     TRACS_HIP_CHECK(hipMemcpyAsync(tot, totals, 128, hipMemcpyDeviceToHost, stream));
     TRACS_HIP_CHECK(hipStreamSynchronize(stream));
@@ -620,7 +622,7 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     const bool consensus = !*partial && !force_general;
     const size_t L_dense = (size_t)tot[M_DENSE], L_minor = (size_t)tot[M_MINOR], L_full = (size_t)tot[M_FULL];
     size_t L_count = (size_t)tot[M_COUNT], L_nnl = (size_t)tot[M_NNL], L_lst = (size_t)tot[M_LST], L_un = (size_t)tot[M_UN];
-    const unsigned long long tot_p = tot[7];
+    const unsigned long long tot_p = tot[7], tot_q = tot[13];
     unsigned long long tot_o = tot[8], tot_nnl = tot[10];
     int lst_slot = M_LST, ovf_slot = 1;                      // which mask / per-group overflow bound the lists are built from
     if (force == 0 || a->L == 0 || a->n < 2) return TRACS_OK;
@@ -653,10 +655,10 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
         static const double env_cap = [] { const char *e = std::getenv("TRACS_LIST_CAP"); return e ? 4.0 * std::atof(e) : -1.0; }();
         const double cap = 0.8 * (double)NPLANES * (double)groups * (double)a->n_pad * sizeof(uint4);
         // N-list lines (primary + the overflow lines they can need at most), p lists and their per-sample form, the rows' N bitmaps
-        const double bytes = ((double)L_lst + (double)tot_o) * 128.0 + 16.0 * (double)tot_p +
+        const double bytes = ((double)L_lst + (double)tot_o) * 128.0 + 12.0 * (double)tot_p + ((double)L_lst + (double)tot_q) * 128.0 +
                              (L_nnl ? (double)a->n * (double)((groups + 7) / 8 * 8) * sizeof(uint4) : 0.0);
         if (L_lst >= (1ull << 27) || a->n >= (1ull << 27) || bytes > (env_cap >= 0.0 ? std::min(env_cap, cap) : cap) ||
-            L_lst + tot_o >= (1ull << 32))                  // (line indices are 32 bits)
+            L_lst + tot_o >= (1ull << 32) || L_lst + tot_q >= (1ull << 32))                  // (line indices are 32 bits)
             return L_nnl ? decide(a, allow_minor, false, stream, partial) : decide(a, false, false, stream, partial);
     }
 
@@ -710,7 +712,7 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
         mb.planes = a->planes; mb.minor_mask = mask_of(M_MINOR); mb.nnl_mask = mask_of(M_NNL); mb.lst_mask = mask_of(lst_slot);
         mb.ref_x = mask_of(M_REFX); mb.ref_y = mask_of(M_REFY); mb.un_mask = mask_of(M_UN); mb.off_lst = off_of(lst_slot);
         mb.cntP = cntP; mb.cntN = cntN; mb.baseP = off64; mb.baseO = off64 + (size_t)ovf_slot * groups; mb.flags = flags; mb.flag_words = flag_words;
-        mb.sites = L_lst; mb.tot_p = tot_p; mb.tot_o = tot_o; mb.tot_nnl = tot_nnl;
+        mb.sites = L_lst; mb.tot_p = tot_p; mb.tot_o = tot_o; mb.tot_nnl = tot_nnl; mb.baseQ = off64 + 6 * groups; mb.tot_q = tot_q;
         mb.n_rows = a->n_row_hint;
         for (int k = 0; k < 4; k++) mb.rows[k] = (unsigned)std::min<size_t>(a->row_hint[k], a->n);
         rc = minority_lists_build(a, mb, stream, &built);

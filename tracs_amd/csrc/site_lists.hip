@@ -5,7 +5,8 @@
 //
 //   per site     N LIST ("n8" lines, pairsnp_kernels.h): its N samples in sample order, byte deltas, 124 per 128-byte line -- the site
 //                of rank r (among the sites with lists) owns line r; a list that needs more goes on in overflow lines of its group;
-//                P LIST: its listed samples (sample << 5 | w << 4 | allele mask), minority sites only;
+//                P LIST ("q" lines of 32 dwords): its listed samples (sample << 5 | w << 4 | allele mask) behind a header, minority sites only --
+//                the site of rank r owns q line r, longer lists go on in consecutive overflow lines;
 //   per sample   its LISTED entries (rank << 5 | w << 4 | mask) -- few: a sample differs from the others at a few hundred sites;
 //                its N BITMAP over the NNL sites, sample-major (T: 16 bytes per 128-site group, the transposed N plane): what
 //                nn_rows_kernel reads instead of a stream of list addresses.
@@ -32,9 +33,12 @@ struct SiteLists {
     uint4 *lines = nullptr;                    // n8 lines: [0, sites) primary, then each group's overflow block
     unsigned long long n_lines = 0;
     unsigned long long *p_off = nullptr;       // [sites + 1]
-    unsigned *p_ent = nullptr;
-    unsigned *p_w1 = nullptr;                  // [sites]: a site's p list holds its w = 1 entries first -- this many (a listed sample whose mask
-                                               //   contains the reference base only ever pairs up with those: minor_fixup_kernel)
+    uint4 *qlines = nullptr;                   // the p lists as "q lines" of 32 dwords: the site of rank r owns line r -- dword 0 its header
+                                               //   (k | w1 << 16: listed samples, and how many of them, at the front, have w = 1: a listed sample
+                                               //   whose mask contains the reference base only ever pairs up with those), dwords 1..30 its first
+                                               //   entries (sample << 5 | w << 4 | mask), dword 31 the index of its first overflow line; overflow
+                                               //   lines (31 entries each) are consecutive.  ONE line fetch per walk for lists of up to 30
+    unsigned long long n_qlines = 0;
     unsigned long long *s_off = nullptr;       // [n + 1]
     unsigned *s_ent = nullptr;
     unsigned *c_p = nullptr;                   // per sample: sum of w over its listed entries
@@ -113,12 +117,13 @@ struct N8Encoder {
 };
 
 __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBuild mb, size_t n_pad, unsigned n,
-                                                         unsigned long long *__restrict__ p_off, unsigned *__restrict__ p_ent,
+                                                         unsigned long long *__restrict__ p_off, unsigned *__restrict__ qd,
                                                          uint2 *__restrict__ E, uint4 *__restrict__ lines,
-                                                         unsigned *__restrict__ cnt, unsigned *__restrict__ c_p, unsigned *__restrict__ p_w1)
+                                                         unsigned *__restrict__ cnt, unsigned *__restrict__ c_p)
 {
     __shared__ unsigned bm[SITES_PER_GROUP * BM_STRIDE];     // the piece's N bits, site-major: bm[site * BM_STRIDE + 32-sample word]
     __shared__ unsigned cn[SITES_PER_GROUP], kp[SITES_PER_GROUP], ovf[SITES_PER_GROUP], curP[SITES_PER_GROUP], curQ[SITES_PER_GROUP], rk[SITES_PER_GROUP];
+    __shared__ unsigned qb[SITES_PER_GROUP];                 // first overflow line of the site's p list
     __shared__ unsigned long long bP[SITES_PER_GROUP];
     __shared__ unsigned short queue[PIECE_SAMPLES];          // the piece's samples with listed sites in this group (offsets into the piece)
     __shared__ unsigned qn[2];                               // (by parity of the piece: the other one is reset while this one is read)
@@ -147,10 +152,11 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
     N8Encoder enc{lines, 0u, 0u, 0u, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
     if (mine) {
         unsigned long long pp = 0;
-        unsigned po = 0;
-        for (int t = 0; t < tid; t++) { pp += kp[t]; po += ovf[t]; }
+        unsigned po = 0, pq = 0;
+        for (int t = 0; t < tid; t++) { pp += kp[t]; po += ovf[t]; pq += kp[t] / 31u; }
         const unsigned rank = lst_rank(m4, mb.off_lst[g], tw, tb);
         bP[tid] = mb.baseP[g] + pp; rk[tid] = rank;
+        qb[tid] = (unsigned)(mb.sites + mb.baseQ[g] + pq);
         p_off[rank] = bP[tid];
         enc.line = rank;
         enc.left = cn[tid];
@@ -228,7 +234,9 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
                     // the site's w = 1 entries from the front of its run, the others from the back
                     const unsigned slot = (code & 16u) ? atomicAdd(&curP[w * 32 + b], 1u) : kp[w * 32 + b] - 1u - atomicAdd(&curQ[w * 32 + b], 1u);
                     const unsigned long long pos = bP[w * 32 + b] + slot;
-                    p_ent[pos] = (s << ENT_SHIFT) | code;
+                    // entry `slot` of the site's list: dword slot + 1 of its q lines (31 dwords a line; dword 0 of the list is the header)
+                    const unsigned qs = slot + 1u, qt = qs / 31u;
+                    qd[(size_t)(qt ? qb[w * 32 + b] + qt - 1u : rk[w * 32 + b]) * 32 + (qs - qt * 31u)] = (s << ENT_SHIFT) | code;
                     E[pos] = make_uint2(s, (rk[w * 32 + b] << ENT_SHIFT) | code);
                     listed++; listed_w += code >> 4;
                 }
@@ -270,7 +278,10 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
         }
         __syncthreads();
     }
-    if (mine) { enc.finish(); p_w1[rk[tid]] = curP[tid]; }
+    if (mine) {
+        enc.finish();
+        if (kp[tid]) { qd[(size_t)rk[tid] * 32] = kp[tid] | (curP[tid] << 16); qd[(size_t)rk[tid] * 32 + 31] = qb[tid]; }
+    }
 }
 
 // ---- per sample: listed entries (from E) ---------------------------------------------------------------------------------------
@@ -671,8 +682,7 @@ __global__ __launch_bounds__(TRACS_NN_THREADS) void nn_rows_kernel(const uint4 *
 // Negative terms wrap in the unsigned row and cancel in the final sum.
 template <bool CLAMP>
 __global__ __launch_bounds__(1024) void minor_fixup_kernel(const unsigned long long *__restrict__ s_off, const unsigned *__restrict__ s_ent,
-                                                           const unsigned long long *__restrict__ p_off, const unsigned *__restrict__ p_ent,
-                                                           const unsigned *__restrict__ p_w1,
+                                                           const unsigned *__restrict__ qd,
                                                            const uint4 *__restrict__ lines, const unsigned *__restrict__ c_p, unsigned n,
                                                            unsigned row_begin, unsigned row_end, unsigned col_begin, unsigned chunk,
                                                            unsigned *__restrict__ dist, size_t ld, unsigned *__restrict__ S, size_t s_pitch)
@@ -694,50 +704,64 @@ __global__ __launch_bounds__(1024) void minor_fixup_kernel(const unsigned long l
     __syncthreads();
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     if (upper && e1 > e0) {
-        // phase A.  A quarter wave takes 16 listed entries of sample x at a time: lane l fetches entry l and its site's list bounds
-        // (one memory round trip for the 16 of them); lists of at most four samples (the usual case: one or two) stay in their
-        // lane, the others are walked by the 16 lanes together.
-        const unsigned sub = threadIdx.x >> 4, nsub = blockDim.x >> 4, l16 = threadIdx.x & 15;
-        for (unsigned long long base = e0 + (unsigned long long)sub * 16; base < e1; base += (unsigned long long)nsub * 16) {
-            const unsigned long long e = base + l16;
-            unsigned my_code = 0;
-            unsigned long long my_pa = 0, my_pz = 0;
-            const bool live = e < e1;
-            if (live) {
-                const unsigned ent = s_ent[e];
-                my_code = ent & 31u;
-                // (x's mask contains the reference base: [masks disjoint] - w_x - w_j is 0 against every listed j whose mask does too --
-                // only the site's w = 1 entries, at the front of its p list, can add anything)
-                my_pa = p_off[ent >> ENT_SHIFT];
-                my_pz = (my_code & 16u) ? p_off[(ent >> ENT_SHIFT) + 1] : my_pa + p_w1[ent >> ENT_SHIFT];
-            }
-            auto apply_p = [&](unsigned v, unsigned code5) {          // both listed: [masks disjoint] - w_x - w_j
-                const unsigned j = v >> ENT_SHIFT;
-                const int add = (((v & 15u) & (code5 & 15u)) == 0u ? 1 : 0) - (int)(code5 >> 4) - (int)((v >> 4) & 1u);
-                if (add != 0 && j >= up0 && j < up1) atomicAdd(&row[j - c0], (unsigned)add);
-            };
-            bool coop = live;
-            if (live && my_pz - my_pa <= 4) {
-                unsigned v[4];
+        // phase A.  Every listed entry of sample x is a walk of its site's p list: q line `rank` -- header (k, w1), 30 entries, the index of
+        // the first overflow line -- and, for lists beyond 30, the consecutive overflow lines.  A wave keeps a ring of (line, what) in LDS
+        // and works it off 16 lines at a time, FOUR lanes per line, 8 dwords per lane (the line is one 128-byte fetch, its header tells how
+        // far to go: k entries when w_x = 1, only the w1 entries with w = 1 at the front when x's mask holds the reference base -- against
+        // the others [masks disjoint] - w_x - w_j is 0).  Round 4 read a site's bounds from p_off (two more cache lines per walk, at random)
+        // and its entries from p_ent with 16 lanes in a loop: three lines and a loop trip per walk where this form has one of each.
+        const unsigned *__restrict__ q = qd;
+        uint2 *ring = reinterpret_cast<uint2 *>(row + chunk + 64 + wave * (WALK_LDS_PER_WAVE / 4));
+        unsigned rhead = 0, rcount = 0;
+        const unsigned grp = lane >> 2, l4 = lane & 3u;
+        ring[lane] = make_uint2(0u, 0u); ring[64 + lane] = make_uint2(0u, 0u);
+        auto wave_sync = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
+        auto push = [&](bool has, unsigned line, unsigned what) {
+            const unsigned long long m = __ballot(has);
+            const unsigned r = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            if (has) ring[(rhead + rcount + r) & (LINE_RING - 1u)] = make_uint2(line, what);
+            rcount += (unsigned)__popcll(m);
+        };
+        // what: code of x (5 bits) | overflow line (bit 5) | entries still to read from here on (overflow lines)
+        auto round = [&]() {
+            const unsigned k16 = min(rcount, 16u);
+            const uint2 ref = ring[(rhead + grp) & (LINE_RING - 1u)];
+            const uint4 *lp = reinterpret_cast<const uint4 *>(q + (size_t)ref.x * 32) + l4 * 2;
+            const uint4 d0 = lp[0], d1 = lp[1];
+            rhead = (rhead + k16) & (LINE_RING - 1u); rcount -= k16;
+            const bool has = grp < k16;
+            const unsigned code = ref.y & 31u;
+            const bool ovf = (ref.y >> 5) & 1u;
+            const unsigned hdr = (unsigned)__builtin_amdgcn_update_dpp(0, (int)d0.x, 0x00, 0xF, 0xF, false);      // quad_perm:[0,0,0,0]
+            const unsigned tail = (unsigned)__builtin_amdgcn_update_dpp(0, (int)d1.w, 0xFF, 0xF, 0xF, false);     // quad_perm:[3,3,3,3]
+            const unsigned first = ovf ? 0u : 1u;
+            const unsigned limit = ovf ? (ref.y >> 6) : ((code & 16u) ? (hdr & 0xFFFFu) : (hdr >> 16));
+            const unsigned v[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+            const unsigned mx = code & 15u;
+            const int wx = (int)(code >> 4);
 #pragma unroll
-                for (int m = 0; m < 4; m++) v[m] = my_pa + m < my_pz ? p_ent[my_pa + m] : 0xFFFFFFFFu;
-#pragma unroll
-                for (int m = 0; m < 4; m++) if (v[m] != 0xFFFFFFFFu) apply_p(v[m], my_code);
-                coop = false;
+            for (int t = 0; t < 8; t++) {
+                const unsigned dw = l4 * 8u + (unsigned)t;
+                const unsigned j = v[t] >> ENT_SHIFT;
+                const bool in = has && dw >= first && dw < 31u && dw - first < limit && j >= up0 && j < up1;
+                const int add = (((v[t] & 15u) & mx) == 0u ? 1 : 0) - wx - (int)((v[t] >> 4) & 1u);      // both listed: [masks disjoint] - w_x - w_j
+                if (in && add != 0) atomicAdd(&row[j - c0], (unsigned)add);
             }
-            unsigned todo = (unsigned)(__ballot(coop) >> (threadIdx.x & 48)) & 0xFFFFu;     // this quarter wave's entries still to walk
-            while (todo) {
-                const int k = __ffs(todo) - 1;
-                todo &= todo - 1;
-                const unsigned code5 = __shfl(my_code, k, 16);
-                const unsigned long long pa = __shfl(my_pa, k, 16), pz = __shfl(my_pz, k, 16);
-                for (unsigned long long t = pa + l16; t < pz; t += 64) {
-                    const bool h1 = t + 16 < pz, h2 = t + 32 < pz, h3 = t + 48 < pz;
-                    const unsigned v0 = p_ent[t], v1 = h1 ? p_ent[t + 16] : 0u, v2 = h2 ? p_ent[t + 32] : 0u, v3 = h3 ? p_ent[t + 48] : 0u;
-                    apply_p(v0, code5); if (h1) apply_p(v1, code5); if (h2) apply_p(v2, code5); if (h3) apply_p(v3, code5);
-                }
-            }
+            const unsigned cap = 31u - first;
+            push(has && l4 == 0u && limit > cap, ovf ? ref.x + 1u : tail, code | 32u | ((limit - cap) << 6));
+        };
+        for (unsigned long long base = e0 + (unsigned long long)wave * 64; base < e1; base += (unsigned long long)nwaves * 64) {
+            const unsigned long long e = base + lane;
+            const unsigned ent = e < e1 ? s_ent[e] : 0u;
+            while (rcount > LINE_RING - 64u - 16u) { wave_sync(); round(); }
+            push(e < e1, ent >> ENT_SHIFT, ent & 31u);
         }
+        while (rcount) { wave_sync(); round(); }
+        wave_sync();
     }
     // phase B: N-list walks, both triangles: column y goes to row[y - c0]
     {
@@ -813,8 +837,8 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb_, hipStream_t 
     g->tgroups = (groups + 7) / 8 * 8;
     SL_TRY(pack_alloc(a, (g->n_lines + 1) * 128, reinterpret_cast<void **>(&g->lines)));
     SL_TRY(pack_alloc(a, (L + 1) * 8, reinterpret_cast<void **>(&g->p_off)));
-    SL_TRY(pack_alloc(a, std::max<size_t>(mb.tot_p, 1) * 4, reinterpret_cast<void **>(&g->p_ent)));
-    SL_TRY(pack_alloc(a, (L + 1) * 4, reinterpret_cast<void **>(&g->p_w1)));
+    g->n_qlines = mb.tot_p ? (unsigned long long)L + mb.tot_q : 0ull;
+    SL_TRY(pack_alloc(a, (g->n_qlines + 1) * 128, reinterpret_cast<void **>(&g->qlines)));
     SL_TRY(pack_alloc(a, (n + 1) * 8, reinterpret_cast<void **>(&g->s_off)));
     SL_TRY(pack_alloc(a, std::max<size_t>(mb.tot_p, 1) * 4, reinterpret_cast<void **>(&g->s_ent)));
     SL_TRY(pack_alloc(a, std::max<size_t>(n, 1) * 4, reinterpret_cast<void **>(&g->c_p)));
@@ -833,9 +857,9 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb_, hipStream_t 
     SL_TRY(hipMemcpyAsync(g->lst_mask, mb.lst_mask, groups * sizeof(uint4), hipMemcpyDeviceToDevice, stream));
     SL_TRY(hipMemcpyAsync(g->off_lst, mb.off_lst, groups * sizeof(unsigned), hipMemcpyDeviceToDevice, stream));
     const double plane_b = (double)groups * (double)a->n_pad * sizeof(uint4);      // the N plane
-    hipLaunchKernelGGL(site_lists_kernel, dim3((unsigned)groups), dim3(SITE_THREADS), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off, g->p_ent, E, g->lines, cnt, g->c_p, g->p_w1);
+    hipLaunchKernelGGL(site_lists_kernel, dim3((unsigned)groups), dim3(SITE_THREADS), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off, reinterpret_cast<unsigned *>(g->qlines), E, g->lines, cnt, g->c_p);
     pack_stage_mark("lists: per site", stream, plane_b + (double)groups * SITES_PER_GROUP * 8.0,
-                    (double)L * 128.0 + (double)mb.tot_p * 12.0 + (double)L * 8.0);
+                    (double)L * 128.0 + (double)mb.tot_p * 12.0 + (double)L * 8.0 + (double)(mb.tot_q + std::min<unsigned long long>(L, mb.tot_p)) * 8.0);
     const unsigned egrid = (unsigned)((mb.tot_p + 255) / 256);
     hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, cnt, n, g->s_off);
     bool two_pass = false;
@@ -946,10 +970,10 @@ int minority_fixup(tracs_alignment *a, size_t row_begin, size_t row_end, size_t 
     if (rc) return rc;
     const dim3 grid((unsigned)(n - row_begin), (unsigned)((n + chunk - 1) / chunk));
     if (grid.y == 1)
-        hipLaunchKernelGGL(minor_fixup_kernel<false>, grid, dim3(1024), lds, stream, g->s_off, g->s_ent, g->p_off, g->p_ent, g->p_w1, g->lines, g->c_p, (unsigned)n,
+        hipLaunchKernelGGL(minor_fixup_kernel<false>, grid, dim3(1024), lds, stream, g->s_off, g->s_ent, reinterpret_cast<const unsigned *>(g->qlines), g->lines, g->c_p, (unsigned)n,
                            (unsigned)row_begin, (unsigned)row_end, (unsigned)col_begin, chunk, dist, ld, S, s_pitch);
     else
-        hipLaunchKernelGGL(minor_fixup_kernel<true>, grid, dim3(1024), lds, stream, g->s_off, g->s_ent, g->p_off, g->p_ent, g->p_w1, g->lines, g->c_p, (unsigned)n,
+        hipLaunchKernelGGL(minor_fixup_kernel<true>, grid, dim3(1024), lds, stream, g->s_off, g->s_ent, reinterpret_cast<const unsigned *>(g->qlines), g->lines, g->c_p, (unsigned)n,
                            (unsigned)row_begin, (unsigned)row_end, (unsigned)col_begin, chunk, dist, ld, S, s_pitch);
     const dim3 tgrid((unsigned)((n - row_begin + 31) / 32), (unsigned)((row_end - row_begin + 31) / 32));
     hipLaunchKernelGGL(transpose_add_kernel, tgrid, dim3(256), 0, stream, S, s_pitch, (unsigned)n, (unsigned)row_begin, (unsigned)row_end,
@@ -965,9 +989,9 @@ extern "C" {
 // Diagnostics (tests/test_gpu_lists.py): the lists of an alignment on site classes, copied to the host.
 //   what 0  sizes: out64[0..7] = sites with lists, lines, p entries, tgroups, groups, bitmap present, n, the most N sites of a sample
 //   what 1  lines (n_lines x 128 bytes)     what 2  lst_mask (groups x 16 bytes)     what 3  off_lst (groups x 4 bytes)
-//   what 4  p_off ((sites + 1) x 8)          what 5  p_ent (tot_p x 4)                what 6  s_off ((n + 1) x 8)
+//   what 4  p_off ((sites + 1) x 8)          (5: gone with p_ent)                     what 6  s_off ((n + 1) x 8)
 //   what 7  s_ent (tot_p x 4)                what 8  T (n x tgroups x 16)             what 9  c_p (n x 4)
-//   what 10 p_w1 (sites x 4)
+//   what 10 q lines (n_qlines x 128: the p lists)     what 11 out64[0] = n_qlines
 // Returns the bytes copied (what >= 1), 0 when the lists do not exist or `cap` is too small.
 size_t tracs_debug_lists(const tracs_alignment *a, int what, void *out, size_t cap)
 {
@@ -987,12 +1011,12 @@ size_t tracs_debug_lists(const tracs_alignment *a, int what, void *out, size_t c
     case 2: src = g->lst_mask; bytes = g->groups * 16; break;
     case 3: src = g->off_lst; bytes = g->groups * 4; break;
     case 4: src = g->p_off; bytes = (g->sites + 1) * 8; break;
-    case 5: src = g->p_ent; bytes = g->tot_p * 4; break;
     case 6: src = g->s_off; bytes = (a->n + 1) * 8; break;
     case 7: src = g->s_ent; bytes = g->tot_p * 4; break;
     case 8: src = g->T; bytes = g->T ? a->n * g->tgroups * 16 : 0; break;
     case 9: src = g->c_p; bytes = a->n * 4; break;
-    case 10: src = g->p_w1; bytes = g->sites * 4; break;
+    case 10: src = g->qlines; bytes = g->n_qlines * 128; break;
+    case 11: if (cap < 8) return 0; *static_cast<uint64_t *>(out) = g->n_qlines; return 8;
     default: return 0;
     }
     if (!src || bytes == 0 || bytes > cap) return 0;
