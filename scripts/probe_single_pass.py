@@ -13,7 +13,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 5000000
 d = torch.device("cuda", 0)
 seed = 20241022 + 2
-kw = dict(mu_lineage=0.0, mu_sample=1e-4, n_lineages=1, p_n=0.01, p_partial=0.0)
+kw = dict(mu_lineage=0.0, mu_sample=1e-4, n_lineages=1, p_n=0.01, p_partial=float(os.environ.get("PARTIAL", "0")))
 _, days_np = synth.dates(n, seed=seed)
 days = torch.from_numpy(days_np).to(d)
 dm = torch.zeros((n, n), dtype=torch.int32, device=d)
@@ -53,5 +53,5 @@ def one_pass(tag):
 
 one_pass("cold")
 one_pass("warm")
-if len(sys.argv) <= 3:
+if len(sys.argv) <= 3 and not os.environ.get("PARTIAL"):
     one_pass("warm2")

@@ -159,10 +159,12 @@ def run_case(case, nn_lists):
     p_off = _dump(hiplib, aln, 4, np.uint64, sites + 1)
     assert int(p_off[-1]) == tot_p
     if tot_p:
+        p_ent = _dump(hiplib, aln, 5, np.uint32, tot_p)                              # lists of at most 4 samples
         nq = np.zeros(1, np.uint64)
         assert hiplib.tracs_debug_lists(aln._h, 11, nq.ctypes.data_as(C.c_void_p), 8) == 8
-        q = _dump(hiplib, aln, 10, np.uint32, int(nq[0]) * 32).reshape(-1, 32)      # the p lists: q lines of 32 dwords
-        assert int(nq[0]) >= sites
+        ks_all = np.diff(p_off.astype(np.int64))
+        assert (int(nq[0]) >= sites) == bool((ks_all > 4).any())                     # q lines exist iff some list is a long one
+        q = _dump(hiplib, aln, 10, np.uint32, int(nq[0]) * 32).reshape(-1, 32) if nq[0] else None      # the longer p lists: q lines of 32 dwords
         s_off = _dump(hiplib, aln, 6, np.uint64, n + 1)
         s_ent = _dump(hiplib, aln, 7, np.uint32, tot_p)
         c_p = _dump(hiplib, aln, 9, np.uint32, n)
@@ -176,17 +178,21 @@ def run_case(case, nn_lists):
             k = int(p_off[r + 1]) - int(p_off[r])
             if k == 0:
                 continue
-            # site r's q lines: line r = header (k | w1 << 16), entries 0..29, index of the first overflow line; then 31 entries a line
-            hdr, ovf = int(q[r, 0]), int(q[r, 31])
-            assert hdr & 0xFFFF == k and (k <= 30 or sites <= ovf <= int(nq[0]) - (k // 31))
-            slot = np.arange(k) + 1
-            line = np.where(slot < 31, r, ovf + slot // 31 - 1)
-            ents = q[line, slot % 31]
+            if k <= 4:
+                ents = p_ent[int(p_off[r]):int(p_off[r + 1])]
+            else:
+                # site r's q lines: line r = header (k | w1 << 16), entries 0..29, index of the first overflow line; then 31 entries a line
+                hdr, ovf = int(q[r, 0]), int(q[r, 31])
+                assert hdr & 0xFFFF == k and (k <= 30 or sites <= ovf <= int(nq[0]) - (k // 31))
+                slot = np.arange(k) + 1
+                line = np.where(slot < 31, r, ovf + slot // 31 - 1)
+                ents = q[line, slot % 31]
             samp, w, mask = ents >> 5, (ents >> 4) & 1, ents & 15
             assert len(set(samp.tolist())) == samp.size
-            # the w = 1 entries first, w1 of them (minor_fixup_kernel walks only those from a listed sample with w = 0)
-            w1 = hdr >> 16
-            assert w1 == int(w.sum()) and (w[:w1] == 1).all() and (w[w1:] == 0).all()
+            if k > 4:
+                # the w = 1 entries first, w1 of them (minor_fixup_kernel walks only those from a listed sample with w = 0)
+                w1 = hdr >> 16
+                assert w1 == int(w.sum()) and (w[:w1] == 1).all() and (w[w1:] == 0).all()
             assert (M[samp, t] == mask).all() and (mask != 15).all()
             rest = np.setdiff1d(np.arange(n), np.concatenate([samp, np.nonzero(isN[:, t])[0]]))
             if rest.size:                                                 # everybody else carries the one reference base
@@ -200,7 +206,9 @@ def run_case(case, nn_lists):
         for s_ in range(n):
             ents = s_ent[int(s_off[s_]):int(s_off[s_ + 1])]
             for e in ents.tolist():
-                pairs_sample.add((s_, e >> 5, (e >> 4) & 1, e & 15))
+                r_ = (e & 0x7FFFFFFF) >> 5
+                assert bool(e >> 31) == (int(p_off[r_ + 1]) - int(p_off[r_]) > 4)          # flagged: the site's p list is a q line
+                pairs_sample.add((s_, r_, (e >> 4) & 1, e & 15))
             assert int(c_p[s_]) == int(((ents >> 4) & 1).sum())
         assert pairs_site == pairs_sample
     # ---- the rows' N bitmaps: per site either the N plane's column (an NNL site) or nothing

@@ -119,6 +119,9 @@ __host__ __device__ inline float n8_lines_expected(unsigned c, unsigned n)
     const float cap = (float)c + (float)(n / N8_SKIP);
     return __builtin_ceilf((bytes < cap ? bytes : cap) / (float)N8_PAYLOAD);
 }
+// p lists of at most this many samples stay in p_ent (walked in the lane that finds them); longer ones are q lines (site_lists.hip)
+constexpr unsigned P_SHORT_MAX = 4;
+
 struct MinorBuild {
     const uint4 *planes;                     // the five general planes
     const uint4 *minor_mask, *nnl_mask, *lst_mask, *un_mask;   // per group: minority sites, N co-occurrence list sites, their union; sites outside the dense class with an N
@@ -134,6 +137,7 @@ struct MinorBuild {
     size_t sites;                            // sites with lists
     unsigned long long tot_p, tot_o;         // p-list entries, overflow lines (upper bound) in all
     unsigned long long tot_q;                // overflow lines of the p lists in all
+    int long_p;                              // some minority site lists more than P_SHORT_MAX samples: its p list is a q line (else: no q lines at all)
     unsigned long long tot_nnl;              // N samples at the NNL sites: list walks of one pass of nn_rows_add
 };
 int minority_lists_build(tracs_alignment *a, const MinorBuild &mb, hipStream_t stream, int *ok);

@@ -299,6 +299,7 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
                 pm[2 * wave] = (unsigned)bal; pm[2 * wave + 1] = (unsigned)(bal >> 32);
             }
         }
+        if (__ballot(minor && k > P_SHORT_MAX) && lane == 0) atomicOr(partial_flag, 2u);      // some p list is a long one (q lines: site_lists.hip)
         cntP[g * SITES_PER_GROUP + tid] = (unsigned)k;
         cntN[g * SITES_PER_GROUP + tid] = (unsigned)c;
         // per group: p-list entries; overflow lines the N lists of its listed sites can need at most (each has its primary line);
@@ -619,10 +620,11 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     TRACS_HIP_CHECK(hipStreamSynchronize(stream));
     stage_mark("class sizes", stream);
     *partial = (int)(reinterpret_cast<const unsigned *>(&tot[15])[0] & 1u);
+    const bool long_p = (reinterpret_cast<const unsigned *>(&tot[15])[0] & 2u) != 0u;
     const bool consensus = !*partial && !force_general;
     const size_t L_dense = (size_t)tot[M_DENSE], L_minor = (size_t)tot[M_MINOR], L_full = (size_t)tot[M_FULL];
     size_t L_count = (size_t)tot[M_COUNT], L_nnl = (size_t)tot[M_NNL], L_lst = (size_t)tot[M_LST], L_un = (size_t)tot[M_UN];
-    const unsigned long long tot_p = tot[7], tot_q = tot[13];
+    const unsigned long long tot_p = tot[7], tot_q = long_p ? tot[13] : 0ull;
     unsigned long long tot_o = tot[8], tot_nnl = tot[10];
     int lst_slot = M_LST, ovf_slot = 1;                      // which mask / per-group overflow bound the lists are built from
     if (force == 0 || a->L == 0 || a->n < 2) return TRACS_OK;
@@ -655,9 +657,9 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
         static const double env_cap = [] { const char *e = std::getenv("TRACS_LIST_CAP"); return e ? 4.0 * std::atof(e) : -1.0; }();
         const double cap = 0.8 * (double)NPLANES * (double)groups * (double)a->n_pad * sizeof(uint4);
         // N-list lines (primary + the overflow lines they can need at most), p lists and their per-sample form, the rows' N bitmaps
-        const double bytes = ((double)L_lst + (double)tot_o) * 128.0 + 12.0 * (double)tot_p + ((double)L_lst + (double)tot_q) * 128.0 +
+        const double bytes = ((double)L_lst + (double)tot_o) * 128.0 + 16.0 * (double)tot_p + (long_p ? ((double)L_lst + (double)tot_q) * 128.0 : 0.0) +
                              (L_nnl ? (double)a->n * (double)((groups + 7) / 8 * 8) * sizeof(uint4) : 0.0);
-        if (L_lst >= (1ull << 27) || a->n >= (1ull << 27) || bytes > (env_cap >= 0.0 ? std::min(env_cap, cap) : cap) ||
+        if (L_lst >= (1ull << 26) || a->n >= (1ull << 27) || bytes > (env_cap >= 0.0 ? std::min(env_cap, cap) : cap) ||
             L_lst + tot_o >= (1ull << 32) || L_lst + tot_q >= (1ull << 32))                  // (line indices are 32 bits)
             return L_nnl ? decide(a, allow_minor, false, stream, partial) : decide(a, false, false, stream, partial);
     }
@@ -712,7 +714,7 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
         mb.planes = a->planes; mb.minor_mask = mask_of(M_MINOR); mb.nnl_mask = mask_of(M_NNL); mb.lst_mask = mask_of(lst_slot);
         mb.ref_x = mask_of(M_REFX); mb.ref_y = mask_of(M_REFY); mb.un_mask = mask_of(M_UN); mb.off_lst = off_of(lst_slot);
         mb.cntP = cntP; mb.cntN = cntN; mb.baseP = off64; mb.baseO = off64 + (size_t)ovf_slot * groups; mb.flags = flags; mb.flag_words = flag_words;
-        mb.sites = L_lst; mb.tot_p = tot_p; mb.tot_o = tot_o; mb.tot_nnl = tot_nnl; mb.baseQ = off64 + 6 * groups; mb.tot_q = tot_q;
+        mb.sites = L_lst; mb.tot_p = tot_p; mb.tot_o = tot_o; mb.tot_nnl = tot_nnl; mb.baseQ = off64 + 6 * groups; mb.tot_q = tot_q; mb.long_p = long_p ? 1 : 0;
         mb.n_rows = a->n_row_hint;
         for (int k = 0; k < 4; k++) mb.rows[k] = (unsigned)std::min<size_t>(a->row_hint[k], a->n);
         rc = minority_lists_build(a, mb, stream, &built);

@@ -33,7 +33,8 @@ struct SiteLists {
     uint4 *lines = nullptr;                    // n8 lines: [0, sites) primary, then each group's overflow block
     unsigned long long n_lines = 0;
     unsigned long long *p_off = nullptr;       // [sites + 1]
-    uint4 *qlines = nullptr;                   // the p lists as "q lines" of 32 dwords: the site of rank r owns line r -- dword 0 its header
+    unsigned *p_ent = nullptr;                 // p lists of at most P_SHORT_MAX samples (the usual case: one or two): p_ent[p_off[r] ..]
+    uint4 *qlines = nullptr;                   // the longer p lists as "q lines" of 32 dwords: the site of rank r owns line r -- dword 0 its header
                                                //   (k | w1 << 16: listed samples, and how many of them, at the front, have w = 1: a listed sample
                                                //   whose mask contains the reference base only ever pairs up with those), dwords 1..30 its first
                                                //   entries (sample << 5 | w << 4 | mask), dword 31 the index of its first overflow line; overflow
@@ -53,6 +54,7 @@ struct SiteLists {
     int n_rows = 0;
 };
 constexpr int ENT_SHIFT = 5;                   // entries: index << 5 | w << 4 | 4-bit allele mask
+constexpr unsigned ENT_LONG = 0x80000000u;     // per-sample entries: the site's p list is a q line (ranks stay below 2^26)
 
 __device__ __forceinline__ unsigned word_of(const uint4 &v, int w) { return w == 0 ? v.x : w == 1 ? v.y : w == 2 ? v.z : v.w; }
 
@@ -117,13 +119,16 @@ struct N8Encoder {
 };
 
 __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBuild mb, size_t n_pad, unsigned n,
-                                                         unsigned long long *__restrict__ p_off, unsigned *__restrict__ qd,
-                                                         uint2 *__restrict__ E, uint4 *__restrict__ lines,
+                                                         unsigned long long *__restrict__ p_off, unsigned *__restrict__ p_ent,
+                                                         unsigned *__restrict__ qd, uint2 *__restrict__ E, uint4 *__restrict__ lines,
                                                          unsigned *__restrict__ cnt, unsigned *__restrict__ c_p)
 {
     __shared__ unsigned bm[SITES_PER_GROUP * BM_STRIDE];     // the piece's N bits, site-major: bm[site * BM_STRIDE + 32-sample word]
-    __shared__ unsigned cn[SITES_PER_GROUP], kp[SITES_PER_GROUP], ovf[SITES_PER_GROUP], curP[SITES_PER_GROUP], curQ[SITES_PER_GROUP], rk[SITES_PER_GROUP];
+    // (LDS decides how many of these workgroups a CU holds -- seven at 22.5 KB --: ovf is only read while the sites' bases are summed and
+    // serves as the back cursor of the p lists afterwards; a site's own N count lives in its thread)
+    __shared__ unsigned kp[SITES_PER_GROUP], ovf[SITES_PER_GROUP], curP[SITES_PER_GROUP], rk[SITES_PER_GROUP];
     __shared__ unsigned qb[SITES_PER_GROUP];                 // first overflow line of the site's p list
+    unsigned *const curQ = ovf;
     __shared__ unsigned long long bP[SITES_PER_GROUP];
     __shared__ unsigned short queue[PIECE_SAMPLES];          // the piece's samples with listed sites in this group (offsets into the piece)
     __shared__ unsigned qn[2];                               // (by parity of the piece: the other one is reset while this one is read)
@@ -139,12 +144,12 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
     static_assert(SITE_THREADS == SITES_PER_GROUP, "thread = site");
     const int tw = tid >> 5, tb = tid & 31;
     const bool mine = (m[tw] >> tb) & 1u;
+    const unsigned my_cn = mine ? mb.cntN[g * SITES_PER_GROUP + tid] : 0u;
     {
-        const unsigned c = mine ? mb.cntN[g * SITES_PER_GROUP + tid] : 0u;
-        cn[tid] = c;
+        const unsigned c = my_cn;
         kp[tid] = (mine && ((mp[tw] >> tb) & 1u)) ? mb.cntP[g * SITES_PER_GROUP + tid] : 0u;
         ovf[tid] = mine ? n8_lines_max(c, n) - 1u : 0u;
-        curP[tid] = 0; curQ[tid] = 0;
+        curP[tid] = 0;
         if (tid < 2) qn[tid] = 0;
     }
     __syncthreads();
@@ -159,10 +164,11 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
         qb[tid] = (unsigned)(mb.sites + mb.baseQ[g] + pq);
         p_off[rank] = bP[tid];
         enc.line = rank;
-        enc.left = cn[tid];
+        enc.left = my_cn;
         enc.next_ovf = (unsigned)(mb.sites + mb.baseO[g] + po);
     }
     __syncthreads();
+    curQ[tid] = 0;                                           // (first used behind the piece loop's barrier)
     const uint4 RX = mb.ref_x[g], RY = mb.ref_y[g];
     const uint4 *base = mb.planes + (g * NPLANES) * n_pad;
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
@@ -234,10 +240,15 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
                     // the site's w = 1 entries from the front of its run, the others from the back
                     const unsigned slot = (code & 16u) ? atomicAdd(&curP[w * 32 + b], 1u) : kp[w * 32 + b] - 1u - atomicAdd(&curQ[w * 32 + b], 1u);
                     const unsigned long long pos = bP[w * 32 + b] + slot;
-                    // entry `slot` of the site's list: dword slot + 1 of its q lines (31 dwords a line; dword 0 of the list is the header)
-                    const unsigned qs = slot + 1u, qt = qs / 31u;
-                    qd[(size_t)(qt ? qb[w * 32 + b] + qt - 1u : rk[w * 32 + b]) * 32 + (qs - qt * 31u)] = (s << ENT_SHIFT) | code;
-                    E[pos] = make_uint2(s, (rk[w * 32 + b] << ENT_SHIFT) | code);
+                    const bool is_long = kp[w * 32 + b] > P_SHORT_MAX;
+                    if (is_long) {
+                        // entry `slot` of the site's list: dword slot + 1 of its q lines (31 dwords a line; dword 0 of the list is the header)
+                        const unsigned qs = slot + 1u, qt = qs / 31u;
+                        qd[(size_t)(qt ? qb[w * 32 + b] + qt - 1u : rk[w * 32 + b]) * 32 + (qs - qt * 31u)] = (s << ENT_SHIFT) | code;
+                    } else {
+                        p_ent[pos] = (s << ENT_SHIFT) | code;
+                    }
+                    E[pos] = make_uint2(s, (is_long ? ENT_LONG : 0u) | (rk[w * 32 + b] << ENT_SHIFT) | code);
                     listed++; listed_w += code >> 4;
                 }
             }
@@ -245,7 +256,7 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
             if (listed_w) atomicAdd(&c_p[s], listed_w);
         }
         // ---- the site's thread: its 32 words of the piece in order (four independent reads at a time), every set bit a sample
-        if (mine && cn[tid] != 0u) {
+        if (mine && my_cn != 0u) {
             // (one loop over the lane's own set bits: the wave runs as many rounds as its busiest lane has samples in the piece --
             // word by word it ran the busiest lane of every word, four times as many)
             static_assert(PIECE_WORDS == 32, "one bit per word of the piece");
@@ -280,7 +291,7 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
     }
     if (mine) {
         enc.finish();
-        if (kp[tid]) { qd[(size_t)rk[tid] * 32] = kp[tid] | (curP[tid] << 16); qd[(size_t)rk[tid] * 32 + 31] = qb[tid]; }
+        if (kp[tid] > P_SHORT_MAX) { qd[(size_t)rk[tid] * 32] = kp[tid] | (curP[tid] << 16); qd[(size_t)rk[tid] * 32 + 31] = qb[tid]; }
     }
 }
 
@@ -682,6 +693,7 @@ __global__ __launch_bounds__(TRACS_NN_THREADS) void nn_rows_kernel(const uint4 *
 // Negative terms wrap in the unsigned row and cancel in the final sum.
 template <bool CLAMP>
 __global__ __launch_bounds__(1024) void minor_fixup_kernel(const unsigned long long *__restrict__ s_off, const unsigned *__restrict__ s_ent,
+                                                           const unsigned long long *__restrict__ p_off, const unsigned *__restrict__ p_ent,
                                                            const unsigned *__restrict__ qd,
                                                            const uint4 *__restrict__ lines, const unsigned *__restrict__ c_p, unsigned n,
                                                            unsigned row_begin, unsigned row_end, unsigned col_begin, unsigned chunk,
@@ -757,8 +769,25 @@ __global__ __launch_bounds__(1024) void minor_fixup_kernel(const unsigned long l
         for (unsigned long long base = e0 + (unsigned long long)wave * 64; base < e1; base += (unsigned long long)nwaves * 64) {
             const unsigned long long e = base + lane;
             const unsigned ent = e < e1 ? s_ent[e] : 0u;
+            const bool is_long = (ent & ENT_LONG) != 0u;
+            const unsigned rank = (ent & ~ENT_LONG) >> ENT_SHIFT;
+            if (e < e1 && !is_long) {
+                // a list of at most P_SHORT_MAX samples (the usual case: one or two) stays in the lane that found it
+                const unsigned long long pa = p_off[rank], pz = p_off[rank + 1];
+                const unsigned mx = ent & 15u;
+                const int wx = (int)((ent >> 4) & 1u);
+                unsigned v[P_SHORT_MAX];
+#pragma unroll
+                for (unsigned m = 0; m < P_SHORT_MAX; m++) v[m] = pa + m < pz ? p_ent[pa + m] : 0xFFFFFFFFu;
+#pragma unroll
+                for (unsigned m = 0; m < P_SHORT_MAX; m++) {
+                    const unsigned j = v[m] >> ENT_SHIFT;
+                    const int add = (((v[m] & 15u) & mx) == 0u ? 1 : 0) - wx - (int)((v[m] >> 4) & 1u);
+                    if (v[m] != 0xFFFFFFFFu && add != 0 && j >= up0 && j < up1) atomicAdd(&row[j - c0], (unsigned)add);
+                }
+            }
             while (rcount > LINE_RING - 64u - 16u) { wave_sync(); round(); }
-            push(e < e1, ent >> ENT_SHIFT, ent & 31u);
+            push(e < e1 && is_long, rank, ent & 31u);
         }
         while (rcount) { wave_sync(); round(); }
         wave_sync();
@@ -772,7 +801,7 @@ __global__ __launch_bounds__(1024) void minor_fixup_kernel(const unsigned long l
             const unsigned long long e = base + lane;
             const unsigned ent = e < e1 ? s_ent[e] : 0u;
             W.drain_lines_to(31);
-            W.push_line(e < e1 && (ent & 16u), ent >> ENT_SHIFT);
+            W.push_line(e < e1 && (ent & 16u), (ent & ~ENT_LONG) >> ENT_SHIFT);
         }
         W.finish();
     }
@@ -826,7 +855,7 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb_, hipStream_t 
     minority_lists_free(a);
     MinorBuild mb = mb_;
     const size_t n = a->n, L = mb.sites, groups = a->groups;
-    if (L == 0 || L >= (1ull << 27) || n >= (1ull << 27)) return TRACS_OK;           // entries hold rank << 5 / sample << 5
+    if (L == 0 || L >= (1ull << 26) || n >= (1ull << 27)) return TRACS_OK;           // entries hold rank << 5 (+ a flag bit) / sample << 5
     auto *g = new SiteLists();
     auto fail_soft = [&]() { (void)hipGetLastError(); delete g; return TRACS_OK; };
 #define SL_TRY(x) do { if ((x) != hipSuccess) return fail_soft(); } while (0)
@@ -837,7 +866,8 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb_, hipStream_t 
     g->tgroups = (groups + 7) / 8 * 8;
     SL_TRY(pack_alloc(a, (g->n_lines + 1) * 128, reinterpret_cast<void **>(&g->lines)));
     SL_TRY(pack_alloc(a, (L + 1) * 8, reinterpret_cast<void **>(&g->p_off)));
-    g->n_qlines = mb.tot_p ? (unsigned long long)L + mb.tot_q : 0ull;
+    SL_TRY(pack_alloc(a, std::max<size_t>(mb.tot_p, 1) * 4, reinterpret_cast<void **>(&g->p_ent)));
+    g->n_qlines = mb.long_p ? (unsigned long long)L + mb.tot_q : 0ull;
     SL_TRY(pack_alloc(a, (g->n_qlines + 1) * 128, reinterpret_cast<void **>(&g->qlines)));
     SL_TRY(pack_alloc(a, (n + 1) * 8, reinterpret_cast<void **>(&g->s_off)));
     SL_TRY(pack_alloc(a, std::max<size_t>(mb.tot_p, 1) * 4, reinterpret_cast<void **>(&g->s_ent)));
@@ -857,7 +887,7 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb_, hipStream_t 
     SL_TRY(hipMemcpyAsync(g->lst_mask, mb.lst_mask, groups * sizeof(uint4), hipMemcpyDeviceToDevice, stream));
     SL_TRY(hipMemcpyAsync(g->off_lst, mb.off_lst, groups * sizeof(unsigned), hipMemcpyDeviceToDevice, stream));
     const double plane_b = (double)groups * (double)a->n_pad * sizeof(uint4);      // the N plane
-    hipLaunchKernelGGL(site_lists_kernel, dim3((unsigned)groups), dim3(SITE_THREADS), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off, reinterpret_cast<unsigned *>(g->qlines), E, g->lines, cnt, g->c_p);
+    hipLaunchKernelGGL(site_lists_kernel, dim3((unsigned)groups), dim3(SITE_THREADS), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off, g->p_ent, reinterpret_cast<unsigned *>(g->qlines), E, g->lines, cnt, g->c_p);
     pack_stage_mark("lists: per site", stream, plane_b + (double)groups * SITES_PER_GROUP * 8.0,
                     (double)L * 128.0 + (double)mb.tot_p * 12.0 + (double)L * 8.0 + (double)(mb.tot_q + std::min<unsigned long long>(L, mb.tot_p)) * 8.0);
     const unsigned egrid = (unsigned)((mb.tot_p + 255) / 256);
@@ -970,10 +1000,10 @@ int minority_fixup(tracs_alignment *a, size_t row_begin, size_t row_end, size_t 
     if (rc) return rc;
     const dim3 grid((unsigned)(n - row_begin), (unsigned)((n + chunk - 1) / chunk));
     if (grid.y == 1)
-        hipLaunchKernelGGL(minor_fixup_kernel<false>, grid, dim3(1024), lds, stream, g->s_off, g->s_ent, reinterpret_cast<const unsigned *>(g->qlines), g->lines, g->c_p, (unsigned)n,
+        hipLaunchKernelGGL(minor_fixup_kernel<false>, grid, dim3(1024), lds, stream, g->s_off, g->s_ent, g->p_off, g->p_ent, reinterpret_cast<const unsigned *>(g->qlines), g->lines, g->c_p, (unsigned)n,
                            (unsigned)row_begin, (unsigned)row_end, (unsigned)col_begin, chunk, dist, ld, S, s_pitch);
     else
-        hipLaunchKernelGGL(minor_fixup_kernel<true>, grid, dim3(1024), lds, stream, g->s_off, g->s_ent, reinterpret_cast<const unsigned *>(g->qlines), g->lines, g->c_p, (unsigned)n,
+        hipLaunchKernelGGL(minor_fixup_kernel<true>, grid, dim3(1024), lds, stream, g->s_off, g->s_ent, g->p_off, g->p_ent, reinterpret_cast<const unsigned *>(g->qlines), g->lines, g->c_p, (unsigned)n,
                            (unsigned)row_begin, (unsigned)row_end, (unsigned)col_begin, chunk, dist, ld, S, s_pitch);
     const dim3 tgrid((unsigned)((n - row_begin + 31) / 32), (unsigned)((row_end - row_begin + 31) / 32));
     hipLaunchKernelGGL(transpose_add_kernel, tgrid, dim3(256), 0, stream, S, s_pitch, (unsigned)n, (unsigned)row_begin, (unsigned)row_end,
@@ -989,7 +1019,7 @@ extern "C" {
 // Diagnostics (tests/test_gpu_lists.py): the lists of an alignment on site classes, copied to the host.
 //   what 0  sizes: out64[0..7] = sites with lists, lines, p entries, tgroups, groups, bitmap present, n, the most N sites of a sample
 //   what 1  lines (n_lines x 128 bytes)     what 2  lst_mask (groups x 16 bytes)     what 3  off_lst (groups x 4 bytes)
-//   what 4  p_off ((sites + 1) x 8)          (5: gone with p_ent)                     what 6  s_off ((n + 1) x 8)
+//   what 4  p_off ((sites + 1) x 8)          what 5  p_ent (tot_p x 4: short lists)   what 6  s_off ((n + 1) x 8)
 //   what 7  s_ent (tot_p x 4)                what 8  T (n x tgroups x 16)             what 9  c_p (n x 4)
 //   what 10 q lines (n_qlines x 128: the p lists)     what 11 out64[0] = n_qlines
 // Returns the bytes copied (what >= 1), 0 when the lists do not exist or `cap` is too small.
@@ -1011,6 +1041,7 @@ size_t tracs_debug_lists(const tracs_alignment *a, int what, void *out, size_t c
     case 2: src = g->lst_mask; bytes = g->groups * 16; break;
     case 3: src = g->off_lst; bytes = g->groups * 4; break;
     case 4: src = g->p_off; bytes = (g->sites + 1) * 8; break;
+    case 5: src = g->p_ent; bytes = g->tot_p * 4; break;
     case 6: src = g->s_off; bytes = (a->n + 1) * 8; break;
     case 7: src = g->s_ent; bytes = g->tot_p * 4; break;
     case 8: src = g->T; bytes = g->T ? a->n * g->tgroups * 16 : 0; break;
