@@ -257,11 +257,14 @@ print("RCCL C ABI OK")
     assert out.returncode == 0 and "RCCL C ABI OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
-@pytest.mark.parametrize("mode", ["plain", "thresholded+db", "thresholded+filter+db"])
+@pytest.mark.parametrize("mode", ["plain", "thresholded+db", "thresholded+filter+db", "empty+db"])
 def test_distance_cli_two_ranks_equals_one(mode, tmp_path):
     """`tracs distance --gpus 2` (one process per rank; two gloo ranks sharing the GPU here) writes byte for byte the CSV of the
     single-GPU run: site shards (every rank counts all pairs over its slice of the sites, the sums arrive as row panels) in the
-    first two modes, the row-chunk partition of the pair matrix with --filter."""
+    first two modes, the row-chunk partition of the pair matrix with --filter; an EMPTY first file against a database (no row to compare:
+    the header alone, from both).  The single-GPU leg takes the array path as the ranks do (TRACS_DISTANCE_ARRAYS: the same exp() for
+    P(direct); the device-resident path of the single-GPU command is compared with it, and with the reference's CSVs, in
+    tests/test_gpu_golden.py::test_cli_end_to_end_vs_reference_driver)."""
     import subprocess
     from tracs_amd import synth
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -269,24 +272,28 @@ def test_distance_cli_two_ranks_equals_one(mode, tmp_path):
     seqs = synth.alignment(n, L, seed=31, mu_lineage=3e-3, mu_sample=4e-4, p_n=0.02, p_partial=0.003)
     names = ["s%03d" % i for i in range(n)]
     fa = tmp_path / "aln_combined.fasta"
-    synth.write_fasta(str(fa), seqs[:150], names=names[:150])
+    if mode == "empty+db":
+        fa.write_text("")
+    else:
+        synth.write_fasta(str(fa), seqs[:150], names=names[:150])
     db = tmp_path / "db.fasta"
     synth.write_fasta(str(db), seqs[150:], names=names[150:])
     iso, _ = synth.dates(n, seed=31, span_days=300)
     meta = tmp_path / "dates.csv"
     meta.write_text("name,date\n" + "".join("%s,%s\n" % (a, b) for a, b in zip(names, iso)))
     extra = {"plain": [], "thresholded+db": ["-D", "200", "--msa-db", str(db), "-K", "400"],
-             "thresholded+filter+db": ["-D", "200", "--filter", "--msa-db", str(db), "-K", "400"]}[mode]
+             "thresholded+filter+db": ["-D", "200", "--filter", "--msa-db", str(db), "-K", "400"],
+             "empty+db": ["--msa-db", str(db)]}[mode]
     outs = []
     for gpus in (1, 2):
         out = tmp_path / ("out%d.csv" % gpus)
-        env = dict(os.environ, TRACS_DIST_BACKEND="gloo")
+        env = dict(os.environ, TRACS_DIST_BACKEND="gloo", TRACS_DISTANCE_ARRAYS="1")
         rc = subprocess.run([sys.executable, "-m", "tracs_amd", "distance", "--msa", str(fa), "--meta", str(meta), "-o", str(out),
                              "--gpus", str(gpus)] + extra, capture_output=True, text=True, cwd=root, env=env, timeout=600)
         assert rc.returncode == 0, rc.stdout[-2000:] + rc.stderr[-3000:]
         outs.append(open(out).read())
     assert outs[0] == outs[1]
-    assert outs[0].count("\n") > (1000 if mode == "plain" else 100)
+    assert outs[0].count("\n") > (1000 if mode == "plain" else 100) or (mode == "empty+db" and outs[0].count("\n") == 1)
 
 
 def test_general_path_beyond_one_lds_row(dev, oracle):
