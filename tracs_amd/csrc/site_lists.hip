@@ -88,20 +88,28 @@ struct N8Encoder {
     uint4 *lines;
     unsigned line, next_ovf, fill, prev;
     unsigned left;                             // samples of the site still to come
-    unsigned a0, a1, a2, a3;                   // the pending bytes, shifted in from the top
+    unsigned a0, a1, a2, a3, a4;               // the last 20 bytes, shifted in from the top
     static constexpr unsigned DONE = 0xFFFFu;  // fill once the list has left with its last line
-    // one byte; `more`: something of the list follows it (a skip byte, or a sample's byte with samples still to come).  One store
-    // site for both kinds of piece -- a full 16 bytes, and the line's last 12 with the index of the line that goes on -- : the
-    // wave runs it whenever one of its 64 sites stores, i.e. nearly every time, so it is run once per byte, not twice
-    __device__ __forceinline__ void put(unsigned b, bool more)
+    static __device__ __forceinline__ unsigned funnel(unsigned hi, unsigned lo, unsigned bits) { return (unsigned)((((unsigned long long)hi << 32) | lo) >> bits); }
+    // r (1 .. 4) bytes at once, the first in the low bits of nb, r <= N8_PAYLOAD - fill: the window moves r bytes, and when that
+    // crosses a 16-byte boundary of the line (or fills it) the piece behind the boundary is cut out of the window and stored -- at
+    // most one store per call.  `more`: something of the list follows these bytes (the rest of a sample's skip run and its own byte,
+    // or samples still to come).  Round 4 shifted, tested and stored once per BYTE: ~80 instructions a byte, of which the bytes
+    // themselves were 25; four bytes a call bring that to ~35 a byte (the wave runs as many calls as its busiest site has bytes / 4).
+    __device__ __forceinline__ void append(unsigned nb, unsigned r, bool more)
     {
-        a0 = __builtin_amdgcn_alignbit(a1, a0, 8); a1 = __builtin_amdgcn_alignbit(a2, a1, 8); a2 = __builtin_amdgcn_alignbit(a3, a2, 8);
-        a3 = (a3 >> 8) | (b << 24);
-        fill++;
+        const unsigned sh = 8u * r;
+        a0 = funnel(a1, a0, sh); a1 = funnel(a2, a1, sh); a2 = funnel(a3, a2, sh); a3 = funnel(a4, a3, sh); a4 = funnel(nb, a4, sh);
+        const unsigned old = fill;
+        fill += r;
         const bool full = fill == N8_PAYLOAD;
-        if ((fill & 15u) == 0u || full) {
-            const unsigned nx = more ? next_ovf : N8_NONE;
-            lines[(size_t)line * 8 + (full ? 7u : (fill >> 4) - 1u)] = full ? make_uint4(a1, a2, a3, nx) : make_uint4(a0, a1, a2, a3);
+        if ((old >> 4) != (fill >> 4) || full) {
+            // a piece that ended x = fill mod 16 bytes ago: bytes [4 - x, 20 - x) of the window; the line's last piece: its last 12 bytes
+            // and the index of the line that goes on
+            const unsigned s2 = 32u - 8u * (fill & 15u);
+            const uint4 piece = full ? make_uint4(a2, a3, a4, more ? next_ovf : N8_NONE)
+                                     : make_uint4(funnel(a1, a0, s2), funnel(a2, a1, s2), funnel(a3, a2, s2), funnel(a4, a3, s2));
+            lines[(size_t)line * 8 + (full ? 7u : (fill >> 4) - 1u)] = piece;
             if (full) {
                 if (more) { line = next_ovf++; fill = 0; }
                 else fill = DONE;
@@ -112,7 +120,7 @@ struct N8Encoder {
     {
         if (fill == DONE) return;              // (the list ended with the last byte of a line)
         const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-        while ((fill & 15u) != 0u && fill != DONE) put(0xFFu, false);          // the piece under way (at 124 bytes: the line's last)
+        while ((fill & 15u) != 0u && fill != DONE) append(0xFFu, 1u, false);          // the piece under way (at 124 bytes: the line's last)
         if (fill == DONE) return;
         for (unsigned q = fill >> 4; q < 8u; q++) lines[(size_t)line * 8 + q] = ones;     // (the last: padding + N8_NONE)
     }
@@ -154,7 +162,7 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
     }
     __syncthreads();
     const Transpose32 transpose(lane);
-    N8Encoder enc{lines, 0u, 0u, 0u, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
+    N8Encoder enc{lines, 0u, 0u, 0u, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u, 0u};
     if (mine) {
         unsigned long long pp = 0;
         unsigned po = 0, pq = 0;
@@ -264,27 +272,37 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
             unsigned nz = 0;
 #pragma unroll
             for (unsigned c = 0; c < PIECE_WORDS; c++) nz |= (rowp[c] != 0u ? 1u : 0u) << c;
-            // one byte per round: a sample whose gap needs skip bytes stays for as many rounds (the wave runs the encoder once per
-            // round whatever the lanes emit)
+            // up to four bytes per round (a sample whose gap needs skip bytes -- 253 each -- takes as many bytes): the wave runs as many
+            // rounds as its busiest site has bytes in the piece, divided by four
             unsigned w = 0, c = 0, gap = 0;
             bool have = false;
             for (;;) {
-                if (!have) {
-                    if (w == 0u) {
-                        if (nz == 0u) break;
-                        c = __ffs(nz) - 1; nz &= nz - 1;
-                        w = rowp[c];
+                unsigned nb = 0, r = 0;
+                const unsigned cap = min(4u, N8_PAYLOAD - enc.fill);       // (a call never crosses the end of a line)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if (r < cap) {
+                        if (!have) {
+                            if (w == 0u && nz != 0u) { c = __ffs(nz) - 1; nz &= nz - 1; w = rowp[c]; }
+                            if (w != 0u) {
+                                const unsigned b = __ffs(w) - 1;
+                                w &= w - 1;
+                                const unsigned smp = piece + 32u * c + b;
+                                gap = smp - enc.prev;      // (prev = 0xFFFFFFFF before the first: smp + 1)
+                                enc.prev = smp; enc.left--;
+                                have = true;
+                            }
+                        }
+                        if (have) {
+                            const bool skip = gap >= N8_SKIP;
+                            nb |= (skip ? N8_SKIP : gap) << (8u * r);
+                            r++;
+                            if (skip) gap -= N8_SKIP; else have = false;
+                        }
                     }
-                    const unsigned b = __ffs(w) - 1;
-                    w &= w - 1;
-                    const unsigned smp = piece + 32u * c + b;
-                    gap = smp - enc.prev;      // (prev = 0xFFFFFFFF before the first: smp + 1)
-                    enc.prev = smp; enc.left--;
-                    have = true;
                 }
-                const bool skip = gap >= N8_SKIP;
-                enc.put(skip ? N8_SKIP : gap, skip || enc.left != 0u);
-                if (skip) gap -= N8_SKIP; else have = false;
+                if (r == 0u) break;
+                enc.append(nb, r, have || enc.left != 0u);
             }
         }
         __syncthreads();
