@@ -227,6 +227,44 @@ def test_cli_end_to_end_vs_reference_driver(api, golden_dir, tmp_path, monkeypat
     cluster._ids.clear()
 
 
+def test_cli_device_path_in_small_batches_equals_array_path(api, tmp_path):
+    """The device-resident path of `tracs distance` (tracs_distance_run) with its device-to-host batches cut to 1 000 rows -- 20 of
+    them, two in flight -- against the array path on the same alignment: the same rows in the same order; SNP distance, compared
+    sites, names and date difference identical as text, P(direct) and E(K) to 10^-12 (exp on the device / in numpy).  With a SNP
+    threshold and -K, with a database file, and without metadata."""
+    import subprocess
+    from tracs_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n, L = 203, 20000
+    seqs = synth.alignment(n, L, seed=37, mu_lineage=3e-3, mu_sample=4e-4, p_n=0.02, p_partial=0.003)
+    names = ["s%03d" % i for i in range(n)]
+    fa, db, meta = tmp_path / "aln_combined.fasta", tmp_path / "db.fasta", tmp_path / "dates.csv"
+    synth.write_fasta(str(fa), seqs[:150], names=names[:150])
+    synth.write_fasta(str(db), seqs[150:], names=names[150:])
+    iso, _ = synth.dates(n, seed=37, span_days=300)
+    meta.write_text("name,date\n" + "".join("%s,%s\n" % (a, b) for a, b in zip(names, iso)))
+    for tag, extra in (("meta", ["--meta", str(meta)]), ("thr", ["--meta", str(meta), "-D", "150", "-K", "300", "--msa-db", str(db)]), ("nometa", [])):
+        outs = {}
+        for path in ("device", "arrays"):
+            out = tmp_path / ("%s_%s.csv" % (tag, path))
+            env = dict(os.environ, TRACS_DISTANCE_BATCH_ROWS="1000")
+            if path == "arrays":
+                env["TRACS_DISTANCE_ARRAYS"] = "1"
+            rc = subprocess.run([sys.executable, "-m", "tracs_amd", "distance", "--msa", str(fa), "-o", str(out), "--loglevel", "ERROR"] + extra,
+                                capture_output=True, text=True, cwd=root, env=env, timeout=600)
+            assert rc.returncode == 0, rc.stdout[-2000:] + rc.stderr[-3000:]
+            outs[path] = open(out).read().split("\n")
+        a, b = outs["device"], outs["arrays"]
+        assert len(a) == len(b) and a[0] == b[0] and len(a) > (10000 if tag == "meta" else 300)
+        for x, y in zip(a[1:], b[1:]):
+            if x == y:
+                continue
+            fx, fy = x.split(","), y.split(",")
+            assert fx[:4] == fy[:4] and fx[6:] == fy[6:], (x, y)
+            for c in (4, 5):
+                assert abs(float(fx[c]) - float(fy[c])) <= 1e-12 * abs(float(fy[c])) + 1e-300, (x, y)
+
+
 def test_drop_in_module_names():
     import TRACS
     for f in ("pairsnp", "trans_dist", "lprob_k_given_N", "calculate_posteriors"):

@@ -10,7 +10,6 @@
 #include <algorithm>
 #include <chrono>
 #include <csignal>
-#include <sys/mman.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -206,22 +205,11 @@ int tracs_alignment_from_fasta(const char *const *fasta, int n_fasta, tracs_alig
     clock.mark("allocate planes + arena");
     // pack in sample batches of <= 1 GiB of ASCII
     const size_t batch = fd.L ? std::max<size_t>(1, (1ull << 30) / fd.L) : fd.n;
-    // The host copy of the text (n L bytes: 5 GB at 10 000 x 500 kbp) goes back to the system batch by batch, on a helper thread, while
-    // the next batch travels: giving a few million touched pages back takes a few tenths of a second -- paid all at once after the
-    // last batch (or at process exit) it was 0.25 s of the command; released beside the row writer it slowed that down instead.
-    std::thread releaser;
     for (size_t s = 0; s < fd.n && fd.L; s += batch) {
         const size_t cnt = std::min(batch, fd.n - s);
         rc = tracs_alignment_pack(a, fd.seq.data() + s * fd.L, s, cnt, 0, nullptr);
-        if (releaser.joinable()) releaser.join();
         if (rc) { tracs_alignment_free(a); return rc; }
-        uint8_t *b0 = fd.seq.data() + s * fd.L, *b1 = b0 + cnt * fd.L;
-        releaser = std::thread([b0, b1]() {
-            const uintptr_t page = 4096, lo = (reinterpret_cast<uintptr_t>(b0) + page - 1) & ~(page - 1), hi = reinterpret_cast<uintptr_t>(b1) & ~(page - 1);
-            if (hi > lo) (void)madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_DONTNEED);
-        });
     }
-    if (releaser.joinable()) releaser.join();
     clock.mark("H2D + pack", (double)fd.n * (double)fd.L);
     if (names_out) {
         size_t bytes = 0;
@@ -429,7 +417,8 @@ int tracs_distance_run(tracs_distance *h, int dist, const int32_t *days, double 
     const size_t i_end = h->n_fasta == 1 ? n : h->n0;               // pair ranges (:348-360)
     const size_t j_start = h->n_fasta == 1 ? 0 : h->n0;
     const bool with_dates = days != nullptr;
-    constexpr size_t CH = (size_t)1 << 22;                          // rows per device-to-host batch
+    // rows per device-to-host batch (TRACS_DISTANCE_BATCH_ROWS: diagnostics -- small batches in tests)
+    static const size_t CH = [] { const char *e = std::getenv("TRACS_DISTANCE_BATCH_ROWS"); const long long v = e ? std::atoll(e) : 0; return v >= 16 ? (size_t)v : (size_t)1 << 22; }();
     unsigned *d_dist = nullptr, *d_nn = nullptr, *d_coo = nullptr;
     double *d_p = nullptr, *d_e = nullptr, *d_cp = nullptr;
     int *d_days = nullptr;
