@@ -30,7 +30,8 @@ Prints ONE JSON line (rank 0):
                     beside it (`other_kernels`, `kernels_ms`), with the class sizes (`site_classes`).  With TRACS_SITE_CLASSES=0 it is
                     the pair kernel over every site
   roofline_general  the same pass over the SAME alignment with 0.5 % partial IUPAC codes added (SURVEY.md 8d's C4 mix):
-                    one-hot matrix-core kernel + sparse partial-code correction (N = 1 only; not part of `value`)
+                    one-hot matrix-core kernel + sparse partial-code correction, with the once-per-call stages and their bytes
+                    (N = 1 only; not part of `value`; the same alignment is the `partial` leg of `sensitivity`)
   dm_frontend       counts -> posterior filter -> 4-bit codes -> packed planes for a batch of samples (SURVEY.md 8d C3's
                     "counts->posterior->code fused front-end"), timed separately (N = 1 only)
   cpu_baseline      the oracle (CPU port of the reference algorithm) on the host cores on a bounded sample of the same
@@ -861,9 +862,10 @@ def sensitivity(args, n, L, seed, days, dev, synth, torch, device, lib, value_de
         torch.cuda.synchronize()
         return first, e0.elapsed_time(e1) / 2, int(dmat.sum().item()), int(nmat.sum().item())
     out = {}
-    for name in ("lineage", "divergent", "clean", "gappy", "runs"):
+    for name in ("lineage", "divergent", "clean", "gappy", "runs", "partial"):
         a = dev.Alignment(n, L)
-        synth.pack_synthetic_device(a, seed=seed, **synth_kw(0.0, name))
+        # ("partial": the metric's alignment + 0.5 % partial IUPAC codes -- what `tracs align` writes without --consensus, tracs/align.py:616-622)
+        synth.pack_synthetic_device(a, seed=seed, **(synth_kw(P_PARTIAL_C4, "sparse") if name == "partial" else synth_kw(0.0, name)))
         first, ms, cd, cn = timed(a)
         classes, kernel, split, a_count = a.site_classes, a.kernel, pair_split_ms(lib), a.count_source
         lib.tracs_debug_force_site_classes(0)
@@ -878,7 +880,8 @@ def sensitivity(args, n, L, seed, days, dev, synth, torch, device, lib, value_de
                      "site_classes": None if classes is None else dict(zip(("dense", "counted", "minority", "full"), classes)),
                      "kernel": kernel, "kernels_ms": None if not split else dict(zip(("pair", "lists", "count", "nn_lists"), split)),
                      "count_source": a_count,
-                     "mean_d": cd / float(pairs), "checksum_d": cd, "checksum_nn": cn, "generator": WORKLOADS[name]}
+                     "mean_d": cd / float(pairs), "checksum_d": cd, "checksum_nn": cn,
+                     "generator": dict(WORKLOADS["sparse"], p_partial=P_PARTIAL_C4) if name == "partial" else WORKLOADS[name]}
     worst = min(out, key=lambda k: out[k]["pairs_per_s"])
     return {"workloads": out, "worst": worst,
             "spread": max([value_default] + [w["pairs_per_s"] for w in out.values()]) / min([value_default] + [w["pairs_per_s"] for w in out.values()]),
@@ -912,6 +915,7 @@ def general_pass(args, n, L, seed, dev, synth, torch, device):
     c1.record()
     torch.cuda.synchronize()
     call_s = c0.elapsed_time(c1) / 1e3 / reps
+    call_stages = dev.pack_stages_bytes()                     # the once-per-call stages of the last of those calls
     from tracs_amd import _lib
     split, classes, pairs = pair_split_ms(_lib.load()), aln.site_classes, n * (n - 1) // 2
     traffic = _traffic_from_profiles(n, L, 1, aln.kernel + ("+classes" if classes else ""))
@@ -930,6 +934,7 @@ def general_pass(args, n, L, seed, dev, synth, torch, device):
         r = roofline_of(aln.kernel, "general", pairs, L, kern_s, traffic, n)
     r["dense_call_ms"] = kern_s * 1e3
     r["one_call_ms"] = call_s * 1e3                          # (pairsnp only: once-per-pack work + the dense call, no transcluster)
+    r["roofline_per_pack"] = per_pack_roofline(call_stages)
     if split:
         r["kernels_ms"] = {"pairsnp_mfma_kernel": split[0], "general_fixup_kernel (partial codes of the dense sites + minority lists)": split[1],
                            "count_pass": split[2], "nn_rows_kernel": split[3]}

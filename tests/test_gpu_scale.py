@@ -388,11 +388,11 @@ def test_bench_line_contract_small():
     assert sp["warm_ms"] >= j["ms_per_step"] * 0.8 and abs(sp["value_single_pass"] - 700 * 699 / 2 / (sp["warm_ms"] / 1e3)) < 1e-6 * sp["value_single_pass"]
     # the other workloads: classes on / off agree (bench.py exits non-zero otherwise), the worst one is beside `value`
     sw = j["sensitivity"]["workloads"]
-    assert set(sw) == {"lineage", "divergent", "clean", "gappy", "runs"}
+    assert set(sw) == {"lineage", "divergent", "clean", "gappy", "runs", "partial"}
     assert j["value_worst_workload"] <= j["value"] and j["value_worst_workload"] == min([j["value"]] + [w["pairs_per_s"] for w in sw.values()])
     assert all(o["kernel_ms"] >= 0 for o in r["other_kernels"]) and r["minority_lists_ms"] >= 0 and len(r["kernels_ms"]) == 4
     g = j["roofline_general"]
-    assert g["bound"] in ("mfma", "hbm") and g["mean_d"] > j["config"]["mean_d"]
+    assert g["bound"] in ("mfma", "hbm") and g["mean_d"] > j["config"]["mean_d"] and g["roofline_per_pack"]["per_pack_ms"] > 0
     assert j["dm_frontend"]["encoding"] in ("general", "consensus")
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["unit"] == "pairs/s" and "sample" in c
