@@ -342,11 +342,13 @@ class TriExchange:
         elif send.is_cuda and d.get_backend() == "nccl":
             d.all_to_all_single(recv, send)
         else:                                              # gloo (ranks sharing a GPU, CPU tests): P - 1 rounds of send / recv
+            # (through host tensors: gloo moves device tensors at a few tens of MB/s)
             recv[self.rank * block_bytes:(self.rank + 1) * block_bytes].copy_(send[self.rank * block_bytes:(self.rank + 1) * block_bytes])
             for k in range(1, self.world):
                 to, frm = (self.rank + k) % self.world, (self.rank - k) % self.world
-                w = d.isend(send[to * block_bytes:(to + 1) * block_bytes].contiguous(), dst=to)
-                got = torch.empty(block_bytes, dtype=torch.uint8, device=send.device)
+                out = send[to * block_bytes:(to + 1) * block_bytes].cpu().contiguous()
+                w = d.isend(out, dst=to)
+                got = torch.empty(block_bytes, dtype=torch.uint8)
                 d.recv(got, src=frm)
                 recv[frm * block_bytes:(frm + 1) * block_bytes].copy_(got)
                 w.wait()
