@@ -1,7 +1,9 @@
 #!/bin/bash
+# probe_single_pass.py for several builds (TRACS_EXTRA_HIPCC_FLAGS): usage (GPU box): bash scripts/gpu_exp_nt.sh "<flags 1>" "<flags 2>" ...
 cd "$GRAFT_REPO_ROOT" || exit 1
-for V in "" "-DTRACS_EXP_NT" ; do
+for V in "$@"; do
   echo "=== $V"
   TRACS_EXTRA_HIPCC_FLAGS="$V" python -m tracs_amd.build --force > /dev/null 2>&1 || { echo build failed; continue; }
-  timeout 600 python scripts/probe_single_pass.py 2>&1 | grep -E "stages|kernels|repeat" | tail -5
+  timeout 600 python scripts/probe_single_pass.py 2>&1 | grep -E "stages|warm2: pairsnp" | tail -2
+  N=10000 python scripts/probe_transcluster.py 1000 2>&1 | tail -1
 done

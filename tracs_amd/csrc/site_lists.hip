@@ -75,41 +75,36 @@ __device__ __forceinline__ bool row_wanted(const MinorBuild &mb, size_t s)
 
 // ---- per site: N lists (n8 lines) and p lists ---------------------------------------------------------------------------------
 // One workgroup per 128-site group.  The group's N bits are TRANSPOSED -- samples x sites, as the plane holds them, into sites x
-// samples -- through LDS, 1 024 samples (a PIECE) at a time: a wave takes 64 samples (coalesced 16-byte loads), transposes each
+// samples -- through LDS, 512 samples (a PIECE) at a time: a wave takes 64 samples (coalesced 16-byte loads), transposes each
 // 32 x 32 bit block in registers (five butterfly steps of lane exchanges: Transpose32) and writes the site-major words; then the
 // site's own thread reads its 32 words of the piece in order and feeds every set bit to its encoder -- the samples come out sorted,
 // no cursor, no atomic, no sort, and the work does not depend on how many samples are N (rounds 3-4a dropped sample numbers
 // into per-site runs through LDS cursors and sorted the runs: quadratic in the drift of the waves, 114 ms per pack at 10 % N).
 // The encoder state (last position, the line's fill, the pending 16 bytes) stays in the site thread's registers from piece to piece.
-constexpr unsigned PIECE_SAMPLES = 1024, PIECE_WORDS = PIECE_SAMPLES / 32, BM_STRIDE = PIECE_WORDS + 1;     // (odd stride: conflict-free column writes)
+// (512 samples a piece: 3.3 ms per call at 10 000 x 5 Mbp against 4.0 with 1 024 -- eight workgroups of 14 KB per CU, the registers'
+// limit, instead of seven of 22 KB --, 3.6 with 256, 4.6 with 128, 7.3 with 2 048: profiles/r05/site_lists_piece_sweep.txt)
+// ... for consensus alignments; with partial IUPAC codes (47 % of the samples of a group flagged for the p lists at 0.5 % of them)
+// the queue of flagged samples wants the longer piece: 10.9 ms with 1 024 against 13.3 with 512 -- the kernel is a template on it.
 constexpr unsigned SITE_THREADS = 128;         // one thread per site of the group: both waves busy in both phases, eight workgroups per CU (17 KiB of LDS each)
 
 struct N8Encoder {
     uint4 *lines;
     unsigned line, next_ovf, fill, prev;
     unsigned left;                             // samples of the site still to come
-    unsigned a0, a1, a2, a3, a4;               // the last 20 bytes, shifted in from the top
+    unsigned a0, a1, a2, a3;                   // the pending bytes, shifted in from the top
     static constexpr unsigned DONE = 0xFFFFu;  // fill once the list has left with its last line
-    static __device__ __forceinline__ unsigned funnel(unsigned hi, unsigned lo, unsigned bits) { return (unsigned)((((unsigned long long)hi << 32) | lo) >> bits); }
-    // r (1 .. 4) bytes at once, the first in the low bits of nb, r <= N8_PAYLOAD - fill: the window moves r bytes, and when that
-    // crosses a 16-byte boundary of the line (or fills it) the piece behind the boundary is cut out of the window and stored -- at
-    // most one store per call.  `more`: something of the list follows these bytes (the rest of a sample's skip run and its own byte,
-    // or samples still to come).  Round 4 shifted, tested and stored once per BYTE: ~80 instructions a byte, of which the bytes
-    // themselves were 25; four bytes a call bring that to ~35 a byte (the wave runs as many calls as its busiest site has bytes / 4).
-    __device__ __forceinline__ void append(unsigned nb, unsigned r, bool more)
+    // one byte; `more`: something of the list follows it (a skip byte, or a sample's byte with samples still to come).  One store
+    // site for both kinds of piece -- a full 16 bytes, and the line's last 12 with the index of the line that goes on -- : the
+    // wave runs it whenever one of its 64 sites stores, i.e. nearly every time, so it is run once per byte, not twice
+    __device__ __forceinline__ void put(unsigned b, bool more)
     {
-        const unsigned sh = 8u * r;
-        a0 = funnel(a1, a0, sh); a1 = funnel(a2, a1, sh); a2 = funnel(a3, a2, sh); a3 = funnel(a4, a3, sh); a4 = funnel(nb, a4, sh);
-        const unsigned old = fill;
-        fill += r;
+        a0 = __builtin_amdgcn_alignbit(a1, a0, 8); a1 = __builtin_amdgcn_alignbit(a2, a1, 8); a2 = __builtin_amdgcn_alignbit(a3, a2, 8);
+        a3 = (a3 >> 8) | (b << 24);
+        fill++;
         const bool full = fill == N8_PAYLOAD;
-        if ((old >> 4) != (fill >> 4) || full) {
-            // a piece that ended x = fill mod 16 bytes ago: bytes [4 - x, 20 - x) of the window; the line's last piece: its last 12 bytes
-            // and the index of the line that goes on
-            const unsigned s2 = 32u - 8u * (fill & 15u);
-            const uint4 piece = full ? make_uint4(a2, a3, a4, more ? next_ovf : N8_NONE)
-                                     : make_uint4(funnel(a1, a0, s2), funnel(a2, a1, s2), funnel(a3, a2, s2), funnel(a4, a3, s2));
-            lines[(size_t)line * 8 + (full ? 7u : (fill >> 4) - 1u)] = piece;
+        if ((fill & 15u) == 0u || full) {
+            const unsigned nx = more ? next_ovf : N8_NONE;
+            lines[(size_t)line * 8 + (full ? 7u : (fill >> 4) - 1u)] = full ? make_uint4(a1, a2, a3, nx) : make_uint4(a0, a1, a2, a3);
             if (full) {
                 if (more) { line = next_ovf++; fill = 0; }
                 else fill = DONE;
@@ -120,17 +115,19 @@ struct N8Encoder {
     {
         if (fill == DONE) return;              // (the list ended with the last byte of a line)
         const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-        while ((fill & 15u) != 0u && fill != DONE) append(0xFFu, 1u, false);          // the piece under way (at 124 bytes: the line's last)
+        while ((fill & 15u) != 0u && fill != DONE) put(0xFFu, false);          // the piece under way (at 124 bytes: the line's last)
         if (fill == DONE) return;
         for (unsigned q = fill >> 4; q < 8u; q++) lines[(size_t)line * 8 + q] = ones;     // (the last: padding + N8_NONE)
     }
 };
 
+template <unsigned PIECE_SAMPLES>
 __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBuild mb, size_t n_pad, unsigned n,
                                                          unsigned long long *__restrict__ p_off, unsigned *__restrict__ p_ent,
                                                          unsigned *__restrict__ qd, uint2 *__restrict__ E, uint4 *__restrict__ lines,
                                                          unsigned *__restrict__ cnt, unsigned *__restrict__ c_p)
 {
+    constexpr unsigned PIECE_WORDS = PIECE_SAMPLES / 32, BM_STRIDE = PIECE_WORDS + 1;     // (odd stride: conflict-free column writes)
     __shared__ unsigned bm[SITES_PER_GROUP * BM_STRIDE];     // the piece's N bits, site-major: bm[site * BM_STRIDE + 32-sample word]
     // (LDS decides how many of these workgroups a CU holds -- seven at 22.5 KB --: ovf is only read while the sites' bases are summed and
     // serves as the back cursor of the p lists afterwards; a site's own N count lives in its thread)
@@ -162,7 +159,7 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
     }
     __syncthreads();
     const Transpose32 transpose(lane);
-    N8Encoder enc{lines, 0u, 0u, 0u, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u, 0u};
+    N8Encoder enc{lines, 0u, 0u, 0u, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
     if (mine) {
         unsigned long long pp = 0;
         unsigned po = 0, pq = 0;
@@ -267,42 +264,32 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
         if (mine && my_cn != 0u) {
             // (one loop over the lane's own set bits: the wave runs as many rounds as its busiest lane has samples in the piece --
             // word by word it ran the busiest lane of every word, four times as many)
-            static_assert(PIECE_WORDS == 32, "one bit per word of the piece");
+            static_assert(PIECE_WORDS <= 64, "one bit per word of the piece");
             const unsigned *rowp = bm + (unsigned)tid * BM_STRIDE;
-            unsigned nz = 0;
+            unsigned long long nz = 0;
 #pragma unroll
-            for (unsigned c = 0; c < PIECE_WORDS; c++) nz |= (rowp[c] != 0u ? 1u : 0u) << c;
-            // up to four bytes per round (a sample whose gap needs skip bytes -- 253 each -- takes as many bytes): the wave runs as many
-            // rounds as its busiest site has bytes in the piece, divided by four
+            for (unsigned c = 0; c < PIECE_WORDS; c++) nz |= (unsigned long long)(rowp[c] != 0u ? 1u : 0u) << c;
+            // one byte per round: a sample whose gap needs skip bytes stays for as many rounds (the wave runs the encoder once per
+            // round whatever the lanes emit)
             unsigned w = 0, c = 0, gap = 0;
             bool have = false;
             for (;;) {
-                unsigned nb = 0, r = 0;
-                const unsigned cap = min(4u, N8_PAYLOAD - enc.fill);       // (a call never crosses the end of a line)
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    if (r < cap) {
-                        if (!have) {
-                            if (w == 0u && nz != 0u) { c = __ffs(nz) - 1; nz &= nz - 1; w = rowp[c]; }
-                            if (w != 0u) {
-                                const unsigned b = __ffs(w) - 1;
-                                w &= w - 1;
-                                const unsigned smp = piece + 32u * c + b;
-                                gap = smp - enc.prev;      // (prev = 0xFFFFFFFF before the first: smp + 1)
-                                enc.prev = smp; enc.left--;
-                                have = true;
-                            }
-                        }
-                        if (have) {
-                            const bool skip = gap >= N8_SKIP;
-                            nb |= (skip ? N8_SKIP : gap) << (8u * r);
-                            r++;
-                            if (skip) gap -= N8_SKIP; else have = false;
-                        }
+                if (!have) {
+                    if (w == 0u) {
+                        if (nz == 0ull) break;
+                        c = __ffsll((long long)nz) - 1; nz &= nz - 1;
+                        w = rowp[c];
                     }
+                    const unsigned b = __ffs(w) - 1;
+                    w &= w - 1;
+                    const unsigned smp = piece + 32u * c + b;
+                    gap = smp - enc.prev;      // (prev = 0xFFFFFFFF before the first: smp + 1)
+                    enc.prev = smp; enc.left--;
+                    have = true;
                 }
-                if (r == 0u) break;
-                enc.append(nb, r, have || enc.left != 0u);
+                const bool skip = gap >= N8_SKIP;
+                enc.put(skip ? N8_SKIP : gap, skip || enc.left != 0u);
+                if (skip) gap -= N8_SKIP; else have = false;
             }
         }
         __syncthreads();
@@ -905,7 +892,12 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb_, hipStream_t 
     SL_TRY(hipMemcpyAsync(g->lst_mask, mb.lst_mask, groups * sizeof(uint4), hipMemcpyDeviceToDevice, stream));
     SL_TRY(hipMemcpyAsync(g->off_lst, mb.off_lst, groups * sizeof(unsigned), hipMemcpyDeviceToDevice, stream));
     const double plane_b = (double)groups * (double)a->n_pad * sizeof(uint4);      // the N plane
-    hipLaunchKernelGGL(site_lists_kernel, dim3((unsigned)groups), dim3(SITE_THREADS), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off, g->p_ent, reinterpret_cast<unsigned *>(g->qlines), E, g->lines, cnt, g->c_p);
+    // (pieces of 512 samples; 1 024 when many samples per group are flagged for the p lists -- more than one listed entry per ten
+    // (sample, group) pairs: alignments with partial codes)
+    if ((double)mb.tot_p > 0.1 * (double)n * (double)groups)
+        hipLaunchKernelGGL((site_lists_kernel<1024>), dim3((unsigned)groups), dim3(SITE_THREADS), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off, g->p_ent, reinterpret_cast<unsigned *>(g->qlines), E, g->lines, cnt, g->c_p);
+    else
+        hipLaunchKernelGGL((site_lists_kernel<512>), dim3((unsigned)groups), dim3(SITE_THREADS), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off, g->p_ent, reinterpret_cast<unsigned *>(g->qlines), E, g->lines, cnt, g->c_p);
     pack_stage_mark("lists: per site", stream, plane_b + (double)groups * SITES_PER_GROUP * 8.0,
                     (double)L * 128.0 + (double)mb.tot_p * 12.0 + (double)L * 8.0 + (double)(mb.tot_q + std::min<unsigned long long>(L, mb.tot_p)) * 8.0);
     const unsigned egrid = (unsigned)((mb.tot_p + 255) / 256);
