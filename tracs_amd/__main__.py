@@ -8,9 +8,6 @@ import argparse
 import sys
 
 from . import __version__
-from .cluster import cluster_parser
-from .combine import combine_parser
-from .distance import distance_parser
 
 OUT_OF_SCOPE = ["align", "threshold", "build-db", "pipe", "plot"]
 
@@ -49,10 +46,29 @@ def main():
     parser = argparse.ArgumentParser(prog="tracs")
     parser.add_argument("--version", action="version", version="%(prog)s (tracs_amd) " + __version__)
     sub = parser.add_subparsers(title="subcommands", dest="command")
-    distance_parser(sub.add_parser("distance"))
-    cluster_parser(sub.add_parser("cluster"))
-    combine_parser(sub.add_parser("combine"))
-    align_post_parser(sub.add_parser("align-post"))
+    # (a command's module is imported when that command -- or the help -- is asked for: `tracs distance` on ten isolates is 0.4 s, of
+    # which the interpreter and the imports are most; the cluster command's numpy is not its business)
+    want = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] in ("distance", "cluster", "combine", "align-post") else None
+
+    def register(name, get):
+        if want is None or want == name:
+            get()(sub.add_parser(name))
+
+    def _distance():
+        from .distance import distance_parser
+        return distance_parser
+
+    def _cluster():
+        from .cluster import cluster_parser
+        return cluster_parser
+
+    def _combine():
+        from .combine import combine_parser
+        return combine_parser
+    register("distance", _distance)
+    register("cluster", _cluster)
+    register("combine", _combine)
+    register("align-post", lambda: align_post_parser)
     if len(sys.argv) > 1 and sys.argv[1] in OUT_OF_SCOPE:
         parser.error("'%s' is not part of the MI355X distance path; use the reference TRACS for it" % sys.argv[1])
     args = parser.parse_args()

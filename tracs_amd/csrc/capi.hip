@@ -418,7 +418,9 @@ int tracs_distance_run(tracs_distance *h, int dist, const int32_t *days, double 
     const size_t j_start = h->n_fasta == 1 ? 0 : h->n0;
     const bool with_dates = days != nullptr;
     // rows per device-to-host batch (TRACS_DISTANCE_BATCH_ROWS: diagnostics -- small batches in tests)
-    static const size_t CH = [] { const char *e = std::getenv("TRACS_DISTANCE_BATCH_ROWS"); const long long v = e ? std::atoll(e) : 0; return v >= 16 ? (size_t)v : (size_t)1 << 22; }();
+    static const size_t CH_MAX = [] { const char *e = std::getenv("TRACS_DISTANCE_BATCH_ROWS"); const long long v = e ? std::atoll(e) : 0; return v >= 16 ? (size_t)v : (size_t)1 << 22; }();
+    // (never more than the pairs there can be: ten isolates do not pin a quarter of a gigabyte of host memory)
+    const size_t CH = std::max<size_t>(64, std::min<size_t>(CH_MAX, (h->n_fasta == 1 ? h->a->n : h->n0) * h->a->n));
     unsigned *d_dist = nullptr, *d_nn = nullptr, *d_coo = nullptr;
     double *d_p = nullptr, *d_e = nullptr, *d_cp = nullptr;
     int *d_days = nullptr;

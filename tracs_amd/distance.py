@@ -11,12 +11,19 @@ import os
 import sys
 from datetime import date
 
-import numpy as np
-
 from . import _lib
-from .api import pairsnp_arrays
-from .transcluster import calculate_trans_prob
 from .utils import check_positive_float, check_positive_int
+
+
+def pairsnp_arrays(*args, **kwargs):
+    """tracs_amd.api.pairsnp_arrays, imported with numpy on first use (the array route only: --filter, --gpus N, incomplete metadata)"""
+    from .api import pairsnp_arrays as f
+    return f(*args, **kwargs)
+
+
+def calculate_trans_prob(*args, **kwargs):
+    from .transcluster import calculate_trans_prob as f
+    return f(*args, **kwargs)
 
 HEADER = ("sampleA,sampleB,date difference,SNP distance,transmission distance,expected K,"
           "filtered SNP distance,sites considered,MSA file\n")
@@ -75,6 +82,7 @@ def _read_dates(path):
 def _append_rows(path, names, rows, cols, snpd, filt, ncomp, ddiff, tdist, ek, kmax, ref):
     """CSV rows in the reference's format (:206-258), formatted and written by libtracs_hip.so's host code; floats print as
     Python's str(float).  ddiff is None without metadata; filt is None for the "NA" column."""
+    import numpy as np
     L = _lib.load()
     u64p, dp = C.POINTER(C.c_uint64), C.POINTER(C.c_double)
 
@@ -151,6 +159,7 @@ def _cli_of(args):
 
 def _pairs_multi_gpu(msas, args, ctx):
     """pairsnp's six outputs for one MSA, computed by all ranks and assembled on rank 0 (None on the others)."""
+    import numpy as np
     from . import device as dev
     from . import multigpu, partition
     dist, rank, world, device = ctx
