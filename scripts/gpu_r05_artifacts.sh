@@ -38,9 +38,10 @@ for d in ['pmc_FETCH_SIZE', 'pmc_WRITE_SIZE', 'pmc_l2']:
 PY
 cat $OUT/pmc_bench_c3.txt
 cd $GRAFT_REPO_ROOT
-TRACS_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 --steps 5 --warmup 2 > $OUT/bench_n2.log 2>&1; grep '^{' $OUT/bench_n2.log | tail -1 > $OUT/bench_n2_gloo_one_gpu.json; cut -c1-400 $OUT/bench_n2_gloo_one_gpu.json
-TRACS_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 --steps 5 --warmup 2 --partition pairs --cpu-seconds 1 > $OUT/bench_n2p.log 2>&1; grep '^{' $OUT/bench_n2p.log | tail -1 > $OUT/bench_n2_pairs_gloo_one_gpu.json; cut -c1-300 $OUT/bench_n2_pairs_gloo_one_gpu.json
+# (the N = 2 line through gloo on this box's one GPU, small: a functional record of the launch + compact exchange, not a timing)
+TRACS_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 --steps 3 --warmup 1 --samples 2000 --sites 500000 --cpu-seconds 1 > $OUT/bench_n2.log 2>&1; grep '^{' $OUT/bench_n2.log | tail -1 > $OUT/bench_n2_gloo_one_gpu_2000x500000.json; cut -c1-300 $OUT/bench_n2_gloo_one_gpu_2000x500000.json
 timeout 600 python bench.py --samples 1000 --sites 1000000 --steps 20 --warmup 5 --no-extras > $OUT/bench_c2.log 2>&1; tail -1 $OUT/bench_c2.log > $OUT/bench_c2.json; cut -c1-250 $OUT/bench_c2.json
 timeout 900 python scripts/bench_e2e.py 10000 500000 > $OUT/e2e_10000x500000.json 2> $OUT/e2e.err; cut -c1-1800 $OUT/e2e_10000x500000.json; tail -3 $OUT/e2e.err
 timeout 900 python scripts/bench_e2e.py 2000 5000000 > $OUT/e2e_2000x5000000.json 2>> $OUT/e2e.err; cut -c1-300 $OUT/e2e_2000x5000000.json
 timeout 300 python scripts/bench_e2e.py 10 100000 > $OUT/e2e_10x100000.json 2>> $OUT/e2e.err; cut -c1-300 $OUT/e2e_10x100000.json
+timeout 900 python bench.py --partial 0.005 --steps 5 --warmup 2 --no-extras --cpu-seconds 1 > $OUT/bench_partial.log 2>&1; tail -1 $OUT/bench_partial.log > $OUT/bench_partial.json; cut -c1-250 $OUT/bench_partial.json
