@@ -230,7 +230,8 @@ def test_cli_end_to_end_vs_reference_driver(api, golden_dir, tmp_path, monkeypat
 def test_cli_device_path_in_small_batches_equals_array_path(api, tmp_path):
     """The device-resident path of `tracs distance` (tracs_distance_run) with its device-to-host batches cut to 1 000 rows -- 20 of
     them, two in flight -- against the array path on the same alignment: the same rows in the same order; SNP distance, compared
-    sites, names and date difference identical as text, P(direct) and E(K) to 10^-12 (exp on the device / in numpy).  With a SNP
+    sites, names and date difference identical as text, P(direct) and E(K) to 10^-9 (exp on the device / in numpy; the dense route sums long series from per-gap
+    tables, the array route per key).  With a SNP
     threshold and -K, with a database file, and without metadata."""
     import subprocess
     from tracs_amd import synth
@@ -262,7 +263,7 @@ def test_cli_device_path_in_small_batches_equals_array_path(api, tmp_path):
             fx, fy = x.split(","), y.split(",")
             assert fx[:4] == fy[:4] and fx[6:] == fy[6:], (x, y)
             for c in (4, 5):
-                assert abs(float(fx[c]) - float(fy[c])) <= 1e-12 * abs(float(fy[c])) + 1e-300, (x, y)
+                assert abs(float(fx[c]) - float(fy[c])) <= 1e-9 * abs(float(fy[c])) + 1e-300, (x, y)
 
 
 def test_drop_in_module_names():

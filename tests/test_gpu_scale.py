@@ -296,6 +296,45 @@ def test_distance_cli_two_ranks_equals_one(mode, tmp_path):
     assert outs[0].count("\n") > (1000 if mode == "plain" else 100) or (mode == "empty+db" and outs[0].count("\n") == 1)
 
 
+def test_cli_device_path_over_several_row_panels(tmp_path):
+    """27 000 samples: the dense matrices of `tracs distance` are cut into row panels of ~9 900 rows (1 GiB per uint32 matrix) -- three
+    of them here.  The device-resident path (tracs_distance_run: transcluster and COO extraction per panel, rows in batches) writes what
+    the array path writes: the same rows in the same order (text-identical but for the last bits of P(direct): exp on the device / in
+    numpy).  A SNP threshold keeps the CSV small."""
+    import subprocess
+    from tracs_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n, L = 27000, 384
+    seqs = synth.alignment(n, L, seed=41, mu_lineage=4e-2, mu_sample=2e-3, n_lineages=400, p_n=0.01)
+    names = ["s%05d" % i for i in range(n)]
+    fa, meta = tmp_path / "big_combined.fasta", tmp_path / "dates.csv"
+    synth.write_fasta(str(fa), seqs, names=names)
+    iso, _ = synth.dates(n, seed=41, span_days=400)
+    meta.write_text("name,date\n" + "".join("%s,%s\n" % (a, b) for a, b in zip(names, iso)))
+    outs = {}
+    for path in ("device", "arrays"):
+        out = tmp_path / ("%s.csv" % path)
+        env = dict(os.environ, TRACS_DISTANCE_BATCH_ROWS="50000")
+        if path == "arrays":
+            env["TRACS_DISTANCE_ARRAYS"] = "1"
+        rc = subprocess.run([sys.executable, "-m", "tracs_amd", "distance", "--msa", str(fa), "--meta", str(meta), "-o", str(out), "-D", "3",
+                             "--loglevel", "ERROR"], capture_output=True, text=True, cwd=root, env=env, timeout=900)
+        assert rc.returncode == 0, rc.stdout[-2000:] + rc.stderr[-3000:]
+        outs[path] = open(out).read().split("\n")
+    a, b = outs["device"], outs["arrays"]
+    assert len(a) == len(b) and a[0] == b[0] and len(a) > 100000, (len(a), len(b))
+    rows_seen = set()
+    for x, y in zip(a[1:], b[1:]):
+        if x != y:
+            fx, fy = x.split(","), y.split(",")
+            assert fx[:4] == fy[:4] and fx[6:] == fy[6:], (x, y)
+            for c in (4, 5):
+                assert abs(float(fx[c]) - float(fy[c])) <= 1e-9 * abs(float(fy[c])) + 1e-300, (x, y)
+        if x:
+            rows_seen.add(int(x[1:6]) // 9900)
+    assert len(rows_seen) >= 3                                   # pairs from every panel
+
+
 def test_general_path_beyond_one_lds_row(dev, oracle):
     """33 100 samples with partial codes: the sparse correction's row no longer fits one 32 768-column LDS chunk, the sample ids
     in the per-site lists pass 2^15, and the matrix holds 5.5 x 10^8 pairs; 80 samples spread over the whole range (and all

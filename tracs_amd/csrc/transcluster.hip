@@ -485,6 +485,87 @@ __device__ __forceinline__ bool tc_eval_ratio(int N, double delta, long long gap
     return true;
 }
 
+// The same for sampling dates a day apart or less (delta = 0: the reference's closed-form branch, :163-167).  t1(k) = (N + 1) ln lamb + k ln
+// beta + lgG(N + k + 1) - lgG(N + 1) - lgG(k + 1) - (N + k + 1) ln(lamb + beta) + ln k and t2(k) = t1(k) - (N + k + 1) ln(lamb + beta):
+// both ratios are rational (r1 = beta (N + k + 1) / ((lamb + beta) k), r2 = r1 / (lamb + beta)), no table is read, and nothing of the
+// head may be skipped (t2 peaks early: its head IS its sum).  Two exponentials per lane and step.  With the default rates the t2 sum is
+// e^-4000 of the bound and the loop runs its 9 999 terms, as the reference's does.
+__device__ __forceinline__ bool tc_eval_ratio_zero(int N, const TcParams &P, const double *__restrict__ lg, double &eK, double &p0)
+{
+    if (N + 10001 >= LG_TABLE) return false;
+    const double *__restrict__ lkt = lg + LG_TABLE;
+    const double *__restrict__ invk = lg + LG_TABLE + LK_TABLE;
+    const int lane = threadIdx.x & 63;
+    const double n1 = (double)(N + 1);
+    const double lg_n1 = lg[N + 1];
+    p0 = (n1 * P.ln_lamb + 0.0 * P.ln_beta + lg_n1 - lg_n1 - lg[1] - n1 * P.ln_lb);
+    const double upper = exp(P.ln_beta + log(n1) - P.ln_lamb);
+    auto t1_at = [&](int k) {
+        const long long M = (long long)N + k;
+        return n1 * P.ln_lamb + (double)k * P.ln_beta + lg[M + 1] - lg_n1 - lg[k + 1] - (double)(M + 1) * P.ln_lb + lkt[k];
+    };
+    constexpr int FT = TRACS_TC_FT;
+    const double lb = P.lamb + P.beta;
+    const int k1 = (int)fmin(9999.0, fmax(1.0, floor(P.beta * n1 / P.lamb)));
+    const double den2 = lb * lb - P.beta;
+    const int k2 = den2 > 0.0 ? (int)fmin(9999.0, fmax(1.0, floor(P.beta * n1 / den2))) : 9999;
+    const double ref1 = t1_at(k1);
+    const double ref2 = t1_at(k2) - (double)(N + k2 + 1) * P.ln_lb;
+    const double flim = (upper - P.thr) * exp(-ref2);
+    const double qb = P.beta / lb, ilb = 1.0 / lb;
+    auto wave_prefix = [&](double e) {
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const double o = __shfl_up(e, off, 64);
+            if (lane >= off) e += o;
+        }
+        return e;
+    };
+    double S1 = 0.0, S2 = 0.0;
+    for (int k0 = 1; k0 < 10000; k0 += 64 * FT) {
+        const int kb = k0 + lane * FT;
+        double rk[FT];
+#pragma unroll
+        for (int q = 0; q < FT; q++) rk[q] = invk[kb + q < 10000 ? kb + q : 1];
+        const double t1b = kb < 10000 ? t1_at(kb) : 0.0;
+        const double e10 = kb < 10000 ? exp(t1b - ref1) : 0.0;
+        const double e20 = kb < 10000 ? exp(t1b - (double)(N + kb + 1) * P.ln_lb - ref2) : 0.0;
+        double e1 = e10, e2 = e20, r1 = 0.0, r2 = 0.0;
+#pragma unroll
+        for (int q = 0; q < FT; q++) {
+            const int k = kb + q;
+            const bool in = k < 10000;
+            r1 += in ? e1 : 0.0; r2 += in ? e2 : 0.0;
+            const double r = qb * (double)(N + k + 1) * rk[q];
+            e1 *= r; e2 *= r * ilb;
+        }
+        const double i1 = wave_prefix(r1), i2 = wave_prefix(r2);
+        const double b1 = S1 + (i1 - r1), b2 = S2 + (i2 - r2);
+        const unsigned long long m = __ballot(kb < 10000 && !(b2 + r2 < flim));
+        if (m) {
+            const int f = __ffsll((long long)m) - 1;
+            double val = 0.0;
+            if (lane == f) {
+                double a1 = b1, a2 = b2;
+                e1 = e10; e2 = e20;
+                bool found = false;
+#pragma unroll
+                for (int q = 0; q < FT; q++) {
+                    const int k = kb + q;
+                    if (k < 10000 && !found) { a1 += e1; a2 += e2; val = a1; found = !(a2 < flim); }
+                    const double r = qb * (double)(N + k + 1) * rk[q];
+                    e1 *= r; e2 *= r * ilb;
+                }
+            }
+            eK = __shfl(val, f, 64) * exp(ref1);
+            return true;
+        }
+        S1 = __shfl(b1 + r1, 63, 64); S2 = __shfl(b2 + r2, 63, 64);
+    }
+    eK = S1 * exp(ref1);                                              // ran to k = 9999
+    return true;
+}
+
 __global__ void lgamma_table_kernel(double *__restrict__ lg, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -638,7 +719,8 @@ constexpr int TC_WAVE_PREFIX_MIN = 128; // delta > 0 and N at least this: the wh
 template <class Src>
 __global__ void tc_keys_kernel(Src src, const unsigned *__restrict__ key_elem, unsigned nk, TcParams P,
                                const double *__restrict__ lg, double *__restrict__ key_p0, double *__restrict__ key_eK,
-                               unsigned *__restrict__ long_ids, unsigned *__restrict__ n_long, double *__restrict__ key_state, KeyTable kt)
+                               unsigned *__restrict__ long_ids, unsigned *__restrict__ n_long, unsigned *__restrict__ n_zero,
+                               double *__restrict__ key_state, KeyTable kt)
 {
     P.ln_lamb = log(P.lamb); P.ln_beta = log(P.beta); P.ln_lb = log(P.lamb + P.beta);
     for (unsigned id = blockIdx.x * blockDim.x + threadIdx.x; id < nk; id += gridDim.x * blockDim.x) {
@@ -653,9 +735,12 @@ __global__ void tc_keys_kernel(Src src, const unsigned *__restrict__ key_elem, u
         }
         // nothing summed here: the wave kernel does the prefix too.  (Same-day pairs as well: their series is as long, and one thread
         // folding its first TC_SERIAL_CAP terms kept this kernel's last waves running 0.6 ms after the others.)
+        // The same-day keys are listed from the back of long_ids: theirs are the longest loops of the wave kernel (no head to skip),
+        // which takes them first.
         if (N >= TC_WAVE_PREFIX_MIN) {
             key_state[4 * (size_t)id] = __builtin_nan("");
-            long_ids[atomicAdd(n_long, 1u)] = id;
+            if (d == 0.0) long_ids[nk - 1u - atomicAdd(n_zero, 1u)] = id;
+            else long_ids[atomicAdd(n_long, 1u)] = id;
             continue;
         }
         double p0, eK = 0.0; int ks;
@@ -717,27 +802,64 @@ __global__ __launch_bounds__(64) void tc_tables_kernel(TcTables *__restrict__ ta
         }
         return e;
     };
+    if (linear) {
+        // Both rows of a gap by the term-ratio recurrence: a_j = arg^j / j! (arg = x for S, lamb delta for the Poisson sum of :144-148),
+        // a_(j+1) = a_j arg / (j + 1), in units of the largest term (at j = floor(arg) <= 600: the first term, e^-ref of it, is a normal
+        // double) -- a lane takes one exponential per step and FT terms, the steps' run sums are prefix-summed over the wave: a quarter of
+        // the steps of the log-space form below, no running maximum, no logarithm but for the short log-space rows (pois, ln S_N).
+        constexpr int FT = 4;
+        for (unsigned gap = 1 + blockIdx.x; gap <= gap_max; gap += gridDim.x) {
+            const double delta = (double)((long long)gap * 86400ll) / 31556952.0;        // the sources' expression (DenseSource::get)
+            const double x = delta * (P.lamb + P.beta);
+            for (int which = 0; which < 2; which++) {
+                const unsigned long long len = which ? ldn : ldm;
+                double *__restrict__ row = (which ? pois + (size_t)gap * ldn : lnS + (size_t)gap * ldm);
+                double *__restrict__ row_n = lnS_n + (size_t)gap * ldn;
+                const double arg = which ? P.lamb * delta : x, la = log(arg);
+                const long long jp = (long long)floor(arg);
+                const double ref = imul(jp, la) - lg_at(lg, jp + 1);
+                const double unit = exp(ref - x);                              // F = S exp(-x) = pre * unit
+                double S = 0.0;                                                // (wave-uniform)
+                for (unsigned long long i0 = 0; i0 < len; i0 += 64 * FT) {
+                    const unsigned long long j0 = i0 + (unsigned long long)lane * FT;
+                    double a = j0 < len ? exp(imul((long long)j0, la) - lg_at(lg, (long long)j0 + 1) - ref) : 0.0;
+                    double p[FT], r = 0.0;
+#pragma unroll
+                    for (int q = 0; q < FT; q++) {
+                        r += j0 + q < len ? a : 0.0;
+                        p[q] = r;
+                        a *= arg / (double)(j0 + q + 1);
+                    }
+                    const double incl = wave_prefix(r), base = S + (incl - r);
+#pragma unroll
+                    for (int q = 0; q < FT; q++) {
+                        const unsigned long long j = j0 + q;
+                        if (j >= len) continue;
+                        const double pre = base + p[q];
+                        if (which) row[j] = ref + log(pre);
+                        else { row[j] = pre * unit; if (j < ldn) row_n[j] = ref + log(pre); }
+                    }
+                    S = __shfl(base + r, 63, 64);
+                }
+            }
+        }
+        return;
+    }
     for (unsigned gap = 1 + blockIdx.x; gap <= gap_max; gap += gridDim.x) {
         const double delta = (double)((long long)gap * 86400ll) / 31556952.0;        // the sources' expression (DenseSource::get)
         const double ld = log(delta), lx = log(P.lamb * delta);
-        const double x = delta * (P.lamb + P.beta);
         for (int which = 0; which < 2; which++) {
             const unsigned long long len = which ? ldn : ldm;
             double *__restrict__ row = (which ? pois + (size_t)gap * ldn : lnS + (size_t)gap * ldm);
-            double *__restrict__ row_n = lnS_n + (size_t)gap * ldn;
-            const bool lin = linear && which == 0;
-            double mx = -INFINITY, scaled = 0.0, unit = 0.0;      // unit = exp(mx - x): F = S exp(-x) = pre * unit
+            double mx = -INFINITY, scaled = 0.0;
             for (unsigned long long i0 = 0; i0 < len; i0 += 64) {
                 const long long i = (long long)(i0 + lane);
                 const bool in = (unsigned long long)i < len;
                 const double t = !in ? -INFINITY : which ? imul(i, lx) - lg_at(lg, i + 1) : imul(i, ld) + (double)i * P.ln_lb - lg_at(lg, i + 1);
                 const double m = wave_max(t);
-                if (m > mx) { scaled = mx == -INFINITY ? 0.0 : scaled * exp(mx - m); mx = m; if (lin) unit = exp(mx - x); }
+                if (m > mx) { scaled = mx == -INFINITY ? 0.0 : scaled * exp(mx - m); mx = m; }
                 const double pre = scaled + wave_prefix(t == -INFINITY ? 0.0 : exp(t - mx));
-                if (in) {
-                    if (lin) { row[i] = pre * unit; if ((unsigned long long)i < ldn) row_n[i] = mx + log(pre); }
-                    else row[i] = mx + log(pre);
-                }
+                if (in) row[i] = mx + log(pre);
                 scaled = __shfl(pre, 63, 64);
             }
         }
@@ -778,15 +900,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TRACS_TC_WAV
 // take, go on to tc_long_keys_kernel through rest_ids
 template <class Src>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TRACS_TC_RW, TRACS_TC_RW))) void tc_ratio_keys_kernel(Src src, const unsigned *__restrict__ key_elem, const unsigned *__restrict__ long_ids,
-                                                           const unsigned *__restrict__ n_long, TcParams P, const double *__restrict__ lg,
+                                                           const unsigned *__restrict__ n_long, const unsigned *__restrict__ n_zero, unsigned nk,
+                                                           TcParams P, const double *__restrict__ lg,
                                                            double *__restrict__ key_p0, double *__restrict__ key_eK,
                                                            const double *__restrict__ key_state, KeyTable kt, const TcTables *__restrict__ tab,
                                                            unsigned *__restrict__ rest_ids, unsigned *__restrict__ n_rest)
 {
     P.ln_lamb = log(P.lamb); P.ln_beta = log(P.beta); P.ln_lb = log(P.lamb + P.beta);
-    const unsigned nl = *n_long;
+    const unsigned nz = *n_zero, nl = nz + *n_long;
     for (unsigned w = blockIdx.x; w < nl; w += gridDim.x) {
-        const unsigned id = long_ids[w];
+        const unsigned id = w < nz ? long_ids[nk - 1u - w] : long_ids[w - nz];      // (same-day keys first: the longest loops)
         int N; double d;
         const size_t elem = (size_t)key_elem[id];
         src.get(elem, N, d);
@@ -794,7 +917,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TRACS_TC_RW,
         const double *st = key_state + 4 * (size_t)id;
         const bool fresh = st[0] != st[0];
         double eK = 0.0, p0 = 0.0;
-        const bool took = fresh && tc_eval_ratio(N, d, gap, P, lg, tab, eK, p0);          // (wave-uniform)
+        const bool took = fresh && (d == 0.0 ? tc_eval_ratio_zero(N, P, lg, eK, p0) : tc_eval_ratio(N, d, gap, P, lg, tab, eK, p0));     // (wave-uniform)
         if ((threadIdx.x & 63) != 0) continue;
         if (!took) { rest_ids[atomicAdd(n_rest, 1u)] = id; continue; }
         key_eK[id] = eK; key_p0[id] = p0;
@@ -1073,8 +1196,9 @@ static int tc_evaluate_keys(const Src &src, const unsigned *key_elem, unsigned n
     P.ln_lamb = P.ln_beta = P.ln_lb = 0.0;
 
     // one wave per block: keys differ widely in trip count, small blocks keep the SIMDs busy
+    TRACS_HIP_CHECK(hipMemsetAsync(n_keys + 8, 0, 8, stream));            // [8] same-day long keys, [9] keys left to the log-space loop
     hipLaunchKernelGGL((tc_keys_kernel<Src>), dim3((nk + 63) / 64), dim3(64), 0, stream, src, key_elem, nk, P, lg, key_p0, key_eK,
-                       long_ids, n_keys + 1, key_state, kt);
+                       long_ids, n_keys + 1, n_keys + 8, key_state, kt);
     // (gap, M) tables of the prefix sums, when the source has day gaps and the keys' bounds fit (decided on the device)
     TcTables *tab = nullptr;
     double *tab_lnS = nullptr, *tab_pois = nullptr, *tab_lnS_n = nullptr;
@@ -1099,14 +1223,13 @@ static int tc_evaluate_keys(const Src &src, const unsigned *key_elem, unsigned n
         }
     }
     // long series (E(K) loop beyond TC_SERIAL_CAP terms): one wave per key -- the term-ratio loop where the linear tables hold the key,
-    // the log-space loop for the rest (n_keys[3] of them, listed by the first kernel)
+    // the log-space loop for the rest (n_keys[9] of them, listed by the first kernel)
     unsigned *rest_ids = nullptr;
     if ((rc = workspace_get(TcWorkspaceIds::REST_IDS, (size_t)nk * 4, reinterpret_cast<void **>(&rest_ids)))) return rc;
-    TRACS_HIP_CHECK(hipMemsetAsync(n_keys + 3, 0, 4, stream));
     hipLaunchKernelGGL((tc_ratio_keys_kernel<Src>), dim3(std::min<unsigned>(nk, 256u * 32u)), dim3(64), 0, stream, src, key_elem,
-                       long_ids, n_keys + 1, P, lg, key_p0, key_eK, key_state, kt, tab, rest_ids, n_keys + 3);
+                       long_ids, n_keys + 1, n_keys + 8, nk, P, lg, key_p0, key_eK, key_state, kt, tab, rest_ids, n_keys + 9);
     hipLaunchKernelGGL((tc_long_keys_kernel<Src>), dim3(std::min<unsigned>(nk, 256u * 32u)), dim3(64), 0, stream, src, key_elem,
-                       rest_ids, n_keys + 3, P, lg, key_p0, key_eK, key_state, kt, tab);
+                       rest_ids, n_keys + 9, P, lg, key_p0, key_eK, key_state, kt, tab);
     *key_p0_out = key_p0; *key_eK_out = key_eK;
     return TRACS_OK;
 }
