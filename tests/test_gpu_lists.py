@@ -190,7 +190,7 @@ def run_case(case, nn_lists):
             samp, w, mask = ents >> 5, (ents >> 4) & 1, ents & 15
             assert len(set(samp.tolist())) == samp.size
             if k > 4:
-                # the w = 1 entries first, w1 of them (minor_fixup_kernel walks only those from a listed sample with w = 0)
+                # the w = 1 entries first, w1 of them
                 w1 = hdr >> 16
                 assert w1 == int(w.sum()) and (w[:w1] == 1).all() and (w[w1:] == 0).all()
             assert (M[samp, t] == mask).all() and (mask != 15).all()
@@ -209,8 +209,10 @@ def run_case(case, nn_lists):
                 r_ = (e & 0x7FFFFFFF) >> 5
                 assert bool(e >> 31) == (int(p_off[r_ + 1]) - int(p_off[r_]) > 4)          # flagged: the site's p list is a q line
                 pairs_sample.add((s_, r_, (e >> 4) & 1, e & 15))
-            assert int(c_p[s_]) == int(((ents >> 4) & 1).sum())
-        assert pairs_site == pairs_sample
+            assert int(c_p[s_]) == ents.size and (((ents >> 4) & 1) == 1).all()
+        # the per-sample lists hold the entries that walk lists (minor_fixup_kernel): those whose mask lacks the reference base
+        assert pairs_sample == {e for e in pairs_site if e[2] == 1}
+        assert int(s_off[n]) == len(pairs_sample)
     # ---- the rows' N bitmaps: per site either the N plane's column (an NNL site) or nothing
     if has_T:
         T = _dump(hiplib, aln, 8, np.uint32, n * tgroups * 4).reshape(n, tgroups * 4)

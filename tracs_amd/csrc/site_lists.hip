@@ -7,7 +7,8 @@
 //                of rank r (among the sites with lists) owns line r; a list that needs more goes on in overflow lines of its group;
 //                P LIST ("q" lines of 32 dwords): its listed samples (sample << 5 | w << 4 | allele mask) behind a header, minority sites only --
 //                the site of rank r owns q line r, longer lists go on in consecutive overflow lines;
-//   per sample   its LISTED entries (rank << 5 | w << 4 | mask) -- few: a sample differs from the others at a few hundred sites;
+//   per sample   its LISTED entries with w = 1 (rank << 5 | w << 4 | mask: its mask lacks the site's reference base -- the entries that
+//                walk lists) -- few: a sample differs from the others at a few hundred sites;
 //                its N BITMAP over the NNL sites, sample-major (T: 16 bytes per 128-site group, the transposed N plane): what
 //                nn_rows_kernel reads instead of a stream of list addresses.
 //
@@ -16,7 +17,7 @@
 //
 // The walks.  nn_rows_kernel: row i of the pair matrix in LDS; every N site of sample i (a set bit of its bitmap) is a work item --
 // the site's line(s), scanned by four lanes and decoded piece by piece: NN(i, j) += 1 for every listed j > i.  minor_fixup_kernel:
-// row x; every listed entry of sample x walks its site's P list (both listed: [masks disjoint] - w_x - w_j, for j > x) and, when w_x = 1, the site's N LIST:
+// row x; every such entry of sample x walks its site's P list (both listed: [masks disjoint] - w_x - w_j) and the site's N LIST:
 // -w_x for EVERY N sample y -- y > x lands in row x of dist, y < x in cell (y, x): a scratch row that transpose_add_kernel folds into
 // the rows above.  So an N sample never looks at the p list of a site: the walks go from the few listed samples to the many N
 // samples (k walks of a cN-entry list, not cN walks of a k-entry list), and the per-sample streams of N entries that rounds 2-3
@@ -124,8 +125,9 @@ struct N8Encoder {
 template <unsigned PIECE_SAMPLES>
 __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBuild mb, size_t n_pad, unsigned n,
                                                          unsigned long long *__restrict__ p_off, unsigned *__restrict__ p_ent,
-                                                         unsigned *__restrict__ qd, uint2 *__restrict__ E, uint4 *__restrict__ lines,
-                                                         unsigned *__restrict__ cnt, unsigned *__restrict__ c_p)
+                                                         unsigned *__restrict__ qd, uint2 *__restrict__ E, uint2 *__restrict__ E1,
+                                                         unsigned long long *__restrict__ n_e1, uint4 *__restrict__ lines,
+                                                         unsigned *__restrict__ c_p)
 {
     constexpr unsigned PIECE_WORDS = PIECE_SAMPLES / 32, BM_STRIDE = PIECE_WORDS + 1;     // (odd stride: conflict-free column writes)
     __shared__ unsigned bm[SITES_PER_GROUP * BM_STRIDE];     // the piece's N bits, site-major: bm[site * BM_STRIDE + 32-sample word]
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
         for (unsigned k = tid; k < qcount; k += SITE_THREADS) {
             const unsigned s = piece + queue[k];
             const uint4 A = base[s], C = base[n_pad + s], G = base[2 * n_pad + s], T = base[3 * n_pad + s], N = base[4 * n_pad + s];
-            unsigned listed = 0, listed_w = 0;               // this sample's listed entries in the group, and their w's
+            unsigned listed_w = 0;                           // this sample's listed entries with w = 1 in the group
 #pragma unroll
             for (int w = 0; w < 4; w++) {
                 const unsigned a = word_of(A, w), c = word_of(C, w), gg = word_of(G, w), t = word_of(T, w), isn = word_of(N, w);
@@ -253,11 +255,11 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
                     } else {
                         p_ent[pos] = (s << ENT_SHIFT) | code;
                     }
-                    E[pos] = make_uint2(s, (is_long ? ENT_LONG : 0u) | (rk[w * 32 + b] << ENT_SHIFT) | code);
-                    listed++; listed_w += code >> 4;
+                    // (only a sample with w = 1 walks lists afterwards: the others' entries exist in the site's list alone)
+                    if (code & 16u) E[pos] = make_uint2(s, (is_long ? ENT_LONG : 0u) | (rk[w * 32 + b] << ENT_SHIFT) | code);
+                    listed_w += code >> 4;
                 }
             }
-            if (listed) atomicAdd(&cnt[s], listed);
             if (listed_w) atomicAdd(&c_p[s], listed_w);
         }
         // ---- the site's thread: its 32 words of the piece in order (four independent reads at a time), every set bit a sample
@@ -298,17 +300,32 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
         enc.finish();
         if (kp[tid] > P_SHORT_MAX) { qd[(size_t)rk[tid] * 32] = kp[tid] | (curP[tid] << 16); qd[(size_t)rk[tid] * 32 + 31] = qb[tid]; }
     }
+    // the w = 1 entries -- the first curP of each site's run in E -- closed up into E1, a bag the per-sample lists are bucketed from: one
+    // global atomic per wave (the piece loop's last barrier stands between E's writers and these reads)
+    if (any_minor) {
+        const unsigned w1 = mine ? curP[tid] : 0u;
+        unsigned x = w1;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const unsigned o = __shfl_up(x, off, 64); if ((int)lane >= off) x += o; }
+        const unsigned total = __shfl(x, 63, 64);
+        if (total) {                                         // (wave-uniform)
+            unsigned long long at = 0;
+            if (lane == 0) at = atomicAdd(n_e1, (unsigned long long)total);
+            at = __shfl(at, 0, 64) + (x - w1);
+            const uint2 *src = E + (mine ? bP[tid] : 0ull);
+            for (unsigned k = 0; k < w1; k++) E1[at + k] = src[k];
+        }
+    }
 }
 
 // ---- per sample: listed entries (from E) ---------------------------------------------------------------------------------------
-// (their number per sample, cnt[s], and c_p[s] = the sum of their w's come from the per-site pass.)  The entries of E are placed
-// through per-sample cursors.
-__global__ __launch_bounds__(256) void listed_entries_kernel(const uint2 *__restrict__ E, unsigned long long count,
+// (their number per sample, c_p[s], comes from the per-site pass.)  The entries of E are placed through per-sample cursors.
+__global__ __launch_bounds__(256) void listed_entries_kernel(const uint2 *__restrict__ E, const unsigned long long *__restrict__ countp,
                                                              const unsigned long long *__restrict__ off, unsigned *__restrict__ cur,
                                                              unsigned *__restrict__ ent)
 {
     const unsigned long long k = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
-    if (k >= count) return;
+    if (k >= *countp) return;
     const uint2 e = E[k];
     ent[off[e.x] + atomicAdd(&cur[e.x], 1u)] = e.y;
 }
@@ -321,15 +338,16 @@ __global__ __launch_bounds__(256) void listed_entries_kernel(const uint2 *__rest
 //   pass B   within a bucket by sample (at most 1 024 samples), into s_ent.
 // A tile reserves its share of every run it touches with one global atomic per run, and its writes into a run are consecutive.
 constexpr unsigned ENT_TILE_THREADS = 1024, ENT_PER_THREAD = 8, ENT_TILE = ENT_TILE_THREADS * ENT_PER_THREAD;
-__global__ __launch_bounds__(ENT_TILE_THREADS) void entries_to_buckets_kernel(const uint2 *__restrict__ E, unsigned long long count, unsigned shift,
+__global__ __launch_bounds__(ENT_TILE_THREADS) void entries_to_buckets_kernel(const uint2 *__restrict__ E, const unsigned long long *__restrict__ countp, unsigned shift,
                                                                               unsigned n, const unsigned long long *__restrict__ s_off,
                                                                               unsigned *__restrict__ bcur, uint2 *__restrict__ tmp)
 {
     __shared__ unsigned hist[256], base[256];
     const unsigned tid = threadIdx.x;
+    const unsigned long long count = *countp, t0 = (unsigned long long)blockIdx.x * ENT_TILE;
+    if (t0 >= count) return;                                 // (the grid covers every entry of the p lists; E holds the w = 1 ones)
     if (tid < 256u) hist[tid] = 0;
     __syncthreads();
-    const unsigned long long t0 = (unsigned long long)blockIdx.x * ENT_TILE;
     uint2 e[ENT_PER_THREAD];
     unsigned slot[ENT_PER_THREAD];
 #pragma unroll
@@ -692,7 +710,8 @@ __global__ __launch_bounds__(TRACS_NN_THREADS) void nn_rows_kernel(const uint4 *
 //     d += sum_{S_i} w_i + sum_{S_j} w_j - sum_{s in S_i: j is N} w_i - sum_{s in S_j: i is N} w_j
 //          + sum over S_i n S_j of ([M_i n M_j = {}] - w_i - w_j)
 // (consensus alignments: M = {own base}, w = 1).  The first two sums are per-sample constants (c_p).  Row x (one workgroup):
-//     phase A  x in the call's rows: every listed entry of x walks its site's p list: the last sum, for j > x;
+//     phase A  every listed entry of x with w = 1 walks its site's p list: the last sum -- for j > x (row x of dist) and, where w_j = 0,
+//              for j < x too (cell (j, x)): the entries with w = 0 do not walk (two such never add anything: both masks hold the reference base);
 //     phase B  every listed entry of x with w = 1 walks its site's N list: -1 for EVERY N sample y there -- the third sum for y > x
 //              (row x of dist), the fourth for y < x (cell (y, x): a scratch row, folded in by transpose_add_kernel).
 // Negative terms wrap in the unsigned row and cancel in the final sum.
@@ -720,13 +739,13 @@ __global__ __launch_bounds__(1024) void minor_fixup_kernel(const unsigned long l
     for (unsigned j = threadIdx.x; j < span + 64u; j += blockDim.x) row[j] = 0;
     __syncthreads();
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    if (upper && e1 > e0) {
-        // phase A.  Every listed entry of sample x is a walk of its site's p list: q line `rank` -- header (k, w1), 30 entries, the index of
-        // the first overflow line -- and, for lists beyond 30, the consecutive overflow lines.  A wave keeps a ring of (line, what) in LDS
-        // and works it off 16 lines at a time, FOUR lanes per line, 8 dwords per lane (the line is one 128-byte fetch, its header tells how
-        // far to go: k entries when w_x = 1, only the w1 entries with w = 1 at the front when x's mask holds the reference base -- against
-        // the others [masks disjoint] - w_x - w_j is 0).  Round 4 read a site's bounds from p_off (two more cache lines per walk, at random)
-        // and its entries from p_ent with 16 lanes in a loop: three lines and a loop trip per walk where this form has one of each.
+    if ((upper || lower) && e1 > e0) {
+        // phase A.  Every entry of sample x (w_x = 1) is a walk of its site's p list: q line `rank` -- header (k, w1), 30 entries, the index
+        // of the first overflow line -- and, for lists beyond 30, the consecutive overflow lines.  A wave keeps a ring of (line, what) in
+        // LDS and works it off 16 lines at a time, FOUR lanes per line, 8 dwords per lane (the line is one 128-byte fetch, its header tells
+        // how far to go).  The listed samples whose mask holds the reference base (w = 0: partial codes) do not walk: against each other
+        // [masks disjoint] - w - w is 0, and their pairs with a w = 1 sample are that sample's -- in both triangles, like the N samples of
+        // phase B (with 0.5 % partial codes 98 % of the entries are such: 253 M walks of a line each, 11 ms, are 5 M).
         const unsigned *__restrict__ q = qd;
         uint2 *ring = reinterpret_cast<uint2 *>(row + chunk + 64 + wave * (WALK_LDS_PER_WAVE / 4));
         unsigned rhead = 0, rcount = 0;
@@ -756,16 +775,18 @@ __global__ __launch_bounds__(1024) void minor_fixup_kernel(const unsigned long l
             const unsigned hdr = (unsigned)__builtin_amdgcn_update_dpp(0, (int)d0.x, 0x00, 0xF, 0xF, false);      // quad_perm:[0,0,0,0]
             const unsigned tail = (unsigned)__builtin_amdgcn_update_dpp(0, (int)d1.w, 0xFF, 0xF, 0xF, false);     // quad_perm:[3,3,3,3]
             const unsigned first = ovf ? 0u : 1u;
-            const unsigned limit = ovf ? (ref.y >> 6) : ((code & 16u) ? (hdr & 0xFFFFu) : (hdr >> 16));
+            const unsigned limit = ovf ? (ref.y >> 6) : (hdr & 0xFFFFu);
             const unsigned v[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
             const unsigned mx = code & 15u;
-            const int wx = (int)(code >> 4);
 #pragma unroll
             for (int t = 0; t < 8; t++) {
                 const unsigned dw = l4 * 8u + (unsigned)t;
                 const unsigned j = v[t] >> ENT_SHIFT;
-                const bool in = has && dw >= first && dw < 31u && dw - first < limit && j >= up0 && j < up1;
-                const int add = (((v[t] & 15u) & mx) == 0u ? 1 : 0) - wx - (int)((v[t] >> 4) & 1u);      // both listed: [masks disjoint] - w_x - w_j
+                const unsigned wj = (v[t] >> 4) & 1u;
+                // cell (x, j) for j > x; cell (j, x) for a j < x that does not walk itself (w_j = 0)
+                const bool in = has && dw >= first && dw < 31u && dw - first < limit &&
+                                ((j >= up0 && j < up1) || (wj == 0u && j >= lw0 && j < lw1));
+                const int add = (((v[t] & 15u) & mx) == 0u ? 1 : 0) - 1 - (int)wj;      // both listed: [masks disjoint] - w_x - w_j
                 if (in && add != 0) atomicAdd(&row[j - c0], (unsigned)add);
             }
             const unsigned cap = 31u - first;
@@ -780,15 +801,15 @@ __global__ __launch_bounds__(1024) void minor_fixup_kernel(const unsigned long l
                 // a list of at most P_SHORT_MAX samples (the usual case: one or two) stays in the lane that found it
                 const unsigned long long pa = p_off[rank], pz = p_off[rank + 1];
                 const unsigned mx = ent & 15u;
-                const int wx = (int)((ent >> 4) & 1u);
                 unsigned v[P_SHORT_MAX];
 #pragma unroll
                 for (unsigned m = 0; m < P_SHORT_MAX; m++) v[m] = pa + m < pz ? p_ent[pa + m] : 0xFFFFFFFFu;
 #pragma unroll
                 for (unsigned m = 0; m < P_SHORT_MAX; m++) {
                     const unsigned j = v[m] >> ENT_SHIFT;
-                    const int add = (((v[m] & 15u) & mx) == 0u ? 1 : 0) - wx - (int)((v[m] >> 4) & 1u);
-                    if (v[m] != 0xFFFFFFFFu && add != 0 && j >= up0 && j < up1) atomicAdd(&row[j - c0], (unsigned)add);
+                    const unsigned wj = (v[m] >> 4) & 1u;
+                    const int add = (((v[m] & 15u) & mx) == 0u ? 1 : 0) - 1 - (int)wj;
+                    if (v[m] != 0xFFFFFFFFu && add != 0 && ((j >= up0 && j < up1) || (wj == 0u && j >= lw0 && j < lw1))) atomicAdd(&row[j - c0], (unsigned)add);
                 }
             }
             while (rcount > LINE_RING - 64u - 16u) { wave_sync(); round(); }
@@ -806,7 +827,7 @@ __global__ __launch_bounds__(1024) void minor_fixup_kernel(const unsigned long l
             const unsigned long long e = base + lane;
             const unsigned ent = e < e1 ? s_ent[e] : 0u;
             W.drain_lines_to(31);
-            W.push_line(e < e1 && (ent & 16u), (ent & ~ENT_LONG) >> ENT_SHIFT);
+            W.push_line(e < e1, (ent & ~ENT_LONG) >> ENT_SHIFT);
         }
         W.finish();
     }
@@ -882,10 +903,14 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb_, hipStream_t 
     const bool bitmaps = mb.tot_nnl > 0;
     if (bitmaps) SL_TRY(pack_alloc(a, n * g->tgroups * sizeof(uint4), reinterpret_cast<void **>(&g->T)));
     unsigned *cnt = nullptr;
-    uint2 *E = nullptr;
+    uint2 *E = nullptr, *E1 = nullptr;
     int rc;
+    // E: the p entries with w = 1 where the per-site pass drops them (by list position); E1: the same closed up (n_e1 of them, counted on
+    // the device) -- E's memory serves again as the first bucketing pass's output
     if ((rc = workspace_get(60, (2 * std::max<size_t>(n, 1) + 8 + 256) * 4, reinterpret_cast<void **>(&cnt))) ||
-        (rc = workspace_get(62, std::max<size_t>(mb.tot_p, 1) * sizeof(uint2), reinterpret_cast<void **>(&E)))) { delete g; return rc; }
+        (rc = workspace_get(62, std::max<size_t>(mb.tot_p, 1) * sizeof(uint2), reinterpret_cast<void **>(&E))) ||
+        (rc = workspace_get(63, std::max<size_t>(mb.tot_p, 1) * sizeof(uint2), reinterpret_cast<void **>(&E1)))) { delete g; return rc; }
+    unsigned long long *n_e1 = reinterpret_cast<unsigned long long *>(cnt);
     unsigned *cur = cnt + std::max<size_t>(n, 1), *d_max = cur + std::max<size_t>(n, 1), *bcur = d_max + 8;
     SL_TRY(hipMemsetAsync(cnt, 0, (2 * std::max<size_t>(n, 1) + 8 + 256) * 4, stream));
     SL_TRY(hipMemsetAsync(g->c_p, 0, std::max<size_t>(n, 1) * 4, stream));
@@ -895,33 +920,32 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb_, hipStream_t 
     // (pieces of 512 samples; 1 024 when many samples per group are flagged for the p lists -- more than one listed entry per ten
     // (sample, group) pairs: alignments with partial codes)
     if ((double)mb.tot_p > 0.1 * (double)n * (double)groups)
-        hipLaunchKernelGGL((site_lists_kernel<1024>), dim3((unsigned)groups), dim3(SITE_THREADS), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off, g->p_ent, reinterpret_cast<unsigned *>(g->qlines), E, g->lines, cnt, g->c_p);
+        hipLaunchKernelGGL((site_lists_kernel<1024>), dim3((unsigned)groups), dim3(SITE_THREADS), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off, g->p_ent, reinterpret_cast<unsigned *>(g->qlines), E, E1, n_e1, g->lines, g->c_p);
     else
-        hipLaunchKernelGGL((site_lists_kernel<512>), dim3((unsigned)groups), dim3(SITE_THREADS), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off, g->p_ent, reinterpret_cast<unsigned *>(g->qlines), E, g->lines, cnt, g->c_p);
+        hipLaunchKernelGGL((site_lists_kernel<512>), dim3((unsigned)groups), dim3(SITE_THREADS), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off, g->p_ent, reinterpret_cast<unsigned *>(g->qlines), E, E1, n_e1, g->lines, g->c_p);
     pack_stage_mark("lists: per site", stream, plane_b + (double)groups * SITES_PER_GROUP * 8.0,
-                    (double)L * 128.0 + (double)mb.tot_p * 12.0 + (double)L * 8.0 + (double)(mb.tot_q + std::min<unsigned long long>(L, mb.tot_p)) * 8.0);
-    const unsigned egrid = (unsigned)((mb.tot_p + 255) / 256);
-    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, cnt, n, g->s_off);
+                    (double)L * 128.0 + (double)mb.tot_p * 4.0 + (double)L * 8.0 + (double)(mb.tot_q + std::min<unsigned long long>(L, mb.tot_p)) * 8.0);
+    // the per-sample lists hold the w = 1 entries: c_p[s] of them
+    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, g->c_p, n, g->s_off);
     bool two_pass = false;
-    if (egrid) {
+    if (mb.tot_p) {
         unsigned shift = 0;
         while (((n - 1) >> shift) >= 256u) shift++;                                   // at most 256 buckets of 2^shift samples
-        uint2 *tmp = nullptr;
-        two_pass = mb.tot_p >= ENT_TILE && mb.tot_p < (1ull << 32) && shift <= 10 &&      // (32-bit run cursors; at most 1 024 samples per bucket)
-                              workspace_get(63, (size_t)mb.tot_p * sizeof(uint2), reinterpret_cast<void **>(&tmp)) == TRACS_OK;
+        uint2 *tmp = E;
+        two_pass = mb.tot_p >= ENT_TILE && mb.tot_p < (1ull << 32) && shift <= 10;      // (32-bit run cursors; at most 1 024 samples per bucket)
+        // (grids by the p lists' total, an upper bound: the blocks beyond the w = 1 entries leave at once)
         if (two_pass) {
             const unsigned buckets = (unsigned)(((n - 1) >> shift) + 1);
-            hipLaunchKernelGGL(entries_to_buckets_kernel, dim3((unsigned)((mb.tot_p + ENT_TILE - 1) / ENT_TILE)), dim3(ENT_TILE_THREADS), 0, stream, E, mb.tot_p,
+            hipLaunchKernelGGL(entries_to_buckets_kernel, dim3((unsigned)((mb.tot_p + ENT_TILE - 1) / ENT_TILE)), dim3(ENT_TILE_THREADS), 0, stream, E1, n_e1,
                                shift, (unsigned)n, g->s_off, bcur, tmp);
             const unsigned per_bucket = (unsigned)std::min<unsigned long long>(64, std::max<unsigned long long>(1, mb.tot_p / buckets / ENT_TILE + 1));
             hipLaunchKernelGGL(buckets_to_samples_kernel, dim3(per_bucket, buckets), dim3(ENT_TILE_THREADS), 0, stream, tmp, shift, (unsigned)n, g->s_off, cur, g->s_ent);
         } else {
-            (void)hipGetLastError(); set_error("");
-            hipLaunchKernelGGL(listed_entries_kernel, dim3(egrid), dim3(256), 0, stream, E, mb.tot_p, g->s_off, cur, g->s_ent);
+            hipLaunchKernelGGL(listed_entries_kernel, dim3((unsigned)std::min<unsigned long long>(0x7FFFFFFFull, (mb.tot_p + 255) / 256)), dim3(256), 0, stream, E1, n_e1, g->s_off, cur, g->s_ent);
         }
     }
-    pack_stage_mark("listed entries per sample", stream, (double)mb.tot_p * (two_pass ? 16.0 : 8.0) + (double)n * 4.0,
-                    (double)mb.tot_p * (two_pass ? 12.0 : 4.0) + (double)n * 12.0);
+    pack_stage_mark("listed entries per sample", stream, (double)std::min<unsigned long long>(mb.tot_p, L) * (two_pass ? 16.0 : 8.0) + (double)n * 4.0,
+                    (double)std::min<unsigned long long>(mb.tot_p, L) * (two_pass ? 12.0 : 4.0) + (double)n * 12.0);
     if (bitmaps) {
         // (a->c_counted was zeroed by the caller: this kernel is what fills it when the rows' bitmaps are built)
         const size_t octs = g->tgroups / 8;
