@@ -59,6 +59,8 @@ CASES = [
     dict(n=700, L=3000, p_n=0.01, mu=3e-4, seed=5, bitmaps=True, edges=True),      # lists that end exactly at the encoder's boundaries
     dict(n=900, L=6000, p_n=0.01, mu=6e-3, seed=6, bitmaps=True),       # ~30 000 listed entries: the bucketed fill of the per-sample lists
     dict(n=4000, L=1024, p_n=0.001, mu=1e-4, seed=7, p_partial=0.009, long_p=True),      # ~36 partial codes per site: p lists beyond one q line
+    dict(n=4000, L=1024, p_n=0.0005, mu=1e-4, seed=8, p_partial=0.019, long_p=True),     # ~76 per site, ~9 700 per group: beyond the LDS image of p_lists_kernel (8 192)
+    dict(n=2000, L=2048, p_n=0.002, mu=1e-4, seed=9, p_partial=0.0055),                  # ~11 per site, ~1 400 per group: p_lists_kernel with short (<= 4) and long lists side by side
 ]
 
 # N samples of hand-made sites (case `edges`): the byte counts the encoder's branches turn on

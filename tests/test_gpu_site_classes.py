@@ -134,7 +134,7 @@ def test_repack_redecides(hiplib, oracle):
 def test_every_class_at_once(hiplib, oracle, p_partial):
     """(consensus / general encoding) Lineage-structured columns (a fifth of the samples differ: dense), private substitutions (minority), columns without
     any N (full), columns of N (empty), N elsewhere (counted) -- in one alignment, 1 000 samples so that the list budget
-    (k (cN + k) <= n^2 / 8000) separates one- and two-sample sites from the lineage sites."""
+    (k (cN + k) <= n^2 / 2000) separates one- and two-sample sites from the lineage sites."""
     from tracs_amd import device as dev
     n, L = 1000, 6000
     rng = np.random.default_rng(77)
@@ -212,7 +212,7 @@ REGIMES = {
 @pytest.mark.parametrize("regime", sorted(REGIMES))
 def test_cost_model_never_loses_to_the_dense_pass(regime, hiplib, oracle):
     """2 000 samples x 1 Mbp per regime: whatever the cost model decides (csrc/site_classes.hip: classes when
-    (4 L_dense + L_counted) / 4 L < 0.92, minority lists within n^2 / 8000 entries per site) must (a) give the oracle's d and nn
+    (4 L_dense + L_counted) / 4 L < 0.92, minority lists within n^2 / 2000 entries per site) must (a) give the oracle's d and nn
     bit for bit -- checked on a 300-sample block, and over the whole matrix against the run with every site through the pair
     kernel -- and (b) not be slower than that run: a steady-state pass <= 1.1 x the dense pass, and one pass INCLUDING the
     once-per-pack work <= 1.1 x the dense run's.  The reference's cost is the same on all of them (src/pairsnp.hpp:395-420)."""

@@ -23,14 +23,15 @@ static thread_local std::string g_error;
 void set_error(const std::string &msg) { g_error = msg; }
 
 struct Scratch { void *ptr = nullptr; size_t bytes = 0; };
-static Scratch g_scratch[8][64];
+constexpr int kScratchSlots = 96;
+static Scratch g_scratch[8][kScratchSlots];
 static std::mutex g_scratch_mu;
 
 int workspace_get(int slot, size_t bytes, void **out)
 {
     int dev = 0;
     TRACS_HIP_CHECK(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 8 || slot < 0 || slot >= 64) { set_error("workspace_get: bad device/slot"); return TRACS_E_ARG; }
+    if (dev < 0 || dev >= 8 || slot < 0 || slot >= kScratchSlots) { set_error("workspace_get: bad device/slot"); return TRACS_E_ARG; }
     std::lock_guard<std::mutex> lock(g_scratch_mu);
     Scratch &s = g_scratch[dev][slot];
     if (s.bytes < bytes) {

@@ -603,8 +603,13 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     auto off_of = [&](int slot) { return offs + (size_t)slot * groups; };
     unsigned *cntP = cnts, *cntN = cnts + groups * SITES_PER_GROUP;
     // a site goes to the minority lists while its k (cN + k) entries cost less than the extra operand planes over all pairs:
-    // ~51 ns per site at 10 000 samples (pair kernel) against ~2-4 ps per list entry (general_fixup_kernel)
-    const double bsites = (double)a->n * (double)a->n / 8000.0;
+    // 51 ns per site at 10 000 samples in the pair kernel (consensus planes; 120 ns in the general encoding, and as much again to
+    // re-pack the site) against 0.2-1.3 ps per list entry (minor_fixup_kernel: 0.65 ms for 5e8 entries on the bench alignment, 8.2 ms
+    // for 3.8e10 with 0.5 % partial codes) -- k (cN + k) <= n^2 / 2000: 50 000 entries at 10 000 samples.  (n^2 / 8000 until round 5
+    // sent the 16 896 sites of the partial-code alignment with k >= 73 through the pair kernel: 4.5 ms of a 51.5 ms call;
+    // TRACS_MINOR_BUDGET_DIV overrides the divisor for that measurement)
+    static const double budget_div = [] { const char *e = std::getenv("TRACS_MINOR_BUDGET_DIV"); return e && std::atof(e) > 0 ? std::atof(e) : 2000.0; }();
+    const double bsites = (double)a->n * (double)a->n / budget_div;
     const unsigned budget = (no_minor || !allow_minor) ? 0u : (unsigned)std::min(1.0e9, std::max(16.0, bsites));
     // The N co-occurrences of a site with cN N samples cost cN list walks of one cache line per ~115 samples of the list (n8 lines,
     // pairsnp_kernels.h; nn_rows_kernel is bound by the lines it pulls through the fabric) against n^2 / 2 pairs on the matrix
@@ -716,7 +721,7 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
         MinorBuild mb;
         mb.planes = a->planes; mb.minor_mask = mask_of(M_MINOR); mb.nnl_mask = mask_of(M_NNL); mb.lst_mask = mask_of(lst_slot);
         mb.ref_x = mask_of(M_REFX); mb.ref_y = mask_of(M_REFY); mb.un_mask = mask_of(M_UN); mb.off_lst = off_of(lst_slot);
-        mb.cntP = cntP; mb.cntN = cntN; mb.baseP = off64; mb.baseO = off64 + (size_t)ovf_slot * groups; mb.flags = flags; mb.flag_words = flag_words;
+        mb.cntP = cntP; mb.cntN = cntN; mb.gP = gcnt; mb.baseP = off64; mb.baseO = off64 + (size_t)ovf_slot * groups; mb.flags = flags; mb.flag_words = flag_words;
         mb.sites = L_lst; mb.tot_p = tot_p; mb.tot_o = tot_o; mb.tot_nnl = tot_nnl; mb.baseQ = off64 + 6 * groups; mb.tot_q = tot_q; mb.long_p = long_p ? 1 : 0;
         mb.n_rows = a->n_row_hint;
         for (int k = 0; k < 4; k++) mb.rows[k] = (unsigned)std::min<size_t>(a->row_hint[k], a->n);

@@ -86,6 +86,10 @@ __device__ __forceinline__ bool row_wanted(const MinorBuild &mb, size_t s)
 // limit, instead of seven of 22 KB --, 3.6 with 256, 4.6 with 128, 7.3 with 2 048: profiles/r05/site_lists_piece_sweep.txt)
 // ... for consensus alignments; with partial IUPAC codes (47 % of the samples of a group flagged for the p lists at 0.5 % of them)
 // the queue of flagged samples wants the longer piece: 10.9 ms with 1 024 against 13.3 with 512 -- the kernel is a template on it.
+// a group's p lists are built in LDS by p_lists_kernel when they hold PL_MIN .. PL_CAP entries (fewer: not worth a workgroup of its
+// own -- the bench alignment has 128 per group --, more: beyond the image; both: site_lists_kernel, entry by entry)
+constexpr unsigned PL_THREADS = 256, PL_MIN = 1024, PL_CAP = 8192, PL_CHUNK = 4096;
+__device__ __forceinline__ bool p_lists_in_lds(unsigned group_entries) { return group_entries >= PL_MIN && group_entries <= PL_CAP; }
 constexpr unsigned SITE_THREADS = 128;         // one thread per site of the group: both waves busy in both phases, eight workgroups per CU (17 KiB of LDS each)
 
 struct N8Encoder {
@@ -148,6 +152,9 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
     const unsigned m[4] = {m4.x, m4.y, m4.z, m4.w};          // sites with lists
     const unsigned mp[4] = {q4.x, q4.y, q4.z, q4.w};         // minority sites among them (p lists)
     const bool any_minor = (q4.x | q4.y | q4.z | q4.w) != 0u;
+    // the group's p lists: p_lists_kernel's, or -- few entries, or more than that kernel sorts in LDS -- built here, from the planes of
+    // its flagged samples, piece by piece, entry by entry
+    const bool from_planes = any_minor && !p_lists_in_lds(mb.gP[g]);
     static_assert(SITE_THREADS == SITES_PER_GROUP, "thread = site");
     const int tw = tid >> 5, tb = tid & 31;
     const bool mine = (m[tw] >> tb) & 1u;
@@ -179,6 +186,22 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
     const uint4 RX = mb.ref_x[g], RY = mb.ref_y[g];
     const uint4 *base = mb.planes + (g * NPLANES) * n_pad;
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    // listed sample s at site `st` of the group (a minority site) with code = w << 4 | allele mask: into the site's p list -- its w = 1
+    // entries from the front of its run, the others from the back -- and, when w = 1, into E
+    auto place = [&](unsigned s, unsigned st, unsigned code) {
+        const unsigned slot = (code & 16u) ? atomicAdd(&curP[st], 1u) : kp[st] - 1u - atomicAdd(&curQ[st], 1u);
+        const unsigned long long pos = bP[st] + slot;
+        const bool is_long = kp[st] > P_SHORT_MAX;
+        if (is_long) {
+            // entry `slot` of the site's list: dword slot + 1 of its q lines (31 dwords a line; dword 0 of the list is the header)
+            const unsigned qs = slot + 1u, qt = qs / 31u;
+            qd[(size_t)(qt ? qb[st] + qt - 1u : rk[st]) * 32 + (qs - qt * 31u)] = (s << ENT_SHIFT) | code;
+        } else {
+            p_ent[pos] = (s << ENT_SHIFT) | code;
+        }
+        // (only a sample with w = 1 walks lists afterwards: the others' entries exist in the site's list alone)
+        if (code & 16u) E[pos] = make_uint2(s, (is_long ? ENT_LONG : 0u) | (rk[st] << ENT_SHIFT) | code);
+    };
     for (unsigned piece = 0; piece < n; piece += PIECE_SAMPLES) {
         const unsigned par = (piece / PIECE_SAMPLES) & 1u;
         // ---- the piece's samples, 64 per wave and step (the next step's N words and flag word are requested before this step's
@@ -188,7 +211,7 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
         unsigned long long fl_next = 0ull;
         {
             const unsigned s = piece + sl * 64u + lane;
-            if (s < n) { N_next = base[4 * n_pad + s]; if (any_minor) fl_next = mb.flags[g * mb.flag_words + (s >> 6)]; }
+            if (s < n) { N_next = base[4 * n_pad + s]; if (from_planes) fl_next = mb.flags[g * mb.flag_words + (s >> 6)]; }
         }
         for (; sl < PIECE_SAMPLES / 64u; sl += SITE_THREADS / 64u) {
             const unsigned s = piece + sl * 64u + lane;
@@ -197,7 +220,7 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
             {
                 const unsigned sn = s + SITE_THREADS;
                 N_next = zero4; fl_next = 0ull;
-                if (sl + SITE_THREADS / 64u < PIECE_SAMPLES / 64u && sn < n) { N_next = base[4 * n_pad + sn]; if (any_minor) fl_next = mb.flags[g * mb.flag_words + (sn >> 6)]; }
+                if (sl + SITE_THREADS / 64u < PIECE_SAMPLES / 64u && sn < n) { N_next = base[4 * n_pad + sn]; if (from_planes) fl_next = mb.flags[g * mb.flag_words + (sn >> 6)]; }
             }
             if (piece + sl * 64u < n) {                        // (wave-uniform: a slab beyond the last sample leaves its words zero below)
                 const unsigned col = sl * 2u + (lane >> 5), r = lane & 31u;
@@ -227,11 +250,12 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
         if (tid == 0) qn[par ^ 1u] = 0;
         for (unsigned k = tid; k < qcount; k += SITE_THREADS) {
             const unsigned s = piece + queue[k];
-            const uint4 A = base[s], C = base[n_pad + s], G = base[2 * n_pad + s], T = base[3 * n_pad + s], N = base[4 * n_pad + s];
+            // (the stored N plane is A & C & G & T by construction: four loads, not five)
+            const uint4 A = base[s], C = base[n_pad + s], G = base[2 * n_pad + s], T = base[3 * n_pad + s];
             unsigned listed_w = 0;                           // this sample's listed entries with w = 1 in the group
 #pragma unroll
             for (int w = 0; w < 4; w++) {
-                const unsigned a = word_of(A, w), c = word_of(C, w), gg = word_of(G, w), t = word_of(T, w), isn = word_of(N, w);
+                const unsigned a = word_of(A, w), c = word_of(C, w), gg = word_of(G, w), t = word_of(T, w), isn = a & c & gg & t;
                 const unsigned rx = word_of(RX, w), ry = word_of(RY, w);
                 const unsigned ra = ~rx & ~ry, rc = rx & ~ry, rg = ~rx & ry, rt = rx & ry;
                 const unsigned has_ref = (a & ra) | (c & rc) | (gg & rg) | (t & rt);
@@ -244,19 +268,7 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
                     pm &= pm - 1;
                     const unsigned mask = ((a >> b) & 1u) | (((c >> b) & 1u) << 1) | (((gg >> b) & 1u) << 2) | (((t >> b) & 1u) << 3);
                     const unsigned code = (((has_ref >> b) & 1u) ? 0u : 16u) | mask;
-                    // the site's w = 1 entries from the front of its run, the others from the back
-                    const unsigned slot = (code & 16u) ? atomicAdd(&curP[w * 32 + b], 1u) : kp[w * 32 + b] - 1u - atomicAdd(&curQ[w * 32 + b], 1u);
-                    const unsigned long long pos = bP[w * 32 + b] + slot;
-                    const bool is_long = kp[w * 32 + b] > P_SHORT_MAX;
-                    if (is_long) {
-                        // entry `slot` of the site's list: dword slot + 1 of its q lines (31 dwords a line; dword 0 of the list is the header)
-                        const unsigned qs = slot + 1u, qt = qs / 31u;
-                        qd[(size_t)(qt ? qb[w * 32 + b] + qt - 1u : rk[w * 32 + b]) * 32 + (qs - qt * 31u)] = (s << ENT_SHIFT) | code;
-                    } else {
-                        p_ent[pos] = (s << ENT_SHIFT) | code;
-                    }
-                    // (only a sample with w = 1 walks lists afterwards: the others' entries exist in the site's list alone)
-                    if (code & 16u) E[pos] = make_uint2(s, (is_long ? ENT_LONG : 0u) | (rk[w * 32 + b] << ENT_SHIFT) | code);
+                    place(s, (unsigned)(w * 32 + b), code);
                     listed_w += code >> 4;
                 }
             }
@@ -298,11 +310,11 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
     }
     if (mine) {
         enc.finish();
-        if (kp[tid] > P_SHORT_MAX) { qd[(size_t)rk[tid] * 32] = kp[tid] | (curP[tid] << 16); qd[(size_t)rk[tid] * 32 + 31] = qb[tid]; }
+        if (from_planes && kp[tid] > P_SHORT_MAX) { qd[(size_t)rk[tid] * 32] = kp[tid] | (curP[tid] << 16); qd[(size_t)rk[tid] * 32 + 31] = qb[tid]; }
     }
     // the w = 1 entries -- the first curP of each site's run in E -- closed up into E1, a bag the per-sample lists are bucketed from: one
     // global atomic per wave (the piece loop's last barrier stands between E's writers and these reads)
-    if (any_minor) {
+    if (from_planes) {
         const unsigned w1 = mine ? curP[tid] : 0u;
         unsigned x = w1;
 #pragma unroll
@@ -314,6 +326,141 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
             at = __shfl(at, 0, 64) + (x - w1);
             const uint2 *src = E + (mine ? bP[tid] : 0ull);
             for (unsigned k = 0; k < w1; k++) E1[at + k] = src[k];
+        }
+    }
+}
+
+// ---- per site: p lists ---------------------------------------------------------------------------------------------------------------
+// One workgroup per group: its FLAGGED samples (listed somewhere in the group: classify_sites_kernel's flag words) are queued 4 096
+// samples at a time, their four allele words read, and every listed (sample, site) pair is dropped into an LDS image of the group's
+// p lists -- a counting sort on the sites' known sizes; within a site the w = 1 entries from the front, the others from the back --
+// which then leaves as whole lines: the short lists into p_ent, the long ones as q lines written 128 bytes at a time, the w = 1
+// entries into E1.  (Dropped one by one into global memory -- site_lists_kernel's way until round 5, kept for the groups whose
+// lists outgrow the image -- the 253 M entries of an alignment with 0.5 % partial codes were 253 M four-byte stores into 1.3 GB of
+// q lines that left the L2 half written and came back to be finished.)
+__global__ __launch_bounds__(PL_THREADS) void p_lists_kernel(const MinorBuild mb, size_t n_pad, unsigned n, unsigned *__restrict__ p_ent,
+                                                             unsigned *__restrict__ qd, uint2 *__restrict__ E1,
+                                                             unsigned long long *__restrict__ n_e1, unsigned *__restrict__ c_p)
+{
+    __shared__ unsigned sorted[PL_CAP];
+    __shared__ unsigned kp[SITES_PER_GROUP], loff[SITES_PER_GROUP], curP[SITES_PER_GROUP], curQ[SITES_PER_GROUP], rk[SITES_PER_GROUP], qb[SITES_PER_GROUP];
+    __shared__ unsigned w1off[SITES_PER_GROUP];
+    __shared__ unsigned short queue[PL_CHUNK];
+    __shared__ unsigned wtot[PL_THREADS / 64];
+    __shared__ unsigned long long e1_base;
+    const size_t g = blockIdx.x;
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint4 q4 = mb.minor_mask[g];
+    if ((q4.x | q4.y | q4.z | q4.w) == 0u) return;
+    const unsigned long long baseP = mb.baseP[g];
+    if (!p_lists_in_lds(mb.gP[g])) return;                   // (site_lists_kernel builds this group's)
+    if (tid < SITES_PER_GROUP) {
+        const bool mine = (word_of(q4, (int)(tid >> 5)) >> (tid & 31u)) & 1u;
+        kp[tid] = mine ? mb.cntP[g * SITES_PER_GROUP + tid] : 0u;
+        curP[tid] = 0; curQ[tid] = 0;
+    }
+    __syncthreads();
+    if (tid < SITES_PER_GROUP) {
+        unsigned pp = 0, pq = 0;
+        for (unsigned t = 0; t < tid; t++) { pp += kp[t]; pq += kp[t] / 31u; }
+        loff[tid] = pp;
+        rk[tid] = lst_rank(mb.lst_mask[g], mb.off_lst[g], (int)(tid >> 5), (int)(tid & 31u));
+        qb[tid] = (unsigned)(mb.sites + mb.baseQ[g] + pq);
+    }
+    const uint4 RX = mb.ref_x[g], RY = mb.ref_y[g];
+    const uint4 *base = mb.planes + (g * NPLANES) * n_pad;
+    const unsigned mp[4] = {q4.x, q4.y, q4.z, q4.w};
+    for (unsigned c0 = 0; c0 < n; c0 += PL_CHUNK) {
+        // the chunk's flagged samples: thread t looks at samples c0 + 16 t .. + 15
+        const unsigned s0 = c0 + 16u * tid;
+        unsigned bits = s0 < n ? (unsigned)(mb.flags[g * mb.flag_words + (s0 >> 6)] >> (s0 & 63u)) & 0xFFFFu : 0u;
+        const unsigned cnt = (unsigned)__popc(bits);
+        unsigned x = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const unsigned o = __shfl_up(x, off, 64); if ((int)lane >= off) x += o; }
+        if (lane == 63u) wtot[wave] = x;
+        __syncthreads();                                     // (also: the sites' offsets, the previous chunk's queue worked off)
+        unsigned pos = x - cnt, qcount = 0;
+#pragma unroll
+        for (unsigned w = 0; w < PL_THREADS / 64u; w++) { const unsigned t = wtot[w]; if (w < wave) pos += t; qcount += t; }
+        while (bits) { const unsigned b = (unsigned)__ffs(bits) - 1u; bits &= bits - 1u; queue[pos++] = (unsigned short)(16u * tid + b); }
+        __syncthreads();
+        for (unsigned k0 = 0; k0 < qcount; k0 += 2u * PL_THREADS) {
+            // two samples per thread and step: eight 16-byte loads under way
+            const unsigned ka = k0 + tid, kb = k0 + PL_THREADS + tid;
+            const bool ha = ka < qcount, hb = kb < qcount;
+            const unsigned sa = c0 + (ha ? queue[ka] : 0u), sb = c0 + (hb ? queue[kb] : 0u);
+            const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+            // (the stored N plane is A & C & G & T by construction: four loads, not five)
+            const uint4 Aa = ha ? base[sa] : z, Ca = ha ? base[n_pad + sa] : z, Ga = ha ? base[2 * n_pad + sa] : z, Ta = ha ? base[3 * n_pad + sa] : z;
+            const uint4 Ab = hb ? base[sb] : z, Cb = hb ? base[n_pad + sb] : z, Gb = hb ? base[2 * n_pad + sb] : z, Tb = hb ? base[3 * n_pad + sb] : z;
+            auto sample = [&](unsigned s, const uint4 &A, const uint4 &C, const uint4 &G, const uint4 &T) {
+                unsigned listed_w = 0;
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    const unsigned a = word_of(A, w), c = word_of(C, w), gg = word_of(G, w), t = word_of(T, w), isn = a & c & gg & t;
+                    const unsigned rx = word_of(RX, w), ry = word_of(RY, w);
+                    const unsigned ra = ~rx & ~ry, rc = rx & ~ry, rg = ~rx & ry, rt = rx & ry;
+                    const unsigned has_ref = (a & ra) | (c & rc) | (gg & rg) | (t & rt);
+                    const unsigned only_ref = ~((a ^ ra) | (c ^ rc) | (gg ^ rg) | (t ^ rt));
+                    // (the classification's predicate exactly: carries some allele bit, is not N, is not exactly the reference base)
+                    unsigned pm = (a | c | gg | t) & ~isn & ~only_ref & mp[w];
+                    while (pm) {
+                        const unsigned b = (unsigned)__ffs(pm) - 1u;
+                        pm &= pm - 1u;
+                        const unsigned mask = ((a >> b) & 1u) | (((c >> b) & 1u) << 1) | (((gg >> b) & 1u) << 2) | (((t >> b) & 1u) << 3);
+                        const unsigned code = (((has_ref >> b) & 1u) ? 0u : 16u) | mask;
+                        const unsigned st = (unsigned)w * 32u + b;
+                        const unsigned slot = (code & 16u) ? atomicAdd(&curP[st], 1u) : kp[st] - 1u - atomicAdd(&curQ[st], 1u);
+                        sorted[loff[st] + slot] = (s << ENT_SHIFT) | code;
+                        listed_w += code >> 4;
+                    }
+                }
+                if (listed_w) atomicAdd(&c_p[s], listed_w);
+            };
+            if (ha) sample(sa, Aa, Ca, Ga, Ta);
+            if (hb) sample(sb, Ab, Cb, Gb, Tb);
+        }
+    }
+    __syncthreads();
+    // the w = 1 entries: one reservation in E1 for the group
+    if (tid < 64u) {
+        const unsigned a = curP[tid], b = curP[64 + tid];
+        unsigned xa = a, xb = b;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned oa = __shfl_up(xa, off, 64), ob = __shfl_up(xb, off, 64);
+            if ((int)tid >= off) { xa += oa; xb += ob; }
+        }
+        const unsigned ta = __shfl(xa, 63, 64), tb = __shfl(xb, 63, 64);
+        w1off[tid] = xa - a; w1off[64 + tid] = ta + xb - b;
+        if (tid == 0) e1_base = (ta + tb) ? atomicAdd(n_e1, (unsigned long long)(ta + tb)) : 0ull;
+    }
+    __syncthreads();
+    if (tid < SITES_PER_GROUP) {
+        const unsigned k = kp[tid], w1 = curP[tid], lo = loff[tid];
+        const bool is_long = k > P_SHORT_MAX;
+        if (k && !is_long)
+            for (unsigned m = 0; m < k; m++) p_ent[baseP + lo + m] = sorted[lo + m];
+        const unsigned long long at = e1_base + w1off[tid];
+        for (unsigned m = 0; m < w1; m++) {
+            const unsigned ent = sorted[lo + m];
+            E1[at + m] = make_uint2(ent >> ENT_SHIFT, (is_long ? ENT_LONG : 0u) | (rk[tid] << ENT_SHIFT) | (ent & 31u));
+        }
+    }
+    // q lines: half a wave per line, 32 dwords = 128 bytes per store
+    const unsigned hw = tid >> 5, l = tid & 31u;
+    for (unsigned st = hw; st < SITES_PER_GROUP; st += PL_THREADS / 32u) {
+        const unsigned k = kp[st];
+        if (k <= P_SHORT_MAX) continue;
+        const unsigned lo = loff[st], lines_n = k / 31u + 1u;
+        for (unsigned j = 0; j < lines_n; j++) {
+            const unsigned qs = 31u * j + l;                 // dword of the list (0: the header; entry i at dword i + 1)
+            unsigned v = 0u;
+            if (l == 31u) v = j == 0u ? qb[st] : 0u;
+            else if (qs == 0u) v = k | (curP[st] << 16);
+            else if (qs <= k) v = sorted[lo + qs - 1u];
+            qd[(size_t)(j ? qb[st] + j - 1u : rk[st]) * 32 + l] = v;
         }
     }
 }
@@ -917,12 +1064,9 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb_, hipStream_t 
     SL_TRY(hipMemcpyAsync(g->lst_mask, mb.lst_mask, groups * sizeof(uint4), hipMemcpyDeviceToDevice, stream));
     SL_TRY(hipMemcpyAsync(g->off_lst, mb.off_lst, groups * sizeof(unsigned), hipMemcpyDeviceToDevice, stream));
     const double plane_b = (double)groups * (double)a->n_pad * sizeof(uint4);      // the N plane
-    // (pieces of 512 samples; 1 024 when many samples per group are flagged for the p lists -- more than one listed entry per ten
-    // (sample, group) pairs: alignments with partial codes)
-    if ((double)mb.tot_p > 0.1 * (double)n * (double)groups)
-        hipLaunchKernelGGL((site_lists_kernel<1024>), dim3((unsigned)groups), dim3(SITE_THREADS), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off, g->p_ent, reinterpret_cast<unsigned *>(g->qlines), E, E1, n_e1, g->lines, g->c_p);
-    else
-        hipLaunchKernelGGL((site_lists_kernel<512>), dim3((unsigned)groups), dim3(SITE_THREADS), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off, g->p_ent, reinterpret_cast<unsigned *>(g->qlines), E, E1, n_e1, g->lines, g->c_p);
+    hipLaunchKernelGGL((site_lists_kernel<512>), dim3((unsigned)groups), dim3(SITE_THREADS), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off, g->p_ent, reinterpret_cast<unsigned *>(g->qlines), E, E1, n_e1, g->lines, g->c_p);
+    if (mb.tot_p)
+        hipLaunchKernelGGL(p_lists_kernel, dim3((unsigned)groups), dim3(PL_THREADS), 0, stream, mb, a->n_pad, (unsigned)n, g->p_ent, reinterpret_cast<unsigned *>(g->qlines), E1, n_e1, g->c_p);
     pack_stage_mark("lists: per site", stream, plane_b + (double)groups * SITES_PER_GROUP * 8.0,
                     (double)L * 128.0 + (double)mb.tot_p * 4.0 + (double)L * 8.0 + (double)(mb.tot_q + std::min<unsigned long long>(L, mb.tot_p)) * 8.0);
     // the per-sample lists hold the w = 1 entries: c_p[s] of them
