@@ -55,6 +55,7 @@ struct SiteLists {
     int n_rows = 0;
 };
 constexpr int ENT_SHIFT = 5;                   // entries: index << 5 | w << 4 | 4-bit allele mask
+constexpr unsigned ENT_HOLE = 0xFFFFFFFFu;     // E: (sample, entry) by list position; sample = ENT_HOLE where the list's entry has w = 0
 constexpr unsigned ENT_LONG = 0x80000000u;     // per-sample entries: the site's p list is a q line (ranks stay below 2^26)
 
 __device__ __forceinline__ unsigned word_of(const uint4 &v, int w) { return w == 0 ? v.x : w == 1 ? v.y : w == 2 ? v.z : v.w; }
@@ -129,8 +130,7 @@ struct N8Encoder {
 template <unsigned PIECE_SAMPLES>
 __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBuild mb, size_t n_pad, unsigned n,
                                                          unsigned long long *__restrict__ p_off, unsigned *__restrict__ p_ent,
-                                                         unsigned *__restrict__ qd, uint2 *__restrict__ E, uint2 *__restrict__ E1,
-                                                         unsigned long long *__restrict__ n_e1, uint4 *__restrict__ lines,
+                                                         unsigned *__restrict__ qd, uint2 *__restrict__ E, uint4 *__restrict__ lines,
                                                          unsigned *__restrict__ c_p)
 {
     constexpr unsigned PIECE_WORDS = PIECE_SAMPLES / 32, BM_STRIDE = PIECE_WORDS + 1;     // (odd stride: conflict-free column writes)
@@ -199,8 +199,8 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
         } else {
             p_ent[pos] = (s << ENT_SHIFT) | code;
         }
-        // (only a sample with w = 1 walks lists afterwards: the others' entries exist in the site's list alone)
-        if (code & 16u) E[pos] = make_uint2(s, (is_long ? ENT_LONG : 0u) | (rk[st] << ENT_SHIFT) | code);
+        // (only a sample with w = 1 walks lists afterwards: the others' entries exist in the site's list alone -- a hole in E)
+        E[pos] = (code & 16u) ? make_uint2(s, (is_long ? ENT_LONG : 0u) | (rk[st] << ENT_SHIFT) | code) : make_uint2(ENT_HOLE, 0u);
     };
     for (unsigned piece = 0; piece < n; piece += PIECE_SAMPLES) {
         const unsigned par = (piece / PIECE_SAMPLES) & 1u;
@@ -312,22 +312,6 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
         enc.finish();
         if (from_planes && kp[tid] > P_SHORT_MAX) { qd[(size_t)rk[tid] * 32] = kp[tid] | (curP[tid] << 16); qd[(size_t)rk[tid] * 32 + 31] = qb[tid]; }
     }
-    // the w = 1 entries -- the first curP of each site's run in E -- closed up into E1, a bag the per-sample lists are bucketed from: one
-    // global atomic per wave (the piece loop's last barrier stands between E's writers and these reads)
-    if (from_planes) {
-        const unsigned w1 = mine ? curP[tid] : 0u;
-        unsigned x = w1;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const unsigned o = __shfl_up(x, off, 64); if ((int)lane >= off) x += o; }
-        const unsigned total = __shfl(x, 63, 64);
-        if (total) {                                         // (wave-uniform)
-            unsigned long long at = 0;
-            if (lane == 0) at = atomicAdd(n_e1, (unsigned long long)total);
-            at = __shfl(at, 0, 64) + (x - w1);
-            const uint2 *src = E + (mine ? bP[tid] : 0ull);
-            for (unsigned k = 0; k < w1; k++) E1[at + k] = src[k];
-        }
-    }
 }
 
 // ---- per site: p lists ---------------------------------------------------------------------------------------------------------------
@@ -335,19 +319,17 @@ __global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBui
 // samples at a time, their four allele words read, and every listed (sample, site) pair is dropped into an LDS image of the group's
 // p lists -- a counting sort on the sites' known sizes; within a site the w = 1 entries from the front, the others from the back --
 // which then leaves as whole lines: the short lists into p_ent, the long ones as q lines written 128 bytes at a time, the w = 1
-// entries into E1.  (Dropped one by one into global memory -- site_lists_kernel's way until round 5, kept for the groups whose
+// entries into E.  (Dropped one by one into global memory -- site_lists_kernel's way until round 5, kept for the groups whose
 // lists outgrow the image -- the 253 M entries of an alignment with 0.5 % partial codes were 253 M four-byte stores into 1.3 GB of
 // q lines that left the L2 half written and came back to be finished.)
 __global__ __launch_bounds__(PL_THREADS) void p_lists_kernel(const MinorBuild mb, size_t n_pad, unsigned n, unsigned *__restrict__ p_ent,
-                                                             unsigned *__restrict__ qd, uint2 *__restrict__ E1,
-                                                             unsigned long long *__restrict__ n_e1, unsigned *__restrict__ c_p)
+                                                             unsigned *__restrict__ qd, uint2 *__restrict__ E, unsigned *__restrict__ c_p)
 {
     __shared__ unsigned sorted[PL_CAP];
+    __shared__ unsigned char site_of[PL_CAP];                // the site each entry of the image belongs to
     __shared__ unsigned kp[SITES_PER_GROUP], loff[SITES_PER_GROUP], curP[SITES_PER_GROUP], curQ[SITES_PER_GROUP], rk[SITES_PER_GROUP], qb[SITES_PER_GROUP];
-    __shared__ unsigned w1off[SITES_PER_GROUP];
     __shared__ unsigned short queue[PL_CHUNK];
     __shared__ unsigned wtot[PL_THREADS / 64];
-    __shared__ unsigned long long e1_base;
     const size_t g = blockIdx.x;
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint4 q4 = mb.minor_mask[g];
@@ -413,6 +395,7 @@ __global__ __launch_bounds__(PL_THREADS) void p_lists_kernel(const MinorBuild mb
                         const unsigned st = (unsigned)w * 32u + b;
                         const unsigned slot = (code & 16u) ? atomicAdd(&curP[st], 1u) : kp[st] - 1u - atomicAdd(&curQ[st], 1u);
                         sorted[loff[st] + slot] = (s << ENT_SHIFT) | code;
+                        site_of[loff[st] + slot] = (unsigned char)st;
                         listed_w += code >> 4;
                     }
                 }
@@ -423,30 +406,13 @@ __global__ __launch_bounds__(PL_THREADS) void p_lists_kernel(const MinorBuild mb
         }
     }
     __syncthreads();
-    // the w = 1 entries: one reservation in E1 for the group
-    if (tid < 64u) {
-        const unsigned a = curP[tid], b = curP[64 + tid];
-        unsigned xa = a, xb = b;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned oa = __shfl_up(xa, off, 64), ob = __shfl_up(xb, off, 64);
-            if ((int)tid >= off) { xa += oa; xb += ob; }
-        }
-        const unsigned ta = __shfl(xa, 63, 64), tb = __shfl(xb, 63, 64);
-        w1off[tid] = xa - a; w1off[64 + tid] = ta + xb - b;
-        if (tid == 0) e1_base = (ta + tb) ? atomicAdd(n_e1, (unsigned long long)(ta + tb)) : 0ull;
-    }
-    __syncthreads();
-    if (tid < SITES_PER_GROUP) {
-        const unsigned k = kp[tid], w1 = curP[tid], lo = loff[tid];
-        const bool is_long = k > P_SHORT_MAX;
-        if (k && !is_long)
-            for (unsigned m = 0; m < k; m++) p_ent[baseP + lo + m] = sorted[lo + m];
-        const unsigned long long at = e1_base + w1off[tid];
-        for (unsigned m = 0; m < w1; m++) {
-            const unsigned ent = sorted[lo + m];
-            E1[at + m] = make_uint2(ent >> ENT_SHIFT, (is_long ? ENT_LONG : 0u) | (rk[tid] << ENT_SHIFT) | (ent & 31u));
-        }
+    // the image leaves as it is: E (by list position: the w = 1 entries, holes for the others), the short lists into p_ent
+    const unsigned total = mb.gP[g];
+    for (unsigned i = tid; i < total; i += PL_THREADS) {
+        const unsigned ent = sorted[i], st = site_of[i];
+        const bool is_long = kp[st] > P_SHORT_MAX;
+        E[baseP + i] = (ent & 16u) ? make_uint2(ent >> ENT_SHIFT, (is_long ? ENT_LONG : 0u) | (rk[st] << ENT_SHIFT) | (ent & 31u)) : make_uint2(ENT_HOLE, 0u);
+        if (!is_long) p_ent[baseP + i] = ent;
     }
     // q lines: half a wave per line, 32 dwords = 128 bytes per store
     const unsigned hw = tid >> 5, l = tid & 31u;
@@ -467,13 +433,14 @@ __global__ __launch_bounds__(PL_THREADS) void p_lists_kernel(const MinorBuild mb
 
 // ---- per sample: listed entries (from E) ---------------------------------------------------------------------------------------
 // (their number per sample, c_p[s], comes from the per-site pass.)  The entries of E are placed through per-sample cursors.
-__global__ __launch_bounds__(256) void listed_entries_kernel(const uint2 *__restrict__ E, const unsigned long long *__restrict__ countp,
+__global__ __launch_bounds__(256) void listed_entries_kernel(const uint2 *__restrict__ E, unsigned long long count,
                                                              const unsigned long long *__restrict__ off, unsigned *__restrict__ cur,
                                                              unsigned *__restrict__ ent)
 {
     const unsigned long long k = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
-    if (k >= *countp) return;
+    if (k >= count) return;
     const uint2 e = E[k];
+    if (e.x == ENT_HOLE) return;
     ent[off[e.x] + atomicAdd(&cur[e.x], 1u)] = e.y;
 }
 
@@ -485,14 +452,13 @@ __global__ __launch_bounds__(256) void listed_entries_kernel(const uint2 *__rest
 //   pass B   within a bucket by sample (at most 1 024 samples), into s_ent.
 // A tile reserves its share of every run it touches with one global atomic per run, and its writes into a run are consecutive.
 constexpr unsigned ENT_TILE_THREADS = 1024, ENT_PER_THREAD = 8, ENT_TILE = ENT_TILE_THREADS * ENT_PER_THREAD;
-__global__ __launch_bounds__(ENT_TILE_THREADS) void entries_to_buckets_kernel(const uint2 *__restrict__ E, const unsigned long long *__restrict__ countp, unsigned shift,
+__global__ __launch_bounds__(ENT_TILE_THREADS) void entries_to_buckets_kernel(const uint2 *__restrict__ E, unsigned long long count, unsigned shift,
                                                                               unsigned n, const unsigned long long *__restrict__ s_off,
                                                                               unsigned *__restrict__ bcur, uint2 *__restrict__ tmp)
 {
     __shared__ unsigned hist[256], base[256];
     const unsigned tid = threadIdx.x;
-    const unsigned long long count = *countp, t0 = (unsigned long long)blockIdx.x * ENT_TILE;
-    if (t0 >= count) return;                                 // (the grid covers every entry of the p lists; E holds the w = 1 ones)
+    const unsigned long long t0 = (unsigned long long)blockIdx.x * ENT_TILE;
     if (tid < 256u) hist[tid] = 0;
     __syncthreads();
     uint2 e[ENT_PER_THREAD];
@@ -500,16 +466,15 @@ __global__ __launch_bounds__(ENT_TILE_THREADS) void entries_to_buckets_kernel(co
 #pragma unroll
     for (int q = 0; q < (int)ENT_PER_THREAD; q++) {
         const unsigned long long k = t0 + (unsigned long long)q * ENT_TILE_THREADS + tid;
-        e[q] = k < count ? E[k] : make_uint2(0u, 0u);
-        slot[q] = k < count ? atomicAdd(&hist[e[q].x >> shift], 1u) : 0u;
+        e[q] = k < count ? E[k] : make_uint2(ENT_HOLE, 0u);                     // (holes: the p lists' entries with w = 0)
+        slot[q] = e[q].x != ENT_HOLE ? atomicAdd(&hist[e[q].x >> shift], 1u) : 0u;
     }
     __syncthreads();
     if (tid < 256u && hist[tid]) base[tid] = atomicAdd(&bcur[tid], hist[tid]);
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < (int)ENT_PER_THREAD; q++) {
-        const unsigned long long k = t0 + (unsigned long long)q * ENT_TILE_THREADS + tid;
-        if (k >= count) continue;
+        if (e[q].x == ENT_HOLE) continue;
         const unsigned b = e[q].x >> shift;
         tmp[s_off[min((unsigned long long)n, (unsigned long long)b << shift)] + base[b] + slot[q]] = e[q];
     }
@@ -1050,45 +1015,44 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb_, hipStream_t 
     const bool bitmaps = mb.tot_nnl > 0;
     if (bitmaps) SL_TRY(pack_alloc(a, n * g->tgroups * sizeof(uint4), reinterpret_cast<void **>(&g->T)));
     unsigned *cnt = nullptr;
-    uint2 *E = nullptr, *E1 = nullptr;
+    uint2 *E = nullptr;
     int rc;
-    // E: the p entries with w = 1 where the per-site pass drops them (by list position); E1: the same closed up (n_e1 of them, counted on
-    // the device) -- E's memory serves again as the first bucketing pass's output
+    // E: (sample, entry) of every p-list entry with w = 1, by list position -- holes where w = 0 --: what the per-sample lists are bucketed from
     if ((rc = workspace_get(60, (2 * std::max<size_t>(n, 1) + 8 + 256) * 4, reinterpret_cast<void **>(&cnt))) ||
-        (rc = workspace_get(62, std::max<size_t>(mb.tot_p, 1) * sizeof(uint2), reinterpret_cast<void **>(&E))) ||
-        (rc = workspace_get(63, std::max<size_t>(mb.tot_p, 1) * sizeof(uint2), reinterpret_cast<void **>(&E1)))) { delete g; return rc; }
-    unsigned long long *n_e1 = reinterpret_cast<unsigned long long *>(cnt);
+        (rc = workspace_get(62, std::max<size_t>(mb.tot_p, 1) * sizeof(uint2), reinterpret_cast<void **>(&E)))) { delete g; return rc; }
     unsigned *cur = cnt + std::max<size_t>(n, 1), *d_max = cur + std::max<size_t>(n, 1), *bcur = d_max + 8;
     SL_TRY(hipMemsetAsync(cnt, 0, (2 * std::max<size_t>(n, 1) + 8 + 256) * 4, stream));
     SL_TRY(hipMemsetAsync(g->c_p, 0, std::max<size_t>(n, 1) * 4, stream));
     SL_TRY(hipMemcpyAsync(g->lst_mask, mb.lst_mask, groups * sizeof(uint4), hipMemcpyDeviceToDevice, stream));
     SL_TRY(hipMemcpyAsync(g->off_lst, mb.off_lst, groups * sizeof(unsigned), hipMemcpyDeviceToDevice, stream));
     const double plane_b = (double)groups * (double)a->n_pad * sizeof(uint4);      // the N plane
-    hipLaunchKernelGGL((site_lists_kernel<512>), dim3((unsigned)groups), dim3(SITE_THREADS), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off, g->p_ent, reinterpret_cast<unsigned *>(g->qlines), E, E1, n_e1, g->lines, g->c_p);
-    if (mb.tot_p)
-        hipLaunchKernelGGL(p_lists_kernel, dim3((unsigned)groups), dim3(PL_THREADS), 0, stream, mb, a->n_pad, (unsigned)n, g->p_ent, reinterpret_cast<unsigned *>(g->qlines), E1, n_e1, g->c_p);
+    hipLaunchKernelGGL((site_lists_kernel<512>), dim3((unsigned)groups), dim3(SITE_THREADS), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off, g->p_ent, reinterpret_cast<unsigned *>(g->qlines), E, g->lines, g->c_p);
+    // (a group can only reach p_lists_kernel's threshold when the alignment has that many entries)
+    if (mb.tot_p >= PL_MIN)
+        hipLaunchKernelGGL(p_lists_kernel, dim3((unsigned)groups), dim3(PL_THREADS), 0, stream, mb, a->n_pad, (unsigned)n, g->p_ent, reinterpret_cast<unsigned *>(g->qlines), E, g->c_p);
     pack_stage_mark("lists: per site", stream, plane_b + (double)groups * SITES_PER_GROUP * 8.0,
-                    (double)L * 128.0 + (double)mb.tot_p * 4.0 + (double)L * 8.0 + (double)(mb.tot_q + std::min<unsigned long long>(L, mb.tot_p)) * 8.0);
+                    (double)L * 128.0 + (double)mb.tot_p * 12.0 + (double)L * 8.0 + (double)(mb.tot_q + std::min<unsigned long long>(L, mb.tot_p)) * 8.0);
     // the per-sample lists hold the w = 1 entries: c_p[s] of them
     hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, g->c_p, n, g->s_off);
     bool two_pass = false;
     if (mb.tot_p) {
         unsigned shift = 0;
         while (((n - 1) >> shift) >= 256u) shift++;                                   // at most 256 buckets of 2^shift samples
-        uint2 *tmp = E;
-        two_pass = mb.tot_p >= ENT_TILE && mb.tot_p < (1ull << 32) && shift <= 10;      // (32-bit run cursors; at most 1 024 samples per bucket)
-        // (grids by the p lists' total, an upper bound: the blocks beyond the w = 1 entries leave at once)
+        uint2 *tmp = nullptr;
+        two_pass = mb.tot_p >= ENT_TILE && mb.tot_p < (1ull << 32) && shift <= 10 &&      // (32-bit run cursors; at most 1 024 samples per bucket)
+                              workspace_get(63, (size_t)mb.tot_p * sizeof(uint2), reinterpret_cast<void **>(&tmp)) == TRACS_OK;
         if (two_pass) {
             const unsigned buckets = (unsigned)(((n - 1) >> shift) + 1);
-            hipLaunchKernelGGL(entries_to_buckets_kernel, dim3((unsigned)((mb.tot_p + ENT_TILE - 1) / ENT_TILE)), dim3(ENT_TILE_THREADS), 0, stream, E1, n_e1,
+            hipLaunchKernelGGL(entries_to_buckets_kernel, dim3((unsigned)((mb.tot_p + ENT_TILE - 1) / ENT_TILE)), dim3(ENT_TILE_THREADS), 0, stream, E, mb.tot_p,
                                shift, (unsigned)n, g->s_off, bcur, tmp);
             const unsigned per_bucket = (unsigned)std::min<unsigned long long>(64, std::max<unsigned long long>(1, mb.tot_p / buckets / ENT_TILE + 1));
             hipLaunchKernelGGL(buckets_to_samples_kernel, dim3(per_bucket, buckets), dim3(ENT_TILE_THREADS), 0, stream, tmp, shift, (unsigned)n, g->s_off, cur, g->s_ent);
         } else {
-            hipLaunchKernelGGL(listed_entries_kernel, dim3((unsigned)std::min<unsigned long long>(0x7FFFFFFFull, (mb.tot_p + 255) / 256)), dim3(256), 0, stream, E1, n_e1, g->s_off, cur, g->s_ent);
+            (void)hipGetLastError(); set_error("");
+            hipLaunchKernelGGL(listed_entries_kernel, dim3((unsigned)((mb.tot_p + 255) / 256)), dim3(256), 0, stream, E, mb.tot_p, g->s_off, cur, g->s_ent);
         }
     }
-    pack_stage_mark("listed entries per sample", stream, (double)std::min<unsigned long long>(mb.tot_p, L) * (two_pass ? 16.0 : 8.0) + (double)n * 4.0,
+    pack_stage_mark("listed entries per sample", stream, (double)mb.tot_p * 8.0 + (double)std::min<unsigned long long>(mb.tot_p, L) * (two_pass ? 8.0 : 0.0) + (double)n * 4.0,
                     (double)std::min<unsigned long long>(mb.tot_p, L) * (two_pass ? 12.0 : 4.0) + (double)n * 12.0);
     if (bitmaps) {
         // (a->c_counted was zeroed by the caller: this kernel is what fills it when the rows' bitmaps are built)
