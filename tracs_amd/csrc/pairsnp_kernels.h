@@ -129,6 +129,7 @@ struct MinorBuild {
     const unsigned *off_lst;                 // per group: sites with lists before it (a site's list index = its rank among them)
     const unsigned *cntP, *cntN;             // per site: listed samples, N samples
     const unsigned *gP;                      // per group: p-list entries of its minority sites
+    unsigned long long max_gp;               //   ... and the most any group has
     const unsigned long long *baseP, *baseO; // per group: p-list entries / overflow lines (upper bounds) of the groups before it
     const unsigned long long *baseQ;         // per group: overflow lines of the p lists (q lines) of the groups before it
     const unsigned long long *flags;         // per group and 64 samples: listed somewhere in the group

@@ -347,11 +347,12 @@ __global__ __launch_bounds__(1024) void group_offsets_kernel(const uint4 *__rest
         if (b < 7) { const uint4 a = masks[(size_t)b * groups + g]; return (unsigned long long)(__popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w)); }
         return gcounts[(size_t)(b - 7) * groups + g];
     };
-    unsigned long long base = 0, c_next = count_of((size_t)t);
+    unsigned long long base = 0, c_next = count_of((size_t)t), c_max = 0;
     int par = 0;
     for (size_t g0 = 0; g0 < groups; g0 += 1024, par ^= 1) {
         const size_t g = g0 + t;
         const unsigned long long c = c_next;
+        c_max = max(c_max, c);
         c_next = count_of(g + 1024);
         unsigned long long incl = c;
 #pragma unroll
@@ -371,6 +372,11 @@ __global__ __launch_bounds__(1024) void group_offsets_kernel(const uint4 *__rest
         base += all;
     }
     if (t == 0) totals[b] = base;
+    if (b == 7) {                                            // the most p-list entries any group has: totals[14] (p_lists_kernel is launched for such groups only)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c_max = max(c_max, (unsigned long long)__shfl_xor(c_max, off, 64));
+        if (lane == 0 && c_max) atomicMax(&totals[14], c_max);
+    }
 }
 
 // the sites of a class in site order: list[off[g] ..] = the set bits of mask[g]
@@ -723,6 +729,7 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
         mb.ref_x = mask_of(M_REFX); mb.ref_y = mask_of(M_REFY); mb.un_mask = mask_of(M_UN); mb.off_lst = off_of(lst_slot);
         mb.cntP = cntP; mb.cntN = cntN; mb.gP = gcnt; mb.baseP = off64; mb.baseO = off64 + (size_t)ovf_slot * groups; mb.flags = flags; mb.flag_words = flag_words;
         mb.sites = L_lst; mb.tot_p = tot_p; mb.tot_o = tot_o; mb.tot_nnl = tot_nnl; mb.baseQ = off64 + 6 * groups; mb.tot_q = tot_q; mb.long_p = long_p ? 1 : 0;
+        mb.max_gp = tot[14];
         mb.n_rows = a->n_row_hint;
         for (int k = 0; k < 4; k++) mb.rows[k] = (unsigned)std::min<size_t>(a->row_hint[k], a->n);
         rc = minority_lists_build(a, mb, stream, &built);

@@ -127,8 +127,17 @@ struct N8Encoder {
     }
 };
 
+// (six waves per SIMD -- 80 VGPRs --: the p-list branch costs two registers more, spilled there, and a wave of the encoder's)
+#ifndef TRACS_SITE_WAVES
+#define TRACS_SITE_WAVES 6
+#endif
+#if TRACS_SITE_WAVES > 0
+#define TRACS_SITE_ATTR __attribute__((amdgpu_waves_per_eu(TRACS_SITE_WAVES, TRACS_SITE_WAVES)))
+#else
+#define TRACS_SITE_ATTR
+#endif
 template <unsigned PIECE_SAMPLES>
-__global__ __launch_bounds__(SITE_THREADS) void site_lists_kernel(const MinorBuild mb, size_t n_pad, unsigned n,
+__global__ __launch_bounds__(SITE_THREADS) TRACS_SITE_ATTR void site_lists_kernel(const MinorBuild mb, size_t n_pad, unsigned n,
                                                          unsigned long long *__restrict__ p_off, unsigned *__restrict__ p_ent,
                                                          unsigned *__restrict__ qd, uint2 *__restrict__ E, uint4 *__restrict__ lines,
                                                          unsigned *__restrict__ c_p)
@@ -1027,8 +1036,8 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb_, hipStream_t 
     SL_TRY(hipMemcpyAsync(g->off_lst, mb.off_lst, groups * sizeof(unsigned), hipMemcpyDeviceToDevice, stream));
     const double plane_b = (double)groups * (double)a->n_pad * sizeof(uint4);      // the N plane
     hipLaunchKernelGGL((site_lists_kernel<512>), dim3((unsigned)groups), dim3(SITE_THREADS), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off, g->p_ent, reinterpret_cast<unsigned *>(g->qlines), E, g->lines, g->c_p);
-    // (a group can only reach p_lists_kernel's threshold when the alignment has that many entries)
-    if (mb.tot_p >= PL_MIN)
+    // (only when some group's lists are that kernel's: at least PL_MIN entries)
+    if (mb.max_gp >= PL_MIN)
         hipLaunchKernelGGL(p_lists_kernel, dim3((unsigned)groups), dim3(PL_THREADS), 0, stream, mb, a->n_pad, (unsigned)n, g->p_ent, reinterpret_cast<unsigned *>(g->qlines), E, g->c_p);
     pack_stage_mark("lists: per site", stream, plane_b + (double)groups * SITES_PER_GROUP * 8.0,
                     (double)L * 128.0 + (double)mb.tot_p * 12.0 + (double)L * 8.0 + (double)(mb.tot_q + std::min<unsigned long long>(L, mb.tot_p)) * 8.0);
