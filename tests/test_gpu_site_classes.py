@@ -361,15 +361,17 @@ def test_long_n_lists(hiplib, oracle, env, p_n):
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
 
 
-@pytest.mark.parametrize("n", [65534, 65600])
-def test_lists_at_the_16_bit_boundary(hiplib, oracle, n):
+@pytest.mark.parametrize("n,p_partial", [(65534, 0.0), (65600, 0.0), (65600, 0.0003)])
+def test_lists_at_the_16_bit_boundary(hiplib, oracle, n, p_partial):
     """65 534 / 65 600 samples: two column chunks per row, and -- beyond 65 536 samples -- the per-site pass takes every group in
     pieces (its LDS staging holds 16-bit offsets from a piece's first sample); lists of a few N samples among 65 000: long runs of
-    skip bytes.  Row panels against the oracle on a subset of the columns (the panel rows + 1 500 random samples)."""
+    skip bytes.  With partial codes (~20 listed samples per site, ~2 500 per group) the p lists are p_lists_kernel's: its queue of
+    flagged samples in chunks of 4 096, sample numbers beyond 16 bits in the q lines.  Row panels against the oracle on a subset of
+    the columns (the panel rows + 1 500 random samples)."""
     import torch
     from tracs_amd import device as dev, synth
     L = 512
-    seqs = synth.alignment(n, L, seed=123, mu_lineage=2e-3, mu_sample=3e-4, n_lineages=9, p_n=0.004)
+    seqs = synth.alignment(n, L, seed=123, mu_lineage=2e-3, mu_sample=3e-4, n_lineages=9, p_n=0.004, p_partial=p_partial)
     aln = dev.Alignment(n, L)
     aln.pack(seqs)
     rng = np.random.default_rng(5)

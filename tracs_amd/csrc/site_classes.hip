@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
 
     // ---- pass 2: k and cN of every site -----------------------------------------------------------------------------------
     unsigned anyb[4] = {0, 0, 0, 0}, bad = 0;
-    const int site = tid & 127, sw = site >> 5, sb = site & 31, half = tid >> 7;
+    const int site = tid & 127, sw = site >> 5, sb = site & 31;
     // flush: the bit planes of all threads through LDS, one counter at a time.  Wave w takes word w (32 sites): for every plane and
     // every 64 threads, a 32 x 32 bit transpose across the half waves turns "bit b of thread t" into "bit t of lane b", whose
     // popcount is the site's count over those 32 threads -- 18 instructions per 64 words where summing bit by bit took 4 per bit
