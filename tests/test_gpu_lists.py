@@ -58,7 +58,8 @@ CASES = [
     dict(n=130, L=4000, p_n=0.05, mu=2e-3, seed=4, p_partial=0.002),    # partial codes among the listed samples
     dict(n=700, L=3000, p_n=0.01, mu=3e-4, seed=5, bitmaps=True, edges=True),      # lists that end exactly at the encoder's boundaries
     dict(n=900, L=6000, p_n=0.01, mu=6e-3, seed=6, bitmaps=True),       # ~30 000 listed entries: the bucketed fill of the per-sample lists
-    dict(n=4000, L=1024, p_n=0.001, mu=1e-4, seed=7, p_partial=0.009, long_p=True),      # ~36 partial codes per site: p lists beyond one q line
+    dict(n=4000, L=1024, p_n=0.001, mu=1e-4, seed=7, p_partial=0.009, long_p=True, qw=64),      # ~36 partial codes per site: 256-byte q lines, some lists beyond one
+    dict(n=4000, L=1024, p_n=0.001, mu=1e-4, seed=7, p_partial=0.009, long_p=True, qw=32, env={"TRACS_QLINE_DWORDS": "32"}),      # ... the same in 128-byte q lines: most lists with an overflow line
     dict(n=4000, L=1024, p_n=0.0005, mu=1e-4, seed=8, p_partial=0.019, long_p=True),     # ~76 per site, ~9 700 per group: beyond the LDS image of p_lists_kernel (8 192)
     dict(n=2000, L=2048, p_n=0.002, mu=1e-4, seed=9, p_partial=0.0055),                  # ~11 per site, ~1 400 per group: p_lists_kernel with short (<= 4) and long lists side by side
 ]
@@ -79,7 +80,7 @@ EDGE_LISTS = [
 
 
 @pytest.mark.parametrize("nn_lists", ["always", "cost-model"])
-@pytest.mark.parametrize("case", range(len(CASES)), ids=lambda k: "n%d_L%d_pn%g" % (CASES[k]["n"], CASES[k]["L"], CASES[k]["p_n"]))
+@pytest.mark.parametrize("case", range(len(CASES)), ids=lambda k: "c%d_n%d_L%d_pn%g" % (k, CASES[k]["n"], CASES[k]["L"], CASES[k]["p_n"]))
 def test_lists_against_numpy(hiplib, case, nn_lists):
     """(a child process per case: the list threshold TRACS_NN_LIST_K is read once per process)"""
     import subprocess
@@ -87,8 +88,10 @@ def test_lists_against_numpy(hiplib, case, nn_lists):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
     env.pop("TRACS_NN_LIST_K", None)
+    env.pop("TRACS_QLINE_DWORDS", None)
     if nn_lists == "always":
         env["TRACS_NN_LIST_K"] = "1"
+    env.update(CASES[case].get("env", {}))
     code = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_lists as T; T.run_case(T.CASES[%d], %r)" % (
         root, os.path.join(root, "tests"), case, nn_lists)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900, cwd=root)
@@ -166,7 +169,16 @@ def run_case(case, nn_lists):
         assert hiplib.tracs_debug_lists(aln._h, 11, nq.ctypes.data_as(C.c_void_p), 8) == 8
         ks_all = np.diff(p_off.astype(np.int64))
         assert (int(nq[0]) >= sites) == bool((ks_all > 4).any())                     # q lines exist iff some list is a long one
-        q = _dump(hiplib, aln, 10, np.uint32, int(nq[0]) * 32).reshape(-1, 32) if nq[0] else None      # the longer p lists: q lines of 32 dwords
+        qwb = np.zeros(1, np.uint64)
+        assert hiplib.tracs_debug_lists(aln._h, 12, qwb.ctypes.data_as(C.c_void_p), 8) == 8
+        qw = int(qwb[0])                                                             # dwords per q line: 32, or 64 when the lists are long on average
+        if case.get("env", {}).get("TRACS_QLINE_DWORDS"):
+            assert qw == int(case["env"]["TRACS_QLINE_DWORDS"])
+        else:
+            assert qw == (64 if ks_all[ks_all > 0].mean() > 24 and (ks_all > 4).any() else 32), (qw, ks_all[ks_all > 0].mean())
+        if case.get("qw"):
+            assert qw == case["qw"]
+        q = _dump(hiplib, aln, 10, np.uint32, int(nq[0]) * qw).reshape(-1, qw) if nq[0] else None      # the longer p lists: q lines of qw dwords
         s_off = _dump(hiplib, aln, 6, np.uint64, n + 1)
         s_ent = _dump(hiplib, aln, 7, np.uint32, tot_p)
         c_p = _dump(hiplib, aln, 9, np.uint32, n)
@@ -174,7 +186,9 @@ def run_case(case, nn_lists):
         pairs_site = set()
         if case.get("long_p"):
             ks = np.diff(p_off.astype(np.int64))
-            assert (ks > 31).sum() > 50 and (ks > 62).sum() >= 0, ks.max()              # lists with one overflow line (and more)
+            assert (ks > 30).sum() > 50, ks.max()                                   # lists beyond a 128-byte line ...
+            assert qw == 64 or (ks > qw - 1).sum() > 50, ks.max()                   # ... in 128-byte lines: with an overflow line (and more)
+            assert case["seed"] != 8 or (ks > qw - 1).sum() > 50, ks.max()          # (~76 per site: overflow lines at either width)
         for r in range(sites):
             t = site_of_rank[r]
             k = int(p_off[r + 1]) - int(p_off[r])
@@ -183,12 +197,13 @@ def run_case(case, nn_lists):
             if k <= 4:
                 ents = p_ent[int(p_off[r]):int(p_off[r + 1])]
             else:
-                # site r's q lines: line r = header (k | w1 << 16), entries 0..29, index of the first overflow line; then 31 entries a line
-                hdr, ovf = int(q[r, 0]), int(q[r, 31])
-                assert hdr & 0xFFFF == k and (k <= 30 or sites <= ovf <= int(nq[0]) - (k // 31))
+                # site r's q lines: line r = header (k | w1 << 16), qw - 2 entries, index of the first overflow line; then qw - 1 entries a line
+                per = qw - 1
+                hdr, ovf = int(q[r, 0]), int(q[r, per])
+                assert hdr & 0xFFFF == k and (k <= per - 1 or sites <= ovf <= int(nq[0]) - (k // per))
                 slot = np.arange(k) + 1
-                line = np.where(slot < 31, r, ovf + slot // 31 - 1)
-                ents = q[line, slot % 31]
+                line = np.where(slot < per, r, ovf + slot // per - 1)
+                ents = q[line, slot % per]
             samp, w, mask = ents >> 5, (ents >> 4) & 1, ents & 15
             assert len(set(samp.tolist())) == samp.size
             if k > 4:

@@ -121,6 +121,8 @@ __host__ __device__ inline float n8_lines_expected(unsigned c, unsigned n)
 }
 // p lists of at most this many samples stay in p_ent (walked in the lane that finds them); longer ones are q lines (site_lists.hip)
 constexpr unsigned P_SHORT_MAX = 4;
+// q lines are 256 bytes instead of 128 when the minority sites list more than this many samples on average
+constexpr double Q_WIDE_MEAN = 24.0;
 
 struct MinorBuild {
     const uint4 *planes;                     // the five general planes
@@ -140,6 +142,7 @@ struct MinorBuild {
     unsigned long long tot_p, tot_o;         // p-list entries, overflow lines (upper bound) in all
     unsigned long long tot_q;                // overflow lines of the p lists in all
     int long_p;                              // some minority site lists more than P_SHORT_MAX samples: its p list is a q line (else: no q lines at all)
+    unsigned qw;                             // dwords per q line: 32, or 64 when the lists are long on average (site_lists.hip)
     unsigned long long tot_nnl;              // N samples at the NNL sites: list walks of one pass of nn_rows_add
 };
 int minority_lists_build(tracs_alignment *a, const MinorBuild &mb, hipStream_t stream, int *ok);

@@ -639,6 +639,9 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     const size_t L_dense = (size_t)tot[M_DENSE], L_minor = (size_t)tot[M_MINOR], L_full = (size_t)tot[M_FULL];
     size_t L_count = (size_t)tot[M_COUNT], L_nnl = (size_t)tot[M_NNL], L_lst = (size_t)tot[M_LST], L_un = (size_t)tot[M_UN];
     const unsigned long long tot_p = tot[7], tot_q = long_p ? tot[13] : 0ull;
+    // (256-byte q lines when the minority sites list more than Q_WIDE_MEAN samples on average: site_lists.hip; TRACS_QLINE_DWORDS=32|64 forces)
+    static const int force_qw = [] { const char *e = std::getenv("TRACS_QLINE_DWORDS"); return e ? std::atoi(e) : 0; }();
+    const unsigned qw = force_qw == 32 || force_qw == 64 ? (unsigned)force_qw : ((long_p && L_minor && (double)tot_p > Q_WIDE_MEAN * (double)L_minor) ? 64u : 32u);
     unsigned long long tot_o = tot[8], tot_nnl = tot[10];
     int lst_slot = M_LST, ovf_slot = 1;                      // which mask / per-group overflow bound the lists are built from
     if (force == 0 || a->L == 0 || a->n < 2) return TRACS_OK;
@@ -671,7 +674,7 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
         static const double env_cap = [] { const char *e = std::getenv("TRACS_LIST_CAP"); return e ? 4.0 * std::atof(e) : -1.0; }();
         const double cap = 0.8 * (double)NPLANES * (double)groups * (double)a->n_pad * sizeof(uint4);
         // N-list lines (primary + the overflow lines they can need at most), p lists and their per-sample form, the rows' N bitmaps
-        const double bytes = ((double)L_lst + (double)tot_o) * 128.0 + 16.0 * (double)tot_p + (long_p ? ((double)L_lst + (double)tot_q) * 128.0 : 0.0) +
+        const double bytes = ((double)L_lst + (double)tot_o) * 128.0 + 16.0 * (double)tot_p + (long_p ? ((double)L_lst + (double)tot_q) * 4.0 * (double)qw : 0.0) +
                              (L_nnl ? (double)a->n * (double)((groups + 7) / 8 * 8) * sizeof(uint4) : 0.0);
         if (L_lst >= (1ull << 26) || a->n >= (1ull << 27) || bytes > (env_cap >= 0.0 ? std::min(env_cap, cap) : cap) ||
             L_lst + tot_o >= (1ull << 32) || L_lst + tot_q >= (1ull << 32))                  // (line indices are 32 bits)
@@ -730,6 +733,7 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
         mb.cntP = cntP; mb.cntN = cntN; mb.gP = gcnt; mb.baseP = off64; mb.baseO = off64 + (size_t)ovf_slot * groups; mb.flags = flags; mb.flag_words = flag_words;
         mb.sites = L_lst; mb.tot_p = tot_p; mb.tot_o = tot_o; mb.tot_nnl = tot_nnl; mb.baseQ = off64 + 6 * groups; mb.tot_q = tot_q; mb.long_p = long_p ? 1 : 0;
         mb.max_gp = tot[14];
+        mb.qw = qw;
         mb.n_rows = a->n_row_hint;
         for (int k = 0; k < 4; k++) mb.rows[k] = (unsigned)std::min<size_t>(a->row_hint[k], a->n);
         rc = minority_lists_build(a, mb, stream, &built);

@@ -41,6 +41,9 @@ struct SiteLists {
                                                //   entries (sample << 5 | w << 4 | mask), dword 31 the index of its first overflow line; overflow
                                                //   lines (31 entries each) are consecutive.  ONE line fetch per walk for lists of up to 30
     unsigned long long n_qlines = 0;
+    unsigned qw = 32;                          // dwords per q line: 32 -- or 64 (a 256-byte line: header, 62 entries, first overflow line; 63 entries per
+                                               //   overflow line) when the alignment's minority sites list more than Q_WIDE_MEAN samples on average: a
+                                               //   51-entry list is one fetch then, not a line and, behind its header, a second one
     unsigned long long *s_off = nullptr;       // [n + 1]
     unsigned *s_ent = nullptr;
     unsigned *c_p = nullptr;                   // per sample: sum of w over its listed entries
@@ -203,8 +206,8 @@ __global__ __launch_bounds__(SITE_THREADS) TRACS_SITE_ATTR void site_lists_kerne
         const bool is_long = kp[st] > P_SHORT_MAX;
         if (is_long) {
             // entry `slot` of the site's list: dword slot + 1 of its q lines (31 dwords a line; dword 0 of the list is the header)
-            const unsigned qs = slot + 1u, qt = qs / 31u;
-            qd[(size_t)(qt ? qb[st] + qt - 1u : rk[st]) * 32 + (qs - qt * 31u)] = (s << ENT_SHIFT) | code;
+            const unsigned qs = slot + 1u, qt = qs / (mb.qw - 1u);
+            qd[(size_t)(qt ? qb[st] + qt - 1u : rk[st]) * mb.qw + (qs - qt * (mb.qw - 1u))] = (s << ENT_SHIFT) | code;
         } else {
             p_ent[pos] = (s << ENT_SHIFT) | code;
         }
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(SITE_THREADS) TRACS_SITE_ATTR void site_lists_kerne
     }
     if (mine) {
         enc.finish();
-        if (from_planes && kp[tid] > P_SHORT_MAX) { qd[(size_t)rk[tid] * 32] = kp[tid] | (curP[tid] << 16); qd[(size_t)rk[tid] * 32 + 31] = qb[tid]; }
+        if (from_planes && kp[tid] > P_SHORT_MAX) { qd[(size_t)rk[tid] * mb.qw] = kp[tid] | (curP[tid] << 16); qd[(size_t)rk[tid] * mb.qw + mb.qw - 1u] = qb[tid]; }
     }
 }
 
@@ -423,19 +426,20 @@ __global__ __launch_bounds__(PL_THREADS) void p_lists_kernel(const MinorBuild mb
         E[baseP + i] = (ent & 16u) ? make_uint2(ent >> ENT_SHIFT, (is_long ? ENT_LONG : 0u) | (rk[st] << ENT_SHIFT) | (ent & 31u)) : make_uint2(ENT_HOLE, 0u);
         if (!is_long) p_ent[baseP + i] = ent;
     }
-    // q lines: half a wave per line, 32 dwords = 128 bytes per store
-    const unsigned hw = tid >> 5, l = tid & 31u;
-    for (unsigned st = hw; st < SITES_PER_GROUP; st += PL_THREADS / 32u) {
+    // q lines: qw dwords = 128 or 256 bytes per store, half a wave or a wave per line
+    const unsigned qw = mb.qw, per = qw - 1u;
+    const unsigned hw = tid / qw, l = tid % qw;
+    for (unsigned st = hw; st < SITES_PER_GROUP; st += PL_THREADS / qw) {
         const unsigned k = kp[st];
         if (k <= P_SHORT_MAX) continue;
-        const unsigned lo = loff[st], lines_n = k / 31u + 1u;
+        const unsigned lo = loff[st], lines_n = k / per + 1u;
         for (unsigned j = 0; j < lines_n; j++) {
-            const unsigned qs = 31u * j + l;                 // dword of the list (0: the header; entry i at dword i + 1)
+            const unsigned qs = per * j + l;                 // dword of the list (0: the header; entry i at dword i + 1)
             unsigned v = 0u;
-            if (l == 31u) v = j == 0u ? qb[st] : 0u;
+            if (l == per) v = j == 0u ? qb[st] : 0u;
             else if (qs == 0u) v = k | (curP[st] << 16);
             else if (qs <= k) v = sorted[lo + qs - 1u];
-            qd[(size_t)(j ? qb[st] + j - 1u : rk[st]) * 32 + l] = v;
+            qd[(size_t)(j ? qb[st] + j - 1u : rk[st]) * qw + l] = v;
         }
     }
 }
@@ -836,7 +840,7 @@ __global__ __launch_bounds__(TRACS_NN_THREADS) void nn_rows_kernel(const uint4 *
 //     phase B  every listed entry of x with w = 1 walks its site's N list: -1 for EVERY N sample y there -- the third sum for y > x
 //              (row x of dist), the fourth for y < x (cell (y, x): a scratch row, folded in by transpose_add_kernel).
 // Negative terms wrap in the unsigned row and cancel in the final sum.
-template <bool CLAMP>
+template <bool CLAMP, unsigned QW>
 __global__ __launch_bounds__(1024) void minor_fixup_kernel(const unsigned long long *__restrict__ s_off, const unsigned *__restrict__ s_ent,
                                                            const unsigned long long *__restrict__ p_off, const unsigned *__restrict__ p_ent,
                                                            const unsigned *__restrict__ qd,
@@ -887,30 +891,36 @@ __global__ __launch_bounds__(1024) void minor_fixup_kernel(const unsigned long l
         auto round = [&]() {
             const unsigned k16 = min(rcount, 16u);
             const uint2 ref = ring[(rhead + grp) & (LINE_RING - 1u)];
-            const uint4 *lp = reinterpret_cast<const uint4 *>(q + (size_t)ref.x * 32) + l4 * 2;
-            const uint4 d0 = lp[0], d1 = lp[1];
+            // (a q line is QW dwords -- 128 or 256 bytes --, QW / 4 per lane)
+            constexpr unsigned DPL = QW / 4u, PER = QW - 1u;
+            const uint4 *lp = reinterpret_cast<const uint4 *>(q + (size_t)ref.x * QW) + l4 * (DPL / 4u);
+            uint4 dq[DPL / 4u];
+#pragma unroll
+            for (unsigned t = 0; t < DPL / 4u; t++) dq[t] = lp[t];
             rhead = (rhead + k16) & (LINE_RING - 1u); rcount -= k16;
             const bool has = grp < k16;
             const unsigned code = ref.y & 31u;
             const bool ovf = (ref.y >> 5) & 1u;
-            const unsigned hdr = (unsigned)__builtin_amdgcn_update_dpp(0, (int)d0.x, 0x00, 0xF, 0xF, false);      // quad_perm:[0,0,0,0]
-            const unsigned tail = (unsigned)__builtin_amdgcn_update_dpp(0, (int)d1.w, 0xFF, 0xF, 0xF, false);     // quad_perm:[3,3,3,3]
+            const unsigned hdr = (unsigned)__builtin_amdgcn_update_dpp(0, (int)dq[0].x, 0x00, 0xF, 0xF, false);      // quad_perm:[0,0,0,0]
+            const unsigned tail = (unsigned)__builtin_amdgcn_update_dpp(0, (int)dq[DPL / 4u - 1u].w, 0xFF, 0xF, 0xF, false);     // quad_perm:[3,3,3,3]
             const unsigned first = ovf ? 0u : 1u;
             const unsigned limit = ovf ? (ref.y >> 6) : (hdr & 0xFFFFu);
-            const unsigned v[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+            unsigned v[DPL];
+#pragma unroll
+            for (unsigned t = 0; t < DPL / 4u; t++) { v[4 * t] = dq[t].x; v[4 * t + 1] = dq[t].y; v[4 * t + 2] = dq[t].z; v[4 * t + 3] = dq[t].w; }
             const unsigned mx = code & 15u;
 #pragma unroll
-            for (int t = 0; t < 8; t++) {
-                const unsigned dw = l4 * 8u + (unsigned)t;
+            for (unsigned t = 0; t < DPL; t++) {
+                const unsigned dw = l4 * DPL + t;
                 const unsigned j = v[t] >> ENT_SHIFT;
                 const unsigned wj = (v[t] >> 4) & 1u;
                 // cell (x, j) for j > x; cell (j, x) for a j < x that does not walk itself (w_j = 0)
-                const bool in = has && dw >= first && dw < 31u && dw - first < limit &&
+                const bool in = has && dw >= first && dw < PER && dw - first < limit &&
                                 ((j >= up0 && j < up1) || (wj == 0u && j >= lw0 && j < lw1));
                 const int add = (((v[t] & 15u) & mx) == 0u ? 1 : 0) - 1 - (int)wj;      // both listed: [masks disjoint] - w_x - w_j
                 if (in && add != 0) atomicAdd(&row[j - c0], (unsigned)add);
             }
-            const unsigned cap = 31u - first;
+            const unsigned cap = PER - first;
             push(has && l4 == 0u && limit > cap, ovf ? ref.x + 1u : tail, code | 32u | ((limit - cap) << 6));
         };
         for (unsigned long long base = e0 + (unsigned long long)wave * 64; base < e1; base += (unsigned long long)nwaves * 64) {
@@ -1015,7 +1025,8 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb_, hipStream_t 
     SL_TRY(pack_alloc(a, (L + 1) * 8, reinterpret_cast<void **>(&g->p_off)));
     SL_TRY(pack_alloc(a, std::max<size_t>(mb.tot_p, 1) * 4, reinterpret_cast<void **>(&g->p_ent)));
     g->n_qlines = mb.long_p ? (unsigned long long)L + mb.tot_q : 0ull;
-    SL_TRY(pack_alloc(a, (g->n_qlines + 1) * 128, reinterpret_cast<void **>(&g->qlines)));
+    g->qw = mb.qw;
+    SL_TRY(pack_alloc(a, (g->n_qlines + 1) * (size_t)g->qw * 4, reinterpret_cast<void **>(&g->qlines)));
     SL_TRY(pack_alloc(a, (n + 1) * 8, reinterpret_cast<void **>(&g->s_off)));
     SL_TRY(pack_alloc(a, std::max<size_t>(mb.tot_p, 1) * 4, reinterpret_cast<void **>(&g->s_ent)));
     SL_TRY(pack_alloc(a, std::max<size_t>(n, 1) * 4, reinterpret_cast<void **>(&g->c_p)));
@@ -1140,8 +1151,11 @@ int minority_fixup(tracs_alignment *a, size_t row_begin, size_t row_end, size_t 
     (void)hipGetDevice(&dev);
     static bool attr_set[64] = {false};
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(minor_fixup_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ROW_CHUNK_MAX * 4 + 256 + 16 * (int)WALK_LDS_PER_WAVE));
-        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(minor_fixup_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ROW_CHUNK_MAX * 4 + 256 + 16 * (int)WALK_LDS_PER_WAVE));
+        const int fix_lds = (int)ROW_CHUNK_MAX * 4 + 256 + 16 * (int)WALK_LDS_PER_WAVE;
+        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(minor_fixup_kernel<true, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, fix_lds));
+        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(minor_fixup_kernel<false, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, fix_lds));
+        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(minor_fixup_kernel<true, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, fix_lds));
+        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(minor_fixup_kernel<false, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, fix_lds));
         attr_set[dev] = true;
     }
     // scratch rows for the cells (y, x) with y < x that row x's walks feed: (n - row_begin) rows of (row_end - row_begin) columns
@@ -1150,12 +1164,11 @@ int minority_fixup(tracs_alignment *a, size_t row_begin, size_t row_end, size_t 
     const int rc = workspace_get(46, (n - row_begin) * s_pitch * sizeof(unsigned), reinterpret_cast<void **>(&S));
     if (rc) return rc;
     const dim3 grid((unsigned)(n - row_begin), (unsigned)((n + chunk - 1) / chunk));
-    if (grid.y == 1)
-        hipLaunchKernelGGL(minor_fixup_kernel<false>, grid, dim3(1024), lds, stream, g->s_off, g->s_ent, g->p_off, g->p_ent, reinterpret_cast<const unsigned *>(g->qlines), g->lines, g->c_p, (unsigned)n,
-                           (unsigned)row_begin, (unsigned)row_end, (unsigned)col_begin, chunk, dist, ld, S, s_pitch);
-    else
-        hipLaunchKernelGGL(minor_fixup_kernel<true>, grid, dim3(1024), lds, stream, g->s_off, g->s_ent, g->p_off, g->p_ent, reinterpret_cast<const unsigned *>(g->qlines), g->lines, g->c_p, (unsigned)n,
-                           (unsigned)row_begin, (unsigned)row_end, (unsigned)col_begin, chunk, dist, ld, S, s_pitch);
+#define TRACS_FIXUP_LAUNCH(CL, QWV) hipLaunchKernelGGL((minor_fixup_kernel<CL, QWV>), grid, dim3(1024), lds, stream, g->s_off, g->s_ent, g->p_off, g->p_ent, \
+        reinterpret_cast<const unsigned *>(g->qlines), g->lines, g->c_p, (unsigned)n, (unsigned)row_begin, (unsigned)row_end, (unsigned)col_begin, chunk, dist, ld, S, s_pitch)
+    if (grid.y == 1) { if (g->qw == 64u) TRACS_FIXUP_LAUNCH(false, 64); else TRACS_FIXUP_LAUNCH(false, 32); }
+    else { if (g->qw == 64u) TRACS_FIXUP_LAUNCH(true, 64); else TRACS_FIXUP_LAUNCH(true, 32); }
+#undef TRACS_FIXUP_LAUNCH
     const dim3 tgrid((unsigned)((n - row_begin + 31) / 32), (unsigned)((row_end - row_begin + 31) / 32));
     hipLaunchKernelGGL(transpose_add_kernel, tgrid, dim3(256), 0, stream, S, s_pitch, (unsigned)n, (unsigned)row_begin, (unsigned)row_end,
                        (unsigned)col_begin, dist, ld);
@@ -1172,7 +1185,7 @@ extern "C" {
 //   what 1  lines (n_lines x 128 bytes)     what 2  lst_mask (groups x 16 bytes)     what 3  off_lst (groups x 4 bytes)
 //   what 4  p_off ((sites + 1) x 8)          what 5  p_ent (tot_p x 4: short lists)   what 6  s_off ((n + 1) x 8)
 //   what 7  s_ent (tot_p x 4)                what 8  T (n x tgroups x 16)             what 9  c_p (n x 4)
-//   what 10 q lines (n_qlines x 128: the p lists)     what 11 out64[0] = n_qlines
+//   what 10 q lines (n_qlines x 4 qw bytes: the p lists)     what 11 out64[0] = n_qlines     what 12 out64[0] = qw (dwords per q line)
 // Returns the bytes copied (what >= 1), 0 when the lists do not exist or `cap` is too small.
 size_t tracs_debug_lists(const tracs_alignment *a, int what, void *out, size_t cap)
 {
@@ -1197,8 +1210,9 @@ size_t tracs_debug_lists(const tracs_alignment *a, int what, void *out, size_t c
     case 7: src = g->s_ent; bytes = g->tot_p * 4; break;
     case 8: src = g->T; bytes = g->T ? a->n * g->tgroups * 16 : 0; break;
     case 9: src = g->c_p; bytes = a->n * 4; break;
-    case 10: src = g->qlines; bytes = g->n_qlines * 128; break;
+    case 10: src = g->qlines; bytes = g->n_qlines * g->qw * 4; break;
     case 11: if (cap < 8) return 0; *static_cast<uint64_t *>(out) = g->n_qlines; return 8;
+    case 12: if (cap < 8) return 0; *static_cast<uint64_t *>(out) = g->qw; return 8;
     default: return 0;
     }
     if (!src || bytes == 0 || bytes > cap) return 0;
