@@ -142,7 +142,8 @@ struct N8Encoder {
 template <unsigned PIECE_SAMPLES>
 __global__ __launch_bounds__(SITE_THREADS) TRACS_SITE_ATTR void site_lists_kernel(const MinorBuild mb, size_t n_pad, unsigned n,
                                                          unsigned long long *__restrict__ p_off, unsigned *__restrict__ p_ent,
-                                                         unsigned *__restrict__ qd, uint2 *__restrict__ E, uint4 *__restrict__ lines,
+                                                         unsigned *__restrict__ qd, uint2 *__restrict__ E, unsigned *__restrict__ e_cnt,
+                                                         uint4 *__restrict__ lines,
                                                          unsigned *__restrict__ c_p)
 {
     constexpr unsigned PIECE_WORDS = PIECE_SAMPLES / 32, BM_STRIDE = PIECE_WORDS + 1;     // (odd stride: conflict-free column writes)
@@ -167,6 +168,7 @@ __global__ __launch_bounds__(SITE_THREADS) TRACS_SITE_ATTR void site_lists_kerne
     // the group's p lists: p_lists_kernel's, or -- few entries, or more than that kernel sorts in LDS -- built here, from the planes of
     // its flagged samples, piece by piece, entry by entry
     const bool from_planes = any_minor && !p_lists_in_lds(mb.gP[g]);
+    if (from_planes && tid == 0) e_cnt[g] = 0xFFFFFFFFu;     // (its entries in E: by list position, with holes)
     static_assert(SITE_THREADS == SITES_PER_GROUP, "thread = site");
     const int tw = tid >> 5, tb = tid & 31;
     const bool mine = (m[tw] >> tb) & 1u;
@@ -335,9 +337,11 @@ __global__ __launch_bounds__(SITE_THREADS) TRACS_SITE_ATTR void site_lists_kerne
 // lists outgrow the image -- the 253 M entries of an alignment with 0.5 % partial codes were 253 M four-byte stores into 1.3 GB of
 // q lines that left the L2 half written and came back to be finished.)
 __global__ __launch_bounds__(PL_THREADS) void p_lists_kernel(const MinorBuild mb, size_t n_pad, unsigned n, unsigned *__restrict__ p_ent,
-                                                             unsigned *__restrict__ qd, uint2 *__restrict__ E, unsigned *__restrict__ c_p)
+                                                             unsigned *__restrict__ qd, uint2 *__restrict__ E, unsigned *__restrict__ e_cnt,
+                                                             int holes, unsigned *__restrict__ c_p)
 {
     __shared__ unsigned sorted[PL_CAP];
+    __shared__ unsigned w1off[SITES_PER_GROUP];
     __shared__ unsigned char site_of[PL_CAP];                // the site each entry of the image belongs to
     __shared__ unsigned kp[SITES_PER_GROUP], loff[SITES_PER_GROUP], curP[SITES_PER_GROUP], curQ[SITES_PER_GROUP], rk[SITES_PER_GROUP], qb[SITES_PER_GROUP];
     __shared__ unsigned short queue[PL_CHUNK];
@@ -418,12 +422,28 @@ __global__ __launch_bounds__(PL_THREADS) void p_lists_kernel(const MinorBuild mb
         }
     }
     __syncthreads();
-    // the image leaves as it is: E (by list position: the w = 1 entries, holes for the others), the short lists into p_ent
+    // the image leaves: E -- the group's w = 1 entries closed up at the front of its run (e_cnt[g] of them; `holes`: by list position,
+    // holes for the others, what the one-pass fill of small alignments reads) --, the short lists into p_ent
+    if (tid < 64u) {
+        const unsigned a = curP[tid], b = curP[64 + tid];
+        unsigned xa = a, xb = b;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned oa = __shfl_up(xa, off, 64), ob = __shfl_up(xb, off, 64);
+            if ((int)tid >= off) { xa += oa; xb += ob; }
+        }
+        const unsigned ta = __shfl(xa, 63, 64), tb = __shfl(xb, 63, 64);
+        w1off[tid] = xa - a; w1off[64 + tid] = ta + xb - b;
+        if (tid == 0) e_cnt[g] = holes ? 0xFFFFFFFFu : ta + tb;
+    }
+    __syncthreads();
     const unsigned total = mb.gP[g];
     for (unsigned i = tid; i < total; i += PL_THREADS) {
         const unsigned ent = sorted[i], st = site_of[i];
         const bool is_long = kp[st] > P_SHORT_MAX;
-        E[baseP + i] = (ent & 16u) ? make_uint2(ent >> ENT_SHIFT, (is_long ? ENT_LONG : 0u) | (rk[st] << ENT_SHIFT) | (ent & 31u)) : make_uint2(ENT_HOLE, 0u);
+        const uint2 ev = make_uint2(ent >> ENT_SHIFT, (is_long ? ENT_LONG : 0u) | (rk[st] << ENT_SHIFT) | (ent & 31u));
+        if (holes) E[baseP + i] = (ent & 16u) ? ev : make_uint2(ENT_HOLE, 0u);
+        else if (ent & 16u) E[baseP + w1off[st] + (i - loff[st])] = ev;
         if (!is_long) p_ent[baseP + i] = ent;
     }
     // q lines: qw dwords = 128 or 256 bytes per store, half a wave or a wave per line
@@ -465,31 +485,59 @@ __global__ __launch_bounds__(256) void listed_entries_kernel(const uint2 *__rest
 //   pass B   within a bucket by sample (at most 1 024 samples), into s_ent.
 // A tile reserves its share of every run it touches with one global atomic per run, and its writes into a run are consecutive.
 constexpr unsigned ENT_TILE_THREADS = 1024, ENT_PER_THREAD = 8, ENT_TILE = ENT_TILE_THREADS * ENT_PER_THREAD;
-__global__ __launch_bounds__(ENT_TILE_THREADS) void entries_to_buckets_kernel(const uint2 *__restrict__ E, unsigned long long count, unsigned shift,
-                                                                              unsigned n, const unsigned long long *__restrict__ s_off,
+constexpr unsigned ENT_GROUPS = 64;            // groups per workgroup of the first pass
+__global__ __launch_bounds__(ENT_TILE_THREADS) void entries_to_buckets_kernel(const uint2 *__restrict__ E, const unsigned *__restrict__ e_cnt,
+                                                                              const unsigned *__restrict__ gP, const unsigned long long *__restrict__ baseP,
+                                                                              size_t groups, unsigned shift, unsigned n,
+                                                                              const unsigned long long *__restrict__ s_off,
                                                                               unsigned *__restrict__ bcur, uint2 *__restrict__ tmp)
 {
+    // A workgroup takes ENT_GROUPS consecutive groups: group g's entries are E[baseP[g] .. + min(e_cnt[g], gP[g])) -- closed up by
+    // p_lists_kernel, or all of its list positions (holes among them) --; the concatenation is worked off a tile at a time.
     __shared__ unsigned hist[256], base[256];
+    __shared__ unsigned pre[ENT_GROUPS + 1];
+    __shared__ unsigned long long gbase[ENT_GROUPS];
     const unsigned tid = threadIdx.x;
-    const unsigned long long t0 = (unsigned long long)blockIdx.x * ENT_TILE;
-    if (tid < 256u) hist[tid] = 0;
-    __syncthreads();
-    uint2 e[ENT_PER_THREAD];
-    unsigned slot[ENT_PER_THREAD];
+    const size_t g0 = (size_t)blockIdx.x * ENT_GROUPS;
+    if (tid < 64u) {
+        const size_t g = g0 + tid;
+        const unsigned c = g < groups ? min(e_cnt[g], gP[g]) : 0u;      // (a group without p lists: gP = 0, e_cnt never written)
+        unsigned x = c;
 #pragma unroll
-    for (int q = 0; q < (int)ENT_PER_THREAD; q++) {
-        const unsigned long long k = t0 + (unsigned long long)q * ENT_TILE_THREADS + tid;
-        e[q] = k < count ? E[k] : make_uint2(ENT_HOLE, 0u);                     // (holes: the p lists' entries with w = 0)
-        slot[q] = e[q].x != ENT_HOLE ? atomicAdd(&hist[e[q].x >> shift], 1u) : 0u;
+        for (int off = 1; off < 64; off <<= 1) { const unsigned o = __shfl_up(x, off, 64); if ((int)tid >= off) x += o; }
+        pre[tid + 1] = x;
+        if (tid == 0) pre[0] = 0;
+        gbase[tid] = g < groups ? baseP[g] : 0ull;
     }
     __syncthreads();
-    if (tid < 256u && hist[tid]) base[tid] = atomicAdd(&bcur[tid], hist[tid]);
-    __syncthreads();
+    const unsigned total = pre[ENT_GROUPS];
+    for (unsigned t0 = 0; t0 < total; t0 += ENT_TILE) {
+        if (tid < 256u) hist[tid] = 0;
+        __syncthreads();
+        uint2 e[ENT_PER_THREAD];
+        unsigned slot[ENT_PER_THREAD];
 #pragma unroll
-    for (int q = 0; q < (int)ENT_PER_THREAD; q++) {
-        if (e[q].x == ENT_HOLE) continue;
-        const unsigned b = e[q].x >> shift;
-        tmp[s_off[min((unsigned long long)n, (unsigned long long)b << shift)] + base[b] + slot[q]] = e[q];
+        for (int q = 0; q < (int)ENT_PER_THREAD; q++) {
+            const unsigned k = t0 + (unsigned)q * ENT_TILE_THREADS + tid;
+            e[q] = make_uint2(ENT_HOLE, 0u);
+            if (k < total) {
+                unsigned lo = 0, hi = ENT_GROUPS;            // the group of entry k: pre[lo] <= k < pre[lo + 1]
+#pragma unroll
+                for (int st = 0; st < 6; st++) { const unsigned mid = (lo + hi) >> 1; if (pre[mid] <= k) lo = mid; else hi = mid; }
+                e[q] = E[gbase[lo] + (k - pre[lo])];
+            }
+            slot[q] = e[q].x != ENT_HOLE ? atomicAdd(&hist[e[q].x >> shift], 1u) : 0u;      // (holes: the p lists' entries with w = 0)
+        }
+        __syncthreads();
+        if (tid < 256u && hist[tid]) base[tid] = atomicAdd(&bcur[tid], hist[tid]);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < (int)ENT_PER_THREAD; q++) {
+            if (e[q].x == ENT_HOLE) continue;
+            const unsigned b = e[q].x >> shift;
+            tmp[s_off[min((unsigned long long)n, (unsigned long long)b << shift)] + base[b] + slot[q]] = e[q];
+        }
+        __syncthreads();
     }
 }
 __global__ __launch_bounds__(ENT_TILE_THREADS) void buckets_to_samples_kernel(const uint2 *__restrict__ tmp, unsigned shift, unsigned n,
@@ -1034,46 +1082,47 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb_, hipStream_t 
     SL_TRY(pack_alloc(a, groups * sizeof(unsigned), reinterpret_cast<void **>(&g->off_lst)));
     const bool bitmaps = mb.tot_nnl > 0;
     if (bitmaps) SL_TRY(pack_alloc(a, n * g->tgroups * sizeof(uint4), reinterpret_cast<void **>(&g->T)));
-    unsigned *cnt = nullptr;
-    uint2 *E = nullptr;
+    unsigned *cnt = nullptr, *e_cnt = nullptr;
+    uint2 *E = nullptr, *tmp = nullptr;
     int rc;
-    // E: (sample, entry) of every p-list entry with w = 1, by list position -- holes where w = 0 --: what the per-sample lists are bucketed from
+    // E: (sample, entry) of every p-list entry with w = 1: what the per-sample lists are bucketed from.  A group's entries sit in its run of
+    // list positions -- closed up at the front (e_cnt[g] of them: p_lists_kernel) or where their list has them, holes between
+    // (e_cnt[g] = all ones: site_lists_kernel; everywhere when the fill is the one-pass one)
     if ((rc = workspace_get(60, (2 * std::max<size_t>(n, 1) + 8 + 256) * 4, reinterpret_cast<void **>(&cnt))) ||
+        (rc = workspace_get(61, std::max<size_t>(groups, 1) * sizeof(unsigned), reinterpret_cast<void **>(&e_cnt))) ||
         (rc = workspace_get(62, std::max<size_t>(mb.tot_p, 1) * sizeof(uint2), reinterpret_cast<void **>(&E)))) { delete g; return rc; }
     unsigned *cur = cnt + std::max<size_t>(n, 1), *d_max = cur + std::max<size_t>(n, 1), *bcur = d_max + 8;
+    unsigned shift = 0;
+    while (n && ((n - 1) >> shift) >= 256u) shift++;                                  // at most 256 buckets of 2^shift samples
+    const bool two_pass = mb.tot_p >= ENT_TILE && mb.tot_p < (1ull << 32) && shift <= 10 &&      // (32-bit run cursors; at most 1 024 samples per bucket)
+                          workspace_get(63, (size_t)mb.tot_p * sizeof(uint2), reinterpret_cast<void **>(&tmp)) == TRACS_OK;
+    if (!two_pass) { (void)hipGetLastError(); set_error(""); }
     SL_TRY(hipMemsetAsync(cnt, 0, (2 * std::max<size_t>(n, 1) + 8 + 256) * 4, stream));
     SL_TRY(hipMemsetAsync(g->c_p, 0, std::max<size_t>(n, 1) * 4, stream));
     SL_TRY(hipMemcpyAsync(g->lst_mask, mb.lst_mask, groups * sizeof(uint4), hipMemcpyDeviceToDevice, stream));
     SL_TRY(hipMemcpyAsync(g->off_lst, mb.off_lst, groups * sizeof(unsigned), hipMemcpyDeviceToDevice, stream));
     const double plane_b = (double)groups * (double)a->n_pad * sizeof(uint4);      // the N plane
-    hipLaunchKernelGGL((site_lists_kernel<512>), dim3((unsigned)groups), dim3(SITE_THREADS), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off, g->p_ent, reinterpret_cast<unsigned *>(g->qlines), E, g->lines, g->c_p);
+    hipLaunchKernelGGL((site_lists_kernel<512>), dim3((unsigned)groups), dim3(SITE_THREADS), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off, g->p_ent, reinterpret_cast<unsigned *>(g->qlines), E, e_cnt, g->lines, g->c_p);
     // (only when some group's lists are that kernel's: at least PL_MIN entries)
     if (mb.max_gp >= PL_MIN)
-        hipLaunchKernelGGL(p_lists_kernel, dim3((unsigned)groups), dim3(PL_THREADS), 0, stream, mb, a->n_pad, (unsigned)n, g->p_ent, reinterpret_cast<unsigned *>(g->qlines), E, g->c_p);
+        hipLaunchKernelGGL(p_lists_kernel, dim3((unsigned)groups), dim3(PL_THREADS), 0, stream, mb, a->n_pad, (unsigned)n, g->p_ent, reinterpret_cast<unsigned *>(g->qlines), E, e_cnt, two_pass ? 0 : 1, g->c_p);
     pack_stage_mark("lists: per site", stream, plane_b + (double)groups * SITES_PER_GROUP * 8.0,
                     (double)L * 128.0 + (double)mb.tot_p * 12.0 + (double)L * 8.0 + (double)(mb.tot_q + std::min<unsigned long long>(L, mb.tot_p)) * 8.0);
     // the per-sample lists hold the w = 1 entries: c_p[s] of them
     hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, g->c_p, n, g->s_off);
-    bool two_pass = false;
     if (mb.tot_p) {
-        unsigned shift = 0;
-        while (((n - 1) >> shift) >= 256u) shift++;                                   // at most 256 buckets of 2^shift samples
-        uint2 *tmp = nullptr;
-        two_pass = mb.tot_p >= ENT_TILE && mb.tot_p < (1ull << 32) && shift <= 10 &&      // (32-bit run cursors; at most 1 024 samples per bucket)
-                              workspace_get(63, (size_t)mb.tot_p * sizeof(uint2), reinterpret_cast<void **>(&tmp)) == TRACS_OK;
         if (two_pass) {
             const unsigned buckets = (unsigned)(((n - 1) >> shift) + 1);
-            hipLaunchKernelGGL(entries_to_buckets_kernel, dim3((unsigned)((mb.tot_p + ENT_TILE - 1) / ENT_TILE)), dim3(ENT_TILE_THREADS), 0, stream, E, mb.tot_p,
-                               shift, (unsigned)n, g->s_off, bcur, tmp);
+            hipLaunchKernelGGL(entries_to_buckets_kernel, dim3((unsigned)((groups + ENT_GROUPS - 1) / ENT_GROUPS)), dim3(ENT_TILE_THREADS), 0, stream, E, e_cnt, mb.gP, mb.baseP,
+                               groups, shift, (unsigned)n, g->s_off, bcur, tmp);
             const unsigned per_bucket = (unsigned)std::min<unsigned long long>(64, std::max<unsigned long long>(1, mb.tot_p / buckets / ENT_TILE + 1));
             hipLaunchKernelGGL(buckets_to_samples_kernel, dim3(per_bucket, buckets), dim3(ENT_TILE_THREADS), 0, stream, tmp, shift, (unsigned)n, g->s_off, cur, g->s_ent);
         } else {
-            (void)hipGetLastError(); set_error("");
             hipLaunchKernelGGL(listed_entries_kernel, dim3((unsigned)((mb.tot_p + 255) / 256)), dim3(256), 0, stream, E, mb.tot_p, g->s_off, cur, g->s_ent);
         }
     }
-    pack_stage_mark("listed entries per sample", stream, (double)mb.tot_p * 8.0 + (double)std::min<unsigned long long>(mb.tot_p, L) * (two_pass ? 8.0 : 0.0) + (double)n * 4.0,
-                    (double)std::min<unsigned long long>(mb.tot_p, L) * (two_pass ? 12.0 : 4.0) + (double)n * 12.0);
+    pack_stage_mark("listed entries per sample", stream, (double)std::min<unsigned long long>(mb.tot_p, 2 * L) * (two_pass ? 16.0 : 8.0) + (double)n * 4.0,
+                    (double)std::min<unsigned long long>(mb.tot_p, 2 * L) * (two_pass ? 12.0 : 4.0) + (double)n * 12.0);
     if (bitmaps) {
         // (a->c_counted was zeroed by the caller: this kernel is what fills it when the rows' bitmaps are built)
         const size_t octs = g->tgroups / 8;
