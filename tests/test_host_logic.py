@@ -235,6 +235,10 @@ def test_minority_site_identity():
             a, b = codes[i], codes[j]
             d_true = int((pc[a & b] == 0).sum())
             both = is_listed[i] & is_listed[j]
-            form = int(w[i].sum() + w[j].sum() - (w[i] & is_n[j]).sum() - (w[j] & is_n[i]).sum()
-                       + ((pc[a & b] == 0).astype(int) - w[i].astype(int) - w[j].astype(int))[both].sum())
+            last = (pc[a & b] == 0).astype(int) - w[i].astype(int) - w[j].astype(int)
+            form = int(w[i].sum() + w[j].sum() - (w[i] & is_n[j]).sum() - (w[j] & is_n[i]).sum() + last[both].sum())
             assert form == d_true
+            # what minor_fixup_kernel walks (round 5): only the listed samples with w = 1 -- two listed samples that both hold the
+            # reference base add nothing to the last sum, so it is the sum over the sites at which i or j walks
+            assert (last[both & ~w[i] & ~w[j]] == 0).all()
+            assert int(last[both & (w[i] | w[j])].sum()) == int(last[both].sum())
