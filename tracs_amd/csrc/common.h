@@ -78,7 +78,11 @@ struct tracs_alignment {
     // would otherwise land inside the first pass.  pack_alloc falls back to hipMalloc when the arena is too small.
     uint8_t *arena = nullptr;
     size_t arena_bytes = 0, arena_used = 0;
-    std::vector<void *> pack_extra;
+    struct PackBlock { void *p; size_t bytes; };
+    std::vector<PackBlock> pack_extra;       // what did not fit the arena, in use by the current pack ...
+    std::vector<PackBlock> pack_spare;       // ... and released by the one before: handed out again before anything is allocated (a
+                                             //   handle that is packed and called again and again -- bench.py -- would otherwise free and
+                                             //   allocate gigabytes per call: ~24 ms per GB when the driver has to clear them, seconds at times)
     tracs::GeneralSparse *sparse = nullptr;   // general matrix-core path: per-site / per-sample lists of N and partial codes
     int sparse_state = 0;        // 0 not built, 1 built, -1 not available for this alignment (too dense / too large / no memory)
     // cached tile schedules of the last dense regions (region x workgroup tile): the pair kernel's and the counting pass's, for

@@ -660,14 +660,27 @@ hipError_t pack_alloc(tracs_alignment *a, size_t bytes, void **out)
         a->arena_used += need;
         return hipSuccess;
     }
-    const hipError_t e = hipMalloc(out, std::max<size_t>(bytes, 256));
-    if (e == hipSuccess) a->pack_extra.push_back(*out);
+    // a block the previous pack released, if one is large enough (the smallest such; not one more than twice the size)
+    size_t best = a->pack_spare.size();
+    for (size_t k = 0; k < a->pack_spare.size(); k++)
+        if (a->pack_spare[k].bytes >= need && a->pack_spare[k].bytes <= 2 * need + (1u << 20) &&
+            (best == a->pack_spare.size() || a->pack_spare[k].bytes < a->pack_spare[best].bytes)) best = k;
+    if (best != a->pack_spare.size()) {
+        *out = a->pack_spare[best].p;
+        a->pack_extra.push_back(a->pack_spare[best]);
+        a->pack_spare.erase(a->pack_spare.begin() + (long)best);
+        return hipSuccess;
+    }
+    const hipError_t e = hipMalloc(out, need);
+    if (e == hipSuccess) a->pack_extra.push_back({*out, need});
     else *out = nullptr;
     return e;
 }
 void pack_release(tracs_alignment *a)
 {
-    for (void *p : a->pack_extra) (void)hipFree(p);
+    // (the spare blocks nobody took this time are freed: a handle keeps what its last pack needed beside the arena, not more)
+    for (auto &b : a->pack_spare) (void)hipFree(b.p);
+    a->pack_spare = std::move(a->pack_extra);
     a->pack_extra.clear();
     a->arena_used = 0;
 }
@@ -709,6 +722,8 @@ void tracs_alignment_free(tracs_alignment *a)
     if (!a) return;
     general_sparse_free(a);
     site_classes_free(a);
+    for (auto &b : a->pack_spare) (void)hipFree(b.p);
+    a->pack_spare.clear();
     if (a->arena) (void)hipFree(a->arena);
     if (a->planes) (void)hipFree(a->planes);
     if (a->cplanes) (void)hipFree(a->cplanes);
