@@ -196,6 +196,15 @@ int tracs_filter_recomb_device(const tracs_alignment *a, const uint32_t *rows, c
                                const int64_t *pos_off, uint32_t *positions, uint32_t *found, uint32_t *filt,
                                void *stream);
 
+/* The same filter without the positions (what `tracs distance --filter` and tracs_pairsnp(filter = 1) use): filt[t] =
+ * filter_recomb (src/pairsnp.hpp:251-318) of the emitted pair (rows[t], cols[t]) whose SNP distance is d[t] (:405-413); all
+ * device uint32[n_pairs].  A pair's SNP sites come from the two samples' departure lists (the sites at which a sample is neither
+ * N nor exactly the site's reference base), built with two N bitmaps once per packed alignment and kept on the handle; pairs
+ * whose lists do not fit a wave's LDS, and alignments too divergent for lists, are scanned like the reference scans them.
+ * TRACS_FILTER_LISTS=0: always the scan; TRACS_FILTER_TABLE=0: the binomial tail summed per SNP instead of per distinct
+ * (d, count).  Synchronises the stream (an internal consistency check: every pair's SNP count must equal d[t]).            */
+int tracs_filter_recomb_pairs(tracs_alignment *a, const uint32_t *rows, const uint32_t *cols, const uint32_t *d, size_t n_pairs,
+                              uint32_t *filt, void *stream);
 /* transcluster on device arrays (same math as tracs_trans_dist).  workspace is managed
  * internally (hipMallocAsync on the stream).  exp_p0 != 0 writes exp(p0) (what
  * tracs/transcluster.py:38-39 returns with log=False).                                     */

@@ -84,6 +84,84 @@ def extract_kernel(request, monkeypatch):
     return request.param
 
 
+# every way tracs_filter_recomb_pairs can take: lists + table (the default), lists with the tail summed per SNP, the scan of the
+# planes for every pair, and lists whose LDS capacity leaves some pairs to the scan
+ROUTES = {"lists": {}, "lists_no_table": {"TRACS_FILTER_TABLE": "0"}, "scan": {"TRACS_FILTER_LISTS": "0"},
+          "lists_cap64": {"TRACS_FILTER_CAP": "64"}}
+
+
+@pytest.fixture(params=sorted(ROUTES))
+def route(request, monkeypatch):
+    for k, v in ROUTES[request.param].items():
+        monkeypatch.setenv(k, v)
+    return request.param
+
+
+def _blocky(oracle, n, L, seed, **kw):
+    """an alignment with recombination-like blocks (runs of substitutions, one touching each end of the alignment)"""
+    from tracs_amd import synth
+    seqs = synth.alignment(n, L, seed=seed, **kw)
+    lut = np.zeros(256, np.uint8) + ord("N")
+    for a, b in zip(b"ACGT", b"CGTA"):
+        lut[a] = b
+    rng = np.random.default_rng(seed)
+    for s in rng.choice(n, size=max(2, n // 4), replace=False):
+        a = int(rng.integers(0, L - 400))
+        w = int(rng.integers(20, 400))
+        keep = rng.random(w) < rng.choice([0.15, 0.5, 1.0])
+        seg = seqs[s, a:a + w]
+        seqs[s, a:a + w] = np.where(keep & (seg != ord("N")), lut[seg], seg)
+    seqs[1, :120] = lut[seqs[1, :120]]
+    seqs[2, L - 90:] = lut[seqs[2, L - 90:]]
+    return seqs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(24, 120000, dict(mu_lineage=4e-4, mu_sample=1e-4, p_n=0.01, p_partial=0.002)),
+                                   (40, 70001, dict(mu_lineage=1e-3, mu_sample=3e-4, p_n=0.02, p_partial=0.01, p_lower=0.1)),
+                                   (33, 50000, dict(mu_lineage=0.0, mu_sample=2e-3, p_n=0.1)),
+                                   (12, 9000, dict(mu_lineage=2e-2, mu_sample=5e-2, p_n=0.05, p_partial=0.02)),
+                                   (70, 30011, dict(mu_lineage=0.0, mu_sample=1e-4, p_n=0.0))])
+def test_gpu_filter_pairs_matches_oracle(oracle, hiplib, route, shape):
+    """tracs_filter_recomb_pairs (every route) = the oracle's filter_recomb on every pair, thresholded or not"""
+    import torch
+    from tracs_amd import device as dev
+    n, L, kw = shape
+    seqs = _blocky(oracle, n, L, seed=n + L, **kw)
+    aln = dev.Alignment(n, L)
+    aln.pack(seqs)
+    r, c, d, _ = oracle.pairsnp_arrays(seqs)
+    ef = oracle.filter_recomb_pairs(seqs, r, c, 4)
+    assert (ef < d).any()
+    for sel in (np.ones(len(r), bool), d <= np.median(d), np.arange(len(r)) % 7 == 3):
+        rows = torch.from_numpy(r[sel].astype(np.int32)).cuda()
+        cols = torch.from_numpy(c[sel].astype(np.int32)).cuda()
+        dd = torch.from_numpy(d[sel].astype(np.int32)).cuda()
+        got = dev.filter_recomb_pairs(aln, rows, cols, dd).cpu().numpy()
+        assert np.array_equal(got, ef[sel].astype(np.int32)), (route, np.where(got != ef[sel])[0][:10])
+    info = dev.filter_index_info(aln)
+    assert info is not None and (not info["lists"] if route == "scan" else info["lists"] or kw["mu_sample"] > 1e-2)
+    # a wrong distance is caught, never filtered silently
+    bad = torch.from_numpy((d + 1).astype(np.int32)).cuda()
+    with pytest.raises(RuntimeError, match="does not match the distance"):
+        dev.filter_recomb_pairs(aln, torch.from_numpy(r.astype(np.int32)).cuda(), torch.from_numpy(c.astype(np.int32)).cuda(), bad)
+
+
+@pytest.mark.gpu
+def test_gpu_filter_index_follows_the_planes(oracle, hiplib):
+    """the departure lists are rebuilt when the handle is packed again"""
+    import torch
+    from tracs_amd import device as dev
+    n, L = 16, 40000
+    aln = dev.Alignment(n, L)
+    for seed in (1, 2):
+        seqs = _blocky(oracle, n, L, seed=seed, mu_lineage=1e-3, mu_sample=2e-4, p_n=0.03)
+        aln.pack(seqs)
+        r, c, d, _ = oracle.pairsnp_arrays(seqs)
+        got = dev.filter_recomb_pairs(aln, *(torch.from_numpy(x.astype(np.int32)).cuda() for x in (r, c, d))).cpu().numpy()
+        assert np.array_equal(got, oracle.filter_recomb_pairs(seqs, r, c, 4).astype(np.int32))
+
+
 @pytest.mark.gpu
 def test_gpu_filter_matches_oracle(oracle, hiplib, tmp_path, extract_kernel):
     import torch  # noqa: F401

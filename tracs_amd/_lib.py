@@ -21,7 +21,7 @@ SYMBOLS = [
     "tracs_alignment_create", "tracs_alignment_free", "tracs_alignment_n", "tracs_alignment_len",
     "tracs_alignment_bytes", "tracs_alignment_planes", "tracs_alignment_touch", "tracs_alignment_hint_rows", "tracs_pairsnp_notify_distances", "tracs_set_stream_policy", "tracs_alignment_pack", "tracs_alignment_from_fasta",
     "tracs_free",
-    "tracs_pairsnp_dense", "tracs_pairsnp_dense_thr", "tracs_coo_count", "tracs_coo_fill", "tracs_filter_recomb_device",
+    "tracs_pairsnp_dense", "tracs_pairsnp_dense_thr", "tracs_coo_count", "tracs_coo_fill", "tracs_filter_recomb_device", "tracs_filter_recomb_pairs",
     "tracs_trans_dist_device", "tracs_trans_dist_dense", "tracs_trans_dist_dense2", "tracs_trans_table_dense", "tracs_trans_table_gather",
     "tracs_calculate_posteriors_device", "tracs_posterior_codes_device", "tracs_posterior_codes_cov_device",
     "tracs_codes_to_iupac_device", "tracs_alignment_pack_codes", "tracs_alignment_pack_codes_batch", "tracs_edges_count_f64", "tracs_edges_fill_f64",
@@ -147,6 +147,10 @@ def load():
     L.tracs_edges_fill_f64.argtypes = [vp, vp, sz, sz, sz, sz, sz, C.c_int32, dbl, vp, vp, vp, vp, vp]
     L.tracs_filter_recomb_device.restype = C.c_int
     L.tracs_filter_recomb_device.argtypes = [vp, vp, vp, sz, vp, vp, vp, vp, vp]
+    L.tracs_filter_recomb_pairs.restype = C.c_int
+    L.tracs_filter_recomb_pairs.argtypes = [vp, vp, vp, vp, sz, vp, vp]
+    L.tracs_debug_filter_index.restype = C.c_int
+    L.tracs_debug_filter_index.argtypes = [vp, C.POINTER(C.c_double)]
     L.tracs_trans_dist_device.restype = C.c_int
     L.tracs_trans_dist_device.argtypes = [vp, vp, sz, dbl, dbl, dbl, C.c_int, vp, vp, vp]
     L.tracs_trans_dist_dense.restype = C.c_int

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libtracs_hip.so")
-SOURCES = ["capi.hip", "pairsnp.hip", "pairsnp_mfma.hip", "general_sparse.hip", "site_lists.hip", "site_classes.hip", "transcluster.hip", "dmultinomial.hip", "cluster.hip", "filter.hip", "dirichlet.hip", "exchange.hip", "fasta.cpp", "alignio.cpp", "comm.cpp"]
+SOURCES = ["capi.hip", "pairsnp.hip", "pairsnp_mfma.hip", "general_sparse.hip", "site_lists.hip", "site_classes.hip", "transcluster.hip", "dmultinomial.hip", "cluster.hip", "filter.hip", "filter_lists.hip", "dirichlet.hip", "exchange.hip", "fasta.cpp", "alignio.cpp", "comm.cpp"]
 HEADERS = ["common.h", "pairsnp_kernels.h", "fasta.h", "rowwriter.h", os.path.join("..", "..", "include", "tracs_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fgpu-rdc" if False else "-fno-gpu-rdc",

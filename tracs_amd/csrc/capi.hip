@@ -248,11 +248,11 @@ int tracs_pairsnp(const char *const *fasta, int n_fasta, int n_threads, int dist
     const size_t j_start = n_fasta == 1 ? 0 : n0;
 
     unsigned *d_dist = nullptr, *d_nn = nullptr, *d_rows = nullptr, *d_cols = nullptr, *d_d = nullptr, *d_n = nullptr;
-    unsigned *d_pos = nullptr, *d_found = nullptr, *d_filt = nullptr;
-    long long *d_off = nullptr, *d_poff = nullptr;
-    size_t pos_cap = 0, pair_cap = 0;
+    unsigned *d_filt = nullptr;
+    long long *d_off = nullptr;
+    size_t pair_cap = 0;
     auto cleanup = [&]() {
-        void *p[] = {d_dist, d_nn, d_rows, d_cols, d_d, d_n, d_off, d_pos, d_found, d_filt, d_poff};
+        void *p[] = {d_dist, d_nn, d_rows, d_cols, d_d, d_n, d_off, d_filt};
         for (void *q : p) if (q) (void)hipFree(q);
         tracs_alignment_free(a);
     };
@@ -312,46 +312,17 @@ int tracs_pairsnp(const char *const *fasta, int n_fasta, int n_threads, int dist
             PS_CHECK(pull(d_n, res->ncomp));
             lap(t_pull);
             if (filter) {
-                // recombination filter on the pairs just emitted, in sub-batches whose SNP-site lists fit 2^28 entries
-                const size_t base = res->dist.size() - (size_t)total;
-                const size_t kMaxPos = 1ull << 28;
-                std::vector<long long> poff;
-                size_t t0 = 0;
-                while (t0 < (size_t)total) {
-                    if (g_sigint) { cleanup(); delete res; set_error("Interrupted by user!"); return TRACS_E_INTERRUPTED; }
-                    poff.assign(1, 0);
-                    size_t t1 = t0;
-                    while (t1 < (size_t)total && (t1 == t0 || (size_t)poff.back() + res->dist[base + t1] <= kMaxPos)) {
-                        poff.push_back(poff.back() + (long long)res->dist[base + t1]);
-                        t1++;
-                    }
-                    const size_t np = t1 - t0, npos = (size_t)poff.back();
-                    if (np > pair_cap) {
-                        void *q[] = {d_found, d_filt, d_poff};
-                        for (void *x : q) if (x) PS_CHECK(hipFree(x));
-                        d_found = d_filt = nullptr; d_poff = nullptr;
-                        pair_cap = np + np / 4 + 16;
-                        PS_CHECK(hipMalloc(reinterpret_cast<void **>(&d_found), pair_cap * 4));
-                        PS_CHECK(hipMalloc(reinterpret_cast<void **>(&d_filt), pair_cap * 4));
-                        PS_CHECK(hipMalloc(reinterpret_cast<void **>(&d_poff), (pair_cap + 1) * 8));
-                    }
-                    if (npos + 1 > pos_cap) {
-                        if (d_pos) PS_CHECK(hipFree(d_pos));
-                        d_pos = nullptr;
-                        pos_cap = npos + npos / 4 + 16;
-                        PS_CHECK(hipMalloc(reinterpret_cast<void **>(&d_pos), pos_cap * 4));
-                    }
-                    PS_CHECK(hipMemcpy(d_poff, poff.data(), (np + 1) * 8, hipMemcpyHostToDevice));
-                    PS_RC(tracs_filter_recomb_device(a, d_rows + t0, d_cols + t0, np, reinterpret_cast<int64_t *>(d_poff), d_pos,
-                                                     d_found, d_filt, nullptr));
-                    h32.resize(np);
-                    PS_CHECK(hipMemcpy(h32.data(), d_found, np * 4, hipMemcpyDeviceToHost));
-                    for (size_t t = 0; t < np; t++)
-                        if (h32[t] != res->dist[base + t0 + t]) { cleanup(); delete res; set_error("filter: SNP site list does not match the distance (internal error)"); return TRACS_E_HIP; }
-                    PS_CHECK(hipMemcpy(h32.data(), d_filt, np * 4, hipMemcpyDeviceToHost));
-                    widen_append(res->filt, h32.data(), np);
-                    t0 = t1;
+                // recombination filter on the pairs just emitted (:405-413): SNP sites from the samples' departure lists
+                if (g_sigint) { cleanup(); delete res; set_error("Interrupted by user!"); return TRACS_E_INTERRUPTED; }
+                if ((size_t)total > pair_cap) {
+                    if (d_filt) PS_CHECK(hipFree(d_filt));
+                    d_filt = nullptr;
+                    pair_cap = (size_t)total + (size_t)total / 4 + 16;
+                    PS_CHECK(hipMalloc(reinterpret_cast<void **>(&d_filt), pair_cap * 4));
                 }
+                PS_RC(tracs_filter_recomb_pairs(a, d_rows, d_cols, d_d, (size_t)total, d_filt, nullptr));
+                PS_CHECK(hipMemcpy(h32.data(), d_filt, (size_t)total * 4, hipMemcpyDeviceToHost));
+                widen_append(res->filt, h32.data(), (size_t)total);
                 lap(t_filter);
             }
         }

@@ -40,7 +40,7 @@ static inline size_t pad_samples(size_t n) { return (n + SAMPLE_PAD - 1) / SAMPL
 
 }  // namespace tracs
 
-namespace tracs { struct GeneralSparse; struct SiteLists; }
+namespace tracs { struct GeneralSparse; struct SiteLists; struct FilterIndex; }
 
 struct tracs_alignment {
     size_t n = 0, L = 0, n_pad = 0, groups = 0;
@@ -85,6 +85,8 @@ struct tracs_alignment {
                                              //   allocate gigabytes per call: ~24 ms per GB when the driver has to clear them, seconds at times)
     tracs::GeneralSparse *sparse = nullptr;   // general matrix-core path: per-site / per-sample lists of N and partial codes
     int sparse_state = 0;        // 0 not built, 1 built, -1 not available for this alignment (too dense / too large / no memory)
+    tracs::FilterIndex *flt = nullptr;        // recombination filter: per-sample departure lists + N bitmaps (filter_lists.hip)
+    bool flt_stale = true;       // packed since the filter index was built
     // cached tile schedules of the last dense regions (region x workgroup tile): the pair kernel's and the counting pass's, for
     // the two row ranges a multi-GPU rank alternates between; replaced round-robin
     struct TileCache {
@@ -104,6 +106,8 @@ static inline const uint4 *pair_planes(const tracs_alignment *a, bool consensus)
 }
 static inline size_t pair_L(const tracs_alignment *a) { return a->classes_state == 1 ? a->L_var : a->L; }
 static inline size_t pair_groups(const tracs_alignment *a) { return a->classes_state == 1 ? a->groups_var : a->groups; }
+
+void filter_index_free(tracs_alignment *a);        // filter_lists.hip
 
 // device memory that lives until the alignment is packed again (site_classes_free releases all of it at once)
 hipError_t pack_alloc(tracs_alignment *a, size_t bytes, void **out);

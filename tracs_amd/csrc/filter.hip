@@ -13,6 +13,7 @@
 //                          binomial tail is summed directly (integer a, b: I_p(k+1, n-k) is a finite sum).
 // PARITY UNPINNED: Boost's ibetac is replaced by the exact finite sum.
 #include "common.h"
+#include "filter_math.h"
 
 #include <cstdlib>
 
@@ -125,28 +126,6 @@ __device__ __forceinline__ long long lower_bound_u32(const unsigned *a, long lon
     return lo;
 }
 
-// P(X <= k), X ~ Binomial(n, p), 0 <= k < n, summed on the shorter side of the mean in log space.
-__device__ double binom_cdf(int n, double p, int k, const double *__restrict__ lg)
-{
-    const double lp = log(p), lq = log1p(-p), ln1 = lg[n + 1];
-    const double mean = (double)n * p;
-    if ((double)k + 1.0 > mean) {
-        // upper tail sum_{j=k+1}^{n}: terms fall off geometrically past the mean
-        double term = exp(ln1 - lg[k + 2] - lg[n - k] + (double)(k + 1) * lp + (double)(n - k - 1) * lq);
-        double sum = term;
-        const double odds = p / (1.0 - p);
-        for (int j = k + 1; j < n; j++) {
-            term *= (double)(n - j) / (double)(j + 1) * odds;
-            sum += term;
-            if (term < sum * 1e-18) break;
-        }
-        return 1.0 - sum;
-    }
-    double sum = 0.0;
-    for (int j = 0; j <= k; j++) sum += exp(ln1 - lg[j + 1] - lg[n - j + 1] + (double)j * lp + (double)(n - j) * lq);
-    return sum;
-}
-
 __global__ __launch_bounds__(64) void filter_test_kernel(const unsigned *__restrict__ positions,
                                                          const long long *__restrict__ pos_off, size_t n_pairs, unsigned L,
                                                          const double *__restrict__ lg, unsigned *__restrict__ filt)
@@ -156,13 +135,10 @@ __global__ __launch_bounds__(64) void filter_test_kernel(const unsigned *__restr
         const unsigned *pos = positions + pos_off[t];
         const long long dn = pos_off[t + 1] - pos_off[t];
         if (dn <= 1) { if (lane == 0) filt[t] = (unsigned)dn; continue; }      // :259-261
-        const double d = (double)dn;
         const int aln = (int)L;
-        const double p = d / (double)aln;                                      // :265
-        const double thr = 0.05 / d;                                           // :266
-        int wh = (int)(1.0 / p / 2.0 + 1);                                     // :269
-        wh = min(wh, 5000);                                                    // :270
-        wh = max(wh, 50);                                                      // :271
+        const FilterWindow fw = filter_window(dn, L);                          // :265-271
+        const double p = fw.p, thr = fw.thr;
+        const int wh = fw.wh;
         unsigned kept = 0;
         for (long long u = lane; u < dn; u += 64) {
             const int i = (int)pos[u];
@@ -173,9 +149,7 @@ __global__ __launch_bounds__(64) void filter_test_kernel(const unsigned *__restr
             const long long count = last - first + 1;
             if (count > 1) {                                                   // :294
                 const long long length = (long long)pos[last] - (long long)pos[first] + 1;   // :242
-                const double cdf = count >= length ? 1.0 : binom_cdf((int)length, p, (int)count, lg);
-                const double p_value = 1.0 - cdf;                              // :302
-                if (p_value >= thr) kept++;                                    // :305
+                if (filter_keep(length, count, p, thr, lg)) kept++;            // :294-309
             } else {
                 kept++;                                                        // :311
             }

@@ -722,6 +722,7 @@ void tracs_alignment_free(tracs_alignment *a)
     if (!a) return;
     general_sparse_free(a);
     site_classes_free(a);
+    filter_index_free(a);
     for (auto &b : a->pack_spare) (void)hipFree(b.p);
     a->pack_spare.clear();
     if (a->arena) (void)hipFree(a->arena);
@@ -749,6 +750,7 @@ int tracs_alignment_touch(tracs_alignment *a)
     if (!a) { set_error("tracs_alignment_touch: NULL argument"); return TRACS_E_ARG; }
     DeviceCall guard(nullptr);
     a->dirty = true;                   // the consensus form / sparse lists (if any) must be re-derived
+    a->flt_stale = true;
     return TRACS_OK;
 }
 
@@ -776,6 +778,7 @@ int tracs_alignment_pack(tracs_alignment *a, const uint8_t *ascii, size_t first,
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     DeviceCall guard(stream);
     a->dirty = true;                   // the consensus form / sparse lists (if any) must be re-derived
+    a->flt_stale = true;
     const uint8_t *d_ascii = ascii;
     uint8_t *tmp = nullptr;
     if (!ascii_on_device) {
@@ -810,6 +813,7 @@ int tracs_alignment_pack_codes_batch(tracs_alignment *a, const uint8_t *codes, s
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     DeviceCall guard(stream);
     a->dirty = true;
+    a->flt_stale = true;
     const size_t slice = 65535ull * 64ull;
     for (size_t c0 = 0; c0 < count; c0 += slice) {
         const size_t cnt = std::min(slice, count - c0);

@@ -260,6 +260,30 @@ def filter_recomb_device(aln, rows, cols, d):
     return filt[:n], found[:n], pos[:total], off
 
 
+def filter_recomb_pairs(aln, rows, cols, d):
+    """Filtered distances (src/pairsnp.hpp:251-318) of the emitted pairs (rows, cols) with SNP distances d: torch.int32 device
+    vectors in, torch.int32 out.  The pairs' SNP sites come from the samples' departure lists (csrc/filter_lists.hip), built on the
+    alignment's first filter call after a pack."""
+    L = _lib.require_gpu()
+    n = rows.numel()
+    filt = torch.empty(max(n, 1), dtype=torch.int32, device=rows.device)
+    if n:
+        _lib.check(L.tracs_filter_recomb_pairs(aln._h, _ptr(rows), _ptr(cols), _ptr(d), n, _ptr(filt), _stream()))
+    return filt[:n]
+
+
+def filter_index_info(aln):
+    """Diagnostics of the alignment's filter index (None before the first filter call)."""
+    import ctypes as C
+    L = _lib.require_gpu()
+    out = (C.c_double * 10)()
+    if not L.tracs_debug_filter_index(aln._h, out):
+        return None
+    keys = ("ref", "count", "offsets", "fill", "nt", "ns")
+    return {"lists": bool(out[0]), "entries": int(out[1]), "longest_list": int(out[2]), "alloc_ms": out[3],
+            "build_ms": {k: out[4 + i] for i, k in enumerate(keys)}}
+
+
 def trans_dist_device(snpdiff, datediff, lamb, beta, threshold_Ek, exp_p0=False):
     L = _lib.require_gpu()
     n = snpdiff.numel()

@@ -238,7 +238,7 @@ def pairs_of_rank(aln, i_end, j_start, dist_threshold, rank, world, recomb_filte
                 dev.pairsnp_dense(aln, dpan, npan, row_begin=r0, row_end=r1, col_begin=j_start, dist_threshold=dist_threshold, base_row=r0)
                 got = dev.coo_from_dense(dpan, npan, n, dist_threshold, row_begin=r0, row_end=r1, col_begin=j_start, base_row=r0)
                 if recomb_filter:
-                    got = list(got) + [dev.filter_recomb_device(aln, got[0], got[1], got[2])[0].clone()]
+                    got = list(got) + [dev.filter_recomb_pairs(aln, got[0], got[1], got[2]).clone()]
                 for t in range(k):
                     acc[t].append(got[t])
             parts[c] = tuple(torch.cat(a) if a else torch.empty(0, dtype=torch.int32, device=dev_) for a in acc)
