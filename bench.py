@@ -144,11 +144,18 @@ WORKLOADS = {
     # a random 0.5-30 % of the samples, 1 % N overall (tracs_amd/synth.py: coverage_runs) -- the reference's cost does not care
     # (src/pairsnp.hpp:417-420), the site classes' does
     "runs": dict(mu_lineage=0.0, mu_sample=MU, n_lineages=1, p_n=0.0, runs=dict(p_n=P_N, mean_len=500, frac_lo=0.005, frac_hi=0.30)),
+    # what `tracs align` itself writes (tracs/align.py:599-622): every sample N wherever ITS coverage is below the thresholds -- here
+    # 30 % of the sites, in runs of geometric length (mean 5 kb) whose boundaries are the sample's own --, partial IUPAC codes where
+    # two alleles pass the posterior filter (0.5 % of the sites; the default, without --consensus), two lineages
+    "coverage": dict(mu_lineage=1e-4, mu_sample=MU, n_lineages=2, p_n=0.0, gaps=dict(frac=0.30, mean_len=5000), p_partial=P_PARTIAL_C4),
 }
 
 
 def synth_kw(p_partial=0.0, workload="sparse"):
-    return dict(WORKLOADS[workload], p_partial=p_partial)
+    kw = dict(WORKLOADS[workload])
+    if p_partial or "p_partial" not in kw:
+        kw["p_partial"] = p_partial
+    return kw
 
 
 def pair_split_ms(lib, calls=1):
@@ -619,7 +626,10 @@ def main():
             out["single_pass"] = single
         if world == 1 and not args.no_extras and args.partial == 0 and args.workload == "sparse":
             out["sensitivity"] = sensitivity(args, n, L, seed, days, dev, synth, torch, device, lib, value)
-            out["value_worst_workload"] = min([value] + [w["pairs_per_s"] for w in out["sensitivity"]["workloads"].values()])
+            out["value_worst_workload"] = min([value] + [w["pairs_per_s"] for w in out["sensitivity"]["workloads"].values()])   # per call, like `value`
+        if world == 1 and not args.no_extras:
+            # `tracs distance --filter`: the recombination filter over every emitted pair of the timed alignment (not part of `value`)
+            out["filter"] = filter_leg(n, L, seed, synth_kw(args.partial, args.workload), aln, dmat, nmat, dev, synth, torch, device)
         if world == 1 and not args.no_extras and args.partial == 0:
             out["roofline_general"] = general_pass(args, n, L, seed, dev, synth, torch, device)
             out["dm_frontend"] = dm_frontend(args, L, dev, torch, device)
@@ -835,57 +845,149 @@ def _traffic_from_profiles(n, L, world, kernel):
 
 
 def sensitivity(args, n, L, seed, days, dev, synth, torch, device, lib, value_default):
-    """The same pass on five other synthetic alignments of the same shape (WORKLOADS), each with the site classes as the cost
-    model decides and with every site through the pair kernel (tracs_debug_force_site_classes(0), the same handle re-decided):
-    ms per pass in steady state (pairsnp + transcluster, 2 passes after one untimed), class sizes, and the two runs' checksums,
-    which must agree.  The reference's cost does not depend on the data (src/pairsnp.hpp:395-420 visits every site of every pair);
-    this path's does: the spread is reported, and the worst workload's rate goes beside `value` as value_worst_workload."""
+    """The same CALL on seven other synthetic alignments of the same shape (WORKLOADS + `partial`), on the headline's unit: ONE CALL
+    per step -- the planes count as freshly packed before every call (mark_packed, like step()), so the encoding, the site classes
+    and every list are rebuilt inside the timed region -- pairsnp + transcluster, 2 calls after one untimed first call, HIP events.
+    Beside it the steady-state pass over the alignment as it stands (rounds 1-5's figure), the class sizes, the kernels' split, and
+    the same handle with every site through the pair kernel (tracs_debug_force_site_classes(0)), whose checksums must agree.  The
+    reference's cost does not depend on the data (src/pairsnp.hpp:395-420 visits every site of every pair); this path's does:
+    `value_worst_workload` and `spread` come from the PER-CALL figures only."""
     pairs = n * (n - 1) // 2
     dmat = torch.zeros((n, n), dtype=torch.int32, device=device)
     nmat = torch.zeros((n, n), dtype=torch.int32, device=device)
     pmat = torch.zeros((n, n), dtype=torch.float64, device=device)
     emat = torch.zeros((n, n), dtype=torch.float64, device=device)
 
-    def timed(a):
-        def one():
+    def timed(a, per_call=True):
+        def one(fresh):
+            if fresh:
+                a.mark_packed()
             dev.pairsnp_dense(a, dmat, nmat)
             dev.trans_dist_dense_ranges(dmat, n, days, args.lamb, args.beta, args.precision, pmat, emat, [(0, n)], exp_p0=True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        one()
+        one(False)
         torch.cuda.synchronize()
         first = (time.perf_counter() - t0) * 1e3
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        one(); one()
-        e1.record()
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e[0].record()
+        if per_call:
+            one(True); one(True)
+        e[1].record()
+        one(False); one(False)
+        e[2].record()
         torch.cuda.synchronize()
-        return first, e0.elapsed_time(e1) / 2, int(dmat.sum().item()), int(nmat.sum().item())
+        return {"first": first, "call": e[0].elapsed_time(e[1]) / 2 if per_call else None, "steady": e[1].elapsed_time(e[2]) / 2,
+                "cd": int(dmat.sum().item()), "cn": int(nmat.sum().item())}
     out = {}
-    for name in ("lineage", "divergent", "clean", "gappy", "runs", "partial"):
+    for name in ("lineage", "divergent", "clean", "gappy", "runs", "partial", "coverage"):
         a = dev.Alignment(n, L)
         # ("partial": the metric's alignment + 0.5 % partial IUPAC codes -- what `tracs align` writes without --consensus, tracs/align.py:616-622)
         synth.pack_synthetic_device(a, seed=seed, **(synth_kw(P_PARTIAL_C4, "sparse") if name == "partial" else synth_kw(0.0, name)))
-        first, ms, cd, cn = timed(a)
+        r = timed(a)
+        stages = dev.pack_stages()
         classes, kernel, split, a_count = a.site_classes, a.kernel, pair_split_ms(lib), a.count_source
         lib.tracs_debug_force_site_classes(0)
         a.mark_packed()
-        first0, ms0, cd0, cn0 = timed(a)
+        r0 = timed(a, per_call=False)
         lib.tracs_debug_force_site_classes(-2)
         a.close()
-        if (cd, cn) != (cd0, cn0):
-            raise SystemExit("PARITY FAILURE: workload %s, site classes change the result (%d, %d) vs (%d, %d)" % (name, cd, cn, cd0, cn0))
-        out[name] = {"ms_per_pass": ms, "pairs_per_s": pairs / (ms / 1e3), "single_pass_ms": first,
-                     "ms_per_pass_classes_off": ms0, "single_pass_ms_classes_off": first0,
+        if (r["cd"], r["cn"]) != (r0["cd"], r0["cn"]):
+            raise SystemExit("PARITY FAILURE: workload %s, site classes change the result (%d, %d) vs (%d, %d)"
+                             % (name, r["cd"], r["cn"], r0["cd"], r0["cn"]))
+        out[name] = {"ms_per_call": r["call"], "pairs_per_s": pairs / (r["call"] / 1e3),
+                     "ms_per_pass_steady_state": r["steady"], "pairs_per_s_steady_state": pairs / (r["steady"] / 1e3),
+                     "first_call_ms": r["first"], "once_per_call_ms": sum(ms for _, ms in stages),
+                     "once_per_call_stages_ms": {k: round(v, 3) for k, v in stages},
+                     "ms_per_pass_classes_off": r0["steady"], "first_call_ms_classes_off": r0["first"],
                      "site_classes": None if classes is None else dict(zip(("dense", "counted", "minority", "full"), classes)),
                      "kernel": kernel, "kernels_ms": None if not split else dict(zip(("pair", "lists", "count", "nn_lists"), split)),
                      "count_source": a_count,
-                     "mean_d": cd / float(pairs), "checksum_d": cd, "checksum_nn": cn,
+                     "mean_d": r["cd"] / float(pairs), "checksum_d": r["cd"], "checksum_nn": r["cn"],
                      "generator": dict(WORKLOADS["sparse"], p_partial=P_PARTIAL_C4) if name == "partial" else WORKLOADS[name]}
     worst = min(out, key=lambda k: out[k]["pairs_per_s"])
-    return {"workloads": out, "worst": worst,
-            "spread": max([value_default] + [w["pairs_per_s"] for w in out.values()]) / min([value_default] + [w["pairs_per_s"] for w in out.values()]),
-            "note": "10k x 5 Mbp each; default run vs every site through the pair kernel (same handle, re-decided); checksums of d and nn equal"}
+    rates = [value_default] + [w["pairs_per_s"] for w in out.values()]
+    return {"workloads": out, "worst": worst, "spread": max(rates) / min(rates), "unit": "ONE CALL per step, like `value`",
+            "note": "10k x 5 Mbp each; ms_per_call / pairs_per_s: the planes freshly packed before every call (everything the library builds "
+                    "per alignment inside the timed region, pairsnp + transcluster); *_steady_state: passes over the alignment as it stands; "
+                    "classes_off: every site through the pair kernel (same handle, re-decided); checksums of d and nn equal"}
+
+
+def filter_leg(n, L, seed, kw, aln, dmat, nmat, dev, synth, torch, device, snp_threshold=100, scan_sample=200000, check=24, reps=2):
+    """`tracs distance --filter` at the bench's size: the recombination filter (src/pairsnp.hpp:251-318) on every pair the dense call
+    emits (:405-413), planes and distance matrix resident in HBM.  Seconds per call over ALL emitted pairs:
+      first_call_s   on a freshly packed handle: departure lists + N bitmaps built (index_build_ms), thresholds built, pairs filtered
+      warm_call_s    the same call again (index and thresholds kept on the handle)
+      threshold      the same with -D snp_threshold (only the pairs within the threshold are emitted)
+      scan_route     rounds 1-5's route (a pair's SNP bits re-derived from the planes) on a bounded sample, extrapolated by pair count
+      oracle_check   the first `check` samples: GPU filtered distances == oracle at full length (always; a mismatch ends the run)"""
+    import numpy as np
+    rows, cols, d, _ = dev.coo_from_dense(dmat, nmat, n)
+    pairs = rows.numel()
+    out = {"pairs": pairs, "max_d": int(d.max().item()) if pairs else 0}
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize()
+        return r, time.perf_counter() - t
+    aln.mark_packed()
+    probe = min(pairs, 4096)
+    _, t_probe = timed(lambda: dev.filter_recomb_pairs(aln, rows[:probe], cols[:probe], d[:probe]))       # builds the index
+    info = dev.filter_index_info(aln)
+    listed = bool(info and info["lists"] and info["longest_list"] <= 4096)
+    out.update({"index": info, "index_build_ms": None if info is None else sum(info["build_ms"].values()), "first_probe_call_s": t_probe,
+                "route": "departure lists" if listed else "scan of the planes (lists too long for a wave's LDS, or not built)"})
+    if not listed:
+        # every pair would take the scan (minutes at this size): a bounded sample, extrapolated by pair count
+        m = min(pairs, scan_sample)
+        sel = torch.arange(0, pairs, max(1, pairs // m), device=device)[:m]
+        rows, cols, d = rows[sel].contiguous(), cols[sel].contiguous(), d[sel].contiguous()
+        out["sampled_pairs"] = int(m)
+    aln.mark_packed()
+    filt, t_first = timed(lambda: dev.filter_recomb_pairs(aln, rows, cols, d))
+    warm = []
+    for _ in range(reps):
+        f2, t = timed(lambda: dev.filter_recomb_pairs(aln, rows, cols, d))
+        warm.append(t)
+        if not torch.equal(f2, filt):
+            raise SystemExit("PARITY FAILURE: two filter calls over the same pairs differ")
+    scale = pairs / float(rows.numel())
+    out.update({"first_call_s": t_first * scale, "warm_call_s": min(warm) * scale, "pairs_per_s": rows.numel() / min(warm),
+                "mean_filtered_d": float(filt.to(torch.float64).mean().item()), "pairs_with_fewer_snps": int((filt < d).sum().item()),
+                "checksum_filt": int(filt.to(torch.int64).sum().item())})
+    pairs_run = rows.numel()
+    (r2, c2, d2, _), t_coo = timed(lambda: dev.coo_from_dense(dmat, nmat, n, snp_threshold))
+    t_thr = timed(lambda: dev.filter_recomb_pairs(aln, r2, c2, d2))[1] if r2.numel() else 0.0
+    out["threshold"] = {"D": snp_threshold, "pairs": int(r2.numel()), "coo_s": t_coo, "filter_s": t_thr}
+    m = min(pairs_run, scan_sample)
+    if m:
+        sel = torch.arange(0, pairs_run, max(1, pairs_run // m), device=device)[:m]
+        rs, cs, ds = rows[sel].contiguous(), cols[sel].contiguous(), d[sel].contiguous()
+        (fs, found, _, _), t_scan = timed(lambda: dev.filter_recomb_device(aln, rs, cs, ds))
+        if not (torch.equal(found, ds) and torch.equal(fs, filt[sel])):
+            raise SystemExit("PARITY FAILURE: the list route and the scan route of the filter differ")
+        out["scan_route"] = {"pairs": int(m), "seconds": t_scan, "pairs_per_s": m / t_scan, "all_pairs_s": t_scan * pairs / m,
+                             "bytes_per_pair": float(L), "achieved_GBps": m * float(L) / t_scan / 1e9,
+                             "note": "tracs_filter_recomb_device: 8 planes x L / 8 bytes per pair; extrapolated to all pairs"}
+    k = min(n, check)
+    if k >= 2:
+        from oracle import oracle as O
+        seqs = synth.first_samples_host(n, L, seed, k, **kw)
+        r, c, dd, _ = O.pairsnp_arrays(seqs)
+        t0 = time.perf_counter()
+        cores = len(os.sched_getaffinity(0))
+        ef = O.filter_recomb_pairs(seqs, r, c, cores)
+        t_or = time.perf_counter() - t0
+        ri, ci = torch.from_numpy(r.astype(np.int32)).to(device), torch.from_numpy(c.astype(np.int32)).to(device)
+        gd = dmat[ri.long(), ci.long()].contiguous()
+        gf = dev.filter_recomb_pairs(aln, ri, ci, gd).cpu().numpy()
+        ok = bool(np.array_equal(gd.cpu().numpy(), dd.astype(np.int32)) and np.array_equal(gf, ef.astype(np.int32)))
+        out["oracle_check"] = {"samples": k, "pairs": int(len(r)), "equal": ok, "cpu_pairs_per_s": len(r) / t_or, "cores": cores, "kind": "port"}
+        if not ok:
+            raise SystemExit("PARITY FAILURE: filtered distances differ from the oracle on the first %d samples" % k)
+    return out
 
 
 def general_pass(args, n, L, seed, dev, synth, torch, device):

@@ -84,10 +84,15 @@ def extract_kernel(request, monkeypatch):
     return request.param
 
 
-# every way tracs_filter_recomb_pairs can take: lists + table (the default), lists with the tail summed per SNP, the scan of the
-# planes for every pair, and lists whose LDS capacity leaves some pairs to the scan
+# every way tracs_filter_recomb_pairs can take: lists + table (the default: the merge-path kernel), lists with the tail summed per
+# SNP, the scan of the planes for every pair, lists whose LDS capacity leaves some pairs to the scan, and the binary-search kernel
+# (what lists of more than 1 024 entries use)
 ROUTES = {"lists": {}, "lists_no_table": {"TRACS_FILTER_TABLE": "0"}, "scan": {"TRACS_FILTER_LISTS": "0"},
-          "lists_cap64": {"TRACS_FILTER_CAP": "64"}}
+          "scan_batches": {"TRACS_FILTER_LISTS": "0", "TRACS_FILTER_SCAN_MAXPOS": "20000"},
+          "scan_batches_lanes": {"TRACS_FILTER_LISTS": "0", "TRACS_FILTER_SCAN_MAXPOS": "50000", "TRACS_FILTER_LANES_MIN": "0"},
+          "lists_cap64_batches": {"TRACS_FILTER_CAP": "64", "TRACS_FILTER_SCAN_MAXPOS": "3000"},
+          "lists_cap64": {"TRACS_FILTER_CAP": "64"}, "lists_search_kernel": {"TRACS_FILTER_KERNEL": "1"},
+          "lists_search_kernel_cap128": {"TRACS_FILTER_KERNEL": "1", "TRACS_FILTER_CAP": "128"}}
 
 
 @pytest.fixture(params=sorted(ROUTES))
@@ -140,7 +145,7 @@ def test_gpu_filter_pairs_matches_oracle(oracle, hiplib, route, shape):
         got = dev.filter_recomb_pairs(aln, rows, cols, dd).cpu().numpy()
         assert np.array_equal(got, ef[sel].astype(np.int32)), (route, np.where(got != ef[sel])[0][:10])
     info = dev.filter_index_info(aln)
-    assert info is not None and (not info["lists"] if route == "scan" else info["lists"] or kw["mu_sample"] > 1e-2)
+    assert info is not None and (not info["lists"] if route.startswith("scan") else info["lists"] or kw["mu_sample"] > 1e-2)
     # a wrong distance is caught, never filtered silently
     bad = torch.from_numpy((d + 1).astype(np.int32)).cuda()
     with pytest.raises(RuntimeError, match="does not match the distance"):

@@ -61,13 +61,16 @@ def test_config1_distance_cli_10x100kb(hiplib, oracle, tmp_path):
     check_trans_dist(oracle, ed.astype(np.int32), delta, 1e-3 * 29903, 73.0, 0.01, np.log(np.array(p)), np.array(ek))
 
 
-def _generate_with_blocks(dev, synth, n, L, seed, blocks, **kw):
-    """Pack the synthetic alignment on the device; keep the ASCII of the sample ranges in `blocks` on the host."""
+def _generate_with_blocks(dev, synth, n, L, seed, blocks, mutate=None, **kw):
+    """Pack the synthetic alignment on the device; keep the ASCII of the sample ranges in `blocks` on the host.
+    mutate(rows, first): edits a batch of samples (device uint8 [k, L]) before it is packed."""
     import torch
     aln = dev.Alignment(n, L)
     kept = {}
 
     def emit(rows, first):
+        if mutate is not None:
+            mutate(rows, first)
         aln.pack(rows, first=first)
         for b0, b1 in blocks:
             lo, hi = max(b0, first), min(b1, first + rows.shape[0])
@@ -130,6 +133,65 @@ def test_config3_full_size(dev, oracle, p_partial):
     assert bool(torch.equal(d3[keep], d[keep])) and bool(torch.equal(n3[keep], nn[keep]))
     rest = torch.triu(d > thr, diagonal=1)
     assert bool(((d3[rest] < 0) | (d3[rest] > thr)).all())
+    aln.close()
+
+
+@pytest.mark.parametrize("p_partial", [0.0, 0.005], ids=["consensus", "partial-codes"])
+def test_config3_full_size_filter(dev, oracle, p_partial):
+    """`tracs distance --filter` at the metric's size (src/pairsnp.hpp:251-318 on every emitted pair, :405-413): three 32-sample
+    blocks (first rows, middle, last) and all their cross pairs -- 4 560 pairs at full length -- against the oracle's filter_recomb,
+    with planted runs of substitutions (what the filter exists to remove) in some of them.  Consensus alignment: the departure
+    lists, ALL 49 995 000 pairs filtered in one call; with partial codes the lists outgrow a wave's LDS and the pairs take the scan
+    of the planes (the block's pairs only)."""
+    import torch
+    from tracs_amd import synth
+    n, L = 10000, 5000000
+    blocks = [(0, 32), (4984, 5016), (n - 32, n)]
+    planted = {3: (1000, 400), 17: (2500000, 250), 4990: (4999700, 300), 5001: (0, 350), n - 2: (777777, 500), n - 30: (2500100, 200)}
+    lut = torch.arange(256, dtype=torch.uint8, device="cuda")
+    for a, b in zip(b"ACGT", b"CGTA"):
+        lut[a] = b
+
+    def mutate(rows, first):
+        for s, (at, w) in planted.items():
+            if first <= s < first + rows.shape[0]:
+                seg = rows[s - first, at:at + w]
+                rows[s - first, at:at + w] = lut[seg.long()]
+
+    aln, idx, host = _generate_with_blocks(dev, synth, n, L, 20241022 + 2, blocks, mutate=mutate, mu_lineage=0.0, mu_sample=1e-4,
+                                           n_lineages=1, p_n=0.01, p_partial=p_partial)
+    d = torch.zeros((n, n), dtype=torch.int32, device="cuda")
+    nn = torch.zeros((n, n), dtype=torch.int32, device="cuda")
+    dev.pairsnp_dense(aln, d, nn)
+    er, ec, ed, enn = oracle.pairsnp_arrays(host, n_threads=max(1, os.cpu_count() or 1))
+    ef = oracle.filter_recomb_pairs(host, er, ec, max(1, os.cpu_count() or 1)).astype(np.int32)
+    gi = torch.from_numpy(idx[er.astype(np.int64)].astype(np.int32)).cuda()
+    gj = torch.from_numpy(idx[ec.astype(np.int64)].astype(np.int32)).cuda()
+    gd = d[gi.long(), gj.long()].contiguous()
+    assert np.array_equal(gd.cpu().numpy(), ed.astype(np.int32))
+    # the block's pairs on their own (any order of pairs is a valid call)
+    got = dev.filter_recomb_pairs(aln, gi, gj, gd).cpu().numpy()
+    assert np.array_equal(got, ef), np.where(got != ef)[0][:10]
+    hit = np.isin(idx[er.astype(np.int64)], list(planted)) | np.isin(idx[ec.astype(np.int64)], list(planted))
+    assert (ed[hit].astype(np.int64) - ef[hit] >= 150).all() and (ef <= ed).all()       # the planted runs are filtered out
+    info = dev.filter_index_info(aln)
+    assert info["lists"] and info["entries"] > 4_000_000
+    if p_partial == 0:
+        assert info["longest_list"] <= 1024                     # every pair from the lists (the merge-path kernel)
+        rows, cols, dd, _ = dev.coo_from_dense(d, nn, n)
+        assert rows.numel() == n * (n - 1) // 2
+        filt = dev.filter_recomb_pairs(aln, rows, cols, dd)
+        assert bool((filt <= dd).all()) and bool((filt >= 0).all())
+        fm = torch.zeros((n, n), dtype=torch.int32, device="cuda")
+        fm[rows.long(), cols.long()] = filt
+        assert np.array_equal(fm[gi.long(), gj.long()].cpu().numpy(), ef)
+        # the filtered distance only depends on the pair: a thresholded emission gives the same values
+        thr = int(dd.double().mean().item()) - 20
+        r2, c2, d2, _ = dev.coo_from_dense(d, nn, n, thr)
+        assert 1000 < r2.numel() < rows.numel()
+        assert bool(torch.equal(dev.filter_recomb_pairs(aln, r2, c2, d2), fm[r2.long(), c2.long()]))
+    else:
+        assert info["longest_list"] > 4096                      # the lists do not fit a wave's LDS: these pairs were scanned
     aln.close()
 
 

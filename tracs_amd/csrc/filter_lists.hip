@@ -17,7 +17,7 @@
 // monotone in the span: per distinct d one row of thresholds "smallest span that survives with `count` SNPs in the
 // window" is built on first use (the reference memoises (n, p, k) -> cdf in a std::map, :41-58), so the test per SNP is
 // one compare.  Pairs whose lists do not fit the wave's LDS (and alignments whose lists cannot be built) take the scan
-// of the planes (flt_scan_kernel below; filter.hip keeps the form that also returns the positions).
+// of the planes (filter.hip: the reference's own way, which also returns the positions).
 // PARITY UNPINNED: Boost's ibetac is replaced by the exact finite sum.
 #include "common.h"
 #include "filter_math.h"
@@ -31,10 +31,11 @@
 namespace tracs {
 
 int get_lgamma_table_for_filter(hipStream_t stream, const double **out);   // transcluster.hip
+int filter_scan_route(const tracs_alignment *a, const unsigned *rows, const unsigned *cols, const unsigned *d, size_t n_pairs, unsigned max_d,
+                      unsigned *filt, const unsigned *tbl, const unsigned char *tbl_state, const double *lg, unsigned *bad,
+                      hipStream_t stream);                                   // filter.hip
 
 constexpr unsigned FLT_GCHUNK = 256;          // groups per (sample, chunk) thread of the list builders
-constexpr unsigned FLT_KT = 64;               // threshold table: counts 2 .. 63 per row
-constexpr unsigned FLT_DCAP = 65536;          // ... rows for d <= this (beyond: the tail is summed per SNP)
 constexpr unsigned FLT_CAP_MAX = 4096;        // list entries per sample a wave can hold in LDS
 constexpr unsigned FLT_POS_BITS = 27;         // entry = pos << 5 | w << 4 | mask
 
@@ -430,16 +431,190 @@ __global__ __launch_bounds__(WPB * 64) void flt_pairs_kernel(FltPairArgs A)
     if (lane == 0) A.filt[t] = kept;
 }
 
+// ---- the pairs, second form (lists of up to 1 024 entries) ----------------------------------------------------------------------
+// One wave per pair, R = rounds of 64 entries per list.  What the first form spends its time on is latency: ten dependent LDS reads
+// per entry for the merge ranks, and one N lookup per entry in global memory whose answer the next instruction waits for.  Here
+//   * both lists are loaded into registers and ALL their N lookups are issued before any answer is used (2 R loads in flight per
+//     lane); the answer folds into the entry's w bit (a listed sample whose partner is N at the site can never make a SNP there),
+//     so nothing later touches global memory;
+//   * the merge is a merge path: lane l owns the merged entries [l C, (l + 1) C), finds where its share starts in the two lists
+//     with ONE binary search along its diagonal and then takes C entries one after the other (one LDS read per entry);
+//   * the lane's survivors are counted on the way, a prefix sum over the lanes places them, each lane copies its own;
+//   * the window test reads a SNP's two neighbours on either side up front (windows rarely hold more), and the thresholds of the
+//     pair's d sit in registers, one count per lane (ds_bpermute instead of a table read).
+template <int R>
+__global__ __launch_bounds__(64) void flt_pairs2_kernel(FltPairArgs A)
+{
+    extern __shared__ unsigned flt_lds[];
+    constexpr unsigned CAP = R * 64, INF = 0xFFFFFFFFu;
+    const unsigned lane = threadIdx.x;
+    const size_t t = blockIdx.x;
+    unsigned *LA = flt_lds, *LB = LA + CAP, *M = LB + CAP;                 // M: 2 CAP + 128 words
+    const unsigned i = A.rows[t], j = A.cols[t];
+    const unsigned long long oi = A.dep_off[i], oj = A.dep_off[j];
+    const unsigned la = (unsigned)(A.dep_off[i + 1] - oi), lb = (unsigned)(A.dep_off[j + 1] - oj);
+    if (la > CAP || lb > CAP) {                                            // left to the scan of the planes
+        if (lane == 0) { A.filt[t] = 0xFFFFFFFFu; atomicAdd(A.counters + 1, 1u); atomicMax(A.counters + 2, A.d[t]); }
+        return;
+    }
+    const unsigned dt = A.d[t];
+    const bool have_row = A.tbl && dt >= 2 && dt <= FLT_DCAP && A.tbl_state[dt] == 1;
+    const unsigned rowv = have_row ? A.tbl[(size_t)dt * FLT_KT + lane] : INF;      // smallest surviving span for count = lane
+    unsigned ea[R], eb[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const unsigned k = (unsigned)r * 64 + lane;
+        ea[r] = k < la ? A.dep[oi + k] : INF;
+        eb[r] = k < lb ? A.dep[oj + k] : INF;
+    }
+    const unsigned *nsj = A.ns + (j >> 5);
+    const unsigned jbit = j & 31u;
+    const unsigned *nti = A.nt + (size_t)i * A.nt_words;
+    unsigned na[R], nb[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const unsigned k = (unsigned)r * 64 + lane;
+        na[r] = (k < la && (ea[r] & 16u)) ? nsj[(size_t)(ea[r] >> 5) * A.ns_words] : 0u;
+        nb[r] = (k < lb && (eb[r] & 16u)) ? nti[eb[r] >> 10] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const unsigned k = (unsigned)r * 64 + lane;
+        if (k < la) LA[k] = ea[r] & ~(((na[r] >> jbit) & 1u) << 4);
+        if (k < lb) LB[k] = eb[r] & ~(((nb[r] >> ((eb[r] >> 5) & 31u)) & 1u) << 4);
+    }
+    flt_wave_sync();
+#if defined(TRACS_FLT_CUT) && TRACS_FLT_CUT == 1
+    if (lane == 0) A.filt[t] = LA[0] + LB[0];
+    return;
+#endif
+    // merge path
+    const unsigned tot = la + lb, C = (tot + 63u) / 64u, stride = C | 1u;
+    const unsigned D = min(tot, lane * C);
+    unsigned a, b;
+    {
+        unsigned lo = D > lb ? D - lb : 0u, hi = min(D, la);
+        while (lo < hi) {
+            const unsigned mid = (lo + hi) >> 1;
+            if ((LA[mid] >> 5) <= (LB[D - 1u - mid] >> 5)) lo = mid + 1u; else hi = mid;
+        }
+        a = lo; b = D - lo;
+    }
+    unsigned va = a < la ? LA[a] : INF, vb = b < lb ? LB[b] : INF;
+    unsigned lastA = a > 0u ? (LA[a - 1u] >> 5) : INF;
+    unsigned cnt = 0;
+    unsigned *Mrow = M + lane * stride;
+    for (unsigned step = 0; step < C; step++) {
+        const unsigned pa = va >> 5, pb = vb >> 5;
+        const bool takeA = pa <= pb;
+        // an entry of i: both listed -> the masks decide; else its w bit (partner carries the reference base; N folded in above).
+        // an entry of j: dead when i lists the site too (i's entry carried the verdict)
+        const unsigned snpA = pa == pb ? (((va & vb & 15u) == 0u) ? 1u : 0u) : ((va >> 4) & 1u);
+        const unsigned snpB = lastA == pb ? 0u : ((vb >> 4) & 1u);
+        const unsigned snp = (D + step < tot) ? (takeA ? snpA : snpB) : 0u;
+        Mrow[step] = (takeA ? pa : pb) | (snp << 31);
+        cnt += snp;
+        const unsigned nidx = takeA ? a + 1u : CAP + b + 1u, nlim = takeA ? la : CAP + lb;
+        const unsigned nxt = nidx < nlim ? LA[nidx] : INF;
+        if (takeA) { lastA = pa; a++; va = nxt; } else { b++; vb = nxt; }
+    }
+    // place the survivors
+    unsigned incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned v = __shfl_up(incl, off, 64);
+        if (lane >= (unsigned)off) incl += v;
+    }
+    const unsigned dn = __shfl(incl, 63, 64);
+#if defined(TRACS_FLT_CUT) && TRACS_FLT_CUT == 2
+    if (lane == 0) A.filt[t] = dn;
+    return;
+#endif
+    flt_wave_sync();                                                       // every lane is done with the two lists
+    unsigned *S = LA;
+    {
+        unsigned o = incl - cnt;
+        for (unsigned step = 0; step < C; step++) {
+            const unsigned v = Mrow[step];
+            if (v >> 31) S[o++] = v & 0x7FFFFFFFu;
+        }
+    }
+    flt_wave_sync();
+#if defined(TRACS_FLT_CUT) && TRACS_FLT_CUT == 3
+    if (lane == 0) A.filt[t] = dn + S[0];
+    return;
+#endif
+    if (dn != dt && lane == 0) atomicAdd(A.counters, 1u);
+    if (dn <= 1u) { if (lane == 0) A.filt[t] = dn; return; }              // :259-261
+    // window test (:273-314)
+    const FilterWindow fw = filter_window((long long)dn, A.L);
+    const int wh = fw.wh, aln = (int)A.L, n_s = (int)dn;
+    unsigned kept = 0;
+    for (int u0 = 0; u0 < n_s; u0 += 64) {
+        const int u = u0 + (int)lane;
+        const bool act = u < n_s;
+        int count = 0, length = 0;
+        if (act) {
+            const int x = (int)S[u];
+            const int p1 = u >= 1 ? (int)S[u - 1] : -1, p2 = u >= 2 ? (int)S[u - 2] : -1;
+            const int n1 = u + 1 < n_s ? (int)S[u + 1] : 0x7FFFFFFF, n2 = u + 2 < n_s ? (int)S[u + 2] : 0x7FFFFFFF;
+            const int left = max(0, x - wh);                               // :284
+            const int right = min(aln, x + wh + 1);                        // :285
+            int f = u, l = u, xf = x, xl = x;
+            if (p1 >= left) {
+                f = u - 1; xf = p1;
+                if (p2 >= left) {
+                    f = u - 2;
+                    int steps = 0;
+                    while (f > 0 && (int)S[f - 1] >= left) {
+                        --f;
+                        if (++steps == 6) { f = flt_lower_bound(S, 0, f, (unsigned)left); break; }
+                    }
+                    xf = (int)S[f];
+                }
+            }
+            if (n1 < right) {
+                l = u + 1; xl = n1;
+                if (n2 < right) {
+                    l = u + 2;
+                    int steps = 0;
+                    while (l + 1 < n_s && (int)S[l + 1] < right) {
+                        ++l;
+                        if (++steps == 6) { l = flt_lower_bound(S, l + 1, n_s, (unsigned)right) - 1; break; }
+                    }
+                    xl = (int)S[l];
+                }
+            }
+            count = l - f + 1;
+            length = xl - xf + 1;                                          // :242
+        }
+        const unsigned thr = __shfl(rowv, count < (int)FLT_KT ? count : 0, 64);
+        if (act) {
+            bool keep = true;                                              // alone in its window: :311
+            if (count > 1) {                                               // :294
+                if (have_row && count < (int)FLT_KT) keep = (unsigned)length >= thr;
+                else keep = filter_keep(length, count, fw.p, fw.thr, A.lg);
+            }
+            kept += keep ? 1u : 0u;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) kept += __shfl_xor(kept, off, 64);
+    if (lane == 0) A.filt[t] = kept;
+}
+
+template <int R>
+static void flt_launch2(const FltPairArgs &A, hipStream_t stream)
+{
+    hipLaunchKernelGGL((flt_pairs2_kernel<R>), dim3((unsigned)A.n_pairs), dim3(64), (size_t)(4 * R * 64 + 128) * 4, stream, A);
+}
+
 // pairs left to the scan: their indices, closed up
 __global__ __launch_bounds__(256) void flt_collect_kernel(const unsigned *__restrict__ filt, size_t n_pairs, unsigned *__restrict__ idx,
                                                           unsigned *__restrict__ cursor)
 {
     for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < n_pairs; t += (size_t)gridDim.x * 256)
         if (filt[t] == 0xFFFFFFFFu) idx[atomicAdd(cursor, 1u)] = (unsigned)t;
-}
-__global__ __launch_bounds__(256) void flt_iota_kernel(unsigned *__restrict__ idx, size_t n)
-{
-    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (size_t)gridDim.x * 256) idx[t] = (unsigned)t;
 }
 __global__ __launch_bounds__(256) void flt_max_kernel(const unsigned *__restrict__ d, size_t n, unsigned *__restrict__ out)
 {
@@ -450,62 +625,20 @@ __global__ __launch_bounds__(256) void flt_max_kernel(const unsigned *__restrict
     if ((threadIdx.x & 63) == 0) atomicMax(out, m);
 }
 
-// The scan of the planes for the pairs idx[0 .. n_idx): one wave per pair, its SNP sites into the wave's slot of `scratch`
-// (slot entries each: the largest d of those pairs), then the same window test.  What the reference does per pair (:254-314).
-__global__ __launch_bounds__(64) void flt_scan_pairs_kernel(const uint4 *__restrict__ P, size_t n_pad, unsigned L,
-                                                            const unsigned *__restrict__ rows, const unsigned *__restrict__ cols,
-                                                            const unsigned *__restrict__ d, const unsigned *__restrict__ idx, size_t n_idx,
-                                                            unsigned *__restrict__ scratch, size_t slot, const unsigned *__restrict__ tbl,
-                                                            const unsigned char *__restrict__ tbl_state, const double *__restrict__ lg,
-                                                            unsigned *__restrict__ filt, unsigned *__restrict__ counters)
+// the pairs left to the scan, closed up / their results put back
+__global__ __launch_bounds__(256) void flt_gather_kernel(const unsigned *__restrict__ idx, size_t n_idx, const unsigned *__restrict__ rows,
+                                                         const unsigned *__restrict__ cols, const unsigned *__restrict__ d,
+                                                         unsigned *__restrict__ r2, unsigned *__restrict__ c2, unsigned *__restrict__ d2)
 {
-    const int lane = threadIdx.x;
-    unsigned *S = scratch + (size_t)blockIdx.x * slot;
-    const unsigned W = (L + 31) / 32;
-    for (size_t q = blockIdx.x; q < n_idx; q += gridDim.x) {
-        const size_t t = idx[q];
-        const size_t si = rows[t], sj = cols[t];
-        unsigned o = 0;
-        for (unsigned base = 0; base < W; base += 64) {
-            const unsigned w = base + lane;
-            unsigned snp = 0;
-            if (w < W) {
-                const size_t g = w >> 2;
-                const unsigned comp = w & 3;
-                const unsigned *pi = reinterpret_cast<const unsigned *>(P + g * NPLANES * n_pad + si) + comp;
-                const unsigned *pj = reinterpret_cast<const unsigned *>(P + g * NPLANES * n_pad + sj) + comp;
-                const size_t ps = n_pad * 4;
-                const unsigned m = (pi[0] & pj[0]) | (pi[ps] & pj[ps]) | (pi[2 * ps] & pj[2 * ps]) | (pi[3 * ps] & pj[3 * ps]);
-                snp = ~m;                                                  // res.flip(), :254
-                const unsigned rem = L - w * 32;
-                if (rem < 32) snp &= (1u << rem) - 1u;
-            }
-            const unsigned c = __popc(snp);
-            unsigned incl = c;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const unsigned v = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += v;
-            }
-            unsigned dst = o + incl - c;
-            while (snp) {
-                const int b = __ffs(snp) - 1;
-                snp &= snp - 1;
-                if (dst < slot) S[dst] = w * 32 + b;
-                dst++;
-            }
-            o += __shfl(incl, 63, 64);
-        }
-        __threadfence_block();
-        flt_wave_sync();
-        const unsigned dn = o;
-        if (dn != d[t] || dn > slot) { if (lane == 0) { atomicAdd(counters, 1u); filt[t] = 0; } continue; }
-        if (dn <= 1) { if (lane == 0) filt[t] = dn; continue; }
-        const unsigned *row = (tbl && dn <= FLT_DCAP && tbl_state[dn] == 1) ? tbl + (size_t)dn * FLT_KT : nullptr;
-        const unsigned kept = flt_window_test(S, (int)dn, L, row, lg, lane);
-        if (lane == 0) filt[t] = kept;
-        flt_wave_sync();
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n_idx; q += (size_t)gridDim.x * 256) {
+        const unsigned t = idx[q];
+        r2[q] = rows[t]; c2[q] = cols[t]; d2[q] = d[t];
     }
+}
+__global__ __launch_bounds__(256) void flt_scatter_kernel(const unsigned *__restrict__ idx, size_t n_idx, const unsigned *__restrict__ f2,
+                                                          unsigned *__restrict__ filt)
+{
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n_idx; q += (size_t)gridDim.x * 256) filt[idx[q]] = f2[q];
 }
 
 // ---- host ------------------------------------------------------------------------------------------------------------------------
@@ -676,7 +809,19 @@ int tracs_filter_recomb_pairs(tracs_alignment *a, const uint32_t *rows, const ui
         A.L = (unsigned)a->L; A.cap = cap;
         A.tbl = tbl; A.tbl_state = f->tbl_state; A.lg = lg;
         A.filt = filt; A.counters = f->counters;
-        if (cap <= 1024)
+        const char *form_env = std::getenv("TRACS_FILTER_KERNEL");
+        const int form = form_env ? std::atoi(form_env) : 2;
+        if (form == 2 && cap <= 1024) {
+            const unsigned r = cap / 64;
+            if (r <= 1) flt_launch2<1>(A, stream);
+            else if (r <= 2) flt_launch2<2>(A, stream);
+            else if (r <= 4) flt_launch2<4>(A, stream);
+            else if (r <= 6) flt_launch2<6>(A, stream);
+            else if (r <= 8) flt_launch2<8>(A, stream);
+            else if (r <= 10) flt_launch2<10>(A, stream);
+            else if (r <= 12) flt_launch2<12>(A, stream);
+            else flt_launch2<16>(A, stream);
+        } else if (cap <= 1024)
             hipLaunchKernelGGL((flt_pairs_kernel<4>), dim3((unsigned)((n_pairs + 3) / 4)), dim3(256), (size_t)cap * 64, stream, A);
         else
             hipLaunchKernelGGL((flt_pairs_kernel<1>), dim3((unsigned)n_pairs), dim3(64), (size_t)cap * 16, stream, A);
@@ -690,27 +835,26 @@ int tracs_filter_recomb_pairs(tracs_alignment *a, const uint32_t *rows, const ui
         all_left = false;
     }
     if (n_left == 0) return TRACS_OK;
-    // the scan of the planes for what is left
-    unsigned *idx, *scratch;
-    if ((rc = workspace_get(FltWs::IDX, n_left * 4, reinterpret_cast<void **>(&idx)))) return rc;
+    // the scan of the planes for what is left (filter.hip)
+    TRACS_HIP_CHECK(hipMemsetAsync(f->counters, 0, 4, stream));
+    const unsigned blocks = (unsigned)std::min<size_t>((n_pairs + 255) / 256, 256 * 16);
     if (all_left) {
-        const unsigned blocks = (unsigned)std::min<size_t>((n_pairs + 255) / 256, 256 * 16);
-        hipLaunchKernelGGL(flt_iota_kernel, dim3(blocks), dim3(256), 0, stream, idx, n_pairs);
         hipLaunchKernelGGL(flt_max_kernel, dim3(blocks), dim3(256), 0, stream, d, n_pairs, f->counters + 2);
         TRACS_HIP_CHECK(hipMemcpyAsync(&max_d_left, f->counters + 2, 4, hipMemcpyDeviceToHost, stream));
         TRACS_HIP_CHECK(hipStreamSynchronize(stream));
+        if ((rc = filter_scan_route(a, rows, cols, d, n_pairs, max_d_left, filt, tbl, f->tbl_state, lg, f->counters, stream))) return rc;
     } else {
+        unsigned *idx, *g;
+        if ((rc = workspace_get(FltWs::IDX, n_left * 4, reinterpret_cast<void **>(&idx))) ||
+            (rc = workspace_get(FltWs::SCRATCH, n_left * 16, reinterpret_cast<void **>(&g)))) return rc;
+        unsigned *r2 = g, *c2 = g + n_left, *d2 = g + 2 * n_left, *f2 = g + 3 * n_left;
         TRACS_HIP_CHECK(hipMemsetAsync(f->counters + 4, 0, 4, stream));
-        const unsigned blocks = (unsigned)std::min<size_t>((n_pairs + 255) / 256, 256 * 16);
         hipLaunchKernelGGL(flt_collect_kernel, dim3(blocks), dim3(256), 0, stream, filt, n_pairs, idx, f->counters + 4);
+        const unsigned gb = (unsigned)std::min<size_t>((n_left + 255) / 256, 256 * 16);
+        hipLaunchKernelGGL(flt_gather_kernel, dim3(gb), dim3(256), 0, stream, idx, n_left, rows, cols, d, r2, c2, d2);
+        if ((rc = filter_scan_route(a, r2, c2, d2, n_left, max_d_left, f2, tbl, f->tbl_state, lg, f->counters, stream))) return rc;
+        hipLaunchKernelGGL(flt_scatter_kernel, dim3(gb), dim3(256), 0, stream, idx, n_left, f2, filt);
     }
-    const size_t slot = std::max<size_t>(64, ((size_t)max_d_left + 63) / 64 * 64);
-    size_t waves = std::min<size_t>(n_left, 256 * 16);
-    while (waves > 256 && waves * slot * 4 > (4ull << 30)) waves /= 2;
-    if ((rc = workspace_get(FltWs::SCRATCH, waves * slot * 4, reinterpret_cast<void **>(&scratch)))) return rc;
-    TRACS_HIP_CHECK(hipMemsetAsync(f->counters, 0, 4, stream));
-    hipLaunchKernelGGL(flt_scan_pairs_kernel, dim3((unsigned)waves), dim3(64), 0, stream, a->planes, a->n_pad, (unsigned)a->L, rows, cols, d, idx,
-                       n_left, scratch, slot, tbl, f->tbl_state, lg, filt, f->counters);
     TRACS_HIP_CHECK(hipGetLastError());
     unsigned bad = 0;
     TRACS_HIP_CHECK(hipMemcpyAsync(&bad, f->counters, 4, hipMemcpyDeviceToHost, stream));

@@ -7,6 +7,9 @@
 
 namespace tracs {
 
+constexpr unsigned FLT_KT = 64;               // threshold table (filter_lists.hip): counts 2 .. 63 per row
+constexpr unsigned FLT_DCAP = 65536;          // ... rows for d <= this (beyond: the tail is summed per SNP)
+
 // what filter_recomb derives from a pair's SNP count d and the alignment length (:265-271)
 struct FilterWindow {
     double p, thr;

@@ -127,12 +127,14 @@ def run_members(seed, s, fracs):
 
 
 def generate_device(n, L, seed, emit, mu_lineage=1e-5, mu_sample=1e-6, n_lineages=None, p_n=0.01, batch=32,
-                    limit=None, p_partial=0.0, n_every=1, runs=None):
+                    limit=None, p_partial=0.0, n_every=1, runs=None, gaps=None):
     """The same two-level model generated on the GPU in batches of `batch` samples; every batch
     (uint8 [cnt, L] ASCII on the device) is handed to emit(rows, first).  Deterministic in `seed`;
     `limit` stops after the first `limit` samples (same values as a full run).  n_every = k: only every k-th sample carries
     N, at k p_n sites (the same amount of N, concentrated in 1 / k of the samples).  runs = dict(p_n=, mean_len=, frac_lo=,
-    frac_hi=): N in runs of consecutive sites shared by subsets of the samples (coverage_runs).  Setup code, untimed."""
+    frac_hi=): N in runs of consecutive sites shared by subsets of the samples (coverage_runs).  gaps = dict(frac=, mean_len=): every
+    sample is N over `frac` of the sites in runs of geometric length (mean mean_len) whose boundaries are its own -- what `tracs
+    align` writes where a sample's coverage is below its thresholds (tracs/align.py:599-613).  Setup code, untimed."""
     import torch
     dev = torch.device("cuda", torch.cuda.current_device())
     g = torch.Generator(device=dev)
@@ -176,6 +178,17 @@ def generate_device(n, L, seed, emit, mu_lineage=1e-5, mu_sample=1e-6, n_lineage
                 m = torch.rand(L, generator=g, device=dev) < p_partial
                 k = int(m.sum().item())
                 rows[b][m] = plut[torch.randint(0, 10, (k,), generator=g, device=dev)]
+            if gaps:                # per-sample coverage gaps (last: a masked site is N whatever was called there): k runs cover 1 - exp(-k mean_len / L) of the sites
+                k = max(1, int(round(-np.log(1.0 - gaps["frac"]) * L / gaps["mean_len"])))
+                st = torch.randint(0, L, (k,), generator=g, device=dev)
+                u = torch.rand(k, generator=g, device=dev, dtype=torch.float64).clamp_(1e-12, 1.0)
+                ln = (torch.log(u) / np.log1p(-1.0 / gaps["mean_len"])).floor().long() + 1        # geometric, mean mean_len
+                en = torch.minimum(st + ln, torch.tensor(L, device=dev))
+                edge = torch.zeros(L + 1, dtype=torch.int32, device=dev)
+                one = torch.ones(k, dtype=torch.int32, device=dev)
+                edge.index_add_(0, st, one)
+                edge.index_add_(0, en, -one)
+                rows[b][torch.cumsum(edge, 0)[:L] > 0] = ord("N")
         emit(rows, s0)
     torch.cuda.synchronize()
 
