@@ -202,6 +202,9 @@ FULL_SIZE_PATHS = {
     "clean": lambda c, src, ls: src[2] == 0 and src[0] == 0 and c[3] > 4_000_000 and not ls.get("bitmaps", False),   # no N: neither lists nor counting pass for nn
     "gappy": lambda c, src, ls: src[1] is True and src[2] == 0 and c[2] > 2_000_000,              # every site on the matrix cores, in place; minority lists of ~1000 N samples
     "runs": lambda c, src, ls: src[0] > 50_000 and src[1] is False and src[2] > 10_000,           # counted (re-packed) and listed sites side by side
+    # what `tracs align` writes (30 % N per sample in runs of its own, partial codes, two lineages): every site minority by k^2, no N
+    # lists, the N x listed terms from the two one-plane passes (nw_gram), compared sites from the N plane in place
+    "coverage": lambda c, src, ls: c[2] > 4_900_000 and c[0] < 20_000 and src[1] is True and src[2] == 0 and ls["p_entries"] > 100_000_000,
 }
 
 
@@ -221,8 +224,9 @@ def test_config3_full_size_other_workloads(dev, oracle, workload):
     dev.pairsnp_dense(aln, d, nn)
     torch.cuda.synchronize()
     classes, src, ls = aln.site_classes, aln.count_source, aln.list_stats
-    assert classes is not None and aln.kernel == "mfma", (classes, aln.kernel)
+    assert classes is not None and aln.kernel == ("mfma-general" if workload == "coverage" else "mfma"), (classes, aln.kernel)
     assert FULL_SIZE_PATHS[workload](classes, src, ls), (workload, classes, src, ls)
+    assert aln.nw_gram == (workload == "coverage")
     er, ec, ed, enn = oracle.pairsnp_arrays(host, n_threads=max(1, os.cpu_count() or 1))
     sub = torch.from_numpy(idx).cuda()
     dsub, nsub = d[sub][:, sub].cpu().numpy(), nn[sub][:, sub].cpu().numpy()

@@ -69,6 +69,7 @@ def _check(dev, oracle, seqs, expect_classes=True, thresholds=True):
             assert np.array_equal(nn.cpu().numpy()[ri[keep], ci[keep]], enn[keep].astype(np.int32))
             far = dh[ri[~keep], ci[~keep]].astype(np.int64)
             assert ((far > thr) | (far < 0)).all()
+    _check.nw_gram = aln.nw_gram
     aln.close()
     return cls
 

@@ -226,6 +226,8 @@ def load():
     L.tracs_set_stream_policy.argtypes = [C.c_int]
     L.tracs_alignment_hint_rows.restype = C.c_int
     L.tracs_alignment_hint_rows.argtypes = [vp, C.POINTER(sz), C.c_int]
+    L.tracs_debug_alignment_nw_gram.restype = C.c_int
+    L.tracs_debug_alignment_nw_gram.argtypes = [vp]
     L.tracs_debug_alignment_count_source.restype = C.c_int
     L.tracs_debug_alignment_count_source.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.tracs_debug_force_site_classes.restype = None

@@ -56,6 +56,9 @@ struct tracs_alignment {
     // source -- and a one-operand matrix-core pass over the N plane of the other sites (`iplanes`, or the stored N plane in
     // place) completes the compared-sites counts.
     uint4 *vplanes = nullptr, *iplanes = nullptr;
+    uint4 *uplane = nullptr;                  // nw_gram: "is N, or listed with w = 1 at a minority site" (one plane per group, site_classes.hip)
+    bool nw_gram = false;                     // the minority sites' N x listed terms come from two one-plane matrix passes (U U^T - n n^T),
+                                              // their lists hold the listed samples only (no N lists)
     size_t L_var = 0, L_inv = 0, groups_var = 0, groups_inv = 0;
     size_t L_minor = 0, L_full = 0;           // minority sites (listed in `minor`; they are part of L_un or L_full as well);
                                               // sites without any N outside vplanes: +1 to every compared-sites count

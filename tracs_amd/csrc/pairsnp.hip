@@ -849,6 +849,9 @@ int tracs_debug_alignment_site_classes(const tracs_alignment *a, uint64_t *out)
     return a->classes_state;
 }
 
+// 1 when the minority sites' N x listed terms of the last decided classes come from the matrix cores (nw_gram, site_classes.hip)
+int tracs_debug_alignment_nw_gram(const tracs_alignment *a) { return (a && a->classes_state == 1 && a->nw_gram) ? 1 : 0; }
+
 // what completes the compared-sites counts of the last decided classes: out[0] = sites the counting pass reads on the matrix
 // cores, out[1] = 1 when that is the stored N plane in place, out[2] = sites whose N co-occurrences come from lists, out[3] = list
 // entries one pass of that walk visits, out[4], out[5] = entries of the N lists / the listed-sample lists, out[6] = bytes per N entry,
@@ -1042,7 +1045,8 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
             const double all_cells = 0.5 * (double)a->n * (double)a->n;
             const double frac = std::min(1.0, cells / std::max(1.0, all_cells));
             const double t_valu = cells * (double)a->groups * 4.0 * 7.0 / 38e12;
-            const double t_mfma = cells * ((double)pair_L(a) * 10.0 + (a->classes_state == 1 ? (double)a->L_inv * 2.0 : 0.0)) / 5.4e15
+            const double count_sites = a->classes_state != 1 ? 0.0 : (double)(a->count_in_place ? a->L : a->L_inv) + (a->nw_gram ? (double)a->L : 0.0);
+            const double t_mfma = cells * ((double)pair_L(a) * 10.0 + count_sites * 2.0) / 5.4e15
                                   + updates * frac / 3.0e11;                  // measured: 5.4 PFLOP/s, 4 x 10^11 list entries/s
             mfma_general = gen_force == 1 || (gen_force != 0 && t_mfma < t_valu);
         }
@@ -1151,12 +1155,15 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
     //                 sites keep the fp32 partial sums exact, ranges add with integer atomics; range 0 adds |U| - c_i - c_j;
     //   lists         nn_rows_kernel over the sites with few N samples (cN^2 list entries per site);
     //   neither       sites with one N sample or none only add their part of |U| - c_i - c_j.
+    // nw_gram (site_classes.hip): the same pass over the stored N plane also ADDS n n^T to the distances, and a second one over the
+    // U plane subtracts U U^T -- the minority sites' N x listed terms; both run whether or not the caller wants nn.
+    const bool gram = classes && a->nw_gram;
     auto count_pass = [&](const int2 *tl, size_t ntl) -> int {
-        if (!classes || !ncomp || (a->L_un == 0 && a->L_full == 0)) { pair_mark(3, stream); return TRACS_OK; }
+        if (!classes || (!ncomp && !gram) || (a->L_un == 0 && a->L_full == 0 && !gram)) { pair_mark(3, stream); return TRACS_OK; }
         const bool in_place = a->count_in_place;
         const unsigned lu = (unsigned)(in_place ? a->L : a->L_full + a->L_un);
         bool terms_added = false;
-        if (a->L_inv > 0) {
+        if (a->L_inv > 0 || gram) {
             // tl == nullptr: every tile of the region, in the counting pass's own workgroup tile (its own cached schedule);
             // otherwise the given tiles (the live ones of a thresholded run) in the pair kernel's geometry
             CountShape C = count_shape_like(kTI, kTJ);
@@ -1176,7 +1183,7 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
             int g = (gi + k - 1) / k;
             g = (g + gcc - 1) / gcc * gcc;
             k = (gi + g - 1) / g;
-            if (in_place && k > 1 && !nn_zeroed) {
+            if (in_place && k > 1 && !nn_zeroed && ncomp) {
                 // several ranges add onto the cells: zero them first (nothing else has written nn) -- unless the call already has
                 dim3 grid(64, (unsigned)std::min<size_t>(row_end - row_begin, 65535));
                 hipLaunchKernelGGL(init_cells_kernel, grid, dim3(256), 0, stream, (unsigned *)nullptr, ncomp, ld, (unsigned)a->n,
@@ -1192,13 +1199,19 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
                 A.c_n = a->c_counted;
                 A.n = (unsigned)a->n; A.row_end = (unsigned)row_end; A.col_begin = (unsigned)col_begin;
                 A.dist = dist; A.ncomp = ncomp; A.ld = ld; A.thr = 0xFFFFFFFFu; A.ph = TilePhase{0, 0, nullptr};
+                A.count_mode = gram ? 1 : 0;
                 C.fn((unsigned)(ntl * (size_t)k), stream, A);
+                if (gram) {
+                    A.P = a->uplane; A.count_gp = 1; A.count_store = 0; A.c_n = nullptr; A.count_mode = 2;
+                    C.fn((unsigned)(ntl * (size_t)k), stream, A);
+                }
             }
             // (a thresholded run counts its live tiles only: the cells of the others keep whatever the pair kernel left -- ncomp of a
             // pair beyond the threshold is unspecified -- and the list pass below adds to every cell of the region all the same)
             terms_added = true;
         }
         pair_mark(3, stream);
+        if (!ncomp) return TRACS_OK;                           // (gram without nn: the distances' passes were all there was to do)
         if (a->L_nnl > 0) {
             const int rc = nn_rows_add(a, row_begin, row_end, col_begin, ncomp, ld, terms_added ? 0 : 1, lu, stream);
             if (rc) return rc;
@@ -1226,7 +1239,7 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
         int rc = minor_pass();
         if (rc) return rc;
         pair_mark(2, stream);
-        dist_final(stream);
+        if (!gram) dist_final(stream);                         // (gram: the counting passes still add to the distances)
         if ((rc = count_pass(nullptr, 0))) return rc;
         pair_mark(4, stream);
         TRACS_HIP_CHECK(hipGetLastError());
@@ -1266,7 +1279,7 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
         if (mfma_general && (rc = general_sparse_fixup(a, row_begin, row_end, col_begin, dist, ncomp_pair, ld, stream))) return rc;
         if ((rc = minor_pass())) return rc;
         pair_mark(2, stream);
-        dist_final(stream);
+        if (!gram) dist_final(stream);                         // (gram: the counting passes still add to the distances)
         if ((rc = count_pass(live_tiles, n_live))) return rc;
         pair_mark(4, stream);
         TRACS_HIP_CHECK(hipGetLastError());
@@ -1289,7 +1302,7 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
     if (mfma_general && (rc = general_sparse_fixup(a, row_begin, row_end, col_begin, dist, ncomp_pair, ld, stream))) return rc;
     if ((rc = minor_pass())) return rc;
     pair_mark(2, stream);
-    dist_final(stream);
+    if (!gram) dist_final(stream);
     if ((rc = count_pass(nullptr, 0))) return rc;
     pair_mark(4, stream);
     TRACS_HIP_CHECK(hipGetLastError());

@@ -49,6 +49,8 @@ struct MfmaArgs {
     int count_store = 0;       // counting form: store nn instead of adding to the cells (in-place source, one range per tile)
     int keep_bound = 0;        // consensus form, thresholded runs: dead cells keep their lower bound instead of the 0xFFFFFFFF flag
                                // (terms are added to the cells afterwards: minority sites)
+    int count_mode = 0;        // counting form: 0 compared-sites counts only; 1 and dist += sum v_i v_j; 2 dist -= sum v_i v_j, nothing else
+                               // (nw_gram: the two passes of U U^T - n n^T)
 };
 
 struct MfmaShape {
@@ -144,6 +146,7 @@ struct MinorBuild {
     int long_p;                              // some minority site lists more than P_SHORT_MAX samples: its p list is a q line (else: no q lines at all)
     unsigned qw;                             // dwords per q line: 32, or 64 when the lists are long on average (site_lists.hip)
     unsigned long long tot_nnl;              // N samples at the NNL sites: list walks of one pass of nn_rows_add
+    int gram = 0;                            // no N lists at all: the minority sites' N x listed terms come from the matrix cores (site_classes.hip)
 };
 int minority_lists_build(tracs_alignment *a, const MinorBuild &mb, hipStream_t stream, int *ok);
 void minority_lists_free(tracs_alignment *a);

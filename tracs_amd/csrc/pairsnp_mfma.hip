@@ -402,6 +402,10 @@ __global__ __launch_bounds__(NWR * NWC * 64, (NBR * NBC > 4 ? 1 : COUNT ? 4 : 2)
                         // operand plane n = "is N here" (mostly zero words): NN = sum n n', and nn = sites - c_i - c_j + NN
                         // (A.L: the sites this pass stands for, added once per cell by range 0).  The cells hold the dense sites'
                         // counts already (or zeros: in-place source, split range); a single range over the in-place source stores.
+                        // count_mode (nw_gram): the same sums are terms of the distances -- + n n^T, - U U^T (site_classes.hip)
+                        if (A.count_mode == 2) { atomicAdd(&A.dist[(size_t)i * A.ld + j], 0u - (unsigned)V); continue; }
+                        if (A.count_mode == 1) atomicAdd(&A.dist[(size_t)i * A.ld + j], (unsigned)V);
+                        if (!A.ncomp) continue;
                         const unsigned val = (unsigned)V + (ks == 0 ? A.L - (A.c_n ? A.c_n[i] + A.c_n[j] : 0u) : 0u);
                         if (A.count_store) A.ncomp[(size_t)i * A.ld + j] = val;
                         else atomicAdd(&A.ncomp[(size_t)i * A.ld + j], val);

@@ -140,8 +140,10 @@ enum { M_DENSE = 0, M_COUNT, M_MINOR, M_FULL, M_NNL, M_LST, M_UN, M_REFX, M_REFY
 //   M_NNL    sites whose N co-occurrences come from their N lists (cN >= 2, cN x the lines of the list <= nn_list_max: nn_rows_kernel, site_lists.hip)
 //   M_LST    sites that carry lists at all (minority or NNL): list index = rank among these
 //   M_UN     every site outside the dense class with cN >= 1 (M_COUNT, M_NNL and the cN = 1 sites, which have no co-occurrence)
+// gram != 0 (the N x listed terms of the minority sites on the matrix cores, decide() below): a site's cost no longer grows with its
+// N samples -- minority while k^2 <= budget --, no site carries an N list, every N co-occurrence is counted on the matrix cores
 __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__restrict__ P, size_t n_pad, unsigned n, unsigned budget,
-                                                             unsigned nn_list_max, uint4 *__restrict__ masks, size_t groups,
+                                                             unsigned nn_list_max, unsigned gram, uint4 *__restrict__ masks, size_t groups,
                                                              unsigned *__restrict__ cntP, unsigned *__restrict__ cntN,
                                                              unsigned *__restrict__ gP, unsigned *__restrict__ gN, unsigned *__restrict__ gQ,
                                                              unsigned *__restrict__ gR, unsigned *__restrict__ gS, unsigned *__restrict__ gI,
@@ -284,11 +286,11 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
         const unsigned anyw = red[0][3][w] | red[1][3][w] | red[2][3][w] | red[3][3][w];
         const bool some = (anyw >> b) & 1u;
         const unsigned long long k = tot[0][tid], c = some ? tot[1][tid] : 0ull;      // (an empty site: every sample is N)
-        const bool minor = some && k >= 1 && budget > 0 && k * (c + k) <= (unsigned long long)budget;
+        const bool minor = some && k >= 1 && budget > 0 && k * ((gram ? 0ull : c) + k) <= (unsigned long long)budget;
         const bool dense = some && k >= 1 && !minor;
         const bool un = some && !dense && c >= 1;
         // (a walk costs the lines of the list: pairsnp_kernels.h, n8 lines)
-        const bool nnl = un && c >= 2 && (float)c * n8_lines_expected((unsigned)c, n) <= (float)nn_list_max;
+        const bool nnl = !gram && un && c >= 2 && (float)c * n8_lines_expected((unsigned)c, n) <= (float)nn_list_max;
         const bool counted = un && c >= 2 && !nnl;          // (a site with one N sample has no pair of N samples)
         const bool full = some && !dense && c == 0;
         const bool lst = minor || nnl;
@@ -309,8 +311,8 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
         // list entries one pass of the N co-occurrence walk decodes (cN per walk, cN walks) and its walks; N-list walks of the
         // minority fix-up (one per listed sample of a site with an N sample)
         // (gJ: lines a minority site's p list needs beyond its own: 31 dwords a line, the first one of the list its header -- q lines, site_lists.hip)
-        unsigned sv[7] = {minor ? (unsigned)k : 0u, lst ? n8_lines_max((unsigned)c, n) - 1u : 0u, nnl ? (unsigned)min(c * c, 33554431ull) : 0u, nnl ? (unsigned)c : 0u,
-                          (minor && c) ? (unsigned)k : 0u, minor ? n8_lines_max((unsigned)c, n) - 1u : 0u, minor ? (unsigned)(k / 31ull) : 0u};
+        unsigned sv[7] = {minor ? (unsigned)k : 0u, (lst && !gram) ? n8_lines_max((unsigned)c, n) - 1u : 0u, nnl ? (unsigned)min(c * c, 33554431ull) : 0u, nnl ? (unsigned)c : 0u,
+                          (minor && c && !gram) ? (unsigned)k : 0u, (minor && !gram) ? n8_lines_max((unsigned)c, n) - 1u : 0u, minor ? (unsigned)(k / 31ull) : 0u};
 #pragma unroll
         for (int m = 0; m < 7; m++) {
 #pragma unroll
@@ -517,11 +519,42 @@ __global__ __launch_bounds__(256) void plane_popcount_masked_kernel(const uint4 
     if (c) atomicAdd(&out[s], c);
 }
 
+// The U plane of an alignment whose minority sites take their N x listed terms from the matrix cores: per (site, sample) "is N, or --
+// at a minority site -- is listed with an allele mask that lacks the site's reference base" (w = 1).  With n = the N plane and w = that
+// second set (disjoint: a listed sample is not N),  U U^T - n n^T = w n^T + n w^T + w w^T  over the minority sites: what phase B of
+// minor_fixup_kernel walks lists for (site_lists.hip), as two one-plane passes of pairsnp_mfma_kernel<COUNT>.  Layout: one plane per
+// group, like `iplanes`.  thread = (group, sample), lanes over samples.
+__global__ __launch_bounds__(256) void u_plane_kernel(const uint4 *__restrict__ P, size_t n_pad, unsigned n, size_t groups,
+                                                      const uint4 *__restrict__ minor_mask, const uint4 *__restrict__ ref_x,
+                                                      const uint4 *__restrict__ ref_y, uint4 *__restrict__ U)
+{
+    const size_t g = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const unsigned s = blockIdx.y * 64 + (threadIdx.x & 63);
+    if (g >= groups || s >= n) return;
+    typedef unsigned upl_u32x4 __attribute__((ext_vector_type(4)));
+    const uint4 *bp = P + (g * NPLANES) * n_pad + s;
+    const upl_u32x4 A = __builtin_nontemporal_load(reinterpret_cast<const upl_u32x4 *>(bp)), C = __builtin_nontemporal_load(reinterpret_cast<const upl_u32x4 *>(bp + n_pad)),
+                    G = __builtin_nontemporal_load(reinterpret_cast<const upl_u32x4 *>(bp + 2 * n_pad)), T = __builtin_nontemporal_load(reinterpret_cast<const upl_u32x4 *>(bp + 3 * n_pad));
+    const uint4 M = minor_mask[g], RX = ref_x[g], RY = ref_y[g];
+    const unsigned a[4] = {A.x, A.y, A.z, A.w}, c[4] = {C.x, C.y, C.z, C.w}, gg[4] = {G.x, G.y, G.z, G.w}, t[4] = {T.x, T.y, T.z, T.w};
+    const unsigned m[4] = {M.x, M.y, M.z, M.w}, rx[4] = {RX.x, RX.y, RX.z, RX.w}, ry[4] = {RY.x, RY.y, RY.z, RY.w};
+    unsigned u[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const unsigned isn = a[w] & c[w] & gg[w] & t[w];
+        const unsigned ra = ~rx[w] & ~ry[w], rc = rx[w] & ~ry[w], rg = ~rx[w] & ry[w], rt = rx[w] & ry[w];
+        const unsigned has_ref = (a[w] & ra) | (c[w] & rc) | (gg[w] & rg) | (t[w] & rt);
+        u[w] = isn | ((a[w] | c[w] | gg[w] | t[w]) & ~has_ref & m[w]);
+    }
+    U[g * n_pad + s] = make_uint4(u[0], u[1], u[2], u[3]);
+}
+
 void site_classes_free(tracs_alignment *a)
 {
     minority_lists_free(a);
     a->c_counted = nullptr;
-    a->vplanes = a->iplanes = nullptr;
+    a->vplanes = a->iplanes = a->uplane = nullptr;
+    a->nw_gram = false;
     pack_release(a);                                       // vplanes, iplanes, N counts, minority lists: one arena
     a->L_var = a->L_inv = a->groups_var = a->groups_inv = 0;
     a->L_minor = a->L_full = a->L_un = a->L_nnl = 0;
@@ -580,9 +613,23 @@ void pack_stage_end()
 // Decides (once per pack) the encoding and whether the pair kernels run on site classes, and builds the re-packed alignments
 // and lists if so.  *partial: some sample carries a partial IUPAC code (the alignment has no consensus form).  Soft-fails
 // (classes_state = -1) when memory is short.
-static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStream_t stream, int *partial)
+// gram: the second form of the classes, tried when the first is refused (or TRACS_NW_GRAM=1) -- the minority sites' N x listed terms
+// on the matrix cores.  With many N samples per site (tracs align masks every position below its coverage thresholds: tens of per
+// cent of every sample, tracs/align.py:599-613) a listed sample's walk of the site's N list costs cN entries, k (cN + k) leaves
+// the list budget and every site would go through the pair kernel; the terms the N lists are walked for are
+//     sum_s w_a(s) n_b(s) + n_a(s) w_b(s)  =  (U U^T - n n^T - w w^T)(a, b),   U = n | w  (u_plane_kernel above),
+// two one-plane matrix passes over all sites whatever cN is (n n^T is the compared-sites count's own pass, in place), and w w^T
+// joins the both-listed term of the p-list walk.  A minority site then costs k^2 list entries, and no site carries an N list.
+// Tried when the list form costs more matrix work than this one can (two planes of every site), taken when it then costs less
+// (`beat`: the list form's cost); refused -> the list form again (its masks were overwritten: classified once more, `no_gram`).
+// TRACS_NW_GRAM=1 always, 0 never.
+static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStream_t stream, int *partial, bool gram = false, double beat = 1.0,
+                  bool no_gram = false)
 {
     a->classes_state = -1;
+    const int env_gram = [] { const char *e = std::getenv("TRACS_NW_GRAM"); return e ? std::atoi(e) : -1; }();    // (read per pack: tests switch it)
+    if (env_gram == 1 && allow_minor) gram = true;
+    const bool gram_next = !gram && !no_gram && env_gram != 0 && allow_minor && allow_nnl;
     static const int env_force = [] { const char *e = std::getenv("TRACS_SITE_CLASSES"); return e ? std::atoi(e) : -1; }();
     const int force = g_force_classes >= -1 ? g_force_classes : env_force;
     static const bool no_minor = [] { const char *e = std::getenv("TRACS_MINORITY"); return e && std::atoi(e) == 0; }();
@@ -625,7 +672,7 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     const unsigned nn_list_max = (no_nnl || !allow_nnl) ? 0u : (unsigned)std::min(4.0e9, nnl_k * (double)a->n * (double)a->n);
     TRACS_HIP_CHECK(hipMemsetAsync(totals, 0, 128, stream));
     hipLaunchKernelGGL(classify_sites_kernel, dim3((unsigned)groups), dim3(256), 0, stream, a->planes, a->n_pad, (unsigned)a->n, budget,
-                       nn_list_max, masks, groups, cntP, cntN, gcnt, gcnt + groups, gcnt + 2 * groups, gcnt + 3 * groups, gcnt + 4 * groups, gcnt + 5 * groups, gcnt + 6 * groups, flags, flag_words, d_flag);
+                       nn_list_max, gram ? 1u : 0u, masks, groups, cntP, cntN, gcnt, gcnt + groups, gcnt + 2 * groups, gcnt + 3 * groups, gcnt + 4 * groups, gcnt + 5 * groups, gcnt + 6 * groups, flags, flag_words, d_flag);
     const double plane_b = (double)groups * (double)a->n_pad * sizeof(uint4);      // one bit plane of the alignment
     stage_mark("classify", stream, 4.0 * plane_b, (double)groups * (M_SLOTS * 16.0 + 3.0 * SITES_PER_GROUP * 4.0 + flag_words * 8.0));
     hipLaunchKernelGGL(group_offsets_kernel, dim3(14), dim3(1024), 0, stream, masks, gcnt, groups, offs, off64, totals);
@@ -655,7 +702,8 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     static const int force_in_place = [] { const char *e = std::getenv("TRACS_COUNT_IN_PLACE"); return e ? std::atoi(e) : -1; }();
     const double t_extra = 1.5e-13 * (double)(a->L - L_count) * (double)a->n * (double)a->n;
     const double t_repack = 4.0e-10 * (double)L_count * (double)a->n_pad;
-    const bool in_place = L_count > 0 && (force_in_place >= 0 ? force_in_place == 1 : t_extra < t_repack);
+    // (gram: n n^T over every site is part of the distances: always the stored N plane in place)
+    const bool in_place = gram || (L_count > 0 && (force_in_place >= 0 ? force_in_place == 1 : t_extra < t_repack));
     if (in_place && L_nnl) {
         // the same classes with the NNL sites counted: lists = the minority sites (their masks, ranks and overflow bounds exist)
         L_count += L_nnl; L_lst = L_minor; L_nnl = 0;
@@ -664,7 +712,13 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     }
     // matrix instructions per pair: planes_full per site now; planes_full per dense site + one per counted site with classes
     const double planes_full = consensus ? 4.0 : 5.0;
-    const double cost = (planes_full * (double)L_dense + (double)(in_place ? a->L : L_count)) / (planes_full * (double)a->L);
+    const double cost = (planes_full * (double)L_dense + (double)(in_place ? a->L : L_count) + (gram ? (double)a->L : 0.0)) / (planes_full * (double)a->L);
+    if (gram && env_gram != 1 && force != 1 && cost >= std::min(0.92, beat - 0.02)) return TRACS_OK;      // (the caller goes on with the list form)
+    if (gram_next && force != 0 && cost > 2.0 / planes_full + 0.05) {
+        const int rc2 = decide(a, allow_minor, allow_nnl, stream, partial, true, cost);
+        if (rc2 || a->classes_state == 1) return rc2;
+        return decide(a, allow_minor, allow_nnl, stream, partial, false, 1.0, true);
+    }
     if (force != 1 && cost >= 0.92) return TRACS_OK;
     // the lists must stay small beside the planes (<= one entry per 8 sites of the whole alignment; TRACS_LIST_CAP: diagnostics):
     // otherwise first without the N co-occurrence lists (those sites are counted on the matrix cores), then without any list
@@ -677,8 +731,10 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
         const double bytes = ((double)L_lst + (double)tot_o) * 128.0 + 16.0 * (double)tot_p + (long_p ? ((double)L_lst + (double)tot_q) * 4.0 * (double)qw : 0.0) +
                              (L_nnl ? (double)a->n * (double)((groups + 7) / 8 * 8) * sizeof(uint4) : 0.0);
         if (L_lst >= (1ull << 26) || a->n >= (1ull << 27) || bytes > (env_cap >= 0.0 ? std::min(env_cap, cap) : cap) ||
-            L_lst + tot_o >= (1ull << 32) || L_lst + tot_q >= (1ull << 32))                  // (line indices are 32 bits)
+            L_lst + tot_o >= (1ull << 32) || L_lst + tot_q >= (1ull << 32)) {                // (line indices are 32 bits)
+            if (gram) return TRACS_OK;                                                       // (refused: the caller goes on with the list form)
             return L_nnl ? decide(a, allow_minor, false, stream, partial) : decide(a, false, false, stream, partial);
+        }
     }
 
     auto soft_fail = [&]() { (void)hipGetLastError(); site_classes_free(a); a->classes_state = -1; return TRACS_OK; };
@@ -734,14 +790,27 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
         mb.sites = L_lst; mb.tot_p = tot_p; mb.tot_o = tot_o; mb.tot_nnl = tot_nnl; mb.baseQ = off64 + 6 * groups; mb.tot_q = tot_q; mb.long_p = long_p ? 1 : 0;
         mb.max_gp = tot[14];
         mb.qw = qw;
+        mb.gram = gram ? 1 : 0;
         mb.n_rows = a->n_row_hint;
         for (int k = 0; k < 4; k++) mb.rows[k] = (unsigned)std::min<size_t>(a->row_hint[k], a->n);
         rc = minority_lists_build(a, mb, stream, &built);
         if (rc) { site_classes_free(a); a->classes_state = -1; return rc; }
         if (!built) {                                          // no memory: the same classes with fewer lists
             soft_fail();
+            if (gram) return TRACS_OK;
             return L_nnl ? decide(a, allow_minor, false, stream, partial) : decide(a, false, false, stream, partial);
         }
+    }
+    const bool gram_on = gram && L_minor > 0 && a->lists != nullptr;
+    if (gram_on) {
+        const size_t ubytes = class_plane_bytes(a, groups, 1, PAD_GROUPS);
+        if (pack_alloc(a, ubytes, reinterpret_cast<void **>(&a->uplane)) != hipSuccess) return soft_fail();
+        // (the pad groups and the slack behind them: zero)
+        ok = ok && hipMemsetAsync(a->uplane + groups * a->n_pad, 0, ubytes - groups * a->n_pad * sizeof(uint4), stream) == hipSuccess;
+        if (a->n_pad > a->n) ok = ok && hipMemsetAsync(a->uplane, 0, groups * a->n_pad * sizeof(uint4), stream) == hipSuccess;
+        hipLaunchKernelGGL(u_plane_kernel, dim3((unsigned)((groups + 3) / 4), sblocks), dim3(256), 0, stream, a->planes, a->n_pad, (unsigned)a->n,
+                           groups, mask_of(M_MINOR), mask_of(M_REFX), mask_of(M_REFY), a->uplane);
+        stage_mark("U plane (N | listed, w = 1)", stream, 4.0 * plane_b, plane_b);
     }
     ok = ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(stream) == hipSuccess;
     if (!ok) { site_classes_free(a); a->classes_state = -1; set_error("site_classes_decide: re-pack failed"); return TRACS_E_HIP; }
@@ -749,6 +818,7 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     a->L_minor = L_minor; a->L_full = L_full; a->L_un = L_un; a->L_nnl = L_nnl;
     a->nn_visits = tot[9]; a->list_entries_n = (L_lst ? (unsigned long long)L_lst + tot_o : 0ull); a->list_entries_p = tot_p; a->nn_walks = tot_nnl; a->fix_walks = tot[11];
     a->count_in_place = in_place;
+    a->nw_gram = gram_on;
     a->classes_cons = consensus;
     a->classes_state = 1;
     return TRACS_OK;

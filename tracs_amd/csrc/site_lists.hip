@@ -172,7 +172,8 @@ __global__ __launch_bounds__(SITE_THREADS) TRACS_SITE_ATTR void site_lists_kerne
     static_assert(SITE_THREADS == SITES_PER_GROUP, "thread = site");
     const int tw = tid >> 5, tb = tid & 31;
     const bool mine = (m[tw] >> tb) & 1u;
-    const unsigned my_cn = mine ? mb.cntN[g * SITES_PER_GROUP + tid] : 0u;
+    const bool want_n = mb.gram == 0;                        // (gram: the sites carry p lists only -- the N plane is not even read)
+    const unsigned my_cn = (mine && want_n) ? mb.cntN[g * SITES_PER_GROUP + tid] : 0u;
     {
         const unsigned c = my_cn;
         kp[tid] = (mine && ((mp[tw] >> tb) & 1u)) ? mb.cntP[g * SITES_PER_GROUP + tid] : 0u;
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(SITE_THREADS) TRACS_SITE_ATTR void site_lists_kerne
         unsigned long long fl_next = 0ull;
         {
             const unsigned s = piece + sl * 64u + lane;
-            if (s < n) { N_next = base[4 * n_pad + s]; if (from_planes) fl_next = mb.flags[g * mb.flag_words + (s >> 6)]; }
+            if (s < n) { if (want_n) N_next = base[4 * n_pad + s]; if (from_planes) fl_next = mb.flags[g * mb.flag_words + (s >> 6)]; }
         }
         for (; sl < PIECE_SAMPLES / 64u; sl += SITE_THREADS / 64u) {
             const unsigned s = piece + sl * 64u + lane;
@@ -234,9 +235,10 @@ __global__ __launch_bounds__(SITE_THREADS) TRACS_SITE_ATTR void site_lists_kerne
             {
                 const unsigned sn = s + SITE_THREADS;
                 N_next = zero4; fl_next = 0ull;
-                if (sl + SITE_THREADS / 64u < PIECE_SAMPLES / 64u && sn < n) { N_next = base[4 * n_pad + sn]; if (from_planes) fl_next = mb.flags[g * mb.flag_words + (sn >> 6)]; }
+                if (sl + SITE_THREADS / 64u < PIECE_SAMPLES / 64u && sn < n) { if (want_n) N_next = base[4 * n_pad + sn]; if (from_planes) fl_next = mb.flags[g * mb.flag_words + (sn >> 6)]; }
             }
-            if (piece + sl * 64u < n) {                        // (wave-uniform: a slab beyond the last sample leaves its words zero below)
+            if (!want_n) {
+            } else if (piece + sl * 64u < n) {                 // (wave-uniform: a slab beyond the last sample leaves its words zero below)
                 const unsigned col = sl * 2u + (lane >> 5), r = lane & 31u;
                 bm[(0u + r) * BM_STRIDE + col] = transpose(N.x & m[0]);
                 bm[(32u + r) * BM_STRIDE + col] = transpose(N.y & m[1]);
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(SITE_THREADS) TRACS_SITE_ATTR void site_lists_kerne
         __syncthreads();
     }
     if (mine) {
-        enc.finish();
+        if (want_n) enc.finish();
         if (from_planes && kp[tid] > P_SHORT_MAX) { qd[(size_t)rk[tid] * mb.qw] = kp[tid] | (curP[tid] << 16); qd[(size_t)rk[tid] * mb.qw + mb.qw - 1u] = qb[tid]; }
     }
 }
@@ -888,7 +890,10 @@ __global__ __launch_bounds__(TRACS_NN_THREADS) void nn_rows_kernel(const uint4 *
 //     phase B  every listed entry of x with w = 1 walks its site's N list: -1 for EVERY N sample y there -- the third sum for y > x
 //              (row x of dist), the fourth for y < x (cell (y, x): a scratch row, folded in by transpose_add_kernel).
 // Negative terms wrap in the unsigned row and cancel in the final sum.
-template <bool CLAMP, unsigned QW>
+// GRAM (site_classes.hip, nw_gram): the third and fourth sums come from the matrix cores as (U U^T - n n^T)(x, j) = w n^T + n w^T + w w^T
+// over the minority sites -- phase B does not exist, and the both-listed term of phase A gives w_x w_j back: [masks disjoint] - w_x - w_j
+// + w_x w_j = [masks disjoint] - 1 for the walker's w_x = 1.
+template <bool CLAMP, unsigned QW, bool GRAM>
 __global__ __launch_bounds__(1024) void minor_fixup_kernel(const unsigned long long *__restrict__ s_off, const unsigned *__restrict__ s_ent,
                                                            const unsigned long long *__restrict__ p_off, const unsigned *__restrict__ p_ent,
                                                            const unsigned *__restrict__ qd,
@@ -965,7 +970,7 @@ __global__ __launch_bounds__(1024) void minor_fixup_kernel(const unsigned long l
                 // cell (x, j) for j > x; cell (j, x) for a j < x that does not walk itself (w_j = 0)
                 const bool in = has && dw >= first && dw < PER && dw - first < limit &&
                                 ((j >= up0 && j < up1) || (wj == 0u && j >= lw0 && j < lw1));
-                const int add = (((v[t] & 15u) & mx) == 0u ? 1 : 0) - 1 - (int)wj;      // both listed: [masks disjoint] - w_x - w_j
+                const int add = (((v[t] & 15u) & mx) == 0u ? 1 : 0) - 1 - (GRAM ? 0 : (int)wj);      // both listed: [masks disjoint] - w_x - w_j (+ w_x w_j: GRAM)
                 if (in && add != 0) atomicAdd(&row[j - c0], (unsigned)add);
             }
             const unsigned cap = PER - first;
@@ -987,7 +992,7 @@ __global__ __launch_bounds__(1024) void minor_fixup_kernel(const unsigned long l
                 for (unsigned m = 0; m < P_SHORT_MAX; m++) {
                     const unsigned j = v[m] >> ENT_SHIFT;
                     const unsigned wj = (v[m] >> 4) & 1u;
-                    const int add = (((v[m] & 15u) & mx) == 0u ? 1 : 0) - 1 - (int)wj;
+                    const int add = (((v[m] & 15u) & mx) == 0u ? 1 : 0) - 1 - (GRAM ? 0 : (int)wj);
                     if (v[m] != 0xFFFFFFFFu && add != 0 && ((j >= up0 && j < up1) || (wj == 0u && j >= lw0 && j < lw1))) atomicAdd(&row[j - c0], (unsigned)add);
                 }
             }
@@ -998,7 +1003,7 @@ __global__ __launch_bounds__(1024) void minor_fixup_kernel(const unsigned long l
         wave_sync();
     }
     // phase B: N-list walks, both triangles: column y goes to row[y - c0]
-    {
+    if constexpr (!GRAM) {
         Walk<CLAMP> W;
         W.init(lines, row + chunk + 64 + wave * (WALK_LDS_PER_WAVE / 4), lane);
         W.neg4lo = 0u - 4u * c0; W.dump4 = 4u * (span + lane); W.val = 0xFFFFFFFFu; W.cut = 0u;
@@ -1067,7 +1072,7 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb_, hipStream_t 
     g->sites = L; g->groups = groups; g->tot_p = mb.tot_p; g->tot_nnl = mb.tot_nnl;
     g->n_rows = mb.n_rows;
     for (int k = 0; k < 4; k++) g->rows[k] = mb.rows[k];
-    g->n_lines = (unsigned long long)L + mb.tot_o;
+    g->n_lines = mb.gram ? 0ull : (unsigned long long)L + mb.tot_o;      // (gram: no site carries an N list)
     g->tgroups = (groups + 7) / 8 * 8;
     SL_TRY(pack_alloc(a, (g->n_lines + 1) * 128, reinterpret_cast<void **>(&g->lines)));
     SL_TRY(pack_alloc(a, (L + 1) * 8, reinterpret_cast<void **>(&g->p_off)));
@@ -1201,10 +1206,11 @@ int minority_fixup(tracs_alignment *a, size_t row_begin, size_t row_end, size_t 
     static bool attr_set[64] = {false};
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
         const int fix_lds = (int)ROW_CHUNK_MAX * 4 + 256 + 16 * (int)WALK_LDS_PER_WAVE;
-        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(minor_fixup_kernel<true, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, fix_lds));
-        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(minor_fixup_kernel<false, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, fix_lds));
-        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(minor_fixup_kernel<true, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, fix_lds));
-        TRACS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(minor_fixup_kernel<false, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, fix_lds));
+        const void *fns[8] = {reinterpret_cast<const void *>(minor_fixup_kernel<true, 32, false>), reinterpret_cast<const void *>(minor_fixup_kernel<false, 32, false>),
+                              reinterpret_cast<const void *>(minor_fixup_kernel<true, 64, false>), reinterpret_cast<const void *>(minor_fixup_kernel<false, 64, false>),
+                              reinterpret_cast<const void *>(minor_fixup_kernel<true, 32, true>), reinterpret_cast<const void *>(minor_fixup_kernel<false, 32, true>),
+                              reinterpret_cast<const void *>(minor_fixup_kernel<true, 64, true>), reinterpret_cast<const void *>(minor_fixup_kernel<false, 64, true>)};
+        for (const void *fn : fns) TRACS_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, fix_lds));
         attr_set[dev] = true;
     }
     // scratch rows for the cells (y, x) with y < x that row x's walks feed: (n - row_begin) rows of (row_end - row_begin) columns
@@ -1213,10 +1219,17 @@ int minority_fixup(tracs_alignment *a, size_t row_begin, size_t row_end, size_t 
     const int rc = workspace_get(46, (n - row_begin) * s_pitch * sizeof(unsigned), reinterpret_cast<void **>(&S));
     if (rc) return rc;
     const dim3 grid((unsigned)(n - row_begin), (unsigned)((n + chunk - 1) / chunk));
-#define TRACS_FIXUP_LAUNCH(CL, QWV) hipLaunchKernelGGL((minor_fixup_kernel<CL, QWV>), grid, dim3(1024), lds, stream, g->s_off, g->s_ent, g->p_off, g->p_ent, \
+#define TRACS_FIXUP_LAUNCH(CL, QWV) hipLaunchKernelGGL((minor_fixup_kernel<CL, QWV, GR>), grid, dim3(1024), lds, stream, g->s_off, g->s_ent, g->p_off, g->p_ent, \
         reinterpret_cast<const unsigned *>(g->qlines), g->lines, g->c_p, (unsigned)n, (unsigned)row_begin, (unsigned)row_end, (unsigned)col_begin, chunk, dist, ld, S, s_pitch)
-    if (grid.y == 1) { if (g->qw == 64u) TRACS_FIXUP_LAUNCH(false, 64); else TRACS_FIXUP_LAUNCH(false, 32); }
-    else { if (g->qw == 64u) TRACS_FIXUP_LAUNCH(true, 64); else TRACS_FIXUP_LAUNCH(true, 32); }
+    if (a->nw_gram) {
+        constexpr bool GR = true;
+        if (grid.y == 1) { if (g->qw == 64u) TRACS_FIXUP_LAUNCH(false, 64); else TRACS_FIXUP_LAUNCH(false, 32); }
+        else { if (g->qw == 64u) TRACS_FIXUP_LAUNCH(true, 64); else TRACS_FIXUP_LAUNCH(true, 32); }
+    } else {
+        constexpr bool GR = false;
+        if (grid.y == 1) { if (g->qw == 64u) TRACS_FIXUP_LAUNCH(false, 64); else TRACS_FIXUP_LAUNCH(false, 32); }
+        else { if (g->qw == 64u) TRACS_FIXUP_LAUNCH(true, 64); else TRACS_FIXUP_LAUNCH(true, 32); }
+    }
 #undef TRACS_FIXUP_LAUNCH
     const dim3 tgrid((unsigned)((n - row_begin + 31) / 32), (unsigned)((row_end - row_begin + 31) / 32));
     hipLaunchKernelGGL(transpose_add_kernel, tgrid, dim3(256), 0, stream, S, s_pitch, (unsigned)n, (unsigned)row_begin, (unsigned)row_end,

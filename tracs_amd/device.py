@@ -112,6 +112,12 @@ class Alignment:
         return tuple(int(x) for x in out) if state == 1 else None
 
     @property
+    def nw_gram(self):
+        """True when the minority sites' N x listed terms of the last decided classes come from two one-plane passes on the matrix cores
+        (U U^T - n n^T, csrc/site_classes.hip) instead of walks of the sites' N lists."""
+        return bool(self._L.tracs_debug_alignment_nw_gram(self._h))
+
+    @property
     def count_source(self):
         """(sites the counting pass reads on the matrix cores, in_place, sites whose N co-occurrences come from lists) for an
         alignment on site classes: in_place = the stored N plane of every site, read where it lies (the pair kernels then write d
