@@ -96,8 +96,11 @@ def parse():
 
 
 def in_launcher():
-    """True when a launcher (torch.distributed.run) started this process as one rank of a job."""
-    return "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    """True when a launcher (torch.distributed.run: ours -- launch_ranks marks its children -- or the driver's) started this process as
+    one rank of a job: RANK / WORLD_SIZE alone (a SLURM step's ambient variables) do not count, the launcher's rendezvous does."""
+    if os.environ.get("TRACS_BENCH_WORKER") == "1":
+        return True
+    return all(k in os.environ for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"))
 
 
 def launch_ranks(args):
@@ -111,7 +114,7 @@ def launch_ranks(args):
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), TRACS_BENCH_WORKER="1")
     return subprocess.run(cmd, env=env).returncode
 
 
@@ -350,6 +353,9 @@ def main():
         # NO fallback: a communicator that cannot be made or fails its self-test ends this rank non-zero (the launcher ends the rest).
         from tracs_amd import rccl
         backend = rccl.backend_choice(world, ndev, "TRACS_BENCH_BACKEND")
+        if world > ndev and os.environ.get("TRACS_BENCH_BACKEND") != "gloo":
+            # more ranks than GPUs only ever makes sense for the gloo smoke tests: never a line that says n_gpus = world by accident
+            raise SystemExit("--gpus %d but %d GPU(s) visible (TRACS_BENCH_BACKEND=gloo lets ranks share a GPU: tests)" % (world, ndev))
         if backend == "rccl":
             try:
                 cand = rccl.RcclDist(device)
@@ -614,9 +620,11 @@ def main():
                           "mean_d": checksum / float(pairs_total), "distinct_keys": keys[0],
                           "clock_rate": args.lamb, "trans_rate": args.beta, "precision": args.precision,
                           "transcluster_ms_per_step": sum(tc_ms) / len(tc_ms),
-                          "partition": "row panels, fold pairing, %d rank(s); RCCL all-gather of the d / nn panels%s; P and E(K) derived on every "
-                                       "rank from the gathered d, key evaluations split over the ranks (key-table all-reduce)"
-                                       % (world, "" if cp is None else " (%d bytes per cell: 16 bits where the values fit)" % cp.bytes_per_cell()),
+                          "partition": ("one rank: no exchange" if world == 1 else
+                                        "row panels, fold pairing, %d ranks; RCCL all-gather of the d / nn panels (%d bytes per cell: 16 bits where the "
+                                        "values fit); P and E(K) derived on every rank from the gathered d, key evaluations split over the ranks "
+                                        "(key-table all-reduce)" % (world, cp.bytes_per_cell())),
+                          "result_placement": "whole matrices on every rank",
                           "workload_name": args.workload, "exchange": exchange,
                           "streams": ("2: transcluster on a second stream beside the rest of the dense call, from the moment the distances "
                                       "are final (tracs_pairsnp_notify_distances)") if overlap else "1",
@@ -802,6 +810,7 @@ def site_sharded(args, n, L, seed, world, rank, device, dist, exchange, comm_inf
                                                          "workload '%s'" % args.workload, pairs_total),
                           "samples": n, "sites": L, "pairs": pairs_total, "workload_name": args.workload, "exchange": exchange,
                           "communicator": comm_info, "ranks_seen": comm_info["ranks_seen"],
+                          "result_placement": "distributed rows: rank q ends with d, nn, P and E(K) of the rows it owns (no all-gather)",
                           "partition": "SITE shards: rank r holds groups [%d r / %d, ..) of the packed planes (%d of %d sites on rank 0) and counts all "
                                        "pairs over them; d and nn summed by the compact exchange -- upper-triangle cells, %d + %d bytes per cell "
                                        "(d; nn as its deficit below the slice's length), all-to-all, summed by the receiver --: rank q owns the rows "

@@ -308,6 +308,12 @@ int tracs_pileup_counts(const char *path, const char *const *contig_names, const
  * reference appends (tracs/align.py:580-596).  gzip_level 0..9.                                                   */
 int tracs_write_posterior_csv(const char *path, const double *post, size_t L, size_t K, int gzip_level);
 
+/* Starts, on a thread of its own, what a process's first call otherwise waits for: the HIP runtime, the device context and this
+ * library's code object.  Returns at once; later calls wait where they need the device.  `tracs distance` calls it before it reads
+ * its metadata (tracs/distance.py:161-166) -- a 10 x 100 kb alignment spends more time starting up than computing.  No-op unless
+ * exactly one device is visible. */
+void tracs_warm_up(void);
+
 /* `tracs distance` for one alignment (tracs/distance.py:159-258) with the results on the device until the CSV rows.
  *   tracs_distance_open   read + pack the FASTA file(s) (1 file: all pairs; 2: file 0 x file 1, src/pairsnp.hpp:348-360); the names
  *                         (tracs_distance_nseq / _name) are what the caller looks the sampling dates up by

@@ -31,11 +31,21 @@ def test_gpus_1_is_one_process():
     assert out.returncode == 0 and json.loads(out.stdout.strip().splitlines()[-1])["n_gpus"] == 1
 
 
+LAUNCHER = {"LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"}     # what torch.distributed.run exports beside RANK / WORLD_SIZE
+
+
 def test_world_size_must_equal_gpus():
-    out = _run(["--gpus", "8", "--launch-check"], {"RANK": "0", "WORLD_SIZE": "1"})
+    out = _run(["--gpus", "8", "--launch-check"], dict(LAUNCHER, RANK="0", WORLD_SIZE="1"))
     assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr
-    out = _run(["--gpus", "2", "--launch-check"], {"RANK": "0", "WORLD_SIZE": "3"})
+    out = _run(["--gpus", "2", "--launch-check"], dict(LAUNCHER, RANK="0", WORLD_SIZE="3"))
     assert out.returncode != 0 and "WORLD_SIZE=3" in out.stderr
+
+
+def test_ambient_rank_variables_are_not_a_launcher():
+    """RANK / WORLD_SIZE without a launcher's rendezvous (a SLURM step, somebody else's environment) do not make this process a rank"""
+    out = _run(["--gpus", "1", "--launch-check"], {"RANK": "2", "WORLD_SIZE": "4"})
+    assert out.returncode == 0, out.stderr
+    assert json.loads(out.stdout.strip().splitlines()[-1])["n_gpus"] == 1
 
 
 def test_a_failing_rank_fails_the_command():

@@ -427,8 +427,15 @@ def test_bench_line_contract_small():
     assert sp["warm_ms"] >= j["ms_per_step"] * 0.8 and abs(sp["value_single_pass"] - 700 * 699 / 2 / (sp["warm_ms"] / 1e3)) < 1e-6 * sp["value_single_pass"]
     # the other workloads: classes on / off agree (bench.py exits non-zero otherwise), the worst one is beside `value`
     sw = j["sensitivity"]["workloads"]
-    assert set(sw) == {"lineage", "divergent", "clean", "gappy", "runs", "partial"}
+    assert set(sw) == {"lineage", "divergent", "clean", "gappy", "runs", "partial", "coverage"}
+    # every leg on the headline's unit (ONE CALL per step: ms_per_call), the steady-state pass beside it; worst / spread from the per-call figures
+    assert all(w["ms_per_call"] > 0 and w["ms_per_pass_steady_state"] > 0 and abs(w["pairs_per_s"] - 700 * 699 / 2 / (w["ms_per_call"] / 1e3)) < 1e-6 * w["pairs_per_s"]
+               for w in sw.values())
     assert j["value_worst_workload"] <= j["value"] and j["value_worst_workload"] == min([j["value"]] + [w["pairs_per_s"] for w in sw.values()])
+    # `tracs distance --filter` over every emitted pair of the timed alignment: the list route, checked against the oracle
+    f = j["filter"]
+    assert f["pairs"] == 700 * 699 // 2 and f["route"] == "departure lists" and f["oracle_check"]["equal"] is True and f["warm_call_s"] > 0
+    assert f["scan_route"]["all_pairs_s"] > 0 and f["index"]["lists"] is True
     assert all(o["kernel_ms"] >= 0 for o in r["other_kernels"]) and r["minority_lists_ms"] >= 0 and len(r["kernels_ms"]) == 4
     g = j["roofline_general"]
     assert g["bound"] in ("mfma", "hbm") and g["mean_d"] > j["config"]["mean_d"] and g["roofline_per_pack"]["per_pack_ms"] > 0

@@ -35,6 +35,7 @@ SYMBOLS = [
     "tracs_bcast_planes", "tracs_allgather_panels", "tracs_allreduce", "tracs_reduce_scatter", "tracs_send", "tracs_recv",
     "tracs_alltoall", "tracs_tri_pack", "tracs_tri_sum", "tracs_rccl_version",
     "tracs_coo_fill_f64", "tracs_distance_open", "tracs_distance_nseq", "tracs_distance_name", "tracs_distance_run", "tracs_distance_free",
+    "tracs_warm_up",
 ]
 
 
@@ -139,6 +140,8 @@ def load():
     L.tracs_distance_name.argtypes = [vp, sz]
     L.tracs_distance_run.restype = C.c_int
     L.tracs_distance_run.argtypes = [vp, C.c_int, C.POINTER(C.c_int32), dbl, dbl, dbl, dbl, C.c_char_p, C.c_char_p, u64p, u64p]
+    L.tracs_warm_up.restype = None
+    L.tracs_warm_up.argtypes = []
     L.tracs_distance_free.restype = None
     L.tracs_distance_free.argtypes = [vp]
     L.tracs_edges_count_f64.restype = C.c_int

@@ -170,6 +170,26 @@ int tracs_debug_read_fasta(const char *path, size_t *n, size_t *L, uint64_t *has
     return TRACS_OK;
 }
 
+// The start-up of a process's first call, off the caller's thread: the HIP runtime, the device context and this library's code
+// object (loaded on its first kernel launch: tens of milliseconds for ~2 MB of kernels).  `tracs distance` calls it before it reads
+// its metadata and the FASTA, so a small alignment does not wait for them in tracs_distance_open.  Only with ONE visible device:
+// a fresh thread's current device is 0, which is not necessarily the caller's.
+__global__ void warm_up_kernel(unsigned *p) { if (p) *p = 0u; }
+static void warm_up_body()
+{
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess || nd != 1) { (void)hipGetLastError(); return; }
+    (void)hipFree(nullptr);
+    hipLaunchKernelGGL(warm_up_kernel, dim3(1), dim3(1), 0, nullptr, (unsigned *)nullptr);
+    (void)hipDeviceSynchronize();
+    (void)hipGetLastError();
+}
+extern "C" void tracs_warm_up(void)
+{
+    static std::once_flag once;
+    std::call_once(once, [] { std::thread(warm_up_body).detach(); });
+}
+
 int tracs_alignment_from_fasta(const char *const *fasta, int n_fasta, tracs_alignment **out, char **names_out,
                                size_t *names_bytes, size_t *n_first_file)
 {
@@ -180,7 +200,9 @@ int tracs_alignment_from_fasta(const char *const *fasta, int n_fasta, tracs_alig
     size_t n0 = 0;
     StageClock clock;
     // the HIP runtime comes up (first call of the process: ~0.3-0.5 s) while the host threads read the text
-    std::thread warm([]() { int nd = 0; (void)hipGetDeviceCount(&nd); if (nd > 0) (void)hipFree(nullptr); });
+    // (a context only where there is one device to have it on: with several visible, a fresh thread's current device is 0, not
+    // necessarily the caller's -- a rank of a multi-GPU job would leave a primary context on GPU 0 --; the runtime itself still comes up)
+    std::thread warm(warm_up_body);
     struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } join_warm{warm};
     for (int f = 0; f < n_fasta; f++) {
         std::string err;

@@ -86,6 +86,7 @@ struct tracs_alignment {
     std::vector<PackBlock> pack_spare;       // ... and released by the one before: handed out again before anything is allocated (a
                                              //   handle that is packed and called again and again -- bench.py -- would otherwise free and
                                              //   allocate gigabytes per call: ~24 ms per GB when the driver has to clear them, seconds at times)
+    bool pack_oom = false;                   // a pack_alloc of the current pack failed: pack_release frees its blocks instead of parking them
     tracs::GeneralSparse *sparse = nullptr;   // general matrix-core path: per-site / per-sample lists of N and partial codes
     int sparse_state = 0;        // 0 not built, 1 built, -1 not available for this alignment (too dense / too large / no memory)
     tracs::FilterIndex *flt = nullptr;        // recombination filter: per-sample departure lists + N bitmaps (filter_lists.hip)

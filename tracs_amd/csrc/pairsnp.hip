@@ -671,16 +671,26 @@ hipError_t pack_alloc(tracs_alignment *a, size_t bytes, void **out)
         a->pack_spare.erase(a->pack_spare.begin() + (long)best);
         return hipSuccess;
     }
-    const hipError_t e = hipMalloc(out, need);
+    hipError_t e = hipMalloc(out, need);
+    if (e != hipSuccess && !a->pack_spare.empty()) {
+        // out of memory with blocks parked from the previous pack: give those back and try once more
+        (void)hipGetLastError();
+        for (auto &b : a->pack_spare) (void)hipFree(b.p);
+        a->pack_spare.clear();
+        e = hipMalloc(out, need);
+    }
     if (e == hipSuccess) a->pack_extra.push_back({*out, need});
-    else *out = nullptr;
+    else { *out = nullptr; a->pack_oom = true; }
     return e;
 }
 void pack_release(tracs_alignment *a)
 {
-    // (the spare blocks nobody took this time are freed: a handle keeps what its last pack needed beside the arena, not more)
+    // (the spare blocks nobody took this time are freed: a handle keeps what its last pack needed beside the arena, not more --
+    // and nothing at all after an allocation failed: what follows an out-of-memory soft fail needs the memory itself)
     for (auto &b : a->pack_spare) (void)hipFree(b.p);
-    a->pack_spare = std::move(a->pack_extra);
+    a->pack_spare.clear();
+    if (a->pack_oom) { for (auto &b : a->pack_extra) (void)hipFree(b.p); a->pack_oom = false; }
+    else a->pack_spare = std::move(a->pack_extra);
     a->pack_extra.clear();
     a->arena_used = 0;
 }

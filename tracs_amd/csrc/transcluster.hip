@@ -954,13 +954,17 @@ __global__ void tc_gather_kernel(Src src, const unsigned *__restrict__ eslot, co
 constexpr unsigned long long TC_GRID_BITS = 1ull << 24;
 
 // Row-structured passes over a dense block (bounds, marking, gather): workgroup (x, y) is row x of the block and slice y of its
-// columns; a thread takes four consecutive columns at a time (16-byte loads of the distances and of the days), starting at the
-// row's first cell: no division per cell, nothing issued below the diagonal.
+// columns; a thread takes four columns at a time, starting at the row's first cell: no division per cell, nothing issued below the
+// diagonal.  The four are TWO PAIRS, 128 columns apart: of the 256 columns a wave covers per step, lane l takes 2 l, 2 l + 1 and
+// 128 + 2 l, 128 + 2 l + 1 -- 8-byte loads of the distances and the days, and a pair's two doubles of P (of E(K)) are ONE 16-byte
+// store whose 64 lanes write 1 KiB without a gap.  (Four consecutive columns per lane until round 6: each 16-byte store filled half
+// of a 32-byte sector, the other half came with the next instruction -- the memory side saw twice the bytes: 1.55 GB written for
+// 0.8 GB of upper triangle, profiles/r05/pmc_bench_c3.txt.)
 struct RowQuad {
-    size_t i, j0;                // row (sample index), first column of the quad (a multiple of 4)
-    unsigned d[4];
+    size_t i, j[2];              // row (sample index), first column of either pair (even)
+    unsigned d[4];               // cells j[0], j[0] + 1, j[1], j[1] + 1
     int day[4];
-    bool ok[4];                  // column j0 + k is a cell of the block within the threshold
+    bool ok[4];                  // the column is a cell of the block within the threshold
 };
 constexpr unsigned TC_ROW_THREADS = 256;
 __device__ __forceinline__ bool tc_wide(const DenseSource &src)
@@ -974,23 +978,28 @@ __device__ __forceinline__ void tc_for_row_quads(const DenseSource &src, F f)
     const size_t jlo = max(i + 1, src.col_begin);
     const bool wide = tc_wide(src);
     const unsigned *row = src.dist + i * src.ld;
-    for (size_t q = jlo / 4 + (size_t)blockIdx.y * TC_ROW_THREADS + threadIdx.x; q * 4 < src.n; q += (size_t)gridDim.y * TC_ROW_THREADS) {
+    const unsigned lane = threadIdx.x & 63u;
+    // q0: the first quad of this thread's WAVE in this step (64 quads = 256 columns per wave and step)
+    for (size_t q0 = jlo / 4 + (size_t)blockIdx.y * TC_ROW_THREADS + (threadIdx.x - lane); q0 * 4 < src.n; q0 += (size_t)gridDim.y * TC_ROW_THREADS) {
         RowQuad c;
-        c.i = i; c.j0 = q * 4;
-        if (wide && c.j0 + 3 < src.n) {
-            // (the distances stream by once: non-temporal, so that they do not push the key tables / the key bitmap -- read at random by
-            // every cell -- out of L2)
-            typedef unsigned tc_u32x4 __attribute__((ext_vector_type(4)));
-            const tc_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const tc_u32x4 *>(row + c.j0));
-            const int4 t = *reinterpret_cast<const int4 *>(src.days + c.j0);
-            c.d[0] = v.x; c.d[1] = v.y; c.d[2] = v.z; c.d[3] = v.w;
-            c.day[0] = t.x; c.day[1] = t.y; c.day[2] = t.z; c.day[3] = t.w;
-        } else {
+        c.i = i; c.j[0] = q0 * 4 + 2 * lane; c.j[1] = c.j[0] + 128;
 #pragma unroll
-            for (int k = 0; k < 4; k++) { const bool in = c.j0 + k < src.n; c.d[k] = in ? row[c.j0 + k] : 0u; c.day[k] = in ? src.days[c.j0 + k] : 0; }
+        for (int h = 0; h < 2; h++) {
+            if (wide && c.j[h] + 1 < src.n) {
+                // (the distances stream by once: non-temporal, so that they do not push the key tables / the key bitmap -- read at random
+                // by every cell -- out of L2)
+                typedef unsigned tc_u32x2 __attribute__((ext_vector_type(2)));
+                const tc_u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const tc_u32x2 *>(row + c.j[h]));
+                const int2 t = *reinterpret_cast<const int2 *>(src.days + c.j[h]);
+                c.d[2 * h] = v.x; c.d[2 * h + 1] = v.y;
+                c.day[2 * h] = t.x; c.day[2 * h + 1] = t.y;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 2; k++) { const bool in = c.j[h] + k < src.n; c.d[2 * h + k] = in ? row[c.j[h] + k] : 0u; c.day[2 * h + k] = in ? src.days[c.j[h] + k] : 0; }
+            }
+#pragma unroll
+            for (int k = 0; k < 2; k++) c.ok[2 * h + k] = c.j[h] + k >= jlo && c.j[h] + k < src.n && (long long)c.d[2 * h + k] <= (long long)src.thr;
         }
-#pragma unroll
-        for (int k = 0; k < 4; k++) c.ok[k] = c.j0 + k >= jlo && c.j0 + k < src.n && (long long)c.d[k] <= (long long)src.thr;
         f(c);
     }
 }
@@ -1095,18 +1104,18 @@ __global__ __launch_bounds__(TC_ROW_THREADS) void tc_table_gather2_kernel(DenseS
                 }
             }
         }
-        const size_t o = c.i * src.ld + c.j0;
 #pragma unroll
         for (int h = 0; h < 4; h += 2) {
+            const size_t o = c.i * src.ld + c.j[h >> 1];
             if (wide_out && ok[h] && ok[h + 1]) {
                 typedef double tc_f64x2 __attribute__((ext_vector_type(2)));
                 tc_f64x2 a, b;
                 a.x = vp[h]; a.y = vp[h + 1]; b.x = ve[h]; b.y = ve[h + 1];
-                __builtin_nontemporal_store(a, reinterpret_cast<tc_f64x2 *>(p0 + o + h));
-                __builtin_nontemporal_store(b, reinterpret_cast<tc_f64x2 *>(eK + o + h));
+                __builtin_nontemporal_store(a, reinterpret_cast<tc_f64x2 *>(p0 + o));
+                __builtin_nontemporal_store(b, reinterpret_cast<tc_f64x2 *>(eK + o));
             } else {
-                if (ok[h]) { p0[o + h] = vp[h]; eK[o + h] = ve[h]; }
-                if (ok[h + 1]) { p0[o + h + 1] = vp[h + 1]; eK[o + h + 1] = ve[h + 1]; }
+                if (ok[h]) { p0[o] = vp[h]; eK[o] = ve[h]; }
+                if (ok[h + 1]) { p0[o + 1] = vp[h + 1]; eK[o + 1] = ve[h + 1]; }
             }
         }
     });

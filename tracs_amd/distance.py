@@ -203,6 +203,13 @@ def distance(args):
             raise SystemExit(rc)
         return
     ctx = multigpu.init() if multigpu.in_worker() else None
+    if ctx is None:
+        # the HIP runtime, the context and the library's kernels come up beside the metadata and the FASTA read (csrc/capi.hip)
+        from . import _lib
+        try:
+            _lib.load().tracs_warm_up()
+        except Exception:                                        # (no library / no GPU: the first real call says so)
+            pass
     lead = ctx is None or ctx[1] == 0
     logging.basicConfig(level=args.loglevel, format="%(asctime)s - %(levelname)s - %(message)s",
                         datefmt="%Y-%m-%d %H:%M:%S")

@@ -58,10 +58,12 @@ def init():
             d = rccl.RcclDist(device)
             ok = d.self_test()
         except Exception as e:                                   # noqa: BLE001
-            sys.stderr.write("tracs: rank %d: no RCCL communicator through libtracs_hip (%s)\n" % (rank, e))
+            sys.stderr.write("tracs: rank %d: no RCCL communicator through libtracs_hip (%s); TRACS_DIST_BACKEND=nccl|gloo asks for "
+                             "torch.distributed's exchange instead\n" % (rank, e))
             raise SystemExit(3)
         if not ok:
-            sys.stderr.write("tracs: rank %d: the RCCL communicator failed its self-test\n" % rank)
+            sys.stderr.write("tracs: rank %d: the RCCL communicator failed its self-test; TRACS_DIST_BACKEND=nccl|gloo asks for "
+                             "torch.distributed's exchange instead\n" % rank)
             raise SystemExit(3)
         return d, rank, world, device
     if not dist.is_initialized():
@@ -173,6 +175,8 @@ def pairs_site_sharded(aln, i_end, j_start, dist_threshold, rank, world, dist):
         ex = partition.TriExchange(n, r0, r1, j_start, rank, world, dist, dev_)
         ex.decide(dpan, npan, aln.L, base_row=r0)
         ex.run(dpan, npan, aln.L, L_total, base_row=r0)
+        if not ex.check():                                      # a value left the width decided for this panel: never a truncated sum
+            raise RuntimeError("tracs: the compact exchange overflowed its cell width (rank %d, rows %d..%d)" % (rank, r0, r1))
         got = [[] for _ in range(4)]
         for q0, q1 in ex.own_ranges:
             g = dev.coo_from_dense(dpan, npan, n, dist_threshold, row_begin=q0, row_end=q1, col_begin=j_start, base_row=r0)
