@@ -442,14 +442,20 @@ __global__ __launch_bounds__(WPB * 64) void flt_pairs_kernel(FltPairArgs A)
 //   * the lane's survivors are counted on the way, a prefix sum over the lanes places them, each lane copies its own;
 //   * the window test reads a SNP's two neighbours on either side up front (windows rarely hold more), and the thresholds of the
 //     pair's d sit in registers, one count per lane (ds_bpermute instead of a table read).
+//   * a wave takes FLT_PB consecutive pairs: in a row-major emission they share the row i and, 31 times out of 32, the 32-sample word
+//     of j -- the list of i and its NS words stay in registers from one pair to the next (half of a pair's scattered lookups).
+constexpr unsigned FLT_PB = 8;
 template <int R>
-__global__ __launch_bounds__(64) void flt_pairs2_kernel(FltPairArgs A)
+struct FltRowCache {
+    unsigned i = 0xFFFFFFFFu, jw = 0xFFFFFFFFu, la = 0;
+    unsigned ea[R], na[R];
+};
+
+template <int R>
+__device__ __forceinline__ void flt_pair2(const FltPairArgs &A, const size_t t, const unsigned lane, unsigned *LA, unsigned *LB, unsigned *M,
+                                          FltRowCache<R> &rc)
 {
-    extern __shared__ unsigned flt_lds[];
     constexpr unsigned CAP = R * 64, INF = 0xFFFFFFFFu;
-    const unsigned lane = threadIdx.x;
-    const size_t t = blockIdx.x;
-    unsigned *LA = flt_lds, *LB = LA + CAP, *M = LB + CAP;                 // M: 2 CAP + 128 words
     const unsigned i = A.rows[t], j = A.cols[t];
     const unsigned long long oi = A.dep_off[i], oj = A.dep_off[j];
     const unsigned la = (unsigned)(A.dep_off[i + 1] - oi), lb = (unsigned)(A.dep_off[j + 1] - oj);
@@ -460,27 +466,35 @@ __global__ __launch_bounds__(64) void flt_pairs2_kernel(FltPairArgs A)
     const unsigned dt = A.d[t];
     const bool have_row = A.tbl && dt >= 2 && dt <= FLT_DCAP && A.tbl_state[dt] == 1;
     const unsigned rowv = have_row ? A.tbl[(size_t)dt * FLT_KT + lane] : INF;      // smallest surviving span for count = lane
-    unsigned ea[R], eb[R];
+    const bool same_i = rc.i == i, same_w = same_i && rc.jw == (j >> 5);      // (wave-uniform)
+    const unsigned lmax = max(la, lb);                                     // (rounds beyond both lists are skipped: wave-uniform)
+    unsigned eb[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const unsigned k = (unsigned)r * 64 + lane;
-        ea[r] = k < la ? A.dep[oi + k] : INF;
+        eb[r] = INF;
+        if ((unsigned)r * 64 >= lmax) continue;
+        if (!same_i) rc.ea[r] = k < la ? A.dep[oi + k] : INF;
         eb[r] = k < lb ? A.dep[oj + k] : INF;
     }
     const unsigned *nsj = A.ns + (j >> 5);
     const unsigned jbit = j & 31u;
     const unsigned *nti = A.nt + (size_t)i * A.nt_words;
-    unsigned na[R], nb[R];
+    unsigned nb[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const unsigned k = (unsigned)r * 64 + lane;
-        na[r] = (k < la && (ea[r] & 16u)) ? nsj[(size_t)(ea[r] >> 5) * A.ns_words] : 0u;
+        nb[r] = 0u;
+        if ((unsigned)r * 64 >= lmax) continue;
+        if (!same_w) rc.na[r] = (k < la && (rc.ea[r] & 16u)) ? nsj[(size_t)(rc.ea[r] >> 5) * A.ns_words] : 0u;
         nb[r] = (k < lb && (eb[r] & 16u)) ? nti[eb[r] >> 10] : 0u;
     }
+    rc.i = i; rc.jw = j >> 5; rc.la = la;
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const unsigned k = (unsigned)r * 64 + lane;
-        if (k < la) LA[k] = ea[r] & ~(((na[r] >> jbit) & 1u) << 4);
+        if ((unsigned)r * 64 >= lmax) continue;
+        if (k < la) LA[k] = rc.ea[r] & ~(((rc.na[r] >> jbit) & 1u) << 4);
         if (k < lb) LB[k] = eb[r] & ~(((nb[r] >> ((eb[r] >> 5) & 31u)) & 1u) << 4);
     }
     flt_wave_sync();
@@ -531,13 +545,15 @@ __global__ __launch_bounds__(64) void flt_pairs2_kernel(FltPairArgs A)
     return;
 #endif
     flt_wave_sync();                                                       // every lane is done with the two lists
-    unsigned *S = LA;
+    // S[-2], S[-1] = -1 and S[dn], S[dn + 1] = INT_MAX: the window test reads two neighbours either way without asking where the list ends
+    unsigned *S = LA + 2;
     {
         unsigned o = incl - cnt;
         for (unsigned step = 0; step < C; step++) {
             const unsigned v = Mrow[step];
             if (v >> 31) S[o++] = v & 0x7FFFFFFFu;
         }
+        if (lane < 2) { LA[lane] = 0xFFFFFFFFu; S[dn + lane] = 0x7FFFFFFFu; }
     }
     flt_wave_sync();
 #if defined(TRACS_FLT_CUT) && TRACS_FLT_CUT == 3
@@ -556,8 +572,7 @@ __global__ __launch_bounds__(64) void flt_pairs2_kernel(FltPairArgs A)
         int count = 0, length = 0;
         if (act) {
             const int x = (int)S[u];
-            const int p1 = u >= 1 ? (int)S[u - 1] : -1, p2 = u >= 2 ? (int)S[u - 2] : -1;
-            const int n1 = u + 1 < n_s ? (int)S[u + 1] : 0x7FFFFFFF, n2 = u + 2 < n_s ? (int)S[u + 2] : 0x7FFFFFFF;
+            const int p1 = (int)S[u - 1], p2 = (int)S[u - 2], n1 = (int)S[u + 1], n2 = (int)S[u + 2];
             const int left = max(0, x - wh);                               // :284
             const int right = min(aln, x + wh + 1);                        // :285
             int f = u, l = u, xf = x, xl = x;
@@ -566,7 +581,7 @@ __global__ __launch_bounds__(64) void flt_pairs2_kernel(FltPairArgs A)
                 if (p2 >= left) {
                     f = u - 2;
                     int steps = 0;
-                    while (f > 0 && (int)S[f - 1] >= left) {
+                    while ((int)S[f - 1] >= left) {
                         --f;
                         if (++steps == 6) { f = flt_lower_bound(S, 0, f, (unsigned)left); break; }
                     }
@@ -578,7 +593,7 @@ __global__ __launch_bounds__(64) void flt_pairs2_kernel(FltPairArgs A)
                 if (n2 < right) {
                     l = u + 2;
                     int steps = 0;
-                    while (l + 1 < n_s && (int)S[l + 1] < right) {
+                    while ((int)S[l + 1] < right) {
                         ++l;
                         if (++steps == 6) { l = flt_lower_bound(S, l + 1, n_s, (unsigned)right) - 1; break; }
                     }
@@ -604,9 +619,24 @@ __global__ __launch_bounds__(64) void flt_pairs2_kernel(FltPairArgs A)
 }
 
 template <int R>
+__global__ __launch_bounds__(64) void flt_pairs2_kernel(FltPairArgs A)
+{
+    extern __shared__ unsigned flt_lds[];
+    constexpr unsigned CAP = R * 64;
+    const unsigned lane = threadIdx.x;
+    unsigned *LA = flt_lds, *LB = LA + CAP, *M = LB + CAP;                 // M: 2 CAP + 128 words
+    FltRowCache<R> rc;
+    const size_t t0 = (size_t)blockIdx.x * FLT_PB, t1 = min(A.n_pairs, t0 + FLT_PB);
+    for (size_t t = t0; t < t1; t++) {
+        flt_pair2<R>(A, t, lane, LA, LB, M, rc);
+        flt_wave_sync();                                                   // (the next pair's lists take the place of this one's SNP sites)
+    }
+}
+
+template <int R>
 static void flt_launch2(const FltPairArgs &A, hipStream_t stream)
 {
-    hipLaunchKernelGGL((flt_pairs2_kernel<R>), dim3((unsigned)A.n_pairs), dim3(64), (size_t)(4 * R * 64 + 128) * 4, stream, A);
+    hipLaunchKernelGGL((flt_pairs2_kernel<R>), dim3((unsigned)((A.n_pairs + FLT_PB - 1) / FLT_PB)), dim3(64), (size_t)(4 * R * 64 + 128) * 4, stream, A);
 }
 
 // pairs left to the scan: their indices, closed up
