@@ -16,8 +16,9 @@
 // its window [i - w, i + w + 1) a few entries to either side.  The binomial tail depends on (d, span, count) only and is
 // monotone in the span: per distinct d one row of thresholds "smallest span that survives with `count` SNPs in the
 // window" is built on first use (the reference memoises (n, p, k) -> cdf in a std::map, :41-58), so the test per SNP is
-// one compare.  Pairs whose lists do not fit the wave's LDS (and alignments whose lists cannot be built) take the scan
-// of the planes (filter.hip: the reference's own way, which also returns the positions).
+// one compare.  Pairs whose lists do not fit a wave's LDS (partial IUPAC codes: tens of thousands of entries per sample) take the
+// same merge over global memory (flt_pairs_long_kernel); alignments whose lists cannot be built (more than a tenth of all cells
+// listed, no memory) the scan of the planes (filter.hip: the reference's own way, which also returns the positions).
 // PARITY UNPINNED: Boost's ibetac is replaced by the exact finite sum.
 #include "common.h"
 #include "filter_math.h"
@@ -431,6 +432,68 @@ __global__ __launch_bounds__(WPB * 64) void flt_pairs_kernel(FltPairArgs A)
     if (lane == 0) A.filt[t] = kept;
 }
 
+// The window test (:273-314) over a pair's sorted SNP sites S[0 .. dn), dn >= 2, with S[-2] = S[-1] = -1 and S[dn] = S[dn + 1] = INT_MAX
+// around them: a SNP reads two neighbours either way up front (windows rarely hold more); the thresholds of the pair's d sit in
+// registers, one count per lane (rowv; have_row: the row exists).  One wave; returns the wave's total.
+template <class Ptr>
+__device__ __forceinline__ unsigned flt_window_test2(Ptr S, const unsigned dn, const FltPairArgs &A, const unsigned rowv, const bool have_row,
+                                                     const unsigned lane)
+{
+    const FilterWindow fw = filter_window((long long)dn, A.L);
+    const int wh = fw.wh, aln = (int)A.L, n_s = (int)dn;
+    unsigned kept = 0;
+    for (int u0 = 0; u0 < n_s; u0 += 64) {
+        const int u = u0 + (int)lane;
+        const bool act = u < n_s;
+        int count = 0, length = 0;
+        if (act) {
+            const int x = (int)S[u];
+            const int p1 = (int)S[u - 1], p2 = (int)S[u - 2], n1 = (int)S[u + 1], n2 = (int)S[u + 2];
+            const int left = max(0, x - wh);                               // :284
+            const int right = min(aln, x + wh + 1);                        // :285
+            int f = u, l = u, xf = x, xl = x;
+            if (p1 >= left) {
+                f = u - 1; xf = p1;
+                if (p2 >= left) {
+                    f = u - 2;
+                    int steps = 0;
+                    while ((int)S[f - 1] >= left) {
+                        --f;
+                        if (++steps == 6) { f = flt_lower_bound(S, 0, f, (unsigned)left); break; }
+                    }
+                    xf = (int)S[f];
+                }
+            }
+            if (n1 < right) {
+                l = u + 1; xl = n1;
+                if (n2 < right) {
+                    l = u + 2;
+                    int steps = 0;
+                    while ((int)S[l + 1] < right) {
+                        ++l;
+                        if (++steps == 6) { l = flt_lower_bound(S, l + 1, n_s, (unsigned)right) - 1; break; }
+                    }
+                    xl = (int)S[l];
+                }
+            }
+            count = l - f + 1;
+            length = xl - xf + 1;                                          // :242
+        }
+        const unsigned thr = __shfl(rowv, count < (int)FLT_KT ? count : 0, 64);
+        if (act) {
+            bool keep = true;                                              // alone in its window: :311
+            if (count > 1) {                                               // :294
+                if (have_row && count < (int)FLT_KT) keep = (unsigned)length >= thr;
+                else keep = filter_keep(length, count, fw.p, fw.thr, A.lg);
+            }
+            kept += keep ? 1u : 0u;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) kept += __shfl_xor(kept, off, 64);
+    return kept;
+}
+
 // ---- the pairs, second form (lists of up to 1 024 entries) ----------------------------------------------------------------------
 // One wave per pair, R = rounds of 64 entries per list.  What the first form spends its time on is latency: ten dependent LDS reads
 // per entry for the merge ranks, and one N lookup per entry in global memory whose answer the next instruction waits for.  Here
@@ -562,59 +625,7 @@ __device__ __forceinline__ void flt_pair2(const FltPairArgs &A, const size_t t, 
 #endif
     if (dn != dt && lane == 0) atomicAdd(A.counters, 1u);
     if (dn <= 1u) { if (lane == 0) A.filt[t] = dn; return; }              // :259-261
-    // window test (:273-314)
-    const FilterWindow fw = filter_window((long long)dn, A.L);
-    const int wh = fw.wh, aln = (int)A.L, n_s = (int)dn;
-    unsigned kept = 0;
-    for (int u0 = 0; u0 < n_s; u0 += 64) {
-        const int u = u0 + (int)lane;
-        const bool act = u < n_s;
-        int count = 0, length = 0;
-        if (act) {
-            const int x = (int)S[u];
-            const int p1 = (int)S[u - 1], p2 = (int)S[u - 2], n1 = (int)S[u + 1], n2 = (int)S[u + 2];
-            const int left = max(0, x - wh);                               // :284
-            const int right = min(aln, x + wh + 1);                        // :285
-            int f = u, l = u, xf = x, xl = x;
-            if (p1 >= left) {
-                f = u - 1; xf = p1;
-                if (p2 >= left) {
-                    f = u - 2;
-                    int steps = 0;
-                    while ((int)S[f - 1] >= left) {
-                        --f;
-                        if (++steps == 6) { f = flt_lower_bound(S, 0, f, (unsigned)left); break; }
-                    }
-                    xf = (int)S[f];
-                }
-            }
-            if (n1 < right) {
-                l = u + 1; xl = n1;
-                if (n2 < right) {
-                    l = u + 2;
-                    int steps = 0;
-                    while ((int)S[l + 1] < right) {
-                        ++l;
-                        if (++steps == 6) { l = flt_lower_bound(S, l + 1, n_s, (unsigned)right) - 1; break; }
-                    }
-                    xl = (int)S[l];
-                }
-            }
-            count = l - f + 1;
-            length = xl - xf + 1;                                          // :242
-        }
-        const unsigned thr = __shfl(rowv, count < (int)FLT_KT ? count : 0, 64);
-        if (act) {
-            bool keep = true;                                              // alone in its window: :311
-            if (count > 1) {                                               // :294
-                if (have_row && count < (int)FLT_KT) keep = (unsigned)length >= thr;
-                else keep = filter_keep(length, count, fw.p, fw.thr, A.lg);
-            }
-            kept += keep ? 1u : 0u;
-        }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) kept += __shfl_xor(kept, off, 64);
+    const unsigned kept = flt_window_test2(S, dn, A, rowv, have_row, lane);
     if (lane == 0) A.filt[t] = kept;
 }
 
@@ -639,7 +650,91 @@ static void flt_launch2(const FltPairArgs &A, hipStream_t stream)
     hipLaunchKernelGGL((flt_pairs2_kernel<R>), dim3((unsigned)((A.n_pairs + FLT_PB - 1) / FLT_PB)), dim3(64), (size_t)(4 * R * 64 + 128) * 4, stream, A);
 }
 
-// pairs left to the scan: their indices, closed up
+// ---- the pairs whose lists do not fit a wave's LDS (partial IUPAC codes: tens of thousands of entries per sample) ------------------
+// The same merge path with the lists where they lie and the merged sequence in the wave's slot of a scratch buffer in global memory:
+// lane l takes the merged entries [l C, (l + 1) C) one after the other -- its two streams advance four bytes a step, a cache line
+// serves sixteen steps -- and writes  site | candidate << 31 | "ask NS for j" << 30 | "ask NT for i" << 29;  a second pass over
+// the sequence, 64 entries per instruction, asks the N bitmaps (independent loads: nothing waits for an answer inside the lanes'
+// sequential merge) and closes the survivors up IN PLACE (a survivor never lands ahead of what is still to be read); then the window
+// test reads the SNP sites from there.  One wave per pair of idx[0 .. n_idx), as many waves as the scratch buffer has slots.
+__global__ __launch_bounds__(64) void flt_pairs_long_kernel(FltPairArgs A, const unsigned *__restrict__ idx, size_t n_idx,
+                                                            unsigned *__restrict__ scratch, size_t slot)
+{
+    constexpr unsigned INF = 0xFFFFFFFFu;
+    const unsigned lane = threadIdx.x;
+    unsigned *M = scratch + (size_t)blockIdx.x * slot + 2;                 // (two sentinels in front, two behind)
+    for (size_t q = blockIdx.x; q < n_idx; q += gridDim.x) {
+        const size_t t = idx[q];
+        const unsigned i = A.rows[t], j = A.cols[t];
+        const unsigned long long oi = A.dep_off[i], oj = A.dep_off[j];
+        const unsigned la = (unsigned)(A.dep_off[i + 1] - oi), lb = (unsigned)(A.dep_off[j + 1] - oj);
+        const unsigned *DA = A.dep + oi, *DB = A.dep + oj;
+        const unsigned dt = A.d[t];
+        const bool have_row = A.tbl && dt >= 2 && dt <= FLT_DCAP && A.tbl_state[dt] == 1;
+        const unsigned rowv = have_row ? A.tbl[(size_t)dt * FLT_KT + lane] : INF;
+        const unsigned tot = la + lb, C = (tot + 63u) / 64u;
+        const unsigned D = min(tot, lane * C);
+        unsigned a, b;
+        {
+            unsigned lo = D > lb ? D - lb : 0u, hi = min(D, la);
+            while (lo < hi) {
+                const unsigned mid = (lo + hi) >> 1;
+                if ((DA[mid] >> 5) <= (DB[D - 1u - mid] >> 5)) lo = mid + 1u; else hi = mid;
+            }
+            a = lo; b = D - lo;
+        }
+        unsigned va = a < la ? DA[a] : INF, vb = b < lb ? DB[b] : INF;
+        unsigned lastA = a > 0u ? (DA[a - 1u] >> 5) : INF;
+        for (unsigned step = 0; step < C; step++) {
+            const unsigned pa = va >> 5, pb = vb >> 5;
+            const bool takeA = pa <= pb;
+            // i's entry: both listed -> the masks decide (final); else a candidate iff its alleles lack the reference base, unless j is N
+            // there (NS).  j's entry: dead when i lists the site too; else the same with i's N bit (NT).
+            const unsigned wa = (va >> 4) & 1u, wb = (vb >> 4) & 1u;
+            const unsigned fa = pa == pb ? ((((va & vb & 15u) == 0u) ? 1u : 0u) << 31) : ((wa << 31) | (wa << 30));
+            const unsigned fb = lastA == pb ? 0u : ((wb << 31) | (wb << 29));
+            if (D + step < tot) M[D + step] = (takeA ? pa : pb) | (takeA ? fa : fb);
+            if (takeA) { lastA = pa; a++; va = a < la ? DA[a] : INF; } else { b++; vb = b < lb ? DB[b] : INF; }
+        }
+        __threadfence_block();
+        flt_wave_sync();
+        const unsigned *nsj = A.ns + (j >> 5);
+        const unsigned jbit = j & 31u;
+        const unsigned *nti = A.nt + (size_t)i * A.nt_words;
+        unsigned dn = 0;
+        for (unsigned c0 = 0; c0 < tot; c0 += 256) {
+            unsigned v[4], nw[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const unsigned c = c0 + (unsigned)u * 64 + lane; v[u] = c < tot ? M[c] : 0u; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const unsigned pos = v[u] & 0x07FFFFFFu;
+                nw[u] = 0u;
+                if (v[u] & (1u << 30)) nw[u] = (nsj[(size_t)pos * A.ns_words] >> jbit) & 1u;
+                else if (v[u] & (1u << 29)) nw[u] = (nti[pos >> 5] >> (pos & 31u)) & 1u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const bool alive = (v[u] >> 31) && !nw[u];
+                const unsigned long long bal = __ballot(alive);
+                if (alive) M[dn + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = v[u] & 0x07FFFFFFu;
+                dn += (unsigned)__popcll(bal);
+            }
+        }
+        if (lane < 2) { M[(int)lane - 2] = 0xFFFFFFFFu; M[dn + lane] = 0x7FFFFFFFu; }
+        __threadfence_block();
+        flt_wave_sync();
+        if (dn != dt && lane == 0) atomicAdd(A.counters, 1u);
+        if (dn <= 1u) { if (lane == 0) A.filt[t] = dn; }                  // :259-261
+        else {
+            const unsigned kept = flt_window_test2(M, dn, A, rowv, have_row, lane);
+            if (lane == 0) A.filt[t] = kept;
+        }
+        flt_wave_sync();
+    }
+}
+
+// pairs whose lists did not fit the LDS kernel: their indices, closed up
 __global__ __launch_bounds__(256) void flt_collect_kernel(const unsigned *__restrict__ filt, size_t n_pairs, unsigned *__restrict__ idx,
                                                           unsigned *__restrict__ cursor)
 {
@@ -653,22 +748,6 @@ __global__ __launch_bounds__(256) void flt_max_kernel(const unsigned *__restrict
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor(m, off, 64));
     if ((threadIdx.x & 63) == 0) atomicMax(out, m);
-}
-
-// the pairs left to the scan, closed up / their results put back
-__global__ __launch_bounds__(256) void flt_gather_kernel(const unsigned *__restrict__ idx, size_t n_idx, const unsigned *__restrict__ rows,
-                                                         const unsigned *__restrict__ cols, const unsigned *__restrict__ d,
-                                                         unsigned *__restrict__ r2, unsigned *__restrict__ c2, unsigned *__restrict__ d2)
-{
-    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n_idx; q += (size_t)gridDim.x * 256) {
-        const unsigned t = idx[q];
-        r2[q] = rows[t]; c2[q] = cols[t]; d2[q] = d[t];
-    }
-}
-__global__ __launch_bounds__(256) void flt_scatter_kernel(const unsigned *__restrict__ idx, size_t n_idx, const unsigned *__restrict__ f2,
-                                                          unsigned *__restrict__ filt)
-{
-    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n_idx; q += (size_t)gridDim.x * 256) filt[idx[q]] = f2[q];
 }
 
 // ---- host ------------------------------------------------------------------------------------------------------------------------
@@ -874,16 +953,24 @@ int tracs_filter_recomb_pairs(tracs_alignment *a, const uint32_t *rows, const ui
         TRACS_HIP_CHECK(hipStreamSynchronize(stream));
         if ((rc = filter_scan_route(a, rows, cols, d, n_pairs, max_d_left, filt, tbl, f->tbl_state, lg, f->counters, stream))) return rc;
     } else {
-        unsigned *idx, *g;
+        // lists too long for a wave's LDS: the same merge over global memory (flt_pairs_long_kernel)
+        unsigned *idx, *scratch;
+        const size_t slot = ((size_t)2 * f->max_len + 8 + 63) / 64 * 64;
+        size_t waves = std::min<size_t>(n_left, 256 * 16);
+        while (waves > 256 && waves * slot * 4 > (3ull << 30)) waves /= 2;
         if ((rc = workspace_get(FltWs::IDX, n_left * 4, reinterpret_cast<void **>(&idx))) ||
-            (rc = workspace_get(FltWs::SCRATCH, n_left * 16, reinterpret_cast<void **>(&g)))) return rc;
-        unsigned *r2 = g, *c2 = g + n_left, *d2 = g + 2 * n_left, *f2 = g + 3 * n_left;
+            (rc = workspace_get(FltWs::SCRATCH, waves * slot * 4, reinterpret_cast<void **>(&scratch)))) return rc;
         TRACS_HIP_CHECK(hipMemsetAsync(f->counters + 4, 0, 4, stream));
         hipLaunchKernelGGL(flt_collect_kernel, dim3(blocks), dim3(256), 0, stream, filt, n_pairs, idx, f->counters + 4);
-        const unsigned gb = (unsigned)std::min<size_t>((n_left + 255) / 256, 256 * 16);
-        hipLaunchKernelGGL(flt_gather_kernel, dim3(gb), dim3(256), 0, stream, idx, n_left, rows, cols, d, r2, c2, d2);
-        if ((rc = filter_scan_route(a, r2, c2, d2, n_left, max_d_left, f2, tbl, f->tbl_state, lg, f->counters, stream))) return rc;
-        hipLaunchKernelGGL(flt_scatter_kernel, dim3(gb), dim3(256), 0, stream, idx, n_left, f2, filt);
+        FltPairArgs A;
+        A.rows = rows; A.cols = cols; A.d = d; A.n_pairs = n_pairs;
+        A.dep = f->dep; A.dep_off = f->dep_off;
+        A.nt = reinterpret_cast<const unsigned *>(f->nt); A.ns = f->ns;
+        A.nt_words = f->nt_groups * 4; A.ns_words = f->ns_words;
+        A.L = (unsigned)a->L; A.cap = 0;
+        A.tbl = tbl; A.tbl_state = f->tbl_state; A.lg = lg;
+        A.filt = filt; A.counters = f->counters;
+        hipLaunchKernelGGL(flt_pairs_long_kernel, dim3((unsigned)waves), dim3(64), 0, stream, A, idx, n_left, scratch, slot);
     }
     TRACS_HIP_CHECK(hipGetLastError());
     unsigned bad = 0;
