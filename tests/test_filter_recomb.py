@@ -85,13 +85,13 @@ def extract_kernel(request, monkeypatch):
 
 
 # every way tracs_filter_recomb_pairs can take: lists + table (the default: the merge-path kernel), lists with the tail summed per
-# SNP, the scan of the planes for every pair, lists whose LDS capacity leaves some pairs to the scan, and the binary-search kernel
-# (what lists of more than 1 024 entries use)
+# SNP, the scan of the planes for every pair, lists whose LDS capacity sends pairs to the long-list kernels (tiled: the default;
+# sequential), and the binary-search kernel
 ROUTES = {"lists": {}, "lists_no_table": {"TRACS_FILTER_TABLE": "0"}, "scan": {"TRACS_FILTER_LISTS": "0"},
           "scan_batches": {"TRACS_FILTER_LISTS": "0", "TRACS_FILTER_SCAN_MAXPOS": "20000"},
           "scan_batches_lanes": {"TRACS_FILTER_LISTS": "0", "TRACS_FILTER_SCAN_MAXPOS": "50000", "TRACS_FILTER_LANES_MIN": "0"},
           "lists_cap64_batches": {"TRACS_FILTER_CAP": "64", "TRACS_FILTER_SCAN_MAXPOS": "3000"},
-          "lists_cap64": {"TRACS_FILTER_CAP": "64"}, "lists_search_kernel": {"TRACS_FILTER_KERNEL": "1"},
+          "lists_cap64": {"TRACS_FILTER_CAP": "64"}, "lists_cap64_sequential_long_kernel": {"TRACS_FILTER_CAP": "64", "TRACS_FILTER_LONG": "seq"}, "lists_search_kernel": {"TRACS_FILTER_KERNEL": "1"},
           "lists_search_kernel_cap128": {"TRACS_FILTER_KERNEL": "1", "TRACS_FILTER_CAP": "128"}}
 
 

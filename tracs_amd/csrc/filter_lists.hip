@@ -734,6 +734,134 @@ __global__ __launch_bounds__(64) void flt_pairs_long_kernel(FltPairArgs A, const
     }
 }
 
+// ---- long lists, tiled -------------------------------------------------------------------------------------------------------------
+// The sequential merge above waits for a cache line every few steps.  Here the merged sequence is cut into TILES of FLT_TILE entries
+// by merge-path diagonals (lane k finds where tile k starts in the two lists: one binary search over global memory per tile, all
+// tiles of a round at once), and every tile is the short-list kernel's work: its share of either list loaded into LDS with ALL its
+// N lookups in flight at once, a merge path in LDS, the lanes' survivors appended to the pair's SNP sites in the wave's scratch slot.
+// (A site both samples list may straddle a tile boundary -- i's entry last in one tile, j's first in the next: i's entry looks at the
+// entry of j behind the tile's share, j's entry at the site of i's entry before it.)
+constexpr unsigned FLT_TILE = 1024, FLT_TILE_R = FLT_TILE / 64;
+__global__ __launch_bounds__(64) void flt_pairs_tiled_kernel(FltPairArgs A, const unsigned *__restrict__ idx, size_t n_idx,
+                                                             unsigned *__restrict__ scratch, size_t slot)
+{
+    extern __shared__ unsigned flt_lds[];
+    constexpr unsigned CAP = FLT_TILE + 64, INF = 0xFFFFFFFFu, R = FLT_TILE_R;
+    const unsigned lane = threadIdx.x;
+    unsigned *LA = flt_lds, *LB = LA + CAP, *M = LB + CAP, *split = M + 2 * FLT_TILE + 128;      // split: 65 words
+    unsigned *S = scratch + (size_t)blockIdx.x * slot + 2;                 // (two sentinels in front, two behind)
+    for (size_t q = blockIdx.x; q < n_idx; q += gridDim.x) {
+        const size_t t = idx[q];
+        const unsigned i = A.rows[t], j = A.cols[t];
+        const unsigned long long oi = A.dep_off[i], oj = A.dep_off[j];
+        const unsigned la = (unsigned)(A.dep_off[i + 1] - oi), lb = (unsigned)(A.dep_off[j + 1] - oj);
+        const unsigned *DA = A.dep + oi, *DB = A.dep + oj;
+        const unsigned dt = A.d[t];
+        const bool have_row = A.tbl && dt >= 2 && dt <= FLT_DCAP && A.tbl_state[dt] == 1;
+        const unsigned rowv = have_row ? A.tbl[(size_t)dt * FLT_KT + lane] : INF;
+        const unsigned *nsj = A.ns + (j >> 5);
+        const unsigned jbit = j & 31u;
+        const unsigned *nti = A.nt + (size_t)i * A.nt_words;
+        const unsigned tot = la + lb, tiles = (tot + FLT_TILE - 1) / FLT_TILE;
+        unsigned dn = 0;
+        for (unsigned k0 = 0; k0 < tiles; k0 += 64) {
+            // where the tiles k0 .. k0 + 63 (and the one behind them) start in i's list: split[k]; in j's: k FLT_TILE - split[k]
+            for (unsigned kk = lane; kk < 65u; kk += 64) {
+                const unsigned D = min(tot, (k0 + kk) * FLT_TILE);
+                unsigned lo = D > lb ? D - lb : 0u, hi = min(D, la);
+                while (lo < hi) {
+                    const unsigned mid = (lo + hi) >> 1;
+                    if ((DA[mid] >> 5) <= (DB[D - 1u - mid] >> 5)) lo = mid + 1u; else hi = mid;
+                }
+                split[kk] = lo;
+            }
+            flt_wave_sync();
+            for (unsigned kt = 0; kt < 64u && k0 + kt < tiles; kt++) {
+                const unsigned D0 = (k0 + kt) * FLT_TILE, D1 = min(tot, D0 + FLT_TILE);
+                const unsigned a0 = split[kt], a1 = split[kt + 1], b0 = D0 - a0, b1 = D1 - a1;
+                const unsigned la_t = a1 - a0, lb_t = b1 - b0, tot_t = la_t + lb_t;
+                // the tile's entries (+ the entry of j behind its share: what a straddling twin of i's last entry would be), N lookups folded in
+                unsigned ea[R], eb[R], na[R], nb[R];
+#pragma unroll
+                for (unsigned r = 0; r < R; r++) {
+                    const unsigned k = r * 64 + lane;
+                    ea[r] = k < la_t ? DA[a0 + k] : INF;
+                    eb[r] = k < lb_t ? DB[b0 + k] : INF;
+                }
+                const unsigned peek = b1 < lb ? DB[b1] : INF;
+                const unsigned prevA = a0 > 0u ? (DA[a0 - 1u] >> 5) : INF;
+#pragma unroll
+                for (unsigned r = 0; r < R; r++) {
+                    const unsigned k = r * 64 + lane;
+                    na[r] = (k < la_t && (ea[r] & 16u)) ? nsj[(size_t)(ea[r] >> 5) * A.ns_words] : 0u;
+                    nb[r] = (k < lb_t && (eb[r] & 16u)) ? nti[eb[r] >> 10] : 0u;
+                }
+#pragma unroll
+                for (unsigned r = 0; r < R; r++) {
+                    const unsigned k = r * 64 + lane;
+                    if (k < la_t) LA[k] = ea[r] & ~(((na[r] >> jbit) & 1u) << 4);
+                    if (k < lb_t) LB[k] = eb[r] & ~(((nb[r] >> ((eb[r] >> 5) & 31u)) & 1u) << 4);
+                }
+                if (lane == 0) LB[lb_t] = peek;
+                flt_wave_sync();
+                // merge path inside the tile (flt_pair2's)
+                const unsigned C = (tot_t + 63u) / 64u, stride = C | 1u;
+                const unsigned D = min(tot_t, lane * C);
+                unsigned a, b;
+                {
+                    unsigned lo = D > lb_t ? D - lb_t : 0u, hi = min(D, la_t);
+                    while (lo < hi) {
+                        const unsigned mid = (lo + hi) >> 1;
+                        if ((LA[mid] >> 5) <= (LB[D - 1u - mid] >> 5)) lo = mid + 1u; else hi = mid;
+                    }
+                    a = lo; b = D - lo;
+                }
+                unsigned va = a < la_t ? LA[a] : INF, vb = b <= lb_t ? LB[b] : INF;
+                unsigned lastA = a > 0u ? (LA[a - 1u] >> 5) : prevA;
+                unsigned cnt = 0;
+                unsigned *Mrow = M + lane * stride;
+                for (unsigned step = 0; step < C; step++) {
+                    const unsigned pa = va >> 5, pb = vb >> 5;
+                    const bool takeA = pa <= pb;
+                    const unsigned snpA = pa == pb ? (((va & vb & 15u) == 0u) ? 1u : 0u) : ((va >> 4) & 1u);
+                    const unsigned snpB = lastA == pb ? 0u : ((vb >> 4) & 1u);
+                    const unsigned snp = (D + step < tot_t) ? (takeA ? snpA : snpB) : 0u;
+                    Mrow[step] = (takeA ? pa : pb) | (snp << 31);
+                    cnt += snp;
+                    const unsigned nidx = takeA ? a + 1u : CAP + b + 1u, nlim = takeA ? la_t : CAP + lb_t + 1u;
+                    const unsigned nxt = nidx < nlim ? LA[nidx] : INF;
+                    if (takeA) { lastA = pa; a++; va = nxt; } else { b++; vb = nxt; }
+                }
+                unsigned incl = cnt;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const unsigned v = __shfl_up(incl, off, 64);
+                    if (lane >= (unsigned)off) incl += v;
+                }
+                {
+                    unsigned o = dn + incl - cnt;
+                    for (unsigned step = 0; step < C; step++) {
+                        const unsigned v = Mrow[step];
+                        if (v >> 31) S[o++] = v & 0x7FFFFFFFu;
+                    }
+                }
+                dn += __shfl(incl, 63, 64);
+                flt_wave_sync();                                           // (the next tile's entries take the place of this one's)
+            }
+        }
+        if (lane < 2) { S[(int)lane - 2] = 0xFFFFFFFFu; S[dn + lane] = 0x7FFFFFFFu; }
+        __threadfence_block();
+        flt_wave_sync();
+        if (dn != dt && lane == 0) atomicAdd(A.counters, 1u);
+        if (dn <= 1u) { if (lane == 0) A.filt[t] = dn; }                  // :259-261
+        else {
+            const unsigned kept = flt_window_test2(S, dn, A, rowv, have_row, lane);
+            if (lane == 0) A.filt[t] = kept;
+        }
+        flt_wave_sync();
+    }
+}
+
 // pairs whose lists did not fit the LDS kernel: their indices, closed up
 __global__ __launch_bounds__(256) void flt_collect_kernel(const unsigned *__restrict__ filt, size_t n_pairs, unsigned *__restrict__ idx,
                                                           unsigned *__restrict__ cursor)
@@ -970,7 +1098,13 @@ int tracs_filter_recomb_pairs(tracs_alignment *a, const uint32_t *rows, const ui
         A.L = (unsigned)a->L; A.cap = 0;
         A.tbl = tbl; A.tbl_state = f->tbl_state; A.lg = lg;
         A.filt = filt; A.counters = f->counters;
-        hipLaunchKernelGGL(flt_pairs_long_kernel, dim3((unsigned)waves), dim3(64), 0, stream, A, idx, n_left, scratch, slot);
+        // (TRACS_FILTER_LONG=seq: the per-lane sequential merge over global memory instead of the tiled one: tests, A/B)
+        const char *lf = std::getenv("TRACS_FILTER_LONG");
+        if (lf && lf[0] == 's')
+            hipLaunchKernelGGL(flt_pairs_long_kernel, dim3((unsigned)waves), dim3(64), 0, stream, A, idx, n_left, scratch, slot);
+        else
+            hipLaunchKernelGGL(flt_pairs_tiled_kernel, dim3((unsigned)waves), dim3(64), (size_t)(2 * (FLT_TILE + 64) + 2 * FLT_TILE + 128 + 80) * 4, stream, A,
+                               idx, n_left, scratch, slot);
     }
     TRACS_HIP_CHECK(hipGetLastError());
     unsigned bad = 0;
