@@ -1111,8 +1111,12 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb_, hipStream_t 
     // (only when some group's lists are that kernel's: at least PL_MIN entries)
     if (mb.max_gp >= PL_MIN)
         hipLaunchKernelGGL(p_lists_kernel, dim3((unsigned)groups), dim3(PL_THREADS), 0, stream, mb, a->n_pad, (unsigned)n, g->p_ent, reinterpret_cast<unsigned *>(g->qlines), E, e_cnt, two_pass ? 0 : 1, g->c_p);
-    pack_stage_mark("lists: per site", stream, plane_b + (double)groups * SITES_PER_GROUP * 8.0,
-                    (double)L * 128.0 + (double)mb.tot_p * 12.0 + (double)L * 8.0 + (double)(mb.tot_q + std::min<unsigned long long>(L, mb.tot_p)) * 8.0);
+    // bytes as the memory system moves them (PMC, profiles/r06/pmc_site_lists_kernel.txt: 9.1 GB fetched, 1.7 GB written at 10 000 x 5 Mbp
+    // where the arrays alone are 6.3 + 0.8 GB): a listed (sample, group) pair's four allele words are four 16-byte gathers that pull a
+    // whole 128-byte line each (3.9 M pairs: 2.0 GB for 0.25 GB of words), and an n8 line leaves as 16-byte pieces, half a 32-byte sector each
+    const double flagged = (double)std::min<unsigned long long>(mb.tot_p, (unsigned long long)n * groups);
+    pack_stage_mark("lists: per site", stream, (mb.gram ? 0.0 : plane_b) + (double)groups * SITES_PER_GROUP * 8.0 + std::min(flagged * 4.0 * 128.0, 4.0 * plane_b),
+                    (mb.gram ? 0.0 : (double)L * 128.0 * 2.0) + (double)mb.tot_p * 12.0 + (double)L * 8.0 + (double)(mb.tot_q + std::min<unsigned long long>(L, mb.tot_p)) * 8.0);
     // the per-sample lists hold the w = 1 entries: c_p[s] of them
     hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, g->c_p, n, g->s_off);
     if (mb.tot_p) {
