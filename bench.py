@@ -895,7 +895,7 @@ def sensitivity(args, n, L, seed, days, dev, synth, torch, device, lib, value_de
         synth.pack_synthetic_device(a, seed=seed, **(synth_kw(P_PARTIAL_C4, "sparse") if name == "partial" else synth_kw(0.0, name)))
         r = timed(a)
         stages = dev.pack_stages()
-        classes, kernel, split, a_count, gram = a.site_classes, a.kernel, pair_split_ms(lib), a.count_source, a.nw_gram
+        classes, kernel, split, a_count, gram = a.site_classes, a.kernel, pair_split_ms(lib), a.count_source, a.nw_form
         lib.tracs_debug_force_site_classes(0)
         a.mark_packed()
         r0 = timed(a, per_call=False)
@@ -912,7 +912,8 @@ def sensitivity(args, n, L, seed, days, dev, synth, torch, device, lib, value_de
                      "site_classes": None if classes is None else dict(zip(("dense", "counted", "minority", "full"), classes)),
                      "kernel": kernel, "kernels_ms": None if not split else dict(zip(("pair", "lists", "count", "nn_lists"), split)),
                      "count_source": a_count,
-                     "n_x_listed_terms": "two one-plane passes on the matrix cores (U U^T - n n^T: nw_gram)" if gram else "walks of the sites' N lists",
+                     "n_x_listed_terms": {"u-pass": "two one-plane passes on the matrix cores (U U^T - n n^T: nw_gram)",
+                                          "ns-rows": "rows of the site-major N matrix summed per listed sample (nw_rows)"}.get(gram, "walks of the sites' N lists"),
                      "mean_d": r["cd"] / float(pairs), "checksum_d": r["cd"], "checksum_nn": r["cn"],
                      "generator": dict(WORKLOADS["sparse"], p_partial=P_PARTIAL_C4) if name == "partial" else WORKLOADS[name]}
     worst = min(out, key=lambda k: out[k]["pairs_per_s"])

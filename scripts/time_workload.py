@@ -37,7 +37,7 @@ print("first call %.1f ms" % ((time.perf_counter() - t) * 1e3))
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
 ev[0].record(); one(True); one(True); ev[1].record(); one(False); one(False); ev[2].record(); torch.cuda.synchronize()
 print("%s: per call %.2f ms, steady %.2f ms; classes %s kernel %s nw_gram %s count_source %s" % (
-    wl, ev[0].elapsed_time(ev[1]) / 2, ev[1].elapsed_time(ev[2]) / 2, aln.site_classes, aln.kernel, aln.nw_gram, aln.count_source))
+    wl, ev[0].elapsed_time(ev[1]) / 2, ev[1].elapsed_time(ev[2]) / 2, aln.site_classes, aln.kernel, aln.nw_form, aln.count_source))
 print("kernels ms (pair, lists, count, nn_lists):", B.pair_split_ms(lib))
 print("stages:", [(k, round(v, 2)) for k, v in dev.pack_stages()])
 print("list stats:", aln.list_stats, "mean d %.1f" % (float(d.sum().item()) / (n * (n - 1) / 2)))

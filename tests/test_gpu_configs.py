@@ -229,7 +229,7 @@ def test_config3_full_size_other_workloads(dev, oracle, workload):
     classes, src, ls = aln.site_classes, aln.count_source, aln.list_stats
     assert classes is not None and aln.kernel == ("mfma-general" if workload == "coverage" else "mfma"), (classes, aln.kernel)
     assert FULL_SIZE_PATHS[workload](classes, src, ls), (workload, classes, src, ls)
-    assert aln.nw_gram == (workload == "coverage")
+    assert aln.nw_gram == (workload == "coverage") and aln.nw_form == ("ns-rows" if workload == "coverage" else None)
     er, ec, ed, enn = oracle.pairsnp_arrays(host, n_threads=max(1, os.cpu_count() or 1))
     sub = torch.from_numpy(idx).cuda()
     dsub, nsub = d[sub][:, sub].cpu().numpy(), nn[sub][:, sub].cpu().numpy()

@@ -37,11 +37,15 @@ def _masked(n, L, seed, frac=0.3, mean_len=400, p_partial=0.0, mu=2e-4, lineages
     return seqs
 
 
+@pytest.mark.parametrize("rows", ["0", "1"], ids=["u-pass", "ns-rows"])
 @pytest.mark.parametrize("n,L,p_partial", [(70, 5000, 0.0), (70, 5000, 0.0005), (200, 40000, 0.0002), (131, 300001, 0.0001), (33, 129, 0.0),
                                            (700, 9000, 0.0), (260, 20000, 0.01)])
-def test_forced_on_ordinary_alignments(hiplib, oracle, monkeypatch, n, L, p_partial):
+def test_forced_on_ordinary_alignments(hiplib, oracle, monkeypatch, n, L, p_partial, rows):
+    """both ways the second form gets its N x listed terms: the U pass on the matrix cores, and the rows of the site-major N matrix
+    summed per listed sample inside the fix-up (minor_fixup_kernel<NSROWS>)"""
     from tracs_amd import device as dev
     monkeypatch.setenv("TRACS_NW_GRAM", "1")
+    monkeypatch.setenv("TRACS_NW_ROWS", rows)
     seqs = _structured(n, L, seed=n * 7 + L, p_partial=p_partial, mu=2e-4 if L > 1000 else 5e-3)
     cls = _check(dev, oracle, seqs, expect_classes=None)      # (a small general alignment may still prefer the VALU kernel: cost model)
     assert cls is None or (cls[2] > 0 and _check.nw_gram)
@@ -54,6 +58,7 @@ def test_chosen_for_alignments_masked_by_coverage(hiplib, oracle, monkeypatch, n
     """30 % N per sample in runs of its own: the list form is refused (every site dense), the matrix-core form takes over"""
     from tracs_amd import device as dev
     monkeypatch.delenv("TRACS_NW_GRAM", raising=False)
+    monkeypatch.delenv("TRACS_NW_ROWS", raising=False)
     seqs = _masked(n, L, seed=n + L, p_partial=p_partial, lineages=lineages)
     cls = _check(dev, oracle, seqs, expect_classes=None)
     print(n, L, p_partial, cls, _check.nw_gram)

@@ -59,6 +59,8 @@ struct tracs_alignment {
     uint4 *uplane = nullptr;                  // nw_gram: "is N, or listed with w = 1 at a minority site" (one plane per group, site_classes.hip)
     bool nw_gram = false;                     // the minority sites' N x listed terms come from two one-plane matrix passes (U U^T - n n^T),
                                               // their lists hold the listed samples only (no N lists)
+    bool nw_rows = false;                     // ... or, where the listed samples are few, from the rows of the site-major N matrix summed per listed
+                                              // sample (site_lists.hip, minor_fixup_kernel<NSROWS>): no U plane, no second matrix pass
     size_t L_var = 0, L_inv = 0, groups_var = 0, groups_inv = 0;
     size_t L_minor = 0, L_full = 0;           // minority sites (listed in `minor`; they are part of L_un or L_full as well);
                                               // sites without any N outside vplanes: +1 to every compared-sites count

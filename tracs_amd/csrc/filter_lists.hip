@@ -263,6 +263,11 @@ __global__ __launch_bounds__(256) void flt_ns_kernel(const uint4 *__restrict__ P
     }
 }
 
+void launch_ns_build(const uint4 *planes, size_t n_pad, unsigned groups, unsigned *ns, size_t ns_words, hipStream_t stream)
+{
+    hipLaunchKernelGGL(flt_ns_kernel, dim3(groups, (unsigned)(ns_words / 32)), dim3(256), 0, stream, planes, n_pad, groups, ns, ns_words);
+}
+
 // ---- thresholds of the binomial test ------------------------------------------------------------------------------------------
 // wanted rows: the d of this call's pairs
 __global__ __launch_bounds__(256) void flt_mark_kernel(const unsigned *__restrict__ d, size_t n_pairs, unsigned char *__restrict__ state)
@@ -930,7 +935,7 @@ static int filter_index_get(tracs_alignment *a, hipStream_t stream)
     auto soft_fail = [&]() { (void)hipGetLastError(); f->usable = false; return TRACS_OK; };
     const auto t0 = std::chrono::steady_clock::now();
     // fixed-size parts (kept from one build of the handle to the next)
-    const size_t nt_groups = (groups + 31) / 32 * 32, ns_words = (a->n_pad / 32 + 31) / 32 * 32;
+    const size_t nt_groups = (groups + 31) / 32 * 32, ns_words = ns_words_for(a->n_pad);
     f->nt_groups = nt_groups; f->ns_words = ns_words;
     if (!flt_alloc(&f->ref, (size_t)groups * 4 * sizeof(uint4)) || !flt_alloc(&f->dep_off, ((size_t)n + 1) * 8) ||
         !flt_alloc(&f->counters, 64) || !flt_alloc(&f->nt, (size_t)n * nt_groups * sizeof(uint4)) ||
@@ -974,8 +979,7 @@ static int filter_index_get(tracs_alignment *a, hipStream_t stream)
     hipLaunchKernelGGL(flt_nt_kernel, dim3((unsigned)(nt_groups / 32), (n + 63) / 64), dim3(256), 0, stream, a->planes, a->n_pad, n, groups,
                        f->nt, nt_groups);
     TRACS_HIP_CHECK(hipEventRecord(ev[5], stream));
-    hipLaunchKernelGGL(flt_ns_kernel, dim3(groups, (unsigned)(ns_words / 32)), dim3(256), 0, stream, a->planes, a->n_pad, groups, f->ns,
-                       ns_words);
+    launch_ns_build(a->planes, a->n_pad, groups, f->ns, ns_words, stream);
     TRACS_HIP_CHECK(hipEventRecord(ev[6], stream));
     TRACS_HIP_CHECK(hipGetLastError());
     TRACS_HIP_CHECK(hipStreamSynchronize(stream));

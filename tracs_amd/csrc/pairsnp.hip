@@ -860,7 +860,7 @@ int tracs_debug_alignment_site_classes(const tracs_alignment *a, uint64_t *out)
 }
 
 // 1 when the minority sites' N x listed terms of the last decided classes come from the matrix cores (nw_gram, site_classes.hip)
-int tracs_debug_alignment_nw_gram(const tracs_alignment *a) { return (a && a->classes_state == 1 && a->nw_gram) ? 1 : 0; }
+int tracs_debug_alignment_nw_gram(const tracs_alignment *a) { return (a && a->classes_state == 1 && a->nw_gram) ? (a->nw_rows ? 2 : 1) : 0; }
 
 // what completes the compared-sites counts of the last decided classes: out[0] = sites the counting pass reads on the matrix
 // cores, out[1] = 1 when that is the stored N plane in place, out[2] = sites whose N co-occurrences come from lists, out[3] = list
@@ -1167,7 +1167,8 @@ static int pairsnp_dense_impl(const tracs_alignment *a_, size_t row_begin, size_
     //   neither       sites with one N sample or none only add their part of |U| - c_i - c_j.
     // nw_gram (site_classes.hip): the same pass over the stored N plane also ADDS n n^T to the distances, and a second one over the
     // U plane subtracts U U^T -- the minority sites' N x listed terms; both run whether or not the caller wants nn.
-    const bool gram = classes && a->nw_gram;
+    // (nw_rows: the same terms from the rows of the site-major N matrix inside the fix-up -- the passes below then count compared sites only)
+    const bool gram = classes && a->nw_gram && !a->nw_rows;
     auto count_pass = [&](const int2 *tl, size_t ntl) -> int {
         if (!classes || (!ncomp && !gram) || (a->L_un == 0 && a->L_full == 0 && !gram)) { pair_mark(3, stream); return TRACS_OK; }
         const bool in_place = a->count_in_place;

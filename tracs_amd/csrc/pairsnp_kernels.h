@@ -146,7 +146,8 @@ struct MinorBuild {
     int long_p;                              // some minority site lists more than P_SHORT_MAX samples: its p list is a q line (else: no q lines at all)
     unsigned qw;                             // dwords per q line: 32, or 64 when the lists are long on average (site_lists.hip)
     unsigned long long tot_nnl;              // N samples at the NNL sites: list walks of one pass of nn_rows_add
-    int gram = 0;                            // no N lists at all: the minority sites' N x listed terms come from the matrix cores (site_classes.hip)
+    int gram = 0;                            // != 0: no N lists at all -- the minority sites' N x listed terms come from the matrix cores (1: U U^T - n n^T,
+                                             // site_classes.hip) or from the rows of the site-major N matrix (2: the builder also makes NS and the ranks' sites)
 };
 int minority_lists_build(tracs_alignment *a, const MinorBuild &mb, hipStream_t stream, int *ok);
 void minority_lists_free(tracs_alignment *a);
@@ -155,7 +156,46 @@ int minority_fixup(tracs_alignment *a, size_t row_begin, size_t row_end, size_t 
 int nn_rows_add(tracs_alignment *a, size_t row_begin, size_t row_end, size_t col_begin, unsigned *ncomp, size_t ld, int add_terms,
                 unsigned lu, hipStream_t stream);
 
+// NS[site][sample word]: the N plane bit-transposed to site-major, ns_words 32-sample words per site (a multiple of 32: whole 128-byte
+// lines): what the recombination filter asks "is j N at a site of i's list" (filter_lists.hip) and what the second form of the site
+// classes sums per listed sample (site_lists.hip, minor_fixup_kernel<NSROWS>)
+static inline size_t ns_words_for(size_t n_pad) { return (n_pad / 32 + 31) / 32 * 32; }
+void launch_ns_build(const uint4 *planes, size_t n_pad, unsigned groups, unsigned *ns, size_t ns_words, hipStream_t stream);   // filter_lists.hip
+
 #ifdef __HIPCC__
+// add the 32 one-bit values of `m` to 32 bit-sliced counters (plane j holds bit j of every counter); <= 255 adds between flushes
+__device__ __forceinline__ void sliced_add(unsigned (&p)[8], unsigned m)
+{
+    unsigned c = m;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { const unsigned t = p[j] & c; p[j] ^= c; c = t; }
+}
+
+// carry-save adder over 32 one-bit lanes: three addends of weight w -> sum (weight w) and carry (weight 2w); gfx950's v_bitop3_b32
+// evaluates either in one instruction (truth tables 0x96 = a ^ b ^ c, 0xE8 = majority)
+__device__ __forceinline__ void csa(unsigned &hi, unsigned &lo, unsigned a, unsigned b, unsigned c)
+{
+    lo = __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+    hi = __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8);
+}
+
+// add eight 32-lane one-bit values to the bit-sliced counters: a Harley-Seal tree folds them into the planes of weight 1, 2, 4 and
+// ONE carry of weight 8, which then ripples through planes 3..7 -- 24 instructions for eight addends (sliced_add: 16 each)
+__device__ __forceinline__ void sliced_add8(unsigned (&p)[8], const unsigned (&x)[8])
+{
+    unsigned twos_a, twos_b, fours_a, fours_b, eights;
+    csa(twos_a, p[0], p[0], x[0], x[1]);
+    csa(twos_b, p[0], p[0], x[2], x[3]);
+    csa(fours_a, p[1], p[1], twos_a, twos_b);
+    csa(twos_a, p[0], p[0], x[4], x[5]);
+    csa(twos_b, p[0], p[0], x[6], x[7]);
+    csa(fours_b, p[1], p[1], twos_a, twos_b);
+    csa(eights, p[2], p[2], fours_a, fours_b);
+    unsigned c = eights;
+#pragma unroll
+    for (int j = 3; j < 8; j++) { const unsigned t = p[j] & c; p[j] ^= c; c = t; }
+}
+
 // 32 x 32 bit transpose across the 32 lanes of a half wave: lane k holds row k; afterwards bit j of lane k is bit k of what lane j
 // held.  Five butterfly steps (j = 16, 8, 4, 2, 1): lanes k and k ^ j exchange words (ds_swizzle, bit mode) and swap the high
 // half-blocks of the lower lane's word with the low half-blocks of the higher lane's -- per lane: keep the bits of K, take the

@@ -48,39 +48,6 @@
 
 namespace tracs {
 
-// add the 32 one-bit values of `m` to 32 bit-sliced counters (plane j holds bit j of every counter); <= 255 adds between flushes
-__device__ __forceinline__ void sliced_add(unsigned (&p)[8], unsigned m)
-{
-    unsigned c = m;
-#pragma unroll
-    for (int j = 0; j < 8; j++) { const unsigned t = p[j] & c; p[j] ^= c; c = t; }
-}
-
-// carry-save adder over 32 one-bit lanes: three addends of weight w -> sum (weight w) and carry (weight 2w); gfx950's v_bitop3_b32
-// evaluates either in one instruction (truth tables 0x96 = a ^ b ^ c, 0xE8 = majority)
-__device__ __forceinline__ void csa(unsigned &hi, unsigned &lo, unsigned a, unsigned b, unsigned c)
-{
-    lo = __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
-    hi = __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8);
-}
-
-// add eight 32-lane one-bit values to the bit-sliced counters: a Harley-Seal tree folds them into the planes of weight 1, 2, 4 and
-// ONE carry of weight 8, which then ripples through planes 3..7 -- 24 instructions for eight addends (sliced_add: 16 each)
-__device__ __forceinline__ void sliced_add8(unsigned (&p)[8], const unsigned (&x)[8])
-{
-    unsigned twos_a, twos_b, fours_a, fours_b, eights;
-    csa(twos_a, p[0], p[0], x[0], x[1]);
-    csa(twos_b, p[0], p[0], x[2], x[3]);
-    csa(fours_a, p[1], p[1], twos_a, twos_b);
-    csa(twos_a, p[0], p[0], x[4], x[5]);
-    csa(twos_b, p[0], p[0], x[6], x[7]);
-    csa(fours_b, p[1], p[1], twos_a, twos_b);
-    csa(eights, p[2], p[2], fours_a, fours_b);
-    unsigned c = eights;
-#pragma unroll
-    for (int j = 3; j < 8; j++) { const unsigned t = p[j] & c; p[j] ^= c; c = t; }
-}
-
 struct GroupWords { unsigned x[4], y[4], one[4], some[4], isn[4], bad[4]; };
 
 // what pass 2 needs of a sample's 32-site word: diff = listed (not N and not exactly the reference base, given one-hot in ra..rt),
@@ -554,7 +521,7 @@ void site_classes_free(tracs_alignment *a)
     minority_lists_free(a);
     a->c_counted = nullptr;
     a->vplanes = a->iplanes = a->uplane = nullptr;
-    a->nw_gram = false;
+    a->nw_gram = a->nw_rows = false;
     pack_release(a);                                       // vplanes, iplanes, N counts, minority lists: one arena
     a->L_var = a->L_inv = a->groups_var = a->groups_inv = 0;
     a->L_minor = a->L_full = a->L_un = a->L_nnl = 0;
@@ -780,6 +747,7 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
                            a->planes + 4 * a->n_pad, mask_of(M_UN), a->n_pad, (unsigned)a->n, groups, a->c_counted);
     if (gi) stage_mark("re-pack counted sites", stream, plane_b, (double)ibytes);
     else if (in_place || (L_un && !counts_with_bitmaps)) stage_mark("N counts per sample", stream, plane_b, 0.0);
+    bool gram_rows = false;
     if (L_lst) {
         // the lists (site_lists.hip): per-site lists from the N plane and the flagged samples, the rows' N bitmaps from the N plane
         int built = 0;
@@ -790,7 +758,14 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
         mb.sites = L_lst; mb.tot_p = tot_p; mb.tot_o = tot_o; mb.tot_nnl = tot_nnl; mb.baseQ = off64 + 6 * groups; mb.tot_q = tot_q; mb.long_p = long_p ? 1 : 0;
         mb.max_gp = tot[14];
         mb.qw = qw;
-        mb.gram = gram ? 1 : 0;
+        // second form: the N x listed terms from the rows of the site-major N matrix, summed per listed sample (|W| x ns_words x 4 bytes from
+        // HBM at ~4.5 TB/s, + the matrix itself: one read and one write of a plane), when that is less than a one-plane pass over every site
+        // (1.5e-13 ms per site and pair of samples) + the U plane (four plane reads); tot_p bounds |W| from above.  TRACS_NW_ROWS=0|1 forces.
+        const int env_rows = [] { const char *e = std::getenv("TRACS_NW_ROWS"); return e ? std::atoi(e) : -1; }();
+        const double t_rows = (double)tot_p * (double)ns_words_for(a->n_pad) * 4.0 / 4.5e9 + 2.0 * plane_b / 5.0e9;
+        const double t_upass = 1.5e-13 * (double)a->L * (double)a->n * (double)a->n + 4.0 * plane_b / 5.0e9;
+        gram_rows = gram && (env_rows >= 0 ? env_rows == 1 : t_rows < t_upass);
+        mb.gram = gram ? (gram_rows ? 2 : 1) : 0;
         mb.n_rows = a->n_row_hint;
         for (int k = 0; k < 4; k++) mb.rows[k] = (unsigned)std::min<size_t>(a->row_hint[k], a->n);
         rc = minority_lists_build(a, mb, stream, &built);
@@ -802,7 +777,7 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
         }
     }
     const bool gram_on = gram && L_minor > 0 && a->lists != nullptr;
-    if (gram_on) {
+    if (gram_on && !gram_rows) {
         const size_t ubytes = class_plane_bytes(a, groups, 1, PAD_GROUPS);
         if (pack_alloc(a, ubytes, reinterpret_cast<void **>(&a->uplane)) != hipSuccess) return soft_fail();
         // (the pad groups and the slack behind them: zero)
@@ -819,6 +794,7 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     a->nn_visits = tot[9]; a->list_entries_n = (L_lst ? (unsigned long long)L_lst + tot_o : 0ull); a->list_entries_p = tot_p; a->nn_walks = tot_nnl; a->fix_walks = tot[11];
     a->count_in_place = in_place;
     a->nw_gram = gram_on;
+    a->nw_rows = gram_on && gram_rows;
     a->classes_cons = consensus;
     a->classes_state = 1;
     return TRACS_OK;

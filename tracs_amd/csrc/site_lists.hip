@@ -56,6 +56,10 @@ struct SiteLists {
     unsigned max_row = 0;                      // the most N sites (outside the dense class) any sample has: row splits of nn_rows_kernel
     unsigned rows[4] = {0, 0, 0, 0};           // T holds the rows of these ranges only (n_rows of them; 0: all)
     int n_rows = 0;
+    // nw_rows (the second form of the classes without its U pass): the N plane site-major and the site of every rank
+    unsigned *ns = nullptr;                    // [site][ns_words] sample bits (pairsnp_kernels.h: launch_ns_build)
+    size_t ns_words = 0;
+    unsigned *site_of = nullptr;               // [sites]: site of the list rank
 };
 constexpr int ENT_SHIFT = 5;                   // entries: index << 5 | w << 4 | 4-bit allele mask
 constexpr unsigned ENT_HOLE = 0xFFFFFFFFu;     // E: (sample, entry) by list position; sample = ENT_HOLE where the list's entry has w = 0
@@ -893,13 +897,20 @@ __global__ __launch_bounds__(TRACS_NN_THREADS) void nn_rows_kernel(const uint4 *
 // GRAM (site_classes.hip, nw_gram): the third and fourth sums come from the matrix cores as (U U^T - n n^T)(x, j) = w n^T + n w^T + w w^T
 // over the minority sites -- phase B does not exist, and the both-listed term of phase A gives w_x w_j back: [masks disjoint] - w_x - w_j
 // + w_x w_j = [masks disjoint] - 1 for the walker's w_x = 1.
-template <bool CLAMP, unsigned QW, bool GRAM>
+// NSROWS (nw_rows): phase B without N lists -- sum_s w_x(s) n_y(s) over the sites x is listed at (w = 1) is the column sum of those
+// sites' rows of the site-major N matrix NS: thread w of a group of threads owns the 32 samples of word w, adds the words of x's sites
+// into bit-sliced counters in registers (the classification's carry-save tree: 3 instructions per word) and takes them off row[] every
+// 248 sites.  The rows stream from HBM once per listed (sample, site): |W| x ns_words x 4 bytes -- where W is sparse (0.2 % of the cells
+// on bench.py's coverage workload: 96 GB) a fraction of the U U^T pass it replaces.
+template <bool CLAMP, unsigned QW, bool GRAM, bool NSROWS = false>
 __global__ __launch_bounds__(1024) void minor_fixup_kernel(const unsigned long long *__restrict__ s_off, const unsigned *__restrict__ s_ent,
                                                            const unsigned long long *__restrict__ p_off, const unsigned *__restrict__ p_ent,
                                                            const unsigned *__restrict__ qd,
                                                            const uint4 *__restrict__ lines, const unsigned *__restrict__ c_p, unsigned n,
                                                            unsigned row_begin, unsigned row_end, unsigned col_begin, unsigned chunk,
-                                                           unsigned *__restrict__ dist, size_t ld, unsigned *__restrict__ S, size_t s_pitch)
+                                                           unsigned *__restrict__ dist, size_t ld, unsigned *__restrict__ S, size_t s_pitch,
+                                                           const unsigned *__restrict__ ns = nullptr, size_t ns_words = 0,
+                                                           const unsigned *__restrict__ site_of = nullptr)
 {
     extern __shared__ unsigned row[];
     const unsigned x = row_begin + blockIdx.x;
@@ -1003,7 +1014,48 @@ __global__ __launch_bounds__(1024) void minor_fixup_kernel(const unsigned long l
         wave_sync();
     }
     // phase B: N-list walks, both triangles: column y goes to row[y - c0]
-    if constexpr (!GRAM) {
+    if constexpr (NSROWS) {
+        __syncthreads();                                       // (phase A's atomics on row[] are done: the flush below reads and writes it plainly per column)
+        const unsigned w0 = c0 >> 5, w1 = (c1 + 31u) >> 5;     // the words of this chunk's columns
+        const unsigned tpg = (w1 - w0 + 63u) / 64u * 64u, ngrp = max(1u, blockDim.x / tpg);
+        const unsigned grp = threadIdx.x / tpg, wi = w0 + threadIdx.x % tpg;
+        const bool active = grp < ngrp && wi < w1 && (upper || lower);
+        unsigned pl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned since = 0;
+        auto flush = [&]() {
+#pragma unroll 4
+            for (unsigned b = 0; b < 32u; b++) {
+                unsigned c = 0;
+#pragma unroll
+                for (int jx = 0; jx < 8; jx++) c |= ((pl[jx] >> b) & 1u) << jx;
+                const unsigned y = wi * 32u + b;
+                if (c && y >= c0 && y < c1) atomicAdd(&row[y - c0], 0u - c);
+            }
+#pragma unroll
+            for (int jx = 0; jx < 8; jx++) pl[jx] = 0;
+            since = 0;
+        };
+        if (active) {
+            const unsigned *col = ns + wi;
+            unsigned long long e = e0 + grp;
+            for (; e + 7ull * ngrp < e1; e += 8ull * ngrp) {
+                unsigned xs[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const unsigned ent = s_ent[e + (unsigned long long)k * ngrp];
+                    xs[k] = __builtin_nontemporal_load(col + (size_t)site_of[(ent & ~ENT_LONG) >> ENT_SHIFT] * ns_words);
+                }
+                sliced_add8(pl, xs);
+                if (++since == 31u) flush();
+            }
+            for (; e < e1; e += ngrp) {
+                const unsigned ent = s_ent[e];
+                sliced_add(pl, __builtin_nontemporal_load(col + (size_t)site_of[(ent & ~ENT_LONG) >> ENT_SHIFT] * ns_words));
+                if (++since >= 24u) flush();                   // (single adds count one each: 8 x 31 + these stay below 255)
+            }
+            if (since) flush();
+        }
+    } else if constexpr (!GRAM) {
         Walk<CLAMP> W;
         W.init(lines, row + chunk + 64 + wave * (WALK_LDS_PER_WAVE / 4), lane);
         W.neg4lo = 0u - 4u * c0; W.dump4 = 4u * (span + lane); W.val = 0xFFFFFFFFu; W.cut = 0u;
@@ -1048,6 +1100,22 @@ __global__ __launch_bounds__(256) void transpose_add_kernel(const unsigned *__re
         const unsigned y = yb + ty + 8 * k, x = xb + tx;
         const unsigned v = tile[tx][ty + 8 * k];
         if (v && x < n && y < row_end && y < x && x >= col_begin) dist[(size_t)y * ld + x] += v;
+    }
+}
+
+// site_of[rank] = the site of the list rank: the set bits of the groups' list masks in site order
+__global__ __launch_bounds__(256) void site_of_rank_kernel(const uint4 *__restrict__ mask, const unsigned *__restrict__ off, size_t groups,
+                                                           unsigned *__restrict__ site_of)
+{
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= groups) return;
+    const uint4 m4 = mask[g];
+    const unsigned m[4] = {m4.x, m4.y, m4.z, m4.w};
+    unsigned o = off[g];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        unsigned xw = m[w];
+        while (xw) { const unsigned b = __ffs(xw) - 1; site_of[o++] = (unsigned)(g * SITES_PER_GROUP + w * 32 + b); xw &= xw - 1; }
     }
 }
 
@@ -1145,6 +1213,15 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb_, hipStream_t 
         pack_stage_mark("N bitmaps of the rows", stream, plane_b, rows * (double)g->tgroups * sizeof(uint4));
         SL_TRY(hipMemcpyAsync(&g->max_row, d_max, 4, hipMemcpyDeviceToHost, stream));       // (read after the caller's synchronisation)
     }
+    if (mb.gram == 2) {
+        // nw_rows: the N plane site-major, and the site of every rank (class_list_kernel's job, here over the mask of the sites with lists)
+        g->ns_words = ns_words_for(a->n_pad);
+        SL_TRY(pack_alloc(a, groups * 128 * g->ns_words * 4, reinterpret_cast<void **>(&g->ns)));
+        SL_TRY(pack_alloc(a, std::max<size_t>(L, 1) * 4, reinterpret_cast<void **>(&g->site_of)));
+        launch_ns_build(a->planes, a->n_pad, (unsigned)groups, g->ns, g->ns_words, stream);
+        hipLaunchKernelGGL(site_of_rank_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, stream, g->lst_mask, g->off_lst, groups, g->site_of);
+        pack_stage_mark("N plane site-major (NS)", stream, plane_b, (double)groups * 128.0 * (double)g->ns_words * 4.0);
+    }
     SL_TRY(hipGetLastError());
 #undef SL_TRY
     a->lists = g;
@@ -1210,10 +1287,12 @@ int minority_fixup(tracs_alignment *a, size_t row_begin, size_t row_end, size_t 
     static bool attr_set[64] = {false};
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
         const int fix_lds = (int)ROW_CHUNK_MAX * 4 + 256 + 16 * (int)WALK_LDS_PER_WAVE;
-        const void *fns[8] = {reinterpret_cast<const void *>(minor_fixup_kernel<true, 32, false>), reinterpret_cast<const void *>(minor_fixup_kernel<false, 32, false>),
-                              reinterpret_cast<const void *>(minor_fixup_kernel<true, 64, false>), reinterpret_cast<const void *>(minor_fixup_kernel<false, 64, false>),
-                              reinterpret_cast<const void *>(minor_fixup_kernel<true, 32, true>), reinterpret_cast<const void *>(minor_fixup_kernel<false, 32, true>),
-                              reinterpret_cast<const void *>(minor_fixup_kernel<true, 64, true>), reinterpret_cast<const void *>(minor_fixup_kernel<false, 64, true>)};
+        const void *fns[12] = {reinterpret_cast<const void *>(minor_fixup_kernel<true, 32, false>), reinterpret_cast<const void *>(minor_fixup_kernel<false, 32, false>),
+                               reinterpret_cast<const void *>(minor_fixup_kernel<true, 64, false>), reinterpret_cast<const void *>(minor_fixup_kernel<false, 64, false>),
+                               reinterpret_cast<const void *>(minor_fixup_kernel<true, 32, true>), reinterpret_cast<const void *>(minor_fixup_kernel<false, 32, true>),
+                               reinterpret_cast<const void *>(minor_fixup_kernel<true, 64, true>), reinterpret_cast<const void *>(minor_fixup_kernel<false, 64, true>),
+                               reinterpret_cast<const void *>(minor_fixup_kernel<true, 32, false, true>), reinterpret_cast<const void *>(minor_fixup_kernel<false, 32, false, true>),
+                               reinterpret_cast<const void *>(minor_fixup_kernel<true, 64, false, true>), reinterpret_cast<const void *>(minor_fixup_kernel<false, 64, false, true>)};
         for (const void *fn : fns) TRACS_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, fix_lds));
         attr_set[dev] = true;
     }
@@ -1223,14 +1302,19 @@ int minority_fixup(tracs_alignment *a, size_t row_begin, size_t row_end, size_t 
     const int rc = workspace_get(46, (n - row_begin) * s_pitch * sizeof(unsigned), reinterpret_cast<void **>(&S));
     if (rc) return rc;
     const dim3 grid((unsigned)(n - row_begin), (unsigned)((n + chunk - 1) / chunk));
-#define TRACS_FIXUP_LAUNCH(CL, QWV) hipLaunchKernelGGL((minor_fixup_kernel<CL, QWV, GR>), grid, dim3(1024), lds, stream, g->s_off, g->s_ent, g->p_off, g->p_ent, \
-        reinterpret_cast<const unsigned *>(g->qlines), g->lines, g->c_p, (unsigned)n, (unsigned)row_begin, (unsigned)row_end, (unsigned)col_begin, chunk, dist, ld, S, s_pitch)
-    if (a->nw_gram) {
-        constexpr bool GR = true;
+#define TRACS_FIXUP_LAUNCH(CL, QWV) hipLaunchKernelGGL((minor_fixup_kernel<CL, QWV, GR, NR>), grid, dim3(1024), lds, stream, g->s_off, g->s_ent, g->p_off, g->p_ent, \
+        reinterpret_cast<const unsigned *>(g->qlines), g->lines, g->c_p, (unsigned)n, (unsigned)row_begin, (unsigned)row_end, (unsigned)col_begin, chunk, dist, ld, S, s_pitch, \
+        g->ns, g->ns_words, g->site_of)
+    if (a->nw_rows) {
+        constexpr bool GR = false, NR = true;
+        if (grid.y == 1) { if (g->qw == 64u) TRACS_FIXUP_LAUNCH(false, 64); else TRACS_FIXUP_LAUNCH(false, 32); }
+        else { if (g->qw == 64u) TRACS_FIXUP_LAUNCH(true, 64); else TRACS_FIXUP_LAUNCH(true, 32); }
+    } else if (a->nw_gram) {
+        constexpr bool GR = true, NR = false;
         if (grid.y == 1) { if (g->qw == 64u) TRACS_FIXUP_LAUNCH(false, 64); else TRACS_FIXUP_LAUNCH(false, 32); }
         else { if (g->qw == 64u) TRACS_FIXUP_LAUNCH(true, 64); else TRACS_FIXUP_LAUNCH(true, 32); }
     } else {
-        constexpr bool GR = false;
+        constexpr bool GR = false, NR = false;
         if (grid.y == 1) { if (g->qw == 64u) TRACS_FIXUP_LAUNCH(false, 64); else TRACS_FIXUP_LAUNCH(false, 32); }
         else { if (g->qw == 64u) TRACS_FIXUP_LAUNCH(true, 64); else TRACS_FIXUP_LAUNCH(true, 32); }
     }

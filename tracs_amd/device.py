@@ -118,6 +118,12 @@ class Alignment:
         return bool(self._L.tracs_debug_alignment_nw_gram(self._h))
 
     @property
+    def nw_form(self):
+        """None / 'u-pass' (U U^T - n n^T: two one-plane matrix passes) / 'ns-rows' (the rows of the site-major N matrix summed per listed
+        sample inside the fix-up: one matrix pass, for the compared sites alone) -- how the second form of the classes gets its terms."""
+        return {0: None, 1: "u-pass", 2: "ns-rows"}.get(self._L.tracs_debug_alignment_nw_gram(self._h))
+
+    @property
     def count_source(self):
         """(sites the counting pass reads on the matrix cores, in_place, sites whose N co-occurrences come from lists) for an
         alignment on site classes: in_place = the stored N plane of every site, read where it lies (the pair kernels then write d
