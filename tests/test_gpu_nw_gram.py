@@ -70,3 +70,33 @@ def test_chosen_for_alignments_masked_by_coverage(hiplib, oracle, monkeypatch, n
     monkeypatch.setenv("TRACS_NW_GRAM", "0")
     _check(dev, oracle, seqs, expect_classes=None)
     assert not _check.nw_gram
+
+
+@pytest.mark.parametrize("rows", ["0", "1"], ids=["u-pass", "ns-rows"])
+@pytest.mark.parametrize("n,p_partial", [(40000, 0.0003), (65600, 0.0)])
+def test_two_column_chunks(hiplib, oracle, monkeypatch, n, p_partial, rows):
+    """beyond 36 800 samples a row of the pair matrix is two column chunks of the fix-up (the NS rows' words are cut with them), beyond
+    65 536 the per-site pass takes every group in pieces: row panels against the oracle on a subset of the columns"""
+    import torch
+    from tracs_amd import device as dev, synth
+    monkeypatch.setenv("TRACS_NW_GRAM", "1")
+    monkeypatch.setenv("TRACS_NW_ROWS", rows)
+    L = 512
+    seqs = synth.alignment(n, L, seed=321, mu_lineage=2e-3, mu_sample=3e-4, n_lineages=9, p_n=0.05, p_partial=p_partial)
+    aln = dev.Alignment(n, L)
+    aln.pack(seqs)
+    rng = np.random.default_rng(6)
+    others = np.sort(rng.choice(n, 1200, replace=False))
+    for r0, r1 in ((10, 26), (36790, 36806), (n - 16, n)):
+        dp = torch.zeros((r1 - r0, n), dtype=torch.int32, device="cuda")
+        npn = torch.zeros_like(dp)
+        dev.pairsnp_dense(aln, dp, npn, row_begin=r0, row_end=r1, base_row=r0)
+        assert aln.site_classes is not None and aln.nw_form == ("ns-rows" if rows == "1" else "u-pass"), (aln.site_classes, aln.nw_form)
+        sub = np.unique(np.concatenate([np.arange(r0, r1), others]))
+        er, ec, ed, enn = oracle.pairsnp_arrays(seqs[sub], n_threads=16)
+        gi, gj = sub[er.astype(np.int64)], sub[ec.astype(np.int64)]
+        sel = (gi >= r0) & (gi < r1)
+        dh, nh = dp.cpu().numpy(), npn.cpu().numpy()
+        assert np.array_equal(dh[gi[sel] - r0, gj[sel]], ed[sel].astype(np.int32)), (r0, r1)
+        assert np.array_equal(nh[gi[sel] - r0, gj[sel]], enn[sel].astype(np.int32)), (r0, r1)
+    aln.close()

@@ -1017,43 +1017,47 @@ __global__ __launch_bounds__(1024) void minor_fixup_kernel(const unsigned long l
     if constexpr (NSROWS) {
         __syncthreads();                                       // (phase A's atomics on row[] are done: the flush below reads and writes it plainly per column)
         const unsigned w0 = c0 >> 5, w1 = (c1 + 31u) >> 5;     // the words of this chunk's columns
-        const unsigned tpg = (w1 - w0 + 63u) / 64u * 64u, ngrp = max(1u, blockDim.x / tpg);
-        const unsigned grp = threadIdx.x / tpg, wi = w0 + threadIdx.x % tpg;
-        const bool active = grp < ngrp && wi < w1 && (upper || lower);
-        unsigned pl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        unsigned since = 0;
-        auto flush = [&]() {
+        // groups of threads share the sites of x; a chunk of more words than the workgroup has threads takes several passes
+        const unsigned tpg = min((w1 - w0 + 63u) / 64u * 64u, blockDim.x), ngrp = max(1u, blockDim.x / tpg);
+        const unsigned grp = threadIdx.x / tpg;
+        for (unsigned wb = w0; wb < w1; wb += tpg) {
+            const unsigned wi = wb + threadIdx.x % tpg;
+            const bool active = grp < ngrp && wi < w1 && (upper || lower);
+            unsigned pl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            unsigned since = 0;
+            auto flush = [&]() {
 #pragma unroll 4
-            for (unsigned b = 0; b < 32u; b++) {
-                unsigned c = 0;
+                for (unsigned b = 0; b < 32u; b++) {
+                    unsigned c = 0;
 #pragma unroll
-                for (int jx = 0; jx < 8; jx++) c |= ((pl[jx] >> b) & 1u) << jx;
-                const unsigned y = wi * 32u + b;
-                if (c && y >= c0 && y < c1) atomicAdd(&row[y - c0], 0u - c);
-            }
-#pragma unroll
-            for (int jx = 0; jx < 8; jx++) pl[jx] = 0;
-            since = 0;
-        };
-        if (active) {
-            const unsigned *col = ns + wi;
-            unsigned long long e = e0 + grp;
-            for (; e + 7ull * ngrp < e1; e += 8ull * ngrp) {
-                unsigned xs[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const unsigned ent = s_ent[e + (unsigned long long)k * ngrp];
-                    xs[k] = __builtin_nontemporal_load(col + (size_t)site_of[(ent & ~ENT_LONG) >> ENT_SHIFT] * ns_words);
+                    for (int jx = 0; jx < 8; jx++) c |= ((pl[jx] >> b) & 1u) << jx;
+                    const unsigned y = wi * 32u + b;
+                    if (c && y >= c0 && y < c1) atomicAdd(&row[y - c0], 0u - c);
                 }
-                sliced_add8(pl, xs);
-                if (++since == 31u) flush();
+#pragma unroll
+                for (int jx = 0; jx < 8; jx++) pl[jx] = 0;
+                since = 0;
+            };
+            if (active) {
+                const unsigned *col = ns + wi;
+                unsigned long long e = e0 + grp;
+                for (; e + 7ull * ngrp < e1; e += 8ull * ngrp) {
+                    unsigned xs[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const unsigned ent = s_ent[e + (unsigned long long)k * ngrp];
+                        xs[k] = __builtin_nontemporal_load(col + (size_t)site_of[(ent & ~ENT_LONG) >> ENT_SHIFT] * ns_words);
+                    }
+                    sliced_add8(pl, xs);
+                    if (++since == 31u) flush();
+                }
+                for (; e < e1; e += ngrp) {
+                    const unsigned ent = s_ent[e];
+                    sliced_add(pl, __builtin_nontemporal_load(col + (size_t)site_of[(ent & ~ENT_LONG) >> ENT_SHIFT] * ns_words));
+                    if (++since >= 24u) flush();               // (single adds count one each: 8 x 31 + these stay below 255)
+                }
+                if (since) flush();
             }
-            for (; e < e1; e += ngrp) {
-                const unsigned ent = s_ent[e];
-                sliced_add(pl, __builtin_nontemporal_load(col + (size_t)site_of[(ent & ~ENT_LONG) >> ENT_SHIFT] * ns_words));
-                if (++since >= 24u) flush();                   // (single adds count one each: 8 x 31 + these stay below 255)
-            }
-            if (since) flush();
         }
     } else if constexpr (!GRAM) {
         Walk<CLAMP> W;
