@@ -322,14 +322,16 @@ void tracs_warm_up(void);
  *                         given, COO extraction incl. P(direct) and E(K), one device-to-host pass in batches, rows formatted and
  *                         appended to `path` (the caller has written the header) in the reference's format and order.  days == NULL:
  *                         no metadata ("NA" for delta / P / E(K), 0 in the filtered column, :240-258); else "NA" in the filtered
- *                         column (:204) and, k_max >= 0, only rows with k_max >= E(K) (:222).  The recombination filter (--filter)
- *                         is not part of this path (tracs_pairsnp).                                                             */
+ *                         column (:204) and, k_max >= 0, only rows with k_max >= E(K) (:222).  filter != 0 (--filter): the emitted
+ *                         pairs go through tracs_filter_recomb_pairs (src/pairsnp.hpp:405-413), the filtered column holds their
+ *                         filtered distances, and P(direct) / E(K) are those of the FILTERED distance (tracs/distance.py:183-193),
+ *                         evaluated per emitted pair (tracs_trans_dist_device) instead of on the panel.                          */
 typedef struct tracs_distance tracs_distance;
 int tracs_distance_open(const char *const *fasta, int n_fasta, tracs_distance **out);
 size_t tracs_distance_nseq(const tracs_distance *h);
 const char *tracs_distance_name(const tracs_distance *h, size_t i);
 int tracs_distance_run(tracs_distance *h, int dist, const int32_t *days, double lamb, double beta, double precision, double k_max,
-                       const char *path, const char *ref, uint64_t *rows_written, uint64_t *n_pairs);
+                       const char *path, const char *ref, int filter, uint64_t *rows_written, uint64_t *n_pairs);
 void tracs_distance_free(tracs_distance *h);
 
 /* Rows of `tracs distance`'s CSV appended to path (tracs/distance.py:206-258; the caller writes the header, :157):

@@ -22,6 +22,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("samples", type=int)
 ap.add_argument("sites", type=int)
 ap.add_argument("-D", dest="thr", type=int, default=None)
+ap.add_argument("--filter", action="store_true", help="tracs distance --filter (the recombination filter on every emitted pair)")
 ap.add_argument("--dir", default=None)
 ap.add_argument("--keep", action="store_true")
 args = ap.parse_args()
@@ -51,6 +52,8 @@ csv = os.path.join(tmp, "out.csv")
 cmd = [sys.executable, "-m", "tracs_amd", "distance", "--msa", fa, "--meta", meta, "-o", csv, "--loglevel", "ERROR"]
 if args.thr is not None:
     cmd += ["-D", str(args.thr)]
+if args.filter:
+    cmd += ["--filter"]
 t0 = time.perf_counter()
 rc = subprocess.run(cmd, cwd=root, capture_output=True, text=True, env=dict(os.environ, TRACS_STAGE_TRACE="1"))
 wall_first = time.perf_counter() - t0                           # the first run on a fresh box pages the libraries in
@@ -71,7 +74,7 @@ with open(csv, "rb") as fh:
 rows -= 1
 pairs = n * (n - 1) // 2
 fasta_bytes = os.path.getsize(fa)
-out = {"samples": n, "sites": L, "pairs": pairs, "snp_threshold": args.thr, "fasta_GB": fasta_bytes / 1e9, "csv_GB": os.path.getsize(csv) / 1e9,
+out = {"samples": n, "sites": L, "pairs": pairs, "snp_threshold": args.thr, "filter": bool(args.filter), "fasta_GB": fasta_bytes / 1e9, "csv_GB": os.path.getsize(csv) / 1e9,
        "csv_rows": rows, "command_seconds": wall, "command_seconds_first_run_on_the_box": wall_first, "pairs_per_s_end_to_end": pairs / wall, "stages": stages,
        "accounted_seconds": sum(s["seconds"] for s in stages if not s["stage"].startswith(("pairsnp (total", "[sum]"))),
        "fasta_write_seconds_setup": t_write,

@@ -199,8 +199,8 @@ def test_pairsnp_fixture(api, golden_dir, tmp_path):
 @pytest.mark.parametrize("path", ["device", "arrays"])
 def test_cli_end_to_end_vs_reference_driver(api, golden_dir, tmp_path, monkeypatch, path):
     """`tracs distance` + `tracs cluster` on the GPU against the CSVs the reference's own drivers wrote -- through the device-resident
-    path of the single-GPU command (tracs_distance_open / _run: results on the device until the CSV rows; the --filter runs take the
-    array path either way) and through the array path (TRACS.pairsnp-shaped arrays -> calculate_trans_prob -> rows)."""
+    path of the single-GPU command (tracs_distance_open / _run: results on the device until the CSV rows, the --filter runs included:
+    the filter and the transmission model of the filtered distances per emitted pair on the device) and through the array path (TRACS.pairsnp-shaped arrays -> calculate_trans_prob -> rows)."""
     if path == "arrays":
         monkeypatch.setenv("TRACS_DISTANCE_ARRAYS", "1")
     else:
@@ -244,7 +244,8 @@ def test_cli_device_path_in_small_batches_equals_array_path(api, tmp_path):
     synth.write_fasta(str(db), seqs[150:], names=names[150:])
     iso, _ = synth.dates(n, seed=37, span_days=300)
     meta.write_text("name,date\n" + "".join("%s,%s\n" % (a, b) for a, b in zip(names, iso)))
-    for tag, extra in (("meta", ["--meta", str(meta)]), ("thr", ["--meta", str(meta), "-D", "150", "-K", "300", "--msa-db", str(db)]), ("nometa", [])):
+    for tag, extra in (("meta", ["--meta", str(meta)]), ("thr", ["--meta", str(meta), "-D", "150", "-K", "300", "--msa-db", str(db)]), ("nometa", []),
+                       ("filter", ["--meta", str(meta), "--filter"]), ("filter_thr_nometa", ["--filter", "-D", "150", "--msa-db", str(db)])):
         outs = {}
         for path in ("device", "arrays"):
             out = tmp_path / ("%s_%s.csv" % (tag, path))

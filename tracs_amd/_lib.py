@@ -139,7 +139,7 @@ def load():
     L.tracs_distance_name.restype = C.c_char_p
     L.tracs_distance_name.argtypes = [vp, sz]
     L.tracs_distance_run.restype = C.c_int
-    L.tracs_distance_run.argtypes = [vp, C.c_int, C.POINTER(C.c_int32), dbl, dbl, dbl, dbl, C.c_char_p, C.c_char_p, u64p, u64p]
+    L.tracs_distance_run.argtypes = [vp, C.c_int, C.POINTER(C.c_int32), dbl, dbl, dbl, dbl, C.c_char_p, C.c_char_p, C.c_int, u64p, u64p]
     L.tracs_warm_up.restype = None
     L.tracs_warm_up.argtypes = []
     L.tracs_distance_free.restype = None

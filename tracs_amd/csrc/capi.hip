@@ -399,8 +399,18 @@ size_t tracs_distance_nseq(const tracs_distance *h) { return h ? h->names.size()
 const char *tracs_distance_name(const tracs_distance *h, size_t i) { return (h && i < h->names.size()) ? h->names[i].c_str() : nullptr; }
 void tracs_distance_free(tracs_distance *h) { if (h) { if (h->a) tracs_alignment_free(h->a); delete h; } }
 
+// the date difference of every emitted pair, as tracs/transcluster.py:26-33 takes it: |t_i - t_j| / 31556952.0 with t = whole days in seconds
+__global__ __launch_bounds__(256) void coo_delta_kernel(const unsigned *__restrict__ rows, const unsigned *__restrict__ cols, const int *__restrict__ days,
+                                                        size_t n, double *__restrict__ out)
+{
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (size_t)gridDim.x * 256) {
+        const long long dd = (long long)days[rows[t]] - (long long)days[cols[t]];
+        out[t] = (double)((dd < 0 ? -dd : dd) * 86400ll) / 31556952.0;
+    }
+}
+
 int tracs_distance_run(tracs_distance *h, int dist, const int32_t *days, double lamb, double beta, double precision, double k_max,
-                       const char *path, const char *ref, uint64_t *rows_written, uint64_t *n_pairs)
+                       const char *path, const char *ref, int filter, uint64_t *rows_written, uint64_t *n_pairs)
 {
     if (rows_written) *rows_written = 0;
     if (n_pairs) *n_pairs = 0;
@@ -417,6 +427,8 @@ int tracs_distance_run(tracs_distance *h, int dist, const int32_t *days, double 
     const size_t CH = std::max<size_t>(64, std::min<size_t>(CH_MAX, (h->n_fasta == 1 ? h->a->n : h->n0) * h->a->n));
     unsigned *d_dist = nullptr, *d_nn = nullptr, *d_coo = nullptr;
     double *d_p = nullptr, *d_e = nullptr, *d_cp = nullptr;
+    const bool dense_tc = with_dates && !filter;                   // --filter: the transmission model is driven by the FILTERED distance
+                                                                    // (tracs/distance.py:183-193): per emitted pair, after the filter
     int *d_days = nullptr;
     long long *d_off = nullptr;
     char *pin[2] = {nullptr, nullptr};
@@ -450,14 +462,18 @@ int tracs_distance_run(tracs_distance *h, int dist, const int32_t *days, double 
         DR_CHECK(hipMalloc(reinterpret_cast<void **>(&d_dist), panel * n * 4));
         DR_CHECK(hipMalloc(reinterpret_cast<void **>(&d_nn), panel * n * 4));
         DR_CHECK(hipMalloc(reinterpret_cast<void **>(&d_off), (panel + 1) * 8));
-        if (with_dates) {
+        if (dense_tc) {
             DR_CHECK(hipMalloc(reinterpret_cast<void **>(&d_p), panel * n * 8));
             DR_CHECK(hipMalloc(reinterpret_cast<void **>(&d_e), panel * n * 8));
+        }
+        if (with_dates) {
             DR_CHECK(hipMalloc(reinterpret_cast<void **>(&d_days), n * 4));
             DR_CHECK(hipMemcpy(d_days, days, n * 4, hipMemcpyHostToDevice));
         }
-        // a batch on the host: four uint32 columns, then two f64 ones; two of them, so that one is formatted while the next arrives
-        const size_t batch_bytes = CH * (16 + (with_dates ? 16 : 0));
+        // a batch on the host: four uint32 columns (five with --filter), then two f64 ones; two of them, so that one is formatted while the
+        // next arrives
+        const size_t n32 = filter ? 5 : 4;
+        const size_t batch_bytes = CH * (n32 * 4 + (with_dates ? 16 : 0) + 4);
         for (auto &q : pin) DR_CHECK(hipHostMalloc(reinterpret_cast<void **>(&q), batch_bytes, hipHostMallocDefault));
         DR_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
         for (auto &e : ev) DR_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -469,10 +485,10 @@ int tracs_distance_run(tracs_distance *h, int dist, const int32_t *days, double 
             if (g_sigint) { cleanup(); set_error("Interrupted by user!"); return TRACS_E_INTERRUPTED; }
             const size_t r1 = std::min(i_end, r0 + panel);
             unsigned *bd = d_dist - r0 * n, *bn = d_nn - r0 * n;     // addressed as base[i * ld + j] with i absolute
-            double *bp = with_dates ? d_p - r0 * n : nullptr, *be = with_dates ? d_e - r0 * n : nullptr;
+            double *bp = dense_tc ? d_p - r0 * n : nullptr, *be = dense_tc ? d_e - r0 * n : nullptr;
             DR_RC(tracs_pairsnp_dense_thr(a, r0, r1, j_start, bd, bn, n, dist, nullptr));
             lap(t_dense);
-            if (with_dates)
+            if (dense_tc)
                 DR_RC(tracs_trans_dist_dense(bd, n, n, r0, r1, j_start, dist, d_days, lamb, beta, precision, 1, bp, be, nullptr));
             lap(t_tc);
             DR_RC(tracs_coo_count(bd, n, n, r0, r1, j_start, dist, reinterpret_cast<int64_t *>(d_off), nullptr));
@@ -484,14 +500,25 @@ int tracs_distance_run(tracs_distance *h, int dist, const int32_t *days, double 
                 if (d_cp) DR_CHECK(hipFree(d_cp));
                 d_coo = nullptr; d_cp = nullptr;
                 cap = (size_t)total;
-                DR_CHECK(hipMalloc(reinterpret_cast<void **>(&d_coo), cap * 16));
-                if (with_dates) DR_CHECK(hipMalloc(reinterpret_cast<void **>(&d_cp), cap * 16));
+                DR_CHECK(hipMalloc(reinterpret_cast<void **>(&d_coo), cap * 4 * n32));
+                if (with_dates) DR_CHECK(hipMalloc(reinterpret_cast<void **>(&d_cp), cap * (filter ? 24 : 16)));
             }
-            unsigned *c_rows = d_coo, *c_cols = d_coo + cap, *c_d = d_coo + 2 * cap, *c_n = d_coo + 3 * cap;
-            double *c_p = d_cp, *c_e = with_dates ? d_cp + cap : nullptr;
+            unsigned *c_rows = d_coo, *c_cols = d_coo + cap, *c_d = d_coo + 2 * cap, *c_n = d_coo + 3 * cap, *c_f = filter ? d_coo + 4 * cap : nullptr;
+            double *c_p = d_cp, *c_e = with_dates ? d_cp + cap : nullptr, *c_delta = (with_dates && filter) ? d_cp + 2 * cap : nullptr;
             DR_RC(tracs_coo_fill(bd, bn, n, n, r0, r1, j_start, dist, reinterpret_cast<int64_t *>(d_off), c_rows, c_cols, c_d, c_n, nullptr));
-            if (with_dates)
+            if (dense_tc)
                 DR_RC(tracs_coo_fill_f64(bd, n, n, r0, r1, j_start, dist, reinterpret_cast<int64_t *>(d_off), bp, be, c_p, c_e, nullptr));
+            if (filter) {
+                // the recombination filter on the emitted pairs (src/pairsnp.hpp:405-413), then -- with dates -- P(direct) and E(K) of the
+                // filtered distances, pair by pair (tracs/distance.py:183-193 -> tracs/transcluster.py:8-41 -> trans_dist)
+                DR_RC(tracs_filter_recomb_pairs(a, c_rows, c_cols, c_d, (size_t)total, c_f, nullptr));
+                if (with_dates) {
+                    hipLaunchKernelGGL(coo_delta_kernel, dim3((unsigned)std::min<size_t>(((size_t)total + 255) / 256, 65535)), dim3(256), 0, nullptr, c_rows, c_cols,
+                                       d_days, (size_t)total, c_delta);
+                    DR_RC(tracs_trans_dist_device(reinterpret_cast<const int32_t *>(c_f), c_delta, (size_t)total, lamb, beta, precision, 1, c_p, c_e, nullptr));
+                }
+                lap(t_tc);
+            }
             DR_CHECK(hipEventRecord(ready, nullptr));
             DR_CHECK(hipStreamWaitEvent(copy_stream, ready, 0));
             lap(t_coo);
@@ -499,14 +526,15 @@ int tracs_distance_run(tracs_distance *h, int dist, const int32_t *days, double 
             auto post = [&](size_t k) -> hipError_t {                 // batch k -> pinned set k % 2
                 const size_t o = k * CH, cnt = std::min(CH, (size_t)total - o);
                 char *dst = pin[k & 1];
-                const unsigned *src32[4] = {c_rows, c_cols, c_d, c_n};
-                for (int q = 0; q < 4; q++) {
+                const unsigned *src32[5] = {c_rows, c_cols, c_d, c_n, c_f};
+                for (size_t q = 0; q < n32; q++) {
                     const hipError_t e = hipMemcpyAsync(dst + (size_t)q * CH * 4, src32[q] + o, cnt * 4, hipMemcpyDeviceToHost, copy_stream);
                     if (e != hipSuccess) return e;
                 }
                 if (with_dates) {
-                    hipError_t e = hipMemcpyAsync(dst + CH * 16, c_p + o, cnt * 8, hipMemcpyDeviceToHost, copy_stream);
-                    if (e == hipSuccess) e = hipMemcpyAsync(dst + CH * 24, c_e + o, cnt * 8, hipMemcpyDeviceToHost, copy_stream);
+                    const size_t f64_at = (CH * n32 * 4 + 7) / 8 * 8;
+                    hipError_t e = hipMemcpyAsync(dst + f64_at, c_p + o, cnt * 8, hipMemcpyDeviceToHost, copy_stream);
+                    if (e == hipSuccess) e = hipMemcpyAsync(dst + f64_at + CH * 8, c_e + o, cnt * 8, hipMemcpyDeviceToHost, copy_stream);
                     if (e != hipSuccess) return e;
                 }
                 return hipEventRecord(ev[k & 1], copy_stream);
@@ -519,9 +547,11 @@ int tracs_distance_run(tracs_distance *h, int dist, const int32_t *days, double 
                 const size_t cnt = std::min(CH, (size_t)total - k * CH);
                 const char *src = pin[k & 1];
                 const uint32_t *hr = reinterpret_cast<const uint32_t *>(src), *hc = hr + CH, *hd = hr + 2 * CH, *hn = hr + 3 * CH;
-                const double *hp = reinterpret_cast<const double *>(src + CH * 16), *he = reinterpret_cast<const double *>(src + CH * 24);
-                // metadata on, --filter off: a column of "NA" (:204); metadata off: zeros (:240-258)
-                DR_RC(writer.append_u32(hr, hc, hd, with_dates ? nullptr : zeros.data(), hn, days, with_dates ? hp : nullptr, with_dates ? he : nullptr,
+                const size_t f64_at = (CH * n32 * 4 + 7) / 8 * 8;
+                const double *hp = reinterpret_cast<const double *>(src + f64_at), *he = hp + CH;
+                // the filtered column: --filter: the filtered distances; else metadata on: a column of "NA" (:204), metadata off: zeros (:240-258)
+                const uint32_t *hf = filter ? hr + 4 * CH : (with_dates ? nullptr : zeros.data());
+                DR_RC(writer.append_u32(hr, hc, hd, hf, hn, days, with_dates ? hp : nullptr, with_dates ? he : nullptr,
                                         cnt, with_dates ? 1 : 0, with_dates ? k_max : -1.0));
             }
             pairs += (uint64_t)total;

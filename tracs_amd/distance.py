@@ -16,7 +16,7 @@ from .utils import check_positive_float, check_positive_int
 
 
 def pairsnp_arrays(*args, **kwargs):
-    """tracs_amd.api.pairsnp_arrays, imported with numpy on first use (the array route only: --filter, --gpus N, incomplete metadata)"""
+    """tracs_amd.api.pairsnp_arrays, imported with numpy on first use (the array route only: --gpus N, incomplete metadata, TRACS_DISTANCE_ARRAYS)"""
     from .api import pairsnp_arrays as f
     return f(*args, **kwargs)
 
@@ -133,7 +133,8 @@ def _rows_on_device(msas, args, dates, ref, stage):
             logging.info("Inferring transmission probabilities for %s", msas[0])
         kmax = -1.0 if (args.trans_threshold is None or dates is None) else float(args.trans_threshold)
         _lib.check(L.tracs_distance_run(h, int(args.snp_threshold), days, float(args.clock_rate), float(args.trans_rate), float(args.precision),
-                                        kmax, os.fsencode(args.output_file), ref.encode(), C.byref(written), C.byref(pairs)))
+                                        kmax, os.fsencode(args.output_file), ref.encode(), int(bool(args.recomb_filter)), C.byref(written),
+                                        C.byref(pairs)))
         stage("[sum] tracs_distance_run (dense panels, transcluster, rows: %d pairs, %d rows written)" % (pairs.value, written.value))
         return True
     finally:
@@ -240,8 +241,9 @@ def distance(args):
         msas = [msa, args.msa_db] if args.msa_db is not None else [msa]
         t_stage[0] = time.perf_counter()
         ref = os.path.basename(msa).split(".")[0].replace("_combined", "")      # (:208-209)
-        if ctx is None and not args.recomb_filter and os.environ.get("TRACS_DISTANCE_ARRAYS") is None:
-            # one GPU, no recombination filter: the results stay on the device until the CSV rows
+        if ctx is None and os.environ.get("TRACS_DISTANCE_ARRAYS") is None:
+            # one GPU: the results stay on the device until the CSV rows (with --filter: the filtered distances and the transmission
+            # model they drive too)
             for p in msas:
                 if not os.path.exists(p):
                     raise FileNotFoundError(p)               # (api.pairsnp_arrays's diagnosis; the reference passes a NULL gzFile on)
