@@ -746,7 +746,12 @@ __global__ __launch_bounds__(64) void flt_pairs_long_kernel(FltPairArgs A, const
 // N lookups in flight at once, a merge path in LDS, the lanes' survivors appended to the pair's SNP sites in the wave's scratch slot.
 // (A site both samples list may straddle a tile boundary -- i's entry last in one tile, j's first in the next: i's entry looks at the
 // entry of j behind the tile's share, j's entry at the site of i's entry before it.)
-constexpr unsigned FLT_TILE = 1024, FLT_TILE_R = FLT_TILE / 64;
+// (512 entries a tile: 24.4 s for the 49 995 000 pairs of the partial-code alignment, 27.3 with 256, 39.5 with 1 024, 45.2 with 2 048 --
+// 9.5 KB of LDS and half the registers per wave: sixteen waves per CU hide the tile's memory round trips, profiles/r06/filter_tile_sweep.txt)
+#ifndef TRACS_FLT_TILE
+#define TRACS_FLT_TILE 512
+#endif
+constexpr unsigned FLT_TILE = TRACS_FLT_TILE, FLT_TILE_R = FLT_TILE / 64;
 __global__ __launch_bounds__(64) void flt_pairs_tiled_kernel(FltPairArgs A, const unsigned *__restrict__ idx, size_t n_idx,
                                                              unsigned *__restrict__ scratch, size_t slot)
 {
