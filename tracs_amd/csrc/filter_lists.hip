@@ -512,7 +512,13 @@ __device__ __forceinline__ unsigned flt_window_test2(Ptr S, const unsigned dn, c
 //     pair's d sit in registers, one count per lane (ds_bpermute instead of a table read).
 //   * a wave takes FLT_PB consecutive pairs: in a row-major emission they share the row i and, 31 times out of 32, the 32-sample word
 //     of j -- the list of i and its NS words stay in registers from one pair to the next (half of a pair's scattered lookups).
-constexpr unsigned FLT_PB = 8;
+#ifndef TRACS_FLT_PB
+#define TRACS_FLT_PB 8
+#endif
+#ifndef TRACS_FLT_REGS
+#define TRACS_FLT_REGS 1
+#endif
+constexpr unsigned FLT_PB = TRACS_FLT_PB;
 template <int R>
 struct FltRowCache {
     unsigned i = 0xFFFFFFFFu, jw = 0xFFFFFFFFu, la = 0;
@@ -585,16 +591,31 @@ __device__ __forceinline__ void flt_pair2(const FltPairArgs &A, const size_t t, 
     unsigned va = a < la ? LA[a] : INF, vb = b < lb ? LB[b] : INF;
     unsigned lastA = a > 0u ? (LA[a - 1u] >> 5) : INF;
     unsigned cnt = 0;
+#if TRACS_FLT_REGS
+    // a lane's merged entries stay in its registers (at most 2 R of them: the step loop is unrolled, rounds beyond C skipped wave-
+    // uniformly): no M array -- half the LDS per wave, and with it more waves per CU to hide the pair's memory round trips behind
+    unsigned sv[2 * R];
+    (void)M; (void)stride;
+#pragma unroll
+    for (int step = 0; step < 2 * R; step++) {
+        sv[step] = 0u;
+        if ((unsigned)step >= C) continue;
+#else
     unsigned *Mrow = M + lane * stride;
     for (unsigned step = 0; step < C; step++) {
+#endif
         const unsigned pa = va >> 5, pb = vb >> 5;
         const bool takeA = pa <= pb;
         // an entry of i: both listed -> the masks decide; else its w bit (partner carries the reference base; N folded in above).
         // an entry of j: dead when i lists the site too (i's entry carried the verdict)
         const unsigned snpA = pa == pb ? (((va & vb & 15u) == 0u) ? 1u : 0u) : ((va >> 4) & 1u);
         const unsigned snpB = lastA == pb ? 0u : ((vb >> 4) & 1u);
-        const unsigned snp = (D + step < tot) ? (takeA ? snpA : snpB) : 0u;
+        const unsigned snp = (D + (unsigned)step < tot) ? (takeA ? snpA : snpB) : 0u;
+#if TRACS_FLT_REGS
+        sv[step] = (takeA ? pa : pb) | (snp << 31);
+#else
         Mrow[step] = (takeA ? pa : pb) | (snp << 31);
+#endif
         cnt += snp;
         const unsigned nidx = takeA ? a + 1u : CAP + b + 1u, nlim = takeA ? la : CAP + lb;
         const unsigned nxt = nidx < nlim ? LA[nidx] : INF;
@@ -617,10 +638,16 @@ __device__ __forceinline__ void flt_pair2(const FltPairArgs &A, const size_t t, 
     unsigned *S = LA + 2;
     {
         unsigned o = incl - cnt;
+#if TRACS_FLT_REGS
+#pragma unroll
+        for (int step = 0; step < 2 * R; step++)
+            if (sv[step] >> 31) S[o++] = sv[step] & 0x7FFFFFFFu;
+#else
         for (unsigned step = 0; step < C; step++) {
             const unsigned v = Mrow[step];
             if (v >> 31) S[o++] = v & 0x7FFFFFFFu;
         }
+#endif
         if (lane < 2) { LA[lane] = 0xFFFFFFFFu; S[dn + lane] = 0x7FFFFFFFu; }
     }
     flt_wave_sync();
@@ -634,8 +661,19 @@ __device__ __forceinline__ void flt_pair2(const FltPairArgs &A, const size_t t, 
     if (lane == 0) A.filt[t] = kept;
 }
 
+// (four waves per SIMD: 238.9 ms for the 49 995 000 pairs of the bench alignment where the compiler's own choice -- 149 VGPRs, three
+// waves -- takes 292.5; five: 249.9 (spills), six: 314.6; with the merged entries in LDS instead of registers and four waves: 269.1 --
+// the kernel waits on memory, waves are what hides it: profiles/r06/filter_phase_cuts.txt)
+#ifndef TRACS_FLT_WAVES
+#define TRACS_FLT_WAVES 4
+#endif
+#if TRACS_FLT_WAVES > 0
+#define TRACS_FLT_ATTR __attribute__((amdgpu_waves_per_eu(TRACS_FLT_WAVES, TRACS_FLT_WAVES)))
+#else
+#define TRACS_FLT_ATTR
+#endif
 template <int R>
-__global__ __launch_bounds__(64) void flt_pairs2_kernel(FltPairArgs A)
+__global__ __launch_bounds__(64) TRACS_FLT_ATTR void flt_pairs2_kernel(FltPairArgs A)
 {
     extern __shared__ unsigned flt_lds[];
     constexpr unsigned CAP = R * 64;
@@ -652,7 +690,8 @@ __global__ __launch_bounds__(64) void flt_pairs2_kernel(FltPairArgs A)
 template <int R>
 static void flt_launch2(const FltPairArgs &A, hipStream_t stream)
 {
-    hipLaunchKernelGGL((flt_pairs2_kernel<R>), dim3((unsigned)((A.n_pairs + FLT_PB - 1) / FLT_PB)), dim3(64), (size_t)(4 * R * 64 + 128) * 4, stream, A);
+    const size_t lds_words = TRACS_FLT_REGS ? (size_t)2 * R * 64 + 8 : (size_t)4 * R * 64 + 128;
+    hipLaunchKernelGGL((flt_pairs2_kernel<R>), dim3((unsigned)((A.n_pairs + FLT_PB - 1) / FLT_PB)), dim3(64), lds_words * 4, stream, A);
 }
 
 // ---- the pairs whose lists do not fit a wave's LDS (partial IUPAC codes: tens of thousands of entries per sample) ------------------
@@ -752,7 +791,15 @@ __global__ __launch_bounds__(64) void flt_pairs_long_kernel(FltPairArgs A, const
 #define TRACS_FLT_TILE 512
 #endif
 constexpr unsigned FLT_TILE = TRACS_FLT_TILE, FLT_TILE_R = FLT_TILE / 64;
-__global__ __launch_bounds__(64) void flt_pairs_tiled_kernel(FltPairArgs A, const unsigned *__restrict__ idx, size_t n_idx,
+#ifndef TRACS_FLT_TWAVES
+#define TRACS_FLT_TWAVES 0
+#endif
+#if TRACS_FLT_TWAVES > 0
+#define TRACS_FLT_TATTR __attribute__((amdgpu_waves_per_eu(TRACS_FLT_TWAVES, TRACS_FLT_TWAVES)))
+#else
+#define TRACS_FLT_TATTR
+#endif
+__global__ __launch_bounds__(64) TRACS_FLT_TATTR void flt_pairs_tiled_kernel(FltPairArgs A, const unsigned *__restrict__ idx, size_t n_idx,
                                                              unsigned *__restrict__ scratch, size_t slot)
 {
     extern __shared__ unsigned flt_lds[];
