@@ -116,14 +116,17 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
                                                              unsigned *__restrict__ gR, unsigned *__restrict__ gS, unsigned *__restrict__ gI,
                                                              unsigned *__restrict__ gJ,
                                                              unsigned long long *__restrict__ flags, size_t flag_words,
-                                                             unsigned *__restrict__ partial_flag)
+                                                             unsigned *__restrict__ partial_flag,
+                                                             uint4 *__restrict__ masks2 = nullptr, unsigned *__restrict__ gcnt2 = nullptr)
 {
+    // masks2 / gcnt2 (may be NULL): the class masks and per-group sums of the SAME pass under the other criterion (gram = 1), so that
+    // decide() can take the second form of the classes without classifying again (bit 2 of *partial_flag: some p list of that form is long)
     const size_t g = blockIdx.x;
     __shared__ unsigned red[4][4][4];
     __shared__ unsigned sref[4][4];                     // one-base sample seen, ref X, ref Y, somebody is not N
     __shared__ unsigned planes_lds[4][8][256];          // one counter's bit planes of every thread (32 KiB): [word][plane][thread]
     __shared__ unsigned tot[2][SITES_PER_GROUP];        // k, cN
-    __shared__ unsigned wsum[2][7];
+    __shared__ unsigned wsum[2][2][7];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < SITES_PER_GROUP) { tot[0][tid] = 0; tot[1][tid] = 0; }
     if (tid < 4) { sref[0][tid] = 0; sref[1][tid] = 0; sref[2][tid] = 0; sref[3][tid] = 0; }
@@ -253,45 +256,53 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
         const unsigned anyw = red[0][3][w] | red[1][3][w] | red[2][3][w] | red[3][3][w];
         const bool some = (anyw >> b) & 1u;
         const unsigned long long k = tot[0][tid], c = some ? tot[1][tid] : 0ull;      // (an empty site: every sample is N)
-        const bool minor = some && k >= 1 && budget > 0 && k * ((gram ? 0ull : c) + k) <= (unsigned long long)budget;
-        const bool dense = some && k >= 1 && !minor;
-        const bool un = some && !dense && c >= 1;
-        // (a walk costs the lines of the list: pairsnp_kernels.h, n8 lines)
-        const bool nnl = !gram && un && c >= 2 && (float)c * n8_lines_expected((unsigned)c, n) <= (float)nn_list_max;
-        const bool counted = un && c >= 2 && !nnl;          // (a site with one N sample has no pair of N samples)
-        const bool full = some && !dense && c == 0;
-        const bool lst = minor || nnl;
-        const bool cls[7] = {dense, counted, minor, full, nnl, lst, un};
-        constexpr int slot[7] = {M_DENSE, M_COUNT, M_MINOR, M_FULL, M_NNL, M_LST, M_UN};
-#pragma unroll
-        for (int m = 0; m < 7; m++) {
-            const unsigned long long bal = __ballot(cls[m]);
-            if (lane == 0) {
-                unsigned *pm = reinterpret_cast<unsigned *>(&masks[(size_t)slot[m] * groups + g]);
-                pm[2 * wave] = (unsigned)bal; pm[2 * wave + 1] = (unsigned)(bal >> 32);
-            }
-        }
-        if (__ballot(minor && k > P_SHORT_MAX) && lane == 0) atomicOr(partial_flag, 2u);      // some p list is a long one (q lines: site_lists.hip)
         cntP[g * SITES_PER_GROUP + tid] = (unsigned)k;
         cntN[g * SITES_PER_GROUP + tid] = (unsigned)c;
-        // per group: p-list entries; overflow lines the N lists of its listed sites can need at most (each has its primary line);
-        // list entries one pass of the N co-occurrence walk decodes (cN per walk, cN walks) and its walks; N-list walks of the
-        // minority fix-up (one per listed sample of a site with an N sample)
-        // (gJ: lines a minority site's p list needs beyond its own: 31 dwords a line, the first one of the list its header -- q lines, site_lists.hip)
-        unsigned sv[7] = {minor ? (unsigned)k : 0u, (lst && !gram) ? n8_lines_max((unsigned)c, n) - 1u : 0u, nnl ? (unsigned)min(c * c, 33554431ull) : 0u, nnl ? (unsigned)c : 0u,
-                          (minor && c && !gram) ? (unsigned)k : 0u, (minor && !gram) ? n8_lines_max((unsigned)c, n) - 1u : 0u, minor ? (unsigned)(k / 31ull) : 0u};
 #pragma unroll
-        for (int m = 0; m < 7; m++) {
+        for (int form = 0; form < 2; form++) {
+            if (form == 1 && masks2 == nullptr) break;                  // (kernel-uniform)
+            const bool gr = form == 1 || gram != 0u;
+            uint4 *const mk = form == 0 ? masks : masks2;
+            const bool minor = some && k >= 1 && budget > 0 && k * ((gr ? 0ull : c) + k) <= (unsigned long long)budget;
+            const bool dense = some && k >= 1 && !minor;
+            const bool un = some && !dense && c >= 1;
+            // (a walk costs the lines of the list: pairsnp_kernels.h, n8 lines)
+            const bool nnl = !gr && un && c >= 2 && (float)c * n8_lines_expected((unsigned)c, n) <= (float)nn_list_max;
+            const bool counted = un && c >= 2 && !nnl;          // (a site with one N sample has no pair of N samples)
+            const bool full = some && !dense && c == 0;
+            const bool lst = minor || nnl;
+            const bool cls[7] = {dense, counted, minor, full, nnl, lst, un};
+            constexpr int slot[7] = {M_DENSE, M_COUNT, M_MINOR, M_FULL, M_NNL, M_LST, M_UN};
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) sv[m] += __shfl_xor(sv[m], off, 64);
-            if (lane == 0) wsum[wave][m] = sv[m];
+            for (int m = 0; m < 7; m++) {
+                const unsigned long long bal = __ballot(cls[m]);
+                if (lane == 0) {
+                    unsigned *pm = reinterpret_cast<unsigned *>(&mk[(size_t)slot[m] * groups + g]);
+                    pm[2 * wave] = (unsigned)bal; pm[2 * wave + 1] = (unsigned)(bal >> 32);
+                }
+            }
+            // some p list is a long one (q lines: site_lists.hip): bit 1 for the first set of classes, bit 2 for the second
+            if (__ballot(minor && k > P_SHORT_MAX) && lane == 0) atomicOr(partial_flag, form == 0 ? 2u : 4u);
+            // per group: p-list entries; overflow lines the N lists of its listed sites can need at most (each has its primary line);
+            // list entries one pass of the N co-occurrence walk decodes (cN per walk, cN walks) and its walks; N-list walks of the
+            // minority fix-up (one per listed sample of a site with an N sample)
+            // (gJ: lines a minority site's p list needs beyond its own: 31 dwords a line, the first one of the list its header -- q lines, site_lists.hip)
+            unsigned sv[7] = {minor ? (unsigned)k : 0u, (lst && !gr) ? n8_lines_max((unsigned)c, n) - 1u : 0u, nnl ? (unsigned)min(c * c, 33554431ull) : 0u, nnl ? (unsigned)c : 0u,
+                              (minor && c && !gr) ? (unsigned)k : 0u, (minor && !gr) ? n8_lines_max((unsigned)c, n) - 1u : 0u, minor ? (unsigned)(k / 31ull) : 0u};
+#pragma unroll
+            for (int m = 0; m < 7; m++) {
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) sv[m] += __shfl_xor(sv[m], off, 64);
+                if (lane == 0) wsum[form][wave][m] = sv[m];
+            }
         }
     }
     __syncthreads();
     if (tid == 0) {
-        gP[g] = wsum[0][0] + wsum[1][0]; gN[g] = wsum[0][1] + wsum[1][1]; gQ[g] = wsum[0][2] + wsum[1][2];
-        gR[g] = wsum[0][3] + wsum[1][3]; gS[g] = wsum[0][4] + wsum[1][4]; gI[g] = wsum[0][5] + wsum[1][5]; gJ[g] = wsum[0][6] + wsum[1][6];
+        gP[g] = wsum[0][0][0] + wsum[0][1][0]; gN[g] = wsum[0][0][1] + wsum[0][1][1]; gQ[g] = wsum[0][0][2] + wsum[0][1][2];
+        gR[g] = wsum[0][0][3] + wsum[0][1][3]; gS[g] = wsum[0][0][4] + wsum[0][1][4]; gI[g] = wsum[0][0][5] + wsum[0][1][5]; gJ[g] = wsum[0][0][6] + wsum[0][1][6];
     }
+    if (tid < 7 && gcnt2 != nullptr) gcnt2[(size_t)tid * groups + g] = wsum[1][0][tid] + wsum[1][1][tid];
     if (tid < 4) {
         reinterpret_cast<unsigned *>(&masks[(size_t)M_REFX * groups + g])[tid] = refx[tid];
         reinterpret_cast<unsigned *>(&masks[(size_t)M_REFY * groups + g])[tid] = refy[tid];
@@ -611,15 +622,21 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     unsigned *offs = nullptr, *cnts = nullptr, *gcnt = nullptr, *d_flag = nullptr;
     unsigned long long *off64 = nullptr, *totals = nullptr, *flags = nullptr;
     int rc;
-    if ((rc = workspace_get(52, M_SLOTS * groups * sizeof(uint4), reinterpret_cast<void **>(&masks)))) return rc;
-    if ((rc = workspace_get(53, 7 * groups * sizeof(unsigned), reinterpret_cast<void **>(&offs)))) return rc;
+    // (two sets of class masks / sums / offsets / totals: the second holds the classes of the same pass under the other form's criterion)
+    if ((rc = workspace_get(52, 2 * M_SLOTS * groups * sizeof(uint4), reinterpret_cast<void **>(&masks)))) return rc;
+    if ((rc = workspace_get(53, 2 * 7 * groups * sizeof(unsigned), reinterpret_cast<void **>(&offs)))) return rc;
     if ((rc = workspace_get(54, 2 * groups * SITES_PER_GROUP * sizeof(unsigned), reinterpret_cast<void **>(&cnts)))) return rc;
-    if ((rc = workspace_get(55, 7 * groups * sizeof(unsigned), reinterpret_cast<void **>(&gcnt)))) return rc;
-    if ((rc = workspace_get(56, 7 * (groups + 1) * sizeof(unsigned long long), reinterpret_cast<void **>(&off64)))) return rc;
-    if ((rc = workspace_get(57, 128, reinterpret_cast<void **>(&totals)))) return rc;
+    if ((rc = workspace_get(55, 2 * 7 * groups * sizeof(unsigned), reinterpret_cast<void **>(&gcnt)))) return rc;
+    if ((rc = workspace_get(56, 2 * 7 * (groups + 1) * sizeof(unsigned long long), reinterpret_cast<void **>(&off64)))) return rc;
+    if ((rc = workspace_get(57, 256, reinterpret_cast<void **>(&totals)))) return rc;
     if ((rc = workspace_get(58, groups * flag_words * sizeof(unsigned long long), reinterpret_cast<void **>(&flags)))) return rc;
     d_flag = reinterpret_cast<unsigned *>(totals + 15);
-    auto mask_of = [&](int slot) { return masks + (size_t)slot * groups; };
+    uint4 *const masks_ref = masks;                              // (the reference base bits are written with the first set only)
+    uint4 *const masks2 = masks + (size_t)M_SLOTS * groups;
+    unsigned *const offs2 = offs + 7 * groups, *const gcnt2 = gcnt + 7 * groups;
+    unsigned long long *const off64_2 = off64 + 7 * (groups + 1), *const totals2 = totals + 16;
+    bool switched = false;                                       // the second form entered in place, from the second set of classes
+    auto mask_of = [&](int slot) { return (slot == M_REFX || slot == M_REFY ? masks_ref : masks) + (size_t)slot * groups; };
     auto off_of = [&](int slot) { return offs + (size_t)slot * groups; };
     unsigned *cntP = cnts, *cntN = cnts + groups * SITES_PER_GROUP;
     // a site goes to the minority lists while its k (cN + k) entries cost less than the extra operand planes over all pairs:
@@ -637,9 +654,10 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     static const bool no_nnl = [] { const char *e = std::getenv("TRACS_NN_LISTS"); return e && std::atoi(e) == 0; }();
     static const double nnl_k = [] { const char *e = std::getenv("TRACS_NN_LIST_K"); return e ? std::atof(e) : 6e-6; }();
     const unsigned nn_list_max = (no_nnl || !allow_nnl) ? 0u : (unsigned)std::min(4.0e9, nnl_k * (double)a->n * (double)a->n);
-    TRACS_HIP_CHECK(hipMemsetAsync(totals, 0, 128, stream));
+    TRACS_HIP_CHECK(hipMemsetAsync(totals, 0, 256, stream));
     hipLaunchKernelGGL(classify_sites_kernel, dim3((unsigned)groups), dim3(256), 0, stream, a->planes, a->n_pad, (unsigned)a->n, budget,
-                       nn_list_max, gram ? 1u : 0u, masks, groups, cntP, cntN, gcnt, gcnt + groups, gcnt + 2 * groups, gcnt + 3 * groups, gcnt + 4 * groups, gcnt + 5 * groups, gcnt + 6 * groups, flags, flag_words, d_flag);
+                       nn_list_max, gram ? 1u : 0u, masks, groups, cntP, cntN, gcnt, gcnt + groups, gcnt + 2 * groups, gcnt + 3 * groups, gcnt + 4 * groups, gcnt + 5 * groups, gcnt + 6 * groups, flags, flag_words, d_flag,
+                       gram_next ? masks2 : (uint4 *)nullptr, gram_next ? gcnt2 : (unsigned *)nullptr);
     const double plane_b = (double)groups * (double)a->n_pad * sizeof(uint4);      // one bit plane of the alignment
     stage_mark("classify", stream, 4.0 * plane_b, (double)groups * (M_SLOTS * 16.0 + 3.0 * SITES_PER_GROUP * 4.0 + flag_words * 8.0));
     hipLaunchKernelGGL(group_offsets_kernel, dim3(14), dim3(1024), 0, stream, masks, gcnt, groups, offs, off64, totals);
@@ -647,15 +665,16 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     TRACS_HIP_CHECK(hipMemcpyAsync(tot, totals, 128, hipMemcpyDeviceToHost, stream));
     TRACS_HIP_CHECK(hipStreamSynchronize(stream));
     stage_mark("class sizes", stream);
-    *partial = (int)(reinterpret_cast<const unsigned *>(&tot[15])[0] & 1u);
-    const bool long_p = (reinterpret_cast<const unsigned *>(&tot[15])[0] & 2u) != 0u;
+    const unsigned class_flags = reinterpret_cast<const unsigned *>(&tot[15])[0];
+    *partial = (int)(class_flags & 1u);
+    bool long_p = (class_flags & 2u) != 0u;
     const bool consensus = !*partial && !force_general;
-    const size_t L_dense = (size_t)tot[M_DENSE], L_minor = (size_t)tot[M_MINOR], L_full = (size_t)tot[M_FULL];
+    size_t L_dense = (size_t)tot[M_DENSE], L_minor = (size_t)tot[M_MINOR], L_full = (size_t)tot[M_FULL];
     size_t L_count = (size_t)tot[M_COUNT], L_nnl = (size_t)tot[M_NNL], L_lst = (size_t)tot[M_LST], L_un = (size_t)tot[M_UN];
-    const unsigned long long tot_p = tot[7], tot_q = long_p ? tot[13] : 0ull;
+    unsigned long long tot_p = tot[7], tot_q = long_p ? tot[13] : 0ull;
     // (256-byte q lines when the minority sites list more than Q_WIDE_MEAN samples on average: site_lists.hip; TRACS_QLINE_DWORDS=32|64 forces)
     static const int force_qw = [] { const char *e = std::getenv("TRACS_QLINE_DWORDS"); return e ? std::atoi(e) : 0; }();
-    const unsigned qw = force_qw == 32 || force_qw == 64 ? (unsigned)force_qw : ((long_p && L_minor && (double)tot_p > Q_WIDE_MEAN * (double)L_minor) ? 64u : 32u);
+    unsigned qw = force_qw == 32 || force_qw == 64 ? (unsigned)force_qw : ((long_p && L_minor && (double)tot_p > Q_WIDE_MEAN * (double)L_minor) ? 64u : 32u);
     unsigned long long tot_o = tot[8], tot_nnl = tot[10];
     int lst_slot = M_LST, ovf_slot = 1;                      // which mask / per-group overflow bound the lists are built from
     if (force == 0 || a->L == 0 || a->n < 2) return TRACS_OK;
@@ -670,7 +689,7 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     const double t_extra = 1.5e-13 * (double)(a->L - L_count) * (double)a->n * (double)a->n;
     const double t_repack = 4.0e-10 * (double)L_count * (double)a->n_pad;
     // (gram: n n^T over every site is part of the distances: always the stored N plane in place)
-    const bool in_place = gram || (L_count > 0 && (force_in_place >= 0 ? force_in_place == 1 : t_extra < t_repack));
+    bool in_place = gram || (L_count > 0 && (force_in_place >= 0 ? force_in_place == 1 : t_extra < t_repack));
     if (in_place && L_nnl) {
         // the same classes with the NNL sites counted: lists = the minority sites (their masks, ranks and overflow bounds exist)
         L_count += L_nnl; L_lst = L_minor; L_nnl = 0;
@@ -679,13 +698,35 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     }
     // matrix instructions per pair: planes_full per site now; planes_full per dense site + one per counted site with classes
     const double planes_full = consensus ? 4.0 : 5.0;
-    const double cost = (planes_full * (double)L_dense + (double)(in_place ? a->L : L_count) + (gram ? (double)a->L : 0.0)) / (planes_full * (double)a->L);
+    double cost = (planes_full * (double)L_dense + (double)(in_place ? a->L : L_count) + (gram ? (double)a->L : 0.0)) / (planes_full * (double)a->L);
     if (gram && env_gram != 1 && force != 1 && cost >= std::min(0.92, beat - 0.02)) return TRACS_OK;      // (the caller goes on with the list form)
     if (gram_next && force != 0 && cost > 2.0 / planes_full + 0.05) {
-        const int rc2 = decide(a, allow_minor, allow_nnl, stream, partial, true, cost);
-        if (rc2 || a->classes_state == 1) return rc2;
-        return decide(a, allow_minor, allow_nnl, stream, partial, false, 1.0, true);
+        // the list form costs more matrix work than the second form can: that form's classes came out of the same pass (masks2) --
+        // their sizes, their cost; taken when it is the cheaper one
+        hipLaunchKernelGGL(group_offsets_kernel, dim3(14), dim3(1024), 0, stream, masks2, gcnt2, groups, offs2, off64_2, totals2);
+        unsigned long long t2[16] = {0};
+        TRACS_HIP_CHECK(hipMemcpyAsync(t2, totals2, 128, hipMemcpyDeviceToHost, stream));
+        TRACS_HIP_CHECK(hipStreamSynchronize(stream));
+        stage_mark("class sizes (second form)", stream);
+        const double cost2 = (planes_full * (double)t2[M_DENSE] + 2.0 * (double)a->L) / (planes_full * (double)a->L);
+        if (cost2 < std::min(0.92, cost - 0.02)) {
+            gram = true; switched = true;
+            masks = masks2; offs = offs2; gcnt = gcnt2; off64 = off64_2;
+            for (int k = 0; k < 15; k++) tot[k] = t2[k];
+            long_p = (class_flags & 4u) != 0u;
+            L_dense = (size_t)tot[M_DENSE]; L_minor = (size_t)tot[M_MINOR]; L_full = (size_t)tot[M_FULL];
+            L_count = (size_t)tot[M_COUNT]; L_nnl = (size_t)tot[M_NNL]; L_lst = (size_t)tot[M_LST]; L_un = (size_t)tot[M_UN];
+            tot_p = tot[7]; tot_q = long_p ? tot[13] : 0ull;
+            qw = force_qw == 32 || force_qw == 64 ? (unsigned)force_qw : ((long_p && L_minor && (double)tot_p > Q_WIDE_MEAN * (double)L_minor) ? 64u : 32u);
+            tot_o = tot[8]; tot_nnl = tot[10];
+            lst_slot = M_LST; ovf_slot = 1;
+            in_place = true;
+            cost = cost2;
+        }
     }
+    // (a refusal further down, of a form entered in place: the list form again -- classified once more, its masks were kept but its
+    // choices above were made for the other set)
+    auto refuse_gram = [&]() -> int { return switched ? decide(a, allow_minor, allow_nnl, stream, partial, false, 1.0, true) : TRACS_OK; };
     if (force != 1 && cost >= 0.92) return TRACS_OK;
     // the lists must stay small beside the planes (<= one entry per 8 sites of the whole alignment; TRACS_LIST_CAP: diagnostics):
     // otherwise first without the N co-occurrence lists (those sites are counted on the matrix cores), then without any list
@@ -699,7 +740,7 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
                              (L_nnl ? (double)a->n * (double)((groups + 7) / 8 * 8) * sizeof(uint4) : 0.0);
         if (L_lst >= (1ull << 26) || a->n >= (1ull << 27) || bytes > (env_cap >= 0.0 ? std::min(env_cap, cap) : cap) ||
             L_lst + tot_o >= (1ull << 32) || L_lst + tot_q >= (1ull << 32)) {                // (line indices are 32 bits)
-            if (gram) return TRACS_OK;                                                       // (refused: the caller goes on with the list form)
+            if (gram) return refuse_gram();                                                  // (refused: the list form instead)
             return L_nnl ? decide(a, allow_minor, false, stream, partial) : decide(a, false, false, stream, partial);
         }
     }
@@ -772,14 +813,14 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
         if (rc) { site_classes_free(a); a->classes_state = -1; return rc; }
         if (!built) {                                          // no memory: the same classes with fewer lists
             soft_fail();
-            if (gram) return TRACS_OK;
+            if (gram) return refuse_gram();
             return L_nnl ? decide(a, allow_minor, false, stream, partial) : decide(a, false, false, stream, partial);
         }
     }
     const bool gram_on = gram && L_minor > 0 && a->lists != nullptr;
     if (gram_on && !gram_rows) {
         const size_t ubytes = class_plane_bytes(a, groups, 1, PAD_GROUPS);
-        if (pack_alloc(a, ubytes, reinterpret_cast<void **>(&a->uplane)) != hipSuccess) return soft_fail();
+        if (pack_alloc(a, ubytes, reinterpret_cast<void **>(&a->uplane)) != hipSuccess) { soft_fail(); return refuse_gram(); }
         // (the pad groups and the slack behind them: zero)
         ok = ok && hipMemsetAsync(a->uplane + groups * a->n_pad, 0, ubytes - groups * a->n_pad * sizeof(uint4), stream) == hipSuccess;
         if (a->n_pad > a->n) ok = ok && hipMemsetAsync(a->uplane, 0, groups * a->n_pad * sizeof(uint4), stream) == hipSuccess;
