@@ -1022,11 +1022,29 @@ __global__ __launch_bounds__(1024) void tc_day_bounds_kernel(const int *__restri
 // One pass over the cells: cb[0] = largest distance of a valid cell, and bit N * stride + gap of every valid cell's key (stride = the
 // span of the days + 1, known before the pass: tc_day_bounds_kernel); cb[3] = 1 when a key falls outside the grid's TC_GRID_BITS bits --
 // then the marks are incomplete and the caller takes the hash route.  (Round 4 swept the cells twice: the bounds first.)
+// A row's keys fall into a narrow band of the grid (its distances differ by tens, the gaps span the days): the workgroup keeps a WINDOW
+// of the bitmap in LDS -- TC_MARK_WIN words from the word of (the row's first distance - half the window's span of distances) x stride
+// on --, sets its bits there (LDS atomics instead of a scattered global read and, for a new key, a global atomic per cell: 50 M of them at
+// 10 000 samples, and 500 000 contending for 640 words at 1 000), and ORs the window's non-zero words into the grid at the end.  Keys
+// outside the window take the global way.
+constexpr unsigned TC_MARK_WIN = 3072;              // words: 98 304 keys = 134 distances x a two-year span of days
 __global__ __launch_bounds__(TC_ROW_THREADS) void tc_mark_kernel(DenseSource src, unsigned *__restrict__ cb, unsigned *__restrict__ bits)
 {
+    __shared__ unsigned win[TC_MARK_WIN];
+    __shared__ unsigned anchor_d;
     if (cb[2] < cb[1]) { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) cb[3] = 1u; return; }
     const unsigned long long stride = (unsigned long long)(cb[2] - cb[1]) + 1ull;
-    const int di = src.days[src.row_of(blockIdx.x)];
+    const size_t i_row = src.row_of(blockIdx.x);
+    const int di = src.days[i_row];
+    for (unsigned w = threadIdx.x; w < TC_MARK_WIN; w += TC_ROW_THREADS) win[w] = 0u;
+    if (threadIdx.x == 0) {
+        const size_t j0 = max(i_row + 1, src.col_begin);
+        anchor_d = j0 < src.n ? src.dist[i_row * src.ld + j0] : 0u;
+    }
+    __syncthreads();
+    const unsigned long long span_d = ((unsigned long long)TC_MARK_WIN * 32ull) / stride;       // distances the window spans
+    const unsigned long long d0 = anchor_d > span_d / 2 ? anchor_d - span_d / 2 : 0ull;
+    const unsigned long long w_base = (d0 * stride) >> 5;
     unsigned mn = 0;
     bool beyond = false;
     tc_for_row_quads(src, [&](const RowQuad &c) {
@@ -1039,9 +1057,19 @@ __global__ __launch_bounds__(TC_ROW_THREADS) void tc_mark_kernel(DenseSource src
             if (key >= TC_GRID_BITS) { beyond = true; continue; }
             const unsigned idx = (unsigned)key;
             const unsigned bit = 1u << (idx & 31u);
-            if (!(bits[idx >> 5] & bit)) atomicOr(&bits[idx >> 5], bit);
+            const unsigned long long w = (unsigned long long)(idx >> 5);
+            if (w >= w_base && w < w_base + TC_MARK_WIN) atomicOr(&win[(unsigned)(w - w_base)], bit);
+            else if (!(bits[idx >> 5] & bit)) atomicOr(&bits[idx >> 5], bit);
         }
     });
+    __syncthreads();
+    for (unsigned w = threadIdx.x; w < TC_MARK_WIN; w += TC_ROW_THREADS) {
+        const unsigned v = win[w];
+        if (v && w_base + w < TC_GRID_BITS / 32) {
+            unsigned *dst = &bits[(size_t)(w_base + w)];
+            if ((*dst & v) != v) atomicOr(dst, v);
+        }
+    }
     for (int off = 32; off > 0; off >>= 1) mn = max(mn, (unsigned)__shfl_xor((int)mn, off, 64));
     // (one address for every workgroup of the grid: an atomic only from a wave that would raise what is there)
     if ((threadIdx.x & 63) == 0 && mn > __hip_atomic_load(&cb[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&cb[0], mn);
@@ -1321,7 +1349,8 @@ static int run_trans_dist_grid(const DenseSource &src, size_t total, double lamb
     TRACS_HIP_CHECK(hipMemsetAsync(bits, 0, (size_t)words * 4, stream));
     const dim3 row_grid = tc_row_grid(src);
     hipLaunchKernelGGL(tc_day_bounds_kernel, dim3(1), dim3(1024), 0, stream, src.days, src.n, cb);
-    hipLaunchKernelGGL(tc_mark_kernel, row_grid, dim3(TC_ROW_THREADS), 0, stream, src, cb, bits);
+    // (marking: one workgroup per row -- its LDS window is cleared and flushed once per workgroup)
+    hipLaunchKernelGGL(tc_mark_kernel, dim3(row_grid.x, src.n <= 32768 ? 1u : row_grid.y), dim3(TC_ROW_THREADS), 0, stream, src, cb, bits);
     hipLaunchKernelGGL(tc_bits_count_kernel, dim3(1024), dim3(256), 0, stream, bits, words, n_keys);
     unsigned h[8] = {0};
     TRACS_HIP_CHECK(hipMemcpyAsync(h, n_keys, 32, hipMemcpyDeviceToHost, stream));
