@@ -635,9 +635,11 @@ def main():
         if world == 1 and not args.no_extras and args.partial == 0 and args.workload == "sparse":
             out["sensitivity"] = sensitivity(args, n, L, seed, days, dev, synth, torch, device, lib, value)
             out["value_worst_workload"] = min([value] + [w["pairs_per_s"] for w in out["sensitivity"]["workloads"].values()])   # per call, like `value`
+        filter_block = None
         if world == 1 and not args.no_extras:
             # `tracs distance --filter`: the recombination filter over every emitted pair of the timed alignment (not part of `value`)
             out["filter"] = filter_leg(n, L, seed, synth_kw(args.partial, args.workload), aln, dmat, nmat, dev, synth, torch, device)
+            filter_block = out["filter"].pop("_block", None)
         if world == 1 and not args.no_extras and args.partial == 0:
             out["roofline_general"] = general_pass(args, n, L, seed, dev, synth, torch, device)
             out["dm_frontend"] = dm_frontend(args, L, dev, torch, device)
@@ -647,7 +649,10 @@ def main():
                 keys[0] = distinct_keys(torch, dmat, n, days, [(0, n)])
                 out["config"]["distinct_keys"] = keys[0]
         # ALWAYS: the first 128 samples' block against the oracle (full length, bit-equal), with or without the timed CPU legs
-        out["cpu_baseline"] = cpu_baseline(n, L, seed, days_np, args, dmat, nmat, keys[0], check_only=args.no_cpu_baseline)
+        out["cpu_baseline"] = cpu_baseline(n, L, seed, days_np, args, dmat, nmat, keys[0], check_only=args.no_cpu_baseline,
+                                           filter_block=filter_block)
+        if filter_block is not None and "filter" in out:
+            out["filter"]["oracle_check"] = out["cpu_baseline"].get("filter")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -931,7 +936,7 @@ def filter_leg(n, L, seed, kw, aln, dmat, nmat, dev, synth, torch, device, snp_t
       warm_call_s    the same call again (index and thresholds kept on the handle)
       threshold      the same with -D snp_threshold (only the pairs within the threshold are emitted)
       scan_route     rounds 1-5's route (a pair's SNP bits re-derived from the planes) on a bounded sample, extrapolated by pair count
-      oracle_check   the first `check` samples: GPU filtered distances == oracle at full length (always; a mismatch ends the run)"""
+    The first `check` samples' filtered distances go back under "_block" for cpu_baseline to hold against the oracle (`filter` there)."""
     import numpy as np
     rows, cols, d, _ = dev.coo_from_dense(dmat, nmat, n)
     pairs = rows.numel()
@@ -982,22 +987,13 @@ def filter_leg(n, L, seed, kw, aln, dmat, nmat, dev, synth, torch, device, snp_t
         out["scan_route"] = {"pairs": int(m), "seconds": t_scan, "pairs_per_s": m / t_scan, "all_pairs_s": t_scan * pairs / m,
                              "bytes_per_pair": float(L), "achieved_GBps": m * float(L) / t_scan / 1e9,
                              "note": "tracs_filter_recomb_device: 8 planes x L / 8 bytes per pair; extrapolated to all pairs"}
+    # the first `check` samples' pairs, for cpu_baseline (the one place that may touch oracle/) to hold against the oracle's filter_recomb
     k = min(n, check)
     if k >= 2:
-        from oracle import oracle as O
-        seqs = synth.first_samples_host(n, L, seed, k, **kw)
-        r, c, dd, _ = O.pairsnp_arrays(seqs)
-        t0 = time.perf_counter()
-        cores = len(os.sched_getaffinity(0))
-        ef = O.filter_recomb_pairs(seqs, r, c, cores)
-        t_or = time.perf_counter() - t0
-        ri, ci = torch.from_numpy(r.astype(np.int32)).to(device), torch.from_numpy(c.astype(np.int32)).to(device)
+        iu = np.triu_indices(k, 1)                              # row-major pair order (src/pairsnp.hpp:451-455)
+        ri, ci = torch.from_numpy(iu[0].astype(np.int32)).to(device), torch.from_numpy(iu[1].astype(np.int32)).to(device)
         gd = dmat[ri.long(), ci.long()].contiguous()
-        gf = dev.filter_recomb_pairs(aln, ri, ci, gd).cpu().numpy()
-        ok = bool(np.array_equal(gd.cpu().numpy(), dd.astype(np.int32)) and np.array_equal(gf, ef.astype(np.int32)))
-        out["oracle_check"] = {"samples": k, "pairs": int(len(r)), "equal": ok, "cpu_pairs_per_s": len(r) / t_or, "cores": cores, "kind": "port"}
-        if not ok:
-            raise SystemExit("PARITY FAILURE: filtered distances differ from the oracle on the first %d samples" % k)
+        out["_block"] = {"samples": k, "rows": iu[0], "cols": iu[1], "d": gd.cpu().numpy(), "filt": dev.filter_recomb_pairs(aln, ri, ci, gd).cpu().numpy()}
     return out
 
 
@@ -1129,7 +1125,7 @@ def dm_frontend(args, L, dev, torch, device):
     return out
 
 
-def cpu_baseline(n, L, seed, days_np, args, dmat, nmat, n_keys_full, m_max=128, check_only=False):
+def cpu_baseline(n, L, seed, days_np, args, dmat, nmat, n_keys_full, m_max=128, check_only=False, filter_block=None):
     """The oracle (C/OpenMP port of the reference algorithm) on the host cores, on a bounded sample of the same workload.
     Two legs, reported separately and never extrapolated through each other:
       pair loop   the first m samples of the SAME alignment, all m(m-1)/2 pairs at full length L, both passes, as the
@@ -1162,8 +1158,21 @@ def cpu_baseline(n, L, seed, days_np, args, dmat, nmat, n_keys_full, m_max=128, 
     gn = nmat[:m, :m].cpu().numpy().astype(np.int64)[ri, ci]
     if not (np.array_equal(gd, d.astype(np.int64)) and np.array_equal(gn, nn.astype(np.int64))):
         raise SystemExit("PARITY FAILURE: GPU d/nn differ from the oracle on the %d x %d sample block" % (m, m))
+    # the recombination filter (src/pairsnp.hpp:251-318) of the first samples' pairs: the oracle's scan of the planes against the GPU's
+    # filtered distances bench.py's `filter` leg handed over -- a result check (always) and the CPU rate beside the GPU's
+    flt = None
+    if filter_block is not None and filter_block["samples"] <= m:
+        kf = filter_block["samples"]
+        t0 = time.perf_counter()
+        ef = O.filter_recomb_pairs(seqs[:kf], filter_block["rows"].astype(np.uint64), filter_block["cols"].astype(np.uint64), cores)
+        t_f = time.perf_counter() - t0
+        ok = bool(np.array_equal(filter_block["d"].astype(np.int64), dmat[:kf, :kf].cpu().numpy().astype(np.int64)[filter_block["rows"], filter_block["cols"]]) and
+                  np.array_equal(filter_block["filt"].astype(np.int64), ef.astype(np.int64)))
+        if not ok:
+            raise SystemExit("PARITY FAILURE: filtered distances differ from the oracle on the first %d samples" % kf)
+        flt = {"samples": kf, "pairs": int(len(ef)), "equal": True, "cpu_pairs_per_s": len(ef) / t_f, "cores": cores, "kind": "port"}
     if check_only:
-        return {"value": None, "kind": "port", "cores": cores, "unit": "pairs/s",
+        return {"value": None, "kind": "port", "cores": cores, "unit": "pairs/s", "filter": flt,
                 "sample": "--no-cpu-baseline: only the result check ran -- first %d samples x %d sites, GPU d/nn bit-equal to the oracle" % (m, L)}
     delta = np.abs(days_np[ri] - days_np[ci]).astype(np.float64) * 86400.0 / 31556952.0
     # distinct keys in first-appearance order; time them in growing batches until the budget is spent
@@ -1181,7 +1190,7 @@ def cpu_baseline(n, L, seed, days_np, args, dmat, nmat, n_keys_full, m_max=128, 
     pairs_total = n * (n - 1) // 2
     value = pairs_total / (pairs_total / pair_rate + n_keys_full / key_rate)
     ref = _reference_trans_dist(kd[:done], kdel[:done], args)
-    return {"value": value, "unit": "pairs/s", "cores": cores, "kind": "port",
+    return {"value": value, "unit": "pairs/s", "cores": cores, "kind": "port", "filter": flt,
             "pairsnp_pairs_per_s": pair_rate, "pairsnp_threads": cores, "pairsnp_seconds": t_snp,
             "trans_dist_keys_per_s": key_rate, "trans_dist_threads": 1, "trans_dist_seconds": t_tc,
             "trans_dist_reference": ref,

@@ -47,6 +47,18 @@ def main():
     out = {"samples": n, "sites": L, "workload": args.workload, "partial": args.partial, "dense_call_s": time.perf_counter() - t0}
     out.update(B.filter_leg(n, L, seed, kw, aln, dmat, nmat, dev, synth, torch, device, snp_threshold=args.snp_threshold,
                             scan_sample=args.scan_sample, check=args.check))
+    blk = out.pop("_block", None)
+    if blk is not None:                                         # (bench.py proper leaves this to its cpu_baseline leg)
+        import numpy as np
+        from oracle import oracle as O
+        seqs = synth.first_samples_host(n, L, seed, blk["samples"], **kw)
+        t1 = time.perf_counter()
+        ef = O.filter_recomb_pairs(seqs, blk["rows"].astype(np.uint64), blk["cols"].astype(np.uint64), os.cpu_count() or 1)
+        ok = bool(np.array_equal(blk["filt"].astype(np.int64), ef.astype(np.int64)))
+        out["oracle_check"] = {"samples": blk["samples"], "pairs": int(len(ef)), "equal": ok, "cpu_pairs_per_s": len(ef) / (time.perf_counter() - t1)}
+        if not ok:
+            print(json.dumps(out, indent=1))
+            raise SystemExit("PARITY FAILURE: filtered distances differ from the oracle")
     print(json.dumps(out, indent=1))
     if args.out:
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
