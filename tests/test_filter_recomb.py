@@ -51,6 +51,23 @@ def test_oracle_filter_vs_python_restatement(oracle):
         assert oracle.filter_recomb_positions(pos, L) == _py_filter(pos, L)
 
 
+def test_binomial_tail_grows_with_the_span(oracle):
+    """What the GPU's threshold rows rest on (csrc/filter_lists.hip: per d, the smallest span that survives with `count` SNPs in the
+    window): 1 - BinomCDF(count; n, p) >= 0.05 / d, once true, stays true for every longer span -- checked with the oracle's CDF over
+    the whole range a window can have (count < n <= 2 w + 1) for distances from a handful to tens of thousands."""
+    for L, d in ((5000000, 980), (5000000, 21000), (5000000, 2), (120000, 37), (9000, 600), (1000000, 65536)):
+        p, thr = d / L, 0.05 / d
+        w = max(min(int(1.0 / p / 2.0 + 1), 5000), 50)
+        nmax = min(L, 2 * w + 1)
+        for k in (2, 3, 5, 9, 17, 40, 63):
+            if k + 1 > nmax:
+                continue
+            ns = np.unique(np.concatenate([np.arange(k + 1, min(nmax, k + 400) + 1), np.linspace(k + 1, nmax, 300).astype(int)]))
+            keep = np.array([1.0 - oracle.binomial_cdf(int(n), p, k) >= thr for n in ns])
+            first = int(np.argmax(keep)) if keep.any() else len(keep)
+            assert keep[first:].all() and not keep[:first].any(), (L, d, k)
+
+
 def test_oracle_filter_removes_a_planted_block(oracle):
     from tracs_amd import synth
     L = 150000
