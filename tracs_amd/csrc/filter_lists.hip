@@ -791,8 +791,16 @@ __global__ __launch_bounds__(64) void flt_pairs_long_kernel(FltPairArgs A, const
 #define TRACS_FLT_TILE 512
 #endif
 constexpr unsigned FLT_TILE = TRACS_FLT_TILE, FLT_TILE_R = FLT_TILE / 64;
+// (a tile's merged entries in registers -- 4.9 KB of LDS per wave --, six waves per SIMD and 24 per CU in the grid: 22.5 s where the
+// M array in LDS and sixteen waves per CU take 24.0: profiles/r06/filter_tile_sweep.txt)
 #ifndef TRACS_FLT_TWAVES
-#define TRACS_FLT_TWAVES 0
+#define TRACS_FLT_TWAVES 6
+#endif
+#ifndef TRACS_FLT_TREGS
+#define TRACS_FLT_TREGS 1
+#endif
+#ifndef TRACS_FLT_TGRID
+#define TRACS_FLT_TGRID 24
 #endif
 #if TRACS_FLT_TWAVES > 0
 #define TRACS_FLT_TATTR __attribute__((amdgpu_waves_per_eu(TRACS_FLT_TWAVES, TRACS_FLT_TWAVES)))
@@ -805,7 +813,11 @@ __global__ __launch_bounds__(64) TRACS_FLT_TATTR void flt_pairs_tiled_kernel(Flt
     extern __shared__ unsigned flt_lds[];
     constexpr unsigned CAP = FLT_TILE + 64, INF = 0xFFFFFFFFu, R = FLT_TILE_R;
     const unsigned lane = threadIdx.x;
+#if TRACS_FLT_TREGS
+    unsigned *LA = flt_lds, *LB = LA + CAP, *M = nullptr, *split = LB + CAP;                     // split: 65 words
+#else
     unsigned *LA = flt_lds, *LB = LA + CAP, *M = LB + CAP, *split = M + 2 * FLT_TILE + 128;      // split: 65 words
+#endif
     unsigned *S = scratch + (size_t)blockIdx.x * slot + 2;                 // (two sentinels in front, two behind)
     for (size_t q = blockIdx.x; q < n_idx; q += gridDim.x) {
         const size_t t = idx[q];
@@ -876,14 +888,27 @@ __global__ __launch_bounds__(64) TRACS_FLT_TATTR void flt_pairs_tiled_kernel(Flt
                 unsigned va = a < la_t ? LA[a] : INF, vb = b <= lb_t ? LB[b] : INF;
                 unsigned lastA = a > 0u ? (LA[a - 1u] >> 5) : prevA;
                 unsigned cnt = 0;
+#if TRACS_FLT_TREGS
+                unsigned sv[R];                                            // (C <= R: a tile's merged entries, FLT_TILE / 64 per lane)
+                (void)stride;
+#pragma unroll
+                for (unsigned step = 0; step < R; step++) {
+                    sv[step] = 0u;
+                    if (step >= C) continue;
+#else
                 unsigned *Mrow = M + lane * stride;
                 for (unsigned step = 0; step < C; step++) {
+#endif
                     const unsigned pa = va >> 5, pb = vb >> 5;
                     const bool takeA = pa <= pb;
                     const unsigned snpA = pa == pb ? (((va & vb & 15u) == 0u) ? 1u : 0u) : ((va >> 4) & 1u);
                     const unsigned snpB = lastA == pb ? 0u : ((vb >> 4) & 1u);
                     const unsigned snp = (D + step < tot_t) ? (takeA ? snpA : snpB) : 0u;
+#if TRACS_FLT_TREGS
+                    sv[step] = (takeA ? pa : pb) | (snp << 31);
+#else
                     Mrow[step] = (takeA ? pa : pb) | (snp << 31);
+#endif
                     cnt += snp;
                     const unsigned nidx = takeA ? a + 1u : CAP + b + 1u, nlim = takeA ? la_t : CAP + lb_t + 1u;
                     const unsigned nxt = nidx < nlim ? LA[nidx] : INF;
@@ -897,10 +922,16 @@ __global__ __launch_bounds__(64) TRACS_FLT_TATTR void flt_pairs_tiled_kernel(Flt
                 }
                 {
                     unsigned o = dn + incl - cnt;
+#if TRACS_FLT_TREGS
+#pragma unroll
+                    for (unsigned step = 0; step < R; step++)
+                        if (sv[step] >> 31) S[o++] = sv[step] & 0x7FFFFFFFu;
+#else
                     for (unsigned step = 0; step < C; step++) {
                         const unsigned v = Mrow[step];
                         if (v >> 31) S[o++] = v & 0x7FFFFFFFu;
                     }
+#endif
                 }
                 dn += __shfl(incl, 63, 64);
                 flt_wave_sync();                                           // (the next tile's entries take the place of this one's)
@@ -1140,7 +1171,7 @@ int tracs_filter_recomb_pairs(tracs_alignment *a, const uint32_t *rows, const ui
         // lists too long for a wave's LDS: the same merge over global memory (flt_pairs_long_kernel)
         unsigned *idx, *scratch;
         const size_t slot = ((size_t)2 * f->max_len + 8 + 63) / 64 * 64;
-        size_t waves = std::min<size_t>(n_left, 256 * 16);
+        size_t waves = std::min<size_t>(n_left, 256 * TRACS_FLT_TGRID);
         while (waves > 256 && waves * slot * 4 > (3ull << 30)) waves /= 2;
         if ((rc = workspace_get(FltWs::IDX, n_left * 4, reinterpret_cast<void **>(&idx))) ||
             (rc = workspace_get(FltWs::SCRATCH, waves * slot * 4, reinterpret_cast<void **>(&scratch)))) return rc;
@@ -1159,8 +1190,8 @@ int tracs_filter_recomb_pairs(tracs_alignment *a, const uint32_t *rows, const ui
         if (lf && lf[0] == 's')
             hipLaunchKernelGGL(flt_pairs_long_kernel, dim3((unsigned)waves), dim3(64), 0, stream, A, idx, n_left, scratch, slot);
         else
-            hipLaunchKernelGGL(flt_pairs_tiled_kernel, dim3((unsigned)waves), dim3(64), (size_t)(2 * (FLT_TILE + 64) + 2 * FLT_TILE + 128 + 80) * 4, stream, A,
-                               idx, n_left, scratch, slot);
+            hipLaunchKernelGGL(flt_pairs_tiled_kernel, dim3((unsigned)waves), dim3(64),
+                               (size_t)(2 * (FLT_TILE + 64) + (TRACS_FLT_TREGS ? 0 : 2 * FLT_TILE + 128) + 80) * 4, stream, A, idx, n_left, scratch, slot);
     }
     TRACS_HIP_CHECK(hipGetLastError());
     unsigned bad = 0;
