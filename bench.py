@@ -723,6 +723,9 @@ def site_sharded(args, n, L, seed, world, rank, device, dist, exchange, comm_inf
     lib.tracs_debug_pack_timing(1)
     ex = partition.TriExchange(n, 0, n, 0, rank, world, dist, device)
     own = ex.own_ranges                                        # the rows this rank owns of every result (at most two ranges)
+    # transcluster over the own rows with the key evaluations split over the ranks (partition.KeySplit: every distinct key of the whole
+    # matrix evaluated by ONE rank, two small all-gathers); TRACS_KEY_SPLIT=0: every rank evaluates the keys of its own rows
+    ks = partition.KeySplit(n, rank, world, dist, device) if os.environ.get("TRACS_KEY_SPLIT", "1") != "0" else None
 
     def step(per_call=True):
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -733,7 +736,9 @@ def site_sharded(args, n, L, seed, world, rank, device, dist, exchange, comm_inf
         marks[1].record()
         ex.run(dmat, nmat, l1 - l0, L)                         # pack -> all-to-all -> sum into the own rows
         marks[2].record()
-        if own:
+        if ks is not None:
+            ks.run(dmat, days, own, args.lamb, args.beta, args.precision, pmat, emat, exp_p0=True)
+        elif own:
             dev.trans_dist_dense_ranges(dmat, n, days, args.lamb, args.beta, args.precision, pmat, emat, own, exp_p0=True)
         marks[3].record()
         return marks
@@ -821,6 +826,13 @@ def site_sharded(args, n, L, seed, world, rank, device, dist, exchange, comm_inf
                                        "(d; nn as its deficit below the slice's length), all-to-all, summed by the receiver --: rank q owns the rows "
                                        "of chunks q and %d - q (%d rows each; no all-gather; transcluster on a rank's own rows)"
                                        % (groups, world, l1 - l0, L, ex.widths[0], ex.widths[1], 2 * world - 1, ex.cs),
+                          "transcluster_keys": ({"route": ks.last_route, "distinct_keys_whole_matrix": ks.last_info[0],
+                                                 "evaluated_by_rank0": int(_lib.load().tracs_debug_last_trans_dist_keys()) if ks.last_route == "split" else None,
+                                                 "bytes_gathered_per_rank_per_call": ks.bytes_gathered_per_call(),
+                                                 "how": "every rank marks its rows' (N, day gap) keys in a bitmap, all-gather + OR, rank r evaluates the "
+                                                        "keys of ordinal r mod P, all-gather of the compact (log p0, E(K)) arrays, every rank fills its table"}
+                                                if ks is not None and ks.last_info is not None else
+                                                {"route": "every rank evaluates the keys of its own rows"}),
                           "rank0_ms": {"dense call over the slice (once-per-pack work included)": mean_ms(0, 1),
                                        "exchange (pack, all-to-all, sum)": mean_ms(1, 2), "transcluster over the rank's own rows": mean_ms(2, 3)},
                           "exchange_bytes_per_rank_per_call": ex.bytes_sent_per_call(), "exchange_bytes_per_cell": ex.bytes_per_cell(),

@@ -238,6 +238,31 @@ int tracs_trans_table_gather(const uint32_t *dist, size_t ld, size_t n, size_t r
                              const double *table_p0, const double *table_eK, int exp_p0, double *p0, double *eK,
                              uint32_t *overflow, void *stream);
 
+/* The distinct keys SPLIT over ranks that each hold rows of the matrix (site shards): src/transcluster.hpp:245-246,
+ * 265-282 memoises per (N, delta) key -- here every key of the WHOLE matrix is evaluated by exactly one rank.
+ *   tracs_trans_keys_words     uint32 words of a key bitmap (the (N, day gap) grid + four words: largest distance, smallest and
+ *                              largest day + 2^31, "a key fell outside the grid")
+ *   tracs_trans_keys_mark      the keys of the cells (i in the row ranges -- 0, 1 or 2 --, j >= max(col_begin, i + 1), d <=
+ *                              dist_threshold) marked into `keys` (device, tracs_trans_keys_words() words, overwritten)
+ *   tracs_trans_keys_merge     keys <- the union of `parts` bitmaps laid end to end in `all` (what an all-gather leaves)
+ *   tracs_trans_keys_info      host info[4] = {distinct keys, largest distance, span of the days, 1 if the keys fit the grid};
+ *                              synchronises the stream.  info[3] == 0: take tracs_trans_dist_dense2 on the own rows instead
+ *   tracs_trans_keys_evaluate  the keys whose ordinal (set bits before it in the union) is = part mod parts, evaluated into
+ *                              vals[2 (ordinal / parts)] = log p0, [.. + 1] = E(K) (device f64, per >= ceil(keys / parts) slots)
+ *   tracs_trans_keys_gather    vals_all = the `parts` arrays of `per` slots each, end to end (what an all-gather leaves): p0 / eK
+ *                              of every cell of the row ranges, as tracs_trans_dist_dense2 writes them
+ * Same arithmetic per key as tracs_trans_dist_dense.                                                                          */
+size_t tracs_trans_keys_words(void);
+int tracs_trans_keys_mark(const uint32_t *dist, size_t ld, size_t n, const size_t *row_ranges, int n_ranges, size_t col_begin,
+                          int32_t dist_threshold, const int32_t *days, uint32_t *keys, void *stream);
+int tracs_trans_keys_merge(uint32_t *keys, const uint32_t *all, int parts, void *stream);
+int tracs_trans_keys_info(const uint32_t *keys, uint64_t *info, void *stream);
+int tracs_trans_keys_evaluate(const uint32_t *keys, const uint64_t *info, int part, int parts, double lamb, double beta,
+                              double threshold_Ek, double *vals, size_t per, void *stream);
+int tracs_trans_keys_gather(const uint32_t *dist, size_t ld, size_t n, const size_t *row_ranges, int n_ranges, size_t col_begin,
+                            int32_t dist_threshold, const int32_t *days, const uint32_t *keys, const uint64_t *info,
+                            const double *vals_all, int parts, size_t per, int exp_p0, double *p0, double *eK, void *stream);
+
 /* calculate_posteriors on device arrays; counts/posterior are device f64 [L][K].            */
 int tracs_calculate_posteriors_device(const double *counts, size_t L, size_t K, const double *alphas_host,
                                       int keep, double threshold, double *posterior, void *stream);

@@ -122,6 +122,11 @@ def test_bench_gpus_2_launches_its_own_ranks(part):
         # (P - 1) blocks of this rank's share of the upper triangle: a quarter of two full uint32 matrices, give or take the chunking
         assert j["config"]["exchange_bytes_per_rank_per_call"] <= 0.3 * 2 * 4 * 1501 * 1501 / 2
         assert j["roofline_per_pack"]["per_pack_ms"] > 0
+        # transcluster's distinct keys split over the two ranks (partition.KeySplit): rank 0 evaluated half of the whole matrix's keys
+        tk = j["config"]["transcluster_keys"]
+        assert tk["route"] == "split" and tk["distinct_keys_whole_matrix"] == j["config"]["distinct_keys"]
+        assert tk["evaluated_by_rank0"] == -(-tk["distinct_keys_whole_matrix"] // 2)
+        assert tk["bytes_gathered_per_rank_per_call"] == (2 ** 24 // 32 + 4) * 4 + 16 * -(-tk["distinct_keys_whole_matrix"] // 2)
 
 
 def test_bench_refuses_a_world_that_is_not_gpus():

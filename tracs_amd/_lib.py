@@ -23,6 +23,7 @@ SYMBOLS = [
     "tracs_free",
     "tracs_pairsnp_dense", "tracs_pairsnp_dense_thr", "tracs_coo_count", "tracs_coo_fill", "tracs_filter_recomb_device", "tracs_filter_recomb_pairs",
     "tracs_trans_dist_device", "tracs_trans_dist_dense", "tracs_trans_dist_dense2", "tracs_trans_table_dense", "tracs_trans_table_gather",
+    "tracs_trans_keys_words", "tracs_trans_keys_mark", "tracs_trans_keys_merge", "tracs_trans_keys_info", "tracs_trans_keys_evaluate", "tracs_trans_keys_gather",
     "tracs_calculate_posteriors_device", "tracs_posterior_codes_device", "tracs_posterior_codes_cov_device",
     "tracs_codes_to_iupac_device", "tracs_alignment_pack_codes", "tracs_alignment_pack_codes_batch", "tracs_edges_count_f64", "tracs_edges_fill_f64",
     "tracs_coverage_profile_device32", "tracs_posterior_codes_cov_device32", "tracs_consensus_codes_device32", "tracs_coverage_profile_device",
@@ -164,6 +165,18 @@ def load():
     L.tracs_trans_table_dense.argtypes = [vp, sz, sz, sz, sz, sz, C.c_int32, vp, dbl, dbl, dbl, C.c_int, C.c_int, C.c_uint32, C.c_uint32, vp, vp, vp, vp]
     L.tracs_trans_table_gather.restype = C.c_int
     L.tracs_trans_table_gather.argtypes = [vp, sz, sz, sz, sz, sz, C.c_int32, vp, C.c_uint32, C.c_uint32, vp, vp, C.c_int, vp, vp, vp, vp]
+    L.tracs_trans_keys_words.restype = sz
+    L.tracs_trans_keys_words.argtypes = []
+    L.tracs_trans_keys_mark.restype = C.c_int
+    L.tracs_trans_keys_mark.argtypes = [vp, sz, sz, C.POINTER(sz), C.c_int, sz, C.c_int32, vp, vp, vp]
+    L.tracs_trans_keys_merge.restype = C.c_int
+    L.tracs_trans_keys_merge.argtypes = [vp, vp, C.c_int, vp]
+    L.tracs_trans_keys_info.restype = C.c_int
+    L.tracs_trans_keys_info.argtypes = [vp, C.POINTER(C.c_uint64), vp]
+    L.tracs_trans_keys_evaluate.restype = C.c_int
+    L.tracs_trans_keys_evaluate.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int, C.c_int, dbl, dbl, dbl, vp, sz, vp]
+    L.tracs_trans_keys_gather.restype = C.c_int
+    L.tracs_trans_keys_gather.argtypes = [vp, sz, sz, C.POINTER(sz), C.c_int, sz, C.c_int32, vp, vp, C.POINTER(C.c_uint64), vp, C.c_int, sz, C.c_int, vp, vp, vp]
     L.tracs_calculate_posteriors_device.restype = C.c_int
     L.tracs_calculate_posteriors_device.argtypes = [vp, sz, sz, dp, C.c_int, dbl, vp, vp]
     L.tracs_posterior_codes_device.restype = C.c_int

@@ -1382,6 +1382,134 @@ static int run_trans_dist_grid(const DenseSource &src, size_t total, double lamb
     return TRACS_OK;
 }
 
+// ---- the distinct keys split over the ranks (site shards, every rank holds ROWS of the summed matrix) -----------------
+// A rank's rows see most of the matrix's distinct (N, day gap) keys, so evaluating "its" keys is nearly all of them on every rank.
+// Instead: every rank marks the keys of its rows in the grid bitmap (tc_mark_kernel; KS_WORDS words + a trailer of four: largest
+// distance, smallest / largest day + 2^31, "a key fell outside the grid"), the bitmaps are all-gathered and ORed -- every rank now
+// holds the SAME union --, the keys are numbered by their position in the union (ordinal = set bits before it), rank r evaluates the
+// ordinals o with o % P == r into a compact array (slot o / P: log p0, E(K)), the arrays are all-gathered (16 bytes per distinct key
+// in total), and every rank fills its dense (N, gap) table from them and gathers its rows.  No atomics in the numbering: every rank
+// derives the same ordinals from the same bitmap.
+constexpr unsigned KS_WORDS = (unsigned)(TC_GRID_BITS / 32);
+constexpr unsigned KS_TRAILER = 4;
+constexpr unsigned KS_CHUNK = 1024;                         // words per workgroup of the numbering
+constexpr unsigned KS_CHUNKS = KS_WORDS / KS_CHUNK;
+static_assert(KS_CHUNKS == 512, "ks_chunk_scan_kernel: one thread per chunk");
+struct KsWs { enum { RANK = 80, CHUNK, INFO }; };
+
+__global__ void ks_merge_kernel(unsigned *__restrict__ own, const unsigned *__restrict__ all, int parts)
+{
+    const size_t stride = (size_t)KS_WORDS + KS_TRAILER;
+    for (unsigned w = blockIdx.x * blockDim.x + threadIdx.x; w < KS_WORDS + KS_TRAILER; w += gridDim.x * blockDim.x) {
+        unsigned v = all[w];
+        for (int p = 1; p < parts; p++) {
+            const unsigned o = all[(size_t)p * stride + w];
+            if (w < KS_WORDS || w == KS_WORDS + 3u) v |= o;          // marks; "does not fit"
+            else if (w == KS_WORDS + 1u) v = min(v, o);              // smallest day
+            else v = max(v, o);                                      // largest distance, largest day
+        }
+        own[w] = v;
+    }
+}
+
+// word_rank[w] = set bits of the chunk before word w; chunk_sum[c] = set bits of chunk c
+__global__ __launch_bounds__(256) void ks_rank_kernel(const unsigned *__restrict__ bits, unsigned *__restrict__ word_rank, unsigned *__restrict__ chunk_sum)
+{
+    __shared__ unsigned wtot[4];
+    const unsigned t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const size_t w0 = (size_t)blockIdx.x * KS_CHUNK + 4u * t;
+    const uint4 v = *reinterpret_cast<const uint4 *>(bits + w0);
+    const unsigned c0 = __popc(v.x), c1 = __popc(v.y), c2 = __popc(v.z), c3 = __popc(v.w), c = c0 + c1 + c2 + c3;
+    unsigned x = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const unsigned o = __shfl_up(x, off, 64); if ((int)lane >= off) x += o; }
+    if (lane == 63u) wtot[wave] = x;
+    __syncthreads();
+    unsigned before = x - c;
+    for (unsigned k = 0; k < wave; k++) before += wtot[k];
+    *reinterpret_cast<uint4 *>(word_rank + w0) = make_uint4(before, before + c0, before + c0 + c1, before + c0 + c1 + c2);
+    if (t == 255u) chunk_sum[blockIdx.x] = before + c;
+}
+
+// chunk sums -> exclusive bases (in place); total[0] = distinct keys
+__global__ __launch_bounds__(512) void ks_chunk_scan_kernel(unsigned *__restrict__ chunk, unsigned *__restrict__ total)
+{
+    __shared__ unsigned wtot[8];
+    const unsigned t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const unsigned c = chunk[t];
+    unsigned x = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const unsigned o = __shfl_up(x, off, 64); if ((int)lane >= off) x += o; }
+    if (lane == 63u) wtot[wave] = x;
+    __syncthreads();
+    unsigned before = x - c;
+    for (unsigned k = 0; k < wave; k++) before += wtot[k];
+    chunk[t] = before;
+    if (t == 511u) total[0] = before + c;
+}
+
+// the grid indices of this rank's keys (ordinal % parts == part) at key_elem[ordinal / parts]
+__global__ void ks_collect_kernel(const unsigned *__restrict__ bits, const unsigned *__restrict__ word_rank, const unsigned *__restrict__ chunk_base,
+                                  unsigned part, unsigned parts, unsigned *__restrict__ key_elem)
+{
+    for (unsigned w = blockIdx.x * blockDim.x + threadIdx.x; w < KS_WORDS; w += gridDim.x * blockDim.x) {
+        unsigned x = bits[w];
+        if (!x) continue;
+        unsigned o = chunk_base[w / KS_CHUNK] + word_rank[w];
+        while (x) {
+            if (o % parts == part) key_elem[o / parts] = w * 32u + (unsigned)(__ffs(x) - 1);
+            x &= x - 1; o++;
+        }
+    }
+}
+
+__global__ void ks_pack_kernel(const unsigned *__restrict__ key_elem, unsigned n_own, const double *__restrict__ tables, double *__restrict__ vals)
+{
+    for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < n_own; j += gridDim.x * blockDim.x)
+        *reinterpret_cast<double2 *>(vals + 2 * (size_t)j) = *reinterpret_cast<const double2 *>(tables + 2 * (size_t)key_elem[j]);
+}
+
+// every key's (log p0 -> p0 if asked, E(K)) from the gathered arrays into the dense table
+__global__ void ks_unpack_kernel(const unsigned *__restrict__ bits, const unsigned *__restrict__ word_rank, const unsigned *__restrict__ chunk_base,
+                                 unsigned parts, size_t per, const double *__restrict__ vals_all, int exp_p0, double *__restrict__ tables)
+{
+    for (unsigned w = blockIdx.x * blockDim.x + threadIdx.x; w < KS_WORDS; w += gridDim.x * blockDim.x) {
+        unsigned x = bits[w];
+        if (!x) continue;
+        unsigned o = chunk_base[w / KS_CHUNK] + word_rank[w];
+        while (x) {
+            const size_t idx = (size_t)w * 32u + (unsigned)(__ffs(x) - 1);
+            double2 v = *reinterpret_cast<const double2 *>(vals_all + 2 * ((size_t)(o % parts) * per + o / parts));
+            if (exp_p0) v.x = exp(v.x);
+            *reinterpret_cast<double2 *>(tables + 2 * idx) = v;
+            x &= x - 1; o++;
+        }
+    }
+}
+
+static int ks_number(const unsigned *keys, unsigned **word_rank, unsigned **chunk_base, unsigned *total_dev, hipStream_t stream)
+{
+    int rc;
+    if ((rc = workspace_get(KsWs::RANK, (size_t)KS_WORDS * 4, reinterpret_cast<void **>(word_rank)))) return rc;
+    if ((rc = workspace_get(KsWs::CHUNK, (size_t)KS_CHUNKS * 4, reinterpret_cast<void **>(chunk_base)))) return rc;
+    hipLaunchKernelGGL(ks_rank_kernel, dim3(KS_CHUNKS), dim3(256), 0, stream, keys, *word_rank, *chunk_base);
+    hipLaunchKernelGGL(ks_chunk_scan_kernel, dim3(1), dim3(512), 0, stream, *chunk_base, total_dev);
+    TRACS_HIP_CHECK(hipGetLastError());
+    return TRACS_OK;
+}
+
+struct KsInfo { unsigned long long nk, n_max, d_max, fits; };
+static int ks_info_of(const uint64_t *info, KsInfo &k, const char *who)
+{
+    if (!info) { set_error(std::string(who) + ": NULL info"); return TRACS_E_ARG; }
+    k.nk = info[0]; k.n_max = info[1]; k.d_max = info[2]; k.fits = info[3];
+    if (!k.fits || (k.n_max + 1ull) * (k.d_max + 1ull) > TC_GRID_BITS || k.nk > TC_GRID_BITS) {
+        set_error(std::string(who) + ": the keys do not fit the grid (tracs_trans_keys_info said so: take tracs_trans_dist_dense2)");
+        return TRACS_E_ARG;
+    }
+    return TRACS_OK;
+}
+
 }  // namespace tracs
 
 using namespace tracs;
@@ -1389,6 +1517,129 @@ using namespace tracs;
 extern "C" {
 
 unsigned long long tracs_debug_last_trans_dist_keys(void) { return g_last_keys; }
+
+size_t tracs_trans_keys_words(void) { return (size_t)KS_WORDS + KS_TRAILER; }
+
+int tracs_trans_keys_mark(const uint32_t *dist, size_t ld, size_t n, const size_t *row_ranges, int n_ranges, size_t col_begin,
+                          int32_t dist_threshold, const int32_t *days, uint32_t *keys, void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!days || !keys || (n_ranges > 0 && (!dist || !row_ranges))) { set_error("tracs_trans_keys_mark: NULL argument"); return TRACS_E_ARG; }
+    if (n_ranges < 0 || n_ranges > 2) { set_error("tracs_trans_keys_mark: 0, 1 or 2 row ranges"); return TRACS_E_ARG; }
+    DeviceCall guard(stream);
+    DenseSource src{dist, days, ld, n, 0, 0, col_begin, dist_threshold};
+    if (n_ranges >= 1) { src.row_begin = std::min(row_ranges[0], n); src.row_end = std::min(row_ranges[1], n); }
+    if (n_ranges == 2) { src.row_begin2 = std::min(row_ranges[2], n); src.row_end2 = std::min(row_ranges[3], n); }
+    if (src.row_end < src.row_begin || src.row_end2 < src.row_begin2) { set_error("tracs_trans_keys_mark: bad range"); return TRACS_E_ARG; }
+    unsigned *bits = keys, *cb = keys + KS_WORDS;
+    const unsigned init[KS_TRAILER] = {0u, 0xFFFFFFFFu, 0u, 0u};
+    TRACS_HIP_CHECK(hipMemsetAsync(bits, 0, (size_t)KS_WORDS * 4, stream));
+    TRACS_HIP_CHECK(hipMemcpyAsync(cb, init, sizeof(init), hipMemcpyHostToDevice, stream));
+    if (n == 0) return TRACS_OK;
+    hipLaunchKernelGGL(tc_day_bounds_kernel, dim3(1), dim3(1024), 0, stream, days, n, cb);
+    const dim3 row_grid = tc_row_grid(src);
+    if (row_grid.x > 0)
+        hipLaunchKernelGGL(tc_mark_kernel, dim3(row_grid.x, n <= 32768 ? 1u : row_grid.y), dim3(TC_ROW_THREADS), 0, stream, src, cb, bits);
+    TRACS_HIP_CHECK(hipGetLastError());
+    return TRACS_OK;
+}
+
+int tracs_trans_keys_merge(uint32_t *keys, const uint32_t *all, int parts, void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!keys || !all || parts < 1) { set_error("tracs_trans_keys_merge: bad argument"); return TRACS_E_ARG; }
+    DeviceCall guard(stream);
+    hipLaunchKernelGGL(ks_merge_kernel, dim3(1024), dim3(256), 0, stream, keys, all, parts);
+    TRACS_HIP_CHECK(hipGetLastError());
+    return TRACS_OK;
+}
+
+int tracs_trans_keys_info(const uint32_t *keys, uint64_t *info, void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!keys || !info) { set_error("tracs_trans_keys_info: NULL argument"); return TRACS_E_ARG; }
+    DeviceCall guard(stream);
+    unsigned *word_rank = nullptr, *chunk_base = nullptr, *total = nullptr;
+    int rc;
+    if ((rc = workspace_get(KsWs::INFO, 64, reinterpret_cast<void **>(&total)))) return rc;
+    if ((rc = ks_number(keys, &word_rank, &chunk_base, total, stream))) return rc;
+    unsigned h[1 + KS_TRAILER] = {0};
+    TRACS_HIP_CHECK(hipMemcpyAsync(h, total, 4, hipMemcpyDeviceToHost, stream));
+    TRACS_HIP_CHECK(hipMemcpyAsync(h + 1, keys + KS_WORDS, KS_TRAILER * 4, hipMemcpyDeviceToHost, stream));
+    TRACS_HIP_CHECK(hipStreamSynchronize(stream));
+    const bool days_ok = h[3] >= h[2];
+    info[0] = h[0]; info[1] = h[1]; info[2] = days_ok ? h[3] - h[2] : 0u;
+    info[3] = (days_ok && !h[4] && ((unsigned long long)h[1] + 1ull) * ((unsigned long long)(h[3] - h[2]) + 1ull) <= TC_GRID_BITS) ? 1u : 0u;
+    return TRACS_OK;
+}
+
+int tracs_trans_keys_evaluate(const uint32_t *keys, const uint64_t *info, int part, int parts, double lamb, double beta,
+                              double threshold_Ek, double *vals, size_t per, void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    KsInfo k;
+    int rc;
+    if (!keys) { set_error("tracs_trans_keys_evaluate: NULL argument"); return TRACS_E_ARG; }
+    if ((rc = ks_info_of(info, k, "tracs_trans_keys_evaluate"))) return rc;
+    if (parts < 1 || part < 0 || part >= parts) { set_error("tracs_trans_keys_evaluate: bad key partition"); return TRACS_E_ARG; }
+    const unsigned n_own = k.nk > (unsigned long long)part ? (unsigned)((k.nk - part + parts - 1) / parts) : 0u;
+    g_last_keys = n_own;
+    if (n_own == 0) return TRACS_OK;
+    if (!vals || per < n_own) { set_error("tracs_trans_keys_evaluate: vals holds fewer than ceil(keys / parts) slots"); return TRACS_E_ARG; }
+    DeviceCall guard(stream);
+    const double *lg = nullptr;
+    if ((rc = get_lgamma_table(stream, &lg))) return rc;
+    unsigned *word_rank = nullptr, *chunk_base = nullptr, *n_keys = nullptr, *key_elem = nullptr;
+    double *tables = nullptr;
+    if ((rc = workspace_get(TcWorkspaceIds::NKEYS, 64, reinterpret_cast<void **>(&n_keys)))) return rc;
+    if ((rc = ks_number(keys, &word_rank, &chunk_base, n_keys + 12, stream))) return rc;
+    const size_t cells = (size_t)(k.n_max + 1) * (size_t)(k.d_max + 1);
+    if ((rc = workspace_get(TcWorkspaceIds::GRID_TABLES, cells * 16, reinterpret_cast<void **>(&tables)))) return rc;
+    if ((rc = workspace_get(TcWorkspaceIds::KEY_ELEM, (size_t)n_own * 4, reinterpret_cast<void **>(&key_elem)))) return rc;
+    hipLaunchKernelGGL(ks_collect_kernel, dim3(1024), dim3(256), 0, stream, keys, word_rank, chunk_base, (unsigned)part, (unsigned)parts, key_elem);
+    const unsigned init[8] = {n_own, 0u, 0u, 0u, 0u, 0u, 0u, 0u};      // [0] keys, [1] long keys; [7] a key outside the table (cannot happen)
+    TRACS_HIP_CHECK(hipMemcpyAsync(n_keys, init, sizeof(init), hipMemcpyHostToDevice, stream));
+    KeyTable kt;
+    kt.n_max = (unsigned)k.n_max; kt.d_max = (unsigned)k.d_max; kt.p0 = tables; kt.eK = tables + 1; kt.step = 2; kt.overflow = n_keys + 7;
+    GridSource grid{(unsigned)k.d_max + 1u, cells};
+    double *key_p0 = nullptr, *key_eK = nullptr;
+    if ((rc = tc_evaluate_keys(grid, key_elem, n_own, n_keys, lamb, beta, threshold_Ek, lg, &key_p0, &key_eK, kt, stream))) return rc;
+    hipLaunchKernelGGL(ks_pack_kernel, dim3(std::min(1024u, (n_own + 255u) / 256u)), dim3(256), 0, stream, key_elem, n_own, tables, vals);
+    TRACS_HIP_CHECK(hipGetLastError());
+    return TRACS_OK;
+}
+
+int tracs_trans_keys_gather(const uint32_t *dist, size_t ld, size_t n, const size_t *row_ranges, int n_ranges, size_t col_begin,
+                            int32_t dist_threshold, const int32_t *days, const uint32_t *keys, const uint64_t *info,
+                            const double *vals_all, int parts, size_t per, int exp_p0, double *p0, double *eK, void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    KsInfo k;
+    int rc;
+    if (!keys || !days || (n_ranges > 0 && (!dist || !row_ranges || !p0 || !eK))) { set_error("tracs_trans_keys_gather: NULL argument"); return TRACS_E_ARG; }
+    if ((rc = ks_info_of(info, k, "tracs_trans_keys_gather"))) return rc;
+    if (n_ranges < 0 || n_ranges > 2 || parts < 1) { set_error("tracs_trans_keys_gather: bad argument"); return TRACS_E_ARG; }
+    DenseSource src{dist, days, ld, n, 0, 0, col_begin, dist_threshold};
+    if (n_ranges >= 1) { src.row_begin = std::min(row_ranges[0], n); src.row_end = std::min(row_ranges[1], n); }
+    if (n_ranges == 2) { src.row_begin2 = std::min(row_ranges[2], n); src.row_end2 = std::min(row_ranges[3], n); }
+    if (src.row_end < src.row_begin || src.row_end2 < src.row_begin2) { set_error("tracs_trans_keys_gather: bad range"); return TRACS_E_ARG; }
+    const dim3 row_grid = tc_row_grid(src);
+    if (row_grid.x == 0 || n == 0 || k.nk == 0) return TRACS_OK;
+    if (!vals_all || per * (unsigned long long)parts < k.nk) { set_error("tracs_trans_keys_gather: vals_all holds fewer slots than keys"); return TRACS_E_ARG; }
+    DeviceCall guard(stream);
+    unsigned *word_rank = nullptr, *chunk_base = nullptr, *n_keys = nullptr;
+    double *tables = nullptr;
+    if ((rc = workspace_get(TcWorkspaceIds::NKEYS, 64, reinterpret_cast<void **>(&n_keys)))) return rc;
+    if ((rc = ks_number(keys, &word_rank, &chunk_base, n_keys + 12, stream))) return rc;
+    const size_t cells = (size_t)(k.n_max + 1) * (size_t)(k.d_max + 1);
+    if ((rc = workspace_get(TcWorkspaceIds::GRID_TABLES, cells * 16, reinterpret_cast<void **>(&tables)))) return rc;
+    hipLaunchKernelGGL(ks_unpack_kernel, dim3(1024), dim3(256), 0, stream, keys, word_rank, chunk_base, (unsigned)parts, per, vals_all, exp_p0, tables);
+    KeyTable kt;
+    kt.n_max = (unsigned)k.n_max; kt.d_max = (unsigned)k.d_max; kt.p0 = tables; kt.eK = tables + 1; kt.step = 2; kt.overflow = n_keys + 7;
+    hipLaunchKernelGGL(tc_table_gather2_kernel, row_grid, dim3(TC_ROW_THREADS), 0, stream, src, kt, 0, p0, eK);
+    TRACS_HIP_CHECK(hipGetLastError());
+    return TRACS_OK;
+}
 
 // More than 2^31 elements go in passes (each with its own key table): an unthresholded `tracs distance --meta` run with
 // ~92 700 samples or more hands over > 4.29 x 10^9 pairs in one call (src/transcluster.hpp:263 simply loops).

@@ -356,6 +356,57 @@ def trans_dist_dense_partitioned(dist, n, days, lamb, beta, threshold_Ek, p0, eK
         raise _lib.TracsError("trans_dist key table too small (n_max / d_max)")
 
 
+# ---- the distinct keys split over ranks that each hold rows of the matrix (partition.KeySplit; csrc/transcluster.hip) ---------------
+def trans_keys_words():
+    return int(_lib.require_gpu().tracs_trans_keys_words())
+
+
+def _ranges_arg(ranges):
+    flat = [int(x) for r in ranges for x in r]
+    return (C.c_size_t * max(1, len(flat)))(*flat), len(ranges)
+
+
+def trans_keys_mark(dist, n, days, ranges, keys, dist_threshold=2147483647, col_begin=0):
+    """keys (torch.int32 [trans_keys_words()], overwritten) <- the (SNP distance, day gap) keys of the cells of the row ranges"""
+    L = _lib.require_gpu()
+    assert len(ranges) <= 2 and keys.is_contiguous() and keys.numel() == trans_keys_words()
+    arr, k = _ranges_arg(ranges)
+    _lib.check(L.tracs_trans_keys_mark(_ptr(dist), dist.stride(0), n, arr, k, col_begin, int(dist_threshold), _ptr(days), _ptr(keys), _stream()))
+
+
+def trans_keys_merge(keys, gathered, parts):
+    L = _lib.require_gpu()
+    assert gathered.is_contiguous() and gathered.numel() == parts * keys.numel()
+    _lib.check(L.tracs_trans_keys_merge(_ptr(keys), _ptr(gathered), int(parts), _stream()))
+
+
+def trans_keys_info(keys):
+    """-> (distinct keys, largest distance, span of the days, fits the grid) of a (merged) key bitmap; synchronises"""
+    L = _lib.require_gpu()
+    info = (C.c_uint64 * 4)()
+    _lib.check(L.tracs_trans_keys_info(_ptr(keys), info, _stream()))
+    return tuple(int(x) for x in info)
+
+
+def trans_keys_evaluate(keys, info, part, parts, lamb, beta, threshold_Ek, vals):
+    """vals (torch.float64 [per, 2]) <- (log p0, E(K)) of the keys with ordinal = part mod parts, at slot ordinal // parts"""
+    L = _lib.require_gpu()
+    assert vals.is_contiguous() and vals.dtype == torch.float64
+    arr = (C.c_uint64 * 4)(*info)
+    _lib.check(L.tracs_trans_keys_evaluate(_ptr(keys), arr, int(part), int(parts), float(lamb), float(beta), float(threshold_Ek),
+                                           _ptr(vals), vals.numel() // 2, _stream()))
+
+
+def trans_keys_gather(dist, n, days, ranges, keys, info, vals_all, parts, p0, eK, exp_p0=True, dist_threshold=2147483647, col_begin=0):
+    L = _lib.require_gpu()
+    ld = dist.stride(0)
+    assert p0.stride(0) == ld and eK.stride(0) == ld and len(ranges) <= 2 and vals_all.is_contiguous()
+    arr, k = _ranges_arg(ranges)
+    inf = (C.c_uint64 * 4)(*info)
+    _lib.check(L.tracs_trans_keys_gather(_ptr(dist), ld, n, arr, k, col_begin, int(dist_threshold), _ptr(days), _ptr(keys), inf,
+                                         _ptr(vals_all), int(parts), vals_all.numel() // (2 * parts), int(exp_p0), _ptr(p0), _ptr(eK), _stream()))
+
+
 def calculate_posteriors_device(counts, alphas, keep, threshold):
     L = _lib.require_gpu()
     a = np.ascontiguousarray(alphas, dtype=np.float64)

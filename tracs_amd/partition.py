@@ -407,3 +407,113 @@ class TriExchange:
         bad = self._max((self.stats[:, 1].to(torch.int64) & 0xFFFFFFFF).clone() * torch.tensor(
             [1 if self.widths[0] == 2 else 0, 1 if self.widths[1] == 2 else 0], dtype=torch.int64, device=self.device))
         return int(bad.sum().item()) == 0
+
+
+# ---- SITE shards: transcluster over a rank's own rows, the key evaluations split over the ranks ------------------------------------
+# After the compact exchange rank q holds the rows it owns of the summed d.  trans_dist memoises per (N, delta) key
+# (src/transcluster.hpp:245-246,265-282) and a rank's rows see most of the matrix's distinct keys -- evaluating "its" keys is nearly
+# all of them on every rank (0.9 of the 1.3 ms predicted for P = 8).  Here every distinct key of the WHOLE matrix is
+# evaluated by exactly one rank: mark the own rows' keys in the (N, day gap) bitmap -> all-gather + OR (2 MB per rank) -> the keys
+# numbered by their position in the union, rank r evaluates ordinals r, r + P, .. -> all-gather of the compact (log p0, E(K)) arrays
+# (16 bytes per distinct key in total) -> every rank fills its table and gathers its rows (csrc/transcluster.hip, tracs_trans_keys_*).
+
+class KeySplit:
+    """`run()` per call: P / E(K) of the cells of this rank's own row ranges, bit-identical to tracs_trans_dist_dense2 on them."""
+
+    def __init__(self, n, rank, world, dist, device):
+        self.n, self.rank, self.world, self.dist, self.device = n, rank, world, dist, device
+        self._bufs = {}
+        self.last_info = None                    # (distinct keys of the whole matrix, largest distance, span of the days, fits)
+        self.last_route = None                   # "split" | "whole" (the keys do not fit the grid: every rank evaluates its rows' keys)
+
+    # ---- the kernels (libtracs_hip.so: csrc/transcluster.hip) -------------------------------------------------------------------
+    def _words(self):
+        from . import device as dev
+        return dev.trans_keys_words()
+
+    def _mark(self, dmat, days, ranges, keys, dist_threshold, col_begin):
+        from . import device as dev
+        dev.trans_keys_mark(dmat, self.n, days, ranges, keys, dist_threshold, col_begin)
+
+    def _merge(self, keys, gathered):
+        from . import device as dev
+        dev.trans_keys_merge(keys, gathered, self.world)
+
+    def _info(self, keys):
+        from . import device as dev
+        return dev.trans_keys_info(keys)
+
+    def _evaluate(self, keys, info, lamb, beta, precision, vals):
+        from . import device as dev
+        dev.trans_keys_evaluate(keys, info, self.rank, self.world, lamb, beta, precision, vals)
+
+    def _gather(self, dmat, days, ranges, keys, info, vals_all, pmat, emat, exp_p0, dist_threshold, col_begin):
+        from . import device as dev
+        dev.trans_keys_gather(dmat, self.n, days, ranges, keys, info, vals_all, self.world, pmat, emat, exp_p0, dist_threshold, col_begin)
+
+    def _whole(self, dmat, days, ranges, lamb, beta, precision, pmat, emat, exp_p0, dist_threshold, col_begin):
+        from . import device as dev
+        if ranges:
+            dev.trans_dist_dense_ranges(dmat, self.n, days, lamb, beta, precision, pmat, emat, ranges, exp_p0=exp_p0,
+                                        dist_threshold=dist_threshold, col_begin=col_begin)
+
+    # ---- protocol ---------------------------------------------------------------------------------------------------------------
+    def _buf(self, name, numel, dtype):
+        import torch
+        b = self._bufs.get(name)
+        if b is None or b.numel() < numel or b.dtype != dtype:
+            b = torch.empty(numel, dtype=dtype, device=self.device)
+            self._bufs[name] = b
+        return b[:numel]
+
+    def _all_gather(self, flat, k):
+        """flat: `world` blocks of k elements, this rank's already in place -> every rank's block in place"""
+        import torch
+        d, w, r = self.dist, self.world, self.rank
+        if w == 1:
+            return
+        mine = flat[r * k:(r + 1) * k]
+        if hasattr(d, "all_to_all_blocks"):                # tracs_amd.rccl.RcclDist: tracs_allgather_panels, in place
+            d.all_gather([flat[q * k:(q + 1) * k] for q in range(w)], mine)
+        elif flat.is_cuda and d.get_backend() == "nccl":
+            d.all_gather_into_tensor(flat, mine.clone())
+        else:                                              # gloo (ranks sharing a GPU, CPU tests): through host tensors
+            host = mine.cpu().contiguous()
+            outs = [torch.empty_like(host) for _ in range(w)]
+            d.all_gather(outs, host)
+            for q in range(w):
+                if q != r:
+                    flat[q * k:(q + 1) * k].copy_(outs[q])
+
+    def run(self, dmat, days, ranges, lamb, beta, precision, pmat, emat, exp_p0=True, dist_threshold=2147483647, col_begin=0):
+        """-> True when the keys were split, False when every rank evaluated the keys of its own rows (they did not fit the grid: the
+        same decision on every rank, from the merged bitmap)."""
+        import torch
+        words = self._words()
+        gathered = self._buf("keys_all", self.world * words, torch.int32)
+        keys = gathered[self.rank * words:(self.rank + 1) * words] if self.world > 1 else self._buf("keys", words, torch.int32)
+        self._mark(dmat, days, ranges, keys, dist_threshold, col_begin)
+        if self.world > 1:
+            self._all_gather(gathered, words)
+            keys = self._buf("keys", words, torch.int32)
+            self._merge(keys, gathered)
+        info = self._info(keys)
+        self.last_info = info
+        if not info[3]:
+            self.last_route = "whole"
+            self._whole(dmat, days, ranges, lamb, beta, precision, pmat, emat, exp_p0, dist_threshold, col_begin)
+            return False
+        self.last_route = "split"
+        per = max(1, -(-info[0] // self.world))
+        vals_all = self._buf("vals_all", self.world * per * 2, torch.float64)
+        self._evaluate(keys, info, lamb, beta, precision, vals_all[self.rank * per * 2:(self.rank + 1) * per * 2])
+        self._all_gather(vals_all, per * 2)
+        self._gather(dmat, days, ranges, keys, info, vals_all, pmat, emat, exp_p0, dist_threshold, col_begin)
+        return True
+
+    def bytes_gathered_per_call(self):
+        """bytes this rank receives per call: the other ranks' key bitmaps and their compact value arrays"""
+        if self.last_info is None or self.world == 1:
+            return 0
+        per = max(1, -(-self.last_info[0] // self.world))
+        return (self.world - 1) * (self._words() * 4 + (per * 16 if self.last_info[3] else 0))
