@@ -96,7 +96,12 @@ __device__ __forceinline__ bool row_wanted(const MinorBuild &mb, size_t s)
 // the queue of flagged samples wants the longer piece: 10.9 ms with 1 024 against 13.3 with 512 -- the kernel is a template on it.
 // a group's p lists are built in LDS by p_lists_kernel when they hold PL_MIN .. PL_CAP entries (fewer: not worth a workgroup of its
 // own -- the bench alignment has 128 per group --, more: beyond the image; both: site_lists_kernel, entry by entry)
-constexpr unsigned PL_THREADS = 256, PL_MIN = 1024, PL_CAP = 8192, PL_CHUNK = 4096;
+// (512 threads: 8.17 ms of per-site list building against 8.42 with 256 on the partial-code alignment -- profiles/r06/partial_floor.txt)
+#ifndef TRACS_PL_THREADS
+#define TRACS_PL_THREADS 512
+#endif
+constexpr unsigned PL_THREADS = TRACS_PL_THREADS, PL_MIN = 1024, PL_CAP = 8192, PL_CHUNK = 4096, PL_PER_THREAD = PL_CHUNK / PL_THREADS;
+static_assert(PL_PER_THREAD * PL_THREADS == PL_CHUNK && PL_PER_THREAD <= 32 && 64 % PL_PER_THREAD == 0, "p_lists_kernel: a thread's samples sit in one flag word");
 __device__ __forceinline__ bool p_lists_in_lds(unsigned group_entries) { return group_entries >= PL_MIN && group_entries <= PL_CAP; }
 constexpr unsigned SITE_THREADS = 128;         // one thread per site of the group: both waves busy in both phases, eight workgroups per CU (17 KiB of LDS each)
 
@@ -374,10 +379,14 @@ __global__ __launch_bounds__(PL_THREADS) void p_lists_kernel(const MinorBuild mb
     const uint4 RX = mb.ref_x[g], RY = mb.ref_y[g];
     const uint4 *base = mb.planes + (g * NPLANES) * n_pad;
     const unsigned mp[4] = {q4.x, q4.y, q4.z, q4.w};
+#if defined(TRACS_PL_CUT) && TRACS_PL_CUT == 3
+    for (unsigned c0 = 0; c0 < 0; c0 += PL_CHUNK) {
+#else
     for (unsigned c0 = 0; c0 < n; c0 += PL_CHUNK) {
-        // the chunk's flagged samples: thread t looks at samples c0 + 16 t .. + 15
-        const unsigned s0 = c0 + 16u * tid;
-        unsigned bits = s0 < n ? (unsigned)(mb.flags[g * mb.flag_words + (s0 >> 6)] >> (s0 & 63u)) & 0xFFFFu : 0u;
+#endif
+        // the chunk's flagged samples: thread t looks at samples c0 + PL_PER_THREAD t .. (8 of them)
+        const unsigned s0 = c0 + PL_PER_THREAD * tid;
+        unsigned bits = s0 < n ? (unsigned)(mb.flags[g * mb.flag_words + (s0 >> 6)] >> (s0 & 63u)) & ((1u << PL_PER_THREAD) - 1u) : 0u;
         const unsigned cnt = (unsigned)__popc(bits);
         unsigned x = cnt;
 #pragma unroll
@@ -387,7 +396,7 @@ __global__ __launch_bounds__(PL_THREADS) void p_lists_kernel(const MinorBuild mb
         unsigned pos = x - cnt, qcount = 0;
 #pragma unroll
         for (unsigned w = 0; w < PL_THREADS / 64u; w++) { const unsigned t = wtot[w]; if (w < wave) pos += t; qcount += t; }
-        while (bits) { const unsigned b = (unsigned)__ffs(bits) - 1u; bits &= bits - 1u; queue[pos++] = (unsigned short)(16u * tid + b); }
+        while (bits) { const unsigned b = (unsigned)__ffs(bits) - 1u; bits &= bits - 1u; queue[pos++] = (unsigned short)(PL_PER_THREAD * tid + b); }
         __syncthreads();
         for (unsigned k0 = 0; k0 < qcount; k0 += 2u * PL_THREADS) {
             // two samples per thread and step: eight 16-byte loads under way
@@ -421,12 +430,21 @@ __global__ __launch_bounds__(PL_THREADS) void p_lists_kernel(const MinorBuild mb
                         listed_w += code >> 4;
                     }
                 }
+#ifndef TRACS_PL_NO_CP
                 if (listed_w) atomicAdd(&c_p[s], listed_w);
+#endif
             };
+#if defined(TRACS_PL_CUT) && TRACS_PL_CUT == 2
+            if ((Aa.x ^ Ca.y ^ Ga.z ^ Ta.w ^ Ab.x ^ Cb.y ^ Gb.z ^ Tb.w) == 0x12345679u) c_p[0] = 1u;      // (timing build: the loads stay)
+#else
             if (ha) sample(sa, Aa, Ca, Ga, Ta);
             if (hb) sample(sb, Ab, Cb, Gb, Tb);
+#endif
         }
     }
+#if defined(TRACS_PL_CUT) && (TRACS_PL_CUT == 1 || TRACS_PL_CUT == 2)
+    return;
+#endif
     __syncthreads();
     // the image leaves: E -- the group's w = 1 entries closed up at the front of its run (e_cnt[g] of them; `holes`: by list position,
     // holes for the others, what the one-pass fill of small alignments reads) --, the short lists into p_ent
