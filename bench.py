@@ -827,7 +827,7 @@ def site_sharded(args, n, L, seed, world, rank, device, dist, exchange, comm_inf
                                        "of chunks q and %d - q (%d rows each; no all-gather; transcluster on a rank's own rows)"
                                        % (groups, world, l1 - l0, L, ex.widths[0], ex.widths[1], 2 * world - 1, ex.cs),
                           "transcluster_keys": ({"route": ks.last_route, "distinct_keys_whole_matrix": ks.last_info[0],
-                                                 "evaluated_by_rank0": int(_lib.load().tracs_debug_last_trans_dist_keys()) if ks.last_route == "split" else None,
+                                                 "evaluated_by_rank0": ks.last_evaluated if ks.last_route == "split" else None,
                                                  "bytes_gathered_per_rank_per_call": ks.bytes_gathered_per_call(),
                                                  "how": "every rank marks its rows' (N, day gap) keys in a bitmap, all-gather + OR, rank r evaluates the "
                                                         "keys of ordinal r mod P, all-gather of the compact (log p0, E(K)) arrays, every rank fills its table"}

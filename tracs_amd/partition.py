@@ -425,6 +425,7 @@ class KeySplit:
         self._bufs = {}
         self.last_info = None                    # (distinct keys of the whole matrix, largest distance, span of the days, fits)
         self.last_route = None                   # "split" | "whole" (the keys do not fit the grid: every rank evaluates its rows' keys)
+        self.last_evaluated = None               # keys this rank evaluated in the last split call
 
     # ---- the kernels (libtracs_hip.so: csrc/transcluster.hip) -------------------------------------------------------------------
     def _words(self):
@@ -444,8 +445,10 @@ class KeySplit:
         return dev.trans_keys_info(keys)
 
     def _evaluate(self, keys, info, lamb, beta, precision, vals):
+        from . import _lib
         from . import device as dev
         dev.trans_keys_evaluate(keys, info, self.rank, self.world, lamb, beta, precision, vals)
+        self.last_evaluated = int(_lib.load().tracs_debug_last_trans_dist_keys())      # the keys THIS rank evaluated
 
     def _gather(self, dmat, days, ranges, keys, info, vals_all, pmat, emat, exp_p0, dist_threshold, col_begin):
         from . import device as dev
