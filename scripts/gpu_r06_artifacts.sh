@@ -49,3 +49,10 @@ timeout 900 python scripts/bench_e2e.py 10000 500000 > $OUT/e2e_10000x500000.jso
 timeout 900 python scripts/bench_e2e.py 2000 5000000 > $OUT/e2e_2000x5000000.json 2>> $OUT/e2e.err; cut -c1-300 $OUT/e2e_2000x5000000.json
 timeout 300 python scripts/bench_e2e.py 10 100000 > $OUT/e2e_10x100000.json 2>> $OUT/e2e.err; cut -c1-300 $OUT/e2e_10x100000.json
 timeout 900 python bench.py --partial 0.005 --steps 5 --warmup 2 --no-extras --cpu-seconds 1 > $OUT/bench_partial.log 2>&1; tail -1 $OUT/bench_partial.log > $OUT/bench_partial.json; cut -c1-250 $OUT/bench_partial.json
+# the partial-code alignment's kernel trace (the table of profiles/r06/partial_floor.txt)
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/$TAG/partial -o trace -- python3 $GRAFT_REPO_ROOT/bench.py --partial 0.005 --steps 3 --warmup 1 --no-extras --no-cpu-baseline > $OUT/partial_trace.log 2>&1
+cp $(find /tmp/$TAG/partial -name "*kernel_stats.csv" | head -1) $OUT/partial_kernel_stats.csv
+cd $GRAFT_REPO_ROOT
+# the e2e command line with --filter
+timeout 900 python scripts/bench_e2e.py 10000 500000 --filter > $OUT/e2e_10000x500000_filter.json 2>> $OUT/e2e.err; cut -c1-300 $OUT/e2e_10000x500000_filter.json
