@@ -109,7 +109,12 @@ enum { M_DENSE = 0, M_COUNT, M_MINOR, M_FULL, M_NNL, M_LST, M_UN, M_REFX, M_REFY
 //   M_UN     every site outside the dense class with cN >= 1 (M_COUNT, M_NNL and the cN = 1 sites, which have no co-occurrence)
 // gram != 0 (the N x listed terms of the minority sites on the matrix cores, decide() below): a site's cost no longer grows with its
 // N samples -- minority while k^2 <= budget --, no site carries an N list, every N co-occurrence is counted on the matrix cores
-__global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__restrict__ P, size_t n_pad, unsigned n, unsigned budget,
+// NT threads per workgroup: 128 (two waves; TRACS_CLASSIFY_THREADS=256: the four of rounds 3 - 6a).  The registers allow two waves per SIMD
+// either way (213 VGPRs); as four workgroups of two waves a CU overlaps one group's flushes and barriers with another group's loads better
+// than as two of four, and an alignment of at most 1 024 samples is one step of pass 2 with every thread's eight loads in use:
+// 4.4 - 4.55 -> 4.1 - 4.3 ms at 10 000 x 5 Mbp, 0.275 -> 0.19 ms at 1 000 x 1 Mbp (config 2: 1.22 -> 1.11 ms per call).
+template <int NT>
+__global__ __launch_bounds__(NT) void classify_sites_kernel(const uint4 *__restrict__ P, size_t n_pad, unsigned n, unsigned budget,
                                                              unsigned nn_list_max, unsigned gram, uint4 *__restrict__ masks, size_t groups,
                                                              unsigned *__restrict__ cntP, unsigned *__restrict__ cntN,
                                                              unsigned *__restrict__ gP, unsigned *__restrict__ gN, unsigned *__restrict__ gQ,
@@ -122,9 +127,11 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
     // masks2 / gcnt2 (may be NULL): the class masks and per-group sums of the SAME pass under the other criterion (gram = 1), so that
     // decide() can take the second form of the classes without classifying again (bit 2 of *partial_flag: some p list of that form is long)
     const size_t g = blockIdx.x;
-    __shared__ unsigned red[4][4][4];
+    constexpr int WAVES = NT / 64;
+    static_assert(NT == 128 || NT == 256, "classify_sites_kernel: two or four waves");
+    __shared__ unsigned red[WAVES][4][4];
     __shared__ unsigned sref[4][4];                     // one-base sample seen, ref X, ref Y, somebody is not N
-    __shared__ unsigned planes_lds[4][8][256];          // one counter's bit planes of every thread (32 KiB): [word][plane][thread]
+    __shared__ unsigned planes_lds[4][8][NT];            // one counter's bit planes of every thread (32 KiB at 256 threads): [word][plane][thread]
     __shared__ unsigned tot[2][SITES_PER_GROUP];        // k, cN
     __shared__ unsigned wsum[2][2][7];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -133,7 +140,7 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
     __syncthreads();
 
     // ---- pass 1: reference bases ----------------------------------------------------------------------------------------
-    for (unsigned base = 0; base < n; base += 256) {
+    for (unsigned base = 0; base < n; base += NT) {
         unsigned seen[4] = {0, 0, 0, 0}, rx[4] = {0, 0, 0, 0}, ry[4] = {0, 0, 0, 0};
         const unsigned s = base + tid;
         if (s < n) {
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
         if (tid < 4) {
             const int w = tid;
             unsigned fs = sref[0][w], fx = sref[1][w], fy = sref[2][w];           // earlier chunks first
-            for (int k = 0; k < 4; k++) { fx |= red[k][1][w] & ~fs; fy |= red[k][2][w] & ~fs; fs |= red[k][0][w]; }
+            for (int k = 0; k < WAVES; k++) { fx |= red[k][1][w] & ~fs; fy |= red[k][2][w] & ~fs; fs |= red[k][0][w]; }
             sref[0][w] = fs; sref[1][w] = fx; sref[2][w] = fy;
         }
         __syncthreads();
@@ -183,13 +190,17 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
 #pragma unroll
             for (int j = 0; j < 8; j++) { planes_lds[w][j][tid] = pl[w][j]; pl[w][j] = 0; }
         __syncthreads();
-        unsigned acc = 0;
+        // (wave w takes words w, w + WAVES, ..)
 #pragma unroll
-        for (int j = 0; j < 8; j++)
+        for (int w = wave; w < 4; w += WAVES) {
+            unsigned acc = 0;
 #pragma unroll
-            for (int blk = 0; blk < 4; blk++) acc += (unsigned)__popc(tr(planes_lds[wave][j][blk * 64 + lane])) << j;
-        acc += __shfl_xor(acc, 32, 64);
-        if (lane < 32) tot[which][wave * 32 + lane] += acc;
+            for (int j = 0; j < 8; j++)
+#pragma unroll
+                for (int blk = 0; blk < WAVES; blk++) acc += (unsigned)__popc(tr(planes_lds[w][j][blk * 64 + lane])) << j;
+            acc += __shfl_xor(acc, 32, 64);
+            if (lane < 32) tot[which][w * 32 + lane] += acc;
+        }
     };
     unsigned kp[4][8], np[4][8];
 #pragma unroll
@@ -203,11 +214,11 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
     // Eight samples per thread and step: their words are classified as they arrive (32 16-byte loads in flight per thread), then
     // added to the bit-sliced counters eight at a time (sliced_add8).  The counters hold 8 bits: flushed every 31 steps.
     unsigned since = 0;
-    for (unsigned base = 0; base < n; base += 256 * 8) {
+    for (unsigned base = 0; base < n; base += NT * 8) {
         unsigned db[8][4], nb[8][4];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const unsigned s = base + k * 256 + tid;
+            const unsigned s = base + k * NT + tid;
             bool listed_here = false;
 #pragma unroll
             for (int w = 0; w < 4; w++) { db[k][w] = 0; nb[k][w] = 0; }
@@ -227,9 +238,9 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
                     listed_here = listed_here || db[k][w] != 0u;
                 }
             }
-            if (base + k * 256 < n) {                          // (block-uniform)
+            if (base + k * NT < n) {                            // (block-uniform)
                 const unsigned long long fl = __ballot(listed_here);
-                if (lane == 0) flags[g * flag_words + ((base + k * 256) >> 6) + wave] = fl;
+                if (lane == 0) flags[g * flag_words + ((base + k * NT) >> 6) + wave] = fl;
             }
         }
 #pragma unroll
@@ -253,7 +264,9 @@ __global__ __launch_bounds__(256) void classify_sites_kernel(const uint4 *__rest
     if (tid == 0 && any_bad) atomicOr(partial_flag, 1u);
     if (tid < SITES_PER_GROUP) {
         const int w = sw, b = sb;
-        const unsigned anyw = red[0][3][w] | red[1][3][w] | red[2][3][w] | red[3][3][w];
+        unsigned anyw = 0;
+#pragma unroll
+        for (int k = 0; k < WAVES; k++) anyw |= red[k][3][w];
         const bool some = (anyw >> b) & 1u;
         const unsigned long long k = tot[0][tid], c = some ? tot[1][tid] : 0ull;      // (an empty site: every sample is N)
         cntP[g * SITES_PER_GROUP + tid] = (unsigned)k;
@@ -655,9 +668,15 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
     static const double nnl_k = [] { const char *e = std::getenv("TRACS_NN_LIST_K"); return e ? std::atof(e) : 6e-6; }();
     const unsigned nn_list_max = (no_nnl || !allow_nnl) ? 0u : (unsigned)std::min(4.0e9, nnl_k * (double)a->n * (double)a->n);
     TRACS_HIP_CHECK(hipMemsetAsync(totals, 0, 256, stream));
-    hipLaunchKernelGGL(classify_sites_kernel, dim3((unsigned)groups), dim3(256), 0, stream, a->planes, a->n_pad, (unsigned)a->n, budget,
-                       nn_list_max, gram ? 1u : 0u, masks, groups, cntP, cntN, gcnt, gcnt + groups, gcnt + 2 * groups, gcnt + 3 * groups, gcnt + 4 * groups, gcnt + 5 * groups, gcnt + 6 * groups, flags, flag_words, d_flag,
-                       gram_next ? masks2 : (uint4 *)nullptr, gram_next ? gcnt2 : (unsigned *)nullptr);
+#define TRACS_CLASSIFY_ARGS a->planes, a->n_pad, (unsigned)a->n, budget, nn_list_max, gram ? 1u : 0u, masks, groups, cntP, cntN, gcnt, gcnt + groups, \
+                            gcnt + 2 * groups, gcnt + 3 * groups, gcnt + 4 * groups, gcnt + 5 * groups, gcnt + 6 * groups, flags, flag_words, d_flag,          \
+                            gram_next ? masks2 : (uint4 *)nullptr, gram_next ? gcnt2 : (unsigned *)nullptr
+    static const int env_threads = [] { const char *e = std::getenv("TRACS_CLASSIFY_THREADS"); return e ? std::atoi(e) : 0; }();
+    if (env_threads != 256)
+        hipLaunchKernelGGL(classify_sites_kernel<128>, dim3((unsigned)groups), dim3(128), 0, stream, TRACS_CLASSIFY_ARGS);
+    else
+        hipLaunchKernelGGL(classify_sites_kernel<256>, dim3((unsigned)groups), dim3(256), 0, stream, TRACS_CLASSIFY_ARGS);
+#undef TRACS_CLASSIFY_ARGS
     const double plane_b = (double)groups * (double)a->n_pad * sizeof(uint4);      // one bit plane of the alignment
     stage_mark("classify", stream, 4.0 * plane_b, (double)groups * (M_SLOTS * 16.0 + 3.0 * SITES_PER_GROUP * 4.0 + flag_words * 8.0));
     hipLaunchKernelGGL(group_offsets_kernel, dim3(14), dim3(1024), 0, stream, masks, gcnt, groups, offs, off64, totals);
