@@ -109,10 +109,11 @@ enum { M_DENSE = 0, M_COUNT, M_MINOR, M_FULL, M_NNL, M_LST, M_UN, M_REFX, M_REFY
 //   M_UN     every site outside the dense class with cN >= 1 (M_COUNT, M_NNL and the cN = 1 sites, which have no co-occurrence)
 // gram != 0 (the N x listed terms of the minority sites on the matrix cores, decide() below): a site's cost no longer grows with its
 // N samples -- minority while k^2 <= budget --, no site carries an N list, every N co-occurrence is counted on the matrix cores
-// NT threads per workgroup: 128 (two waves; TRACS_CLASSIFY_THREADS=256: the four of rounds 3 - 6a).  The registers allow two waves per SIMD
-// either way (213 VGPRs); as four workgroups of two waves a CU overlaps one group's flushes and barriers with another group's loads better
-// than as two of four, and an alignment of at most 1 024 samples is one step of pass 2 with every thread's eight loads in use:
-// 4.4 - 4.55 -> 4.1 - 4.3 ms at 10 000 x 5 Mbp, 0.275 -> 0.19 ms at 1 000 x 1 Mbp (config 2: 1.22 -> 1.11 ms per call).
+// NT threads per workgroup: 128 (two waves), 64 for alignments of at most 2 048 samples; TRACS_CLASSIFY_THREADS=64|128|256 forces (256: the
+// four waves of rounds 3 - 6a).  The registers allow two waves per SIMD either way (213 VGPRs); as four workgroups of two waves a CU overlaps
+// one group's flushes and barriers with another group's loads better than as two of four: 4.4 - 4.55 -> 4.0 - 4.4 ms at 10 000 x 5 Mbp (one wave
+// per workgroup: 4.4 again); at 1 000 x 1 Mbp, where a group's fixed costs are what counts, 0.275 (256) -> 0.19 (128) -> 0.17 ms (64): config 2
+// 1.22 -> 1.07 ms per call (profiles/r06/classify_threads.txt).
 template <int NT>
 __global__ __launch_bounds__(NT) void classify_sites_kernel(const uint4 *__restrict__ P, size_t n_pad, unsigned n, unsigned budget,
                                                              unsigned nn_list_max, unsigned gram, uint4 *__restrict__ masks, size_t groups,
@@ -128,14 +129,14 @@ __global__ __launch_bounds__(NT) void classify_sites_kernel(const uint4 *__restr
     // decide() can take the second form of the classes without classifying again (bit 2 of *partial_flag: some p list of that form is long)
     const size_t g = blockIdx.x;
     constexpr int WAVES = NT / 64;
-    static_assert(NT == 128 || NT == 256, "classify_sites_kernel: two or four waves");
+    static_assert(NT == 64 || NT == 128 || NT == 256, "classify_sites_kernel: one, two or four waves");
     __shared__ unsigned red[WAVES][4][4];
     __shared__ unsigned sref[4][4];                     // one-base sample seen, ref X, ref Y, somebody is not N
     __shared__ unsigned planes_lds[4][8][NT];            // one counter's bit planes of every thread (32 KiB at 256 threads): [word][plane][thread]
     __shared__ unsigned tot[2][SITES_PER_GROUP];        // k, cN
     __shared__ unsigned wsum[2][2][7];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < SITES_PER_GROUP) { tot[0][tid] = 0; tot[1][tid] = 0; }
+    for (int st = tid; st < (int)SITES_PER_GROUP; st += NT) { tot[0][st] = 0; tot[1][st] = 0; }
     if (tid < 4) { sref[0][tid] = 0; sref[1][tid] = 0; sref[2][tid] = 0; sref[3][tid] = 0; }
     __syncthreads();
 
@@ -177,7 +178,6 @@ __global__ __launch_bounds__(NT) void classify_sites_kernel(const uint4 *__restr
 
     // ---- pass 2: k and cN of every site -----------------------------------------------------------------------------------
     unsigned anyb[4] = {0, 0, 0, 0}, bad = 0;
-    const int site = tid & 127, sw = site >> 5, sb = site & 31;
     // flush: the bit planes of all threads through LDS, one counter at a time.  Wave w takes word w (32 sites): for every plane and
     // every 64 threads, a 32 x 32 bit transpose across the half waves turns "bit b of thread t" into "bit t of lane b", whose
     // popcount is the site's count over those 32 threads -- 18 instructions per 64 words where summing bit by bit took 4 per bit
@@ -262,15 +262,16 @@ __global__ __launch_bounds__(NT) void classify_sites_kernel(const uint4 *__restr
     }
     const int any_bad = __syncthreads_or(bad != 0u);
     if (tid == 0 && any_bad) atomicOr(partial_flag, 1u);
-    if (tid < SITES_PER_GROUP) {
-        const int w = sw, b = sb;
+    // (a site per thread: with one wave per workgroup in two rounds; `hw`: the site's 64-site half)
+    for (int st = tid; st < (int)SITES_PER_GROUP; st += NT) {
+        const int w = st >> 5, b = st & 31, hw = st >> 6;
         unsigned anyw = 0;
 #pragma unroll
         for (int k = 0; k < WAVES; k++) anyw |= red[k][3][w];
         const bool some = (anyw >> b) & 1u;
-        const unsigned long long k = tot[0][tid], c = some ? tot[1][tid] : 0ull;      // (an empty site: every sample is N)
-        cntP[g * SITES_PER_GROUP + tid] = (unsigned)k;
-        cntN[g * SITES_PER_GROUP + tid] = (unsigned)c;
+        const unsigned long long k = tot[0][st], c = some ? tot[1][st] : 0ull;      // (an empty site: every sample is N)
+        cntP[g * SITES_PER_GROUP + st] = (unsigned)k;
+        cntN[g * SITES_PER_GROUP + st] = (unsigned)c;
 #pragma unroll
         for (int form = 0; form < 2; form++) {
             if (form == 1 && masks2 == nullptr) break;                  // (kernel-uniform)
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(NT) void classify_sites_kernel(const uint4 *__restr
                 const unsigned long long bal = __ballot(cls[m]);
                 if (lane == 0) {
                     unsigned *pm = reinterpret_cast<unsigned *>(&mk[(size_t)slot[m] * groups + g]);
-                    pm[2 * wave] = (unsigned)bal; pm[2 * wave + 1] = (unsigned)(bal >> 32);
+                    pm[2 * hw] = (unsigned)bal; pm[2 * hw + 1] = (unsigned)(bal >> 32);
                 }
             }
             // some p list is a long one (q lines: site_lists.hip): bit 1 for the first set of classes, bit 2 for the second
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(NT) void classify_sites_kernel(const uint4 *__restr
             for (int m = 0; m < 7; m++) {
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) sv[m] += __shfl_xor(sv[m], off, 64);
-                if (lane == 0) wsum[form][wave][m] = sv[m];
+                if (lane == 0) wsum[form][hw][m] = sv[m];
             }
         }
     }
@@ -672,7 +673,9 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
                             gcnt + 2 * groups, gcnt + 3 * groups, gcnt + 4 * groups, gcnt + 5 * groups, gcnt + 6 * groups, flags, flag_words, d_flag,          \
                             gram_next ? masks2 : (uint4 *)nullptr, gram_next ? gcnt2 : (unsigned *)nullptr
     static const int env_threads = [] { const char *e = std::getenv("TRACS_CLASSIFY_THREADS"); return e ? std::atoi(e) : 0; }();
-    if (env_threads != 256)
+    if (env_threads == 64 || (env_threads == 0 && a->n <= 2048))
+        hipLaunchKernelGGL(classify_sites_kernel<64>, dim3((unsigned)groups), dim3(64), 0, stream, TRACS_CLASSIFY_ARGS);
+    else if (env_threads != 256)
         hipLaunchKernelGGL(classify_sites_kernel<128>, dim3((unsigned)groups), dim3(128), 0, stream, TRACS_CLASSIFY_ARGS);
     else
         hipLaunchKernelGGL(classify_sites_kernel<256>, dim3((unsigned)groups), dim3(256), 0, stream, TRACS_CLASSIFY_ARGS);

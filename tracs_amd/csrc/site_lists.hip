@@ -646,7 +646,10 @@ __global__ __launch_bounds__(256) void n_bitmap_kernel(const MinorBuild mb, size
     const uint4 *np = mb.planes + 4 * n_pad + min(s, n_pad - 1);
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
     unsigned cnt = 0;
-    constexpr int INF = 4;                                   // octets in flight per thread (64 bytes: the loop is bound by what is in flight)
+#ifndef TRACS_NB_INF
+#define TRACS_NB_INF 4
+#endif
+    constexpr int INF = TRACS_NB_INF;                        // octets in flight per thread (64 bytes: the loop is bound by what is in flight)
     for (size_t o = o0; o < o1; o += INF) {
         uint4 v[INF];
 #pragma unroll
