@@ -196,6 +196,18 @@ __device__ __forceinline__ void sliced_add8(unsigned (&p)[8], const unsigned (&x
     for (int j = 3; j < 8; j++) { const unsigned t = p[j] & c; p[j] ^= c; c = t; }
 }
 
+// four addends: planes of weight 1 and 2 and one carry of weight 4 that ripples through planes 2..7
+__device__ __forceinline__ void sliced_add4(unsigned (&p)[8], const unsigned (&x)[4])
+{
+    unsigned twos_a, twos_b, fours;
+    csa(twos_a, p[0], p[0], x[0], x[1]);
+    csa(twos_b, p[0], p[0], x[2], x[3]);
+    csa(fours, p[1], p[1], twos_a, twos_b);
+    unsigned c = fours;
+#pragma unroll
+    for (int j = 2; j < 8; j++) { const unsigned t = p[j] & c; p[j] ^= c; c = t; }
+}
+
 // 32 x 32 bit transpose across the 32 lanes of a half wave: lane k holds row k; afterwards bit j of lane k is bit k of what lane j
 // held.  Five butterfly steps (j = 16, 8, 4, 2, 1): lanes k and k ^ j exchange words (ds_swizzle, bit mode) and swap the high
 // half-blocks of the lower lane's word with the low half-blocks of the higher lane's -- per lane: keep the bits of K, take the

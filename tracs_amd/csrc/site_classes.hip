@@ -110,12 +110,26 @@ enum { M_DENSE = 0, M_COUNT, M_MINOR, M_FULL, M_NNL, M_LST, M_UN, M_REFX, M_REFY
 // gram != 0 (the N x listed terms of the minority sites on the matrix cores, decide() below): a site's cost no longer grows with its
 // N samples -- minority while k^2 <= budget --, no site carries an N list, every N co-occurrence is counted on the matrix cores
 // NT threads per workgroup: 128 (two waves), 64 for alignments of at most 2 048 samples; TRACS_CLASSIFY_THREADS=64|128|256 forces (256: the
-// four waves of rounds 3 - 6a).  The registers allow two waves per SIMD either way (213 VGPRs); as four workgroups of two waves a CU overlaps
-// one group's flushes and barriers with another group's loads better than as two of four: 4.4 - 4.55 -> 4.0 - 4.4 ms at 10 000 x 5 Mbp (one wave
+// four waves of rounds 3 - 6a).  As workgroups of two waves a CU overlaps
+// one group's flushes and barriers with another group's loads better than as workgroups of four: 4.4 - 4.55 -> 4.0 - 4.4 ms at 10 000 x 5 Mbp with eight samples per step (one wave
 // per workgroup: 4.4 again); at 1 000 x 1 Mbp, where a group's fixed costs are what counts, 0.275 (256) -> 0.19 (128) -> 0.17 ms (64): config 2
 // 1.22 -> 1.07 ms per call (profiles/r06/classify_threads.txt).
+// Four samples per thread and step at three waves per SIMD (170 VGPRs as compiled, held to 168): 4.4 -> 4.2 ms at 10 000 x 5 Mbp against
+// eight samples at two waves (213 VGPRs) -- the sliced adds cost twice the instructions per sample, which this kernel has to spare; four
+// waves spill: 7.6 ms (profiles/r06/classify_threads.txt).  -DTRACS_CLASSIFY_SPS=8 -DTRACS_CLASSIFY_WAVES=0: the round-5 shape.
+#ifndef TRACS_CLASSIFY_SPS
+#define TRACS_CLASSIFY_SPS 4
+#endif
+#ifndef TRACS_CLASSIFY_WAVES
+#define TRACS_CLASSIFY_WAVES (TRACS_CLASSIFY_SPS == 4 ? 3 : 0)
+#endif
+#if TRACS_CLASSIFY_WAVES > 0
+#define TRACS_CLASSIFY_ATTR __attribute__((amdgpu_waves_per_eu(TRACS_CLASSIFY_WAVES, TRACS_CLASSIFY_WAVES)))
+#else
+#define TRACS_CLASSIFY_ATTR
+#endif
 template <int NT>
-__global__ __launch_bounds__(NT) void classify_sites_kernel(const uint4 *__restrict__ P, size_t n_pad, unsigned n, unsigned budget,
+__global__ __launch_bounds__(NT) TRACS_CLASSIFY_ATTR void classify_sites_kernel(const uint4 *__restrict__ P, size_t n_pad, unsigned n, unsigned budget,
                                                              unsigned nn_list_max, unsigned gram, uint4 *__restrict__ masks, size_t groups,
                                                              unsigned *__restrict__ cntP, unsigned *__restrict__ cntN,
                                                              unsigned *__restrict__ gP, unsigned *__restrict__ gN, unsigned *__restrict__ gQ,
@@ -211,13 +225,15 @@ __global__ __launch_bounds__(NT) void classify_sites_kernel(const uint4 *__restr
     unsigned ra[4], rc[4], rg[4], rt[4];
 #pragma unroll
     for (int w = 0; w < 4; w++) { ra[w] = ~refx[w] & ~refy[w]; rc[w] = refx[w] & ~refy[w]; rg[w] = ~refx[w] & refy[w]; rt[w] = refx[w] & refy[w]; }
-    // Eight samples per thread and step: their words are classified as they arrive (32 16-byte loads in flight per thread), then
-    // added to the bit-sliced counters eight at a time (sliced_add8).  The counters hold 8 bits: flushed every 31 steps.
+    // SPS samples per thread and step: their words are classified as they arrive (4 SPS 16-byte loads in flight per thread), then
+    // added to the bit-sliced counters SPS at a time (sliced_add8 / sliced_add4).  The counters hold 8 bits: flushed every 31 / 63 steps.
+    constexpr int SPS = TRACS_CLASSIFY_SPS;                 // samples per thread and step
+    static_assert(SPS == 8 || SPS == 4, "classify_sites_kernel: four or eight samples per step");
     unsigned since = 0;
-    for (unsigned base = 0; base < n; base += NT * 8) {
-        unsigned db[8][4], nb[8][4];
+    for (unsigned base = 0; base < n; base += NT * SPS) {
+        unsigned db[SPS][4], nb[SPS][4];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
+        for (int k = 0; k < SPS; k++) {
             const unsigned s = base + k * NT + tid;
             bool listed_here = false;
 #pragma unroll
@@ -245,12 +261,18 @@ __global__ __launch_bounds__(NT) void classify_sites_kernel(const uint4 *__restr
         }
 #pragma unroll
         for (int w = 0; w < 4; w++) {
-            const unsigned xd[8] = {db[0][w], db[1][w], db[2][w], db[3][w], db[4][w], db[5][w], db[6][w], db[7][w]};
-            const unsigned xn[8] = {nb[0][w], nb[1][w], nb[2][w], nb[3][w], nb[4][w], nb[5][w], nb[6][w], nb[7][w]};
-            sliced_add8(kp[w], xd);
-            sliced_add8(np[w], xn);
+            if constexpr (SPS == 8) {
+                const unsigned xd[8] = {db[0][w], db[1][w], db[2][w], db[3][w], db[SPS - 4][w], db[SPS - 3][w], db[SPS - 2][w], db[SPS - 1][w]};
+                const unsigned xn[8] = {nb[0][w], nb[1][w], nb[2][w], nb[3][w], nb[SPS - 4][w], nb[SPS - 3][w], nb[SPS - 2][w], nb[SPS - 1][w]};
+                sliced_add8(kp[w], xd);
+                sliced_add8(np[w], xn);
+            } else {
+                const unsigned xd[4] = {db[0][w], db[1][w], db[2][w], db[3][w]}, xn[4] = {nb[0][w], nb[1][w], nb[2][w], nb[3][w]};
+                sliced_add4(kp[w], xd);
+                sliced_add4(np[w], xn);
+            }
         }
-        if (++since == 31u) { flush(kp, 0); flush(np, 1); since = 0; }     // block-uniform
+        if (++since == (SPS == 8 ? 31u : 63u)) { flush(kp, 0); flush(np, 1); since = 0; }     // block-uniform
     }
     if (since) { flush(kp, 0); flush(np, 1); }
     // somebody is not N, per site
