@@ -635,12 +635,17 @@ __global__ __launch_bounds__(1024) void scan_counts_kernel(const unsigned *__res
 // group, the 128 contiguous bytes of the 8 samples; its store, per sample, the 128 contiguous bytes of the 8 groups: whole cache
 // lines on both sides of the transposition, no LDS.  c_counted[s] += the sample's N sites among the sites of un_mask (what the
 // compared-sites formula needs), summed over the wave's octets in registers, then over the 8 lanes of a sample.
+#ifndef TRACS_NB_GW
+#define TRACS_NB_GW 8
+#endif
+constexpr unsigned NB_GW = TRACS_NB_GW, NB_SW = 64u / NB_GW;      // groups x samples of a wave's tile (8 x 8; 4 x 16 / 16 x 4: timing builds)
+static_assert(NB_GW == 4 || NB_GW == 8 || NB_GW == 16, "n_bitmap_kernel: 4, 8 or 16 groups per wave");
 __global__ __launch_bounds__(256) void n_bitmap_kernel(const MinorBuild mb, size_t n_pad, unsigned n, size_t groups, size_t tgroups,
                                                        size_t oct_per_chunk, uint4 *__restrict__ T, unsigned *__restrict__ c_counted)
 {
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const size_t s = ((size_t)blockIdx.x * 4 + wave) * 8 + (lane >> 3);
-    const size_t o0 = (size_t)blockIdx.y * oct_per_chunk, o1 = min(tgroups / 8, o0 + oct_per_chunk);
+    const size_t s = ((size_t)blockIdx.x * 4 + wave) * NB_SW + (lane / NB_GW);
+    const size_t o0 = (size_t)blockIdx.y * oct_per_chunk, o1 = min(tgroups / NB_GW, o0 + oct_per_chunk);
     const bool live = s < n;
     const bool row = live && T != nullptr && row_wanted(mb, s);
     const uint4 *np = mb.planes + 4 * n_pad + min(s, n_pad - 1);
@@ -654,21 +659,22 @@ __global__ __launch_bounds__(256) void n_bitmap_kernel(const MinorBuild mb, size
         uint4 v[INF];
 #pragma unroll
         for (int k = 0; k < INF; k++) {
-            const size_t g = (o + k) * 8 + (lane & 7u);
+            const size_t g = (o + k) * NB_GW + (lane % NB_GW);
             v[k] = make_uint4(0u, 0u, 0u, 0u);
             if (o + k < o1 && g < groups && live) v[k] = np[g * NPLANES * n_pad];
         }
 #pragma unroll
         for (int k = 0; k < INF; k++) {
-            const size_t g = (o + k) * 8 + (lane & 7u);
+            const size_t g = (o + k) * NB_GW + (lane % NB_GW);
             const size_t gm = min(g, groups - 1);
             const uint4 um = mb.un_mask[gm], lm = mb.nnl_mask[gm];
             cnt += __popc(v[k].x & um.x) + __popc(v[k].y & um.y) + __popc(v[k].z & um.z) + __popc(v[k].w & um.w);      // (zero past o1)
             if (row && o + k < o1) T[s * tgroups + g] = g < groups ? make_uint4(v[k].x & lm.x, v[k].y & lm.y, v[k].z & lm.z, v[k].w & lm.w) : zero4;
         }
     }
-    cnt += __shfl_xor(cnt, 1, 64); cnt += __shfl_xor(cnt, 2, 64); cnt += __shfl_xor(cnt, 4, 64);
-    if (live && (lane & 7u) == 0u && cnt) atomicAdd(&c_counted[s], cnt);
+#pragma unroll
+    for (unsigned off = 1; off < NB_GW; off <<= 1) cnt += __shfl_xor(cnt, off, 64);
+    if (live && (lane % NB_GW) == 0u && cnt) atomicAdd(&c_counted[s], cnt);
 }
 
 __global__ void max_count_kernel(const unsigned *__restrict__ c, size_t n, unsigned *__restrict__ out)
@@ -1166,7 +1172,7 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb_, hipStream_t 
     g->n_rows = mb.n_rows;
     for (int k = 0; k < 4; k++) g->rows[k] = mb.rows[k];
     g->n_lines = mb.gram ? 0ull : (unsigned long long)L + mb.tot_o;      // (gram: no site carries an N list)
-    g->tgroups = (groups + 7) / 8 * 8;
+    g->tgroups = (groups + 15) / 16 * 16;
     SL_TRY(pack_alloc(a, (g->n_lines + 1) * 128, reinterpret_cast<void **>(&g->lines)));
     SL_TRY(pack_alloc(a, (L + 1) * 8, reinterpret_cast<void **>(&g->p_off)));
     SL_TRY(pack_alloc(a, std::max<size_t>(mb.tot_p, 1) * 4, reinterpret_cast<void **>(&g->p_ent)));
@@ -1227,10 +1233,10 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb_, hipStream_t 
                     (double)std::min<unsigned long long>(mb.tot_p, 2 * L) * (two_pass ? 12.0 : 4.0) + (double)n * 12.0);
     if (bitmaps) {
         // (a->c_counted was zeroed by the caller: this kernel is what fills it when the rows' bitmaps are built)
-        const size_t octs = g->tgroups / 8;
+        const size_t octs = g->tgroups / NB_GW;
         const unsigned chunks = (unsigned)std::min<size_t>(64, std::max<size_t>(1, octs / 16));
         const size_t opc = (octs + chunks - 1) / chunks;
-        const dim3 grid((unsigned)((n + 31) / 32), (unsigned)((octs + opc - 1) / opc));
+        const dim3 grid((unsigned)((n + 4 * NB_SW - 1) / (4 * NB_SW)), (unsigned)((octs + opc - 1) / opc));
         hipLaunchKernelGGL(n_bitmap_kernel, grid, dim3(256), 0, stream, mb, a->n_pad, (unsigned)n, groups, g->tgroups, opc, g->T, a->c_counted);
         hipLaunchKernelGGL(max_count_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a->c_counted, n, d_max);
         double rows = (double)n;
