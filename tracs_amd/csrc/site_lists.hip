@@ -139,9 +139,10 @@ struct N8Encoder {
     }
 };
 
-// (six waves per SIMD -- 80 VGPRs --: the p-list branch costs two registers more, spilled there, and a wave of the encoder's)
+// (a register budget of eight waves per SIMD -- 64 VGPRs; LDS holds six: 3.32 -> 3.21 ms at 10 000 x 5 Mbp against the budget of six, 80
+// VGPRs, of rounds 5 - 6a; five: 3.49, four: 4.06, the compiler's own choice: 3.24 -- profiles/r06/classify_threads.txt)
 #ifndef TRACS_SITE_WAVES
-#define TRACS_SITE_WAVES 6
+#define TRACS_SITE_WAVES 8
 #endif
 #if TRACS_SITE_WAVES > 0
 #define TRACS_SITE_ATTR __attribute__((amdgpu_waves_per_eu(TRACS_SITE_WAVES, TRACS_SITE_WAVES)))
