@@ -1207,7 +1207,10 @@ int minority_lists_build(tracs_alignment *a, const MinorBuild &mb_, hipStream_t 
     SL_TRY(hipMemcpyAsync(g->lst_mask, mb.lst_mask, groups * sizeof(uint4), hipMemcpyDeviceToDevice, stream));
     SL_TRY(hipMemcpyAsync(g->off_lst, mb.off_lst, groups * sizeof(unsigned), hipMemcpyDeviceToDevice, stream));
     const double plane_b = (double)groups * (double)a->n_pad * sizeof(uint4);      // the N plane
-    hipLaunchKernelGGL((site_lists_kernel<512>), dim3((unsigned)groups), dim3(SITE_THREADS), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off, g->p_ent, reinterpret_cast<unsigned *>(g->qlines), E, e_cnt, g->lines, g->c_p);
+#ifndef TRACS_SITE_PIECE
+#define TRACS_SITE_PIECE 512
+#endif
+    hipLaunchKernelGGL((site_lists_kernel<TRACS_SITE_PIECE>), dim3((unsigned)groups), dim3(SITE_THREADS), 0, stream, mb, a->n_pad, (unsigned)n, g->p_off, g->p_ent, reinterpret_cast<unsigned *>(g->qlines), E, e_cnt, g->lines, g->c_p);
     // (only when some group's lists are that kernel's: at least PL_MIN entries)
     if (mb.max_gp >= PL_MIN)
         hipLaunchKernelGGL(p_lists_kernel, dim3((unsigned)groups), dim3(PL_THREADS), 0, stream, mb, a->n_pad, (unsigned)n, g->p_ent, reinterpret_cast<unsigned *>(g->qlines), E, e_cnt, two_pass ? 0 : 1, g->c_p);
