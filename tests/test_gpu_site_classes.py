@@ -83,6 +83,19 @@ def test_site_classes_match_oracle(hiplib, oracle, n, L, p_partial):
     assert cls[0] + cls[2] > 0 and cls[0] < L and cls[1] > 0      # some site is variable (dense or minority), most are not
 
 
+@pytest.mark.parametrize("threads", ["64", "128", "256"])
+@pytest.mark.parametrize("n,L,p_partial", [(300, 20000, 0.0), (300, 20000, 0.001), (2500, 3000, 0.0005)])
+def test_every_shape_of_the_classification(hiplib, oracle, monkeypatch, threads, n, L, p_partial):
+    """classify_sites_kernel as workgroups of one, two and four waves (TRACS_CLASSIFY_THREADS; the default picks one by the number of
+    samples): the same classes, the same distances -- incl. more samples than one step of pass 2 covers at any of the three sizes."""
+    from tracs_amd import device as dev
+    monkeypatch.setenv("TRACS_CLASSIFY_THREADS", threads)
+    seqs = _structured(n, L, seed=n + L + int(threads), p_partial=p_partial, mu=5e-4)
+    got = _check(dev, oracle, seqs)
+    monkeypatch.delenv("TRACS_CLASSIFY_THREADS")
+    assert got == _check(dev, oracle, seqs)                         # ... and as the default's choice classifies them
+
+
 def test_no_variable_site(hiplib, oracle):
     """Identical samples (+ N): every distance is 0 and the compared-sites counts come from the invariant sites alone."""
     from tracs_amd import device as dev

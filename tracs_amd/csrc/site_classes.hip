@@ -694,7 +694,7 @@ static int decide(tracs_alignment *a, bool allow_minor, bool allow_nnl, hipStrea
 #define TRACS_CLASSIFY_ARGS a->planes, a->n_pad, (unsigned)a->n, budget, nn_list_max, gram ? 1u : 0u, masks, groups, cntP, cntN, gcnt, gcnt + groups, \
                             gcnt + 2 * groups, gcnt + 3 * groups, gcnt + 4 * groups, gcnt + 5 * groups, gcnt + 6 * groups, flags, flag_words, d_flag,          \
                             gram_next ? masks2 : (uint4 *)nullptr, gram_next ? gcnt2 : (unsigned *)nullptr
-    static const int env_threads = [] { const char *e = std::getenv("TRACS_CLASSIFY_THREADS"); return e ? std::atoi(e) : 0; }();
+    const int env_threads = [] { const char *e = std::getenv("TRACS_CLASSIFY_THREADS"); return e ? std::atoi(e) : 0; }();      // (read per pack: tests switch it)
     if (env_threads == 64 || (env_threads == 0 && a->n <= 2048))
         hipLaunchKernelGGL(classify_sites_kernel<64>, dim3((unsigned)groups), dim3(64), 0, stream, TRACS_CLASSIFY_ARGS);
     else if (env_threads != 256)
